@@ -1,0 +1,159 @@
+"""ctypes binding of ``libdctr_hip.so`` (C ABI declared in ``include/dctr.h``).
+
+The HIP extension IS the product path: there is no CPU or eager-PyTorch fallback.  ``lib()``
+raises ``DctrExtensionError`` when the shared library is missing or cannot be loaded, and every
+op raises when asked to run without a HIP device.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
+
+c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
+
+ABI_VERSION = 1
+
+POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
+CROSS_VECTOR, CROSS_MATRIX = 0, 1
+ACT_LINEAR, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_DICE = 0, 1, 2, 3, 4
+STATUS_INDEX_OOR = 1
+
+ACT_CODES = {None: ACT_LINEAR, "linear": ACT_LINEAR, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH,
+             "dice": ACT_DICE, "Dice": ACT_DICE}
+POOL_CODES = {"sum": POOL_SUM, "mean": POOL_MEAN, "max": POOL_MAX}
+
+
+class DctrExtensionError(RuntimeError):
+    pass
+
+
+class DctrError(RuntimeError):
+    """A dctr_* entry point returned non-zero."""
+
+
+# ---------------------------------------------------------------------------------------------
+# struct mirrors (field order and types must match include/dctr.h)
+# ---------------------------------------------------------------------------------------------
+class FieldDesc(ctypes.Structure):
+    _fields_ = [("table", c_vp), ("lin_table", c_vp), ("vocab", c_i64), ("dim", c_i32), ("out_offset", c_i32),
+                ("in_fm", c_i32), ("hash_mode", c_i32), ("identity", c_i32), ("pad_", c_i32)]
+
+
+class GatherFmArgs(ctypes.Structure):
+    _fields_ = [("fields", c_vp), ("ids", c_vp), ("ids_stride_f", c_i64), ("ids_stride_b", c_i64),
+                ("ids_is_i64", c_i32), ("n_fields", c_i32), ("max_dim", c_i32), ("all_dim4", c_i32),
+                ("any_hash", c_i32), ("n_dense", c_i32), ("dense", c_vp), ("dense_stride", c_i64),
+                ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("pad_", c_i32), ("batch", c_i64),
+                ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp)]
+
+
+class PoolArgs(ctypes.Structure):
+    _fields_ = [("idx", c_vp), ("table", c_vp), ("lin_table", c_vp), ("length", c_vp), ("weight", c_vp),
+                ("vocab", c_i64), ("idx_stride", c_i64), ("batch", c_i64), ("idx_is_i64", c_i32), ("maxlen", c_i32),
+                ("dim", c_i32), ("combiner", c_i32), ("weight_norm", c_i32), ("hash_mode", c_i32), ("out", c_vp),
+                ("out_stride", c_i64), ("lin_out", c_vp), ("status", c_vp)]
+
+
+class LookupArgs(ctypes.Structure):
+    _fields_ = [("idx", c_vp), ("table", c_vp), ("vocab", c_i64), ("n", c_i64), ("idx_is_i64", c_i32), ("dim", c_i32),
+                ("hash_mode", c_i32), ("pad_", c_i32), ("out", c_vp), ("out_stride", c_i64), ("mask", c_vp),
+                ("status", c_vp)]
+
+
+class CinArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("batch", c_i64), ("fields", c_i32), ("dim", c_i32), ("n_layers", c_i32),
+                ("split_half", c_i32), ("activation", c_i32), ("pad_", c_i32), ("layer_size", c_vp),
+                ("filters", c_vp), ("bias", c_vp), ("out", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz)]
+
+
+class MlpArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("in_dim", c_i32), ("n_layers", c_i32),
+                ("units", c_vp), ("kernels", c_vp), ("biases", c_vp), ("activation", c_i32), ("has_head", c_i32),
+                ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
+                ("sigmoid_out", c_i32), ("head_w", c_vp), ("add0", c_vp), ("add1", c_vp), ("global_bias", c_vp),
+                ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz)]
+
+
+class DinAttnArgs(ctypes.Structure):
+    _fields_ = [("query", c_vp), ("keys", c_vp), ("key_mask", c_vp), ("batch", c_i64), ("maxlen", c_i32),
+                ("dim", c_i32), ("n_layers", c_i32), ("activation", c_i32), ("units", c_vp), ("kernels", c_vp),
+                ("biases", c_vp), ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
+                ("weight_normalization", c_i32), ("out_kernel", c_vp), ("out_bias", c_vp), ("out", c_vp),
+                ("out_stride", c_i64), ("scores", c_vp)]
+
+
+# every symbol include/dctr.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dctr_abi_version": (ctypes.c_int, []),
+    "dctr_last_error": (ctypes.c_char_p, []),
+    "dctr_target_arch": (ctypes.c_char_p, []),
+    "dctr_hash_bucket_i32": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
+    "dctr_hash_bucket_i64": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
+    "dctr_hash_bucket_bytes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
+    "dctr_embed_gather_fm": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), c_vp]),
+    "dctr_embed_pool": (ctypes.c_int, [ctypes.POINTER(PoolArgs), c_vp]),
+    "dctr_embed_lookup": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_vp]),
+    "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
+    "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
+    "dctr_afm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "dctr_inner_product_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
+    "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
+    "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  torch is imported FIRST so that the library's
+    ``NEEDED libamdhip64.so.7`` binds to the HIP runtime PyTorch already loaded."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
+    if not os.path.exists(LIB_PATH):
+        raise DctrExtensionError(
+            "HIP extension %s is not built. Run `python -m deepctr_amd.build` (needs hipcc; target gfx950). "
+            "There is no CPU / PyTorch fallback for this path." % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise DctrExtensionError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise DctrExtensionError("%s does not export %s (stale build? run python -m deepctr_amd.build --force)"
+                                     % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    ver = handle.dctr_abi_version()
+    if ver != ABI_VERSION:
+        raise DctrExtensionError("ABI mismatch: library %d, python %d" % (ver, ABI_VERSION))
+    _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dctr_last_error()
+        raise DctrError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def require_device():
+    """Return the torch HIP device or raise: the path never runs on the CPU."""
+    import torch
+    if not torch.cuda.is_available():
+        raise DctrExtensionError("no HIP device visible: deepctr_amd's forward path only runs on an AMD GPU "
+                                 "(MI355X / gfx950); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

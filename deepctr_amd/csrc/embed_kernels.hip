@@ -1,0 +1,534 @@
+// a3-a8 — the HBM-bound core of the path: multi-table embedding gather fused with the DNN-input
+// concat, the first-order (Linear) term and the FM second-order term; masked sequence pooling for
+// VarLenSparseFeat; plain per-position lookup (DIN keys).
+//
+// Reference op sequence replaced (per batch, C2 = 26 sparse fields): 26 keras Embedding gathers
+// (deepctr/inputs.py:101-117) + 26 one-wide gathers for the linear term (feature_column.py:171-210)
+// + Concat/Flatten (layers/utils.py:336-346) + FM's 2 reductions over [B,F,E]
+// (layers/interaction.py:588-604) + Linear's reduce_sum/tensordot (layers/utils.py:160-175).
+//
+// Lane layout (wave = 64): a table row of `dim` floats is read by LPR adjacent lanes, VEC floats
+// each (VEC = 4 -> one global_load_dwordx4 per lane, a 64-B row = 4 lanes), so a wave-instruction
+// fetches 64/LPR rows = 1 KiB of row data with every lane active.  Lane (s, q) owns chunk q of
+// sample s and walks the FIELDS, so the FM sums over fields accumulate in registers with no
+// cross-lane traffic; only the final sum over the embedding dimension crosses lanes (log2(LPR)
+// DPP/shuffle steps).  Loads are issued in three phases per chunk of U fields (ids -> rows -> use)
+// so U row reads per lane are in flight before the first use.
+// Small batches are latency-, not bandwidth-bound (B=4096 x 26 rows = one 32-KiB burst per CU), so
+// when the plain layout would give < 8 waves per CU the four waves of a workgroup split the
+// FIELDS of the same 64/LPR samples (FSPLIT) and combine their partial sums through LDS.
+#include <math.h>
+
+#include "dctr_common.h"
+#include "farmhash_device.h"
+
+namespace {
+
+typedef dctr_gather_fm_args_t GatherParams;   // passed by value in the kernarg segment (scalar loads)
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *p = v[0];
+    }
+}
+
+// Branch-free id read: one 32-bit load for the low word plus one for the high word (int64 ids) so that
+// no control flow separates the id loads of different fields (they must all be in flight together).
+struct RawId {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ RawId load_id(const void* idx, int64_t pos, int is_i64) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(idx);
+    RawId r;
+    r.lo = w[is_i64 ? 2 * pos : pos];
+    r.hi = w[is_i64 ? 2 * pos + 1 : pos];
+    return r;
+}
+__device__ __forceinline__ int64_t id_value(RawId r, int is_i64) {
+    return is_i64 ? (int64_t)(((uint64_t)r.hi << 32) | r.lo) : (int64_t)(int32_t)r.lo;
+}
+__device__ __forceinline__ int64_t read_id(const void* idx, int64_t pos, int is_i64) {
+    return id_value(load_id(idx, pos, is_i64), is_i64);
+}
+
+__device__ __forceinline__ int64_t resolve_row(int64_t raw, int hash_mode, int is_i64, int64_t vocab) {
+    if (hash_mode == 0) return raw;
+    return dctr::hash_bucket_id(raw, !is_i64, (uint64_t)vocab, hash_mode == 2);
+}
+
+template <int LPR>
+__device__ __forceinline__ float reduce_lpr(float v) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+struct GatherAcc {
+    float lin;
+    int oor;
+};
+
+// The descriptor array is read-only for the whole launch.  Viewing it through the AMDGPU constant
+// address space (4) lets the compiler fetch it with scalar loads (s_load_*, scalar cache) into SGPRs:
+// descriptor-dependent branches become scalar branches and never wait on the vector memory counter.
+#define DCTR_CONSTANT __attribute__((address_space(4)))
+typedef const dctr_field_t DCTR_CONSTANT* cfield_ptr;
+
+struct FieldRegs {
+    const float* table;
+    const float* lin_table;
+    int64_t vocab;
+    int dim, out_offset, in_fm, hash_mode, identity;
+};
+__device__ __forceinline__ FieldRegs load_field(cfield_ptr F, int j) {
+    FieldRegs r;
+    r.table = F[j].table;
+    r.lin_table = F[j].lin_table;
+    r.vocab = F[j].vocab;
+    r.dim = F[j].dim;
+    r.out_offset = F[j].out_offset;
+    r.in_fm = F[j].in_fm;
+    r.hash_mode = F[j].hash_mode;
+    r.identity = F[j].identity;
+    return r;
+}
+
+// One chunk of U fields (j0, j0+step, ...).  Phases with NO control flow inside a phase:
+//   1. U id loads — addresses come from kernel arguments only (id matrix base + strides), so they are
+//      issued before the descriptor scalar loads have returned;
+//   2. rows resolved (optional in-register hash), bounds check;
+//   3. U row loads + U one-wide linear loads, all in flight before the first use
+//      (out-of-range / tail / inactive lanes read a valid dummy address and are masked afterwards);
+//   4. FM / linear accumulation and the concat write.
+template <int VEC, int LPR, int U, bool HASH>
+__device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int step, int64_t b, bool valid, int q,
+                                             float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc) {
+    const int last = p.n_fields - 1;
+    const int64_t bb = valid ? b : 0;
+    RawId raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = min(j0 + u * step, last);
+        raw[u] = load_id(p.ids, (int64_t)j * p.ids_stride_f + bb * p.ids_stride_b, p.ids_is_i64);
+    }
+    cfield_ptr F = (cfield_ptr)p.fields;
+    FieldRegs fr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) fr[u] = load_field(F, min(j0 + u * step, last));
+    int64_t row[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int jj = j0 + u * step;
+        const FieldRegs& f = fr[u];
+        int64_t r = f.identity ? b : id_value(raw[u], p.ids_is_i64);
+        if constexpr (HASH) {
+            if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
+        }
+        const bool live = valid && jj <= last;
+        ok[u] = live && (uint64_t)r < (uint64_t)f.vocab;
+        if (live && !ok[u]) acc.oor = 1;
+        row[u] = ok[u] ? r : 0;
+    }
+    float v[U][VEC];
+    float lv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const FieldRegs& f = fr[u];
+        const int qq = (q * VEC < f.dim) ? q * VEC : 0;
+        load_vec<VEC>(f.table + row[u] * f.dim + qq, v[u]);
+        const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] : reinterpret_cast<const float*>(p.fields);
+        lv[u] = *lp;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const FieldRegs& f = fr[u];
+        const bool act = ok[u] && q * VEC < f.dim;
+        if (ok[u] && q == 0 && f.lin_table != nullptr) acc.lin += lv[u];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v[u][c] = act ? v[u][c] : 0.f;
+        if (f.in_fm) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                sum[c] += v[u][c];
+                sq[c] = fmaf(v[u][c], v[u][c], sq[c]);
+            }
+        }
+        if (p.dnn_in != nullptr && f.out_offset >= 0 && valid && (j0 + u * step) <= last && q * VEC < f.dim)
+            store_vec<VEC>(p.dnn_in + b * p.out_stride + f.out_offset + q * VEC, v[u]);
+    }
+}
+
+// HASH = false builds carry no hashing code at all (the host knows whether any field has hash_mode != 0).
+template <int VEC, int LPR, bool FSPLIT, bool HASH>
+__global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
+    constexpr int SPW = 64 / LPR;  // samples per wave
+    constexpr int DB = 4 * LPR;    // dense columns per pass (4 per lane)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = lane / LPR, q = lane % LPR;
+    const int64_t b = FSPLIT ? (int64_t)blockIdx.x * SPW + s : ((int64_t)blockIdx.x * 4 + wave) * SPW + s;
+    const bool valid = b < p.batch;
+    const int64_t bb = valid ? b : 0;
+    const int f_begin = FSPLIT ? wave : 0;
+    const int f_step = FSPLIT ? 4 : 1;
+
+    // dense block 0 is requested first (kernel-argument addresses only) and consumed last, so its
+    // latency hides behind the id -> row chain.  With FSPLIT the dense passes go to the last waves,
+    // which own the fewest fields.
+    const bool dense0_mine = p.n_dense > 0 && (!FSPLIT || wave == 3);
+    float dx[4], dw[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = q + m * LPR;
+        const int kk = (dense0_mine && k < p.n_dense) ? k : 0;
+        dx[m] = dense0_mine ? p.dense[bb * p.dense_stride + kk] : 0.f;
+        dw[m] = (dense0_mine && p.dense_lin_w != nullptr) ? p.dense_lin_w[kk] : 0.f;
+    }
+
+    float sum[VEC], sq[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) sum[c] = sq[c] = 0.f;
+    GatherAcc acc{0.f, 0};
+
+    int j = f_begin;
+    // full chunks of 8 fields, then one clamped tail chunk sized to what is left
+    for (; j + 7 * f_step < p.n_fields; j += 8 * f_step) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
+    if (j < p.n_fields) {
+        const int left = (p.n_fields - j + f_step - 1) / f_step;   // 1..7, wave-uniform
+        if (left > 4) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
+        else if (left > 2) gather_chunk<VEC, LPR, 4, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
+        else gather_chunk<VEC, LPR, 2, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
+    }
+    float lin = acc.lin;
+
+    // dense features: passthrough into the concat + dense . Linear.kernel
+    if (dense0_mine) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = q + m * LPR;
+            if (valid && k < p.n_dense) {
+                if (p.dnn_in != nullptr && p.dense_out_offset >= 0)
+                    p.dnn_in[b * p.out_stride + p.dense_out_offset + k] = dx[m];
+                lin = fmaf(dx[m], dw[m], lin);
+            }
+        }
+    }
+    for (int k0 = DB, kb = 1; k0 < p.n_dense; k0 += DB, ++kb) {
+        if (FSPLIT && wave != 3 - (kb & 3)) continue;
+        float x[4], w[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = k0 + q + m * LPR;
+            const int kk = k < p.n_dense ? k : 0;
+            x[m] = p.dense[bb * p.dense_stride + kk];
+            w[m] = p.dense_lin_w != nullptr ? p.dense_lin_w[kk] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = k0 + q + m * LPR;
+            if (valid && k < p.n_dense) {
+                if (p.dnn_in != nullptr && p.dense_out_offset >= 0)
+                    p.dnn_in[b * p.out_stride + p.dense_out_offset + k] = x[m];
+                lin = fmaf(x[m], w[m], lin);
+            }
+        }
+    }
+
+    if constexpr (FSPLIT) {
+        __shared__ float red[3][2 * VEC + 1][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                red[wave - 1][c][lane] = sum[c];
+                red[wave - 1][VEC + c][lane] = sq[c];
+            }
+            red[wave - 1][2 * VEC][lane] = lin;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    sum[c] += red[w][c][lane];
+                    sq[c] += red[w][VEC + c][lane];
+                }
+                lin += red[w][2 * VEC][lane];
+            }
+        }
+    }
+
+    if (!FSPLIT || wave == 0) {
+        float fm = 0.f;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) fm += sum[c] * sum[c] - sq[c];
+        fm = 0.5f * reduce_lpr<LPR>(fm);
+        lin = reduce_lpr<LPR>(lin);
+        if (valid && q == 0) {
+            if (p.fm_logit != nullptr) p.fm_logit[b] = fm;
+            if (p.lin_logit != nullptr) p.lin_logit[b] = lin;
+        }
+    }
+    if (p.status != nullptr && __any(acc.oor) && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked sequence pooling (VarLenSparseFeat)
+// ---------------------------------------------------------------------------------------------------
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void pool_kernel(dctr_pool_args_t a) {
+    constexpr int SPW = 64 / LPR;
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = lane / LPR, q = lane % LPR;
+    const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * SPW + s;
+    const bool valid = b < a.batch;
+    const int T = a.maxlen;
+    const bool by_len = a.length != nullptr;
+    const int len = (by_len && valid) ? a.length[b] : 0;
+    const float PAD = -4294967296.f;  // float32(-2**32 + 1), reference layers/sequence.py:171
+    int oor = 0;
+
+    // softmax statistics of the masked weights (WeightedSequenceLayer, weight_normalization=True)
+    float wmax = -INFINITY, wden = 1.f;
+    const bool wnorm = a.weight != nullptr && a.weight_norm;
+    if (wnorm && valid) {
+        for (int t = 0; t < T; ++t) {
+            bool m;
+            if (by_len) m = t < len;
+            else m = resolve_row(read_id(a.idx, b * a.idx_stride + t, a.idx_is_i64), a.hash_mode, a.idx_is_i64,
+                                 a.vocab) != 0;
+            const float w = m ? a.weight[b * (int64_t)T + t] : PAD;
+            wmax = fmaxf(wmax, w);
+        }
+        wden = 0.f;
+        for (int t = 0; t < T; ++t) {
+            bool m;
+            if (by_len) m = t < len;
+            else m = resolve_row(read_id(a.idx, b * a.idx_stride + t, a.idx_is_i64), a.hash_mode, a.idx_is_i64,
+                                 a.vocab) != 0;
+            const float w = m ? a.weight[b * (int64_t)T + t] : PAD;
+            wden += expf(w - wmax);
+        }
+    }
+
+    float acc[VEC];
+    const bool is_max = a.combiner == DCTR_POOL_MAX;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = is_max ? -INFINITY : 0.f;
+    float lacc = is_max ? -INFINITY : 0.f;
+    float cnt = 0.f;
+
+    for (int t0 = 0; t0 < T; t0 += U) {
+        int64_t row[U];
+        bool ok[U];
+        float mk[U], wt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            row[u] = 0;
+            ok[u] = false;
+            mk[u] = 0.f;
+            wt[u] = 1.f;
+            if (t < T && valid) {
+                const int64_t r = resolve_row(read_id(a.idx, b * a.idx_stride + t, a.idx_is_i64), a.hash_mode,
+                                              a.idx_is_i64, a.vocab);
+                ok[u] = (uint64_t)r < (uint64_t)a.vocab;
+                if (!ok[u]) oor = 1;
+                row[u] = r;
+                const bool m = by_len ? (t < len) : (r != 0);
+                mk[u] = m ? 1.f : 0.f;
+                if (a.weight != nullptr) {
+                    const float w = a.weight[b * (int64_t)T + t];
+                    wt[u] = wnorm ? expf((m ? w : PAD) - wmax) / wden : (m ? w : 0.f);
+                }
+            }
+        }
+        float v[U][VEC], lv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[u][c] = 0.f;
+            lv[u] = 0.f;
+            if (ok[u] && q * VEC < a.dim) load_vec<VEC>(a.table + row[u] * a.dim + q * VEC, v[u]);
+            if (ok[u] && q == 0 && a.lin_table != nullptr) lv[u] = a.lin_table[row[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            if (t < T && valid) {
+                cnt += mk[u];
+                if (is_max) {
+                    const float pen = (1.f - mk[u]) * 1e9f;  // layers/sequence.py:97
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc[c] = fmaxf(acc[c], v[u][c] * wt[u] - pen);
+                    lacc = fmaxf(lacc, lv[u] * wt[u] - pen);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc[c] += v[u][c] * wt[u] * mk[u];
+                    lacc += lv[u] * wt[u] * mk[u];
+                }
+            }
+        }
+    }
+    if (a.combiner == DCTR_POOL_MEAN) {
+        const float denom = (by_len ? (float)len : cnt) + 1e-8f;  // layers/sequence.py:65,103
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = acc[c] / denom;
+        lacc = lacc / denom;
+    }
+    if (valid) {
+        if (q * VEC < a.dim) store_vec<VEC>(a.out + b * a.out_stride + q * VEC, acc);
+        if (q == 0 && a.lin_out != nullptr) a.lin_out[b] = lacc;
+    }
+    if (a.status != nullptr && __any(oor) && lane == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plain lookup: n ids -> n rows (+ mask)
+// ---------------------------------------------------------------------------------------------------
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void lookup_kernel(dctr_lookup_args_t a) {
+    constexpr int RPB = 256 / LPR;  // rows per block pass
+    const int r = threadIdx.x / LPR, q = threadIdx.x % LPR;
+    int oor = 0;
+    for (int64_t i = (int64_t)blockIdx.x * RPB + r; i < a.n; i += (int64_t)gridDim.x * RPB) {
+        const int64_t row = resolve_row(read_id(a.idx, i, a.idx_is_i64), a.hash_mode, a.idx_is_i64, a.vocab);
+        const bool ok = (uint64_t)row < (uint64_t)a.vocab;
+        if (!ok) oor = 1;
+        float v[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v[c] = 0.f;
+        if (q * VEC < a.dim) {
+            if (ok) load_vec<VEC>(a.table + row * a.dim + q * VEC, v);
+            store_vec<VEC>(a.out + i * a.out_stride + q * VEC, v);
+        }
+        if (q == 0 && a.mask != nullptr) a.mask[i] = row != 0 ? 1 : 0;
+    }
+    if (a.status != nullptr && __any(oor) && (threadIdx.x & 63) == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------------------------------
+// lanes per row for (max_dim, VEC): smallest power of two with LPR * VEC >= max_dim
+int lanes_per_row(int max_dim, int vec) {
+    int l = 1;
+    while (l * vec < max_dim) l <<= 1;
+    return l;
+}
+
+#define DCTR_DISPATCH_LPR(VECV, lpr, CALL)        \
+    switch (lpr) {                                \
+        case 1: CALL(VECV, 1); break;             \
+        case 2: CALL(VECV, 2); break;             \
+        case 4: CALL(VECV, 4); break;             \
+        case 8: CALL(VECV, 8); break;             \
+        case 16: CALL(VECV, 16); break;           \
+        case 32: CALL(VECV, 32); break;           \
+        case 64: CALL(VECV, 64); break;           \
+        default: break;                           \
+    }
+
+}  // namespace
+
+extern "C" int dctr_embed_gather_fm(const dctr_gather_fm_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "embed_gather_fm: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->n_fields >= 0 && a->n_dense >= 0, DCTR_E_DIM, "embed_gather_fm: negative size");
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->n_fields + a->n_dense > 0, DCTR_E_DIM, "embed_gather_fm: no fields");
+    DCTR_REQUIRE(a->n_fields == 0 || (a->fields != nullptr && a->ids != nullptr), DCTR_E_NULL,
+                 "embed_gather_fm: null field descriptors / id matrix");
+    DCTR_REQUIRE(a->n_dense == 0 || a->dense != nullptr, DCTR_E_NULL, "embed_gather_fm: null dense matrix");
+    DCTR_REQUIRE(a->n_dense == 0 || a->dense_stride >= a->n_dense, DCTR_E_DIM, "embed_gather_fm: dense_stride < n_dense");
+    const int vec = (a->all_dim4 && a->n_fields > 0) ? 4 : 1;
+    const int max_dim = a->max_dim > 0 ? a->max_dim : 1;
+    DCTR_REQUIRE(max_dim <= 64 * vec, DCTR_E_UNSUPPORTED,
+                 "embed_gather_fm: embedding_dim %d > %d not supported by the lane layout", max_dim, 64 * vec);
+    if (a->dnn_in != nullptr && vec == 4)
+        DCTR_REQUIRE(dctr_aligned16(a->dnn_in) && a->out_stride % 4 == 0, DCTR_E_ALIGN,
+                     "embed_gather_fm: dnn_in must be 16-B aligned with out_stride %% 4 == 0 when all_dim4");
+    const int lpr = lanes_per_row(max_dim, vec);
+    const int spw = 64 / lpr;
+    const int64_t waves_plain = dctr_ceil_div(a->batch, spw);
+    const bool fsplit = waves_plain < 256 * 8 && a->n_fields >= 8;
+    GatherParams p = *a;
+    if (p.n_fields == 0) {  // dense-only call: keep the dummy-address reads valid
+        p.fields = reinterpret_cast<const dctr_field_t*>(a->dense);
+        p.ids = a->dense;
+    }
+    const int64_t blocks = fsplit ? waves_plain : dctr_ceil_div(waves_plain, 4);
+    DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_gather_fm: batch too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_G(VECV, L, FS, HS) \
+    hipLaunchKernelGGL((gather_fm_kernel<VECV, L, FS, HS>), dim3((unsigned)blocks), dim3(256), 0, st, p)
+#define CALL_G(VECV, L)                                                 \
+    do {                                                                \
+        if (fsplit) {                                                   \
+            if (a->any_hash) LAUNCH_G(VECV, L, true, true);             \
+            else LAUNCH_G(VECV, L, true, false);                        \
+        } else {                                                        \
+            if (a->any_hash) LAUNCH_G(VECV, L, false, true);            \
+            else LAUNCH_G(VECV, L, false, false);                       \
+        }                                                               \
+    } while (0)
+    if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_G) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_G) }
+#undef CALL_G
+#undef LAUNCH_G
+    return dctr_launch_status("dctr_embed_gather_fm");
+}
+
+extern "C" int dctr_embed_pool(const dctr_pool_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "embed_pool: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->maxlen >= 1 && a->dim >= 1, DCTR_E_DIM, "embed_pool: bad sizes B=%lld T=%d dim=%d",
+                 (long long)a->batch, a->maxlen, a->dim);
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->idx && a->table && a->out, DCTR_E_NULL, "embed_pool: null pointer");
+    DCTR_REQUIRE(a->combiner >= DCTR_POOL_SUM && a->combiner <= DCTR_POOL_MAX, DCTR_E_ENUM, "embed_pool: combiner %d",
+                 a->combiner);
+    DCTR_REQUIRE(a->hash_mode == 0 || a->hash_mode == 2, DCTR_E_ENUM, "embed_pool: hash_mode %d", a->hash_mode);
+    const bool v4 = a->dim % 4 == 0 && dctr_aligned16(a->table) && dctr_aligned16(a->out) && a->out_stride % 4 == 0;
+    const int vec = v4 ? 4 : 1;
+    DCTR_REQUIRE(a->dim <= 64 * vec, DCTR_E_UNSUPPORTED, "embed_pool: embedding_dim %d too large", a->dim);
+    const int lpr = lanes_per_row(a->dim, vec);
+    const int64_t blocks = dctr_ceil_div(dctr_ceil_div(a->batch, 64 / lpr), 4);
+    DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool: batch too large");
+    hipStream_t st = (hipStream_t)stream;
+#define CALL_P(VECV, L) hipLaunchKernelGGL((pool_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
+    if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_P) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_P) }
+#undef CALL_P
+    return dctr_launch_status("dctr_embed_pool");
+}
+
+extern "C" int dctr_embed_lookup(const dctr_lookup_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "embed_lookup: null args");
+    DCTR_REQUIRE(a->n >= 0 && a->dim >= 1, DCTR_E_DIM, "embed_lookup: bad sizes");
+    if (a->n == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->idx && a->table && a->out, DCTR_E_NULL, "embed_lookup: null pointer");
+    DCTR_REQUIRE(a->out_stride >= a->dim, DCTR_E_DIM, "embed_lookup: out_stride < dim");
+    const bool v4 = a->dim % 4 == 0 && dctr_aligned16(a->table) && dctr_aligned16(a->out) && a->out_stride % 4 == 0;
+    const int vec = v4 ? 4 : 1;
+    DCTR_REQUIRE(a->dim <= 64 * vec, DCTR_E_UNSUPPORTED, "embed_lookup: embedding_dim %d too large", a->dim);
+    const int lpr = lanes_per_row(a->dim, vec);
+    int64_t blocks = dctr_ceil_div(a->n, 256 / lpr);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL_L(VECV, L) hipLaunchKernelGGL((lookup_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
+    if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_L) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_L) }
+#undef CALL_L
+    return dctr_launch_status("dctr_embed_lookup");
+}

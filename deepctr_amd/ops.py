@@ -1,0 +1,388 @@
+"""Thin Python wrappers over the C ABI (include/dctr.h): argument checking, output allocation
+with PyTorch (device memory + streams are plumbing), one C call per op on torch's current stream.
+
+Every function requires HIP-resident tensors and the built extension; nothing here computes on
+the CPU and nothing falls back to eager PyTorch math.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _C
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise _C.DctrExtensionError("deepctr_amd ops need HIP device tensors (got %s); there is no CPU path"
+                                        % (type(t).__name__ if not isinstance(t, torch.Tensor) else str(t.device)))
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _ids(t, name):
+    if t.dtype == torch.int32:
+        return t if t.is_contiguous() else t.contiguous(), 0
+    if t.dtype == torch.int64:
+        return t if t.is_contiguous() else t.contiguous(), 1
+    raise TypeError("%s must be int32 or int64, got %s" % (name, t.dtype))
+
+
+def _ptr_array(tensors):
+    """host array of device pointers (const float* const*)."""
+    arr = (ctypes.c_void_p * max(1, len(tensors)))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def _i32_array(vals):
+    arr = (ctypes.c_int32 * max(1, len(vals)))()
+    for i, v in enumerate(vals):
+        arr[i] = int(v)
+    return arr
+
+
+# ---------------------------------------------------------------------------------------------
+# a2 Hash
+# ---------------------------------------------------------------------------------------------
+def hash_bucket(x, num_buckets, mask_zero=False):
+    """Hash.call for integer ids (reference layers/utils.py:89-112): int32/int64 tensor -> int64 tensor."""
+    _dev_check(x)
+    lib = _C.lib()
+    xc, is64 = _ids(x, "x")
+    out = torch.empty(xc.shape, dtype=torch.int64, device=xc.device)
+    fn = lib.dctr_hash_bucket_i64 if is64 else lib.dctr_hash_bucket_i32
+    _C.check(fn(_ptr(xc), xc.numel(), int(num_buckets), int(bool(mask_zero)), _ptr(out), _C.stream_ptr()),
+             "dctr_hash_bucket")
+    return out
+
+
+def pack_strings(values):
+    """Host-side packing of a string column: (uint8 bytes, int64 offsets[n+1]) NumPy arrays."""
+    flat = [v if isinstance(v, (bytes, np.bytes_)) else str(v).encode("utf-8") for v in values]
+    offsets = np.zeros(len(flat) + 1, dtype=np.int64)
+    if flat:
+        np.cumsum([len(b) for b in flat], out=offsets[1:])
+    data = np.frombuffer(b"".join(flat), dtype=np.uint8) if offsets[-1] > 0 else np.zeros(1, np.uint8)
+    return np.ascontiguousarray(data), offsets
+
+
+def hash_bucket_strings(values, num_buckets, mask_zero=False, device=None):
+    """Hash.call for string-dtype features: strings are packed on the host (they are host data in the
+    reference too), hashed on the device.  Returns an int64 device tensor with the shape of ``values``."""
+    device = device or _C.require_device()
+    lib = _C.lib()
+    arr = np.asarray(values, dtype=object)
+    data, offsets = pack_strings(list(arr.reshape(-1)))
+    d_bytes = torch.from_numpy(data.copy()).to(device)
+    d_off = torch.from_numpy(offsets).to(device)
+    out = torch.empty(arr.size, dtype=torch.int64, device=device)
+    _C.check(lib.dctr_hash_bucket_bytes(_ptr(d_bytes), _ptr(d_off), arr.size, int(num_buckets), int(bool(mask_zero)),
+                                        _ptr(out), _C.stream_ptr()), "dctr_hash_bucket_bytes")
+    return out.reshape(arr.shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# a3-a8 embedding ops
+# ---------------------------------------------------------------------------------------------
+def new_status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def check_status(status, what="embedding lookup"):
+    """Raise like the reference's Embedding gather on a CPU does when an index is out of range."""
+    v = int(status.item())
+    if v & _C.STATUS_INDEX_OOR:
+        status.zero_()
+        raise IndexError("%s: index out of range [0, vocabulary_size)" % what)
+
+
+def embed_lookup(idx, table, hash_mode=0, out=None, out_stride=None, return_mask=False, status=None):
+    """Row gather: idx [...] -> [..., dim] (keras Embedding.call, reference inputs.py:101-117).  With
+    ``return_mask`` also returns the mask_zero mask (post-hash idx != 0) as a uint8 tensor."""
+    _dev_check(idx, table)
+    lib = _C.lib()
+    ic, is64 = _ids(idx, "idx")
+    table = _f32c(table, "table")
+    vocab, dim = table.shape
+    n = ic.numel()
+    if out is None:
+        out = torch.empty(tuple(ic.shape) + (dim,), dtype=torch.float32, device=table.device)
+        out_stride = dim
+    mask = torch.empty(ic.shape, dtype=torch.uint8, device=table.device) if return_mask else None
+    a = _C.LookupArgs(idx=ic.data_ptr(), table=table.data_ptr(), vocab=vocab, n=n, idx_is_i64=is64, dim=dim,
+                      hash_mode=hash_mode, out=out.data_ptr(), out_stride=out_stride,
+                      mask=None if mask is None else mask.data_ptr(),
+                      status=None if status is None else status.data_ptr())
+    _C.check(lib.dctr_embed_lookup(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_lookup")
+    return (out, mask) if return_mask else out
+
+
+def embed_pool(idx, table, combiner="mean", length=None, weight=None, weight_norm=True, lin_table=None, hash_mode=0,
+               out=None, out_stride=None, lin_out=None, status=None):
+    """VarLenSparseFeat lookup + (weighted) masked pooling: idx [B,T] -> [B,dim] (reference
+    inputs.py:120-158, layers/sequence.py:76-106,155-183).  ``length`` [B] selects the length-mask form,
+    otherwise mask_zero on the (post-hash) index.  Returns (pooled, pooled_linear or None)."""
+    _dev_check(idx, table, length, weight, lin_table)
+    lib = _C.lib()
+    ic, is64 = _ids(idx, "idx")
+    if ic.dim() != 2:
+        raise ValueError("idx must be [B, T]")
+    B, T = ic.shape
+    table = _f32c(table, "table")
+    vocab, dim = table.shape
+    if out is None:
+        out = torch.empty(B, dim, dtype=torch.float32, device=table.device)
+        out_stride = dim
+    if lin_table is not None:
+        lin_table = _f32c(lin_table, "lin_table").reshape(-1)
+        if lin_out is None:
+            lin_out = torch.empty(B, dtype=torch.float32, device=table.device)
+    if length is not None:
+        length = length.reshape(-1).to(torch.int32).contiguous()
+    if weight is not None:
+        weight = _f32c(weight, "weight").reshape(B, T)
+    a = _C.PoolArgs(idx=ic.data_ptr(), table=table.data_ptr(), lin_table=None if lin_table is None else lin_table.data_ptr(),
+                    length=None if length is None else length.data_ptr(),
+                    weight=None if weight is None else weight.data_ptr(), vocab=vocab, idx_stride=T, batch=B,
+                    idx_is_i64=is64, maxlen=T, dim=dim, combiner=_C.POOL_CODES[combiner], weight_norm=int(bool(weight_norm)),
+                    hash_mode=hash_mode, out=out.data_ptr(), out_stride=out_stride,
+                    lin_out=None if lin_out is None else lin_out.data_ptr(),
+                    status=None if status is None else status.data_ptr())
+    _C.check(lib.dctr_embed_pool(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_pool")
+    return out, lin_out
+
+
+def make_field_descriptors(fields, device):
+    """fields: list of dicts(table, lin_table, vocab, dim, out_offset, in_fm, hash_mode, identity) ->
+    uint8 device tensor holding the dctr_field_t array (kept alive by the caller)."""
+    arr = (_C.FieldDesc * max(1, len(fields)))()
+    for j, f in enumerate(fields):
+        arr[j].table = f["table"].data_ptr()
+        arr[j].lin_table = None if f.get("lin_table") is None else f["lin_table"].data_ptr()
+        arr[j].vocab = int(f["vocab"])
+        arr[j].dim = int(f["dim"])
+        arr[j].out_offset = int(f.get("out_offset", -1))
+        arr[j].in_fm = int(bool(f.get("in_fm", False)))
+        arr[j].hash_mode = int(f.get("hash_mode", 0))
+        arr[j].identity = int(bool(f.get("identity", False)))
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+def embed_gather_fm(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
+                    dense=None, dense_lin_w=None, dense_out_offset=-1, dnn_in=None, out_stride=0, fm_logit=None,
+                    lin_logit=None, status=None):
+    """Fused multi-table gather + concat + linear term + FM (see include/dctr.h).  Low-level: the caller
+    (the model plan) owns descriptor and output buffers."""
+    lib = _C.lib()
+    _dev_check(desc, ids, dense, dnn_in)
+    is64 = 0
+    if ids is not None:
+        if ids.dtype == torch.int64:
+            is64 = 1
+        elif ids.dtype != torch.int32:
+            raise TypeError("ids must be int32 or int64")
+    n_dense = 0 if dense is None else dense.shape[1]
+    a = _C.GatherFmArgs(fields=None if desc is None else desc.data_ptr(), ids=None if ids is None else ids.data_ptr(),
+                        ids_stride_f=ids_stride_f, ids_stride_b=ids_stride_b, ids_is_i64=is64, n_fields=n_fields,
+                        max_dim=max_dim, all_dim4=int(bool(all_dim4)), any_hash=int(bool(any_hash)), n_dense=n_dense,
+                        dense=None if dense is None else dense.data_ptr(),
+                        dense_stride=0 if dense is None else dense.stride(0),
+                        dense_lin_w=None if dense_lin_w is None else dense_lin_w.data_ptr(),
+                        dense_out_offset=dense_out_offset, batch=batch,
+                        dnn_in=None if dnn_in is None else dnn_in.data_ptr(), out_stride=out_stride,
+                        fm_logit=None if fm_logit is None else fm_logit.data_ptr(),
+                        lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
+                        status=None if status is None else status.data_ptr())
+    _C.check(lib.dctr_embed_gather_fm(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+
+
+# ---------------------------------------------------------------------------------------------
+# a8-a12 interaction layers
+# ---------------------------------------------------------------------------------------------
+def fm(x):
+    """FM.call (reference interaction.py:588-604): x [B,F,E] -> [B,1]."""
+    _dev_check(x)
+    if x.dim() != 3:
+        raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % x.dim())
+    x = _f32c(x, "x")
+    B, F, E = x.shape
+    y = torch.empty(B, 1, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().dctr_fm_fwd(_ptr(x), B, F, E, _ptr(y), _C.stream_ptr()), "dctr_fm_fwd")
+    return y
+
+
+def crossnet(x, kernels, bias, parameterization="vector"):
+    """CrossNet.call (reference interaction.py:405-424): x [B,d]; kernels [L,d] or [L,d,d]; bias [L,d]."""
+    _dev_check(x, kernels, bias)
+    if x.dim() != 2:
+        raise ValueError("Unexpected inputs dimensions %d, expect to be 2 dimensions" % x.dim())
+    if parameterization not in ("vector", "matrix"):
+        raise ValueError("parameterization should be 'vector' or 'matrix'")
+    x = _f32c(x, "x")
+    B, d = x.shape
+    L = 0 if kernels is None else kernels.shape[0]
+    y = torch.empty(B, d, dtype=torch.float32, device=x.device)
+    mode = _C.CROSS_VECTOR if parameterization == "vector" else _C.CROSS_MATRIX
+    kernels = None if kernels is None else _f32c(kernels, "kernels")
+    bias = None if bias is None else _f32c(bias, "bias")
+    _C.check(_C.lib().dctr_crossnet_fwd(_ptr(x), B, d, d, _ptr(kernels), _ptr(bias), L, mode, _ptr(y), d,
+                                        _C.stream_ptr()), "dctr_crossnet_fwd")
+    return y
+
+
+def cin_output_dim(layer_size, split_half):
+    if split_half:
+        return sum(layer_size[:-1]) // 2 + layer_size[-1]
+    return sum(layer_size)
+
+
+def cin(x, filters, biases, layer_size, split_half=True, activation="relu"):
+    """CIN.call (reference interaction.py:277-325): x [B,F0,D]; filters[k] [F0*Fk, Hk]; -> [B, featuremap_num]."""
+    _dev_check(x, *filters, *biases)
+    if x.dim() != 3:
+        raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % x.dim())
+    x = _f32c(x, "x")
+    B, F0, D = x.shape
+    n = len(layer_size)
+    filters = [_f32c(f, "filter").reshape(-1, h) for f, h in zip(filters, layer_size)]
+    biases = [_f32c(b, "bias") for b in biases]
+    out = torch.empty(B, cin_output_dim(list(layer_size), split_half), dtype=torch.float32, device=x.device)
+    ls = _i32_array(layer_size)
+    fp, bp = _ptr_array(filters), _ptr_array(biases)
+    if activation not in _C.ACT_CODES or _C.ACT_CODES[activation] == _C.ACT_DICE:
+        raise ValueError("CIN activation %r is not supported" % (activation,))
+    a = _C.CinArgs(x=x.data_ptr(), batch=B, fields=F0, dim=D, n_layers=n, split_half=int(bool(split_half)),
+                   activation=_C.ACT_CODES[activation], layer_size=ctypes.cast(ls, ctypes.c_void_p),
+                   filters=ctypes.cast(fp, ctypes.c_void_p), bias=ctypes.cast(bp, ctypes.c_void_p), out=out.data_ptr(),
+                   workspace=None, workspace_bytes=0)
+    _C.check(_C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_fwd")
+    return out
+
+
+def afm(x, attention_W, attention_b, projection_h, projection_p):
+    """AFMLayer.call (reference interaction.py:116-146), inference: x [B,F,E] -> [B,1]."""
+    _dev_check(x, attention_W, attention_b, projection_h, projection_p)
+    x = _f32c(x, "x")
+    B, F, E = x.shape
+    A = attention_W.shape[1]
+    y = torch.empty(B, 1, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().dctr_afm_fwd(_ptr(x), B, F, E, _ptr(_f32c(attention_W, "W")), _ptr(_f32c(attention_b, "b")),
+                                   _ptr(_f32c(projection_h, "h").reshape(-1)), _ptr(_f32c(projection_p, "p").reshape(-1)),
+                                   A, _ptr(y), _C.stream_ptr()), "dctr_afm_fwd")
+    return y
+
+
+def inner_product(x, reduce_sum=True):
+    """InnerProductLayer.call (reference interaction.py:655-678): x [B,F,E] -> [B,P,1] or [B,P,E]."""
+    _dev_check(x)
+    x = _f32c(x, "x")
+    B, F, E = x.shape
+    P = F * (F - 1) // 2
+    y = torch.empty(B, P, 1 if reduce_sum else E, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().dctr_inner_product_fwd(_ptr(x), B, F, E, int(bool(reduce_sum)), _ptr(y), _C.stream_ptr()),
+             "dctr_inner_product_fwd")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# adjacent: DNN (+ head), DIN attention
+# ---------------------------------------------------------------------------------------------
+def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
+        sigmoid_out=False, in_dim=None, out=None):
+    """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
+    logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
+    ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'."""
+    _dev_check(x, *kernels, *biases)
+    if x.dim() != 2:
+        raise ValueError("mlp expects a 2-D input")
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        x = _f32c(x, "x")
+    B = x.shape[0]
+    in_dim = x.shape[1] if in_dim is None else in_dim
+    n = len(kernels)
+    units = [k.shape[1] for k in kernels]
+    kernels = [_f32c(k, "kernel") for k in kernels]
+    biases = [None if b is None else _f32c(b, "bias") for b in biases]
+    act = _C.ACT_CODES[activation]
+    has_head = head_w is not None
+    last = units[-1] if n else in_dim
+    if out is None:
+        out = torch.empty((B,) if has_head else (B, last), dtype=torch.float32, device=x.device)
+    add = [a_ for a_ in add if a_ is not None]
+    if len(add) > 2:
+        raise ValueError("at most two extra logit vectors can be fused into the head")
+    keep = [kernels, biases]
+    da = dm = dv = None
+    if act == _C.ACT_DICE and n > 0:
+        da = _ptr_array([_f32c(d[0], "alpha") for d in dice])
+        dm = _ptr_array([_f32c(d[1], "mean") for d in dice])
+        dv = _ptr_array([_f32c(d[2], "var") for d in dice])
+    ua, kp, bp = _i32_array(units), _ptr_array(kernels), _ptr_array(biases)
+    a = _C.MlpArgs(x=x.data_ptr(), batch=B, x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
+                   units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
+                   biases=ctypes.cast(bp, ctypes.c_void_p), activation=act, has_head=int(has_head),
+                   dice_alpha=None if da is None else ctypes.cast(da, ctypes.c_void_p),
+                   dice_mean=None if dm is None else ctypes.cast(dm, ctypes.c_void_p),
+                   dice_var=None if dv is None else ctypes.cast(dv, ctypes.c_void_p), dice_eps=float(dice_eps),
+                   sigmoid_out=int(bool(sigmoid_out)),
+                   head_w=None if head_w is None else _f32c(head_w, "head_w").data_ptr(),
+                   add0=add[0].data_ptr() if len(add) > 0 else None, add1=add[1].data_ptr() if len(add) > 1 else None,
+                   global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
+                   y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0)
+    _C.check(_C.lib().dctr_mlp_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_fwd")
+    del keep
+    return out
+
+
+def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, activation="sigmoid", dice=None,
+                  dice_eps=1e-9, weight_normalization=False, return_score=False, out=None, out_stride=None):
+    """AttentionSequencePoolingLayer.call (reference sequence.py:261-298): query [B,1,E] / [B,E], keys [B,T,E],
+    key_mask [B,T] (bool/uint8) -> [B,1,E] (or the scores [B,1,T])."""
+    _dev_check(query, keys, key_mask, out_kernel, out_bias)
+    keys = _f32c(keys, "keys")
+    B, T, E = keys.shape
+    query = _f32c(query, "query").reshape(B, E)
+    mask = key_mask.to(torch.uint8).reshape(B, T).contiguous()
+    n = len(kernels)
+    units = [k.shape[1] for k in kernels]
+    kernels = [_f32c(k, "kernel") for k in kernels]
+    biases = [None if b is None else _f32c(b, "bias") for b in biases]
+    act = _C.ACT_CODES[activation]
+    own_out = out is None
+    if own_out:
+        out = torch.empty(B, E, dtype=torch.float32, device=keys.device)
+        out_stride = E
+    scores = torch.empty(B, T, dtype=torch.float32, device=keys.device) if return_score else None
+    da = dm = dv = None
+    if act == _C.ACT_DICE and n > 0:
+        da = _ptr_array([_f32c(d[0], "alpha") for d in dice])
+        dm = _ptr_array([_f32c(d[1], "mean") for d in dice])
+        dv = _ptr_array([_f32c(d[2], "var") for d in dice])
+    ua, kp, bp = _i32_array(units), _ptr_array(kernels), _ptr_array(biases)
+    a = _C.DinAttnArgs(query=query.data_ptr(), keys=keys.data_ptr(), key_mask=mask.data_ptr(), batch=B, maxlen=T, dim=E,
+                       n_layers=n, activation=act, units=ctypes.cast(ua, ctypes.c_void_p),
+                       kernels=ctypes.cast(kp, ctypes.c_void_p), biases=ctypes.cast(bp, ctypes.c_void_p),
+                       dice_alpha=None if da is None else ctypes.cast(da, ctypes.c_void_p),
+                       dice_mean=None if dm is None else ctypes.cast(dm, ctypes.c_void_p),
+                       dice_var=None if dv is None else ctypes.cast(dv, ctypes.c_void_p), dice_eps=float(dice_eps),
+                       weight_normalization=int(bool(weight_normalization)),
+                       out_kernel=_f32c(out_kernel, "out_kernel").reshape(-1).data_ptr(),
+                       out_bias=_f32c(out_bias, "out_bias").data_ptr(), out=out.data_ptr(), out_stride=out_stride,
+                       scores=None if scores is None else scores.data_ptr())
+    _C.check(_C.lib().dctr_din_attn_pool_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_din_attn_pool_fwd")
+    if return_score:
+        return scores.reshape(B, 1, T)
+    return out.reshape(B, 1, E) if own_out else out

@@ -1,0 +1,281 @@
+/*
+ * dctr.h — C ABI of libdctr_hip.so: the MI355X (gfx950) kernels behind DeepCTR's
+ * embedding-lookup + feature-interaction forward path.
+ *
+ * The reference (shenweichen/DeepCTR, /root/reference) has NO native / FFI layer: every op on this
+ * path is a TensorFlow op sequence issued from a Keras `Layer.call`.  Each entry point below therefore
+ * replaces one such `call` (or a fused run of them); the reference symbol it stands in for is cited
+ * as deepctr/<file>:<lines>.  INTEGRATION.md shows the ctypes stub a DeepCTR maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no C++ types, no exceptions across the boundary.
+ *   - every pointer inside an argument struct is a DEVICE pointer on the current HIP device unless
+ *     the field comment says "host"; the struct itself is host memory, read during the call only.
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates,
+ *     frees or synchronises; work is enqueued on `stream` (a hipStream_t; NULL = default stream).
+ *   - return value: 0 = enqueued; <0 = DCTR_E_* argument error (nothing enqueued);
+ *     >0 = hipError_t reported by the launch.  dctr_last_error() gives a thread-local message.
+ *   - functions are re-entrant and stateless; ordering is by `stream` only.
+ *   - fp32 tensors are row-major and contiguous unless a stride field says otherwise.
+ */
+#ifndef DCTR_H_
+#define DCTR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCTR_ABI_VERSION 1
+
+enum {
+    DCTR_OK = 0,
+    DCTR_E_NULL = -1,        /* required pointer is NULL                    */
+    DCTR_E_DIM = -2,         /* size / dimension out of the supported range */
+    DCTR_E_ALIGN = -3,       /* pointer or stride not aligned as documented */
+    DCTR_E_ENUM = -4,        /* unknown enum value                          */
+    DCTR_E_UNSUPPORTED = -5  /* valid request this build does not implement */
+};
+
+/* bits OR-ed into the optional device status word by the gather kernels */
+enum { DCTR_STATUS_INDEX_OOR = 1 };
+
+int dctr_abi_version(void);
+const char* dctr_last_error(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char* dctr_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a2  Hash.call — deepctr/layers/utils.py:89-112
+ *     out = Fingerprint64(decimal_ascii(x)) mod nb  (uint64 modulo, stored as int64),
+ *     nb = num_buckets - (mask_zero ? 1 : 0);  mask_zero: out = (out + 1) * (x != 0).
+ *     Bit-exact with tf.strings.to_hash_bucket_fast(tf.as_string(x), nb).
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_hash_bucket_i32(const int32_t* x, int64_t n, int64_t num_buckets, int mask_zero, int64_t* out,
+                         void* stream);
+int dctr_hash_bucket_i64(const int64_t* x, int64_t n, int64_t num_buckets, int mask_zero, int64_t* out,
+                         void* stream);
+/* string-dtype features: `bytes` = concatenated UTF-8, offsets[n+1] (int64) delimit element i;
+ * mask_zero masks the literal string "0" (utils.py:95,108-110). */
+int dctr_hash_bucket_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t n, int64_t num_buckets,
+                           int mask_zero, int64_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a3/a4/a6/a7/a8 fused:  embedding_lookup (deepctr/inputs.py:101-117, keras Embedding gather) for
+ * every SparseFeat + concat into the DNN-input layout (layers/utils.py:336-346) + Linear.call
+ * (layers/utils.py:160-175, the 1-wide `linear0sparse_emb_*` tables of feature_column.py:171-210)
+ * + FM.call (layers/interaction.py:588-604), optional in-kernel Hash (a2).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* table;      /* [vocab, dim] fp32; 16-B aligned when dim % 4 == 0                      */
+    const float* lin_table;  /* [vocab] fp32 (1-wide linear table) or NULL = no first-order term        */
+    int64_t vocab;
+    int32_t dim;             /* embedding_dim of this field                                             */
+    int32_t out_offset;      /* column of this field inside a dnn_in row; <0: not copied                */
+    int32_t in_fm;           /* 1: participates in the FM term                                          */
+    int32_t hash_mode;       /* 0: id is the row; 1: Hash(vocab); 2: Hash(vocab, mask_zero=True)        */
+    int32_t identity;        /* 1: row = sample index b (field pre-pooled by dctr_embed_pool); id unused */
+    int32_t pad_;
+} dctr_field_t;
+
+typedef struct {
+    const dctr_field_t* fields;   /* DEVICE array [n_fields]                                            */
+    const void* ids;              /* DEVICE id matrix: field j, sample b at ids[j*ids_stride_f + b*ids_stride_b]
+                                     (DeepCTR feeds one id column per feature -> natural layout [F, B]);
+                                     one row per field, in field order (rows of identity fields unused)   */
+    int64_t ids_stride_f;         /* in elements                                                        */
+    int64_t ids_stride_b;
+    int32_t ids_is_i64;           /* 0: int32 ids, 1: int64 ids                                         */
+    int32_t n_fields;
+    int32_t max_dim;              /* max over fields of dim (host copy, selects the lane layout)        */
+    int32_t all_dim4;             /* 1: every dim % 4 == 0, tables 16-B aligned, out offsets % 4 == 0    */
+    int32_t any_hash;             /* 1: some field has hash_mode != 0 (host copy; selects the hashing build)*/
+    int32_t n_dense;              /* width of the dense matrix (sum of DenseFeat dimensions), 0 = none   */
+    const float* dense;           /* DEVICE [B, dense_stride] dense feature values or NULL              */
+    int64_t dense_stride;
+    const float* dense_lin_w;     /* DEVICE [n_dense] = Linear.kernel (layers/utils.py:150-158) or NULL */
+    int32_t dense_out_offset;     /* first dense column inside a dnn_in row; <0: not copied             */
+    int32_t pad_;
+    int64_t batch;
+    float* dnn_in;                /* [B, out_stride] or NULL                                            */
+    int64_t out_stride;           /* elements; % 4 == 0 when all_dim4                                   */
+    float* fm_logit;              /* [B] or NULL:  0.5 * sum_d((sum_f e)^2 - sum_f e^2) over in_fm fields */
+    float* lin_logit;             /* [B] or NULL:  sum_f lin_table_f[row] + dense . dense_lin_w         */
+    int32_t* status;              /* optional device word, DCTR_STATUS_* bits are OR-ed in              */
+} dctr_gather_fm_args_t;
+
+int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a5  varlen_embedding_lookup + WeightedSequenceLayer + SequencePoolingLayer
+ *     deepctr/inputs.py:120-158, layers/sequence.py:76-106 and :155-183.
+ * ------------------------------------------------------------------------------------------------ */
+enum { DCTR_POOL_SUM = 0, DCTR_POOL_MEAN = 1, DCTR_POOL_MAX = 2 };
+
+typedef struct {
+    const void* idx;         /* [B, T] ids, row stride idx_stride (elements)                            */
+    const float* table;      /* [vocab, dim]                                                            */
+    const float* lin_table;  /* [vocab] or NULL: also pool the 1-wide linear table into lin_out         */
+    const int32_t* length;   /* [B] valid lengths (length_name given) or NULL = mask_zero on idx != 0   */
+    const float* weight;     /* [B, T] per-position weights (weight_name) or NULL                       */
+    int64_t vocab;
+    int64_t idx_stride;
+    int64_t batch;
+    int32_t idx_is_i64;
+    int32_t maxlen;          /* T                                                                       */
+    int32_t dim;
+    int32_t combiner;        /* DCTR_POOL_*                                                             */
+    int32_t weight_norm;     /* softmax-normalise the weights over valid positions (sequence.py:170-177)*/
+    int32_t hash_mode;       /* 0 none, 2 = Hash(vocab, mask_zero=True) (inputs.py:125-126)             */
+    float* out;              /* [B, out_stride] pooled vectors                                          */
+    int64_t out_stride;
+    float* lin_out;          /* [B] pooled 1-wide term or NULL                                          */
+    int32_t* status;
+} dctr_pool_args_t;
+
+int dctr_embed_pool(const dctr_pool_args_t* args, void* stream);
+
+/* plain per-position lookup [B,T] -> [B,T,dim] (+ mask byte per position), used for DIN keys
+ * (deepctr/models/sequence/din.py:68-69) and by the eager `embedding_lookup` API. */
+typedef struct {
+    const void* idx;
+    const float* table;
+    int64_t vocab;
+    int64_t n;               /* number of ids (B*T)                                                     */
+    int32_t idx_is_i64;
+    int32_t dim;
+    int32_t hash_mode;
+    int32_t pad_;
+    float* out;              /* [n, out_stride] (out_stride >= dim): lets callers write into a concat   */
+    int64_t out_stride;
+    uint8_t* mask;           /* [n] (post-hash idx != 0) or NULL                                        */
+    int32_t* status;
+} dctr_lookup_args_t;
+
+int dctr_embed_lookup(const dctr_lookup_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a8  FM.call stand-alone — deepctr/layers/interaction.py:588-604.   x [B,F,E] -> y [B]
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_fm_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a9  CrossNet.call — deepctr/layers/interaction.py:405-424
+ *     vector: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ;  matrix: x_{l+1} = x0 .* (W_l x_l + b_l) + x_l
+ *     kernels: [layers, d] (vector) or [layers, d, d] (matrix, W[i][j] row-major); bias [layers, d].
+ * ------------------------------------------------------------------------------------------------ */
+enum { DCTR_CROSS_VECTOR = 0, DCTR_CROSS_MATRIX = 1 };
+int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* kernels,
+                      const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a10 CIN.call — deepctr/layers/interaction.py:277-325   (outer product + 1x1 conv on f32 MFMA)
+ *     x [B,F0,D];  filters[k]: [F0*F_k, H_k] row-major (the reference's [1,F0*F_k,H_k] squeezed,
+ *     row index i*F_k + j);  bias[k]: [H_k];  out [B, featuremap_num] (already summed over D).
+ * ------------------------------------------------------------------------------------------------ */
+enum { DCTR_ACT_LINEAR = 0, DCTR_ACT_RELU = 1, DCTR_ACT_SIGMOID = 2, DCTR_ACT_TANH = 3, DCTR_ACT_DICE = 4 };
+typedef struct {
+    const float* x;
+    int64_t batch;
+    int32_t fields;               /* F0 */
+    int32_t dim;                  /* D  */
+    int32_t n_layers;
+    int32_t split_half;
+    int32_t activation;           /* DCTR_ACT_LINEAR | RELU | SIGMOID | TANH */
+    int32_t pad_;
+    const int32_t* layer_size;    /* HOST array [n_layers] */
+    const float* const* filters;  /* HOST array of n_layers DEVICE pointers */
+    const float* const* bias;     /* HOST array of n_layers DEVICE pointers */
+    float* out;                   /* [B, featuremap_num] */
+    void* workspace;              /* device scratch, dctr_cin_workspace_bytes() bytes, 16-B aligned */
+    size_t workspace_bytes;
+} dctr_cin_args_t;
+size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* args);
+int dctr_cin_fwd(const dctr_cin_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a11 AFMLayer.call — deepctr/layers/interaction.py:116-146 (inference: dropout inactive)
+ *     x [B,F,E]; W [E,A]; b [A]; h [A]; p [E]  ->  y [B]
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_afm_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, const float* att_w,
+                 const float* att_b, const float* proj_h, const float* proj_p, int32_t att_factor, float* y,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a12 InnerProductLayer.call — deepctr/layers/interaction.py:655-678
+ *     x [B,F,E] -> y [B, F(F-1)/2] (reduce_sum) or [B, F(F-1)/2, E]; pair order (i<j) row-major.
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_inner_product_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, int32_t reduce_sum,
+                           float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * adjacent  DNN.call (+ Dense(1, use_bias=False) head, add_func, PredictionLayer.call)
+ *     deepctr/layers/core.py:189-208, :250-259; layers/utils.py:328-333.
+ *     y = x; for each layer: y = act(y W_l + b_l).  Optional head: logit = y . head_w (+ add0 + add1
+ *     + global_bias), sigmoid if binary.  W_l: [in_l, out_l] row-major (Keras kernel layout).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* x;               /* [B, x_stride] */
+    int64_t batch;
+    int64_t x_stride;
+    int32_t in_dim;
+    int32_t n_layers;
+    const int32_t* units;         /* HOST array [n_layers] */
+    const float* const* kernels;  /* HOST array of DEVICE pointers */
+    const float* const* biases;   /* HOST array of DEVICE pointers */
+    int32_t activation;           /* DCTR_ACT_* (DICE: dice_* arrays below) */
+    int32_t has_head;
+    const float* const* dice_alpha;   /* HOST arrays of DEVICE pointers [n_layers] or NULL */
+    const float* const* dice_mean;
+    const float* const* dice_var;
+    float dice_eps;
+    int32_t sigmoid_out;          /* PredictionLayer task == "binary" */
+    const float* head_w;          /* [units[last]] or NULL */
+    const float* add0;            /* [B] extra logits (linear / FM ...) or NULL */
+    const float* add1;
+    const float* global_bias;     /* [1] device or NULL */
+    float* y;                     /* has_head ? [B] : [B, y_stride] */
+    int64_t y_stride;
+    void* workspace;
+    size_t workspace_bytes;
+} dctr_mlp_args_t;
+size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
+int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a13 AttentionSequencePoolingLayer.call + LocalActivationUnit.call (DIN)
+ *     deepctr/layers/sequence.py:261-298, layers/core.py:94-108, activation.py:59-64.
+ *     query [B,E]; keys [B,T,E]; key_mask [B,T] bytes; att MLP over [q,k,q-k,q*k] (4E -> h1 -> .. -> 1)
+ *     out [B,E] = sum_t score_t * k_t.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* query;
+    const float* keys;
+    const uint8_t* key_mask;
+    int64_t batch;
+    int32_t maxlen;
+    int32_t dim;                  /* E (query / key width) */
+    int32_t n_layers;
+    int32_t activation;           /* DCTR_ACT_SIGMOID | RELU | DICE ... */
+    const int32_t* units;         /* HOST */
+    const float* const* kernels;  /* HOST array of DEVICE ptrs; kernels[0]: [4E, units[0]] */
+    const float* const* biases;
+    const float* const* dice_alpha;
+    const float* const* dice_mean;
+    const float* const* dice_var;
+    float dice_eps;
+    int32_t weight_normalization;
+    const float* out_kernel;      /* [units[last]] */
+    const float* out_bias;        /* [1] */
+    float* out;                   /* [B, out_stride] */
+    int64_t out_stride;
+    float* scores;                /* optional [B,T] (return_score) */
+} dctr_din_attn_args_t;
+int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTR_H_ */

@@ -1,0 +1,35 @@
+"""Shared helpers for the test-suite (tests may use oracle/, the product may not)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def golden_meta(g):
+    return json.loads(bytes(g["meta"]).decode())
+
+
+def logits_close(got, ref, rtol=1e-4, atol=1e-6):
+    """BASELINE north_star bar: fp32 within 1e-4 relative (plus 1e-6 absolute floor for values near 0)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
+    bar = rtol * np.abs(ref) + atol
+    return bool((err <= bar).all()), float((err / bar).max()) if err.size else 0.0
+
+
+def assert_close(got, ref, rtol=1e-4, atol=1e-6, what=""):
+    ok, worst = logits_close(got, ref, rtol, atol)
+    assert ok, "%s: max err / bar = %.3g (rtol=%g atol=%g)" % (what, worst, rtol, atol)
+
+
+def sigmoid_inv(y):
+    y = np.clip(np.asarray(y, dtype=np.float64), 1e-300, 1 - 1e-16)
+    return np.log(y) - np.log1p(-y)
