@@ -63,8 +63,8 @@ class LookupArgs(ctypes.Structure):
 
 
 class CinArgs(ctypes.Structure):
-    _fields_ = [("x", c_vp), ("batch", c_i64), ("fields", c_i32), ("dim", c_i32), ("n_layers", c_i32),
-                ("split_half", c_i32), ("activation", c_i32), ("pad_", c_i32), ("layer_size", c_vp),
+    _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("fields", c_i32), ("dim", c_i32),
+                ("n_layers", c_i32), ("split_half", c_i32), ("activation", c_i32), ("pad_", c_i32), ("layer_size", c_vp),
                 ("filters", c_vp), ("bias", c_vp), ("out", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz)]
 
 
@@ -72,7 +72,7 @@ class MlpArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("in_dim", c_i32), ("n_layers", c_i32),
                 ("units", c_vp), ("kernels", c_vp), ("biases", c_vp), ("activation", c_i32), ("has_head", c_i32),
                 ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
-                ("sigmoid_out", c_i32), ("head_w", c_vp), ("add0", c_vp), ("add1", c_vp), ("global_bias", c_vp),
+                ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
                 ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz)]
 
 
@@ -95,7 +95,7 @@ SYMBOLS = {
     "dctr_embed_gather_fm": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), c_vp]),
     "dctr_embed_pool": (ctypes.c_int, [ctypes.POINTER(PoolArgs), c_vp]),
     "dctr_embed_lookup": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_vp]),
-    "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),

@@ -22,6 +22,7 @@ constexpr int RT_MAX = 4;  // row tiles (16 rows each) per workgroup
 struct CinParams {
     const float* x;
     int64_t batch;
+    int64_t x_stride;
     int32_t F0, D, n_layers, split_half, activation;
     int32_t SB;        // samples per workgroup
     int32_t RT;        // row tiles = ceil(SB*D/16)
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void cin_kernel(CinParams p) {
     const int64_t b0 = (int64_t)blockIdx.x * SB;
     for (int i = threadIdx.x; i < SB * F0 * D; i += 256) {
         const int s = i / (F0 * D);
-        x0s[i] = (b0 + s < p.batch) ? p.x[b0 * F0 * D + i] : 0.f;
+        x0s[i] = (b0 + s < p.batch) ? p.x[(b0 + s) * p.x_stride + (i - s * F0 * D)] : 0.f;
     }
     __syncthreads();
 
@@ -187,10 +188,12 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     DCTR_REQUIRE(a->x && a->out && a->layer_size && a->filters && a->bias, DCTR_E_NULL, "cin_fwd: null pointer");
     DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "cin_fwd: activation %d",
                  a->activation);
+    DCTR_REQUIRE(a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
     DCTR_REQUIRE(a->dim <= 64, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d > 64 not supported", a->dim);
     CinParams p{};
     p.x = a->x;
     p.batch = a->batch;
+    p.x_stride = a->x_stride;
     p.F0 = a->fields;
     p.D = a->dim;
     p.n_layers = a->n_layers;

@@ -17,14 +17,14 @@ namespace {
 // FM: lane (s, q) owns embedding dims d = q, q+LPR, ... of sample s and walks the fields.
 // ---------------------------------------------------------------------------------------------------
 template <int LPR>
-__global__ __launch_bounds__(256) void fm_kernel(const float* __restrict__ x, int64_t batch, int F, int E,
-                                                 float* __restrict__ y) {
+__global__ __launch_bounds__(256) void fm_kernel(const float* __restrict__ x, int64_t batch, int64_t x_stride, int F,
+                                                 int E, float* __restrict__ y) {
     constexpr int SPB = 256 / LPR;
     const int s = threadIdx.x / LPR, q = threadIdx.x % LPR;
     const int64_t b = (int64_t)blockIdx.x * SPB + s;
     float acc = 0.f;
     if (b < batch) {
-        const float* xb = x + b * (int64_t)F * E;
+        const float* xb = x + b * x_stride;
         for (int d = q; d < E; d += LPR) {
             float sum = 0.f, sq = 0.f;
             for (int f = 0; f < F; ++f) {
@@ -256,16 +256,19 @@ int pow2_at_least(int v, int cap) {
 
 }  // namespace
 
-extern "C" int dctr_fm_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, float* y, void* stream) {
+extern "C" int dctr_fm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, float* y,
+                           void* stream) {
     DCTR_REQUIRE(batch >= 0 && fields >= 1 && dim >= 1, DCTR_E_DIM, "fm_fwd: bad sizes B=%lld F=%d E=%d", (long long)batch,
                  fields, dim);
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && y, DCTR_E_NULL, "fm_fwd: null pointer");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim, DCTR_E_DIM, "fm_fwd: x_stride < fields*dim");
     const int lpr = pow2_at_least(dim, 64);
     const int64_t blocks = dctr_ceil_div(batch, 256 / lpr);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "fm_fwd: batch too large");
     hipStream_t st = (hipStream_t)stream;
-#define CALL_FM(L) hipLaunchKernelGGL((fm_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, fields, dim, y)
+#define CALL_FM(L) \
+    hipLaunchKernelGGL((fm_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, x_stride, fields, dim, y)
     switch (lpr) {
         case 1: CALL_FM(1); break;
         case 2: CALL_FM(2); break;

@@ -33,8 +33,7 @@ struct MlpParams {
     int32_t has_head;
     int32_t sigmoid_out;
     const float* head_w;
-    const float* add0;
-    const float* add1;
+    const float* add[4];
     const float* global_bias;
     float* y;
     int64_t y_stride;
@@ -125,8 +124,9 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpParams p) {
         const int64_t b = b0 + row;
         if (part == 0 && b < p.batch) {
             float v = acc;
-            if (p.add0 != nullptr) v += p.add0[b];
-            if (p.add1 != nullptr) v += p.add1[b];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (p.add[i] != nullptr) v += p.add[i][b];
             if (p.global_bias != nullptr) v += p.global_bias[0];
             if (p.sigmoid_out) v = dctr::sigmoidf_(v);
             p.y[b] = v;
@@ -188,8 +188,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) {
     p.has_head = a->has_head;
     p.sigmoid_out = a->sigmoid_out;
     p.head_w = a->head_w;
-    p.add0 = a->add0;
-    p.add1 = a->add1;
+    for (int i = 0; i < 4; ++i) p.add[i] = a->add[i];
     p.global_bias = a->global_bias;
     p.y = a->y;
     p.y_stride = a->y_stride;

@@ -220,7 +220,17 @@ def fm(x):
     x = _f32c(x, "x")
     B, F, E = x.shape
     y = torch.empty(B, 1, dtype=torch.float32, device=x.device)
-    _C.check(_C.lib().dctr_fm_fwd(_ptr(x), B, F, E, _ptr(y), _C.stream_ptr()), "dctr_fm_fwd")
+    _C.check(_C.lib().dctr_fm_fwd(_ptr(x), B, F * E, F, E, _ptr(y), _C.stream_ptr()), "dctr_fm_fwd")
+    return y
+
+
+def fm_strided(x2d, offset, fields, dim):
+    """FM over columns [offset, offset + fields*dim) of a [B, stride] concat buffer, read in place."""
+    _dev_check(x2d)
+    B = x2d.shape[0]
+    y = torch.empty(B, dtype=torch.float32, device=x2d.device)
+    base = ctypes.c_void_p(x2d.data_ptr() + 4 * offset)
+    _C.check(_C.lib().dctr_fm_fwd(base, B, x2d.stride(0), fields, dim, _ptr(y), _C.stream_ptr()), "dctr_fm_fwd")
     return y
 
 
@@ -249,22 +259,28 @@ def cin_output_dim(layer_size, split_half):
     return sum(layer_size)
 
 
-def cin(x, filters, biases, layer_size, split_half=True, activation="relu"):
-    """CIN.call (reference interaction.py:277-325): x [B,F0,D]; filters[k] [F0*Fk, Hk]; -> [B, featuremap_num]."""
+def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None):
+    """CIN.call (reference interaction.py:277-325): x [B,F0,D] (or, with ``fields``/``dim`` given, the leading
+    F0*D columns of a [B, stride] concat buffer read in place); filters[k] [F0*Fk, Hk]; -> [B, featuremap_num]."""
     _dev_check(x, *filters, *biases)
-    if x.dim() != 3:
-        raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % x.dim())
-    x = _f32c(x, "x")
-    B, F0, D = x.shape
+    if fields is None:
+        if x.dim() != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % x.dim())
+        x = _f32c(x, "x")
+        B, F0, D = x.shape
+        x_stride = F0 * D
+    else:
+        B, F0, D, x_stride = x.shape[0], fields, dim, x.stride(0)
     n = len(layer_size)
     filters = [_f32c(f, "filter").reshape(-1, h) for f, h in zip(filters, layer_size)]
     biases = [_f32c(b, "bias") for b in biases]
-    out = torch.empty(B, cin_output_dim(list(layer_size), split_half), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, cin_output_dim(list(layer_size), split_half), dtype=torch.float32, device=x.device)
     ls = _i32_array(layer_size)
     fp, bp = _ptr_array(filters), _ptr_array(biases)
     if activation not in _C.ACT_CODES or _C.ACT_CODES[activation] == _C.ACT_DICE:
         raise ValueError("CIN activation %r is not supported" % (activation,))
-    a = _C.CinArgs(x=x.data_ptr(), batch=B, fields=F0, dim=D, n_layers=n, split_half=int(bool(split_half)),
+    a = _C.CinArgs(x=x.data_ptr(), batch=B, x_stride=x_stride, fields=F0, dim=D, n_layers=n, split_half=int(bool(split_half)),
                    activation=_C.ACT_CODES[activation], layer_size=ctypes.cast(ls, ctypes.c_void_p),
                    filters=ctypes.cast(fp, ctypes.c_void_p), bias=ctypes.cast(bp, ctypes.c_void_p), out=out.data_ptr(),
                    workspace=None, workspace_bytes=0)
@@ -322,8 +338,11 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
     if out is None:
         out = torch.empty((B,) if has_head else (B, last), dtype=torch.float32, device=x.device)
     add = [a_ for a_ in add if a_ is not None]
-    if len(add) > 2:
-        raise ValueError("at most two extra logit vectors can be fused into the head")
+    if len(add) > 4:
+        raise ValueError("at most four extra logit vectors can be fused into the head")
+    add_arr = (ctypes.c_void_p * 4)()
+    for i_, t_ in enumerate(add):
+        add_arr[i_] = t_.data_ptr()
     keep = [kernels, biases]
     da = dm = dv = None
     if act == _C.ACT_DICE and n > 0:
@@ -339,7 +358,7 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    dice_var=None if dv is None else ctypes.cast(dv, ctypes.c_void_p), dice_eps=float(dice_eps),
                    sigmoid_out=int(bool(sigmoid_out)),
                    head_w=None if head_w is None else _f32c(head_w, "head_w").data_ptr(),
-                   add0=add[0].data_ptr() if len(add) > 0 else None, add1=add[1].data_ptr() if len(add) > 1 else None,
+                   add=add_arr,
                    global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
                    y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0)
     _C.check(_C.lib().dctr_mlp_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_fwd")

@@ -157,9 +157,9 @@ typedef struct {
 int dctr_embed_lookup(const dctr_lookup_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * a8  FM.call stand-alone — deepctr/layers/interaction.py:588-604.   x [B,F,E] -> y [B]
+ * a8  FM.call stand-alone — deepctr/layers/interaction.py:588-604.   x [B,F,E] (sample stride x_stride) -> y [B]
  * ------------------------------------------------------------------------------------------------ */
-int dctr_fm_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, float* y, void* stream);
+int dctr_fm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a9  CrossNet.call — deepctr/layers/interaction.py:405-424
@@ -177,8 +177,9 @@ int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stri
  * ------------------------------------------------------------------------------------------------ */
 enum { DCTR_ACT_LINEAR = 0, DCTR_ACT_RELU = 1, DCTR_ACT_SIGMOID = 2, DCTR_ACT_TANH = 3, DCTR_ACT_DICE = 4 };
 typedef struct {
-    const float* x;
+    const float* x;               /* sample b at x + b * x_stride, then [F0, D] row-major */
     int64_t batch;
+    int64_t x_stride;             /* elements between samples (>= F0*D): lets CIN read the dnn_in concat in place */
     int32_t fields;               /* F0 */
     int32_t dim;                  /* D  */
     int32_t n_layers;
@@ -233,8 +234,7 @@ typedef struct {
     float dice_eps;
     int32_t sigmoid_out;          /* PredictionLayer task == "binary" */
     const float* head_w;          /* [units[last]] or NULL */
-    const float* add0;            /* [B] extra logits (linear / FM ...) or NULL */
-    const float* add1;
+    const float* add[4];          /* up to four [B] extra logit vectors (linear, FM, CIN ...) or NULL */
     const float* global_bias;     /* [1] device or NULL */
     float* y;                     /* has_head ? [B] : [B, y_stride] */
     int64_t y_stride;

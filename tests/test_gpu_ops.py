@@ -1,0 +1,404 @@
+"""GPU parity tests, op level: every HIP kernel (called through the C ABI via deepctr_amd.ops) against
+the NumPy oracle on seeded inputs and against the golden fixtures made from the reference's own code.
+Bars: bit-exact for hash / index / copied rows; |d| <= 1e-4*|ref| + 1e-6 for fp32 (BASELINE north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import farmhash as fh
+from oracle import ref_numpy as R
+from tests.util import assert_close, assert_fm_close, golden_meta, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# a2 hash — bit exact
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mask_zero", [False, True])
+def test_hash_ints_bit_exact(device, mask_zero):
+    from deepctr_amd import ops
+    g = load_golden("hash")
+    rng = np.random.RandomState(1)
+    x32 = np.concatenate([g["ints32"], rng.randint(-2 ** 31, 2 ** 31 - 1, 200000).astype(np.int32)])
+    x64 = np.concatenate([g["ints64"], rng.randint(-2 ** 62, 2 ** 62, 100000).astype(np.int64),
+                          10 ** np.arange(0, 19, dtype=np.int64), 10 ** np.arange(0, 19, dtype=np.int64) - 1])
+    for nb in (4, 1000, 100000, 2 ** 31 - 1, 10 ** 7 + 19):
+        got = ops.hash_bucket(dev(x32, device), nb, mask_zero).cpu().numpy()
+        assert (got == fh.hash_bucket_int(x32, nb, mask_zero)).all()
+        got = ops.hash_bucket(dev(x64, device), nb, mask_zero).cpu().numpy()
+        assert (got == fh.hash_bucket_int(x64, nb, mask_zero)).all()
+    for nb in (4, 1000, 100000, 2 ** 31 - 1):   # fixtures produced by the reference's Hash.call
+        got = ops.hash_bucket(dev(g["ints32"], device), nb, mask_zero).cpu().numpy()
+        assert (got == g["i32_nb%d_mz%d" % (nb, mask_zero)]).all()
+        got = ops.hash_bucket(dev(g["ints64"], device), nb, mask_zero).cpu().numpy()
+        assert (got == g["i64_nb%d_mz%d" % (nb, mask_zero)]).all()
+
+
+def test_hash_strings_bit_exact(device):
+    from deepctr_amd import ops
+    g = load_golden("hash")
+    strs = [s.decode() for s in g["strs"]]
+    rng = np.random.RandomState(2)
+    extra = ["".join(chr(rng.randint(33, 127)) for _ in range(n)) for n in list(range(0, 140)) + [255, 256, 257, 1000]]
+    for nb in (4, 1000, 100000, 2 ** 31 - 1):
+        for mz in (False, True):
+            got = ops.hash_bucket_strings(strs, nb, mz, device).cpu().numpy()
+            assert (got == g["str_nb%d_mz%d" % (nb, int(mz))]).all()
+            got = ops.hash_bucket_strings(extra, nb, mz, device).cpu().numpy()
+            assert (got == fh.hash_bucket_str(np.array(extra, dtype=object), nb, mz)).all()
+    t = load_golden("criteo_tokens")
+    toks = [s.decode() for s in t["tokens"]]
+    assert (ops.hash_bucket_strings(toks, 1000, False, device).cpu().numpy() == t["hash_nb1000"]).all()
+    assert ops.hash_bucket_strings([], 10, False, device).numel() == 0
+
+
+def test_hash_empty_and_errors(device):
+    from deepctr_amd import ops, _C
+    assert ops.hash_bucket(torch.zeros(0, dtype=torch.int32, device=device), 10).numel() == 0
+    with pytest.raises(_C.DctrError):
+        ops.hash_bucket(torch.zeros(4, dtype=torch.int32, device=device), 1, mask_zero=True)   # no bucket left
+    with pytest.raises(_C.DctrExtensionError):
+        ops.hash_bucket(torch.zeros(4, dtype=torch.int32), 10)                                  # CPU tensor
+
+
+# ---------------------------------------------------------------------------------------------
+# a3-a8 fused gather + linear + FM
+# ---------------------------------------------------------------------------------------------
+def _gather_case(device, B, dims, vocab, n_dense, hash_modes=None, ids64=False, in_fm=None, seed=0, lin=True):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(seed)
+    F = len(dims)
+    hash_modes = hash_modes or [0] * F
+    in_fm = in_fm if in_fm is not None else [1] * F
+    tables = [rng.standard_normal((vocab[j], dims[j])).astype(np.float32) * 0.3 for j in range(F)]
+    lins = [rng.standard_normal(vocab[j]).astype(np.float32) * 0.1 for j in range(F)]
+    raw = np.stack([rng.randint(0, 2 ** 31 - 1 if hash_modes[j] else vocab[j], B) for j in range(F)]) if F else \
+        np.zeros((0, B), np.int64)
+    raw = raw.astype(np.int64 if ids64 else np.int32)
+    dense = rng.rand(B, n_dense).astype(np.float32) if n_dense else None
+    linw = rng.standard_normal(n_dense).astype(np.float32) if n_dense else None
+    all4 = all(d % 4 == 0 for d in dims) and F > 0
+    offs = np.concatenate([[0], np.cumsum(dims)]).astype(int)
+    total = int(offs[-1]) + n_dense
+    stride = (total + 3) // 4 * 4
+    t_dev = [dev(t, device) for t in tables]
+    l_dev = [dev(l_, device) for l_ in lins]
+    fields = [dict(table=t_dev[j], lin_table=l_dev[j] if lin else None, vocab=vocab[j], dim=dims[j], out_offset=int(offs[j]),
+                   in_fm=in_fm[j], hash_mode=hash_modes[j]) for j in range(F)]
+    desc = ops.make_field_descriptors(fields, device)
+    ids = dev(raw, device)
+    dnn_in = torch.full((B, stride), float("nan"), device=device)
+    fm = torch.empty(B, device=device)
+    ll = torch.empty(B, device=device)
+    status = ops.new_status(device)
+    ops.embed_gather_fm(desc, F, ids, B, 1, B, max(dims) if dims else 1, all4, any(hash_modes),
+                        dense=None if dense is None else dev(dense, device), dense_lin_w=None if linw is None else dev(linw, device),
+                        dense_out_offset=int(offs[-1]), dnn_in=dnn_in, out_stride=stride, fm_logit=fm, lin_logit=ll, status=status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    # oracle
+    rows = [fh.hash_bucket_int(raw[j], vocab[j], hash_modes[j] == 2) if hash_modes[j] else raw[j].astype(np.int64) for j in range(F)]
+    embs = [tables[j][rows[j]] for j in range(F)]
+    ref_in = np.concatenate(embs + ([dense] if dense is not None else []), axis=1) if (F or n_dense) else np.zeros((B, 0))
+    got_in = dnn_in.cpu().numpy()[:, :total]
+    assert (got_in == ref_in).all(), "concat rows must be bit-exact copies"
+    fm_fields = [embs[j].astype(np.float64) for j in range(F) if in_fm[j]]
+    if fm_fields:
+        assert_fm_close(fm.cpu().numpy(), np.stack(fm_fields, axis=1))
+    ref_lin = np.zeros(B)
+    if lin:
+        for j in range(F):
+            ref_lin += lins[j][rows[j]].astype(np.float64)
+    if dense is not None:
+        ref_lin += dense.astype(np.float64) @ linw.astype(np.float64)
+    assert_close(ll.cpu().numpy(), ref_lin, what="linear")
+
+
+@pytest.mark.parametrize("B", [1, 5, 256, 4096, 4099, 20000])
+def test_gather_fm_c2_shapes(device, B):
+    _gather_case(device, B, [16] * 26, [100000] * 26, 13, seed=B)
+
+
+def test_gather_fm_variants(device):
+    _gather_case(device, 300, [4] * 26, [200] * 26, 13, seed=1)                       # config-1 shape (E=4)
+    _gather_case(device, 777, [32] * 26, [5000] * 26, 13, seed=2, ids64=True)           # config-5 shape (E=32), int64 ids
+    _gather_case(device, 333, [8, 8, 8], [50, 60, 70], 0, seed=3)                       # < 8 fields, no dense
+    _gather_case(device, 333, [10, 4, 8, 4], [3, 2, 4, 3], 1, seed=4, in_fm=[0, 1, 0, 1])   # DIN-like mixed dims (scalar path)
+    _gather_case(device, 129, [3] * 9, [11] * 9, 2, seed=5)                             # odd dim
+    _gather_case(device, 64, [64, 64], [40, 40], 70, seed=6)                            # wide rows, > 64 dense columns
+    _gather_case(device, 500, [16] * 12, [1000] * 12, 5, seed=7, hash_modes=[1, 2, 0] * 4)          # in-kernel Hash
+    _gather_case(device, 500, [16] * 12, [1000] * 12, 5, seed=8, hash_modes=[2, 1, 0] * 4, ids64=True)
+    _gather_case(device, 100, [16] * 30, [100] * 30, 0, seed=9, lin=False)              # no linear tables
+    _gather_case(device, 50, [], [], 7, seed=10)                                         # dense only
+
+
+def test_gather_fm_flags_out_of_range(device):
+    from deepctr_amd import ops
+    table = torch.randn(10, 4, device=device)
+    desc = ops.make_field_descriptors([dict(table=table, vocab=10, dim=4, out_offset=0)], device)
+    ids = torch.tensor([[1, 2, 10, -1]], dtype=torch.int32, device=device)
+    out = torch.zeros(4, 4, device=device)
+    status = ops.new_status(device)
+    ops.embed_gather_fm(desc, 1, ids, 4, 1, 4, 4, True, False, dnn_in=out, out_stride=4, status=status)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        ops.check_status(status)
+    assert (out[:2].cpu() == table[[1, 2]].cpu()).all() and (out[2:] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# a5 pooling, lookup
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("combiner", ["sum", "mean", "max"])
+@pytest.mark.parametrize("by_len", [False, True])
+@pytest.mark.parametrize("weighted", [None, True, False])
+def test_embed_pool(device, combiner, by_len, weighted):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(3)
+    for (B, T, E, V) in ((37, 10, 8, 20), (5, 1, 4, 3), (130, 50, 32, 1000), (9, 7, 3, 6)):
+        table = rng.standard_normal((V, E)).astype(np.float32) * 0.5
+        lin = rng.standard_normal(V).astype(np.float32)
+        ids = rng.randint(1, V, (B, T)).astype(np.int32)
+        lens = rng.randint(0, T + 1, B).astype(np.int32)
+        lens[0] = T
+        if B > 1:
+            lens[1] = 0
+        ids[np.arange(T)[None, :] >= lens[:, None]] = 0
+        if not by_len and B > 2 and T > 2:
+            ids[2, 1] = 0                      # interior padding: mask_zero masks are not prefixes
+        w = rng.standard_normal((B, T, 1)).astype(np.float32) if weighted is not None else None
+        mask = ids != 0
+        seq = table[ids]
+        seq1 = lin[ids][:, :, None]
+        kw = dict(lengths=lens) if by_len else dict(mask=mask)
+        if w is not None:
+            seq = R.weighted_sequence(seq, w, weight_normalization=bool(weighted), **kw)
+            seq1 = R.weighted_sequence(seq1, w, weight_normalization=bool(weighted), **kw)
+        ref = R.sequence_pooling(seq, combiner, **kw)[:, 0, :]
+        ref1 = R.sequence_pooling(seq1, combiner, **kw)[:, 0, 0]
+        out, lout = ops.embed_pool(dev(ids, device), dev(table, device), combiner, length=dev(lens, device) if by_len else None,
+                                   weight=None if w is None else dev(w, device), weight_norm=bool(weighted),
+                                   lin_table=dev(lin, device))
+        assert_close(out.cpu().numpy(), ref, what="pool %s" % combiner)
+        assert_close(lout.cpu().numpy(), ref1, what="pool lin %s" % combiner)
+
+
+def test_embed_pool_golden_and_hash(device):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(4)
+    V, E, B, T = 50, 8, 40, 6
+    table = rng.standard_normal((V, E)).astype(np.float32)
+    raw = rng.randint(0, 10 ** 6, (B, T)).astype(np.int32)
+    raw[:, 4:] = 0
+    rows = fh.hash_bucket_int(raw, V, True)
+    ref = R.sequence_pooling(table[rows], "mean", mask=rows != 0)[:, 0, :]
+    out, _ = ops.embed_pool(dev(raw, device), dev(table, device), "mean", hash_mode=2)
+    assert_close(out.cpu().numpy(), ref, what="pool hashed")
+
+
+def test_embed_lookup(device):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(5)
+    for (V, E) in ((100, 16), (7, 3), (50, 32), (9, 10)):
+        table = rng.standard_normal((V, E)).astype(np.float32)
+        ids = rng.randint(0, V, (13, 5)).astype(np.int64)
+        out, mask = ops.embed_lookup(dev(ids, device), dev(table, device), return_mask=True)
+        assert (out.cpu().numpy() == table[ids]).all()
+        assert (mask.cpu().numpy().astype(bool) == (ids != 0)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# a8-a12 interaction layers vs golden (reference code) and vs oracle at larger shapes
+# ---------------------------------------------------------------------------------------------
+def test_fm(device):
+    from deepctr_amd import ops
+    g = load_golden("interaction")
+    for tag in ("t", "c2", "one"):
+        assert_close(ops.fm(dev(g["fm_%s_x" % tag], device)).cpu().numpy(), g["fm_%s_y" % tag], what="fm " + tag)
+    rng = np.random.RandomState(6)
+    for shp in ((4096, 26, 16), (33, 5, 7), (10, 3, 100)):
+        x = rng.standard_normal(shp).astype(np.float32)
+        assert_fm_close(ops.fm(dev(x, device)).cpu().numpy(), x, what="fm %s" % (shp,))
+    with pytest.raises(ValueError):
+        ops.fm(torch.zeros(3, 4, device=device))
+
+
+def test_crossnet(device):
+    from deepctr_amd import ops
+    g = load_golden("interaction")
+    meta = golden_meta(g)
+    for tag in ("v0", "v1", "v3", "m1", "m2", "v2w", "m2w"):
+        m = meta["cross_" + tag]
+        n = m["layer_num"]
+        x = g["cross_%s_x" % tag]
+        d = x.shape[1]
+        if n:
+            ks = np.stack([g["cross_%s_kernel%d" % (tag, k)].reshape(d, -1) for k in range(n)])
+            ks = ks.reshape(n, d) if m["parameterization"] == "vector" else ks
+            bs = np.stack([g["cross_%s_bias%d" % (tag, k)].reshape(d) for k in range(n)])
+            y = ops.crossnet(dev(x, device), dev(ks, device), dev(bs, device), m["parameterization"])
+        else:
+            y = ops.crossnet(dev(x, device), None, None, m["parameterization"])
+        assert_close(y.cpu().numpy(), g["cross_%s_y" % tag], what="crossnet " + tag)
+    rng = np.random.RandomState(7)
+    for par, B, d, L in (("vector", 4096, 429, 2), ("matrix", 300, 429, 2), ("vector", 9, 1500, 3), ("matrix", 17, 64, 4)):
+        x = rng.standard_normal((B, d)).astype(np.float32)
+        ks = (rng.standard_normal((L, d) if par == "vector" else (L, d, d)) / np.sqrt(d)).astype(np.float32)
+        bs = rng.standard_normal((L, d)).astype(np.float32) * 0.1
+        ref = R.crossnet(x.astype(np.float64), [k.reshape(d, -1).astype(np.float64) for k in ks],
+                         [b.reshape(d, 1).astype(np.float64) for b in bs], par)
+        y = ops.crossnet(dev(x, device), dev(ks, device), dev(bs, device), par)
+        assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="crossnet %s d=%d" % (par, d))
+
+
+def test_cin(device):
+    from deepctr_amd import ops
+    g = load_golden("interaction")
+    meta = golden_meta(g)
+    for tag in "abcde":
+        m = meta["cin_" + tag]
+        n = len(m["layer_size"])
+        fs = [dev(g["cin_%s_filter%d" % (tag, k)][0], device) for k in range(n)]
+        bs = [dev(g["cin_%s_bias%d" % (tag, k)], device) for k in range(n)]
+        y = ops.cin(dev(g["cin_%s_x" % tag], device), fs, bs, m["layer_size"], m["split_half"], m["activation"])
+        assert_close(y.cpu().numpy(), g["cin_%s_y" % tag], rtol=1e-4, atol=1e-5, what="cin " + tag)
+    # C3 shape against the float64 oracle
+    rng = np.random.RandomState(8)
+    B, F0, D, ls = 70, 26, 16, (128, 128)
+    x = (rng.standard_normal((B, F0, D)) * 0.3).astype(np.float32)
+    fk = [F0, 64]
+    fs = [(rng.standard_normal((1, F0 * fk[k], ls[k])) / np.sqrt(F0 * fk[k])).astype(np.float32) for k in range(2)]
+    bs = [rng.standard_normal(ls[k]).astype(np.float32) * 0.1 for k in range(2)]
+    ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], True, "relu")
+    y = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, True, "relu")
+    assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="cin C3")
+
+
+def test_afm_inner_product(device):
+    from deepctr_amd import ops
+    g = load_golden("interaction")
+    for tag in ("t", "w", "two"):
+        x = dev(g["afm_%s_x" % tag], device)
+        y = ops.afm(x, dev(g["afm_%s_attention_W" % tag], device), dev(g["afm_%s_attention_b" % tag], device),
+                    dev(g["afm_%s_projection_h" % tag], device), dev(g["afm_%s_projection_p" % tag], device))
+        assert_close(y.cpu().numpy(), g["afm_%s_y" % tag], what="afm " + tag)
+        assert_close(ops.inner_product(x, True).cpu().numpy(), g["ip_%s_sum" % tag], what="ip sum " + tag)
+        assert_close(ops.inner_product(x, False).cpu().numpy(), g["ip_%s_full" % tag], what="ip full " + tag)
+
+
+# ---------------------------------------------------------------------------------------------
+# adjacent: DNN (+head), DIN attention
+# ---------------------------------------------------------------------------------------------
+def test_mlp_golden(device):
+    from deepctr_amd import ops
+    g = load_golden("core")
+    x = dev(g["x"], device)
+    for tag, n, act in (("relu", 3, "relu"), ("dice", 2, "dice"), ("sig", 1, "sigmoid")):
+        pre = "dnn_%s_w/dnn" % tag
+        ks = [dev(g["%s/kernel%d" % (pre, i)], device) for i in range(n)]
+        bs = [dev(g["%s/bias%d" % (pre, i)], device) for i in range(n)]
+        dice = None
+        if act == "dice":
+            dice = []
+            for i in range(n):
+                sfx = "" if i == 0 else "_%d" % i
+                dice.append(tuple(dev(g[k], device) for k in ("dnn_dice_w/dice%s/dice_alpha" % sfx,
+                                                              "dnn_dice_w/batch_normalization%s/moving_mean" % sfx,
+                                                              "dnn_dice_w/batch_normalization%s/moving_variance" % sfx)))
+        y = ops.mlp(x, ks, bs, act, dice=dice)
+        assert_close(y.cpu().numpy(), g["dnn_%s_y" % tag], what="dnn " + tag)
+
+
+@pytest.mark.parametrize("B", [1, 16, 4096, 4100])
+def test_mlp_c2_with_head(device, B):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(9)
+    dims = [429, 256, 128, 64]
+    x = rng.standard_normal((B, 432)).astype(np.float32)
+    x[:, 429:] = np.nan                                  # stride padding must never be read
+    ks = [(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / (dims[i] + dims[i + 1]))).astype(np.float32) for i in range(3)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(3)]
+    hw = rng.standard_normal(64).astype(np.float32) * 0.2
+    a0, a1 = rng.standard_normal(B).astype(np.float32), rng.standard_normal(B).astype(np.float32)
+    gb = np.array([0.3], np.float32)
+    h = R.dnn(x[:, :429].astype(np.float64), [k.astype(np.float64) for k in ks], [b.astype(np.float64) for b in bs], "relu")
+    logit = h @ hw.astype(np.float64) + a0 + a1 + gb[0]
+    y = ops.mlp(dev(x, device), [dev(k, device) for k in ks], [dev(b, device) for b in bs], "relu", head_w=dev(hw, device),
+                add=(dev(a0, device), dev(a1, device)), global_bias=dev(gb, device), sigmoid_out=False, in_dim=429)
+    assert_close(y.cpu().numpy(), logit, what="mlp head logits")
+    y = ops.mlp(dev(x, device), [dev(k, device) for k in ks], [dev(b, device) for b in bs], "relu", head_w=dev(hw, device),
+                add=(dev(a0, device), dev(a1, device)), global_bias=dev(gb, device), sigmoid_out=True, in_dim=429)
+    assert_close(y.cpu().numpy(), 1 / (1 + np.exp(-logit)), what="mlp head probs")
+    # no-layer head (Dense(1) on a concat) and odd widths
+    y = ops.mlp(dev(x, device), [], [], "relu", head_w=dev(rng.standard_normal(429).astype(np.float32), device), in_dim=429)
+    assert y.shape == (B,)
+    x2 = rng.standard_normal((B, 39)).astype(np.float32)
+    ks2 = [rng.standard_normal((39, 4)).astype(np.float32) * 0.3, rng.standard_normal((4, 5)).astype(np.float32),
+           rng.standard_normal((5, 70)).astype(np.float32) * 0.3]
+    bs2 = [rng.standard_normal(4).astype(np.float32), rng.standard_normal(5).astype(np.float32), rng.standard_normal(70).astype(np.float32)]
+    ref = R.dnn(x2.astype(np.float64), [k.astype(np.float64) for k in ks2], [b.astype(np.float64) for b in bs2], "tanh")
+    y = ops.mlp(dev(x2, device), [dev(k, device) for k in ks2], [dev(b, device) for b in bs2], "tanh")
+    assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="mlp odd widths")
+
+
+def _att_weights(g, prefix, n_layers, act, device):
+    ks = [dev(g["%s/dnn/kernel%d" % (prefix, i)], device) for i in range(n_layers)]
+    bs = [dev(g["%s/dnn/bias%d" % (prefix, i)], device) for i in range(n_layers)]
+    dice = None
+    if act == "dice":
+        dice = []
+        for i in range(n_layers):
+            sfx = "" if i == 0 else "_%d" % i
+            dice.append(tuple(dev(g[k], device) for k in ("%s/dice%s/dice_alpha" % (prefix, sfx),
+                                                          "%s/batch_normalization%s/moving_mean" % (prefix, sfx),
+                                                          "%s/batch_normalization%s/moving_variance" % (prefix, sfx))))
+    return ks, bs, dev(g[prefix + "/local_activation_unit/kernel"], device), dev(g[prefix + "/local_activation_unit/bias"], device), dice
+
+
+def test_din_attention_golden(device):
+    from deepctr_amd import ops
+    g = load_golden("sequence")
+    meta = golden_meta(g)
+    seq, lengths, mask, query = g["seq"], g["lengths"], g["mask"], g["query"]
+    len_mask = R.sequence_mask(lengths, seq.shape[1])
+    for tag in ("sig", "sig_wn", "dice", "dice_wn", "relu"):
+        m = meta["att_" + tag]
+        for form, km in (("len", len_mask), ("mask", mask)):
+            ks, bs, ok, ob, dice = _att_weights(g, "att_%s_%s_w" % (tag, form), len(m["hidden"]), m["activation"], device)
+            y = ops.din_attention(dev(query, device), dev(seq, device), dev(km, device), ks, bs, ok, ob, m["activation"], dice,
+                                  weight_normalization=m["weight_normalization"])
+            assert_close(y.cpu().numpy(), g["att_%s_%s_y" % (tag, form)], what="attention %s %s" % (tag, form))
+
+
+def test_din_attention_c4_shape(device):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(10)
+    for (B, T, E, hid) in ((64, 50, 64, (80, 40)), (5, 130, 16, (36,)), (3, 4, 12, ())):
+        q = rng.standard_normal((B, 1, E)).astype(np.float32) * 0.5
+        k = rng.standard_normal((B, T, E)).astype(np.float32) * 0.5
+        lens = rng.randint(0, T + 1, B)
+        km = np.arange(T)[None, :] < lens[:, None]
+        dims = [4 * E] + list(hid)
+        ks = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(hid))]
+        bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(hid))]
+        ok = rng.standard_normal((dims[-1], 1)).astype(np.float32) * 0.3
+        ob = np.array([0.05], np.float32)
+        dice = [(rng.standard_normal(h).astype(np.float32) * 0.3, rng.standard_normal(h).astype(np.float32) * 0.1,
+                 rng.uniform(0.5, 1.5, h).astype(np.float32)) for h in hid]
+        for act, wn in (("dice", False), ("sigmoid", True)):
+            ref = R.attention_sequence_pooling(q.astype(np.float64), k.astype(np.float64), km, [w.astype(np.float64) for w in ks],
+                                               [b.astype(np.float64) for b in bs], ok.astype(np.float64), ob.astype(np.float64), act,
+                                               [tuple(a.astype(np.float64) for a in d) for d in dice] if act == "dice" else None, wn)
+            y = ops.din_attention(dev(q, device), dev(k, device), dev(km, device), [dev(w, device) for w in ks],
+                                  [dev(b, device) for b in bs], dev(ok, device), dev(ob, device), act,
+                                  [tuple(dev(a, device) for a in d) for d in dice] if act == "dice" else None,
+                                  weight_normalization=wn)
+            assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="din attention B=%d T=%d %s" % (B, T, act))

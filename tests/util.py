@@ -33,3 +33,14 @@ def assert_close(got, ref, rtol=1e-4, atol=1e-6, what=""):
 def sigmoid_inv(y):
     y = np.clip(np.asarray(y, dtype=np.float64), 1e-300, 1 - 1e-16)
     return np.log(y) - np.log1p(-y)
+
+
+def assert_fm_close(got, x, what="fm"):
+    """FM = 0.5*sum_d(S_d^2 - Q_d) cancels, so besides the 1e-4 relative bar the fp32 floor is a few ulp of the
+    TERMS (0.5*sum_d(S_d^2 + Q_d)), not of the result; x [B,F,E] are the embeddings fed to FM."""
+    x = np.asarray(x, dtype=np.float64)
+    ref = 0.5 * (np.square(x.sum(1)) - np.square(x).sum(1)).sum(-1)
+    scale = 0.5 * (np.square(x.sum(1)) + np.square(x).sum(1)).sum(-1)
+    err = np.abs(np.asarray(got, dtype=np.float64).reshape(-1) - ref)
+    bar = 1e-4 * np.abs(ref) + 1e-6 + 4 * np.finfo(np.float32).eps * scale
+    assert (err <= bar).all(), "%s: max err/bar %.3g" % (what, float((err / bar).max()))
