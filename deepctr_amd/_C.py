@@ -45,7 +45,7 @@ class GatherFmArgs(ctypes.Structure):
     _fields_ = [("fields", c_vp), ("ids", c_vp), ("ids_stride_f", c_i64), ("ids_stride_b", c_i64),
                 ("ids_is_i64", c_i32), ("n_fields", c_i32), ("max_dim", c_i32), ("all_dim4", c_i32),
                 ("any_hash", c_i32), ("n_dense", c_i32), ("dense", c_vp), ("dense_stride", c_i64),
-                ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("pad_", c_i32), ("batch", c_i64),
+                ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("dense_copy_cols", c_i32), ("batch", c_i64),
                 ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp)]
 
 
@@ -89,12 +89,15 @@ SYMBOLS = {
     "dctr_abi_version": (ctypes.c_int, []),
     "dctr_last_error": (ctypes.c_char_p, []),
     "dctr_target_arch": (ctypes.c_char_p, []),
+    "dctr_profile_next_launch": (ctypes.c_int, []),
+    "dctr_profile_last_ms": (ctypes.c_float, []),
     "dctr_hash_bucket_i32": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_hash_bucket_i64": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_hash_bucket_bytes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_embed_gather_fm": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), c_vp]),
     "dctr_embed_pool": (ctypes.c_int, [ctypes.POINTER(PoolArgs), c_vp]),
     "dctr_embed_lookup": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_vp]),
+    "dctr_seq_weight_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),

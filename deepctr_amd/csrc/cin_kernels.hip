@@ -227,6 +227,6 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     }
     const int64_t blocks = dctr_ceil_div(a->batch, p.SB);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "cin_fwd: batch too large");
-    hipLaunchKernelGGL(cin_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    DCTR_LAUNCH(cin_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     return dctr_launch_status("dctr_cin_fwd");
 }

@@ -1,6 +1,7 @@
 // Shared host-side helpers for the libdctr_hip.so translation units (gfx950 only; no CUDA paths).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "dctr.h"
@@ -29,3 +30,18 @@ static inline bool dctr_aligned16(const void* p) { return (((uintptr_t)p) & 15u)
 static inline int64_t dctr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 #define DCTR_WAVE 64
+
+// Kernel-duration probe (bench / tests): when armed by dctr_profile_next_launch(), the NEXT launch on this
+// host thread goes out through hipExtLaunchKernelGGL with a start/stop event pair, i.e. the GPU timestamps
+// of that dispatch alone (what rocprofv3 --kernel-trace reports), not an event-to-event period that also
+// contains launch gaps.  dctr_profile_last_ms() waits for the stop event and returns the duration.
+bool dctr_profile_take(hipEvent_t* start, hipEvent_t* stop);
+
+#define DCTR_LAUNCH(kernel, grid, block, lds, stream, ...)                                             \
+    do {                                                                                               \
+        hipEvent_t dctr_e0_, dctr_e1_;                                                                 \
+        if (dctr_profile_take(&dctr_e0_, &dctr_e1_))                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, dctr_e0_, dctr_e1_, 0, __VA_ARGS__); \
+        else                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                         \
+    } while (0)

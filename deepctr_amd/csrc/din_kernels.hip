@@ -258,6 +258,6 @@ extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* strea
                      hipGetErrorString(e));
     }
     DCTR_REQUIRE(a->batch <= 0x7fffffffLL, DCTR_E_DIM, "din_attn_pool_fwd: batch too large");
-    hipLaunchKernelGGL(din_attn_kernel, dim3((unsigned)a->batch), dim3(256), lds, (hipStream_t)stream, p);
+    DCTR_LAUNCH(din_attn_kernel, dim3((unsigned)a->batch), dim3(256), lds, (hipStream_t)stream, p);
     return dctr_launch_status("dctr_din_attn_pool_fwd");
 }

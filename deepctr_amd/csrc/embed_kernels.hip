@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
         for (int m = 0; m < 4; ++m) {
             const int k = q + m * LPR;
             if (valid && k < p.n_dense) {
-                if (p.dnn_in != nullptr && p.dense_out_offset >= 0)
+                if (p.dnn_in != nullptr && p.dense_out_offset >= 0 && k < p.dense_copy_cols)
                     p.dnn_in[b * p.out_stride + p.dense_out_offset + k] = dx[m];
                 lin = fmaf(dx[m], dw[m], lin);
             }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
         for (int m = 0; m < 4; ++m) {
             const int k = k0 + q + m * LPR;
             if (valid && k < p.n_dense) {
-                if (p.dnn_in != nullptr && p.dense_out_offset >= 0)
+                if (p.dnn_in != nullptr && p.dense_out_offset >= 0 && k < p.dense_copy_cols)
                     p.dnn_in[b * p.out_stride + p.dense_out_offset + k] = x[m];
                 lin = fmaf(x[m], w[m], lin);
             }
@@ -423,6 +423,45 @@ __global__ __launch_bounds__(256) void lookup_kernel(dctr_lookup_args_t a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// stand-alone WeightedSequenceLayer.call over a materialised [B,T,E] tensor (reference layers/sequence.py:155-183)
+// one wave per sample: masked weights -> (optional) softmax over T -> out[b,t,:] = seq[b,t,:] * w[b,t]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seq_weight_kernel(const float* __restrict__ seq, const float* __restrict__ weight,
+                                                         const uint8_t* __restrict__ mask, const int32_t* __restrict__ length,
+                                                         int64_t batch, int T, int E, int weight_norm,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const float PAD = -4294967296.f;
+    const int len = length != nullptr ? length[b] : 0;
+    float mx = -INFINITY, den = 1.f;
+    if (weight_norm) {
+        for (int t = lane; t < T; t += 64) {
+            const bool m = length != nullptr ? (t < len) : (mask[b * T + t] != 0);
+            mx = fmaxf(mx, m ? weight[b * T + t] : PAD);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        den = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const bool m = length != nullptr ? (t < len) : (mask[b * T + t] != 0);
+            den += expf((m ? weight[b * T + t] : PAD) - mx);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) den += __shfl_xor(den, o, 64);
+    }
+    const int64_t n = (int64_t)T * E;
+    for (int64_t i = lane; i < n; i += 64) {
+        const int t = (int)(i / E);
+        const bool m = length != nullptr ? (t < len) : (mask[b * T + t] != 0);
+        const float wv = weight[b * T + t];
+        const float w = weight_norm ? expf((m ? wv : PAD) - mx) / den : (m ? wv : 0.f);
+        out[b * n + i] = seq[b * n + i] * w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------------------------------
 // lanes per row for (max_dim, VEC): smallest power of two with LPR * VEC >= max_dim
@@ -455,6 +494,8 @@ extern "C" int dctr_embed_gather_fm(const dctr_gather_fm_args_t* a, void* stream
                  "embed_gather_fm: null field descriptors / id matrix");
     DCTR_REQUIRE(a->n_dense == 0 || a->dense != nullptr, DCTR_E_NULL, "embed_gather_fm: null dense matrix");
     DCTR_REQUIRE(a->n_dense == 0 || a->dense_stride >= a->n_dense, DCTR_E_DIM, "embed_gather_fm: dense_stride < n_dense");
+    DCTR_REQUIRE(a->dense_copy_cols >= 0 && a->dense_copy_cols <= a->n_dense, DCTR_E_DIM,
+                 "embed_gather_fm: dense_copy_cols outside [0, n_dense]");
     const int vec = (a->all_dim4 && a->n_fields > 0) ? 4 : 1;
     const int max_dim = a->max_dim > 0 ? a->max_dim : 1;
     DCTR_REQUIRE(max_dim <= 64 * vec, DCTR_E_UNSUPPORTED,
@@ -475,7 +516,7 @@ extern "C" int dctr_embed_gather_fm(const dctr_gather_fm_args_t* a, void* stream
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_gather_fm: batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_G(VECV, L, FS, HS) \
-    hipLaunchKernelGGL((gather_fm_kernel<VECV, L, FS, HS>), dim3((unsigned)blocks), dim3(256), 0, st, p)
+    DCTR_LAUNCH((gather_fm_kernel<VECV, L, FS, HS>), dim3((unsigned)blocks), dim3(256), 0, st, p)
 #define CALL_G(VECV, L)                                                 \
     do {                                                                \
         if (fsplit) {                                                   \
@@ -508,7 +549,7 @@ extern "C" int dctr_embed_pool(const dctr_pool_args_t* a, void* stream) {
     const int64_t blocks = dctr_ceil_div(dctr_ceil_div(a->batch, 64 / lpr), 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool: batch too large");
     hipStream_t st = (hipStream_t)stream;
-#define CALL_P(VECV, L) hipLaunchKernelGGL((pool_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
+#define CALL_P(VECV, L) DCTR_LAUNCH((pool_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
     if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_P) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_P) }
 #undef CALL_P
     return dctr_launch_status("dctr_embed_pool");
@@ -527,8 +568,21 @@ extern "C" int dctr_embed_lookup(const dctr_lookup_args_t* a, void* stream) {
     int64_t blocks = dctr_ceil_div(a->n, 256 / lpr);
     if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
-#define CALL_L(VECV, L) hipLaunchKernelGGL((lookup_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
+#define CALL_L(VECV, L) DCTR_LAUNCH((lookup_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
     if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_L) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_L) }
 #undef CALL_L
     return dctr_launch_status("dctr_embed_lookup");
+}
+
+extern "C" int dctr_seq_weight_fwd(const float* seq, const float* weight, const uint8_t* mask, const int32_t* length,
+                                   int64_t batch, int32_t maxlen, int32_t dim, int32_t weight_norm, float* out,
+                                   void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1 && dim >= 1, DCTR_E_DIM, "seq_weight_fwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(seq && weight && out && (mask || length), DCTR_E_NULL, "seq_weight_fwd: null pointer");
+    const int64_t blocks = dctr_ceil_div(batch, 4);
+    DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "seq_weight_fwd: batch too large");
+    DCTR_LAUNCH(seq_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seq, weight, mask,
+                       length, batch, maxlen, dim, weight_norm, out);
+    return dctr_launch_status("dctr_seq_weight_fwd");
 }

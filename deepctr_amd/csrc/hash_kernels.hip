@@ -52,7 +52,7 @@ extern "C" int dctr_hash_bucket_i32(const int32_t* x, int64_t n, int64_t num_buc
     int c = check_common(x, n, num_buckets, mask_zero, out);
     if (c < 0) return c;
     if (c == 1) return DCTR_OK;
-    hipLaunchKernelGGL(hash_int_kernel<int32_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n,
+    DCTR_LAUNCH(hash_int_kernel<int32_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n,
                        (uint64_t)num_buckets, mask_zero, out);
     return dctr_launch_status("dctr_hash_bucket_i32");
 }
@@ -62,7 +62,7 @@ extern "C" int dctr_hash_bucket_i64(const int64_t* x, int64_t n, int64_t num_buc
     int c = check_common(x, n, num_buckets, mask_zero, out);
     if (c < 0) return c;
     if (c == 1) return DCTR_OK;
-    hipLaunchKernelGGL(hash_int_kernel<int64_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n,
+    DCTR_LAUNCH(hash_int_kernel<int64_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n,
                        (uint64_t)num_buckets, mask_zero, out);
     return dctr_launch_status("dctr_hash_bucket_i64");
 }
@@ -73,7 +73,7 @@ extern "C" int dctr_hash_bucket_bytes(const uint8_t* bytes, const int64_t* offse
     if (c < 0) return c;
     if (c == 1) return DCTR_OK;
     DCTR_REQUIRE(offsets, DCTR_E_NULL, "hash_bucket_bytes: null offsets");
-    hipLaunchKernelGGL(hash_bytes_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, bytes, offsets, n,
+    DCTR_LAUNCH(hash_bytes_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, bytes, offsets, n,
                        (uint64_t)num_buckets, mask_zero, out);
     return dctr_launch_status("dctr_hash_bucket_bytes");
 }

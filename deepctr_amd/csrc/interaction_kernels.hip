@@ -268,7 +268,7 @@ extern "C" int dctr_fm_fwd(const float* x, int64_t batch, int64_t x_stride, int3
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "fm_fwd: batch too large");
     hipStream_t st = (hipStream_t)stream;
 #define CALL_FM(L) \
-    hipLaunchKernelGGL((fm_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, x_stride, fields, dim, y)
+    DCTR_LAUNCH((fm_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, x_stride, fields, dim, y)
     switch (lpr) {
         case 1: CALL_FM(1); break;
         case 2: CALL_FM(2); break;
@@ -297,7 +297,7 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
         const int nr = pow2_at_least((dim + 63) / 64, 32);
 #define CALL_CV(N)                                                                                                  \
-    hipLaunchKernelGGL((cross_vector_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, \
+    DCTR_LAUNCH((cross_vector_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, \
                        kernels, bias, layers, y, y_stride)
         switch (nr) {
             case 1: CALL_CV(1); break;
@@ -319,7 +319,7 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
         }
         const int64_t blocks = dctr_ceil_div(batch, 16);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
-        hipLaunchKernelGGL(cross_matrix_kernel, dim3((unsigned)blocks), dim3(256), lds, st, x, batch, dim, x_stride, kernels,
+        DCTR_LAUNCH(cross_matrix_kernel, dim3((unsigned)blocks), dim3(256), lds, st, x, batch, dim, x_stride, kernels,
                            bias, layers, y, y_stride, lda);
     }
     return dctr_launch_status("dctr_crossnet_fwd");
@@ -340,7 +340,7 @@ extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int32_t fields, int32
     }
     const int64_t blocks = dctr_ceil_div(batch, 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "afm_fwd: batch too large");
-    hipLaunchKernelGGL(afm_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, batch, fields, dim,
+    DCTR_LAUNCH(afm_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, batch, fields, dim,
                        att_w, att_b, proj_h, proj_p, att_factor, y);
     return dctr_launch_status("dctr_afm_fwd");
 }
@@ -359,7 +359,7 @@ extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int32_t fie
     }
     const int64_t blocks = dctr_ceil_div(batch, 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "inner_product_fwd: batch too large");
-    hipLaunchKernelGGL(inner_product_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, batch, fields,
+    DCTR_LAUNCH(inner_product_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, batch, fields,
                        dim, reduce_sum, y);
     return dctr_launch_status("dctr_inner_product_fwd");
 }

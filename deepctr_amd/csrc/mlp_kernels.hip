@@ -201,6 +201,6 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) {
     }
     const int64_t blocks = dctr_ceil_div(a->batch, 16);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
-    hipLaunchKernelGGL(mlp_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    DCTR_LAUNCH(mlp_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     return dctr_launch_status("dctr_mlp_fwd");
 }

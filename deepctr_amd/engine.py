@@ -1,0 +1,553 @@
+"""Model object + execution plan: what replaces the reference's Keras graph.
+
+The reference builds a ``tf.keras.Model`` once (deepctr/models/*.py) and lets Keras run, per batch,
+~52 Embedding gathers + concat + reductions before the first GEMM.  Here a model constructor compiles the
+feature columns into an ``EmbeddingStage`` (table registry, id-matrix row order, descriptor array, dnn_in
+layout) once; ``predict`` stages the inputs on the device ONCE (one id matrix [F, N], one dense matrix
+[N, ND], one tensor per sequence feature) and then issues, per batch, 2-3 C-ABI calls on torch's current
+stream with nothing but pointer offsets changing between batches.
+
+Public surface kept from ``tf.keras.Model`` as DeepCTR users / tests call it (reference
+docs/source/Model_Methods.md, tests/utils.py:356-381): compile, fit, evaluate, predict, predict_on_batch,
+train_on_batch, get_layer, get_weights / set_weights, save_weights / load_weights, count_params, summary.
+Weight access by the reference's layer names is the guaranteed contract (``get_layer('sparse_emb_C1')``,
+``set_weights_by_name({'dnn/kernel0': ...})``); list order of get_weights() is this build's own.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _C, ops
+from .feature_column import DenseFeat, SparseFeat, VarLenSparseFeat, _is_string_dtype, build_input_features
+from .layers.base import default_device
+from .layers.utils import as_tf_string, load_vocabulary
+
+
+# ---------------------------------------------------------------------------------------------------
+# input staging
+# ---------------------------------------------------------------------------------------------------
+class Staged(object):
+    """All N rows of one predict/evaluate call, resident on the device."""
+
+    def __init__(self, n):
+        self.n = n
+        self.ids = None          # [R, N] int32|int64: one row per gather field
+        self.dense = None        # [N, ND] float32
+        self.seq = {}            # varlen feature name -> [N, T] ids
+        self.length = {}         # length_name -> [N] int32
+        self.weight = {}         # weight_name -> [N, T] float32
+
+
+def _column(x, name):
+    if name not in x:
+        raise KeyError("model input %r is missing from the feed" % (name,))
+    return np.asarray(x[name])
+
+
+def _is_stringy(a):
+    return a.dtype.kind in "USO"
+
+
+def prehashed_on_host(fc):
+    """True when the ids of this feature are resolved while staging (vocabulary_path lookup, or string-dtype
+    features, which are host data in the reference as well) instead of by the in-kernel integer Hash."""
+    return bool(fc.use_hash and (fc.vocabulary_path or _is_string_dtype(fc.dtype)))
+
+
+def _ids_from_column(a, fc, mask_zero, device):
+    """Host/device preparation of one id column -> ndarray | device tensor of integer ids."""
+    if fc.use_hash and fc.vocabulary_path:
+        table = load_vocabulary(fc.vocabulary_path)
+        return np.array([table.get(as_tf_string(v), 0) for v in a.reshape(-1)], dtype=np.int64).reshape(a.shape)
+    if prehashed_on_host(fc):
+        t = ops.hash_bucket_strings([as_tf_string(v) for v in a.reshape(-1)], fc.vocabulary_size, mask_zero, device)
+        return t.reshape(a.shape)
+    if _is_stringy(a):
+        raise TypeError("feature %r is declared dtype=%r but was fed strings; declare dtype='string' (with "
+                        "use_hash=True) to hash string ids" % (fc.name, fc.dtype))
+    if a.dtype.kind == "f":
+        a = a.astype(np.int64)
+    if a.dtype.kind not in "iu":
+        raise TypeError("feature %r: unsupported id dtype %s" % (fc.name, a.dtype))
+    return a
+
+
+def _fit_int32(arrs):
+    for a in arrs:
+        if isinstance(a, torch.Tensor):
+            if a.dtype == torch.int64:
+                return False
+        elif a.dtype.itemsize > 4 and a.size and (a.min() < -2 ** 31 or a.max() > 2 ** 31 - 1):
+            return False
+    return True
+
+
+# ---------------------------------------------------------------------------------------------------
+# embedding stage (shared by DeepFM / DCN / xDeepFM / DIN)
+# ---------------------------------------------------------------------------------------------------
+class FieldSpec(object):
+    def __init__(self, fc, kind, table, lin_table, dim, out_offset, in_fm, hash_mode):
+        self.fc, self.kind, self.table, self.lin_table = fc, kind, table, lin_table
+        self.dim, self.out_offset, self.in_fm, self.hash_mode = dim, out_offset, in_fm, hash_mode
+
+
+class EmbeddingStage(object):
+    """Compiles (linear_feature_columns, dnn_feature_columns) into the fused-gather plan.
+
+    Ordering rules reproduced from the reference: ``input_from_feature_columns`` puts all SparseFeat first and
+    then all VarLenSparseFeat, bucketed by ``group_name`` in first-appearance order (feature_column.py:213-233,
+    inputs.py:175-181); DenseFeat follow in column order (inputs.py:161-172); the DNN input is
+    ``[flatten(concat(embeddings)), concat(dense)]`` (layers/utils.py:336-346)."""
+
+    def __init__(self, tables, linear_tables, linear_cols, dnn_cols, fm_groups=(), mask_feat_list=(), extra_dims=(),
+                 skip_varlen=(), device=None):
+        self.device = device or default_device()
+        self.tables, self.linear_tables = tables, linear_tables
+        self.linear_cols, self.dnn_cols = list(linear_cols or []), list(dnn_cols or [])
+        self.mask_feat_list = tuple(mask_feat_list)
+        lin_by_name = {fc.name: fc for fc in self.linear_cols}
+
+        sparse = [fc for fc in self.dnn_cols if isinstance(fc, SparseFeat)]
+        varlen = [fc for fc in self.dnn_cols if isinstance(fc, VarLenSparseFeat) and fc.name not in skip_varlen]
+        groups = OrderedDict()
+        for fc in sparse:
+            groups.setdefault(fc.group_name, []).append(fc)
+        vgroups = OrderedDict()
+        for fc in varlen:
+            vgroups.setdefault(fc.group_name, []).append(fc)
+        for k, v in vgroups.items():
+            groups.setdefault(k, []).extend(v)
+        self.group_slices = OrderedDict()     # group -> (first column, n fields, dim or None)
+        self.fm_group_names = [g for g in groups if g in tuple(fm_groups)]
+        fused_fm = self.fm_group_names[0] if self.fm_group_names else None
+
+        self.fields = []                      # FieldSpec in dnn_in order
+        off = 0
+        for gname, fcs in groups.items():
+            first = off
+            dims = set()
+            for fc in fcs:
+                lin_t = None
+                if fc.name in lin_by_name:
+                    lin_t = self.linear_tables[fc.embedding_name].embeddings
+                table = self.tables[fc.embedding_name].embeddings
+                if isinstance(fc, SparseFeat):
+                    hm = 0
+                    if fc.use_hash and not prehashed_on_host(fc):
+                        hm = 2 if fc.name in self.mask_feat_list else 1
+                    spec = FieldSpec(fc, "sparse", table, lin_t, fc.embedding_dim, off, gname == fused_fm, hm)
+                else:
+                    spec = FieldSpec(fc, "pooled", table, lin_t, fc.embedding_dim, off, gname == fused_fm, 0)
+                self.fields.append(spec)
+                dims.add(fc.embedding_dim)
+                off += fc.embedding_dim
+            self.group_slices[gname] = (first, len(fcs), dims.pop() if len(dims) == 1 else None)
+        for g in self.fm_group_names:
+            if self.group_slices[g][2] is None:
+                raise ValueError("FM group %r mixes embedding_dim values" % g)
+        self.emb_dim_total = off
+        self.extra_offsets = OrderedDict()
+        for name, dim in extra_dims:          # e.g. DIN's attention output sits between embeddings and dense
+            self.extra_offsets[name] = off
+            off += dim
+        self.dense_offset = off
+
+        # dense: dnn DenseFeat first (copied into dnn_in), then DenseFeat that only the linear part uses
+        dnn_dense = [fc for fc in self.dnn_cols if isinstance(fc, DenseFeat)]
+        lin_dense = [fc for fc in self.linear_cols if isinstance(fc, DenseFeat)]
+        self.dense_cols = list(dnn_dense) + [fc for fc in lin_dense if fc.name not in set(d.name for d in dnn_dense)]
+        self.n_dense_dnn = sum(fc.dimension for fc in dnn_dense)
+        self.n_dense = sum(fc.dimension for fc in self.dense_cols)
+        self.n_lin_dense = sum(fc.dimension for fc in lin_dense)
+        # column j of the dense matrix -> row of Linear.kernel (or -1)
+        row_of = {}
+        r = 0
+        for fc in lin_dense:
+            for p in range(fc.dimension):
+                row_of[(fc.name, p)] = r
+                r += 1
+        self.dense_lin_rows = []
+        for fc in self.dense_cols:
+            for p in range(fc.dimension):
+                self.dense_lin_rows.append(row_of.get((fc.name, p), -1))
+        self.in_dim = off + self.n_dense_dnn
+        self.out_stride = (self.in_dim + 3) // 4 * 4
+
+        # linear-only features (in linear_feature_columns but not in dnn_feature_columns)
+        dnn_names = set(fc.name for fc in self.dnn_cols)
+        self.lin_only = [fc for fc in self.linear_cols if not isinstance(fc, DenseFeat) and fc.name not in dnn_names]
+        self.has_linear = len(self.linear_cols) > 0
+
+        self.sparse_fields = [f for f in self.fields if f.kind == "sparse"]
+        self.pooled_fields = [f for f in self.fields if f.kind == "pooled"]
+        self.all_dim4 = len(self.fields) > 0 and all(
+            f.dim % 4 == 0 and f.out_offset % 4 == 0 and (f.kind == "pooled" or f.table.data_ptr() % 16 == 0)
+            for f in self.fields)
+        self.max_dim = max([f.dim for f in self.fields] + [1])
+        self.any_hash = any(f.hash_mode for f in self.fields)
+        self._ws = {}
+
+    # -- staging -----------------------------------------------------------------------------------
+    def id_features(self):
+        """One id-matrix row per field of the fused gather (identity rows for pooled fields stay zero), followed
+        by one row per linear-only sparse feature."""
+        rows = [f.fc if f.kind == "sparse" else None for f in self.fields]
+        rows += [fc if isinstance(fc, SparseFeat) else None for fc in self.lin_only]
+        return rows
+
+    def varlen_features(self):
+        return [f.fc for f in self.pooled_fields] + [fc for fc in self.lin_only if isinstance(fc, VarLenSparseFeat)]
+
+    def stage(self, x, staged):
+        dev = self.device
+        cols = []
+        for fc in self.id_features():
+            if fc is None:
+                cols.append(None)
+                continue
+            a = _column(x, fc.name).reshape(-1)
+            if a.shape[0] != staged.n:
+                raise ValueError("feature %r has %d rows, expected %d" % (fc.name, a.shape[0], staged.n))
+            cols.append(_ids_from_column(a, fc, fc.name in self.mask_feat_list, dev))
+        real = [c for c in cols if c is not None]
+        if cols:
+            use32 = _fit_int32(real)
+            mat = torch.zeros(len(cols), staged.n, dtype=torch.int32 if use32 else torch.int64, device=dev)
+            host_rows = [i for i, c in enumerate(cols) if c is not None and not isinstance(c, torch.Tensor)]
+            if host_rows:
+                host = np.stack([cols[i].astype(np.int32 if use32 else np.int64, copy=False) for i in host_rows])
+                mat[torch.as_tensor(host_rows, device=dev)] = torch.from_numpy(host).to(dev)
+            for i, c in enumerate(cols):
+                if isinstance(c, torch.Tensor):
+                    mat[i] = c.to(mat.dtype)
+            staged.ids = mat
+        if self.dense_cols:
+            parts = []
+            on_device = any(fc.transform_fn is not None for fc in self.dense_cols)
+            for fc in self.dense_cols:
+                a = _column(x, fc.name).astype(np.float32, copy=False).reshape(staged.n, -1)
+                if a.shape[1] != fc.dimension:
+                    raise ValueError("dense feature %r: expected dimension %d, got %d" % (fc.name, fc.dimension, a.shape[1]))
+                if on_device:
+                    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                    if fc.transform_fn is not None:
+                        t = fc.transform_fn(t).to(torch.float32).reshape(staged.n, -1)
+                    parts.append(t)
+                else:
+                    parts.append(a)
+            staged.dense = torch.cat(parts, dim=1).contiguous() if on_device else \
+                torch.from_numpy(np.ascontiguousarray(np.concatenate(parts, axis=1))).to(dev)
+        for fc in self.varlen_features():
+            self.stage_varlen(x, staged, fc)
+
+    def stage_varlen(self, x, staged, fc):
+        dev = self.device
+        if fc.name not in staged.seq:
+            a = _column(x, fc.name).reshape(staged.n, -1)
+            if a.shape[1] != fc.maxlen:
+                raise ValueError("sequence feature %r: expected maxlen %d, got %d" % (fc.name, fc.maxlen, a.shape[1]))
+            ids = _ids_from_column(a, fc, True, dev)
+            if not isinstance(ids, torch.Tensor):
+                ids = torch.from_numpy(np.ascontiguousarray(ids.astype(np.int32 if _fit_int32([ids]) else np.int64))).to(dev)
+            staged.seq[fc.name] = ids.contiguous()
+        if fc.length_name is not None and fc.length_name not in staged.length:
+            staged.length[fc.length_name] = torch.from_numpy(
+                np.ascontiguousarray(_column(x, fc.length_name).reshape(-1).astype(np.int32))).to(dev)
+        if fc.weight_name is not None and fc.weight_name not in staged.weight:
+            w = _column(x, fc.weight_name).astype(np.float32).reshape(staged.n, -1)
+            staged.weight[fc.weight_name] = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
+
+    # -- execution ---------------------------------------------------------------------------------
+    def workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        dev = self.device
+        ws = {"B": B}
+        ws["dnn_in"] = torch.zeros(B, self.out_stride, dtype=torch.float32, device=dev)
+        ws["fm"] = torch.zeros(B, dtype=torch.float32, device=dev)
+        ws["lin"] = torch.zeros(B, dtype=torch.float32, device=dev)
+        ws["status"] = ops.new_status(dev)
+        ws["pooled"], ws["pooled_lin"] = {}, {}
+        for f in self.pooled_fields:
+            ws["pooled"][f.fc.name] = torch.zeros(B, f.dim, dtype=torch.float32, device=dev)
+            if f.lin_table is not None:
+                ws["pooled_lin"][f.fc.name] = torch.zeros(B, dtype=torch.float32, device=dev)
+        fields = []
+        for f in self.fields:
+            if f.kind == "sparse":
+                fields.append(dict(table=f.table, lin_table=f.lin_table, vocab=f.table.shape[0], dim=f.dim,
+                                   out_offset=f.out_offset, in_fm=f.in_fm, hash_mode=f.hash_mode))
+            else:
+                fields.append(dict(table=ws["pooled"][f.fc.name], lin_table=ws["pooled_lin"].get(f.fc.name), vocab=B,
+                                   dim=f.dim, out_offset=f.out_offset, in_fm=f.in_fm, identity=True))
+        ws["desc"] = ops.make_field_descriptors(fields, dev) if fields else None
+        if self.lin_only:
+            ws["lin2"] = torch.zeros(B, dtype=torch.float32, device=dev)
+            ws["lin2_pool"] = {fc.name: torch.zeros(B, 1, dtype=torch.float32, device=dev)
+                               for fc in self.lin_only if isinstance(fc, VarLenSparseFeat)}
+            f2 = []
+            for fc in self.lin_only:
+                lt = self.linear_tables[fc.embedding_name].embeddings
+                if isinstance(fc, SparseFeat):
+                    hm = (2 if fc.name in self.mask_feat_list else 1) if (fc.use_hash and not prehashed_on_host(fc)) else 0
+                    f2.append(dict(table=lt, lin_table=lt.reshape(-1), vocab=lt.shape[0], dim=1, hash_mode=hm))
+                else:
+                    buf = ws["lin2_pool"][fc.name]
+                    f2.append(dict(table=buf, lin_table=buf.reshape(-1), vocab=B, dim=1, identity=True))
+            ws["desc2"] = ops.make_field_descriptors(f2, dev)
+            ws["n_fields2"] = len(f2)
+            ws["any_hash2"] = any(d.get("hash_mode", 0) for d in f2)
+        if len(self._ws) > 8:
+            self._ws.clear()
+        self._ws[B] = ws
+        return ws
+
+    def refresh(self, linear_kernel):
+        """Per predict() call: Linear.kernel rows permuted into dense-matrix column order."""
+        self.dense_lin_w = None
+        if self.n_dense and self.n_lin_dense and linear_kernel is not None:
+            rows = torch.as_tensor(self.dense_lin_rows, device=self.device)
+            k = linear_kernel.reshape(-1)
+            w = torch.zeros(self.n_dense, dtype=torch.float32, device=self.device)
+            sel = rows >= 0
+            w[sel] = k[rows[sel]]
+            self.dense_lin_w = w
+
+    def _pool(self, fc, staged, lo, hi, table, lin_table, out, lin_out, status):
+        ids = staged.seq[fc.name][lo:hi]
+        length = staged.length[fc.length_name][lo:hi] if fc.length_name is not None else None
+        weight = staged.weight[fc.weight_name][lo:hi] if fc.weight_name is not None else None
+        hm = 2 if (fc.use_hash and not prehashed_on_host(fc)) else 0
+        ops.embed_pool(ids, table, fc.combiner, length=length, weight=weight, weight_norm=fc.weight_norm,
+                       lin_table=lin_table, hash_mode=hm, out=out, out_stride=out.stride(0), lin_out=lin_out, status=status)
+
+    def run(self, staged, lo, hi):
+        """Launch the pooling kernels and the fused gather for rows [lo, hi).  Returns the workspace dict:
+        'dnn_in' [B, out_stride], 'lin' [B] (None-equivalent when the model has no linear part), 'fm' [B]."""
+        B = hi - lo
+        ws = self.workspace(B)
+        st = ws["status"]
+        for f in self.pooled_fields:
+            self._pool(f.fc, staged, lo, hi, f.table, f.lin_table.reshape(-1) if f.lin_table is not None else None,
+                       ws["pooled"][f.fc.name], ws["pooled_lin"].get(f.fc.name), st)
+        nf = len(self.fields)
+        ids = staged.ids[:, lo:hi] if staged.ids is not None else None
+        dense = staged.dense[lo:hi] if staged.dense is not None else None
+        ops.embed_gather_fm(ws["desc"], nf, ids, staged.ids.stride(0) if ids is not None else 0, 1, B, self.max_dim,
+                            self.all_dim4, self.any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
+                            dense_out_offset=self.dense_offset if self.n_dense_dnn else -1, dense_copy_cols=self.n_dense_dnn,
+                            dnn_in=ws["dnn_in"], out_stride=self.out_stride,
+                            fm_logit=ws["fm"] if self.fm_group_names else None,
+                            lin_logit=ws["lin"] if self.has_linear else None, status=st)
+        ws["fm_extra"] = []
+        for g in self.fm_group_names[1:]:       # further FM groups read their slice of dnn_in in place
+            first, n, dim = self.group_slices[g]
+            ws["fm_extra"].append(ops.fm_strided(ws["dnn_in"], first, n, dim))
+        if self.lin_only:
+            for fc in self.lin_only:
+                if isinstance(fc, VarLenSparseFeat):
+                    lt = self.linear_tables[fc.embedding_name].embeddings
+                    self._pool(fc, staged, lo, hi, lt, None, ws["lin2_pool"][fc.name], None, st)
+            ids2 = staged.ids[nf:, lo:hi]
+            ops.embed_gather_fm(ws["desc2"], ws["n_fields2"], ids2, staged.ids.stride(0), 1, B, 1, False, ws["any_hash2"],
+                                lin_logit=ws["lin2"], status=st)
+        return ws
+
+
+# ---------------------------------------------------------------------------------------------------
+# Model
+# ---------------------------------------------------------------------------------------------------
+# keras layer names of BatchNormalization layers that live inside Dice -> this build's Dice layer names
+def _alias(name):
+    if name.startswith("batch_normalization"):
+        return "dice" + name[len("batch_normalization"):]
+    return name
+
+
+class Model(object):
+    """Forward-only (HIP) model with the tf.keras.Model surface DeepCTR users call.  Subclasses set up
+    ``self.inputs`` (OrderedDict name -> InputSpec, reference order), register layers with ``_add`` and
+    implement ``_stage_inputs(x, staged)`` and ``_forward(staged, lo, hi, out)``."""
+
+    def __init__(self, name, feature_columns, device=None, task="binary"):
+        self.name = name
+        self.device = torch.device(device) if device is not None else default_device()
+        self.inputs = build_input_features(feature_columns)
+        self.input_names = list(self.inputs.keys())
+        self.layers_by_name = OrderedDict()
+        self.task = task
+        self._compiled = None
+        self.stop_training = False
+
+    # -- layers / weights ------------------------------------------------------------------------------
+    def _add(self, layer):
+        if layer.name in self.layers_by_name:
+            raise ValueError("duplicate layer name %r" % layer.name)
+        self.layers_by_name[layer.name] = layer
+        return layer
+
+    @property
+    def layers(self):
+        return list(self.layers_by_name.values())
+
+    def get_layer(self, name=None, index=None):
+        if name is not None:
+            for layer in self._all_layers():
+                if layer.name == name:
+                    return layer
+            raise ValueError("No such layer: %s" % name)
+        return self.layers[index]
+
+    def _all_layers(self):
+        out = []
+
+        def walk(layer):
+            out.append(layer)
+            for s in layer._sublayers:
+                walk(s)
+        for layer in self.layers:
+            walk(layer)
+        return out
+
+    def named_weights(self):
+        out = []
+        for layer in self.layers:
+            out.extend(layer.named_weights())
+        return out
+
+    @property
+    def weights(self):
+        return [t for _, t in self.named_weights()]
+
+    def get_weights(self):
+        return [t.detach().cpu().numpy() for _, t in self.named_weights()]
+
+    def set_weights(self, values):
+        ws = self.named_weights()
+        if len(values) != len(ws):
+            raise ValueError("model expects %d weight arrays, got %d" % (len(ws), len(values)))
+        self.set_weights_by_name({n: v for (n, _), v in zip(ws, values)})
+
+    def get_weights_by_name(self):
+        return OrderedDict((n, t.detach().cpu().numpy()) for n, t in self.named_weights())
+
+    def set_weights_by_name(self, mapping, strict=True):
+        """Load weights keyed "<keras layer name>/<weight name>" (the reference's layer names, e.g.
+        ``sparse_emb_C1/embeddings``, ``linear0sparse_emb_C1/embeddings``, ``dnn/kernel0``, ``dense/kernel``,
+        ``cin/filter0``, ``prediction_layer/global_bias``).  BatchNormalization statistics of Dice are accepted
+        under their keras names (``batch_normalization/moving_mean``)."""
+        mine = OrderedDict(self.named_weights())
+        seen = set()
+        for key, val in mapping.items():
+            lname, wname = key.rsplit("/", 1)
+            k2 = "%s/%s" % (_alias(lname), wname)
+            if k2 not in mine:
+                if strict and not (lname.startswith("linearsparse_")):   # dangling tables the reference never uses
+                    raise KeyError("no weight named %r in model %s" % (key, self.name))
+                continue
+            t = mine[k2]
+            v = np.asarray(val, dtype=np.float32)
+            if tuple(v.shape) != tuple(t.shape):
+                raise ValueError("weight %s: shape %s does not match %s" % (key, v.shape, tuple(t.shape)))
+            with torch.no_grad():
+                t.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+            seen.add(k2)
+        if strict:
+            missing = [k for k in mine if k not in seen]
+            if missing:
+                raise KeyError("weights missing from the mapping: %s" % missing[:8])
+
+    def save_weights(self, filepath, overwrite=True):
+        path = filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz"
+        np.savez(path, **{k.replace("/", "|"): v for k, v in self.get_weights_by_name().items()})
+
+    def load_weights(self, filepath):
+        path = filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz"
+        z = np.load(path)
+        self.set_weights_by_name({k.replace("|", "/"): z[k] for k in z.files})
+
+    def count_params(self):
+        return sum(int(t.numel()) for t in self.weights)
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s"' % self.name)
+        for layer in self._all_layers():
+            n = sum(int(t.numel()) for t in layer._weights.values())
+            print_fn("  %-40s %-28s %12d" % (layer.name, type(layer).__name__, n))
+        print_fn("Total params: %d" % self.count_params())
+
+    # -- inputs --------------------------------------------------------------------------------------
+    def _as_feed(self, x):
+        if isinstance(x, dict):
+            return x
+        if isinstance(x, (list, tuple)):
+            if len(x) != len(self.input_names):
+                raise ValueError("model %s expects %d input arrays (%s), got %d" % (self.name, len(self.input_names),
+                                                                                  self.input_names, len(x)))
+            return dict(zip(self.input_names, x))
+        raise TypeError("x must be a dict name -> array or a list in get_feature_names order")
+
+    def _num_rows(self, feed):
+        return int(np.asarray(feed[self.input_names[0]]).shape[0])
+
+    def stage(self, x):
+        """Copy every input column to the device once (the only host->device traffic of a predict call)."""
+        _C.require_device()
+        _C.lib()
+        feed = self._as_feed(x)
+        staged = Staged(self._num_rows(feed))
+        self._stage_inputs(feed, staged)
+        return staged
+
+    # -- inference -----------------------------------------------------------------------------------
+    def _begin(self):
+        """Hook: per-call refresh of weight-derived buffers."""
+
+    def predict(self, x, batch_size=256, verbose=0, **kwargs):
+        staged = self.stage(x)
+        out = torch.empty(staged.n, dtype=torch.float32, device=self.device)
+        self._begin()
+        bs = int(batch_size) if batch_size else staged.n
+        for lo in range(0, staged.n, bs):
+            hi = min(staged.n, lo + bs)
+            self._forward(staged, lo, hi, out[lo:hi])
+        self._check_status()
+        return out.cpu().numpy().reshape(-1, 1)
+
+    def predict_on_batch(self, x):
+        return self.predict(x, batch_size=None)
+
+    def __call__(self, x, training=False):
+        return torch.from_numpy(self.predict(x, batch_size=None))
+
+    def _check_status(self):
+        pass
+
+    # -- training surface ----------------------------------------------------------------------------
+    def compile(self, optimizer="adam", loss=None, metrics=None, **kwargs):
+        self._compiled = {"optimizer": optimizer, "loss": loss, "metrics": metrics or []}
+
+    def evaluate(self, x, y, batch_size=256, verbose=0, **kwargs):
+        p = self.predict(x, batch_size).reshape(-1).astype(np.float64)
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        loss_name = (self._compiled or {}).get("loss") or ("binary_crossentropy" if self.task == "binary" else "mse")
+        if loss_name in ("binary_crossentropy", "logloss"):
+            eps = 1e-7
+            pc = np.clip(p, eps, 1 - eps)
+            loss = float(-(y * np.log(pc) + (1 - y) * np.log(1 - pc)).mean())
+        else:
+            loss = float(((p - y) ** 2).mean())
+        return loss
+
+    def fit(self, x=None, y=None, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, **kwargs):
+        from .training import fit_model
+        return fit_model(self, x, y, batch_size=batch_size, epochs=epochs, verbose=verbose,
+                         validation_split=validation_split, shuffle=shuffle, **kwargs)
+
+    def train_on_batch(self, x, y, **kwargs):
+        from .training import fit_model
+        h = fit_model(self, x, y, batch_size=None, epochs=1, verbose=0, shuffle=False)
+        return h.history["loss"][-1]

@@ -1,0 +1,76 @@
+"""DCN — same signature as ``deepctr.models.dcn.DCN`` (reference deepctr/models/dcn.py:22-78).
+Launches per batch: fused gather (+ linear logit) -> CrossNet kernel and DNN kernel writing the two halves
+of one [B, d + hidden] buffer (the reference's Concatenate) -> head kernel (Dense(1) + linear logit +
+global bias + sigmoid)."""
+import torch
+
+from .. import ops
+from ..engine import EmbeddingStage
+from ..layers.base import name_scope
+from ..layers.core import DNN, Dense, PredictionLayer
+from ..layers.interaction import CrossNet
+from ._common import FeatureModel
+
+
+class _DCN(FeatureModel):
+    def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units,
+                 seed, dnn_dropout, dnn_use_bn, dnn_activation, task, device):
+        super(_DCN, self).__init__("DCN", list(dnn_feature_columns), device, task)
+        with name_scope():
+            self.build_linear(linear_feature_columns, seed)
+            self.build_embeddings(dnn_feature_columns, seed)
+            self.stage_plan = EmbeddingStage(self.tables, self.linear_tables, linear_feature_columns,
+                                             dnn_feature_columns, device=self.device)
+            d = self.stage_plan.in_dim
+            self.dnn = self.cross = None
+            width = 0
+            if len(dnn_hidden_units) > 0:
+                self.dnn = self._add(DNN(dnn_hidden_units, dnn_activation, 0, dnn_dropout, dnn_use_bn, seed=seed,
+                                         device=self.device).build_for(d))
+                width += dnn_hidden_units[-1]
+            if cross_num > 0:
+                self.cross = self._add(CrossNet(cross_num, parameterization=cross_parameterization,
+                                                device=self.device).build_for(d))
+                width += d
+            self.width = width
+            self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(width))
+            self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
+        self._stack = {}
+
+    def _begin(self):
+        super(_DCN, self)._begin()
+        self._cross_packed = self.cross.packed() if self.cross is not None else None
+
+    def _forward(self, staged, lo, hi, out):
+        ws = self.stage_plan.run(staged, lo, hi)
+        B = hi - lo
+        d = self.stage_plan.in_dim
+        stack = self._stack.get(B)
+        if stack is None:
+            stack = self._stack[B] = torch.zeros(B, (self.width + 3) // 4 * 4, dtype=torch.float32, device=self.device)
+        col = 0
+        if self.cross is not None:          # stack_out = Concatenate()([cross_out, deep_out])  (dcn.py:61)
+            ks, bs = self._cross_packed
+            import ctypes
+            from .. import _C
+            mode = _C.CROSS_VECTOR if self.cross.parameterization == "vector" else _C.CROSS_MATRIX
+            _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(ws["dnn_in"].data_ptr()), B, d, ws["dnn_in"].stride(0),
+                                                ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()),
+                                                self.cross.layer_num, mode, ctypes.c_void_p(stack.data_ptr()),
+                                                stack.stride(0), _C.stream_ptr()), "dctr_crossnet_fwd")
+            col = d
+        if self.dnn is not None:
+            ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+                    in_dim=d, out=stack[:, col:])
+        ops.mlp(stack, [], [], "linear", head_w=self.dense.w('kernel'), add=self._logits_to_add(ws),
+                global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=self.width, out=out)
+
+
+def DCN(linear_feature_columns, dnn_feature_columns, cross_num=2, cross_parameterization='vector',
+        dnn_hidden_units=(256, 128, 64), l2_reg_linear=1e-5, l2_reg_embedding=1e-5, l2_reg_cross=1e-5, l2_reg_dnn=0,
+        seed=1024, dnn_dropout=0, dnn_use_bn=False, dnn_activation='relu', task='binary', device=None):
+    """Instantiates the Deep&Cross Network architecture on the MI355X forward path."""
+    if len(dnn_hidden_units) == 0 and cross_num == 0:
+        raise ValueError("Either hidden_layer or cross layer must > 0")
+    return _DCN(linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units, seed,
+                dnn_dropout, dnn_use_bn, dnn_activation, task, device)

@@ -1,0 +1,48 @@
+"""DeepFM — same signature as ``deepctr.models.deepfm.DeepFM`` (reference deepctr/models/deepfm.py:22-65).
+
+Per batch the reference graph runs 2x26 Embedding gathers, Concat/Flatten, FM's reductions, Linear, three
+Dense+ReLU, Dense(1), Add and the PredictionLayer as separate TF kernels; here it is TWO launches:
+``dctr_embed_gather_fm`` (ids -> DNN input + linear logit + FM logit) and ``dctr_mlp_fwd`` (all DNN layers +
+Dense(1) head + logit sum + global bias + sigmoid)."""
+from ..engine import EmbeddingStage
+from ..feature_column import DEFAULT_GROUP_NAME
+from ..layers.base import name_scope
+from ..layers.core import DNN, Dense, PredictionLayer
+from .. import ops
+from ._common import FeatureModel
+
+
+class _DeepFM(FeatureModel):
+    def __init__(self, linear_feature_columns, dnn_feature_columns, fm_group, dnn_hidden_units, seed, dnn_dropout,
+                 dnn_activation, dnn_use_bn, task, device):
+        super(_DeepFM, self).__init__("DeepFM", list(linear_feature_columns) + list(dnn_feature_columns), device, task)
+        with name_scope():
+            self.build_linear(linear_feature_columns, seed)
+            self.build_embeddings(dnn_feature_columns, seed)
+            self.stage_plan = EmbeddingStage(self.tables, self.linear_tables, linear_feature_columns,
+                                             dnn_feature_columns, fm_groups=tuple(fm_group), device=self.device)
+            self.dnn = self._add(DNN(dnn_hidden_units, dnn_activation, 0, dnn_dropout, dnn_use_bn, seed=seed,
+                                     device=self.device).build_for(self.stage_plan.in_dim))
+            last = dnn_hidden_units[-1] if len(dnn_hidden_units) else self.stage_plan.in_dim
+            self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(last))
+            self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
+
+    def _forward(self, staged, lo, hi, out):
+        ws = self.stage_plan.run(staged, lo, hi)
+        add = self._logits_to_add(ws)
+        if self.stage_plan.fm_group_names:
+            add.append(ws["fm"])
+            add.extend(ws["fm_extra"])
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+                head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
+                sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out)
+
+
+def DeepFM(linear_feature_columns, dnn_feature_columns, fm_group=(DEFAULT_GROUP_NAME,), dnn_hidden_units=(256, 128, 64),
+           l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_dnn=0, seed=1024, dnn_dropout=0,
+           dnn_activation='relu', dnn_use_bn=False, task='binary', device=None):
+    """Instantiates the DeepFM architecture on the MI355X forward path.
+
+    Arguments are those of the reference constructor; the l2_* regularisers only matter to training losses."""
+    return _DeepFM(linear_feature_columns, dnn_feature_columns, fm_group, dnn_hidden_units, seed, dnn_dropout,
+                   dnn_activation, dnn_use_bn, task, device)

@@ -1,0 +1,66 @@
+"""xDeepFM — same signature as ``deepctr.models.xdeepfm.xDeepFM`` (reference deepctr/models/xdeepfm.py:18-70).
+Launches per batch: fused gather (+ linear logit) -> CIN kernel (all layers, f32 MFMA, reads the embedding
+part of the DNN input in place) -> Dense(1) on the CIN maps -> DNN kernel with the fused head."""
+import torch
+
+from .. import ops
+from ..engine import EmbeddingStage
+from ..layers.base import name_scope
+from ..layers.core import DNN, Dense, PredictionLayer
+from ..layers.interaction import CIN
+from ._common import FeatureModel
+
+
+class _xDeepFM(FeatureModel):
+    def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units, cin_layer_size, cin_split_half,
+                 cin_activation, seed, dnn_dropout, dnn_activation, dnn_use_bn, task, device):
+        super(_xDeepFM, self).__init__("xDeepFM", list(linear_feature_columns) + list(dnn_feature_columns), device, task)
+        with name_scope():
+            self.build_linear(linear_feature_columns, seed)
+            self.build_embeddings(dnn_feature_columns, seed)
+            self.stage_plan = EmbeddingStage(self.tables, self.linear_tables, linear_feature_columns,
+                                             dnn_feature_columns, device=self.device)
+            sp = self.stage_plan
+            self.dnn = self._add(DNN(dnn_hidden_units, dnn_activation, 0, dnn_dropout, dnn_use_bn, seed=seed,
+                                     device=self.device).build_for(sp.in_dim))
+            last = dnn_hidden_units[-1] if len(dnn_hidden_units) else sp.in_dim
+            self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(last))
+            self.cin = None
+            if len(cin_layer_size) > 0:
+                dims = set(f.dim for f in sp.fields)
+                if len(dims) != 1:
+                    raise ValueError("CIN needs one embedding_dim for every sparse / sequence feature, got %s" % sorted(dims))
+                self.cin_dim = dims.pop()
+                self.cin = self._add(CIN(cin_layer_size, cin_activation, cin_split_half, 0, seed,
+                                         device=self.device).build_for(len(sp.fields)))
+                self.cin_out_dim = ops.cin_output_dim(list(cin_layer_size), cin_split_half)
+                self.dense_1 = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(self.cin_out_dim))
+            self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
+        self._buf = {}
+
+    def _forward(self, staged, lo, hi, out):
+        ws = self.stage_plan.run(staged, lo, hi)
+        B = hi - lo
+        add = self._logits_to_add(ws)
+        if self.cin is not None:
+            bufs = self._buf.get(B)
+            if bufs is None:
+                bufs = self._buf[B] = (torch.zeros(B, self.cin_out_dim, dtype=torch.float32, device=self.device),
+                                       torch.zeros(B, dtype=torch.float32, device=self.device))
+            maps, logit = bufs
+            ops.cin(ws["dnn_in"], [f.reshape(-1, f.shape[-1]) for f in self.cin.filters], self.cin.biases,
+                    list(self.cin.layer_size), self.cin.split_half, self.cin.activation, fields=len(self.stage_plan.fields),
+                    dim=self.cin_dim, out=maps)
+            ops.mlp(maps, [], [], "linear", head_w=self.dense_1.w('kernel'), in_dim=self.cin_out_dim, out=logit)
+            add.append(logit)
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+                head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
+                sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out)
+
+
+def xDeepFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 128, 64), cin_layer_size=(128, 128,),
+            cin_split_half=True, cin_activation='relu', l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_dnn=0,
+            l2_reg_cin=0, seed=1024, dnn_dropout=0, dnn_activation='relu', dnn_use_bn=False, task='binary', device=None):
+    """Instantiates the xDeepFM architecture on the MI355X forward path."""
+    return _xDeepFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units, cin_layer_size, cin_split_half,
+                    cin_activation, seed, dnn_dropout, dnn_activation, dnn_use_bn, task, device)

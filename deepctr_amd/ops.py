@@ -165,6 +165,20 @@ def embed_pool(idx, table, combiner="mean", length=None, weight=None, weight_nor
     return out, lin_out
 
 
+def seq_weight(seq, weight, mask=None, length=None, weight_norm=True):
+    """WeightedSequenceLayer.call on a materialised [B,T,E] tensor (reference sequence.py:155-183)."""
+    _dev_check(seq, weight, mask, length)
+    seq = _f32c(seq, "seq")
+    B, T, E = seq.shape
+    weight = _f32c(weight, "weight").reshape(B, T)
+    m = None if mask is None else mask.to(torch.uint8).reshape(B, T).contiguous()
+    ln = None if length is None else length.reshape(-1).to(torch.int32).contiguous()
+    out = torch.empty_like(seq)
+    _C.check(_C.lib().dctr_seq_weight_fwd(_ptr(seq), _ptr(weight), _ptr(m), _ptr(ln), B, T, E, int(bool(weight_norm)),
+                                          _ptr(out), _C.stream_ptr()), "dctr_seq_weight_fwd")
+    return out
+
+
 def make_field_descriptors(fields, device):
     """fields: list of dicts(table, lin_table, vocab, dim, out_offset, in_fm, hash_mode, identity) ->
     uint8 device tensor holding the dctr_field_t array (kept alive by the caller)."""
@@ -182,7 +196,7 @@ def make_field_descriptors(fields, device):
 
 
 def embed_gather_fm(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
-                    dense=None, dense_lin_w=None, dense_out_offset=-1, dnn_in=None, out_stride=0, fm_logit=None,
+                    dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0, fm_logit=None,
                     lin_logit=None, status=None):
     """Fused multi-table gather + concat + linear term + FM (see include/dctr.h).  Low-level: the caller
     (the model plan) owns descriptor and output buffers."""
@@ -201,7 +215,8 @@ def embed_gather_fm(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_
                         dense=None if dense is None else dense.data_ptr(),
                         dense_stride=0 if dense is None else dense.stride(0),
                         dense_lin_w=None if dense_lin_w is None else dense_lin_w.data_ptr(),
-                        dense_out_offset=dense_out_offset, batch=batch,
+                        dense_out_offset=dense_out_offset,
+                        dense_copy_cols=n_dense if dense_copy_cols is None else dense_copy_cols, batch=batch,
                         dnn_in=None if dnn_in is None else dnn_in.data_ptr(), out_stride=out_stride,
                         fm_logit=None if fm_logit is None else fm_logit.data_ptr(),
                         lin_logit=None if lin_logit is None else lin_logit.data_ptr(),

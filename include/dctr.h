@@ -46,6 +46,11 @@ int dctr_abi_version(void);
 const char* dctr_last_error(void);
 /* name of the gfx target the kernels were compiled for ("gfx950") */
 const char* dctr_target_arch(void);
+/* Measurement aid (bench.py): arm a probe for the NEXT kernel launched by this host thread; the launch then
+ * carries a start/stop event pair (hipExtLaunchKernelGGL), so dctr_profile_last_ms() returns the duration of
+ * that one dispatch as the GPU timestamps it (same quantity as rocprofv3 --kernel-trace), or -1 if none. */
+int dctr_profile_next_launch(void);
+float dctr_profile_last_ms(void);
 
 /* ------------------------------------------------------------------------------------------------
  * a2  Hash.call — deepctr/layers/utils.py:89-112
@@ -97,7 +102,8 @@ typedef struct {
     int64_t dense_stride;
     const float* dense_lin_w;     /* DEVICE [n_dense] = Linear.kernel (layers/utils.py:150-158) or NULL */
     int32_t dense_out_offset;     /* first dense column inside a dnn_in row; <0: not copied             */
-    int32_t pad_;
+    int32_t dense_copy_cols;      /* leading dense columns copied into dnn_in (the rest only feed the linear
+                                     term: DenseFeat present in linear_feature_columns only); <= n_dense   */
     int64_t batch;
     float* dnn_in;                /* [B, out_stride] or NULL                                            */
     int64_t out_stride;           /* elements; % 4 == 0 when all_dim4                                   */
@@ -136,6 +142,12 @@ typedef struct {
 } dctr_pool_args_t;
 
 int dctr_embed_pool(const dctr_pool_args_t* args, void* stream);
+
+/* stand-alone WeightedSequenceLayer.call (layers/sequence.py:155-183) on a materialised seq [B,T,dim]:
+ * out = seq * w, w = weight masked by `mask` [B,T] bytes or `length` [B] (0 outside; softmax over T of the
+ * -2^32+1 padded weights when weight_norm). */
+int dctr_seq_weight_fwd(const float* seq, const float* weight, const uint8_t* mask, const int32_t* length,
+                        int64_t batch, int32_t maxlen, int32_t dim, int32_t weight_norm, float* out, void* stream);
 
 /* plain per-position lookup [B,T] -> [B,T,dim] (+ mask byte per position), used for DIN keys
  * (deepctr/models/sequence/din.py:68-69) and by the eager `embedding_lookup` API. */

@@ -26,7 +26,7 @@ def make_args(idx, dense, dnn_in, fm, ll):
     B = idx.shape[1]
     return _C.GatherFmArgs(fields=fdev.data_ptr(), ids=idx.data_ptr(), ids_stride_f=B, ids_stride_b=1, ids_is_i64=0, n_fields=F,
                            max_dim=E, all_dim4=1, any_hash=0, n_dense=ND, dense=dense.data_ptr(), dense_stride=ND,
-                           dense_lin_w=linw.data_ptr(), dense_out_offset=F * E, batch=B, dnn_in=dnn_in.data_ptr(),
+                           dense_lin_w=linw.data_ptr(), dense_out_offset=F * E, dense_copy_cols=ND, batch=B, dnn_in=dnn_in.data_ptr(),
                            out_stride=stride, fm_logit=fm.data_ptr(), lin_logit=ll.data_ptr(), status=status.data_ptr())
 
 # parity at B=4096 (+ ragged B)

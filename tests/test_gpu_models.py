@@ -1,0 +1,183 @@
+"""GPU parity tests, model level: deepctr_amd.models.{DeepFM,DCN,xDeepFM,DIN}.predict against the golden
+fixtures produced by the reference's own constructors (oracle/make_golden.py) and against the NumPy model
+oracle on larger seeded inputs.  Bar: probabilities and (unsaturated) logits within 1e-4 relative."""
+import numpy as np
+import pytest
+
+from oracle import ref_models as RM
+from tests.spec import columns_from_spec
+from tests.test_oracle_golden import MODEL_FIXTURES
+from tests.util import assert_close, golden_meta, load_golden, sigmoid_inv
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(meta, device):
+    from deepctr_amd.models import DCN, DIN, DeepFM, xDeepFM
+    dnn_cols = columns_from_spec(meta["dnn"])
+    lin_cols = columns_from_spec(meta["linear"])
+    kw = dict(meta["kwargs"])
+    name = meta["model"]
+    if name == "DIN":
+        return DIN(dnn_cols, meta["extra_args"][0], device=device, **kw)
+    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM}[name]
+    return ctor(lin_cols, dnn_cols, device=device, **kw)
+
+
+def well_conditioned_rows(meta, feed, n):
+    """The reference's max-pooling of an all-padding sequence yields emb - 1e9 (layers/sequence.py:96-98; reproduced
+    and tested at op level).  Fed to FM, (sum e)^2 - sum e^2 then cancels at the 1e18 scale and the logit is rounding
+    noise of either sign in ANY fp32 implementation, so those rows are excluded from FM-model comparisons."""
+    ok = np.ones(n, dtype=bool)
+    if meta["model"] != "DeepFM":
+        return ok
+    for d in meta["dnn"]:
+        if d["type"] == "varlen" and d.get("combiner") == "max":
+            if d.get("length_name"):
+                ok &= np.asarray(feed[d["length_name"]]).reshape(-1) > 0
+            else:
+                ok &= (np.asarray(feed[d["sparsefeat"]["name"]]).reshape(n, -1) != 0).any(axis=1)
+    return ok
+
+
+def check_probs(y, ref, what, rows=None):
+    assert y.shape == ref.shape and y.dtype == np.float32
+    if rows is not None:
+        y, ref = y[rows], ref[rows]
+    assert_close(y, ref, rtol=1e-4, atol=1e-6, what=what + " prob")
+    ok = (ref > 1e-6) & (ref < 1 - 1e-6)
+    if ok.any():
+        assert_close(sigmoid_inv(y[ok]), sigmoid_inv(ref[ok]), rtol=1e-4, atol=2e-5, what=what + " logit")
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_model_matches_reference_code(device, name):
+    g = load_golden(name)
+    meta = golden_meta(g)
+    model = build_model(meta, device)
+    model.set_weights_by_name({k[2:]: v for k, v in g.items() if k.startswith("w/")})
+    feed = {k[5:]: v for k, v in g.items() if k.startswith("feed/")}
+    rows = well_conditioned_rows(meta, feed, g["y"].shape[0])
+    assert rows.sum() >= 0.8 * rows.size
+    for bs in (256, 5):
+        y = model.predict(feed, batch_size=bs)
+        check_probs(y, g["y"], "%s bs=%d" % (name, bs), rows)
+    # list-style input in get_feature_names order, as examples/run_classification_criteo.py does
+    y = model.predict([feed[n] for n in model.input_names], batch_size=64)
+    check_probs(y, g["y"], name + " list feed", rows)
+
+
+def _criteo_like(rng, n, F=26, V=1000, E=16, ND=13):
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    cols = [SparseFeat("C%d" % i, V, E) for i in range(1, F + 1)] + [DenseFeat("I%d" % i, 1) for i in range(1, ND + 1)]
+    feed = {"C%d" % i: rng.randint(0, V, n).astype(np.int32) for i in range(1, F + 1)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(1, ND + 1)})
+    return cols, feed
+
+
+def _randomise(model, rng):
+    ws = model.get_weights_by_name()
+    new = {}
+    for k, v in ws.items():
+        if k.endswith("embeddings"):
+            new[k] = rng.standard_normal(v.shape).astype(np.float32) * (0.1 if v.shape[-1] == 1 else 0.05)
+        elif "bias" in k:
+            new[k] = rng.standard_normal(v.shape).astype(np.float32) * 0.1
+        else:
+            std = v.std() if v.std() > 0 else 0.1
+            new[k] = rng.standard_normal(v.shape).astype(np.float32) * std
+    model.set_weights_by_name(new)
+    return new
+
+
+def test_deepfm_c2_shape_vs_oracle(device):
+    """BASELINE config 2 shape (26 sparse + 13 dense, E=16, batch 4096; vocabulary reduced to keep the oracle
+    fast), trained-like weights, float64 oracle."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(0)
+    cols, feed = _criteo_like(rng, 4096 + 37)
+    model = DeepFM(cols, cols, device=device)
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    ref = RM.deepfm(cols, cols, w, feed, dtype=np.float64)
+    check_probs(y, ref.astype(np.float32), "DeepFM C2")
+
+
+def test_xdeepfm_dcn_c3_shape_vs_oracle(device):
+    from deepctr_amd.models import DCN, xDeepFM
+    rng = np.random.RandomState(1)
+    cols, feed = _criteo_like(rng, 300)
+    model = xDeepFM(cols, cols, cin_layer_size=(128, 128), device=device)
+    w = _randomise(model, rng)
+    check_probs(model.predict(feed, batch_size=128), RM.xdeepfm(cols, cols, w, feed, cin_layer_size=(128, 128), dtype=np.float64).astype(np.float32),
+                "xDeepFM C3")
+    for par in ("vector", "matrix"):
+        model = DCN(cols, cols, cross_num=2, cross_parameterization=par, device=device)
+        w = _randomise(model, rng)
+        check_probs(model.predict(feed, batch_size=128),
+                    RM.dcn(cols, cols, w, feed, cross_num=2, cross_parameterization=par, dtype=np.float64).astype(np.float32), "DCN " + par)
+
+
+def test_din_c4_shape_vs_oracle(device):
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DIN
+    rng = np.random.RandomState(2)
+    n, T, E = 200, 50, 32
+    cols = [SparseFeat("user", 1000, E), SparseFeat("gender", 2, E), SparseFeat("item_id", 5001, E), SparseFeat("cate_id", 101, E),
+            DenseFeat("pay_score", 1),
+            VarLenSparseFeat(SparseFeat("hist_item_id", 5001, E, embedding_name="item_id"), maxlen=T),
+            VarLenSparseFeat(SparseFeat("hist_cate_id", 101, E, embedding_name="cate_id"), maxlen=T)]
+    lens = rng.randint(1, T + 1, n)
+    hi = rng.randint(1, 5001, (n, T)).astype(np.int32)
+    hc = rng.randint(1, 101, (n, T)).astype(np.int32)
+    pad = np.arange(T)[None, :] >= lens[:, None]
+    hi[pad] = 0
+    hc[pad] = 0
+    feed = {"user": rng.randint(0, 1000, n).astype(np.int32), "gender": rng.randint(0, 2, n).astype(np.int32),
+            "item_id": rng.randint(1, 5001, n).astype(np.int32), "cate_id": rng.randint(1, 101, n).astype(np.int32),
+            "pay_score": rng.rand(n).astype(np.float32), "hist_item_id": hi, "hist_cate_id": hc}
+    for act in ("dice", "sigmoid"):
+        model = DIN(cols, ["item_id", "cate_id"], att_activation=act, device=device)
+        w = _randomise(model, rng)
+        if act == "dice":
+            for k in list(w):
+                if k.endswith("moving_variance"):
+                    w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
+            model.set_weights_by_name(w)
+        # oracle speaks keras names for the BatchNormalization inside Dice
+        wk = {}
+        for k, v in w.items():
+            lname, wname = k.rsplit("/", 1)
+            if wname in ("moving_mean", "moving_variance"):
+                lname = "batch_normalization" + lname[len("dice"):]
+            wk["%s/%s" % (lname, wname)] = v
+        ref = RM.din(cols, ["item_id", "cate_id"], wk, feed, att_activation=act, dtype=np.float64)
+        check_probs(model.predict(feed, batch_size=64), ref.astype(np.float32), "DIN " + act)
+
+
+def test_out_of_range_index_raises(device):
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(3)
+    cols, feed = _criteo_like(rng, 64, V=50)
+    model = DeepFM(cols, cols, device=device)
+    feed["C3"][5] = 50
+    with pytest.raises(IndexError):
+        model.predict(feed, batch_size=32)
+
+
+def test_weights_roundtrip_and_layer_access(device, tmp_path):
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(4)
+    cols, feed = _criteo_like(rng, 50, V=30, E=4)
+    model = DeepFM(cols, cols, device=device)
+    _randomise(model, rng)
+    y0 = model.predict(feed)
+    model.save_weights(str(tmp_path / "w"))
+    other = DeepFM(cols, cols, device=device)
+    other.load_weights(str(tmp_path / "w"))
+    assert (other.predict(feed) == y0).all()
+    other2 = DeepFM(cols, cols, device=device)
+    other2.set_weights(model.get_weights())
+    assert (other2.predict(feed) == y0).all()
+    emb = model.get_layer("sparse_emb_C1").get_weights()[0]          # docs/source/FAQ.md:81-90
+    assert emb.shape == (30, 4)
