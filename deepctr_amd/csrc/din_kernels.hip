@@ -126,14 +126,34 @@ __global__ __launch_bounds__(256) void din_attn_kernel(DinParams p) {
     const int K0 = 4 * E;
     const int KP0 = dctr::pad16(K0);
     for (int c0 = 0; c0 < T; c0 += CHUNK) {
-        // att_input rows for positions c0 .. c0+63 (rows past T are zero)
+        // keys tile for positions c0 .. c0+63 -> buf1 (all global loads of a pass issued before the LDS stores),
+        // then att_input = [q, k, q-k, q*k] is formed LDS -> LDS (rows past T are zero)
+        {
+            constexpr int U = 8;
+            const int total = CHUNK * E;
+            for (int base = 0; base < total; base += 256 * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = base + u * 256 + threadIdx.x;
+                    const int r = i / E, e = i % E;
+                    v[u] = (i < total && c0 + r < T) ? kb[(int64_t)(c0 + r) * E + e] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = base + u * 256 + threadIdx.x;
+                    if (i < total) buf1[(i / E) * p.lda + (i % E)] = v[u];
+                }
+            }
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < CHUNK * KP0; i += 256) {
             const int r = i / KP0, c = i % KP0;
             const int t = c0 + r;
             float v = 0.f;
             if (t < T && c < K0) {
                 const int part = c / E, e = c % E;
-                const float q = qs[e], kv = kb[(int64_t)t * E + e];
+                const float q = qs[e], kv = buf1[r * p.lda + e];
                 v = part == 0 ? q : (part == 1 ? kv : (part == 2 ? q - kv : q * kv));
             }
             buf0[r * p.lda + c] = v;

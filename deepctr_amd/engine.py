@@ -506,16 +506,22 @@ class Model(object):
     def _begin(self):
         """Hook: per-call refresh of weight-derived buffers."""
 
-    def predict(self, x, batch_size=256, verbose=0, **kwargs):
+    def predict_tensor(self, x, batch_size=256):
+        """predict() that leaves the [N] result on the device (used by the distributed path)."""
         staged = self.stage(x)
         out = torch.empty(staged.n, dtype=torch.float32, device=self.device)
+        if staged.n == 0:
+            return out
         self._begin()
         bs = int(batch_size) if batch_size else staged.n
         for lo in range(0, staged.n, bs):
             hi = min(staged.n, lo + bs)
             self._forward(staged, lo, hi, out[lo:hi])
         self._check_status()
-        return out.cpu().numpy().reshape(-1, 1)
+        return out
+
+    def predict(self, x, batch_size=256, verbose=0, **kwargs):
+        return self.predict_tensor(x, batch_size).cpu().numpy().reshape(-1, 1)
 
     def predict_on_batch(self, x):
         return self.predict(x, batch_size=None)

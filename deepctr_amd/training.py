@@ -1,0 +1,267 @@
+"""``fit`` / ``train_on_batch`` — SURVEY.md §8(f) rank 1, "next" row; kept minimal in round 1.
+
+The forward path this repository is about is inference (``predict``) on hand-written HIP kernels.  Training
+needs gradients; until the HIP backward kernels exist (embedding-row scatter-add, FM/CIN/CrossNet grads) the
+training step uses PyTorch autograd over a differentiable restatement of the SAME forward, built from torch ops
+on the SAME device and the SAME weight tensors (so ``predict`` after ``fit`` runs the HIP kernels on the trained
+weights).  It exists so that the reference's ``compile → fit → predict`` workflow (tests/utils.py:356-381,
+examples/run_classification_criteo.py:44-50) works end to end; it is not a performance path and nothing in
+``predict`` ever routes through it.  Parity of this torch forward with the HIP forward is a GPU test
+(tests/test_gpu_fit.py).
+
+Sequence features, hashing and DIN attention are covered; dropout / l2 regularisers of the reference
+constructors are not applied (documented gap).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .engine import prehashed_on_host
+from .feature_column import SparseFeat, VarLenSparseFeat
+
+
+class History(object):
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+def _rows_for(fc, ids, mask_zero_hash):
+    if fc.use_hash and not prehashed_on_host(fc):
+        return ops.hash_bucket(ids.contiguous(), fc.vocabulary_size, mask_zero_hash)
+    return ids.to(torch.int64)
+
+
+def _pool(seq, fc, mask, length, weight):
+    """reference layers/sequence.py:76-106,155-183 in torch (differentiable)."""
+    B, T, E = seq.shape
+    if length is not None:
+        m = (torch.arange(T, device=seq.device)[None, :] < length.reshape(-1, 1))
+        cnt = length.reshape(-1, 1).to(seq.dtype)
+    else:
+        m = mask
+        cnt = m.sum(dim=1, keepdim=True).to(seq.dtype)
+    if weight is not None:
+        w = weight.reshape(B, T)
+        if fc.weight_norm:
+            w = torch.softmax(torch.where(m, w, torch.full_like(w, float(-2 ** 32 + 1))), dim=1)
+        else:
+            w = torch.where(m, w, torch.zeros_like(w))
+        seq = seq * w.unsqueeze(-1)
+    mf = m.to(seq.dtype).unsqueeze(-1)
+    if fc.combiner == "max":
+        return (seq - (1 - mf) * 1e9).max(dim=1).values
+    s = (seq * mf).sum(dim=1)
+    if fc.combiner == "mean":
+        s = s / (cnt + 1e-8)
+    return s
+
+
+def stage_forward(sp, staged, lo, hi):
+    """Differentiable EmbeddingStage: returns (dnn_in [B,in_dim], linear logit [B] or None, [FM logits])."""
+    B = hi - lo
+    dev = sp.device
+    embs, lin = [], torch.zeros(B, device=dev)
+    has_lin = False
+    for i, f in enumerate(sp.fields):
+        fc = f.fc
+        if f.kind == "sparse":
+            rows = _rows_for(fc, staged.ids[i, lo:hi], fc.name in sp.mask_feat_list)
+            e = f.table[rows]
+            if f.lin_table is not None:
+                lin = lin + f.lin_table.reshape(-1)[rows]
+                has_lin = True
+        else:
+            rows = _rows_for(fc, staged.seq[fc.name][lo:hi], True)
+            length = staged.length[fc.length_name][lo:hi] if fc.length_name is not None else None
+            weight = staged.weight[fc.weight_name][lo:hi] if fc.weight_name is not None else None
+            mask = rows != 0
+            e = _pool(f.table[rows], fc, mask, length, weight)
+            if f.lin_table is not None:
+                lin = lin + _pool(f.lin_table.reshape(-1)[rows].unsqueeze(-1), fc, mask, length, weight).reshape(-1)
+                has_lin = True
+        embs.append(e)
+    fms = []
+    for g in sp.fm_group_names:
+        first, n, dim = sp.group_slices[g]
+        idx = [k for k, f in enumerate(sp.fields) if first <= f.out_offset < first + n * dim]
+        x = torch.stack([embs[k] for k in idx], dim=1)
+        fms.append(0.5 * (x.sum(1).pow(2) - (x * x).sum(1)).sum(-1))
+    parts = list(embs)
+    extra = {}
+    for name, off in sp.extra_offsets.items():
+        extra[name] = len(parts)
+        parts.append(None)                       # filled by the caller (DIN attention output)
+    dense = staged.dense[lo:hi] if staged.dense is not None else None
+    if dense is not None:
+        if sp.n_dense_dnn:
+            parts.append(dense[:, :sp.n_dense_dnn])
+        if sp.dense_lin_w is not None:
+            lin = lin + dense @ sp.dense_lin_w
+            has_lin = True
+    nf = len(sp.fields)
+    for k, fc in enumerate(sp.lin_only):
+        lt = sp.linear_tables[fc.embedding_name].embeddings.reshape(-1)
+        if isinstance(fc, SparseFeat):
+            rows = _rows_for(fc, staged.ids[nf + k, lo:hi], fc.name in sp.mask_feat_list)
+            lin = lin + lt[rows]
+        else:
+            rows = _rows_for(fc, staged.seq[fc.name][lo:hi], True)
+            length = staged.length[fc.length_name][lo:hi] if fc.length_name is not None else None
+            weight = staged.weight[fc.weight_name][lo:hi] if fc.weight_name is not None else None
+            lin = lin + _pool(lt[rows].unsqueeze(-1), fc, rows != 0, length, weight).reshape(-1)
+        has_lin = True
+    return parts, extra, (lin if has_lin else None), fms
+
+
+def _act(name, x, dice=None):
+    if name in ("dice", "Dice"):
+        alpha, mean, var = dice
+        xp = torch.sigmoid((x - mean) / torch.sqrt(var + 1e-9))
+        return alpha * (1 - xp) * x + xp * x
+    return {"relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "linear": lambda v: v, None: lambda v: v}[name](x)
+
+
+def dnn_forward(dnn, x):
+    dice = dnn.dice_params()
+    for i, (w, b) in enumerate(zip(dnn.kernels, dnn.biases)):
+        x = _act(dnn.activation, x @ w + b, dice[i] if dice else None)
+    return x
+
+
+def model_logits(model, staged, lo, hi):
+    """Pre-sigmoid logits [B] of the four in-scope models, torch ops only."""
+    sp = model.stage_plan
+    parts, extra, lin, fms = stage_forward(sp, staged, lo, hi)
+    name = model.name
+    if name == "DIN":
+        q = torch.cat([parts[i] for i in model._query_rows], dim=-1)
+        keys, km = [], None
+        for fc in model.history_cols:
+            emb = model.tables[fc.embedding_name]
+            rows = _rows_for(fc, staged.seq[fc.name][lo:hi], True)
+            keys.append(emb.embeddings[rows])
+            if emb.mask_zero:
+                km = (rows != 0) if km is None else (km & (rows != 0))
+        k = torch.cat(keys, dim=-1)
+        if km is None:
+            km = torch.ones(k.shape[:2], dtype=torch.bool, device=k.device)
+        la = model.attention.local_att
+        qq = q.unsqueeze(1).expand(-1, k.shape[1], -1)
+        att = dnn_forward(la.dnn, torch.cat([qq, k, qq - k, qq * k], dim=-1))
+        score = (att @ la.w("kernel") + la.w("bias")).squeeze(-1)
+        if model.attention.weight_normalization:
+            score = torch.softmax(torch.where(km, score, torch.full_like(score, float(-2 ** 32 + 1))), dim=-1)
+        else:
+            score = torch.where(km, score, torch.zeros_like(score))
+        parts[extra["hist"]] = (score.unsqueeze(1) @ k).squeeze(1)
+    x = torch.cat(parts, dim=-1)
+    if name == "DCN":
+        outs = []
+        if model.cross is not None:
+            x0 = x
+            xl = x
+            for i in range(model.cross.layer_num):
+                w, b = model.cross.w("kernel%d" % i), model.cross.w("bias%d" % i).reshape(-1)
+                if model.cross.parameterization == "vector":
+                    xl = x0 * (xl @ w) + b + xl
+                else:
+                    xl = x0 * (xl @ w.t() + b) + xl
+            outs.append(xl)
+        if model.dnn is not None:
+            outs.append(dnn_forward(model.dnn, x))
+        logit = (torch.cat(outs, dim=-1) @ model.dense.w("kernel")).reshape(-1)
+    else:
+        logit = (dnn_forward(model.dnn, x) @ model.dense.w("kernel")).reshape(-1)
+    if name == "xDeepFM" and model.cin is not None:
+        x0 = torch.stack(parts[:len(sp.fields)], dim=1)             # [B,F,D]
+        hidden, finals = x0, []
+        n = len(model.cin.layer_size)
+        for i, (w, b) in enumerate(zip(model.cin.filters, model.cin.biases)):
+            z = torch.einsum("bid,bjd->bdij", x0, hidden).reshape(x0.shape[0], x0.shape[2], -1)
+            cur = _act(model.cin.activation, z @ w[0] + b).transpose(1, 2)
+            H = cur.shape[1]
+            if model.cin.split_half:
+                if i != n - 1:
+                    hidden, direct = cur[:, :H // 2], cur[:, H // 2:]
+                else:
+                    hidden, direct = None, cur
+            else:
+                hidden, direct = cur, cur
+            finals.append(direct)
+        logit = logit + (torch.cat(finals, dim=1).sum(-1) @ model.dense_1.w("kernel")).reshape(-1)
+    if lin is not None:
+        logit = logit + lin
+    for f in fms:
+        logit = logit + f
+    return logit + model.prediction.w("global_bias")
+
+
+_OPTS = {"adam": lambda p: torch.optim.Adam(p, lr=1e-3, eps=1e-7), "adagrad": lambda p: torch.optim.Adagrad(p, lr=1e-3, eps=1e-7,
+                                                                                                         initial_accumulator_value=0.1),
+         "sgd": lambda p: torch.optim.SGD(p, lr=1e-2), "rmsprop": lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.9, eps=1e-7)}
+
+
+def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, **kwargs):
+    from . import _C
+    _C.require_device()
+    if model._compiled is None:
+        raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+    feed = model._as_feed(x)
+    n = model._num_rows(feed)
+    y = np.asarray(y, dtype=np.float32).reshape(-1)
+    n_val = int(n * validation_split)
+    n_tr = n - n_val
+    tr = {k: np.asarray(v)[:n_tr] for k, v in feed.items()}
+    staged = model.stage(tr)
+    yt = torch.from_numpy(y[:n_tr]).to(model.device)
+    params = [t for name, t in model.named_weights() if "moving_" not in name]
+    for t in params:
+        t.requires_grad_(True)
+    opt = model._compiled["optimizer"]
+    if isinstance(opt, str):
+        if opt.lower() not in _OPTS:
+            raise ValueError("optimizer %r not supported (adam, adagrad, sgd, rmsprop or a torch.optim factory)" % opt)
+        opt = _OPTS[opt.lower()](params)
+    elif callable(opt):
+        opt = opt(params)
+    loss_name = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
+    hist = History()
+    hist.history["loss"] = []
+    bs = int(batch_size) if batch_size else n_tr
+    try:
+        for ep in range(epochs):
+            order = np.arange(0, n_tr, bs)
+            if shuffle:
+                np.random.shuffle(order)
+            tot, cnt = 0.0, 0
+            for lo in order:
+                hi = min(n_tr, lo + bs)
+                model._begin()
+                logit = model_logits(model, staged, int(lo), int(hi))
+                if loss_name in ("binary_crossentropy", "logloss") and model.task == "binary":
+                    loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt[lo:hi])
+                else:
+                    pred = torch.sigmoid(logit) if model.task == "binary" else logit
+                    loss = torch.nn.functional.mse_loss(pred, yt[lo:hi])
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                tot += float(loss.item()) * (hi - lo)
+                cnt += hi - lo
+            hist.history["loss"].append(tot / max(cnt, 1))
+            hist.epoch.append(ep)
+            if n_val:
+                va = {k: np.asarray(v)[n_tr:] for k, v in feed.items()}
+                for t in params:
+                    t.requires_grad_(False)
+                hist.history.setdefault("val_loss", []).append(model.evaluate(va, y[n_tr:], batch_size=bs))
+                for t in params:
+                    t.requires_grad_(True)
+            if verbose:
+                print("Epoch %d/%d - loss: %.4f%s" % (ep + 1, epochs, hist.history["loss"][-1],
+                                                      (" - val_loss: %.4f" % hist.history["val_loss"][-1]) if n_val else ""))
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+    return hist

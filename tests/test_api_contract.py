@@ -1,0 +1,145 @@
+"""CPU: the API contract the reference's own tests pin (tests/feature_test.py:25-60, tests/utils.py:38-105):
+feature-column semantics, shared-embedding naming / mask_zero rules, error text, model input order, weight names.
+No kernels run here (the forward path needs a GPU and says so)."""
+import numpy as np
+import pytest
+
+from deepctr_amd.feature_column import (DEFAULT_GROUP_NAME, DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features,
+                                        get_feature_names)
+from deepctr_amd.inputs import create_embedding_matrix
+from deepctr_amd.models import DCN, DIN, DeepFM, xDeepFM
+
+
+def test_sparsefeat_defaults_and_auto_dim():
+    sf = SparseFeat('user_id', 4)
+    assert (sf.embedding_dim, sf.use_hash, sf.dtype, sf.embedding_name, sf.group_name, sf.trainable) == \
+        (4, False, "int32", 'user_id', DEFAULT_GROUP_NAME, True)
+    assert (sf.embeddings_initializer.mean, sf.embeddings_initializer.stddev, sf.embeddings_initializer.seed) == (0.0, 0.0001, 2020)
+    assert SparseFeat('x', 10000, embedding_dim="auto").embedding_dim == 6 * int(pow(10000, 0.25))
+    assert hash(sf) == hash('user_id')
+
+
+def test_vocabulary_path_is_carried_through():            # reference tests/feature_test.py:25-32
+    sf = SparseFeat('user_id', 4, vocabulary_path="./dummy_test.csv")
+    assert sf.vocabulary_path == "./dummy_test.csv"
+    assert VarLenSparseFeat(sf, 6).vocabulary_path == "./dummy_test.csv"
+
+
+def test_string_dtype_requires_hash():                    # reference feature_column.py:24-31
+    with pytest.raises(ValueError, match="requires use_hash=True"):
+        build_input_features([SparseFeat('s', 4, dtype="string")])
+    build_input_features([SparseFeat('s', 4, dtype="string", use_hash=True)])
+
+
+def test_build_input_features_order_shapes_dtypes():      # reference feature_column.py:145-168
+    cols = [VarLenSparseFeat(SparseFeat("w_seq", 2, 4), maxlen=3, length_name="w_len", weight_name="w"),
+            SparseFeat("a", 5), DenseFeat("d", 3), VarLenSparseFeat(SparseFeat("seq", 7, 4), maxlen=5)]
+    f = build_input_features(cols)
+    assert list(f.keys()) == ["w_seq", "w", "w_len", "a", "d", "seq"] == get_feature_names(cols)
+    assert f["w_seq"].shape == (3,) and f["w"].shape == (3, 1) and f["w"].dtype == "float32"
+    assert f["w_len"].shape == (1,) and f["w_len"].dtype == "int32" and f["d"].shape == (3,) and f["a"].shape == (1,)
+    with pytest.raises(TypeError):
+        build_input_features([object()])
+
+
+def test_create_embedding_matrix_reuses_same_embedding_name():   # reference tests/feature_test.py:35-50
+    cols = [SparseFeat('item_id', 4, embedding_dim=8), SparseFeat('item_id_copy', 4, embedding_dim=8, embedding_name='item_id'),
+            VarLenSparseFeat(SparseFeat('hist_item_id', 4, embedding_dim=8, embedding_name='item_id'), maxlen=3),
+            VarLenSparseFeat(SparseFeat('neg_hist_item_id', 4, embedding_dim=8, embedding_name='item_id'), maxlen=3)]
+    d = create_embedding_matrix(cols, l2_reg=0, seed=1024)
+    assert list(d.keys()) == ['item_id']
+    assert d['item_id'].name == 'sparse_emb_item_id'
+    assert d['item_id'].mask_zero is True
+    assert d['item_id'].get_weights()[0].shape == (4, 8)
+    seq_only = create_embedding_matrix([VarLenSparseFeat(SparseFeat('s', 4, 8), maxlen=3)], 0, 1024, prefix="linear0")
+    assert seq_only['s'].name == 'linear0sparse_seq_emb_s' and seq_only['s'].mask_zero is True
+
+
+def test_create_embedding_matrix_rejects_inconsistent_shared_embedding():   # reference tests/feature_test.py:53-60
+    cols = [SparseFeat('item_id', 4, embedding_dim=8),
+            VarLenSparseFeat(SparseFeat('hist_item_id', 5, embedding_dim=8, embedding_name='item_id'), maxlen=3)]
+    with pytest.raises(ValueError, match="same embedding_name"):
+        create_embedding_matrix(cols, l2_reg=0, seed=1024)
+
+
+def _mixed():
+    return [SparseFeat('C%d' % i, 10 + i, 4, group_name="g" if i == 2 else DEFAULT_GROUP_NAME) for i in range(3)] + \
+           [DenseFeat('I0', 1), DenseFeat('vec', 3), VarLenSparseFeat(SparseFeat('s', 7, 4), maxlen=5)]
+
+
+def test_model_weight_names_follow_the_reference():
+    cols = _mixed()
+    m = DeepFM(cols, cols, dnn_hidden_units=(8, 4))
+    names = [n for n, _ in m.named_weights()]
+    for want in ("linear0sparse_emb_C0/embeddings", "linear0sparse_seq_emb_s/embeddings", "linear/linear_kernel",
+                 "sparse_emb_C1/embeddings", "sparse_seq_emb_s/embeddings", "dnn/kernel0", "dnn/bias1", "dense/kernel",
+                 "prediction_layer/global_bias"):
+        assert want in names, want
+    assert m.input_names == get_feature_names(cols)
+    assert m.get_layer("sparse_emb_C1").get_weights()[0].shape == (11, 4)
+    assert m.get_layer("linear").get_weights()[0].shape == (4, 1)
+    assert dict(m.named_weights())["dnn/kernel0"].shape == (3 * 4 + 4 + 4, 8)
+    x = xDeepFM(cols, cols, dnn_hidden_units=(8,), cin_layer_size=(6, 4))
+    xn = dict(x.named_weights())
+    assert xn["cin/filter0"].shape == (1, 16, 6) and xn["cin/filter1"].shape == (1, 12, 4) and xn["dense_1/kernel"].shape == (7, 1)
+    d = DCN(cols, cols, cross_num=2, cross_parameterization="matrix", dnn_hidden_units=(8,))
+    dn = dict(d.named_weights())
+    assert dn["cross_net/kernel1"].shape == (20, 20) and dn["cross_net/bias0"].shape == (20, 1) and dn["dense/kernel"].shape == (28, 1)
+    with pytest.raises(ValueError, match="Either hidden_layer or cross layer"):
+        DCN(cols, cols, cross_num=0, dnn_hidden_units=())
+
+
+def test_dnn_input_layout_groups_sparse_then_varlen():
+    """feature_column.py:213-233 + inputs.py:175-181: sparse first, then varlen, bucketed by group."""
+    cols = [VarLenSparseFeat(SparseFeat('s', 7, 4), maxlen=5), SparseFeat('a', 5, 4, group_name="g2"), DenseFeat('d', 2),
+            SparseFeat('b', 5, 4), SparseFeat('c', 5, 4, group_name="g2")]
+    m = DeepFM(cols, cols, dnn_hidden_units=(4,), fm_group=("g2",))
+    order = [(f.fc.name, f.out_offset, f.in_fm) for f in m.stage_plan.fields]
+    assert order == [('a', 0, True), ('c', 4, True), ('b', 8, False), ('s', 12, False)]
+    assert m.stage_plan.dense_offset == 16 and m.stage_plan.in_dim == 18 and m.stage_plan.out_stride == 20
+
+
+def test_din_names_and_validation():
+    fc = [SparseFeat('user', 3, embedding_dim=10), SparseFeat('gender', 2, embedding_dim=4), SparseFeat('item_id', 4, embedding_dim=8),
+          SparseFeat('cate_id', 3, embedding_dim=4), DenseFeat('pay_score', 1),
+          VarLenSparseFeat(SparseFeat('hist_item_id', 4, embedding_dim=8, embedding_name='item_id'), maxlen=4, length_name="seq_length"),
+          VarLenSparseFeat(SparseFeat('hist_cate_id', 3, embedding_dim=4, embedding_name='cate_id'), maxlen=4, length_name="seq_length")]
+    m = DIN(fc, ['item_id', 'cate_id'], dnn_hidden_units=[4, 4, 4])
+    n = dict(m.named_weights())
+    assert n["dnn/kernel0"].shape == (48, 80) and n["dnn/kernel1"].shape == (80, 40) and n["dice/dice_alpha"].shape == (80,)
+    assert n["dice_1/moving_variance"].shape == (40,) and n["local_activation_unit/kernel"].shape == (40, 1)
+    assert n["dnn_1/kernel0"].shape == (10 + 4 + 8 + 4 + 12 + 1, 4)
+    assert m.input_names == ['user', 'gender', 'item_id', 'cate_id', 'pay_score', 'hist_item_id', 'seq_length', 'hist_cate_id']
+    assert m.get_layer("sparse_emb_item_id").mask_zero is True
+    with pytest.raises(ValueError):
+        DIN(fc[:5], ['item_id'])
+
+
+def test_forward_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from deepctr_amd import _C
+    cols = _mixed()
+    m = DeepFM(cols, cols, dnn_hidden_units=(4,))
+    feed = {n: np.zeros((3,) + tuple(s.shape)) for n, s in m.inputs.items()}
+    with pytest.raises(_C.DctrExtensionError, match="no CPU fallback"):
+        m.predict(feed)
+
+
+def test_weight_roundtrip_by_name_and_list(tmp_path):
+    cols = _mixed()
+    m = DeepFM(cols, cols, dnn_hidden_units=(4,))
+    rng = np.random.RandomState(0)
+    new = {k: rng.standard_normal(v.shape).astype(np.float32) for k, v in m.get_weights_by_name().items()}
+    m.set_weights_by_name(new)
+    m.save_weights(str(tmp_path / "w.npz"))
+    m2 = DeepFM(cols, cols, dnn_hidden_units=(4,))
+    m2.load_weights(str(tmp_path / "w.npz"))
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        assert (a == b).all()
+    with pytest.raises(KeyError):
+        m2.set_weights_by_name({"nope/kernel": np.zeros(1)})
+    with pytest.raises(ValueError):
+        m2.set_weights_by_name({"dense/kernel": np.zeros((3, 3))}, strict=False)
+    assert m.count_params() == sum(int(np.prod(v.shape)) for v in new.values())

@@ -1,0 +1,52 @@
+"""GPU: the minimal training surface (compile -> fit -> predict, reference tests/utils.py:356-381) and parity of
+the differentiable torch restatement used for gradients with the HIP forward used for predict."""
+import numpy as np
+import pytest
+import torch
+
+from tests.spec import columns_from_spec
+from tests.util import assert_close, golden_meta, load_golden, sigmoid_inv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["model_deepfm_hash", "model_dcn_matrix", "model_xdeepfm", "model_din_big_wn0"])
+def test_torch_training_forward_matches_hip_forward(device, name):
+    from deepctr_amd import training
+    from tests.test_gpu_models import build_model, well_conditioned_rows
+    g = load_golden(name)
+    meta = golden_meta(g)
+    model = build_model(meta, device)
+    model.set_weights_by_name({k[2:]: v for k, v in g.items() if k.startswith("w/")})
+    feed = {k[5:]: v for k, v in g.items() if k.startswith("feed/")}
+    y = model.predict(feed, batch_size=64).reshape(-1)
+    staged = model.stage(feed)
+    model._begin()
+    with torch.no_grad():
+        p = torch.sigmoid(training.model_logits(model, staged, 0, staged.n)).cpu().numpy()
+    rows = well_conditioned_rows(meta, feed, y.shape[0])
+    assert_close(p[rows], y[rows], rtol=1e-4, atol=1e-6, what=name)
+
+
+def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(0)
+    n = 2048
+    cols = [SparseFeat("a", 20, 8), SparseFeat("b", 30, 8, use_hash=True), DenseFeat("d", 2),
+            VarLenSparseFeat(SparseFeat("s", 15, 8), maxlen=4, combiner="mean")]
+    feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 10 ** 6, n), "d": rng.rand(n, 2).astype(np.float32),
+            "s": rng.randint(0, 15, (n, 4))}
+    y = ((feed["a"] % 2) ^ (feed["d"][:, 0] > 0.5)).astype(np.float32)
+    model = DeepFM(cols, cols, dnn_hidden_units=(32, 16), device=device)
+    with pytest.raises(RuntimeError):
+        model.fit(feed, y)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
+    before = model.evaluate(feed, y, batch_size=512)
+    h = model.fit(feed, y, batch_size=256, epochs=8, verbose=0, validation_split=0.25)
+    assert len(h.history["loss"]) == 8 and len(h.history["val_loss"]) == 8
+    after = model.evaluate(feed, y, batch_size=512)
+    assert after < before - 0.05, (before, after)
+    p = model.predict(feed, batch_size=512)
+    assert p.shape == (n, 1) and np.isfinite(p).all()
+    assert isinstance(model.train_on_batch({k: v[:64] for k, v in feed.items()}, y[:64]), float)

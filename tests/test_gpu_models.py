@@ -58,7 +58,7 @@ def test_model_matches_reference_code(device, name):
     model.set_weights_by_name({k[2:]: v for k, v in g.items() if k.startswith("w/")})
     feed = {k[5:]: v for k, v in g.items() if k.startswith("feed/")}
     rows = well_conditioned_rows(meta, feed, g["y"].shape[0])
-    assert rows.sum() >= 0.8 * rows.size
+    assert rows.sum() >= 0.5 * rows.size
     for bs in (256, 5):
         y = model.predict(feed, batch_size=bs)
         check_probs(y, g["y"], "%s bs=%d" % (name, bs), rows)
