@@ -74,14 +74,20 @@ def synthetic_feed(rows, seed):
 
 
 def probe_kernels(model, staged, ring, reps=64):
-    """Mean per-dispatch duration of each kernel of the step (start/stop events around single dispatches)."""
+    """Mean per-dispatch duration (start/stop events around single dispatches = what rocprofv3 --kernel-trace
+    reports) of (a) the kernel(s) the timed step launches and (b) the two stand-alone kernels of the unfused path."""
     from deepctr_amd import _C, ops
     lib = _C.lib()
     sp = model.stage_plan
     out = torch.empty(B, device=model.device)
-    t_gather, t_mlp = [], []
+    t_step, t_gather, t_mlp = [], [], []
+    fused = bool(sp.fusable and model.fused)
     for r in range(reps):
         lo = (r % ring) * B
+        if fused:
+            lib.dctr_profile_next_launch()
+            model._forward(staged, lo, lo + B, out)
+            t_step.append(lib.dctr_profile_last_ms())
         lib.dctr_profile_next_launch()
         ws = sp.run(staged, lo, lo + B)
         t_gather.append(lib.dctr_profile_last_ms())
@@ -91,9 +97,8 @@ def probe_kernels(model, staged, ring, reps=64):
                 in_dim=sp.in_dim, out=out)
         t_mlp.append(lib.dctr_profile_last_ms())
     torch.cuda.synchronize()
-    g = float(np.mean(t_gather[reps // 4:])) * 1e-3
-    m = float(np.mean(t_mlp[reps // 4:])) * 1e-3
-    return g, m
+    mean = lambda t: float(np.mean(t[reps // 4:])) * 1e-3 if t else None  # noqa: E731
+    return mean(t_step), mean(t_gather), mean(t_mlp)
 
 
 def cpu_baseline(model, cols, budget_s=12.0):
@@ -199,33 +204,48 @@ def main():
     result = None
     if rank == 0:
         value = world * B * K / elapsed if K else 0.0
-        t_gather, t_mlp = probe_kernels(model, staged, ring)
+        t_fused, t_gather, t_mlp = probe_kernels(model, staged, ring)
         gather_gbs = ALG_BYTES_PER_SAMPLE * B / t_gather / 1e9
         mlp_tf = DNN_FLOP_PER_SAMPLE * B / t_mlp / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("gather_fm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        kernels = []
+        if t_fused is not None:
+            kernels.append({"kernel": "mlp_kernel, fused gather (dctr_embed_mlp_fwd: ids -> LDS tile -> DNN -> head)",
+                            "in_step": True, "us_per_launch": t_fused * 1e6, "bound": "mfma",
+                            "achieved": DNN_FLOP_PER_SAMPLE * B / t_fused / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": DNN_FLOP_PER_SAMPLE * B / t_fused / 1e12 / F32_MFMA_PEAK_TF,
+                            "hbm_algorithmic_GBps": ALG_BYTES_PER_SAMPLE * B / t_fused / 1e9,
+                            "hbm_frac": ALG_BYTES_PER_SAMPLE * B / t_fused / 1e9 / HBM_PEAK_GBS})
+        kernels.append({"kernel": "gather_fm_kernel (stand-alone fused 26-table gather + concat + linear + FM)",
+                        "in_step": t_fused is None, "us_per_launch": t_gather * 1e6, "bound": "hbm", "achieved": gather_gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gather_gbs / HBM_PEAK_GBS})
+        kernels.append({"kernel": "mlp_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA)", "in_step": t_fused is None,
+                        "us_per_launch": t_mlp * 1e6, "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF})
+        dom = kernels[0]
+        roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
+                    "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "us_per_launch": dom["us_per_launch"],
+                    "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * B,
+                    "algorithmic_flop_per_launch": DNN_FLOP_PER_SAMPLE * B}
+        if "hbm_frac" in dom:
+            roofline["hbm_algorithmic_GBps"], roofline["hbm_frac"] = dom["hbm_algorithmic_GBps"], dom["hbm_frac"]
         result = {
             "metric": "samples/sec fwd DeepFM Criteo-26x1e5 emb16 b4096", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3 if K else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DeepFM forward, 26 sparse x vocab 1e5 + 13 dense, emb_dim 16, "
                                    "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, "
-                                   "ring of %d distinct batches, %s" % (ring, "1 hipGraph of K steps" if graph else "eager"),
+                                   "ring of %d distinct batches, %s, %s" % (
+                                       ring, "1 hipGraph of K steps" if graph else "eager",
+                                       "1 launch/step (fused gather+DNN)" if t_fused is not None else "2 launches/step"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "row-sharded x%d, tables replicated" % world},
-            "roofline": {"kernel": "gather_fm_kernel (fused 26-table gather + concat + linear + FM)", "bound": "hbm",
-                         "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gather_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "us_per_launch": t_gather * 1e6,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * B},
-            "kernels": [
-                {"kernel": "gather_fm_kernel", "us_per_launch": t_gather * 1e6, "bound": "hbm", "achieved": gather_gbs,
-                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gather_gbs / HBM_PEAK_GBS},
-                {"kernel": "mlp_kernel (DNN 429-256-128-64 + head, f32 MFMA)", "us_per_launch": t_mlp * 1e6, "bound": "mfma",
-                 "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF}],
+            "roofline": roofline, "kernels": kernels,
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -106,6 +106,7 @@ SYMBOLS = {
     "dctr_inner_product_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
+    "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
 }
 

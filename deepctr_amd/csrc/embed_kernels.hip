@@ -20,156 +20,9 @@
 #include <math.h>
 
 #include "dctr_common.h"
-#include "farmhash_device.h"
+#include "embed_device.h"
 
 namespace {
-
-typedef dctr_gather_fm_args_t GatherParams;   // passed by value in the kernarg segment (scalar loads)
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-        v[0] = *p;
-    }
-}
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-        *p = v[0];
-    }
-}
-
-// Branch-free id read: one 32-bit load for the low word plus one for the high word (int64 ids) so that
-// no control flow separates the id loads of different fields (they must all be in flight together).
-struct RawId {
-    uint32_t lo, hi;
-};
-__device__ __forceinline__ RawId load_id(const void* idx, int64_t pos, int is_i64) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(idx);
-    RawId r;
-    r.lo = w[is_i64 ? 2 * pos : pos];
-    r.hi = w[is_i64 ? 2 * pos + 1 : pos];
-    return r;
-}
-__device__ __forceinline__ int64_t id_value(RawId r, int is_i64) {
-    return is_i64 ? (int64_t)(((uint64_t)r.hi << 32) | r.lo) : (int64_t)(int32_t)r.lo;
-}
-__device__ __forceinline__ int64_t read_id(const void* idx, int64_t pos, int is_i64) {
-    return id_value(load_id(idx, pos, is_i64), is_i64);
-}
-
-__device__ __forceinline__ int64_t resolve_row(int64_t raw, int hash_mode, int is_i64, int64_t vocab) {
-    if (hash_mode == 0) return raw;
-    return dctr::hash_bucket_id(raw, !is_i64, (uint64_t)vocab, hash_mode == 2);
-}
-
-template <int LPR>
-__device__ __forceinline__ float reduce_lpr(float v) {
-#pragma unroll
-    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-struct GatherAcc {
-    float lin;
-    int oor;
-};
-
-// The descriptor array is read-only for the whole launch.  Viewing it through the AMDGPU constant
-// address space (4) lets the compiler fetch it with scalar loads (s_load_*, scalar cache) into SGPRs:
-// descriptor-dependent branches become scalar branches and never wait on the vector memory counter.
-#define DCTR_CONSTANT __attribute__((address_space(4)))
-typedef const dctr_field_t DCTR_CONSTANT* cfield_ptr;
-
-struct FieldRegs {
-    const float* table;
-    const float* lin_table;
-    int64_t vocab;
-    int dim, out_offset, in_fm, hash_mode, identity;
-};
-__device__ __forceinline__ FieldRegs load_field(cfield_ptr F, int j) {
-    FieldRegs r;
-    r.table = F[j].table;
-    r.lin_table = F[j].lin_table;
-    r.vocab = F[j].vocab;
-    r.dim = F[j].dim;
-    r.out_offset = F[j].out_offset;
-    r.in_fm = F[j].in_fm;
-    r.hash_mode = F[j].hash_mode;
-    r.identity = F[j].identity;
-    return r;
-}
-
-// One chunk of U fields (j0, j0+step, ...).  Phases with NO control flow inside a phase:
-//   1. U id loads — addresses come from kernel arguments only (id matrix base + strides), so they are
-//      issued before the descriptor scalar loads have returned;
-//   2. rows resolved (optional in-register hash), bounds check;
-//   3. U row loads + U one-wide linear loads, all in flight before the first use
-//      (out-of-range / tail / inactive lanes read a valid dummy address and are masked afterwards);
-//   4. FM / linear accumulation and the concat write.
-template <int VEC, int LPR, int U, bool HASH>
-__device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int step, int64_t b, bool valid, int q,
-                                             float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc) {
-    const int last = p.n_fields - 1;
-    const int64_t bb = valid ? b : 0;
-    RawId raw[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = min(j0 + u * step, last);
-        raw[u] = load_id(p.ids, (int64_t)j * p.ids_stride_f + bb * p.ids_stride_b, p.ids_is_i64);
-    }
-    cfield_ptr F = (cfield_ptr)p.fields;
-    FieldRegs fr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) fr[u] = load_field(F, min(j0 + u * step, last));
-    int64_t row[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int jj = j0 + u * step;
-        const FieldRegs& f = fr[u];
-        int64_t r = f.identity ? b : id_value(raw[u], p.ids_is_i64);
-        if constexpr (HASH) {
-            if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
-        }
-        const bool live = valid && jj <= last;
-        ok[u] = live && (uint64_t)r < (uint64_t)f.vocab;
-        if (live && !ok[u]) acc.oor = 1;
-        row[u] = ok[u] ? r : 0;
-    }
-    float v[U][VEC];
-    float lv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const FieldRegs& f = fr[u];
-        const int qq = (q * VEC < f.dim) ? q * VEC : 0;
-        load_vec<VEC>(f.table + row[u] * f.dim + qq, v[u]);
-        const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] : reinterpret_cast<const float*>(p.fields);
-        lv[u] = *lp;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const FieldRegs& f = fr[u];
-        const bool act = ok[u] && q * VEC < f.dim;
-        if (ok[u] && q == 0 && f.lin_table != nullptr) acc.lin += lv[u];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) v[u][c] = act ? v[u][c] : 0.f;
-        if (f.in_fm) {
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                sum[c] += v[u][c];
-                sq[c] = fmaf(v[u][c], v[u][c], sq[c]);
-            }
-        }
-        if (p.dnn_in != nullptr && f.out_offset >= 0 && valid && (j0 + u * step) <= last && q * VEC < f.dim)
-            store_vec<VEC>(p.dnn_in + b * p.out_stride + f.out_offset + q * VEC, v[u]);
-    }
-}
 
 // HASH = false builds carry no hashing code at all (the host knows whether any field has hash_mode != 0).
 template <int VEC, int LPR, bool FSPLIT, bool HASH>
@@ -203,15 +56,11 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
     for (int c = 0; c < VEC; ++c) sum[c] = sq[c] = 0.f;
     GatherAcc acc{0.f, 0};
 
-    int j = f_begin;
-    // full chunks of 8 fields, then one clamped tail chunk sized to what is left
-    for (; j + 7 * f_step < p.n_fields; j += 8 * f_step) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
-    if (j < p.n_fields) {
-        const int left = (p.n_fields - j + f_step - 1) / f_step;   // 1..7, wave-uniform
-        if (left > 4) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
-        else if (left > 2) gather_chunk<VEC, LPR, 4, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
-        else gather_chunk<VEC, LPR, 2, HASH>(p, j, f_step, b, valid, q, sum, sq, acc);
-    }
+    float* const out_row = p.dnn_in != nullptr ? p.dnn_in + (valid ? b : 0) * p.out_stride : nullptr;
+    auto store = [out_row](int col, const float (&v)[VEC]) {
+        if (out_row != nullptr) store_vec<VEC>(out_row + col, v);
+    };
+    gather_fields<VEC, LPR, HASH>(p, f_begin, f_step, b, valid, q, sum, sq, acc, store);
     float lin = acc.lin;
 
     // dense features: passthrough into the concat + dense . Linear.kernel

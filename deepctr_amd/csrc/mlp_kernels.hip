@@ -1,20 +1,37 @@
 // adjacent to the hot path — DNN.call (+ Dense(1,use_bias=False) head + add_func + PredictionLayer.call)
 // reference deepctr/layers/core.py:189-208, :250-259, layers/utils.py:328-333.
 //
-// One kernel runs the WHOLE multilayer perceptron for a 16-row tile of the batch: activations never
-// leave LDS between layers, weights (603 KB for 429-256-128-64) stream from L2, and the head
-// (Dense(1) + linear/FM logits + global bias + sigmoid) is the epilogue.  Replaces per layer in the
-// reference: tensordot + bias_add + activation (+ BN/Dice) kernels, then Dense, Add, bias_add, sigmoid.
+// One kernel runs the WHOLE multilayer perceptron for a 16-row tile of the batch: activations never leave LDS
+// between layers, and the head (Dense(1) + linear/FM logits + global bias + sigmoid) is the epilogue.  Replaces,
+// per layer, the reference's tensordot + bias_add + activation (+ Dice) kernels, then Dense, Add, bias_add, sigmoid.
 //
-// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32) — see mfma_tile.h.  At B = 4096 that is 256
-// workgroups = one per CU, four waves each (one per SIMD); each wave owns a 16*TPW-column slice of the
-// layer output and walks K.  fp32 MFMA floor for 429-256-128-64: 301.7 kFLOP/sample -> 7.9 us / 4096.
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32, see mfma_tile.h).  At B = 4096 the grid is 256 workgroups = one
+// per CU, four waves = one per SIMD, so there is NO second wave to hide latency behind: every wave owns a
+// 16*TPW-column slice of the layer output, walks K, and keeps its B operand in a two-stage REGISTER pipeline —
+// the global_load_dwordx{TPW} of the next 8 k-steps (32 MFMAs = 1024 issue cycles) are in flight while the
+// current 8 are consumed, which covers the L2 latency of the weight stream (603 KB per workgroup, L2-resident).
+// Measured alternatives (scripts/mlp_lab.cpp): loads issued and waited per 4 MFMAs 58 us; weights staged through
+// LDS in double-buffered 32-KB chunks 44 us (ds_write + barrier per chunk cost more than the MFMAs they feed).
+// fp32 MFMA floor for 429-256-128-64: 301.7 kFLOP/sample -> 7.9 us per 4096 rows.
 #include "dctr_common.h"
+#include "embed_device.h"
 #include "mfma_tile.h"
+
+#ifdef DCTR_LAB_TIMING
+__device__ unsigned long long dctr_lab_ts[64];
+#define LAB_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) dctr_lab_ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LAB_TS(i) do {} while (0)
+#endif
 
 namespace {
 
 constexpr int MAX_LAYERS = 8;
+#ifndef DCTR_MLP_WAVES
+#define DCTR_MLP_WAVES 8          // waves per 16-row workgroup: 8 = two per SIMD (the second hides the first's waits)
+#endif
+constexpr int NWAVE = DCTR_MLP_WAVES;
+constexpr int NTHR = 64 * NWAVE;
 
 struct MlpParams {
     const float* x;
@@ -37,29 +54,20 @@ struct MlpParams {
     const float* global_bias;
     float* y;
     int64_t y_stride;
-    int32_t lda;  // LDS row stride (floats), >= pad16(max width) + 4
+    int32_t lda;  // LDS row stride (floats) = pad64(max width) + 4
 };
 
-// ---------------------------------------------------------------------------------------------------
-// One layer:  out[16 x N] = act(in[16 x K] @ W[K x N] + bias)
-//
-// W streams through LDS in K-chunks of KC rows (a chunk = KC*N contiguous floats of the Keras-layout kernel,
-// <= 32 KB), double-buffered: while the four waves issue the MFMAs of chunk c, every thread already has the
-// global_load_dwordx4s of chunk c+1 in flight (fully coalesced: 4 KB per wave-instruction), and parks them in
-// the other LDS buffer before the single barrier of the iteration.  A wave's B fragment then is ONE
-// ds_read_b128/b64/b32 per k-step and its A fragment two ds_read_b128 per chunk — the global-memory latency
-// that used to sit between every four MFMAs (one wave per SIMD, nothing to switch to) is off the critical path.
-// k-slot mapping inside a chunk: MFMA slot g = lane>>4 owns k = k0 + g*(KC/4) + t.
-// ---------------------------------------------------------------------------------------------------
-constexpr int WBUF_FLOATS = 8192;   // one weight buffer: 32 KB
-constexpr int MAXV = WBUF_FLOATS / (256 * 4);   // float4 per thread per chunk (8)
-constexpr int ACC_SLOTS = 8;        // f32x4 accumulators per wave (MAXT wave-tiles x TPW columns)
+// gather arguments of the fused path; lpr == 0 selects the plain x-staging path
+struct GatherFused : dctr_gather_fm_args_t {
+    int32_t fm_logit_used;   // add the FM logit of the gather epilogue to the head
+    int32_t lin_logit_used;  // add the linear logit
+};
+struct FusedGather {
+    GatherFused g;
+    int32_t lpr;
+};
 
-__device__ __forceinline__ int chunk_rows(int K, int N) {
-    int kc = (WBUF_FLOATS / N) & ~15;
-    const int kp = dctr::pad16(K);
-    return kc < kp ? kc : kp;
-}
+__device__ __forceinline__ int pad64(int k) { return (k + 63) & ~63; }
 
 template <int ACT>
 __device__ __forceinline__ float act_t(float v, float al, float mu, float var, float eps) {
@@ -70,215 +78,355 @@ __device__ __forceinline__ float act_t(float v, float al, float mu, float var, f
     else return v;
 }
 
-// All MAXV loads are unconditional (clamped to a safe address) and carry no control flow, so they are issued
-// back-to-back and stay in flight during the MFMAs; masking happens when they are parked in LDS.
-__device__ __forceinline__ void chunk_fetch(const float* __restrict__ W, int K, int N, int k0, float4 (&r)[MAXV]) {
-    const int64_t kn = (int64_t)K * N;
-    const int64_t g_safe = kn >= 4 ? ((kn - 4) & ~(int64_t)3) : 0;
-    const int64_t g0 = (int64_t)k0 * N;
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-        int64_t gi = g0 + (v * 256 + threadIdx.x) * 4;
-        gi = gi < g_safe ? gi : g_safe;
-        r[v] = *reinterpret_cast<const float4*>(W + gi);
+// B fragments of 8 consecutive k-steps of one wave-tile.  MFMA slot g = lane>>4 takes row k = 4*t + g, so the four
+// slots (x the waves' column slices) read 4 ADJACENT weight rows = one contiguous 4 KB; the A tile in LDS is stored
+// column-permuted to match (logical column k at (k&3)*KQ + (k>>2)), so a lane still reads its 8 k-steps with two
+// ds_read_b128.
+// The loads are raw BUFFER loads: the per-lane offset (slot row g, column slice) is constant for the whole tile,
+// the row advance is a scalar offset, and rows >= K fall outside num_records and return 0 from the hardware bounds
+// check — i.e. ZERO VALU per load.  (With flat 64-bit addressing hipcc spent ~9 VALU incl. two quarter-rate
+// v_mad_u64_u32 per load, ~700 issue cycles per 1024-cycle stage that a lone wave per SIMD cannot overlap.)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int TPW>
+__device__ __forceinline__ void buf_load_cols(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float (&b)[TPW]) {
+    if constexpr (TPW == 4) {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        b[0] = __uint_as_float(t.x); b[1] = __uint_as_float(t.y); b[2] = __uint_as_float(t.z); b[3] = __uint_as_float(t.w);
+    } else if constexpr (TPW == 2) {
+        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        b[0] = __uint_as_float(t.x); b[1] = __uint_as_float(t.y);
+    } else {
+        b[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
     }
 }
 
-__device__ __forceinline__ void chunk_park(float* wbuf, const float* __restrict__ W, int K, int N, int k0, int KC,
-                                           const float4 (&r)[MAXV]) {
-    const int total = KC * N;
-    const int valid = max(0, min(KC, K - k0)) * N;
-    const int64_t kn = (int64_t)K * N;
-    const int64_t g0 = (int64_t)k0 * N;
+// stage s covers k-steps t = 8s .. 8s+7: row of slot g = 4*t + g  ->  byte offset (4*t)*N*4 (scalar) + voff (lane)
+template <int TPW>
+__device__ __forceinline__ void load_b8(__amdgpu_buffer_rsrc_t rsrc, int voff, int row4_bytes, int s, float (&b)[8][TPW]) {
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-        const int i = (v * 256 + threadIdx.x) * 4;
-        if (i < total) {
-            float4 t = r[v];
-            if (i + 3 >= valid) {                               // chunk tail: rows past K are zero
-                const bool whole = g0 + i + 3 < kn;             // was the float4 read in place (not clamped)?
-                float e[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (i + c >= valid) e[c] = 0.f;
-                    else if (!whole) e[c] = W[g0 + i + c];       // <= 3 floats of the very last row of W
-                }
-                t = make_float4(e[0], e[1], e[2], e[3]);
-            }
-            *reinterpret_cast<float4*>(wbuf + i) = t;
-        }
-    }
+    for (int tt = 0; tt < 8; ++tt) buf_load_cols<TPW>(rsrc, voff, (8 * s + tt) * row4_bytes, b[tt]);
 }
 
-// MFMAs of one chunk for the NT wave-tiles this wave owns (compile-time NT: no per-step branches)
-template <int TPW, int NT>
-__device__ __forceinline__ void chunk_compute(const float* arow, const float* brow, int KQ, int N, const int* ncol,
-                                              dctr::f32x4 (&acc)[ACC_SLOTS / TPW][TPW]) {
-    for (int t0 = 0; t0 < KQ; t0 += 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(arow + t0);
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-        float b[4][NT][TPW];
+__device__ __forceinline__ int lds_pos(int k, int KQ) { return (k & 3) * KQ + (k >> 2); }
+
+// A fragments of the same 8 k-steps: two ds_read_b128 of the column-permuted LDS tile
+__device__ __forceinline__ void load_a8(const float* arow, float (&a)[8]) {
+    const float4 a0 = *reinterpret_cast<const float4*>(arow);
+    const float4 a1 = *reinterpret_cast<const float4*>(arow + 4);
+    a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+    a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+}
+
+template <int TPW>
+__device__ __forceinline__ void mfma8(const float (&av)[8], const float (&b)[8][TPW], dctr::f32x4 (&acc)[TPW]) {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-            for (int i = 0; i < NT; ++i) dctr::load_cols<TPW>(brow + (t0 + tt) * N + ncol[i], b[tt][i]);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int cc = 0; cc < TPW; ++cc)
-                    acc[i][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b[tt][i][cc], acc[i][cc], 0, 0, 0);
+        for (int c = 0; c < TPW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b[tt][c], acc[c], 0, 0, 0);
+}
+
+// C[16 x 16*TPW] = A[16 x K] * W[K x N] for one wave-tile.  K is walked in stages of 8 k-steps per MFMA slot
+// (8*TPW MFMAs); THREE register stages rotate so that the operands of stages s+1 and s+2 are in flight while
+// stage s issues its MFMAs (>= 2 x 256*TPW cycles of cover for the L2 latency of the weight stream).  The
+// sched_barriers pin the order "issue loads, then MFMAs" — without them hipcc sinks each load next to its first
+// use and the wave alternates load-wait / MFMA (measured: 62 cycles per 32-cycle MFMA).
+#ifdef DCTR_LAB_NO_SB
+#define DCTR_SB do {} while (0)
+#else
+#define DCTR_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+template <int TPW>
+__device__ __forceinline__ void tile_gemm_pipe(const float* A, int lda, int K, const float* __restrict__ W, int N,
+                                               int n_base, dctr::f32x4 (&acc)[TPW]) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int KQ = pad64(K) / 4;
+    const float* arow = A + j * lda + g * KQ;
+    int n0 = n_base + TPW * j;
+    if (n0 + TPW > N) n0 = N - TPW;                       // TPW > 1 only when N % (16*TPW) == 0
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, K * N * 4, 0x00020000);
+    const int voff = (g * N + n0) * 4;                    // lane-constant byte offset: slot row g, column slice
+    const int row4_bytes = 4 * N * 4;                     // four weight rows
+    const int n_it = KQ / 8;                              // >= 2
+    const int s_last = n_it - 1;
+    float b0[8][TPW], b1[8][TPW], b2[8][TPW];
+    float a0[8], a1[8], a2[8];
+#define DCTR_STAGE_LOAD(S, AB, BB)                                  \
+    do {                                                            \
+        const int s_ = min((S), s_last);                            \
+        load_b8<TPW>(rsrc, voff, row4_bytes, s_, BB);               \
+        load_a8(arow + s_ * 8, AB);                                 \
+    } while (0)
+    DCTR_STAGE_LOAD(0, a0, b0);
+    DCTR_STAGE_LOAD(1, a1, b1);
+    for (int it = 0; it < n_it; it += 3) {
+        DCTR_STAGE_LOAD(it + 2, a2, b2);
+        DCTR_SB;
+        mfma8<TPW>(a0, b0, acc);
+        DCTR_SB;
+        DCTR_STAGE_LOAD(it + 3, a0, b0);
+        DCTR_SB;
+        if (it + 1 < n_it) mfma8<TPW>(a1, b1, acc);
+        DCTR_SB;
+        DCTR_STAGE_LOAD(it + 4, a1, b1);
+        DCTR_SB;
+        if (it + 2 < n_it) mfma8<TPW>(a2, b2, acc);
+        DCTR_SB;
     }
+#undef DCTR_STAGE_LOAD
 }
 
 template <int TPW, int ACT>
-__device__ __forceinline__ void layer_chunked(const MlpParams& p, int l, const float* in, float* out, float* wbuf0,
-                                              float* wbuf1, int K, int N) {
+__device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
     using dctr::f32x4;
-    constexpr int MAXT = ACC_SLOTS / TPW;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int KC = chunk_rows(K, N);
-    const int KQ = KC / 4;                                   // k per MFMA slot per chunk, multiple of 4
-    const int n_chunks = (K + KC - 1) / KC;
     const int n_tiles = (N + 16 * TPW - 1) / (16 * TPW);
-    const int nt_w = wave < n_tiles ? (n_tiles - wave + 3) / 4 : 0;     // wave-tiles owned by this wave
-    const float* W = p.W[l];
-
-    f32x4 acc[MAXT][TPW];
+    const int KQn = pad64(N) / 4;                       // the next layer reads this tile with K = N
+    for (int wt = wave; wt < n_tiles; wt += NWAVE) {
+        const int n_base = wt * 16 * TPW;
+        f32x4 acc[TPW];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i)
-#pragma unroll
-        for (int c = 0; c < TPW; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int ncol[MAXT];                                          // first column of this lane in wave-tile i (clamped)
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-        int n0 = (wave + 4 * i) * 16 * TPW + TPW * j;
-        if (n0 + TPW > N) n0 = N - TPW;
-        ncol[i] = n0;
-    }
-
-    float4 stage[MAXV];
-    chunk_fetch(W, K, N, 0, stage);
-    chunk_park(wbuf0, W, K, N, 0, KC, stage);
-    __syncthreads();
-    for (int c = 0; c < n_chunks; ++c) {
-        const float* wb = (c & 1) ? wbuf1 : wbuf0;
-        float* wnext = (c & 1) ? wbuf0 : wbuf1;
-        const bool more = c + 1 < n_chunks;
-#ifndef DCTR_LAB_NO_FETCH
-        if (more) chunk_fetch(W, K, N, (c + 1) * KC, stage);               // in flight during the MFMAs below
+        for (int c = 0; c < TPW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef DCTR_LAB_COPIES
+        tile_gemm_pipe<TPW>(in, p.lda, K, p.W[l] + (size_t)((blockIdx.x / 8) % DCTR_LAB_COPIES) * 110080, N, n_base, acc);
+#else
+        tile_gemm_pipe<TPW>(in, p.lda, K, p.W[l], N, n_base, acc);
 #endif
-        const float* arow = in + j * p.lda + c * KC + g * KQ;
-        const float* brow = wb + (g * KQ) * N;
-#ifndef DCTR_LAB_NO_MFMA
-        switch (nt_w) {
-            case 1: chunk_compute<TPW, 1>(arow, brow, KQ, N, ncol, acc); break;
-            case 2: if constexpr (MAXT >= 2) chunk_compute<TPW, 2>(arow, brow, KQ, N, ncol, acc); break;
-            case 3: if constexpr (MAXT >= 4) chunk_compute<TPW, 3>(arow, brow, KQ, N, ncol, acc); break;
-            case 4: if constexpr (MAXT >= 4) chunk_compute<TPW, 4>(arow, brow, KQ, N, ncol, acc); break;
-            case 5: if constexpr (MAXT >= 8) chunk_compute<TPW, 5>(arow, brow, KQ, N, ncol, acc); break;
-            case 6: if constexpr (MAXT >= 8) chunk_compute<TPW, 6>(arow, brow, KQ, N, ncol, acc); break;
-            case 7: if constexpr (MAXT >= 8) chunk_compute<TPW, 7>(arow, brow, KQ, N, ncol, acc); break;
-            case 8: if constexpr (MAXT >= 8) chunk_compute<TPW, 8>(arow, brow, KQ, N, ncol, acc); break;
-            default: break;
-        }
-#endif
-#ifndef DCTR_LAB_NO_PARK
-        if (more) chunk_park(wnext, W, K, N, (c + 1) * KC, KC, stage);
-#endif
-        __syncthreads();
-    }
-
-    // epilogue: bias + activation -> LDS (C layout: row = 4g + r, col = tile base + TPW*j + c)
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-        if ((wave + 4 * i) < n_tiles) {
-#pragma unroll
-            for (int cc = 0; cc < TPW; ++cc) {
-                const int n = (wave + 4 * i) * 16 * TPW + TPW * j + cc;
-                if (n < N) {
-                    const float bv = p.bias[l] != nullptr ? p.bias[l][n] : 0.f;
-                    float al = 0.f, mu = 0.f, var = 1.f;
-                    if constexpr (ACT == DCTR_ACT_DICE) {
-                        al = p.dice_alpha[l][n];
-                        mu = p.dice_mean[l][n];
-                        var = p.dice_var[l][n];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        out[(4 * g + r) * p.lda + n] = act_t<ACT>(acc[i][cc][r] + bv, al, mu, var, p.dice_eps);
+        for (int c = 0; c < TPW; ++c) {
+            const int n = n_base + TPW * j + c;
+            if (n < N) {
+                const float bv = p.bias[l] != nullptr ? p.bias[l][n] : 0.f;
+                float al = 0.f, mu = 0.f, var = 1.f;
+                if constexpr (ACT == DCTR_ACT_DICE) {
+                    al = p.dice_alpha[l][n];
+                    mu = p.dice_mean[l][n];
+                    var = p.dice_var[l][n];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(4 * g + r) * p.lda + lds_pos(n, KQn)] = act_t<ACT>(acc[c][r] + bv, al, mu, var, p.dice_eps);
             }
         }
     }
-    // zero the K padding the NEXT layer will read: columns [N, lda)
-    for (int i = threadIdx.x; i < 16 * (p.lda - N); i += 256) {
-        const int r = i / (p.lda - N), c = N + i % (p.lda - N);
-        out[r * p.lda + c] = 0.f;
+    // zero the K padding the NEXT layer reads: columns [N, pad64(N))
+    const int npad = pad64(N) - N;
+    if (npad > 0) {
+        for (int i = threadIdx.x; i < 16 * 64; i += NTHR) {
+            const int r = i >> 6, c = i & 63;
+            if (c < npad) out[r * p.lda + lds_pos(N + c, KQn)] = 0.f;
+        }
     }
 }
 
 template <int ACT>
-__device__ __forceinline__ void layer_dispatch(const MlpParams& p, int l, const float* in, float* out, float* wbuf0,
-                                               float* wbuf1, int K, int N) {
-    if (N % 64 == 0) layer_chunked<4, ACT>(p, l, in, out, wbuf0, wbuf1, K, N);
-    else if (N % 32 == 0) layer_chunked<2, ACT>(p, l, in, out, wbuf0, wbuf1, K, N);
-    else layer_chunked<1, ACT>(p, l, in, out, wbuf0, wbuf1, K, N);
+__device__ __forceinline__ void layer_dispatch(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
+    // widest column slice per wave that still gives every wave of the workgroup a tile
+    if (N % 64 == 0 && N >= 64 * NWAVE) layer_tiles<4, ACT>(p, l, in, out, K, N);
+    else if (N % 32 == 0 && N >= 32 * NWAVE) layer_tiles<2, ACT>(p, l, in, out, K, N);
+    else layer_tiles<1, ACT>(p, l, in, out, K, N);
 }
 
-__global__ __launch_bounds__(256) void mlp_kernel(MlpParams p) {
+// ---------------------------------------------------------------------------------------------------
+// Fused input producer (dctr_embed_mlp_fwd): the DNN-input tile of the workgroup's 16 samples is GATHERED
+// straight into LDS — embedding rows, dense passthrough — and the linear + FM logits of the gather epilogue stay
+// in LDS for the head.  Versus dctr_embed_gather_fm + dctr_mlp_fwd this removes the [B, 432] fp32 tile's trip
+// through HBM (1.7 KB written and read back per sample), the [B] logit vectors and one kernel launch.
+// The waves of the workgroup split the FIELDS (as the stand-alone gather does at small batch); lane (s, q) owns
+// chunk q of sample s; samples are covered in 16*LPR/64 passes.
+// ---------------------------------------------------------------------------------------------------
+template <int LPR, bool HASH>
+__device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const GatherFused& g, float* tile, float* red,
+                                                   float* extra, int64_t b0) {
+    constexpr int VEC = 4;
+    constexpr int SPW = 64 / LPR;                             // samples per wave pass
+    constexpr int PASSES = SPW >= 16 ? 1 : 16 / SPW;
+    constexpr int RW = 2 * VEC + 1;                            // partials per lane: sum[4], sq[4], lin
+    const int KQ0 = pad64(p.in_dim) / 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int s = lane / LPR, q = lane % LPR;
+
+    // columns past the real input (K padding) and rows past the batch are zero
+    for (int i = threadIdx.x; i < 16 * KQ0; i += NTHR) {
+        const int r = i / KQ0, c4 = i - r * KQ0;
+        const bool rowok = b0 + r < g.batch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!rowok || 4 * c4 + k >= p.in_dim) tile[r * p.lda + k * KQ0 + c4] = 0.f;
+    }
+
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int r = pass * SPW + s;
+        const int64_t b = b0 + r;
+        const bool valid = r < 16 && b < g.batch;
+        float sum[VEC], sq[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) sum[c] = sq[c] = 0.f;
+        GatherAcc acc{0.f, 0};
+        float* const trow = tile + (r & 15) * p.lda;
+        auto store = [trow, KQ0](int col, const float (&v)[VEC]) {     // col % 4 == 0: columns col+k -> k*KQ0 + col/4
+            float* dst = trow + (col >> 2);
+            dst[0] = v[0];
+            dst[KQ0] = v[1];
+            dst[2 * KQ0] = v[2];
+            dst[3 * KQ0] = v[3];
+        };
+        gather_fields<VEC, LPR, HASH>(g, wave, NWAVE, b, valid, q, sum, sq, acc, store);
+        float* rp = red + ((wave * PASSES + pass) * RW) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            rp[c * 64] = sum[c];
+            rp[(VEC + c) * 64] = sq[c];
+        }
+        rp[2 * VEC * 64] = acc.lin;
+        if (g.status != nullptr && __any(acc.oor) && lane == 0) atomicOr(g.status, (int)DCTR_STATUS_INDEX_OOR);
+    }
+
+    // dense features: lanes 0..15 of the last wave take one sample each (passthrough + dense . Linear.kernel)
+    float dlin = 0.f;
+    if (g.n_dense > 0 && wave == NWAVE - 1 && lane < 16) {
+        const int r = lane;
+        const bool valid = b0 + r < g.batch;
+        const float* src = g.dense + (valid ? b0 + r : 0) * g.dense_stride;
+        for (int k0 = 0; k0 < g.n_dense; k0 += 8) {
+            float x[8], w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int k = min(k0 + m, g.n_dense - 1);
+                x[m] = src[k];
+                w[m] = g.dense_lin_w != nullptr ? g.dense_lin_w[k] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int k = k0 + m;
+                if (k < g.n_dense && valid) {
+                    if (g.dense_out_offset >= 0 && k < g.dense_copy_cols)
+                        tile[r * p.lda + lds_pos(g.dense_out_offset + k, KQ0)] = x[m];
+                    dlin = fmaf(x[m], w[m], dlin);
+                }
+            }
+        }
+        extra[16 + r] = dlin;
+    }
+    __syncthreads();
+
+    // combine the waves' partial sums: FM = 0.5 * sum_d((sum_f e)^2 - sum_f e^2), linear = sum of the 1-wide rows
+    if (threadIdx.x < PASSES * 64) {
+        const int pass = threadIdx.x >> 6;
+        const int r = pass * SPW + s;
+        float S[VEC], Q[VEC], lin = 0.f;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) S[c] = Q[c] = 0.f;
+        for (int w = 0; w < NWAVE; ++w) {
+            const float* rp = red + ((w * PASSES + pass) * RW) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                S[c] += rp[c * 64];
+                Q[c] += rp[(VEC + c) * 64];
+            }
+            lin += rp[2 * VEC * 64];
+        }
+        float fm = 0.f;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) fm += S[c] * S[c] - Q[c];
+        fm = 0.5f * reduce_lpr<LPR>(fm);
+        lin = reduce_lpr<LPR>(lin);
+        if (q == 0 && r < 16) {
+            if (g.n_dense > 0) lin += extra[16 + r];
+            const int64_t b = b0 + r;
+            if (b < g.batch) {
+                if (g.fm_logit != nullptr) g.fm_logit[b] = fm;
+                if (g.lin_logit != nullptr) g.lin_logit[b] = lin;
+            }
+            extra[r] = (g.fm_logit_used ? fm : 0.f) + (g.lin_logit_used ? lin : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf0 = smem;
     float* buf1 = smem + 16 * p.lda;
-    float* wbuf0 = smem + 32 * p.lda;
-    float* wbuf1 = wbuf0 + WBUF_FLOATS;
     const int64_t b0 = (int64_t)blockIdx.x * 16;
+    LAB_TS(0);
 
-    // stage the input tile (rows beyond the batch and the K padding are zero).  All global loads of a pass are
-    // issued before the first LDS store: a plain load->store loop serialises ~27 dependent memory round trips.
+    float* extra = smem + 32 * p.lda;                              // [32]: per-row fused logits, dense partials
+    if (fg.lpr != 0) {
+        float* red = extra + 32;
+        const GatherFused& g = fg.g;
+#define DCTR_FUSED(L)                                                              \
+    do {                                                                           \
+        if (g.any_hash) fused_gather_stage<L, true>(p, g, buf0, red, extra, b0);  \
+        else fused_gather_stage<L, false>(p, g, buf0, red, extra, b0);            \
+    } while (0)
+        switch (fg.lpr) {
+            case 1: DCTR_FUSED(1); break;
+            case 2: DCTR_FUSED(2); break;
+            case 4: DCTR_FUSED(4); break;
+            case 8: DCTR_FUSED(8); break;
+            default: DCTR_FUSED(16); break;
+        }
+#undef DCTR_FUSED
+    } else {
+    // stage the input tile (rows beyond the batch and the K padding are zero) into the column-permuted layout.
+    // Division-free mapping: wave w takes rows w, w+NWAVE, ...; lanes walk the float4 groups of a row.  Loads are
+    // unconditional (clamped address, masked afterwards) and all issued before the first LDS store.
     {
-        const int n4 = p.lda / 4;                                  // float4 per LDS row (lda % 4 == 0)
+        const int KQ0 = pad64(p.in_dim) / 4;                       // float4 groups per row incl. zero padding
         const int in4 = (p.in_dim + 3) / 4;
         const bool vec = (p.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0);
-        constexpr int U = 8;
-        for (int base = 0; base < 16 * n4; base += 256 * U) {
-            float4 v[U];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        constexpr int RPW = 16 / NWAVE > 0 ? 16 / NWAVE : 1;       // rows per wave
+        for (int c0 = 0; c0 < KQ0; c0 += 128) {
+            float4 v[RPW][2];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * 256 + threadIdx.x;
-                const int r = idx / n4, c4 = idx % n4;
-                const int64_t b = b0 + r;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < 16 * n4 && b < p.batch && c4 < in4) {
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = (wave + rr * NWAVE) & 15;
+                const int64_t b = min(b0 + r, p.batch - 1);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c4 = min(c0 + h * 64 + lane, in4 - 1);
                     const float* src = p.x + b * p.x_stride + 4 * c4;
                     if (vec) {
-                        v[u] = *reinterpret_cast<const float4*>(src);
+                        v[rr][h] = *reinterpret_cast<const float4*>(src);
                     } else {
-                        v[u].x = src[0];
-                        if (4 * c4 + 1 < p.in_dim) v[u].y = src[1];
-                        if (4 * c4 + 2 < p.in_dim) v[u].z = src[2];
-                        if (4 * c4 + 3 < p.in_dim) v[u].w = src[3];
+                        const int c = 4 * c4, last = p.in_dim - 1;
+                        v[rr][h] = make_float4(src[0], src[min(c + 1, last) - c], src[min(c + 2, last) - c],
+                                               src[min(c + 3, last) - c]);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * 256 + threadIdx.x;
-                if (idx < 16 * n4) {
-                    const int c4 = idx % n4;
-                    float4 t = v[u];
-                    if (4 * c4 + 1 >= p.in_dim) t.y = 0.f;          // never let stride padding of x into the tile
-                    if (4 * c4 + 2 >= p.in_dim) t.z = 0.f;
-                    if (4 * c4 + 3 >= p.in_dim) t.w = 0.f;
-                    if (4 * c4 >= p.in_dim) t.x = 0.f;
-                    *reinterpret_cast<float4*>(buf0 + 4 * idx) = t;
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = wave + rr * NWAVE;
+                const bool rowok = r < 16 && b0 + r < p.batch;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c4 = c0 + h * 64 + lane;
+                    if (r < 16 && c4 < KQ0) {
+                        float4 t = v[rr][h];
+                        if (!rowok || 4 * c4 >= p.in_dim) t.x = 0.f;   // never let stride padding of x into the tile
+                        if (!rowok || 4 * c4 + 1 >= p.in_dim) t.y = 0.f;
+                        if (!rowok || 4 * c4 + 2 >= p.in_dim) t.z = 0.f;
+                        if (!rowok || 4 * c4 + 3 >= p.in_dim) t.w = 0.f;
+                        float* dst = buf0 + r * p.lda + c4;             // columns 4*c4+s -> position s*KQ0 + c4
+                        dst[0] = t.x;
+                        dst[KQ0] = t.y;
+                        dst[2 * KQ0] = t.z;
+                        dst[3 * KQ0] = t.w;
+                    }
                 }
             }
         }
     }
+    }
     __syncthreads();
+    LAB_TS(1);
 
     float* in = buf0;
     float* out = buf1;
@@ -286,13 +434,14 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpParams p) {
     for (int l = 0; l < p.n_layers; ++l) {
         const int N = p.units[l];
         switch (p.activation) {
-            case DCTR_ACT_RELU: layer_dispatch<DCTR_ACT_RELU>(p, l, in, out, wbuf0, wbuf1, K, N); break;
-            case DCTR_ACT_SIGMOID: layer_dispatch<DCTR_ACT_SIGMOID>(p, l, in, out, wbuf0, wbuf1, K, N); break;
-            case DCTR_ACT_TANH: layer_dispatch<DCTR_ACT_TANH>(p, l, in, out, wbuf0, wbuf1, K, N); break;
-            case DCTR_ACT_DICE: layer_dispatch<DCTR_ACT_DICE>(p, l, in, out, wbuf0, wbuf1, K, N); break;
-            default: layer_dispatch<DCTR_ACT_LINEAR>(p, l, in, out, wbuf0, wbuf1, K, N); break;
+            case DCTR_ACT_RELU: layer_dispatch<DCTR_ACT_RELU>(p, l, in, out, K, N); break;
+            case DCTR_ACT_SIGMOID: layer_dispatch<DCTR_ACT_SIGMOID>(p, l, in, out, K, N); break;
+            case DCTR_ACT_TANH: layer_dispatch<DCTR_ACT_TANH>(p, l, in, out, K, N); break;
+            case DCTR_ACT_DICE: layer_dispatch<DCTR_ACT_DICE>(p, l, in, out, K, N); break;
+            default: layer_dispatch<DCTR_ACT_LINEAR>(p, l, in, out, K, N); break;
         }
         __syncthreads();
+        LAB_TS(2 + l);
         float* t = in;
         in = out;
         out = t;
@@ -301,14 +450,16 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpParams p) {
 
     if (p.has_head) {
         // logit[row] = h[row,:] . head_w (+ extra logits + global bias), sigmoid for task == binary
-        const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
+        const int row = (threadIdx.x >> 4) & 15, part = threadIdx.x & 15;
         float acc = 0.f;
-        for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + n], p.head_w[n], acc);
+        const int KQh = pad64(K) / 4;
+        for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);
 #pragma unroll
         for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
         const int64_t b = b0 + row;
-        if (part == 0 && b < p.batch) {
+        if (part == 0 && b < p.batch && threadIdx.x < 256) {
             float v = acc;
+            if (fg.lpr != 0) v += extra[row];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (p.add[i] != nullptr) v += p.add[i][b];
@@ -317,47 +468,37 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpParams p) {
             p.y[b] = v;
         }
     } else {
-        for (int i = threadIdx.x; i < 16 * K; i += 256) {
+        for (int i = threadIdx.x; i < 16 * K; i += NTHR) {
             const int r = i / K, c = i % K;
             const int64_t b = b0 + r;
-            if (b < p.batch) p.y[b * p.y_stride + c] = in[r * p.lda + c];
+            if (b < p.batch) p.y[b * p.y_stride + c] = in[r * p.lda + lds_pos(c, pad64(K) / 4)];
         }
     }
+    LAB_TS(10);
 }
 
-// LDS row stride: every layer reads its input padded to n_chunks*KC columns (zero beyond K)
 int mlp_lda(const dctr_mlp_args_t* a) {
-    int need = (a->in_dim + 15) & ~15;
-    int K = a->in_dim;
-    for (int l = 0; l < a->n_layers; ++l) {
-        const int N = a->units[l];
-        int kc = (WBUF_FLOATS / N) & ~15;
-        const int kp = (K + 15) & ~15;
-        kc = kc < kp ? kc : kp;
-        const int padded = ((K + kc - 1) / kc) * kc;
-        need = padded > need ? padded : need;
-        need = N > need ? N : need;
-        K = N;
-    }
-    return ((need + 15) & ~15) + 4;
+    int w = a->in_dim;
+    for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
+    return ((w + 63) & ~63) + 4;
 }
 
 }  // namespace
 
 extern "C" size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t*) { return 0; }  // activations live in LDS
 
-extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) {
+static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_fwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->in_dim >= 1 && a->n_layers >= 0 && a->n_layers <= MAX_LAYERS, DCTR_E_DIM,
                  "mlp_fwd: bad sizes (batch=%lld in_dim=%d layers=%d, max %d layers)", (long long)a->batch, a->in_dim,
                  a->n_layers, MAX_LAYERS);
     if (a->batch == 0) return DCTR_OK;
-    DCTR_REQUIRE(a->x && a->y, DCTR_E_NULL, "mlp_fwd: null x / y");
+    DCTR_REQUIRE((ga != nullptr || a->x) && a->y, DCTR_E_NULL, "mlp_fwd: null x / y");
     DCTR_REQUIRE(a->n_layers == 0 || (a->units && a->kernels && a->biases), DCTR_E_NULL, "mlp_fwd: null layer arrays");
     DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_DICE, DCTR_E_ENUM, "mlp_fwd: activation %d",
                  a->activation);
     DCTR_REQUIRE(!a->has_head || a->head_w, DCTR_E_NULL, "mlp_fwd: has_head without head_w");
-    if (a->activation == DCTR_ACT_DICE)
+    if (a->activation == DCTR_ACT_DICE && a->n_layers > 0)
         DCTR_REQUIRE(a->dice_alpha && a->dice_mean && a->dice_var, DCTR_E_NULL, "mlp_fwd: dice without parameters");
     MlpParams p{};
     p.x = a->x;
@@ -366,8 +507,7 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) {
     p.in_dim = a->in_dim;
     p.n_layers = a->n_layers;
     for (int l = 0; l < a->n_layers; ++l) {
-        DCTR_REQUIRE(a->units[l] >= 1 && a->units[l] <= 512, DCTR_E_UNSUPPORTED,
-                     "mlp_fwd: units[%d]=%d outside [1, 512] (one 32-KB weight chunk must hold >= 16 rows)", l, a->units[l]);
+        DCTR_REQUIRE(a->units[l] >= 1, DCTR_E_DIM, "mlp_fwd: units[%d]=%d", l, a->units[l]);
         DCTR_REQUIRE(a->kernels[l] != nullptr, DCTR_E_NULL, "mlp_fwd: kernels[%d] null", l);
         DCTR_REQUIRE(dctr_aligned16(a->kernels[l]), DCTR_E_ALIGN, "mlp_fwd: kernels[%d] not 16-B aligned", l);
         p.units[l] = a->units[l];
@@ -390,14 +530,46 @@ extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) {
     p.y = a->y;
     p.y_stride = a->y_stride;
     p.lda = mlp_lda(a);
-    const size_t lds = ((size_t)2 * 16 * p.lda + 2 * WBUF_FLOATS) * sizeof(float);
+    FusedGather fg{};
+    size_t red_floats = 0;
+    if (ga != nullptr) {
+        DCTR_REQUIRE(ga->batch == a->batch, DCTR_E_DIM, "embed_mlp_fwd: gather batch %lld != mlp batch %lld",
+                     (long long)ga->batch, (long long)a->batch);
+        DCTR_REQUIRE(ga->n_fields >= 1 && ga->fields && ga->ids, DCTR_E_NULL, "embed_mlp_fwd: needs >= 1 gather field");
+        DCTR_REQUIRE(ga->all_dim4 && ga->max_dim >= 1 && ga->max_dim <= 64, DCTR_E_UNSUPPORTED,
+                     "embed_mlp_fwd: fused path needs every embedding_dim %% 4 == 0 and <= 64 (got max_dim %d, all_dim4 %d)",
+                     ga->max_dim, ga->all_dim4);
+        DCTR_REQUIRE(ga->n_dense == 0 || (ga->dense && ga->dense_stride >= ga->n_dense), DCTR_E_NULL,
+                     "embed_mlp_fwd: bad dense matrix");
+        DCTR_REQUIRE(ga->dense_copy_cols >= 0 && ga->dense_copy_cols <= ga->n_dense, DCTR_E_DIM,
+                     "embed_mlp_fwd: dense_copy_cols outside [0, n_dense]");
+        static_cast<dctr_gather_fm_args_t&>(fg.g) = *ga;
+        fg.g.fm_logit_used = fm_used;
+        fg.g.lin_logit_used = lin_used;
+        int lpr = 1;
+        while (lpr * 4 < ga->max_dim) lpr <<= 1;
+        fg.lpr = lpr;
+        const int passes = (64 / lpr) >= 16 ? 1 : 16 / (64 / lpr);
+        red_floats = (size_t)NWAVE * passes * 9 * 64;
+    }
+    const size_t lds = ((size_t)2 * 16 * p.lda + 32 + red_floats) * sizeof(float);
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "mlp_fwd: layer width needs %zu B of LDS (> 160 KiB)", lds);
-    {
+    if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_fwd: cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
     }
     const int64_t blocks = dctr_ceil_div(a->batch, 16);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
-    DCTR_LAUNCH(mlp_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    DCTR_LAUNCH(mlp_kernel, dim3((unsigned)blocks), dim3(NTHR), lds, (hipStream_t)stream, p, fg);
     return dctr_launch_status("dctr_mlp_fwd");
+}
+
+extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) { return mlp_launch(a, nullptr, 0, 0, stream); }
+
+extern "C" int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit,
+                                  int32_t add_lin_logit, void* stream) {
+    DCTR_REQUIRE(g != nullptr && m != nullptr, DCTR_E_NULL, "embed_mlp_fwd: null args");
+    DCTR_REQUIRE(m->has_head || (!add_fm_logit && !add_lin_logit), DCTR_E_DIM,
+                 "embed_mlp_fwd: the gather logits can only be added by the fused head");
+    return mlp_launch(m, g, add_fm_logit ? 1 : 0, add_lin_logit ? 1 : 0, stream);
 }

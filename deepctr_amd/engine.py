@@ -324,29 +324,53 @@ class EmbeddingStage(object):
         ops.embed_pool(ids, table, fc.combiner, length=length, weight=weight, weight_norm=fc.weight_norm,
                        lin_table=lin_table, hash_mode=hm, out=out, out_stride=out.stride(0), lin_out=lin_out, status=status)
 
-    def run(self, staged, lo, hi):
-        """Launch the pooling kernels and the fused gather for rows [lo, hi).  Returns the workspace dict:
-        'dnn_in' [B, out_stride], 'lin' [B] (None-equivalent when the model has no linear part), 'fm' [B]."""
+    def gather_args(self, staged, lo, hi, ws, to_hbm=True):
+        """dctr_gather_fm_args_t for rows [lo, hi) (pooled fields must already be in the workspace)."""
         B = hi - lo
-        ws = self.workspace(B)
+        nf = len(self.fields)
+        ids = staged.ids[:, lo:hi] if staged.ids is not None else None
+        dense = staged.dense[lo:hi] if staged.dense is not None else None
+        return ops.make_gather_args(ws["desc"], nf, ids, staged.ids.stride(0) if ids is not None else 0, 1, B, self.max_dim,
+                                    self.all_dim4, self.any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
+                                    dense_out_offset=self.dense_offset if self.n_dense_dnn else -1,
+                                    dense_copy_cols=self.n_dense_dnn, dnn_in=ws["dnn_in"] if to_hbm else None,
+                                    out_stride=self.out_stride,
+                                    fm_logit=ws["fm"] if (self.fm_group_names and to_hbm) else None,
+                                    lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"])
+
+    def run_pools(self, staged, lo, hi):
+        ws = self.workspace(hi - lo)
         st = ws["status"]
         for f in self.pooled_fields:
             self._pool(f.fc, staged, lo, hi, f.table, f.lin_table.reshape(-1) if f.lin_table is not None else None,
                        ws["pooled"][f.fc.name], ws["pooled_lin"].get(f.fc.name), st)
+        return ws
+
+    @property
+    def fusable(self):
+        """Can dctr_embed_mlp_fwd produce the DNN input in LDS (no dnn_in in HBM)?"""
+        return (len(self.fields) > 0 and self.all_dim4 and self.max_dim <= 64 and len(self.fm_group_names) <= 1
+                and not self.extra_offsets)
+
+    def run(self, staged, lo, hi):
+        """Launch the pooling kernels and the fused gather for rows [lo, hi).  Returns the workspace dict:
+        'dnn_in' [B, out_stride], 'lin' [B] (None-equivalent when the model has no linear part), 'fm' [B]."""
+        B = hi - lo
+        ws = self.run_pools(staged, lo, hi)
+        st = ws["status"]
         nf = len(self.fields)
-        ids = staged.ids[:, lo:hi] if staged.ids is not None else None
-        dense = staged.dense[lo:hi] if staged.dense is not None else None
-        ops.embed_gather_fm(ws["desc"], nf, ids, staged.ids.stride(0) if ids is not None else 0, 1, B, self.max_dim,
-                            self.all_dim4, self.any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
-                            dense_out_offset=self.dense_offset if self.n_dense_dnn else -1, dense_copy_cols=self.n_dense_dnn,
-                            dnn_in=ws["dnn_in"], out_stride=self.out_stride,
-                            fm_logit=ws["fm"] if self.fm_group_names else None,
-                            lin_logit=ws["lin"] if self.has_linear else None, status=st)
+        a = self.gather_args(staged, lo, hi, ws)
+        _C.check(_C.lib().dctr_embed_gather_fm(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
         ws["fm_extra"] = []
         for g in self.fm_group_names[1:]:       # further FM groups read their slice of dnn_in in place
             first, n, dim = self.group_slices[g]
             ws["fm_extra"].append(ops.fm_strided(ws["dnn_in"], first, n, dim))
+        self.run_lin_only(staged, lo, hi, ws)
+        return ws
+
+    def run_lin_only(self, staged, lo, hi, ws):
         if self.lin_only:
+            B, nf, st = hi - lo, len(self.fields), ws["status"]
             for fc in self.lin_only:
                 if isinstance(fc, VarLenSparseFeat):
                     lt = self.linear_tables[fc.embedding_name].embeddings
@@ -354,7 +378,6 @@ class EmbeddingStage(object):
             ids2 = staged.ids[nf:, lo:hi]
             ops.embed_gather_fm(ws["desc2"], ws["n_fields2"], ids2, staged.ids.stride(0), 1, B, 1, False, ws["any_hash2"],
                                 lin_logit=ws["lin2"], status=st)
-        return ws
 
 
 # ---------------------------------------------------------------------------------------------------

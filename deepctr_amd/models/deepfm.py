@@ -26,8 +26,20 @@ class _DeepFM(FeatureModel):
             last = dnn_hidden_units[-1] if len(dnn_hidden_units) else self.stage_plan.in_dim
             self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(last))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
+        self.fused = True        # use dctr_embed_mlp_fwd when the plan allows it (set False for the 2-launch path)
 
     def _forward(self, staged, lo, hi, out):
+        sp = self.stage_plan
+        if sp.fusable and self.fused:
+            # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
+            ws = sp.run_pools(staged, lo, hi)
+            sp.run_lin_only(staged, lo, hi, ws)
+            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
+            ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+                    head_w=self.dense.w('kernel'), add=[ws["lin2"]] if "lin2" in ws else [],
+                    global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
+                    out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo)
+            return
         ws = self.stage_plan.run(staged, lo, hi)
         add = self._logits_to_add(ws)
         if self.stage_plan.fm_group_names:

@@ -195,12 +195,10 @@ def make_field_descriptors(fields, device):
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
-def embed_gather_fm(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
-                    dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0, fm_logit=None,
-                    lin_logit=None, status=None):
-    """Fused multi-table gather + concat + linear term + FM (see include/dctr.h).  Low-level: the caller
-    (the model plan) owns descriptor and output buffers."""
-    lib = _C.lib()
+def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
+                     dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0,
+                     fm_logit=None, lin_logit=None, status=None):
+    """Fill a dctr_gather_fm_args_t (see include/dctr.h).  The caller keeps every tensor alive."""
     _dev_check(desc, ids, dense, dnn_in)
     is64 = 0
     if ids is not None:
@@ -209,19 +207,25 @@ def embed_gather_fm(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_
         elif ids.dtype != torch.int32:
             raise TypeError("ids must be int32 or int64")
     n_dense = 0 if dense is None else dense.shape[1]
-    a = _C.GatherFmArgs(fields=None if desc is None else desc.data_ptr(), ids=None if ids is None else ids.data_ptr(),
-                        ids_stride_f=ids_stride_f, ids_stride_b=ids_stride_b, ids_is_i64=is64, n_fields=n_fields,
-                        max_dim=max_dim, all_dim4=int(bool(all_dim4)), any_hash=int(bool(any_hash)), n_dense=n_dense,
-                        dense=None if dense is None else dense.data_ptr(),
-                        dense_stride=0 if dense is None else dense.stride(0),
-                        dense_lin_w=None if dense_lin_w is None else dense_lin_w.data_ptr(),
-                        dense_out_offset=dense_out_offset,
-                        dense_copy_cols=n_dense if dense_copy_cols is None else dense_copy_cols, batch=batch,
-                        dnn_in=None if dnn_in is None else dnn_in.data_ptr(), out_stride=out_stride,
-                        fm_logit=None if fm_logit is None else fm_logit.data_ptr(),
-                        lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
-                        status=None if status is None else status.data_ptr())
-    _C.check(lib.dctr_embed_gather_fm(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+    return _C.GatherFmArgs(fields=None if desc is None else desc.data_ptr(), ids=None if ids is None else ids.data_ptr(),
+                           ids_stride_f=ids_stride_f, ids_stride_b=ids_stride_b, ids_is_i64=is64, n_fields=n_fields,
+                           max_dim=max_dim, all_dim4=int(bool(all_dim4)), any_hash=int(bool(any_hash)), n_dense=n_dense,
+                           dense=None if dense is None else dense.data_ptr(),
+                           dense_stride=0 if dense is None else dense.stride(0),
+                           dense_lin_w=None if dense_lin_w is None else dense_lin_w.data_ptr(),
+                           dense_out_offset=dense_out_offset,
+                           dense_copy_cols=n_dense if dense_copy_cols is None else dense_copy_cols, batch=batch,
+                           dnn_in=None if dnn_in is None else dnn_in.data_ptr(), out_stride=out_stride,
+                           fm_logit=None if fm_logit is None else fm_logit.data_ptr(),
+                           lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
+                           status=None if status is None else status.data_ptr())
+
+
+def embed_gather_fm(*args, **kwargs):
+    """Fused multi-table gather + concat + linear term + FM (see include/dctr.h).  Low-level: the caller
+    (the model plan) owns descriptor and output buffers.  Same arguments as ``make_gather_args``."""
+    a = make_gather_args(*args, **kwargs)
+    _C.check(_C.lib().dctr_embed_gather_fm(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -332,17 +336,20 @@ def inner_product(x, reduce_sum=True):
 # adjacent: DNN (+ head), DIN attention
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
-        sigmoid_out=False, in_dim=None, out=None):
+        sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'."""
     _dev_check(x, *kernels, *biases)
-    if x.dim() != 2:
-        raise ValueError("mlp expects a 2-D input")
-    if x.dtype != torch.float32 or x.stride(1) != 1:
-        x = _f32c(x, "x")
-    B = x.shape[0]
-    in_dim = x.shape[1] if in_dim is None else in_dim
+    if gather is None:
+        if x.dim() != 2:
+            raise ValueError("mlp expects a 2-D input")
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            x = _f32c(x, "x")
+        B = x.shape[0]
+        in_dim = x.shape[1] if in_dim is None else in_dim
+    else:       # fused path: the input tile is gathered inside the kernel (dctr_embed_mlp_fwd)
+        B = int(batch)
     n = len(kernels)
     units = [k.shape[1] for k in kernels]
     kernels = [_f32c(k, "kernel") for k in kernels]
@@ -351,7 +358,8 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
     has_head = head_w is not None
     last = units[-1] if n else in_dim
     if out is None:
-        out = torch.empty((B,) if has_head else (B, last), dtype=torch.float32, device=x.device)
+        dev_t = x if x is not None else (kernels[0] if kernels else head_w)
+        out = torch.empty((B,) if has_head else (B, last), dtype=torch.float32, device=dev_t.device)
     add = [a_ for a_ in add if a_ is not None]
     if len(add) > 4:
         raise ValueError("at most four extra logit vectors can be fused into the head")
@@ -365,7 +373,8 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
         dm = _ptr_array([_f32c(d[1], "mean") for d in dice])
         dv = _ptr_array([_f32c(d[2], "var") for d in dice])
     ua, kp, bp = _i32_array(units), _ptr_array(kernels), _ptr_array(biases)
-    a = _C.MlpArgs(x=x.data_ptr(), batch=B, x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
+    a = _C.MlpArgs(x=None if gather is not None else x.data_ptr(), batch=B,
+                   x_stride=0 if gather is not None else x.stride(0), in_dim=in_dim, n_layers=n,
                    units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
                    biases=ctypes.cast(bp, ctypes.c_void_p), activation=act, has_head=int(has_head),
                    dice_alpha=None if da is None else ctypes.cast(da, ctypes.c_void_p),
@@ -376,7 +385,11 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    add=add_arr,
                    global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
                    y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0)
-    _C.check(_C.lib().dctr_mlp_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_fwd")
+    if gather is not None:
+        _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(gather), ctypes.byref(a), int(bool(add_fm_logit)),
+                                             int(bool(add_lin_logit)), _C.stream_ptr()), "dctr_embed_mlp_fwd")
+    else:
+        _C.check(_C.lib().dctr_mlp_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_fwd")
     del keep
     return out
 

@@ -257,6 +257,17 @@ size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
 int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a3-a8 + DNN fused: dctr_embed_gather_fm feeding dctr_mlp_fwd inside ONE launch.  The DNN-input tile is gathered
+ * straight into LDS (g->dnn_in is ignored; m->x is ignored; m->in_dim must equal the gathered row width =
+ * sum of the fields' dims at their out_offsets + dense_copy_cols), and the gather's FM / linear logits are added to
+ * the head when the flags say so (they are also written to g->fm_logit / g->lin_logit when those are non-NULL).
+ * Requirements: g->all_dim4, embedding_dim <= 64.  This is DeepFM's whole forward as a single kernel
+ * (deepctr/models/deepfm.py:42-65).
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit,
+                       int32_t add_lin_logit, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a13 AttentionSequencePoolingLayer.call + LocalActivationUnit.call (DIN)
  *     deepctr/layers/sequence.py:261-298, layers/core.py:94-108, activation.py:59-64.
  *     query [B,E]; keys [B,T,E]; key_mask [B,T] bytes; att MLP over [q,k,q-k,q*k] (4E -> h1 -> .. -> 1)

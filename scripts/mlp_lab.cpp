@@ -9,7 +9,7 @@ int main(int argc, char** argv) {
     const int dims[4] = {429, 256, 128, 64};
     float *x, *y, *W[3], *bias[3], *head;
     CK(hipMalloc(&x, (size_t)B * 432 * 4)); CK(hipMalloc(&y, B * 4)); CK(hipMemset(x, 0, (size_t)B * 432 * 4));
-    for (int l = 0; l < 3; ++l) { CK(hipMalloc(&W[l], (size_t)dims[l] * dims[l + 1] * 4)); CK(hipMemset(W[l], 0, (size_t)dims[l] * dims[l + 1] * 4)); CK(hipMalloc(&bias[l], dims[l + 1] * 4)); CK(hipMemset(bias[l], 0, dims[l + 1] * 4)); }
+    for (int l = 0; l < 3; ++l) { CK(hipMalloc(&W[l], (size_t)110080 * 4 * 33)); CK(hipMemset(W[l], 0, (size_t)110080 * 4 * 33)); CK(hipMalloc(&bias[l], dims[l + 1] * 4)); CK(hipMemset(bias[l], 0, dims[l + 1] * 4)); }
     CK(hipMalloc(&head, 64 * 4)); CK(hipMemset(head, 0, 256));
     int32_t units[3] = {256, 128, 64};
     const float* ks[3] = {W[0], W[1], W[2]}; const float* bs[3] = {bias[0], bias[1], bias[2]};
@@ -25,6 +25,13 @@ int main(int argc, char** argv) {
         float ms = dctr_profile_last_ms();
         if (r >= 20) t.push_back(ms * 1000.f);
     }
+#ifdef DCTR_LAB_TIMING
+    {
+        unsigned long long ts[64];
+        CK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(dctr_lab_ts), sizeof(ts)));
+        printf("cycles: stage %llu  L0 %llu  L1 %llu  L2 %llu  head %llu  total %llu\n", ts[1]-ts[0], ts[2]-ts[1], ts[3]-ts[2], ts[4]-ts[3], ts[10]-ts[4], ts[10]-ts[0]);
+    }
+#endif
     std::sort(t.begin(), t.end());
     printf("%-24s B=%d  median %.2f us  min %.2f us\n", LABNAME, B, t[t.size() / 2], t[0]);
     return 0;

@@ -181,3 +181,26 @@ def test_weights_roundtrip_and_layer_access(device, tmp_path):
     assert (other2.predict(feed) == y0).all()
     emb = model.get_layer("sparse_emb_C1").get_weights()[0]          # docs/source/FAQ.md:81-90
     assert emb.shape == (30, 4)
+
+
+def test_deepfm_fused_launch_matches_two_launch_path(device):
+    """dctr_embed_mlp_fwd (gather -> LDS tile -> DNN in one launch) against dctr_embed_gather_fm + dctr_mlp_fwd,
+    incl. hashed ids, a pooled sequence feature, ragged batch and E = 8 / 16 / 32."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(11)
+    for E, n, hashed in ((16, 4096 + 5, False), (32, 300, True), (8, 77, False), (4, 50, True)):
+        cols = [SparseFeat("C%d" % i, 500, E, use_hash=(hashed and i % 2 == 0)) for i in range(26)] + \
+               [DenseFeat("I%d" % i, 1) for i in range(13)] + [VarLenSparseFeat(SparseFeat("tags", 40, E), maxlen=5)]
+        feed = {"C%d" % i: rng.randint(0, 10 ** 6 if (hashed and i % 2 == 0) else 500, n).astype(np.int32) for i in range(26)}
+        feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(13)})
+        feed["tags"] = rng.randint(0, 40, (n, 5)).astype(np.int32)
+        model = DeepFM(cols, cols, dnn_hidden_units=(64, 32), device=device)
+        w = _randomise(model, rng)
+        assert model.stage_plan.fusable and model.fused
+        y1 = model.predict(feed, batch_size=4096)
+        model.fused = False
+        y2 = model.predict(feed, batch_size=4096)
+        check_probs(y1, y2, "fused vs two-launch E=%d" % E)
+        ref = RM.deepfm(cols, cols, w, feed, dnn_hidden_units=(64, 32), dtype=np.float64)
+        check_probs(y1, ref.astype(np.float32), "fused vs oracle E=%d" % E)
