@@ -6,21 +6,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the whole hot path over ONE batch of 4096 rows per GPU: ids -> fused multi-table gather
-+ linear term + FM (``dctr_embed_gather_fm``) -> DNN 429-256-128-64 + Dense(1) + logit sum + sigmoid
-(``dctr_mlp_fwd``).  Nothing is skipped, inputs are device-resident before the timed region, every step reads
-a DIFFERENT batch of ids (a ring of --ring batches, so rows are not L2-hot from the previous step).  The K timed
-steps are captured in one hipGraph (the per-step host cost of two ctypes calls would otherwise dominate a ~15 us
-step); the timed region is bracketed by barrier + synchronize, MAX over ranks.
+A "step" = one pass of the whole hot path over ONE batch of 4096 rows per GPU: ids -> multi-table gather + linear
+term + FM -> DNN 429-256-128-64 + Dense(1) + logit sum + sigmoid, as ONE launch (``dctr_embed_mlp_fwd``: the DNN
+input tile is gathered straight into LDS).  Nothing is skipped, inputs are device-resident before the timed region,
+every step reads a DIFFERENT batch of ids (a ring of --ring batches, so rows are not L2-hot from the previous
+step).  The K timed steps are captured in one hipGraph (the host cost of a ctypes call would otherwise dominate a
+~20 us step) with --streams independent batches in flight; the timed region is bracketed by barrier +
+synchronize, MAX over ranks.
 
 Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free; the final logits of the
 K steps are all-gathered ONCE (RCCL) inside the timed region — the path's only exchange.
 
 Extra objects on the JSON line:
-  roofline      the HBM-bound kernel of the path (fused gather+linear+FM): algorithmic bytes per launch
-                (1,928 B/sample) / its mean dispatch duration, measured with per-dispatch
-                start/stop events (hipExtLaunchKernelGGL; same quantity rocprofv3 --kernel-trace reports).
-  kernels       the same for every kernel of the step (the DNN kernel is MFMA-bound: fp32 matrix peak 157.3 TF).
+  roofline      the dominant kernel of the timed step = the fused gather+DNN kernel.  It is bound by the fp32
+                matrix pipe (301,696 DNN FLOP/sample against 1,928 algorithmic HBM bytes/sample): achieved TFLOP/s =
+                algorithmic FLOP per launch / mean dispatch duration (per-dispatch start/stop events via
+                hipExtLaunchKernelGGL = the quantity rocprofv3 --kernel-trace reports), peak 157.3 TF; its HBM
+                figure (algorithmic bytes / the same duration, of 8 TB/s) is reported next to it as hbm_frac.
+  kernels       the same for the two stand-alone kernels of the unfused path: gather_fm_kernel (the HBM-bound
+                kernel north_star names: 1,928 B/sample) and mlp_kernel (MFMA-bound).
   cpu_baseline  the oracle's torch-CPU restatement of the reference op sequence timed on the host cores
                 (rank 0, N=1 only; TensorFlow itself is not installable here — BASELINE.md §4).
 """
@@ -130,6 +134,8 @@ def main():
     ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of one hipGraph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent batches in flight: step i is enqueued on stream i %% streams (fused 1-launch path only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,15 +171,26 @@ def main():
         step(i, scratch)
     torch.cuda.synchronize()
 
+    # Consecutive steps are independent batches.  With the 1-launch fused path a step touches no shared scratch, so
+    # step i goes to stream i % n_streams: the gather phase (latency-bound) of one batch overlaps the MFMA phase of
+    # the previous one on the same CU (the kernel is sized for two co-resident workgroups per CU).
+    fused = bool(model.stage_plan.fusable and model.fused and not model.stage_plan.pooled_fields and not model.stage_plan.lin_only)
+    n_streams = max(1, args.streams) if fused else 1
     graph = None
     if not args.no_graph and K > 0:
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device)
+        branches = [side] + [torch.cuda.Stream(device) for _ in range(n_streams - 1)]
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
+                for br in branches[1:]:
+                    br.wait_stream(side)                       # fork
                 for i in range(K):
-                    step(i, logits[i * B:(i + 1) * B])
+                    with torch.cuda.stream(branches[i % n_streams]):
+                        step(i, logits[i * B:(i + 1) * B])
+                for br in branches[1:]:
+                    side.wait_stream(br)                       # join
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
@@ -243,7 +260,8 @@ def main():
                                    "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, "
                                    "ring of %d distinct batches, %s, %s" % (
                                        ring, "1 hipGraph of K steps" if graph else "eager",
-                                       "1 launch/step (fused gather+DNN)" if t_fused is not None else "2 launches/step"),
+                                       ("1 launch/step (fused gather+DNN), %d batches in flight" % n_streams)
+                                       if t_fused is not None else "2 launches/step"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "row-sharded x%d, tables replicated" % world},
             "roofline": roofline, "kernels": kernels,
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,

@@ -224,9 +224,10 @@ __device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const flo
 
 template <int ACT>
 __device__ __forceinline__ void layer_dispatch(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
-    // widest column slice per wave that still gives every wave of the workgroup a tile
-    if (N % 64 == 0 && N >= 64 * NWAVE) layer_tiles<4, ACT>(p, l, in, out, K, N);
-    else if (N % 32 == 0 && N >= 32 * NWAVE) layer_tiles<2, ACT>(p, l, in, out, K, N);
+    // widest column slice per wave that still gives every wave of the workgroup a tile.  TPW = 4 (96 B-operand
+    // registers in the 3-stage pipeline) would push the kernel past 128 VGPRs, i.e. below 4 waves per SIMD = two
+    // co-resident workgroups per CU, so 32 columns per wave is the widest slice.
+    if (N % 32 == 0 && N >= 32 * NWAVE) layer_tiles<2, ACT>(p, l, in, out, K, N);
     else layer_tiles<1, ACT>(p, l, in, out, K, N);
 }
 
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) 
 
     float* extra = smem + 32 * p.lda;                              // [32]: per-row fused logits, dense partials
     if (fg.lpr != 0) {
-        float* red = extra + 32;
+        float* red = buf1;                                         // partial sums live in the (still unused) 2nd tile
         const GatherFused& g = fg.g;
 #define DCTR_FUSED(L)                                                              \
     do {                                                                           \
@@ -550,9 +551,11 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         while (lpr * 4 < ga->max_dim) lpr <<= 1;
         fg.lpr = lpr;
         const int passes = (64 / lpr) >= 16 ? 1 : 16 / (64 / lpr);
-        red_floats = (size_t)NWAVE * passes * 9 * 64;
+        red_floats = (size_t)NWAVE * passes * 9 * 64;           // aliases the second activation tile
+        DCTR_REQUIRE(red_floats <= (size_t)16 * p.lda, DCTR_E_UNSUPPORTED,
+                     "embed_mlp_fwd: layer widths too small to hold the gather partial sums (%zu floats)", red_floats);
     }
-    const size_t lds = ((size_t)2 * 16 * p.lda + 32 + red_floats) * sizeof(float);
+    const size_t lds = ((size_t)2 * 16 * p.lda + 32) * sizeof(float);
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "mlp_fwd: layer width needs %zu B of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

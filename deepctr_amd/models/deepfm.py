@@ -26,7 +26,16 @@ class _DeepFM(FeatureModel):
             last = dnn_hidden_units[-1] if len(dnn_hidden_units) else self.stage_plan.in_dim
             self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(last))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
-        self.fused = True        # use dctr_embed_mlp_fwd when the plan allows it (set False for the 2-launch path)
+        # use dctr_embed_mlp_fwd when the plan allows it (set False for the 2-launch path); the gather's partial sums
+        # alias the second 16-row activation tile in LDS, which must be large enough for them
+        sp = self.stage_plan
+        width = max([sp.in_dim] + list(dnn_hidden_units))
+        lda = (width + 63) // 64 * 64 + 4
+        lpr = 1
+        while lpr * 4 < sp.max_dim:
+            lpr *= 2
+        passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
+        self.fused = bool(sp.fusable and 8 * passes * 9 * 64 <= 16 * lda)
 
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
