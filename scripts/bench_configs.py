@@ -1,0 +1,126 @@
+"""Throughput of the other BASELINE.json configs on one MI355X (reported in BASELINE.md §5; bench.py stays on
+configs[1]).  Forward only, device-resident synthetic inputs, eager per-batch launches timed with events over
+--steps batches (a ring of distinct batches)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat  # noqa: E402
+from deepctr_amd.models import DCN, DIN, DeepFM, xDeepFM  # noqa: E402
+
+
+def init_on_device(model, seed=0):
+    g = torch.Generator(device=model.device).manual_seed(seed)
+    with torch.no_grad():
+        for name, t in model.named_weights():
+            if name.endswith("embeddings"):
+                std = 0.1 if t.shape[-1] == 1 else 0.05
+            elif "moving_variance" in name:
+                t.fill_(1.0)
+                continue
+            elif "bias" in name or "moving_mean" in name or "alpha" in name:
+                std = 0.05
+            else:
+                std = float((2.0 / sum(t.shape[-2:])) ** 0.5) if t.dim() >= 2 else 0.05
+            t.normal_(0.0, std, generator=g)
+
+
+def criteo(rng, rows, F=26, V=100000, ND=13):
+    feed = {"C%d" % i: rng.randint(0, V, rows).astype(np.int32) for i in range(1, F + 1)}
+    feed.update({"I%d" % i: rng.rand(rows).astype(np.float32) for i in range(1, ND + 1)})
+    return feed
+
+
+def run(name, model, feed, B, steps, ring):
+    staged = model.stage(feed)
+    model._begin()
+    out = torch.empty(B, device=model.device)
+    for i in range(min(ring, 8)):
+        model._forward(staged, (i % ring) * B, (i % ring) * B + B, out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(model.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for i in range(steps):
+                model._forward(staged, (i % ring) * B, (i % ring) * B + B, out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    model._check_status()
+    print("%-34s B=%-6d %9.2f us/batch  %10.2f M samples/s" % (name, B, dt * 1e6, B / dt / 1e6), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="c2,c2_2launch,c3,dcn_v,dcn_m,c4,c5")
+    ap.add_argument("--steps", type=int, default=64)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(0)
+    ring = 16
+    want = args.configs.split(",")
+    cols16 = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
+    if "c2" in want or "c2_2launch" in want:
+        m = DeepFM(cols16, cols16, device=dev)
+        init_on_device(m)
+        feed = criteo(rng, ring * 4096)
+        if "c2" in want:
+            run("C2 DeepFM (1 launch/step)", m, feed, 4096, args.steps, ring)
+        if "c2_2launch" in want:
+            m.fused = False
+            run("C2 DeepFM (2 launches/step)", m, feed, 4096, args.steps, ring)
+        del m
+    if "c3" in want:
+        m = xDeepFM(cols16, cols16, cin_layer_size=(128, 128), device=dev)
+        init_on_device(m)
+        run("C3 xDeepFM CIN[128,128]", m, criteo(rng, ring * 4096), 4096, args.steps, ring)
+        del m
+    for par, tag in (("vector", "dcn_v"), ("matrix", "dcn_m")):
+        if tag in want:
+            m = DCN(cols16, cols16, cross_num=2, cross_parameterization=par, device=dev)
+            init_on_device(m)
+            run("DCN cross_num=2 %s" % par, m, criteo(rng, ring * 4096), 4096, args.steps, ring)
+            del m
+    if "c4" in want:
+        T, E, B = 50, 32, 2048
+        cols = [SparseFeat("user", 100000, E), SparseFeat("gender", 2, E), SparseFeat("item_id", 1000001, E),
+                SparseFeat("cate_id", 10001, E), DenseFeat("pay_score", 1),
+                VarLenSparseFeat(SparseFeat("hist_item_id", 1000001, E, embedding_name="item_id"), maxlen=T),
+                VarLenSparseFeat(SparseFeat("hist_cate_id", 10001, E, embedding_name="cate_id"), maxlen=T)]
+        n = ring * B
+        lens = rng.randint(1, T + 1, n)
+        hi = rng.randint(1, 1000001, (n, T)).astype(np.int32)
+        hc = rng.randint(1, 10001, (n, T)).astype(np.int32)
+        pad = np.arange(T)[None, :] >= lens[:, None]
+        hi[pad] = 0
+        hc[pad] = 0
+        feed = {"user": rng.randint(0, 100000, n).astype(np.int32), "gender": rng.randint(0, 2, n).astype(np.int32),
+                "item_id": rng.randint(1, 1000001, n).astype(np.int32), "cate_id": rng.randint(1, 10001, n).astype(np.int32),
+                "pay_score": rng.rand(n).astype(np.float32), "hist_item_id": hi, "hist_cate_id": hc}
+        m = DIN(cols, ["item_id", "cate_id"], device=dev)
+        init_on_device(m)
+        run("C4 DIN T=50 E=32 (dice)", m, feed, B, args.steps, ring)
+        del m
+    if "c5" in want:
+        V, E, B = 10 ** 7, 32, 8192
+        cols = [SparseFeat("C%d" % i, V, E) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
+        t0 = time.time()
+        m = DeepFM(cols, cols, device=dev)
+        init_on_device(m)
+        torch.cuda.synchronize()
+        print("C5 tables: %.1f GB allocated+initialised in %.0f s" % (torch.cuda.memory_allocated() / 1e9, time.time() - t0), flush=True)
+        run("C5 DeepFM vocab 1e7 E=32 (1 GPU shard)", m, criteo(rng, ring * B, V=V), B, args.steps, ring)
+
+
+if __name__ == "__main__":
+    main()
