@@ -148,7 +148,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run: always take the rank path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -160,7 +160,7 @@ def main():
     staged = model.stage(synthetic_feed(ring * B, 1000 + rank))       # device-resident before timing
     model._begin()
     logits = torch.empty(max(K, 1) * B, dtype=torch.float32, device=device)
-    gathered = torch.empty(world * logits.numel(), dtype=torch.float32, device=device) if world > 1 else None
+    gathered = torch.empty(world * logits.numel(), dtype=torch.float32, device=device) if dist is not None else None
 
     def step(i, out):
         lo = (i % ring) * B
