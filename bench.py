@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of one hipGraph")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent batches in flight: step i is enqueued on stream i %% streams (fused 1-launch path only)")
+    ap.add_argument("--tile-rows", type=int, default=0,
+                    help="batch rows per workgroup of the fused kernel (0 = library default, 16, 32); same bits")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +158,7 @@ def main():
     from deepctr_amd import _C
     _C.lib()
     model, cols = build_model(device)
+    model.tile_rows = args.tile_rows
     K, W, ring = args.steps, args.warmup, max(1, min(args.ring, max(args.steps, 1)))
     staged = model.stage(synthetic_feed(ring * B, 1000 + rank))       # device-resident before timing
     model._begin()
@@ -260,7 +263,7 @@ def main():
                                    "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, "
                                    "ring of %d distinct batches, %s, %s" % (
                                        ring, "1 hipGraph of K steps" if graph else "eager",
-                                       ("1 launch/step (fused gather+DNN), %d batches in flight" % n_streams)
+                                       ("1 launch/step (fused gather+DNN), %d batches in flight, tile_rows %d" % (n_streams, args.tile_rows))
                                        if t_fused is not None else "2 launches/step"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "row-sharded x%d, tables replicated" % world},
             "roofline": roofline, "kernels": kernels,

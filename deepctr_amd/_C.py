@@ -73,7 +73,8 @@ class MlpArgs(ctypes.Structure):
                 ("units", c_vp), ("kernels", c_vp), ("biases", c_vp), ("activation", c_i32), ("has_head", c_i32),
                 ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
                 ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
-                ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz)]
+                ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
+                ("tile_rows", c_i32), ("reserved_", c_i32)]
 
 
 class DinAttnArgs(ctypes.Structure):

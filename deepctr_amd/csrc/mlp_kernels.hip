@@ -119,15 +119,19 @@ __device__ __forceinline__ void load_a8(const float* arow, float (&a)[8]) {
     a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
 }
 
-template <int TPW>
-__device__ __forceinline__ void mfma8(const float (&av)[8], const float (&b)[8][TPW], dctr::f32x4 (&acc)[TPW]) {
+template <int TPW, int RT>
+__device__ __forceinline__ void mfma8(const float (&av)[RT][8], const float (&b)[8][TPW], dctr::f32x4 (&acc)[RT][TPW]) {
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-        for (int c = 0; c < TPW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b[tt][c], acc[c], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+                acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][tt], b[tt][c], acc[rt][c], 0, 0, 0);
 }
 
-// C[16 x 16*TPW] = A[16 x K] * W[K x N] for one wave-tile.  K is walked in stages of 8 k-steps per MFMA slot
+// C[16*RT x 16*TPW] = A[16*RT x K] * W[K x N] for one wave-tile (every B fragment feeds RT row tiles: the weight
+// stream per row drops by RT).  K is walked in stages of 8 k-steps per MFMA slot
 // (8*TPW MFMAs); THREE register stages rotate so that the operands of stages s+1 and s+2 are in flight while
 // stage s issues its MFMAs (>= 2 x 256*TPW cycles of cover for the L2 latency of the weight stream).  The
 // sched_barriers pin the order "issue loads, then MFMAs" — without them hipcc sinks each load next to its first
@@ -137,9 +141,9 @@ __device__ __forceinline__ void mfma8(const float (&av)[8], const float (&b)[8][
 #else
 #define DCTR_SB __builtin_amdgcn_sched_barrier(0)
 #endif
-template <int TPW>
+template <int TPW, int RT>
 __device__ __forceinline__ void tile_gemm_pipe(const float* A, int lda, int K, const float* __restrict__ W, int N,
-                                               int n_base, dctr::f32x4 (&acc)[TPW]) {
+                                               int n_base, dctr::f32x4 (&acc)[RT][TPW]) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int KQ = pad64(K) / 4;
     const float* arow = A + j * lda + g * KQ;
@@ -152,33 +156,34 @@ __device__ __forceinline__ void tile_gemm_pipe(const float* A, int lda, int K, c
     const int n_it = KQ / 8;                              // >= 2
     const int s_last = n_it - 1;
     float b0[8][TPW], b1[8][TPW], b2[8][TPW];
-    float a0[8], a1[8], a2[8];
-#define DCTR_STAGE_LOAD(S, AB, BB)                                  \
-    do {                                                            \
-        const int s_ = min((S), s_last);                            \
-        load_b8<TPW>(rsrc, voff, row4_bytes, s_, BB);               \
-        load_a8(arow + s_ * 8, AB);                                 \
+    float a0[RT][8], a1[RT][8], a2[RT][8];
+#define DCTR_STAGE_LOAD(S, AB, BB)                                                      \
+    do {                                                                                \
+        const int s_ = min((S), s_last);                                                \
+        load_b8<TPW>(rsrc, voff, row4_bytes, s_, BB);                                   \
+        _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_)                            \
+            load_a8(arow + rt_ * 16 * lda + s_ * 8, AB[rt_]);                           \
     } while (0)
     DCTR_STAGE_LOAD(0, a0, b0);
     DCTR_STAGE_LOAD(1, a1, b1);
     for (int it = 0; it < n_it; it += 3) {
         DCTR_STAGE_LOAD(it + 2, a2, b2);
         DCTR_SB;
-        mfma8<TPW>(a0, b0, acc);
+        mfma8<TPW, RT>(a0, b0, acc);
         DCTR_SB;
         DCTR_STAGE_LOAD(it + 3, a0, b0);
         DCTR_SB;
-        if (it + 1 < n_it) mfma8<TPW>(a1, b1, acc);
+        if (it + 1 < n_it) mfma8<TPW, RT>(a1, b1, acc);
         DCTR_SB;
         DCTR_STAGE_LOAD(it + 4, a1, b1);
         DCTR_SB;
-        if (it + 2 < n_it) mfma8<TPW>(a2, b2, acc);
+        if (it + 2 < n_it) mfma8<TPW, RT>(a2, b2, acc);
         DCTR_SB;
     }
 #undef DCTR_STAGE_LOAD
 }
 
-template <int TPW, int ACT>
+template <int TPW, int ACT, int RT>
 __device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
     using dctr::f32x4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -187,13 +192,15 @@ __device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const flo
     const int KQn = pad64(N) / 4;                       // the next layer reads this tile with K = N
     for (int wt = wave; wt < n_tiles; wt += NWAVE) {
         const int n_base = wt * 16 * TPW;
-        f32x4 acc[TPW];
+        f32x4 acc[RT][TPW];
 #pragma unroll
-        for (int c = 0; c < TPW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef DCTR_LAB_COPIES
-        tile_gemm_pipe<TPW>(in, p.lda, K, p.W[l] + (size_t)((blockIdx.x / 8) % DCTR_LAB_COPIES) * 110080, N, n_base, acc);
+        tile_gemm_pipe<TPW, RT>(in, p.lda, K, p.W[l] + (size_t)((blockIdx.x / 8) % DCTR_LAB_COPIES) * 110080, N, n_base, acc);
 #else
-        tile_gemm_pipe<TPW>(in, p.lda, K, p.W[l], N, n_base, acc);
+        tile_gemm_pipe<TPW, RT>(in, p.lda, K, p.W[l], N, n_base, acc);
 #endif
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
@@ -207,28 +214,31 @@ __device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const flo
                     var = p.dice_var[l][n];
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    out[(4 * g + r) * p.lda + lds_pos(n, KQn)] = act_t<ACT>(acc[c][r] + bv, al, mu, var, p.dice_eps);
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out[(rt * 16 + 4 * g + r) * p.lda + lds_pos(n, KQn)] =
+                            act_t<ACT>(acc[rt][c][r] + bv, al, mu, var, p.dice_eps);
             }
         }
     }
     // zero the K padding the NEXT layer reads: columns [N, pad64(N))
     const int npad = pad64(N) - N;
     if (npad > 0) {
-        for (int i = threadIdx.x; i < 16 * 64; i += NTHR) {
+        for (int i = threadIdx.x; i < 16 * RT * 64; i += NTHR) {
             const int r = i >> 6, c = i & 63;
             if (c < npad) out[r * p.lda + lds_pos(N + c, KQn)] = 0.f;
         }
     }
 }
 
-template <int ACT>
+template <int ACT, int RT>
 __device__ __forceinline__ void layer_dispatch(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
     // widest column slice per wave that still gives every wave of the workgroup a tile.  TPW = 4 (96 B-operand
     // registers in the 3-stage pipeline) would push the kernel past 128 VGPRs, i.e. below 4 waves per SIMD = two
     // co-resident workgroups per CU, so 32 columns per wave is the widest slice.
-    if (N % 32 == 0 && N >= 32 * NWAVE) layer_tiles<2, ACT>(p, l, in, out, K, N);
-    else layer_tiles<1, ACT>(p, l, in, out, K, N);
+    if (N % 32 == 0 && N >= 32 * NWAVE) layer_tiles<2, ACT, RT>(p, l, in, out, K, N);
+    else layer_tiles<1, ACT, RT>(p, l, in, out, K, N);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -239,12 +249,14 @@ __device__ __forceinline__ void layer_dispatch(const MlpParams& p, int l, const 
 // The waves of the workgroup split the FIELDS (as the stand-alone gather does at small batch); lane (s, q) owns
 // chunk q of sample s; samples are covered in 16*LPR/64 passes.
 // ---------------------------------------------------------------------------------------------------
-template <int LPR, bool HASH>
+template <int LPR, bool HASH, int RT>
 __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const GatherFused& g, float* tile, float* red,
                                                    float* extra, int64_t b0) {
     constexpr int VEC = 4;
+    constexpr int ROWS = 16 * RT;                             // samples of this workgroup
     constexpr int SPW = 64 / LPR;                             // samples per wave pass
-    constexpr int PASSES = SPW >= 16 ? 1 : 16 / SPW;
+    constexpr int PASSES = SPW >= ROWS ? 1 : ROWS / SPW;
+    static_assert(PASSES * 64 <= NTHR, "the combine step gives one wave per pass");
     constexpr int RW = 2 * VEC + 1;                            // partials per lane: sum[4], sq[4], lin
     const int KQ0 = pad64(p.in_dim) / 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -252,7 +264,7 @@ __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const Gat
     const int s = lane / LPR, q = lane % LPR;
 
     // columns past the real input (K padding) and rows past the batch are zero
-    for (int i = threadIdx.x; i < 16 * KQ0; i += NTHR) {
+    for (int i = threadIdx.x; i < ROWS * KQ0; i += NTHR) {
         const int r = i / KQ0, c4 = i - r * KQ0;
         const bool rowok = b0 + r < g.batch;
 #pragma unroll
@@ -264,12 +276,12 @@ __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const Gat
     for (int pass = 0; pass < PASSES; ++pass) {
         const int r = pass * SPW + s;
         const int64_t b = b0 + r;
-        const bool valid = r < 16 && b < g.batch;
+        const bool valid = r < ROWS && b < g.batch;
         float sum[VEC], sq[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) sum[c] = sq[c] = 0.f;
         GatherAcc acc{0.f, 0};
-        float* const trow = tile + (r & 15) * p.lda;
+        float* const trow = tile + (r & (ROWS - 1)) * p.lda;
         auto store = [trow, KQ0](int col, const float (&v)[VEC]) {     // col % 4 == 0: columns col+k -> k*KQ0 + col/4
             float* dst = trow + (col >> 2);
             dst[0] = v[0];
@@ -288,9 +300,9 @@ __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const Gat
         if (g.status != nullptr && __any(acc.oor) && lane == 0) atomicOr(g.status, (int)DCTR_STATUS_INDEX_OOR);
     }
 
-    // dense features: lanes 0..15 of the last wave take one sample each (passthrough + dense . Linear.kernel)
+    // dense features: lanes 0..ROWS-1 of the last wave take one sample each (passthrough + dense . Linear.kernel)
     float dlin = 0.f;
-    if (g.n_dense > 0 && wave == NWAVE - 1 && lane < 16) {
+    if (g.n_dense > 0 && wave == NWAVE - 1 && lane < ROWS) {
         const int r = lane;
         const bool valid = b0 + r < g.batch;
         const float* src = g.dense + (valid ? b0 + r : 0) * g.dense_stride;
@@ -312,7 +324,7 @@ __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const Gat
                 }
             }
         }
-        extra[16 + r] = dlin;
+        extra[ROWS + r] = dlin;
     }
     __syncthreads();
 
@@ -337,8 +349,8 @@ __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const Gat
         for (int c = 0; c < VEC; ++c) fm += S[c] * S[c] - Q[c];
         fm = 0.5f * reduce_lpr<LPR>(fm);
         lin = reduce_lpr<LPR>(lin);
-        if (q == 0 && r < 16) {
-            if (g.n_dense > 0) lin += extra[16 + r];
+        if (q == 0 && r < ROWS) {
+            if (g.n_dense > 0) lin += extra[ROWS + r];
             const int64_t b = b0 + r;
             if (b < g.batch) {
                 if (g.fm_logit != nullptr) g.fm_logit[b] = fm;
@@ -349,21 +361,23 @@ __device__ __forceinline__ void fused_gather_stage(const MlpParams& p, const Gat
     }
 }
 
+template <int RT>
 __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) {
+    constexpr int ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf0 = smem;
-    float* buf1 = smem + 16 * p.lda;
-    const int64_t b0 = (int64_t)blockIdx.x * 16;
+    float* buf1 = smem + ROWS * p.lda;
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     LAB_TS(0);
 
-    float* extra = smem + 32 * p.lda;                              // [32]: per-row fused logits, dense partials
-    if (fg.lpr != 0) {
+    float* extra = smem + 2 * ROWS * p.lda;                        // [2*ROWS]: per-row fused logits, dense partials
+    if constexpr (RT <= 2) if (fg.lpr != 0) {
         float* red = buf1;                                         // partial sums live in the (still unused) 2nd tile
         const GatherFused& g = fg.g;
 #define DCTR_FUSED(L)                                                              \
     do {                                                                           \
-        if (g.any_hash) fused_gather_stage<L, true>(p, g, buf0, red, extra, b0);  \
-        else fused_gather_stage<L, false>(p, g, buf0, red, extra, b0);            \
+        if (g.any_hash) fused_gather_stage<L, true, RT>(p, g, buf0, red, extra, b0);  \
+        else fused_gather_stage<L, false, RT>(p, g, buf0, red, extra, b0);            \
     } while (0)
         switch (fg.lpr) {
             case 1: DCTR_FUSED(1); break;
@@ -373,7 +387,8 @@ __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) 
             default: DCTR_FUSED(16); break;
         }
 #undef DCTR_FUSED
-    } else {
+    }
+    if (fg.lpr == 0) {
     // stage the input tile (rows beyond the batch and the K padding are zero) into the column-permuted layout.
     // Division-free mapping: wave w takes rows w, w+NWAVE, ...; lanes walk the float4 groups of a row.  Loads are
     // unconditional (clamped address, masked afterwards) and all issued before the first LDS store.
@@ -382,12 +397,12 @@ __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) 
         const int in4 = (p.in_dim + 3) / 4;
         const bool vec = (p.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0);
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        constexpr int RPW = 16 / NWAVE > 0 ? 16 / NWAVE : 1;       // rows per wave
+        constexpr int RPW = ROWS / NWAVE > 0 ? ROWS / NWAVE : 1;   // rows per wave
         for (int c0 = 0; c0 < KQ0; c0 += 128) {
             float4 v[RPW][2];
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
-                const int r = (wave + rr * NWAVE) & 15;
+                const int r = (wave + rr * NWAVE) & (ROWS - 1);
                 const int64_t b = min(b0 + r, p.batch - 1);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -405,11 +420,11 @@ __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) 
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
                 const int r = wave + rr * NWAVE;
-                const bool rowok = r < 16 && b0 + r < p.batch;
+                const bool rowok = r < ROWS && b0 + r < p.batch;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int c4 = c0 + h * 64 + lane;
-                    if (r < 16 && c4 < KQ0) {
+                    if (r < ROWS && c4 < KQ0) {
                         float4 t = v[rr][h];
                         if (!rowok || 4 * c4 >= p.in_dim) t.x = 0.f;   // never let stride padding of x into the tile
                         if (!rowok || 4 * c4 + 1 >= p.in_dim) t.y = 0.f;
@@ -435,11 +450,11 @@ __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) 
     for (int l = 0; l < p.n_layers; ++l) {
         const int N = p.units[l];
         switch (p.activation) {
-            case DCTR_ACT_RELU: layer_dispatch<DCTR_ACT_RELU>(p, l, in, out, K, N); break;
-            case DCTR_ACT_SIGMOID: layer_dispatch<DCTR_ACT_SIGMOID>(p, l, in, out, K, N); break;
-            case DCTR_ACT_TANH: layer_dispatch<DCTR_ACT_TANH>(p, l, in, out, K, N); break;
-            case DCTR_ACT_DICE: layer_dispatch<DCTR_ACT_DICE>(p, l, in, out, K, N); break;
-            default: layer_dispatch<DCTR_ACT_LINEAR>(p, l, in, out, K, N); break;
+            case DCTR_ACT_RELU: layer_dispatch<DCTR_ACT_RELU, RT>(p, l, in, out, K, N); break;
+            case DCTR_ACT_SIGMOID: layer_dispatch<DCTR_ACT_SIGMOID, RT>(p, l, in, out, K, N); break;
+            case DCTR_ACT_TANH: layer_dispatch<DCTR_ACT_TANH, RT>(p, l, in, out, K, N); break;
+            case DCTR_ACT_DICE: layer_dispatch<DCTR_ACT_DICE, RT>(p, l, in, out, K, N); break;
+            default: layer_dispatch<DCTR_ACT_LINEAR, RT>(p, l, in, out, K, N); break;
         }
         __syncthreads();
         LAB_TS(2 + l);
@@ -451,25 +466,27 @@ __global__ __launch_bounds__(NTHR) void mlp_kernel(MlpParams p, FusedGather fg) 
 
     if (p.has_head) {
         // logit[row] = h[row,:] . head_w (+ extra logits + global bias), sigmoid for task == binary
-        const int row = (threadIdx.x >> 4) & 15, part = threadIdx.x & 15;
-        float acc = 0.f;
+        const int part = threadIdx.x & 15;
         const int KQh = pad64(K) / 4;
-        for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);
+        for (int row = threadIdx.x >> 4; row < ROWS; row += NTHR / 16) {
+            float acc = 0.f;
+            for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);
 #pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-        const int64_t b = b0 + row;
-        if (part == 0 && b < p.batch && threadIdx.x < 256) {
-            float v = acc;
-            if (fg.lpr != 0) v += extra[row];
+            for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            const int64_t b = b0 + row;
+            if (part == 0 && b < p.batch) {
+                float v = acc;
+                if (fg.lpr != 0) v += extra[row];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (p.add[i] != nullptr) v += p.add[i][b];
-            if (p.global_bias != nullptr) v += p.global_bias[0];
-            if (p.sigmoid_out) v = dctr::sigmoidf_(v);
-            p.y[b] = v;
+                for (int i = 0; i < 4; ++i)
+                    if (p.add[i] != nullptr) v += p.add[i][b];
+                if (p.global_bias != nullptr) v += p.global_bias[0];
+                if (p.sigmoid_out) v = dctr::sigmoidf_(v);
+                p.y[b] = v;
+            }
         }
     } else {
-        for (int i = threadIdx.x; i < 16 * K; i += NTHR) {
+        for (int i = threadIdx.x; i < ROWS * K; i += NTHR) {
             const int r = i / K, c = i % K;
             const int64_t b = b0 + r;
             if (b < p.batch) p.y[b * p.y_stride + c] = in[r * p.lda + lds_pos(c, pad64(K) / 4)];
@@ -532,7 +549,14 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     p.y_stride = a->y_stride;
     p.lda = mlp_lda(a);
     FusedGather fg{};
-    size_t red_floats = 0;
+    // rows per workgroup.  auto: 16 while that still gives every CU a workgroup (latency), else 32
+    int rt = a->tile_rows / 16;
+    DCTR_REQUIRE(a->tile_rows == 0 || ((rt == 1 || rt == 2 || rt == 4) && a->tile_rows % 16 == 0), DCTR_E_DIM,
+                 "mlp_fwd: tile_rows %d (0, 16, 32 or 64)", a->tile_rows);
+    if (rt == 0) rt = a->batch > 16 * 2 * 256 ? 2 : 1;
+    while (rt > 1 && ((size_t)2 * 16 * rt * p.lda + 2 * 16 * rt) * sizeof(float) > 160 * 1024) rt >>= 1;
+    if (ga != nullptr && rt > 2) rt = 2;
+    const int rows = 16 * rt;
     if (ga != nullptr) {
         DCTR_REQUIRE(ga->batch == a->batch, DCTR_E_DIM, "embed_mlp_fwd: gather batch %lld != mlp batch %lld",
                      (long long)ga->batch, (long long)a->batch);
@@ -550,20 +574,24 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         int lpr = 1;
         while (lpr * 4 < ga->max_dim) lpr <<= 1;
         fg.lpr = lpr;
-        const int passes = (64 / lpr) >= 16 ? 1 : 16 / (64 / lpr);
-        red_floats = (size_t)NWAVE * passes * 9 * 64;           // aliases the second activation tile
-        DCTR_REQUIRE(red_floats <= (size_t)16 * p.lda, DCTR_E_UNSUPPORTED,
+        const int spw = 64 / lpr;
+        const int passes = spw >= rows ? 1 : rows / spw;
+        const size_t red_floats = (size_t)NWAVE * passes * 9 * 64;   // aliases the second activation tile
+        DCTR_REQUIRE(red_floats <= (size_t)rows * p.lda, DCTR_E_UNSUPPORTED,
                      "embed_mlp_fwd: layer widths too small to hold the gather partial sums (%zu floats)", red_floats);
     }
-    const size_t lds = ((size_t)2 * 16 * p.lda + 32) * sizeof(float);
+    const size_t lds = ((size_t)2 * rows * p.lda + 2 * rows) * sizeof(float);
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "mlp_fwd: layer width needs %zu B of LDS (> 160 KiB)", lds);
+    const void* fn = rt == 1 ? (const void*)mlp_kernel<1> : rt == 2 ? (const void*)mlp_kernel<2> : (const void*)mlp_kernel<4>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_fwd: cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
     }
-    const int64_t blocks = dctr_ceil_div(a->batch, 16);
+    const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)rows);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
-    DCTR_LAUNCH(mlp_kernel, dim3((unsigned)blocks), dim3(NTHR), lds, (hipStream_t)stream, p, fg);
+    if (rt == 1) DCTR_LAUNCH(mlp_kernel<1>, dim3((unsigned)blocks), dim3(NTHR), lds, (hipStream_t)stream, p, fg);
+    else if (rt == 2) DCTR_LAUNCH(mlp_kernel<2>, dim3((unsigned)blocks), dim3(NTHR), lds, (hipStream_t)stream, p, fg);
+    else DCTR_LAUNCH(mlp_kernel<4>, dim3((unsigned)blocks), dim3(NTHR), lds, (hipStream_t)stream, p, fg);
     return dctr_launch_status("dctr_mlp_fwd");
 }
 

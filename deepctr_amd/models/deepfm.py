@@ -36,6 +36,7 @@ class _DeepFM(FeatureModel):
             lpr *= 2
         passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
         self.fused = bool(sp.fusable and 8 * passes * 9 * 64 <= 16 * lda)
+        self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64), same bits
 
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
@@ -47,7 +48,8 @@ class _DeepFM(FeatureModel):
             ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
                     head_w=self.dense.w('kernel'), add=[ws["lin2"]] if "lin2" in ws else [],
                     global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
-                    out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo)
+                    out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
+                    tile_rows=self.tile_rows)
             return
         ws = self.stage_plan.run(staged, lo, hi)
         add = self._logits_to_add(ws)
@@ -56,7 +58,7 @@ class _DeepFM(FeatureModel):
             add.extend(ws["fm_extra"])
         ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
                 head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
-                sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out)
+                sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out, tile_rows=self.tile_rows)
 
 
 def DeepFM(linear_feature_columns, dnn_feature_columns, fm_group=(DEFAULT_GROUP_NAME,), dnn_hidden_units=(256, 128, 64),

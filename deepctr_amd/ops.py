@@ -336,10 +336,12 @@ def inner_product(x, reduce_sum=True):
 # adjacent: DNN (+ head), DIN attention
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
-        sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None):
+        sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
+        tile_rows=0):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
-    ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'."""
+    ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
+    ``tile_rows`` (0 = auto, 16, 32, 64) is the batch rows per workgroup — a throughput/latency knob, same bits."""
     _dev_check(x, *kernels, *biases)
     if gather is None:
         if x.dim() != 2:
@@ -384,7 +386,8 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    head_w=None if head_w is None else _f32c(head_w, "head_w").data_ptr(),
                    add=add_arr,
                    global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
-                   y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0)
+                   y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0,
+                   tile_rows=int(tile_rows))
     if gather is not None:
         _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(gather), ctypes.byref(a), int(bool(add_fm_logit)),
                                              int(bool(add_lin_logit)), _C.stream_ptr()), "dctr_embed_mlp_fwd")

@@ -252,6 +252,10 @@ typedef struct {
     int64_t y_stride;
     void* workspace;
     size_t workspace_bytes;
+    int32_t tile_rows;            /* batch rows per workgroup: 0 = auto, or 16 / 32 / 64.  Larger tiles re-use every
+                                     weight fragment for more rows (less L2->CU weight traffic per row, the bound of
+                                     this kernel) at the price of fewer workgroups; results are bit-identical. */
+    int32_t reserved_;
 } dctr_mlp_args_t;
 size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
 int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);

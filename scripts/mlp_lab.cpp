@@ -6,6 +6,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4096;
+    const int tile_rows = argc > 2 ? atoi(argv[2]) : 0;
     const int dims[4] = {429, 256, 128, 64};
     float *x, *y, *W[3], *bias[3], *head;
     CK(hipMalloc(&x, (size_t)B * 432 * 4)); CK(hipMalloc(&y, B * 4)); CK(hipMemset(x, 0, (size_t)B * 432 * 4));
@@ -15,6 +16,7 @@ int main(int argc, char** argv) {
     const float* ks[3] = {W[0], W[1], W[2]}; const float* bs[3] = {bias[0], bias[1], bias[2]};
     dctr_mlp_args_t a{};
     a.x = x; a.batch = B; a.x_stride = 432; a.in_dim = 429; a.n_layers = 3; a.units = units; a.kernels = ks; a.biases = bs;
+    a.tile_rows = tile_rows;
     a.activation = DCTR_ACT_RELU; a.has_head = 1; a.sigmoid_out = 1; a.head_w = head; a.y = y;
     hipStream_t st; CK(hipStreamCreate(&st));
     std::vector<float> t;
@@ -33,6 +35,6 @@ int main(int argc, char** argv) {
     }
 #endif
     std::sort(t.begin(), t.end());
-    printf("%-24s B=%d  median %.2f us  min %.2f us\n", LABNAME, B, t[t.size() / 2], t[0]);
+    printf("%-12s tile_rows=%d B=%d  median %.2f us  min %.2f us\n", LABNAME, tile_rows, B, t[t.size() / 2], t[0]);
     return 0;
 }

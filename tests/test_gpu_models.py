@@ -203,5 +203,9 @@ def test_deepfm_fused_launch_matches_two_launch_path(device):
         model.fused = False
         y2 = model.predict(feed, batch_size=4096)
         check_probs(y1, y2, "fused vs two-launch E=%d" % E)
+        if E >= 16:                               # 32 rows per workgroup (weights re-used for two row tiles): same bits
+            model.fused, model.tile_rows = True, 32
+            np.testing.assert_array_equal(model.predict(feed, batch_size=4096), y1)
+            model.tile_rows = 0
         ref = RM.deepfm(cols, cols, w, feed, dnn_hidden_units=(64, 32), dtype=np.float64)
         check_probs(y1, ref.astype(np.float32), "fused vs oracle E=%d" % E)

@@ -317,6 +317,29 @@ def test_mlp_golden(device):
         assert_close(y.cpu().numpy(), g["dnn_%s_y" % tag], what="dnn " + tag)
 
 
+@pytest.mark.parametrize("B", [1, 33, 4100])
+def test_mlp_tile_rows_are_bit_identical(device, B):
+    """tile_rows only changes how many batch rows share a weight fragment: 16 / 32 / 64 give the same bits
+    (with and without head, relu and dice, odd widths)."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(19)
+    for dims, act in (([429, 256, 128, 64], "relu"), ([39, 80, 40], "dice"), ([7, 5, 70], "tanh")):
+        x = dev(rng.standard_normal((B, dims[0])).astype(np.float32), device)
+        ks = [dev((rng.standard_normal((dims[i], dims[i + 1])) * 0.1).astype(np.float32), device) for i in range(len(dims) - 1)]
+        bs = [dev(rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1, device) for i in range(len(dims) - 1)]
+        dice = None
+        if act == "dice":
+            dice = [(dev(rng.rand(n).astype(np.float32), device), dev(rng.standard_normal(n).astype(np.float32), device),
+                     dev(rng.rand(n).astype(np.float32) + 0.5, device)) for n in dims[1:]]
+        hw = dev(rng.standard_normal(dims[-1]).astype(np.float32), device)
+        for head in (None, hw):
+            ys = [ops.mlp(x, ks, bs, act, dice=dice, head_w=head, tile_rows=t).cpu().numpy() for t in (16, 32, 64, 0)]
+            for y in ys[1:]:
+                np.testing.assert_array_equal(ys[0], y)
+    with pytest.raises(Exception):
+        ops.mlp(x, ks, bs, act, tile_rows=48)
+
+
 @pytest.mark.parametrize("B", [1, 16, 4096, 4100])
 def test_mlp_c2_with_head(device, B):
     from deepctr_amd import ops
