@@ -46,7 +46,8 @@ class GatherFmArgs(ctypes.Structure):
                 ("ids_is_i64", c_i32), ("n_fields", c_i32), ("max_dim", c_i32), ("all_dim4", c_i32),
                 ("any_hash", c_i32), ("n_dense", c_i32), ("dense", c_vp), ("dense_stride", c_i64),
                 ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("dense_copy_cols", c_i32), ("batch", c_i64),
-                ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp)]
+                ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp),
+                ("split_col", c_i32), ("split_field", c_i32)]
 
 
 class PoolArgs(ctypes.Structure):

@@ -26,6 +26,9 @@ SOURCES = [
     "hash_kernels.hip",
     "embed_kernels.hip",
     "mlp_kernels.hip",
+    "mlp_kernels_rt1.hip",
+    "mlp_kernels_rt2.hip",
+    "mlp_kernels_rt4.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "din_kernels.hip",
@@ -54,7 +57,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
+    headers = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "dctr.h"))
     objs = []
     procs = []

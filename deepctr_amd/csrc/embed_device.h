@@ -101,9 +101,9 @@ __device__ __forceinline__ FieldRegs load_field(cfield_ptr F, int j) {
 // `store(out_offset_plus_chunk, v)` receives the column of the first element inside a DNN-input row and the VEC
 // values: the stand-alone gather writes them to dnn_in in HBM, the fused gather->DNN kernel to its LDS tile.
 template <int VEC, int LPR, int U, bool HASH, typename Store>
-__device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int step, int64_t b, bool valid, int q,
-                                             float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc, Store store) {
-    const int last = p.n_fields - 1;
+__device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int step, int f_end, int64_t b, bool valid,
+                                             int q, float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc, Store store) {
+    const int last = f_end - 1;
     const int64_t bb = valid ? b : 0;
     RawId raw[U];
 #pragma unroll
@@ -158,18 +158,19 @@ __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int 
     }
 }
 
-// all fields j = f_begin, f_begin + f_step, ...: full chunks of 8, then one clamped tail chunk sized to what is left
+// fields j = f_begin, f_begin + f_step, ... < f_end: full chunks of 8, then one clamped tail chunk sized to what is left
 template <int VEC, int LPR, bool HASH, typename Store>
-__device__ __forceinline__ void gather_fields(const GatherParams& p, int f_begin, int f_step, int64_t b, bool valid,
-                                              int q, float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc, Store store) {
+__device__ __forceinline__ void gather_fields(const GatherParams& p, int f_begin, int f_step, int f_end, int64_t b,
+                                              bool valid, int q, float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc,
+                                              Store store) {
     int j = f_begin;
-    for (; j + 7 * f_step < p.n_fields; j += 8 * f_step)
-        gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, b, valid, q, sum, sq, acc, store);
-    if (j < p.n_fields) {
-        const int left = (p.n_fields - j + f_step - 1) / f_step;   // 1..7, wave-uniform
-        if (left > 4) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, b, valid, q, sum, sq, acc, store);
-        else if (left > 2) gather_chunk<VEC, LPR, 4, HASH>(p, j, f_step, b, valid, q, sum, sq, acc, store);
-        else gather_chunk<VEC, LPR, 2, HASH>(p, j, f_step, b, valid, q, sum, sq, acc, store);
+    for (; j + 7 * f_step < f_end; j += 8 * f_step)
+        gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
+    if (j < f_end) {
+        const int left = (f_end - j + f_step - 1) / f_step;   // 1..7, wave-uniform
+        if (left > 4) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
+        else if (left > 2) gather_chunk<VEC, LPR, 4, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
+        else gather_chunk<VEC, LPR, 2, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
     }
 }
 

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
     auto store = [out_row](int col, const float (&v)[VEC]) {
         if (out_row != nullptr) store_vec<VEC>(out_row + col, v);
     };
-    gather_fields<VEC, LPR, HASH>(p, f_begin, f_step, b, valid, q, sum, sq, acc, store);
+    gather_fields<VEC, LPR, HASH>(p, f_begin, f_step, p.n_fields, b, valid, q, sum, sq, acc, store);
     float lin = acc.lin;
 
     // dense features: passthrough into the concat + dense . Linear.kernel

@@ -1,0 +1,614 @@
+// Device side of dctr_mlp_fwd / dctr_embed_mlp_fwd: the whole-MLP kernel template (see mlp_kernels.hip for the
+// design notes).  Included by one translation unit per row-tile count RT (mlp_kernels_rt{1,2,4}.hip) so that the
+// instantiations compile in parallel, and by mlp_kernels.hip for the parameter structs.
+#pragma once
+#include "dctr_common.h"
+#include "embed_device.h"
+#include "mfma_tile.h"
+
+#ifdef DCTR_LAB_TIMING
+extern __device__ unsigned long long dctr_lab_ts[64];
+#define LAB_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) dctr_lab_ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LAB_TS(i) do {} while (0)
+#endif
+
+namespace dctr_mlp {
+
+constexpr int MAX_LAYERS = 8;
+#ifndef DCTR_MLP_WAVES
+#define DCTR_MLP_WAVES 8          // waves per 16-row workgroup: 8 = two per SIMD (the second hides the first's waits)
+#endif
+constexpr int NWAVE = DCTR_MLP_WAVES;
+constexpr int NTHR = 64 * NWAVE;
+
+struct MlpParams {
+    const float* x;
+    int64_t batch;
+    int64_t x_stride;
+    int32_t in_dim;
+    int32_t n_layers;
+    int32_t units[MAX_LAYERS];
+    const float* W[MAX_LAYERS];
+    const float* bias[MAX_LAYERS];
+    const float* dice_alpha[MAX_LAYERS];
+    const float* dice_mean[MAX_LAYERS];
+    const float* dice_var[MAX_LAYERS];
+    float dice_eps;
+    int32_t activation;
+    int32_t has_head;
+    int32_t sigmoid_out;
+    const float* head_w;
+    const float* add[4];
+    const float* global_bias;
+    float* y;
+    int64_t y_stride;
+    int32_t lda;      // LDS row stride (floats) = pad64(max tile width) + 4
+    int32_t k_split;  // 0, or the column (multiple of 64) at which the layer-0 input tile is built in two halves
+};
+
+// gather arguments of the fused path; lpr == 0 selects the plain x-staging path
+struct GatherFused : dctr_gather_fm_args_t {
+    int32_t fm_logit_used;   // add the FM logit of the gather epilogue to the head
+    int32_t lin_logit_used;  // add the linear logit
+};
+struct FusedGather {
+    GatherFused g;
+    int32_t lpr;
+};
+
+__device__ __forceinline__ int pad64(int k) { return (k + 63) & ~63; }
+
+template <int ACT>
+__device__ __forceinline__ float act_t(float v, float al, float mu, float var, float eps) {
+    if constexpr (ACT == DCTR_ACT_DICE) return dctr::dice_act(v, al, mu, var, eps);
+    else if constexpr (ACT == DCTR_ACT_RELU) return fmaxf(v, 0.f);
+    else if constexpr (ACT == DCTR_ACT_SIGMOID) return dctr::sigmoidf_(v);
+    else if constexpr (ACT == DCTR_ACT_TANH) return tanhf(v);
+    else return v;
+}
+
+// B fragments of 8 consecutive k-steps of one wave-tile.  MFMA slot g = lane>>4 takes row k = 4*t + g, so the four
+// slots (x the waves' column slices) read 4 ADJACENT weight rows = one contiguous 4 KB; the A tile in LDS is stored
+// column-permuted to match (logical column k at (k&3)*KQ + (k>>2)), so a lane still reads its 8 k-steps with two
+// ds_read_b128.
+// The loads are raw BUFFER loads: the per-lane offset (slot row g, column slice) is constant for the whole tile,
+// the row advance is a scalar offset, and rows >= K fall outside num_records and return 0 from the hardware bounds
+// check — i.e. ZERO VALU per load.  (With flat 64-bit addressing hipcc spent ~9 VALU incl. two quarter-rate
+// v_mad_u64_u32 per load, ~700 issue cycles per 1024-cycle stage that a lone wave per SIMD cannot overlap.)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int TPW>
+__device__ __forceinline__ void buf_load_cols(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float (&b)[TPW]) {
+    if constexpr (TPW == 4) {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        b[0] = __uint_as_float(t.x); b[1] = __uint_as_float(t.y); b[2] = __uint_as_float(t.z); b[3] = __uint_as_float(t.w);
+    } else if constexpr (TPW == 2) {
+        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        b[0] = __uint_as_float(t.x); b[1] = __uint_as_float(t.y);
+    } else {
+        b[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    }
+}
+
+// stage s covers k-steps t = SD*s .. SD*s+SD-1: row of slot g = 4*t + g -> byte offset (4*t)*N*4 (scalar) + voff (lane)
+template <int TPW, int SD>
+__device__ __forceinline__ void load_bs(__amdgpu_buffer_rsrc_t rsrc, int voff, int row4_bytes, int s, float (&b)[SD][TPW]) {
+#pragma unroll
+    for (int tt = 0; tt < SD; ++tt) buf_load_cols<TPW>(rsrc, voff, (SD * s + tt) * row4_bytes, b[tt]);
+}
+
+__device__ __forceinline__ int lds_pos(int k, int KQ) { return (k & 3) * KQ + (k >> 2); }
+
+// A fragments of the same SD k-steps: SD/4 ds_read_b128 of the column-permuted LDS tile
+template <int SD>
+__device__ __forceinline__ void load_as(const float* arow, float (&a)[SD]) {
+#pragma unroll
+    for (int h = 0; h < SD / 4; ++h) {
+        const float4 v = *reinterpret_cast<const float4*>(arow + 4 * h);
+        a[4 * h] = v.x; a[4 * h + 1] = v.y; a[4 * h + 2] = v.z; a[4 * h + 3] = v.w;
+    }
+}
+
+template <int TPW, int RT, int SD>
+__device__ __forceinline__ void mfmas(const float (&av)[RT][SD], const float (&b)[SD][TPW], dctr::f32x4 (&acc)[RT][TPW]) {
+#pragma unroll
+    for (int tt = 0; tt < SD; ++tt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+                acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][tt], b[tt][c], acc[rt][c], 0, 0, 0);
+}
+
+// C[16*RT x 16*TPW] = A[16*RT x K] * W[K x N] for one wave-tile (every B fragment feeds RT row tiles: the weight
+// stream per row drops by RT).  K is walked in stages of 8 k-steps per MFMA slot
+// (8*TPW MFMAs); THREE register stages rotate so that the operands of stages s+1 and s+2 are in flight while
+// stage s issues its MFMAs (>= 2 x 256*TPW cycles of cover for the L2 latency of the weight stream).  The
+// sched_barriers pin the order "issue loads, then MFMAs" — without them hipcc sinks each load next to its first
+// use and the wave alternates load-wait / MFMA (measured: 62 cycles per 32-cycle MFMA).
+#ifdef DCTR_LAB_NO_SB
+#define DCTR_SB do {} while (0)
+#else
+#define DCTR_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+template <int TPW, int RT, int SD>
+__device__ __forceinline__ void tile_gemm_pipe(const float* A, int lda, int KQ, int k_rows, const float* __restrict__ W,
+                                               int N, int n_base, dctr::f32x4 (&acc)[RT][TPW]) {
+    // A: LDS tile of 4*KQ (zero-padded) columns in the permuted layout; W: k_rows x N weight rows for those columns
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const float* arow = A + j * lda + g * KQ;
+    int n0 = n_base + TPW * j;
+    if (n0 + TPW > N) n0 = N - TPW;                       // TPW > 1 only when N % (16*TPW) == 0
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, k_rows * N * 4, 0x00020000);
+    const int voff = (g * N + n0) * 4;                    // lane-constant byte offset: slot row g, column slice
+    const int row4_bytes = 4 * N * 4;                     // four weight rows
+    const int n_it = KQ / SD;                             // >= 2
+    const int s_last = n_it - 1;
+    float b0[SD][TPW], b1[SD][TPW], b2[SD][TPW];
+    float a0[RT][SD], a1[RT][SD], a2[RT][SD];
+#define DCTR_STAGE_LOAD(S, AB, BB)                                                      \
+    do {                                                                                \
+        const int s_ = min((S), s_last);                                                \
+        load_bs<TPW, SD>(rsrc, voff, row4_bytes, s_, BB);                               \
+        _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_)                            \
+            load_as<SD>(arow + rt_ * 16 * lda + s_ * SD, AB[rt_]);                      \
+    } while (0)
+    DCTR_STAGE_LOAD(0, a0, b0);
+    DCTR_STAGE_LOAD(1, a1, b1);
+    for (int it = 0; it < n_it; it += 3) {
+        DCTR_STAGE_LOAD(it + 2, a2, b2);
+        DCTR_SB;
+        mfmas<TPW, RT, SD>(a0, b0, acc);
+        DCTR_SB;
+        DCTR_STAGE_LOAD(it + 3, a0, b0);
+        DCTR_SB;
+        if (it + 1 < n_it) mfmas<TPW, RT, SD>(a1, b1, acc);
+        DCTR_SB;
+        DCTR_STAGE_LOAD(it + 4, a1, b1);
+        DCTR_SB;
+        if (it + 2 < n_it) mfmas<TPW, RT, SD>(a2, b2, acc);
+        DCTR_SB;
+    }
+#undef DCTR_STAGE_LOAD
+}
+
+// k-steps per pipeline stage: 8 with one row tile (two 8-wave workgroups per CU, each wave needs deep cover), 4 with
+// two or more row tiles (every B fragment already feeds >= 2x the MFMAs, and the A/B stage registers must stay
+// <= 128 VGPRs in total so that two workgroups still share a CU)
+template <int RT> struct StageDepth { static constexpr int value = RT == 1 ? 8 : 4; };
+
+// bias + activation of one wave-tile, written to the next layer's LDS tile (permuted layout, K = N)
+template <int TPW, int ACT, int RT>
+__device__ __forceinline__ void tile_epilogue(const MlpParams& p, int l, float* out, int N, int n_base,
+                                              const dctr::f32x4 (&acc)[RT][TPW]) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int KQn = pad64(N) / 4;
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int n = n_base + TPW * j + c;
+        if (n < N) {
+            const float bv = p.bias[l] != nullptr ? p.bias[l][n] : 0.f;
+            float al = 0.f, mu = 0.f, var = 1.f;
+            if constexpr (ACT == DCTR_ACT_DICE) {
+                al = p.dice_alpha[l][n];
+                mu = p.dice_mean[l][n];
+                var = p.dice_var[l][n];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(rt * 16 + 4 * g + r) * p.lda + lds_pos(n, KQn)] =
+                        act_t<ACT>(acc[rt][c][r] + bv, al, mu, var, p.dice_eps);
+        }
+    }
+}
+
+// zero the K padding the NEXT layer reads: columns [N, pad64(N))
+template <int RT>
+__device__ __forceinline__ void zero_k_padding(const MlpParams& p, float* out, int N) {
+    const int npad = pad64(N) - N;
+    const int KQn = pad64(N) / 4;
+    if (npad > 0) {
+        for (int i = threadIdx.x; i < 16 * RT * 64; i += NTHR) {
+            const int r = i >> 6, c = i & 63;
+            if (c < npad) out[r * p.lda + lds_pos(N + c, KQn)] = 0.f;
+        }
+    }
+}
+
+template <int TPW, int ACT, int RT>
+__device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
+    using dctr::f32x4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_tiles = (N + 16 * TPW - 1) / (16 * TPW);
+    for (int wt = wave; wt < n_tiles; wt += NWAVE) {
+        const int n_base = wt * 16 * TPW;
+        f32x4 acc[RT][TPW];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef DCTR_LAB_COPIES
+        tile_gemm_pipe<TPW, RT, StageDepth<RT>::value>(in, p.lda, pad64(K) / 4, K,
+                                                       p.W[l] + (size_t)((blockIdx.x / 8) % DCTR_LAB_COPIES) * 110080, N, n_base, acc);
+#else
+        tile_gemm_pipe<TPW, RT, StageDepth<RT>::value>(in, p.lda, pad64(K) / 4, K, p.W[l], N, n_base, acc);
+#endif
+        tile_epilogue<TPW, ACT, RT>(p, l, out, N, n_base, acc);
+    }
+    zero_k_padding<RT>(p, out, N);
+}
+
+template <int ACT, int RT>
+__device__ __forceinline__ void layer_dispatch(const MlpParams& p, int l, const float* in, float* out, int K, int N) {
+    // widest column slice per wave that still gives every wave of the workgroup a tile.  TPW = 4 (96 B-operand
+    // registers in the 3-stage pipeline) would push the kernel past 128 VGPRs, i.e. below 4 waves per SIMD = two
+    // co-resident workgroups per CU, so 32 columns per wave is the widest slice.
+    if (N % 32 == 0 && N >= 32 * NWAVE) layer_tiles<2, ACT, RT>(p, l, in, out, K, N);
+    else layer_tiles<1, ACT, RT>(p, l, in, out, K, N);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Input producers.  The layer-0 input tile is built in LDS either whole or in two K-halves ("chunks": columns
+// [c0, c0 + 4*KQ) of the zero-padded row, stored in the permuted layout with stride KQ); with two halves the
+// workgroup needs half the tile and two workgroups of 32 rows share a CU, so one's gather (latency-bound) runs
+// under the other's MFMAs.
+// ---------------------------------------------------------------------------------------------------
+struct Chunk {
+    int c0;        // first DNN-input column
+    int KQ;        // (padded width) / 4
+    int f_lo, f_hi;  // gather fields of this chunk (fused path)
+    bool first, last;
+};
+
+// Plain path: x rows from HBM (rows beyond the batch and the K padding are zero).  Division-free mapping: wave w
+// takes rows w, w+NWAVE, ...; lanes walk the float4 groups of a row.  Loads are unconditional (clamped address,
+// masked afterwards) and all issued before the first LDS store.
+template <int RT>
+__device__ __forceinline__ void stage_x_chunk(const MlpParams& p, float* tile, int64_t b0, const Chunk& ck) {
+    constexpr int ROWS = 16 * RT;
+    const int KQc = ck.KQ;
+    const int in4 = (p.in_dim + 3) / 4;                        // float4 groups of a real row
+    const int c40 = ck.c0 / 4;
+    const bool vec = (p.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int RPW = ROWS / NWAVE > 0 ? ROWS / NWAVE : 1;   // rows per wave
+    for (int q0 = 0; q0 < KQc; q0 += 128) {
+        float4 v[RPW][2];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = (wave + rr * NWAVE) & (ROWS - 1);
+            const int64_t b = min(b0 + r, p.batch - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c4 = min(c40 + q0 + h * 64 + lane, in4 - 1);
+                const float* src = p.x + b * p.x_stride + 4 * c4;
+                if (vec) {
+                    v[rr][h] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    const int c = 4 * c4, last = p.in_dim - 1;
+                    v[rr][h] = make_float4(src[0], src[min(c + 1, last) - c], src[min(c + 2, last) - c],
+                                           src[min(c + 3, last) - c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave + rr * NWAVE;
+            const bool rowok = r < ROWS && b0 + r < p.batch;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q4 = q0 + h * 64 + lane;                 // float4 group inside the chunk
+                const int c = 4 * (c40 + q4);                      // its first real column
+                if (r < ROWS && q4 < KQc) {
+                    float4 t = v[rr][h];
+                    if (!rowok || c >= p.in_dim) t.x = 0.f;        // never let stride padding of x into the tile
+                    if (!rowok || c + 1 >= p.in_dim) t.y = 0.f;
+                    if (!rowok || c + 2 >= p.in_dim) t.z = 0.f;
+                    if (!rowok || c + 3 >= p.in_dim) t.w = 0.f;
+                    float* dst = tile + r * p.lda + q4;            // local columns 4*q4+s -> position s*KQc + q4
+                    dst[0] = t.x;
+                    dst[KQc] = t.y;
+                    dst[2 * KQc] = t.z;
+                    dst[3 * KQc] = t.w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Fused path (dctr_embed_mlp_fwd): the tile of the workgroup's samples is GATHERED straight into LDS — embedding
+// rows, dense passthrough — and the linear + FM logits of the gather epilogue stay in LDS for the head.  Versus
+// dctr_embed_gather_fm + dctr_mlp_fwd this removes the [B, 432] fp32 tile's trip through HBM (1.7 KB written and
+// read back per sample), the [B] logit vectors and one kernel launch.  The waves of the workgroup split the FIELDS
+// (as the stand-alone gather does at small batch); lane (s, q) owns chunk q of sample s; samples are covered in
+// ROWS*LPR/64 passes.  Per-lane partial sums (sum_f e [4], sum_f e^2, linear) are parked in `red` between the two
+// K-halves and combined across waves after the last one.
+template <int LPR, bool HASH, int RT>
+__device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const GatherFused& g, float* tile, float* red,
+                                                   float* extra, int64_t b0, const Chunk& ck) {
+    constexpr int VEC = 4;
+    constexpr int ROWS = 16 * RT;                             // samples of this workgroup
+    constexpr int SPW = 64 / LPR;                             // samples per wave pass
+    constexpr int PASSES = SPW >= ROWS ? 1 : ROWS / SPW;
+    constexpr int RW = VEC + 2;                                // parked per lane: sum[4], sum of squares, linear
+    static_assert(PASSES * 64 <= NTHR, "the combine step gives one wave per pass");
+    const int KQc = ck.KQ, c0 = ck.c0;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int s = lane / LPR, q = lane % LPR;
+
+    // columns past the real input (K padding) and rows past the batch are zero
+    for (int i = threadIdx.x; i < ROWS * KQc; i += NTHR) {
+        const int r = i / KQc, c4 = i - r * KQc;
+        const bool rowok = b0 + r < g.batch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!rowok || c0 + 4 * c4 + k >= p.in_dim) tile[r * p.lda + k * KQc + c4] = 0.f;
+    }
+
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int r = pass * SPW + s;
+        const int64_t b = b0 + r;
+        const bool valid = r < ROWS && b < g.batch;
+        float* rp = red + ((wave * PASSES + pass) * RW) * 64 + lane;
+        float sum[VEC], sq[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            sum[c] = ck.first ? 0.f : rp[c * 64];
+            sq[c] = 0.f;
+        }
+        GatherAcc acc{ck.first ? 0.f : rp[(VEC + 1) * 64], 0};
+        float* const trow = tile + (r & (ROWS - 1)) * p.lda;
+        auto store = [trow, KQc, c0](int col, const float (&v)[VEC]) {   // col % 4 == 0: local col+k -> k*KQc + col/4
+            float* dst = trow + ((col - c0) >> 2);
+            dst[0] = v[0];
+            dst[KQc] = v[1];
+            dst[2 * KQc] = v[2];
+            dst[3 * KQc] = v[3];
+        };
+        gather_fields<VEC, LPR, HASH>(g, ck.f_lo + wave, NWAVE, ck.f_hi, b, valid, q, sum, sq, acc, store);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) rp[c * 64] = sum[c];
+        rp[VEC * 64] = (ck.first ? 0.f : rp[VEC * 64]) + ((sq[0] + sq[1]) + (sq[2] + sq[3]));
+        rp[(VEC + 1) * 64] = acc.lin;
+        if (g.status != nullptr && __any(acc.oor) && lane == 0) atomicOr(g.status, (int)DCTR_STATUS_INDEX_OOR);
+    }
+    if (!ck.last) {
+        __syncthreads();
+        return;
+    }
+
+    // dense features: lanes 0..ROWS-1 of the last wave take one sample each (passthrough + dense . Linear.kernel)
+    float dlin = 0.f;
+    if (g.n_dense > 0 && wave == NWAVE - 1 && lane < ROWS) {
+        const int r = lane;
+        const bool valid = b0 + r < g.batch;
+        const float* src = g.dense + (valid ? b0 + r : 0) * g.dense_stride;
+        for (int k0 = 0; k0 < g.n_dense; k0 += 8) {
+            float x[8], w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int k = min(k0 + m, g.n_dense - 1);
+                x[m] = src[k];
+                w[m] = g.dense_lin_w != nullptr ? g.dense_lin_w[k] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int k = k0 + m;
+                if (k < g.n_dense && valid) {
+                    if (g.dense_out_offset >= 0 && k < g.dense_copy_cols)
+                        tile[r * p.lda + lds_pos(g.dense_out_offset + k - c0, KQc)] = x[m];
+                    dlin = fmaf(x[m], w[m], dlin);
+                }
+            }
+        }
+        extra[ROWS + r] = dlin;
+    }
+    __syncthreads();
+
+    // combine the waves' partial sums: FM = 0.5 * (sum_d (sum_f e)^2 - sum_d sum_f e^2), linear = sum of 1-wide rows
+    if (threadIdx.x < PASSES * 64) {
+        const int pass = threadIdx.x >> 6;
+        const int r = pass * SPW + s;
+        float S[VEC], Q = 0.f, lin = 0.f;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) S[c] = 0.f;
+        for (int w = 0; w < NWAVE; ++w) {
+            const float* rp = red + ((w * PASSES + pass) * RW) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) S[c] += rp[c * 64];
+            Q += rp[VEC * 64];
+            lin += rp[(VEC + 1) * 64];
+        }
+        float fm = -Q;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) fm = fmaf(S[c], S[c], fm);
+        fm = 0.5f * reduce_lpr<LPR>(fm);
+        lin = reduce_lpr<LPR>(lin);
+        if (q == 0 && r < ROWS) {
+            if (g.n_dense > 0) lin += extra[ROWS + r];
+            const int64_t b = b0 + r;
+            if (b < g.batch) {
+                if (g.fm_logit != nullptr) g.fm_logit[b] = fm;
+                if (g.lin_logit != nullptr) g.lin_logit[b] = lin;
+            }
+            extra[r] = (g.fm_logit_used ? fm : 0.f) + (g.lin_logit_used ? lin : 0.f);
+        }
+    }
+    __syncthreads();     // `red` aliases the tile the first layer writes
+}
+
+template <int RT>
+__device__ __forceinline__ void produce_chunk(const MlpParams& p, const FusedGather& fg, float* tile, float* red,
+                                              float* extra, int64_t b0, const Chunk& ck) {
+    if constexpr (RT <= 2) {
+        if (fg.lpr != 0) {
+            const GatherFused& g = fg.g;
+#define DCTR_FUSED(L)                                                                   \
+    do {                                                                                \
+        if (g.any_hash) fused_gather_chunk<L, true, RT>(p, g, tile, red, extra, b0, ck);  \
+        else fused_gather_chunk<L, false, RT>(p, g, tile, red, extra, b0, ck);            \
+    } while (0)
+            switch (fg.lpr) {                                  // host: 4 lanes per row up to dim 16, 8 to 32, 16 to 64
+                case 4: DCTR_FUSED(4); break;
+                case 8: DCTR_FUSED(8); break;
+                default: DCTR_FUSED(16); break;
+            }
+#undef DCTR_FUSED
+            return;
+        }
+    }
+    stage_x_chunk<RT>(p, tile, b0, ck);
+}
+
+template <int TPW, int RT>
+__device__ __forceinline__ void zero_acc(dctr::f32x4 (&acc)[RT][TPW]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) acc[rt][c] = dctr::f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int RT>
+__global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p, FusedGather fg) {
+    constexpr int ROWS = 16 * RT;
+    constexpr int SD = StageDepth<RT>::value;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf0 = smem;
+    float* buf1 = smem + ROWS * p.lda;
+    float* extra = smem + 2 * ROWS * p.lda;                        // [2*ROWS]: per-row fused logits, dense partials
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    LAB_TS(0);
+
+    float* in = buf0;
+    float* out = buf1;
+    int K = p.in_dim;
+    int l = 0;
+    const int n_fields = fg.lpr != 0 ? fg.g.n_fields : 0;
+    if (p.k_split == 0) {
+        const Chunk ck{0, pad64(p.in_dim) / 4, 0, n_fields, true, true};
+        produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);       // partial sums live in the (still unused) 2nd tile
+        LAB_TS(1);
+    } else {
+        // layer 0 in two K-halves: every wave owns ONE wave-tile of the layer output (host guarantees it) and keeps
+        // its accumulators in registers while the second half of the input tile replaces the first in LDS
+        using dctr::f32x4;
+        const int N = p.units[0];
+        const bool wide = N % 32 == 0 && N >= 32 * NWAVE;
+        f32x4 acc2[RT][2];
+        f32x4 acc1[RT][1];
+        zero_acc<2, RT>(acc2);
+        zero_acc<1, RT>(acc1);
+        const int n_tiles = (N + (wide ? 32 : 16) - 1) / (wide ? 32 : 16);
+        const int n_base = wave * (wide ? 32 : 16);
+        const int kpad = pad64(p.in_dim);
+        const int cw0 = p.k_split, cw1 = kpad - p.k_split;
+        const int f_mid = fg.lpr != 0 ? fg.g.split_field : 0;
+        const float* W0 = p.W[0];
+        {
+            const Chunk ck{0, cw0 / 4, 0, f_mid, true, false};
+            produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
+            LAB_TS(1);
+            if (wave < n_tiles) {
+                if (wide) tile_gemm_pipe<2, RT, SD>(buf0, p.lda, cw0 / 4, cw0, W0, N, n_base, acc2);
+                else tile_gemm_pipe<1, RT, SD>(buf0, p.lda, cw0 / 4, cw0, W0, N, n_base, acc1);
+            }
+            __syncthreads();                                      // buf0 is rebuilt by the second half
+        }
+        {
+            const Chunk ck{cw0, cw1 / 4, f_mid, n_fields, false, true};
+            produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
+            if (wave < n_tiles) {
+                const int k_rows = p.in_dim - cw0;
+                const float* W = W0 + (size_t)cw0 * N;
+                if (wide) tile_gemm_pipe<2, RT, SD>(buf0, p.lda, cw1 / 4, k_rows, W, N, n_base, acc2);
+                else tile_gemm_pipe<1, RT, SD>(buf0, p.lda, cw1 / 4, k_rows, W, N, n_base, acc1);
+            }
+        }
+        if (wave < n_tiles) {
+#define DCTR_EPI(ACT)                                                              \
+    do {                                                                           \
+        if (wide) tile_epilogue<2, ACT, RT>(p, 0, buf1, N, n_base, acc2);          \
+        else tile_epilogue<1, ACT, RT>(p, 0, buf1, N, n_base, acc1);               \
+    } while (0)
+            switch (p.activation) {
+                case DCTR_ACT_RELU: DCTR_EPI(DCTR_ACT_RELU); break;
+                case DCTR_ACT_SIGMOID: DCTR_EPI(DCTR_ACT_SIGMOID); break;
+                case DCTR_ACT_TANH: DCTR_EPI(DCTR_ACT_TANH); break;
+                case DCTR_ACT_DICE: DCTR_EPI(DCTR_ACT_DICE); break;
+                default: DCTR_EPI(DCTR_ACT_LINEAR); break;
+            }
+#undef DCTR_EPI
+        }
+        zero_k_padding<RT>(p, buf1, N);
+        __syncthreads();
+        LAB_TS(2);
+        in = buf1;
+        out = buf0;
+        K = N;
+        l = 1;
+    }
+
+    for (; l < p.n_layers; ++l) {
+        const int N = p.units[l];
+        switch (p.activation) {
+            case DCTR_ACT_RELU: layer_dispatch<DCTR_ACT_RELU, RT>(p, l, in, out, K, N); break;
+            case DCTR_ACT_SIGMOID: layer_dispatch<DCTR_ACT_SIGMOID, RT>(p, l, in, out, K, N); break;
+            case DCTR_ACT_TANH: layer_dispatch<DCTR_ACT_TANH, RT>(p, l, in, out, K, N); break;
+            case DCTR_ACT_DICE: layer_dispatch<DCTR_ACT_DICE, RT>(p, l, in, out, K, N); break;
+            default: layer_dispatch<DCTR_ACT_LINEAR, RT>(p, l, in, out, K, N); break;
+        }
+        __syncthreads();
+        LAB_TS(2 + l);
+        float* t = in;
+        in = out;
+        out = t;
+        K = N;
+    }
+
+    if (p.has_head) {
+        // logit[row] = h[row,:] . head_w (+ extra logits + global bias), sigmoid for task == binary
+        const int part = threadIdx.x & 15;
+        const int KQh = pad64(K) / 4;
+        for (int row = threadIdx.x >> 4; row < ROWS; row += NTHR / 16) {
+            float acc = 0.f;
+            for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            const int64_t b = b0 + row;
+            if (part == 0 && b < p.batch) {
+                float v = acc;
+                if (fg.lpr != 0) v += extra[row];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p.add[i] != nullptr) v += p.add[i][b];
+                if (p.global_bias != nullptr) v += p.global_bias[0];
+                if (p.sigmoid_out) v = dctr::sigmoidf_(v);
+                p.y[b] = v;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < ROWS * K; i += NTHR) {
+            const int r = i / K, c = i % K;
+            const int64_t b = b0 + r;
+            if (b < p.batch) p.y[b * p.y_stride + c] = in[r * p.lda + lds_pos(c, pad64(K) / 4)];
+        }
+    }
+    LAB_TS(10);
+}
+
+
+// launchers, one per translation unit mlp_kernels_rt{1,2,4}.hip
+int launch_rt1(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
+int launch_rt2(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
+int launch_rt4(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
+
+}  // namespace dctr_mlp

@@ -187,7 +187,23 @@ class EmbeddingStage(object):
             for f in self.fields)
         self.max_dim = max([f.dim for f in self.fields] + [1])
         self.any_hash = any(f.hash_mode for f in self.fields)
+        self.k_split = self._find_k_split()
         self._ws = {}
+
+    def _find_k_split(self):
+        """(split_col, split_field) offered to dctr_embed_mlp_fwd (include/dctr.h): the field boundary on a multiple of
+        64 columns nearest to half the padded DNN-input row; fields are in dnn_in order, dense columns come last."""
+        padded = (self.in_dim + 63) // 64 * 64
+        best = (0, 0)
+        for i, f in enumerate(self.fields):
+            c = f.out_offset
+            if i == 0 or c % 64 != 0 or not 0 < c < padded:
+                continue
+            if self.n_dense_dnn and self.dense_offset < c:
+                continue
+            if best == (0, 0) or abs(2 * c - padded) <= abs(2 * best[0] - padded):
+                best = (c, i)
+        return best
 
     # -- staging -----------------------------------------------------------------------------------
     def id_features(self):
@@ -336,7 +352,8 @@ class EmbeddingStage(object):
                                     dense_copy_cols=self.n_dense_dnn, dnn_in=ws["dnn_in"] if to_hbm else None,
                                     out_stride=self.out_stride,
                                     fm_logit=ws["fm"] if (self.fm_group_names and to_hbm) else None,
-                                    lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"])
+                                    lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"],
+                                    split=self.k_split)
 
     def run_pools(self, staged, lo, hi):
         ws = self.workspace(hi - lo)

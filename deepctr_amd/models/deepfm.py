@@ -31,11 +31,11 @@ class _DeepFM(FeatureModel):
         sp = self.stage_plan
         width = max([sp.in_dim] + list(dnn_hidden_units))
         lda = (width + 63) // 64 * 64 + 4
-        lpr = 1
+        lpr = 4
         while lpr * 4 < sp.max_dim:
             lpr *= 2
         passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
-        self.fused = bool(sp.fusable and 8 * passes * 9 * 64 <= 16 * lda)
+        self.fused = bool(sp.fusable and 8 * passes * 6 * 64 <= 16 * lda)
         self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64), same bits
 
     def _forward(self, staged, lo, hi, out):

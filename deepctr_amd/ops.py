@@ -197,8 +197,9 @@ def make_field_descriptors(fields, device):
 
 def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
                      dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0,
-                     fm_logit=None, lin_logit=None, status=None):
-    """Fill a dctr_gather_fm_args_t (see include/dctr.h).  The caller keeps every tensor alive."""
+                     fm_logit=None, lin_logit=None, status=None, split=(0, 0)):
+    """Fill a dctr_gather_fm_args_t (see include/dctr.h).  The caller keeps every tensor alive.
+    ``split`` = (split_col, split_field), see the header; (0, 0) = none."""
     _dev_check(desc, ids, dense, dnn_in)
     is64 = 0
     if ids is not None:
@@ -218,7 +219,8 @@ def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max
                            dnn_in=None if dnn_in is None else dnn_in.data_ptr(), out_stride=out_stride,
                            fm_logit=None if fm_logit is None else fm_logit.data_ptr(),
                            lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
-                           status=None if status is None else status.data_ptr())
+                           status=None if status is None else status.data_ptr(),
+                           split_col=int(split[0]), split_field=int(split[1]))
 
 
 def embed_gather_fm(*args, **kwargs):

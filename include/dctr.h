@@ -110,6 +110,11 @@ typedef struct {
     float* fm_logit;              /* [B] or NULL:  0.5 * sum_d((sum_f e)^2 - sum_f e^2) over in_fm fields */
     float* lin_logit;             /* [B] or NULL:  sum_f lin_table_f[row] + dense . dense_lin_w         */
     int32_t* status;              /* optional device word, DCTR_STATUS_* bits are OR-ed in              */
+    int32_t split_col;            /* dctr_embed_mlp_fwd only; 0 = none.  A dnn_in column (multiple of 64) with:
+                                     fields[0 .. split_field) write only columns < split_col, fields[split_field ..)
+                                     and the dense passthrough only columns >= split_col.  Lets the fused kernel
+                                     build the DNN-input tile in two K-halves (half the LDS, two workgroups per CU). */
+    int32_t split_field;
 } dctr_gather_fm_args_t;
 
 int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);

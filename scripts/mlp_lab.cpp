@@ -1,6 +1,14 @@
 // Lab harness for dctr_mlp_fwd (bring-up tool): per-dispatch time of the C2 DNN at B=4096 under -DDCTR_LAB_* ablations.
 #include "../deepctr_amd/csrc/abi.cpp"
 #include "../deepctr_amd/csrc/mlp_kernels.hip"
+#ifdef DCTR_LAB_TIMING
+__device__ unsigned long long dctr_lab_ts[64];
+#endif
+#include "../deepctr_amd/csrc/mlp_kernels_rt1.hip"
+#undef DCTR_MLP_RT
+#include "../deepctr_amd/csrc/mlp_kernels_rt2.hip"
+#undef DCTR_MLP_RT
+#include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
 #include <vector>
 #include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)

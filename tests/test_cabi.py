@@ -33,7 +33,7 @@ def test_struct_sizes_match_the_header_layout():
     import ctypes
     from deepctr_amd import _C
     assert ctypes.sizeof(_C.FieldDesc) == 48
-    assert ctypes.sizeof(_C.GatherFmArgs) == 8 * 4 + 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6
+    assert ctypes.sizeof(_C.GatherFmArgs) == 8 * 4 + 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 2
     assert ctypes.sizeof(_C.LookupArgs) == 8 * 4 + 4 * 4 + 8 * 4
     assert ctypes.sizeof(_C.PoolArgs) == 8 * 8 + 4 * 6 + 8 * 4
 

@@ -198,14 +198,15 @@ def test_deepfm_fused_launch_matches_two_launch_path(device):
         model = DeepFM(cols, cols, dnn_hidden_units=(64, 32), device=device)
         w = _randomise(model, rng)
         assert model.stage_plan.fusable
-        assert model.fused == (E >= 16)          # tiny tiles cannot hold the gather partial sums -> two-launch path
+        assert model.fused == (E >= 8)           # tiny tiles cannot hold the gather partial sums -> two-launch path
         y1 = model.predict(feed, batch_size=4096)
-        model.fused = False
+        was_fused, model.fused = model.fused, False
         y2 = model.predict(feed, batch_size=4096)
         check_probs(y1, y2, "fused vs two-launch E=%d" % E)
-        if E >= 16:                               # 32 rows per workgroup (weights re-used for two row tiles): same bits
+        if was_fused:                             # 32 rows per workgroup, layer-0 input tile built in two K-halves
             model.fused, model.tile_rows = True, 32
-            np.testing.assert_array_equal(model.predict(feed, batch_size=4096), y1)
+            y3 = model.predict(feed, batch_size=4096)
+            check_probs(y3, y1, "fused tile_rows 32 vs 16 E=%d" % E)   # K-split changes the FM / layer-0 summation order
             model.tile_rows = 0
         ref = RM.deepfm(cols, cols, w, feed, dnn_hidden_units=(64, 32), dtype=np.float64)
         check_probs(y1, ref.astype(np.float32), "fused vs oracle E=%d" % E)
