@@ -83,7 +83,7 @@ class DinAttnArgs(ctypes.Structure):
                 ("dim", c_i32), ("n_layers", c_i32), ("activation", c_i32), ("units", c_vp), ("kernels", c_vp),
                 ("biases", c_vp), ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
                 ("weight_normalization", c_i32), ("out_kernel", c_vp), ("out_bias", c_vp), ("out", c_vp),
-                ("out_stride", c_i64), ("scores", c_vp)]
+                ("out_stride", c_i64), ("scores", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz)]
 
 
 # every symbol include/dctr.h declares: name -> (restype, argtypes)
@@ -109,6 +109,7 @@ SYMBOLS = {
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
     "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),
+    "dctr_din_attn_workspace_bytes": (c_sz, [ctypes.POINTER(DinAttnArgs)]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
 }
 

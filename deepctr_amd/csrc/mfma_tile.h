@@ -90,7 +90,9 @@ __device__ __forceinline__ void tile_gemm_nk(const float* A, int lda, int K, int
     }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid on the hardware transcendental units: v_exp_f32 (via __expf) and v_rcp_f32, ~2 ulp; the IEEE expf +
+// division pair costs ~40 VALU instructions = 160 cycles per wave64 element, which dominated the Dice epilogues.
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
 
 // activation codes = DCTR_ACT_* (include/dctr.h)
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -104,10 +106,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // Dice, inference form (reference layers/activation.py:59-64):
 //   x_p = sigmoid((x - mean) * rsqrt(var + eps));  y = alpha*(1-x_p)*x + x_p*x
+__device__ __forceinline__ float dice_pre(float v, float alpha, float inv, float shift) {   // inv, shift per column
+    const float xp = sigmoidf_(v * inv + shift);
+    return alpha * (1.f - xp) * v + xp * v;
+}
 __device__ __forceinline__ float dice_act(float v, float alpha, float mean, float var, float eps) {
     const float inv = 1.f / sqrtf(var + eps);
-    const float xp = sigmoidf_(v * inv + (-mean * inv));
-    return alpha * (1.f - xp) * v + xp * v;
+    return dice_pre(v, alpha, inv, -mean * inv);
 }
 
 }  // namespace dctr

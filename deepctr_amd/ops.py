@@ -400,9 +400,11 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
 
 
 def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, activation="sigmoid", dice=None,
-                  dice_eps=1e-9, weight_normalization=False, return_score=False, out=None, out_stride=None):
+                  dice_eps=1e-9, weight_normalization=False, return_score=False, out=None, out_stride=None,
+                  workspace=True):
     """AttentionSequencePoolingLayer.call (reference sequence.py:261-298): query [B,1,E] / [B,E], keys [B,T,E],
-    key_mask [B,T] (bool/uint8) -> [B,1,E] (or the scores [B,1,T])."""
+    key_mask [B,T] (bool/uint8) -> [B,1,E] (or the scores [B,1,T]).  ``workspace=False`` withholds the [B*T]
+    scratch and thereby selects the one-workgroup-per-sample kernel (see include/dctr.h)."""
     _dev_check(query, keys, key_mask, out_kernel, out_bias)
     keys = _f32c(keys, "keys")
     B, T, E = keys.shape
@@ -434,6 +436,10 @@ def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, 
                        out_kernel=_f32c(out_kernel, "out_kernel").reshape(-1).data_ptr(),
                        out_bias=_f32c(out_bias, "out_bias").data_ptr(), out=out.data_ptr(), out_stride=out_stride,
                        scores=None if scores is None else scores.data_ptr())
+    if workspace:                      # [B*T] raw scores: enables the weights-in-LDS row kernel (include/dctr.h)
+        ws = torch.empty(max(1, int(_C.lib().dctr_din_attn_workspace_bytes(ctypes.byref(a))) // 4), dtype=torch.float32,
+                         device=keys.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _C.check(_C.lib().dctr_din_attn_pool_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_din_attn_pool_fwd")
     if return_score:
         return scores.reshape(B, 1, T)

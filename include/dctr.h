@@ -304,7 +304,13 @@ typedef struct {
     float* out;                   /* [B, out_stride] */
     int64_t out_stride;
     float* scores;                /* optional [B,T] (return_score) */
+    void* workspace;              /* optional device scratch of dctr_din_attn_workspace_bytes() bytes, 16-B aligned.
+                                     With it (and dim % 16 == 0 and <= 64, layer widths <= 96, query / keys 16-B aligned) the
+                                     attention MLP runs as one row problem over all B*T positions with the weights
+                                     resident in LDS (two launches); without it, one workgroup per sample. */
+    size_t workspace_bytes;
 } dctr_din_attn_args_t;
+size_t dctr_din_attn_workspace_bytes(const dctr_din_attn_args_t* args);
 int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* args, void* stream);
 
 #ifdef __cplusplus

@@ -425,3 +425,36 @@ def test_din_attention_c4_shape(device):
                                   [tuple(dev(a, device) for a in d) for d in dice] if act == "dice" else None,
                                   weight_normalization=wn)
             assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="din attention B=%d T=%d %s" % (B, T, act))
+
+
+@pytest.mark.parametrize("B,T,E,hid", [(2048, 50, 64, (80, 40)), (37, 21, 32, (128, 48, 20)), (9, 3, 16, (8,))])
+def test_din_attention_row_kernel_matches_per_sample_kernel(device, B, T, E, hid):
+    """The weights-in-LDS row kernel (workspace given) against the one-workgroup-per-sample kernel and the oracle,
+    outputs and scores, with and without weight_normalization; B*T is not a multiple of the 16-row tile."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(23)
+    q = dev(rng.standard_normal((B, 1, E)).astype(np.float32) * 0.5, device)
+    k = dev(rng.standard_normal((B, T, E)).astype(np.float32) * 0.5, device)
+    lens = rng.randint(0, T + 1, B)
+    km = np.arange(T)[None, :] < lens[:, None]
+    dims = [4 * E] + list(hid)
+    ks = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(hid))]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(hid))]
+    ok = rng.standard_normal((dims[-1], 1)).astype(np.float32) * 0.3
+    ob = np.array([0.05], np.float32)
+    dice = [(rng.standard_normal(h).astype(np.float32) * 0.3, rng.standard_normal(h).astype(np.float32) * 0.1,
+             rng.uniform(0.5, 1.5, h).astype(np.float32)) for h in hid]
+    args = (q, k, dev(km, device), [dev(w, device) for w in ks], [dev(b, device) for b in bs], dev(ok, device), dev(ob, device))
+    for act, wn in (("dice", False), ("sigmoid", True), ("relu", False)):
+        d = [tuple(dev(a, device) for a in dd) for dd in dice] if act == "dice" else None
+        for rs in (False, True):
+            fast = ops.din_attention(*args, act, d, weight_normalization=wn, return_score=rs).cpu().numpy()
+            slow = ops.din_attention(*args, act, d, weight_normalization=wn, return_score=rs, workspace=False).cpu().numpy()
+            assert_close(fast, slow, rtol=1e-4, atol=1e-5, what="din row kernel vs per-sample kernel %s wn=%s scores=%s" % (act, wn, rs))
+        if B <= 64:
+            ref = R.attention_sequence_pooling(q.cpu().numpy().astype(np.float64), k.cpu().numpy().astype(np.float64), km,
+                                               [w.astype(np.float64) for w in ks], [b.astype(np.float64) for b in bs],
+                                               ok.astype(np.float64), ob.astype(np.float64), act,
+                                               [tuple(a.astype(np.float64) for a in dd) for dd in dice] if act == "dice" else None, wn)
+            assert_close(ops.din_attention(*args, act, d, weight_normalization=wn).cpu().numpy(), ref, rtol=1e-4, atol=1e-5,
+                         what="din row kernel vs oracle %s" % act)
