@@ -101,7 +101,8 @@ SYMBOLS = {
     "dctr_embed_lookup": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_vp]),
     "dctr_seq_weight_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
-    "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "dctr_crossnet_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp]),
+    "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
     "dctr_afm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),

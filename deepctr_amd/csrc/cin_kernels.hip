@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int CIN_MAX_LAYERS = 8;
-constexpr int RT_MAX = 4;  // row tiles (16 rows each) per workgroup
+constexpr int RT_MAX = 8;  // row tiles (16 rows each) per workgroup
 
 struct CinParams {
     const float* x;
@@ -27,6 +27,7 @@ struct CinParams {
     int32_t SB;        // samples per workgroup
     int32_t RT;        // row tiles = ceil(SB*D/16)
     int32_t Hmax;      // LDS per-sample stride of the y buffers, in maps
+    int32_t reg_reduce;  // 1: the direct maps are summed over D in registers and never stored (D % 4 == 0)
     int32_t out_dim;   // featuremap_num
     int32_t H[CIN_MAX_LAYERS];
     const float* W[CIN_MAX_LAYERS];
@@ -34,75 +35,178 @@ struct CinParams {
     float* out;
 };
 
+typedef unsigned int cin_u32x2 __attribute__((ext_vector_type(2)));
+
 template <int TPW>
+__device__ __forceinline__ void cin_buf_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float (&b)[TPW]) {
+    if constexpr (TPW == 2) {
+        const cin_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        b[0] = __uint_as_float(t.x); b[1] = __uint_as_float(t.y);
+    } else {
+        b[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    }
+}
+
+#define CIN_SB __builtin_amdgcn_sched_barrier(0)
+
+// One CIN layer for the workgroup's M = SB*D rows.  K = F0*Fk is walked in STAGES of SS k-steps of one i:
+// stage (i, c) covers j = 4*(SS*c + tt) + g, tt < SS (slot g of the MFMA takes j = 4*jt + g).  Software pipeline:
+//   * B (filter rows i*Fk + j, a wave's 16*TPW-column slice) comes from L2 through raw buffer loads — lane-constant
+//     offset, scalar row offset, zero VALU — into THREE rotating register stages (two stages of MFMAs of cover);
+//   * the A operand x0[row,i] * x_k[row,j] is formed in registers: its LDS reads for stage s+1 are issued before the
+//     MFMAs of stage s and multiplied after them;
+//   * sched_barriers pin "issue loads, then MFMAs" (hipcc otherwise sinks each load next to its use).
+// The earlier form (one filter load, four LDS reads, eight MFMAs, wait) ran at 48 % of the nominal f32-MFMA rate; this
+// one at 60 % (C3: 420 us per 4096 samples; a pure-MFMA loop sustains 139 of the nominal 157 TFLOP/s on this part).
+template <int TPW, int RT>
 __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float* x0s, const float* xk, int xk_stride,
-                                          int Fk, float* ycur) {
+                                          int Fk, float* ycur, int Hn, int d0, int64_t bbase, int out_off) {
     using dctr::f32x4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, g = lane >> 4, jl = lane & 15;
     const int D = p.D, F0 = p.F0, H = p.H[k];
     const int M = p.SB * D;
     // per row tile: LDS offsets of this lane's row (s,d) in the x0 tile and in the x_k tile
-    int off0[RT_MAX], offk[RT_MAX];
-    bool rowok[RT_MAX];
+    int off0[RT], offk[RT];
+    bool rowok[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT_MAX; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const int m = rt * 16 + jl;
-        rowok[rt] = rt < p.RT && m < M;
+        rowok[rt] = m < M;
         const int mm = rowok[rt] ? m : 0;
         const int s = mm / D, d = mm % D;
         off0[rt] = s * F0 * D + d;
         offk[rt] = s * xk_stride + d;
     }
     const int n_tiles = (H + 16 * TPW - 1) / (16 * TPW);
-    const int JT = (Fk + 3) / 4;
+    constexpr int SS = RT > 4 ? 2 : 4;    // k-steps per stage: 16*TPW... = SS*RT*TPW MFMAs; fewer with 8 row tiles (VGPRs)
+    const int JT = (Fk + 3) / 4;          // k-steps per i
+    const int NC = (JT + SS - 1) / SS;    // stages per i
+    const int n_stage = F0 * NC;
     const float* Wk = p.W[k];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wk), 0, F0 * Fk * H * 4, 0x00020000);
     for (int wt = wave; wt < n_tiles; wt += 4) {
         const int n_base = wt * 16 * TPW;
         int n0 = n_base + TPW * jl;
         if (n0 + TPW > H) n0 = H - TPW;
-        f32x4 acc[RT_MAX][TPW];
+        const int voff = (g * H + n0) * 4;            // lane-constant byte offset: slot row g, column slice
+        f32x4 acc[RT][TPW];
 #pragma unroll
-        for (int rt = 0; rt < RT_MAX; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < F0; ++i) {
-            float xi[RT_MAX];
+
+        // stage counters of the two prefetch streams (scalar): B runs two stages ahead, the A reads one
+        int iB = 0, cB = 0, iR = 0, cR = 0;
+        auto load_b = [&](float (&b)[SS][TPW]) {      // stage (iB, cB), then advance
 #pragma unroll
-            for (int rt = 0; rt < RT_MAX; ++rt) xi[rt] = rowok[rt] ? x0s[off0[rt] + i * D] : 0.f;
-            const float* wrow = Wk + (int64_t)i * Fk * H + n0;
-#pragma unroll 2
-            for (int jt = 0; jt < JT; ++jt) {
-                const int j = 4 * jt + g;
-                const bool jok = j < Fk;
-                const int jj = jok ? j : Fk - 1;
-                float b[TPW];
-                dctr::load_cols<TPW>(wrow + (int64_t)jj * H, b);
-                float a[RT_MAX];
+            for (int tt = 0; tt < SS; ++tt) {
+                const int jt = min(SS * cB + tt, JT - 1);             // steps past JT are masked on the A side
+                cin_buf_load<TPW>(rsrc, voff, (iB * Fk + 4 * jt) * H * 4, b[tt]);
+            }
+            if (++cB == NC) { cB = 0; iB = min(iB + 1, F0 - 1); }
+        };
+        float rxi[RT], rxk[SS][RT];
+        int c_raw = 0;
+        auto load_raw = [&]() {                       // stage (iR, cR), then advance
+            c_raw = cR;
 #pragma unroll
-                for (int rt = 0; rt < RT_MAX; ++rt) a[rt] = jok ? xi[rt] * xk[offk[rt] + jj * D] : 0.f;
+            for (int rt = 0; rt < RT; ++rt) rxi[rt] = x0s[off0[rt] + iR * D];
 #pragma unroll
-                for (int rt = 0; rt < RT_MAX; ++rt)
+            for (int tt = 0; tt < SS; ++tt) {
+                const int j = min(4 * (SS * cR + tt) + g, Fk - 1);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) rxk[tt][rt] = xk[offk[rt] + j * D];
+            }
+            if (++cR == NC) { cR = 0; iR = min(iR + 1, F0 - 1); }
+        };
+        float a[SS][RT];
+        auto make_a = [&]() {
+#pragma unroll
+            for (int tt = 0; tt < SS; ++tt) {
+                const bool jok = 4 * (SS * c_raw + tt) + g < Fk;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[tt][rt] = (jok && rowok[rt]) ? rxi[rt] * rxk[tt][rt] : 0.f;
+            }
+        };
+        auto mfmas = [&](const float (&b)[SS][TPW]) {
+#pragma unroll
+            for (int tt = 0; tt < SS; ++tt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int c = 0; c < TPW; ++c)
-                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[c], acc[rt][c], 0, 0, 0);
-            }
+                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][rt], b[tt][c], acc[rt][c], 0, 0, 0);
+        };
+        float b0[SS][TPW], b1[SS][TPW], b2[SS][TPW];
+        load_b(b0);
+        load_b(b1);
+        load_raw();
+        make_a();
+        // stage s: B of stage s+2 -> BZ and the A reads of stage s+1 are issued, then the MFMAs of stage s, then the
+        // products of stage s+1 overwrite `a` (its last reader has issued).  Interleaving those products with the
+        // MFMAs instead (double-buffered a, sched_group_barrier 1:1) measured 6 % SLOWER.
+#define CIN_STAGE(BX, BZ)        \
+    do {                         \
+        load_b(BZ);              \
+        load_raw();              \
+        CIN_SB;                  \
+        mfmas(BX);               \
+        CIN_SB;                  \
+        make_a();                \
+        CIN_SB;                  \
+    } while (0)
+        for (int s = 0; s < n_stage; s += 3) {
+            CIN_STAGE(b0, b2);
+            if (s + 1 < n_stage) CIN_STAGE(b1, b0);
+            if (s + 2 < n_stage) CIN_STAGE(b2, b1);
         }
-        // epilogue: bias + activation, store y[s][n][d] (C layout: row = 4g + r, col = n_base + TPW*jl + c)
+#undef CIN_STAGE
+        // epilogue: bias + activation (C layout: row m = 16rt + 4g + r = (sample s, d), col n = n_base + TPW*jl + c).
+        // Maps [0, Hn) feed the next layer -> y[s][n][d] in LDS.  Maps [d0, H) go to the output summed over d
+        // (interaction.py:322-323): with reg_reduce that sum is taken here — 4 rows in the lane, lanes 16 / 32 apart
+        // (the other k-slots' rows of the same sample), then the D/16 row tiles of a sample — and written straight
+        // to `out`; otherwise (D % 4 != 0) every map is stored and cin_kernel sums from LDS.
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
             const int n = n_base + TPW * jl + c;
-            if (n < H) {
-                const float bv = p.bias[k][n];
+            const bool nok = n < H;
+            const float bv = nok ? p.bias[k][n] : 0.f;
+            float dsum[RT];
 #pragma unroll
-                for (int rt = 0; rt < RT_MAX; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
+                float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = rt * 16 + 4 * g + r;
-                        if (rt < p.RT && m < M) {
-                            const int s = m / D, d = m % D;
-                            ycur[(s * p.Hmax + n) * D + d] = dctr::apply_act(acc[rt][c][r] + bv, p.activation);
-                        }
+                for (int r = 0; r < 4; ++r) v[r] = dctr::apply_act(acc[rt][c][r] + bv, p.activation);
+                const bool store = nok && (!p.reg_reduce || n < Hn);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = rt * 16 + 4 * g + r;
+                    if (store && m < M) {
+                        const int s = m / D, d = m - s * D;
+                        ycur[(s * p.Hmax + n) * D + d] = v[r];
+                    }
+                }
+                float t = (v[0] + v[1]) + (v[2] + v[3]);
+                if (D >= 8) t += __shfl_xor(t, 16, 64);
+                if (D >= 16) t += __shfl_xor(t, 32, 64);
+                dsum[rt] = t;
+            }
+            if (p.reg_reduce && nok && n >= d0) {
+                const int per = D >= 16 ? D / 16 : 1;                 // row tiles per sample
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (rt % per != 0) continue;
+                    float t = dsum[rt];
+#pragma unroll
+                    for (int q = 1; q < RT; ++q)
+                        if (q < per && rt + q < RT) t += dsum[rt + q];
+                    const int m = rt * 16 + 4 * g;                    // first row of this lane's group
+                    const bool lead = D >= 16 ? g == 0 : (4 * g) % D == 0;
+                    if (lead && m < M) {
+                        const int64_t b = bbase + m / D;
+                        if (b < p.batch) p.out[b * p.out_dim + out_off + (n - d0)] = t;
                     }
                 }
             }
@@ -110,16 +214,33 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
     }
 }
 
-__global__ __launch_bounds__(256) void cin_kernel(CinParams p) {
+template <int RT>
+__global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = p.D, F0 = p.F0, SB = p.SB;
     float* x0s = smem;                              // [SB][F0][D]
     float* y0 = x0s + ((SB * F0 * D + 3) & ~3);     // [SB][Hmax][D]
     float* y1 = y0 + SB * p.Hmax * D;
     const int64_t b0 = (int64_t)blockIdx.x * SB;
-    for (int i = threadIdx.x; i < SB * F0 * D; i += 256) {
-        const int s = i / (F0 * D);
-        x0s[i] = (b0 + s < p.batch) ? p.x[(b0 + s) * p.x_stride + (i - s * F0 * D)] : 0.f;
+    {
+        // x0 tile: all global loads of a pass in flight before the LDS stores
+        const int total = SB * F0 * D, fd = F0 * D;
+        for (int base = 0; base < total; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * 256 + (int)threadIdx.x, total - 1);
+                const int s = i / fd;
+                const int64_t b = min(b0 + s, p.batch - 1);
+                v[u] = p.x[b * p.x_stride + (i - s * fd)];
+                if (b0 + s >= p.batch) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                if (i < total) x0s[i] = v[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -130,9 +251,6 @@ __global__ __launch_bounds__(256) void cin_kernel(CinParams p) {
     int out_off = 0;
     for (int k = 0; k < p.n_layers; ++k) {
         const int H = p.H[k];
-        if (H % 32 == 0) cin_layer<2>(p, k, x0s, xk, xk_stride, Fk, ycur);
-        else cin_layer<1>(p, k, x0s, xk, xk_stride, Fk, ycur);
-        __syncthreads();
         // split (interaction.py:308-317): maps [0, Hn) feed the next layer, maps [d0, H) go to the output
         const bool last = k == p.n_layers - 1;
         int Hn, d0;
@@ -140,18 +258,23 @@ __global__ __launch_bounds__(256) void cin_kernel(CinParams p) {
             Hn = last ? 0 : H / 2;
             d0 = last ? 0 : H / 2;
         } else {
-            Hn = H;
+            Hn = last ? 0 : H;
             d0 = 0;
         }
+        if (H % 32 == 0) cin_layer<2, RT>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
+        else cin_layer<1, RT>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
+        __syncthreads();
         const int nd = H - d0;
-        // result = reduce_sum(concat(direct), -1): deterministic serial sum over d
-        for (int t = threadIdx.x; t < SB * nd; t += 256) {
-            const int s = t / nd, n = d0 + t % nd;
-            if (b0 + s < p.batch) {
-                const float* yp = ycur + (s * p.Hmax + n) * D;
-                float acc = 0.f;
-                for (int d = 0; d < D; ++d) acc += yp[d];
-                p.out[(b0 + s) * p.out_dim + out_off + (n - d0)] = acc;
+        if (!p.reg_reduce) {
+            // result = reduce_sum(concat(direct), -1): deterministic serial sum over d
+            for (int t = threadIdx.x; t < SB * nd; t += 256) {
+                const int s = t / nd, n = d0 + t % nd;
+                if (b0 + s < p.batch) {
+                    const float* yp = ycur + (s * p.Hmax + n) * D;
+                    float acc = 0.f;
+                    for (int d = 0; d < D; ++d) acc += yp[d];
+                    p.out[(b0 + s) * p.out_dim + out_off + (n - d0)] = acc;
+                }
             }
         }
         out_off += nd;
@@ -199,14 +322,13 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     p.n_layers = a->n_layers;
     p.split_half = a->split_half ? 1 : 0;
     p.activation = a->activation;
-    p.SB = 64 / a->dim;
-    if (p.SB < 1) p.SB = 1;
-    p.RT = (p.SB * a->dim + 15) / 16;
+    p.reg_reduce = a->dim % 4 == 0 ? 1 : 0;
     int hmax = 1;
     for (int k = 0; k < a->n_layers; ++k) {
         const int H = a->layer_size[k];
         DCTR_REQUIRE(H >= 1, DCTR_E_DIM, "cin_fwd: layer_size[%d]=%d", k, H);
-        if (a->split_half && k != a->n_layers - 1)
+        const bool last = k == a->n_layers - 1;
+        if (a->split_half && !last)
             DCTR_REQUIRE(H % 2 == 0, DCTR_E_DIM,
                          "cin_fwd: layer_size must be even except for the last layer when split_half=True");
         DCTR_REQUIRE(a->filters[k] && a->bias[k], DCTR_E_NULL, "cin_fwd: filters/bias[%d] null", k);
@@ -214,19 +336,39 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
         p.H[k] = H;
         p.W[k] = a->filters[k];
         p.bias[k] = a->bias[k];
-        hmax = H > hmax ? H : hmax;
+        // maps kept in LDS: all of them without reg_reduce, else only those the next layer reads
+        const int keep = !p.reg_reduce ? H : (last ? 1 : (a->split_half ? H / 2 : H));
+        hmax = keep > hmax ? keep : hmax;
     }
     p.Hmax = hmax;
     p.out_dim = cin_out_dim(a);
     p.out = a->out;
-    const size_t lds = ((size_t)((p.SB * p.F0 * p.D + 3) & ~3) + (size_t)2 * p.SB * p.Hmax * p.D) * sizeof(float);
+    // rows per workgroup: 128 (eight 16-row tiles, every filter fragment feeds eight MFMAs per column tile: the
+    // filter stream from L2, 851 KB per workgroup at C3 layer 2, is what bounds this kernel) when two workgroups
+    // still fit a CU's LDS, else 64
+    auto lds_of = [&](int sb) {
+        return ((size_t)((sb * p.F0 * p.D + 3) & ~3) + (size_t)2 * sb * p.Hmax * p.D) * sizeof(float);
+    };
+    int rt = 8;
+    p.SB = 128 / a->dim;
+    if (p.SB < 1) p.SB = 1;
+    if (lds_of(p.SB) > 80 * 1024 || p.SB * a->dim > 128) {
+        rt = 4;
+        p.SB = 64 / a->dim;
+        if (p.SB < 1) p.SB = 1;
+    }
+    p.RT = (p.SB * a->dim + 15) / 16;
+    DCTR_REQUIRE(p.RT <= rt, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d needs %d row tiles", a->dim, p.RT);
+    const size_t lds = lds_of(p.SB);
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "cin_fwd: needs %zu B of LDS (> 160 KiB)", lds);
+    const void* fn = rt == 8 ? (const void*)cin_kernel<8> : (const void*)cin_kernel<4>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)cin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DCTR_REQUIRE(e == hipSuccess, (int)e, "cin_fwd: cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
     }
     const int64_t blocks = dctr_ceil_div(a->batch, p.SB);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "cin_fwd: batch too large");
-    DCTR_LAUNCH(cin_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    if (rt == 8) DCTR_LAUNCH(cin_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else DCTR_LAUNCH(cin_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     return dctr_launch_status("dctr_cin_fwd");
 }

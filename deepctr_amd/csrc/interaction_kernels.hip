@@ -82,44 +82,123 @@ __global__ __launch_bounds__(256) void cross_vector_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-// CrossNet 'matrix': 16-sample tile per workgroup, x0 and x_l in LDS, W_l x_l on f32 MFMA.
+// CrossNet 'matrix' (interaction.py:416-420): x_{l+1} = x_0 * (W_l x_l + b_l) + x_l.
+// 16-sample tile per workgroup of 8 waves; x_0, x_l, x_{l+1} in LDS; W_l x_l on v_mfma_f32_16x16x4_f32.
+// W_l is [out n, in k] row-major, i.e. the MFMA B operand walks k ALONG a row: a lane loads 16 B = 4 consecutive k
+// of row n0 + j (raw buffer load, lane-constant offset + scalar k advance), and the MFMA k-slot g of step u takes
+// k = 16t + 4g + u, so that the matching A fragment is one ds_read_b128 of the (un-permuted) x_l tile.  Three
+// register stages of 32 k each keep two stages of loads in flight under the MFMAs (the 736 KB of W_l at d = 429
+// stream from L2 once per workgroup and layer; that stream, ~16 B/clk per CU, bounds the kernel, not the MFMAs).
+// When d % 4 != 0 (or W is not 16-B aligned) the rows are first re-packed to an aligned stride in the workspace.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cross_matrix_kernel(const float* __restrict__ x, int64_t batch, int d,
-                                                           int64_t x_stride, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, int layers,
-                                                           float* __restrict__ y, int64_t y_stride, int lda) {
+typedef unsigned int cross_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CROSS_WAVES = 8;
+
+__device__ __forceinline__ void cross_load_stage(__amdgpu_buffer_rsrc_t rsrc, int voff, const float* arow, int s,
+                                                 float4 (&b)[2], float4 (&a)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const cross_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (2 * s + h) * 64, 0);
+        b[h] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+        a[h] = *reinterpret_cast<const float4*>(arow + (2 * s + h) * 16);
+    }
+}
+
+// W rows re-packed to a 16-B aligned stride (zero tail): dwordx4 loads need 16-B aligned addresses, and the raw-buffer
+// bounds check drops a WHOLE dwordx4 that straddles the end of the array
+__global__ __launch_bounds__(256) void cross_repack_kernel(const float* __restrict__ w, int d, int dp, int64_t rows,
+                                                           float* __restrict__ out) {
+    const int64_t total = rows * dp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dp;
+        const int c = (int)(i - r * dp);
+        out[i] = c < d ? w[r * d + c] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void cross_mfma_stage(const float4 (&a)[2], const float4 (&b)[2], dctr::f32x4& acc) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].x, b[h].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].y, b[h].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].z, b[h].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].w, b[h].w, acc, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const float* __restrict__ x, int64_t batch, int d,
+                                                                        int64_t x_stride, const float* __restrict__ w,
+                                                                        int wstride, const float* __restrict__ bias,
+                                                                        int layers, float* __restrict__ y, int64_t y_stride,
+                                                                        int lda) {
     using dctr::f32x4;
+    constexpr int NTHR = 64 * CROSS_WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* x0 = smem;                 // [16][lda]
+    float* x0 = smem;                 // [16][lda], columns >= d zero up to the next multiple of 32
     float* xa = smem + 16 * lda;      // x_l
     float* xb = smem + 32 * lda;      // x_{l+1}
     const int64_t b0 = (int64_t)blockIdx.x * 16;
-    const int KP = dctr::pad16(d);
-    for (int i = threadIdx.x; i < 16 * KP; i += 256) {
-        const int r = i / KP, c = i % KP;
-        const float v = (b0 + r < batch && c < d) ? x[(b0 + r) * x_stride + c] : 0.f;
-        x0[r * lda + c] = v;
-        xa[r * lda + c] = v;
-        xb[r * lda + c] = 0.f;
+    const int KP = (d + 31) & ~31;
+    for (int base = 0; base < 16 * KP; base += NTHR * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NTHR + threadIdx.x;
+            const int r = (i / KP) & 15, c = i % KP;
+            const int64_t b = min(b0 + r, batch - 1);
+            v[u] = x[b * x_stride + min(c, d - 1)];
+            if (b0 + r >= batch || c >= d) v[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NTHR + threadIdx.x;
+            if (i < 16 * KP) {
+                const int r = i / KP, c = i % KP;
+                x0[r * lda + c] = v[u];
+                xa[r * lda + c] = v[u];
+                xb[r * lda + c] = 0.f;
+            }
+        }
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int KQ = KP / 4;
     const int n_tiles = (d + 15) / 16;
+    const int n_stage = KP / 32;
     for (int l = 0; l < layers; ++l) {
-        const float* W = w + (int64_t)l * d * d;
-        for (int wt = wave; wt < n_tiles; wt += 4) {
-            f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-            dctr::tile_gemm_nk<1>(xa, lda, d, KQ, W, d, wt * 16, acc);
+        const float* W = w + (int64_t)l * d * wstride;     // rows 16-B aligned: wstride % 4 == 0
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, d * wstride * 4, 0x00020000);
+        const float* arow = xa + j * lda + 4 * g;
+        for (int wt = wave; wt < n_tiles; wt += CROSS_WAVES) {
             const int n = wt * 16 + j;
+            const int voff = (min(n, d - 1) * wstride + 4 * g) * 4;   // row n, first k of this lane's slot
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 bA[2], bB[2], bC[2], aA[2], aB[2], aC[2];
+            const int s_last = n_stage - 1;
+            cross_load_stage(rsrc, voff, arow, 0, bA, aA);
+            cross_load_stage(rsrc, voff, arow, min(1, s_last), bB, aB);
+            for (int s = 0; s < n_stage; s += 3) {
+                cross_load_stage(rsrc, voff, arow, min(s + 2, s_last), bC, aC);
+                __builtin_amdgcn_sched_barrier(0);
+                cross_mfma_stage(aA, bA, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                cross_load_stage(rsrc, voff, arow, min(s + 3, s_last), bA, aA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < n_stage) cross_mfma_stage(aB, bB, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                cross_load_stage(rsrc, voff, arow, min(s + 4, s_last), bB, aB);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 2 < n_stage) cross_mfma_stage(aC, bC, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (n < d) {
                 const float bv = bias[(int64_t)l * d + n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * g + r;
                     // interaction.py:419-420: x_l = x_0 * (W x_l + b) + x_l
-                    xb[row * lda + n] = x0[row * lda + n] * (acc[0][r] + bv) + xa[row * lda + n];
+                    xb[row * lda + n] = x0[row * lda + n] * (acc[r] + bv) + xa[row * lda + n];
                 }
             }
         }
@@ -128,7 +207,7 @@ __global__ __launch_bounds__(256) void cross_matrix_kernel(const float* __restri
         xa = xb;
         xb = t;
     }
-    for (int i = threadIdx.x; i < 16 * d; i += 256) {
+    for (int i = threadIdx.x; i < 16 * d; i += NTHR) {
         const int r = i / d, c = i % d;
         if (b0 + r < batch) y[(b0 + r) * y_stride + c] = xa[r * lda + c];
     }
@@ -282,9 +361,15 @@ extern "C" int dctr_fm_fwd(const float* x, int64_t batch, int64_t x_stride, int3
     return dctr_launch_status("dctr_fm_fwd");
 }
 
+extern "C" size_t dctr_crossnet_workspace_bytes(int32_t dim, int32_t layers, int32_t mode, const float* kernels) {
+    if (mode != DCTR_CROSS_MATRIX || layers <= 0 || dim < 1) return 0;
+    if (dim % 4 == 0 && dctr_aligned16(kernels)) return 0;
+    return (size_t)layers * dim * ((dim + 3) & ~3) * sizeof(float);
+}
+
 extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* kernels,
                                  const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride,
-                                 void* stream) {
+                                 void* workspace, size_t workspace_bytes, void* stream) {
     DCTR_REQUIRE(batch >= 0 && dim >= 1 && layers >= 0, DCTR_E_DIM, "crossnet_fwd: bad sizes");
     DCTR_REQUIRE(mode == DCTR_CROSS_VECTOR || mode == DCTR_CROSS_MATRIX, DCTR_E_ENUM, "crossnet_fwd: mode %d", mode);
     if (batch == 0) return DCTR_OK;
@@ -309,7 +394,7 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
         }
 #undef CALL_CV
     } else {
-        const int lda = ((dim + 15) & ~15) + 4;
+        const int lda = ((dim + 31) & ~31) + 4;
         const size_t lds = (size_t)3 * 16 * lda * sizeof(float);
         DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d needs %zu B of LDS", dim, lds);
         if (lds > 64 * 1024) {
@@ -319,7 +404,21 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
         }
         const int64_t blocks = dctr_ceil_div(batch, 16);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
-        DCTR_LAUNCH(cross_matrix_kernel, dim3((unsigned)blocks), dim3(256), lds, st, x, batch, dim, x_stride, kernels,
+        DCTR_REQUIRE((int64_t)dim * (dim + 3) * 4 < 0x7fffffffLL, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d too large", dim);
+        const size_t need = dctr_crossnet_workspace_bytes(dim, layers, mode, kernels);
+        const float* wk = kernels;
+        int wstride = dim;
+        if (need > 0) {
+            DCTR_REQUIRE(workspace != nullptr && workspace_bytes >= need && dctr_aligned16(workspace), DCTR_E_NULL,
+                         "crossnet_fwd(matrix): needs a 16-B aligned workspace of %zu B (dctr_crossnet_workspace_bytes)", need);
+            wstride = (dim + 3) & ~3;
+            const int64_t rows = (int64_t)layers * dim;
+            const int64_t rb = dctr_ceil_div(rows * wstride, (int64_t)256);
+            hipLaunchKernelGGL(cross_repack_kernel, dim3((unsigned)(rb > 2048 ? 2048 : rb)), dim3(256), 0, st, kernels, dim,
+                               wstride, rows, static_cast<float*>(workspace));
+            wk = static_cast<const float*>(workspace);
+        }
+        DCTR_LAUNCH(cross_matrix_kernel, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
                            bias, layers, y, y_stride, lda);
     }
     return dctr_launch_status("dctr_crossnet_fwd");

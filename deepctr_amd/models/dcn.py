@@ -40,6 +40,7 @@ class _DCN(FeatureModel):
     def _begin(self):
         super(_DCN, self)._begin()
         self._cross_packed = self.cross.packed() if self.cross is not None else None
+        self._cross_ws = getattr(self, "_cross_ws", None)
 
     def _forward(self, staged, lo, hi, out):
         ws = self.stage_plan.run(staged, lo, hi)
@@ -54,10 +55,15 @@ class _DCN(FeatureModel):
             import ctypes
             from .. import _C
             mode = _C.CROSS_VECTOR if self.cross.parameterization == "vector" else _C.CROSS_MATRIX
+            need = int(_C.lib().dctr_crossnet_workspace_bytes(d, self.cross.layer_num, mode, ctypes.c_void_p(ks.data_ptr())))
+            if need and (self._cross_ws is None or self._cross_ws.numel() * 4 < need):
+                self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)   # re-packed W rows
             _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(ws["dnn_in"].data_ptr()), B, d, ws["dnn_in"].stride(0),
                                                 ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()),
                                                 self.cross.layer_num, mode, ctypes.c_void_p(stack.data_ptr()),
-                                                stack.stride(0), _C.stream_ptr()), "dctr_crossnet_fwd")
+                                                stack.stride(0),
+                                                ctypes.c_void_p(self._cross_ws.data_ptr()) if need else None, need,
+                                                _C.stream_ptr()), "dctr_crossnet_fwd")
             col = d
         if self.dnn is not None:
             ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),

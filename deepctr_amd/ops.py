@@ -269,8 +269,10 @@ def crossnet(x, kernels, bias, parameterization="vector"):
     mode = _C.CROSS_VECTOR if parameterization == "vector" else _C.CROSS_MATRIX
     kernels = None if kernels is None else _f32c(kernels, "kernels")
     bias = None if bias is None else _f32c(bias, "bias")
+    need = int(_C.lib().dctr_crossnet_workspace_bytes(d, L, mode, _ptr(kernels)))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device) if need else None     # re-packed W rows
     _C.check(_C.lib().dctr_crossnet_fwd(_ptr(x), B, d, d, _ptr(kernels), _ptr(bias), L, mode, _ptr(y), d,
-                                        _C.stream_ptr()), "dctr_crossnet_fwd")
+                                        _ptr(ws), need, _C.stream_ptr()), "dctr_crossnet_fwd")
     return y
 
 

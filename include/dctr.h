@@ -184,8 +184,12 @@ int dctr_fm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields,
  *     kernels: [layers, d] (vector) or [layers, d, d] (matrix, W[i][j] row-major); bias [layers, d].
  * ------------------------------------------------------------------------------------------------ */
 enum { DCTR_CROSS_VECTOR = 0, DCTR_CROSS_MATRIX = 1 };
+/* Device scratch the matrix form needs when dim % 4 != 0 or `kernels` is not 16-B aligned (the W rows are re-packed to
+ * a 16-B aligned stride for the dwordx4 weight loads); 0 otherwise. */
+size_t dctr_crossnet_workspace_bytes(int32_t dim, int32_t layers, int32_t mode, const float* kernels);
 int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* kernels,
-                      const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride, void* stream);
+                      const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10 CIN.call — deepctr/layers/interaction.py:277-325   (outer product + 1x1 conv on f32 MFMA)

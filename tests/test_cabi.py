@@ -51,4 +51,5 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.dctr_embed_gather_fm(None, None) == -1
     a = _C.GatherFmArgs(batch=4, n_fields=0, n_dense=0)
     assert lib.dctr_embed_gather_fm(ctypes.byref(a), None) == -2
-    assert lib.dctr_crossnet_fwd(None, 4, 8, 8, None, None, 1, 7, None, 8, None) == -4     # DCTR_E_ENUM
+    assert lib.dctr_crossnet_fwd(None, 4, 8, 8, None, None, 1, 7, None, 8, None, 0, None) == -4     # DCTR_E_ENUM
+    assert lib.dctr_crossnet_workspace_bytes(429, 2, 1, None) == 2 * 429 * 432 * 4 and lib.dctr_crossnet_workspace_bytes(64, 2, 1, None) == 0
