@@ -256,6 +256,13 @@ def main():
                     "algorithmic_flop_per_launch": DNN_FLOP_PER_SAMPLE * B}
         if "hbm_frac" in dom:
             roofline["hbm_algorithmic_GBps"], roofline["hbm_frac"] = dom["hbm_algorithmic_GBps"], dom["hbm_frac"]
+        # `achieved` / `frac` above are per LAUNCH (one launch = 128 workgroups of 32 rows = half the CUs; --streams
+        # launches overlap in the timed region, so each launch's duration is also what rocprofv3 reports there).
+        # The rate the whole GPU sustains in the timed region is the aggregate below.
+        roofline["concurrent_launches"] = n_streams
+        roofline["aggregate_achieved"] = (value / world) * DNN_FLOP_PER_SAMPLE / 1e12
+        roofline["aggregate_frac"] = roofline["aggregate_achieved"] / F32_MFMA_PEAK_TF
+        roofline["sustained_mfma_f32_peak_measured"] = 139.0    # scripts/mfma_lab.cpp: pure v_mfma_f32_16x16x4 loop, all CUs
         result = {
             "metric": "samples/sec fwd DeepFM Criteo-26x1e5 emb16 b4096", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3 if K else None,
