@@ -2,6 +2,7 @@
 // design notes).  Included by one translation unit per row-tile count RT (mlp_kernels_rt{1,2,4}.hip) so that the
 // instantiations compile in parallel, and by mlp_kernels.hip for the parameter structs.
 #pragma once
+#include <type_traits>
 #include "dctr_common.h"
 #include "embed_device.h"
 #include "mfma_tile.h"
@@ -343,55 +344,150 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
     const int lane = threadIdx.x & 63;
     const int s = lane / LPR, q = lane % LPR;
 
-    // columns past the real input (K padding) and rows past the batch are zero
-    for (int i = threadIdx.x; i < ROWS * KQc; i += NTHR) {
-        const int r = i / KQc, c4 = i - r * KQc;
-        const bool rowok = b0 + r < g.batch;
+    // columns past the real input (K padding) and rows past the batch are zero; nothing to do for a chunk of real
+    // columns in a full workgroup, and only the padding columns otherwise
+    {
+        const bool full_rows = b0 + ROWS <= g.batch;
+        const int real4 = full_rows ? min(max((p.in_dim - c0) / 4, 0), KQc) : 0;    // leading float4 groups that need no fill
+        const int nfill = KQc - real4;
+        for (int i = threadIdx.x; i < ROWS * nfill; i += NTHR) {
+            const int r = i / nfill, c4 = real4 + (i - r * nfill);
+            const bool rowok = b0 + r < g.batch;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (!rowok || c0 + 4 * c4 + k >= p.in_dim) tile[r * p.lda + k * KQc + c4] = 0.f;
+            for (int k = 0; k < 4; ++k)
+                if (!rowok || c0 + 4 * c4 + k >= p.in_dim) tile[r * p.lda + k * KQc + c4] = 0.f;
+        }
     }
 
+    // dense features (last chunk): lanes 0..ROWS-1 of the last wave take one sample each.  The first 16 values are
+    // requested NOW and consumed after the gather, whose two memory round trips hide theirs.
+    const bool dense_wave = ck.last && g.n_dense > 0 && wave == NWAVE - 1;
+    float dx[16];
+    if (dense_wave) {
+        const int r = min(lane, ROWS - 1);
+        const float* src = g.dense + min(b0 + r, g.batch - 1) * g.dense_stride;
 #pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const int r = pass * SPW + s;
-        const int64_t b = b0 + r;
-        const bool valid = r < ROWS && b < g.batch;
-        float* rp = red + ((wave * PASSES + pass) * RW) * 64 + lane;
-        float sum[VEC], sq[VEC];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            sum[c] = ck.first ? 0.f : rp[c * 64];
-            sq[c] = 0.f;
-        }
-        GatherAcc acc{ck.first ? 0.f : rp[(VEC + 1) * 64], 0};
-        float* const trow = tile + (r & (ROWS - 1)) * p.lda;
-        auto store = [trow, KQc, c0](int col, const float (&v)[VEC]) {   // col % 4 == 0: local col+k -> k*KQc + col/4
-            float* dst = trow + ((col - c0) >> 2);
-            dst[0] = v[0];
-            dst[KQc] = v[1];
-            dst[2 * KQc] = v[2];
-            dst[3 * KQc] = v[3];
-        };
-        gather_fields<VEC, LPR, HASH>(g, ck.f_lo + wave, NWAVE, ck.f_hi, b, valid, q, sum, sq, acc, store);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) rp[c * 64] = sum[c];
-        rp[VEC * 64] = (ck.first ? 0.f : rp[VEC * 64]) + ((sq[0] + sq[1]) + (sq[2] + sq[3]));
-        rp[(VEC + 1) * 64] = acc.lin;
-        if (g.status != nullptr && __any(acc.oor) && lane == 0) atomicOr(g.status, (int)DCTR_STATUS_INDEX_OOR);
+        for (int m = 0; m < 16; ++m) dx[m] = src[min(m, g.n_dense - 1)];
     }
+
+    LAB_TS(ck.first ? 20 : 30);
+    // The wave's work items are (field, pass) pairs: field f_lo + wave + NWAVE*fi, samples pass*SPW + s.  They are
+    // processed eight at a time in branch-free phases — 8 id loads, then 8 row + 8 linear loads, then use — so a chunk
+    // costs two memory round trips whatever PASSES is (one pass at a time cost 2*PASSES of them).
+    static_assert(8 % PASSES == 0, "PASSES divides the batch");
+    float sum[PASSES][VEC], sqs[PASSES], lin[PASSES];
+    int oor = 0;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const float* rp = red + ((wave * PASSES + ps) * RW) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) sum[ps][c] = ck.first ? 0.f : rp[c * 64];
+        sqs[ps] = ck.first ? 0.f : rp[VEC * 64];
+        lin[ps] = ck.first ? 0.f : rp[(VEC + 1) * 64];
+    }
+    cfield_ptr Fd = (cfield_ptr)g.fields;
+    const int f_last = ck.f_hi - 1;
+    auto run_batches = [&](auto UC) {
+    constexpr int U = decltype(UC)::value, FPB = U / PASSES;   // items, fields per batch
+    for (int fb = ck.f_lo + wave; fb < ck.f_hi; fb += NWAVE * FPB) {
+        RawId raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = min(fb + NWAVE * (u / PASSES), f_last);
+            const int r = (u % PASSES) * SPW + s;
+            const int64_t b = b0 + r;
+            const int64_t bb = (r < ROWS && b < g.batch) ? b : 0;
+            raw[u] = load_id(g.ids, (int64_t)f * g.ids_stride_f + bb * g.ids_stride_b, g.ids_is_i64);
+        }
+        FieldRegs fr[FPB];
+#pragma unroll
+        for (int k = 0; k < FPB; ++k) fr[k] = load_field(Fd, min(fb + NWAVE * k, f_last));
+        int64_t row[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const FieldRegs& f = fr[u / PASSES];
+            const int r = (u % PASSES) * SPW + s;
+            const int64_t b = b0 + r;
+            const bool live = r < ROWS && b < g.batch && fb + NWAVE * (u / PASSES) <= f_last;
+            int64_t rw = f.identity ? b : id_value(raw[u], g.ids_is_i64);
+            if constexpr (HASH) {
+                if (f.hash_mode != 0) rw = resolve_row(rw, f.hash_mode, g.ids_is_i64, f.vocab);
+            }
+            ok[u] = live && (uint64_t)rw < (uint64_t)f.vocab;
+            if (live && !ok[u]) oor = 1;
+            row[u] = ok[u] ? rw : 0;
+        }
+        float v[U][VEC], lv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const FieldRegs& f = fr[u / PASSES];
+            const int qq = (q * VEC < f.dim) ? q * VEC : 0;
+            load_vec<VEC>(f.table + row[u] * f.dim + qq, v[u]);
+            const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] : reinterpret_cast<const float*>(g.fields);
+            lv[u] = *lp;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const FieldRegs& f = fr[u / PASSES];
+            const int ps = u % PASSES;
+            const bool act = ok[u] && q * VEC < f.dim;
+            if (ok[u] && q == 0 && f.lin_table != nullptr) lin[ps] += lv[u];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[u][c] = act ? v[u][c] : 0.f;
+            if (f.in_fm) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    sum[ps][c] += v[u][c];
+                    sqs[ps] = fmaf(v[u][c], v[u][c], sqs[ps]);
+                }
+            }
+            const int r = ps * SPW + s;
+            const bool live = r < ROWS && b0 + r < g.batch && fb + NWAVE * (u / PASSES) <= f_last;
+            if (f.out_offset >= 0 && live && q * VEC < f.dim) {
+                float* dst = tile + r * p.lda + ((f.out_offset + q * VEC - c0) >> 2);   // local col+k -> k*KQc + col/4
+                dst[0] = v[u][0];
+                dst[KQc] = v[u][1];
+                dst[2 * KQc] = v[u][2];
+                dst[3 * KQc] = v[u][3];
+            }
+        }
+    }
+    };
+    // four items per batch (C2: 2 fields x 2 passes per K-half, or 4 fields x 1 pass): eight would push the kernel past
+    // 128 VGPRs, i.e. spill around the MFMA loops
+    run_batches(std::integral_constant<int, (PASSES <= 4 ? 4 : 8)>{});
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        float* rp = red + ((wave * PASSES + ps) * RW) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) rp[c * 64] = sum[ps][c];
+        rp[VEC * 64] = sqs[ps];
+        rp[(VEC + 1) * 64] = lin[ps];
+    }
+    if (g.status != nullptr && __any(oor) && lane == 0) atomicOr(g.status, (int)DCTR_STATUS_INDEX_OOR);
+    LAB_TS(ck.first ? 21 : 31);
     if (!ck.last) {
         __syncthreads();
+        LAB_TS(22);
         return;
     }
 
-    // dense features: lanes 0..ROWS-1 of the last wave take one sample each (passthrough + dense . Linear.kernel)
-    float dlin = 0.f;
-    if (g.n_dense > 0 && wave == NWAVE - 1 && lane < ROWS) {
+    // dense features: passthrough + dense . Linear.kernel
+    if (dense_wave && lane < ROWS) {
         const int r = lane;
         const bool valid = b0 + r < g.batch;
         const float* src = g.dense + (valid ? b0 + r : 0) * g.dense_stride;
-        for (int k0 = 0; k0 < g.n_dense; k0 += 8) {
+        float dlin = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < g.n_dense && valid) {
+                if (g.dense_out_offset >= 0 && m < g.dense_copy_cols)
+                    tile[r * p.lda + lds_pos(g.dense_out_offset + m - c0, KQc)] = dx[m];
+                dlin = fmaf(dx[m], g.dense_lin_w != nullptr ? g.dense_lin_w[m] : 0.f, dlin);
+            }
+        }
+        for (int k0 = 16; k0 < g.n_dense; k0 += 8) {
             float x[8], w[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -413,6 +509,7 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
     }
     __syncthreads();
 
+    LAB_TS(32);
     // combine the waves' partial sums: FM = 0.5 * (sum_d (sum_f e)^2 - sum_d sum_f e^2), linear = sum of 1-wide rows
     if (threadIdx.x < PASSES * 64) {
         const int pass = threadIdx.x >> 6;
@@ -443,6 +540,7 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
         }
     }
     __syncthreads();     // `red` aliases the tile the first layer writes
+    LAB_TS(33);
 }
 
 template <int RT>
@@ -456,11 +554,11 @@ __device__ __forceinline__ void produce_chunk(const MlpParams& p, const FusedGat
         if (g.any_hash) fused_gather_chunk<L, true, RT>(p, g, tile, red, extra, b0, ck);  \
         else fused_gather_chunk<L, false, RT>(p, g, tile, red, extra, b0, ck);            \
     } while (0)
-            switch (fg.lpr) {                                  // host: 4 lanes per row up to dim 16, 8 to 32, 16 to 64
-                case 4: DCTR_FUSED(4); break;
-                case 8: DCTR_FUSED(8); break;
-                default: DCTR_FUSED(16); break;
-            }
+            // host: 4 lanes per row up to dim 16, 8 to 32, 16 to 64 (the last only with 16-row workgroups: eight passes
+            // of partial sums do not fit the 128-VGPR budget of the 32-row kernel)
+            if (fg.lpr == 4) DCTR_FUSED(4);
+            else if (fg.lpr == 8) DCTR_FUSED(8);
+            else if constexpr (RT == 1) DCTR_FUSED(16);
 #undef DCTR_FUSED
             return;
         }

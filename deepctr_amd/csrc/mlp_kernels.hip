@@ -117,6 +117,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
                  "mlp_fwd: tile_rows %d (0, 16, 32 or 64)", a->tile_rows);
     if (rt == 0) rt = a->batch > 16 * 2 * 256 ? 2 : 1;
     if (ga != nullptr && rt > 2) rt = 2;
+    if (ga != nullptr && lpr == 16) rt = 1;                  // embedding_dim > 32: see produce_chunk
 
     // layer-0 K split candidate: the caller's field boundary (fused) or the middle of the padded row (plain), usable
     // when every wave owns at most one wave-tile of layer 0 (its accumulators stay in registers across the halves)
