@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of one hipGraph")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="independent batches in flight: step i is enqueued on stream i %% streams (fused 1-launch path only)")
     ap.add_argument("--tile-rows", type=int, default=32,
                     help="batch rows per workgroup of the fused kernel (0 = library default, 16 = lowest latency of one "
