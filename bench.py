@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=32,
                     help="batch rows per workgroup of the fused kernel (0 = library default, 16 = lowest latency of one "
                          "batch, 32 = highest throughput with several batches in flight)")
+    ap.add_argument("--no-k-split", action="store_true", help="lab: do not offer the layer-0 K split to the fused kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,6 +161,8 @@ def main():
     _C.lib()
     model, cols = build_model(device)
     model.tile_rows = args.tile_rows
+    if args.no_k_split:
+        model.stage_plan.k_split = (0, 0)
     K, W, ring = args.steps, args.warmup, max(1, min(args.ring, max(args.steps, 1)))
     staged = model.stage(synthetic_feed(ring * B, 1000 + rank))       # device-resident before timing
     model._begin()

@@ -75,7 +75,23 @@ class MlpArgs(ctypes.Structure):
                 ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
                 ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
                 ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
-                ("tile_rows", c_i32), ("reserved_", c_i32)]
+                ("save_acts", c_vp), ("tile_rows", c_i32), ("reserved_", c_i32)]
+
+
+class FieldGrad(ctypes.Structure):
+    _fields_ = [("g_table", c_vp), ("g_lin_table", c_vp)]
+
+
+class GatherFmBwdArgs(ctypes.Structure):
+    _fields_ = [("fwd", ctypes.POINTER(GatherFmArgs)), ("grads", c_vp), ("d_dnn_in", c_vp), ("d_stride", c_i64),
+                ("d_fm", c_vp), ("d_lin", c_vp), ("g_dense_lin_w", c_vp), ("dense_lin_rows", c_vp)]
+
+
+class MlpBwdArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("in_dim", c_i32), ("n_layers", c_i32),
+                ("units", c_vp), ("kernels", c_vp), ("acts", c_vp), ("activation", c_i32), ("pad_", c_i32),
+                ("head_w", c_vp), ("dlogit", c_vp), ("d_kernels", c_vp), ("d_biases", c_vp), ("d_head_w", c_vp),
+                ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz)]
 
 
 class DinAttnArgs(ctypes.Structure):
@@ -110,6 +126,11 @@ SYMBOLS = {
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
     "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),
+    "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
+    "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
+    "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
+    "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_din_attn_workspace_bytes": (c_sz, [ctypes.POINTER(DinAttnArgs)]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
 }

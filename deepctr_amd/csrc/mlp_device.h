@@ -44,6 +44,7 @@ struct MlpParams {
     const float* global_bias;
     float* y;
     int64_t y_stride;
+    float* save[MAX_LAYERS];  // training: layer l's activations [B, units[l]] also go to HBM (NULL = inference)
     int32_t lda;      // LDS row stride (floats) = pad64(max tile width) + 4
     int32_t k_split;  // 0, or the column (multiple of 64) at which the layer-0 input tile is built in two halves
 };
@@ -187,6 +188,8 @@ __device__ __forceinline__ void tile_epilogue(const MlpParams& p, int l, float* 
                                               const dctr::f32x4 (&acc)[RT][TPW]) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int KQn = pad64(N) / 4;
+    float* const sv = p.save[l];
+    const int64_t row0 = (int64_t)blockIdx.x * (16 * RT);
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
         const int n = n_base + TPW * j + c;
@@ -201,9 +204,14 @@ __device__ __forceinline__ void tile_epilogue(const MlpParams& p, int l, float* 
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    out[(rt * 16 + 4 * g + r) * p.lda + lds_pos(n, KQn)] =
-                        act_t<ACT>(acc[rt][c][r] + bv, al, mu, var, p.dice_eps);
+                for (int r = 0; r < 4; ++r) {
+                    const float v = act_t<ACT>(acc[rt][c][r] + bv, al, mu, var, p.dice_eps);
+                    out[(rt * 16 + 4 * g + r) * p.lda + lds_pos(n, KQn)] = v;
+                    if (sv != nullptr) {
+                        const int64_t b = row0 + rt * 16 + 4 * g + r;
+                        if (b < p.batch) sv[b * N + n] = v;
+                    }
+                }
         }
     }
 }

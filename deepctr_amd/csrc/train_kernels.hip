@@ -1,0 +1,345 @@
+// SURVEY.md §8(f) rank 1 — backward + optimizer for the hot path's ops, so that `fit()` runs on HIP kernels:
+//   dctr_bce_grad             loss + d(loss)/d(logit) of PredictionLayer('binary') + binary_crossentropy / of mse
+//   dctr_embed_gather_fm_bwd  backward of dctr_embed_gather_fm: embedding_lookup + concat (inputs.py:101-117,
+//                             layers/utils.py:336-346), get_linear_logit (feature_column.py:171-210) and FM
+//                             (layers/interaction.py:588-604): row gradients scatter-added into dense gradient tables
+//   dctr_mlp_bwd              backward of DNN.call + Dense(1) head (layers/core.py:189-208): the two GEMMs per layer
+//                             are plain library GEMMs (rocBLAS); masks, bias sums and the head are kernels here
+//   dctr_adam_step            Keras Adam (non-lazy: every row of a table moves every step, as TF's
+//                             _resource_apply_sparse does) with the reference's l2 regulariser folded in
+// The reference has no code of its own for any of this (Keras autodiff + tf.keras.optimizers); the formulas are the
+// derivatives of the forward expressions cited above.
+#include <rocblas/rocblas.h>
+
+#include "dctr_common.h"
+#include "embed_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// loss
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                       int64_t batch, int task, float* __restrict__ dlogit,
+                                                       float* __restrict__ loss_sum, float* __restrict__ dlogit_sum) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f, ds = 0.f;
+    if (b < batch) {
+        const float p = pred[b], t = y[b];
+        if (task == 0) {
+            // d/dlogit of mean BCE(sigmoid(logit), y) = (p - y) / B; value with Keras' epsilon clip (backend.epsilon = 1e-7)
+            const float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+            l = -(t * logf(pc) + (1.f - t) * logf(1.f - pc));
+            ds = (p - t) / (float)batch;
+        } else {
+            l = (p - t) * (p - t);
+            ds = 2.f * (p - t) / (float)batch;
+        }
+        dlogit[b] = ds;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        l += __shfl_xor(l, m, 64);
+        ds += __shfl_xor(ds, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (loss_sum != nullptr) unsafeAtomicAdd(loss_sum, l);
+        if (dlogit_sum != nullptr) unsafeAtomicAdd(dlogit_sum, ds);     // gradient of PredictionLayer's global_bias
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// embedding / linear / FM backward.  Lane (s, q) = 16-B chunk q of sample s, as in the forward gather.
+//   d e_f = d dnn_in[b, off_f ..] + d_fm[b] * (S - e_f)     (S = sum over the FM fields of e: FM = 0.5 (S^2 - sum e^2))
+//   d lin_f[row] += d_lin[b]
+// ---------------------------------------------------------------------------------------------------
+template <int LPR, bool HASH>
+__global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_t p, const dctr_field_grad_t* __restrict__ gr,
+                                                            const float* __restrict__ d_in, int64_t d_stride,
+                                                            const float* __restrict__ d_fm, const float* __restrict__ d_lin,
+                                                            float* __restrict__ g_dense_lin_w,
+                                                            const int32_t* __restrict__ dense_lin_rows) {
+    constexpr int VEC = 4, SPB = 256 / LPR;
+    const int s = threadIdx.x / LPR, q = threadIdx.x % LPR;
+    const int64_t b = (int64_t)blockIdx.x * SPB + s;
+    const bool valid = b < p.batch;
+    cfield_ptr F = (cfield_ptr)p.fields;
+    const float dfm = (valid && d_fm != nullptr) ? d_fm[b] : 0.f;
+    const float dlin = (valid && d_lin != nullptr) ? d_lin[b] : 0.f;
+    // pass 1: S
+    float S[VEC] = {0.f, 0.f, 0.f, 0.f};
+    if (d_fm != nullptr) {
+        for (int j = 0; j < p.n_fields; ++j) {
+            const FieldRegs f = load_field(F, j);
+            if (!f.in_fm) continue;
+            int64_t r = f.identity ? b : read_id(p.ids, (int64_t)j * p.ids_stride_f + (valid ? b : 0) * p.ids_stride_b, p.ids_is_i64);
+            if constexpr (HASH) {
+                if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
+            }
+            const bool ok = valid && (uint64_t)r < (uint64_t)f.vocab && q * VEC < f.dim;
+            float v[VEC];
+            load_vec<VEC>(f.table + (ok ? r : 0) * f.dim + (ok ? q * VEC : 0), v);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) S[c] += ok ? v[c] : 0.f;
+        }
+    }
+    // pass 2: row gradients
+    for (int j = 0; j < p.n_fields; ++j) {
+        const FieldRegs f = load_field(F, j);
+        int64_t r = f.identity ? b : read_id(p.ids, (int64_t)j * p.ids_stride_f + (valid ? b : 0) * p.ids_stride_b, p.ids_is_i64);
+        if constexpr (HASH) {
+            if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
+        }
+        const bool rok = valid && (uint64_t)r < (uint64_t)f.vocab;
+        const bool ok = rok && q * VEC < f.dim;
+        float* gt = gr[j].g_table;
+        float* gl = gr[j].g_lin_table;
+        if (ok && gt != nullptr) {
+            float g[VEC] = {0.f, 0.f, 0.f, 0.f};
+            if (f.out_offset >= 0 && d_in != nullptr) {
+                const float4 t = *reinterpret_cast<const float4*>(d_in + b * d_stride + f.out_offset + q * VEC);
+                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+            }
+            if (f.in_fm && d_fm != nullptr) {
+                float v[VEC];
+                load_vec<VEC>(f.table + r * f.dim + q * VEC, v);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) g[c] = fmaf(dfm, S[c] - v[c], g[c]);
+            }
+            float* dst = gt + r * f.dim + q * VEC;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) unsafeAtomicAdd(dst + c, g[c]);
+        }
+        if (rok && q == 0 && gl != nullptr && f.lin_table != nullptr) unsafeAtomicAdd(gl + r, dlin);
+    }
+    // dense . Linear.kernel: d w[k] += sum_b d_lin[b] * dense[b, k]
+    if (g_dense_lin_w != nullptr && p.n_dense > 0 && valid && q == 0) {
+        const float* src = p.dense + b * p.dense_stride;
+        for (int k = 0; k < p.n_dense; ++k) {
+            const int row = dense_lin_rows != nullptr ? dense_lin_rows[k] : k;     // dense column k -> row of Linear.kernel
+            if (row >= 0) unsafeAtomicAdd(g_dense_lin_w + row, dlin * src[k]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DNN backward helpers
+// ---------------------------------------------------------------------------------------------------
+// dZ[b, n] = dlogit[b] * head_w[n] * act'(h[b, n]);   d_head_w[n] += sum_b dlogit[b] * h[b, n]
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ head_w,
+                                                       const float* __restrict__ h, int64_t batch, int N, int act,
+                                                       float* __restrict__ dz, float* __restrict__ d_head_w) {
+    // block = 64 rows x all columns; thread t walks columns t, t+256, ...
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float hw = head_w[n];
+        float acc = 0.f;
+        for (int r = 0; r < 64; ++r) {
+            const int64_t b = r0 + r;
+            if (b >= batch) break;
+            const float hv = h[b * N + n], dl = dlogit[b];
+            float d = dl * hw;
+            if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
+            else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
+            else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
+            dz[b * N + n] = d;
+            acc = fmaf(dl, hv, acc);
+        }
+        unsafeAtomicAdd(d_head_w + n, acc);
+    }
+}
+
+// in place: dh[b, n] *= act'(h[b, n]);  db[n] += sum_b dz[b, n]   (also used with h == NULL: only the column sums)
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t batch,
+                                                             int N, int act, float* __restrict__ db) {
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < 64; ++r) {
+            const int64_t b = r0 + r;
+            if (b >= batch) break;
+            float d = dh[b * N + n];
+            if (h != nullptr) {
+                const float hv = h[b * N + n];
+                if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
+                else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
+                else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
+                dh[b * N + n] = d;
+            }
+            acc += d;
+        }
+        if (db != nullptr) unsafeAtomicAdd(db + n, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (Keras): m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= alpha * m / (sqrt(v) + eps),
+// alpha = lr * sqrt(1 - b2^t) / (1 - b1^t) computed by the caller;  g includes 2*l2*w;  the gradient buffer is cleared.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ g, int64_t n, float alpha, float b1, float b2, float eps,
+                                                   float l2, int zero_grad) {
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 wv = reinterpret_cast<float4*>(w)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gv = reinterpret_cast<float4*>(g)[i];
+        float* wp = &wv.x; float* mp = &mv.x; float* vp = &vv.x; const float* gp = &gv.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gg = fmaf(2.f * l2, wp[c], gp[c]);
+            mp[c] = fmaf(b1, mp[c], (1.f - b1) * gg);
+            vp[c] = fmaf(b2, vp[c], (1.f - b2) * gg * gg);
+            wp[c] -= alpha * mp[c] / (sqrtf(vp[c]) + eps);
+        }
+        reinterpret_cast<float4*>(w)[i] = wv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gg = fmaf(2.f * l2, w[i], g[i]);
+        m[i] = fmaf(b1, m[i], (1.f - b1) * gg);
+        v[i] = fmaf(b2, v[i], (1.f - b2) * gg * gg);
+        w[i] -= alpha * m[i] / (sqrtf(v[i]) + eps);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+rocblas_handle blas_handle() {
+    static thread_local rocblas_handle h = nullptr;
+    if (h == nullptr) {
+        if (rocblas_create_handle(&h) != rocblas_status_success) h = nullptr;
+    }
+    return h;
+}
+
+}  // namespace
+
+extern "C" int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
+                             float* dlogit_sum, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && (task == 0 || task == 1), DCTR_E_DIM, "bce_grad: bad batch / task");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(pred && y && dlogit, DCTR_E_NULL, "bce_grad: null pointer");
+    hipLaunchKernelGGL(bce_grad_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, pred,
+                       y, batch, (int)task, dlogit, loss_sum, dlogit_sum);
+    return dctr_launch_status("dctr_bce_grad");
+}
+
+extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr && a->fwd != nullptr, DCTR_E_NULL, "embed_gather_fm_bwd: null args");
+    const dctr_gather_fm_args_t* f = a->fwd;
+    DCTR_REQUIRE(f->batch >= 0 && f->n_fields >= 0, DCTR_E_DIM, "embed_gather_fm_bwd: bad sizes");
+    if (f->batch == 0 || f->n_fields == 0) return DCTR_OK;
+    DCTR_REQUIRE(f->fields && f->ids && a->grads, DCTR_E_NULL, "embed_gather_fm_bwd: null fields / ids / grads");
+    DCTR_REQUIRE(f->all_dim4 && f->max_dim <= 64, DCTR_E_UNSUPPORTED,
+                 "embed_gather_fm_bwd: needs every embedding_dim %% 4 == 0 and <= 64");
+    DCTR_REQUIRE(a->d_dnn_in == nullptr || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_dnn_in)), DCTR_E_ALIGN,
+                 "embed_gather_fm_bwd: d_dnn_in must be 16-B aligned with a stride %% 4 == 0");
+    int lpr = 1;
+    while (lpr * 4 < f->max_dim) lpr <<= 1;
+    const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(256 / lpr));
+    DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_gather_fm_bwd: batch too large");
+    hipStream_t st = (hipStream_t)stream;
+#define CALL_BWD(L)                                                                                                       \
+    do {                                                                                                                  \
+        if (f->any_hash)                                                                                                  \
+            hipLaunchKernelGGL((gather_fm_bwd_kernel<L, true>), dim3((unsigned)blocks), dim3(256), 0, st, *f, a->grads,   \
+                               a->d_dnn_in, a->d_stride, a->d_fm, a->d_lin, a->g_dense_lin_w, a->dense_lin_rows);        \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gather_fm_bwd_kernel<L, false>), dim3((unsigned)blocks), dim3(256), 0, st, *f, a->grads,  \
+                               a->d_dnn_in, a->d_stride, a->d_fm, a->d_lin, a->g_dense_lin_w, a->dense_lin_rows);        \
+    } while (0)
+    switch (lpr) {
+        case 1: CALL_BWD(1); break;
+        case 2: CALL_BWD(2); break;
+        case 4: CALL_BWD(4); break;
+        case 8: CALL_BWD(8); break;
+        default: CALL_BWD(16); break;
+    }
+#undef CALL_BWD
+    return dctr_launch_status("dctr_embed_gather_fm_bwd");
+}
+
+extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
+    if (a == nullptr || a->batch <= 0) return 0;
+    int w = a->in_dim;
+    for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
+    return (size_t)2 * a->batch * w * sizeof(float);
+}
+
+extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_bwd: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->in_dim >= 1 && a->n_layers >= 1 && a->n_layers <= 8, DCTR_E_DIM, "mlp_bwd: bad sizes");
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->x && a->units && a->kernels && a->acts && a->dlogit && a->head_w && a->d_kernels && a->d_head_w, DCTR_E_NULL,
+                 "mlp_bwd: null pointer");
+    DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_UNSUPPORTED,
+                 "mlp_bwd: activation %d has no backward yet (linear, relu, sigmoid, tanh)", a->activation);
+    DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_mlp_bwd_workspace_bytes(a), DCTR_E_NULL,
+                 "mlp_bwd: needs a workspace of dctr_mlp_bwd_workspace_bytes() bytes");
+    DCTR_REQUIRE(a->batch < 0x7fffffffLL, DCTR_E_DIM, "mlp_bwd: batch too large");
+    rocblas_handle h = blas_handle();
+    DCTR_REQUIRE(h != nullptr, DCTR_E_UNSUPPORTED, "mlp_bwd: rocBLAS handle creation failed");
+    hipStream_t st = (hipStream_t)stream;
+    DCTR_REQUIRE(rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_set_stream failed");
+    int w = a->in_dim;
+    for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
+    float* bufA = static_cast<float*>(a->workspace);
+    float* bufB = bufA + (size_t)a->batch * w;
+    const int B = (int)a->batch;
+    const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)64);
+    const int L = a->n_layers;
+    // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit
+    const int NL = a->units[L - 1];
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(rb), dim3(256), 0, st, a->dlogit, a->head_w, a->acts[L - 1], a->batch, NL,
+                       (int)a->activation, bufA, a->d_head_w);
+    float* dz = bufA;
+    float* other = bufB;
+    const float one = 1.f, zero = 0.f;
+    for (int l = L - 1; l >= 0; --l) {
+        const int N = a->units[l], K = l == 0 ? a->in_dim : a->units[l - 1];
+        const float* xin = l == 0 ? a->x : a->acts[l - 1];
+        const int ldx = l == 0 ? (int)a->x_stride : K;
+        // d_bias[n] += sum_b dZ[b, n]   (dZ is final here: the head / the previous iteration applied act')
+        if (a->d_biases != nullptr && a->d_biases[l] != nullptr)
+            hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, dz, (const float*)nullptr, a->batch, N, 0,
+                               a->d_biases[l]);
+        // dW[K, N] (row-major) += X^T dZ:  column-major  dW'(N x K) = dZ'(N x B) * X'(K x B)^T
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, dz, N, xin, ldx,
+                                          &one, a->d_kernels[l], N);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        // dH_prev[B, K] = dZ W^T:  column-major  dH'(K x B) = W'(N x K)^T * dZ'(N x B)
+        const bool to_dx = l == 0;
+        if (to_dx && a->dx == nullptr) break;
+        float* dst = to_dx ? a->dx : other;
+        const int ldd = to_dx ? (int)a->dx_stride : K;
+        rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, B, N, &one, a->kernels[l], N, dz, N, &zero,
+                           dst, ldd);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dX) failed (%d)", (int)rs);
+        if (!to_dx) {
+            // dZ_prev = dH_prev .* act'(h_prev)
+            if (a->activation != DCTR_ACT_LINEAR)
+                hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, other, a->acts[l - 1], a->batch, K,
+                                   (int)a->activation, (float*)nullptr);
+            float* t = dz;
+            dz = other;
+            other = t;
+        }
+    }
+    return dctr_launch_status("dctr_mlp_bwd");
+}
+
+extern "C" int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n, float alpha, float beta1, float beta2,
+                              float eps, float l2, int32_t zero_grad, void* stream) {
+    DCTR_REQUIRE(n >= 0, DCTR_E_DIM, "adam_step: n < 0");
+    if (n == 0) return DCTR_OK;
+    DCTR_REQUIRE(w && m && v && g, DCTR_E_NULL, "adam_step: null pointer");
+    DCTR_REQUIRE(dctr_aligned16(w) && dctr_aligned16(m) && dctr_aligned16(v) && dctr_aligned16(g), DCTR_E_ALIGN,
+                 "adam_step: buffers must be 16-B aligned");
+    int64_t blocks = dctr_ceil_div(n / 4 + 1, (int64_t)256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, g, n, alpha, beta1, beta2,
+                       eps, l2, (int)zero_grad);
+    return dctr_launch_status("dctr_adam_step");
+}

@@ -67,5 +67,9 @@ def DeepFM(linear_feature_columns, dnn_feature_columns, fm_group=(DEFAULT_GROUP_
     """Instantiates the DeepFM architecture on the MI355X forward path.
 
     Arguments are those of the reference constructor; the l2_* regularisers only matter to training losses."""
-    return _DeepFM(linear_feature_columns, dnn_feature_columns, fm_group, dnn_hidden_units, seed, dnn_dropout,
-                   dnn_activation, dnn_use_bn, task, device)
+    m = _DeepFM(linear_feature_columns, dnn_feature_columns, fm_group, dnn_hidden_units, seed, dnn_dropout,
+                dnn_activation, dnn_use_bn, task, device)
+    # l2 regularisers of the reference constructor (feature_column.py:171-210, inputs.py:22, core.py:168): applied by
+    # the HIP training step (training_hip.py) as 2*l2*w added to the gradients
+    m.regularizers = {"embedding": float(l2_reg_embedding), "linear": float(l2_reg_linear), "dnn": float(l2_reg_dnn)}
+    return m

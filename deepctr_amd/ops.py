@@ -341,7 +341,7 @@ def inner_product(x, reduce_sum=True):
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
         sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
-        tile_rows=0):
+        tile_rows=0, save_acts=None):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
@@ -392,6 +392,10 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
                    y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0,
                    tile_rows=int(tile_rows))
+    if save_acts is not None:           # training: layer outputs [B, units[l]] also go to HBM (dctr_mlp_bwd reads them)
+        sa = _ptr_array(list(save_acts))
+        keep.append(sa)
+        a.save_acts = ctypes.cast(sa, ctypes.c_void_p)
     if gather is not None:
         _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(gather), ctypes.byref(a), int(bool(add_fm_logit)),
                                              int(bool(add_lin_logit)), _C.stream_ptr()), "dctr_embed_mlp_fwd")
@@ -446,3 +450,61 @@ def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, 
     if return_score:
         return scores.reshape(B, 1, T)
     return out.reshape(B, 1, E) if own_out else out
+
+
+# ---------------------------------------------------------------------------------------------
+# backward + optimizer (include/dctr.h, last section)
+# ---------------------------------------------------------------------------------------------
+def bce_grad(pred, y, dlogit, loss_sum=None, dlogit_sum=None, task="binary"):
+    """d(mean loss)/d(logit) for PredictionLayer + binary_crossentropy (or mse); the optional device floats accumulate
+    the summed loss and the summed dlogit (= gradient of the global bias)."""
+    _dev_check(pred, y, dlogit)
+    _C.check(_C.lib().dctr_bce_grad(_ptr(pred), _ptr(y), pred.numel(), 0 if task == "binary" else 1, _ptr(dlogit),
+                                    _ptr(loss_sum), _ptr(dlogit_sum), _C.stream_ptr()), "dctr_bce_grad")
+
+
+def make_field_grads(entries, device):
+    """DEVICE array of dctr_field_grad_t from [(g_table or None, g_lin_table or None), ...]."""
+    arr = (_C.FieldGrad * max(1, len(entries)))()
+    for i, (gt, gl) in enumerate(entries):
+        arr[i].g_table = None if gt is None else gt.data_ptr()
+        arr[i].g_lin_table = None if gl is None else gl.data_ptr()
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def embed_gather_fm_bwd(fwd_args, grads_dev, d_dnn_in=None, d_fm=None, d_lin=None, g_dense_lin_w=None, dense_lin_rows=None):
+    """Backward of dctr_embed_gather_fm: row gradients are atomically added into the dense gradient tables."""
+    a = _C.GatherFmBwdArgs(fwd=ctypes.pointer(fwd_args), grads=grads_dev.data_ptr(),
+                           d_dnn_in=None if d_dnn_in is None else d_dnn_in.data_ptr(),
+                           d_stride=0 if d_dnn_in is None else d_dnn_in.stride(0),
+                           d_fm=None if d_fm is None else d_fm.data_ptr(), d_lin=None if d_lin is None else d_lin.data_ptr(),
+                           g_dense_lin_w=None if g_dense_lin_w is None else g_dense_lin_w.data_ptr(),
+                           dense_lin_rows=None if dense_lin_rows is None else dense_lin_rows.data_ptr())
+    _C.check(_C.lib().dctr_embed_gather_fm_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm_bwd")
+
+
+def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None):
+    """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written."""
+    _dev_check(x, dlogit, *kernels)
+    n = len(kernels)
+    units = [k.shape[1] for k in kernels]
+    ua, kp, ap = _i32_array(units), _ptr_array(kernels), _ptr_array(acts)
+    dkp, dbp = _ptr_array(d_kernels), _ptr_array(d_biases)
+    a = _C.MlpBwdArgs(x=x.data_ptr(), batch=x.shape[0], x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
+                      units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
+                      acts=ctypes.cast(ap, ctypes.c_void_p), activation=_C.ACT_CODES[activation], head_w=head_w.data_ptr(),
+                      dlogit=dlogit.data_ptr(), d_kernels=ctypes.cast(dkp, ctypes.c_void_p),
+                      d_biases=ctypes.cast(dbp, ctypes.c_void_p), d_head_w=d_head_w.data_ptr(),
+                      dx=None if dx is None else dx.data_ptr(), dx_stride=0 if dx is None else dx.stride(0))
+    need = int(_C.lib().dctr_mlp_bwd_workspace_bytes(ctypes.byref(a)))
+    ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _C.check(_C.lib().dctr_mlp_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_bwd")
+
+
+def adam_step(w, m, v, g, alpha, beta1=0.9, beta2=0.999, eps=1e-7, l2=0.0, zero_grad=True):
+    """Keras Adam over a whole contiguous parameter (non-lazy), see include/dctr.h."""
+    _dev_check(w, m, v, g)
+    _C.check(_C.lib().dctr_adam_step(_ptr(w), _ptr(m), _ptr(v), _ptr(g), w.numel(), float(alpha), float(beta1), float(beta2),
+                                     float(eps), float(l2), int(bool(zero_grad)), _C.stream_ptr()), "dctr_adam_step")

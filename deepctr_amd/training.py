@@ -202,6 +202,38 @@ _OPTS = {"adam": lambda p: torch.optim.Adam(p, lr=1e-3, eps=1e-7), "adagrad": la
          "sgd": lambda p: torch.optim.SGD(p, lr=1e-2), "rmsprop": lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.9, eps=1e-7)}
 
 
+def _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle):
+    """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
+    moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation."""
+    from .training_hip import HipTrainer
+    tr = getattr(model, "_hip_trainer", None)
+    if tr is None:
+        tr = model._hip_trainer = HipTrainer(model)
+    hist = History()
+    hist.history["loss"] = []
+    bs = int(batch_size) if batch_size else n_tr
+    for ep in range(epochs):
+        order = np.arange(0, n_tr, bs)
+        if shuffle:
+            np.random.shuffle(order)
+        tot = torch.zeros(1, dtype=torch.float64, device=model.device)
+        for lo in order:
+            hi = min(n_tr, lo + bs)
+            model._begin()
+            loss = tr.step(staged, int(lo), int(hi), yt[lo:hi])
+            tot += loss.double() * (hi - lo)
+        model._check_status()
+        hist.history["loss"].append(float(tot.item()) / max(n_tr, 1))
+        hist.epoch.append(ep)
+        if n_val:
+            va = {k: np.asarray(v)[n_tr:] for k, v in feed.items()}
+            hist.history.setdefault("val_loss", []).append(model.evaluate(va, y[n_tr:], batch_size=bs))
+        if verbose:
+            print("Epoch %d/%d - loss: %.4f%s" % (ep + 1, epochs, hist.history["loss"][-1],
+                                                  (" - val_loss: %.4f" % hist.history["val_loss"][-1]) if n_val else ""))
+    return hist
+
+
 def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, **kwargs):
     from . import _C
     _C.require_device()
@@ -215,6 +247,13 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     tr = {k: np.asarray(v)[:n_tr] for k, v in feed.items()}
     staged = model.stage(tr)
     yt = torch.from_numpy(y[:n_tr]).to(model.device)
+    loss_name0 = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
+    from . import training_hip
+    if (getattr(model, "hip_training", True) and isinstance(model._compiled["optimizer"], str)
+            and model._compiled["optimizer"].lower() == "adam" and training_hip.supported(model)
+            and ((loss_name0 in ("binary_crossentropy", "logloss") and model.task == "binary")
+                 or (loss_name0 in ("mse", "mean_squared_error") and model.task != "binary"))):
+        return _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
     params = [t for name, t in model.named_weights() if "moving_" not in name]
     for t in params:
         t.requires_grad_(True)

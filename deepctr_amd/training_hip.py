@@ -1,0 +1,138 @@
+"""HIP training step — SURVEY.md §8(f) rank 1: backward + optimizer of the hot path on HIP kernels.
+
+Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer) with fixed-length
+features: forward = ``dctr_embed_gather_fm`` + ``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` →
+``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` → ``dctr_adam_step`` per parameter.  No torch autograd, no torch
+optimizer: PyTorch only owns the buffers.  Models / options outside that family keep the torch-autograd step of
+``training.py`` (the interaction-layer backward kernels for CIN / CrossNet / attention do not exist yet).
+
+Semantics follow tf.keras as the reference uses it (``model.compile("adam", "binary_crossentropy")``,
+examples/run_classification_criteo.py:44-50): Adam lr 1e-3, beta 0.9 / 0.999, epsilon 1e-7, NON-lazy on embeddings
+(every row of a table decays every step, as ``_resource_apply_sparse`` does), L2 regularisers of the constructor
+(``l2_reg_embedding``, ``l2_reg_linear``, ``l2_reg_dnn``) added to the gradients.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def supported(model):
+    """Can this model train on the HIP step?  (DeepFM family, fixed-length features, relu/linear/sigmoid/tanh DNN.)"""
+    sp = getattr(model, "stage_plan", None)
+    dnn = getattr(model, "dnn", None)
+    if sp is None or dnn is None or type(model).__name__ != "_DeepFM":
+        return False
+    if sp.pooled_fields or sp.lin_only or len(sp.fm_group_names) > 1 or sp.extra_offsets or not sp.all_dim4:
+        return False
+    if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
+        return False
+    if getattr(dnn, "dropout_rate", 0):
+        return False
+    return True
+
+
+class _Param(object):
+    __slots__ = ("w", "m", "v", "g", "l2")
+
+    def __init__(self, w, l2=0.0):
+        self.w = w
+        self.m = torch.zeros_like(w)
+        self.v = torch.zeros_like(w)
+        self.g = torch.zeros_like(w)
+        self.l2 = float(l2)
+
+
+class HipTrainer(object):
+    def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+        if not supported(model):
+            raise ValueError("model is outside the HIP training step's family (see training_hip.supported)")
+        self.model, self.lr, self.b1, self.b2, self.eps = model, float(lr), float(beta1), float(beta2), float(eps)
+        self.t = 0
+        sp = model.stage_plan
+        reg = getattr(model, "regularizers", {})
+        l2e, l2l, l2d = reg.get("embedding", 0.0), reg.get("linear", 0.0), reg.get("dnn", 0.0)
+        self.params = []
+        by_ptr = {}
+
+        def param(t, l2=0.0):
+            key = t.data_ptr()
+            if key not in by_ptr:
+                by_ptr[key] = _Param(t, l2)
+                self.params.append(by_ptr[key])
+            return by_ptr[key]
+
+        entries = []
+        for f in sp.fields:
+            pt = param(f.table, l2e)
+            pl = param(f.lin_table, l2l) if f.lin_table is not None else None
+            entries.append((pt.g, None if pl is None else pl.g))
+        self.field_grads = ops.make_field_grads(entries, model.device)
+        # Linear.kernel (dense features of the linear part): the forward reads a copy permuted into dense-matrix column
+        # order (EmbeddingStage.refresh); the backward kernel scatters straight into the real kernel's gradient
+        self.p_dense_lin, self.dense_rows = None, None
+        if model.linear is not None and sp.n_dense and sp.n_lin_dense and sp.has_linear:
+            self.p_dense_lin = param(model.linear.w("linear_kernel"), l2l)
+            self.dense_rows = torch.as_tensor(sp.dense_lin_rows, dtype=torch.int32, device=model.device)
+        self.p_kernels = [param(k, l2d) for k in model.dnn.kernels]
+        self.p_biases = [param(b) for b in model.dnn.biases]
+        self.p_head = param(model.dense.w("kernel"))
+        self.p_gbias = param(model.prediction.w("global_bias")) if model.prediction.use_bias else None
+        self._buf = {}
+
+    def _buffers(self, B):
+        b = self._buf.get(B)
+        if b is None:
+            dev = self.model.device
+            sp = self.model.stage_plan
+            units = [k.shape[1] for k in self.model.dnn.kernels]
+            b = self._buf[B] = {
+                "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
+                "pred": torch.empty(B, dtype=torch.float32, device=dev),
+                "dlogit": torch.empty(B, dtype=torch.float32, device=dev),
+                "dx": torch.empty(B, sp.out_stride, dtype=torch.float32, device=dev),
+                "loss": torch.zeros(1, dtype=torch.float32, device=dev),
+            }
+        return b
+
+    def step(self, staged, lo, hi, y, apply=True):
+        """One optimizer step on rows [lo, hi) of the staged inputs; y: device float tensor [hi-lo].  Returns the mean
+        loss of the batch BEFORE the update (a device tensor; no host synchronisation here).  ``apply=False`` stops
+        after the backward pass and leaves the gradients in the ``g`` buffers (tests)."""
+        model, sp = self.model, self.model.stage_plan
+        model._begin()                      # weight-derived forward buffers follow the last update
+        B = hi - lo
+        buf = self._buffers(B)
+        binary = model.task == "binary"
+        # forward (two launches, activations saved)
+        ws = sp.run(staged, lo, hi)
+        add = []
+        if sp.has_linear:
+            add.append(ws["lin"])
+        if sp.fm_group_names:
+            add.append(ws["fm"])
+        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w, add=add,
+                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
+                out=buf["pred"], save_acts=buf["acts"])
+        # loss gradient
+        buf["loss"].zero_()
+        ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"],
+                     dlogit_sum=None if self.p_gbias is None else self.p_gbias.g, task="binary" if binary else "regression")
+        # DNN backward
+        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
+                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=buf["dx"])
+        # embedding / linear / FM backward
+        g = sp.gather_args(staged, lo, hi, ws)
+        ops.embed_gather_fm_bwd(g, self.field_grads, d_dnn_in=buf["dx"], d_fm=buf["dlogit"] if sp.fm_group_names else None,
+                                d_lin=buf["dlogit"] if sp.has_linear else None,
+                                g_dense_lin_w=None if self.p_dense_lin is None else self.p_dense_lin.g,
+                                dense_lin_rows=self.dense_rows)
+        if not apply:
+            return buf["loss"] / B
+        # Adam
+        self.t += 1
+        alpha = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for p in self.params:
+            ops.adam_step(p.w, p.m, p.v, p.g, alpha, self.b1, self.b2, self.eps, p.l2)
+        return buf["loss"] / B

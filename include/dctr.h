@@ -261,6 +261,8 @@ typedef struct {
     int64_t y_stride;
     void* workspace;
     size_t workspace_bytes;
+    float* const* save_acts;      /* training: HOST array [n_layers] of DEVICE pointers; layer l's activations
+                                     [B, units[l]] (row stride units[l]) are also written there.  NULL = inference. */
     int32_t tile_rows;            /* batch rows per workgroup: 0 = auto, or 16 / 32 / 64.  Larger tiles re-use every
                                      weight fragment for more rows (less L2->CU weight traffic per row, the bound of
                                      this kernel) at the price of fewer workgroups; results are bit-identical. */
@@ -316,6 +318,72 @@ typedef struct {
 } dctr_din_attn_args_t;
 size_t dctr_din_attn_workspace_bytes(const dctr_din_attn_args_t* args);
 int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* args, void* stream);
+
+/* ================================================================================================
+ * SURVEY.md §8(f) rank 1 — backward + optimizer of the hot path ("next" row; forward entry points above are
+ * unchanged).  The reference has no code for these (Keras autodiff, tf.keras.optimizers.Adam): each entry is the
+ * derivative of the forward expression of the cited lines.  Gradient tables are dense fp32 buffers of the same shape as
+ * the parameter, ACCUMULATED into (atomics); dctr_adam_step consumes and clears them.
+ * ================================================================================================ */
+
+/* loss of PredictionLayer + compile(loss=...): task 0 = binary_crossentropy on sigmoid outputs (value with Keras'
+ * 1e-7 clip), task 1 = mse.  dlogit[b] = d(mean loss)/d(logit_b); optional device floats: loss_sum += sum_b loss_b,
+ * dlogit_sum += sum_b dlogit[b] (= gradient of PredictionLayer's global_bias, layers/core.py:250-259). */
+int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
+                  float* dlogit_sum, void* stream);
+
+typedef struct {
+    float* g_table;       /* [vocab, dim] gradient of the field's table, or NULL (frozen / absent)  */
+    float* g_lin_table;   /* [vocab] gradient of its 1-wide linear table, or NULL                   */
+} dctr_field_grad_t;
+
+/* backward of dctr_embed_gather_fm (inputs.py:101-117, layers/utils.py:336-346, feature_column.py:171-210,
+ * layers/interaction.py:588-604):  d e_f = d_dnn_in[b, off_f..] + d_fm[b] * (sum_f' e_f' - e_f);  d lin_f[row] += d_lin[b];
+ * d dense_lin_w[k] += d_lin[b] * dense[b,k]. */
+typedef struct {
+    const dctr_gather_fm_args_t* fwd;   /* the forward call's arguments (descriptors, ids, dense)            */
+    const dctr_field_grad_t* grads;     /* DEVICE array [n_fields], parallel to fwd->fields                  */
+    const float* d_dnn_in;              /* [B, d_stride] gradient w.r.t. dnn_in, or NULL                      */
+    int64_t d_stride;
+    const float* d_fm;                  /* [B] gradient w.r.t. fm_logit, or NULL (model without FM)           */
+    const float* d_lin;                 /* [B] gradient w.r.t. lin_logit, or NULL                             */
+    float* g_dense_lin_w;               /* gradient of Linear.kernel, or NULL                                 */
+    const int32_t* dense_lin_rows;      /* DEVICE [n_dense]: row of Linear.kernel fed by dense column k (-1: none);
+                                           NULL = identity (fwd->dense_lin_w is the kernel itself)            */
+} dctr_gather_fm_bwd_args_t;
+int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* args, void* stream);
+
+/* backward of dctr_mlp_fwd with has_head (layers/core.py:189-208 + Dense(1, use_bias=False)): needs the activations the
+ * forward saved through save_acts.  The two GEMMs per layer are plain rocBLAS sgemm calls on `stream`. */
+typedef struct {
+    const float* x;               /* [B, x_stride] the forward's input (dnn_in)                          */
+    int64_t batch;
+    int64_t x_stride;
+    int32_t in_dim;
+    int32_t n_layers;             /* >= 1                                                                */
+    const int32_t* units;         /* HOST [n_layers]                                                     */
+    const float* const* kernels;  /* HOST array of DEVICE pointers, as in the forward                    */
+    const float* const* acts;     /* HOST array of DEVICE pointers: saved activations [B, units[l]]      */
+    int32_t activation;           /* DCTR_ACT_LINEAR | RELU | SIGMOID | TANH                             */
+    int32_t pad_;
+    const float* head_w;          /* [units[last]]                                                       */
+    const float* dlogit;          /* [B]                                                                 */
+    float* const* d_kernels;      /* HOST array of DEVICE pointers [in_l, out_l], accumulated into       */
+    float* const* d_biases;       /* HOST array of DEVICE pointers [out_l] (or NULL entries), accumulated */
+    float* d_head_w;              /* [units[last]], accumulated                                          */
+    float* dx;                    /* [B, dx_stride] gradient w.r.t. x (written), or NULL                 */
+    int64_t dx_stride;
+    void* workspace;              /* dctr_mlp_bwd_workspace_bytes() bytes, 16-B aligned                  */
+    size_t workspace_bytes;
+} dctr_mlp_bwd_args_t;
+size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
+int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
+
+/* Keras Adam step over n contiguous floats (a whole table or weight): g' = g + 2*l2*w;  m = b1 m + (1-b1) g';
+ * v = b2 v + (1-b2) g'^2;  w -= alpha * m / (sqrt(v) + eps) with alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the caller.
+ * Non-lazy like tf.keras' sparse apply: rows without a gradient still decay.  zero_grad clears g. */
+int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n, float alpha, float beta1, float beta2, float eps,
+                   float l2, int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

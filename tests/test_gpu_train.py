@@ -1,0 +1,171 @@
+"""GPU: SURVEY §8(f) rank 1 — backward + optimizer kernels (dctr_bce_grad, dctr_mlp_bwd, dctr_embed_gather_fm_bwd,
+dctr_adam_step) against torch autograd / torch.optim on the CPU in float64 (the checker), and the HIP training step of
+DeepFM against the torch-autograd step it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def test_bce_grad(device):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(1)
+    for B in (1, 300, 4097):
+        p = rng.uniform(0.001, 0.999, B).astype(np.float32)
+        p[0] = 1.0                                      # clipped in the value, not in the gradient
+        y = (rng.rand(B) > 0.5).astype(np.float32)
+        dl = torch.empty(B, device=device)
+        ls, ds = torch.zeros(1, device=device), torch.zeros(1, device=device)
+        ops.bce_grad(dev(p, device), dev(y, device), dl, ls, ds)
+        pc = np.clip(p.astype(np.float64), 1e-7, 1 - 1e-7)
+        assert_close(dl.cpu().numpy(), (p.astype(np.float64) - y) / B, rtol=1e-6, atol=1e-9, what="dlogit")
+        assert_close(ls.cpu().numpy(), [-(y * np.log(pc) + (1 - y) * np.log(1 - pc)).sum()], rtol=1e-4, atol=1e-5, what="loss")
+        assert_close(ds.cpu().numpy(), [((p.astype(np.float64) - y) / B).sum()], rtol=1e-4, atol=1e-6, what="dlogit sum")
+        ops.bce_grad(dev(p, device), dev(y, device), dl, None, None, task="regression")
+        assert_close(dl.cpu().numpy(), 2 * (p.astype(np.float64) - y) / B, rtol=1e-6, atol=1e-9, what="mse dlogit")
+
+
+def test_adam_step_matches_torch_adam(device):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(2)
+    for n in (5, 1024, 100003):
+        w0 = rng.standard_normal(n).astype(np.float32)
+        wt = torch.tensor(w0.astype(np.float64), requires_grad=True)
+        opt = torch.optim.Adam([wt], lr=1e-3, eps=1e-3, weight_decay=2 * 0.01)      # l2 = 0.01 -> grad += 2*l2*w
+        w = dev(w0, device)
+        m, v = torch.zeros_like(w), torch.zeros_like(w)
+        for t in range(1, 4):
+            g0 = rng.standard_normal(n).astype(np.float32) * 0.1
+            wt.grad = torch.tensor(g0.astype(np.float64))
+            opt.step()
+            g = dev(g0, device)
+            alpha = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            # torch: w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)  ==  Keras form with eps' = eps*sqrt(1-b2^t)
+            ops.adam_step(w, m, v, g, alpha, 0.9, 0.999, 1e-3 * np.sqrt(1 - 0.999 ** t), l2=0.01)
+            assert float(g.abs().max()) == 0.0                                       # gradient buffer cleared
+        assert_close(w.cpu().numpy(), wt.detach().numpy(), rtol=1e-5, atol=1e-6, what="adam n=%d" % n)
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh", "sigmoid", "linear"])
+def test_mlp_bwd_matches_autograd(device, act):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(3)
+    for B, dims in ((37, [13, 8, 5]), (300, [429, 256, 128, 64]), (65, [20, 7])):
+        x = rng.standard_normal((B, dims[0] + 3)).astype(np.float32)      # row stride > in_dim
+        ks = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+        bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(dims) - 1)]
+        hw = rng.standard_normal(dims[-1]).astype(np.float32) * 0.3
+        dl = rng.standard_normal(B).astype(np.float32) / B
+        # checker: torch autograd, float64, CPU
+        xt = torch.tensor(x[:, :dims[0]].astype(np.float64), requires_grad=True)
+        kt = [torch.tensor(k.astype(np.float64), requires_grad=True) for k in ks]
+        bt = [torch.tensor(b.astype(np.float64), requires_grad=True) for b in bs]
+        ht = torch.tensor(hw.astype(np.float64), requires_grad=True)
+        h = xt
+        f = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "linear": lambda z: z}[act]
+        for k, b in zip(kt, bt):
+            h = f(h @ k + b)
+        ((h @ ht) * torch.tensor(dl.astype(np.float64))).sum().backward()
+        # HIP
+        xd = dev(x, device)
+        kd, bd, hd = [dev(k, device) for k in ks], [dev(b, device) for b in bs], dev(hw, device)
+        acts = [torch.empty(B, n, device=device) for n in dims[1:]]
+        ops.mlp(xd, kd, bd, act, head_w=hd, in_dim=dims[0], save_acts=acts)
+        dk = [torch.zeros_like(k) for k in kd]
+        db = [torch.zeros_like(b) for b in bd]
+        dh = torch.zeros_like(hd)
+        dx = torch.full((B, dims[0] + 1), 7.0, device=device)
+        ops.mlp_bwd(xd, dims[0], kd, acts, act, hd, dev(dl, device), dk, db, dh, dx=dx)
+        tag = "%s B=%d %s" % (act, B, dims)
+        for i in range(len(ks)):
+            assert_close(dk[i].cpu().numpy(), kt[i].grad.numpy(), rtol=1e-4, atol=1e-6, what="dW%d %s" % (i, tag))
+            assert_close(db[i].cpu().numpy(), bt[i].grad.numpy(), rtol=1e-4, atol=1e-6, what="db%d %s" % (i, tag))
+        assert_close(dh.cpu().numpy(), ht.grad.numpy(), rtol=1e-4, atol=1e-6, what="dhead " + tag)
+        assert_close(dx[:, :dims[0]].cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=1e-7, what="dx " + tag)
+        assert float((dx[:, dims[0]:] - 7.0).abs().max()) == 0.0            # columns past in_dim untouched
+
+
+def _deepfm(device, E=16, hidden=(32, 16), hashed=False, n_sparse=6):
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM
+    cols = [SparseFeat("C%d" % i, 50 + 7 * i, E, use_hash=(hashed and i % 2 == 0)) for i in range(n_sparse)] + \
+           [DenseFeat("I%d" % i, 1) for i in range(3)]
+    return DeepFM(cols, cols, dnn_hidden_units=hidden, l2_reg_linear=0, l2_reg_embedding=0, device=device), cols
+
+
+def _feed(rng, cols, n, hashed=False):
+    feed = {}
+    for c in cols:
+        if hasattr(c, "vocabulary_size"):
+            feed[c.name] = rng.randint(0, 10 ** 6 if c.use_hash else c.vocabulary_size, n).astype(np.int32)
+        else:
+            feed[c.name] = rng.rand(n).astype(np.float32)
+    return feed
+
+
+@pytest.mark.parametrize("E,hashed", [(16, False), (8, True), (32, False)])
+def test_hip_training_gradients_match_torch_autograd(device, E, hashed):
+    """Every gradient the HIP step produces (tables incl. duplicate ids, linear tables, Linear kernel, DNN, head, global
+    bias) against torch autograd over training.model_logits on the same device and weights."""
+    from deepctr_amd import training
+    from deepctr_amd.training_hip import HipTrainer
+    from tests.test_gpu_models import _randomise
+    rng = np.random.RandomState(5)
+    model, cols = _deepfm(device, E=E, hashed=hashed)
+    _randomise(model, rng)
+    n = 333
+    feed = _feed(rng, cols, n, hashed)
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    staged = model.stage(feed)
+    model._begin()
+    tr = HipTrainer(model)
+    yt = dev(y, device)
+    loss = tr.step(staged, 0, n, yt, apply=False)
+    # checker: autograd through the torch restatement of the same forward
+    params = [p.w for p in tr.params]
+    for t in params:
+        t.requires_grad_(True)
+    try:
+        model._begin()                  # the permuted copy of Linear.kernel must be built from the grad-tracking kernel
+        logit = training.model_logits(model, staged, 0, n)
+        ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+    assert_close(loss.cpu().numpy(), [float(ref_loss.detach())], rtol=1e-4, atol=1e-6, what="loss")
+    for p, gref in zip(tr.params, grads):
+        gref = torch.zeros_like(p.w) if gref is None else gref
+        assert_close(p.g.cpu().numpy(), gref.cpu().numpy(), rtol=2e-4, atol=2e-7, what="grad of %s" % (tuple(p.w.shape),))
+
+
+def test_deepfm_fit_runs_on_the_hip_step_and_learns(device):
+    rng = np.random.RandomState(6)
+    model, cols = _deepfm(device, E=16, hidden=(64, 32))
+    n = 4096
+    feed = _feed(rng, cols, n)
+    y = ((feed["C0"] % 2) ^ (feed["I0"] > 0.5)).astype(np.float32)
+    model.compile("adam", "binary_crossentropy")
+    before = model.evaluate(feed, y, batch_size=1024)
+    h = model.fit(feed, y, batch_size=256, epochs=10, verbose=0, validation_split=0.25)
+    assert getattr(model, "_hip_trainer", None) is not None, "fit() did not take the HIP training step"
+    after = model.evaluate(feed, y, batch_size=1024)
+    assert len(h.history["loss"]) == 10 and len(h.history["val_loss"]) == 10
+    assert after < before - 0.1, (before, after)
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    # same data through the torch-autograd step from the same start: the two optimisers track each other
+    model2, _ = _deepfm(device, E=16, hidden=(64, 32))
+    model2.hip_training = False
+    model2.compile("adam", "binary_crossentropy")
+    h2 = model2.fit(feed, y, batch_size=256, epochs=10, verbose=0, validation_split=0.25, shuffle=False)
+    model3, _ = _deepfm(device, E=16, hidden=(64, 32))
+    model3.compile("adam", "binary_crossentropy")
+    h3 = model3.fit(feed, y, batch_size=256, epochs=10, verbose=0, validation_split=0.25, shuffle=False)
+    assert abs(h2.history["loss"][-1] - h3.history["loss"][-1]) < 0.02, (h2.history["loss"], h3.history["loss"])
