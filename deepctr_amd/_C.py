@@ -94,6 +94,10 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz)]
 
 
+class AdamSeg(ctypes.Structure):
+    _fields_ = [("w", c_vp), ("m", c_vp), ("v", c_vp), ("g", c_vp), ("n", c_i64), ("l2", c_f32), ("pad_", c_i32)]
+
+
 class DinAttnArgs(ctypes.Structure):
     _fields_ = [("query", c_vp), ("keys", c_vp), ("key_mask", c_vp), ("batch", c_i64), ("maxlen", c_i32),
                 ("dim", c_i32), ("n_layers", c_i32), ("activation", c_i32), ("units", c_vp), ("kernels", c_vp),
@@ -131,6 +135,7 @@ SYMBOLS = {
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "dctr_adam_multi": (ctypes.c_int, [c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_din_attn_workspace_bytes": (c_sz, [ctypes.POINTER(DinAttnArgs)]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
 }

@@ -125,16 +125,18 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
 // ---------------------------------------------------------------------------------------------------
 // DNN backward helpers
 // ---------------------------------------------------------------------------------------------------
+constexpr int BWD_ROWS = 16;     // batch rows per workgroup of the two helpers below (B = 4096 -> 256 workgroups)
+
 // dZ[b, n] = dlogit[b] * head_w[n] * act'(h[b, n]);   d_head_w[n] += sum_b dlogit[b] * h[b, n]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ head_w,
                                                        const float* __restrict__ h, int64_t batch, int N, int act,
                                                        float* __restrict__ dz, float* __restrict__ d_head_w) {
-    // block = 64 rows x all columns; thread t walks columns t, t+256, ...
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    // block = BWD_ROWS rows x all columns; thread t walks columns t, t+256, ...
+    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float hw = head_w[n];
         float acc = 0.f;
-        for (int r = 0; r < 64; ++r) {
+        for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= batch) break;
             const float hv = h[b * N + n], dl = dlogit[b];
@@ -152,10 +154,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // in place: dh[b, n] *= act'(h[b, n]);  db[n] += sum_b dz[b, n]   (also used with h == NULL: only the column sums)
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t batch,
                                                              int N, int act, float* __restrict__ db) {
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     for (int n = threadIdx.x; n < N; n += 256) {
         float acc = 0.f;
-        for (int r = 0; r < 64; ++r) {
+        for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= batch) break;
             float d = dh[b * N + n];
@@ -203,6 +205,44 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
         v[i] = fmaf(b2, v[i], (1.f - b2) * gg * gg);
         w[i] -= alpha * m[i] / (sqrtf(v[i]) + eps);
         if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// all parameters of a model in ONE launch: blockIdx.y = segment, blockIdx.x walks the segment (blocks past its end exit)
+__global__ __launch_bounds__(256) void adam_multi_kernel(const dctr_adam_seg_t* __restrict__ segs, float alpha, float b1,
+                                                         float b2, float eps, int zero_grad) {
+    const dctr_adam_seg_t sg = segs[blockIdx.y];
+    float* __restrict__ w = sg.w;
+    float* __restrict__ m = sg.m;
+    float* __restrict__ v = sg.v;
+    float* __restrict__ g = sg.g;
+    const float l2 = sg.l2;
+    const int64_t n = sg.n, n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 wv = reinterpret_cast<float4*>(w)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gv = reinterpret_cast<float4*>(g)[i];
+        float* wp = &wv.x; float* mp = &mv.x; float* vp = &vv.x; const float* gp = &gv.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gg = fmaf(2.f * l2, wp[c], gp[c]);
+            mp[c] = fmaf(b1, mp[c], (1.f - b1) * gg);
+            vp[c] = fmaf(b2, vp[c], (1.f - b2) * gg * gg);
+            wp[c] -= alpha * mp[c] / (sqrtf(vp[c]) + eps);
+        }
+        reinterpret_cast<float4*>(w)[i] = wv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+            const float gg = fmaf(2.f * l2, w[i], g[i]);
+            m[i] = fmaf(b1, m[i], (1.f - b1) * gg);
+            v[i] = fmaf(b2, v[i], (1.f - b2) * gg * gg);
+            w[i] -= alpha * m[i] / (sqrtf(v[i]) + eps);
+            if (zero_grad) g[i] = 0.f;
+        }
     }
 }
 
@@ -288,7 +328,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     float* bufA = static_cast<float*>(a->workspace);
     float* bufB = bufA + (size_t)a->batch * w;
     const int B = (int)a->batch;
-    const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)64);
+    const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
     const int L = a->n_layers;
     // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit
     const int NL = a->units[L - 1];
@@ -342,4 +382,16 @@ extern "C" int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n,
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, g, n, alpha, beta1, beta2,
                        eps, l2, (int)zero_grad);
     return dctr_launch_status("dctr_adam_step");
+}
+
+extern "C" int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
+                               float eps, int32_t zero_grad, void* stream) {
+    DCTR_REQUIRE(n_segs >= 0 && n_segs <= 65535 && max_n >= 0, DCTR_E_DIM, "adam_multi: bad n_segs / max_n");
+    if (n_segs == 0 || max_n == 0) return DCTR_OK;
+    DCTR_REQUIRE(segs != nullptr, DCTR_E_NULL, "adam_multi: null segment array");
+    int64_t bx = dctr_ceil_div(max_n / 4 + 1, (int64_t)(256 * 4));      // four float4 per thread in the largest segment
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, segs, alpha,
+                       beta1, beta2, eps, (int)zero_grad);
+    return dctr_launch_status("dctr_adam_multi");
 }

@@ -508,3 +508,20 @@ def adam_step(w, m, v, g, alpha, beta1=0.9, beta2=0.999, eps=1e-7, l2=0.0, zero_
     _dev_check(w, m, v, g)
     _C.check(_C.lib().dctr_adam_step(_ptr(w), _ptr(m), _ptr(v), _ptr(g), w.numel(), float(alpha), float(beta1), float(beta2),
                                      float(eps), float(l2), int(bool(zero_grad)), _C.stream_ptr()), "dctr_adam_step")
+
+
+def make_adam_segments(params, device):
+    """DEVICE array of dctr_adam_seg_t from [(w, m, v, g, l2), ...]; returns (tensor, n_segs, max_n)."""
+    arr = (_C.AdamSeg * max(1, len(params)))()
+    mx = 0
+    for i, (w, m, v, g, l2) in enumerate(params):
+        arr[i].w, arr[i].m, arr[i].v, arr[i].g = w.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr()
+        arr[i].n, arr[i].l2 = w.numel(), float(l2)
+        mx = max(mx, w.numel())
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(params), mx
+
+
+def adam_multi(segs, n_segs, max_n, alpha, beta1=0.9, beta2=0.999, eps=1e-7, zero_grad=True):
+    """dctr_adam_step for every parameter in one launch (segments from make_adam_segments)."""
+    _C.check(_C.lib().dctr_adam_multi(_ptr(segs), int(n_segs), int(max_n), float(alpha), float(beta1), float(beta2),
+                                      float(eps), int(bool(zero_grad)), _C.stream_ptr()), "dctr_adam_multi")

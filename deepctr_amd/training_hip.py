@@ -80,6 +80,8 @@ class HipTrainer(object):
         self.p_head = param(model.dense.w("kernel"))
         self.p_gbias = param(model.prediction.w("global_bias")) if model.prediction.use_bias else None
         self._buf = {}
+        self.segs, self.n_segs, self.max_n = ops.make_adam_segments([(p.w, p.m, p.v, p.g, p.l2) for p in self.params],
+                                                                    model.device)
 
     def _buffers(self, B):
         b = self._buf.get(B)
@@ -133,6 +135,5 @@ class HipTrainer(object):
         # Adam
         self.t += 1
         alpha = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        for p in self.params:
-            ops.adam_step(p.w, p.m, p.v, p.g, alpha, self.b1, self.b2, self.eps, p.l2)
+        ops.adam_multi(self.segs, self.n_segs, self.max_n, alpha, self.b1, self.b2, self.eps)     # one launch, all parameters
         return buf["loss"] / B

@@ -385,6 +385,20 @@ int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
 int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n, float alpha, float beta1, float beta2, float eps,
                    float l2, int32_t zero_grad, void* stream);
 
+/* the same for every parameter of a model in ONE launch: a DEVICE array of segments (16-B aligned buffers);
+ * max_n = the largest segment's n (sizes the grid). */
+typedef struct {
+    float* w;
+    float* m;
+    float* v;
+    float* g;
+    int64_t n;
+    float l2;
+    int32_t pad_;
+} dctr_adam_seg_t;
+int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
+                    float eps, int32_t zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

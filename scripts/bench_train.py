@@ -1,0 +1,52 @@
+"""Training-step throughput of DeepFM at BASELINE configs[1] (C2) on the HIP step:
+forward (gather + DNN, activations saved) + loss gradient + DNN backward + embedding/FM/linear backward + Adam over every
+parameter (non-lazy: all 26 tables move every step, as tf.keras' Adam does).  Prints one line per batch size."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepctr_amd.feature_column import DenseFeat, SparseFeat  # noqa: E402
+from deepctr_amd.models import DeepFM  # noqa: E402
+from deepctr_amd.training_hip import HipTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batches", default="4096,16384")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(0)
+    cols = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
+    model = DeepFM(cols, cols, device=dev)
+    tr = HipTrainer(model)
+    n_param = sum(p.w.numel() for p in tr.params)
+    for B in [int(b) for b in args.batches.split(",")]:
+        ring = 8
+        n = ring * B
+        feed = {"C%d" % i: rng.randint(0, 100000, n).astype(np.int32) for i in range(1, 27)}
+        feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(1, 14)})
+        y = torch.from_numpy((rng.rand(n) > 0.5).astype(np.float32)).to(dev)
+        staged = model.stage(feed)
+        for i in range(4):
+            tr.step(staged, (i % ring) * B, (i % ring) * B + B, y[(i % ring) * B:(i % ring) * B + B])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            lo = (i % ring) * B
+            loss = tr.step(staged, lo, lo + B, y[lo:lo + B])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        model._check_status()
+        # Adam traffic: w, m, v, g read + w, m, v, g written per parameter element
+        print("C2 DeepFM train step  B=%-6d %8.1f us/step  %8.2f M samples/s   (%.1f M parameters: Adam moves %.2f GB/step = %.0f us at 8 TB/s; loss %.4f)"
+              % (B, dt * 1e6, B / dt / 1e6, n_param / 1e6, n_param * 32 / 1e9, n_param * 32 / 8e12 * 1e6, float(loss)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -169,3 +169,26 @@ def test_deepfm_fit_runs_on_the_hip_step_and_learns(device):
     model3.compile("adam", "binary_crossentropy")
     h3 = model3.fit(feed, y, batch_size=256, epochs=10, verbose=0, validation_split=0.25, shuffle=False)
     assert abs(h2.history["loss"][-1] - h3.history["loss"][-1]) < 0.02, (h2.history["loss"], h3.history["loss"])
+
+
+def test_adam_multi_matches_adam_step(device):
+    """One launch over a list of parameters (odd sizes, different l2) == dctr_adam_step per parameter, bit for bit."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(8)
+    sizes = [5, 1600000, 64, 100003, 1]
+    a, b = [], []
+    for n in sizes:
+        w = dev(rng.standard_normal(n).astype(np.float32), device)
+        m = dev(rng.standard_normal(n).astype(np.float32) * 0.01, device)
+        v = dev((rng.rand(n) * 0.01).astype(np.float32), device)
+        g = dev(rng.standard_normal(n).astype(np.float32) * 0.1, device)
+        l2 = 0.0 if n % 2 else 1e-3
+        a.append((w, m, v, g, l2))
+        b.append((w.clone(), m.clone(), v.clone(), g.clone(), l2))
+    for (w, m, v, g, l2) in a:
+        ops.adam_step(w, m, v, g, 1.3e-3, 0.9, 0.999, 1e-7, l2)
+    segs, ns, mx = ops.make_adam_segments(b, device)
+    ops.adam_multi(segs, ns, mx, 1.3e-3, 0.9, 0.999, 1e-7)
+    for pa, pb in zip(a, b):
+        for x, y in zip(pa[:4], pb[:4]):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
