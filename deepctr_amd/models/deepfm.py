@@ -14,8 +14,10 @@ from ._common import FeatureModel
 
 class _DeepFM(FeatureModel):
     def __init__(self, linear_feature_columns, dnn_feature_columns, fm_group, dnn_hidden_units, seed, dnn_dropout,
-                 dnn_activation, dnn_use_bn, task, device):
-        super(_DeepFM, self).__init__("DeepFM", list(linear_feature_columns) + list(dnn_feature_columns), device, task)
+                 dnn_activation, dnn_use_bn, task, device, name="DeepFM", input_columns=None):
+        # WDL (no FM group) and FNN (no FM group, no linear part) are the same graph minus terms: models/wdl.py, fnn.py
+        super(_DeepFM, self).__init__(name, list(linear_feature_columns) + list(dnn_feature_columns)
+                                      if input_columns is None else list(input_columns), device, task)
         with name_scope():
             self.build_linear(linear_feature_columns, seed)
             self.build_embeddings(dnn_feature_columns, seed)

@@ -440,15 +440,36 @@ def gen_criteo_sample():
     _save("criteo_tokens", tokens=np.array([t.encode() for t in toks], dtype="S16"), hash_nb1000=h)
 
 
+def gen_siblings():
+    """sibling models that run on the same kernels (deepctr/models/wdl.py:19-57, fnn.py:18-51)."""
+    rng = np.random.RandomState(15)
+    B = 16
+    spec = mixed_spec(4, False)
+    feed = _feed_for(spec, B, rng)
+    _run_model("model_wdl", "deepctr.models.wdl", "WDL", spec, spec, feed, {"dnn_hidden_units": [16, 8]})
+    _run_model("model_wdl_wide_subset", "deepctr.models.wdl", "WDL", spec[1:6], spec, feed,
+               {"dnn_hidden_units": [8], "dnn_activation": "tanh"})
+    spec_h = mixed_spec(4, True)
+    feed_h = _feed_for(spec_h, B, rng)
+    _run_model("model_fnn", "deepctr.models.fnn", "FNN", spec_h, spec_h, feed_h, {"dnn_hidden_units": [16, 8]})
+    fixed = [d for d in mixed_spec(8, False) if d["type"] != "varlen"]
+    feed_f = _feed_for(fixed, B, rng)
+    _run_model("model_wdl_fixed", "deepctr.models.wdl", "WDL", fixed, fixed, feed_f, {"dnn_hidden_units": [32, 8]})
+    _run_model("model_fnn_fixed", "deepctr.models.fnn", "FNN", fixed, fixed, feed_f, {"dnn_hidden_units": [32, 8]})
+
+
 def main():
     S.install(REF)
     S.WEIGHT_HOOK = weight_hook
+    if len(sys.argv) > 1 and sys.argv[1] == "siblings":      # add-on fixtures only (the others stay byte-identical)
+        return gen_siblings()
     gen_hash()
     gen_interaction()
     gen_sequence()
     gen_core()
     gen_models()
     gen_criteo_sample()
+    gen_siblings()
 
 
 if __name__ == "__main__":

@@ -176,6 +176,25 @@ def deepfm(linear_cols, dnn_cols, weights, feed, fm_group=("default_group",), dn
     return R.prediction_layer(final, weights["prediction_layer/global_bias"].astype(dt), task)
 
 
+def wdl(linear_cols, dnn_cols, weights, feed, dnn_activation="relu", task="binary", dtype=np.float32, **_):
+    """deepctr/models/wdl.py:39-57: linear logit + DNN logit."""
+    dt = np.dtype(dtype).type
+    lin = linear_logit(linear_cols, feed, weights, dt)
+    groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
+    dnn_in = _combined_dnn_input([e for g in groups.values() for e in g], dense)
+    dnn_logit = _dnn("dnn", dnn_in, weights, dt, dnn_activation) @ weights["dense/kernel"].astype(dt)
+    return R.prediction_layer(_add(dnn_logit, lin), weights["prediction_layer/global_bias"].astype(dt), task)
+
+
+def fnn(linear_cols, dnn_cols, weights, feed, dnn_activation="relu", task="binary", dtype=np.float32, **_):
+    """deepctr/models/fnn.py:37-51: DNN logit only (linear_feature_columns only declare inputs)."""
+    dt = np.dtype(dtype).type
+    groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
+    dnn_in = _combined_dnn_input([e for g in groups.values() for e in g], dense)
+    dnn_logit = _dnn("dnn", dnn_in, weights, dt, dnn_activation) @ weights["dense/kernel"].astype(dt)
+    return R.prediction_layer(dnn_logit, weights["prediction_layer/global_bias"].astype(dt), task)
+
+
 def dcn(linear_cols, dnn_cols, weights, feed, cross_num=2, cross_parameterization="vector",
         dnn_hidden_units=(256, 128, 64), dnn_activation="relu", task="binary", dtype=np.float32, **_):
     dt = np.dtype(dtype).type

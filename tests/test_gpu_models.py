@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 def build_model(meta, device):
-    from deepctr_amd.models import DCN, DIN, DeepFM, xDeepFM
+    from deepctr_amd.models import DCN, DIN, FNN, WDL, DeepFM, xDeepFM
     dnn_cols = columns_from_spec(meta["dnn"])
     lin_cols = columns_from_spec(meta["linear"])
     kw = dict(meta["kwargs"])
     name = meta["model"]
     if name == "DIN":
         return DIN(dnn_cols, meta["extra_args"][0], device=device, **kw)
-    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM}[name]
+    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN}[name]
     return ctor(lin_cols, dnn_cols, device=device, **kw)
 
 

@@ -92,12 +92,12 @@ def test_mlp_bwd_matches_autograd(device, act):
         assert float((dx[:, dims[0]:] - 7.0).abs().max()) == 0.0            # columns past in_dim untouched
 
 
-def _deepfm(device, E=16, hidden=(32, 16), hashed=False, n_sparse=6):
+def _deepfm(device, E=16, hidden=(32, 16), hashed=False, n_sparse=6, kind="DeepFM"):
+    from deepctr_amd import models
     from deepctr_amd.feature_column import DenseFeat, SparseFeat
-    from deepctr_amd.models import DeepFM
     cols = [SparseFeat("C%d" % i, 50 + 7 * i, E, use_hash=(hashed and i % 2 == 0)) for i in range(n_sparse)] + \
            [DenseFeat("I%d" % i, 1) for i in range(3)]
-    return DeepFM(cols, cols, dnn_hidden_units=hidden, l2_reg_linear=0, l2_reg_embedding=0, device=device), cols
+    return getattr(models, kind)(cols, cols, dnn_hidden_units=hidden, l2_reg_linear=0, l2_reg_embedding=0, device=device), cols
 
 
 def _feed(rng, cols, n, hashed=False):
@@ -110,15 +110,16 @@ def _feed(rng, cols, n, hashed=False):
     return feed
 
 
-@pytest.mark.parametrize("E,hashed", [(16, False), (8, True), (32, False)])
-def test_hip_training_gradients_match_torch_autograd(device, E, hashed):
+@pytest.mark.parametrize("E,hashed,kind", [(16, False, "DeepFM"), (8, True, "DeepFM"), (32, False, "DeepFM"),
+                                           (16, True, "WDL"), (16, False, "FNN")])
+def test_hip_training_gradients_match_torch_autograd(device, E, hashed, kind):
     """Every gradient the HIP step produces (tables incl. duplicate ids, linear tables, Linear kernel, DNN, head, global
     bias) against torch autograd over training.model_logits on the same device and weights."""
     from deepctr_amd import training
     from deepctr_amd.training_hip import HipTrainer
     from tests.test_gpu_models import _randomise
     rng = np.random.RandomState(5)
-    model, cols = _deepfm(device, E=E, hashed=hashed)
+    model, cols = _deepfm(device, E=E, hashed=hashed, kind=kind)
     _randomise(model, rng)
     n = 333
     feed = _feed(rng, cols, n, hashed)

@@ -205,7 +205,8 @@ def test_core_layers():
 MODEL_FIXTURES = ["model_deepfm_mixed", "model_deepfm_hash", "model_dcn_vector", "model_dcn_matrix", "model_dcn_crossonly",
                   "model_xdeepfm", "model_xdeepfm_nosplit", "model_din_ref_dice_hash0", "model_din_ref_sigmoid_hash0",
                   "model_din_ref_dice_hash1", "model_din_ref_sigmoid_hash1", "model_din_big_wn0", "model_din_big_wn1",
-                  "model_deepfm_criteo_sample"]
+                  "model_deepfm_criteo_sample", "model_wdl", "model_wdl_wide_subset", "model_fnn", "model_wdl_fixed",
+                  "model_fnn_fixed"]
 
 
 def run_oracle_model(g, dtype=np.float32):
@@ -225,6 +226,10 @@ def run_oracle_model(g, dtype=np.float32):
         return RM.xdeepfm(lin_cols, dnn_cols, weights, feed, **kw)
     if name == "DIN":
         return RM.din(dnn_cols, meta["extra_args"][0], weights, feed, **kw)
+    if name == "WDL":
+        return RM.wdl(lin_cols, dnn_cols, weights, feed, **kw)
+    if name == "FNN":
+        return RM.fnn(lin_cols, dnn_cols, weights, feed, **kw)
     raise KeyError(name)
 
 
