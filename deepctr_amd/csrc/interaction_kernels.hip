@@ -227,7 +227,7 @@ __device__ __forceinline__ void pair_ij(int p, int F, int& i, int& j) {
     j = ii + 1 + rem;
 }
 
-__global__ __launch_bounds__(256) void afm_kernel(const float* __restrict__ x, int64_t batch, int F, int E,
+__global__ __launch_bounds__(256) void afm_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F, int E,
                                                   const float* __restrict__ att_w, const float* __restrict__ att_b,
                                                   const float* __restrict__ proj_h, const float* __restrict__ proj_p,
                                                   int A, float* __restrict__ y) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void afm_kernel(const float* __restrict__ x, i
     const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     const bool valid = b < batch;
     if (valid)
-        for (int i = lane; i < F * E; i += 64) xs[i] = x[b * (int64_t)F * E + i];
+        for (int i = lane; i < F * E; i += 64) xs[i] = x[b * x_stride + i];
     __syncthreads();
     if (!valid) return;
 
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void afm_kernel(const float* __restrict__ x, i
 // ---------------------------------------------------------------------------------------------------
 // InnerProduct: one wave per sample.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void inner_product_kernel(const float* __restrict__ x, int64_t batch, int F, int E,
-                                                            int reduce_sum, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void inner_product_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
+                                                            int E, int reduce_sum, float* __restrict__ y, int64_t y_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = F * (F - 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* __restr
     const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     const bool valid = b < batch;
     if (valid)
-        for (int i = lane; i < F * E; i += 64) xs[i] = x[b * (int64_t)F * E + i];
+        for (int i = lane; i < F * E; i += 64) xs[i] = x[b * x_stride + i];
     __syncthreads();
     if (!valid) return;
     if (reduce_sum) {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* __restr
             pair_ij(p, F, i, j);
             float t = 0.f;
             for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e], xs[j * E + e], t);
-            y[b * (int64_t)P + p] = t;
+            y[b * y_stride + p] = t;
         }
     } else {
         const int64_t total = (int64_t)P * E;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* __restr
             const int p = (int)(o / E), e = (int)(o % E);
             int i, j;
             pair_ij(p, F, i, j);
-            y[b * total + o] = xs[i * E + e] * xs[j * E + e];
+            y[b * y_stride + o] = xs[i * E + e] * xs[j * E + e];
         }
     }
 }
@@ -424,10 +424,11 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
     return dctr_launch_status("dctr_crossnet_fwd");
 }
 
-extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, const float* att_w,
-                            const float* att_b, const float* proj_h, const float* proj_p, int32_t att_factor, float* y,
-                            void* stream) {
+extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim,
+                            const float* att_w, const float* att_b, const float* proj_h, const float* proj_p,
+                            int32_t att_factor, float* y, void* stream) {
     DCTR_REQUIRE(batch >= 0 && fields >= 2 && dim >= 1 && att_factor >= 1, DCTR_E_DIM, "afm_fwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim, DCTR_E_DIM, "afm_fwd: x_stride < fields*dim");
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && att_w && att_b && proj_h && proj_p && y, DCTR_E_NULL, "afm_fwd: null pointer");
     const int P = fields * (fields - 1) / 2;
@@ -439,14 +440,17 @@ extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int32_t fields, int32
     }
     const int64_t blocks = dctr_ceil_div(batch, 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "afm_fwd: batch too large");
-    DCTR_LAUNCH(afm_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, batch, fields, dim,
+    DCTR_LAUNCH(afm_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, x_stride, batch, fields, dim,
                        att_w, att_b, proj_h, proj_p, att_factor, y);
     return dctr_launch_status("dctr_afm_fwd");
 }
 
-extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, int32_t reduce_sum,
-                                      float* y, void* stream) {
+extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim,
+                                      int32_t reduce_sum, float* y, int64_t y_stride, void* stream) {
     DCTR_REQUIRE(batch >= 0 && fields >= 2 && dim >= 1, DCTR_E_DIM, "inner_product_fwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim &&
+                     y_stride >= (int64_t)(fields * (fields - 1) / 2) * (reduce_sum ? 1 : dim),
+                 DCTR_E_DIM, "inner_product_fwd: stride smaller than a row");
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && y, DCTR_E_NULL, "inner_product_fwd: null pointer");
     const size_t lds = (size_t)4 * fields * dim * sizeof(float);
@@ -458,7 +462,7 @@ extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int32_t fie
     }
     const int64_t blocks = dctr_ceil_div(batch, 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "inner_product_fwd: batch too large");
-    DCTR_LAUNCH(inner_product_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, batch, fields,
-                       dim, reduce_sum, y);
+    DCTR_LAUNCH(inner_product_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, x_stride, batch,
+                fields, dim, reduce_sum, y, y_stride);
     return dctr_launch_status("dctr_inner_product_fwd");
 }

@@ -191,6 +191,36 @@ class FM(Layer):
         return (None, 1)
 
 
+class OutterProductLayer(Layer):
+    """Weight holder only: PNN (reference models/pnn.py:49) instantiates this layer, and thereby its kernel, even with
+    use_outter=False, so Keras weight lists of a reference PNN contain it.  The outer-product arithmetic
+    (interaction.py:866-924) is outside SURVEY §8 and calling the layer raises."""
+
+    def __init__(self, kernel_type='mat', seed=1024, **kwargs):
+        if kernel_type not in ['mat', 'vec', 'num']:
+            raise ValueError("kernel_type must be mat,vec or num")
+        self.kernel_type = kernel_type
+        self.seed = seed
+        super(OutterProductLayer, self).__init__(**kwargs)
+
+    def build_for(self, num_inputs, embed_size):
+        if self.built:
+            return self
+        num_pairs = int(num_inputs * (num_inputs - 1) / 2)
+        shape = {'mat': (embed_size, num_pairs, embed_size), 'vec': (num_pairs, embed_size), 'num': (num_pairs, 1)}[self.kernel_type]
+        self.add_weight('kernel', shape, GlorotUniform(seed=self.seed))
+        self.built = True
+        return self
+
+    def call(self, inputs, **kwargs):
+        raise NotImplementedError("OutterProductLayer arithmetic is outside the MI355X hot-path scope (SURVEY.md §8)")
+
+    def get_config(self):
+        base = super(OutterProductLayer, self).get_config()
+        base.update({'kernel_type': self.kernel_type, 'seed': self.seed})
+        return base
+
+
 class InnerProductLayer(Layer):
     def __init__(self, reduce_sum=True, **kwargs):
         self.reduce_sum = reduce_sum

@@ -311,27 +311,41 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
     return out
 
 
-def afm(x, attention_W, attention_b, projection_h, projection_p):
-    """AFMLayer.call (reference interaction.py:116-146), inference: x [B,F,E] -> [B,1]."""
+def afm(x, attention_W, attention_b, projection_h, projection_p, fields=None, dim=None, out=None):
+    """AFMLayer.call (reference interaction.py:116-146), inference: x [B,F,E] -> [B,1].
+    With ``fields``/``dim`` x is a 2-D buffer [B, stride >= fields*dim] read in place (a slice of dnn_in)."""
     _dev_check(x, attention_W, attention_b, projection_h, projection_p)
-    x = _f32c(x, "x")
-    B, F, E = x.shape
+    if fields is None:
+        x = _f32c(x, "x")
+        B, F, E = x.shape
+        stride = F * E
+    else:
+        B, F, E, stride = x.shape[0], int(fields), int(dim), x.stride(0)
     A = attention_W.shape[1]
-    y = torch.empty(B, 1, dtype=torch.float32, device=x.device)
-    _C.check(_C.lib().dctr_afm_fwd(_ptr(x), B, F, E, _ptr(_f32c(attention_W, "W")), _ptr(_f32c(attention_b, "b")),
+    y = torch.empty(B, 1, dtype=torch.float32, device=x.device) if out is None else out
+    _C.check(_C.lib().dctr_afm_fwd(_ptr(x), B, stride, F, E, _ptr(_f32c(attention_W, "W")), _ptr(_f32c(attention_b, "b")),
                                    _ptr(_f32c(projection_h, "h").reshape(-1)), _ptr(_f32c(projection_p, "p").reshape(-1)),
                                    A, _ptr(y), _C.stream_ptr()), "dctr_afm_fwd")
     return y
 
 
-def inner_product(x, reduce_sum=True):
-    """InnerProductLayer.call (reference interaction.py:655-678): x [B,F,E] -> [B,P,1] or [B,P,E]."""
+def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
+    """InnerProductLayer.call (reference interaction.py:655-678): x [B,F,E] -> [B,P,1] or [B,P,E].
+    With ``fields``/``dim`` x is a 2-D buffer read in place; ``out`` may be a 2-D (strided) view to write into."""
     _dev_check(x)
-    x = _f32c(x, "x")
-    B, F, E = x.shape
+    if fields is None:
+        x = _f32c(x, "x")
+        B, F, E = x.shape
+        xs = F * E
+    else:
+        B, F, E, xs = x.shape[0], int(fields), int(dim), x.stride(0)
     P = F * (F - 1) // 2
-    y = torch.empty(B, P, 1 if reduce_sum else E, dtype=torch.float32, device=x.device)
-    _C.check(_C.lib().dctr_inner_product_fwd(_ptr(x), B, F, E, int(bool(reduce_sum)), _ptr(y), _C.stream_ptr()),
+    if out is None:
+        y = torch.empty(B, P, 1 if reduce_sum else E, dtype=torch.float32, device=x.device)
+        ys = P * (1 if reduce_sum else E)
+    else:
+        y, ys = out, out.stride(0)
+    _C.check(_C.lib().dctr_inner_product_fwd(_ptr(x), B, xs, F, E, int(bool(reduce_sum)), _ptr(y), ys, _C.stream_ptr()),
              "dctr_inner_product_fwd")
     return y
 

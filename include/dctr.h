@@ -219,18 +219,19 @@ int dctr_cin_fwd(const dctr_cin_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a11 AFMLayer.call — deepctr/layers/interaction.py:116-146 (inference: dropout inactive)
- *     x [B,F,E]; W [E,A]; b [A]; h [A]; p [E]  ->  y [B]
+ *     x [B,F,E] (sample stride x_stride); W [E,A]; b [A]; h [A]; p [E]  ->  y [B]
  * ------------------------------------------------------------------------------------------------ */
-int dctr_afm_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, const float* att_w,
+int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* att_w,
                  const float* att_b, const float* proj_h, const float* proj_p, int32_t att_factor, float* y,
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a12 InnerProductLayer.call — deepctr/layers/interaction.py:655-678
- *     x [B,F,E] -> y [B, F(F-1)/2] (reduce_sum) or [B, F(F-1)/2, E]; pair order (i<j) row-major.
+ *     x [B,F,E] (sample stride x_stride) -> y [B, F(F-1)/2] (reduce_sum) or [B, F(F-1)/2, E], sample stride y_stride;
+ *     pair order (i<j) row-major.
  * ------------------------------------------------------------------------------------------------ */
-int dctr_inner_product_fwd(const float* x, int64_t batch, int32_t fields, int32_t dim, int32_t reduce_sum,
-                           float* y, void* stream);
+int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim,
+                           int32_t reduce_sum, float* y, int64_t y_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * adjacent  DNN.call (+ Dense(1, use_bias=False) head, add_func, PredictionLayer.call)

@@ -440,6 +440,22 @@ def gen_criteo_sample():
     _save("criteo_tokens", tokens=np.array([t.encode() for t in toks], dtype="S16"), hash_nb1000=h)
 
 
+def _run_pnn(name, spec_dnn, feed, kwargs):
+    S.reset()
+    S.set_feed(feed)
+    from deepctr.models.pnn import PNN
+    model = PNN(build_ref_columns(spec_dnn), **kwargs)
+    y = model.predict()
+    arrays = {"y": y.astype(np.float32)}
+    for k, v in feed.items():
+        arrays["feed/" + k] = v
+    for k, v in _weights_dict().items():
+        arrays["w/" + k] = v
+    meta = {"model": "PNN", "linear": [], "dnn": spec_dnn, "kwargs": kwargs, "extra_args": []}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    _save(name, **arrays)
+
+
 def gen_siblings():
     """sibling models that run on the same kernels (deepctr/models/wdl.py:19-57, fnn.py:18-51)."""
     rng = np.random.RandomState(15)
@@ -456,6 +472,19 @@ def gen_siblings():
     feed_f = _feed_for(fixed, B, rng)
     _run_model("model_wdl_fixed", "deepctr.models.wdl", "WDL", fixed, fixed, feed_f, {"dnn_hidden_units": [32, 8]})
     _run_model("model_fnn_fixed", "deepctr.models.fnn", "FNN", fixed, fixed, feed_f, {"dnn_hidden_units": [32, 8]})
+    # AFM (models/afm.py:19-61): no DenseFeat in dnn_feature_columns (support_dense=False)
+    nodense = [d for d in spec if d["type"] != "dense"]
+    _run_model("model_afm", "deepctr.models.afm", "AFM", spec, nodense, feed, {"attention_factor": 4})
+    two = json.loads(json.dumps(nodense))
+    for d in two:
+        if d.get("name") == "sparse_feature_2":
+            d["group_name"] = "g1"                      # an AFMLayer needs >= 2 embeddings per group
+    _run_model("model_afm_two_groups", "deepctr.models.afm", "AFM", spec, two, feed,
+               {"attention_factor": 3, "fm_group": ["default_group", "g1"]})
+    _run_model("model_afm_noatt", "deepctr.models.afm", "AFM", spec, nodense, feed, {"use_attention": False})
+    # PNN (models/pnn.py:19-72), inner product only
+    _run_pnn("model_pnn_inner", spec, feed, {"dnn_hidden_units": [16, 8], "use_inner": True, "use_outter": False})
+    _run_pnn("model_pnn_plain", fixed, feed_f, {"dnn_hidden_units": [8], "use_inner": False, "use_outter": False})
 
 
 def main():

@@ -195,6 +195,46 @@ def fnn(linear_cols, dnn_cols, weights, feed, dnn_activation="relu", task="binar
     return R.prediction_layer(dnn_logit, weights["prediction_layer/global_bias"].astype(dt), task)
 
 
+def afm(linear_cols, dnn_cols, weights, feed, fm_group="default_group", use_attention=True, task="binary",
+        dtype=np.float32, **_):
+    """deepctr/models/afm.py:42-61: linear logit + one AFMLayer (or FM) per embedding group in fm_group.
+    `k in fm_group` is evaluated exactly as the reference does (a substring test when fm_group is the default str)."""
+    dt = np.dtype(dtype).type
+    lin = linear_logit(linear_cols, feed, weights, dt)
+    groups, _dense = _embed_groups(dnn_cols, feed, weights, "", dt)
+    logits = []
+    i = 0
+    for k, v in groups.items():
+        if k not in fm_group:
+            continue
+        if use_attention:
+            pre = "afm_layer" if i == 0 else "afm_layer_%d" % i
+            logits.append(R.afm(list(v), weights[pre + "/attention_W"].astype(dt), weights[pre + "/attention_b"].astype(dt),
+                                weights[pre + "/projection_h"].astype(dt), weights[pre + "/projection_p"].astype(dt)))
+            i += 1
+        else:
+            logits.append(R.fm(np.concatenate(v, axis=1)))
+    return R.prediction_layer(_add(lin, *logits), weights["prediction_layer/global_bias"].astype(dt), task)
+
+
+def pnn(linear_cols, dnn_cols, weights, feed, use_inner=True, use_outter=False, dnn_activation="relu", task="binary",
+        dtype=np.float32, **_):
+    """deepctr/models/pnn.py:43-72, inner-product form: DNN input = [embeddings, flatten(inner products), dense]."""
+    if use_outter:
+        raise NotImplementedError("OutterProductLayer is outside SURVEY §8")
+    dt = np.dtype(dtype).type
+    groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
+    embeds = [e for g in groups.values() for e in g]
+    parts = [np.concatenate(embeds, axis=1).reshape(embeds[0].shape[0], -1)]              # linear_signal, :52-53
+    if use_inner:
+        ip = R.inner_product(embeds, True)                                                # [B,P,1]
+        parts.append(ip.reshape(ip.shape[0], -1))                                         # Flatten, :47-48
+    deep_input = np.concatenate(parts, axis=-1)
+    dnn_in = np.concatenate([deep_input] + [d.reshape(d.shape[0], -1) for d in dense], axis=-1) if dense else deep_input
+    dnn_logit = _dnn("dnn", dnn_in, weights, dt, dnn_activation) @ weights["dense/kernel"].astype(dt)
+    return R.prediction_layer(dnn_logit, weights["prediction_layer/global_bias"].astype(dt), task)
+
+
 def dcn(linear_cols, dnn_cols, weights, feed, cross_num=2, cross_parameterization="vector",
         dnn_hidden_units=(256, 128, 64), dnn_activation="relu", task="binary", dtype=np.float32, **_):
     dt = np.dtype(dtype).type

@@ -643,6 +643,18 @@ class Flatten(Layer):
         return Tensor(a.reshape(a.shape[0], -1))
 
 
+class Reshape(Layer):
+    """tf.keras.layers.Reshape(target_shape): batch dimension kept (used by models/pnn.py:52-53)."""
+
+    def __init__(self, target_shape, **kw):
+        Layer.__init__(self, **kw)
+        self.target_shape = tuple(int(d) for d in target_shape)
+
+    def call(self, inputs):
+        a = np.asarray(_arr(inputs))
+        return Tensor(a.reshape((a.shape[0],) + self.target_shape))
+
+
 class Concatenate(Layer):
     def __init__(self, axis=-1, **kw):
         Layer.__init__(self, **kw)
@@ -859,7 +871,7 @@ def install(reference_root="/root/reference"):
     K = _mod("tensorflow.keras.backend")
     K.ndim, K.repeat_elements, K.concatenate, K.all = _k_ndim, _k_repeat_elements, concat, _k_all
     layers = _mod("tensorflow.keras.layers")
-    for cls in (Layer, Lambda, Embedding, Dense, Flatten, Concatenate, Add, Dropout, Activation, BatchNormalization):
+    for cls in (Layer, Lambda, Embedding, Dense, Flatten, Reshape, Concatenate, Add, Dropout, Activation, BatchNormalization):
         setattr(layers, cls.__name__, cls)
     layers.Input = Input
     keras.layers = layers

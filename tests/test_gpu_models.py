@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 
 
 def build_model(meta, device):
-    from deepctr_amd.models import DCN, DIN, FNN, WDL, DeepFM, xDeepFM
+    from deepctr_amd.models import AFM, DCN, DIN, FNN, PNN, WDL, DeepFM, xDeepFM
     dnn_cols = columns_from_spec(meta["dnn"])
     lin_cols = columns_from_spec(meta["linear"])
     kw = dict(meta["kwargs"])
     name = meta["model"]
     if name == "DIN":
         return DIN(dnn_cols, meta["extra_args"][0], device=device, **kw)
-    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN}[name]
+    if name == "PNN":
+        return PNN(dnn_cols, device=device, **kw)
+    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN, "AFM": AFM}[name]
     return ctor(lin_cols, dnn_cols, device=device, **kw)
 
 
@@ -29,7 +31,7 @@ def well_conditioned_rows(meta, feed, n):
     and tested at op level).  Fed to FM, (sum e)^2 - sum e^2 then cancels at the 1e18 scale and the logit is rounding
     noise of either sign in ANY fp32 implementation, so those rows are excluded from FM-model comparisons."""
     ok = np.ones(n, dtype=bool)
-    if meta["model"] != "DeepFM":
+    if meta["model"] not in ("DeepFM", "AFM", "PNN"):      # the models with second-order terms of the embeddings
         return ok
     for d in meta["dnn"]:
         if d["type"] == "varlen" and d.get("combiner") == "max":
