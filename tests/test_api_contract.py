@@ -143,3 +143,60 @@ def test_weight_roundtrip_by_name_and_list(tmp_path):
     with pytest.raises(ValueError):
         m2.set_weights_by_name({"dense/kernel": np.zeros((3, 3))}, strict=False)
     assert m.count_params() == sum(int(np.prod(v.shape)) for v in new.values())
+
+
+def test_model_constructors_keep_the_reference_signatures():
+    """Every model constructor takes the reference's parameters with the reference's defaults, in the reference's
+    order (read from the committed table below, taken from deepctr/models/*.py), plus a trailing ``device``."""
+    import inspect
+    from deepctr_amd import models
+    ref = {   # name -> [(param, default or inspect._empty), ...]   (deepctr/models/{deepfm,dcn,xdeepfm,wdl,fnn,afm,pnn}.py, sequence/din.py)
+        "DeepFM": ["linear_feature_columns", "dnn_feature_columns", ("fm_group", ("default_group",)),
+                   ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0),
+                   ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"), ("dnn_use_bn", False), ("task", "binary")],
+        "DCN": ["linear_feature_columns", "dnn_feature_columns", ("cross_num", 2), ("cross_parameterization", "vector"),
+                ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_cross", 1e-5),
+                ("l2_reg_dnn", 0), ("seed", 1024), ("dnn_dropout", 0), ("dnn_use_bn", False), ("dnn_activation", "relu"),
+                ("task", "binary")],
+        "WDL": ["linear_feature_columns", "dnn_feature_columns", ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5),
+                ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0), ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"),
+                ("task", "binary")],
+        "FNN": ["linear_feature_columns", "dnn_feature_columns", ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_embedding", 1e-5),
+                ("l2_reg_linear", 1e-5), ("l2_reg_dnn", 0), ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"),
+                ("task", "binary")],
+        "AFM": ["linear_feature_columns", "dnn_feature_columns", ("fm_group", "default_group"), ("use_attention", True),
+                ("attention_factor", 8), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_att", 1e-5),
+                ("afm_dropout", 0), ("seed", 1024), ("task", "binary")],
+        "PNN": ["dnn_feature_columns", ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0),
+                ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"), ("use_inner", True), ("use_outter", False),
+                ("kernel_type", "mat"), ("task", "binary")],
+    }
+    for name, params in ref.items():
+        sig = inspect.signature(getattr(models, name))
+        got = list(sig.parameters.values())
+        assert got[-1].name == "device" and got[-1].default is None, name
+        got = got[:-1]
+        assert len(got) == len(params), (name, [p.name for p in got])
+        for g, want in zip(got, params):
+            wname, wdef = (want, inspect.Parameter.empty) if isinstance(want, str) else want
+            assert g.name == wname, (name, g.name, wname)
+            if wdef is inspect.Parameter.empty:
+                assert g.default is inspect.Parameter.empty, (name, g.name)
+            else:
+                assert g.default == wdef or tuple(g.default) == tuple(wdef), (name, g.name, g.default, wdef)
+
+
+def test_sibling_model_validation_follows_the_reference():
+    import torch
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import AFM, PNN
+    cols = [SparseFeat("a", 10, 4), SparseFeat("b", 10, 4)]
+    cpu = torch.device("cpu")
+    with pytest.raises(ValueError, match="DenseFeat is not supported in dnn_feature_columns"):     # inputs.py:201-202
+        AFM(cols, cols + [DenseFeat("x", 1)], device=cpu)
+    with pytest.raises(ValueError, match="at least 2 inputs"):                                    # interaction.py:75-77
+        AFM(cols, cols[:1], device=cpu)
+    with pytest.raises(ValueError, match="kernel_type must be mat,vec or num"):                    # pnn.py:40-41
+        PNN(cols, kernel_type="x", device=cpu)
+    with pytest.raises(NotImplementedError):
+        PNN(cols, use_outter=True, device=cpu)
