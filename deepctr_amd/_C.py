@@ -17,6 +17,7 @@ ABI_VERSION = 1
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
+OPT_CODES = {"adam": 0, "adagrad": 1, "rmsprop": 2, "sgd": 3}
 ACT_LINEAR, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_DICE = 0, 1, 2, 3, 4
 STATUS_INDEX_OOR = 1
 
@@ -87,6 +88,11 @@ class GatherFmBwdArgs(ctypes.Structure):
                 ("d_fm", c_vp), ("d_lin", c_vp), ("g_dense_lin_w", c_vp), ("dense_lin_rows", c_vp)]
 
 
+class PoolBwdArgs(ctypes.Structure):
+    _fields_ = [("fwd", ctypes.POINTER(PoolArgs)), ("d_out", c_vp), ("d_stride", c_i64), ("d_lin_out", c_vp),
+                ("g_table", c_vp), ("g_lin_table", c_vp)]
+
+
 class MlpBwdArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("in_dim", c_i32), ("n_layers", c_i32),
                 ("units", c_vp), ("kernels", c_vp), ("acts", c_vp), ("activation", c_i32), ("pad_", c_i32),
@@ -132,10 +138,12 @@ SYMBOLS = {
     "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),
     "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
+    "dctr_embed_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolBwdArgs), c_vp]),
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_adam_multi": (ctypes.c_int, [c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "dctr_opt_multi": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_din_attn_workspace_bytes": (c_sz, [ctypes.POINTER(DinAttnArgs)]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
 }

@@ -123,6 +123,99 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward of dctr_embed_pool (inputs.py:120-158, layers/sequence.py:76-106, :155-183): position t of sample b
+// contributed  e_t * wt_t * mk_t  (sum), the same / denom (mean), or was the per-dimension maximum (max); the
+// gradient of the pooled vector is scattered back to the rows with those factors.  Per-position weights are inputs.
+// ---------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const float* __restrict__ d_out, int64_t d_stride,
+                                                       const float* __restrict__ d_lin_out, float* __restrict__ g_table,
+                                                       float* __restrict__ g_lin_table) {
+    constexpr int VEC = 4, SPB = 256 / LPR;
+    const int s = threadIdx.x / LPR, q = threadIdx.x % LPR;
+    const int64_t b = (int64_t)blockIdx.x * SPB + s;
+    if (b >= a.batch) return;
+    const int T = a.maxlen;
+    const bool by_len = a.length != nullptr;
+    const int len = by_len ? a.length[b] : 0;
+    const float PAD = -4294967296.f;
+    const bool has_w = a.weight != nullptr, wnorm = has_w && a.weight_norm;
+    const bool colok = q * VEC < a.dim;
+    auto row_of = [&](int t) { return resolve_row(read_id(a.idx, b * a.idx_stride + t, a.idx_is_i64), a.hash_mode, a.idx_is_i64, a.vocab); };
+    auto mask_of = [&](int t, int64_t r) { return by_len ? (t < len) : (r != 0); };
+    float wmax = -INFINITY, wden = 1.f;
+    if (wnorm) {
+        for (int t = 0; t < T; ++t) wmax = fmaxf(wmax, mask_of(t, row_of(t)) ? a.weight[b * (int64_t)T + t] : PAD);
+        wden = 0.f;
+        for (int t = 0; t < T; ++t) wden += expf((mask_of(t, row_of(t)) ? a.weight[b * (int64_t)T + t] : PAD) - wmax);
+    }
+    auto weight_of = [&](int t, bool m) {
+        if (!has_w) return 1.f;
+        const float w = a.weight[b * (int64_t)T + t];
+        return wnorm ? expf((m ? w : PAD) - wmax) / wden : (m ? w : 0.f);
+    };
+    float dv[VEC] = {0.f, 0.f, 0.f, 0.f};
+    if (colok && d_out != nullptr) load_vec<VEC>(d_out + b * d_stride + q * VEC, dv);
+    const float dl = (d_lin_out != nullptr && q == 0) ? d_lin_out[b] : 0.f;
+    const bool is_max = a.combiner == DCTR_POOL_MAX;
+    float denom = 1.f;
+    if (a.combiner == DCTR_POOL_MEAN) {
+        float cnt = 0.f;
+        if (!by_len)
+            for (int t = 0; t < T; ++t) cnt += mask_of(t, row_of(t)) ? 1.f : 0.f;
+        denom = (by_len ? (float)len : cnt) + 1e-8f;
+    }
+    // max: forward maxima per dimension (and of the 1-wide linear term), then the first position that attains each
+    float mx[VEC] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, lmx = -INFINITY;
+    if (is_max) {
+        for (int t = 0; t < T; ++t) {
+            const int64_t r = row_of(t);
+            const bool ok = (uint64_t)r < (uint64_t)a.vocab, m = mask_of(t, r);
+            const float wt = weight_of(t, m), pen = m ? 0.f : 1e9f;
+            float v[VEC] = {0.f, 0.f, 0.f, 0.f};
+            if (ok && colok) load_vec<VEC>(a.table + r * a.dim + q * VEC, v);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) mx[c] = fmaxf(mx[c], v[c] * wt - pen);
+            if (q == 0 && a.lin_table != nullptr) lmx = fmaxf(lmx, (ok ? a.lin_table[r] : 0.f) * wt - pen);
+        }
+    }
+    bool taken[VEC] = {false, false, false, false};
+    bool ltaken = false;
+    for (int t = 0; t < T; ++t) {
+        const int64_t r = row_of(t);
+        if ((uint64_t)r >= (uint64_t)a.vocab) continue;
+        const bool m = mask_of(t, r);
+        const float wt = weight_of(t, m);
+        if (is_max) {
+            const float pen = m ? 0.f : 1e9f;
+            float v[VEC] = {0.f, 0.f, 0.f, 0.f};
+            if (colok) load_vec<VEC>(a.table + r * a.dim + q * VEC, v);
+            if (colok && g_table != nullptr) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c)
+                    if (!taken[c] && v[c] * wt - pen == mx[c]) {
+                        taken[c] = true;
+                        unsafeAtomicAdd(g_table + r * a.dim + q * VEC + c, dv[c] * wt);
+                    }
+            }
+            if (q == 0 && g_lin_table != nullptr && a.lin_table != nullptr && !ltaken && a.lin_table[r] * wt - pen == lmx) {
+                ltaken = true;
+                unsafeAtomicAdd(g_lin_table + r, dl * wt);
+            }
+        } else {
+            const float f = wt * (m ? 1.f : 0.f) / denom;
+            if (f != 0.f) {
+                if (colok && g_table != nullptr) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) unsafeAtomicAdd(g_table + r * a.dim + q * VEC + c, dv[c] * f);
+                }
+                if (q == 0 && g_lin_table != nullptr && a.lin_table != nullptr) unsafeAtomicAdd(g_lin_table + r, dl * f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // DNN backward helpers
 // ---------------------------------------------------------------------------------------------------
 constexpr int BWD_ROWS = 16;     // batch rows per workgroup of the two helpers below (B = 4096 -> 256 workgroups)
@@ -208,9 +301,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
     }
 }
 
+// one optimizer update of a single element (tf.keras formulas, optimizer_v2/{adam,adagrad,rmsprop,gradient_descent}.py)
+template <int KIND>
+__device__ __forceinline__ void opt_update(float& w, float& m, float& v, float g, float lr, float b1, float b2, float eps) {
+    if constexpr (KIND == DCTR_OPT_ADAM) {            // lr = lr0 * sqrt(1 - b2^t) / (1 - b1^t) from the caller
+        m = fmaf(b1, m, (1.f - b1) * g);
+        v = fmaf(b2, v, (1.f - b2) * g * g);
+        w -= lr * m / (sqrtf(v) + eps);
+    } else if constexpr (KIND == DCTR_OPT_ADAGRAD) {  // v = accumulator (initial_accumulator_value set by the caller)
+        v = fmaf(g, g, v);
+        w -= lr * g / (sqrtf(v) + eps);
+    } else if constexpr (KIND == DCTR_OPT_RMSPROP) {  // b2 = rho; no momentum, not centered
+        v = fmaf(b2, v, (1.f - b2) * g * g);
+        w -= lr * g / (sqrtf(v) + eps);
+    } else {                                          // SGD without momentum
+        w -= lr * g;
+    }
+}
+
 // all parameters of a model in ONE launch: blockIdx.y = segment, blockIdx.x walks the segment (blocks past its end exit)
-__global__ __launch_bounds__(256) void adam_multi_kernel(const dctr_adam_seg_t* __restrict__ segs, float alpha, float b1,
-                                                         float b2, float eps, int zero_grad) {
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* __restrict__ segs, float lr, float b1, float b2,
+                                                        float eps, int zero_grad) {
     const dctr_adam_seg_t sg = segs[blockIdx.y];
     float* __restrict__ w = sg.w;
     float* __restrict__ m = sg.m;
@@ -219,28 +331,26 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const dctr_adam_seg_t* 
     const float l2 = sg.l2;
     const int64_t n = sg.n, n4 = n / 4;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    constexpr bool USE_M = KIND == DCTR_OPT_ADAM, USE_V = KIND != DCTR_OPT_SGD;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 wv = reinterpret_cast<float4*>(w)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float4 wv = reinterpret_cast<float4*>(w)[i];
+        float4 mv = USE_M ? reinterpret_cast<float4*>(m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 vv = USE_V ? reinterpret_cast<float4*>(v)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 gv = reinterpret_cast<float4*>(g)[i];
         float* wp = &wv.x; float* mp = &mv.x; float* vp = &vv.x; const float* gp = &gv.x;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float gg = fmaf(2.f * l2, wp[c], gp[c]);
-            mp[c] = fmaf(b1, mp[c], (1.f - b1) * gg);
-            vp[c] = fmaf(b2, vp[c], (1.f - b2) * gg * gg);
-            wp[c] -= alpha * mp[c] / (sqrtf(vp[c]) + eps);
-        }
+        for (int c = 0; c < 4; ++c) opt_update<KIND>(wp[c], mp[c], vp[c], fmaf(2.f * l2, wp[c], gp[c]), lr, b1, b2, eps);
         reinterpret_cast<float4*>(w)[i] = wv;
-        reinterpret_cast<float4*>(m)[i] = mv;
-        reinterpret_cast<float4*>(v)[i] = vv;
+        if (USE_M) reinterpret_cast<float4*>(m)[i] = mv;
+        if (USE_V) reinterpret_cast<float4*>(v)[i] = vv;
         if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (blockIdx.x == 0) {
         for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
-            const float gg = fmaf(2.f * l2, w[i], g[i]);
-            m[i] = fmaf(b1, m[i], (1.f - b1) * gg);
-            v[i] = fmaf(b2, v[i], (1.f - b2) * gg * gg);
-            w[i] -= alpha * m[i] / (sqrtf(v[i]) + eps);
+            float mm = USE_M ? m[i] : 0.f, vv = USE_V ? v[i] : 0.f;
+            opt_update<KIND>(w[i], mm, vv, fmaf(2.f * l2, w[i], g[i]), lr, b1, b2, eps);
+            if (USE_M) m[i] = mm;
+            if (USE_V) v[i] = vv;
             if (zero_grad) g[i] = 0.f;
         }
     }
@@ -299,6 +409,34 @@ extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void
     }
 #undef CALL_BWD
     return dctr_launch_status("dctr_embed_gather_fm_bwd");
+}
+
+extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr && a->fwd != nullptr, DCTR_E_NULL, "embed_pool_bwd: null args");
+    const dctr_pool_args_t* f = a->fwd;
+    DCTR_REQUIRE(f->batch >= 0 && f->maxlen >= 1 && f->dim >= 1 && f->dim <= 64 && f->dim % 4 == 0, DCTR_E_UNSUPPORTED,
+                 "embed_pool_bwd: needs embedding_dim %% 4 == 0 and <= 64");
+    if (f->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(f->idx && f->table, DCTR_E_NULL, "embed_pool_bwd: null idx / table");
+    DCTR_REQUIRE(a->d_out == nullptr || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_out)), DCTR_E_ALIGN,
+                 "embed_pool_bwd: d_out must be 16-B aligned with a stride %% 4 == 0");
+    int lpr = 1;
+    while (lpr * 4 < f->dim) lpr <<= 1;
+    const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(256 / lpr));
+    DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool_bwd: batch too large");
+    hipStream_t st = (hipStream_t)stream;
+#define CALL_PB(L) \
+    hipLaunchKernelGGL((pool_bwd_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, *f, a->d_out, a->d_stride, a->d_lin_out, \
+                       a->g_table, a->g_lin_table)
+    switch (lpr) {
+        case 1: CALL_PB(1); break;
+        case 2: CALL_PB(2); break;
+        case 4: CALL_PB(4); break;
+        case 8: CALL_PB(8); break;
+        default: CALL_PB(16); break;
+    }
+#undef CALL_PB
+    return dctr_launch_status("dctr_embed_pool_bwd");
 }
 
 extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
@@ -384,14 +522,26 @@ extern "C" int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n,
     return dctr_launch_status("dctr_adam_step");
 }
 
-extern "C" int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
-                               float eps, int32_t zero_grad, void* stream) {
-    DCTR_REQUIRE(n_segs >= 0 && n_segs <= 65535 && max_n >= 0, DCTR_E_DIM, "adam_multi: bad n_segs / max_n");
+extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
+                              float beta2, float eps, int32_t zero_grad, void* stream) {
+    DCTR_REQUIRE(kind >= DCTR_OPT_ADAM && kind <= DCTR_OPT_SGD, DCTR_E_ENUM, "opt_multi: optimizer kind %d", kind);
+    DCTR_REQUIRE(n_segs >= 0 && n_segs <= 65535 && max_n >= 0, DCTR_E_DIM, "opt_multi: bad n_segs / max_n");
     if (n_segs == 0 || max_n == 0) return DCTR_OK;
-    DCTR_REQUIRE(segs != nullptr, DCTR_E_NULL, "adam_multi: null segment array");
+    DCTR_REQUIRE(segs != nullptr, DCTR_E_NULL, "opt_multi: null segment array");
     int64_t bx = dctr_ceil_div(max_n / 4 + 1, (int64_t)(256 * 4));      // four float4 per thread in the largest segment
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)bx, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, segs, alpha,
-                       beta1, beta2, eps, (int)zero_grad);
-    return dctr_launch_status("dctr_adam_multi");
+    const dim3 grid((unsigned)bx, (unsigned)n_segs);
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+        case DCTR_OPT_ADAM: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_ADAM>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        case DCTR_OPT_ADAGRAD: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_ADAGRAD>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        case DCTR_OPT_RMSPROP: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_RMSPROP>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        default: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_SGD>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+    }
+    return dctr_launch_status("dctr_opt_multi");
+}
+
+extern "C" int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
+                               float eps, int32_t zero_grad, void* stream) {
+    return dctr_opt_multi(DCTR_OPT_ADAM, segs, n_segs, max_n, alpha, beta1, beta2, eps, zero_grad, stream);
 }

@@ -188,6 +188,7 @@ class EmbeddingStage(object):
         self.max_dim = max([f.dim for f in self.fields] + [1])
         self.any_hash = any(f.hash_mode for f in self.fields)
         self.k_split = self._find_k_split()
+        self.pool_trace = None        # training: a list that collects (dctr_pool_args_t, tensors) of the forward's pool calls
         self._ws = {}
 
     def _find_k_split(self):
@@ -338,7 +339,8 @@ class EmbeddingStage(object):
         weight = staged.weight[fc.weight_name][lo:hi] if fc.weight_name is not None else None
         hm = 2 if (fc.use_hash and not prehashed_on_host(fc)) else 0
         ops.embed_pool(ids, table, fc.combiner, length=length, weight=weight, weight_norm=fc.weight_norm,
-                       lin_table=lin_table, hash_mode=hm, out=out, out_stride=out.stride(0), lin_out=lin_out, status=status)
+                       lin_table=lin_table, hash_mode=hm, out=out, out_stride=out.stride(0), lin_out=lin_out, status=status,
+                       keep_args=self.pool_trace)
 
     def gather_args(self, staged, lo, hi, ws, to_hbm=True):
         """dctr_gather_fm_args_t for rows [lo, hi) (pooled fields must already be in the workspace)."""

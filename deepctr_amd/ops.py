@@ -131,7 +131,7 @@ def embed_lookup(idx, table, hash_mode=0, out=None, out_stride=None, return_mask
 
 
 def embed_pool(idx, table, combiner="mean", length=None, weight=None, weight_norm=True, lin_table=None, hash_mode=0,
-               out=None, out_stride=None, lin_out=None, status=None):
+               out=None, out_stride=None, lin_out=None, status=None, keep_args=None):
     """VarLenSparseFeat lookup + (weighted) masked pooling: idx [B,T] -> [B,dim] (reference
     inputs.py:120-158, layers/sequence.py:76-106,155-183).  ``length`` [B] selects the length-mask form,
     otherwise mask_zero on the (post-hash) index.  Returns (pooled, pooled_linear or None)."""
@@ -162,7 +162,19 @@ def embed_pool(idx, table, combiner="mean", length=None, weight=None, weight_nor
                     lin_out=None if lin_out is None else lin_out.data_ptr(),
                     status=None if status is None else status.data_ptr())
     _C.check(lib.dctr_embed_pool(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_pool")
+    if keep_args is not None:           # training: the backward call re-uses these arguments (and their tensors)
+        keep_args.append((a, (ic, table, lin_table, length, weight, out, lin_out)))
     return out, lin_out
+
+
+def embed_pool_bwd(fwd_args, d_out=None, d_lin_out=None, g_table=None, g_lin_table=None):
+    """Backward of dctr_embed_pool: scatter-adds into the dense gradient tables (see include/dctr.h)."""
+    a = _C.PoolBwdArgs(fwd=ctypes.pointer(fwd_args), d_out=None if d_out is None else d_out.data_ptr(),
+                       d_stride=0 if d_out is None else d_out.stride(0),
+                       d_lin_out=None if d_lin_out is None else d_lin_out.data_ptr(),
+                       g_table=None if g_table is None else g_table.data_ptr(),
+                       g_lin_table=None if g_lin_table is None else g_lin_table.data_ptr())
+    _C.check(_C.lib().dctr_embed_pool_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_pool_bwd")
 
 
 def seq_weight(seq, weight, mask=None, length=None, weight_norm=True):
@@ -539,3 +551,9 @@ def adam_multi(segs, n_segs, max_n, alpha, beta1=0.9, beta2=0.999, eps=1e-7, zer
     """dctr_adam_step for every parameter in one launch (segments from make_adam_segments)."""
     _C.check(_C.lib().dctr_adam_multi(_ptr(segs), int(n_segs), int(max_n), float(alpha), float(beta1), float(beta2),
                                       float(eps), int(bool(zero_grad)), _C.stream_ptr()), "dctr_adam_multi")
+
+
+def opt_multi(kind, segs, n_segs, max_n, lr, beta1=0.9, beta2=0.999, eps=1e-7, zero_grad=True):
+    """One optimizer step (kind: adam | adagrad | rmsprop | sgd) over every parameter segment in one launch."""
+    _C.check(_C.lib().dctr_opt_multi(_C.OPT_CODES[kind], _ptr(segs), int(n_segs), int(max_n), float(lr), float(beta1),
+                                     float(beta2), float(eps), int(bool(zero_grad)), _C.stream_ptr()), "dctr_opt_multi")

@@ -207,8 +207,8 @@ def _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbos
     moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation."""
     from .training_hip import HipTrainer
     tr = getattr(model, "_hip_trainer", None)
-    if tr is None:
-        tr = model._hip_trainer = HipTrainer(model)
+    if tr is None or tr.kind != model._compiled["optimizer"].lower():
+        tr = model._hip_trainer = HipTrainer(model, model._compiled["optimizer"])
     hist = History()
     hist.history["loss"] = []
     bs = int(batch_size) if batch_size else n_tr
@@ -250,7 +250,7 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     loss_name0 = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
     from . import training_hip
     if (getattr(model, "hip_training", True) and isinstance(model._compiled["optimizer"], str)
-            and model._compiled["optimizer"].lower() == "adam" and training_hip.supported(model)
+            and model._compiled["optimizer"].lower() in training_hip.OPT_DEFAULTS and training_hip.supported(model)
             and ((loss_name0 in ("binary_crossentropy", "logloss") and model.task == "binary")
                  or (loss_name0 in ("mse", "mean_squared_error") and model.task != "binary"))):
         return _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)

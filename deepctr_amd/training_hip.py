@@ -1,13 +1,15 @@
 """HIP training step — SURVEY.md §8(f) rank 1: backward + optimizer of the hot path on HIP kernels.
 
-Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer) with fixed-length
-features: forward = ``dctr_embed_gather_fm`` + ``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` →
-``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` → ``dctr_adam_step`` per parameter.  No torch autograd, no torch
+Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer: DeepFM, WDL, FNN),
+sequence features included: forward = ``dctr_embed_pool`` per sequence feature + ``dctr_embed_gather_fm`` +
+``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` → ``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` →
+``dctr_embed_pool_bwd`` → ``dctr_opt_multi`` (one launch over every parameter).  No torch autograd, no torch
 optimizer: PyTorch only owns the buffers.  Models / options outside that family keep the torch-autograd step of
 ``training.py`` (the interaction-layer backward kernels for CIN / CrossNet / attention do not exist yet).
 
 Semantics follow tf.keras as the reference uses it (``model.compile("adam", "binary_crossentropy")``,
-examples/run_classification_criteo.py:44-50): Adam lr 1e-3, beta 0.9 / 0.999, epsilon 1e-7, NON-lazy on embeddings
+examples/run_classification_criteo.py:44-50; also "adagrad", "rmsprop", "sgd" by name with tf.keras' defaults): Adam lr
+1e-3, beta 0.9 / 0.999, epsilon 1e-7, NON-lazy on embeddings
 (every row of a table decays every step, as ``_resource_apply_sparse`` does), L2 regularisers of the constructor
 (``l2_reg_embedding``, ``l2_reg_linear``, ``l2_reg_dnn``) added to the gradients.
 """
@@ -24,7 +26,7 @@ def supported(model):
     dnn = getattr(model, "dnn", None)
     if sp is None or dnn is None or type(model).__name__ != "_DeepFM":
         return False
-    if sp.pooled_fields or sp.lin_only or len(sp.fm_group_names) > 1 or sp.extra_offsets or not sp.all_dim4:
+    if sp.lin_only or len(sp.fm_group_names) > 1 or sp.extra_offsets or not sp.all_dim4 or sp.max_dim > 64:
         return False
     if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
         return False
@@ -44,11 +46,26 @@ class _Param(object):
         self.l2 = float(l2)
 
 
+# tf.keras defaults of the optimizers model.compile() takes by name (optimizer_v2/*.py)
+OPT_DEFAULTS = {"adam": dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7), "adagrad": dict(lr=1e-3, eps=1e-7, init_acc=0.1),
+                "rmsprop": dict(lr=1e-3, beta2=0.9, eps=1e-7), "sgd": dict(lr=1e-2)}
+
+
 class HipTrainer(object):
-    def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+    def __init__(self, model, optimizer="adam", lr=None, beta1=None, beta2=None, eps=None):
         if not supported(model):
             raise ValueError("model is outside the HIP training step's family (see training_hip.supported)")
-        self.model, self.lr, self.b1, self.b2, self.eps = model, float(lr), float(beta1), float(beta2), float(eps)
+        optimizer = optimizer.lower()
+        if optimizer not in OPT_DEFAULTS:
+            raise ValueError("optimizer %r not supported (adam, adagrad, rmsprop, sgd)" % optimizer)
+        d = OPT_DEFAULTS[optimizer]
+        self.kind = optimizer
+        self.model = model
+        self.lr = float(d["lr"] if lr is None else lr)
+        self.b1 = float(d.get("beta1", 0.0) if beta1 is None else beta1)
+        self.b2 = float(d.get("beta2", 0.0) if beta2 is None else beta2)
+        self.eps = float(d.get("eps", 0.0) if eps is None else eps)
+        self.init_acc = float(d.get("init_acc", 0.0))
         self.t = 0
         sp = model.stage_plan
         reg = getattr(model, "regularizers", {})
@@ -63,12 +80,14 @@ class HipTrainer(object):
                 self.params.append(by_ptr[key])
             return by_ptr[key]
 
-        entries = []
+        # per field: (gradient table, gradient of the linear table).  Sequence features are pooled by dctr_embed_pool into
+        # per-batch buffers the gather reads as identity fields: their gradients land in per-batch buffers too
+        # (_buffers) and dctr_embed_pool_bwd scatters them on to the tables.
+        self.field_params = []
         for f in sp.fields:
             pt = param(f.table, l2e)
             pl = param(f.lin_table, l2l) if f.lin_table is not None else None
-            entries.append((pt.g, None if pl is None else pl.g))
-        self.field_grads = ops.make_field_grads(entries, model.device)
+            self.field_params.append((f, pt, pl))
         # Linear.kernel (dense features of the linear part): the forward reads a copy permuted into dense-matrix column
         # order (EmbeddingStage.refresh); the backward kernel scatters straight into the real kernel's gradient
         self.p_dense_lin, self.dense_rows = None, None
@@ -80,6 +99,9 @@ class HipTrainer(object):
         self.p_head = param(model.dense.w("kernel"))
         self.p_gbias = param(model.prediction.w("global_bias")) if model.prediction.use_bias else None
         self._buf = {}
+        if self.init_acc:
+            for p in self.params:
+                p.v.fill_(self.init_acc)            # Adagrad's initial_accumulator_value
         self.segs, self.n_segs, self.max_n = ops.make_adam_segments([(p.w, p.m, p.v, p.g, p.l2) for p in self.params],
                                                                     model.device)
 
@@ -95,7 +117,18 @@ class HipTrainer(object):
                 "dlogit": torch.empty(B, dtype=torch.float32, device=dev),
                 "dx": torch.empty(B, sp.out_stride, dtype=torch.float32, device=dev),
                 "loss": torch.zeros(1, dtype=torch.float32, device=dev),
+                "pooled_g": {}, "pooled_lin_g": {},
             }
+            entries = []
+            for f, pt, pl in self.field_params:
+                if f.kind == "pooled":
+                    b["pooled_g"][f.fc.name] = torch.zeros(B, f.dim, dtype=torch.float32, device=dev)
+                    if pl is not None:
+                        b["pooled_lin_g"][f.fc.name] = torch.zeros(B, dtype=torch.float32, device=dev)
+                    entries.append((b["pooled_g"][f.fc.name], b["pooled_lin_g"].get(f.fc.name)))
+                else:
+                    entries.append((pt.g, None if pl is None else pl.g))
+            b["field_grads"] = ops.make_field_grads(entries, dev)
         return b
 
     def step(self, staged, lo, hi, y, apply=True):
@@ -107,8 +140,13 @@ class HipTrainer(object):
         B = hi - lo
         buf = self._buffers(B)
         binary = model.task == "binary"
-        # forward (two launches, activations saved)
-        ws = sp.run(staged, lo, hi)
+        # forward (pool launches + two launches, activations saved)
+        sp.pool_trace = []
+        try:
+            ws = sp.run(staged, lo, hi)
+            pool_calls = sp.pool_trace
+        finally:
+            sp.pool_trace = None
         add = []
         if sp.has_linear:
             add.append(ws["lin"])
@@ -125,15 +163,25 @@ class HipTrainer(object):
         ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
                     [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=buf["dx"])
         # embedding / linear / FM backward
+        for t in list(buf["pooled_g"].values()) + list(buf["pooled_lin_g"].values()):
+            t.zero_()
         g = sp.gather_args(staged, lo, hi, ws)
-        ops.embed_gather_fm_bwd(g, self.field_grads, d_dnn_in=buf["dx"], d_fm=buf["dlogit"] if sp.fm_group_names else None,
+        ops.embed_gather_fm_bwd(g, buf["field_grads"], d_dnn_in=buf["dx"], d_fm=buf["dlogit"] if sp.fm_group_names else None,
                                 d_lin=buf["dlogit"] if sp.has_linear else None,
                                 g_dense_lin_w=None if self.p_dense_lin is None else self.p_dense_lin.g,
                                 dense_lin_rows=self.dense_rows)
+        # sequence features: pooled-vector gradients -> rows of their tables
+        pooled = [(f, pt, pl) for f, pt, pl in self.field_params if f.kind == "pooled"]
+        assert len(pool_calls) == len(pooled)
+        for (args, _keep), (f, pt, pl) in zip(pool_calls, pooled):
+            ops.embed_pool_bwd(args, d_out=buf["pooled_g"][f.fc.name], d_lin_out=buf["pooled_lin_g"].get(f.fc.name),
+                               g_table=pt.g, g_lin_table=None if pl is None else pl.g)
         if not apply:
             return buf["loss"] / B
-        # Adam
+        # optimizer: one launch over every parameter
         self.t += 1
-        alpha = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        ops.adam_multi(self.segs, self.n_segs, self.max_n, alpha, self.b1, self.b2, self.eps)     # one launch, all parameters
+        lr = self.lr
+        if self.kind == "adam":
+            lr = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        ops.opt_multi(self.kind, self.segs, self.n_segs, self.max_n, lr, self.b1, self.b2, self.eps)
         return buf["loss"] / B

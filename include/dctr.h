@@ -354,6 +354,19 @@ typedef struct {
 } dctr_gather_fm_bwd_args_t;
 int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* args, void* stream);
 
+/* backward of dctr_embed_pool (inputs.py:120-158, layers/sequence.py:76-106, :155-183): the gradient of a pooled vector
+ * (and of the pooled 1-wide linear term) scattered to the rows of the sequence with the forward's factors — weight *
+ * mask (sum), / length (mean), or to the first position attaining each dimension's maximum (max). */
+typedef struct {
+    const dctr_pool_args_t* fwd;   /* the forward call's arguments                                      */
+    const float* d_out;            /* [B, d_stride] gradient w.r.t. the pooled vectors, or NULL         */
+    int64_t d_stride;
+    const float* d_lin_out;        /* [B] gradient w.r.t. lin_out, or NULL                              */
+    float* g_table;                /* [vocab, dim] accumulated, or NULL                                 */
+    float* g_lin_table;            /* [vocab] accumulated, or NULL                                      */
+} dctr_pool_bwd_args_t;
+int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* args, void* stream);
+
 /* backward of dctr_mlp_fwd with has_head (layers/core.py:189-208 + Dense(1, use_bias=False)): needs the activations the
  * forward saved through save_acts.  The two GEMMs per layer are plain rocBLAS sgemm calls on `stream`. */
 typedef struct {
@@ -399,6 +412,13 @@ typedef struct {
 } dctr_adam_seg_t;
 int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
                     float eps, int32_t zero_grad, void* stream);
+
+/* the other optimizers model.compile() accepts by name in the reference's examples, same segment array (tf.keras
+ * formulas): ADAGRAD v += g^2, w -= lr g/(sqrt(v)+eps) (v starts at initial_accumulator_value, caller-filled);
+ * RMSPROP (beta2 = rho) v = rho v + (1-rho) g^2, w -= lr g/(sqrt(v)+eps); SGD w -= lr g.  ADAM as dctr_adam_multi. */
+enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_RMSPROP = 2, DCTR_OPT_SGD = 3 };
+int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
+                   float beta2, float eps, int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,75 @@ def test_adam_multi_matches_adam_step(device):
     for pa, pb in zip(a, b):
         for x, y in zip(pa[:4], pb[:4]):
             np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "rmsprop", "sgd"])
+def test_opt_multi_matches_torch_optimizers(device, kind):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(9)
+    sizes = [7, 4100]
+    ws = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    wt = [torch.tensor(w.astype(np.float64), requires_grad=True) for w in ws]
+    opt = {"adagrad": lambda: torch.optim.Adagrad(wt, lr=1e-2, eps=1e-7, initial_accumulator_value=0.1),
+           "rmsprop": lambda: torch.optim.RMSprop(wt, lr=1e-2, alpha=0.9, eps=1e-7),
+           "sgd": lambda: torch.optim.SGD(wt, lr=1e-2)}[kind]()
+    wd = [dev(w, device) for w in ws]
+    m = [torch.zeros_like(w) for w in wd]
+    v = [torch.full_like(w, 0.1 if kind == "adagrad" else 0.0) for w in wd]
+    g = [torch.zeros_like(w) for w in wd]
+    segs, ns, mx = ops.make_adam_segments(list(zip(wd, m, v, g, [0.0, 0.0])), device)
+    for _ in range(3):
+        for i, n in enumerate(sizes):
+            g0 = rng.standard_normal(n).astype(np.float32) * 0.1
+            wt[i].grad = torch.tensor(g0.astype(np.float64))
+            g[i].copy_(dev(g0, device))
+        opt.step()
+        ops.opt_multi(kind, segs, ns, mx, 1e-2, 0.0, 0.9, 1e-7)
+    for a, b in zip(wd, wt):
+        assert_close(a.cpu().numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6, what=kind)
+
+
+@pytest.mark.parametrize("fixture", ["model_wdl", "model_fnn"])
+def test_hip_training_gradients_with_sequence_features(device, fixture):
+    """Pooling backward (sum / mean / max, length- and mask-form, weighted, shared and hashed tables) inside the HIP step,
+    against torch autograd, on the reference-shaped mixed feature set of the golden fixtures."""
+    from deepctr_amd import training
+    from deepctr_amd.training_hip import HipTrainer, supported
+    from tests.test_gpu_models import _randomise, build_model
+    from tests.util import golden_meta, load_golden
+    g = load_golden(fixture)
+    meta = golden_meta(g)
+    model = build_model(meta, device)
+    assert supported(model)
+    rng = np.random.RandomState(12)
+    _randomise(model, rng)
+    feed = {k[5:]: v for k, v in g.items() if k.startswith("feed/")}
+    n = g["y"].shape[0]
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    staged = model.stage(feed)
+    model._begin()
+    tr = HipTrainer(model)
+    yt = dev(y, device)
+    loss = tr.step(staged, 0, n, yt, apply=False)
+    params = [p.w for p in tr.params]
+    for t in params:
+        t.requires_grad_(True)
+    try:
+        model._begin()
+        logit = training.model_logits(model, staged, 0, n)
+        ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+    # the loss VALUE follows Keras (probabilities clipped to [1e-7, 1 - 1e-7]); the all-padding max-pooled rows of this
+    # fixture saturate the sigmoid, where binary_cross_entropy_with_logits does not clip.  Gradients agree either way.
+    pc = torch.sigmoid(logit.detach()).double().clamp(1e-7, 1 - 1e-7)
+    keras_loss = float(-(yt.double() * pc.log() + (1 - yt.double()) * (1 - pc).log()).mean())
+    # (computed from fp32 probabilities, as Keras does: for p within a few ulp of 1 the value moves by ~log 2 per ulp)
+    assert_close(loss.cpu().numpy(), [keras_loss], rtol=5e-2, atol=1e-6, what="loss")
+    for p, gref in zip(tr.params, grads):
+        gref = torch.zeros_like(p.w) if gref is None else gref
+        scale = float(gref.abs().max()) + 1e-30
+        assert_close(p.g.cpu().numpy() / scale, gref.cpu().numpy() / scale, rtol=2e-4, atol=2e-6,
+                     what="grad of %s (scaled by %.3g)" % (tuple(p.w.shape), scale))
