@@ -191,10 +191,11 @@ def test_deepfm_fused_launch_matches_two_launch_path(device):
     from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
     from deepctr_amd.models import DeepFM
     rng = np.random.RandomState(11)
-    for E, n, hashed in ((16, 4096 + 5, False), (32, 300, True), (8, 77, False), (4, 50, True)):
-        cols = [SparseFeat("C%d" % i, 500, E, use_hash=(hashed and i % 2 == 0)) for i in range(26)] + \
+    for E, n, hashed, nf in ((16, 4096 + 5, False, 26), (32, 300, True, 26), (8, 77, False, 26), (4, 50, True, 26),
+                             (64, 129, False, 10), (64, 70, True, 26)):      # E = 64: 16 lanes per row; 26 x 64 columns
+        cols = [SparseFeat("C%d" % i, 500, E, use_hash=(hashed and i % 2 == 0)) for i in range(nf)] + \
                [DenseFeat("I%d" % i, 1) for i in range(13)] + [VarLenSparseFeat(SparseFeat("tags", 40, E), maxlen=5)]
-        feed = {"C%d" % i: rng.randint(0, 10 ** 6 if (hashed and i % 2 == 0) else 500, n).astype(np.int32) for i in range(26)}
+        feed = {"C%d" % i: rng.randint(0, 10 ** 6 if (hashed and i % 2 == 0) else 500, n).astype(np.int32) for i in range(nf)}
         feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(13)})
         feed["tags"] = rng.randint(0, 40, (n, 5)).astype(np.int32)
         model = DeepFM(cols, cols, dnn_hidden_units=(64, 32), device=device)

@@ -430,6 +430,7 @@ def test_din_attention_c4_shape(device):
 
 
 @pytest.mark.parametrize("B,T,E,hid", [(2048, 50, 64, (80, 40)), (37, 21, 32, (96, 48, 20)), (9, 3, 16, (8,)),
+                                       (21, 17, 48, (36, 20)),              # three k-step groups per part (odd)
                                        (37, 21, 32, (128, 48, 20))])      # the last one is too wide for the row kernel
 def test_din_attention_row_kernel_matches_per_sample_kernel(device, B, T, E, hid):
     """The weights-in-LDS row kernel (workspace given) against the one-workgroup-per-sample kernel and the oracle,
