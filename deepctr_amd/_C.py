@@ -97,7 +97,15 @@ class MlpBwdArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("in_dim", c_i32), ("n_layers", c_i32),
                 ("units", c_vp), ("kernels", c_vp), ("acts", c_vp), ("activation", c_i32), ("pad_", c_i32),
                 ("head_w", c_vp), ("dlogit", c_vp), ("d_kernels", c_vp), ("d_biases", c_vp), ("d_head_w", c_vp),
-                ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz)]
+                ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
+                ("d_out", c_vp), ("d_out_stride", c_i64)]
+
+
+class CrossBwdArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("x_stride", c_i64), ("batch", c_i64), ("dim", c_i32), ("layers", c_i32), ("mode", c_i32),
+                ("dx_accumulate", c_i32), ("kernels", c_vp), ("bias", c_vp), ("dy", c_vp), ("dy_stride", c_i64),
+                ("d_kernels", c_vp), ("d_bias", c_vp), ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp),
+                ("workspace_bytes", c_sz)]
 
 
 class AdamSeg(ctypes.Structure):
@@ -139,6 +147,9 @@ SYMBOLS = {
     "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
     "dctr_embed_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolBwdArgs), c_vp]),
+    "dctr_dense1_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dctr_crossnet_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CrossBwdArgs)]),
+    "dctr_crossnet_bwd": (ctypes.c_int, [ctypes.POINTER(CrossBwdArgs), c_vp]),
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),

@@ -222,8 +222,9 @@ constexpr int BWD_ROWS = 16;     // batch rows per workgroup of the two helpers 
 
 // dZ[b, n] = dlogit[b] * head_w[n] * act'(h[b, n]);   d_head_w[n] += sum_b dlogit[b] * h[b, n]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ head_w,
-                                                       const float* __restrict__ h, int64_t batch, int N, int act,
-                                                       float* __restrict__ dz, float* __restrict__ d_head_w) {
+                                                       const float* __restrict__ h, int64_t h_stride, int64_t batch, int N,
+                                                       int act, float* __restrict__ dz, int64_t dz_stride,
+                                                       float* __restrict__ d_head_w) {
     // block = BWD_ROWS rows x all columns; thread t walks columns t, t+256, ...
     const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     for (int n = threadIdx.x; n < N; n += 256) {
@@ -232,12 +233,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= batch) break;
-            const float hv = h[b * N + n], dl = dlogit[b];
+            const float hv = h[b * h_stride + n], dl = dlogit[b];
             float d = dl * hw;
             if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
             else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
             else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
-            dz[b * N + n] = d;
+            dz[b * dz_stride + n] = d;
             acc = fmaf(dl, hv, acc);
         }
         unsafeAtomicAdd(d_head_w + n, acc);
@@ -356,6 +357,127 @@ __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// CrossNet backward (interaction.py:405-424).  No activations are saved by the forward: both forms recompute x_l.
+//   vector: x_{l+1} = x0 * s_l + b_l + x_l,  s_l = x_l . w_l
+//     ds = g . x0;  d b_l += g;  d w_l += ds * x_l;  d x0 += g * s_l;  g += ds * w_l      (l = L-1 .. 0),  d x0 += g
+//   One wave walks CROSS_SPW samples (x_l per layer in LDS), accumulating d w / d b in LDS, flushed once with atomics.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CROSS_SPW = 16;
+
+__global__ __launch_bounds__(256) void cross_vector_bwd_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int d,
+                                                               int L, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const float* __restrict__ dy, int64_t dy_stride,
+                                                               float* __restrict__ dw, float* __restrict__ db,
+                                                               float* __restrict__ dx, int64_t dx_stride, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* xs = smem + (size_t)wave * (3 * L * d + L);      // [L][d] x_l
+    float* aw = xs + (size_t)L * d;                           // [L][d] d w accumulators
+    float* ab = aw + (size_t)L * d;                           // [L][d] d b accumulators
+    float* sl = ab + (size_t)L * d;                           // [L] s_l
+    for (int i = lane; i < 2 * L * d; i += 64) aw[i] = 0.f;
+    const int64_t b_first = ((int64_t)blockIdx.x * 4 + wave) * CROSS_SPW;
+    for (int it = 0; it < CROSS_SPW; ++it) {
+        const int64_t b = b_first + it;
+        if (b >= batch) break;
+        const float* x0 = x + b * x_stride;
+        // forward, keeping x_l
+        for (int i = lane; i < d; i += 64) xs[i] = x0[i];
+        for (int l = 0; l < L; ++l) {
+            const float* xl = xs + (size_t)l * d;
+            float dot = 0.f;
+            for (int i = lane; i < d; i += 64) dot = fmaf(xl[i], w[(size_t)l * d + i], dot);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+            if (lane == 0) sl[l] = dot;
+            if (l + 1 < L)
+                for (int i = lane; i < d; i += 64) xs[(size_t)(l + 1) * d + i] = x0[i] * dot + bias[(size_t)l * d + i] + xl[i];
+        }
+        // backward: g lives in dx (or a register-free walk over LDS): reuse ab? no — keep g in the output row
+        float* gout = dx + b * dx_stride;
+        const float* gin = dy + b * dy_stride;
+        // g is held in registers in chunks of 64 columns: up to 32 chunks (d <= 2048)
+        float g[32], dx0[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int i = lane + 64 * r;
+            g[r] = i < d ? gin[i] : 0.f;
+            dx0[r] = 0.f;
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            const float* xl = xs + (size_t)l * d;
+            const float s = sl[l];
+            float ds = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = lane + 64 * r;
+                if (i < d) ds = fmaf(g[r], x0[i], ds);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) ds += __shfl_xor(ds, m, 64);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = lane + 64 * r;
+                if (i < d) {
+                    ab[(size_t)l * d + i] += g[r];
+                    aw[(size_t)l * d + i] = fmaf(ds, xl[i], aw[(size_t)l * d + i]);
+                    dx0[r] = fmaf(g[r], s, dx0[r]);
+                    g[r] = fmaf(ds, w[(size_t)l * d + i], g[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int i = lane + 64 * r;
+            if (i < d) gout[i] = (accumulate ? gout[i] : 0.f) + dx0[r] + g[r];
+        }
+    }
+    for (int i = lane; i < L * d; i += 64) {
+        unsafeAtomicAdd(dw + i, aw[i]);
+        unsafeAtomicAdd(db + i, ab[i]);
+    }
+}
+
+// matrix form, elementwise parts (the GEMMs are rocBLAS): forward  x_next = x0 .* (u + b) + x_l
+__global__ __launch_bounds__(256) void cross_matrix_fwd_elem_kernel(const float* __restrict__ x0, int64_t x_stride,
+                                                                    const float* __restrict__ xl, int64_t xl_stride,
+                                                                    const float* __restrict__ u, const float* __restrict__ bias,
+                                                                    int64_t batch, int d, float* __restrict__ xn) {
+    const int64_t total = batch * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / d;
+        const int c = (int)(i - b * d);
+        xn[i] = x0[b * x_stride + c] * (u[i] + bias[c]) + xl[b * xl_stride + c];
+    }
+}
+
+// backward: du = g .* x0;  dx0 (+)= g .* (u + b)
+__global__ __launch_bounds__(256) void cross_matrix_bwd_elem_kernel(const float* __restrict__ x0, int64_t x_stride,
+                                                                    const float* __restrict__ g, const float* __restrict__ u,
+                                                                    const float* __restrict__ bias, int64_t batch, int d,
+                                                                    float* __restrict__ du, float* __restrict__ dx0) {
+    const int64_t total = batch * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / d;
+        const int c = (int)(i - b * d);
+        const float gv = g[i];
+        du[i] = gv * x0[b * x_stride + c];
+        dx0[i] += gv * (u[i] + bias[c]);
+    }
+}
+
+// out[b, c] (+)= src[b, c]   (strided rows)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ src, int64_t src_stride, int64_t batch, int d,
+                                                       float* __restrict__ out, int64_t out_stride, int accumulate) {
+    const int64_t total = batch * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / d;
+        const int c = (int)(i - b * d);
+        out[b * out_stride + c] = (accumulate ? out[b * out_stride + c] : 0.f) + src[b * src_stride + c];
+    }
+}
+
 rocblas_handle blas_handle() {
     static thread_local rocblas_handle h = nullptr;
     if (h == nullptr) {
@@ -450,8 +572,10 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_bwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->in_dim >= 1 && a->n_layers >= 1 && a->n_layers <= 8, DCTR_E_DIM, "mlp_bwd: bad sizes");
     if (a->batch == 0) return DCTR_OK;
-    DCTR_REQUIRE(a->x && a->units && a->kernels && a->acts && a->dlogit && a->head_w && a->d_kernels && a->d_head_w, DCTR_E_NULL,
-                 "mlp_bwd: null pointer");
+    DCTR_REQUIRE(a->x && a->units && a->kernels && a->acts && a->d_kernels, DCTR_E_NULL, "mlp_bwd: null pointer");
+    DCTR_REQUIRE((a->head_w != nullptr && a->dlogit != nullptr && a->d_head_w != nullptr) ||
+                     (a->head_w == nullptr && a->d_out != nullptr && a->d_out_stride >= a->units[a->n_layers - 1]),
+                 DCTR_E_NULL, "mlp_bwd: needs either (head_w, dlogit, d_head_w) or d_out");
     DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_UNSUPPORTED,
                  "mlp_bwd: activation %d has no backward yet (linear, relu, sigmoid, tanh)", a->activation);
     DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_mlp_bwd_workspace_bytes(a), DCTR_E_NULL,
@@ -470,8 +594,18 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     const int L = a->n_layers;
     // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit
     const int NL = a->units[L - 1];
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(rb), dim3(256), 0, st, a->dlogit, a->head_w, a->acts[L - 1], a->batch, NL,
-                       (int)a->activation, bufA, a->d_head_w);
+    if (a->head_w != nullptr) {
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(rb), dim3(256), 0, st, a->dlogit, a->head_w, a->acts[L - 1], (int64_t)NL,
+                           a->batch, NL, (int)a->activation, bufA, (int64_t)NL, a->d_head_w);
+    } else {
+        // headless (the DNN branch of DCN): the caller hands d(loss)/d(h_last); dZ_last = d_out .* act'(h_last)
+        hipError_t ce = hipMemcpy2DAsync(bufA, (size_t)NL * sizeof(float), a->d_out, (size_t)a->d_out_stride * sizeof(float),
+                                         (size_t)NL * sizeof(float), (size_t)a->batch, hipMemcpyDeviceToDevice, st);
+        DCTR_REQUIRE(ce == hipSuccess, (int)ce, "mlp_bwd: copy of d_out failed: %s", hipGetErrorString(ce));
+        if (a->activation != DCTR_ACT_LINEAR)
+            hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, bufA, a->acts[L - 1], a->batch, NL,
+                               (int)a->activation, (float*)nullptr);
+    }
     float* dz = bufA;
     float* other = bufB;
     const float one = 1.f, zero = 0.f;
@@ -544,4 +678,109 @@ extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t
 extern "C" int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
                                float eps, int32_t zero_grad, void* stream) {
     return dctr_opt_multi(DCTR_OPT_ADAM, segs, n_segs, max_n, alpha, beta1, beta2, eps, zero_grad, stream);
+}
+
+// Dense(1, use_bias=False) on an arbitrary [B, N] input with row stride (DCN's head over the [cross, deep] stack):
+// dx[b, n] = dlogit[b] * w[n];  d_w[n] += sum_b dlogit[b] * x[b, n]
+extern "C" int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, int32_t n, const float* w, const float* dlogit,
+                               float* dx, int64_t dx_stride, float* d_w, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && n >= 1 && x_stride >= n && dx_stride >= n, DCTR_E_DIM, "dense1_bwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x && w && dlogit && dx && d_w, DCTR_E_NULL, "dense1_bwd: null pointer");
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)BWD_ROWS)), dim3(256), 0, (hipStream_t)stream,
+                       dlogit, w, x, x_stride, batch, (int)n, (int)DCTR_ACT_LINEAR, dx, dx_stride, d_w);
+    return dctr_launch_status("dctr_dense1_bwd");
+}
+
+extern "C" size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* a) {
+    if (a == nullptr || a->batch <= 0 || a->layers <= 0 || a->mode != DCTR_CROSS_MATRIX) return 0;
+    // x_1 .. x_{L-1}, u_0 .. u_{L-1}, g, du, dx0
+    return (size_t)(2 * a->layers + 2) * a->batch * a->dim * sizeof(float);
+}
+
+extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "crossnet_bwd: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->dim >= 1 && a->layers >= 0, DCTR_E_DIM, "crossnet_bwd: bad sizes");
+    DCTR_REQUIRE(a->mode == DCTR_CROSS_VECTOR || a->mode == DCTR_CROSS_MATRIX, DCTR_E_ENUM, "crossnet_bwd: mode %d", a->mode);
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->x && a->dy && a->dx && a->x_stride >= a->dim && a->dy_stride >= a->dim && a->dx_stride >= a->dim, DCTR_E_NULL,
+                 "crossnet_bwd: null pointer or stride < dim");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = a->dim, L = a->layers;
+    const unsigned eb = (unsigned)(dctr_ceil_div(a->batch * d, (int64_t)256) > 4096 ? 4096 : dctr_ceil_div(a->batch * d, (int64_t)256));
+    if (L == 0) {
+        hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, a->dy, a->dy_stride, a->batch, d, a->dx, a->dx_stride,
+                           (int)a->dx_accumulate);
+        return dctr_launch_status("dctr_crossnet_bwd");
+    }
+    DCTR_REQUIRE(a->kernels && a->bias && a->d_kernels && a->d_bias, DCTR_E_NULL, "crossnet_bwd: null weights / gradients");
+    if (a->mode == DCTR_CROSS_VECTOR) {
+        DCTR_REQUIRE(d <= 2048, DCTR_E_UNSUPPORTED, "crossnet_bwd(vector): dim %d > 2048", d);
+        const size_t lds = (size_t)4 * (3 * (size_t)L * d + L) * sizeof(float);
+        DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_bwd(vector): %d layers x dim %d need %zu B of LDS", L, d, lds);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)cross_vector_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DCTR_REQUIRE(e == hipSuccess, (int)e, "crossnet_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+        }
+        const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)(4 * CROSS_SPW));
+        hipLaunchKernelGGL(cross_vector_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a->x, a->x_stride, a->batch, d, L,
+                           a->kernels, a->bias, a->dy, a->dy_stride, a->d_kernels, a->d_bias, a->dx, a->dx_stride,
+                           (int)a->dx_accumulate);
+        return dctr_launch_status("dctr_crossnet_bwd");
+    }
+    // matrix: rocBLAS GEMMs + elementwise kernels, intermediates in the workspace
+    DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_crossnet_bwd_workspace_bytes(a) && a->batch < 0x7fffffffLL,
+                 DCTR_E_NULL, "crossnet_bwd(matrix): needs a workspace of dctr_crossnet_bwd_workspace_bytes() bytes");
+    rocblas_handle h = blas_handle();
+    DCTR_REQUIRE(h != nullptr && rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED,
+                 "crossnet_bwd: rocBLAS handle / stream failed");
+    const int B = (int)a->batch;
+    const size_t bd = (size_t)a->batch * d;
+    float* ws = static_cast<float*>(a->workspace);
+    float* xsave = ws;                       // x_1 .. x_{L-1}  (x_0 = a->x)
+    float* us = ws + (size_t)(L - 1) * bd;   // u_0 .. u_{L-1}
+    float* g = us + (size_t)L * bd;
+    float* du = g + bd;
+    float* dx0 = du + bd;
+    const float one = 1.f, zero = 0.f;
+    auto xl_of = [&](int l, const float*& p, int& ld) {
+        if (l == 0) { p = a->x; ld = (int)a->x_stride; }
+        else { p = xsave + (size_t)(l - 1) * bd; ld = d; }
+    };
+    for (int l = 0; l < L; ++l) {            // forward recompute: u_l = x_l W_l^T;  x_{l+1} = x0 .* (u_l + b_l) + x_l
+        const float* xl; int ldx;
+        xl_of(l, xl, ldx);
+        const float* W = a->kernels + (size_t)l * d * d;
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, d, B, d, &one, W, d, xl, ldx, &zero,
+                                          us + (size_t)l * bd, d);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(u) failed (%d)", (int)rs);
+        if (l + 1 < L)
+            hipLaunchKernelGGL(cross_matrix_fwd_elem_kernel, dim3(eb), dim3(256), 0, st, a->x, a->x_stride, xl, (int64_t)ldx,
+                               us + (size_t)l * bd, a->bias + (size_t)l * d, a->batch, d, xsave + (size_t)l * bd);
+    }
+    hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, a->dy, a->dy_stride, a->batch, d, g, (int64_t)d, 0);
+    hipError_t me = hipMemsetAsync(dx0, 0, bd * sizeof(float), st);
+    DCTR_REQUIRE(me == hipSuccess, (int)me, "crossnet_bwd: memset failed: %s", hipGetErrorString(me));
+    const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
+    for (int l = L - 1; l >= 0; --l) {
+        const float* xl; int ldx;
+        xl_of(l, xl, ldx);
+        const float* W = a->kernels + (size_t)l * d * d;
+        hipLaunchKernelGGL(cross_matrix_bwd_elem_kernel, dim3(eb), dim3(256), 0, st, a->x, a->x_stride, g, us + (size_t)l * bd,
+                           a->bias + (size_t)l * d, a->batch, d, du, dx0);
+        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, du, (const float*)nullptr, a->batch, d, 0,
+                           a->d_bias + (size_t)l * d);
+        // dW[n][k] += sum_b du[b][n] x_l[b][k]:  column-major  dW'(k x n) = X'(k x B) * du'(n x B)^T
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, d, B, &one, xl, ldx, du, d, &one,
+                                          a->d_kernels + (size_t)l * d * d, d);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        // g[b][k] += sum_n du[b][n] W[n][k]:  column-major  g'(k x B) += W'(k x n) * du'(n x B)
+        rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, B, d, &one, W, d, du, d, &one, g, d);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(g) failed (%d)", (int)rs);
+    }
+    // d x0 = dx0 + g  (x_0 is also the first x_l)
+    hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, g, (int64_t)d, a->batch, d, dx0, (int64_t)d, 1);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, dx0, (int64_t)d, a->batch, d, a->dx, a->dx_stride,
+                       (int)a->dx_accumulate);
+    return dctr_launch_status("dctr_crossnet_bwd");
 }

@@ -78,5 +78,9 @@ def DCN(linear_feature_columns, dnn_feature_columns, cross_num=2, cross_paramete
     """Instantiates the Deep&Cross Network architecture on the MI355X forward path."""
     if len(dnn_hidden_units) == 0 and cross_num == 0:
         raise ValueError("Either hidden_layer or cross layer must > 0")
-    return _DCN(linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units, seed,
-                dnn_dropout, dnn_use_bn, dnn_activation, task, device)
+    m = _DCN(linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units, seed,
+             dnn_dropout, dnn_use_bn, dnn_activation, task, device)
+    # l2 regularisers of the reference constructor, applied by the HIP training step as 2*l2*w on the gradients
+    m.regularizers = {"embedding": float(l2_reg_embedding), "linear": float(l2_reg_linear), "dnn": float(l2_reg_dnn),
+                      "cross": float(l2_reg_cross)}
+    return m

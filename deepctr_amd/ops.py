@@ -510,19 +510,22 @@ def embed_gather_fm_bwd(fwd_args, grads_dev, d_dnn_in=None, d_fm=None, d_lin=Non
     _C.check(_C.lib().dctr_embed_gather_fm_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm_bwd")
 
 
-def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None):
-    """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written."""
-    _dev_check(x, dlogit, *kernels)
+def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None):
+    """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written.
+    Headless form: head_w = dlogit = d_head_w = None and ``d_out`` [B, >= units[-1]] = gradient w.r.t. the last layer."""
+    _dev_check(x, *kernels)
     n = len(kernels)
     units = [k.shape[1] for k in kernels]
     ua, kp, ap = _i32_array(units), _ptr_array(kernels), _ptr_array(acts)
     dkp, dbp = _ptr_array(d_kernels), _ptr_array(d_biases)
     a = _C.MlpBwdArgs(x=x.data_ptr(), batch=x.shape[0], x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
                       units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
-                      acts=ctypes.cast(ap, ctypes.c_void_p), activation=_C.ACT_CODES[activation], head_w=head_w.data_ptr(),
-                      dlogit=dlogit.data_ptr(), d_kernels=ctypes.cast(dkp, ctypes.c_void_p),
-                      d_biases=ctypes.cast(dbp, ctypes.c_void_p), d_head_w=d_head_w.data_ptr(),
-                      dx=None if dx is None else dx.data_ptr(), dx_stride=0 if dx is None else dx.stride(0))
+                      acts=ctypes.cast(ap, ctypes.c_void_p), activation=_C.ACT_CODES[activation],
+                      head_w=None if head_w is None else head_w.data_ptr(),
+                      dlogit=None if dlogit is None else dlogit.data_ptr(), d_kernels=ctypes.cast(dkp, ctypes.c_void_p),
+                      d_biases=ctypes.cast(dbp, ctypes.c_void_p), d_head_w=None if d_head_w is None else d_head_w.data_ptr(),
+                      dx=None if dx is None else dx.data_ptr(), dx_stride=0 if dx is None else dx.stride(0),
+                      d_out=None if d_out is None else d_out.data_ptr(), d_out_stride=0 if d_out is None else d_out.stride(0))
     need = int(_C.lib().dctr_mlp_bwd_workspace_bytes(ctypes.byref(a)))
     ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), need
@@ -557,3 +560,26 @@ def opt_multi(kind, segs, n_segs, max_n, lr, beta1=0.9, beta2=0.999, eps=1e-7, z
     """One optimizer step (kind: adam | adagrad | rmsprop | sgd) over every parameter segment in one launch."""
     _C.check(_C.lib().dctr_opt_multi(_C.OPT_CODES[kind], _ptr(segs), int(n_segs), int(max_n), float(lr), float(beta1),
                                      float(beta2), float(eps), int(bool(zero_grad)), _C.stream_ptr()), "dctr_opt_multi")
+
+
+def dense1_bwd(x, n, w, dlogit, dx, d_w):
+    """Backward of Dense(1, use_bias=False) on the first n columns of a strided [B, >= n] input (include/dctr.h)."""
+    _dev_check(x, w, dlogit, dx, d_w)
+    _C.check(_C.lib().dctr_dense1_bwd(_ptr(x), x.stride(0), x.shape[0], int(n), _ptr(w), _ptr(dlogit), _ptr(dx), dx.stride(0),
+                                      _ptr(d_w), _C.stream_ptr()), "dctr_dense1_bwd")
+
+
+def crossnet_bwd(x, d, kernels, bias, parameterization, dy, d_kernels, d_bias, dx, accumulate=False):
+    """Backward of dctr_crossnet_fwd: x [B, >= d] the forward input, dy [B, >= d]; d_kernels / d_bias are ACCUMULATED,
+    dx [B, >= d] is written (or added to with ``accumulate``)."""
+    _dev_check(x, dy, dx, kernels, bias)
+    L = 0 if kernels is None else kernels.shape[0]
+    mode = _C.CROSS_VECTOR if parameterization == "vector" else _C.CROSS_MATRIX
+    a = _C.CrossBwdArgs(x=x.data_ptr(), x_stride=x.stride(0), batch=x.shape[0], dim=int(d), layers=L, mode=mode,
+                        dx_accumulate=int(bool(accumulate)), kernels=_ptr(kernels), bias=_ptr(bias), dy=dy.data_ptr(),
+                        dy_stride=dy.stride(0), d_kernels=_ptr(d_kernels), d_bias=_ptr(d_bias), dx=dx.data_ptr(),
+                        dx_stride=dx.stride(0))
+    need = int(_C.lib().dctr_crossnet_bwd_workspace_bytes(ctypes.byref(a)))
+    ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _C.check(_C.lib().dctr_crossnet_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_bwd")

@@ -24,14 +24,18 @@ def supported(model):
     """Can this model train on the HIP step?  (DeepFM family, fixed-length features, relu/linear/sigmoid/tanh DNN.)"""
     sp = getattr(model, "stage_plan", None)
     dnn = getattr(model, "dnn", None)
-    if sp is None or dnn is None or type(model).__name__ != "_DeepFM":
+    kind = type(model).__name__
+    if sp is None or kind not in ("_DeepFM", "_DCN"):
         return False
     if sp.lin_only or len(sp.fm_group_names) > 1 or sp.extra_offsets or not sp.all_dim4 or sp.max_dim > 64:
         return False
-    if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
+    if kind == "_DeepFM" and (dnn is None or not dnn.kernels):
         return False
-    if getattr(dnn, "dropout_rate", 0):
-        return False
+    if dnn is not None:
+        if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
+            return False
+        if getattr(dnn, "dropout_rate", 0):
+            return False
     return True
 
 
@@ -94,9 +98,17 @@ class HipTrainer(object):
         if model.linear is not None and sp.n_dense and sp.n_lin_dense and sp.has_linear:
             self.p_dense_lin = param(model.linear.w("linear_kernel"), l2l)
             self.dense_rows = torch.as_tensor(sp.dense_lin_rows, dtype=torch.int32, device=model.device)
-        self.p_kernels = [param(k, l2d) for k in model.dnn.kernels]
-        self.p_biases = [param(b) for b in model.dnn.biases]
+        self.is_dcn = type(model).__name__ == "_DCN"
+        self.p_kernels = [param(k, l2d) for k in model.dnn.kernels] if model.dnn is not None else []
+        self.p_biases = [param(b) for b in model.dnn.biases] if model.dnn is not None else []
         self.p_head = param(model.dense.w("kernel"))
+        self.p_cross_k = self.p_cross_b = None
+        if self.is_dcn and model.cross is not None:
+            # CrossNet's per-layer kernels / biases become views of one packed tensor each (the layout the C ABI takes),
+            # so that one parameter segment covers them and the layer keeps its Keras-named weights
+            ks, bs = model.cross.packed()
+            self.p_cross_k, self.p_cross_b = param(ks.clone(), reg.get("cross", 0.0)), param(bs.clone())
+            self.bind_cross_views()
         self.p_gbias = param(model.prediction.w("global_bias")) if model.prediction.use_bias else None
         self._buf = {}
         if self.init_acc:
@@ -110,8 +122,9 @@ class HipTrainer(object):
         if b is None:
             dev = self.model.device
             sp = self.model.stage_plan
-            units = [k.shape[1] for k in self.model.dnn.kernels]
+            units = [k.shape[1] for k in self.model.dnn.kernels] if self.model.dnn is not None else []
             b = self._buf[B] = {
+                "dstack": torch.empty(B, (self.model.width + 3) // 4 * 4, dtype=torch.float32, device=dev) if self.is_dcn else None,
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
                 "pred": torch.empty(B, dtype=torch.float32, device=dev),
                 "dlogit": torch.empty(B, dtype=torch.float32, device=dev),
@@ -131,6 +144,78 @@ class HipTrainer(object):
             b["field_grads"] = ops.make_field_grads(entries, dev)
         return b
 
+    def bind_cross_views(self):
+        """(Re-)point CrossNet's Keras-named per-layer weights at views of the packed parameter tensors."""
+        cr = self.model.cross
+        d = cr.dim
+        for i in range(cr.layer_num):
+            cr._weights['kernel%d' % i] = self.p_cross_k.w[i].view(d, -1)
+            cr._weights['bias%d' % i] = self.p_cross_b.w[i].view(d, 1)
+
+    def _loss_grad(self, buf, y, binary):
+        buf["loss"].zero_()
+        ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"],
+                     dlogit_sum=None if self.p_gbias is None else self.p_gbias.g, task="binary" if binary else "regression")
+
+    def _deepfm_forward_backward(self, ws, buf, y, binary):
+        model, sp = self.model, self.model.stage_plan
+        add = []
+        if sp.has_linear:
+            add.append(ws["lin"])
+        if sp.fm_group_names:
+            add.append(ws["fm"])
+        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w, add=add,
+                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
+                out=buf["pred"], save_acts=buf["acts"])
+        self._loss_grad(buf, y, binary)
+        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
+                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=buf["dx"])
+
+    def _dcn_forward_backward(self, ws, buf, y, B, binary):
+        """DCN (models/dcn.py:45-78): [CrossNet(dnn_in), DNN(dnn_in)] -> Dense(1) + linear logit -> PredictionLayer."""
+        model, sp = self.model, self.model.stage_plan
+        d = sp.in_dim
+        stack = model._stack.get(B)
+        if stack is None:
+            stack = model._stack[B] = torch.zeros(B, (model.width + 3) // 4 * 4, dtype=torch.float32, device=model.device)
+        col = 0
+        par = model.cross.parameterization if model.cross is not None else "vector"
+        if model.cross is not None:
+            self._cross_fwd(ws["dnn_in"], d, par, stack)
+            col = d
+        if model.dnn is not None:
+            ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, in_dim=d, out=stack[:, col:],
+                    save_acts=buf["acts"])
+        add = [ws["lin"]] if sp.has_linear else []
+        ops.mlp(stack, [], [], "linear", head_w=self.p_head.w, add=add,
+                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=model.width,
+                out=buf["pred"])
+        self._loss_grad(buf, y, binary)
+        dstack = buf["dstack"]
+        ops.dense1_bwd(stack, model.width, self.p_head.w, buf["dlogit"], dstack, self.p_head.g)
+        have_dx = False
+        if model.dnn is not None:
+            ops.mlp_bwd(ws["dnn_in"], d, model.dnn.kernels, buf["acts"], model.dnn.activation, None, None,
+                        [p.g for p in self.p_kernels], [p.g for p in self.p_biases], None, dx=buf["dx"], d_out=dstack[:, col:])
+            have_dx = True
+        if model.cross is not None:
+            ops.crossnet_bwd(ws["dnn_in"], d, self.p_cross_k.w, self.p_cross_b.w, par, dstack, self.p_cross_k.g, self.p_cross_b.g,
+                             buf["dx"], accumulate=have_dx)
+
+    def _cross_fwd(self, dnn_in, d, par, stack):
+        import ctypes
+        from . import _C
+        mode = _C.CROSS_VECTOR if par == "vector" else _C.CROSS_MATRIX
+        ks, bs = self.p_cross_k.w, self.p_cross_b.w
+        need = int(_C.lib().dctr_crossnet_workspace_bytes(d, ks.shape[0], mode, ctypes.c_void_p(ks.data_ptr())))
+        if need and (getattr(self, "_cross_ws", None) is None or self._cross_ws.numel() * 4 < need):
+            self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=ks.device)
+        _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(dnn_in.data_ptr()), dnn_in.shape[0], d, dnn_in.stride(0),
+                                            ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()), ks.shape[0], mode,
+                                            ctypes.c_void_p(stack.data_ptr()), stack.stride(0),
+                                            ctypes.c_void_p(self._cross_ws.data_ptr()) if need else None, need,
+                                            _C.stream_ptr()), "dctr_crossnet_fwd")
+
     def step(self, staged, lo, hi, y, apply=True):
         """One optimizer step on rows [lo, hi) of the staged inputs; y: device float tensor [hi-lo].  Returns the mean
         loss of the batch BEFORE the update (a device tensor; no host synchronisation here).  ``apply=False`` stops
@@ -147,21 +232,10 @@ class HipTrainer(object):
             pool_calls = sp.pool_trace
         finally:
             sp.pool_trace = None
-        add = []
-        if sp.has_linear:
-            add.append(ws["lin"])
-        if sp.fm_group_names:
-            add.append(ws["fm"])
-        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w, add=add,
-                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
-                out=buf["pred"], save_acts=buf["acts"])
-        # loss gradient
-        buf["loss"].zero_()
-        ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"],
-                     dlogit_sum=None if self.p_gbias is None else self.p_gbias.g, task="binary" if binary else "regression")
-        # DNN backward
-        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
-                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=buf["dx"])
+        if self.is_dcn:
+            self._dcn_forward_backward(ws, buf, y, B, binary)
+        else:
+            self._deepfm_forward_backward(ws, buf, y, binary)
         # embedding / linear / FM backward
         for t in list(buf["pooled_g"].values()) + list(buf["pooled_lin_g"].values()):
             t.zero_()

@@ -389,9 +389,37 @@ typedef struct {
     int64_t dx_stride;
     void* workspace;              /* dctr_mlp_bwd_workspace_bytes() bytes, 16-B aligned                  */
     size_t workspace_bytes;
+    const float* d_out;           /* headless form (head_w == NULL): [B, d_out_stride] gradient w.r.t. the last
+                                     layer's activations (the DNN branch of DCN feeds a wider Dense(1))  */
+    int64_t d_out_stride;
 } dctr_mlp_bwd_args_t;
 size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
 int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
+
+/* backward of Dense(1, use_bias=False) on a strided [B, n] input: dx[b,:] = dlogit[b] * w (written), d_w += x^T dlogit. */
+int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, int32_t n, const float* w, const float* dlogit, float* dx,
+                    int64_t dx_stride, float* d_w, void* stream);
+
+/* backward of dctr_crossnet_fwd (interaction.py:405-424); x_l are recomputed, nothing is saved by the forward.
+ * vector: one fused kernel.  matrix: rocBLAS GEMMs + elementwise kernels through the workspace. */
+typedef struct {
+    const float* x;               /* [B, x_stride] the forward's input x_0                               */
+    int64_t x_stride;
+    int64_t batch;
+    int32_t dim, layers, mode, dx_accumulate;   /* dx_accumulate: 1 = add into dx, 0 = overwrite          */
+    const float* kernels;         /* as in the forward                                                   */
+    const float* bias;
+    const float* dy;              /* [B, dy_stride] gradient w.r.t. the output                           */
+    int64_t dy_stride;
+    float* d_kernels;             /* accumulated, same shape as kernels                                  */
+    float* d_bias;                /* accumulated [layers, dim]                                           */
+    float* dx;                    /* [B, dx_stride] gradient w.r.t. x_0                                  */
+    int64_t dx_stride;
+    void* workspace;              /* dctr_crossnet_bwd_workspace_bytes() bytes (matrix form), 16-B aligned */
+    size_t workspace_bytes;
+} dctr_crossnet_bwd_args_t;
+size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* args);
+int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* args, void* stream);
 
 /* Keras Adam step over n contiguous floats (a whole table or weight): g' = g + 2*l2*w;  m = b1 m + (1-b1) g';
  * v = b2 v + (1-b2) g'^2;  w -= alpha * m / (sqrt(v) + eps) with alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the caller.

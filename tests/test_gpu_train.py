@@ -265,3 +265,84 @@ def test_hip_training_gradients_with_sequence_features(device, fixture):
         scale = float(gref.abs().max()) + 1e-30
         assert_close(p.g.cpu().numpy() / scale, gref.cpu().numpy() / scale, rtol=2e-4, atol=2e-6,
                      what="grad of %s (scaled by %.3g)" % (tuple(p.w.shape), scale))
+
+
+@pytest.mark.parametrize("par,B,d,L", [("vector", 300, 429, 2), ("vector", 70, 45, 3), ("matrix", 130, 45, 2),
+                                       ("matrix", 300, 429, 2), ("vector", 5, 7, 0)])
+def test_crossnet_bwd_matches_autograd(device, par, B, d, L):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(21)
+    x = rng.standard_normal((B, d + 3)).astype(np.float32)
+    ks = (rng.standard_normal((L, d) if par == "vector" else (L, d, d)) / np.sqrt(d)).astype(np.float32)
+    bs = rng.standard_normal((L, d)).astype(np.float32) * 0.1
+    dy = rng.standard_normal((B, d + 1)).astype(np.float32)
+    xt = torch.tensor(x[:, :d].astype(np.float64), requires_grad=True)
+    kt = torch.tensor(ks.astype(np.float64), requires_grad=True)
+    bt = torch.tensor(bs.astype(np.float64), requires_grad=True)
+    xl = xt
+    for l in range(L):                                                   # interaction.py:412-420
+        if par == "vector":
+            xl = xt * (xl @ kt[l]).unsqueeze(1) + bt[l] + xl
+        else:
+            xl = xt * (xl @ kt[l].T + bt[l]) + xl
+    (xl * torch.tensor(dy[:, :d].astype(np.float64))).sum().backward()
+    dk = torch.zeros(ks.shape, device=device) if L else None
+    dbv = torch.zeros(bs.shape, device=device) if L else None
+    dx = torch.full((B, d + 2), 3.0, device=device)
+    ops.crossnet_bwd(dev(x, device), d, dev(ks, device) if L else None, dev(bs, device) if L else None, par, dev(dy, device),
+                     dk, dbv, dx, accumulate=True)
+    tag = "%s B=%d d=%d L=%d" % (par, B, d, L)
+    assert_close((dx[:, :d] - 3.0).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5, what="dx " + tag)
+    assert float((dx[:, d:] - 3.0).abs().max()) == 0.0
+    if L:
+        assert_close(dk.cpu().numpy(), kt.grad.numpy(), rtol=2e-4, atol=2e-5, what="dW " + tag)
+        assert_close(dbv.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-5, what="db " + tag)
+
+
+@pytest.mark.parametrize("par,cross_num,hidden", [("vector", 2, (32, 16)), ("matrix", 2, (32, 16)), ("vector", 3, ()),
+                                                  ("matrix", 0, (24,))])
+def test_dcn_hip_training_gradients_match_torch_autograd(device, par, cross_num, hidden):
+    """DCN on the HIP step: CrossNet backward (vector kernel / matrix via rocBLAS), the headless DNN backward and the
+    Dense(1) over the [cross, deep] stack, against torch autograd over the differentiable restatement."""
+    from deepctr_amd import training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DCN
+    from deepctr_amd.training_hip import HipTrainer, supported
+    from tests.test_gpu_models import _randomise
+    rng = np.random.RandomState(31)
+    cols = [SparseFeat("C%d" % i, 40 + 3 * i, 8, use_hash=(i == 1)) for i in range(5)] + [DenseFeat("I%d" % i, 1) for i in range(3)]
+    model = DCN(cols, cols, cross_num=cross_num, cross_parameterization=par, dnn_hidden_units=hidden, l2_reg_linear=0,
+                l2_reg_embedding=0, l2_reg_cross=0, device=device)
+    assert supported(model)
+    _randomise(model, rng)
+    n = 200
+    feed = _feed(rng, cols, n)
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    staged = model.stage(feed)
+    model._begin()
+    tr = HipTrainer(model)
+    yt = dev(y, device)
+    loss = tr.step(staged, 0, n, yt, apply=False)
+    params = [p.w for p in tr.params]
+    for t in params:
+        t.requires_grad_(True)
+    try:
+        if model.cross is not None:
+            tr.bind_cross_views()        # the per-layer views must descend from the grad-tracking packed tensors
+        model._begin()
+        logit = training.model_logits(model, staged, 0, n)
+        ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+        if model.cross is not None:
+            tr.bind_cross_views()
+    assert_close(loss.cpu().numpy(), [float(ref_loss.detach())], rtol=1e-4, atol=1e-6, what="loss")
+    for p, gref in zip(tr.params, grads):
+        gref = torch.zeros_like(p.w) if gref is None else gref
+        assert_close(p.g.cpu().numpy(), gref.cpu().numpy(), rtol=2e-4, atol=2e-7, what="grad of %s" % (tuple(p.w.shape),))
+    # and a few real steps: the loss goes down
+    model.compile("adam", "binary_crossentropy")
+    h = model.fit(feed, y, batch_size=64, epochs=6, verbose=0)
+    assert getattr(model, "_hip_trainer", None) is not None and h.history["loss"][-1] < h.history["loss"][0]
