@@ -101,6 +101,12 @@ class MlpBwdArgs(ctypes.Structure):
                 ("d_out", c_vp), ("d_out_stride", c_i64)]
 
 
+class CinBwdArgs(ctypes.Structure):
+    _fields_ = [("fwd", ctypes.POINTER(CinArgs)), ("d_out", c_vp), ("out_dim", c_i32), ("dx_accumulate", c_i32),
+                ("d_filters", c_vp), ("d_bias", c_vp), ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp),
+                ("workspace_bytes", c_sz)]
+
+
 class CrossBwdArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("x_stride", c_i64), ("batch", c_i64), ("dim", c_i32), ("layers", c_i32), ("mode", c_i32),
                 ("dx_accumulate", c_i32), ("kernels", c_vp), ("bias", c_vp), ("dy", c_vp), ("dy_stride", c_i64),
@@ -150,6 +156,8 @@ SYMBOLS = {
     "dctr_dense1_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dctr_crossnet_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CrossBwdArgs)]),
     "dctr_crossnet_bwd": (ctypes.c_int, [ctypes.POINTER(CrossBwdArgs), c_vp]),
+    "dctr_cin_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CinBwdArgs)]),
+    "dctr_cin_bwd": (ctypes.c_int, [ctypes.POINTER(CinBwdArgs), c_vp]),
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),

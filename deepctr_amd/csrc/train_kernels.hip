@@ -478,6 +478,101 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// CIN backward (interaction.py:277-325), first version: the reference's own formulation — z materialised per layer,
+// 1x1 conv = GEMM — in the (b,d)-major row layout R = B*D:  X0t [R,F0],  X_k = Y_{k-1}[:, :Hn] [R,F_k],
+//   z_k[r, i*F_k+j] = X0t[r,i] X_k[r,j];   Y_k = act(z_k W_k + b_k) [R,H_k];   out[b, .] = sum_d of the direct maps.
+// The GEMMs (forward recompute, dW = z^T dpre, dz = dpre W^T) are rocBLAS; the rest are the kernels below.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cin_to_rows_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F0,
+                                                          int D, float* __restrict__ xt) {
+    const int64_t total = batch * D * F0;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int i = (int)(o % F0);
+        const int64_t r = o / F0;
+        const int64_t b = r / D;
+        const int d = (int)(r - b * D);
+        xt[o] = x[b * x_stride + (int64_t)i * D + d];
+    }
+}
+
+__global__ __launch_bounds__(256) void cin_from_rows_kernel(const float* __restrict__ dxt, int64_t batch, int F0, int D,
+                                                            float* __restrict__ dx, int64_t dx_stride, int accumulate) {
+    const int64_t total = batch * F0 * D;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int d = (int)(o % D);
+        const int64_t t = o / D;
+        const int i = (int)(t % F0);
+        const int64_t b = t / F0;
+        float* dst = dx + b * dx_stride + (int64_t)i * D + d;
+        *dst = (accumulate ? *dst : 0.f) + dxt[(b * D + d) * F0 + i];
+    }
+}
+
+__global__ __launch_bounds__(256) void cin_outer_kernel(const float* __restrict__ x0t, int F0, const float* __restrict__ xk,
+                                                        int64_t ldk, int Fk, int64_t rows, float* __restrict__ z) {
+    const int K = F0 * Fk;
+    const int64_t total = rows * K;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t r = o / K;
+        const int c = (int)(o - r * K);
+        const int i = c / Fk, j = c - i * Fk;
+        z[o] = x0t[r * F0 + i] * xk[r * ldk + j];
+    }
+}
+
+// Y = act(Y + bias) in place
+__global__ __launch_bounds__(256) void cin_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t rows,
+                                                           int H, int act) {
+    const int64_t total = rows * H;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const float v = y[o] + bias[o % H];
+        y[o] = act == DCTR_ACT_RELU ? fmaxf(v, 0.f) : act == DCTR_ACT_SIGMOID ? 1.f / (1.f + expf(-v)) : act == DCTR_ACT_TANH ? tanhf(v) : v;
+    }
+}
+
+// dpre[r,h] = (hidden part: dxnext[r,h] for h < Hn) + (direct part: d_out[b, off + h - d0] for h >= d0), times act'(Y)
+__global__ __launch_bounds__(256) void cin_dpre_kernel(const float* __restrict__ y, const float* __restrict__ dxnext, int64_t ldn,
+                                                       int Hn, const float* __restrict__ d_out, int64_t out_dim, int off, int d0,
+                                                       int64_t rows, int H, int D, int act, float* __restrict__ dpre) {
+    const int64_t total = rows * H;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t r = o / H;
+        const int h = (int)(o - r * H);
+        float g = 0.f;
+        if (dxnext != nullptr && h < Hn) g += dxnext[r * ldn + h];
+        if (h >= d0) g += d_out[(r / D) * out_dim + off + (h - d0)];
+        const float v = y[o];
+        if (act == DCTR_ACT_RELU) g = v > 0.f ? g : 0.f;
+        else if (act == DCTR_ACT_SIGMOID) g *= v * (1.f - v);
+        else if (act == DCTR_ACT_TANH) g *= 1.f - v * v;
+        dpre[o] = g;
+    }
+}
+
+// from dz [R, F0*Fk]:  dX0t[r,i] += sum_j dz[r, i*Fk+j] Xk[r,j];   dXk[r,j] = sum_i dz[r, i*Fk+j] X0t[r,i]
+__global__ __launch_bounds__(256) void cin_outer_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x0t, int F0,
+                                                            const float* __restrict__ xk, int64_t ldk, int Fk, int64_t rows,
+                                                            float* __restrict__ dx0t, float* __restrict__ dxk) {
+    const int per = F0 + Fk;
+    const int64_t total = rows * per;
+    const int K = F0 * Fk;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t r = o / per;
+        const int c = (int)(o - r * per);
+        const float* dzr = dz + r * K;
+        float acc = 0.f;
+        if (c < F0) {
+            for (int j = 0; j < Fk; ++j) acc = fmaf(dzr[c * Fk + j], xk[r * ldk + j], acc);
+            dx0t[r * F0 + c] += acc;
+        } else if (dxk != nullptr) {
+            const int j = c - F0;
+            for (int i = 0; i < F0; ++i) acc = fmaf(dzr[i * Fk + j], x0t[r * F0 + i], acc);
+            dxk[r * Fk + j] = acc;
+        }
+    }
+}
+
 rocblas_handle blas_handle() {
     static thread_local rocblas_handle h = nullptr;
     if (h == nullptr) {
@@ -783,4 +878,129 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, dx0, (int64_t)d, a->batch, d, a->dx, a->dx_stride,
                        (int)a->dx_accumulate);
     return dctr_launch_status("dctr_crossnet_bwd");
+}
+
+namespace {
+struct CinPlan {
+    int L, F0, D;
+    int H[8], Fk[8], Hn[8], d0[8], off[8];
+    int64_t R;
+    size_t x0t, y[8], z[8], dpre, dz, dx0t, dxk[2], total;
+};
+bool cin_plan(const dctr_cin_args_t* f, CinPlan& p) {
+    p.L = f->n_layers;
+    p.F0 = f->fields;
+    p.D = f->dim;
+    p.R = f->batch * (int64_t)f->dim;
+    if (p.L < 1 || p.L > 8) return false;
+    int fk = p.F0, off = 0;
+    size_t cur = 0;
+    auto take = [&](size_t n) { size_t o = cur; cur += (n + 3) & ~(size_t)3; return o; };
+    p.x0t = take((size_t)p.R * p.F0);
+    size_t zmax = 0, hmax = 0, fkmax = 0;
+    for (int k = 0; k < p.L; ++k) {
+        const int H = f->layer_size[k];
+        const bool last = k == p.L - 1;
+        p.H[k] = H;
+        p.Fk[k] = fk;
+        p.Hn[k] = last ? 0 : (f->split_half ? H / 2 : H);
+        p.d0[k] = f->split_half ? (last ? 0 : H / 2) : 0;
+        p.off[k] = off;
+        off += H - p.d0[k];
+        p.y[k] = take((size_t)p.R * H);
+        p.z[k] = take((size_t)p.R * p.F0 * fk);
+        zmax = (size_t)p.R * p.F0 * fk > zmax ? (size_t)p.R * p.F0 * fk : zmax;
+        hmax = (size_t)H > hmax ? H : hmax;
+        fkmax = (size_t)fk > fkmax ? fk : fkmax;
+        fk = p.Hn[k];
+    }
+    p.dpre = take((size_t)p.R * hmax);
+    p.dz = take(zmax);
+    p.dx0t = take((size_t)p.R * p.F0);
+    p.dxk[0] = take((size_t)p.R * fkmax);
+    p.dxk[1] = take((size_t)p.R * fkmax);
+    p.total = cur;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t dctr_cin_bwd_workspace_bytes(const dctr_cin_bwd_args_t* a) {
+    CinPlan p;
+    if (a == nullptr || a->fwd == nullptr || a->fwd->batch <= 0 || !cin_plan(a->fwd, p)) return 0;
+    return p.total * sizeof(float);
+}
+
+extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr && a->fwd != nullptr, DCTR_E_NULL, "cin_bwd: null args");
+    const dctr_cin_args_t* f = a->fwd;
+    DCTR_REQUIRE(f->batch >= 0 && f->fields >= 1 && f->dim >= 1, DCTR_E_DIM, "cin_bwd: bad sizes");
+    if (f->batch == 0) return DCTR_OK;
+    CinPlan p;
+    DCTR_REQUIRE(cin_plan(f, p), DCTR_E_DIM, "cin_bwd: 1..8 layers");
+    DCTR_REQUIRE(f->x && f->layer_size && f->filters && f->bias && a->d_out && a->d_filters && a->d_bias, DCTR_E_NULL,
+                 "cin_bwd: null pointer");
+    DCTR_REQUIRE(f->activation >= DCTR_ACT_LINEAR && f->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "cin_bwd: activation %d",
+                 f->activation);
+    DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= p.total * sizeof(float), DCTR_E_NULL,
+                 "cin_bwd: needs a workspace of dctr_cin_bwd_workspace_bytes() bytes");
+    DCTR_REQUIRE(p.R < 0x7fffffffLL, DCTR_E_DIM, "cin_bwd: batch * dim too large");
+    rocblas_handle h = blas_handle();
+    hipStream_t st = (hipStream_t)stream;
+    DCTR_REQUIRE(h != nullptr && rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED,
+                 "cin_bwd: rocBLAS handle / stream failed");
+    float* ws = static_cast<float*>(a->workspace);
+    const int R = (int)p.R, F0 = p.F0, D = p.D;
+    auto grid = [](int64_t n) { int64_t b = dctr_ceil_div(n, (int64_t)256); return dim3((unsigned)(b > 8192 ? 8192 : b)); };
+    const float one = 1.f, zero = 0.f;
+    float* x0t = ws + p.x0t;
+    hipLaunchKernelGGL(cin_to_rows_kernel, grid(p.R * F0), dim3(256), 0, st, f->x, f->x_stride, f->batch, F0, D, x0t);
+    // forward recompute
+    for (int k = 0; k < p.L; ++k) {
+        const int Fk = p.Fk[k], H = p.H[k], K = F0 * Fk;
+        const float* xk = k == 0 ? x0t : ws + p.y[k - 1];
+        const int64_t ldk = k == 0 ? F0 : p.H[k - 1];
+        float* z = ws + p.z[k];
+        float* y = ws + p.y[k];
+        hipLaunchKernelGGL(cin_outer_kernel, grid(p.R * K), dim3(256), 0, st, x0t, F0, xk, ldk, Fk, p.R, z);
+        // Y[R,H] = z[R,K] W[K,H]:  column-major  Y'(H x R) = W'(H x K) z'(K x R)
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, H, R, K, &one, f->filters[k], H, z, K,
+                                          &zero, y, H);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(y) failed (%d)", (int)rs);
+        hipLaunchKernelGGL(cin_bias_act_kernel, grid(p.R * H), dim3(256), 0, st, y, f->bias[k], p.R, H, (int)f->activation);
+    }
+    hipError_t me = hipMemsetAsync(ws + p.dx0t, 0, (size_t)p.R * F0 * sizeof(float), st);
+    DCTR_REQUIRE(me == hipSuccess, (int)me, "cin_bwd: memset failed: %s", hipGetErrorString(me));
+    const float* dxnext = nullptr;
+    int64_t ldn = 0;
+    for (int k = p.L - 1; k >= 0; --k) {
+        const int Fk = p.Fk[k], H = p.H[k], K = F0 * Fk;
+        const float* xk = k == 0 ? x0t : ws + p.y[k - 1];
+        const int64_t ldk = k == 0 ? F0 : p.H[k - 1];
+        float* dpre = ws + p.dpre;
+        float* dz = ws + p.dz;
+        hipLaunchKernelGGL(cin_dpre_kernel, grid(p.R * H), dim3(256), 0, st, ws + p.y[k], dxnext, ldn, p.Hn[k], a->d_out,
+                           (int64_t)a->out_dim, p.off[k], p.d0[k], p.R, H, D, (int)f->activation, dpre);
+        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)dctr_ceil_div(p.R, (int64_t)BWD_ROWS)), dim3(256), 0, st, dpre,
+                           (const float*)nullptr, p.R, H, 0, a->d_bias[k]);
+        // dW[K,H] += z^T dpre:  column-major  dW'(H x K) = dpre'(H x R) z'(K x R)^T
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, H, K, R, &one, dpre, H, ws + p.z[k],
+                                          K, &one, a->d_filters[k], H);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        // dz[R,K] = dpre[R,H] W^T:  column-major  dz'(K x R) = W'(H x K)^T dpre'(H x R)
+        rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, R, H, &one, f->filters[k], H, dpre, H, &zero, dz, K);
+        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dz) failed (%d)", (int)rs);
+        float* dxk = ws + p.dxk[k & 1];          // layer 0: x_0 is also its x_k; that second-factor gradient lands in dxk[0]
+        hipLaunchKernelGGL(cin_outer_bwd_kernel, grid(p.R * (F0 + Fk)), dim3(256), 0, st, dz, x0t, F0, xk, ldk, Fk, p.R, ws + p.dx0t,
+                           dxk);
+        dxnext = dxk;
+        ldn = Fk;
+    }
+    if (a->dx != nullptr) {
+        // d x0 = dX0t (first factor, all layers) + layer 0's second factor (in dxk[0], [R, F0])
+        hipLaunchKernelGGL(add_rows_kernel, grid(p.R * F0), dim3(256), 0, st, ws + p.dxk[0], (int64_t)F0, p.R, F0, ws + p.dx0t,
+                           (int64_t)F0, 1);
+        hipLaunchKernelGGL(cin_from_rows_kernel, grid(p.R * F0), dim3(256), 0, st, ws + p.dx0t, f->batch, F0, D, a->dx, a->dx_stride,
+                           (int)a->dx_accumulate);
+    }
+    return dctr_launch_status("dctr_cin_bwd");
 }

@@ -62,5 +62,8 @@ def xDeepFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 
             cin_split_half=True, cin_activation='relu', l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_dnn=0,
             l2_reg_cin=0, seed=1024, dnn_dropout=0, dnn_activation='relu', dnn_use_bn=False, task='binary', device=None):
     """Instantiates the xDeepFM architecture on the MI355X forward path."""
-    return _xDeepFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units, cin_layer_size, cin_split_half,
-                    cin_activation, seed, dnn_dropout, dnn_activation, dnn_use_bn, task, device)
+    m = _xDeepFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units, cin_layer_size, cin_split_half,
+                 cin_activation, seed, dnn_dropout, dnn_activation, dnn_use_bn, task, device)
+    m.regularizers = {"embedding": float(l2_reg_embedding), "linear": float(l2_reg_linear), "dnn": float(l2_reg_dnn),
+                      "cin": float(l2_reg_cin)}
+    return m

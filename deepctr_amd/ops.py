@@ -583,3 +583,34 @@ def crossnet_bwd(x, d, kernels, bias, parameterization, dy, d_kernels, d_bias, d
     ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _C.check(_C.lib().dctr_crossnet_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_bwd")
+
+
+def cin_bwd(x, filters, biases, layer_size, split_half, activation, d_out, d_filters, d_biases, dx=None, accumulate=False,
+            fields=None, dim=None):
+    """Backward of dctr_cin_fwd: x as in ``cin`` (3-D, or the leading F0*D columns of a 2-D buffer with fields/dim);
+    d_out [B, featuremap_num]; d_filters / d_biases are ACCUMULATED; dx (2-D, same layout as x) written or added to."""
+    _dev_check(x, d_out, *filters)
+    if fields is None:
+        x = _f32c(x, "x")
+        B, F0, D = x.shape
+        x_stride = F0 * D
+    else:
+        B, F0, D, x_stride = x.shape[0], fields, dim, x.stride(0)
+    n = len(layer_size)
+    filters = [_f32c(f, "filter").reshape(-1, h) for f, h in zip(filters, layer_size)]
+    biases = [_f32c(b, "bias") for b in biases]
+    ls = _i32_array(layer_size)
+    fp, bp = _ptr_array(filters), _ptr_array(biases)
+    dfp, dbp = _ptr_array(list(d_filters)), _ptr_array(list(d_biases))
+    fwd = _C.CinArgs(x=x.data_ptr(), batch=B, x_stride=x_stride, fields=F0, dim=D, n_layers=n, split_half=int(bool(split_half)),
+                     activation=_C.ACT_CODES[activation], layer_size=ctypes.cast(ls, ctypes.c_void_p),
+                     filters=ctypes.cast(fp, ctypes.c_void_p), bias=ctypes.cast(bp, ctypes.c_void_p), out=None,
+                     workspace=None, workspace_bytes=0)
+    d_out = _f32c(d_out, "d_out")
+    a = _C.CinBwdArgs(fwd=ctypes.pointer(fwd), d_out=d_out.data_ptr(), out_dim=d_out.shape[1], dx_accumulate=int(bool(accumulate)),
+                      d_filters=ctypes.cast(dfp, ctypes.c_void_p), d_bias=ctypes.cast(dbp, ctypes.c_void_p),
+                      dx=None if dx is None else dx.data_ptr(), dx_stride=0 if dx is None else dx.stride(0))
+    need = int(_C.lib().dctr_cin_bwd_workspace_bytes(ctypes.byref(a)))
+    ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _C.check(_C.lib().dctr_cin_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_bwd")

@@ -25,11 +25,13 @@ def supported(model):
     sp = getattr(model, "stage_plan", None)
     dnn = getattr(model, "dnn", None)
     kind = type(model).__name__
-    if sp is None or kind not in ("_DeepFM", "_DCN"):
+    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM"):
         return False
     if sp.lin_only or len(sp.fm_group_names) > 1 or sp.extra_offsets or not sp.all_dim4 or sp.max_dim > 64:
         return False
-    if kind == "_DeepFM" and (dnn is None or not dnn.kernels):
+    if kind in ("_DeepFM", "_xDeepFM") and (dnn is None or not dnn.kernels):
+        return False
+    if kind == "_xDeepFM" and model.cin is not None and model.cin.activation not in ("relu", "linear", "sigmoid", "tanh"):
         return False
     if dnn is not None:
         if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
@@ -102,6 +104,12 @@ class HipTrainer(object):
         self.p_kernels = [param(k, l2d) for k in model.dnn.kernels] if model.dnn is not None else []
         self.p_biases = [param(b) for b in model.dnn.biases] if model.dnn is not None else []
         self.p_head = param(model.dense.w("kernel"))
+        self.is_xdeepfm = type(model).__name__ == "_xDeepFM"
+        self.p_cin_f = self.p_cin_b = self.p_head1 = None
+        if self.is_xdeepfm and model.cin is not None:
+            self.p_cin_f = [param(f, reg.get("cin", 0.0)) for f in model.cin.filters]
+            self.p_cin_b = [param(b) for b in model.cin.biases]
+            self.p_head1 = param(model.dense_1.w("kernel"))
         self.p_cross_k = self.p_cross_b = None
         if self.is_dcn and model.cross is not None:
             # CrossNet's per-layer kernels / biases become views of one packed tensor each (the layout the C ABI takes),
@@ -125,6 +133,9 @@ class HipTrainer(object):
             units = [k.shape[1] for k in self.model.dnn.kernels] if self.model.dnn is not None else []
             b = self._buf[B] = {
                 "dstack": torch.empty(B, (self.model.width + 3) // 4 * 4, dtype=torch.float32, device=dev) if self.is_dcn else None,
+                "maps": torch.empty(B, self.model.cin_out_dim, dtype=torch.float32, device=dev) if self.p_cin_f else None,
+                "dmaps": torch.empty(B, self.model.cin_out_dim, dtype=torch.float32, device=dev) if self.p_cin_f else None,
+                "cin_logit": torch.empty(B, dtype=torch.float32, device=dev) if self.p_cin_f else None,
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
                 "pred": torch.empty(B, dtype=torch.float32, device=dev),
                 "dlogit": torch.empty(B, dtype=torch.float32, device=dev),
@@ -164,12 +175,25 @@ class HipTrainer(object):
             add.append(ws["lin"])
         if sp.fm_group_names:
             add.append(ws["fm"])
+        cin = model.cin if self.p_cin_f else None
+        if cin is not None:             # xDeepFM (models/xdeepfm.py:52-66): CIN over the embeddings -> Dense(1) -> extra logit
+            nf, dim = len(sp.fields), model.cin_dim
+            filt = [f.reshape(-1, f.shape[-1]) for f in cin.filters]
+            ops.cin(ws["dnn_in"], filt, cin.biases, list(cin.layer_size), cin.split_half, cin.activation, fields=nf, dim=dim,
+                    out=buf["maps"])
+            ops.mlp(buf["maps"], [], [], "linear", head_w=self.p_head1.w, in_dim=model.cin_out_dim, out=buf["cin_logit"])
+            add.append(buf["cin_logit"])
         ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w, add=add,
                 global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
                 out=buf["pred"], save_acts=buf["acts"])
         self._loss_grad(buf, y, binary)
         ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
                     [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=buf["dx"])
+        if cin is not None:
+            ops.dense1_bwd(buf["maps"], model.cin_out_dim, self.p_head1.w, buf["dlogit"], buf["dmaps"], self.p_head1.g)
+            ops.cin_bwd(ws["dnn_in"], filt, cin.biases, list(cin.layer_size), cin.split_half, cin.activation, buf["dmaps"],
+                        [p.g.reshape(-1, p.g.shape[-1]) for p in self.p_cin_f], [p.g for p in self.p_cin_b], dx=buf["dx"],
+                        accumulate=True, fields=nf, dim=dim)
 
     def _dcn_forward_backward(self, ws, buf, y, B, binary):
         """DCN (models/dcn.py:45-78): [CrossNet(dnn_in), DNN(dnn_in)] -> Dense(1) + linear logit -> PredictionLayer."""

@@ -421,6 +421,23 @@ typedef struct {
 size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* args);
 int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* args, void* stream);
 
+/* backward of dctr_cin_fwd (interaction.py:277-325), first version: z materialised per layer in the workspace, the
+ * three GEMMs per layer (forward recompute, dW = z^T dpre, dz = dpre W^T) are rocBLAS sgemm. */
+typedef struct {
+    const dctr_cin_args_t* fwd;   /* the forward call's arguments (out / workspace unused)                */
+    const float* d_out;           /* [B, out_dim] gradient w.r.t. the CIN output                          */
+    int32_t out_dim;              /* featuremap_num                                                       */
+    int32_t dx_accumulate;
+    float* const* d_filters;      /* HOST array of DEVICE pointers, accumulated, shapes of fwd->filters   */
+    float* const* d_bias;         /* HOST array of DEVICE pointers, accumulated                           */
+    float* dx;                    /* [B, dx_stride] gradient w.r.t. x (first F0*D columns), or NULL       */
+    int64_t dx_stride;
+    void* workspace;              /* dctr_cin_bwd_workspace_bytes() bytes, 16-B aligned                   */
+    size_t workspace_bytes;
+} dctr_cin_bwd_args_t;
+size_t dctr_cin_bwd_workspace_bytes(const dctr_cin_bwd_args_t* args);
+int dctr_cin_bwd(const dctr_cin_bwd_args_t* args, void* stream);
+
 /* Keras Adam step over n contiguous floats (a whole table or weight): g' = g + 2*l2*w;  m = b1 m + (1-b1) g';
  * v = b2 v + (1-b2) g'^2;  w -= alpha * m / (sqrt(v) + eps) with alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the caller.
  * Non-lazy like tf.keras' sparse apply: rows without a gradient still decay.  zero_grad clears g. */

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepctr_amd.feature_column import DenseFeat, SparseFeat  # noqa: E402
-from deepctr_amd.models import DeepFM  # noqa: E402
+from deepctr_amd import models  # noqa: E402
 from deepctr_amd.training_hip import HipTrainer  # noqa: E402
 
 
@@ -19,11 +19,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batches", default="4096,16384")
+    ap.add_argument("--model", default="DeepFM", help="DeepFM | WDL | FNN | DCN | DCNM (matrix) | xDeepFM")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rng = np.random.RandomState(0)
     cols = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
-    model = DeepFM(cols, cols, device=dev)
+    kw = {"DCNM": dict(cross_parameterization="matrix")}.get(args.model, {})
+    model = getattr(models, {"DCNM": "DCN"}.get(args.model, args.model))(cols, cols, device=dev, **kw)
     tr = HipTrainer(model)
     n_param = sum(p.w.numel() for p in tr.params)
     for B in [int(b) for b in args.batches.split(",")]:
@@ -44,7 +46,7 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         model._check_status()
         # Adam traffic: w, m, v, g read + w, m, v, g written per parameter element
-        print("C2 DeepFM train step  B=%-6d %8.1f us/step  %8.2f M samples/s   (%.1f M parameters: Adam moves %.2f GB/step = %.0f us at 8 TB/s; loss %.4f)"
+        print("C2 " + args.model + " train step  B=%-6d %8.1f us/step  %8.2f M samples/s   (%.1f M parameters: Adam moves %.2f GB/step = %.0f us at 8 TB/s; loss %.4f)"
               % (B, dt * 1e6, B / dt / 1e6, n_param / 1e6, n_param * 32 / 1e9, n_param * 32 / 8e12 * 1e6, float(loss)), flush=True)
 
 

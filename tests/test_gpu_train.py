@@ -346,3 +346,90 @@ def test_dcn_hip_training_gradients_match_torch_autograd(device, par, cross_num,
     model.compile("adam", "binary_crossentropy")
     h = model.fit(feed, y, batch_size=64, epochs=6, verbose=0)
     assert getattr(model, "_hip_trainer", None) is not None and h.history["loss"][-1] < h.history["loss"][0]
+
+
+@pytest.mark.parametrize("B,F0,D,ls,split,act", [(37, 7, 8, (12, 10), True, "relu"), (9, 5, 4, (8, 6, 5), False, "linear"),
+                                                 (64, 26, 16, (32, 16), True, "relu"), (20, 6, 6, (8,), True, "sigmoid")])
+def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act):
+    from deepctr_amd import ops
+    rng = np.random.RandomState(41)
+    x = (rng.standard_normal((B, F0 * D + 5)) * 0.5).astype(np.float32)           # CIN reads the leading F0*D columns
+    fk, fs = F0, []
+    for k, h in enumerate(ls):
+        fs.append((rng.standard_normal((F0 * fk, h)) / np.sqrt(F0 * fk)).astype(np.float32))
+        fk = h // 2 if (split and k != len(ls) - 1) else h
+    bs = [rng.standard_normal(h).astype(np.float32) * 0.1 for h in ls]
+    out_dim = ops.cin_output_dim(list(ls), split)
+    d_out = rng.standard_normal((B, out_dim)).astype(np.float32)
+    # checker: the reference formulation in torch float64 (interaction.py:277-325)
+    xt = torch.tensor(x[:, :F0 * D].astype(np.float64), requires_grad=True)
+    ft = [torch.tensor(f.astype(np.float64), requires_grad=True) for f in fs]
+    bt = [torch.tensor(b.astype(np.float64), requires_grad=True) for b in bs]
+    x0 = xt.reshape(B, F0, D)
+    hidden, finals = x0, []
+    f_act = {"relu": torch.relu, "linear": lambda z: z, "sigmoid": torch.sigmoid}[act]
+    for k, h in enumerate(ls):
+        z = torch.einsum("bid,bjd->bdij", x0, hidden).reshape(B, D, -1)
+        y = f_act(z @ ft[k] + bt[k]).transpose(1, 2)                               # [B, H, D]
+        if split and k != len(ls) - 1:
+            hidden, direct = y[:, :h // 2], y[:, h // 2:]
+        else:
+            hidden, direct = y, y
+        finals.append(direct)
+    res = torch.cat(finals, dim=1).sum(-1)
+    (res * torch.tensor(d_out.astype(np.float64))).sum().backward()
+    xd = dev(x, device)
+    dfs = [torch.zeros(f.shape, device=device) for f in fs]
+    dbs = [torch.zeros(b.shape, device=device) for b in bs]
+    dx = torch.full((B, F0 * D + 2), 2.0, device=device)
+    ops.cin_bwd(xd, [dev(f, device) for f in fs], [dev(b, device) for b in bs], list(ls), split, act, dev(d_out, device), dfs, dbs,
+                dx=dx, accumulate=True, fields=F0, dim=D)
+    tag = "B=%d F0=%d D=%d %s split=%s %s" % (B, F0, D, ls, split, act)
+    assert_close((dx[:, :F0 * D] - 2.0).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5, what="dx " + tag)
+    assert float((dx[:, F0 * D:] - 2.0).abs().max()) == 0.0
+    for k in range(len(ls)):
+        assert_close(dfs[k].cpu().numpy(), ft[k].grad.numpy(), rtol=2e-4, atol=2e-5, what="dW%d %s" % (k, tag))
+        assert_close(dbs[k].cpu().numpy(), bt[k].grad.numpy(), rtol=2e-4, atol=2e-5, what="db%d %s" % (k, tag))
+
+
+@pytest.mark.parametrize("split,cin_act", [(True, "relu"), (False, "linear")])
+def test_xdeepfm_hip_training_gradients_match_torch_autograd(device, split, cin_act):
+    """xDeepFM on the HIP step: CIN backward + its Dense(1), the DNN and the embedding / linear backward against torch
+    autograd over the differentiable restatement; then a short fit."""
+    from deepctr_amd import training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import xDeepFM
+    from deepctr_amd.training_hip import HipTrainer, supported
+    from tests.test_gpu_models import _randomise
+    rng = np.random.RandomState(51)
+    cols = [SparseFeat("C%d" % i, 30 + 3 * i, 8, use_hash=(i == 2)) for i in range(6)] + [DenseFeat("I%d" % i, 1) for i in range(2)]
+    model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(12, 10), cin_split_half=split, cin_activation=cin_act,
+                    l2_reg_linear=0, l2_reg_embedding=0, device=device)
+    assert supported(model)
+    _randomise(model, rng)
+    n = 150
+    feed = _feed(rng, cols, n)
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    staged = model.stage(feed)
+    model._begin()
+    tr = HipTrainer(model)
+    yt = dev(y, device)
+    loss = tr.step(staged, 0, n, yt, apply=False)
+    params = [p.w for p in tr.params]
+    for t in params:
+        t.requires_grad_(True)
+    try:
+        model._begin()
+        logit = training.model_logits(model, staged, 0, n)
+        ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+    assert_close(loss.cpu().numpy(), [float(ref_loss.detach())], rtol=1e-4, atol=1e-6, what="loss")
+    for p, gref in zip(tr.params, grads):
+        gref = torch.zeros_like(p.w) if gref is None else gref
+        assert_close(p.g.cpu().numpy(), gref.cpu().numpy(), rtol=2e-4, atol=2e-7, what="grad of %s" % (tuple(p.w.shape),))
+    model.compile("adam", "binary_crossentropy")
+    h = model.fit(feed, y, batch_size=50, epochs=6, verbose=0)
+    assert getattr(model, "_hip_trainer", None) is not None and h.history["loss"][-1] < h.history["loss"][0]
