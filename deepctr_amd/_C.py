@@ -76,7 +76,7 @@ class MlpArgs(ctypes.Structure):
                 ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
                 ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
                 ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
-                ("save_acts", c_vp), ("tile_rows", c_i32), ("reserved_", c_i32)]
+                ("save_acts", c_vp), ("tile_rows", c_i32), ("reserved_", c_i32), ("probe", c_vp)]
 
 
 class FieldGrad(ctypes.Structure):
@@ -133,6 +133,9 @@ SYMBOLS = {
     "dctr_target_arch": (ctypes.c_char_p, []),
     "dctr_profile_next_launch": (ctypes.c_int, []),
     "dctr_profile_last_ms": (ctypes.c_float, []),
+    "dctr_wall_clock_khz": (ctypes.c_int, []),
+    "dctr_profile_arm": (ctypes.c_int, [c_i32]),
+    "dctr_profile_collect": (ctypes.c_int, [c_vp, c_i32]),
     "dctr_hash_bucket_i32": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_hash_bucket_i64": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_hash_bucket_bytes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),

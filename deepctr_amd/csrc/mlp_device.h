@@ -45,6 +45,7 @@ struct MlpParams {
     float* y;
     int64_t y_stride;
     float* save[MAX_LAYERS];  // training: layer l's activations [B, units[l]] also go to HBM (NULL = inference)
+    unsigned long long* probe;  // measurement aid (NULL normally): {min start, max end} wall-clock stamps of this launch
     int32_t lda;      // LDS row stride (floats) = pad64(max tile width) + 4
     int32_t k_split;  // 0, or the column (multiple of 64) at which the layer-0 input tile is built in two halves
 };
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
     const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LAB_TS(0);
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
 
     float* in = buf0;
     float* out = buf1;
@@ -709,6 +711,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         }
     }
     LAB_TS(10);
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
 }
 
 

@@ -74,6 +74,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         }
     }
     for (int l = 0; l < a->n_layers; ++l) p.save[l] = a->save_acts != nullptr ? a->save_acts[l] : nullptr;
+    p.probe = a->probe;
     p.dice_eps = a->dice_eps;
     p.activation = a->activation;
     p.has_head = a->has_head;

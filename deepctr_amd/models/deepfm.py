@@ -39,6 +39,7 @@ class _DeepFM(FeatureModel):
         passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
         self.fused = bool(sp.fusable and 8 * passes * 6 * 64 <= 16 * lda)
         self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64), same bits
+        self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
 
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
@@ -51,7 +52,7 @@ class _DeepFM(FeatureModel):
                     head_w=self.dense.w('kernel'), add=[ws["lin2"]] if "lin2" in ws else [],
                     global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
                     out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
-                    tile_rows=self.tile_rows)
+                    tile_rows=self.tile_rows, probe=self.probe)
             return
         ws = self.stage_plan.run(staged, lo, hi)
         add = self._logits_to_add(ws)

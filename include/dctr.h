@@ -51,6 +51,12 @@ const char* dctr_target_arch(void);
  * that one dispatch as the GPU timestamps it (same quantity as rocprofv3 --kernel-trace), or -1 if none. */
 int dctr_profile_next_launch(void);
 float dctr_profile_last_ms(void);
+/* The same for the next n (<= 256) launches of this host thread — launches that are in flight together on several
+ * streams take longer than an isolated one, and that is what rocprofv3 reports for the timed region.
+ * dctr_profile_collect waits for them, writes their durations [ms] and returns how many were timed. */
+int dctr_wall_clock_khz(void);   /* rate of the device wall clock used by dctr_mlp_args_t.probe */
+int dctr_profile_arm(int32_t n);
+int dctr_profile_collect(float* ms, int32_t n);
 
 /* ------------------------------------------------------------------------------------------------
  * a2  Hash.call — deepctr/layers/utils.py:89-112
@@ -268,6 +274,11 @@ typedef struct {
                                      weight fragment for more rows (less L2->CU weight traffic per row, the bound of
                                      this kernel) at the price of fewer workgroups; results are bit-identical. */
     int32_t reserved_;
+    unsigned long long* probe;    /* measurement aid, normally NULL: DEVICE uint64[2]; every workgroup does
+                                     atomicMin(probe[0], t_start) / atomicMax(probe[1], t_end) with the constant-rate
+                                     wall clock (dctr_wall_clock_khz()), so probe[1] - probe[0] is this launch's duration
+                                     even inside a hipGraph, where event pairs cannot be attached.  Caller initialises
+                                     to {UINT64_MAX, 0}. */
 } dctr_mlp_args_t;
 size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
 int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
