@@ -551,25 +551,45 @@ __global__ __launch_bounds__(256) void cin_dpre_kernel(const float* __restrict__
 }
 
 // from dz [R, F0*Fk]:  dX0t[r,i] += sum_j dz[r, i*Fk+j] Xk[r,j];   dXk[r,j] = sum_i dz[r, i*Fk+j] X0t[r,i]
+// One wave per row: the row of dz (F0*Fk floats) is staged once in LDS (coalesced) and both sums read it from there,
+// so dz crosses HBM once (two independent thread-per-output passes read it twice: 860 us per step at C3).
 __global__ __launch_bounds__(256) void cin_outer_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x0t, int F0,
                                                             const float* __restrict__ xk, int64_t ldk, int Fk, int64_t rows,
                                                             float* __restrict__ dx0t, float* __restrict__ dxk) {
-    const int per = F0 + Fk;
-    const int64_t total = rows * per;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int K = F0 * Fk;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
-        const int64_t r = o / per;
-        const int c = (int)(o - r * per);
+    float* zr = smem + (size_t)wave * (K + F0 + Fk);        // [K] dz row, [F0] x0t row, [Fk] xk row
+    float* x0r = zr + K;
+    float* xkr = x0r + F0;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
         const float* dzr = dz + r * K;
-        float acc = 0.f;
-        if (c < F0) {
-            for (int j = 0; j < Fk; ++j) acc = fmaf(dzr[c * Fk + j], xk[r * ldk + j], acc);
-            dx0t[r * F0 + c] += acc;
-        } else if (dxk != nullptr) {
-            const int j = c - F0;
-            for (int i = 0; i < F0; ++i) acc = fmaf(dzr[i * Fk + j], x0t[r * F0 + i], acc);
-            dxk[r * Fk + j] = acc;
+        for (int c = lane; c < K; c += 64) zr[c] = dzr[c];
+        for (int i = lane; i < F0; i += 64) x0r[i] = x0t[r * F0 + i];
+        for (int j = lane; j < Fk; j += 64) xkr[j] = xk[r * ldk + j];
+        // (same wave: LDS operations complete in order)
+        for (int i = lane; i < F0; i += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Fk; ++j) acc = fmaf(zr[i * Fk + j], xkr[j], acc);
+            dx0t[r * F0 + i] += acc;
         }
+        if (dxk != nullptr) {
+            for (int j = lane; j < Fk; j += 64) {
+                float acc = 0.f;
+                for (int i = 0; i < F0; ++i) acc = fmaf(zr[i * Fk + j], x0r[i], acc);
+                dxk[r * Fk + j] = acc;
+            }
+        }
+    }
+}
+
+// out[i] += sum_s parts[s * n + i]
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, int64_t n, int n_parts,
+                                                        float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < n_parts; ++s) acc += parts[(int64_t)s * n + i];
+        out[i] += acc;
     }
 }
 
@@ -982,16 +1002,38 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
                            (int64_t)a->out_dim, p.off[k], p.d0[k], p.R, H, D, (int)f->activation, dpre);
         hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)dctr_ceil_div(p.R, (int64_t)BWD_ROWS)), dim3(256), 0, st, dpre,
                            (const float*)nullptr, p.R, H, 0, a->d_bias[k]);
-        // dW[K,H] += z^T dpre:  column-major  dW'(H x K) = dpre'(H x R) z'(K x R)^T
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, H, K, R, &one, dpre, H, ws + p.z[k],
-                                          K, &one, a->d_filters[k], H);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        // dW[K,H] += z^T dpre:  column-major  dW'(H x K) = dpre'(H x R) z'(K x R)^T.  The output is small (H x K) and the
+        // reduction long (R = B*D): as ONE gemm it runs on ~18 workgroups (1.8 ms at C3); split the rows into `parts`
+        // slices computed as a strided batch of partial products in the (now free) dz buffer, then summed.
+        const int64_t hk = (int64_t)H * K;
+        int parts = (int)((size_t)p.R * K / (size_t)hk);                 // partials fit the dz buffer: parts*H*K <= R*K
+        if (parts > 32) parts = 32;
+        while (parts > 1 && R % parts != 0) --parts;
+        rocblas_status rs;
+        if (parts > 1) {
+            const int rs_ = R / parts;
+            rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, H, K, rs_, &one, dpre, H,
+                                               (rocblas_stride)rs_ * H, ws + p.z[k], K, (rocblas_stride)rs_ * K, &zero, dz, H,
+                                               (rocblas_stride)hk, parts);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            hipLaunchKernelGGL(sum_parts_kernel, grid(hk), dim3(256), 0, st, dz, hk, parts, a->d_filters[k]);
+        } else {
+            rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, H, K, R, &one, dpre, H, ws + p.z[k], K, &one,
+                               a->d_filters[k], H);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        }
         // dz[R,K] = dpre[R,H] W^T:  column-major  dz'(K x R) = W'(H x K)^T dpre'(H x R)
         rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, R, H, &one, f->filters[k], H, dpre, H, &zero, dz, K);
         DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dz) failed (%d)", (int)rs);
         float* dxk = ws + p.dxk[k & 1];          // layer 0: x_0 is also its x_k; that second-factor gradient lands in dxk[0]
-        hipLaunchKernelGGL(cin_outer_bwd_kernel, grid(p.R * (F0 + Fk)), dim3(256), 0, st, dz, x0t, F0, xk, ldk, Fk, p.R, ws + p.dx0t,
-                           dxk);
+        {
+            const size_t lds = (size_t)4 * (K + F0 + Fk) * sizeof(float);
+            DCTR_REQUIRE(lds <= 64 * 1024, DCTR_E_UNSUPPORTED, "cin_bwd: F0*Fk = %d too large for the row-staging kernel", K);
+            int64_t nb = dctr_ceil_div(p.R, (int64_t)4);
+            if (nb > 256 * 16) nb = 256 * 16;
+            hipLaunchKernelGGL(cin_outer_bwd_kernel, dim3((unsigned)nb), dim3(256), lds, st, dz, x0t, F0, xk, ldk, Fk, p.R,
+                               ws + p.dx0t, dxk);
+        }
         dxnext = dxk;
         ldn = Fk;
     }
