@@ -142,6 +142,7 @@ SYMBOLS = {
     "dctr_embed_gather_fm": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), c_vp]),
     "dctr_embed_pool": (ctypes.c_int, [ctypes.POINTER(PoolArgs), c_vp]),
     "dctr_embed_lookup": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_vp]),
+    "dctr_embed_lookup_multi": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_i32, c_vp, c_vp, c_i32, c_vp]),
     "dctr_seq_weight_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "dctr_crossnet_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp]),

@@ -271,6 +271,44 @@ __global__ __launch_bounds__(256) void lookup_kernel(dctr_lookup_args_t a) {
     if (a.status != nullptr && __any(oor) && (threadIdx.x & 63) == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
 }
 
+// several lookups in ONE launch (DIN: query features and behaviour sequences): blockIdx.y selects the lookup, lanes
+// beyond a lookup's width idle.  A lookup that writes a mask also ANDs in (id != 0) of up to four further id arrays of
+// the same length: the conjunction of the mask_zero history features' masks the attention layer needs
+// (models/sequence/din.py:68-76; a mask_zero Hash maps 0 -> 0 and nothing else to 0, so the raw id decides).
+constexpr int LOOKUP_MULTI_MAX = 8, LOOKUP_EXTRA_MAX = 4;
+struct LookupMulti {
+    dctr_lookup_args_t a[LOOKUP_MULTI_MAX];
+    const void* extra_idx[LOOKUP_EXTRA_MAX];
+    int32_t extra_is_i64[LOOKUP_EXTRA_MAX];
+    int32_t n_extra;
+};
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void lookup_multi_kernel(LookupMulti m) {
+    constexpr int RPB = 256 / LPR;
+    const dctr_lookup_args_t& a = m.a[blockIdx.y];
+    const int r = threadIdx.x / LPR, q = threadIdx.x % LPR;
+    int oor = 0;
+    for (int64_t i = (int64_t)blockIdx.x * RPB + r; i < a.n; i += (int64_t)gridDim.x * RPB) {
+        const int64_t row = resolve_row(read_id(a.idx, i, a.idx_is_i64), a.hash_mode, a.idx_is_i64, a.vocab);
+        const bool ok = (uint64_t)row < (uint64_t)a.vocab;
+        if (!ok) oor = 1;
+        float v[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v[c] = 0.f;
+        if (q * VEC < a.dim) {
+            if (ok) load_vec<VEC>(a.table + row * a.dim + q * VEC, v);
+            store_vec<VEC>(a.out + i * a.out_stride + q * VEC, v);
+        }
+        if (q == 0 && a.mask != nullptr) {
+            bool nz = row != 0;
+            for (int e = 0; e < m.n_extra; ++e) nz = nz && read_id(m.extra_idx[e], i, m.extra_is_i64[e]) != 0;
+            a.mask[i] = nz ? 1 : 0;
+        }
+    }
+    if (a.status != nullptr && __any(oor) && (threadIdx.x & 63) == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // stand-alone WeightedSequenceLayer.call over a materialised [B,T,E] tensor (reference layers/sequence.py:155-183)
 // one wave per sample: masked weights -> (optional) softmax over T -> out[b,t,:] = seq[b,t,:] * w[b,t]
@@ -434,4 +472,45 @@ extern "C" int dctr_seq_weight_fwd(const float* seq, const float* weight, const 
     DCTR_LAUNCH(seq_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seq, weight, mask,
                        length, batch, maxlen, dim, weight_norm, out);
     return dctr_launch_status("dctr_seq_weight_fwd");
+}
+
+extern "C" int dctr_embed_lookup_multi(const dctr_lookup_args_t* args, int32_t n_lookups, const void* const* extra_mask_idx,
+                                       const int32_t* extra_is_i64, int32_t n_extra, void* stream) {
+    DCTR_REQUIRE(args != nullptr && n_lookups >= 0 && n_lookups <= LOOKUP_MULTI_MAX, DCTR_E_DIM,
+                 "embed_lookup_multi: 0..%d lookups", LOOKUP_MULTI_MAX);
+    DCTR_REQUIRE(n_extra >= 0 && n_extra <= LOOKUP_EXTRA_MAX && (n_extra == 0 || (extra_mask_idx && extra_is_i64)), DCTR_E_DIM,
+                 "embed_lookup_multi: 0..%d extra mask id arrays", LOOKUP_EXTRA_MAX);
+    if (n_lookups == 0) return DCTR_OK;
+    LookupMulti m{};
+    m.n_extra = n_extra;
+    for (int e = 0; e < n_extra; ++e) {
+        DCTR_REQUIRE(extra_mask_idx[e] != nullptr, DCTR_E_NULL, "embed_lookup_multi: extra_mask_idx[%d] null", e);
+        m.extra_idx[e] = extra_mask_idx[e];
+        m.extra_is_i64[e] = extra_is_i64[e];
+    }
+    bool v4 = true;
+    int max_dim = 1;
+    int64_t max_n = 0;
+    for (int k = 0; k < n_lookups; ++k) {
+        const dctr_lookup_args_t* a = &args[k];
+        DCTR_REQUIRE(a->n >= 0 && a->dim >= 1, DCTR_E_DIM, "embed_lookup_multi[%d]: bad sizes", k);
+        DCTR_REQUIRE(a->n == 0 || (a->idx && a->table && a->out), DCTR_E_NULL, "embed_lookup_multi[%d]: null pointer", k);
+        DCTR_REQUIRE(a->out_stride >= a->dim, DCTR_E_DIM, "embed_lookup_multi[%d]: out_stride < dim", k);
+        v4 = v4 && a->dim % 4 == 0 && dctr_aligned16(a->table) && dctr_aligned16(a->out) && a->out_stride % 4 == 0;
+        max_dim = a->dim > max_dim ? a->dim : max_dim;
+        max_n = a->n > max_n ? a->n : max_n;
+        m.a[k] = *a;
+    }
+    if (max_n == 0) return DCTR_OK;
+    const int vec = v4 ? 4 : 1;
+    DCTR_REQUIRE(max_dim <= 64 * vec, DCTR_E_UNSUPPORTED, "embed_lookup_multi: embedding_dim %d too large", max_dim);
+    const int lpr = lanes_per_row(max_dim, vec);
+    int64_t blocks = dctr_ceil_div(max_n, 256 / lpr);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL_LM(VECV, L) \
+    DCTR_LAUNCH((lookup_multi_kernel<VECV, L>), dim3((unsigned)blocks, (unsigned)n_lookups), dim3(256), 0, st, m)
+    if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_LM) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_LM) }
+#undef CALL_LM
+    return dctr_launch_status("dctr_embed_lookup_multi");
 }

@@ -81,25 +81,30 @@ class _DIN(FeatureModel):
                 k=torch.zeros(B, self.T, self.key_dim, dtype=torch.float32, device=self.device),
                 m=torch.ones(B, self.T, dtype=torch.uint8, device=self.device))
         st = ws["status"]
-        col = 0
+        # query features and behaviour sequences: ONE launch (dctr_embed_lookup_multi); the first mask_zero sequence's
+        # lookup writes the attention mask = conjunction of all mask_zero sequences' (id != 0)
+        lookups, col = [], 0
         for fc, row in zip(self.query_cols, self._query_rows):
             table = self.tables[fc.embedding_name].embeddings
             hm = 2 if (fc.use_hash and not prehashed_on_host(fc)) else 0
-            ops.embed_lookup(staged.ids[row, lo:hi], table, hash_mode=hm, out=bufs["q"][:, col:], out_stride=self.query_dim,
-                             status=st)
+            lookups.append(dict(idx=staged.ids[row, lo:hi], table=table, hash_mode=hm, out=bufs["q"][:, col:]))
             col += fc.embedding_dim
         col = 0
-        key_mask = None
+        masked = [fc for fc in self.history_cols if self.tables[fc.embedding_name].mask_zero]
         for fc in self.history_cols:
             emb = self.tables[fc.embedding_name]
             hm = 2 if (fc.use_hash and not prehashed_on_host(fc)) else 0
-            _, m = ops.embed_lookup(staged.seq[fc.name][lo:hi], emb.embeddings, hash_mode=hm, out=bufs["k"][:, :, col:],
-                                    out_stride=self.key_dim, return_mask=True, status=st)
-            if emb.mask_zero:
-                key_mask = m if key_mask is None else (key_mask & m)
+            lk = dict(idx=staged.seq[fc.name][lo:hi], table=emb.embeddings, hash_mode=hm, out=bufs["k"][:, :, col:])
+            if masked and fc is masked[0]:
+                lk["mask"] = bufs["m"]
+            lookups.append(lk)
             col += fc.embedding_dim
-        if key_mask is None:
-            key_mask = bufs["m"]
+        if len(masked) > 5:
+            raise NotImplementedError("DIN with more than five mask_zero behaviour sequences is outside the fused lookup's limits")
+        extra = [staged.seq[fc.name][lo:hi] for fc in masked[1:]]
+        for c0 in range(0, len(lookups), 8):            # eight lookups per launch
+            ops.embed_lookup_multi(lookups[c0:c0 + 8], extra_mask_ids=extra, status=st)
+        key_mask = bufs["m"]                # all ones when no history feature masks zero (never written then)
         hist_off = sp.extra_offsets["hist"]
         self.attention.run(bufs["q"], bufs["k"], key_mask, out=ws["dnn_in"][:, hist_off:], out_stride=sp.out_stride)
         ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),

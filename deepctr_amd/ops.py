@@ -130,6 +130,30 @@ def embed_lookup(idx, table, hash_mode=0, out=None, out_stride=None, return_mask
     return (out, mask) if return_mask else out
 
 
+def embed_lookup_multi(lookups, extra_mask_ids=(), status=None):
+    """Several row gathers in ONE launch.  ``lookups``: list of dicts(idx, table, hash_mode, out (2-D/3-D view with the row
+    stride to write at), mask (uint8 tensor or None)).  A lookup with a mask also ANDs in (id != 0) of every tensor in
+    ``extra_mask_ids`` (same number of ids) — see include/dctr.h."""
+    n = len(lookups)
+    arr = (_C.LookupArgs * max(1, n))()
+    keep = []
+    for k, lk in enumerate(lookups):
+        ic, is64 = _ids(lk["idx"], "idx")
+        table = _f32c(lk["table"], "table")
+        out, mask = lk["out"], lk.get("mask")
+        keep.append((ic, table))
+        arr[k] = _C.LookupArgs(idx=ic.data_ptr(), table=table.data_ptr(), vocab=table.shape[0], n=ic.numel(), idx_is_i64=is64,
+                               dim=table.shape[1], hash_mode=int(lk.get("hash_mode", 0)), out=out.data_ptr(),
+                               out_stride=out.stride(-2), mask=None if mask is None else mask.data_ptr(),
+                               status=None if status is None else status.data_ptr())
+    ex = [_ids(t, "extra_mask_ids") for t in extra_mask_ids]
+    ep = (ctypes.c_void_p * max(1, len(ex)))(*[t.data_ptr() for t, _ in ex])
+    ef = (ctypes.c_int32 * max(1, len(ex)))(*[f for _, f in ex])
+    _C.check(_C.lib().dctr_embed_lookup_multi(arr, n, ctypes.cast(ep, ctypes.c_void_p), ctypes.cast(ef, ctypes.c_void_p), len(ex),
+                                              _C.stream_ptr()), "dctr_embed_lookup_multi")
+    del keep
+
+
 def embed_pool(idx, table, combiner="mean", length=None, weight=None, weight_norm=True, lin_table=None, hash_mode=0,
                out=None, out_stride=None, lin_out=None, status=None, keep_args=None):
     """VarLenSparseFeat lookup + (weighted) masked pooling: idx [B,T] -> [B,dim] (reference

@@ -178,6 +178,11 @@ typedef struct {
 } dctr_lookup_args_t;
 
 int dctr_embed_lookup(const dctr_lookup_args_t* args, void* stream);
+/* up to 8 lookups in ONE launch (DIN's query features + behaviour sequences, din.py:62-76).  A lookup with mask != NULL
+ * additionally ANDs (id != 0) of n_extra (<= 4) further id arrays of the same length into its mask (HOST arrays of
+ * DEVICE pointers / int64 flags): the conjunction of the mask_zero sequences' masks. */
+int dctr_embed_lookup_multi(const dctr_lookup_args_t* args, int32_t n_lookups, const void* const* extra_mask_idx,
+                            const int32_t* extra_is_i64, int32_t n_extra, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a8  FM.call stand-alone — deepctr/layers/interaction.py:588-604.   x [B,F,E] (sample stride x_stride) -> y [B]
