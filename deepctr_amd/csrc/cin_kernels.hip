@@ -50,14 +50,14 @@ __device__ __forceinline__ void cin_buf_load(__amdgpu_buffer_rsrc_t rsrc, int vo
 #define CIN_SB __builtin_amdgcn_sched_barrier(0)
 
 // One CIN layer for the workgroup's M = SB*D rows.  K = F0*Fk is walked in STAGES of SS k-steps of one i:
-// stage (i, c) covers j = 4*(SS*c + tt) + g, tt < SS (slot g of the MFMA takes j = 4*jt + g).  Software pipeline:
+// stage (c, i) covers j = 4*(SS*c + tt) + g, tt < SS (slot g of the MFMA takes j = 4*jt + g).  Software pipeline:
 //   * B (filter rows i*Fk + j, a wave's 16*TPW-column slice) comes from L2 through raw buffer loads — lane-constant
 //     offset, scalar row offset, zero VALU — into THREE rotating register stages (two stages of MFMAs of cover);
 //   * the A operand x0[row,i] * x_k[row,j] is formed in registers: its LDS reads for stage s+1 are issued before the
 //     MFMAs of stage s and multiplied after them;
 //   * sched_barriers pin "issue loads, then MFMAs" (hipcc otherwise sinks each load next to its use).
 // The earlier form (one filter load, four LDS reads, eight MFMAs, wait) ran at 48 % of the nominal f32-MFMA rate; this
-// one at 60 % (C3: 420 us per 4096 samples; a pure-MFMA loop sustains 139 of the nominal 157 TFLOP/s on this part).
+// one at 68 % (C3: 364 us per 4096 samples; a pure-MFMA loop sustains 139 of the nominal 157 TFLOP/s on this part).
 template <int TPW, int RT>
 __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float* x0s, const float* xk, int xk_stride,
                                           int Fk, float* ycur, int Hn, int d0, int64_t bbase, int out_off) {
@@ -97,38 +97,44 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
 #pragma unroll
             for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // stage counters of the two prefetch streams (scalar): B runs two stages ahead, the A reads one
+        // Stage order: chunk c of the j range OUTER, i INNER — stage (c, i) multiplies x0[:, i] with the chunk's SS x 4 values
+        // of x_k, which therefore stay in registers for F0 stages (read from LDS once per chunk, masked there), and only
+        // x0[:, i] (RT values) is read per stage.  (i outer / c inner read 3x as much LDS per stage.)  The order only
+        // permutes the terms of the K sum.  Stage counters of the two prefetch streams (scalar): B runs two stages ahead,
+        // the A reads one.
         int iB = 0, cB = 0, iR = 0, cR = 0;
-        auto load_b = [&](float (&b)[SS][TPW]) {      // stage (iB, cB), then advance
+        auto load_b = [&](float (&b)[SS][TPW]) {      // stage (cB, iB), then advance
 #pragma unroll
             for (int tt = 0; tt < SS; ++tt) {
                 const int jt = min(SS * cB + tt, JT - 1);             // steps past JT are masked on the A side
                 cin_buf_load<TPW>(rsrc, voff, (iB * Fk + 4 * jt) * H * 4, b[tt]);
             }
-            if (++cB == NC) { cB = 0; iB = min(iB + 1, F0 - 1); }
+            if (++iB == F0) { iB = 0; cB = min(cB + 1, NC - 1); }
         };
         float rxi[RT], rxk[SS][RT];
-        int c_raw = 0;
-        auto load_raw = [&]() {                       // stage (iR, cR), then advance
-            c_raw = cR;
+        auto load_raw = [&]() {                       // stage (cR, iR), then advance
+            if (iR == 0) {                            // new chunk: its x_k values, zero where j >= Fk or the row is padding
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) rxi[rt] = x0s[off0[rt] + iR * D];
+                for (int tt = 0; tt < SS; ++tt) {
+                    const int j = 4 * (SS * cR + tt) + g;
+                    const int jc = min(j, Fk - 1);
 #pragma unroll
-            for (int tt = 0; tt < SS; ++tt) {
-                const int j = min(4 * (SS * cR + tt) + g, Fk - 1);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) rxk[tt][rt] = xk[offk[rt] + j * D];
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float v = xk[offk[rt] + jc * D];
+                        rxk[tt][rt] = (j < Fk && rowok[rt]) ? v : 0.f;
+                    }
+                }
             }
-            if (++cR == NC) { cR = 0; iR = min(iR + 1, F0 - 1); }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) rxi[rt] = x0s[off0[rt] + iR * D];      // rows past M read sample 0 (finite), x_k is 0 there
+            if (++iR == F0) { iR = 0; cR = min(cR + 1, NC - 1); }
         };
         float a[SS][RT];
         auto make_a = [&]() {
 #pragma unroll
-            for (int tt = 0; tt < SS; ++tt) {
-                const bool jok = 4 * (SS * c_raw + tt) + g < Fk;
+            for (int tt = 0; tt < SS; ++tt)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[tt][rt] = (jok && rowok[rt]) ? rxi[rt] * rxk[tt][rt] : 0.f;
-            }
+                for (int rt = 0; rt < RT; ++rt) a[tt][rt] = rxi[rt] * rxk[tt][rt];
         };
         auto mfmas = [&](const float (&b)[SS][TPW]) {
 #pragma unroll
