@@ -391,7 +391,7 @@ def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
         sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
-        tile_rows=0, save_acts=None, probe=None):
+        tile_rows=0, save_acts=None, probe=None, launch=True):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
@@ -448,6 +448,8 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
         sa = _ptr_array(list(save_acts))
         keep.append(sa)
         a.save_acts = ctypes.cast(sa, ctypes.c_void_p)
+    if not launch:                      # caller keeps the marshalled arguments and launches itself (per-batch fast path)
+        return a, (keep, ua, kp, bp, da, dm, dv, add_arr, add, head_w, global_bias, out)
     if gather is not None:
         _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(gather), ctypes.byref(a), int(bool(add_fm_logit)),
                                              int(bool(add_lin_logit)), _C.stream_ptr()), "dctr_embed_mlp_fwd")
