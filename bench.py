@@ -70,9 +70,13 @@ def build_model(device):
     return model, cols
 
 
-def synthetic_feed(rows, seed):
+def synthetic_feed(rows, seed, dist="uniform"):
+    """ids i.i.d. uniform on [0, V) (primary, cache-hostile) or Zipf(1.05) folded into [0, V) (secondary)."""
     rng = np.random.RandomState(seed)
-    feed = {"C%d" % i: rng.randint(0, V, rows).astype(np.int32) for i in range(1, F + 1)}
+    if dist == "zipf":
+        feed = {"C%d" % i: ((rng.zipf(1.05, rows) - 1) % V).astype(np.int32) for i in range(1, F + 1)}
+    else:
+        feed = {"C%d" % i: rng.randint(0, V, rows).astype(np.int32) for i in range(1, F + 1)}
     feed.update({"I%d" % i: rng.rand(rows).astype(np.float32) for i in range(1, ND + 1)})
     return feed
 
@@ -139,6 +143,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=32,
                     help="batch rows per workgroup of the fused kernel (0 = library default, 16 = lowest latency of one "
                          "batch, 32 = highest throughput with several batches in flight)")
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"], help="id distribution (SURVEY 8(d))")
     ap.add_argument("--no-k-split", action="store_true", help="lab: do not offer the layer-0 K split to the fused kernel")
     args = ap.parse_args()
 
@@ -164,7 +169,7 @@ def main():
     if args.no_k_split:
         model.stage_plan.k_split = (0, 0)
     K, W, ring = args.steps, args.warmup, max(1, min(args.ring, max(args.steps, 1)))
-    staged = model.stage(synthetic_feed(ring * B, 1000 + rank))       # device-resident before timing
+    staged = model.stage(synthetic_feed(ring * B, 1000 + rank, args.dist))       # device-resident before timing
     model._begin()
     logits = torch.empty(max(K, 1) * B, dtype=torch.float32, device=device)
     gathered = torch.empty(world * logits.numel(), dtype=torch.float32, device=device) if dist is not None else None
@@ -298,8 +303,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DeepFM forward, 26 sparse x vocab 1e5 + 13 dense, emb_dim 16, "
                                    "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, "
-                                   "ring of %d distinct batches, %s, %s" % (
-                                       ring, "1 hipGraph of K steps" if graph else "eager",
+                                   "ids %s, ring of %d distinct batches, %s, %s" % (
+                                       args.dist, ring, "1 hipGraph of K steps" if graph else "eager",
                                        ("1 launch/step (fused gather+DNN), %d batches in flight, tile_rows %d" % (n_streams, args.tile_rows))
                                        if t_fused is not None else "2 launches/step"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "row-sharded x%d, tables replicated" % world},
