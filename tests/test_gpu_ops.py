@@ -480,3 +480,28 @@ def test_cin_embedding_dims(device, D):
         ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], split, act)
         y = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, act)
         assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="cin D=%d layers=%s split=%s" % (D, ls, split))
+
+
+def test_embed_lookup_multi(device):
+    """Several lookups in one launch == the single lookups, bit for bit; the masked lookup's mask is the conjunction of
+    (id != 0) over its own and the extra id arrays; widths differ between lookups; hashed ids."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(33)
+    B, T = 37, 9
+    tabs = [dev(rng.standard_normal((50, 8)).astype(np.float32), device), dev(rng.standard_normal((70, 16)).astype(np.float32), device),
+            dev(rng.standard_normal((40, 4)).astype(np.float32), device)]
+    q_ids = dev(rng.randint(0, 50, B).astype(np.int32), device)
+    s1 = dev((rng.randint(0, 70, (B, T)) * (rng.rand(B, T) > 0.3)).astype(np.int64), device)
+    s2 = dev((rng.randint(0, 10 ** 6, (B, T)) * (rng.rand(B, T) > 0.3)).astype(np.int32), device)      # hashed, mask_zero
+    q = torch.zeros(B, 8, device=device)
+    k = torch.zeros(B, T, 20, device=device)
+    m = torch.full((B, T), 7, dtype=torch.uint8, device=device)
+    ops.embed_lookup_multi([dict(idx=q_ids, table=tabs[0], out=q), dict(idx=s1, table=tabs[1], out=k[:, :, :16], mask=m),
+                            dict(idx=s2, table=tabs[2], hash_mode=2, out=k[:, :, 16:])], extra_mask_ids=[s2])
+    np.testing.assert_array_equal(q.cpu().numpy(), ops.embed_lookup(q_ids, tabs[0]).cpu().numpy())
+    e1, m1 = ops.embed_lookup(s1, tabs[1], return_mask=True)
+    e2, m2 = ops.embed_lookup(s2, tabs[2], hash_mode=2, return_mask=True)
+    np.testing.assert_array_equal(k[:, :, :16].cpu().numpy(), e1.cpu().numpy())
+    np.testing.assert_array_equal(k[:, :, 16:].cpu().numpy(), e2.cpu().numpy())
+    np.testing.assert_array_equal(m.cpu().numpy(), (m1 & m2).cpu().numpy())
+    assert ((s2.cpu().numpy() != 0) == (m2.cpu().numpy() != 0)).all()      # a mask_zero Hash maps only 0 to 0
