@@ -224,6 +224,9 @@ def main():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
 
+    if dist is not None:                                               # untimed: RCCL sets up its all-gather channels
+        dist.all_gather_into_tensor(gathered, logits)
+        torch.cuda.synchronize()
     reset_probes()
     barrier()
     torch.cuda.synchronize()
