@@ -327,6 +327,26 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// BiInteractionPooling (interaction.py:190-203, NFM): y[b, e] = 0.5 * ((sum_f x[b,f,e])^2 - sum_f x[b,f,e]^2)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bi_interaction_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
+                                                             int E, float* __restrict__ y, int64_t y_stride) {
+    const int64_t total = batch * E;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / E;
+        const int e = (int)(o - b * E);
+        const float* xb = x + b * x_stride + e;
+        float s = 0.f, q = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float v = xb[(int64_t)f * E];
+            s += v;
+            q = fmaf(v, v, q);
+        }
+        y[b * y_stride + e] = 0.5f * (s * s - q);
+    }
+}
+
 int pow2_at_least(int v, int cap) {
     int l = 1;
     while (l < v && l < cap) l <<= 1;
@@ -465,4 +485,17 @@ extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_s
     DCTR_LAUNCH(inner_product_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, x_stride, batch,
                 fields, dim, reduce_sum, y, y_stride);
     return dctr_launch_status("dctr_inner_product_fwd");
+}
+
+extern "C" int dctr_bi_interaction_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, float* y,
+                                       int64_t y_stride, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && fields >= 1 && dim >= 1, DCTR_E_DIM, "bi_interaction_fwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x && y, DCTR_E_NULL, "bi_interaction_fwd: null pointer");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim && y_stride >= dim, DCTR_E_DIM, "bi_interaction_fwd: stride smaller than a row");
+    int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
+    if (blocks > 8192) blocks = 8192;
+    DCTR_LAUNCH(bi_interaction_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch, fields, dim, y,
+                y_stride);
+    return dctr_launch_status("dctr_bi_interaction_fwd");
 }

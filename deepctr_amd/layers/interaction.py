@@ -191,6 +191,23 @@ class FM(Layer):
         return (None, 1)
 
 
+class BiInteractionPooling(Layer):
+    """Mirror of deepctr.layers.interaction.BiInteractionPooling (:170-211)."""
+
+    def build(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(input_shape)))
+        super(BiInteractionPooling, self).build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        if inputs.dim() != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (inputs.dim()))
+        return ops.bi_interaction(inputs)
+
+    def compute_output_shape(self, input_shape):
+        return (None, 1, input_shape[-1])
+
+
 class OutterProductLayer(Layer):
     """Weight holder only: PNN (reference models/pnn.py:49) instantiates this layer, and thereby its kernel, even with
     use_outter=False, so Keras weight lists of a reference PNN contain it.  The outer-product arithmetic

@@ -365,6 +365,27 @@ def afm(x, attention_W, attention_b, projection_h, projection_p, fields=None, di
     return y
 
 
+def bi_interaction(x, fields=None, dim=None, out=None):
+    """BiInteractionPooling.call (reference interaction.py:190-203): x [B,F,E] -> [B,1,E]; with ``fields``/``dim`` x is a
+    2-D buffer read in place and ``out`` a 2-D (strided) view to write [B,E] into."""
+    _dev_check(x)
+    if fields is None:
+        if x.dim() != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % x.dim())
+        x = _f32c(x, "x")
+        B, F, E = x.shape
+        xs = F * E
+    else:
+        B, F, E, xs = x.shape[0], int(fields), int(dim), x.stride(0)
+    if out is None:
+        y = torch.empty(B, 1, E, dtype=torch.float32, device=x.device)
+        ys = E
+    else:
+        y, ys = out, out.stride(0)
+    _C.check(_C.lib().dctr_bi_interaction_fwd(_ptr(x), B, xs, F, E, _ptr(y), ys, _C.stream_ptr()), "dctr_bi_interaction_fwd")
+    return y
+
+
 def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
     """InnerProductLayer.call (reference interaction.py:655-678): x [B,F,E] -> [B,P,1] or [B,P,E].
     With ``fields``/``dim`` x is a 2-D buffer read in place; ``out`` may be a 2-D (strided) view to write into."""

@@ -245,6 +245,13 @@ int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_stride, int3
                            int32_t reduce_sum, float* y, int64_t y_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * sibling: BiInteractionPooling.call — deepctr/layers/interaction.py:190-203 (NFM)
+ *     x [B,F,E] (sample stride x_stride) -> y [B,E] (sample stride y_stride) = 0.5 ((sum_f e)^2 - sum_f e^2)
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_bi_interaction_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, float* y,
+                            int64_t y_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * adjacent  DNN.call (+ Dense(1, use_bias=False) head, add_func, PredictionLayer.call)
  *     deepctr/layers/core.py:189-208, :250-259; layers/utils.py:328-333.
  *     y = x; for each layer: y = act(y W_l + b_l).  Optional head: logit = y . head_w (+ add0 + add1

@@ -482,6 +482,9 @@ def gen_siblings():
     _run_model("model_afm_two_groups", "deepctr.models.afm", "AFM", spec, two, feed,
                {"attention_factor": 3, "fm_group": ["default_group", "g1"]})
     _run_model("model_afm_noatt", "deepctr.models.afm", "AFM", spec, nodense, feed, {"use_attention": False})
+    # NFM (models/nfm.py:19-62): BiInteractionPooling of the embeddings -> DNN, + linear logit
+    _run_model("model_nfm", "deepctr.models.nfm", "NFM", spec, spec, feed, {"dnn_hidden_units": [16, 8]})
+    _run_model("model_nfm_fixed", "deepctr.models.nfm", "NFM", fixed, fixed, feed_f, {"dnn_hidden_units": [32, 8]})
     # PNN (models/pnn.py:19-72), inner product only
     _run_pnn("model_pnn_inner", spec, feed, {"dnn_hidden_units": [16, 8], "use_inner": True, "use_outter": False})
     _run_pnn("model_pnn_plain", fixed, feed_f, {"dnn_hidden_units": [8], "use_inner": False, "use_outter": False})

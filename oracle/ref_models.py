@@ -235,6 +235,17 @@ def pnn(linear_cols, dnn_cols, weights, feed, use_inner=True, use_outter=False, 
     return R.prediction_layer(dnn_logit, weights["prediction_layer/global_bias"].astype(dt), task)
 
 
+def nfm(linear_cols, dnn_cols, weights, feed, dnn_activation="relu", task="binary", dtype=np.float32, **_):
+    """deepctr/models/nfm.py:42-62: linear logit + DNN over [BiInteractionPooling(embeddings), dense]."""
+    dt = np.dtype(dtype).type
+    lin = linear_logit(linear_cols, feed, weights, dt)
+    groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
+    bi = R.bi_interaction(np.concatenate([e for g in groups.values() for e in g], axis=1))     # [B,1,E]
+    dnn_in = _combined_dnn_input([bi], dense)
+    dnn_logit = _dnn("dnn", dnn_in, weights, dt, dnn_activation) @ weights["dense/kernel"].astype(dt)
+    return R.prediction_layer(_add(lin, dnn_logit), weights["prediction_layer/global_bias"].astype(dt), task)
+
+
 def dcn(linear_cols, dnn_cols, weights, feed, cross_num=2, cross_parameterization="vector",
         dnn_hidden_units=(256, 128, 64), dnn_activation="relu", task="binary", dtype=np.float32, **_):
     dt = np.dtype(dtype).type

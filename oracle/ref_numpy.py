@@ -187,6 +187,14 @@ def cin(x, filters, biases, split_half=True, activation="relu"):
 # ---------------------------------------------------------------------------------------------
 # a11: AFMLayer.call — reference layers/interaction.py:116-146
 # ---------------------------------------------------------------------------------------------
+def bi_interaction(x):
+    """BiInteractionPooling.call (interaction.py:190-203): x [B,F,E] -> [B,1,E] = 0.5 * ((sum_f e)^2 - sum_f e^2)."""
+    x = np.asarray(x)
+    square_of_sum = np.square(x.sum(axis=1, keepdims=True))
+    sum_of_square = (x * x).sum(axis=1, keepdims=True)
+    return x.dtype.type(0.5) * (square_of_sum - sum_of_square)
+
+
 def afm(embeds, attention_W, attention_b, projection_h, projection_p):
     """embeds: list of F arrays [B,1,E].  Returns [B,1]."""
     rows, cols = [], []

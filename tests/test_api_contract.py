@@ -150,7 +150,7 @@ def test_model_constructors_keep_the_reference_signatures():
     order (read from the committed table below, taken from deepctr/models/*.py), plus a trailing ``device``."""
     import inspect
     from deepctr_amd import models
-    ref = {   # name -> [(param, default or inspect._empty), ...]   (deepctr/models/{deepfm,dcn,xdeepfm,wdl,fnn,afm,pnn}.py, sequence/din.py)
+    ref = {   # name -> [(param, default or inspect._empty), ...]   (deepctr/models/{deepfm,dcn,xdeepfm,wdl,fnn,afm,pnn,nfm}.py, sequence/din.py)
         "DeepFM": ["linear_feature_columns", "dnn_feature_columns", ("fm_group", ("default_group",)),
                    ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0),
                    ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"), ("dnn_use_bn", False), ("task", "binary")],
@@ -167,6 +167,9 @@ def test_model_constructors_keep_the_reference_signatures():
         "AFM": ["linear_feature_columns", "dnn_feature_columns", ("fm_group", "default_group"), ("use_attention", True),
                 ("attention_factor", 8), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_att", 1e-5),
                 ("afm_dropout", 0), ("seed", 1024), ("task", "binary")],
+        "NFM": ["linear_feature_columns", "dnn_feature_columns", ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_embedding", 1e-5),
+                ("l2_reg_linear", 1e-5), ("l2_reg_dnn", 0), ("seed", 1024), ("bi_dropout", 0), ("dnn_dropout", 0),
+                ("dnn_activation", "relu"), ("task", "binary")],
         "PNN": ["dnn_feature_columns", ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0),
                 ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"), ("use_inner", True), ("use_outter", False),
                 ("kernel_type", "mat"), ("task", "binary")],

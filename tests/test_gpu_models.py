@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def build_model(meta, device):
-    from deepctr_amd.models import AFM, DCN, DIN, FNN, PNN, WDL, DeepFM, xDeepFM
+    from deepctr_amd.models import AFM, DCN, DIN, FNN, NFM, PNN, WDL, DeepFM, xDeepFM
     dnn_cols = columns_from_spec(meta["dnn"])
     lin_cols = columns_from_spec(meta["linear"])
     kw = dict(meta["kwargs"])
@@ -22,7 +22,7 @@ def build_model(meta, device):
         return DIN(dnn_cols, meta["extra_args"][0], device=device, **kw)
     if name == "PNN":
         return PNN(dnn_cols, device=device, **kw)
-    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN, "AFM": AFM}[name]
+    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN, "AFM": AFM, "NFM": NFM}[name]
     return ctor(lin_cols, dnn_cols, device=device, **kw)
 
 
@@ -31,7 +31,7 @@ def well_conditioned_rows(meta, feed, n):
     and tested at op level).  Fed to FM, (sum e)^2 - sum e^2 then cancels at the 1e18 scale and the logit is rounding
     noise of either sign in ANY fp32 implementation, so those rows are excluded from FM-model comparisons."""
     ok = np.ones(n, dtype=bool)
-    if meta["model"] not in ("DeepFM", "AFM", "PNN"):      # the models with second-order terms of the embeddings
+    if meta["model"] not in ("DeepFM", "AFM", "PNN", "NFM"):      # the models with second-order terms of the embeddings
         return ok
     for d in meta["dnn"]:
         if d["type"] == "varlen" and d.get("combiner") == "max":

@@ -296,6 +296,29 @@ def test_afm_inner_product(device):
         assert_close(ops.inner_product(x, False).cpu().numpy(), g["ip_%s_full" % tag], what="ip full " + tag)
 
 
+def test_bi_interaction(device):
+    """BiInteractionPooling (interaction.py:190-203) against the oracle (pinned through the NFM model fixtures)."""
+    from deepctr_amd import ops
+    from deepctr_amd.layers import BiInteractionPooling
+    rng = np.random.RandomState(21)
+    for B, F, E in ((1, 1, 1), (70, 26, 16), (513, 7, 5), (0, 3, 4)):
+        x = (rng.standard_normal((B, F, E)) * 0.5).astype(np.float32)
+        ref = R.bi_interaction(x.astype(np.float64))
+        y = BiInteractionPooling(device=device)(dev(x, device))
+        assert tuple(y.shape) == (B, 1, E)
+        assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-6, what="bi %s" % ((B, F, E),))
+    # in place from a wider row buffer into a column slice of the same buffer (how NFM uses it)
+    B, F, E = 33, 6, 8
+    buf = torch.zeros(B, 80, device=device)
+    x = (rng.standard_normal((B, F, E)) * 0.5).astype(np.float32)
+    buf[:, :F * E] = dev(x.reshape(B, -1), device)
+    ops.bi_interaction(buf, fields=F, dim=E, out=buf[:, F * E:])
+    assert_close(buf[:, F * E:F * E + E].cpu().numpy(), R.bi_interaction(x.astype(np.float64))[:, 0], rtol=1e-4, atol=1e-6)
+    assert float(buf[:, F * E + E:].abs().max()) == 0.0
+    with pytest.raises(ValueError, match="expect to be 3 dimensions"):
+        BiInteractionPooling(device=device)(torch.zeros(4, 8, device=device))
+
+
 # ---------------------------------------------------------------------------------------------
 # adjacent: DNN (+head), DIN attention
 # ---------------------------------------------------------------------------------------------

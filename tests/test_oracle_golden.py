@@ -207,7 +207,7 @@ MODEL_FIXTURES = ["model_deepfm_mixed", "model_deepfm_hash", "model_dcn_vector",
                   "model_din_ref_dice_hash1", "model_din_ref_sigmoid_hash1", "model_din_big_wn0", "model_din_big_wn1",
                   "model_deepfm_criteo_sample", "model_wdl", "model_wdl_wide_subset", "model_fnn", "model_wdl_fixed",
                   "model_fnn_fixed", "model_afm", "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner",
-                  "model_pnn_plain"]
+                  "model_pnn_plain", "model_nfm", "model_nfm_fixed"]
 
 
 def run_oracle_model(g, dtype=np.float32):
@@ -235,6 +235,8 @@ def run_oracle_model(g, dtype=np.float32):
         return RM.afm(lin_cols, dnn_cols, weights, feed, **kw)
     if name == "PNN":
         return RM.pnn(lin_cols, dnn_cols, weights, feed, **kw)
+    if name == "NFM":
+        return RM.nfm(lin_cols, dnn_cols, weights, feed, **kw)
     raise KeyError(name)
 
 
