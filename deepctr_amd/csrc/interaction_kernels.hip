@@ -490,9 +490,9 @@ extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_s
 extern "C" int dctr_bi_interaction_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, float* y,
                                        int64_t y_stride, void* stream) {
     DCTR_REQUIRE(batch >= 0 && fields >= 1 && dim >= 1, DCTR_E_DIM, "bi_interaction_fwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim && y_stride >= dim, DCTR_E_DIM, "bi_interaction_fwd: stride smaller than a row");
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && y, DCTR_E_NULL, "bi_interaction_fwd: null pointer");
-    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim && y_stride >= dim, DCTR_E_DIM, "bi_interaction_fwd: stride smaller than a row");
     int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
     if (blocks > 8192) blocks = 8192;
     DCTR_LAUNCH(bi_interaction_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch, fields, dim, y,

@@ -53,3 +53,13 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.dctr_embed_gather_fm(ctypes.byref(a), None) == -2
     assert lib.dctr_crossnet_fwd(None, 4, 8, 8, None, None, 1, 7, None, 8, None, 0, None) == -4     # DCTR_E_ENUM
     assert lib.dctr_crossnet_workspace_bytes(429, 2, 1, None) == 2 * 429 * 432 * 4 and lib.dctr_crossnet_workspace_bytes(64, 2, 1, None) == 0
+    # sibling + training entry points: same contract
+    assert lib.dctr_bi_interaction_fwd(None, 4, 8, 2, 4, None, 4, None) == -1
+    assert lib.dctr_bi_interaction_fwd(None, 4, 7, 2, 4, None, 4, None) == -2     # row stride smaller than F*E
+    assert lib.dctr_bi_interaction_fwd(None, 0, 8, 2, 4, None, 4, None) == 0
+    assert lib.dctr_bce_grad(None, None, 4, 0, None, None, None, None) == -1
+    assert lib.dctr_bce_grad(None, None, 4, 5, None, None, None, None) == -2
+    assert lib.dctr_opt_multi(9, None, 0, 0, 0.001, 0.9, 0.999, 1e-7, 1, None) == -4
+    assert b"optimizer kind 9" in lib.dctr_last_error()
+    assert lib.dctr_mlp_bwd(None, None) == -1 and lib.dctr_cin_bwd(None, None) == -1 and lib.dctr_crossnet_bwd(None, None) == -1
+    assert lib.dctr_embed_gather_fm_bwd(None, None) == -1 and lib.dctr_embed_pool_bwd(None, None) == -1
