@@ -158,6 +158,8 @@ SYMBOLS = {
     "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
     "dctr_embed_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolBwdArgs), c_vp]),
+    "dctr_bi_interaction_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
+    "dctr_inner_product_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_dense1_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dctr_crossnet_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CrossBwdArgs)]),
     "dctr_crossnet_bwd": (ctypes.c_int, [ctypes.POINTER(CrossBwdArgs), c_vp]),

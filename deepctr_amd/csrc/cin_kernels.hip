@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int CIN_MAX_LAYERS = 8;
-constexpr int RT_MAX = 8;  // row tiles (16 rows each) per workgroup
 
 struct CinParams {
     const float* x;

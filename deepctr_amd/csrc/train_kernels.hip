@@ -601,7 +601,81 @@ rocblas_handle blas_handle() {
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// sibling interaction layers: backward of BiInteractionPooling (NFM) and InnerProductLayer(reduce_sum) (PNN).
+// One thread per (row, e); the F embeddings of the row are re-read from the forward's input (HBM/L2, F*E*4 B per row).
+// ---------------------------------------------------------------------------------------------------
+// y[b,e] = 0.5((sum_f x)^2 - sum_f x^2)  =>  dx[b,f,e] = dy[b,e] * (sum_f' x[b,f',e] - x[b,f,e])
+__global__ __launch_bounds__(256) void bi_interaction_bwd_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
+                                                                 int E, const float* __restrict__ dy, int64_t dy_stride,
+                                                                 float* __restrict__ dx, int64_t dx_stride, int accumulate) {
+    const int64_t total = batch * E;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / E;
+        const int e = (int)(o - b * E);
+        const float* xb = x + b * x_stride + e;
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s += xb[(int64_t)f * E];
+        const float g = dy[b * dy_stride + e];
+        float* db = dx + b * dx_stride + e;
+        for (int f = 0; f < F; ++f) {
+            const float v = g * (s - xb[(int64_t)f * E]);
+            db[(int64_t)f * E] = accumulate ? db[(int64_t)f * E] + v : v;
+        }
+    }
+}
+
+// y[b,p(i,j)] = <x_i, x_j> (i<j, pairs ordered by i then j)  =>  dx[b,i,e] = sum_{j != i} dy[b,p(min,max)] * x[b,j,e]
+__global__ __launch_bounds__(256) void inner_product_bwd_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
+                                                                int E, const float* __restrict__ dy, int64_t dy_stride,
+                                                                float* __restrict__ dx, int64_t dx_stride, int accumulate) {
+    const int64_t total = batch * F * E;
+    const int FE = F * E;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / FE;
+        const int c = (int)(o - b * FE);
+        const int i = c / E, e = c - i * E;
+        const float* xb = x + b * x_stride + e;
+        const float* gb = dy + b * dy_stride;
+        float acc = 0.f;
+        for (int j = 0; j < i; ++j) acc = fmaf(gb[j * (2 * F - j - 1) / 2 + (i - j - 1)], xb[(int64_t)j * E], acc);
+        const int base = i * (2 * F - i - 1) / 2 - i - 1;
+        for (int j = i + 1; j < F; ++j) acc = fmaf(gb[base + j], xb[(int64_t)j * E], acc);
+        float* d = dx + b * dx_stride + c;
+        *d = accumulate ? *d + acc : acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int dctr_bi_interaction_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
+                                       int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && fields >= 1 && dim >= 1, DCTR_E_DIM, "bi_interaction_bwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim && dx_stride >= (int64_t)fields * dim && dy_stride >= dim, DCTR_E_DIM,
+                 "bi_interaction_bwd: stride smaller than a row");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x && dy && dx, DCTR_E_NULL, "bi_interaction_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bi_interaction_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch,
+                       (int)fields, (int)dim, dy, dy_stride, dx, dx_stride, (int)accumulate);
+    return dctr_launch_status("dctr_bi_interaction_bwd");
+}
+
+extern "C" int dctr_inner_product_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
+                                      int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && fields >= 2 && fields <= 1024 && dim >= 1, DCTR_E_DIM, "inner_product_bwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim && dx_stride >= (int64_t)fields * dim &&
+                     dy_stride >= (int64_t)fields * (fields - 1) / 2,
+                 DCTR_E_DIM, "inner_product_bwd: stride smaller than a row");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x && dy && dx, DCTR_E_NULL, "inner_product_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * fields * dim, (int64_t)256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(inner_product_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch,
+                       (int)fields, (int)dim, dy, dy_stride, dx, dx_stride, (int)accumulate);
+    return dctr_launch_status("dctr_inner_product_bwd");
+}
 
 extern "C" int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
                              float* dlogit_sum, void* stream) {

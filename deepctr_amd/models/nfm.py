@@ -13,6 +13,7 @@ class _NFM(FeatureModel):
     def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units, seed, bi_dropout, dnn_dropout,
                  dnn_activation, task, device):
         super(_NFM, self).__init__("NFM", list(linear_feature_columns) + list(dnn_feature_columns), device, task)
+        self.bi_dropout = bi_dropout            # training-time only (nfm.py:52-53); the forward path ignores it
         with name_scope():
             self.build_linear(linear_feature_columns, seed)
             self.build_embeddings(dnn_feature_columns, seed)
@@ -46,5 +47,7 @@ def NFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 128,
         l2_reg_linear=1e-5, l2_reg_dnn=0, seed=1024, bi_dropout=0, dnn_dropout=0, dnn_activation='relu', task='binary',
         device=None):
     """Instantiates the Neural Factorization Machine architecture on the MI355X forward path."""
-    return _NFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units, seed, bi_dropout, dnn_dropout,
-                dnn_activation, task, device)
+    m = _NFM(linear_feature_columns, dnn_feature_columns, dnn_hidden_units, seed, bi_dropout, dnn_dropout,
+             dnn_activation, task, device)
+    m.regularizers = {"embedding": float(l2_reg_embedding), "linear": float(l2_reg_linear), "dnn": float(l2_reg_dnn)}
+    return m

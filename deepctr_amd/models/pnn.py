@@ -58,5 +58,7 @@ def PNN(dnn_feature_columns, dnn_hidden_units=(256, 128, 64), l2_reg_embedding=0
         dnn_dropout=0, dnn_activation='relu', use_inner=True, use_outter=False, kernel_type='mat', task='binary',
         device=None):
     """Instantiates the Product-based Neural Network architecture (inner product) on the MI355X forward path."""
-    return _PNN(dnn_feature_columns, dnn_hidden_units, seed, dnn_dropout, dnn_activation, use_inner, use_outter,
-                kernel_type, task, device)
+    m = _PNN(dnn_feature_columns, dnn_hidden_units, seed, dnn_dropout, dnn_activation, use_inner, use_outter,
+             kernel_type, task, device)
+    m.regularizers = {"embedding": float(l2_reg_embedding), "linear": 0.0, "dnn": float(l2_reg_dnn)}
+    return m

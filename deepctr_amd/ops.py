@@ -618,6 +618,22 @@ def dense1_bwd(x, n, w, dlogit, dx, d_w):
                                       _ptr(d_w), _C.stream_ptr()), "dctr_dense1_bwd")
 
 
+def bi_interaction_bwd(x, fields, dim, dy, dx, accumulate=False):
+    """Backward of bi_interaction on a strided [B, >= F*E] buffer: dy [B, >= E], dx [B, >= F*E] (include/dctr.h)."""
+    _dev_check(x, dy, dx)
+    _C.check(_C.lib().dctr_bi_interaction_bwd(_ptr(x), x.shape[0], x.stride(0), int(fields), int(dim), _ptr(dy), dy.stride(0),
+                                              _ptr(dx), dx.stride(0), int(bool(accumulate)), _C.stream_ptr()),
+             "dctr_bi_interaction_bwd")
+
+
+def inner_product_bwd(x, fields, dim, dy, dx, accumulate=False):
+    """Backward of inner_product(reduce_sum=True) on a strided buffer: dy [B, >= F(F-1)/2], dx [B, >= F*E]."""
+    _dev_check(x, dy, dx)
+    _C.check(_C.lib().dctr_inner_product_bwd(_ptr(x), x.shape[0], x.stride(0), int(fields), int(dim), _ptr(dy), dy.stride(0),
+                                             _ptr(dx), dx.stride(0), int(bool(accumulate)), _C.stream_ptr()),
+             "dctr_inner_product_bwd")
+
+
 def crossnet_bwd(x, d, kernels, bias, parameterization, dy, d_kernels, d_bias, dx, accumulate=False):
     """Backward of dctr_crossnet_fwd: x [B, >= d] the forward input, dy [B, >= d]; d_kernels / d_bias are ACCUMULATED,
     dx [B, >= d] is written (or added to with ``accumulate``)."""

@@ -130,7 +130,7 @@ def dnn_forward(dnn, x):
 
 
 def model_logits(model, staged, lo, hi):
-    """Pre-sigmoid logits [B] of the four in-scope models, torch ops only."""
+    """Pre-sigmoid logits [B] of the four in-scope models and their siblings, torch ops only."""
     sp = model.stage_plan
     parts, extra, lin, fms = stage_forward(sp, staged, lo, hi)
     name = model.name
@@ -155,6 +155,33 @@ def model_logits(model, staged, lo, hi):
         else:
             score = torch.where(km, score, torch.zeros_like(score))
         parts[extra["hist"]] = (score.unsqueeze(1) @ k).squeeze(1)
+    if name == "AFM":                       # models/afm.py:45-58: linear logit + AFMLayer (or FM) per group
+        logit = torch.zeros(hi - lo, device=sp.device)
+        if model.use_attention:
+            for g, layer in zip(model.groups, model.afm_layers):
+                first, n, dim = sp.group_slices[g]
+                embs = [parts[k] for k, f in enumerate(sp.fields) if first <= f.out_offset < first + n * dim]
+                ii = [i for i in range(n - 1) for _ in range(i + 1, n)]
+                jj = [j for i in range(n - 1) for j in range(i + 1, n)]
+                bi = torch.stack([embs[i] for i in ii], dim=1) * torch.stack([embs[j] for j in jj], dim=1)     # [B,P,E]
+                att = torch.relu(bi @ layer.w("attention_W") + layer.w("attention_b"))
+                score = torch.softmax(att @ layer.w("projection_h"), dim=1)
+                logit = logit + ((score * bi).sum(1) @ layer.w("projection_p")).reshape(-1)
+        if lin is not None:
+            logit = logit + lin
+        for f in fms:
+            logit = logit + f
+        return logit + model.prediction.w("global_bias")
+    if name == "NFM":                       # models/nfm.py:49-58: DNN over [BiInteractionPooling(embeddings), dense]
+        x0 = torch.stack(parts[:len(sp.fields)], dim=1)
+        parts[extra["bi_interaction"]] = 0.5 * (x0.sum(1).pow(2) - (x0 * x0).sum(1))
+        parts = parts[extra["bi_interaction"]:]
+    if name == "PNN" and "inner_product" in extra:      # models/pnn.py:52-66, InnerProductLayer(reduce_sum) pair order
+        n = len(sp.fields)
+        ii = [i for i in range(n - 1) for _ in range(i + 1, n)]
+        jj = [j for i in range(n - 1) for j in range(i + 1, n)]
+        parts[extra["inner_product"]] = (torch.stack([parts[i] for i in ii], dim=1) *
+                                         torch.stack([parts[j] for j in jj], dim=1)).sum(-1)
     x = torch.cat(parts, dim=-1)
     if name == "DCN":
         outs = []

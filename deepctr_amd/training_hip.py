@@ -1,11 +1,12 @@
 """HIP training step — SURVEY.md §8(f) rank 1: backward + optimizer of the hot path on HIP kernels.
 
-Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer: DeepFM, WDL, FNN),
+Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer: DeepFM, WDL, FNN;
+NFM and PNN add their interaction layer's forward / backward kernel in front of the DNN), DCN and xDeepFM,
 sequence features included: forward = ``dctr_embed_pool`` per sequence feature + ``dctr_embed_gather_fm`` +
 ``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` → ``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` →
 ``dctr_embed_pool_bwd`` → ``dctr_opt_multi`` (one launch over every parameter).  No torch autograd, no torch
-optimizer: PyTorch only owns the buffers.  Models / options outside that family keep the torch-autograd step of
-``training.py`` (the interaction-layer backward kernels for CIN / CrossNet / attention do not exist yet).
+optimizer: PyTorch only owns the buffers.  Models / options outside that family (DIN, AFM, Dice / BatchNormalization /
+dropout in training mode) keep the torch-autograd step of ``training.py``: their attention backward kernels do not exist yet.
 
 Semantics follow tf.keras as the reference uses it (``model.compile("adam", "binary_crossentropy")``,
 examples/run_classification_criteo.py:44-50; also "adagrad", "rmsprop", "sgd" by name with tf.keras' defaults): Adam lr
@@ -25,13 +26,17 @@ def supported(model):
     sp = getattr(model, "stage_plan", None)
     dnn = getattr(model, "dnn", None)
     kind = type(model).__name__
-    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM"):
+    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM", "_NFM", "_PNN"):
         return False
-    if sp.lin_only or len(sp.fm_group_names) > 1 or sp.extra_offsets or not sp.all_dim4 or sp.max_dim > 64:
+    if sp.lin_only or len(sp.fm_group_names) > 1 or not sp.all_dim4 or sp.max_dim > 64:
         return False
-    if kind in ("_DeepFM", "_xDeepFM") and (dnn is None or not dnn.kernels):
+    if sp.extra_offsets and kind not in ("_NFM", "_PNN"):       # the interaction columns those two reserve in dnn_in
+        return False
+    if kind in ("_DeepFM", "_xDeepFM", "_NFM", "_PNN") and (dnn is None or not dnn.kernels):
         return False
     if kind == "_xDeepFM" and model.cin is not None and model.cin.activation not in ("relu", "linear", "sigmoid", "tanh"):
+        return False
+    if getattr(model, "bi_dropout", 0):
         return False
     if dnn is not None:
         if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
@@ -101,6 +106,8 @@ class HipTrainer(object):
             self.p_dense_lin = param(model.linear.w("linear_kernel"), l2l)
             self.dense_rows = torch.as_tensor(sp.dense_lin_rows, dtype=torch.int32, device=model.device)
         self.is_dcn = type(model).__name__ == "_DCN"
+        self.is_nfm = type(model).__name__ == "_NFM"
+        self.is_pnn = type(model).__name__ == "_PNN"
         self.p_kernels = [param(k, l2d) for k in model.dnn.kernels] if model.dnn is not None else []
         self.p_biases = [param(b) for b in model.dnn.biases] if model.dnn is not None else []
         self.p_head = param(model.dense.w("kernel"))
@@ -195,6 +202,37 @@ class HipTrainer(object):
                         [p.g.reshape(-1, p.g.shape[-1]) for p in self.p_cin_f], [p.g for p in self.p_cin_b], dx=buf["dx"],
                         accumulate=True, fields=nf, dim=dim)
 
+    def _nfm_forward_backward(self, ws, buf, y, binary):
+        """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) | dense] -> Dense(1) + linear logit."""
+        model, sp = self.model, self.model.stage_plan
+        off = sp.extra_offsets["bi_interaction"]
+        x = ws["dnn_in"][:, off:]
+        ops.bi_interaction(ws["dnn_in"], fields=model.n_emb, dim=model.emb_dim, out=x)
+        ops.mlp(x, model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
+                add=[ws["lin"]] if sp.has_linear else [], global_bias=None if self.p_gbias is None else self.p_gbias.w,
+                sigmoid_out=binary, in_dim=model.dnn_in_dim, out=buf["pred"], save_acts=buf["acts"])
+        self._loss_grad(buf, y, binary)
+        dx = buf["dx"]
+        ops.mlp_bwd(x, model.dnn_in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
+                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=dx[:, off:])
+        ops.bi_interaction_bwd(ws["dnn_in"], model.n_emb, model.emb_dim, dx[:, off:], dx)
+
+    def _pnn_forward_backward(self, ws, buf, y, binary):
+        """PNN, inner-product form (models/pnn.py:52-72): DNN over [embeddings | pair inner products | dense] -> Dense(1)."""
+        model, sp = self.model, self.model.stage_plan
+        if model.use_inner:
+            off = sp.extra_offsets["inner_product"]
+            ops.inner_product(ws["dnn_in"], True, fields=model.n_emb, dim=model.emb_dim, out=ws["dnn_in"][:, off:])
+        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
+                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
+                out=buf["pred"], save_acts=buf["acts"])
+        self._loss_grad(buf, y, binary)
+        dx = buf["dx"]
+        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
+                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=dx)
+        if model.use_inner:
+            ops.inner_product_bwd(ws["dnn_in"], model.n_emb, model.emb_dim, dx[:, off:], dx, accumulate=True)
+
     def _dcn_forward_backward(self, ws, buf, y, B, binary):
         """DCN (models/dcn.py:45-78): [CrossNet(dnn_in), DNN(dnn_in)] -> Dense(1) + linear logit -> PredictionLayer."""
         model, sp = self.model, self.model.stage_plan
@@ -258,6 +296,10 @@ class HipTrainer(object):
             sp.pool_trace = None
         if self.is_dcn:
             self._dcn_forward_backward(ws, buf, y, B, binary)
+        elif self.is_nfm:
+            self._nfm_forward_backward(ws, buf, y, binary)
+        elif self.is_pnn:
+            self._pnn_forward_backward(ws, buf, y, binary)
         else:
             self._deepfm_forward_backward(ws, buf, y, binary)
         # embedding / linear / FM backward

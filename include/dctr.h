@@ -423,6 +423,14 @@ int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
 int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, int32_t n, const float* w, const float* dlogit, float* dx,
                     int64_t dx_stride, float* d_w, void* stream);
 
+/* backward of dctr_bi_interaction_fwd (interaction.py:190-203): dx[b,f,:] = dy[b,:] * (sum_f' x[b,f',:] - x[b,f,:]),
+ * and of dctr_inner_product_fwd with reduce_sum (interaction.py:655-678): dx[b,i,:] = sum_{j != i} dy[b,pair(i,j)] x[b,j,:].
+ * x as in the forward; dy [B, dy_stride]; dx [B, dx_stride] first F*E columns written, or added to with accumulate=1. */
+int dctr_bi_interaction_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
+                            int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream);
+int dctr_inner_product_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
+                           int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream);
+
 /* backward of dctr_crossnet_fwd (interaction.py:405-424); x_l are recomputed, nothing is saved by the forward.
  * vector: one fused kernel.  matrix: rocBLAS GEMMs + elementwise kernels through the workspace. */
 typedef struct {

@@ -10,7 +10,8 @@ from tests.util import assert_close, golden_meta, load_golden, sigmoid_inv
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["model_deepfm_hash", "model_dcn_matrix", "model_xdeepfm", "model_din_big_wn0"])
+@pytest.mark.parametrize("name", ["model_deepfm_hash", "model_dcn_matrix", "model_xdeepfm", "model_din_big_wn0", "model_afm",
+                                  "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner", "model_pnn_plain", "model_nfm"])
 def test_torch_training_forward_matches_hip_forward(device, name):
     from deepctr_amd import training
     from tests.test_gpu_models import build_model, well_conditioned_rows
@@ -50,3 +51,30 @@ def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
     p = model.predict(feed, batch_size=512)
     assert p.shape == (n, 1) and np.isfinite(p).all()
     assert isinstance(model.train_on_batch({k: v[:64] for k, v in feed.items()}, y[:64]), float)
+
+
+@pytest.mark.parametrize("kind,on_hip", [("NFM", True), ("PNN", True), ("AFM", False)])
+def test_sibling_models_fit(device, kind, on_hip):
+    """fit() of the sibling models: NFM / PNN on the HIP training step, AFM on the torch-autograd step."""
+    from deepctr_amd import models
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    rng = np.random.RandomState(3)
+    n = 2048
+    sparse = [SparseFeat("a", 20, 8), SparseFeat("b", 30, 8, use_hash=True), SparseFeat("c", 12, 8)]
+    cols = sparse + ([] if kind == "AFM" else [DenseFeat("d", 2)])
+    feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 10 ** 6, n), "c": rng.randint(0, 12, n),
+            "d": rng.rand(n, 2).astype(np.float32)}
+    y = (feed["a"] % 2).astype(np.float32)
+    if kind == "PNN":
+        model = models.PNN(cols, dnn_hidden_units=(32, 16), device=device)
+    elif kind == "NFM":
+        model = models.NFM(cols, cols, dnn_hidden_units=(32, 16), device=device)
+    else:
+        model = models.AFM(cols, cols, device=device)
+    feed = {k: v for k, v in feed.items() if k in [c.name for c in cols]}
+    model.compile("adam", "binary_crossentropy")
+    before = model.evaluate(feed, y, batch_size=512)
+    h = model.fit(feed, y, batch_size=128, epochs=12, verbose=0)
+    assert (getattr(model, "_hip_trainer", None) is not None) == on_hip
+    after = model.evaluate(feed, y, batch_size=512)
+    assert h.history["loss"][-1] < h.history["loss"][0] and after < before - 0.02, (before, after, h.history["loss"])

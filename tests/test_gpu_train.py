@@ -147,6 +147,43 @@ def test_hip_training_gradients_match_torch_autograd(device, E, hashed, kind):
         assert_close(p.g.cpu().numpy(), gref.cpu().numpy(), rtol=2e-4, atol=2e-7, what="grad of %s" % (tuple(p.w.shape),))
 
 
+@pytest.mark.parametrize("B,F,E", [(1, 2, 4), (70, 26, 16), (257, 7, 5)])
+def test_bi_interaction_and_inner_product_bwd_match_autograd(device, B, F, E):
+    """dctr_bi_interaction_bwd / dctr_inner_product_bwd on strided buffers (written and accumulated) against torch autograd
+    (atol covers the summation order of sum_f x, |x| ~ 0.5, F terms, times |dy| ~ 3)."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(31)
+    P = F * (F - 1) // 2
+    x = dev((rng.standard_normal((B, F, E)) * 0.5).astype(np.float32), device)
+    buf = torch.zeros(B, F * E + 3, device=device)
+    buf[:, :F * E] = x.reshape(B, -1)
+    xa = x.clone().requires_grad_(True)
+    # BiInteractionPooling
+    dy = dev(rng.standard_normal((B, E + 2)).astype(np.float32), device)
+    (0.5 * (xa.sum(1).pow(2) - (xa * xa).sum(1)) * dy[:, :E]).sum().backward()
+    dx = torch.full((B, F * E + 5), 7.0, device=device)
+    ops.bi_interaction_bwd(buf, F, E, dy, dx)
+    assert_close(dx[:, :F * E].cpu().numpy(), xa.grad.reshape(B, -1).cpu().numpy(), rtol=1e-4, atol=2e-5, what="bi bwd")
+    assert float((dx[:, F * E:] - 7.0).abs().max()) == 0.0
+    ops.bi_interaction_bwd(buf, F, E, dy, dx, accumulate=True)
+    assert_close(dx[:, :F * E].cpu().numpy(), 2 * xa.grad.reshape(B, -1).cpu().numpy(), rtol=1e-4, atol=2e-5, what="bi bwd acc")
+    # InnerProductLayer(reduce_sum=True), pairs in itertools.combinations order
+    xa.grad = None
+    ii = [i for i in range(F - 1) for _ in range(i + 1, F)]
+    jj = [j for i in range(F - 1) for j in range(i + 1, F)]
+    dp = dev(rng.standard_normal((B, P + 1)).astype(np.float32), device)
+    ((xa[:, ii] * xa[:, jj]).sum(-1) * dp[:, :P]).sum().backward()
+    y = torch.empty(B, P, device=device)
+    ops.inner_product(buf, True, fields=F, dim=E, out=y)
+    assert_close(y.cpu().numpy(), (x[:, ii] * x[:, jj]).sum(-1).cpu().numpy(), rtol=1e-4, atol=1e-6, what="ip fwd order")
+    dx = torch.full((B, F * E + 5), 1.0, device=device)
+    ops.inner_product_bwd(buf, F, E, dp, dx, accumulate=True)
+    assert_close(dx[:, :F * E].cpu().numpy() - 1.0, xa.grad.reshape(B, -1).cpu().numpy(), rtol=1e-4, atol=2e-5, what="ip bwd acc")
+    ops.inner_product_bwd(buf, F, E, dp, dx)
+    assert_close(dx[:, :F * E].cpu().numpy(), xa.grad.reshape(B, -1).cpu().numpy(), rtol=1e-4, atol=2e-5, what="ip bwd")
+    assert float((dx[:, F * E:] - 1.0).abs().max()) == 0.0
+
+
 def test_deepfm_fit_runs_on_the_hip_step_and_learns(device):
     rng = np.random.RandomState(6)
     model, cols = _deepfm(device, E=16, hidden=(64, 32))
@@ -221,7 +258,7 @@ def test_opt_multi_matches_torch_optimizers(device, kind):
         assert_close(a.cpu().numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6, what=kind)
 
 
-@pytest.mark.parametrize("fixture", ["model_wdl", "model_fnn"])
+@pytest.mark.parametrize("fixture", ["model_wdl", "model_fnn", "model_nfm", "model_nfm_fixed", "model_pnn_inner", "model_pnn_plain"])
 def test_hip_training_gradients_with_sequence_features(device, fixture):
     """Pooling backward (sum / mean / max, length- and mask-form, weighted, shared and hashed tables) inside the HIP step,
     against torch autograd, on the reference-shaped mixed feature set of the golden fixtures."""
