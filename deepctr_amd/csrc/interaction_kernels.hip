@@ -347,6 +347,124 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// CrossNetMix (interaction.py:511-549, DCN-Mix): per layer, per expert e
+//     g_e = x_l . G_e ;  v = tanh(V_e^T x_l) ;  v = tanh(C_e v) ;  out_e = x_0 * (U_e v + bias)
+//     x_{l+1} = sum_e softmax(g)_e out_e + x_l  =  x_0 * (sum_e U_e (p_e v_e) + bias) + x_l        (sum_e p_e = 1)
+// One workgroup owns R rows for every layer: x_0 / x_l stay in LDS ([d][R], so a column of R rows is one broadcast
+// read), stage 1 gives one thread per low-rank / gating column (a d-long dot per row), stage 2 the r x r mixing and
+// the softmax weights, stage 3 one thread per output column.  Weights are read in the reference's own layouts
+// (U, V [L,experts,d,r]; C [L,experts,r,r]) from L2: 3 * experts * d * r * 4 B per layer per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int d,
+                                                        const float* __restrict__ U, const float* __restrict__ V,
+                                                        const float* __restrict__ C, const float* __restrict__ G,
+                                                        const float* __restrict__ bias, int layers, int ne, int r,
+                                                        float* __restrict__ y, int64_t y_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = ne * r;
+    float* x0 = smem;                     // [d][R]
+    float* xl = x0 + (size_t)d * R;       // [d][R]
+    float* h1 = xl + (size_t)d * R;       // [H][R]   tanh(V^T x_l)
+    float* h2 = h1 + (size_t)H * R;       // [H][R]   p_e * tanh(C v)
+    float* gate = h2 + (size_t)H * R;     // [ne][R]
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * R;
+    for (int j = tid; j < d; j += 256) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int64_t b = b0 + q < batch ? b0 + q : batch - 1;
+            const float v = x[b * x_stride + j];
+            x0[j * R + q] = v;
+            xl[j * R + q] = v;
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < layers; ++l) {
+        const float* Vl = V + (size_t)l * ne * d * r;
+        const float* Ul = U + (size_t)l * ne * d * r;
+        const float* Cl = C + (size_t)l * ne * r * r;
+        // stage 1: low-rank projections and gating scores
+        for (int c = tid; c < H + ne; c += 256) {
+            const float* w;
+            int wstride;
+            if (c < H) {
+                const int e = c / r, k = c - e * r;
+                w = Vl + (size_t)e * d * r + k;
+                wstride = r;
+            } else {
+                w = G + (size_t)(c - H) * d;
+                wstride = 1;
+            }
+            float acc[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = 0.f;
+#pragma unroll 4
+            for (int j = 0; j < d; ++j) {
+                const float wv = w[(size_t)j * wstride];
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[q] = fmaf(xl[j * R + q], wv, acc[q]);
+            }
+            if (c < H) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) h1[c * R + q] = tanhf(acc[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) gate[(c - H) * R + q] = acc[q];
+            }
+        }
+        __syncthreads();
+        // stage 2: r x r mixing in the low-rank space, scaled by the expert's softmax weight
+        for (int c = tid; c < H; c += 256) {
+            const int e = c / r, i = c - e * r;
+            const float* cw = Cl + ((size_t)e * r + i) * r;
+            float acc[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = 0.f;
+            for (int m = 0; m < r; ++m) {
+                const float wv = cw[m];
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[q] = fmaf(h1[(e * r + m) * R + q], wv, acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                float mx = gate[q];
+                for (int t = 1; t < ne; ++t) mx = fmaxf(mx, gate[t * R + q]);
+                float den = 0.f;
+                for (int t = 0; t < ne; ++t) den += expf(gate[t * R + q] - mx);
+                h2[c * R + q] = tanhf(acc[q]) * (expf(gate[e * R + q] - mx) / den);
+            }
+        }
+        __syncthreads();
+        // stage 3: back to d columns, Hadamard with x_0, residual
+        for (int j = tid; j < d; j += 256) {
+            float acc[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = 0.f;
+            for (int e = 0; e < ne; ++e) {
+                const float* uw = Ul + ((size_t)e * d + j) * r;
+                for (int k = 0; k < r; ++k) {
+                    const float wv = uw[k];
+#pragma unroll
+                    for (int q = 0; q < R; ++q) acc[q] = fmaf(h2[(e * r + k) * R + q], wv, acc[q]);
+                }
+            }
+            const float bj = bias[(size_t)l * d + j];
+#pragma unroll
+            for (int q = 0; q < R; ++q) xl[j * R + q] = fmaf(x0[j * R + q], acc[q] + bj, xl[j * R + q]);
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < d; j += 256) {
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (b0 + q < batch) y[(b0 + q) * y_stride + j] = xl[j * R + q];
+    }
+}
+
+size_t cross_mix_lds_bytes(int d, int ne, int r, int R) { return ((size_t)2 * d + 2 * (size_t)ne * r + ne) * R * sizeof(float); }
+
 int pow2_at_least(int v, int cap) {
     int l = 1;
     while (l < v && l < cap) l <<= 1;
@@ -498,4 +616,37 @@ extern "C" int dctr_bi_interaction_fwd(const float* x, int64_t batch, int64_t x_
     DCTR_LAUNCH(bi_interaction_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch, fields, dim, y,
                 y_stride);
     return dctr_launch_status("dctr_bi_interaction_fwd");
+}
+
+extern "C" int dctr_crossnet_mix_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* U, const float* V,
+                                     const float* C, const float* gating, const float* bias, int32_t layers, int32_t experts,
+                                     int32_t low_rank, float* y, int64_t y_stride, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && dim >= 1 && layers >= 0 && experts >= 1 && low_rank >= 1, DCTR_E_DIM, "crossnet_mix_fwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= dim && y_stride >= dim, DCTR_E_DIM, "crossnet_mix_fwd: stride smaller than a row");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x && y, DCTR_E_NULL, "crossnet_mix_fwd: null x / y");
+    DCTR_REQUIRE(layers == 0 || (U && V && C && gating && bias), DCTR_E_NULL, "crossnet_mix_fwd: null weights");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_cap = 64 * 1024;
+    // more rows per workgroup = fewer passes over the weights; fewer when the batch would not fill the chip or LDS is short
+    int R = 8;
+    while (R > 1 && (cross_mix_lds_bytes(dim, experts, low_rank, R) > lds_cap || dctr_ceil_div(batch, (int64_t)R) < 512)) R >>= 1;
+    const size_t lds = cross_mix_lds_bytes(dim, experts, low_rank, R);
+    DCTR_REQUIRE(lds <= lds_cap, DCTR_E_UNSUPPORTED, "crossnet_mix_fwd: dim %d x experts %d x low_rank %d does not fit LDS", dim,
+                 experts, low_rank);
+    const dim3 grid((unsigned)dctr_ceil_div(batch, (int64_t)R));
+#define DCTR_MIX(RR)                                                                                                            \
+    DCTR_LAUNCH(cross_mix_kernel<RR>, grid, dim3(256), lds, st, x, x_stride, batch, dim, U, V, C, gating, bias, layers, experts, \
+                low_rank, y, y_stride)
+    if (R == 8) {
+        DCTR_MIX(8);
+    } else if (R == 4) {
+        DCTR_MIX(4);
+    } else if (R == 2) {
+        DCTR_MIX(2);
+    } else {
+        DCTR_MIX(1);
+    }
+#undef DCTR_MIX
+    return dctr_launch_status("dctr_crossnet_mix_fwd");
 }

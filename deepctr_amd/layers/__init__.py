@@ -3,7 +3,7 @@
 siblings need — SURVEY.md §8a)."""
 from .activation import Dice
 from .core import DNN, Dense, LocalActivationUnit, PredictionLayer
-from .interaction import AFMLayer, BiInteractionPooling, CIN, CrossNet, FM, InnerProductLayer
+from .interaction import AFMLayer, BiInteractionPooling, CIN, CrossNet, CrossNetMix, FM, InnerProductLayer
 from .sequence import AttentionSequencePoolingLayer, SequencePoolingLayer, WeightedSequenceLayer
 from .utils import Concat, Hash, Linear, NoMask, add_func, combined_dnn_input, concat_func
 
@@ -14,6 +14,7 @@ custom_objects = {
     'AFMLayer': AFMLayer,
     'BiInteractionPooling': BiInteractionPooling,
     'CrossNet': CrossNet,
+    'CrossNetMix': CrossNetMix,
     'CIN': CIN,
     'InnerProductLayer': InnerProductLayer,
     'LocalActivationUnit': LocalActivationUnit,

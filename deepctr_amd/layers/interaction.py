@@ -176,6 +176,65 @@ class CrossNet(Layer):
         return input_shape
 
 
+class CrossNetMix(Layer):
+    """Mirror of deepctr.layers.interaction.CrossNetMix (:438-560): the cross part of DCN-Mix (mixture of low-rank experts)."""
+
+    def __init__(self, low_rank=32, num_experts=4, layer_num=2, l2_reg=0, seed=1024, **kwargs):
+        self.low_rank = low_rank
+        self.num_experts = num_experts
+        self.layer_num = layer_num
+        self.l2_reg = l2_reg
+        self.seed = seed
+        super(CrossNetMix, self).__init__(**kwargs)
+
+    def build(self, input_shape):
+        if len(input_shape) != 2:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 2 dimensions" % (len(input_shape),))
+        self.build_for(int(input_shape[-1]))
+
+    def build_for(self, dim):
+        if self.built:
+            return self
+        from .core import Dense
+        for k in ('U_list', 'V_list'):
+            for i in range(self.layer_num):
+                self.add_weight(k + str(i), (self.num_experts, dim, self.low_rank), GlorotNormal(seed=self.seed))
+        for i in range(self.layer_num):
+            self.add_weight('C_list' + str(i), (self.num_experts, self.low_rank, self.low_rank), GlorotNormal(seed=self.seed))
+        # one Dense(1, use_bias=False) per expert, shared by every cross layer (:502, :524)
+        self.gating = [Dense(1, use_bias=False, device=self.device).build_for(dim) for _ in range(self.num_experts)]
+        self._sublayers.extend(self.gating)
+        for i in range(self.layer_num):
+            self.add_weight('bias' + str(i), (dim, 1), Zeros())
+        self.dim = dim
+        self.built = True
+        return self
+
+    def packed(self):
+        """(U, V [L,experts,d,r], C [L,experts,r,r], gating [experts,d], bias [L,d]) as the C ABI takes them."""
+        if self.layer_num == 0:
+            return None, None, None, None, None
+        st = lambda k: torch.stack([self.w(k + str(i)) for i in range(self.layer_num)]).contiguous()   # noqa: E731
+        g = torch.stack([d.w('kernel').reshape(self.dim) for d in self.gating]).contiguous()
+        b = torch.stack([self.w('bias%d' % i).reshape(self.dim) for i in range(self.layer_num)]).contiguous()
+        return st('U_list'), st('V_list'), st('C_list'), g, b
+
+    def call(self, inputs, **kwargs):
+        if inputs.dim() != 2:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 2 dimensions" % (inputs.dim()))
+        return ops.crossnet_mix(inputs, *self.packed())
+
+    def get_config(self):
+        config = {'low_rank': self.low_rank, 'num_experts': self.num_experts, 'layer_num': self.layer_num,
+                  'l2_reg': self.l2_reg, 'seed': self.seed}
+        base = super(CrossNetMix, self).get_config()
+        base.update(config)
+        return base
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+
 class FM(Layer):
     def build(self, input_shape):
         if len(input_shape) != 3:

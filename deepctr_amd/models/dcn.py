@@ -14,8 +14,8 @@ from ._common import FeatureModel
 
 class _DCN(FeatureModel):
     def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units,
-                 seed, dnn_dropout, dnn_use_bn, dnn_activation, task, device):
-        super(_DCN, self).__init__("DCN", list(dnn_feature_columns), device, task)
+                 seed, dnn_dropout, dnn_use_bn, dnn_activation, task, device, name="DCN"):
+        super(_DCN, self).__init__(name, list(dnn_feature_columns), device, task)
         with name_scope():
             self.build_linear(linear_feature_columns, seed)
             self.build_embeddings(dnn_feature_columns, seed)
@@ -29,13 +29,15 @@ class _DCN(FeatureModel):
                                          device=self.device).build_for(d))
                 width += dnn_hidden_units[-1]
             if cross_num > 0:
-                self.cross = self._add(CrossNet(cross_num, parameterization=cross_parameterization,
-                                                device=self.device).build_for(d))
+                self.cross = self._add(self._make_cross(cross_num, cross_parameterization).build_for(d))
                 width += d
             self.width = width
             self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(width))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
         self._stack = {}
+
+    def _make_cross(self, cross_num, cross_parameterization):
+        return CrossNet(cross_num, parameterization=cross_parameterization, device=self.device)
 
     def _begin(self):
         super(_DCN, self)._begin()
@@ -51,25 +53,28 @@ class _DCN(FeatureModel):
             stack = self._stack[B] = torch.zeros(B, (self.width + 3) // 4 * 4, dtype=torch.float32, device=self.device)
         col = 0
         if self.cross is not None:          # stack_out = Concatenate()([cross_out, deep_out])  (dcn.py:61)
-            ks, bs = self._cross_packed
-            import ctypes
-            from .. import _C
-            mode = _C.CROSS_VECTOR if self.cross.parameterization == "vector" else _C.CROSS_MATRIX
-            need = int(_C.lib().dctr_crossnet_workspace_bytes(d, self.cross.layer_num, mode, ctypes.c_void_p(ks.data_ptr())))
-            if need and (self._cross_ws is None or self._cross_ws.numel() * 4 < need):
-                self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)   # re-packed W rows
-            _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(ws["dnn_in"].data_ptr()), B, d, ws["dnn_in"].stride(0),
-                                                ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()),
-                                                self.cross.layer_num, mode, ctypes.c_void_p(stack.data_ptr()),
-                                                stack.stride(0),
-                                                ctypes.c_void_p(self._cross_ws.data_ptr()) if need else None, need,
-                                                _C.stream_ptr()), "dctr_crossnet_fwd")
+            self._run_cross(ws["dnn_in"], B, d, stack)
             col = d
         if self.dnn is not None:
             ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
                     in_dim=d, out=stack[:, col:])
         ops.mlp(stack, [], [], "linear", head_w=self.dense.w('kernel'), add=self._logits_to_add(ws),
                 global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=self.width, out=out)
+
+    def _run_cross(self, dnn_in, B, d, stack):
+        ks, bs = self._cross_packed
+        import ctypes
+        from .. import _C
+        mode = _C.CROSS_VECTOR if self.cross.parameterization == "vector" else _C.CROSS_MATRIX
+        need = int(_C.lib().dctr_crossnet_workspace_bytes(d, self.cross.layer_num, mode, ctypes.c_void_p(ks.data_ptr())))
+        if need and (self._cross_ws is None or self._cross_ws.numel() * 4 < need):
+            self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)   # re-packed W rows
+        _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(dnn_in.data_ptr()), B, d, dnn_in.stride(0),
+                                            ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()),
+                                            self.cross.layer_num, mode, ctypes.c_void_p(stack.data_ptr()),
+                                            stack.stride(0),
+                                            ctypes.c_void_p(self._cross_ws.data_ptr()) if need else None, need,
+                                            _C.stream_ptr()), "dctr_crossnet_fwd")
 
 
 def DCN(linear_feature_columns, dnn_feature_columns, cross_num=2, cross_parameterization='vector',

@@ -365,6 +365,28 @@ def afm(x, attention_W, attention_b, projection_h, projection_p, fields=None, di
     return y
 
 
+def crossnet_mix(x, U, V, C, gating, bias, dim=None, out=None):
+    """CrossNetMix.call (reference interaction.py:511-549): x [B, >= d]; U, V [L,experts,d,r]; C [L,experts,r,r];
+    gating [experts,d]; bias [L,d].  ``out``: a 2-D (strided) view to write [B,d] into."""
+    _dev_check(x, U, V, C, gating, bias)
+    if x.dim() != 2:
+        raise ValueError("Unexpected inputs dimensions %d, expect to be 2 dimensions" % x.dim())
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        x = _f32c(x, "x")
+    d = x.shape[1] if dim is None else int(dim)
+    L = 0 if U is None else U.shape[0]
+    ne, r = (1, 1) if U is None else (U.shape[1], U.shape[3])
+    if L:
+        U, V, C, gating, bias = (_f32c(t, n) for t, n in ((U, "U"), (V, "V"), (C, "C"), (gating, "gating"), (bias, "bias")))
+        if tuple(U.shape) != (L, ne, d, r) or tuple(V.shape) != (L, ne, d, r) or tuple(C.shape) != (L, ne, r, r) \
+                or gating.numel() != ne * d or bias.numel() != L * d:
+            raise ValueError("crossnet_mix: weight shapes do not match [L,experts,d,r] / [L,experts,r,r] / [experts,d] / [L,d]")
+    y = torch.empty(x.shape[0], d, dtype=torch.float32, device=x.device) if out is None else out
+    _C.check(_C.lib().dctr_crossnet_mix_fwd(_ptr(x), x.shape[0], d, x.stride(0), _ptr(U), _ptr(V), _ptr(C), _ptr(gating),
+                                            _ptr(bias), L, ne, r, _ptr(y), y.stride(0), _C.stream_ptr()), "dctr_crossnet_mix_fwd")
+    return y
+
+
 def bi_interaction(x, fields=None, dim=None, out=None):
     """BiInteractionPooling.call (reference interaction.py:190-203): x [B,F,E] -> [B,1,E]; with ``fields``/``dim`` x is a
     2-D buffer read in place and ``out`` a 2-D (strided) view to write [B,E] into."""

@@ -183,7 +183,24 @@ def model_logits(model, staged, lo, hi):
         parts[extra["inner_product"]] = (torch.stack([parts[i] for i in ii], dim=1) *
                                          torch.stack([parts[j] for j in jj], dim=1)).sum(-1)
     x = torch.cat(parts, dim=-1)
-    if name == "DCN":
+    if name == "DCNMix":                    # models/dcnmix.py:53-68 with CrossNetMix (interaction.py:511-549)
+        outs = []
+        if model.cross is not None:
+            cr = model.cross
+            x0 = xl = x
+            for i in range(cr.layer_num):
+                U, V, C, b = cr.w("U_list%d" % i), cr.w("V_list%d" % i), cr.w("C_list%d" % i), cr.w("bias%d" % i).reshape(-1)
+                gate = torch.softmax(torch.cat([xl @ g.w("kernel") for g in cr.gating], dim=-1), dim=-1)       # [B,experts]
+                moe = torch.zeros_like(xl)
+                for e in range(cr.num_experts):
+                    v = torch.tanh(torch.tanh(xl @ V[e]) @ C[e].t())
+                    moe = moe + gate[:, e:e + 1] * (x0 * (v @ U[e].t() + b))
+                xl = moe + xl
+            outs.append(xl)
+        if model.dnn is not None:
+            outs.append(dnn_forward(model.dnn, x))
+        logit = (torch.cat(outs, dim=-1) @ model.dense.w("kernel")).reshape(-1)
+    elif name == "DCN":
         outs = []
         if model.cross is not None:
             x0 = x

@@ -490,6 +490,27 @@ def gen_siblings():
     _run_pnn("model_pnn_plain", fixed, feed_f, {"dnn_hidden_units": [8], "use_inner": False, "use_outter": False})
 
 
+    # DCNMix (models/dcnmix.py:22-78) + the CrossNetMix layer on its own (interaction.py:438-560)
+    _run_model("model_dcnmix", "deepctr.models.dcnmix", "DCNMix", spec, spec, feed,
+               {"dnn_hidden_units": [16, 8], "cross_num": 2, "low_rank": 4, "num_experts": 3})
+    _run_model("model_dcnmix_crossonly", "deepctr.models.dcnmix", "DCNMix", fixed, fixed, feed_f,
+               {"dnn_hidden_units": [], "cross_num": 3, "low_rank": 8, "num_experts": 2})
+    _run_model("model_dcnmix_fixed", "deepctr.models.dcnmix", "DCNMix", fixed, fixed, feed_f, {"dnn_hidden_units": [32, 8]})
+    from deepctr.layers.interaction import CrossNetMix
+    out, meta = {}, {}
+    for tag, (Bm, d, r, ne, nl) in (("a", (9, 45, 4, 3, 2)), ("b", (5, 64, 32, 4, 1)), ("c", (7, 13, 2, 1, 3))):
+        S.reset()
+        x = (rng.standard_normal((Bm, d)) * 0.7).astype(np.float32)
+        layer = CrossNetMix(low_rank=r, num_experts=ne, layer_num=nl)
+        y = layer(T(x))
+        out["mix_%s_x" % tag], out["mix_%s_y" % tag] = x, np.asarray(y.a, dtype=np.float32)
+        for k, v in _weights_dict().items():
+            out["mix_%s_w/%s" % (tag, k)] = v
+        meta[tag] = {"low_rank": r, "num_experts": ne, "layer_num": nl}
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    _save("crossnet_mix", **out)
+
+
 def main():
     S.install(REF)
     S.WEIGHT_HOOK = weight_hook

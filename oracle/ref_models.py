@@ -264,6 +264,32 @@ def dcn(linear_cols, dnn_cols, weights, feed, cross_num=2, cross_parameterizatio
     return R.prediction_layer(final, weights["prediction_layer/global_bias"].astype(dt), task)
 
 
+def dcnmix(linear_cols, dnn_cols, weights, feed, cross_num=2, dnn_hidden_units=(256, 128, 64), low_rank=32, num_experts=4,
+           dnn_activation="relu", task="binary", dtype=np.float32, **_):
+    """deepctr/models/dcnmix.py:22-78.  Layer names follow creation order: the DNN creates no Dense; CrossNetMix.build
+    creates its ``num_experts`` gating Dense layers (dense .. dense_<n-1>), then the model's final Dense(1)."""
+    dt = np.dtype(dtype).type
+    lin = linear_logit(linear_cols, feed, weights, dt)
+    groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
+    dnn_in = _combined_dnn_input([e for g in groups.values() for e in g], dense)
+    outs = []
+    n_dense = 0
+    if cross_num > 0:
+        name = lambda i: "dense/kernel" if i == 0 else "dense_%d/kernel" % i   # noqa: E731
+        gating = [weights[name(e)].astype(dt) for e in range(num_experts)]
+        n_dense = num_experts
+        W = lambda k: [weights["cross_net_mix/%s%d" % (k, i)].astype(dt) for i in range(cross_num)]   # noqa: E731
+        outs.append(R.crossnet_mix(dnn_in, W("U_list"), W("V_list"), W("C_list"), gating, W("bias")))
+    if len(dnn_hidden_units) > 0:
+        outs.append(_dnn("dnn", dnn_in, weights, dt, dnn_activation))
+    if not outs:
+        raise NotImplementedError
+    stack = np.concatenate(outs, axis=-1)
+    head = weights[("dense_%d/kernel" % n_dense) if n_dense else "dense/kernel"].astype(dt)
+    final = _add(stack @ head, lin)
+    return R.prediction_layer(final, weights["prediction_layer/global_bias"].astype(dt), task)
+
+
 def xdeepfm(linear_cols, dnn_cols, weights, feed, cin_layer_size=(128, 128), cin_split_half=True,
             cin_activation="relu", dnn_activation="relu", task="binary", dtype=np.float32, **_):
     dt = np.dtype(dtype).type

@@ -140,6 +140,27 @@ def crossnet(x, kernels, biases, parameterization="vector"):
     return xl[:, :, 0]                                             # :423
 
 
+def crossnet_mix(x, U_list, V_list, C_list, gating, biases):
+    """CrossNetMix.call (interaction.py:511-549).  x [B,d]; per layer U, V [experts,d,r], C [experts,r,r], bias (d,1);
+    gating[e] (d,1) = the kernel of the e-th Dense(1, use_bias=False), shared by every layer (:502,:524)."""
+    x0 = np.asarray(x)[:, :, None]                                 # :516
+    xl = x0
+    for U, V, C, b in zip(U_list, V_list, C_list, biases):
+        outs, gates = [], []
+        for e in range(U.shape[0]):
+            gates.append(xl[:, :, 0] @ gating[e])                  # :524  [B,1]
+            v = np.tanh(np.einsum("ij,bjk->bik", V[e].T, xl))      # :528-531
+            v = np.tanh(np.einsum("ij,bjk->bik", C[e], v))         # :532-533
+            uv = np.einsum("ij,bjk->bik", U[e], v)                 # :536
+            outs.append((x0 * (uv + b))[:, :, 0])                  # :538-541
+        outs = np.stack(outs, 2)                                   # :544  [B,d,experts]
+        g = np.stack(gates, 1)                                     # :545  [B,experts,1]
+        g = np.exp(g - g.max(axis=1, keepdims=True))
+        g = g / g.sum(axis=1, keepdims=True)                       # softmax over experts :546
+        xl = np.matmul(outs, g) + xl                               # :546-547
+    return xl[:, :, 0]                                             # :548
+
+
 def _act(name, x):
     if name in (None, "linear"):
         return x

@@ -304,6 +304,14 @@ def squeeze(x, axis=None):
     return Tensor(np.squeeze(np.asarray(_arr(x)), axis=axis))
 
 
+def stack(values, axis=0, name=None):
+    return Tensor(np.stack([np.asarray(_arr(v)) for v in values], axis=axis))
+
+
+def _tanh(x, name=None):
+    return Tensor(np.tanh(np.asarray(_arr(x))))
+
+
 def tile(x, multiples):
     return Tensor(np.tile(np.asarray(_arr(x)), tuple(int(m) for m in multiples)))
 
@@ -857,7 +865,7 @@ def install(reference_root="/root/reference"):
     tf.bool = bool_
     for fn in (as_dtype, constant, cast, zeros, ones_like, zeros_like, as_string, not_equal, concat, reduce_sum,
                reduce_mean, reduce_max, square, tensordot, split, matmul, reshape, transpose, expand_dims, squeeze,
-               tile, where, multiply, divide, sigmoid, einsum, sequence_mask):
+               tile, where, multiply, divide, sigmoid, einsum, sequence_mask, stack):
         setattr(tf, fn.__name__, fn)
     tf.Tensor = Tensor
     strings = _mod("tensorflow.strings")
@@ -866,6 +874,7 @@ def install(reference_root="/root/reference"):
     tf.string_to_hash_bucket_fast = to_hash_bucket_fast
     nn = _mod("tensorflow.nn")
     nn.relu, nn.softmax, nn.bias_add, nn.conv1d, nn.sigmoid = _relu, _softmax, _bias_add, _conv1d, sigmoid
+    nn.tanh = _tanh
 
     keras = _mod("tensorflow.keras")
     K = _mod("tensorflow.keras.backend")

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat  # noqa: E402
-from deepctr_amd.models import DCN, DIN, DeepFM, xDeepFM  # noqa: E402
+from deepctr_amd.models import DCN, DIN, DCNMix, DeepFM, NFM, xDeepFM  # noqa: E402
 
 
 def init_on_device(model, seed=0):
@@ -62,7 +62,7 @@ def run(name, model, feed, B, steps, ring):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c2,c2_2launch,c3,dcn_v,dcn_m,c4,c5")
+    ap.add_argument("--configs", default="c2,c2_2launch,c3,dcn_v,dcn_m,dcn_mix,nfm,c4,c5")
     ap.add_argument("--steps", type=int, default=64)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -91,6 +91,16 @@ def main():
             init_on_device(m)
             run("DCN cross_num=2 %s" % par, m, criteo(rng, ring * 4096), 4096, args.steps, ring)
             del m
+    if "dcn_mix" in want:
+        m = DCNMix(cols16, cols16, cross_num=2, device=dev)
+        init_on_device(m)
+        run("DCNMix cross_num=2 r32 x4 experts", m, criteo(rng, ring * 4096), 4096, args.steps, ring)
+        del m
+    if "nfm" in want:
+        m = NFM(cols16, cols16, device=dev)
+        init_on_device(m)
+        run("NFM", m, criteo(rng, ring * 4096), 4096, args.steps, ring)
+        del m
     if "c4" in want:
         T, E, B = 50, 32, 2048
         cols = [SparseFeat("user", 100000, E), SparseFeat("gender", 2, E), SparseFeat("item_id", 1000001, E),

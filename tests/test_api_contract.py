@@ -150,7 +150,7 @@ def test_model_constructors_keep_the_reference_signatures():
     order (read from the committed table below, taken from deepctr/models/*.py), plus a trailing ``device``."""
     import inspect
     from deepctr_amd import models
-    ref = {   # name -> [(param, default or inspect._empty), ...]   (deepctr/models/{deepfm,dcn,xdeepfm,wdl,fnn,afm,pnn,nfm}.py, sequence/din.py)
+    ref = {   # name -> [(param, default or inspect._empty), ...]   (deepctr/models/{deepfm,dcn,dcnmix,xdeepfm,wdl,fnn,afm,pnn,nfm}.py, sequence/din.py)
         "DeepFM": ["linear_feature_columns", "dnn_feature_columns", ("fm_group", ("default_group",)),
                    ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0),
                    ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"), ("dnn_use_bn", False), ("task", "binary")],
@@ -158,6 +158,10 @@ def test_model_constructors_keep_the_reference_signatures():
                 ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("l2_reg_cross", 1e-5),
                 ("l2_reg_dnn", 0), ("seed", 1024), ("dnn_dropout", 0), ("dnn_use_bn", False), ("dnn_activation", "relu"),
                 ("task", "binary")],
+        "DCNMix": ["linear_feature_columns", "dnn_feature_columns", ("cross_num", 2), ("dnn_hidden_units", (256, 128, 64)),
+                   ("l2_reg_linear", 1e-5), ("l2_reg_embedding", 1e-5), ("low_rank", 32), ("num_experts", 4), ("l2_reg_cross", 1e-5),
+                   ("l2_reg_dnn", 0), ("seed", 1024), ("dnn_dropout", 0), ("dnn_use_bn", False), ("dnn_activation", "relu"),
+                   ("task", "binary")],
         "WDL": ["linear_feature_columns", "dnn_feature_columns", ("dnn_hidden_units", (256, 128, 64)), ("l2_reg_linear", 1e-5),
                 ("l2_reg_embedding", 1e-5), ("l2_reg_dnn", 0), ("seed", 1024), ("dnn_dropout", 0), ("dnn_activation", "relu"),
                 ("task", "binary")],

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", ["model_deepfm_hash", "model_dcn_matrix", "model_xdeepfm", "model_din_big_wn0", "model_afm",
-                                  "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner", "model_pnn_plain", "model_nfm"])
+                                  "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner", "model_pnn_plain", "model_nfm", "model_dcnmix",
+                                  "model_dcnmix_crossonly"])
 def test_torch_training_forward_matches_hip_forward(device, name):
     from deepctr_amd import training
     from tests.test_gpu_models import build_model, well_conditioned_rows

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def build_model(meta, device):
-    from deepctr_amd.models import AFM, DCN, DIN, FNN, NFM, PNN, WDL, DeepFM, xDeepFM
+    from deepctr_amd.models import AFM, DCN, DIN, FNN, NFM, PNN, WDL, DCNMix, DeepFM, xDeepFM
     dnn_cols = columns_from_spec(meta["dnn"])
     lin_cols = columns_from_spec(meta["linear"])
     kw = dict(meta["kwargs"])
@@ -22,7 +22,7 @@ def build_model(meta, device):
         return DIN(dnn_cols, meta["extra_args"][0], device=device, **kw)
     if name == "PNN":
         return PNN(dnn_cols, device=device, **kw)
-    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN, "AFM": AFM, "NFM": NFM}[name]
+    ctor = {"DeepFM": DeepFM, "DCN": DCN, "xDeepFM": xDeepFM, "WDL": WDL, "FNN": FNN, "AFM": AFM, "NFM": NFM, "DCNMix": DCNMix}[name]
     return ctor(lin_cols, dnn_cols, device=device, **kw)
 
 

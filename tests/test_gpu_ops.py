@@ -296,6 +296,43 @@ def test_afm_inner_product(device):
         assert_close(ops.inner_product(x, False).cpu().numpy(), g["ip_%s_full" % tag], what="ip full " + tag)
 
 
+def test_crossnet_mix(device):
+    """CrossNetMix (interaction.py:511-549): golden fixtures from the reference's layer, then the oracle at DCN-Mix's
+    default shape (low_rank 32, 4 experts) on a Criteo-wide row, ragged batch sizes, strided in / out."""
+    from deepctr_amd import ops
+    from deepctr_amd.layers import CrossNetMix
+    from tests.test_oracle_golden import mix_weights
+    g = load_golden("crossnet_mix")
+    meta = golden_meta(g)
+    for tag in ("a", "b", "c"):
+        U, V, C, gating, bias = mix_weights(g, tag)
+        x = g["mix_%s_x" % tag]
+        layer = CrossNetMix(device=device, **meta[tag]).build_for(x.shape[1])
+        layer.set_weights(U + V + C + bias + gating)          # own weights in creation order, then the gating Dense kernels
+        y = layer(dev(x, device))
+        assert_close(y.cpu().numpy(), g["mix_%s_y" % tag], what="crossnet_mix " + tag)
+    rng = np.random.RandomState(17)
+    for B, d, r, ne, L in ((4096 + 3, 429, 32, 4, 2), (1, 8, 1, 1, 1), (70, 45, 5, 3, 3), (33, 16, 4, 2, 0)):
+        x = (rng.standard_normal((B, d)) * 0.5).astype(np.float32)
+        U = (rng.standard_normal((L, ne, d, r)) / np.sqrt(d)).astype(np.float32)
+        V = (rng.standard_normal((L, ne, d, r)) / np.sqrt(d)).astype(np.float32)
+        C = (rng.standard_normal((L, ne, r, r)) / np.sqrt(r)).astype(np.float32)
+        G = (rng.standard_normal((ne, d)) / np.sqrt(d)).astype(np.float32)
+        b = (rng.standard_normal((L, d)) * 0.1).astype(np.float32)
+        f64 = lambda a: a.astype(np.float64)   # noqa: E731
+        ref = R.crossnet_mix(f64(x), [f64(U[l]) for l in range(L)], [f64(V[l]) for l in range(L)], [f64(C[l]) for l in range(L)],
+                             [f64(G[e])[:, None] for e in range(ne)], [f64(b[l])[:, None] for l in range(L)])
+        buf = torch.zeros(B, d + 5, device=device)
+        buf[:, :d] = dev(x, device)
+        out = torch.full((B, d + 3), -1.0, device=device)
+        ops.crossnet_mix(buf, dev(U, device) if L else None, dev(V, device) if L else None, dev(C, device) if L else None,
+                         dev(G, device) if L else None, dev(b, device) if L else None, dim=d, out=out)
+        assert_close(out[:, :d].cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="crossnet_mix %s" % ((B, d, r, ne, L),))
+        assert float((out[:, d:] + 1.0).abs().max()) == 0.0
+    with pytest.raises(ValueError, match="expect to be 2 dimensions"):
+        CrossNetMix(device=device)(torch.zeros(2, 3, 4, device=device))
+
+
 def test_bi_interaction(device):
     """BiInteractionPooling (interaction.py:190-203) against the oracle (pinned through the NFM model fixtures)."""
     from deepctr_amd import ops

@@ -120,6 +120,26 @@ def test_crossnet():
         assert_close(y, g["cross_%s_y" % tag], what="crossnet " + tag)
 
 
+def mix_weights(g, tag):
+    """(U_list, V_list, C_list, gating kernels, biases) of a CrossNetMix fixture, in layer / expert order."""
+    meta = golden_meta(g)[tag]
+    pre = "mix_%s_w/" % tag
+    W = lambda k: [g["%scross_net_mix/%s%d" % (pre, k, i)] for i in range(meta["layer_num"])]   # noqa: E731
+    gating = [g[pre + ("dense/kernel" if e == 0 else "dense_%d/kernel" % e)] for e in range(meta["num_experts"])]
+    return W("U_list"), W("V_list"), W("C_list"), gating, W("bias")
+
+
+def test_crossnet_mix():
+    g = load_golden("crossnet_mix")
+    for tag in ("a", "b", "c"):
+        U, V, C, gating, bias = mix_weights(g, tag)
+        y = R.crossnet_mix(g["mix_%s_x" % tag], U, V, C, gating, bias)
+        assert_close(y, g["mix_%s_y" % tag], what="crossnet_mix " + tag)
+        y64 = R.crossnet_mix(g["mix_%s_x" % tag].astype(np.float64), *[[w.astype(np.float64) for w in ws]
+                                                                      for ws in (U, V, C, gating, bias)])
+        assert_close(y64, g["mix_%s_y" % tag], what="crossnet_mix f64 " + tag)
+
+
 def test_afm_inner_product():
     g = load_golden("interaction")
     for tag in ("t", "w", "two"):
@@ -207,7 +227,8 @@ MODEL_FIXTURES = ["model_deepfm_mixed", "model_deepfm_hash", "model_dcn_vector",
                   "model_din_ref_dice_hash1", "model_din_ref_sigmoid_hash1", "model_din_big_wn0", "model_din_big_wn1",
                   "model_deepfm_criteo_sample", "model_wdl", "model_wdl_wide_subset", "model_fnn", "model_wdl_fixed",
                   "model_fnn_fixed", "model_afm", "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner",
-                  "model_pnn_plain", "model_nfm", "model_nfm_fixed"]
+                  "model_pnn_plain", "model_nfm", "model_nfm_fixed", "model_dcnmix", "model_dcnmix_crossonly",
+                  "model_dcnmix_fixed"]
 
 
 def run_oracle_model(g, dtype=np.float32):
@@ -235,6 +256,8 @@ def run_oracle_model(g, dtype=np.float32):
         return RM.afm(lin_cols, dnn_cols, weights, feed, **kw)
     if name == "PNN":
         return RM.pnn(lin_cols, dnn_cols, weights, feed, **kw)
+    if name == "DCNMix":
+        return RM.dcnmix(lin_cols, dnn_cols, weights, feed, **kw)
     if name == "NFM":
         return RM.nfm(lin_cols, dnn_cols, weights, feed, **kw)
     raise KeyError(name)
