@@ -114,6 +114,13 @@ class CrossBwdArgs(ctypes.Structure):
                 ("workspace_bytes", c_sz)]
 
 
+class HostCol(ctypes.Structure):
+    _fields_ = [("src", c_vp), ("stride_bytes", c_i64), ("kind", c_i32), ("reserved_", c_i32)]
+
+
+HOST_KINDS = {"int32": 0, "int64": 1, "float32": 2, "float64": 3}
+
+
 class AdamSeg(ctypes.Structure):
     _fields_ = [("w", c_vp), ("m", c_vp), ("v", c_vp), ("g", c_vp), ("n", c_i64), ("l2", c_f32), ("pad_", c_i32)]
 
@@ -150,6 +157,7 @@ SYMBOLS = {
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
     "dctr_afm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "dctr_host_pack_columns": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_i32, c_i32]),
     "dctr_crossnet_mix_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp,
                                              c_i64, c_vp]),
     "dctr_bi_interaction_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -23,6 +23,7 @@ LIB = os.path.join(LIB_DIR, "libdctr_hip.so")
 
 SOURCES = [
     "abi.cpp",
+    "host_pack.cpp",
     "hash_kernels.hip",
     "embed_kernels.hip",
     "mlp_kernels.hip",
@@ -81,7 +82,7 @@ def build(force=False, verbose=True):
         # hipcc's --hip-link would add RUNPATH=/opt/rocm-*/lib, which could pull a second HIP runtime
         # next to the one PyTorch ships; without it NEEDED libamdhip64.so.7 binds to the loaded one.
         rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
-        cmd = ["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + rocm_lib, "-lamdhip64", "-lrocblas"]
+        cmd = ["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + rocm_lib, "-lamdhip64", "-lrocblas", "-pthread"]
         if verbose:
             print("[dctr build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -14,6 +14,7 @@ Weight access by the reference's layer names is the guaranteed contract (``get_l
 ``set_weights_by_name({'dnn/kernel0': ...})``); list order of get_weights() is this build's own.
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -72,6 +73,35 @@ def _ids_from_column(a, fc, mask_zero, device):
     if a.dtype.kind not in "iu":
         raise TypeError("feature %r: unsupported id dtype %s" % (fc.name, a.dtype))
     return a
+
+
+def _usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))       # what this process may run on (cgroup / taskset), not what the box has
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+_PACK_THREADS = max(1, min(4, _usable_cpus()))    # measured on the MI355X host: 4 packer threads beat 1 and 16
+_PIPELINE_MIN_ROWS = 1 << 18      # below this one staging pass + one copy is as fast as the chunked pipeline
+_PIPELINE_CHUNK_ROWS = 1 << 17
+
+
+def _host_cols(arrays):
+    """ctypes array of dctr_host_col_t for 1-D numpy columns (any row stride), or None if a dtype is outside the packer's."""
+    arr = (_C.HostCol * max(1, len(arrays)))()
+    for i, a in enumerate(arrays):
+        kind = _C.HOST_KINDS.get(str(a.dtype))
+        if kind is None or a.ndim != 1 or not a.dtype.isnative:
+            return None
+        arr[i].src, arr[i].stride_bytes, arr[i].kind = a.ctypes.data, a.strides[0], kind
+    return arr
+
+
+def _pack_columns(desc, n_cols, lo, n, dst, dst_kind):
+    """Rows [lo, lo + n) of the described columns -> the [n_cols, n] host tensor ``dst`` (dctr_host_pack_columns)."""
+    _C.check(_C.lib().dctr_host_pack_columns(desc, n_cols, lo, n, ctypes.c_void_p(dst.data_ptr()), dst.stride(0),
+                                             _C.HOST_KINDS[dst_kind], _PACK_THREADS), "dctr_host_pack_columns")
 
 
 def _fit_int32(arrs):
@@ -238,9 +268,13 @@ class EmbeddingStage(object):
             host_rows = [i for i, c in enumerate(cols) if c is not None and not isinstance(c, torch.Tensor)]
             if dev.type == "cuda" and len(host_rows) == len(cols):
                 pin = self._pinned("ids", (len(cols), staged.n), dt)
-                hv = pin.numpy()
-                for i in host_rows:
-                    np.copyto(hv[i], cols[i], casting="unsafe")       # converts the dtype on the way
+                desc = _host_cols(cols)
+                if desc is not None:                                      # threaded convert-and-pack (host_pack.cpp)
+                    _pack_columns(desc, len(cols), 0, staged.n, pin, "int32" if use32 else "int64")
+                else:
+                    hv = pin.numpy()
+                    for i in host_rows:
+                        np.copyto(hv[i], cols[i], casting="unsafe")       # converts the dtype on the way
                 mat = pin.to(dev, non_blocking=True)
             else:
                 mat = torch.zeros(len(cols), staged.n, dtype=dt, device=dev)
@@ -271,11 +305,14 @@ class EmbeddingStage(object):
                 # feature-major in the pinned buffer (contiguous column copies), transposed to [N, ND] on the device
                 nd = sum(p_.shape[1] for p_ in parts)
                 pin = self._pinned("dense", (nd, staged.n), torch.float32)
-                hv, c0 = pin.numpy(), 0
-                for p_ in parts:
-                    for k in range(p_.shape[1]):
-                        np.copyto(hv[c0], p_[:, k])
-                        c0 += 1
+                views = [p_[:, k] for p_ in parts for k in range(p_.shape[1])]
+                desc = _host_cols(views)
+                if desc is not None:
+                    _pack_columns(desc, nd, 0, staged.n, pin, "float32")
+                else:
+                    hv = pin.numpy()
+                    for c0, v in enumerate(views):
+                        np.copyto(hv[c0], v)
                 # (numpy copies on purpose: torch's multi-threaded CPU copy_ leaves its OpenMP workers spinning, which
                 # slowed the per-batch launch loop that follows 7x on the GPU box)
                 staged.dense = pin.to(dev, non_blocking=True).t().contiguous()
@@ -285,6 +322,82 @@ class EmbeddingStage(object):
             self.stage_varlen(x, staged, fc)
         if dev.type == "cuda":
             torch.cuda.current_stream(dev).synchronize()      # the pinned buffers are re-used by the next call
+
+    # -- chunked staging: pack chunk k+1 on the host while chunk k crosses PCIe and chunk k-1 is being scored --------
+    def pipeline_plan(self, x, n):
+        """(id columns, dense column views) when every input is a plain host column the chunked path can take (fixed-length
+        features, integer ids, untransformed dense values, a HIP device); None sends the caller to ``stage``."""
+        if self.device.type != "cuda" or n < _PIPELINE_MIN_ROWS or self.varlen_features():
+            return None
+        cols = []
+        for fc in self.id_features():
+            if fc is None:
+                return None
+            a = _column(x, fc.name).reshape(-1)
+            if a.shape[0] != n:
+                raise ValueError("feature %r has %d rows, expected %d" % (fc.name, a.shape[0], n))
+            c = _ids_from_column(a, fc, fc.name in self.mask_feat_list, self.device)
+            if isinstance(c, torch.Tensor):
+                return None
+            cols.append(c)
+        dense = []
+        for fc in self.dense_cols:
+            if fc.transform_fn is not None:
+                return None
+            a = _column(x, fc.name).astype(np.float32, copy=False).reshape(n, -1)
+            if a.shape[1] != fc.dimension:
+                raise ValueError("dense feature %r: expected dimension %d, got %d" % (fc.name, fc.dimension, a.shape[1]))
+            dense.extend(a[:, k] for k in range(a.shape[1]))
+        if _host_cols(cols) is None or _host_cols(dense) is None:
+            return None
+        return cols, dense
+
+    def stage_chunks(self, plan, staged, chunk_rows):
+        """Generator over row ranges (lo, hi) of ``staged``: each step packs the chunk into one of two page-locked slots,
+        queues its copy (+ the scatter into the [F, N] / [N, ND] device layout) on the copy stream and makes the current
+        stream wait for it — so the caller's launches for chunk k run while chunk k+1 is packed and copied."""
+        cols, dense = plan
+        dev, n = self.device, staged.n
+        F, ND = len(cols), len(dense)
+        use32 = _fit_int32(cols)
+        dt, kind = (torch.int32, "int32") if use32 else (torch.int64, "int64")
+        idesc, ddesc = _host_cols(cols), _host_cols(dense)
+        staged.ids = torch.empty(F, n, dtype=dt, device=dev) if F else None
+        staged.dense = torch.empty(n, ND, dtype=torch.float32, device=dev) if ND else None
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+            self._slot_events = [torch.cuda.Event(), torch.cuda.Event()]
+        cs, cur = self._copy_stream, torch.cuda.current_stream(dev)
+        cs.wait_stream(cur)                        # the freshly allocated buffers may recycle memory ``cur`` still uses
+        CH = int(chunk_rows)
+        for k, lo in enumerate(range(0, n, CH)):
+            hi = min(n, lo + CH)
+            m = hi - lo
+            ev = self._slot_events[k % 2]
+            ev.synchronize()                       # this slot's previous copy has left the pinned buffer
+            with torch.cuda.stream(cs):
+                if F:
+                    pin = self._pinned(("ids", k % 2), (F, m), dt)
+                    _pack_columns(idesc, F, lo, m, pin, kind)
+                    tmp = self._dev_tmp(("ids", k % 2), (F, m), dt)
+                    tmp.copy_(pin, non_blocking=True)
+                    staged.ids[:, lo:hi].copy_(tmp)
+                if ND:
+                    pin = self._pinned(("dense", k % 2), (ND, m), torch.float32)
+                    _pack_columns(ddesc, ND, lo, m, pin, "float32")
+                    tmp = self._dev_tmp(("dense", k % 2), (ND, m), torch.float32)
+                    tmp.copy_(pin, non_blocking=True)
+                    staged.dense[lo:hi].copy_(tmp.t())
+                ev.record(cs)
+            cur.wait_event(ev)
+            yield lo, hi
+
+    def _dev_tmp(self, key, shape, dtype):
+        n = int(np.prod(shape))
+        buf = self._pin.get(("dev", key, dtype))
+        if buf is None or buf.numel() < n:
+            buf = self._pin[("dev", key, dtype)] = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+        return buf[:n].view(*shape)
 
     def _pinned(self, key, shape, dtype):
         """Cached page-locked staging buffer (grown on demand): pinned memory crosses PCIe at ~50 GB/s, pageable numpy
@@ -581,11 +694,26 @@ class Model(object):
         return staged
 
     # -- inference -----------------------------------------------------------------------------------
+    def _pipeline(self, x, batch_size):
+        """Hook: (staged, generator of ready row ranges, batch size) for the chunked staging pipeline, or None."""
+        return None
+
     def _begin(self):
         """Hook: per-call refresh of weight-derived buffers."""
 
     def predict_tensor(self, x, batch_size=256):
         """predict() that leaves the [N] result on the device (used by the distributed path)."""
+        pipe = self._pipeline(x, batch_size)
+        if pipe is not None:
+            staged, chunks, bs = pipe
+            out = torch.empty(staged.n, dtype=torch.float32, device=self.device)
+            self._begin()
+            for c_lo, c_hi in chunks:
+                for lo in range(c_lo, c_hi, bs):
+                    hi = min(c_hi, lo + bs)
+                    self._forward(staged, lo, hi, out[lo:hi])
+            self._check_status()
+            return out
         staged = self.stage(x)
         out = torch.empty(staged.n, dtype=torch.float32, device=self.device)
         if staged.n == 0:

@@ -51,6 +51,22 @@ class FeatureModel(Model):
     def _stage_inputs(self, feed, staged):
         self.stage_plan.stage(feed, staged)
 
+    def _pipeline(self, x, batch_size):
+        """Large host feeds of fixed-length features: stage in chunks overlapped with the copies and the scoring."""
+        from .. import _C, engine
+        if type(self)._stage_inputs is not FeatureModel._stage_inputs or not batch_size:
+            return None
+        _C.require_device()
+        feed = self._as_feed(x)
+        n = self._num_rows(feed)
+        plan = self.stage_plan.pipeline_plan(feed, n)
+        if plan is None:
+            return None
+        bs = int(batch_size)
+        chunk = bs * max(1, -(-engine._PIPELINE_CHUNK_ROWS // bs))     # whole batches per chunk
+        staged = engine.Staged(n)
+        return staged, self.stage_plan.stage_chunks(plan, staged, chunk), bs
+
     def _begin(self):
         self.stage_plan.refresh(self.linear.w('linear_kernel') if self.linear is not None else None)
 

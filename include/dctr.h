@@ -59,6 +59,22 @@ int dctr_profile_arm(int32_t n);
 int dctr_profile_collect(float* ms, int32_t n);
 
 /* ------------------------------------------------------------------------------------------------
+ * host input pipeline — what Keras does with the dict of ndarrays handed to predict()/fit()
+ * (examples/run_classification_criteo.py:40-50).  HOST pointers, no device work: rows [row_lo, row_lo + n_rows) of every
+ * column are converted to dst_kind and written feature-major into dst (column c at dst + c * dst_col_stride elements,
+ * normally page-locked memory), by up to n_threads host threads.  Float -> integer conversion truncates (numpy astype).
+ * ------------------------------------------------------------------------------------------------ */
+enum { DCTR_HOST_I32 = 0, DCTR_HOST_I64 = 1, DCTR_HOST_F32 = 2, DCTR_HOST_F64 = 3 };
+typedef struct {
+    const void* src;              /* first element of the column (row 0)                                 */
+    int64_t stride_bytes;         /* distance between consecutive rows (a column of an [N, k] array: k * itemsize) */
+    int32_t kind;                 /* DCTR_HOST_*                                                         */
+    int32_t reserved_;
+} dctr_host_col_t;
+int dctr_host_pack_columns(const dctr_host_col_t* cols, int32_t n_cols, int64_t row_lo, int64_t n_rows, void* dst,
+                           int64_t dst_col_stride, int32_t dst_kind, int32_t n_threads);
+
+/* ------------------------------------------------------------------------------------------------
  * a2  Hash.call — deepctr/layers/utils.py:89-112
  *     out = Fingerprint64(decimal_ascii(x)) mod nb  (uint64 modulo, stored as int64),
  *     nb = num_buckets - (mask_zero ? 1 : 0);  mask_zero: out = (out + 1) * (x != 0).

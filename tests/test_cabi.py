@@ -63,3 +63,30 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b"optimizer kind 9" in lib.dctr_last_error()
     assert lib.dctr_mlp_bwd(None, None) == -1 and lib.dctr_cin_bwd(None, None) == -1 and lib.dctr_crossnet_bwd(None, None) == -1
     assert lib.dctr_embed_gather_fm_bwd(None, None) == -1 and lib.dctr_embed_pool_bwd(None, None) == -1
+
+
+def test_host_pack_columns_converts_like_numpy():
+    """dctr_host_pack_columns is host code: row ranges of int32 / int64 / float32 / float64 columns,
+    contiguous or strided, into a feature-major matrix of the staging dtype — same values as ndarray.astype."""
+    import numpy as np
+    from deepctr_amd import _C, engine
+    lib = _C.lib()
+    rng = np.random.RandomState(4)
+    n = 200003                                    # > 3 blocks of 65536 rows
+    wide = rng.rand(n, 3) * 50
+    cols = [rng.randint(-5, 100000, n).astype(np.int32), rng.randint(0, 2 ** 40, n).astype(np.int64),
+            (rng.rand(n) * 100).astype(np.float32), wide[:, 1], rng.randint(0, 9, 2 * n).astype(np.int64)[::2]]
+    desc = engine._host_cols(cols)
+    assert desc is not None and engine._host_cols([cols[0].astype(np.int16)]) is None
+    for kind, dt in (("int32", np.int32), ("int64", np.int64), ("float32", np.float32)):
+        for lo, m in ((0, n), (12345, 70001), (n - 3, 3), (5, 0)):
+            dst = np.full((len(cols), m + 5), 7, dtype=dt)
+            for threads in (1, 4):
+                rc = lib.dctr_host_pack_columns(desc, len(cols), lo, m, dst.ctypes.data, m + 5, _C.HOST_KINDS[kind], threads)
+                assert rc == 0, lib.dctr_last_error()
+                for i, c in enumerate(cols):
+                    assert np.array_equal(dst[i, :m], c[lo:lo + m].astype(dt)), (kind, lo, m, i)
+                assert (dst[:, m:] == 7).all()
+    assert lib.dctr_host_pack_columns(desc, len(cols), 0, 8, None, 8, 0, 1) == -1
+    assert lib.dctr_host_pack_columns(desc, len(cols), 0, 8, None, 4, 0, 1) == -2        # column stride < rows
+    assert lib.dctr_host_pack_columns(desc, len(cols), 0, 8, None, 8, 3, 1) == -4        # float64 is not a staging dtype

@@ -213,3 +213,33 @@ def test_deepfm_fused_launch_matches_two_launch_path(device):
             model.tile_rows = 0
         ref = RM.deepfm(cols, cols, w, feed, dnn_hidden_units=(64, 32), dtype=np.float64)
         check_probs(y1, ref.astype(np.float32), "fused vs oracle E=%d" % E)
+
+
+@pytest.mark.parametrize("bs", [4096, 50000, 65536])
+def test_chunked_staging_pipeline_matches_plain_staging(device, bs, monkeypatch):
+    """predict() on a large host feed stages in chunks (pack -> PCIe -> scatter overlapped with scoring, engine.stage_chunks):
+    bit-identical to the single-pass staging, for int32 / int64 / hashed ids and multi-column dense features."""
+    from deepctr_amd import engine
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(9)
+    n = engine._PIPELINE_MIN_ROWS + 12345
+    cols = [SparseFeat("a", 1000, 8), SparseFeat("b", 500, 8, use_hash=True), SparseFeat("c", 77, 8), DenseFeat("d", 3),
+            DenseFeat("e", 1)]
+    feed = {"a": rng.randint(0, 1000, n).astype(np.int32), "b": rng.randint(0, 2 ** 40, n).astype(np.int64),
+            "c": rng.randint(0, 77, n).astype(np.int64), "d": rng.rand(n, 3), "e": rng.rand(n).astype(np.float32)}
+    model = DeepFM(cols, cols, dnn_hidden_units=(32, 16), device=device)
+    _randomise(model, rng)
+    assert model._pipeline(feed, bs) is not None
+    y = model.predict(feed, batch_size=bs)
+    y2 = model.predict(feed, batch_size=bs)                       # slots and events re-used by a second call
+    monkeypatch.setattr(engine, "_PIPELINE_MIN_ROWS", 1 << 40)
+    assert model._pipeline(feed, bs) is None
+    ref = model.predict(feed, batch_size=bs)
+    assert y.shape == (n, 1) and np.array_equal(y, ref) and np.array_equal(y2, ref)
+    # a sequence feature sends the model to the plain path
+    from deepctr_amd.feature_column import VarLenSparseFeat
+    monkeypatch.setattr(engine, "_PIPELINE_MIN_ROWS", 1)
+    cols2 = cols + [VarLenSparseFeat(SparseFeat("s", 9, 8), maxlen=3)]
+    m2 = DeepFM(cols2, cols2, dnn_hidden_units=(8,), device=device)
+    assert m2._pipeline(dict(feed, s=np.zeros((n, 3), np.int32)), bs) is None
