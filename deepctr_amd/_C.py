@@ -158,8 +158,9 @@ SYMBOLS = {
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
     "dctr_afm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "dctr_host_pack_columns": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_i32, c_i32]),
+    "dctr_crossnet_mix_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
     "dctr_crossnet_mix_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                             c_i64, c_vp]),
+                                             c_i64, c_vp, ctypes.c_size_t, c_vp]),
     "dctr_bi_interaction_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_inner_product_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),

@@ -351,14 +351,79 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(const float* __rest
 // CrossNetMix (interaction.py:511-549, DCN-Mix): per layer, per expert e
 //     g_e = x_l . G_e ;  v = tanh(V_e^T x_l) ;  v = tanh(C_e v) ;  out_e = x_0 * (U_e v + bias)
 //     x_{l+1} = sum_e softmax(g)_e out_e + x_l  =  x_0 * (sum_e U_e (p_e v_e) + bias) + x_l        (sum_e p_e = 1)
-// One workgroup owns R rows for every layer: x_0 / x_l stay in LDS ([d][R], so a column of R rows is one broadcast
-// read), stage 1 gives one thread per low-rank / gating column (a d-long dot per row), stage 2 the r x r mixing and
-// the softmax weights, stage 3 one thread per output column.  Weights are read in the reference's own layouts
-// (U, V [L,experts,d,r]; C [L,experts,r,r]) from L2: 3 * experts * d * r * 4 B per layer per workgroup.
+// One workgroup owns R rows for every layer: x_0 / x_l stay in LDS ([d][R], so the R rows of a column are one broadcast
+// read).  Stage 1: one thread per low-rank column (a d-long dot per row; V [experts,d,r] is read with lanes along r,
+// coalesced; with <= 128 columns several threads share one and split the j range), then the gating dots.  Stage 2: the
+// r x r mixing and the softmax weights.  Stage 3: two output columns per thread over U^T [experts*r, d] — U transposed once
+// per call into the workspace so that lanes along d read consecutive floats.  fp32 FMA: for fp32 the VALU and the MFMA peak of gfx950 are the same 157 TFLOP/s, so the
+// bound is keeping WGB weight loads in flight per thread (L2 latency), not the matrix cores.
 // ---------------------------------------------------------------------------------------------------
+constexpr int WGB = 8;   // weight loads issued back to back before their FMAs
+
+__global__ __launch_bounds__(256) void cross_mix_transpose_kernel(const float* __restrict__ U, int64_t mats, int d, int r,
+                                                                  float* __restrict__ Ut) {
+    // U [mats, d, r] -> Ut [mats, r, d]
+    const int64_t total = mats * d * r;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t m = o / ((int64_t)d * r);
+        const int64_t rem = o - m * d * r;
+        const int k = (int)(rem / d), jj = (int)(rem - (int64_t)k * d);
+        Ut[o] = U[(m * d + jj) * r + k];
+    }
+}
+
+// acc[n][q] += sum_j a[j*astride + q] * w[n][j*wstride], j in [j0, j1): `a` in LDS (broadcast reads), NC weight columns in
+// global memory; the next WGB weights per column are in flight while the current ones are used
+template <int RA, int NC>
+__device__ __forceinline__ void dot_rows(const float* __restrict__ a, int astride, const float* const (&w)[NC], int64_t wstride,
+                                         int j0, int j1, float (&acc)[NC][RA]) {
+    float cur[NC][WGB], nxt[NC][WGB];
+    const int nfull = (j1 - j0) / WGB;
+    int jj = j0;
+    if (nfull > 0) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int u = 0; u < WGB; ++u) cur[n][u] = w[n][(int64_t)(jj + u) * wstride];
+    }
+    for (int b = 0; b < nfull; ++b) {
+        if (b + 1 < nfull) {
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int u = 0; u < WGB; ++u) nxt[n][u] = w[n][(int64_t)(jj + WGB + u) * wstride];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < WGB; ++u) {
+            float av[RA];
+#pragma unroll
+            for (int q = 0; q < RA; ++q) av[q] = a[(jj + u) * astride + q];
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int q = 0; q < RA; ++q) acc[n][q] = fmaf(av[q], cur[n][u], acc[n][q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int u = 0; u < WGB; ++u) cur[n][u] = nxt[n][u];
+        jj += WGB;
+    }
+    for (; jj < j1; ++jj) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const float wv = w[n][(int64_t)jj * wstride];
+#pragma unroll
+            for (int q = 0; q < RA; ++q) acc[n][q] = fmaf(a[jj * astride + q], wv, acc[n][q]);
+        }
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int d,
-                                                        const float* __restrict__ U, const float* __restrict__ V,
+                                                        const float* __restrict__ Ut, const float* __restrict__ V,
                                                         const float* __restrict__ C, const float* __restrict__ G,
                                                         const float* __restrict__ bias, int layers, int ne, int r,
                                                         float* __restrict__ y, int64_t y_stride) {
@@ -368,9 +433,15 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
     float* xl = x0 + (size_t)d * R;       // [d][R]
     float* h1 = xl + (size_t)d * R;       // [H][R]   tanh(V^T x_l)
     float* h2 = h1 + (size_t)H * R;       // [H][R]   p_e * tanh(C v)
-    float* gate = h2 + (size_t)H * R;     // [ne][R]
+    float* gate = h2 + (size_t)H * R;     // [8][ne][R] partial gating dots
+    float* h1p = gate + (size_t)8 * ne * R;   // [P1][H][R] partial projections (P1 * H <= 256)
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * R;
+    // few low-rank columns: P1 threads share a column (each a slice of the j range) so that every wave has work
+    const int P1 = H <= 128 ? (256 / H < 8 ? 256 / H : 8) : 1;
+    // gating dots: (expert, row) pairs x GP slices of the j range
+    const int combos = ne * R;
+    const int GP = 256 >= combos ? (256 / combos < 8 ? 256 / combos : 8) : 1;
     for (int j = tid; j < d; j += 256) {
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -383,38 +454,55 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
     __syncthreads();
     for (int l = 0; l < layers; ++l) {
         const float* Vl = V + (size_t)l * ne * d * r;
-        const float* Ul = U + (size_t)l * ne * d * r;
+        const float* Utl = Ut + (size_t)l * H * d;
         const float* Cl = C + (size_t)l * ne * r * r;
-        // stage 1: low-rank projections and gating scores
-        for (int c = tid; c < H + ne; c += 256) {
-            const float* w;
-            int wstride;
-            if (c < H) {
+        // stage 1: low-rank projections ...
+        if (P1 > 1) {
+            if (tid < P1 * H) {
+                const int part = tid / H, c = tid - part * H;
                 const int e = c / r, k = c - e * r;
-                w = Vl + (size_t)e * d * r + k;
-                wstride = r;
-            } else {
-                w = G + (size_t)(c - H) * d;
-                wstride = 1;
+                const int per = (d + P1 - 1) / P1;
+                const int j0 = part * per < d ? part * per : d, j1 = j0 + per < d ? j0 + per : d;
+                float acc[1][R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[0][q] = 0.f;
+                const float* const w[1] = {Vl + (size_t)e * d * r + k};
+                dot_rows<R, 1>(xl, R, w, r, j0, j1, acc);
+#pragma unroll
+                for (int q = 0; q < R; ++q) h1p[(part * H + c) * R + q] = acc[0][q];
             }
-            float acc[R];
+        } else {
+            for (int c = tid; c < H; c += 256) {
+                const int e = c / r, k = c - e * r;
+                float acc[1][R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] = 0.f;
-#pragma unroll 4
-            for (int j = 0; j < d; ++j) {
-                const float wv = w[(size_t)j * wstride];
+                for (int q = 0; q < R; ++q) acc[0][q] = 0.f;
+                const float* const w[1] = {Vl + (size_t)e * d * r + k};
+                dot_rows<R, 1>(xl, R, w, r, 0, d, acc);
 #pragma unroll
-                for (int q = 0; q < R; ++q) acc[q] = fmaf(xl[j * R + q], wv, acc[q]);
-            }
-            if (c < H) {
-#pragma unroll
-                for (int q = 0; q < R; ++q) h1[c * R + q] = tanhf(acc[q]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < R; ++q) gate[(c - H) * R + q] = acc[q];
+                for (int q = 0; q < R; ++q) h1[c * R + q] = tanhf(acc[0][q]);
             }
         }
+        // ... and gating scores: item = (slice, expert, row)
+        for (int it = tid; it < GP * combos; it += 256) {
+            const int part = it / combos, eq = it - part * combos;
+            const int e = eq / R, q = eq - e * R;
+            const int per = (d + GP - 1) / GP;
+            const int j0 = part * per < d ? part * per : d, j1 = j0 + per < d ? j0 + per : d;
+            float acc[1][1] = {{0.f}};
+            const float* const w[1] = {G + (size_t)e * d};
+            dot_rows<1, 1>(xl + q, R, w, 1, j0, j1, acc);
+            gate[(part * ne + e) * R + q] = acc[0][0];
+        }
         __syncthreads();
+        if (P1 > 1) {
+            for (int o = tid; o < H * R; o += 256) {
+                float sum = 0.f;
+                for (int pp = 0; pp < P1; ++pp) sum += h1p[pp * H * R + o];
+                h1[o] = tanhf(sum);
+            }
+            __syncthreads();
+        }
         // stage 2: r x r mixing in the low-rank space, scaled by the expert's softmax weight
         for (int c = tid; c < H; c += 256) {
             const int e = c / r, i = c - e * r;
@@ -429,30 +517,39 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                float mx = gate[q];
-                for (int t = 1; t < ne; ++t) mx = fmaxf(mx, gate[t * R + q]);
-                float den = 0.f;
-                for (int t = 0; t < ne; ++t) den += expf(gate[t * R + q] - mx);
-                h2[c * R + q] = tanhf(acc[q]) * (expf(gate[e * R + q] - mx) / den);
+                float mine = 0.f, mx = -INFINITY, den = 0.f;
+                for (int t = 0; t < ne; ++t) {
+                    float gsum = 0.f;
+                    for (int pp = 0; pp < GP; ++pp) gsum += gate[(pp * ne + t) * R + q];
+                    mx = fmaxf(mx, gsum);
+                }
+                for (int t = 0; t < ne; ++t) {
+                    float gsum = 0.f;
+                    for (int pp = 0; pp < GP; ++pp) gsum += gate[(pp * ne + t) * R + q];
+                    const float ex = expf(gsum - mx);
+                    den += ex;
+                    if (t == e) mine = ex;
+                }
+                h2[c * R + q] = tanhf(acc[q]) * (mine / den);
             }
         }
         __syncthreads();
-        // stage 3: back to d columns, Hadamard with x_0, residual
-        for (int j = tid; j < d; j += 256) {
-            float acc[R];
+        // stage 3: back to d columns (two per thread, sharing the broadcast reads), Hadamard with x_0, residual
+        for (int j = tid; j < d; j += 512) {
+            const int j2 = j + 256 < d ? j + 256 : j;
+            float acc[2][R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] = 0.f;
-            for (int e = 0; e < ne; ++e) {
-                const float* uw = Ul + ((size_t)e * d + j) * r;
-                for (int k = 0; k < r; ++k) {
-                    const float wv = uw[k];
-#pragma unroll
-                    for (int q = 0; q < R; ++q) acc[q] = fmaf(h2[(e * r + k) * R + q], wv, acc[q]);
-                }
-            }
+            for (int q = 0; q < R; ++q) acc[0][q] = acc[1][q] = 0.f;
+            const float* const w[2] = {Utl + j, Utl + j2};
+            dot_rows<R, 2>(h2, R, w, d, 0, H, acc);
             const float bj = bias[(size_t)l * d + j];
 #pragma unroll
-            for (int q = 0; q < R; ++q) xl[j * R + q] = fmaf(x0[j * R + q], acc[q] + bj, xl[j * R + q]);
+            for (int q = 0; q < R; ++q) xl[j * R + q] = fmaf(x0[j * R + q], acc[0][q] + bj, xl[j * R + q]);
+            if (j2 != j) {
+                const float b2 = bias[(size_t)l * d + j2];
+#pragma unroll
+                for (int q = 0; q < R; ++q) xl[j2 * R + q] = fmaf(x0[j2 * R + q], acc[1][q] + b2, xl[j2 * R + q]);
+            }
         }
         __syncthreads();
     }
@@ -463,7 +560,9 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
     }
 }
 
-size_t cross_mix_lds_bytes(int d, int ne, int r, int R) { return ((size_t)2 * d + 2 * (size_t)ne * r + ne) * R * sizeof(float); }
+size_t cross_mix_lds_bytes(int d, int ne, int r, int R) {
+    return ((size_t)2 * d + 2 * (size_t)ne * r + 8 * (size_t)ne + 256) * R * sizeof(float);
+}
 
 int pow2_at_least(int v, int cap) {
     int l = 1;
@@ -618,14 +717,23 @@ extern "C" int dctr_bi_interaction_fwd(const float* x, int64_t batch, int64_t x_
     return dctr_launch_status("dctr_bi_interaction_fwd");
 }
 
+extern "C" size_t dctr_crossnet_mix_workspace_bytes(int32_t dim, int32_t layers, int32_t experts, int32_t low_rank) {
+    if (dim < 1 || layers < 1 || experts < 1 || low_rank < 1) return 0;
+    return (size_t)layers * experts * low_rank * dim * sizeof(float);      // U transposed to [layers, experts*low_rank, dim]
+}
+
 extern "C" int dctr_crossnet_mix_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* U, const float* V,
                                      const float* C, const float* gating, const float* bias, int32_t layers, int32_t experts,
-                                     int32_t low_rank, float* y, int64_t y_stride, void* stream) {
+                                     int32_t low_rank, float* y, int64_t y_stride, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     DCTR_REQUIRE(batch >= 0 && dim >= 1 && layers >= 0 && experts >= 1 && low_rank >= 1, DCTR_E_DIM, "crossnet_mix_fwd: bad sizes");
     DCTR_REQUIRE(x_stride >= dim && y_stride >= dim, DCTR_E_DIM, "crossnet_mix_fwd: stride smaller than a row");
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && y, DCTR_E_NULL, "crossnet_mix_fwd: null x / y");
     DCTR_REQUIRE(layers == 0 || (U && V && C && gating && bias), DCTR_E_NULL, "crossnet_mix_fwd: null weights");
+    const size_t need = dctr_crossnet_mix_workspace_bytes(dim, layers, experts, low_rank);
+    DCTR_REQUIRE(need == 0 || (workspace != nullptr && workspace_bytes >= need), DCTR_E_NULL,
+                 "crossnet_mix_fwd: needs a workspace of %zu B (dctr_crossnet_mix_workspace_bytes)", need);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_cap = 64 * 1024;
     // more rows per workgroup = fewer passes over the weights; fewer when the batch would not fill the chip or LDS is short
@@ -634,9 +742,15 @@ extern "C" int dctr_crossnet_mix_fwd(const float* x, int64_t batch, int32_t dim,
     const size_t lds = cross_mix_lds_bytes(dim, experts, low_rank, R);
     DCTR_REQUIRE(lds <= lds_cap, DCTR_E_UNSUPPORTED, "crossnet_mix_fwd: dim %d x experts %d x low_rank %d does not fit LDS", dim,
                  experts, low_rank);
+    float* Ut = static_cast<float*>(workspace);
+    if (need > 0) {
+        const int64_t tb = dctr_ceil_div((int64_t)(need / sizeof(float)), (int64_t)256);
+        hipLaunchKernelGGL(cross_mix_transpose_kernel, dim3((unsigned)(tb > 4096 ? 4096 : tb)), dim3(256), 0, st, U,
+                           (int64_t)layers * experts, (int)dim, (int)low_rank, Ut);
+    }
     const dim3 grid((unsigned)dctr_ceil_div(batch, (int64_t)R));
-#define DCTR_MIX(RR)                                                                                                            \
-    DCTR_LAUNCH(cross_mix_kernel<RR>, grid, dim3(256), lds, st, x, x_stride, batch, dim, U, V, C, gating, bias, layers, experts, \
+#define DCTR_MIX(RR)                                                                                                             \
+    DCTR_LAUNCH(cross_mix_kernel<RR>, grid, dim3(256), lds, st, x, x_stride, batch, dim, Ut, V, C, gating, bias, layers, experts, \
                 low_rank, y, y_stride)
     if (R == 8) {
         DCTR_MIX(8);

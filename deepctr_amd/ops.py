@@ -365,6 +365,19 @@ def afm(x, attention_W, attention_b, projection_h, projection_p, fields=None, di
     return y
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, nbytes):
+    """Per-device scratch buffer (grown on demand) for kernels whose workspace is rewritten by every call; stream order
+    keeps successive calls on one stream from overlapping."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = _SCRATCH[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return buf
+
+
 def crossnet_mix(x, U, V, C, gating, bias, dim=None, out=None):
     """CrossNetMix.call (reference interaction.py:511-549): x [B, >= d]; U, V [L,experts,d,r]; C [L,experts,r,r];
     gating [experts,d]; bias [L,d].  ``out``: a 2-D (strided) view to write [B,d] into."""
@@ -382,8 +395,11 @@ def crossnet_mix(x, U, V, C, gating, bias, dim=None, out=None):
                 or gating.numel() != ne * d or bias.numel() != L * d:
             raise ValueError("crossnet_mix: weight shapes do not match [L,experts,d,r] / [L,experts,r,r] / [experts,d] / [L,d]")
     y = torch.empty(x.shape[0], d, dtype=torch.float32, device=x.device) if out is None else out
+    need = int(_C.lib().dctr_crossnet_mix_workspace_bytes(d, L, ne, r))
+    ws = _scratch(x.device, need) if need else None
     _C.check(_C.lib().dctr_crossnet_mix_fwd(_ptr(x), x.shape[0], d, x.stride(0), _ptr(U), _ptr(V), _ptr(C), _ptr(gating),
-                                            _ptr(bias), L, ne, r, _ptr(y), y.stride(0), _C.stream_ptr()), "dctr_crossnet_mix_fwd")
+                                            _ptr(bias), L, ne, r, _ptr(y), y.stride(0), _ptr(ws), need, _C.stream_ptr()),
+             "dctr_crossnet_mix_fwd")
     return y
 
 

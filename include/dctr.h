@@ -265,11 +265,13 @@ int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_stride, int3
  *     x [B, dim] (row stride x_stride) -> y [B, dim] (row stride y_stride)
  *     U, V [layers, experts, dim, low_rank], C [layers, experts, low_rank, low_rank] (U_list / V_list / C_list stacked
  *     over layers, :481-500), gating [experts, dim] (the experts' Dense(1, use_bias=False) kernels, shared by every
- *     layer, :502), bias [layers, dim].  layers == 0 copies x to y.
+ *     layer, :502), bias [layers, dim].  layers == 0 copies x to y.  workspace: DEVICE scratch of
+ *     dctr_crossnet_mix_workspace_bytes() bytes (U transposed per call so that the projection back reads it coalesced).
  * ------------------------------------------------------------------------------------------------ */
+size_t dctr_crossnet_mix_workspace_bytes(int32_t dim, int32_t layers, int32_t experts, int32_t low_rank);
 int dctr_crossnet_mix_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* U, const float* V,
                           const float* C, const float* gating, const float* bias, int32_t layers, int32_t experts,
-                          int32_t low_rank, float* y, int64_t y_stride, void* stream);
+                          int32_t low_rank, float* y, int64_t y_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * sibling: BiInteractionPooling.call — deepctr/layers/interaction.py:190-203 (NFM)
