@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
     float* h1 = xl + (size_t)d * R;       // [H][R]   tanh(V^T x_l)
     float* h2 = h1 + (size_t)H * R;       // [H][R]   p_e * tanh(C v)
     float* gate = h2 + (size_t)H * R;     // [8][ne][R] partial gating dots
-    float* h1p = gate + (size_t)8 * ne * R;   // [P1][H][R] partial projections (P1 * H <= 256)
+    float* pw = gate + (size_t)8 * ne * R;    // [ne][R]  softmax weight of every expert
+    float* h1p = pw + (size_t)ne * R;         // [P1][H][R] partial projections (P1 * H <= 256)
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * R;
     // few low-rank columns: P1 threads share a column (each a slice of the j range) so that every wave has work
@@ -501,37 +502,36 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
                 for (int pp = 0; pp < P1; ++pp) sum += h1p[pp * H * R + o];
                 h1[o] = tanhf(sum);
             }
-            __syncthreads();
         }
+        // softmax over the experts' gating scores, once per (expert, row)
+        for (int it = tid; it < combos; it += 256) {
+            const int e = it / R, q = it - e * R;
+            float mine = 0.f, mx = -INFINITY, den = 0.f;
+            for (int t = 0; t < ne; ++t) {
+                float gsum = 0.f;
+                for (int pp = 0; pp < GP; ++pp) gsum += gate[(pp * ne + t) * R + q];
+                mx = fmaxf(mx, gsum);
+            }
+            for (int t = 0; t < ne; ++t) {
+                float gsum = 0.f;
+                for (int pp = 0; pp < GP; ++pp) gsum += gate[(pp * ne + t) * R + q];
+                const float ex = expf(gsum - mx);
+                den += ex;
+                if (t == e) mine = ex;
+            }
+            pw[e * R + q] = mine / den;
+        }
+        __syncthreads();
         // stage 2: r x r mixing in the low-rank space, scaled by the expert's softmax weight
         for (int c = tid; c < H; c += 256) {
             const int e = c / r, i = c - e * r;
-            const float* cw = Cl + ((size_t)e * r + i) * r;
-            float acc[R];
+            float acc[1][R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] = 0.f;
-            for (int m = 0; m < r; ++m) {
-                const float wv = cw[m];
+            for (int q = 0; q < R; ++q) acc[0][q] = 0.f;
+            const float* const w[1] = {Cl + ((size_t)e * r + i) * r};
+            dot_rows<R, 1>(h1 + (size_t)e * r * R, R, w, 1, 0, r, acc);
 #pragma unroll
-                for (int q = 0; q < R; ++q) acc[q] = fmaf(h1[(e * r + m) * R + q], wv, acc[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                float mine = 0.f, mx = -INFINITY, den = 0.f;
-                for (int t = 0; t < ne; ++t) {
-                    float gsum = 0.f;
-                    for (int pp = 0; pp < GP; ++pp) gsum += gate[(pp * ne + t) * R + q];
-                    mx = fmaxf(mx, gsum);
-                }
-                for (int t = 0; t < ne; ++t) {
-                    float gsum = 0.f;
-                    for (int pp = 0; pp < GP; ++pp) gsum += gate[(pp * ne + t) * R + q];
-                    const float ex = expf(gsum - mx);
-                    den += ex;
-                    if (t == e) mine = ex;
-                }
-                h2[c * R + q] = tanhf(acc[q]) * (mine / den);
-            }
+            for (int q = 0; q < R; ++q) h2[c * R + q] = tanhf(acc[0][q]) * pw[e * R + q];
         }
         __syncthreads();
         // stage 3: back to d columns (two per thread, sharing the broadcast reads), Hadamard with x_0, residual
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void cross_mix_kernel(const float* __restrict_
 }
 
 size_t cross_mix_lds_bytes(int d, int ne, int r, int R) {
-    return ((size_t)2 * d + 2 * (size_t)ne * r + 8 * (size_t)ne + 256) * R * sizeof(float);
+    return ((size_t)2 * d + 2 * (size_t)ne * r + 9 * (size_t)ne + 256) * R * sizeof(float);
 }
 
 int pow2_at_least(int v, int cap) {
