@@ -558,6 +558,53 @@ def _alias(name):
     return name
 
 
+def _h5py():
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError("Keras .h5 weight files need h5py, which is not installed; use the .npz form of "
+                          "save_weights / load_weights, or set_weights_by_name({'layer/weight': array})")
+    return h5py
+
+
+def _load_keras_h5(path, h5py=None):
+    """{"<layer>/<weight>": array} from a Keras HDF5 weight file (also the ``model_weights`` group of a full-model file).
+    Layout (keras/saving/hdf5_format.py, save_weights_to_hdf5_group): root attr ``layer_names``; one group per layer with attr
+    ``weight_names`` ("<scope>/<weight>:0") naming its datasets.  SURVEY §8(f) rank 4; parity unpinned: neither h5py nor
+    TensorFlow exists in this image, so no real file has been read yet (tests use a stand-in with the same layout)."""
+    h5py = h5py or _h5py()
+    out = OrderedDict()
+    with h5py.File(path, "r") as f:
+        g = f["model_weights"] if "layer_names" not in f.attrs and "model_weights" in f else f
+        for lname in g.attrs["layer_names"]:
+            lname = lname.decode("utf8") if isinstance(lname, bytes) else str(lname)
+            grp = g[lname]
+            for wname in grp.attrs["weight_names"]:
+                wname = wname.decode("utf8") if isinstance(wname, bytes) else str(wname)
+                parts = wname.split(":")[0].split("/")
+                # "<layer>/<weight>:0", or nested scopes ".../<sub-layer>/<weight>:0": the last scope owns the weight
+                key = "%s/%s" % (parts[-2] if len(parts) >= 2 else lname, parts[-1])
+                out[key] = np.asarray(grp[wname])
+    return out
+
+
+def _save_keras_h5(path, weights, h5py=None):
+    """Inverse of _load_keras_h5: one group per layer, datasets "<layer>/<weight>:0" (loadable with by_name=True)."""
+    h5py = h5py or _h5py()
+    layers = OrderedDict()
+    for key, val in weights.items():
+        lname, wname = key.rsplit("/", 1)
+        layers.setdefault(lname, []).append((wname, val))
+    with h5py.File(path, "w") as f:
+        f.attrs["layer_names"] = [n.encode("utf8") for n in layers]
+        f.attrs["backend"] = b"tensorflow"
+        for lname, ws in layers.items():
+            grp = f.create_group(lname)
+            grp.attrs["weight_names"] = [("%s/%s:0" % (lname, w)).encode("utf8") for w, _ in ws]
+            for w, val in ws:
+                grp.create_dataset("%s/%s:0" % (lname, w), data=np.asarray(val, dtype=np.float32))
+
+
 class Model(object):
     """Forward-only (HIP) model with the tf.keras.Model surface DeepCTR users call.  Subclasses set up
     ``self.inputs`` (OrderedDict name -> InputSpec, reference order), register layers with ``_add`` and
@@ -652,10 +699,18 @@ class Model(object):
                 raise KeyError("weights missing from the mapping: %s" % missing[:8])
 
     def save_weights(self, filepath, overwrite=True):
+        """``.h5`` / ``.hdf5``: the Keras HDF5 weight layout (needs h5py); anything else: an ``.npz`` keyed by
+        "<layer name>|<weight name>"."""
+        if str(filepath).endswith((".h5", ".hdf5")):
+            return _save_keras_h5(str(filepath), self.get_weights_by_name())
         path = filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz"
         np.savez(path, **{k.replace("/", "|"): v for k, v in self.get_weights_by_name().items()})
 
-    def load_weights(self, filepath):
+    def load_weights(self, filepath, by_name=True, strict=True):
+        """``.h5`` / ``.hdf5`` files written by ``tf.keras.Model.save_weights`` of the reference model (docs/source/FAQ.md:7-22)
+        are matched by layer and weight NAME (this build's list order is its own); otherwise the ``.npz`` of save_weights."""
+        if str(filepath).endswith((".h5", ".hdf5")):
+            return self.set_weights_by_name(_load_keras_h5(str(filepath)), strict=strict)
         path = filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz"
         z = np.load(path)
         self.set_weights_by_name({k.replace("|", "/"): z[k] for k in z.files})
