@@ -114,6 +114,12 @@ class CrossBwdArgs(ctypes.Structure):
                 ("workspace_bytes", c_sz)]
 
 
+class AfmBwdArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("fields", c_i32), ("dim", c_i32), ("att_factor", c_i32),
+                ("dx_accumulate", c_i32), ("att_w", c_vp), ("att_b", c_vp), ("proj_h", c_vp), ("proj_p", c_vp), ("dy", c_vp),
+                ("dx", c_vp), ("dx_stride", c_i64), ("d_att_w", c_vp), ("d_att_b", c_vp), ("d_proj_h", c_vp), ("d_proj_p", c_vp)]
+
+
 class HostCol(ctypes.Structure):
     _fields_ = [("src", c_vp), ("stride_bytes", c_i64), ("kind", c_i32), ("reserved_", c_i32)]
 
@@ -169,6 +175,7 @@ SYMBOLS = {
     "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
     "dctr_embed_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolBwdArgs), c_vp]),
+    "dctr_afm_bwd": (ctypes.c_int, [c_vp, c_vp]),
     "dctr_bi_interaction_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_inner_product_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_dense1_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),

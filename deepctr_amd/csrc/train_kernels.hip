@@ -646,7 +646,170 @@ __global__ __launch_bounds__(256) void inner_product_bwd_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward of AFMLayer (interaction.py:116-146).  Same shape as the forward kernel: one wave per sample, the sample's [F,E]
+// tile and the layer's weights in LDS, lanes walk the F(F-1)/2 pairs; nothing was saved by the forward, so the attention
+// logits and the softmax are recomputed.  With bi_p = x_i * x_j, pre_pa = b_a + sum_e bi_pe W_ea, s_p = sum_a relu(pre_pa) h_a,
+// alpha = softmax_p(s), t_p = bi_p . proj_p, y = sum_p alpha_p t_p and g = dy:
+//     ds_p = alpha_p (g t_p - g y),  d pre_pa = ds_p h_a [pre_pa > 0],  d bi_pe = g alpha_p proj_p[e] + sum_a d pre_pa W_ea,
+//     d x_i += d bi_p * x_j,  d x_j += d bi_p * x_i;   weight gradients are summed in LDS per workgroup, then one atomic each.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void afm_pair_ij(int p, int F, int& i, int& j) {
+    int ii = 0, rem = p;
+    while (rem >= F - 1 - ii) {
+        rem -= F - 1 - ii;
+        ++ii;
+    }
+    i = ii;
+    j = ii + 1 + rem;
+}
+
+__global__ __launch_bounds__(256) void afm_bwd_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F, int E,
+                                                      const float* __restrict__ att_w, const float* __restrict__ att_b,
+                                                      const float* __restrict__ proj_h, const float* __restrict__ proj_p, int A,
+                                                      const float* __restrict__ dy, float* __restrict__ dx, int64_t dx_stride,
+                                                      int accumulate, float* __restrict__ g_w, float* __restrict__ g_b,
+                                                      float* __restrict__ g_h, float* __restrict__ g_p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = F * (F - 1) / 2;
+    const int NW = E * A + 2 * A + E;
+    float* wsh = smem;                       // [E*A] attention_W, then b[A], h[A], p[E]
+    float* bsh = wsh + E * A;
+    float* hsh = bsh + A;
+    float* psh = hsh + A;
+    float* gsh = psh + E;                    // gradients in the same order: W, b, h, p
+    float* per_wave = gsh + NW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* xs = per_wave + wave * (2 * F * E + P);   // [F*E] sample tile
+    float* dxs = xs + F * E;                         // [F*E] its gradient
+    float* alpha = dxs + F * E;                      // [P]
+    for (int i = threadIdx.x; i < E * A; i += 256) wsh[i] = att_w[i];
+    for (int i = threadIdx.x; i < A; i += 256) {
+        bsh[i] = att_b[i];
+        hsh[i] = proj_h[i];
+    }
+    for (int i = threadIdx.x; i < E; i += 256) psh[i] = proj_p[i];
+    for (int i = threadIdx.x; i < NW; i += 256) gsh[i] = 0.f;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    const bool valid = b < batch;
+    if (valid)
+        for (int i = lane; i < F * E; i += 64) {
+            xs[i] = x[b * x_stride + i];
+            dxs[i] = 0.f;
+        }
+    __syncthreads();
+    if (valid) {
+        // forward recompute: logits, softmax, y
+        float mx = -INFINITY;
+        for (int p = lane; p < P; p += 64) {
+            int i, j;
+            afm_pair_ij(p, F, i, j);
+            float lg = 0.f;
+            for (int a = 0; a < A; ++a) {
+                float t = bsh[a];
+                for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e] * xs[j * E + e], wsh[e * A + a], t);
+                lg = fmaf(fmaxf(t, 0.f), hsh[a], lg);
+            }
+            alpha[p] = lg;
+            mx = fmaxf(mx, lg);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        float den = 0.f;
+        for (int p = lane; p < P; p += 64) {
+            const float e_ = expf(alpha[p] - mx);
+            alpha[p] = e_;
+            den += e_;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) den += __shfl_xor(den, m, 64);
+        float yv = 0.f;
+        for (int p = lane; p < P; p += 64) {
+            int i, j;
+            afm_pair_ij(p, F, i, j);
+            const float sc = alpha[p] / den;
+            alpha[p] = sc;
+            float t = 0.f;
+            for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e] * xs[j * E + e], psh[e], t);
+            yv = fmaf(sc, t, yv);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) yv += __shfl_xor(yv, m, 64);
+        // backward per pair
+        const float g = dy[b];
+        for (int p = lane; p < P; p += 64) {
+            int i, j;
+            afm_pair_ij(p, F, i, j);
+            const float sc = alpha[p];
+            float t = 0.f;
+            for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e] * xs[j * E + e], psh[e], t);
+            const float ds = sc * g * (t - yv);
+            const float gsc = g * sc;
+            for (int e = 0; e < E; ++e) {
+                const float bi = xs[i * E + e] * xs[j * E + e];
+                atomicAdd(&gsh[E * A + 2 * A + e], gsc * bi);                        // d proj_p
+                const float dbi = gsc * psh[e];
+                atomicAdd(&dxs[i * E + e], dbi * xs[j * E + e]);
+                atomicAdd(&dxs[j * E + e], dbi * xs[i * E + e]);
+            }
+            for (int a = 0; a < A; ++a) {
+                float pre = bsh[a];
+                for (int e = 0; e < E; ++e) pre = fmaf(xs[i * E + e] * xs[j * E + e], wsh[e * A + a], pre);
+                if (pre > 0.f) {
+                    atomicAdd(&gsh[E * A + A + a], ds * pre);                        // d proj_h
+                    const float dpre = ds * hsh[a];
+                    atomicAdd(&gsh[E * A + a], dpre);                                // d attention_b
+                    for (int e = 0; e < E; ++e) {
+                        const float xi = xs[i * E + e], xj = xs[j * E + e];
+                        atomicAdd(&gsh[e * A + a], dpre * xi * xj);                  // d attention_W
+                        const float dbi = dpre * wsh[e * A + a];
+                        atomicAdd(&dxs[i * E + e], dbi * xj);
+                        atomicAdd(&dxs[j * E + e], dbi * xi);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        float* d = dx + b * dx_stride;
+        for (int i = lane; i < F * E; i += 64) d[i] = accumulate ? d[i] + dxs[i] : dxs[i];
+    }
+    for (int i = threadIdx.x; i < NW; i += 256) {
+        const float v = gsh[i];
+        if (v != 0.f) {
+            float* dst = i < E * A ? g_w + i : i < E * A + A ? g_b + (i - E * A) : i < E * A + 2 * A ? g_h + (i - E * A - A)
+                                                                                                   : g_p + (i - E * A - 2 * A);
+            unsafeAtomicAdd(dst, v);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int dctr_afm_bwd(const dctr_afm_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "afm_bwd: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->fields >= 2 && a->dim >= 1 && a->att_factor >= 1, DCTR_E_DIM, "afm_bwd: bad sizes");
+    DCTR_REQUIRE(a->x_stride >= (int64_t)a->fields * a->dim && a->dx_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM,
+                 "afm_bwd: stride smaller than fields*dim");
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->x && a->att_w && a->att_b && a->proj_h && a->proj_p && a->dy && a->dx, DCTR_E_NULL, "afm_bwd: null pointer");
+    DCTR_REQUIRE(a->d_att_w && a->d_att_b && a->d_proj_h && a->d_proj_p, DCTR_E_NULL, "afm_bwd: null gradient pointer");
+    const int P = a->fields * (a->fields - 1) / 2;
+    const size_t nw = (size_t)a->dim * a->att_factor + 2 * a->att_factor + a->dim;
+    const size_t lds = (2 * nw + 4 * (2 * (size_t)a->fields * a->dim + P)) * sizeof(float);
+    DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "afm_bwd: needs %zu B of LDS", lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)afm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DCTR_REQUIRE(e == hipSuccess, (int)e, "afm_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    }
+    const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)4);
+    DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "afm_bwd: batch too large");
+    hipLaunchKernelGGL(afm_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a->x, a->x_stride, a->batch,
+                       (int)a->fields, (int)a->dim, a->att_w, a->att_b, a->proj_h, a->proj_p, (int)a->att_factor, a->dy, a->dx,
+                       a->dx_stride, (int)a->dx_accumulate, a->d_att_w, a->d_att_b, a->d_proj_h, a->d_proj_p);
+    return dctr_launch_status("dctr_afm_bwd");
+}
 
 extern "C" int dctr_bi_interaction_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
                                        int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream) {

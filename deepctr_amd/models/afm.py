@@ -39,6 +39,7 @@ class _AFM(FeatureModel):
                     layer.build([(None, 1, dim)] * n)
                     self.afm_layers.append(self._add(layer))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
+        self.dnn = self.dense = None            # AFM has neither (afm.py:45-58); the HIP training step asks
         self._buf = {}
 
     def _forward(self, staged, lo, hi, out):
@@ -71,5 +72,7 @@ class _AFM(FeatureModel):
 def AFM(linear_feature_columns, dnn_feature_columns, fm_group=DEFAULT_GROUP_NAME, use_attention=True, attention_factor=8,
         l2_reg_linear=1e-5, l2_reg_embedding=1e-5, l2_reg_att=1e-5, afm_dropout=0, seed=1024, task='binary', device=None):
     """Instantiates the Attentional Factorization Machine architecture on the MI355X forward path."""
-    return _AFM(linear_feature_columns, dnn_feature_columns, fm_group, use_attention, attention_factor, l2_reg_att,
-                afm_dropout, seed, task, device)
+    m = _AFM(linear_feature_columns, dnn_feature_columns, fm_group, use_attention, attention_factor, l2_reg_att,
+             afm_dropout, seed, task, device)
+    m.regularizers = {"embedding": float(l2_reg_embedding), "linear": float(l2_reg_linear), "dnn": 0.0}
+    return m

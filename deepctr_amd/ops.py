@@ -656,6 +656,19 @@ def dense1_bwd(x, n, w, dlogit, dx, d_w):
                                       _ptr(d_w), _C.stream_ptr()), "dctr_dense1_bwd")
 
 
+def afm_bwd(x, fields, dim, attention_W, attention_b, projection_h, projection_p, dy, dx, d_W, d_b, d_h, d_p, accumulate=False):
+    """Backward of afm() on a strided [B, >= F*E] buffer: dy [B]; dx [B, >= F*E] written (or added to); the four weight
+    gradients (shapes of the weights) are ACCUMULATED (include/dctr.h)."""
+    _dev_check(x, attention_W, attention_b, projection_h, projection_p, dy, dx, d_W, d_b, d_h, d_p)
+    a = _C.AfmBwdArgs(x=x.data_ptr(), batch=x.shape[0], x_stride=x.stride(0), fields=int(fields), dim=int(dim),
+                      att_factor=attention_W.shape[1], dx_accumulate=int(bool(accumulate)),
+                      att_w=_f32c(attention_W, "W").data_ptr(), att_b=_f32c(attention_b, "b").data_ptr(),
+                      proj_h=_f32c(projection_h, "h").data_ptr(), proj_p=_f32c(projection_p, "p").data_ptr(),
+                      dy=_f32c(dy, "dy").data_ptr(), dx=dx.data_ptr(), dx_stride=dx.stride(0), d_att_w=d_W.data_ptr(),
+                      d_att_b=d_b.data_ptr(), d_proj_h=d_h.data_ptr(), d_proj_p=d_p.data_ptr())
+    _C.check(_C.lib().dctr_afm_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_afm_bwd")
+
+
 def bi_interaction_bwd(x, fields, dim, dy, dx, accumulate=False):
     """Backward of bi_interaction on a strided [B, >= F*E] buffer: dy [B, >= E], dx [B, >= F*E] (include/dctr.h)."""
     _dev_check(x, dy, dx)

@@ -1,11 +1,12 @@
 """HIP training step — SURVEY.md §8(f) rank 1: backward + optimizer of the hot path on HIP kernels.
 
 Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer: DeepFM, WDL, FNN;
-NFM and PNN add their interaction layer's forward / backward kernel in front of the DNN), DCN and xDeepFM,
+NFM and PNN add their interaction layer's forward / backward kernel in front of the DNN; AFM has its
+AFMLayer instead of the DNN), DCN and xDeepFM,
 sequence features included: forward = ``dctr_embed_pool`` per sequence feature + ``dctr_embed_gather_fm`` +
 ``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` → ``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` →
 ``dctr_embed_pool_bwd`` → ``dctr_opt_multi`` (one launch over every parameter).  No torch autograd, no torch
-optimizer: PyTorch only owns the buffers.  Models / options outside that family (DIN, AFM, Dice / BatchNormalization /
+optimizer: PyTorch only owns the buffers.  Models / options outside that family (DIN, DCNMix, Dice / BatchNormalization /
 dropout in training mode) keep the torch-autograd step of ``training.py``: their attention backward kernels do not exist yet.
 
 Semantics follow tf.keras as the reference uses it (``model.compile("adam", "binary_crossentropy")``,
@@ -26,10 +27,12 @@ def supported(model):
     sp = getattr(model, "stage_plan", None)
     dnn = getattr(model, "dnn", None)
     kind = type(model).__name__
-    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM", "_NFM", "_PNN"):
+    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM", "_NFM", "_PNN", "_AFM"):
         return False
     if sp.lin_only or len(sp.fm_group_names) > 1 or not sp.all_dim4 or sp.max_dim > 64:
         return False
+    if kind == "_AFM":                      # no DNN: linear logit + AFMLayer per group (or the gather's FM group)
+        return not any(getattr(layer, "dropout_rate", 0) for layer in model.afm_layers)
     if sp.extra_offsets and kind not in ("_NFM", "_PNN"):       # the interaction columns those two reserve in dnn_in
         return False
     if kind in ("_DeepFM", "_xDeepFM", "_NFM", "_PNN") and (dnn is None or not dnn.kernels):
@@ -106,11 +109,17 @@ class HipTrainer(object):
             self.p_dense_lin = param(model.linear.w("linear_kernel"), l2l)
             self.dense_rows = torch.as_tensor(sp.dense_lin_rows, dtype=torch.int32, device=model.device)
         self.is_dcn = type(model).__name__ == "_DCN"
+        self.is_afm = type(model).__name__ == "_AFM"
+        self.p_afm = []
+        if self.is_afm:
+            for layer in model.afm_layers:      # l2_reg_att applies to attention_W only (interaction.py:100)
+                self.p_afm.append((param(layer.w("attention_W"), getattr(layer, "l2_reg_w", 0.0)), param(layer.w("attention_b")),
+                                   param(layer.w("projection_h")), param(layer.w("projection_p"))))
         self.is_nfm = type(model).__name__ == "_NFM"
         self.is_pnn = type(model).__name__ == "_PNN"
         self.p_kernels = [param(k, l2d) for k in model.dnn.kernels] if model.dnn is not None else []
         self.p_biases = [param(b) for b in model.dnn.biases] if model.dnn is not None else []
-        self.p_head = param(model.dense.w("kernel"))
+        self.p_head = param(model.dense.w("kernel")) if getattr(model, "dense", None) is not None else None
         self.is_xdeepfm = type(model).__name__ == "_xDeepFM"
         self.p_cin_f = self.p_cin_b = self.p_head1 = None
         if self.is_xdeepfm and model.cin is not None:
@@ -201,6 +210,31 @@ class HipTrainer(object):
             ops.cin_bwd(ws["dnn_in"], filt, cin.biases, list(cin.layer_size), cin.split_half, cin.activation, buf["dmaps"],
                         [p.g.reshape(-1, p.g.shape[-1]) for p in self.p_cin_f], [p.g for p in self.p_cin_b], dx=buf["dx"],
                         accumulate=True, fields=nf, dim=dim)
+
+    def _afm_forward_backward(self, ws, buf, y, B, binary):
+        """AFM (models/afm.py:45-58): linear logit + one AFMLayer per group (with attention), or the gather's FM term."""
+        model, sp = self.model, self.model.stage_plan
+        add = [ws["lin"]] if sp.has_linear else []
+        if sp.fm_group_names:
+            add.append(ws["fm"])
+        if "afm_out" not in buf:
+            buf["afm_out"] = [torch.zeros(B, 1, dtype=torch.float32, device=model.device) for _ in model.afm_layers]
+        outs = buf["afm_out"]
+        for g, layer, o in zip(model.groups, model.afm_layers, outs):
+            first, n, dim = sp.group_slices[g]
+            ops.afm(ws["dnn_in"][:, first:], layer.w("attention_W"), layer.w("attention_b"), layer.w("projection_h"),
+                    layer.w("projection_p"), fields=n, dim=dim, out=o)
+        head_in = outs[0] if outs else add[0].reshape(-1, 1)
+        rest = [o.reshape(-1) for o in outs[1:]] if outs else add[1:]
+        ops.mlp(head_in, [], [], "linear", head_w=model._one(), add=(add + rest) if outs else rest,
+                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=1, out=buf["pred"])
+        self._loss_grad(buf, y, binary)
+        dx = buf["dx"]
+        dx.zero_()                                   # groups outside fm_group contribute nothing to the logit
+        for g, layer, ps in zip(model.groups, model.afm_layers, self.p_afm):
+            first, n, dim = sp.group_slices[g]
+            ops.afm_bwd(ws["dnn_in"][:, first:], n, dim, layer.w("attention_W"), layer.w("attention_b"), layer.w("projection_h"),
+                        layer.w("projection_p"), buf["dlogit"], dx[:, first:], ps[0].g, ps[1].g, ps[2].g, ps[3].g)
 
     def _nfm_forward_backward(self, ws, buf, y, binary):
         """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) | dense] -> Dense(1) + linear logit."""
@@ -296,6 +330,8 @@ class HipTrainer(object):
             sp.pool_trace = None
         if self.is_dcn:
             self._dcn_forward_backward(ws, buf, y, B, binary)
+        elif self.is_afm:
+            self._afm_forward_backward(ws, buf, y, B, binary)
         elif self.is_nfm:
             self._nfm_forward_backward(ws, buf, y, binary)
         elif self.is_pnn:

@@ -460,6 +460,28 @@ int dctr_bi_interaction_bwd(const float* x, int64_t batch, int64_t x_stride, int
 int dctr_inner_product_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
                            int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream);
 
+/* backward of dctr_afm_fwd (AFMLayer.call, interaction.py:116-146); the attention is recomputed, nothing is saved by the
+ * forward.  dy [B] = gradient w.r.t. the layer's [B,1] output; dx [B, dx_stride]: first fields*dim columns written (or
+ * added to); d_att_w [dim, att_factor], d_att_b [att_factor], d_proj_h [att_factor], d_proj_p [dim] are ACCUMULATED. */
+typedef struct {
+    const float* x;               /* as in the forward: [B, x_stride], fields*dim used                    */
+    int64_t batch;
+    int64_t x_stride;
+    int32_t fields, dim, att_factor, dx_accumulate;
+    const float* att_w;
+    const float* att_b;
+    const float* proj_h;
+    const float* proj_p;
+    const float* dy;
+    float* dx;
+    int64_t dx_stride;
+    float* d_att_w;
+    float* d_att_b;
+    float* d_proj_h;
+    float* d_proj_p;
+} dctr_afm_bwd_args_t;
+int dctr_afm_bwd(const dctr_afm_bwd_args_t* args, void* stream);
+
 /* backward of dctr_crossnet_fwd (interaction.py:405-424); x_l are recomputed, nothing is saved by the forward.
  * vector: one fused kernel.  matrix: rocBLAS GEMMs + elementwise kernels through the workspace. */
 typedef struct {

