@@ -269,3 +269,26 @@ def test_keras_h5_weight_layout_round_trip(monkeypatch):
     except ImportError:
         with pytest.raises(ImportError, match="npz"):
             engine._h5py()
+
+
+def test_product_package_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under deepctr_amd/ (nor bench.py's timed path) may import oracle/ or read
+    /root/reference; the HIP library must be the only compute path (DctrExtensionError otherwise)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepctr_amd")
+    # imports of the oracle, or code that opens / joins / imports from the reference tree (docstrings only cite file:line)
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|(open\(|path|import).*/root/reference|/root/reference.*(open\(|path|import)")
+    bad = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")):
+                with open(os.path.join(d, f), errors="replace") as fh:
+                    for n, line in enumerate(fh, 1):
+                        if pat.search(line):
+                            bad.append("%s:%d" % (os.path.join(d, f), n))
+    assert not bad, bad
+    import torch
+    from deepctr_amd import _C, ops
+    with pytest.raises(_C.DctrExtensionError, match="no CPU path"):
+        ops.fm(torch.zeros(2, 3, 4))
