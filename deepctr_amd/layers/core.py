@@ -5,7 +5,7 @@ logits and the PredictionLayer into the same launch."""
 import torch
 
 from .. import ops
-from ..initializers import GlorotNormal, Ones, Zeros
+from ..initializers import GlorotNormal, Zeros
 from .activation import SUPPORTED, Dice
 from .base import Layer
 

@@ -1,15 +1,9 @@
 """Shared wiring for the in-scope model constructors."""
-from collections import OrderedDict
-
-import torch
-
 from .. import ops
-from ..engine import EmbeddingStage, Model
+from ..engine import Model
 from ..feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
 from ..initializers import Zeros
 from ..inputs import create_embedding_matrix
-from ..layers.base import name_scope
-from ..layers.core import DNN, Dense, PredictionLayer
 from ..layers.utils import Linear
 
 

@@ -10,7 +10,7 @@ import torch
 
 from ... import ops
 from ...engine import EmbeddingStage, prehashed_on_host
-from ...feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+from ...feature_column import SparseFeat, VarLenSparseFeat
 from ...layers.base import name_scope
 from ...layers.core import DNN, Dense, PredictionLayer
 from ...layers.sequence import AttentionSequencePoolingLayer

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from .engine import prehashed_on_host
-from .feature_column import SparseFeat, VarLenSparseFeat
+from .feature_column import SparseFeat
 
 
 class History(object):
