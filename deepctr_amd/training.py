@@ -298,6 +298,12 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
             and ((loss_name0 in ("binary_crossentropy", "logloss") and model.task == "binary")
                  or (loss_name0 in ("mse", "mean_squared_error") and model.task != "binary"))):
         return _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
+    return _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
+
+
+def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle):
+    """fit() on torch autograd over ``model_logits`` (models / options outside the HIP step).  Device-agnostic torch code: the
+    CPU suite drives it directly on CPU-built models; evaluate() of a validation split needs the GPU forward."""
     params = [t for name, t in model.named_weights() if "moving_" not in name]
     for t in params:
         t.requires_grad_(True)

@@ -62,3 +62,39 @@ def test_restatement_is_differentiable_on_cpu():
     used = [gr for gr in grads if gr is not None]
     assert len(used) >= len(params) - 2 and all(torch.isfinite(gr).all() for gr in used)
     assert any(float(gr.abs().max()) > 0 for gr in used)
+
+
+@pytest.mark.parametrize("kind", ["DIN", "DCNMix"])
+def test_torch_step_trains_the_models_outside_the_hip_step_on_cpu(kind):
+    """fit()'s torch-autograd loop (training._fit_torch) for the two models that still use it, driven on CPU: the loss of a
+    learnable rule goes down and only trainable weights move (Dice's moving statistics stay put)."""
+    from deepctr_amd import engine, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DIN, DCNMix
+    rng = np.random.RandomState(6)
+    n, T, E = 512, 4, 4
+    cpu = torch.device("cpu")
+    if kind == "DIN":
+        cols = [SparseFeat("user", 20, E), SparseFeat("item_id", 13, E), DenseFeat("score", 1),
+                VarLenSparseFeat(SparseFeat("hist_item_id", 13, E, embedding_name="item_id"), maxlen=T)]
+        model = DIN(cols, ["item_id"], dnn_hidden_units=(8, 4), att_hidden_size=(6, 3), device=cpu)
+        hist = rng.randint(1, 13, (n, T))
+        hist[np.arange(T)[None, :] >= rng.randint(1, T + 1, n)[:, None]] = 0
+        feed = {"user": rng.randint(0, 20, n), "item_id": rng.randint(1, 13, n), "score": rng.rand(n).astype(np.float32),
+                "hist_item_id": hist}
+        y = (feed["item_id"] % 2).astype(np.float32)
+    else:
+        cols = [SparseFeat("a", 20, E), SparseFeat("b", 9, E), DenseFeat("d", 2)]
+        model = DCNMix(cols, cols, cross_num=2, dnn_hidden_units=(8, 4), low_rank=3, num_experts=2, device=cpu)
+        feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 9, n), "d": rng.rand(n, 2).astype(np.float32)}
+        y = (feed["a"] % 2).astype(np.float32)
+    model.compile("adam", "binary_crossentropy")
+    staged = engine.Staged(n)
+    model._stage_inputs(feed, staged)
+    before = {k: v.copy() for k, v in model.get_weights_by_name().items()}
+    h = training._fit_torch(model, feed, staged, torch.from_numpy(y), y, n, 0, 64, 6, 0, True)
+    assert len(h.history["loss"]) == 6 and h.history["loss"][-1] < h.history["loss"][0] - 0.01, h.history["loss"]
+    after = model.get_weights_by_name()
+    moved = [k for k in before if not np.array_equal(before[k], after[k])]
+    assert moved and not any("moving_" in k for k in moved)
+    assert all(not t.requires_grad for t in model.weights)
