@@ -96,5 +96,49 @@ def test_torch_step_trains_the_models_outside_the_hip_step_on_cpu(kind):
     assert len(h.history["loss"]) == 6 and h.history["loss"][-1] < h.history["loss"][0] - 0.01, h.history["loss"]
     after = model.get_weights_by_name()
     moved = [k for k in before if not np.array_equal(before[k], after[k])]
-    assert moved and not any("moving_" in k for k in moved)
+    assert moved
+    if kind == "DIN":          # att_activation='dice': its BatchNormalization statistics follow the batches (training mode)
+        stats = [k for k in moved if "moving_" in k]
+        assert len(stats) == 4, stats
+        assert all(np.isfinite(after[k]).all() for k in stats) and all((after[k] > 0).all() for k in stats if "variance" in k)
+    else:
+        assert not any("moving_" in k for k in moved)
     assert all(not t.requires_grad for t in model.weights)
+
+
+def test_dice_training_mode_follows_keras_batchnormalization():
+    """training._act(..., training=True) = Dice over tf.keras' BatchNormalization(center=False, scale=False, epsilon=1e-9) in
+    training mode (layers/activation.py:51-64): batch statistics over every axis but the last, biased variance, moving
+    statistics updated with momentum 0.99, gradients through the statistics; training=False uses the stored statistics."""
+    from deepctr_amd import training
+    rng = np.random.RandomState(1)
+    x = torch.from_numpy(rng.standard_normal((5, 7, 3))).double().requires_grad_(True)
+    alpha = torch.from_numpy(rng.standard_normal(3)).double()
+    mm = torch.from_numpy(rng.standard_normal(3)).double()
+    mv = torch.from_numpy(rng.uniform(0.5, 1.5, 3)).double()
+    mm0, mv0 = mm.clone(), mv.clone()
+    y = training._act("dice", x, (alpha, mm, mv), training=True)
+    xn = x.detach().numpy().reshape(-1, 3)
+    bm, bv = xn.mean(0), xn.var(0)                                   # numpy var is the biased one
+    p = 1.0 / (1.0 + np.exp(-(x.detach().numpy() - bm) / np.sqrt(bv + 1e-9)))
+    ref = alpha.numpy() * (1 - p) * x.detach().numpy() + p * x.detach().numpy()
+    np.testing.assert_allclose(y.detach().numpy(), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mm.numpy(), 0.99 * mm0.numpy() + 0.01 * bm, rtol=1e-12)
+    np.testing.assert_allclose(mv.numpy(), 0.99 * mv0.numpy() + 0.01 * bv, rtol=1e-12)
+    # the batch statistics are part of the graph: shifting every input by a constant changes nothing, so the gradient sums to 0
+    # over the batch for the normalised path; check against finite differences on one element instead
+    g, = torch.autograd.grad(y.sum(), x)
+    eps = 1e-6
+    xp = x.detach().clone()
+    xp[2, 3, 1] += eps
+    yp = training._act("dice", xp, (alpha, mm.clone(), mv.clone()), training=True).sum()
+    xm = x.detach().clone()
+    xm[2, 3, 1] -= eps
+    ym = training._act("dice", xm, (alpha, mm.clone(), mv.clone()), training=True).sum()
+    assert abs(float((yp - ym) / (2 * eps)) - float(g[2, 3, 1])) < 1e-6
+    # inference form: stored statistics, nothing updated
+    mm1, mv1 = mm.clone(), mv.clone()
+    yi = training._act("dice", x.detach(), (alpha, mm, mv))
+    pi = 1.0 / (1.0 + np.exp(-(x.detach().numpy() - mm1.numpy()) / np.sqrt(mv1.numpy() + 1e-9)))
+    np.testing.assert_allclose(yi.numpy(), alpha.numpy() * (1 - pi) * x.detach().numpy() + pi * x.detach().numpy(), rtol=1e-12)
+    assert torch.equal(mm, mm1) and torch.equal(mv, mv1)
