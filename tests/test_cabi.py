@@ -159,3 +159,25 @@ def test_every_ctypes_mirror_has_the_layout_the_c_compiler_gives_the_header(tmp_
         cls = getattr(_C, py)
         want = ctypes.sizeof(cls) if field == "sizeof" else getattr(cls, field).offset
         assert int(val) == want, "%s.%s: C says %s, ctypes %d" % (py, field, val, want)
+
+
+def test_host_packer_is_clean_under_asan_ubsan(tmp_path):
+    """host_pack.cpp is the one piece of multi-threaded host code in the library: build it (host side only) with AddressSanitizer
+    + UndefinedBehaviorSanitizer together with tests/native/host_pack_san.cpp and run it."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "deepctr_amd", "csrc")
+    exe = tmp_path / "host_pack_san"
+    cmd = [hipcc, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "--offload-host-only", "-x", "hip",
+           "-I", os.path.join(root, "include"), "-I", csrc, os.path.join(csrc, "host_pack.cpp"), os.path.join(csrc, "abi.cpp"),
+           os.path.join(root, "tests", "native", "host_pack_san.cpp"), "-o", str(exe), "-pthread"]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", LD_LIBRARY_PATH="/opt/rocm/lib" + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
