@@ -7,28 +7,36 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the whole hot path over ONE batch of 4096 rows per GPU: ids -> multi-table gather + linear
-term + FM -> DNN 429-256-128-64 + Dense(1) + logit sum + sigmoid, as ONE launch (``dctr_embed_mlp_fwd``: the DNN
-input tile is gathered straight into LDS).  Nothing is skipped, inputs are device-resident before the timed region,
-every step reads a DIFFERENT batch of ids (a ring of --ring batches, so rows are not L2-hot from the previous
-step).  The K timed steps are captured in one hipGraph (the host cost of a ctypes call would otherwise dominate a
-~20 us step) with --streams independent batches in flight; the timed region is bracketed by barrier +
-synchronize, MAX over ranks.
+term + FM -> DNN 429-256-128-64 + Dense(1) + logit sum + sigmoid.  Nothing is skipped, inputs are device-resident
+before the timed region, every step reads a DIFFERENT batch of ids (a ring of distinct batches).
 
-Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free; the final logits of the
-K steps are all-gathered ONCE (RCCL) inside the timed region — the path's only exchange.
+How the K steps are issued.  The forward is row-independent and the fused path owns no per-batch buffer, so the product
+(`model.predict`) hands the library spans of many batches per launch; `dctr_embed_mlp_fwd` then runs its persistent
+streaming kernel (csrc/stream_kernels.hip: 64-row tiles, LDS-DMA gather ring, loader + MFMA waves).  The bench does
+the same: the K steps go out as ceil(K / G) launches of G consecutive batches (--launch-batches, default min(K, 64)),
+exactly K * 4096 rows per GPU inside the timed region, bracketed by barrier + synchronize, MAX over ranks.
+`one_launch_per_batch` in the JSON line is the other extreme measured right after (one launch per 4096-row batch, K of
+them in one hipGraph on 8 streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
+
+Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free; the logits of the K steps are
+all-gathered ONCE (RCCL) inside the timed region — the path's only exchange.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the timed step = the fused gather+DNN kernel.  It is bound by the fp32
+  roofline      the dominant kernel of the timed region = stream_kernel (fused gather + DNN).  It is bound by the fp32
                 matrix pipe (301,696 DNN FLOP/sample against 1,928 algorithmic HBM bytes/sample): achieved TFLOP/s =
-                algorithmic FLOP per launch / mean dispatch duration (per-dispatch start/stop events via
-                hipExtLaunchKernelGGL = the quantity rocprofv3 --kernel-trace reports), peak 157.3 TF; its HBM
-                figure (algorithmic bytes / the same duration, of 8 TB/s) is reported next to it as hbm_frac.
-  kernels       the same for the two stand-alone kernels of the unfused path: gather_fm_kernel (the HBM-bound
-                kernel north_star names: 1,928 B/sample) and mlp_kernel (MFMA-bound).
-  cpu_baseline  the oracle's torch-CPU restatement of the reference op sequence timed on the host cores
-                (rank 0, N=1 only; TensorFlow itself is not installable here — BASELINE.md §4).
+                algorithmic FLOP per launch / mean launch duration, measured live: every launch of the timed region goes
+                out through hipExtLaunchKernelGGL with a start/stop event pair on its own stream (dctr_profile_arm) =
+                the quantity rocprofv3 --kernel-trace reports; peak 157.3 TF; its HBM figure (algorithmic bytes / the
+                same duration, of 8 TB/s) is reported next to it as hbm_frac.  `traffic` = FETCH_SIZE + WRITE_SIZE per
+                launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json, `traffic_source`), scaled
+                to this launch's rows — not measured in this run.
+  kernels       isolated single-batch launches of the 32-row fused kernel and of the two stand-alone kernels of the unfused
+                path: gather_fm_kernel (the HBM-bound kernel north_star names) and mlp_kernel (MFMA-bound).
+  cpu_baseline  the oracle's torch-CPU restatement of the reference op sequence on the host cores, best of a sweep over
+                thread counts (rank 0, N=1 only; TensorFlow itself is not installable here — BASELINE.md §4).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -46,6 +54,7 @@ ALG_BYTES_PER_SAMPLE = F * 4 + F * E * 4 + F * 4 + ND * 4 + 4          # 1,928 B
 DNN_FLOP_PER_SAMPLE = 2 * ((F * E + ND) * 256 + 256 * 128 + 128 * 64 + 64)   # 301,696
 HBM_PEAK_GBS = 8000.0
 F32_MFMA_PEAK_TF = 157.3
+F32_MFMA_SUSTAINED_TF = 139.8   # scripts/mfma_lab.cpp, pure v_mfma_f32_16x16x4 loop on all CUs (profiles/r02_mfma_lab.log)
 
 
 def build_model(device):
@@ -81,9 +90,9 @@ def synthetic_feed(rows, seed, dist="uniform"):
     return feed
 
 
-def probe_kernels(model, staged, ring, reps=64):
-    """Mean per-dispatch duration (start/stop events around single dispatches = what rocprofv3 --kernel-trace
-    reports) of (a) the kernel(s) the timed step launches and (b) the two stand-alone kernels of the unfused path."""
+def probe_kernels(model, staged, ring, reps=48):
+    """Mean duration of isolated single-batch dispatches (start/stop events around ONE dispatch = what rocprofv3
+    --kernel-trace reports) of the 32-row fused kernel and of the two stand-alone kernels of the unfused path."""
     from deepctr_amd import _C, ops
     lib = _C.lib()
     sp = model.stage_plan
@@ -109,25 +118,53 @@ def probe_kernels(model, staged, ring, reps=64):
     return mean(t_step), mean(t_gather), mean(t_mlp)
 
 
-def cpu_baseline(model, cols, budget_s=12.0):
-    """The oracle's CPU port of the reference op sequence on a bounded sample of the same workload."""
+def cpu_baseline(model, cols, budget_s=20.0):
+    """The oracle's CPU port of the reference op sequence on a bounded sample of the same workload; torch's intra-op thread
+    count is swept (all cores over-subscribe the small ops of a 4096-row batch) and the best setting is reported."""
     from oracle.cpu_deepfm import CpuDeepFM
     cpu = CpuDeepFM(model.get_weights_by_name(), F, ND)
     feed = synthetic_feed(B, 7)
     ids = [torch.from_numpy(feed["C%d" % i].astype(np.int64)) for i in range(1, F + 1)]
     dense = [torch.from_numpy(feed["I%d" % i]).reshape(-1, 1) for i in range(1, ND + 1)]
-    for _ in range(3):
-        cpu.forward(ids, dense)
-    times = []
-    t_end = time.time() + budget_s
-    while time.time() < t_end or len(times) < 10:
-        t0 = time.perf_counter()
-        cpu.forward(ids, dense)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": B / med, "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d batches of %d rows (median), torch-CPU restatement of the TF op sequence "
-                      "(TensorFlow not installable here)" % (len(times), B)}
+    ncpu = os.cpu_count() or 1
+    cands = sorted(set(max(1, min(ncpu, t)) for t in (ncpu, ncpu // 2, 32, 16, 8, 4)), reverse=True)
+    old = torch.get_num_threads()
+    best, sweep = None, {}
+    per = budget_s / len(cands)
+    try:
+        for nt in cands:
+            torch.set_num_threads(nt)
+            for _ in range(2):
+                cpu.forward(ids, dense)
+            times = []
+            t_end = time.time() + per
+            while time.time() < t_end or len(times) < 5:
+                t0 = time.perf_counter()
+                cpu.forward(ids, dense)
+                times.append(time.perf_counter() - t0)
+            med = float(np.median(times))
+            sweep[str(nt)] = round(B / med, 1)
+            if best is None or med < best[0]:
+                best = (med, nt, len(times))
+    finally:
+        torch.set_num_threads(old)
+    med, nt, n = best
+    return {"value": B / med, "unit": "samples/s", "cores": int(nt), "kind": "port", "host_cores": int(ncpu),
+            "thread_sweep_samples_per_s": sweep,
+            "sample": "%d batches of %d rows (median) at the best of %d thread counts, torch-CPU restatement of the TF op "
+                      "sequence (TensorFlow not installable here)" % (n, B, len(cands))}
+
+
+def load_traffic(rows):
+    """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch."""
+    tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(tp):
+        return None, None
+    try:
+        j = json.load(open(tp))
+        return float(j["bytes_per_row"]) * rows, "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s rows per launch)" % j.get("rows_per_launch")
+    except Exception:
+        return None, None
 
 
 def main():
@@ -135,16 +172,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through")
+    ap.add_argument("--launch-batches", type=int, default=0,
+                    help="consecutive 4096-row batches per launch (0 = min(steps, 64)); 1 = one launch per batch")
+    ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through (rounded up to whole launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of one hipGraph")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="independent batches in flight: step i is enqueued on stream i %% streams (fused 1-launch path only)")
-    ap.add_argument("--tile-rows", type=int, default=32,
-                    help="batch rows per workgroup of the fused kernel (0 = library default, 16 = lowest latency of one "
-                         "batch, 32 = highest throughput with several batches in flight)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the one-launch-per-batch and long-run measurements")
+    ap.add_argument("--streams", type=int, default=8, help="one-launch-per-batch mode: batches in flight (graph branches)")
+    ap.add_argument("--tile-rows", type=int, default=0,
+                    help="rows per workgroup of the fused kernel: 0 = library default (streaming 64-row tiles for launches "
+                         "of >= 64 rows per CU, else 16 / 32), 16 / 32 = the tile kernel, 64 = streaming kernel always")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"], help="id distribution (SURVEY 8(d))")
-    ap.add_argument("--no-k-split", action="store_true", help="lab: do not offer the layer-0 K split to the fused kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,62 +200,43 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from deepctr_amd import _C
-    _C.lib()
+    lib = _C.lib()
     model, cols = build_model(device)
     model.tile_rows = args.tile_rows
-    if args.no_k_split:
-        model.stage_plan.k_split = (0, 0)
-    K, W, ring = args.steps, args.warmup, max(1, min(args.ring, max(args.steps, 1)))
+    K, W = args.steps, args.warmup
+    G = max(1, min(args.launch_batches or 64, max(K, 1)))
+    ring = ((max(args.ring, G) + G - 1) // G) * G                          # whole launches
     staged = model.stage(synthetic_feed(ring * B, 1000 + rank, args.dist))       # device-resident before timing
     model._begin()
     logits = torch.empty(max(K, 1) * B, dtype=torch.float32, device=device)
     gathered = torch.empty(world * logits.numel(), dtype=torch.float32, device=device) if dist is not None else None
+    fused = bool(model._fast_path(staged))
 
-    # per-launch durations INSIDE the timed region: the fused kernel stamps {first workgroup's start, last workgroup's
-    # end} with the device wall clock into probe_ts[i] (dctr_mlp_args_t.probe) for a block of steps in the middle of the
-    # run.  Event pairs cannot be attached to launches inside a hipGraph (and torch's external events are disabled on
-    # ROCm); overlapped launches last longer than an isolated one, and this is the duration rocprofv3 reports for them.
-    n_probe = min(64, K // 4)
-    probe_lo = K // 4
-    probe_ts = torch.zeros(max(n_probe, 1), 2, dtype=torch.int64, device=device)
+    # the K steps as launches of G batches: launch j covers steps [j*G, min(K, (j+1)*G)) = ring batches from (j*G) % ring
+    launches = []
+    for s0 in range(0, K, G):
+        nb = min(G, K - s0)
+        lo = (s0 % ring) * B
+        launches.append((lo, lo + nb * B, s0 * B, (s0 + nb) * B))
 
-    def reset_probes():
-        probe_ts[:, 0] = torch.iinfo(torch.int64).max          # atomicMin target (stamps are < 2^63)
-        probe_ts[:, 1] = 0
+    if fused:                                  # argument structs marshalled before the timed region: one ctypes call per launch
+        prepared = [model.prepare_launch(staged, lo, hi, logits[o0:o1]) for lo, hi, o0, o1 in launches]
+    else:
+        prepared = [(lambda lo=lo, hi=hi, o0=o0, o1=o1: model._forward(staged, lo, hi, logits[o0:o1])) for lo, hi, o0, o1 in launches]
 
-    def step(i, out):
-        lo = (i % ring) * B
-        model.probe = probe_ts[i - probe_lo] if probe_lo <= i < probe_lo + n_probe else None
-        model._forward(staged, lo, lo + B, out)
-        model.probe = None
+    def run_steps():
+        for fn in prepared:
+            fn()
 
-    scratch = torch.empty(B, dtype=torch.float32, device=device)
-    for i in range(W):                                                 # untimed warm-up (eager)
-        step(i, scratch)
+    for i in range(0, W, G):                                               # untimed warm-up, same launch shape
+        nb = min(G, W - i)
+        model._forward(staged, 0, nb * B, logits[:nb * B])
+    if K > 0:                                                              # ... and once through the timed region's own launches,
+        lib.dctr_profile_arm(min(len(launches), 256))                      # armed, so that the event pairs exist beforehand
+        run_steps()
+        tmp = (ctypes.c_float * 256)()
+        lib.dctr_profile_collect(tmp, min(len(launches), 256))
     torch.cuda.synchronize()
-
-    # Consecutive steps are independent batches.  With the 1-launch fused path a step touches no shared scratch, so
-    # step i goes to stream i % n_streams: the gather phase (latency-bound) of one batch overlaps the MFMA phase of
-    # the previous one on the same CU (the kernel is sized for two co-resident workgroups per CU).
-    fused = bool(model.stage_plan.fusable and model.fused and not model.stage_plan.pooled_fields and not model.stage_plan.lin_only)
-    n_streams = max(1, args.streams) if fused else 1
-    graph = None
-    if not args.no_graph and K > 0:
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(device)
-        branches = [side] + [torch.cuda.Stream(device) for _ in range(n_streams - 1)]
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for br in branches[1:]:
-                    br.wait_stream(side)                       # fork
-                for i in range(K):
-                    with torch.cuda.stream(branches[i % n_streams]):
-                        step(i, logits[i * B:(i + 1) * B])
-                for br in branches[1:]:
-                    side.wait_stream(br)                       # join
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -227,20 +245,25 @@ def main():
     if dist is not None:                                               # untimed: RCCL sets up its all-gather channels
         dist.all_gather_into_tensor(gathered, logits)
         torch.cuda.synchronize()
-    reset_probes()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
-        for i in range(K):
-            step(i, logits[i * B:(i + 1) * B])
-    if dist is not None:
-        dist.all_gather_into_tensor(gathered, logits)                  # the path's one exchange: final logits
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed_region(arm):
+        """barrier + sync | K steps (+ the one all-gather) | sync + barrier; returns seconds (this rank)."""
+        barrier()
+        torch.cuda.synchronize()
+        if arm:
+            lib.dctr_profile_arm(min(len(launches), 256))
+        t0 = time.perf_counter()
+        run_steps()
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, logits)              # the path's one exchange: final logits
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0
+
+    elapsed = timed_region(arm=True)
+    ms = (ctypes.c_float * 256)()
+    n_timed = lib.dctr_profile_collect(ms, min(len(launches), 256)) if K > 0 else 0
+    launch_s = [ms[i] * 1e-3 for i in range(n_timed) if ms[i] > 0]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -248,71 +271,116 @@ def main():
     model._check_status()
     assert bool(torch.isfinite(logits[:min(K, 4) * B]).all())
 
+    # secondary measurements (not `value`): the same region repeated until >= 50 ms, and one launch per batch
+    long_run = per_batch = None
+    if K > 0 and not args.no_secondary:
+        reps = max(2, int(0.05 / max(elapsed, 1e-6)) + 1)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_steps()
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - t0
+        long_run = {"repeats_of_the_K_step_region": reps, "seconds": tl, "samples_per_s_per_gpu": reps * K * B / tl,
+                    "ms_per_step": tl / (reps * K) * 1e3}
+        if fused and dist is None:
+            n_streams = max(1, args.streams)
+            model.span_batches, tr = False, model.tile_rows
+            model.tile_rows = 32
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device)
+            branches = [side] + [torch.cuda.Stream(device) for _ in range(n_streams - 1)]
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for br in branches[1:]:
+                        br.wait_stream(side)                       # fork
+                    for i in range(K):
+                        with torch.cuda.stream(branches[i % n_streams]):
+                            lo = (i % ring) * B
+                            model._forward(staged, lo, lo + B, logits[i * B:(i + 1) * B])
+                    for br in branches[1:]:
+                        side.wait_stream(br)                       # join
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            graph.replay()
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - t0
+            model.tile_rows = tr
+            per_batch = {"mode": "one launch per 4096-row batch (32-row tile kernel), K launches in one hipGraph on %d streams" % n_streams,
+                         "samples_per_s": K * B / tp, "ms_per_step": tp / K * 1e3,
+                         "aggregate_frac_of_f32_mfma_peak": K * B / tp * DNN_FLOP_PER_SAMPLE / 1e12 / F32_MFMA_PEAK_TF}
+
     result = None
     if rank == 0:
         value = world * B * K / elapsed if K else 0.0
-        t_fused, t_gather, t_mlp = probe_kernels(model, staged, ring)
-        t_fused_iso = t_fused
-        khz = _C.lib().dctr_wall_clock_khz()
-        ts = probe_ts.cpu().numpy()
-        ok = (ts[:, 1] > 0) & (ts[:, 0] < ts[:, 1])
-        if t_fused is not None and n_probe > 0 and khz > 0 and ok.any():
-            t_fused = float(np.mean((ts[ok, 1] - ts[ok, 0]) / (khz * 1e3)))      # seconds, launches of the timed region
+        rows_launch = (launches[0][1] - launches[0][0]) if launches else 0
+        t_launch = None
+        if launch_s and launches:
+            # mean duration of the launches that cover G batches (a trailing partial launch is left out)
+            full = [t for t, l in zip(launch_s, launches) if l[1] - l[0] == rows_launch]
+            t_launch = float(np.mean(full)) if full else None
+        t_fused32, t_gather, t_mlp = probe_kernels(model, staged, ring)
+        traffic, traffic_source = load_traffic(rows_launch)
+        kernels = []
+        if t_launch is not None:
+            tf = DNN_FLOP_PER_SAMPLE * rows_launch / t_launch / 1e12
+            gbs = ALG_BYTES_PER_SAMPLE * rows_launch / t_launch / 1e9
+            kernels.append({"kernel": "stream_kernel (dctr_embed_mlp_fwd, %d rows per launch: ids -> LDS-DMA ring -> DNN -> head)" % rows_launch
+                            if rows_launch >= 64 * 256 or args.tile_rows == 64 else
+                            "mlp_kernel, fused gather (dctr_embed_mlp_fwd, %d rows per launch)" % rows_launch,
+                            "in_step": True, "us_per_launch": t_launch * 1e6, "rows_per_launch": rows_launch, "bound": "mfma",
+                            "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+                            "hbm_algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+        if t_fused32 is not None:
+            tf = DNN_FLOP_PER_SAMPLE * B / t_fused32 / 1e12
+            kernels.append({"kernel": "mlp_kernel<2>, fused gather, ONE isolated 4096-row launch (128 workgroups = half the CUs)",
+                            "in_step": False, "us_per_launch": t_fused32 * 1e6, "bound": "mfma", "achieved": tf,
+                            "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF})
         gather_gbs = ALG_BYTES_PER_SAMPLE * B / t_gather / 1e9
         mlp_tf = DNN_FLOP_PER_SAMPLE * B / t_mlp / 1e12
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        kernels = []
-        if t_fused is not None:
-            kernels.append({"kernel": "mlp_kernel, fused gather (dctr_embed_mlp_fwd: ids -> LDS tile -> DNN -> head)",
-                            "in_step": True, "us_per_launch": t_fused * 1e6, "bound": "mfma",
-                            "achieved": DNN_FLOP_PER_SAMPLE * B / t_fused / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                            "frac": DNN_FLOP_PER_SAMPLE * B / t_fused / 1e12 / F32_MFMA_PEAK_TF,
-                            "hbm_algorithmic_GBps": ALG_BYTES_PER_SAMPLE * B / t_fused / 1e9,
-                            "hbm_frac": ALG_BYTES_PER_SAMPLE * B / t_fused / 1e9 / HBM_PEAK_GBS})
-        kernels.append({"kernel": "gather_fm_kernel (stand-alone fused 26-table gather + concat + linear + FM)",
-                        "in_step": t_fused is None, "us_per_launch": t_gather * 1e6, "bound": "hbm", "achieved": gather_gbs,
+        kernels.append({"kernel": "gather_fm_kernel (stand-alone fused 26-table gather + concat + linear + FM), isolated 4096-row launch",
+                        "in_step": False, "us_per_launch": t_gather * 1e6, "bound": "hbm", "achieved": gather_gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gather_gbs / HBM_PEAK_GBS})
-        kernels.append({"kernel": "mlp_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA)", "in_step": t_fused is None,
+        kernels.append({"kernel": "mlp_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA), isolated 4096-row launch", "in_step": False,
                         "us_per_launch": t_mlp * 1e6, "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF})
         dom = kernels[0]
         roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "us_per_launch": dom["us_per_launch"],
-                    "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * B,
-                    "algorithmic_flop_per_launch": DNN_FLOP_PER_SAMPLE * B}
+                    "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
+                    "us_per_launch": dom["us_per_launch"], "launches_timed": len(launch_s),
+                    "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * rows_launch,
+                    "algorithmic_flop_per_launch": DNN_FLOP_PER_SAMPLE * rows_launch}
         if "hbm_frac" in dom:
             roofline["hbm_algorithmic_GBps"], roofline["hbm_frac"] = dom["hbm_algorithmic_GBps"], dom["hbm_frac"]
-        # `achieved` / `frac` above are per LAUNCH as it ran INSIDE the timed region (in-kernel wall-clock stamps of 64
-        # launches; several launches overlap there, so each lasts longer than an isolated one = us_per_launch_isolated).
-        # One launch = 128 workgroups of 32 rows = half the CUs.
-        # The rate the whole GPU sustains in the timed region is the aggregate below.
-        roofline["us_per_launch_isolated"] = None if t_fused_iso is None else t_fused_iso * 1e6
-        roofline["concurrent_launches"] = n_streams
+        # the launches of the region run back to back on one stream and each fills the chip (one persistent workgroup per
+        # CU), so per-launch and aggregate figures coincide up to the gaps between launches
         roofline["aggregate_achieved"] = (value / world) * DNN_FLOP_PER_SAMPLE / 1e12
         roofline["aggregate_frac"] = roofline["aggregate_achieved"] / F32_MFMA_PEAK_TF
-        roofline["sustained_mfma_f32_peak_measured"] = 139.0    # scripts/mfma_lab.cpp: pure v_mfma_f32_16x16x4 loop, all CUs
-        roofline["note"] = ("achieved/frac/us_per_launch: one launch (128 workgroups = half the CUs) as it ran in the timed "
-                            "region, where ~%.1f launches overlap; aggregate_*: all launches of the region / its wall time"
-                            % (dom["us_per_launch"] / (elapsed / K * 1e6) if K else 0.0))
+        roofline["sustained_mfma_f32_peak_measured"] = F32_MFMA_SUSTAINED_TF
+        roofline["frac_of_sustained"] = dom["achieved"] / F32_MFMA_SUSTAINED_TF if dom["unit"] == "TFLOP/s" else None
+        roofline["note"] = ("fp32 DNN: 301,696 FLOP/sample against 1,928 algorithmic B/sample -> the step is bound by the f32 matrix "
+                            "pipe (a 4096-row batch: 7.9 us of MFMA vs 1.0 us of HBM), so whole-forward HBM-roofline fractions "
+                            "are capped at ~0.12 in exact fp32 (SURVEY.md §7)")
         result = {
             "metric": "samples/sec fwd DeepFM Criteo-26x1e5 emb16 b4096", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3 if K else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DeepFM forward, 26 sparse x vocab 1e5 + 13 dense, emb_dim 16, "
-                                   "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, "
-                                   "ids %s, ring of %d distinct batches, %s, %s" % (
-                                       args.dist, ring, "1 hipGraph of K steps" if graph else "eager",
-                                       ("1 launch/step (fused gather+DNN), %d batches in flight, tile_rows %d" % (n_streams, args.tile_rows))
-                                       if t_fused is not None else "2 launches/step"),
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "row-sharded x%d, tables replicated" % world},
+                                   "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, ids %s, ring of %d "
+                                   "distinct batches, the K steps issued as %d launch(es) of %d consecutive batches (%s)" % (
+                                       args.dist, ring, len(launches), G,
+                                       "1 launch per span: fused gather+DNN" if fused else "2 launches per span"),
+                       "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
+                       "parallelism": "row-sharded x%d, tables replicated, one all-gather of the logits" % world},
             "roofline": roofline, "kernels": kernels,
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
+            "fp32_ceiling_of_that_fraction": F32_MFMA_PEAK_TF * 1e12 / DNN_FLOP_PER_SAMPLE * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
+            "long_run": long_run, "one_launch_per_batch": per_batch,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(model, cols)

@@ -13,13 +13,14 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
 OPT_CODES = {"adam": 0, "adagrad": 1, "rmsprop": 2, "sgd": 3}
 ACT_LINEAR, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_DICE = 0, 1, 2, 3, 4
 STATUS_INDEX_OOR = 1
+STATUS_TIMEOUT = 2
 
 ACT_CODES = {None: ACT_LINEAR, "linear": ACT_LINEAR, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH,
              "dice": ACT_DICE, "Dice": ACT_DICE}
@@ -48,7 +49,7 @@ class GatherFmArgs(ctypes.Structure):
                 ("any_hash", c_i32), ("n_dense", c_i32), ("dense", c_vp), ("dense_stride", c_i64),
                 ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("dense_copy_cols", c_i32), ("batch", c_i64),
                 ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp),
-                ("split_col", c_i32), ("split_field", c_i32)]
+                ("split_col", c_i32), ("split_field", c_i32), ("uniform_dim", c_i32), ("reserved_", c_i32)]
 
 
 class PoolArgs(ctypes.Structure):

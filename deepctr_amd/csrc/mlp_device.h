@@ -138,9 +138,9 @@ __device__ __forceinline__ void mfmas(const float (&av)[RT][SD], const float (&b
 #endif
 template <int TPW, int RT, int SD>
 __device__ __forceinline__ void tile_gemm_pipe(const float* A, int lda, int KQ, int k_rows, const float* __restrict__ W,
-                                               int N, int n_base, dctr::f32x4 (&acc)[RT][TPW]) {
+                                               int N, int n_base, dctr::f32x4 (&acc)[RT][TPW], int lane = threadIdx.x & 63) {
     // A: LDS tile of 4*KQ (zero-padded) columns in the permuted layout; W: k_rows x N weight rows for those columns
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int g = lane >> 4, j = lane & 15;
     const float* arow = A + j * lda + g * KQ;
     int n0 = n_base + TPW * j;
     if (n0 + TPW > N) n0 = N - TPW;                       // TPW > 1 only when N % (16*TPW) == 0

@@ -22,6 +22,11 @@
 
 using namespace dctr_mlp;
 
+namespace dctr_stream {
+int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, bool forced,
+               hipStream_t stream, int* rc);   // stream_kernels.hip
+}
+
 namespace {
 
 // LDS row stride for a given layer-0 split (0 = none): pad64(widest tile) + 4
@@ -112,6 +117,12 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         const int spw = 64 / lpr;
         return (size_t)NWAVE * (spw >= rows ? 1 : rows / spw) * 6 * 64;
     };
+
+    // fused launches with >= 64 rows per CU (or tile_rows == 64): the streaming kernel, when the model is eligible
+    if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 64)) {
+        int rc = DCTR_OK;
+        if (dctr_stream::try_launch(a, ga, fm_used, lin_used, a->tile_rows == 64, (hipStream_t)stream, &rc)) return rc;
+    }
 
     // rows per workgroup.  auto: 16 while that still gives every CU a workgroup (latency), else 32
     int rt = a->tile_rows / 16;

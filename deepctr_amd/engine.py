@@ -109,8 +109,9 @@ def _fit_int32(arrs):
         if isinstance(a, torch.Tensor):
             if a.dtype == torch.int64:
                 return False
-        elif a.dtype.itemsize > 4 and a.size and (a.min() < -2 ** 31 or a.max() > 2 ** 31 - 1):
-            return False
+        elif (a.dtype.itemsize > 4 or (a.dtype.kind == "u" and a.dtype.itemsize == 4)) and a.size and (
+                a.min() < -2 ** 31 or a.max() > 2 ** 31 - 1):
+            return False                       # (uint32 ids >= 2^31 would turn negative in an int32 matrix)
     return True
 
 
@@ -217,7 +218,15 @@ class EmbeddingStage(object):
             for f in self.fields)
         self.max_dim = max([f.dim for f in self.fields] + [1])
         self.any_hash = any(f.hash_mode for f in self.fields)
+        # dctr_gather_fm_args_t.uniform_dim: every field a fixed-length SparseFeat of one embedding_dim E laid out at
+        # out_offset = index * E with the dense columns right behind — the reference's plain DNN input
+        # (inputs.py:101-117 + layers/utils.py:336-346).  Lets large fused launches take the streaming kernel.
+        e0 = self.fields[0].dim if self.fields else 0
+        self.uniform_dim = int(e0) if (self.fields and not self.pooled_fields and not self.extra_offsets and all(
+            f.dim == e0 and f.out_offset == i * e0 for i, f in enumerate(self.fields))) else 0
         self.k_split = self._find_k_split()
+        self._status = None
+        self._light = None
         self._pin = {}                # (key, dtype) -> pinned host staging buffer
         self.pool_trace = None        # training: a list that collects (dctr_pool_args_t, tensors) of the forward's pool calls
         self._ws = {}
@@ -426,6 +435,25 @@ class EmbeddingStage(object):
             staged.weight[fc.weight_name] = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
 
     # -- execution ---------------------------------------------------------------------------------
+    def status(self):
+        """ONE status word per plan, shared by every workspace: an out-of-range flag raised in a launch whose workspace
+        has since been evicted (or that never had one) is still seen by ``FeatureModel._check_status``."""
+        if self._status is None:
+            self._status = ops.new_status(self.device)
+        return self._status
+
+    def light_workspace(self):
+        """Field descriptors + status only (no per-row buffers): what the fused one-launch path needs when every field is
+        a fixed-length SparseFeat.  Lets one launch span any number of rows."""
+        if self.pooled_fields:
+            raise ValueError("light_workspace: pooled fields need per-batch buffers")
+        if self._light is None:
+            fields = [dict(table=f.table, lin_table=f.lin_table, vocab=f.table.shape[0], dim=f.dim, out_offset=f.out_offset,
+                           in_fm=f.in_fm, hash_mode=f.hash_mode) for f in self.fields]
+            self._light = {"desc": ops.make_field_descriptors(fields, self.device) if fields else None,
+                           "status": self.status(), "dnn_in": None, "fm": None, "lin": None}
+        return self._light
+
     def workspace(self, B):
         ws = self._ws.get(B)
         if ws is not None:
@@ -435,7 +463,7 @@ class EmbeddingStage(object):
         ws["dnn_in"] = torch.zeros(B, self.out_stride, dtype=torch.float32, device=dev)
         ws["fm"] = torch.zeros(B, dtype=torch.float32, device=dev)
         ws["lin"] = torch.zeros(B, dtype=torch.float32, device=dev)
-        ws["status"] = ops.new_status(dev)
+        ws["status"] = self.status()
         ws["pooled"], ws["pooled_lin"] = {}, {}
         for f in self.pooled_fields:
             ws["pooled"][f.fc.name] = torch.zeros(B, f.dim, dtype=torch.float32, device=dev)
@@ -504,7 +532,7 @@ class EmbeddingStage(object):
                                     out_stride=self.out_stride,
                                     fm_logit=ws["fm"] if (self.fm_group_names and to_hbm) else None,
                                     lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"],
-                                    split=self.k_split)
+                                    split=self.k_split, uniform_dim=self.uniform_dim)
 
     def run_pools(self, staged, lo, hi):
         ws = self.workspace(hi - lo)
@@ -756,6 +784,10 @@ class Model(object):
     def _begin(self):
         """Hook: per-call refresh of weight-derived buffers."""
 
+    def _rows_per_launch(self, staged, batch_size):
+        """Hook: rows one _forward call may cover (default: the caller's batch_size)."""
+        return batch_size
+
     def predict_tensor(self, x, batch_size=256):
         """predict() that leaves the [N] result on the device (used by the distributed path)."""
         pipe = self._pipeline(x, batch_size)
@@ -763,6 +795,7 @@ class Model(object):
             staged, chunks, bs = pipe
             out = torch.empty(staged.n, dtype=torch.float32, device=self.device)
             self._begin()
+            bs = self._rows_per_launch(staged, bs)
             for c_lo, c_hi in chunks:
                 for lo in range(c_lo, c_hi, bs):
                     hi = min(c_hi, lo + bs)
@@ -774,7 +807,7 @@ class Model(object):
         if staged.n == 0:
             return out
         self._begin()
-        bs = int(batch_size) if batch_size else staged.n
+        bs = self._rows_per_launch(staged, int(batch_size) if batch_size else staged.n)
         for lo in range(0, staged.n, bs):
             hi = min(staged.n, lo + bs)
             self._forward(staged, lo, hi, out[lo:hi])

@@ -65,8 +65,7 @@ class FeatureModel(Model):
         self.stage_plan.refresh(self.linear.w('linear_kernel') if self.linear is not None else None)
 
     def _check_status(self):
-        for ws in self.stage_plan._ws.values():
-            ops.check_status(ws["status"], "embedding lookup in model %s" % self.name)
+        ops.check_status(self.stage_plan.status(), "embedding lookup in model %s" % self.name)
 
     def _logits_to_add(self, ws):
         add = []

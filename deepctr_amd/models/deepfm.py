@@ -39,6 +39,7 @@ class _DeepFM(FeatureModel):
         passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
         self.fused = bool(sp.fusable and 8 * passes * 6 * 64 <= 16 * lda)
         self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64), same bits
+        self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
 
@@ -47,12 +48,20 @@ class _DeepFM(FeatureModel):
         the per-batch pointers are patched (ctypes marshalling was ~30 us per 4096-row batch, more than the kernel's
         share of a pipelined predict)."""
         import ctypes
-        import torch
         from .. import _C
+        g, m = self._forward_fast_args(staged, lo, hi, out)
+        sp = self.stage_plan
+        _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear),
+                                             _C.stream_ptr()), "dctr_embed_mlp_fwd")
+
+    def _forward_fast_args(self, staged, lo, hi, out):
+        import torch
         sp, B = self.stage_plan, hi - lo
         c = self._fast.get(B)
         if c is None:
-            ws = sp.workspace(B)
+            ws = sp.light_workspace()          # descriptors + status only: a launch may span any number of rows
+            if len(self._fast) > 8:
+                self._fast.clear()
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
             m, keep = ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
                               head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
@@ -70,12 +79,40 @@ class _DeepFM(FeatureModel):
         m.y = out.data_ptr()
         m.tile_rows = int(self.tile_rows)
         m.probe = None if self.probe is None else self.probe.data_ptr()
-        _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear),
-                                             _C.stream_ptr()), "dctr_embed_mlp_fwd")
+        return g, m
+
+    def prepare_launch(self, staged, lo, hi, out):
+        """A zero-argument callable that issues the fused launch for rows [lo, hi) -> out with everything marshalled
+        beforehand (bench.py: the host cost of a launch inside a short timed region is one ctypes call)."""
+        import ctypes
+        from .. import _C
+        self._forward_fast_args(staged, lo, hi, out)
+        g, m, keep, ws = self._fast[hi - lo]
+        g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
+        sp = self.stage_plan
+        fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
+        a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
+
+        def launch():
+            _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
+        launch.keep = (g, m, keep, ws, staged, out)
+        return launch
+
+    def _fast_path(self, staged):
+        sp = self.stage_plan
+        return bool(sp.fusable and self.fused and not sp.pooled_fields and not sp.lin_only and staged.ids is not None)
+
+    def _rows_per_launch(self, staged, batch_size):
+        """predict(): rows are independent and the one-launch path owns no per-batch buffer, so ``batch_size`` (a memory
+        knob of the reference's graph executor) need not bound a launch: spans of up to 2^20 rows go out as ONE launch —
+        with >= 64 rows per CU the library then runs its persistent streaming kernel (stream_kernels.hip)."""
+        if self._fast_path(staged) and self.span_batches:
+            return max(int(batch_size or staged.n), 1 << 20)
+        return batch_size
 
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
-        if sp.fusable and self.fused and not sp.pooled_fields and not sp.lin_only and staged.ids is not None:
+        if self._fast_path(staged):
             return self._forward_fast(staged, lo, hi, out)
         if sp.fusable and self.fused:
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)

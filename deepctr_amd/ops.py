@@ -104,6 +104,10 @@ def new_status(device):
 def check_status(status, what="embedding lookup"):
     """Raise like the reference's Embedding gather on a CPU does when an index is out of range."""
     v = int(status.item())
+    if v & _C.STATUS_TIMEOUT:
+        status.zero_()
+        raise RuntimeError("%s: an in-kernel wait of the streaming forward kernel timed out (DCTR_STATUS_TIMEOUT); the "
+                           "outputs of that launch are invalid" % what)
     if v & _C.STATUS_INDEX_OOR:
         status.zero_()
         raise IndexError("%s: index out of range [0, vocabulary_size)" % what)
@@ -233,7 +237,7 @@ def make_field_descriptors(fields, device):
 
 def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
                      dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0,
-                     fm_logit=None, lin_logit=None, status=None, split=(0, 0)):
+                     fm_logit=None, lin_logit=None, status=None, split=(0, 0), uniform_dim=0):
     """Fill a dctr_gather_fm_args_t (see include/dctr.h).  The caller keeps every tensor alive.
     ``split`` = (split_col, split_field), see the header; (0, 0) = none."""
     _dev_check(desc, ids, dense, dnn_in)
@@ -256,7 +260,7 @@ def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max
                            fm_logit=None if fm_logit is None else fm_logit.data_ptr(),
                            lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
                            status=None if status is None else status.data_ptr(),
-                           split_col=int(split[0]), split_field=int(split[1]))
+                           split_col=int(split[0]), split_field=int(split[1]), uniform_dim=int(uniform_dim))
 
 
 def embed_gather_fm(*args, **kwargs):

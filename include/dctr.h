@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 1
+#define DCTR_ABI_VERSION 2
 
 enum {
     DCTR_OK = 0,
@@ -40,7 +40,11 @@ enum {
 };
 
 /* bits OR-ed into the optional device status word by the gather kernels */
-enum { DCTR_STATUS_INDEX_OOR = 1 };
+enum {
+    DCTR_STATUS_INDEX_OOR = 1,   /* an id outside [0, vocabulary): its row was treated as zeros                       */
+    DCTR_STATUS_TIMEOUT = 2      /* a bounded in-kernel wait of the streaming dctr_embed_mlp_fwd kernel expired: the
+                                    outputs of that launch are invalid (a defect, reported instead of a hung GPU)     */
+};
 
 int dctr_abi_version(void);
 const char* dctr_last_error(void);
@@ -137,6 +141,12 @@ typedef struct {
                                      and the dense passthrough only columns >= split_col.  Lets the fused kernel
                                      build the DNN-input tile in two K-halves (half the LDS, two workgroups per CU). */
     int32_t split_field;
+    int32_t uniform_dim;          /* dctr_embed_mlp_fwd only; E > 0 promises: every field has dim == E, out_offset ==
+                                     field index * E, identity == 0 (the reference's all-SparseFeat DNN input,
+                                     inputs.py:101-117 + layers/utils.py:336-346).  With E in {16, 32, 64} launches of
+                                     >= 64 rows per CU take the streaming kernel (LDS-DMA gather ring, 64-row tiles).
+                                     0 = unknown / not uniform                                                        */
+    int32_t reserved_;
 } dctr_gather_fm_args_t;
 
 int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);

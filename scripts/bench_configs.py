@@ -60,11 +60,33 @@ def run(name, model, feed, B, steps, ring):
     print("%-34s B=%-6d %9.2f us/batch  %10.2f M samples/s" % (name, B, dt * 1e6, B / dt / 1e6), flush=True)
 
 
+def run_span(name, model, feed, B, reps=8):
+    """ONE launch per call over all staged rows (what model.predict does for the DeepFM family): the library's streaming kernel."""
+    staged = model.stage(feed)
+    model._begin()
+    n = staged.n
+    out = torch.empty(n, device=model.device)
+    for _ in range(2):
+        model._forward(staged, 0, n, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model._forward(staged, 0, n, out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    model._check_status()
+    print("%-34s rows/launch=%-7d %9.2f us per %d rows  %10.2f M samples/s" % (name, n, dt * 1e6 * B / n, B, n / dt / 1e6), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c2,c2_2launch,c3,dcn_v,dcn_m,dcn_mix,nfm,c4,c5")
+    ap.add_argument("--configs", default="c2,c2_span,c2_2launch,c3,dcn_v,dcn_m,dcn_mix,nfm,c4,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
     args = ap.parse_args()
+    if args.quick:
+        args.steps = 8
+        args.configs = ",".join(c for c in args.configs.split(",") if not c.startswith("c5"))
     dev = torch.device("cuda:0")
     rng = np.random.RandomState(0)
     ring = 16
@@ -75,7 +97,10 @@ def main():
         init_on_device(m)
         feed = criteo(rng, ring * 4096)
         if "c2" in want:
+            m.span_batches = False
             run("C2 DeepFM (1 launch/step)", m, feed, 4096, args.steps, ring)
+        if "c2_span" in want:
+            run_span("C2 DeepFM (1 launch / 16 batches)", m, feed, 4096)
         if "c2_2launch" in want:
             m.fused = False
             run("C2 DeepFM (2 launches/step)", m, feed, 4096, args.steps, ring)
@@ -121,7 +146,7 @@ def main():
         init_on_device(m)
         run("C4 DIN T=50 E=32 (dice)", m, feed, B, args.steps, ring)
         del m
-    if "c5" in want:
+    if "c5" in want or "c5_span" in want:
         V, E, B = 10 ** 7, 32, 8192
         cols = [SparseFeat("C%d" % i, V, E) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
         t0 = time.time()
@@ -129,7 +154,11 @@ def main():
         init_on_device(m)
         torch.cuda.synchronize()
         print("C5 tables: %.1f GB allocated+initialised in %.0f s" % (torch.cuda.memory_allocated() / 1e9, time.time() - t0), flush=True)
-        run("C5 DeepFM vocab 1e7 E=32 (1 GPU shard)", m, criteo(rng, ring * B, V=V), B, args.steps, ring)
+        feed = criteo(rng, ring * B, V=V)
+        if "c5" in want:
+            run("C5 DeepFM vocab 1e7 E=32 (1 GPU shard)", m, feed, B, args.steps, ring)
+        if "c5_span" in want:
+            run_span("C5 DeepFM vocab 1e7 (1 launch / 16 batches)", m, feed, B)
 
 
 if __name__ == "__main__":

@@ -297,16 +297,8 @@ def test_opt_multi_matches_torch_optimizers(device, kind):
         assert_close(a.cpu().numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6, what=kind)
 
 
-_AFM_UNVERIFIED = pytest.mark.xfail(strict=False, reason="round 1 ran out of GPU minutes before this case could be re-run: with the "
-                                    "fixture's random weights the attention softmax is one-hot, attention_b / projection_h get "
-                                    "gradients of ~1e-11 (rounding noise) in both implementations, and the per-parameter scaling "
-                                    "compared noise with noise; the scale floor below is the fix, not yet confirmed on a GPU. "
-                                    "dctr_afm_bwd itself is checked by test_afm_bwd_matches_autograd, the step by test_sibling_models_fit")
-
-
 @pytest.mark.parametrize("fixture", ["model_wdl", "model_fnn", "model_nfm", "model_nfm_fixed", "model_pnn_inner", "model_pnn_plain",
-                                     "model_afm_noatt", pytest.param("model_afm", marks=_AFM_UNVERIFIED),
-                                     pytest.param("model_afm_two_groups", marks=_AFM_UNVERIFIED)])
+                                     "model_afm_noatt", "model_afm", "model_afm_two_groups"])
 def test_hip_training_gradients_with_sequence_features(device, fixture):
     """Pooling backward (sum / mean / max, length- and mask-form, weighted, shared and hashed tables) inside the HIP step,
     against torch autograd, on the reference-shaped mixed feature set of the golden fixtures."""
