@@ -88,7 +88,9 @@ struct StreamParams {
     const float* global_bias;
     float* y;
     unsigned long long* probe;
-    int32_t extras_off, fdesc_off, ring_off, act_off[2];  // LDS layout, float offsets
+    int32_t extras_off, fdesc_off, cpar_off, hpart_off, ring_off, act_off[2];  // LDS layout, float offsets
+    int32_t bias_off[MAX_LAYERS];              // biases of layer l at cpar_off + bias_off[l] (-1: none); head_w at + headw_off
+    int32_t headw_off;
     int32_t n_tiles;
 };
 
@@ -240,6 +242,43 @@ __device__ __forceinline__ void epilogue(const float* bias, float* out, int lda,
     }
 }
 
+// LAST layer: bias + activation, then straight into the Dense(1) head — partial dot products of this wave's 16*TPW columns
+// for its 16*RTL rows go to hpart[column tile][row]; the activations of the last layer are never stored
+template <int TPW, int ACT, int RTL>
+__device__ __forceinline__ void epilogue_head(const float* bias, const float* headw, float* hpart_rows, int N, int n_base,
+                                              const f32x4 (&acc)[RTL][TPW], int tid) {
+    const int lane = tid & 63, g = lane >> 4, j = lane & 15;
+    float bv[TPW], hw[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int n = n_base + TPW * j + c;
+        bv[c] = (n < N && bias != nullptr) ? bias[n] : 0.f;
+        hw[c] = n < N ? headw[n] : 0.f;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RTL; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) s = fmaf(act_t<ACT>(acc[rt][c][r] + bv[c], 0.f, 0.f, 1.f, 0.f), hw[c], s);
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            if (j == 0) hpart_rows[rt * 16 + 4 * g + r] = s;
+        }
+}
+
+template <int TPW, int RTL>
+__device__ __forceinline__ void epilogue_head_act(int act, const float* bias, const float* headw, float* hpart_rows, int N,
+                                                  int n_base, const f32x4 (&acc)[RTL][TPW], int tid) {
+    switch (act) {
+        case DCTR_ACT_RELU: epilogue_head<TPW, DCTR_ACT_RELU, RTL>(bias, headw, hpart_rows, N, n_base, acc, tid); break;
+        case DCTR_ACT_SIGMOID: epilogue_head<TPW, DCTR_ACT_SIGMOID, RTL>(bias, headw, hpart_rows, N, n_base, acc, tid); break;
+        case DCTR_ACT_TANH: epilogue_head<TPW, DCTR_ACT_TANH, RTL>(bias, headw, hpart_rows, N, n_base, acc, tid); break;
+        default: epilogue_head<TPW, DCTR_ACT_LINEAR, RTL>(bias, headw, hpart_rows, N, n_base, acc, tid); break;
+    }
+}
+
 template <int TPW, int RTL>
 __device__ __forceinline__ void epilogue_act(int act, const float* bias, float* out, int lda, int N, int n_base,
                                              const f32x4 (&acc)[RTL][TPW], int tid) {
@@ -268,8 +307,10 @@ __device__ __forceinline__ void zero_pad_cols(float* out, int lda, int N, int ti
 // tile (rows 0-31 / 32-63), used when there are too few column tiles to occupy the 8 waves.
 template <int TPW, int RTL>
 __device__ __forceinline__ void layer_units(const StreamParams& p, int l, const float* in, int lda_in, float* out,
-                                            int lda_out, int K, int N, int wave, int tid) {
+                                            int lda_out, int K, int N, int wave, int tid, const float* cpar, float* hpart) {
     constexpr int PARTS = 4 / RTL;
+    const float* bias = p.bias_off[l] >= 0 ? cpar + p.bias_off[l] : nullptr;
+    const bool last = l + 1 == p.n_layers;
     const int n_ct = (N + 16 * TPW - 1) / (16 * TPW);
     for (int u = wave; u < n_ct * PARTS; u += NCONS) {
         const int ct = u / PARTS, part = u % PARTS;
@@ -280,7 +321,8 @@ __device__ __forceinline__ void layer_units(const StreamParams& p, int l, const 
 #pragma unroll
             for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         tile_gemm_pipe<TPW, RTL, 4>(in + part * 16 * RTL * lda_in, lda_in, pad64(K) / 4, K, p.W[l], N, n_base, acc, tid & 63);
-        epilogue_act<TPW, RTL>(p.activation, p.bias[l], out + part * 16 * RTL * lda_out, lda_out, N, n_base, acc, tid);
+        if (last) epilogue_head_act<TPW, RTL>(p.activation, bias, cpar + p.headw_off, hpart + ct * ROWS + part * 16 * RTL, N, n_base, acc, tid);
+        else epilogue_act<TPW, RTL>(p.activation, bias, out + part * 16 * RTL * lda_out, lda_out, N, n_base, acc, tid);
     }
 }
 
@@ -288,6 +330,7 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
     int* sync = reinterpret_cast<int*>(smem);
     const float* ring = smem + p.ring_off;
     const float* extras = smem + p.extras_off;
+    const float* cpar = smem + p.cpar_off;        // biases + head weights, copied once per launch
     const int NB = (p.in_dim + 15) >> 4;          // column blocks of the DNN input
     const int NCH = (NB + 3) >> 2;                // ring chunks per tile
     const int N0 = p.units[0];
@@ -307,6 +350,9 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
         // ---- layer 0: stream the ring
         float* out = smem + p.act_off[0];
         int lda_out = pad64(N0) + 4;
+        float* hpart = smem + p.hpart_off + (it & 1) * 8 * ROWS;     // [column tile <= 8][row] head partials of this tile
+        const float* bias0 = p.bias_off[0] >= 0 ? cpar + p.bias_off[0] : nullptr;
+        const bool single = p.n_layers == 1;
 #ifdef DCTR_STREAM_LAB_NOMFMA
         if (false) {
 #else
@@ -318,24 +364,27 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
                 for (int rt = 0; rt < 4; ++rt) { acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 l0_stream<2>(p, ring, sync, seq0, NB, n_base0, acc, tid);
                 if (tson) STS(tsw, 1);
-                epilogue_act<2, 4>(p.activation, p.bias[0], out, lda_out, N0, n_base0, acc, tid);
+                if (single) epilogue_head_act<2, 4>(p.activation, bias0, cpar + p.headw_off, hpart + wave * ROWS, N0, n_base0, acc, tid);
+                else epilogue_act<2, 4>(p.activation, bias0, out, lda_out, N0, n_base0, acc, tid);
             } else {
                 f32x4 acc[4][1];
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 l0_stream<1>(p, ring, sync, seq0, NB, n_base0, acc, tid);
-                epilogue_act<1, 4>(p.activation, p.bias[0], out, lda_out, N0, n_base0, acc, tid);
+                if (single) epilogue_head_act<1, 4>(p.activation, bias0, cpar + p.headw_off, hpart + wave * ROWS, N0, n_base0, acc, tid);
+                else epilogue_act<1, 4>(p.activation, bias0, out, lda_out, N0, n_base0, acc, tid);
             }
         } else {
             l0_idle(p, sync, seq0, NCH);
         }
-        zero_pad_cols(out, lda_out, N0, tid);
+        if (!single) zero_pad_cols(out, lda_out, N0, tid);
         if (tson) STS(tsw, 2);
         cons_barrier(sync, epoch, p.status);
         if (tson) STS(tsw, 3);
         // ---- layers 1..
         const float* in = out;
         int lda_in = lda_out, K = N0;
+        int n_ct_last = wide0 ? (N0 + 31) / 32 : (N0 + 15) / 16;
         for (int l = 1; l < p.n_layers; ++l) {
             const int N = p.units[l];
             out = smem + p.act_off[l & 1];
@@ -345,10 +394,11 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
             if (false) {}
             else
 #endif
-            if (N % 32 == 0 && N >= 32 * NCONS) layer_units<2, 4>(p, l, in, lda_in, out, lda_out, K, N, wave, tid);
-            else if (n_ct16 > NCONS / 2) layer_units<1, 4>(p, l, in, lda_in, out, lda_out, K, N, wave, tid);
-            else layer_units<1, 2>(p, l, in, lda_in, out, lda_out, K, N, wave, tid);
-            zero_pad_cols(out, lda_out, N, tid);
+            if (N % 32 == 0 && N >= 32 * NCONS) layer_units<2, 4>(p, l, in, lda_in, out, lda_out, K, N, wave, tid, cpar, hpart);
+            else if (n_ct16 > NCONS / 2) layer_units<1, 4>(p, l, in, lda_in, out, lda_out, K, N, wave, tid, cpar, hpart);
+            else layer_units<1, 2>(p, l, in, lda_in, out, lda_out, K, N, wave, tid, cpar, hpart);
+            n_ct_last = (N % 32 == 0 && N >= 32 * NCONS) ? N / 32 : n_ct16;
+            if (l + 1 < p.n_layers) zero_pad_cols(out, lda_out, N, tid);
             if (tson) STS(tsw, 2 + 2 * l);
             cons_barrier(sync, epoch, p.status);
             if (tson) STS(tsw, 3 + 2 * l);
@@ -356,34 +406,27 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
             lda_in = lda_out;
             K = N;
         }
-        // ---- head: logit[row] = h[row,:] . head_w + FM/linear logits of the loader + add[] + global bias, sigmoid
-        wait_ge(sync, S_XREADY, NLOAD * (it + 1), p.status);
-        if (tson) STS(tsw, 20);
-        {
-            const int part = tid & 15;
-            const int KQh = pad64(K) / 4;
-            const float* ex = extras + (it & 1) * ROWS;
-            for (int row = tid >> 4; row < ROWS; row += 64 * NCONS / 16) {
-                float acc = 0.f;
-                for (int n = part; n < K; n += 16) acc = fmaf(in[row * lda_in + lds_pos(n, KQh)], p.head_w[n], acc);
+        // ---- head: the last layer's epilogue left partial dot products with head_w per column tile; after that layer's
+        // barrier wave 0 adds them up with the loader's FM / linear logits, add[], the global bias, and applies the sigmoid.
+        // (hpart and extras are double-buffered by tile parity: the other waves are already in the next tile's layer 0)
+        if (wave == 0) {
+            wait_ge(sync, S_XREADY, NLOAD * (it + 1), p.status);
+            if (tson) STS(tsw, 20);
+            const int row = tid & 63;
+            float v = extras[(it & 1) * ROWS + row];
+            for (int ct = 0; ct < n_ct_last; ++ct) v += hpart[ct * ROWS + row];
+            const int64_t b = b0 + row;
+            if (b < p.batch) {
 #pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-                const int64_t b = b0 + row;
-                if (part == 0 && b < p.batch) {
-                    float v = acc + ex[row];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (p.add[i] != nullptr) v += p.add[i][b];
-                    if (p.global_bias != nullptr) v += p.global_bias[0];
-                    if (p.sigmoid_out) v = dctr::sigmoidf_(v);
-                    p.y[b] = v;
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (p.add[i] != nullptr) v += p.add[i][b];
+                if (p.global_bias != nullptr) v += p.global_bias[0];
+                if (p.sigmoid_out) v = dctr::sigmoidf_(v);
+                p.y[b] = v;
             }
+            if (tson) STS(tsw, 21);
+            sig_set(sync, S_XDONE, it + 1);
         }
-        if (tson) STS(tsw, 21);
-        cons_barrier(sync, epoch, p.status);      // the next tile's layer-0 epilogue overwrites this tile's activations
-        if (tson) STS(tsw, 22);
-        if (wave == 0) sig_set(sync, S_XDONE, it + 1);
         seq0 += NCH;
     }
 }
@@ -600,6 +643,13 @@ __global__ __launch_bounds__(NTHREADS) void stream_kernel(StreamParams p) {
     if (threadIdx.x < S_WORDS) reinterpret_cast<int*>(smem)[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 12 * p.n_fields; i += NTHREADS)
         reinterpret_cast<uint32_t*>(smem + p.fdesc_off)[i] = reinterpret_cast<const uint32_t*>(p.fields)[i];
+    {
+        float* cpar = smem + p.cpar_off;
+        for (int l = 0; l < p.n_layers; ++l)
+            if (p.bias_off[l] >= 0)
+                for (int i = threadIdx.x; i < p.units[l]; i += NTHREADS) cpar[p.bias_off[l] + i] = p.bias[l][i];
+        for (int i = threadIdx.x; i < p.units[p.n_layers - 1]; i += NTHREADS) cpar[p.headw_off + i] = p.head_w[i];
+    }
     __syncthreads();
     if (wave < NCONS) {
 #ifdef DCTR_STREAM_LAB_PRIO
@@ -655,7 +705,23 @@ int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_
     if (g->n_fields > 64) return 0;
     p.extras_off = S_WORDS;                                            // [2][64] floats
     p.fdesc_off = 160;                                                 // [n_fields <= 64][12 dwords]
-    p.ring_off = 1024;                                                 // floats: 4 KiB in, 1-KiB aligned slots
+    p.cpar_off = 1024;                                                 // biases of every layer, head weights (< 1024 floats)
+    p.hpart_off = 2048;                                                // [2][8][64] head partials
+    p.ring_off = 3072;                                                 // floats: 12 KiB in, 1-KiB aligned slots
+    {
+        int off = 0;
+        for (int l = 0; l < a->n_layers; ++l) {
+            p.bias_off[l] = a->biases[l] != nullptr ? off : -1;
+            off += a->biases[l] != nullptr ? a->units[l] : 0;
+        }
+        p.headw_off = off;
+        off += a->units[a->n_layers - 1];
+        if (off > 1024) return 0;
+        // column tiles of the last layer (its epilogue parks one head partial per tile and row): at most 8
+        const int nl = a->units[a->n_layers - 1];
+        const bool wide = a->n_layers == 1 ? (nl % 32 == 0 && nl > 16 * NCONS) : (nl % 32 == 0 && nl >= 32 * NCONS);
+        if ((wide ? (nl + 31) / 32 : (nl + 15) / 16) > 8) return 0;
+    }
     p.act_off[0] = p.ring_off + NSLOT * SLOT_F;
     p.act_off[1] = p.act_off[0] + (int)act[0];
     const size_t lds = ((size_t)p.act_off[1] + act[1]) * sizeof(float);
