@@ -127,7 +127,8 @@ class HipTrainer(object):
         if self.is_din:
             la = model.attention.local_att
             dice = la.dnn.dice_params()
-            self.p_att = dict(kernels=[param(k, l2d) for k in la.dnn.kernels], biases=[param(b) for b in la.dnn.biases],
+            # no regulariser on the attention unit (AttentionSequencePoolingLayer builds it with l2_reg=0, sequence.py:243-245)
+            self.p_att = dict(kernels=[param(k) for k in la.dnn.kernels], biases=[param(b) for b in la.dnn.biases],
                               alphas=[param(d[0]) for d in dice] if dice else None, out_w=param(la.w("kernel")),
                               out_b=param(la.w("bias")))
             # history tables receive the key gradients through dctr_embed_lookup_bwd
