@@ -114,23 +114,39 @@ def stage_forward(sp, staged, lo, hi):
     return parts, extra, (lin if has_lin else None), fms
 
 
-def _act(name, x, dice=None):
+BN_MOMENTUM = 0.99      # tf.keras BatchNormalization default; Dice builds its BN with it (layers/activation.py:51-53)
+
+
+def _act(name, x, dice=None, training=False):
     if name in ("dice", "Dice"):
         alpha, mean, var = dice
+        if training:
+            # Dice's BatchNormalization(center=False, scale=False, epsilon=1e-9) as tf.keras runs it under fit(): normalise
+            # with the statistics of THIS batch over every axis but the last (biased variance, gradients flow through
+            # them) and move the stored statistics towards them (layers/activation.py:59-64)
+            dims = tuple(range(x.dim() - 1))
+            bm = x.mean(dim=dims)
+            bv = x.var(dim=dims, unbiased=False)
+            with torch.no_grad():
+                mean.mul_(BN_MOMENTUM).add_(bm.detach(), alpha=1.0 - BN_MOMENTUM)
+                var.mul_(BN_MOMENTUM).add_(bv.detach(), alpha=1.0 - BN_MOMENTUM)
+            mean, var = bm, bv
         xp = torch.sigmoid((x - mean) / torch.sqrt(var + 1e-9))
         return alpha * (1 - xp) * x + xp * x
     return {"relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "linear": lambda v: v, None: lambda v: v}[name](x)
 
 
-def dnn_forward(dnn, x):
+def dnn_forward(dnn, x, training=False):
     dice = dnn.dice_params()
     for i, (w, b) in enumerate(zip(dnn.kernels, dnn.biases)):
-        x = _act(dnn.activation, x @ w + b, dice[i] if dice else None)
+        x = _act(dnn.activation, x @ w + b, dice[i] if dice else None, training)
     return x
 
 
-def model_logits(model, staged, lo, hi):
-    """Pre-sigmoid logits [B] of the four in-scope models and their siblings, torch ops only."""
+def model_logits(model, staged, lo, hi, training=False):
+    """Pre-sigmoid logits [B] of the four in-scope models and their siblings, torch ops only.  ``training`` switches Dice to
+    batch statistics (and updates its moving statistics), as tf.keras does inside fit(); the default is the inference form
+    the HIP forward implements and the gradient tests differentiate."""
     sp = model.stage_plan
     parts, extra, lin, fms = stage_forward(sp, staged, lo, hi)
     name = model.name
@@ -148,7 +164,7 @@ def model_logits(model, staged, lo, hi):
             km = torch.ones(k.shape[:2], dtype=torch.bool, device=k.device)
         la = model.attention.local_att
         qq = q.unsqueeze(1).expand(-1, k.shape[1], -1)
-        att = dnn_forward(la.dnn, torch.cat([qq, k, qq - k, qq * k], dim=-1))
+        att = dnn_forward(la.dnn, torch.cat([qq, k, qq - k, qq * k], dim=-1), training)
         score = (att @ la.w("kernel") + la.w("bias")).squeeze(-1)
         if model.attention.weight_normalization:
             score = torch.softmax(torch.where(km, score, torch.full_like(score, float(-2 ** 32 + 1))), dim=-1)
@@ -198,7 +214,7 @@ def model_logits(model, staged, lo, hi):
                 xl = moe + xl
             outs.append(xl)
         if model.dnn is not None:
-            outs.append(dnn_forward(model.dnn, x))
+            outs.append(dnn_forward(model.dnn, x, training))
         logit = (torch.cat(outs, dim=-1) @ model.dense.w("kernel")).reshape(-1)
     elif name == "DCN":
         outs = []
@@ -213,10 +229,10 @@ def model_logits(model, staged, lo, hi):
                     xl = x0 * (xl @ w.t() + b) + xl
             outs.append(xl)
         if model.dnn is not None:
-            outs.append(dnn_forward(model.dnn, x))
+            outs.append(dnn_forward(model.dnn, x, training))
         logit = (torch.cat(outs, dim=-1) @ model.dense.w("kernel")).reshape(-1)
     else:
-        logit = (dnn_forward(model.dnn, x) @ model.dense.w("kernel")).reshape(-1)
+        logit = (dnn_forward(model.dnn, x, training) @ model.dense.w("kernel")).reshape(-1)
     if name == "xDeepFM" and model.cin is not None:
         x0 = torch.stack(parts[:len(sp.fields)], dim=1)             # [B,F,D]
         hidden, finals = x0, []
@@ -298,6 +314,12 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
             and ((loss_name0 in ("binary_crossentropy", "logloss") and model.task == "binary")
                  or (loss_name0 in ("mse", "mean_squared_error") and model.task != "binary"))):
         return _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
+    return _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
+
+
+def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle):
+    """fit() on torch autograd over ``model_logits`` (models / options outside the HIP step).  Device-agnostic torch code: the
+    CPU suite drives it directly on CPU-built models; evaluate() of a validation split needs the GPU forward."""
     params = [t for name, t in model.named_weights() if "moving_" not in name]
     for t in params:
         t.requires_grad_(True)
@@ -321,7 +343,7 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
             for lo in order:
                 hi = min(n_tr, lo + bs)
                 model._begin()
-                logit = model_logits(model, staged, int(lo), int(hi))
+                logit = model_logits(model, staged, int(lo), int(hi), training=True)
                 if loss_name in ("binary_crossentropy", "logloss") and model.task == "binary":
                     loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt[lo:hi])
                 else:

@@ -1,0 +1,94 @@
+"""CPU: the host input pipeline's logic without a device — what the staged id matrix / dense matrix /
+sequence tensors contain for mixed input dtypes, list-style feeds and bad feeds, and that the chunked-pipeline planner
+accepts exactly the feeds it can take.  The copies themselves (pinned buffers, streams) are GPU tests."""
+import numpy as np
+import pytest
+import torch
+
+
+def _model(cols, device=torch.device("cpu")):
+    from deepctr_amd.models import DeepFM
+    return DeepFM(cols, cols, dnn_hidden_units=(8,), device=device)
+
+
+def test_staged_matrices_follow_field_order_and_dtypes():
+    from deepctr_amd import engine
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    rng = np.random.RandomState(0)
+    n = 37
+    cols = [DenseFeat("d2", 2), SparseFeat("a", 100, 4), VarLenSparseFeat(SparseFeat("s", 9, 4), maxlen=3, length_name="s_len"),
+            SparseFeat("b", 50, 4, use_hash=True), DenseFeat("d1", 1)]
+    feed = {"a": rng.randint(0, 100, n).astype(np.int64), "b": rng.randint(0, 10 ** 9, n).astype(np.int32),
+            "d2": rng.rand(n, 2), "d1": rng.rand(n).astype(np.float32), "s": rng.randint(0, 9, (n, 3)),
+            "s_len": rng.randint(0, 4, n)}
+    model = _model(cols)
+    staged = engine.Staged(n)
+    model._stage_inputs(feed, staged)
+    sp = model.stage_plan
+    # one id row per field of the fused gather, in DNN-input order: SparseFeat first (a, b), then the pooled sequence (identity)
+    names = [f.fc.name for f in sp.fields]
+    assert names == ["a", "b", "s"]
+    assert staged.ids.shape == (3, n) and staged.ids.dtype == torch.int32            # values fit int32 -> narrow matrix
+    assert np.array_equal(staged.ids[0].numpy(), feed["a"]) and np.array_equal(staged.ids[1].numpy(), feed["b"])
+    # dense matrix [N, ND]: DNN dense features in column order (d2 two columns, then d1)
+    assert staged.dense.shape == (n, 3) and staged.dense.dtype == torch.float32
+    np.testing.assert_allclose(staged.dense.numpy(), np.concatenate([feed["d2"], feed["d1"][:, None]], axis=1).astype(np.float32))
+    assert np.array_equal(staged.seq["s"].numpy(), feed["s"]) and np.array_equal(staged.length["s_len"].numpy().reshape(-1), feed["s_len"])
+    # ids beyond int32 widen the whole matrix
+    feed64 = dict(feed, b=(feed["b"].astype(np.int64) + 2 ** 40))
+    staged64 = engine.Staged(n)
+    model._stage_inputs(feed64, staged64)
+    assert staged64.ids.dtype == torch.int64 and np.array_equal(staged64.ids[1].numpy(), feed64["b"])
+
+
+def test_feed_validation_errors():
+    from deepctr_amd import engine
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    cols = [SparseFeat("a", 10, 4), DenseFeat("d", 2)]
+    model = _model(cols)
+    n = 5
+    good = {"a": np.arange(n) % 10, "d": np.zeros((n, 2), np.float32)}
+    with pytest.raises(KeyError, match="missing from the feed"):
+        model._stage_inputs({"a": good["a"]}, engine.Staged(n))
+    with pytest.raises(ValueError, match="has 4 rows, expected 5"):
+        model._stage_inputs(dict(good, a=good["a"][:4]), engine.Staged(n))
+    with pytest.raises(ValueError, match="expected dimension 2"):
+        model._stage_inputs(dict(good, d=np.zeros((n, 3), np.float32)), engine.Staged(n))
+    with pytest.raises(TypeError, match="fed strings"):
+        model._stage_inputs(dict(good, a=np.array(["x"] * n)), engine.Staged(n))
+    with pytest.raises(ValueError, match="expects 2 input arrays"):
+        model._as_feed([good["a"]])
+    assert list(model._as_feed([good["a"], good["d"]])) == model.input_names
+
+
+def test_pipeline_planner_takes_only_plain_host_columns(monkeypatch):
+    """pipeline_plan() is the gate of the chunked pack -> copy -> score path: on a CPU device, for small feeds, with sequence
+    features or a dense transform it must send the caller to the single-pass stage()."""
+    from deepctr_amd import engine
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    monkeypatch.setattr(engine, "_PIPELINE_MIN_ROWS", 16)
+    n = 64
+    cols = [SparseFeat("a", 10, 4), DenseFeat("d", 2)]
+    feed = {"a": np.arange(n) % 10, "d": np.zeros((n, 2), np.float32)}
+    model = _model(cols)
+    sp = model.stage_plan
+    assert sp.pipeline_plan(feed, n) is None                                                # CPU device: no pipeline
+    from deepctr_amd import _C
+    with pytest.raises(_C.DctrExtensionError, match="no CPU fallback"):
+        model._pipeline(feed, 16)                                                           # predict() never runs without a GPU
+    monkeypatch.setattr(sp, "device", torch.device("cuda", 0))                               # planner logic only; nothing is launched
+    plan = sp.pipeline_plan(feed, n)
+    assert plan is not None and len(plan[0]) == 1 and len(plan[1]) == 2
+    assert plan[1][1].strides == (8,)                                                       # a column view of the [N, 2] array
+    assert sp.pipeline_plan({k: v[:8] for k, v in feed.items()}, 8) is None                 # below the row threshold
+    assert sp.pipeline_plan(dict(feed, a=feed["a"].astype(np.int16)), n) is None            # dtype outside the packer's
+    with pytest.raises(ValueError, match="expected 64"):
+        sp.pipeline_plan(dict(feed, a=feed["a"][:10]), n)
+    cols_t = [SparseFeat("a", 10, 4), DenseFeat("d", 2, transform_fn=lambda t: t * 2)]
+    m2 = _model(cols_t)
+    monkeypatch.setattr(m2.stage_plan, "device", torch.device("cuda", 0))
+    assert m2.stage_plan.pipeline_plan(feed, n) is None
+    cols_s = cols + [VarLenSparseFeat(SparseFeat("s", 9, 4), maxlen=3)]
+    m3 = _model(cols_s)
+    monkeypatch.setattr(m3.stage_plan, "device", torch.device("cuda", 0))
+    assert m3.stage_plan.pipeline_plan(dict(feed, s=np.zeros((n, 3), np.int64)), n) is None

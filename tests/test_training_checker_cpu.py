@@ -62,3 +62,83 @@ def test_restatement_is_differentiable_on_cpu():
     used = [gr for gr in grads if gr is not None]
     assert len(used) >= len(params) - 2 and all(torch.isfinite(gr).all() for gr in used)
     assert any(float(gr.abs().max()) > 0 for gr in used)
+
+
+@pytest.mark.parametrize("kind", ["DIN", "DCNMix"])
+def test_torch_step_trains_the_models_outside_the_hip_step_on_cpu(kind):
+    """fit()'s torch-autograd loop (training._fit_torch) for the two models that still use it, driven on CPU: the loss of a
+    learnable rule goes down and only trainable weights move (Dice's moving statistics stay put)."""
+    from deepctr_amd import engine, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DIN, DCNMix
+    rng = np.random.RandomState(6)
+    n, T, E = 512, 4, 4
+    cpu = torch.device("cpu")
+    if kind == "DIN":
+        cols = [SparseFeat("user", 20, E), SparseFeat("item_id", 13, E), DenseFeat("score", 1),
+                VarLenSparseFeat(SparseFeat("hist_item_id", 13, E, embedding_name="item_id"), maxlen=T)]
+        model = DIN(cols, ["item_id"], dnn_hidden_units=(8, 4), att_hidden_size=(6, 3), device=cpu)
+        hist = rng.randint(1, 13, (n, T))
+        hist[np.arange(T)[None, :] >= rng.randint(1, T + 1, n)[:, None]] = 0
+        feed = {"user": rng.randint(0, 20, n), "item_id": rng.randint(1, 13, n), "score": rng.rand(n).astype(np.float32),
+                "hist_item_id": hist}
+        y = (feed["item_id"] % 2).astype(np.float32)
+    else:
+        cols = [SparseFeat("a", 20, E), SparseFeat("b", 9, E), DenseFeat("d", 2)]
+        model = DCNMix(cols, cols, cross_num=2, dnn_hidden_units=(8, 4), low_rank=3, num_experts=2, device=cpu)
+        feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 9, n), "d": rng.rand(n, 2).astype(np.float32)}
+        y = (feed["a"] % 2).astype(np.float32)
+    model.compile("adam", "binary_crossentropy")
+    staged = engine.Staged(n)
+    model._stage_inputs(feed, staged)
+    before = {k: v.copy() for k, v in model.get_weights_by_name().items()}
+    h = training._fit_torch(model, feed, staged, torch.from_numpy(y), y, n, 0, 64, 6, 0, True)
+    assert len(h.history["loss"]) == 6 and h.history["loss"][-1] < h.history["loss"][0] - 0.01, h.history["loss"]
+    after = model.get_weights_by_name()
+    moved = [k for k in before if not np.array_equal(before[k], after[k])]
+    assert moved
+    if kind == "DIN":          # att_activation='dice': its BatchNormalization statistics follow the batches (training mode)
+        stats = [k for k in moved if "moving_" in k]
+        assert len(stats) == 4, stats
+        assert all(np.isfinite(after[k]).all() for k in stats) and all((after[k] > 0).all() for k in stats if "variance" in k)
+    else:
+        assert not any("moving_" in k for k in moved)
+    assert all(not t.requires_grad for t in model.weights)
+
+
+def test_dice_training_mode_follows_keras_batchnormalization():
+    """training._act(..., training=True) = Dice over tf.keras' BatchNormalization(center=False, scale=False, epsilon=1e-9) in
+    training mode (layers/activation.py:51-64): batch statistics over every axis but the last, biased variance, moving
+    statistics updated with momentum 0.99, gradients through the statistics; training=False uses the stored statistics."""
+    from deepctr_amd import training
+    rng = np.random.RandomState(1)
+    x = torch.from_numpy(rng.standard_normal((5, 7, 3))).double().requires_grad_(True)
+    alpha = torch.from_numpy(rng.standard_normal(3)).double()
+    mm = torch.from_numpy(rng.standard_normal(3)).double()
+    mv = torch.from_numpy(rng.uniform(0.5, 1.5, 3)).double()
+    mm0, mv0 = mm.clone(), mv.clone()
+    y = training._act("dice", x, (alpha, mm, mv), training=True)
+    xn = x.detach().numpy().reshape(-1, 3)
+    bm, bv = xn.mean(0), xn.var(0)                                   # numpy var is the biased one
+    p = 1.0 / (1.0 + np.exp(-(x.detach().numpy() - bm) / np.sqrt(bv + 1e-9)))
+    ref = alpha.numpy() * (1 - p) * x.detach().numpy() + p * x.detach().numpy()
+    np.testing.assert_allclose(y.detach().numpy(), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mm.numpy(), 0.99 * mm0.numpy() + 0.01 * bm, rtol=1e-12)
+    np.testing.assert_allclose(mv.numpy(), 0.99 * mv0.numpy() + 0.01 * bv, rtol=1e-12)
+    # the batch statistics are part of the graph: shifting every input by a constant changes nothing, so the gradient sums to 0
+    # over the batch for the normalised path; check against finite differences on one element instead
+    g, = torch.autograd.grad(y.sum(), x)
+    eps = 1e-6
+    xp = x.detach().clone()
+    xp[2, 3, 1] += eps
+    yp = training._act("dice", xp, (alpha, mm.clone(), mv.clone()), training=True).sum()
+    xm = x.detach().clone()
+    xm[2, 3, 1] -= eps
+    ym = training._act("dice", xm, (alpha, mm.clone(), mv.clone()), training=True).sum()
+    assert abs(float((yp - ym) / (2 * eps)) - float(g[2, 3, 1])) < 1e-6
+    # inference form: stored statistics, nothing updated
+    mm1, mv1 = mm.clone(), mv.clone()
+    yi = training._act("dice", x.detach(), (alpha, mm, mv))
+    pi = 1.0 / (1.0 + np.exp(-(x.detach().numpy() - mm1.numpy()) / np.sqrt(mv1.numpy() + 1e-9)))
+    np.testing.assert_allclose(yi.numpy(), alpha.numpy() * (1 - pi) * x.detach().numpy() + pi * x.detach().numpy(), rtol=1e-12)
+    assert torch.equal(mm, mm1) and torch.equal(mv, mv1)
