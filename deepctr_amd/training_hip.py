@@ -36,6 +36,10 @@ def supported(model):
             return False
         if not la.dnn.kernels or getattr(la.dnn, "dropout_rate", 0) or getattr(la.dnn, "use_bn", False):
             return False
+        # Dice: this step evaluates it with the STORED statistics, fit()'s torch step with tf.keras' training-mode batch
+        # statistics (training._act); until the batch-statistics reductions exist here, Dice is opt-in (tests, experiments)
+        if la.dnn.activation in ("dice", "Dice") and not getattr(model, "hip_dice_stored_statistics", False):
+            return False
     if sp.lin_only or len(sp.fm_group_names) > 1 or not sp.all_dim4 or sp.max_dim > 64:
         return False
     if kind == "_AFM":                      # no DNN: linear logit + AFMLayer per group (or the gather's FM group)

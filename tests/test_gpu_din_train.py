@@ -140,6 +140,7 @@ def _din(device, act, E=8, T=6):
             VarLenSparseFeat(SparseFeat("other_seq", 9, E), maxlen=4, combiner="mean")]
     model = DIN(cols, ["item_id", "cate_id"], att_activation=act, dnn_hidden_units=(16, 8), att_hidden_size=(12, 6),
                 l2_reg_embedding=0, device=device)
+    model.hip_dice_stored_statistics = True          # opt in: Dice with the stored statistics (see training_hip.supported)
     return model, cols
 
 
@@ -199,7 +200,7 @@ def test_din_hip_training_gradients_match_torch_autograd(device, act):
 
 def test_din_fit_runs_on_the_hip_step_and_learns(device):
     rng = np.random.RandomState(2)
-    model, cols = _din(device, "dice")
+    model, cols = _din(device, "sigmoid")
     n = 2048
     feed = _din_feed(rng, n)
     y = (feed["cate_id"] % 2).astype(np.float32)
