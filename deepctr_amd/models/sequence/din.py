@@ -126,5 +126,6 @@ def DIN(dnn_feature_columns, history_feature_list, dnn_use_bn=False, dnn_hidden_
     """Instantiates the Deep Interest Network architecture on the MI355X forward path."""
     m = _DIN(dnn_feature_columns, history_feature_list, dnn_use_bn, dnn_hidden_units, dnn_activation,
              att_hidden_size, att_activation, att_weight_normalization, dnn_dropout, seed, task, device)
+    # l2 regularisers of the reference constructor (din.py:56-57, :91); the attention unit has none (sequence.py:243-245)
     m.regularizers = {"embedding": float(l2_reg_embedding), "linear": 0.0, "dnn": float(l2_reg_dnn)}
     return m

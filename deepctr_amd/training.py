@@ -136,11 +136,54 @@ def _act(name, x, dice=None, training=False):
     return {"relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "linear": lambda v: v, None: lambda v: v}[name](x)
 
 
+def _dropout(x, rate, training):
+    """keras Dropout (inverted scaling) in training mode; the mask comes from torch's generator, not TF's."""
+    return torch.nn.functional.dropout(x, float(rate), True) if training and rate and rate > 0 else x
+
+
 def dnn_forward(dnn, x, training=False):
     dice = dnn.dice_params()
     for i, (w, b) in enumerate(zip(dnn.kernels, dnn.biases)):
         x = _act(dnn.activation, x @ w + b, dice[i] if dice else None, training)
+        x = _dropout(x, getattr(dnn, "dropout_rate", 0), training)             # layers/core.py:204-205
     return x
+
+
+def regularized_weights(model):
+    """[(tensor, l2)] for every weight the reference attaches ``l2(l2_reg_*)`` to: embedding tables (inputs.py:22-41), the
+    linear part (feature_column.py:171-210, layers/utils.py:142-158), DNN kernels (core.py:160-166), CrossNet / CrossNetMix
+    kernels (interaction.py:387, :481-500), CIN filters (:258) and AFMLayer.attention_W (:100).  keras l2(l) adds
+    l * sum(w^2) to the loss — over the WHOLE table every step, as the HIP step's 2*l2*w term does."""
+    reg = getattr(model, "regularizers", None) or {}
+    out, seen = [], set()
+
+    def add(t, l2):
+        if t is not None and l2 and t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            out.append((t, float(l2)))
+
+    for emb in (getattr(model, "tables", None) or {}).values():
+        add(emb.embeddings, reg.get("embedding", 0.0))
+    for emb in (getattr(model, "linear_tables", None) or {}).values():
+        add(emb.embeddings, reg.get("linear", 0.0))
+    if getattr(model, "linear", None) is not None:
+        add(model.linear.w("linear_kernel"), reg.get("linear", 0.0))
+    dnn = getattr(model, "dnn", None)
+    if dnn is not None:
+        for k in dnn.kernels:
+            add(k, reg.get("dnn", 0.0))
+    cross = getattr(model, "cross", None)
+    if cross is not None:
+        for name, t in cross._weights.items():
+            if name.startswith(("kernel", "U_list", "V_list", "C_list")):
+                add(t, reg.get("cross", 0.0))
+    cin = getattr(model, "cin", None)
+    if cin is not None:
+        for f in cin.filters:
+            add(f, reg.get("cin", 0.0))
+    for layer in getattr(model, "afm_layers", None) or []:
+        add(layer.w("attention_W"), getattr(layer, "l2_reg_w", 0.0))
+    return out
 
 
 def model_logits(model, staged, lo, hi, training=False):
@@ -182,7 +225,8 @@ def model_logits(model, staged, lo, hi, training=False):
                 bi = torch.stack([embs[i] for i in ii], dim=1) * torch.stack([embs[j] for j in jj], dim=1)     # [B,P,E]
                 att = torch.relu(bi @ layer.w("attention_W") + layer.w("attention_b"))
                 score = torch.softmax(att @ layer.w("projection_h"), dim=1)
-                logit = logit + ((score * bi).sum(1) @ layer.w("projection_p")).reshape(-1)
+                att_out = _dropout((score * bi).sum(1), getattr(layer, "dropout_rate", 0), training)     # interaction.py:142-143
+                logit = logit + (att_out @ layer.w("projection_p")).reshape(-1)
         if lin is not None:
             logit = logit + lin
         for f in fms:
@@ -190,7 +234,8 @@ def model_logits(model, staged, lo, hi, training=False):
         return logit + model.prediction.w("global_bias")
     if name == "NFM":                       # models/nfm.py:49-58: DNN over [BiInteractionPooling(embeddings), dense]
         x0 = torch.stack(parts[:len(sp.fields)], dim=1)
-        parts[extra["bi_interaction"]] = 0.5 * (x0.sum(1).pow(2) - (x0 * x0).sum(1))
+        parts[extra["bi_interaction"]] = _dropout(0.5 * (x0.sum(1).pow(2) - (x0 * x0).sum(1)), getattr(model, "bi_dropout", 0),
+                                                  training)                                      # nfm.py:52-53
         parts = parts[extra["bi_interaction"]:]
     if name == "PNN" and "inner_product" in extra:      # models/pnn.py:52-66, InnerProductLayer(reduce_sum) pair order
         n = len(sp.fields)
@@ -334,6 +379,7 @@ def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verb
     hist = History()
     hist.history["loss"] = []
     bs = int(batch_size) if batch_size else n_tr
+    regs = regularized_weights(model)
     try:
         for ep in range(epochs):
             order = np.arange(0, n_tr, bs)
@@ -349,6 +395,8 @@ def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verb
                 else:
                     pred = torch.sigmoid(logit) if model.task == "binary" else logit
                     loss = torch.nn.functional.mse_loss(pred, yt[lo:hi])
+                for t, l2 in regs:                                  # keras adds the regularisation losses to the loss
+                    loss = loss + l2 * (t * t).sum()
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
                 opt.step()

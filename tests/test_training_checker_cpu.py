@@ -142,3 +142,68 @@ def test_dice_training_mode_follows_keras_batchnormalization():
     pi = 1.0 / (1.0 + np.exp(-(x.detach().numpy() - mm1.numpy()) / np.sqrt(mv1.numpy() + 1e-9)))
     np.testing.assert_allclose(yi.numpy(), alpha.numpy() * (1 - pi) * x.detach().numpy() + pi * x.detach().numpy(), rtol=1e-12)
     assert torch.equal(mm, mm1) and torch.equal(mv, mv1)
+
+
+def test_regularized_weights_follow_the_reference_constructors():
+    """Which weights carry keras l2 regularisers, and with which strength (training.regularized_weights)."""
+    from deepctr_amd import training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import AFM, DCN, DIN, DCNMix, DeepFM, xDeepFM
+    cpu = torch.device("cpu")
+    cols = [SparseFeat("a", 20, 4), SparseFeat("b", 9, 4), DenseFeat("d", 2)]
+
+    def by_name(model):
+        names = {t.data_ptr(): k for k, t in model.named_weights()}
+        return {names[t.data_ptr()]: l2 for t, l2 in training.regularized_weights(model)}
+
+    r = by_name(DeepFM(cols, cols, dnn_hidden_units=(8, 4), l2_reg_linear=1e-3, l2_reg_embedding=2e-3, l2_reg_dnn=3e-3, device=cpu))
+    assert r == {"sparse_emb_a/embeddings": 2e-3, "sparse_emb_b/embeddings": 2e-3, "linear0sparse_emb_a/embeddings": 1e-3,
+                 "linear0sparse_emb_b/embeddings": 1e-3, "linear/linear_kernel": 1e-3, "dnn/kernel0": 3e-3, "dnn/kernel1": 3e-3}
+    r = by_name(DeepFM(cols, cols, dnn_hidden_units=(8,), device=cpu))                       # defaults: l2_reg_dnn = 0
+    assert "dnn/kernel0" not in r and r["sparse_emb_a/embeddings"] == 1e-5 and r["linear/linear_kernel"] == 1e-5
+    r = by_name(DCN(cols, cols, cross_num=2, dnn_hidden_units=(8,), l2_reg_cross=4e-3, device=cpu))
+    assert r["cross_net/kernel0"] == 4e-3 and r["cross_net/kernel1"] == 4e-3 and "cross_net/bias0" not in r
+    r = by_name(DCNMix(cols, cols, cross_num=1, dnn_hidden_units=(8,), low_rank=2, num_experts=2, l2_reg_cross=5e-3, device=cpu))
+    assert {k for k in r if k.startswith("cross_net_mix/")} == {"cross_net_mix/U_list0", "cross_net_mix/V_list0",
+                                                                "cross_net_mix/C_list0"}
+    r = by_name(xDeepFM(cols, cols, dnn_hidden_units=(8,), cin_layer_size=(4, 4), l2_reg_cin=6e-3, device=cpu))
+    assert r["cin/filter0"] == 6e-3 and r["cin/filter1"] == 6e-3 and "cin/bias0" not in r
+    r = by_name(AFM(cols, cols[:2], attention_factor=3, l2_reg_att=7e-3, device=cpu))
+    assert r["afm_layer/attention_W"] == 7e-3 and "afm_layer/projection_p" not in r
+    dcols = [SparseFeat("item_id", 13, 4), VarLenSparseFeat(SparseFeat("hist_item_id", 13, 4, embedding_name="item_id"), maxlen=3)]
+    r = by_name(DIN(dcols, ["item_id"], dnn_hidden_units=(8,), att_hidden_size=(4,), l2_reg_dnn=8e-3, device=cpu))
+    assert r == {"sparse_emb_item_id/embeddings": 1e-6, "dnn_1/kernel0": 8e-3}, r        # the attention unit's DNN ("dnn") has none
+
+
+def test_torch_step_adds_the_l2_terms_and_applies_dropout_in_training_mode():
+    from deepctr_amd import engine, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM
+    cpu = torch.device("cpu")
+    rng = np.random.RandomState(4)
+    n = 64
+    cols = [SparseFeat("a", 7, 4), DenseFeat("d", 1)]
+    feed = {"a": rng.randint(0, 7, n), "d": rng.rand(n).astype(np.float32)}
+    y = rng.randint(0, 2, n).astype(np.float32)
+    model = DeepFM(cols, cols, dnn_hidden_units=(8,), l2_reg_embedding=0.5, l2_reg_linear=0, dnn_dropout=0.5, device=cpu)
+    staged = engine.Staged(n)
+    model._stage_inputs(feed, staged)
+    model._begin()
+    # dropout: inference form is deterministic, training form is not, and keeps the expectation (inverted scaling)
+    with torch.no_grad():
+        a = training.model_logits(model, staged, 0, n)
+        b = training.model_logits(model, staged, 0, n)
+        torch.manual_seed(0)
+        c = training.model_logits(model, staged, 0, n, training=True)
+        d = training.model_logits(model, staged, 0, n, training=True)
+    assert torch.equal(a, b) and not torch.equal(c, d) and not torch.equal(a, c)
+    # one SGD step with lr 1 on a table whose rows no sample touches: only the l2 term moves them, by -2 * l2 * w
+    table = model.tables["a"].embeddings
+    feed0 = dict(feed, a=np.zeros(n, np.int64))
+    staged0 = engine.Staged(n)
+    model._stage_inputs(feed0, staged0)
+    w0 = table.clone()
+    model.compile(lambda params: torch.optim.SGD(params, lr=1.0), "binary_crossentropy")
+    training._fit_torch(model, feed0, staged0, torch.from_numpy(y), y, n, 0, n, 1, 0, False)
+    np.testing.assert_allclose(table[1:].numpy(), (w0[1:] * (1 - 2 * 0.5)).numpy(), atol=1e-7)      # untouched rows: w - 2*l2*w = 0
+    assert not np.allclose(table[0].numpy(), 0.0)
