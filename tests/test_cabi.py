@@ -90,3 +90,72 @@ def test_host_pack_columns_converts_like_numpy():
     assert lib.dctr_host_pack_columns(desc, len(cols), 0, 8, None, 8, 0, 1) == -1
     assert lib.dctr_host_pack_columns(desc, len(cols), 0, 8, None, 4, 0, 1) == -2        # column stride < rows
     assert lib.dctr_host_pack_columns(desc, len(cols), 0, 8, None, 8, 3, 1) == -4        # float64 is not a staging dtype
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/dctr.h is the drop-in boundary: it must compile as C99 (no C++, no torch / HIP types) and a C program must link
+    against libdctr_hip.so and call it without Python in the process."""
+    import os
+    import shutil
+    import subprocess
+    from deepctr_amd import build
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "main.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "dctr.h"\n'
+                   "int main(void) {\n"
+                   "    dctr_gather_fm_args_t g; memset(&g, 0, sizeof g); g.batch = 4;\n"
+                   "    if (dctr_abi_version() != 1 || strcmp(dctr_target_arch(), \"gfx950\") != 0) return 1;\n"
+                   "    if (dctr_fm_fwd(NULL, 4, 8, 2, 4, NULL, NULL) != DCTR_E_NULL) return 2;      /* rejected before any launch */\n"
+                   "    if (dctr_embed_gather_fm(&g, NULL) != DCTR_E_DIM) return 3;\n"
+                   "    if (strlen(dctr_last_error()) == 0) return 4;\n"
+                   "    if (dctr_host_pack_columns(NULL, 0, 0, 0, NULL, 0, DCTR_HOST_I32, 1) != DCTR_OK) return 5;\n"
+                   '    puts("ok");\n    return 0;\n}\n')
+    exe = tmp_path / "cabi_check"
+    lib_dir = os.path.dirname(build.LIB)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                    "-o", str(exe), "-L", lib_dir, "-ldctr_hip", "-Wl,-rpath," + lib_dir], check=True)
+    env = dict(os.environ)
+    rocm = "/opt/rocm/lib"
+    env["LD_LIBRARY_PATH"] = rocm + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
+
+
+def test_every_ctypes_mirror_has_the_layout_the_c_compiler_gives_the_header(tmp_path):
+    """sizeof and the offset of every field of each struct in include/dctr.h, as gcc lays them out, against the ctypes mirrors
+    in deepctr_amd/_C.py (same field order by construction: the C side is generated from the ctypes field names)."""
+    import ctypes
+    import os
+    import shutil
+    import subprocess
+    from deepctr_amd import _C
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"FieldDesc": "dctr_field_t", "GatherFmArgs": "dctr_gather_fm_args_t", "PoolArgs": "dctr_pool_args_t",
+             "LookupArgs": "dctr_lookup_args_t", "CinArgs": "dctr_cin_args_t", "MlpArgs": "dctr_mlp_args_t",
+             "FieldGrad": "dctr_field_grad_t", "GatherFmBwdArgs": "dctr_gather_fm_bwd_args_t", "PoolBwdArgs": "dctr_pool_bwd_args_t",
+             "MlpBwdArgs": "dctr_mlp_bwd_args_t", "CinBwdArgs": "dctr_cin_bwd_args_t", "CrossBwdArgs": "dctr_crossnet_bwd_args_t",
+             "AfmBwdArgs": "dctr_afm_bwd_args_t", "HostCol": "dctr_host_col_t", "AdamSeg": "dctr_adam_seg_t",
+             "DinAttnArgs": "dctr_din_attn_args_t"}
+    mirrors = [n for n in dir(_C) if isinstance(getattr(_C, n), type) and issubclass(getattr(_C, n), ctypes.Structure)
+               and getattr(_C, n) is not ctypes.Structure]
+    assert sorted(mirrors) == sorted(pairs), "a ctypes mirror without a header struct in this test: %s" % (set(mirrors) ^ set(pairs))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dctr.h"', "int main(void) {"]
+    for py, c in pairs.items():
+        lines.append('    printf("%s sizeof %%zu\\n", sizeof(%s));' % (py, c))
+        for fname, _ in getattr(_C, py)._fields_:
+            lines.append('    printf("%s %s %%zu\\n", offsetof(%s, %s));' % (py, fname, c, fname))
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    for line in filter(None, out):
+        py, field, val = line.split()
+        cls = getattr(_C, py)
+        want = ctypes.sizeof(cls) if field == "sizeof" else getattr(cls, field).offset
+        assert int(val) == want, "%s.%s: C says %s, ctypes %d" % (py, field, val, want)
