@@ -99,7 +99,8 @@ class MlpBwdArgs(ctypes.Structure):
                 ("units", c_vp), ("kernels", c_vp), ("acts", c_vp), ("activation", c_i32), ("pad_", c_i32),
                 ("head_w", c_vp), ("dlogit", c_vp), ("d_kernels", c_vp), ("d_biases", c_vp), ("d_head_w", c_vp),
                 ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
-                ("d_out", c_vp), ("d_out_stride", c_i64)]
+                ("d_out", c_vp), ("d_out_stride", c_i64), ("biases", c_vp), ("dice_alpha", c_vp), ("dice_mean", c_vp),
+                ("dice_var", c_vp), ("d_dice_alpha", c_vp), ("dice_eps", c_f32), ("pad2_", c_i32)]
 
 
 class CinBwdArgs(ctypes.Structure):
@@ -177,6 +178,11 @@ SYMBOLS = {
     "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
     "dctr_embed_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolBwdArgs), c_vp]),
     "dctr_afm_bwd": (ctypes.c_int, [c_vp, c_vp]),
+    "dctr_din_att_in_fwd": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "dctr_din_wsum_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "dctr_din_wsum_bwd": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "dctr_din_att_in_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dctr_embed_lookup_bwd": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dctr_bi_interaction_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_inner_product_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_dense1_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),

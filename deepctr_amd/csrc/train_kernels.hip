@@ -785,7 +785,198 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dice (layers/activation.py:59-64, inference statistics):  y = z (alpha + (1 - alpha) p),  p = sigmoid((z - mean) / sqrt(var + eps))
+//   dy/dz = alpha + (1 - alpha) p + z (1 - alpha) p (1 - p) / sqrt(var + eps);   dy/dalpha = z (1 - p)
+// z is not recoverable from y, so dctr_mlp_bwd recomputes Z = X W with one more GEMM and this kernel adds the bias.
+// in place: dh[b,n] (gradient w.r.t. y) -> gradient w.r.t. z;  d_alpha[n] += sum_b dh[b,n] z (1 - p)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dice_bwd_kernel(float* __restrict__ dh, const float* __restrict__ zw, const float* __restrict__ bias,
+                                                       const float* __restrict__ alpha, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, float eps, int64_t batch, int N,
+                                                       float* __restrict__ d_alpha) {
+    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float bn = bias != nullptr ? bias[n] : 0.f, al = alpha[n], mu = mean[n];
+        const float rs = 1.f / sqrtf(var[n] + eps);
+        float acc = 0.f;
+        for (int r = 0; r < BWD_ROWS; ++r) {
+            const int64_t b = r0 + r;
+            if (b >= batch) break;
+            const float z = zw[b * N + n] + bn;
+            const float p = 1.f / (1.f + expf(-(z - mu) * rs));
+            const float d = dh[b * N + n];
+            acc = fmaf(d, z * (1.f - p), acc);
+            dh[b * N + n] = d * (al + (1.f - al) * p + z * (1.f - al) * p * (1.f - p) * rs);
+        }
+        if (d_alpha != nullptr) unsafeAtomicAdd(d_alpha + n, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DIN's LocalActivationUnit as a training step (layers/core.py:94-108, layers/sequence.py:261-298): the attention input
+// [q, k, q - k, q * k] is materialised once per batch ([B*T, 4E]) so that the attention MLP runs through dctr_mlp_fwd /
+// dctr_mlp_bwd with saved activations; the masked weighted sum and the scatter of the key gradients are kernels here.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void din_att_in_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t rows, int T,
+                                                         int E, float* __restrict__ a) {
+    // one thread per (row = b*T + t, e)
+    const int64_t total = rows * E;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t r = o / E;
+        const int e = (int)(o - r * E);
+        const float qv = q[(r / T) * E + e], kv = k[o];
+        float* ar = a + r * 4 * E;
+        ar[e] = qv;
+        ar[E + e] = kv;
+        ar[2 * E + e] = qv - kv;
+        ar[3 * E + e] = qv * kv;
+    }
+}
+
+// out[b, e] = sum_t (mask ? score : 0) k[b,t,e]                         (weight_normalization=False, sequence.py:286-296)
+__global__ __launch_bounds__(256) void din_wsum_kernel(const float* __restrict__ score, const uint8_t* __restrict__ mask,
+                                                       const float* __restrict__ k, int64_t batch, int T, int E,
+                                                       float* __restrict__ out, int64_t out_stride) {
+    const int64_t total = batch * E;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / E;
+        const int e = (int)(o - b * E);
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float s = mask[b * T + t] ? score[b * T + t] : 0.f;
+            acc = fmaf(s, k[(b * T + t) * E + e], acc);
+        }
+        out[b * out_stride + e] = acc;
+    }
+}
+
+// d_score[b,t] = mask ? <d_out[b,:], k[b,t,:]> : 0;  dk[b,t,:] = (mask ? score : 0) d_out[b,:] (written);
+// d_bias += sum d_score (the bias of the unit's final Dense(1));  one wave per (b, t)
+__global__ __launch_bounds__(256) void din_wsum_bwd_kernel(const float* __restrict__ d_out, int64_t d_stride,
+                                                           const float* __restrict__ score, const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ k, int64_t batch, int T, int E,
+                                                           float* __restrict__ d_score, float* __restrict__ dk,
+                                                           float* __restrict__ d_bias) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = batch * T;
+    float bsum = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t b = r / T;
+        const bool m = mask[r] != 0;
+        const float s = m ? score[r] : 0.f;
+        float dot = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            const float g = d_out[b * d_stride + e];
+            dot = fmaf(g, k[r * E + e], dot);
+            dk[r * E + e] = s * g;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        const float ds = m ? dot : 0.f;
+        if (lane == 0) d_score[r] = ds;
+        bsum += ds;
+    }
+    if (d_bias != nullptr && lane == 0 && bsum != 0.f) unsafeAtomicAdd(d_bias, bsum);
+}
+
+// da [B*T, 4E] -> dq[b,e] = sum_t (d0 + d2 + d3 k), added into dx[b, qcol[e]];  dk[b,t,e] += d1 - d2 + d3 q
+__global__ __launch_bounds__(256) void din_att_in_bwd_kernel(const float* __restrict__ da, const float* __restrict__ q,
+                                                             const float* __restrict__ k, int64_t batch, int T, int E,
+                                                             float* __restrict__ dk, float* __restrict__ dx, int64_t dx_stride,
+                                                             const int32_t* __restrict__ qcol) {
+    const int64_t total = batch * E;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / E;
+        const int e = (int)(o - b * E);
+        const float qv = q[o];
+        float dq = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int64_t r = b * T + t;
+            const float* ar = da + r * 4 * E;
+            const float d0 = ar[e], d1 = ar[E + e], d2 = ar[2 * E + e], d3 = ar[3 * E + e];
+            const float kv = k[r * E + e];
+            dq += d0 + d2 + d3 * kv;
+            dk[r * E + e] += d1 - d2 + d3 * qv;
+        }
+        dx[b * dx_stride + qcol[e]] += dq;
+    }
+}
+
+// backward of dctr_embed_lookup: g_table[row(idx[i]), :] += d_out[i, :dim]   (rows out of range are skipped, as the forward
+// zero-fills them and raises the status flag)
+__global__ __launch_bounds__(256) void lookup_bwd_kernel(dctr_lookup_args_t a, const float* __restrict__ d_out, int64_t d_stride,
+                                                         float* __restrict__ g_table) {
+    const int64_t total = a.n * a.dim;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t i = o / a.dim;
+        const int c = (int)(o - i * a.dim);
+        const float g = d_out[i * d_stride + c];
+        if (g == 0.f) continue;
+        const int64_t row = resolve_row(read_id(a.idx, i, a.idx_is_i64), a.hash_mode, a.idx_is_i64, a.vocab);
+        if ((uint64_t)row < (uint64_t)a.vocab) unsafeAtomicAdd(g_table + row * a.dim + c, g);
+    }
+}
+
 }  // namespace
+
+extern "C" int dctr_din_att_in_fwd(const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* a, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1 && dim >= 1, DCTR_E_DIM, "din_att_in_fwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(q && k && a, DCTR_E_NULL, "din_att_in_fwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * maxlen * dim, (int64_t)256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(din_att_in_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, q, k, batch * maxlen, (int)maxlen,
+                       (int)dim, a);
+    return dctr_launch_status("dctr_din_att_in_fwd");
+}
+
+extern "C" int dctr_din_wsum_fwd(const float* score, const uint8_t* mask, const float* k, int64_t batch, int32_t maxlen, int32_t dim,
+                                 float* out, int64_t out_stride, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1 && dim >= 1 && out_stride >= dim, DCTR_E_DIM, "din_wsum_fwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(score && mask && k && out, DCTR_E_NULL, "din_wsum_fwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(din_wsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, score, mask, k, batch, (int)maxlen,
+                       (int)dim, out, out_stride);
+    return dctr_launch_status("dctr_din_wsum_fwd");
+}
+
+extern "C" int dctr_din_wsum_bwd(const float* d_out, int64_t d_stride, const float* score, const uint8_t* mask, const float* k,
+                                 int64_t batch, int32_t maxlen, int32_t dim, float* d_score, float* dk, float* d_bias, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1 && dim >= 1 && d_stride >= dim, DCTR_E_DIM, "din_wsum_bwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(d_out && score && mask && k && d_score && dk, DCTR_E_NULL, "din_wsum_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * maxlen, (int64_t)4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(din_wsum_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_out, d_stride, score, mask, k,
+                       batch, (int)maxlen, (int)dim, d_score, dk, d_bias);
+    return dctr_launch_status("dctr_din_wsum_bwd");
+}
+
+extern "C" int dctr_din_att_in_bwd(const float* da, const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim,
+                                   float* dk, float* dx, int64_t dx_stride, const int32_t* qcol, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1 && dim >= 1, DCTR_E_DIM, "din_att_in_bwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(da && q && k && dk && dx && qcol, DCTR_E_NULL, "din_att_in_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(din_att_in_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, da, q, k, batch, (int)maxlen,
+                       (int)dim, dk, dx, dx_stride, qcol);
+    return dctr_launch_status("dctr_din_att_in_bwd");
+}
+
+extern "C" int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, void* stream) {
+    DCTR_REQUIRE(fwd != nullptr, DCTR_E_NULL, "embed_lookup_bwd: null args");
+    DCTR_REQUIRE(fwd->n >= 0 && fwd->dim >= 1 && d_stride >= fwd->dim && fwd->vocab >= 1, DCTR_E_DIM, "embed_lookup_bwd: bad sizes");
+    if (fwd->n == 0) return DCTR_OK;
+    DCTR_REQUIRE(fwd->idx && d_out && g_table, DCTR_E_NULL, "embed_lookup_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(fwd->n * fwd->dim, (int64_t)256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(lookup_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *fwd, d_out, d_stride, g_table);
+    return dctr_launch_status("dctr_embed_lookup_bwd");
+}
 
 extern "C" int dctr_afm_bwd(const dctr_afm_bwd_args_t* a, void* stream) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "afm_bwd: null args");
@@ -914,10 +1105,11 @@ extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) 
 }
 
 extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
-    if (a == nullptr || a->batch <= 0) return 0;
+    if (a == nullptr || a->batch <= 0 || a->n_layers < 1 || a->units == nullptr) return 0;
     int w = a->in_dim;
     for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
-    return (size_t)2 * a->batch * w * sizeof(float);
+    // two ping-pong buffers [B, widest layer]; Dice needs a third for the recomputed pre-activations
+    return (size_t)(a->activation == DCTR_ACT_DICE ? 3 : 2) * a->batch * w * sizeof(float);
 }
 
 extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
@@ -928,8 +1120,10 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     DCTR_REQUIRE((a->head_w != nullptr && a->dlogit != nullptr && a->d_head_w != nullptr) ||
                      (a->head_w == nullptr && a->d_out != nullptr && a->d_out_stride >= a->units[a->n_layers - 1]),
                  DCTR_E_NULL, "mlp_bwd: needs either (head_w, dlogit, d_head_w) or d_out");
-    DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_UNSUPPORTED,
-                 "mlp_bwd: activation %d has no backward yet (linear, relu, sigmoid, tanh)", a->activation);
+    const bool dice = a->activation == DCTR_ACT_DICE;
+    DCTR_REQUIRE((a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH) || dice, DCTR_E_UNSUPPORTED,
+                 "mlp_bwd: activation %d has no backward (linear, relu, sigmoid, tanh, dice)", a->activation);
+    DCTR_REQUIRE(!dice || (a->dice_alpha && a->dice_mean && a->dice_var), DCTR_E_NULL, "mlp_bwd: dice needs alpha / mean / var");
     DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_mlp_bwd_workspace_bytes(a), DCTR_E_NULL,
                  "mlp_bwd: needs a workspace of dctr_mlp_bwd_workspace_bytes() bytes");
     DCTR_REQUIRE(a->batch < 0x7fffffffLL, DCTR_E_DIM, "mlp_bwd: batch too large");
@@ -941,26 +1135,44 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
     float* bufA = static_cast<float*>(a->workspace);
     float* bufB = bufA + (size_t)a->batch * w;
+    float* bufZ = bufB + (size_t)a->batch * w;                 // dice only
     const int B = (int)a->batch;
     const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
     const int L = a->n_layers;
+    const float one = 1.f, zero = 0.f;
+    // Dice: dH of layer l (in `buf`, in place) -> dZ.  Z_l = X_l W_l is recomputed (column-major Z'(N x B) = W'(N x K) X'(K x B)).
+    auto dice_bwd = [&](int l, float* buf) -> int {
+        const int N = a->units[l], K = l == 0 ? a->in_dim : a->units[l - 1];
+        const float* xin = l == 0 ? a->x : a->acts[l - 1];
+        const int ldx = l == 0 ? (int)a->x_stride : K;
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, N, B, K, &one, a->kernels[l], N, xin, ldx,
+                                          &zero, bufZ, N);
+        if (rs != rocblas_status_success) return (int)rs;
+        hipLaunchKernelGGL(dice_bwd_kernel, dim3(rb), dim3(256), 0, st, buf, bufZ, a->biases != nullptr ? a->biases[l] : nullptr,
+                           a->dice_alpha[l], a->dice_mean[l], a->dice_var[l], a->dice_eps, a->batch, N,
+                           a->d_dice_alpha != nullptr ? a->d_dice_alpha[l] : nullptr);
+        return 0;
+    };
     // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit
     const int NL = a->units[L - 1];
     if (a->head_w != nullptr) {
         hipLaunchKernelGGL(head_bwd_kernel, dim3(rb), dim3(256), 0, st, a->dlogit, a->head_w, a->acts[L - 1], (int64_t)NL,
-                           a->batch, NL, (int)a->activation, bufA, (int64_t)NL, a->d_head_w);
+                           a->batch, NL, dice ? (int)DCTR_ACT_LINEAR : (int)a->activation, bufA, (int64_t)NL, a->d_head_w);
     } else {
         // headless (the DNN branch of DCN): the caller hands d(loss)/d(h_last); dZ_last = d_out .* act'(h_last)
         hipError_t ce = hipMemcpy2DAsync(bufA, (size_t)NL * sizeof(float), a->d_out, (size_t)a->d_out_stride * sizeof(float),
                                          (size_t)NL * sizeof(float), (size_t)a->batch, hipMemcpyDeviceToDevice, st);
         DCTR_REQUIRE(ce == hipSuccess, (int)ce, "mlp_bwd: copy of d_out failed: %s", hipGetErrorString(ce));
-        if (a->activation != DCTR_ACT_LINEAR)
+        if (a->activation != DCTR_ACT_LINEAR && !dice)
             hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, bufA, a->acts[L - 1], a->batch, NL,
                                (int)a->activation, (float*)nullptr);
     }
+    if (dice) {
+        const int rc = dice_bwd(L - 1, bufA);
+        DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(Z) failed (%d)", rc);
+    }
     float* dz = bufA;
     float* other = bufB;
-    const float one = 1.f, zero = 0.f;
     for (int l = L - 1; l >= 0; --l) {
         const int N = a->units[l], K = l == 0 ? a->in_dim : a->units[l - 1];
         const float* xin = l == 0 ? a->x : a->acts[l - 1];
@@ -983,9 +1195,13 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dX) failed (%d)", (int)rs);
         if (!to_dx) {
             // dZ_prev = dH_prev .* act'(h_prev)
-            if (a->activation != DCTR_ACT_LINEAR)
+            if (dice) {
+                const int rc = dice_bwd(l - 1, other);
+                DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(Z) failed (%d)", rc);
+            } else if (a->activation != DCTR_ACT_LINEAR) {
                 hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, other, a->acts[l - 1], a->batch, K,
                                    (int)a->activation, (float*)nullptr);
+            }
             float* t = dz;
             dz = other;
             other = t;

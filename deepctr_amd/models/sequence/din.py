@@ -73,6 +73,17 @@ class _DIN(FeatureModel):
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
         ws = sp.run(staged, lo, hi)
+        bufs = self._attention_inputs(staged, lo, hi, ws)
+        hist_off = sp.extra_offsets["hist"]
+        self.attention.run(bufs["q"], bufs["k"], bufs["m"], out=ws["dnn_in"][:, hist_off:], out_stride=sp.out_stride)
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+                head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
+                sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out)
+
+    def _attention_inputs(self, staged, lo, hi, ws):
+        """Query [B,E'] / key [B,T,E'] embeddings and the key mask [B,T] of rows [lo, hi) (din.py:62-76); also records the
+        lookups of the history features (``bufs['key_lookups']``: (feature, ids, hash_mode, first key column)) for the
+        training step's scatter."""
         B = hi - lo
         bufs = self._buf.get(B)
         if bufs is None:
@@ -91,10 +102,12 @@ class _DIN(FeatureModel):
             col += fc.embedding_dim
         col = 0
         masked = [fc for fc in self.history_cols if self.tables[fc.embedding_name].mask_zero]
+        bufs["key_lookups"] = []
         for fc in self.history_cols:
             emb = self.tables[fc.embedding_name]
             hm = 2 if (fc.use_hash and not prehashed_on_host(fc)) else 0
             lk = dict(idx=staged.seq[fc.name][lo:hi], table=emb.embeddings, hash_mode=hm, out=bufs["k"][:, :, col:])
+            bufs["key_lookups"].append((fc, lk["idx"], hm, col))
             if masked and fc is masked[0]:
                 lk["mask"] = bufs["m"]
             lookups.append(lk)
@@ -104,12 +117,7 @@ class _DIN(FeatureModel):
         extra = [staged.seq[fc.name][lo:hi] for fc in masked[1:]]
         for c0 in range(0, len(lookups), 8):            # eight lookups per launch
             ops.embed_lookup_multi(lookups[c0:c0 + 8], extra_mask_ids=extra, status=st)
-        key_mask = bufs["m"]                # all ones when no history feature masks zero (never written then)
-        hist_off = sp.extra_offsets["hist"]
-        self.attention.run(bufs["q"], bufs["k"], key_mask, out=ws["dnn_in"][:, hist_off:], out_stride=sp.out_stride)
-        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
-                head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
-                sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out)
+        return bufs                         # bufs["m"]: all ones when no history feature masks zero (never written then)
 
 
 def DIN(dnn_feature_columns, history_feature_list, dnn_use_bn=False, dnn_hidden_units=(256, 128, 64),

@@ -601,14 +601,27 @@ def embed_gather_fm_bwd(fwd_args, grads_dev, d_dnn_in=None, d_fm=None, d_lin=Non
     _C.check(_C.lib().dctr_embed_gather_fm_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm_bwd")
 
 
-def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None):
+def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None, biases=None,
+            dice=None, d_dice_alpha=None, dice_eps=1e-9):
     """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written.
-    Headless form: head_w = dlogit = d_head_w = None and ``d_out`` [B, >= units[-1]] = gradient w.r.t. the last layer."""
+    Headless form: head_w = dlogit = d_head_w = None and ``d_out`` [B, >= units[-1]] = gradient w.r.t. the last layer.
+    activation "dice": ``biases`` and ``dice`` = [(alpha, mean, var)] per layer as in the forward; ``d_dice_alpha`` (list,
+    accumulated) optional."""
     _dev_check(x, *kernels)
     n = len(kernels)
     units = [k.shape[1] for k in kernels]
     ua, kp, ap = _i32_array(units), _ptr_array(kernels), _ptr_array(acts)
     dkp, dbp = _ptr_array(d_kernels), _ptr_array(d_biases)
+    extra = {}
+    if activation in ("dice", "Dice"):
+        if dice is None or biases is None:
+            raise ValueError("mlp_bwd: activation 'dice' needs the forward's biases and dice parameters")
+        bp = _ptr_array([None if t is None else _f32c(t, "bias") for t in biases])
+        da, dm, dv = (_ptr_array([_f32c(d[i], "dice") for d in dice]) for i in range(3))
+        gp = _ptr_array(list(d_dice_alpha)) if d_dice_alpha is not None else None
+        extra = dict(biases=ctypes.cast(bp, ctypes.c_void_p), dice_alpha=ctypes.cast(da, ctypes.c_void_p),
+                     dice_mean=ctypes.cast(dm, ctypes.c_void_p), dice_var=ctypes.cast(dv, ctypes.c_void_p),
+                     d_dice_alpha=None if gp is None else ctypes.cast(gp, ctypes.c_void_p), dice_eps=float(dice_eps))
     a = _C.MlpBwdArgs(x=x.data_ptr(), batch=x.shape[0], x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
                       units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
                       acts=ctypes.cast(ap, ctypes.c_void_p), activation=_C.ACT_CODES[activation],
@@ -616,11 +629,55 @@ def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_b
                       dlogit=None if dlogit is None else dlogit.data_ptr(), d_kernels=ctypes.cast(dkp, ctypes.c_void_p),
                       d_biases=ctypes.cast(dbp, ctypes.c_void_p), d_head_w=None if d_head_w is None else d_head_w.data_ptr(),
                       dx=None if dx is None else dx.data_ptr(), dx_stride=0 if dx is None else dx.stride(0),
-                      d_out=None if d_out is None else d_out.data_ptr(), d_out_stride=0 if d_out is None else d_out.stride(0))
+                      d_out=None if d_out is None else d_out.data_ptr(), d_out_stride=0 if d_out is None else d_out.stride(0),
+                      **extra)
     need = int(_C.lib().dctr_mlp_bwd_workspace_bytes(ctypes.byref(a)))
     ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _C.check(_C.lib().dctr_mlp_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_bwd")
+
+
+def din_att_in(q, k, out):
+    """[q, k, q - k, q * k] per (sample, position): q [B,E], k [B,T,E] -> out [B*T, 4E] (include/dctr.h)."""
+    _dev_check(q, k, out)
+    B, T, E = k.shape
+    _C.check(_C.lib().dctr_din_att_in_fwd(_ptr(_f32c(q, "q")), _ptr(_f32c(k, "k")), B, T, E, _ptr(out), _C.stream_ptr()),
+             "dctr_din_att_in_fwd")
+    return out
+
+
+def din_wsum(score, mask, k, out):
+    """out[b, :E] = sum_t (mask ? score : 0) k[b,t,:]; ``out`` a 2-D (strided) view."""
+    _dev_check(score, mask, k, out)
+    B, T, E = k.shape
+    _C.check(_C.lib().dctr_din_wsum_fwd(_ptr(score), _ptr(mask), _ptr(k), B, T, E, _ptr(out), out.stride(0), _C.stream_ptr()),
+             "dctr_din_wsum_fwd")
+    return out
+
+
+def din_wsum_bwd(d_out, score, mask, k, d_score, dk, d_bias=None):
+    _dev_check(d_out, score, mask, k, d_score, dk, d_bias)
+    B, T, E = k.shape
+    _C.check(_C.lib().dctr_din_wsum_bwd(_ptr(d_out), d_out.stride(0), _ptr(score), _ptr(mask), _ptr(k), B, T, E, _ptr(d_score),
+                                        _ptr(dk), _ptr(d_bias), _C.stream_ptr()), "dctr_din_wsum_bwd")
+
+
+def din_att_in_bwd(da, q, k, dk, dx, qcol):
+    _dev_check(da, q, k, dk, dx, qcol)
+    B, T, E = k.shape
+    _C.check(_C.lib().dctr_din_att_in_bwd(_ptr(da), _ptr(q), _ptr(k), B, T, E, _ptr(dk), _ptr(dx), dx.stride(0), _ptr(qcol),
+                                          _C.stream_ptr()), "dctr_din_att_in_bwd")
+
+
+def embed_lookup_bwd(idx, table_shape, hash_mode, d_out, g_table):
+    """g_table[row(idx[i])] += d_out[i]: idx any shape with n ids, d_out a view whose second-to-last stride is the row stride."""
+    _dev_check(idx, d_out, g_table)
+    ic, is64 = _ids(idx, "idx")
+    vocab, dim = table_shape
+    a = _C.LookupArgs(idx=ic.data_ptr(), table=None, vocab=int(vocab), n=ic.numel(), idx_is_i64=is64, dim=int(dim),
+                      hash_mode=int(hash_mode), out=None, out_stride=0, mask=None, status=None)
+    _C.check(_C.lib().dctr_embed_lookup_bwd(ctypes.byref(a), _ptr(d_out), d_out.stride(-2), _ptr(g_table), _C.stream_ptr()),
+             "dctr_embed_lookup_bwd")
 
 
 def adam_step(w, m, v, g, alpha, beta1=0.9, beta2=0.999, eps=1e-7, l2=0.0, zero_grad=True):

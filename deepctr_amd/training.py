@@ -307,6 +307,20 @@ _OPTS = {"adam": lambda p: torch.optim.Adam(p, lr=1e-3, eps=1e-7), "adagrad": la
          "sgd": lambda p: torch.optim.SGD(p, lr=1e-2), "rmsprop": lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.9, eps=1e-7)}
 
 
+def permute_staged_(staged, yt, perm):
+    """Row permutation, IN PLACE, of everything staged per sample (id matrix [F,N], dense [N,ND], sequences, lengths, weights)
+    and of the labels: tf.keras' fit(shuffle=True) permutes samples each epoch.  In place so that device pointers cached by
+    the launch-argument structs stay valid; ``perm``: int64 tensor on the staged tensors' device."""
+    if staged.ids is not None:
+        staged.ids.copy_(staged.ids.index_select(1, perm))
+    if staged.dense is not None:
+        staged.dense.copy_(staged.dense.index_select(0, perm))
+    for group in (staged.seq, staged.length, staged.weight):
+        for k in group:
+            group[k].copy_(group[k].index_select(0, perm))
+    yt.copy_(yt.index_select(0, perm))
+
+
 def _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle):
     """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
     moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation."""
@@ -317,10 +331,12 @@ def _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbos
     hist = History()
     hist.history["loss"] = []
     bs = int(batch_size) if batch_size else n_tr
+    if shuffle:
+        yt = yt.clone()                 # permuted in place below; never the caller's array
     for ep in range(epochs):
         order = np.arange(0, n_tr, bs)
         if shuffle:
-            np.random.shuffle(order)
+            permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
         tot = torch.zeros(1, dtype=torch.float64, device=model.device)
         for lo in order:
             hi = min(n_tr, lo + bs)
@@ -380,11 +396,13 @@ def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verb
     hist.history["loss"] = []
     bs = int(batch_size) if batch_size else n_tr
     regs = regularized_weights(model)
+    if shuffle:
+        yt = yt.clone()                 # permuted in place below; never the caller's array
     try:
         for ep in range(epochs):
             order = np.arange(0, n_tr, bs)
             if shuffle:
-                np.random.shuffle(order)
+                permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
             tot, cnt = 0.0, 0
             for lo in order:
                 hi = min(n_tr, lo + bs)

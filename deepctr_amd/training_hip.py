@@ -27,15 +27,26 @@ def supported(model):
     sp = getattr(model, "stage_plan", None)
     dnn = getattr(model, "dnn", None)
     kind = type(model).__name__
-    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM", "_NFM", "_PNN", "_AFM"):
+    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM", "_NFM", "_PNN", "_AFM", "_DIN"):
         return False
+    if kind == "_DIN":
+        # attention unit: Dice (moving statistics, as the torch step uses) or sigmoid / relu; plain weighted sum only
+        la = model.attention.local_att
+        if model.attention.weight_normalization or la.dnn.activation not in ("dice", "Dice", "sigmoid", "relu", "tanh", "linear"):
+            return False
+        if not la.dnn.kernels or getattr(la.dnn, "dropout_rate", 0) or getattr(la.dnn, "use_bn", False):
+            return False
+        # Dice: this step evaluates it with the STORED statistics, fit()'s torch step with tf.keras' training-mode batch
+        # statistics (training._act); until the batch-statistics reductions exist here, Dice is opt-in (tests, experiments)
+        if la.dnn.activation in ("dice", "Dice") and not getattr(model, "hip_dice_stored_statistics", False):
+            return False
     if sp.lin_only or len(sp.fm_group_names) > 1 or not sp.all_dim4 or sp.max_dim > 64:
         return False
     if kind == "_AFM":                      # no DNN: linear logit + AFMLayer per group (or the gather's FM group)
         return not any(getattr(layer, "dropout_rate", 0) for layer in model.afm_layers)
-    if sp.extra_offsets and kind not in ("_NFM", "_PNN"):       # the interaction columns those two reserve in dnn_in
+    if sp.extra_offsets and kind not in ("_NFM", "_PNN", "_DIN"):   # the interaction columns those reserve in dnn_in
         return False
-    if kind in ("_DeepFM", "_xDeepFM", "_NFM", "_PNN") and (dnn is None or not dnn.kernels):
+    if kind in ("_DeepFM", "_xDeepFM", "_NFM", "_PNN", "_DIN") and (dnn is None or not dnn.kernels):
         return False
     if kind == "_xDeepFM" and model.cin is not None and model.cin.activation not in ("relu", "linear", "sigmoid", "tanh"):
         return False
@@ -115,6 +126,23 @@ class HipTrainer(object):
             for layer in model.afm_layers:      # l2_reg_att applies to attention_W only (interaction.py:100)
                 self.p_afm.append((param(layer.w("attention_W"), getattr(layer, "l2_reg_w", 0.0)), param(layer.w("attention_b")),
                                    param(layer.w("projection_h")), param(layer.w("projection_p"))))
+        self.is_din = type(model).__name__ == "_DIN"
+        self.p_att = None
+        if self.is_din:
+            la = model.attention.local_att
+            dice = la.dnn.dice_params()
+            # no regulariser on the attention unit (AttentionSequencePoolingLayer builds it with l2_reg=0, sequence.py:243-245)
+            self.p_att = dict(kernels=[param(k) for k in la.dnn.kernels], biases=[param(b) for b in la.dnn.biases],
+                              alphas=[param(d[0]) for d in dice] if dice else None, out_w=param(la.w("kernel")),
+                              out_b=param(la.w("bias")))
+            # history tables receive the key gradients through dctr_embed_lookup_bwd
+            self.p_hist = [param(model.tables[fc.embedding_name].embeddings, l2e) for fc in model.history_cols]
+            # columns of the query embeddings inside the DNN input (dq is added there; the gather backward scatters it)
+            qcol = []
+            for fc in model.query_cols:
+                f = next(f for f in sp.fields if f.kind == "sparse" and f.fc.name == fc.name)
+                qcol.extend(range(f.out_offset, f.out_offset + f.dim))
+            self.qcol = torch.as_tensor(qcol, dtype=torch.int32, device=model.device)
         self.is_nfm = type(model).__name__ == "_NFM"
         self.is_pnn = type(model).__name__ == "_PNN"
         self.p_kernels = [param(k, l2d) for k in model.dnn.kernels] if model.dnn is not None else []
@@ -236,6 +264,46 @@ class HipTrainer(object):
             ops.afm_bwd(ws["dnn_in"][:, first:], n, dim, layer.w("attention_W"), layer.w("attention_b"), layer.w("projection_h"),
                         layer.w("projection_p"), buf["dlogit"], dx[:, first:], ps[0].g, ps[1].g, ps[2].g, ps[3].g)
 
+    def _din_forward_backward(self, staged, lo, hi, ws, buf, y, B, binary):
+        """DIN (models/sequence/din.py:62-96): LocalActivationUnit over [q, k, q-k, q*k] per history position -> masked weighted
+        sum of the keys -> DNN over [embeddings | attention output | dense] -> Dense(1).  The unit's MLP runs on the
+        materialised [B*T, 4E'] input through dctr_mlp_fwd / dctr_mlp_bwd (activations saved)."""
+        model, sp = self.model, self.model.stage_plan
+        la, pa = model.attention.local_att, self.p_att
+        T, E = model.T, model.key_dim
+        bufs = model._attention_inputs(staged, lo, hi, ws)
+        q, k, m = bufs["q"], bufs["k"], bufs["m"]
+        if "att_in" not in buf:
+            dev = model.device
+            units = [kk.shape[1] for kk in la.dnn.kernels]
+            buf.update(att_in=torch.empty(B * T, 4 * E, dtype=torch.float32, device=dev),
+                       d_att_in=torch.empty(B * T, 4 * E, dtype=torch.float32, device=dev),
+                       att_acts=[torch.empty(B * T, n, dtype=torch.float32, device=dev) for n in units],
+                       score=torch.empty(B * T, dtype=torch.float32, device=dev),
+                       d_score=torch.empty(B * T, dtype=torch.float32, device=dev),
+                       dk=torch.empty(B, T, E, dtype=torch.float32, device=dev))
+        act = la.dnn.activation
+        dice = la.dnn.dice_params()
+        ops.din_att_in(q, k, buf["att_in"])
+        ops.mlp(buf["att_in"], la.dnn.kernels, la.dnn.biases, act, dice=dice, head_w=pa["out_w"].w, global_bias=pa["out_b"].w,
+                in_dim=4 * E, out=buf["score"], save_acts=buf["att_acts"])
+        hist_off = sp.extra_offsets["hist"]
+        ops.din_wsum(buf["score"], m, k, ws["dnn_in"][:, hist_off:])
+        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
+                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
+                out=buf["pred"], save_acts=buf["acts"])
+        self._loss_grad(buf, y, binary)
+        dx = buf["dx"]
+        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
+                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=dx)
+        ops.din_wsum_bwd(dx[:, hist_off:], buf["score"], m, k, buf["d_score"], buf["dk"], d_bias=pa["out_b"].g)
+        ops.mlp_bwd(buf["att_in"], 4 * E, la.dnn.kernels, buf["att_acts"], act, pa["out_w"].w, buf["d_score"],
+                    [p.g for p in pa["kernels"]], [p.g for p in pa["biases"]], pa["out_w"].g, dx=buf["d_att_in"],
+                    biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None)
+        ops.din_att_in_bwd(buf["d_att_in"], q, k, buf["dk"], dx, self.qcol)
+        for (fc, idx, hm, col), pt in zip(bufs["key_lookups"], self.p_hist):
+            ops.embed_lookup_bwd(idx, tuple(pt.w.shape), hm, buf["dk"][:, :, col:], pt.g)
+
     def _nfm_forward_backward(self, ws, buf, y, binary):
         """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) | dense] -> Dense(1) + linear logit."""
         model, sp = self.model, self.model.stage_plan
@@ -330,6 +398,8 @@ class HipTrainer(object):
             sp.pool_trace = None
         if self.is_dcn:
             self._dcn_forward_backward(ws, buf, y, B, binary)
+        elif self.is_din:
+            self._din_forward_backward(staged, lo, hi, ws, buf, y, B, binary)
         elif self.is_afm:
             self._afm_forward_backward(ws, buf, y, B, binary)
         elif self.is_nfm:

@@ -440,7 +440,7 @@ typedef struct {
     const int32_t* units;         /* HOST [n_layers]                                                     */
     const float* const* kernels;  /* HOST array of DEVICE pointers, as in the forward                    */
     const float* const* acts;     /* HOST array of DEVICE pointers: saved activations [B, units[l]]      */
-    int32_t activation;           /* DCTR_ACT_LINEAR | RELU | SIGMOID | TANH                             */
+    int32_t activation;           /* DCTR_ACT_LINEAR | RELU | SIGMOID | TANH | DICE                      */
     int32_t pad_;
     const float* head_w;          /* [units[last]]                                                       */
     const float* dlogit;          /* [B]                                                                 */
@@ -454,9 +454,34 @@ typedef struct {
     const float* d_out;           /* headless form (head_w == NULL): [B, d_out_stride] gradient w.r.t. the last
                                      layer's activations (the DNN branch of DCN feeds a wider Dense(1))  */
     int64_t d_out_stride;
+    /* DCTR_ACT_DICE only (layers/activation.py:59-64 with the moving statistics): Dice is not invertible from its output,
+     * so the pre-activations are recomputed (one more GEMM per layer) from `biases` and the layer inputs. */
+    const float* const* biases;       /* HOST array of DEVICE pointers [out_l] (entries may be NULL), as in the forward */
+    const float* const* dice_alpha;   /* HOST arrays of DEVICE pointers [out_l]                           */
+    const float* const* dice_mean;
+    const float* const* dice_var;
+    float* const* d_dice_alpha;       /* accumulated; array or entries may be NULL                        */
+    float dice_eps;
+    int32_t pad2_;
 } dctr_mlp_bwd_args_t;
 size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
 int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
+
+/* DIN's LocalActivationUnit as a training step (layers/core.py:94-108, layers/sequence.py:261-298, att_weight_normalization
+ * = False): the attention input a[b*T+t, :] = [q_b, k_bt, q_b - k_bt, q_b * k_bt] ([B*T, 4*dim]) is materialised so that the
+ * unit's MLP runs through dctr_mlp_fwd (save_acts) / dctr_mlp_bwd; out[b,:] = sum_t (mask ? score : 0) k[b,t,:].
+ *   dctr_din_wsum_bwd:   d_score [B*T], dk [B,T,dim] WRITTEN (= masked score * d_out), d_bias += sum d_score (or NULL)
+ *   dctr_din_att_in_bwd: da [B*T, 4*dim] -> dk ADDED to, dq added into dx[b, qcol[e]] (qcol: DEVICE int32 [dim], the columns of
+ *                        the query embeddings inside the DNN input)
+ *   dctr_embed_lookup_bwd: g_table[row(idx[i]), :] += d_out[i, :dim] with the forward's id resolution (hash, range check) */
+int dctr_din_att_in_fwd(const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* a, void* stream);
+int dctr_din_wsum_fwd(const float* score, const uint8_t* mask, const float* k, int64_t batch, int32_t maxlen, int32_t dim,
+                      float* out, int64_t out_stride, void* stream);
+int dctr_din_wsum_bwd(const float* d_out, int64_t d_stride, const float* score, const uint8_t* mask, const float* k, int64_t batch,
+                      int32_t maxlen, int32_t dim, float* d_score, float* dk, float* d_bias, void* stream);
+int dctr_din_att_in_bwd(const float* da, const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* dk,
+                        float* dx, int64_t dx_stride, const int32_t* qcol, void* stream);
+int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, void* stream);
 
 /* backward of Dense(1, use_bias=False) on a strided [B, n] input: dx[b,:] = dlogit[b] * w (written), d_w += x^T dlogit. */
 int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, int32_t n, const float* w, const float* dlogit, float* dx,

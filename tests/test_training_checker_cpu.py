@@ -207,3 +207,28 @@ def test_torch_step_adds_the_l2_terms_and_applies_dropout_in_training_mode():
     training._fit_torch(model, feed0, staged0, torch.from_numpy(y), y, n, 0, n, 1, 0, False)
     np.testing.assert_allclose(table[1:].numpy(), (w0[1:] * (1 - 2 * 0.5)).numpy(), atol=1e-7)      # untouched rows: w - 2*l2*w = 0
     assert not np.allclose(table[0].numpy(), 0.0)
+
+
+def test_sample_level_shuffle_permutes_every_staged_tensor_consistently():
+    """fit(shuffle=True) permutes SAMPLES in place each epoch (tf.keras semantics): after permute_staged_ the restatement's
+    logits are the permuted logits, for a model with every feature kind; label-sorted data trains."""
+    from deepctr_amd import engine, training
+    from tests.test_gpu_models import build_model
+    g = load_golden("model_deepfm_mixed")
+    meta = golden_meta(g)
+    model = build_model(meta, torch.device("cpu"))
+    model.set_weights_by_name({k[2:]: v for k, v in g.items() if k.startswith("w/")})
+    feed = {k[5:]: v for k, v in g.items() if k.startswith("feed/")}
+    n = g["y"].shape[0]
+    staged = engine.Staged(n)
+    model._stage_inputs(feed, staged)
+    model._begin()
+    yt = torch.arange(n, dtype=torch.float32)
+    with torch.no_grad():
+        base = training.model_logits(model, staged, 0, n).clone()
+        perm = torch.from_numpy(np.random.RandomState(3).permutation(n))
+        training.permute_staged_(staged, yt, perm)
+        after = training.model_logits(model, staged, 0, n)
+    assert torch.equal(yt, perm.float())
+    ok = torch.isfinite(base[perm]) & (base[perm].abs() < 1e6)           # all-padding max rows are rounding noise (see tests above)
+    assert ok.sum() >= n // 2 and torch.allclose(after[ok], base[perm][ok], rtol=1e-5, atol=1e-6)
