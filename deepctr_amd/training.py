@@ -149,6 +149,17 @@ def dnn_forward(dnn, x, training=False):
     return x
 
 
+def frozen_weights(model):
+    """data_ptr()s of the tables built from SparseFeat(trainable=False) (reference inputs.py:25: ``emb.trainable =
+    feat.trainable``; docs FAQ "pretrained embeddings"): neither training path may touch them."""
+    out = set()
+    for embs in (getattr(model, "tables", None) or {}, getattr(model, "linear_tables", None) or {}):
+        for emb in embs.values():
+            if not getattr(emb, "trainable", True):
+                out.add(emb.embeddings.data_ptr())
+    return out
+
+
 def regularized_weights(model):
     """[(tensor, l2)] for every weight the reference attaches ``l2(l2_reg_*)`` to: embedding tables (inputs.py:22-41), the
     linear part (feature_column.py:171-210, layers/utils.py:142-158), DNN kernels (core.py:160-166), CrossNet / CrossNetMix
@@ -321,49 +332,102 @@ def permute_staged_(staged, yt, perm):
     yt.copy_(yt.index_select(0, perm))
 
 
-def _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle):
+def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
     """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
-    moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation."""
+    moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation.
+    The reported loss is the data loss (the l2 penalties enter the gradients, not this number)."""
     from .training_hip import HipTrainer
     tr = getattr(model, "_hip_trainer", None)
     if tr is None or tr.kind != model._compiled["optimizer"].lower():
         tr = model._hip_trainer = HipTrainer(model, model._compiled["optimizer"])
-    hist = History()
-    hist.history["loss"] = []
-    bs = int(batch_size) if batch_size else n_tr
-    if shuffle:
-        yt = yt.clone()                 # permuted in place below; never the caller's array
     for ep in range(epochs):
-        order = np.arange(0, n_tr, bs)
         if shuffle:
             permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
         tot = torch.zeros(1, dtype=torch.float64, device=model.device)
-        for lo in order:
+        for lo in range(0, n_tr, bs):
             hi = min(n_tr, lo + bs)
             model._begin()
             loss = tr.step(staged, int(lo), int(hi), yt[lo:hi])
             tot += loss.double() * (hi - lo)
         model._check_status()
-        hist.history["loss"].append(float(tot.item()) / max(n_tr, 1))
-        hist.epoch.append(ep)
-        if n_val:
-            va = {k: np.asarray(v)[n_tr:] for k, v in feed.items()}
-            hist.history.setdefault("val_loss", []).append(model.evaluate(va, y[n_tr:], batch_size=bs))
-        if verbose:
-            print("Epoch %d/%d - loss: %.4f%s" % (ep + 1, epochs, hist.history["loss"][-1],
-                                                  (" - val_loss: %.4f" % hist.history["val_loss"][-1]) if n_val else ""))
-    return hist
+        if epoch_end(ep, float(tot.item()) / max(n_tr, 1)):
+            break
+    return epoch_end.finish()
 
 
-def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, **kwargs):
+_FIT_UNSUPPORTED = ("sample_weight", "class_weight", "steps_per_epoch", "validation_steps", "initial_epoch")
+_FIT_IGNORED = ("workers", "use_multiprocessing", "max_queue_size", "validation_batch_size", "validation_freq")
+
+
+class _EpochEnd(object):
+    """What runs after every epoch of either training path: validation loss (validation_split rows, or ``validation_data``
+    as tf.keras.Model.fit takes it), the History record, the verbose line and the ``callbacks`` protocol the reference's
+    examples rely on (docs FAQ: EarlyStopping / ModelCheckpoint): ``on_epoch_end(epoch, logs)`` is called when present and
+    ``model.stop_training`` ends the loop.  Callback classes themselves are tf.keras' and out of scope: any object with
+    that method works."""
+
+    def __init__(self, model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks):
+        self.model, self.bs, self.epochs, self.verbose = model, bs, epochs, verbose
+        self.val = None
+        if validation_data is not None:
+            if len(validation_data) != 2:
+                raise NotImplementedError("fit(validation_data=...) takes (x_val, y_val); sample weights are not supported")
+            self.val = (validation_data[0], np.asarray(validation_data[1], dtype=np.float32).reshape(-1))
+        elif n_val:
+            self.val = ({k: np.asarray(v)[n_tr:] for k, v in feed.items()}, y[n_tr:])
+        self.callbacks = list(callbacks or [])
+        self.hist = History()
+        self.hist.history["loss"] = []
+        self.hist.model = model
+        model.stop_training = False
+        for cb in self.callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(model)
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin({})
+
+    def __call__(self, ep, loss):
+        h = self.hist
+        h.history["loss"].append(loss)
+        h.epoch.append(ep)
+        logs = {"loss": loss}
+        if self.val is not None:
+            logs["val_loss"] = self.model.evaluate(self.val[0], self.val[1], batch_size=self.bs)
+            h.history.setdefault("val_loss", []).append(logs["val_loss"])
+        if self.verbose:
+            print("Epoch %d/%d - loss: %.4f%s" % (ep + 1, self.epochs, loss,
+                                                  (" - val_loss: %.4f" % logs["val_loss"]) if "val_loss" in logs else ""))
+        for cb in self.callbacks:
+            if hasattr(cb, "on_epoch_end"):
+                cb.on_epoch_end(ep, logs)
+        return bool(getattr(self.model, "stop_training", False))
+
+    def finish(self):
+        for cb in self.callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end({})
+        return self.hist
+
+
+def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, validation_data=None,
+              callbacks=None, **kwargs):
     from . import _C
     _C.require_device()
     if model._compiled is None:
         raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+    for k, v in kwargs.items():
+        if k in _FIT_IGNORED:
+            continue
+        if k in _FIT_UNSUPPORTED:
+            if v is None or (k == "initial_epoch" and v == 0):
+                continue
+            raise NotImplementedError("fit(%s=...) is not implemented by this build (it would silently train on a different "
+                                      "objective if ignored)" % k)
+        raise TypeError("fit() got an unexpected keyword argument %r" % k)
     feed = model._as_feed(x)
     n = model._num_rows(feed)
     y = np.asarray(y, dtype=np.float32).reshape(-1)
-    n_val = int(n * validation_split)
+    n_val = 0 if validation_data is not None else int(n * validation_split)
     n_tr = n - n_val
     tr = {k: np.asarray(v)[:n_tr] for k, v in feed.items()}
     staged = model.stage(tr)
@@ -374,14 +438,19 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
             and model._compiled["optimizer"].lower() in training_hip.OPT_DEFAULTS and training_hip.supported(model)
             and ((loss_name0 in ("binary_crossentropy", "logloss") and model.task == "binary")
                  or (loss_name0 in ("mse", "mean_squared_error") and model.task != "binary"))):
-        return _fit_hip(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
-    return _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle)
+        fit = _fit_hip
+    else:
+        fit = _fit_torch
+    bs = int(batch_size) if batch_size else n_tr
+    return fit(model, staged, yt, n_tr, bs, epochs, shuffle,
+               _EpochEnd(model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks))
 
 
-def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verbose, shuffle):
+def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
     """fit() on torch autograd over ``model_logits`` (models / options outside the HIP step).  Device-agnostic torch code: the
     CPU suite drives it directly on CPU-built models; evaluate() of a validation split needs the GPU forward."""
-    params = [t for name, t in model.named_weights() if "moving_" not in name]
+    frozen = frozen_weights(model)
+    params = [t for name, t in model.named_weights() if "moving_" not in name and t.data_ptr() not in frozen]
     for t in params:
         t.requires_grad_(True)
     opt = model._compiled["optimizer"]
@@ -392,19 +461,13 @@ def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verb
     elif callable(opt):
         opt = opt(params)
     loss_name = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
-    hist = History()
-    hist.history["loss"] = []
-    bs = int(batch_size) if batch_size else n_tr
-    regs = regularized_weights(model)
-    if shuffle:
-        yt = yt.clone()                 # permuted in place below; never the caller's array
+    regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
     try:
         for ep in range(epochs):
-            order = np.arange(0, n_tr, bs)
             if shuffle:
                 permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
             tot, cnt = 0.0, 0
-            for lo in order:
+            for lo in range(0, n_tr, bs):
                 hi = min(n_tr, lo + bs)
                 model._begin()
                 logit = model_logits(model, staged, int(lo), int(hi), training=True)
@@ -420,19 +483,14 @@ def _fit_torch(model, feed, staged, yt, y, n_tr, n_val, batch_size, epochs, verb
                 opt.step()
                 tot += float(loss.item()) * (hi - lo)
                 cnt += hi - lo
-            hist.history["loss"].append(tot / max(cnt, 1))
-            hist.epoch.append(ep)
-            if n_val:
-                va = {k: np.asarray(v)[n_tr:] for k, v in feed.items()}
-                for t in params:
-                    t.requires_grad_(False)
-                hist.history.setdefault("val_loss", []).append(model.evaluate(va, y[n_tr:], batch_size=bs))
-                for t in params:
-                    t.requires_grad_(True)
-            if verbose:
-                print("Epoch %d/%d - loss: %.4f%s" % (ep + 1, epochs, hist.history["loss"][-1],
-                                                      (" - val_loss: %.4f" % hist.history["val_loss"][-1]) if n_val else ""))
+            for t in params:
+                t.requires_grad_(False)
+            stop = epoch_end(ep, tot / max(cnt, 1))
+            for t in params:
+                t.requires_grad_(True)
+            if stop:
+                break
     finally:
         for t in params:
             t.requires_grad_(False)
-    return hist
+    return epoch_end.finish()

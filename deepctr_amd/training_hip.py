@@ -71,6 +71,14 @@ class _Param(object):
         self.l2 = float(l2)
 
 
+class _Frozen(object):
+    """A weight that takes no part in training (Embedding.trainable == False): ``g`` is None = a NULL gradient table."""
+    __slots__ = ("w", "g", "l2")
+
+    def __init__(self, w):
+        self.w, self.g, self.l2 = w, None, 0.0
+
+
 # tf.keras defaults of the optimizers model.compile() takes by name (optimizer_v2/*.py)
 OPT_DEFAULTS = {"adam": dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7), "adagrad": dict(lr=1e-3, eps=1e-7, init_acc=0.1),
                 "rmsprop": dict(lr=1e-3, beta2=0.9, eps=1e-7), "sgd": dict(lr=1e-2)}
@@ -97,12 +105,23 @@ class HipTrainer(object):
         l2e, l2l, l2d = reg.get("embedding", 0.0), reg.get("linear", 0.0), reg.get("dnn", 0.0)
         self.params = []
         by_ptr = {}
+        # SparseFeat(trainable=False) (reference inputs.py:25: emb.trainable = feat.trainable; FAQ "pretrained embeddings"):
+        # a frozen table gets NO gradient buffer (the backward kernels skip NULL gradient tables), no optimizer segment and
+        # no l2 decay — fit() leaves it bit-identical
+        frozen = set()
+        for embs in (getattr(model, "tables", None) or {}, getattr(model, "linear_tables", None) or {}):
+            for emb in embs.values():
+                if not getattr(emb, "trainable", True):
+                    frozen.add(emb.embeddings.data_ptr())
 
         def param(t, l2=0.0):
             key = t.data_ptr()
             if key not in by_ptr:
-                by_ptr[key] = _Param(t, l2)
-                self.params.append(by_ptr[key])
+                if key in frozen:
+                    by_ptr[key] = _Frozen(t)
+                else:
+                    by_ptr[key] = _Param(t, l2)
+                    self.params.append(by_ptr[key])
             return by_ptr[key]
 
         # per field: (gradient table, gradient of the linear table).  Sequence features are pooled by dctr_embed_pool into
@@ -302,7 +321,8 @@ class HipTrainer(object):
                     biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None)
         ops.din_att_in_bwd(buf["d_att_in"], q, k, buf["dk"], dx, self.qcol)
         for (fc, idx, hm, col), pt in zip(bufs["key_lookups"], self.p_hist):
-            ops.embed_lookup_bwd(idx, tuple(pt.w.shape), hm, buf["dk"][:, :, col:], pt.g)
+            if pt.g is not None:                                   # frozen history table: no scatter
+                ops.embed_lookup_bwd(idx, tuple(pt.w.shape), hm, buf["dk"][:, :, col:], pt.g)
 
     def _nfm_forward_backward(self, ws, buf, y, binary):
         """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) | dense] -> Dense(1) + linear logit."""

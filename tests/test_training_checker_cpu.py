@@ -92,7 +92,8 @@ def test_torch_step_trains_the_models_outside_the_hip_step_on_cpu(kind):
     staged = engine.Staged(n)
     model._stage_inputs(feed, staged)
     before = {k: v.copy() for k, v in model.get_weights_by_name().items()}
-    h = training._fit_torch(model, feed, staged, torch.from_numpy(y), y, n, 0, 64, 6, 0, True)
+    h = training._fit_torch(model, staged, torch.from_numpy(y), n, 64, 6, True,
+                            training._EpochEnd(model, feed, y, n, 0, 64, 6, 0, None, None))
     assert len(h.history["loss"]) == 6 and h.history["loss"][-1] < h.history["loss"][0] - 0.01, h.history["loss"]
     after = model.get_weights_by_name()
     moved = [k for k in before if not np.array_equal(before[k], after[k])]
@@ -204,7 +205,8 @@ def test_torch_step_adds_the_l2_terms_and_applies_dropout_in_training_mode():
     model._stage_inputs(feed0, staged0)
     w0 = table.clone()
     model.compile(lambda params: torch.optim.SGD(params, lr=1.0), "binary_crossentropy")
-    training._fit_torch(model, feed0, staged0, torch.from_numpy(y), y, n, 0, n, 1, 0, False)
+    training._fit_torch(model, staged0, torch.from_numpy(y), n, n, 1, False,
+                        training._EpochEnd(model, feed0, y, n, 0, n, 1, 0, None, None))
     np.testing.assert_allclose(table[1:].numpy(), (w0[1:] * (1 - 2 * 0.5)).numpy(), atol=1e-7)      # untouched rows: w - 2*l2*w = 0
     assert not np.allclose(table[0].numpy(), 0.0)
 
@@ -232,3 +234,58 @@ def test_sample_level_shuffle_permutes_every_staged_tensor_consistently():
     assert torch.equal(yt, perm.float())
     ok = torch.isfinite(base[perm]) & (base[perm].abs() < 1e6)           # all-padding max rows are rounding noise (see tests above)
     assert ok.sum() >= n // 2 and torch.allclose(after[ok], base[perm][ok], rtol=1e-5, atol=1e-6)
+
+
+def test_frozen_embedding_and_fit_keyword_contract():
+    """SparseFeat(trainable=False) tables are bit-identical after fit() (reference inputs.py:25, docs FAQ "pretrained
+    embeddings"); unsupported fit() keywords raise instead of silently changing the objective; the callbacks protocol
+    (on_epoch_end / stop_training) is honoured."""
+    import pytest
+    from deepctr_amd import engine, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DCNMix
+    rng = np.random.RandomState(5)
+    n, E = 128, 4
+    cols = [SparseFeat("a", 20, E, trainable=False), SparseFeat("b", 9, E), DenseFeat("d", 2)]
+    model = DCNMix(cols, cols, cross_num=1, dnn_hidden_units=(8,), low_rank=2, num_experts=2, device=torch.device("cpu"))
+    feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 9, n), "d": rng.rand(n, 2).astype(np.float32)}
+    y = (feed["b"] % 2).astype(np.float32)
+    model.compile("adam", "binary_crossentropy")
+    staged = engine.Staged(n)
+    model._stage_inputs(feed, staged)
+    before = {k: v.copy() for k, v in model.get_weights_by_name().items()}
+    assert training.frozen_weights(model) == {model.tables["a"].embeddings.data_ptr(), model.linear_tables["a"].embeddings.data_ptr()}
+
+    class Stop(object):
+        def __init__(self):
+            self.seen = []
+
+        def on_epoch_end(self, epoch, logs):
+            self.seen.append((epoch, sorted(logs)))
+            if epoch == 1:
+                self.model.stop_training = True
+
+        def set_model(self, m):
+            self.model = m
+
+    cb = Stop()
+    h = training._fit_torch(model, staged, torch.from_numpy(y), n, 32, 5, True,
+                            training._EpochEnd(model, feed, y, n, 0, 32, 5, 0, None, [cb]))
+    assert len(h.history["loss"]) == 2 and cb.seen == [(0, ["loss"]), (1, ["loss"])]        # stopped after the second epoch
+    after = model.get_weights_by_name()
+    assert np.array_equal(before["sparse_emb_a/embeddings"], after["sparse_emb_a/embeddings"])
+    assert np.array_equal(before["linear0sparse_emb_a/embeddings"], after["linear0sparse_emb_a/embeddings"])
+    assert not np.array_equal(before["sparse_emb_b/embeddings"], after["sparse_emb_b/embeddings"])
+    for t in model.tables["a"].embeddings, model.linear_tables["a"].embeddings:
+        assert not t.requires_grad
+    # keyword contract of fit_model (checked before anything touches a device)
+    from deepctr_amd import _C
+    real = _C.require_device
+    _C.require_device = lambda: None
+    try:
+        with pytest.raises(NotImplementedError, match="sample_weight"):
+            training.fit_model(model, feed, y, sample_weight=np.ones(n))
+        with pytest.raises(TypeError, match="bogus"):
+            training.fit_model(model, feed, y, bogus=1)
+    finally:
+        _C.require_device = real
