@@ -44,6 +44,8 @@ struct MlpParams {
     const float* global_bias;
     float* y;
     int64_t y_stride;
+    const float* bn_scale[MAX_LAYERS];   // DNN(use_bn): per-column scale / shift between bias_add and the activation (or NULL)
+    const float* bn_shift[MAX_LAYERS];
     float* save[MAX_LAYERS];  // training: layer l's activations [B, units[l]] also go to HBM (NULL = inference)
     unsigned long long* probe;  // measurement aid (NULL normally): {min start, max end} wall-clock stamps of this launch
     int32_t lda;      // LDS row stride (floats) = pad64(max tile width) + 4
@@ -196,6 +198,8 @@ __device__ __forceinline__ void tile_epilogue(const MlpParams& p, int l, float* 
         const int n = n_base + TPW * j + c;
         if (n < N) {
             const float bv = p.bias[l] != nullptr ? p.bias[l][n] : 0.f;
+            const bool bn = p.bn_scale[l] != nullptr;
+            const float bsc = bn ? p.bn_scale[l][n] : 1.f, bsh = bn ? p.bn_shift[l][n] : 0.f;
             float al = 0.f, mu = 0.f, var = 1.f;
             if constexpr (ACT == DCTR_ACT_DICE) {
                 al = p.dice_alpha[l][n];
@@ -206,7 +210,9 @@ __device__ __forceinline__ void tile_epilogue(const MlpParams& p, int l, float* 
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = act_t<ACT>(acc[rt][c][r] + bv, al, mu, var, p.dice_eps);
+                    float z = acc[rt][c][r] + bv;
+                    if (bn) z = fmaf(z, bsc, bsh);              // keras: x * inv + (beta - mean * inv)
+                    const float v = act_t<ACT>(z, al, mu, var, p.dice_eps);
                     out[(rt * 16 + 4 * g + r) * p.lda + lds_pos(n, KQn)] = v;
                     if (sv != nullptr) {
                         const int64_t b = row0 + rt * 16 + 4 * g + r;

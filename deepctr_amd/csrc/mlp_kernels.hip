@@ -79,6 +79,12 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         }
     }
     for (int l = 0; l < a->n_layers; ++l) p.save[l] = a->save_acts != nullptr ? a->save_acts[l] : nullptr;
+    DCTR_REQUIRE((a->bn_scale == nullptr) == (a->bn_shift == nullptr), DCTR_E_NULL, "mlp_fwd: bn_scale and bn_shift go together");
+    for (int l = 0; l < a->n_layers; ++l) {
+        p.bn_scale[l] = a->bn_scale != nullptr ? a->bn_scale[l] : nullptr;
+        p.bn_shift[l] = a->bn_shift != nullptr ? a->bn_shift[l] : nullptr;
+        DCTR_REQUIRE((p.bn_scale[l] == nullptr) == (p.bn_shift[l] == nullptr), DCTR_E_NULL, "mlp_fwd: bn_scale[%d] / bn_shift[%d]", l, l);
+    }
     p.probe = a->probe;
     p.dice_eps = a->dice_eps;
     p.activation = a->activation;

@@ -580,10 +580,20 @@ class EmbeddingStage(object):
 # Model
 # ---------------------------------------------------------------------------------------------------
 # keras layer names of BatchNormalization layers that live inside Dice -> this build's Dice layer names
-def _alias(name):
-    if name.startswith("batch_normalization"):
-        return "dice" + name[len("batch_normalization"):]
-    return name
+def _bn_aliases(layers):
+    """{keras name of the BatchNormalization inside a Dice layer: that Dice layer's name}.  The names come from the auto-name
+    counter keras shares between Dice's BatchNormalization and the BatchNormalization layers of DNN(use_bn=True)."""
+    out = {}
+
+    def walk(layer):
+        bn = getattr(layer, "bn_name", None)
+        if bn is not None:
+            out[bn] = layer.name
+        for sub in getattr(layer, "_sublayers", ()):
+            walk(sub)
+    for layer in layers:
+        walk(layer)
+    return out
 
 
 def _h5py():
@@ -707,9 +717,10 @@ class Model(object):
         under their keras names (``batch_normalization/moving_mean``)."""
         mine = OrderedDict(self.named_weights())
         seen = set()
+        alias = _bn_aliases(self.layers)
         for key, val in mapping.items():
             lname, wname = key.rsplit("/", 1)
-            k2 = "%s/%s" % (_alias(lname), wname)
+            k2 = "%s/%s" % (alias.get(lname, lname) if wname in ("moving_mean", "moving_variance") else lname, wname)
             if k2 not in mine:
                 if strict and not (lname.startswith("linearsparse_")):   # dangling tables the reference never uses
                     raise KeyError("no weight named %r in model %s" % (key, self.name))

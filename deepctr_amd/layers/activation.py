@@ -14,6 +14,10 @@ class Dice(Layer):
 
     def build(self, input_shape):
         n = int(input_shape[-1])
+        # keras creates Dice's BatchNormalization here (activation.py:51-53); its auto-name shares the counter with the
+        # BatchNormalization layers of DNN(use_bn=True).  The statistics live on this layer; `bn_name` is the keras name.
+        from .base import next_auto_name
+        self.bn_name = next_auto_name("batch_normalization")
         self.add_weight('dice_alpha', (n,), Zeros())
         self.add_weight('moving_mean', (n,), Zeros())
         self.add_weight('moving_variance', (n,), Ones())

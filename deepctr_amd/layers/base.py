@@ -23,6 +23,14 @@ def name_scope():
         _NAME_COUNTS.pop()
 
 
+def next_auto_name(base):
+    """The next keras-style auto name for `base` in the current name scope (base, base_1, base_2, ...)."""
+    counts = _NAME_COUNTS[-1]
+    n = counts.get(base, 0)
+    counts[base] = n + 1
+    return base if n == 0 else "%s_%d" % (base, n)
+
+
 def _snake(name):
     s = re.sub("(.)([A-Z][a-z0-9]+)", r"\1_\2", name)
     s = re.sub("([a-z])([A-Z])", r"\1_\2", s).lower()

@@ -5,9 +5,53 @@ logits and the PredictionLayer into the same launch."""
 import torch
 
 from .. import ops
-from ..initializers import GlorotNormal, Zeros
+from ..initializers import GlorotNormal, Ones, Zeros
 from .activation import SUPPORTED, Dice
 from .base import Layer
+
+
+class BatchNormalization(Layer):
+    """tf.keras.layers.BatchNormalization as DNN(use_bn=True) builds it (reference layers/core.py:176-177: default
+    arguments -> axis=-1, momentum=0.99, epsilon=1e-3, center and scale).  Inference form only on the HIP path: a per-column
+    scale / shift that ``dctr_mlp_fwd`` applies between bias_add and the activation (``dctr_mlp_args_t.bn_scale``)."""
+
+    def __init__(self, axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True, **kwargs):
+        self.axis, self.momentum, self.epsilon, self.center, self.scale = axis, momentum, epsilon, center, scale
+        super(BatchNormalization, self).__init__(**kwargs)
+
+    def build(self, input_shape):
+        n = int(input_shape[-1])
+        if self.scale:
+            self.add_weight('gamma', (n,), Ones())
+        if self.center:
+            self.add_weight('beta', (n,), Zeros())
+        self.add_weight('moving_mean', (n,), Zeros())
+        self.add_weight('moving_variance', (n,), Ones())
+        super(BatchNormalization, self).build(input_shape)
+
+    def scale_shift(self):
+        """(inv, off) with y = x * inv + off, computed as keras' inference path does (tf.nn.batch_normalization):
+        inv = rsqrt(var + eps) [* gamma]; off = [beta] - mean * inv."""
+        with torch.no_grad():
+            inv = torch.rsqrt(self.w('moving_variance') + self.epsilon)
+            if self.scale:
+                inv = inv * self.w('gamma')
+            off = -self.w('moving_mean') * inv
+            if self.center:
+                off = self.w('beta') + off
+            # persistent buffers, refreshed IN PLACE: marshalled launch arguments keep pointing at them
+            if getattr(self, "_inv", None) is None:
+                self._inv, self._off = inv.contiguous().clone(), off.contiguous().clone()
+            else:
+                self._inv.copy_(inv)
+                self._off.copy_(off)
+        return self._inv, self._off
+
+    def get_config(self):
+        base = super(BatchNormalization, self).get_config()
+        base.update({'axis': self.axis, 'momentum': self.momentum, 'epsilon': self.epsilon, 'center': self.center,
+                     'scale': self.scale})
+        return base
 
 
 class DNN(Layer):
@@ -21,12 +65,13 @@ class DNN(Layer):
         self.output_activation = output_activation
         self.seed = seed
         super(DNN, self).__init__(**kwargs)
-        if use_bn:
-            raise NotImplementedError("DNN(use_bn=True) is outside the MI355X hot-path scope (SURVEY.md §8)")
-        if output_activation not in (None, activation):
-            raise NotImplementedError("DNN(output_activation != activation) is outside the hot-path scope")
-        if isinstance(activation, str) and activation not in SUPPORTED:
-            raise ValueError("Invalid activation,found %s.You should use a str or a Activation Layer Class." % (activation,))
+        for a_ in (activation, output_activation):
+            if isinstance(a_, str) and a_ not in SUPPORTED:
+                raise ValueError("Invalid activation,found %s.You should use a str or a Activation Layer Class." % (a_,))
+
+    def layer_activation(self, i):
+        """reference core.py:181-184: the last layer takes ``output_activation`` when one is given."""
+        return self.output_activation if (i == len(self.hidden_units) - 1 and self.output_activation) else self.activation
 
     def build(self, input_shape):
         input_size = int(input_shape[-1])
@@ -35,14 +80,26 @@ class DNN(Layer):
             self.add_weight('kernel' + str(i), (hidden_units[i], hidden_units[i + 1]), GlorotNormal(seed=self.seed))
         for i in range(len(self.hidden_units)):
             self.add_weight('bias' + str(i), (self.hidden_units[i],), Zeros())
-        self.dice_layers = []
-        if self.activation in ("dice", "Dice"):
+        # keras creates the BatchNormalization layers here, before the activation layers (core.py:176-184): the auto-name
+        # counter ("batch_normalization", "batch_normalization_1", ...) is shared with the BatchNormalization inside Dice
+        self.bn_layers = []
+        if self.use_bn:
             for i in range(len(self.hidden_units)):
-                d = Dice()
-                d.build((None, self.hidden_units[i]))
-                d.built = True
+                b = BatchNormalization(device=self.device)
+                b.build((None, self.hidden_units[i]))
+                b.built = True
+                self.bn_layers.append(b)
+                self._sublayers.append(b)
+        self.dice_layers = []
+        if any(self.layer_activation(i) in ("dice", "Dice") for i in range(len(self.hidden_units))):
+            for i in range(len(self.hidden_units)):
+                d = None
+                if self.layer_activation(i) in ("dice", "Dice"):
+                    d = Dice(device=self.device)
+                    d.build((None, self.hidden_units[i]))
+                    d.built = True
+                    self._sublayers.append(d)
                 self.dice_layers.append(d)
-                self._sublayers.append(d)
         super(DNN, self).build(input_shape)
 
     def build_for(self, input_size):
@@ -60,7 +117,19 @@ class DNN(Layer):
         return [self.w('bias%d' % i) for i in range(len(self.hidden_units))]
 
     def dice_params(self):
-        return [d.params() for d in self.dice_layers] if self.dice_layers else None
+        if not self.dice_layers:
+            return None
+        if any(d is None for d in self.dice_layers):
+            raise NotImplementedError("Dice on some layers only (output_activation) takes the layer-by-layer path: DNN.call")
+        return [d.params() for d in self.dice_layers]
+
+    def bn_params(self):
+        """[(scale, shift)] per layer for dctr_mlp_fwd, from the CURRENT BatchNormalization weights; None without use_bn."""
+        return [b.scale_shift() for b in self.bn_layers] if self.bn_layers else None
+
+    @property
+    def uniform_activation(self):
+        return not self.output_activation or self.output_activation == self.activation
 
     def call(self, inputs, training=None, **kwargs):
         if training and self.dropout_rate > 0:
@@ -69,7 +138,17 @@ class DNN(Layer):
         x2 = inputs.reshape(-1, inputs.shape[-1])
         if len(self.hidden_units) == 0:
             return inputs
-        y = ops.mlp(x2, self.kernels, self.biases, self.activation, dice=self.dice_params())
+        bn = self.bn_params()
+        if self.uniform_activation:
+            y = ops.mlp(x2, self.kernels, self.biases, self.activation, dice=self.dice_params(), bn=bn)
+        else:                                  # output_activation differs: the last layer is its own launch
+            n = len(self.hidden_units)
+            y = x2
+            for lo, hi in ((0, n - 1), (n - 1, n)):
+                if hi > lo:
+                    act = self.layer_activation(lo)
+                    dice = [self.dice_layers[i].params() for i in range(lo, hi)] if act in ("dice", "Dice") else None
+                    y = ops.mlp(y, self.kernels[lo:hi], self.biases[lo:hi], act, dice=dice, bn=None if bn is None else bn[lo:hi])
         return y.reshape(*lead, self.hidden_units[-1])
 
     def compute_output_shape(self, input_shape):

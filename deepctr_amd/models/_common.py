@@ -63,6 +63,9 @@ class FeatureModel(Model):
 
     def _begin(self):
         self.stage_plan.refresh(self.linear.w('linear_kernel') if self.linear is not None else None)
+        dnn = getattr(self, "dnn", None)
+        if dnn is not None and getattr(dnn, "bn_layers", None):
+            dnn.bn_params()             # BatchNormalization scale / shift follow the current weights (in place)
 
     def _check_status(self):
         ops.check_status(self.stage_plan.status(), "embedding lookup in model %s" % self.name)

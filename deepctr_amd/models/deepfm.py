@@ -63,7 +63,7 @@ class _DeepFM(FeatureModel):
             if len(self._fast) > 8:
                 self._fast.clear()
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
-            m, keep = ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+            m, keep = ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                               head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
                               sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out, gather=g, batch=B, launch=False)
             c = self._fast[B] = (g, m, keep, ws)
@@ -119,7 +119,7 @@ class _DeepFM(FeatureModel):
             ws = sp.run_pools(staged, lo, hi)
             sp.run_lin_only(staged, lo, hi, ws)
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
-            ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+            ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                     head_w=self.dense.w('kernel'), add=[ws["lin2"]] if "lin2" in ws else [],
                     global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
                     out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
@@ -130,7 +130,7 @@ class _DeepFM(FeatureModel):
         if self.stage_plan.fm_group_names:
             add.append(ws["fm"])
             add.extend(ws["fm_extra"])
-        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                 head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
                 sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out, tile_rows=self.tile_rows)
 

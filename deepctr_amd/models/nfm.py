@@ -38,7 +38,7 @@ class _NFM(FeatureModel):
         ws = sp.run(staged, lo, hi)
         off = sp.extra_offsets["bi_interaction"]                # [.. embeddings .. | bi (E) | dense ..]
         ops.bi_interaction(ws["dnn_in"], fields=self.n_emb, dim=self.emb_dim, out=ws["dnn_in"][:, off:])
-        ops.mlp(ws["dnn_in"][:, off:], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+        ops.mlp(ws["dnn_in"][:, off:], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                 head_w=self.dense.w('kernel'), add=self._logits_to_add(ws), global_bias=self.prediction.w('global_bias'),
                 sigmoid_out=self.task == "binary", in_dim=self.dnn_in_dim, out=out)
 

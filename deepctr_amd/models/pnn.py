@@ -49,7 +49,7 @@ class _PNN(FeatureModel):
         if self.use_inner:
             off = sp.extra_offsets["inner_product"]
             ops.inner_product(ws["dnn_in"], True, fields=self.n_emb, dim=self.emb_dim, out=ws["dnn_in"][:, off:])
-        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                 head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
                 sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out)
 

@@ -76,7 +76,7 @@ class _DIN(FeatureModel):
         bufs = self._attention_inputs(staged, lo, hi, ws)
         hist_off = sp.extra_offsets["hist"]
         self.attention.run(bufs["q"], bufs["k"], bufs["m"], out=ws["dnn_in"][:, hist_off:], out_stride=sp.out_stride)
-        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                 head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
                 sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out)
 

@@ -53,7 +53,7 @@ class _xDeepFM(FeatureModel):
                     dim=self.cin_dim, out=maps)
             ops.mlp(maps, [], [], "linear", head_w=self.dense_1.w('kernel'), in_dim=self.cin_out_dim, out=logit)
             add.append(logit)
-        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(),
+        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                 head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
                 sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out)
 

@@ -454,10 +454,12 @@ def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
         sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
-        tile_rows=0, save_acts=None, probe=None, launch=True):
+        tile_rows=0, save_acts=None, probe=None, launch=True, bn=None):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
+    ``bn`` = list of (scale, shift) per layer (or None) for DNN(use_bn=True): inference BatchNormalization between bias_add
+    and the activation, see dctr_mlp_args_t.bn_scale.
     ``tile_rows`` (0 = auto, 16, 32, 64) is the batch rows per workgroup — a throughput/latency knob, same bits."""
     _dev_check(x, *kernels, *biases)
     if gather is None:
@@ -507,6 +509,11 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    tile_rows=int(tile_rows))
     if probe is not None:               # measurement aid: uint64[2] {min start, max end} wall-clock stamps (dctr.h)
         a.probe = probe.data_ptr()
+    if bn is not None and n > 0 and any(b_ is not None for b_ in bn):
+        bsc = _ptr_array([None if b_ is None else _f32c(b_[0], "bn_scale") for b_ in bn])
+        bsh = _ptr_array([None if b_ is None else _f32c(b_[1], "bn_shift") for b_ in bn])
+        keep.append((bsc, bsh, bn))
+        a.bn_scale, a.bn_shift = ctypes.cast(bsc, ctypes.c_void_p), ctypes.cast(bsh, ctypes.c_void_p)
     if save_acts is not None:           # training: layer outputs [B, units[l]] also go to HBM (dctr_mlp_bwd reads them)
         sa = _ptr_array(list(save_acts))
         keep.append(sa)

@@ -141,10 +141,38 @@ def _dropout(x, rate, training):
     return torch.nn.functional.dropout(x, float(rate), True) if training and rate and rate > 0 else x
 
 
+def _batch_norm(bn, x, training):
+    """tf.keras BatchNormalization(axis=-1) as DNN(use_bn=True) calls it (layers/core.py:200-201): training mode normalises
+    with the batch statistics (biased variance, gradients through them) and moves the stored statistics with the layer's
+    momentum; inference mode uses the stored statistics."""
+    mean, var = bn.w("moving_mean"), bn.w("moving_variance")
+    if training:
+        dims = tuple(range(x.dim() - 1))
+        bm = x.mean(dim=dims)
+        bv = x.var(dim=dims, unbiased=False)
+        with torch.no_grad():
+            mean.mul_(bn.momentum).add_(bm.detach(), alpha=1.0 - bn.momentum)
+            var.mul_(bn.momentum).add_(bv.detach(), alpha=1.0 - bn.momentum)
+        mean, var = bm, bv
+    inv = torch.rsqrt(var + bn.epsilon)
+    if bn.scale:
+        inv = inv * bn.w("gamma")
+    off = -mean * inv
+    if bn.center:
+        off = bn.w("beta") + off
+    return x * inv + off
+
+
 def dnn_forward(dnn, x, training=False):
-    dice = dnn.dice_params()
+    dice_layers = getattr(dnn, "dice_layers", None) or []
+    bn_layers = getattr(dnn, "bn_layers", None) or []
     for i, (w, b) in enumerate(zip(dnn.kernels, dnn.biases)):
-        x = _act(dnn.activation, x @ w + b, dice[i] if dice else None, training)
+        x = x @ w + b
+        if bn_layers:
+            x = _batch_norm(bn_layers[i], x, training)
+        act = dnn.layer_activation(i) if hasattr(dnn, "layer_activation") else dnn.activation
+        d = dice_layers[i].params() if (dice_layers and dice_layers[i] is not None) else None
+        x = _act(act, x, d, training)
         x = _dropout(x, getattr(dnn, "dropout_rate", 0), training)             # layers/core.py:204-205
     return x
 

@@ -330,6 +330,11 @@ typedef struct {
                                      wall clock (dctr_wall_clock_khz()), so probe[1] - probe[0] is this launch's duration
                                      even inside a hipGraph, where event pairs cannot be attached.  Caller initialises
                                      to {UINT64_MAX, 0}. */
+    const float* const* bn_scale; /* DNN(use_bn=True), inference form of keras BatchNormalization between bias_add and the
+                                     activation (layers/core.py:200-201): HOST arrays [n_layers] of DEVICE pointers (entries or
+                                     the arrays may be NULL = no BN on that layer): y = act((x W + b) * bn_scale + bn_shift) with
+                                     bn_scale = gamma * rsqrt(moving_variance + epsilon), bn_shift = beta - moving_mean * bn_scale */
+    const float* const* bn_shift;
 } dctr_mlp_args_t;
 size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
 int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);

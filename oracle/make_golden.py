@@ -51,6 +51,8 @@ def weight_hook(layer, wname, default):
         return rng.standard_normal(shape) * 0.1
     if wname == "dice_alpha":
         return rng.standard_normal(shape) * 0.3
+    if wname == "gamma":
+        return 1.0 + rng.standard_normal(shape) * 0.2
     std = float(default.std())
     if std == 0:
         std = 0.1
@@ -438,6 +440,10 @@ def gen_criteo_sample():
     S.reset()
     h = Hash(1000, mask_zero=False)(T(toks.astype(object).reshape(-1, 1))).a.reshape(-1)
     _save("criteo_tokens", tokens=np.array([t.encode() for t in toks], dtype="S16"), hash_nb1000=h)
+    # the 200-row DATA file itself (not source code), so that the example flow can run from the CSV on the GPU box,
+    # where /root/reference does not exist (tests/test_gpu_facade.py)
+    import shutil
+    shutil.copyfile(os.path.join(REF, "examples", "criteo_sample.txt"), os.path.join(GOLDEN, "criteo_sample.txt"))
 
 
 def _run_pnn(name, spec_dnn, feed, kwargs):
@@ -511,11 +517,64 @@ def gen_siblings():
     _save("crossnet_mix", **out)
 
 
+def gen_bn():
+    """dnn_use_bn=True on the four in-scope constructors (deepfm.py:24,58, dcn.py:24,60, xdeepfm.py:21,56, din.py:21,90:
+    keras BatchNormalization between bias_add and the activation, layers/core.py:176-177,200-201) and
+    DNN(output_activation=...) at layer level (:181-184)."""
+    from deepctr.layers.core import DNN
+    rng = np.random.RandomState(23)
+    B = 16
+    spec = mixed_spec(4, False)
+    feed = _feed_for(spec, B, rng)
+    _run_model("model_deepfm_bn", "deepctr.models.deepfm", "DeepFM", spec, spec, feed,
+               {"dnn_hidden_units": [16, 8], "dnn_use_bn": True})
+    _run_model("model_dcn_bn", "deepctr.models.dcn", "DCN", spec, spec, feed,
+               {"cross_num": 2, "cross_parameterization": "vector", "dnn_hidden_units": [8, 4], "dnn_use_bn": True})
+    _run_model("model_xdeepfm_bn", "deepctr.models.xdeepfm", "xDeepFM", spec, spec, feed,
+               {"dnn_hidden_units": [8, 4], "cin_layer_size": [8, 6], "cin_split_half": True, "dnn_use_bn": True})
+    fixed = [d for d in mixed_spec(16, False) if d["type"] != "varlen"]
+    feed_f = _feed_for(fixed, 80, rng)
+    _run_model("model_deepfm_bn_fixed", "deepctr.models.deepfm", "DeepFM", fixed, fixed, feed_f,
+               {"dnn_hidden_units": [32, 16], "dnn_use_bn": True, "dnn_activation": "tanh"})
+    E, T_, n = 8, 6, 24
+    sp = lambda nme, v, **kw: dict(type="sparse", name=nme, vocabulary_size=v, embedding_dim=E, **kw)  # noqa: E731
+    spec_d = [sp("user", 30), sp("item_id", 41), sp("cate_id", 11), dict(type="dense", name="pay_score", dimension=1),
+              dict(type="varlen", sparsefeat=sp("hist_item_id", 41, embedding_name="item_id"), maxlen=T_),
+              dict(type="varlen", sparsefeat=sp("hist_cate_id", 11, embedding_name="cate_id"), maxlen=T_)]
+    lens = rng.randint(1, T_ + 1, n)
+    hi = rng.randint(1, 41, (n, T_)).astype(np.int32)
+    hc = rng.randint(1, 11, (n, T_)).astype(np.int32)
+    pad = np.arange(T_)[None, :] >= lens[:, None]
+    hi[pad] = 0
+    hc[pad] = 0
+    feed_d = {"user": rng.randint(0, 30, n).astype(np.int32), "item_id": rng.randint(1, 41, n).astype(np.int32),
+              "cate_id": rng.randint(1, 11, n).astype(np.int32), "pay_score": rng.rand(n).astype(np.float32),
+              "hist_item_id": hi, "hist_cate_id": hc}
+    for act in ("dice", "sigmoid"):        # dice: the attention unit's BatchNormalization layers come first in keras' naming
+        _run_model("model_din_bn_" + act, "deepctr.models.sequence.din", "DIN", [], spec_d, feed_d,
+                   {"dnn_hidden_units": [16, 8], "att_hidden_size": [12, 6], "att_activation": act, "dnn_use_bn": True},
+                   extra_args=(["item_id", "cate_id"],))
+    # layer level: DNN with use_bn and an output activation that differs from the hidden one
+    S.reset()
+    x = (rng.standard_normal((9, 7)) * 0.8).astype(np.float32)
+    for name, kw in (("relu_sigmoid_bn", dict(activation="relu", output_activation="sigmoid", use_bn=True)),
+                     ("tanh_linear", dict(activation="tanh", output_activation="linear", use_bn=False))):
+        S.reset()
+        layer = DNN((6, 5, 3), seed=3, **kw)
+        y = layer(T(x)).a
+        arrays = {"x": x, "y": np.asarray(y, np.float32)}
+        for k, v in _weights_dict().items():
+            arrays["w/" + k] = v
+        _save("dnn_" + name, **arrays)
+
+
 def main():
     S.install(REF)
     S.WEIGHT_HOOK = weight_hook
     if len(sys.argv) > 1 and sys.argv[1] == "siblings":      # add-on fixtures only (the others stay byte-identical)
         return gen_siblings()
+    if len(sys.argv) > 1 and sys.argv[1] == "bn":
+        return gen_bn()
     gen_hash()
     gen_interaction()
     gen_sequence()
@@ -523,6 +582,7 @@ def main():
     gen_models()
     gen_criteo_sample()
     gen_siblings()
+    gen_bn()
 
 
 if __name__ == "__main__":

@@ -144,14 +144,24 @@ def _combined_dnn_input(emb_list, dense_list):
     return np.concatenate(parts, axis=-1)
 
 
-def _dnn(prefix, x, weights, dt, activation="relu"):
+def _bn_name(k):
+    return "batch_normalization" if k == 0 else "batch_normalization_%d" % k
+
+
+def _dnn(prefix, x, weights, dt, activation="relu", use_bn=False, bn_first=0):
+    """``use_bn``: the DNN's BatchNormalization layers are keras' ``batch_normalization[_k]`` with k = bn_first + layer
+    (the auto-name counter is shared with the BatchNormalization inside every Dice built before this DNN)."""
     ks, bs = [], []
     i = 0
     while "%s/kernel%d" % (prefix, i) in weights:
         ks.append(weights["%s/kernel%d" % (prefix, i)].astype(dt))
         bs.append(weights["%s/bias%d" % (prefix, i)].astype(dt))
         i += 1
-    return R.dnn(x, ks, bs, activation)
+    bn = None
+    if use_bn:
+        bn = [tuple(weights["%s/%s" % (_bn_name(bn_first + j), w)].astype(dt) for w in ("gamma", "beta", "moving_mean", "moving_variance"))
+              for j in range(i)]
+    return R.dnn(x, ks, bs, activation, bn_params=bn)
 
 
 def _add(*logits):
@@ -164,13 +174,13 @@ def _add(*logits):
 
 
 def deepfm(linear_cols, dnn_cols, weights, feed, fm_group=("default_group",), dnn_activation="relu",
-           task="binary", dtype=np.float32, **_):
+           task="binary", dtype=np.float32, dnn_use_bn=False, **_):
     dt = np.dtype(dtype).type
     lin = linear_logit(linear_cols, feed, weights, dt)
     groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
     fm_logits = [R.fm(np.concatenate(v, axis=1)) for k, v in groups.items() if k in fm_group]   # deepfm.py:53-54
     dnn_in = _combined_dnn_input([e for g in groups.values() for e in g], dense)
-    dnn_out = _dnn("dnn", dnn_in, weights, dt, dnn_activation)
+    dnn_out = _dnn("dnn", dnn_in, weights, dt, dnn_activation, dnn_use_bn)
     dnn_logit = dnn_out @ weights["dense/kernel"].astype(dt)
     final = _add(lin, dnn_logit, *fm_logits)
     return R.prediction_layer(final, weights["prediction_layer/global_bias"].astype(dt), task)
@@ -247,7 +257,7 @@ def nfm(linear_cols, dnn_cols, weights, feed, dnn_activation="relu", task="binar
 
 
 def dcn(linear_cols, dnn_cols, weights, feed, cross_num=2, cross_parameterization="vector",
-        dnn_hidden_units=(256, 128, 64), dnn_activation="relu", task="binary", dtype=np.float32, **_):
+        dnn_hidden_units=(256, 128, 64), dnn_activation="relu", task="binary", dtype=np.float32, dnn_use_bn=False, **_):
     dt = np.dtype(dtype).type
     lin = linear_logit(linear_cols, feed, weights, dt)
     groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
@@ -258,7 +268,7 @@ def dcn(linear_cols, dnn_cols, weights, feed, cross_num=2, cross_parameterizatio
         bs = [weights["cross_net/bias%d" % i].astype(dt) for i in range(cross_num)]
         outs.append(R.crossnet(dnn_in, ks, bs, cross_parameterization))
     if len(dnn_hidden_units) > 0:
-        outs.append(_dnn("dnn", dnn_in, weights, dt, dnn_activation))
+        outs.append(_dnn("dnn", dnn_in, weights, dt, dnn_activation, dnn_use_bn))
     stack = np.concatenate(outs, axis=-1)                          # Concatenate()([cross_out, deep_out]) dcn.py:61
     final = _add(stack @ weights["dense/kernel"].astype(dt), lin)
     return R.prediction_layer(final, weights["prediction_layer/global_bias"].astype(dt), task)
@@ -291,13 +301,13 @@ def dcnmix(linear_cols, dnn_cols, weights, feed, cross_num=2, dnn_hidden_units=(
 
 
 def xdeepfm(linear_cols, dnn_cols, weights, feed, cin_layer_size=(128, 128), cin_split_half=True,
-            cin_activation="relu", dnn_activation="relu", task="binary", dtype=np.float32, **_):
+            cin_activation="relu", dnn_activation="relu", task="binary", dtype=np.float32, dnn_use_bn=False, **_):
     dt = np.dtype(dtype).type
     lin = linear_logit(linear_cols, feed, weights, dt)
     groups, dense = _embed_groups(dnn_cols, feed, weights, "", dt)
     emb_list = [e for g in groups.values() for e in g]
     dnn_in = _combined_dnn_input(emb_list, dense)
-    dnn_logit = _dnn("dnn", dnn_in, weights, dt, dnn_activation) @ weights["dense/kernel"].astype(dt)
+    dnn_logit = _dnn("dnn", dnn_in, weights, dt, dnn_activation, dnn_use_bn) @ weights["dense/kernel"].astype(dt)
     final = _add(lin, dnn_logit)
     if len(cin_layer_size) > 0:
         fs = [weights["cin/filter%d" % i].astype(dt) for i in range(len(cin_layer_size))]
@@ -308,7 +318,7 @@ def xdeepfm(linear_cols, dnn_cols, weights, feed, cin_layer_size=(128, 128), cin
 
 
 def din(dnn_cols, history_feature_list, weights, feed, dnn_activation="relu", att_hidden_size=(80, 40),
-        att_activation="dice", att_weight_normalization=False, task="binary", dtype=np.float32, **_):
+        att_activation="dice", att_weight_normalization=False, task="binary", dtype=np.float32, dnn_use_bn=False, **_):
     dt = np.dtype(dtype).type
     tables = _table_names(dnn_cols, "")
     sparse = [fc for fc in dnn_cols if _is_sparse(fc)]
@@ -374,6 +384,8 @@ def din(dnn_cols, history_feature_list, weights, feed, dnn_activation="relu", at
                                         att_activation, dice_params, att_weight_normalization)  # din.py:83-85
     deep = np.concatenate([np.concatenate(dnn_emb, axis=-1), hist], axis=-1)                    # din.py:87
     dnn_in = _combined_dnn_input([deep.reshape(deep.shape[0], 1, -1)], dense)                   # din.py:88-89
-    out = _dnn("dnn_1", dnn_in, weights, dt, dnn_activation)
+    # the attention unit's Dice layers were built first: their BatchNormalization took batch_normalization .. _{n_att-1}
+    bn_first = n_att if att_activation in ("dice", "Dice") else 0
+    out = _dnn("dnn_1", dnn_in, weights, dt, dnn_activation, dnn_use_bn, bn_first)
     final = out @ weights["dense/kernel"].astype(dt)
     return R.prediction_layer(final, weights["prediction_layer/global_bias"].astype(dt), task)

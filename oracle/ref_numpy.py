@@ -265,13 +265,24 @@ def dice(x, alpha, moving_mean, moving_variance, epsilon=1e-9):
     return alpha.astype(dt) * (dt.type(1) - xp) * x + xp * x
 
 
-def dnn(x, kernels, biases, activation="relu", dice_params=None, output_activation=None):
-    """reference layers/core.py:189-208 (use_bn=False, dropout inactive at inference).
-    ``dice_params[i] = (alpha, moving_mean, moving_variance)`` when activation == 'dice'."""
+def batch_norm_inference(x, gamma, beta, mean, var, eps=1e-3):
+    """tf.keras BatchNormalization (defaults: epsilon 1e-3, center, scale) at inference = tf.nn.batch_normalization:
+    inv = rsqrt(var + eps) * gamma;  y = x * inv + (beta - mean * inv)."""
+    t = x.dtype.type
+    inv = t(1) / np.sqrt(var + t(eps)) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def dnn(x, kernels, biases, activation="relu", dice_params=None, output_activation=None, bn_params=None):
+    """reference layers/core.py:189-208 (dropout inactive at inference).
+    ``dice_params[i] = (alpha, moving_mean, moving_variance)`` when activation == 'dice';
+    ``bn_params[i] = (gamma, beta, moving_mean, moving_variance)`` with use_bn (:200-201, between bias_add and activation)."""
     h = np.asarray(x)
     n = len(kernels)
     for i, (w, b) in enumerate(zip(kernels, biases)):
         h = np.tensordot(h, w, axes=(-1, 0)) + b                   # :193-194
+        if bn_params is not None:
+            h = batch_norm_inference(h, *bn_params[i])             # :200-201
         act = output_activation if (i == n - 1 and output_activation) else activation   # core.py:182-185
         if act in ("dice", "Dice"):
             a, mu, var = dice_params[i]

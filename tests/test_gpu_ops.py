@@ -379,6 +379,40 @@ def test_mlp_golden(device):
         assert_close(y.cpu().numpy(), g["dnn_%s_y" % tag], what="dnn " + tag)
 
 
+@pytest.mark.parametrize("name,kw", [("dnn_relu_sigmoid_bn", dict(activation="relu", output_activation="sigmoid", use_bn=True)),
+                                     ("dnn_tanh_linear", dict(activation="tanh", output_activation="linear", use_bn=False))])
+def test_dnn_layer_use_bn_and_output_activation(device, name, kw):
+    """DNN(use_bn=True) / DNN(output_activation=...) (reference layers/core.py:176-184,200-201) against the fixture the
+    reference's own layer code produced, weights loaded by their keras names."""
+    import torch
+    from deepctr_amd.layers import DNN
+    g = load_golden(name)
+    from deepctr_amd.layers.base import name_scope
+    with name_scope():                      # fresh keras-style auto names: dnn, batch_normalization, batch_normalization_1, ...
+        layer = DNN((6, 5, 3), seed=3, device=device, **kw).build_for(7)
+    assert layer.get_config()["use_bn"] == kw["use_bn"] and layer.get_config()["output_activation"] == kw["output_activation"]
+    named = dict(layer.named_weights())
+    for k, v in g.items():
+        if k.startswith("w/"):
+            with torch.no_grad():
+                named[k[2:]].copy_(dev(v, device))
+    y = layer(dev(g["x"], device))
+    assert_close(y.cpu().numpy(), g["y"], rtol=1e-4, atol=1e-6, what=name)
+    # a larger batch, every tile shape, against the float64 restatement
+    from oracle import ref_numpy as R
+    rng = np.random.RandomState(1)
+    x = (rng.standard_normal((1000, 7)) * 0.8).astype(np.float32)
+    n = 3
+    bn = None
+    if kw["use_bn"]:
+        bn = [tuple(g["w/batch_normalization%s/%s" % ("" if i == 0 else "_%d" % i, w)].astype(np.float64)
+                    for w in ("gamma", "beta", "moving_mean", "moving_variance")) for i in range(n)]
+    ref = R.dnn(x.astype(np.float64), [g["w/dnn/kernel%d" % i].astype(np.float64) for i in range(n)],
+                [g["w/dnn/bias%d" % i].astype(np.float64) for i in range(n)], kw["activation"],
+                output_activation=kw["output_activation"], bn_params=bn)
+    assert_close(layer(dev(x, device)).cpu().numpy(), ref, rtol=1e-4, atol=1e-6, what=name + " B=1000")
+
+
 @pytest.mark.parametrize("B", [1, 33, 4100])
 def test_mlp_tile_rows_are_bit_identical(device, B):
     """tile_rows only changes how many batch rows share a weight fragment: 16 / 32 / 64 give the same bits

@@ -228,7 +228,8 @@ MODEL_FIXTURES = ["model_deepfm_mixed", "model_deepfm_hash", "model_dcn_vector",
                   "model_deepfm_criteo_sample", "model_wdl", "model_wdl_wide_subset", "model_fnn", "model_wdl_fixed",
                   "model_fnn_fixed", "model_afm", "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner",
                   "model_pnn_plain", "model_nfm", "model_nfm_fixed", "model_dcnmix", "model_dcnmix_crossonly",
-                  "model_dcnmix_fixed"]
+                  "model_dcnmix_fixed", "model_deepfm_bn", "model_dcn_bn", "model_xdeepfm_bn", "model_deepfm_bn_fixed",
+                  "model_din_bn_dice", "model_din_bn_sigmoid"]
 
 
 def run_oracle_model(g, dtype=np.float32):
@@ -274,3 +275,19 @@ def test_model_oracle_matches_reference_code(name):
     ok = (ref > 1e-6) & (ref < 1 - 1e-6)
     if ok.any():
         assert_close(sigmoid_inv(y[ok]), sigmoid_inv(ref[ok]), rtol=1e-4, atol=2e-5, what=name + " logit")
+
+
+@pytest.mark.parametrize("name,kw", [("dnn_relu_sigmoid_bn", dict(activation="relu", output_activation="sigmoid", use_bn=True)),
+                                     ("dnn_tanh_linear", dict(activation="tanh", output_activation="linear", use_bn=False))])
+def test_dnn_layer_with_bn_and_output_activation(name, kw):
+    """DNN(use_bn, output_activation) of the reference's own layer code (layers/core.py:176-184,189-208) vs the restatement."""
+    g = load_golden(name)
+    n = 3
+    ks = [g["w/dnn/kernel%d" % i] for i in range(n)]
+    bs = [g["w/dnn/bias%d" % i] for i in range(n)]
+    bn = None
+    if kw["use_bn"]:
+        bn = [tuple(g["w/batch_normalization%s/%s" % ("" if i == 0 else "_%d" % i, w)] for w in ("gamma", "beta", "moving_mean", "moving_variance"))
+              for i in range(n)]
+    y = R.dnn(g["x"], ks, bs, kw["activation"], output_activation=kw["output_activation"], bn_params=bn)
+    assert_close(y, g["y"], rtol=1e-5, atol=1e-6, what=name)
