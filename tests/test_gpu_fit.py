@@ -81,3 +81,29 @@ def test_sibling_models_fit(device, kind, on_hip):
     assert (getattr(model, "_hip_trainer", None) is not None) == on_hip
     after = model.evaluate(feed, y, batch_size=512)
     assert h.history["loss"][-1] < h.history["loss"][0] and after < before - 0.02, (before, after, h.history["loss"])
+
+
+@pytest.mark.parametrize("on_hip", [True, False])
+def test_frozen_embedding_is_bit_identical_after_fit(device, on_hip):
+    """SparseFeat(trainable=False): reference inputs.py:25 (emb.trainable = feat.trainable), docs FAQ "pretrained embeddings" —
+    neither the HIP step (no gradient table, no optimizer segment, no l2 decay) nor the torch step may move the table."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(4)
+    n = 1024
+    cols = [SparseFeat("a", 20, 8, trainable=False), SparseFeat("b", 30, 8), DenseFeat("d", 2),
+            VarLenSparseFeat(SparseFeat("s", 15, 8, trainable=False), maxlen=4, combiner="mean")]
+    feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 30, n), "d": rng.rand(n, 2).astype(np.float32),
+            "s": rng.randint(0, 15, (n, 4))}
+    y = ((feed["a"] + feed["b"]) % 2).astype(np.float32)
+    model = DeepFM(cols, cols, dnn_hidden_units=(16, 8), l2_reg_embedding=1e-3, l2_reg_linear=1e-3, device=device)
+    model.hip_training = on_hip
+    model.compile("adam", "binary_crossentropy")
+    before = model.get_weights_by_name()
+    h = model.fit(feed, y, batch_size=256, epochs=3, verbose=0)
+    after = model.get_weights_by_name()
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    for k in ("sparse_emb_a/embeddings", "linear0sparse_emb_a/embeddings", "sparse_seq_emb_s/embeddings", "linear0sparse_seq_emb_s/embeddings"):
+        assert np.array_equal(before[k], after[k]), k
+    assert not np.array_equal(before["sparse_emb_b/embeddings"], after["sparse_emb_b/embeddings"])
+    assert not np.array_equal(before["dnn/kernel0"], after["dnn/kernel0"])
