@@ -580,6 +580,21 @@ class EmbeddingStage(object):
 # Model
 # ---------------------------------------------------------------------------------------------------
 # keras layer names of BatchNormalization layers that live inside Dice -> this build's Dice layer names
+def on_model_device(fn):
+    """Run a model method with the model's device as torch's CURRENT device (models accept ``device=``; kernels, copies
+    and the stream handed to the C ABI all follow the current device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = getattr(self, "device", None)
+        if dev is not None and dev.type == "cuda" and torch.cuda.is_available():
+            with torch.cuda.device(dev):
+                return fn(self, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+    return wrapper
+
+
 def _bn_aliases(layers):
     """{keras name of the BatchNormalization inside a Dice layer: that Dice layer's name}.  The names come from the auto-name
     counter keras shares between Dice's BatchNormalization and the BatchNormalization layers of DNN(use_bn=True)."""
@@ -778,6 +793,7 @@ class Model(object):
     def _num_rows(self, feed):
         return int(np.asarray(feed[self.input_names[0]]).shape[0])
 
+    @on_model_device
     def stage(self, x):
         """Copy every input column to the device once (the only host->device traffic of a predict call)."""
         _C.require_device()
@@ -799,6 +815,7 @@ class Model(object):
         """Hook: rows one _forward call may cover (default: the caller's batch_size)."""
         return batch_size
 
+    @on_model_device
     def predict_tensor(self, x, batch_size=256):
         """predict() that leaves the [N] result on the device (used by the distributed path)."""
         pipe = self._pipeline(x, batch_size)
@@ -841,6 +858,7 @@ class Model(object):
     def compile(self, optimizer="adam", loss=None, metrics=None, **kwargs):
         self._compiled = {"optimizer": optimizer, "loss": loss, "metrics": metrics or []}
 
+    @on_model_device
     def evaluate(self, x, y, batch_size=256, verbose=0, **kwargs):
         p = self.predict(x, batch_size).reshape(-1).astype(np.float64)
         y = np.asarray(y, dtype=np.float64).reshape(-1)
@@ -853,11 +871,13 @@ class Model(object):
             loss = float(((p - y) ** 2).mean())
         return loss
 
+    @on_model_device
     def fit(self, x=None, y=None, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, **kwargs):
         from .training import fit_model
         return fit_model(self, x, y, batch_size=batch_size, epochs=epochs, verbose=verbose,
                          validation_split=validation_split, shuffle=shuffle, **kwargs)
 
+    @on_model_device
     def train_on_batch(self, x, y, **kwargs):
         from .training import fit_model
         h = fit_model(self, x, y, batch_size=None, epochs=1, verbose=0, shuffle=False)

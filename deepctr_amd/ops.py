@@ -13,12 +13,23 @@ from . import _C
 
 
 def _dev_check(*tensors):
+    """Every tensor must live on the CURRENT HIP device: launches go to torch's current stream of the current device
+    (_C.stream_ptr), so a tensor of another device would be read through the wrong queue — unordered with its copies, or a
+    fault.  Models switch the current device themselves (engine.on_model_device); direct callers of ops do it with
+    ``torch.cuda.device(tensor.device)``."""
+    cur = None
     for t in tensors:
         if t is None:
             continue
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
             raise _C.DctrExtensionError("deepctr_amd ops need HIP device tensors (got %s); there is no CPU path"
                                         % (type(t).__name__ if not isinstance(t, torch.Tensor) else str(t.device)))
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise _C.DctrExtensionError("tensor on %s but the current HIP device is cuda:%d: wrap the call in "
+                                        "torch.cuda.device(%d) (kernels are launched on the current device's stream)"
+                                        % (t.device, cur, t.device.index))
 
 
 def _f32c(t, name):
