@@ -31,6 +31,7 @@ SOURCES = [
     "mlp_kernels_rt2.hip",
     "mlp_kernels_rt4.hip",
     "stream_kernels.hip",
+    "chain_kernels.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "din_kernels.hip",

@@ -1,0 +1,706 @@
+// dctr_embed_mlp_fwd, row-chained form — the throughput kernel of the DeepFM-family forward (reference
+// deepctr/inputs.py:101-117 embedding_lookup, feature_column.py:171-210 linear logit, layers/interaction.py:588-604 FM,
+// layers/core.py:189-208 DNN, :250-259 PredictionLayer) for launches that give every CU >= 256 rows.
+//
+// Why a third kernel.  stream_kernel (stream_kernels.hip) splits the layer OUTPUT columns over its 8 MFMA waves: every
+// layer ends in an epilogue that stores the activations to LDS, a barrier of the 8 waves, and a cold start of the next
+// layer's operand pipeline; its MFMA waves alone reach 0.72 of the f32-MFMA rate (profiles/r02_stream_lab_ablation.log),
+// 0.55-0.62 with the loader waves beside them.  Here a wave owns BATCH ROWS end to end and the MLP is computed transposed:
+//   * out^T[n, b] = sum_k W[k, n] * x[b, k]: the WEIGHTS are the MFMA A operand (M = output features), the wave's 32 batch
+//     rows are the N dimension (two 16-wide N tiles).  v_mfma_f32_16x16x4_f32 leaves C[m = 4g + r][n = j] in lane (g, j),
+//     register r — and wants B[k = g][n = j] from lane (g, j): a layer's accumulators ARE the next layer's B operand,
+//     register for register (k-slot g of k-step (M-tile, r) is output feature 4g + r of that M-tile; a K permutation, which
+//     an fp32 fmaf chain does not care about as long as the weight rows are fetched in the same order).  Activations never
+//     leave the register file: no LDS round trip, no epilogue stores, no barrier between layers;
+//   * the 8 waves of a workgroup walk the SAME weight sequence (layer 0 in 16-row k-blocks, layers >= 1 in 64 x 64
+//     sub-blocks), so the weights go L2 -> LDS once per 256 rows (603 KB per 300k cycles = 2 B/clk/CU against the 16 B/clk
+//     the 32-row kernel pulls) through LDS-DMA (global_load_lds_dwordx4, every wave moves 1/8 of a 16-KiB chunk) into a
+//     ring of three chunks; one s_barrier per chunk both publishes the chunk after next and retires the previous one;
+//   * A fragments are ds_read_b128: with M-tile mt of an M-group holding output features 64*mg + 4*i + mt (i = MFMA row),
+//     lane (g, j) reads floats 64*mg + 4j .. + 3 of weight row k: one read feeds FOUR M-tiles, 16 lanes of a group cover
+//     256 contiguous bytes (conflict-free for every lane grouping of ds_read_b128), and the rows need no repacking: the
+//     DMA image of a chunk is the Keras [K, N] rows as they lie in memory;
+//   * the embedding gather goes HBM/MALL -> REGISTERS: lane (g, j) of a wave loads the 16-B piece g of row j's embedding of
+//     one field with one global_load_dwordx4 — which is exactly the B operand of that field's four k-steps.  FM sums and
+//     the linear terms are lane-local adds (reduced over g once per pass).  Rows are requested one k-block (8k cycles)
+//     ahead of their MFMAs, ids two.
+// 8 waves x 32 rows = 256 rows per pass and CU; registers: 128 (layer-0 accumulators: 16 M-tiles x 2 N-tiles) + 64
+// (layer 1) + operand staging -> two waves per SIMD.
+//
+// Eligibility (host, below): uniform embedding_dim 16 or 32, no hashing / identity fields, dense columns right behind the
+// embeddings, every units[l] a multiple of 64 from the instantiated set, a head, no Dice / BatchNormalization / saved
+// activations, and at least 256 rows per CU (or tile_rows == 256).  Everything else takes stream_kernel / mlp_kernel.
+// Same arithmetic as those: v_mfma_f32_16x16x4_f32 = exact fp32; only the summation order over k differs.
+#include "mlp_device.h"
+
+#ifdef DCTR_CHAIN_LAB_TS
+__device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][stamp] of workgroup 0, second pass
+#define CTS(i) do { if (blockIdx.x == 0 && it == 1 && (wave == 0 || wave == 7) && lane == 0) dctr_chain_ts[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CTS(i) do {} while (0)
+#endif
+
+namespace dctr_chain {
+
+using dctr::f32x4;
+using namespace dctr_mlp;
+
+constexpr int NW = 8;                          // waves per workgroup (two per SIMD)
+constexpr int NT = 64 * NW;
+constexpr int RT = 2;                          // 16-row N tiles per wave
+constexpr int PROWS = NW * 16 * RT;            // batch rows per pass
+constexpr int NSLOT = 3;
+constexpr int SLOT_F = 4096;                   // floats per ring chunk (16 KiB)
+constexpr int CPAR_OFF = 0;                    // biases of every layer, head weights (<= 1024 floats)
+constexpr int FDESC_OFF = 1024;                // [n_fields <= 64][12 dwords]
+constexpr int DLW_OFF = 1792;                  // dense_lin_w (<= 256 floats, zeros when absent)
+constexpr int RING_OFF = 2048;
+constexpr int DENSE_OFF = RING_OFF + NSLOT * SLOT_F;   // [256 rows][16 * dense k-blocks] zero-padded dense values of the pass
+constexpr int MAX_DENSE_BLOCKS = 4;
+static inline size_t lds_bytes(int n_dense) { return (size_t)(DENSE_OFF + PROWS * ((n_dense + 15) & ~15)) * sizeof(float); }
+
+struct ChainParams {
+    const dctr_field_t* fields;
+    const void* ids;
+    int64_t ids_stride_f, ids_stride_b;
+    int32_t ids_is_i64, n_fields, n_dense, in_dim;
+    const float* dense;
+    int64_t dense_stride;
+    const float* dense_lin_w;
+    int64_t batch;
+    float* fm_logit;
+    float* lin_logit;
+    int32_t* status;
+    int32_t fm_used, lin_used;
+    const float* W[3];
+    const float* bias[3];
+    int32_t activation, sigmoid_out;
+    const float* head_w;
+    const float* add[4];
+    const float* global_bias;
+    float* y;
+    unsigned long long* probe;
+    int32_t n_pass;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// loads through pointers that come out of LDS (field descriptors) would be FLAT instructions (vmcnt AND lgkmcnt, slower
+// address path): the global address space is stated explicitly
+typedef const __attribute__((address_space(1))) f32x4* gbl_f4_t;
+typedef const __attribute__((address_space(1))) float* gbl_f_t;
+
+// field descriptor words as they lie in LDS (copied once per launch); decoded to scalars where they are used
+struct FieldRaw {
+    uint4 a;       // table, lin_table
+    uint2 b;       // vocab
+    uint32_t c;    // in_fm
+};
+__device__ __forceinline__ FieldRaw field_raw(const float* fdesc, int f) {
+    FieldRaw r;
+    r.a = *reinterpret_cast<const uint4*>(fdesc + 12 * f);
+    r.b = *reinterpret_cast<const uint2*>(fdesc + 12 * f + 4);
+    r.c = *reinterpret_cast<const uint32_t*>(fdesc + 12 * f + 8);
+    return r;
+}
+__device__ __forceinline__ uint64_t sgpr64(uint32_t lo, uint32_t hi) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+}
+
+// activation of a whole accumulator set in place (one switch per layer, not per element)
+template <int ACT, int NM>
+__device__ __forceinline__ void act_block_t(f32x4 (&acc)[NM][2]) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nt][r] = act_t<ACT>(acc[m][nt][r], 0.f, 0.f, 1.f, 0.f);
+}
+template <int NM>
+__device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][2]) {
+    switch (act) {
+        case DCTR_ACT_RELU: act_block_t<DCTR_ACT_RELU, NM>(acc); break;
+        case DCTR_ACT_SIGMOID: act_block_t<DCTR_ACT_SIGMOID, NM>(acc); break;
+        case DCTR_ACT_TANH: act_block_t<DCTR_ACT_TANH, NM>(acc); break;
+        default: break;
+    }
+}
+
+// the gathered operand of one k-block for this lane: 16-B piece g of row j's embedding per N tile, and the field's
+// linear-table entry
+struct XBlk {
+    f32x4 x[RT];
+    float lv[RT];
+};
+
+// EB = embedding_dim / 16 k-blocks per field; M0 / M1 / M2 = units[l] / 64 (M2 == 0: two layers)
+template <int EB, int M0, int M1, int M2>
+__global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
+    constexpr int NL = M2 > 0 ? 3 : 2;
+    constexpr int ML = NL == 3 ? M2 : M1;          // M-groups of the last layer
+    constexpr int S1 = M0 * M1, S2 = M1 * M2;      // chunks (= steps) of layers 1 and 2
+    constexpr int SL = S1 + S2;
+    static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
+    constexpr int E = 16 * EB;
+    constexpr int B1_OFF = 64 * M0, B2_OFF = B1_OFF + 64 * M1, HW_OFF = B2_OFF + 64 * M2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cpar = smem + CPAR_OFF;
+    float* fdesc = smem + FDESC_OFF;
+    float* dlw = smem + DLW_OFF;
+    float* ring = smem + RING_OFF;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
+
+    // ---- once per launch: descriptors, biases, head weights, dense linear weights -> LDS
+    for (int i = threadIdx.x; i < 12 * p.n_fields; i += NT)
+        reinterpret_cast<uint32_t*>(fdesc)[i] = reinterpret_cast<const uint32_t*>(p.fields)[i];
+    for (int i = threadIdx.x; i < 64 * M0; i += NT) cpar[i] = p.bias[0] != nullptr ? p.bias[0][i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * M1; i += NT) cpar[B1_OFF + i] = p.bias[1] != nullptr ? p.bias[1][i] : 0.f;
+    if constexpr (M2 > 0)
+        for (int i = threadIdx.x; i < 64 * M2; i += NT) cpar[B2_OFF + i] = p.bias[2] != nullptr ? p.bias[2][i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * ML; i += NT) cpar[HW_OFF + i] = p.head_w[i];
+    for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
+
+    const int NBE = p.n_fields * EB;               // embedding k-blocks
+    const int NB = (p.in_dim + 15) >> 4;           // k-blocks of the DNN input (= steps of layer 0)
+    const int NDB = NB - NBE;                      // dense k-blocks (0 .. MAX_DENSE_BLOCKS)
+    const int STEPS = NB + SL;
+    const int k_last = p.in_dim - 1;
+    float* dreg = smem + DENSE_OFF + (32 * wave) * (16 * NDB);     // this wave's rows of the dense staging area
+
+    // ---- weight chunks.  Chunk ci of a pass: ci < NB: rows 16*ci .. + 15 of W0 (all 64*M0 columns); then the 64 x 64
+    // sub-blocks (mg, mg1) of W1, mg-major; then those of W2; ci >= STEPS wraps to the next pass.  A chunk image is
+    // 16 pieces of 1 KiB (fewer for M0 < 4); wave w moves pieces w, w + 8: lane l's 16 bytes land at piece + 16 l.
+    // The DMA instruction is issued through inline asm on purpose: hipcc orders every later ds_read behind an LDS-DMA it
+    // can see with s_waitcnt vmcnt(0) (it cannot prove the chunk being filled is not the chunk being read), which would
+    // stall each step on the loads it has just requested.  Unseen, the DMA only makes hipcc's own vmcnt bookkeeping for
+    // the register loads conservative (more operations in the queue than it counts: it can over-wait, never under-wait).
+    // (the lane index is made opaque per call: otherwise the per-lane source offsets of all ten layer >= 1 chunks are
+    // hoisted out of the persistent loop as loop invariants — live VGPRs across the whole pass, i.e. spills)
+    auto dma16 = [&](const void* sbase, uint32_t voff, float* dst) {
+        const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)dst;
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma_l0 = [&](int b, float* dst) {
+        constexpr int ROW_B = 256 * M0;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW) {
+            const int pc = pc0 + wave;
+            if (pc < 4 * M0) {
+                const int o = pc * 1024 + 16 * ln;
+                const int krow = min(16 * b + o / ROW_B, k_last);      // rows past K: a finite stand-in (x is 0 there)
+                dma16(p.W[0], (uint32_t)(krow * ROW_B + (o % ROW_B)), dst + pc * 256);
+            }
+        }
+    };
+    auto dma_ln = [&](const float* W, int N, int mg, int mg1, float* dst) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const char* base = reinterpret_cast<const char*>(W) + ((size_t)(64 * mg) * N + 64 * mg1) * 4;   // scalar
+#pragma unroll
+        for (int pc0 = 0; pc0 < 16; pc0 += NW) {
+            const int pc = pc0 + wave;
+            const int o = pc * 1024 + 16 * ln;
+            dma16(base, (uint32_t)(o >> 8) * (uint32_t)(N * 4) + (uint32_t)(o & 255), dst + pc * 256);
+        }
+    };
+    auto dma_chunk = [&](int ci, float* dst) {
+        if (ci >= STEPS) ci -= STEPS;
+        if (ci < NB) {
+            dma_l0(ci, dst);
+        } else {
+            int c = ci - NB;
+            if (c < S1) {
+                dma_ln(p.W[1], 64 * M1, c / M1, c % M1, dst);
+            } else if constexpr (M2 > 0) {
+                c -= S1;
+                dma_ln(p.W[2], 64 * M2, c / M2, c % M2, dst);
+            }
+        }
+    };
+
+    // ---- ring position: chunk of step s (counted over the whole launch) lives in slot s % 3
+    int slot = 0;                                  // slot of the CURRENT step's chunk
+    auto slot_ptr = [&](int ahead) -> float* {
+        int s = slot + ahead;
+        s = s >= NSLOT ? s - NSLOT : s;
+        return ring + s * SLOT_F;
+    };
+    auto slot_next = [&]() { slot = slot + 1 == NSLOT ? 0 : slot + 1; };
+
+    // ---- rows of this lane in a pass (launches are cut to < 2^31 rows by the host)
+    auto row_of = [&](int pass, int nt) -> int { return pass * PROWS + 32 * wave + 16 * nt + j; };
+    auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), (int)p.batch - 1); };
+    int oor = 0;
+    auto request_ids = [&](int cb, int pass, RawId (&id)[RT]) {
+        const int f = min(cb / EB, p.n_fields - 1);
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt)
+            id[nt] = load_id(p.ids, (int64_t)f * p.ids_stride_f + (int64_t)brow_of(pass, nt) * p.ids_stride_b, p.ids_is_i64);
+    };
+    // issue the loads of embedding k-block cb (ids already here) for the rows of `pass`
+    auto issue_x = [&](int cb, int pass, const RawId (&id)[RT], XBlk& X) {
+        const int f = cb / EB, h = cb % EB;
+        const FieldRaw fr = field_raw(fdesc, f);
+        const float* table = reinterpret_cast<const float*>(sgpr64(fr.a.x, fr.a.y));
+        const float* lin_table = reinterpret_cast<const float*>(sgpr64(fr.a.z, fr.a.w));
+        const int64_t vocab = (int64_t)sgpr64(fr.b.x, fr.b.y);
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            int64_t idk = id_value(id[nt], p.ids_is_i64);
+            const bool ok = (uint64_t)idk < (uint64_t)vocab;
+            if (!ok && row_of(pass, nt) < (int)p.batch) oor = 1;
+            idk = ok ? idk : 0;
+            X.x[nt] = *(gbl_f4_t)(table + idk * E + 16 * h + 4 * g);
+            X.lv[nt] = 0.f;
+            if (h == 0 && lin_table != nullptr) X.lv[nt] = *(gbl_f_t)(lin_table + idk);
+        }
+    };
+    // dense features of a pass: requested, then (a step later) written zero-padded to this wave's LDS rows — the dense
+    // k-blocks of layer 0 read their B operand from there, so the hot loop has ONE kind of global load.  Lane (g, j) moves
+    // columns 4g .. 4g + 3 of dense k-block c for its two rows; the lane's share of dense . dense_lin_w comes out on the way
+    auto dense_request = [&](int c, int pass, float (&td)[RT][4]) {
+        const int d0 = 16 * c + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            gbl_f_t src = (gbl_f_t)(p.dense + (int64_t)brow_of(pass, nt) * p.dense_stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) td[nt][e] = src[min(d0 + e, p.n_dense - 1)];
+        }
+    };
+    auto dense_store = [&](int c, const float (&td)[RT][4], float (&dl)[RT]) {
+        const int d0 = 16 * c + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = d0 + e < p.n_dense ? td[nt][e] : 0.f;
+                dl[nt] = fmaf(v[e], dlw[min(d0 + e, 255)], dl[nt]);
+            }
+            *reinterpret_cast<f32x4*>(dreg + (16 * nt + j) * (16 * NDB) + d0) = v;
+        }
+    };
+    // dense k-blocks 1.. (rare): synchronously
+    auto dense_rest = [&](int pass, float (&dl)[RT]) {
+        for (int c = 1; c < NDB; ++c) {
+            float td[RT][4];
+            dense_request(c, pass, td);
+            dense_store(c, td, dl);
+        }
+    };
+
+    // ---- the barrier of a step: everything this wave requested has landed (its share of the chunk after this one, the
+    // next k-block's rows, ids), all eight waves have finished reading the previous chunk.  The in-flight registers are
+    // named so that hipcc places its own bookkeeping wait here and not in front of their first use
+#define CHAIN_TOP_X(X, ID)                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                     \
+                 : "+v"(X.x[0]), "+v"(X.x[1]), "+v"(X.lv[0]), "+v"(X.lv[1]), "+v"(ID[0].lo), "+v"(ID[0].hi),       \
+                   "+v"(ID[1].lo), "+v"(ID[1].hi)                                                                  \
+                 :                                                                                               \
+                 : "memory")
+#define CHAIN_TOP_ID(ID)                                                                                         \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                     \
+                 : "+v"(ID[0].lo), "+v"(ID[0].hi), "+v"(ID[1].lo), "+v"(ID[1].hi)                                  \
+                 :                                                                                               \
+                 : "memory")
+#define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // A-operand lane offsets (floats) inside a chunk image
+    const int l0off = (4 * g) * (64 * M0) + 4 * j;     // layer 0: k-step t reads row 4g + t, M-group mg at + 64 mg
+    const int lnoff = (16 * g) * 64 + 4 * j;           // layers >= 1: k-step (mt, r) reads row 16g + 4r + mt
+
+    // ---- prologue: chunks 0 and 1, the dense values, ids and rows of k-block 0, ids of k-block 1 of the first pass
+    XBlk XA, XB;
+    RawId idn[RT];
+    float dlin_n[RT];                                  // dense . dense_lin_w share of this lane for the staged pass
+#pragma unroll
+    for (int nt = 0; nt < RT; ++nt) {
+        XA.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        XB.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        XA.lv[nt] = XB.lv[nt] = 0.f;
+        idn[nt].lo = idn[nt].hi = 0u;
+        dlin_n[nt] = 0.f;
+    }
+    __syncthreads();                                   // LDS parameters written
+    // in_fm of every field as one scalar bit mask (n_fields <= 64)
+    const uint64_t fm_mask = __ballot(lane < p.n_fields && reinterpret_cast<const uint32_t*>(fdesc)[12 * min(lane, p.n_fields - 1) + 8] != 0u);
+    {
+        const int pass0 = min((int)blockIdx.x, p.n_pass - 1);
+        dma_chunk(0, slot_ptr(0));
+        dma_chunk(1, slot_ptr(1));
+        request_ids(0, pass0, idn);
+        float td[RT][4];
+        if (NDB > 0) dense_request(0, pass0, td);
+        CHAIN_TOP_ID(idn);
+        if (NDB > 0) {
+            dense_store(0, td, dlin_n);
+            dense_rest(pass0, dlin_n);
+        }
+        issue_x(0, pass0, idn, XA);
+        request_ids(1, pass0, idn);
+    }
+
+    for (int it = 0, pass = blockIdx.x; pass < p.n_pass; ++it, pass += gridDim.x) {
+        (void)it;
+        const int pass_n = min(pass + (int)gridDim.x, p.n_pass - 1);     // rows the gather prologue at the pass's end is for
+        CTS(0);
+        // ================= layer 0: acc0[4 mg + mt][nt] = C tile of output features 64 mg + 4 i + mt
+        f32x4 acc0[4 * M0][RT];
+#pragma unroll
+        for (int mg = 0; mg < M0; ++mg) {
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(cpar + 64 * mg + 16 * g + 4 * q);
+                bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt)
+                    acc0[4 * mg + mt][nt] = f32x4{bv[mt], bv[4 + mt], bv[8 + mt], bv[12 + mt]};
+        }
+        float dlin[RT];
+        f32x4 sum[EB][RT];
+        float sq[RT], lin[RT];
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            dlin[nt] = dlin_n[nt];
+            dlin_n[nt] = 0.f;
+            sq[nt] = lin[nt] = 0.f;
+#pragma unroll
+            for (int h = 0; h < EB; ++h) sum[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // operand pipeline of every layer: micro-steps of ONE ds_read_b128 (4 A fragments = 4 M-tiles) + 4 x RT MFMAs; the
+        // fragment of micro-step u + 1 is requested before the MFMAs of micro-step u (two 4-register buffers, c0 / c1).
+        // Layer 0, k-block step: micro-step u = (k-step t = u / M0, M-group mg = u % M0) reads weight row 4g + t
+        f32x4 c0, c1;
+        auto read_l0 = [&](const float* sb, int u) -> f32x4 {
+            return *reinterpret_cast<const f32x4*>(sb + l0off + (u / M0) * (64 * M0) + 64 * (u % M0));
+        };
+        auto mfma_l0 = [&](const f32x4& a, const XBlk& X, int u) {
+            const int t = u / M0, mg = u % M0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt)
+                    acc0[4 * mg + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], X.x[nt][t], acc0[4 * mg + mt][nt], 0, 0, 0);
+        };
+        // FM / linear bookkeeping of the embedding block being multiplied (lane-local)
+        auto consume_x = [&](int b, const XBlk& X) {
+            const int f = b / EB, h = b % EB;
+            const bool in_fm = (fm_mask >> f) & 1ull;
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) {
+                lin[nt] += X.lv[nt];
+                if (in_fm) {
+#pragma unroll
+                    for (int hh = 0; hh < EB; ++hh)
+                        if (hh == h) sum[hh][nt] += X.x[nt];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sq[nt] = fmaf(X.x[nt][e], X.x[nt][e], sq[nt]);
+                }
+            }
+        };
+        // one layer-0 step: k-block B multiplies with XC while XN (k-block B + 1) and the ids of B + 2 are requested.
+        // A dense k-block takes its operand from the staging rows in LDS instead (uniform branch, once or so per pass)
+#define CHAIN_STEP0(B, XC, XN)                                                                                   \
+        {                                                                                                        \
+            const int b_ = (B);                                                                                  \
+            CHAIN_TOP_X(XC, idn);                                                                                \
+            const float* sb_ = slot_ptr(0);                                                                      \
+            if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
+            if (b_ < NBE) {                                                                                      \
+                consume_x(b_, XC);                                                                               \
+            } else {                                                                                             \
+                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
+                    XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
+            }                                                                                                    \
+            _Pragma("unroll") for (int u_ = 0; u_ < 4 * M0; u_ += 2) {                                           \
+                c1 = read_l0(sb_, u_ + 1);                                                                       \
+                DCTR_SB;                                                                                         \
+                mfma_l0(c0, XC, u_);                                                                             \
+                DCTR_SB;                                                                                         \
+                if (u_ == 0) {                                                                                   \
+                    dma_chunk(b_ + 2, slot_ptr(2));                                                              \
+                    if (b_ + 1 < NBE) issue_x(b_ + 1, pass, idn, XN);                                            \
+                    request_ids(min(b_ + 2, NBE - 1), pass, idn);                                                \
+                }                                                                                                \
+                if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                                  \
+                else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                              \
+                DCTR_SB;                                                                                         \
+                mfma_l0(c1, XC, u_ + 1);                                                                         \
+                DCTR_SB;                                                                                         \
+            }                                                                                                    \
+            slot_next();                                                                                         \
+        }
+        for (int b = 0; b < NB; b += 2) {
+            CHAIN_STEP0(b, XA, XB);
+            if (b + 1 < NB) CHAIN_STEP0(b + 1, XB, XA);
+        }
+#undef CHAIN_STEP0
+        CTS(1);
+        // ---- gather epilogue of the pass: FM = 0.5 (sum_d (sum_f e)^2 - sum_{f,d} e^2), linear; lane-local, then over g
+        float extras[RT];
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            float fm = -sq[nt];
+#pragma unroll
+            for (int h = 0; h < EB; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fm = fmaf(sum[h][nt][e], sum[h][nt][e], fm);
+            fm += __shfl_xor(fm, 16, 64);
+            fm += __shfl_xor(fm, 32, 64);
+            fm *= 0.5f;
+            float dl = dlin[nt];
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+            const float lin_all = lin[nt] + dl;            // every lane of a row loaded the row's linear entries itself
+            extras[nt] = (p.fm_used ? fm : 0.f) + (p.lin_used ? lin_all : 0.f);
+            const int r = row_of(pass, nt);
+            if (g == 0 && r < (int)p.batch) {
+                if (p.fm_logit != nullptr) p.fm_logit[r] = fm;
+                if (p.lin_logit != nullptr) p.lin_logit[r] = lin_all;
+            }
+        }
+        // activation in place: acc0 is now the B operand of layer 1
+        act_block<4 * M0>(p.activation, acc0);
+
+        // ================= layers >= 1: one step per 64 x 64 sub-block (mg, mg1): 16 k-steps (mt, r) of 4 M-tiles x RT MFMAs
+        auto read_an = [&](const float* sb, int ks) -> f32x4 {
+            const int mt = ks >> 2, r = ks & 3;
+            return *reinterpret_cast<const f32x4*>(sb + lnoff + (4 * r + mt) * 64);
+        };
+        int sidx = 0;                                  // step index behind layer 0 (compile-time after unrolling)
+        float td[RT][4];                               // next pass's dense values between its request and its LDS store
+        auto init_acc = [&](auto& acc, int boff, auto MG) {
+            constexpr int MGc = decltype(MG)::value;
+#pragma unroll
+            for (int mg = 0; mg < MGc; ++mg) {
+                float bv[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(cpar + boff + 64 * mg + 16 * g + 4 * q);
+                    bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) acc[4 * mg + mt][nt] = f32x4{bv[mt], bv[4 + mt], bv[8 + mt], bv[12 + mt]};
+            }
+        };
+        // (the generic lambda is instantiated per layer; MI / MO = M-groups of its input / output)
+        auto dense_layer = [&](auto& accin, auto& accout, auto MIc, auto MOc) {
+            constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
+#pragma unroll
+            for (int mg = 0; mg < MI; ++mg) {
+#pragma unroll
+                for (int mg1 = 0; mg1 < MO; ++mg1) {
+                    const bool first = sidx == 0;                  // no prefetch across the layer-0 boundary
+                    const bool last = sidx == SL - 1;
+                    if (last) CHAIN_TOP_ID(idn);                   // the ids requested in the step before
+                    else CHAIN_TOP();
+                    const float* sb = slot_ptr(0);
+                    if (last && NDB > 0) {                         // the next pass's dense values have landed
+                        dense_store(0, td, dlin_n);
+                        dense_rest(pass_n, dlin_n);
+                    }
+                    if (first) c0 = read_an(sb, 0);
+#pragma unroll
+                    for (int ks = 0; ks < 16; ks += 2) {
+                        c1 = read_an(sb, ks + 1);
+                        DCTR_SB;
+#pragma unroll
+                        for (int mt1 = 0; mt1 < 4; ++mt1)
+#pragma unroll
+                            for (int nt = 0; nt < RT; ++nt)
+                                accout[4 * mg1 + mt1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    c0[mt1], accin[4 * mg + (ks >> 2)][nt][ks & 3], accout[4 * mg1 + mt1][nt], 0, 0, 0);
+                        DCTR_SB;
+                        if (ks == 0) {
+                            // after the first k-step: the chunk after next, and at the pass's end the next pass's gather
+                            dma_chunk(NB + sidx + 2, slot_ptr(2));
+                            if (sidx == SL - 2) {
+                                request_ids(0, pass_n, idn);
+                                if (NDB > 0) dense_request(0, pass_n, td);
+                            }
+                            if (last) {
+                                issue_x(0, pass_n, idn, XA);
+                                request_ids(1, pass_n, idn);
+                            }
+                        }
+                        if (ks + 2 < 16) c0 = read_an(sb, ks + 2);
+                        else if (!last) c0 = read_an(slot_ptr(1), 0);
+                        DCTR_SB;
+#pragma unroll
+                        for (int mt1 = 0; mt1 < 4; ++mt1)
+#pragma unroll
+                            for (int nt = 0; nt < RT; ++nt)
+                                accout[4 * mg1 + mt1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    c1[mt1], accin[4 * mg + ((ks + 1) >> 2)][nt][(ks + 1) & 3], accout[4 * mg1 + mt1][nt], 0, 0, 0);
+                        DCTR_SB;
+                    }
+                    slot_next();
+                    ++sidx;
+                }
+            }
+        };
+        f32x4 acc1[4 * M1][RT];
+        init_acc(acc1, B1_OFF, std::integral_constant<int, M1>{});
+        dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{});
+        CTS(2);
+        float hs[RT];
+        // head of the last layer: act(acc) . head_w over this lane's 16 features per M-group, then over g
+        auto head = [&](auto& acc, auto MGc) {
+            constexpr int MG = decltype(MGc)::value;
+            act_block<4 * MG>(p.activation, acc);
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) hs[nt] = 0.f;
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                float hw[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(cpar + HW_OFF + 64 * mg + 16 * g + 4 * q);
+                    hw[4 * q] = t.x; hw[4 * q + 1] = t.y; hw[4 * q + 2] = t.z; hw[4 * q + 3] = t.w;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < RT; ++nt)
+                            hs[nt] = fmaf(acc[4 * mg + mt][nt][r], hw[4 * r + mt], hs[nt]);
+            }
+        };
+        if constexpr (M2 > 0) {
+            act_block<4 * M1>(p.activation, acc1);
+            f32x4 acc2[4 * (M2 > 0 ? M2 : 1)][RT];
+            init_acc(acc2, B2_OFF, std::integral_constant<int, M2>{});
+            dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{});
+            head(acc2, std::integral_constant<int, M2>{});
+        } else {
+            head(acc1, std::integral_constant<int, M1>{});
+        }
+        CTS(3);
+        // ---- Dense(1) + linear / FM logits + add[] + global bias, PredictionLayer
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            float v = hs[nt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            v += extras[nt];
+            const int r = row_of(pass, nt);
+            if (g == 0 && r < (int)p.batch) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p.add[i] != nullptr) v += p.add[i][r];
+                if (p.global_bias != nullptr) v += p.global_bias[0];
+                if (p.sigmoid_out) v = dctr::sigmoidf_(v);
+                p.y[r] = v;
+            }
+        }
+        CTS(4);
+    }
+#undef CHAIN_TOP_X
+#undef CHAIN_TOP_ID
+#undef CHAIN_TOP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wrapped-around DMA of the last pass must not outlive the wave
+    if (p.status != nullptr && __any(oor) && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
+    if (p.probe != nullptr && lane == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------
+static int n_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int EB, int M0, int M1, int M2>
+static int launch(const ChainParams& p, unsigned blocks, hipStream_t stream) {
+    const size_t lds = lds_bytes(p.n_dense);
+    static thread_local size_t granted = 0;                            // (the attribute call costs ~10 us: once per size)
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<EB, M0, M1, M2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) {
+            dctr_set_error("embed_mlp_fwd(chain): cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        granted = lds;
+    }
+    DCTR_LAUNCH((chain_kernel<EB, M0, M1, M2>), dim3(blocks), dim3(NT), lds, stream, p);
+    return dctr_launch_status("dctr_embed_mlp_fwd(chain)");
+}
+
+// rows the chained kernel would take of a launch of `batch` rows: whole multiples of (256 rows x CUs), so that every CU
+// runs the same number of passes; 0 = not eligible.  forced: all rows.
+int64_t eligible_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
+    const int E = g->uniform_dim;
+    if (E != 16 && E != 32) return 0;
+    if (g->any_hash || !a->has_head || a->save_acts != nullptr) return 0;
+    if (a->activation == DCTR_ACT_DICE || a->bn_scale != nullptr) return 0;
+    if (a->n_layers != 3 || a->units[0] != 256 || a->units[1] != 128 || a->units[2] != 64) return 0;
+    if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
+    if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
+    if (a->in_dim != g->n_fields * E + (g->n_dense > 0 ? g->n_dense : 0)) return 0;
+    for (int l = 0; l < a->n_layers; ++l)
+        if (!dctr_aligned16(a->kernels[l])) return 0;
+    if (a->batch >= 0x7fffffffLL - PROWS || (int64_t)a->in_dim * a->units[0] * 4 >= (1LL << 31)) return 0;
+    if (forced) return a->batch;
+    const int64_t wave_rows = (int64_t)PROWS * n_cus();
+    return a->batch / wave_rows * wave_rows;
+}
+
+// launches rows [0, rows) of the call (rows from eligible_rows)
+int launch_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int64_t rows,
+                hipStream_t stream) {
+    ChainParams p{};
+    p.fields = g->fields;
+    p.ids = g->ids;
+    p.ids_stride_f = g->ids_stride_f;
+    p.ids_stride_b = g->ids_stride_b;
+    p.ids_is_i64 = g->ids_is_i64;
+    p.n_fields = g->n_fields;
+    p.n_dense = g->n_dense > 0 ? g->n_dense : 0;
+    p.in_dim = a->in_dim;
+    p.dense = g->dense;
+    p.dense_stride = g->dense_stride;
+    p.dense_lin_w = g->dense_lin_w;
+    p.batch = rows;
+    p.fm_logit = g->fm_logit;
+    p.lin_logit = g->lin_logit;
+    p.status = g->status;
+    p.fm_used = fm_used;
+    p.lin_used = lin_used;
+    for (int l = 0; l < 3; ++l) {
+        p.W[l] = a->kernels[l];
+        p.bias[l] = a->biases[l];
+    }
+    p.activation = a->activation;
+    p.sigmoid_out = a->sigmoid_out;
+    p.head_w = a->head_w;
+    for (int i = 0; i < 4; ++i) p.add[i] = a->add[i];
+    p.global_bias = a->global_bias;
+    p.y = a->y;
+    p.probe = a->probe;
+    const int64_t n_pass = dctr_ceil_div(rows, (int64_t)PROWS);
+    p.n_pass = (int)n_pass;
+    const unsigned blocks = (unsigned)(n_pass < n_cus() ? n_pass : n_cus());
+    if (g->uniform_dim == 16) return launch<1, 4, 2, 1>(p, blocks, stream);
+    return launch<2, 4, 2, 1>(p, blocks, stream);
+}
+
+}  // namespace dctr_chain

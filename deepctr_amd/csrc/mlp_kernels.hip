@@ -26,6 +26,11 @@ namespace dctr_stream {
 int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, bool forced,
                hipStream_t stream, int* rc);   // stream_kernels.hip
 }
+namespace dctr_chain {
+int64_t eligible_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);   // chain_kernels.hip
+int launch_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int64_t rows,
+                hipStream_t stream);
+}
 
 namespace {
 
@@ -124,6 +129,27 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         return (size_t)NWAVE * (spw >= rows ? 1 : rows / spw) * 6 * 64;
     };
 
+    // fused launches with >= 256 rows per CU (or tile_rows == 256): the row-chained kernel takes whole multiples of
+    // 256 rows x CUs (every CU the same number of passes); what is left goes on below as a launch of its own
+    if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 256)) {
+        const int64_t rows = dctr_chain::eligible_rows(a, ga, a->tile_rows == 256);
+        DCTR_REQUIRE(a->tile_rows != 256 || rows > 0, DCTR_E_UNSUPPORTED,
+                     "embed_mlp_fwd: tile_rows 256 (row-chained kernel) needs uniform embedding_dim 16 / 32, units 256-128-64, a head");
+        if (rows > 0) {
+            const int rc = dctr_chain::launch_rows(a, ga, fm_used, lin_used, rows, (hipStream_t)stream);
+            if (rc != DCTR_OK || rows == a->batch) return rc;
+            dctr_mlp_args_t a2 = *a;
+            dctr_gather_fm_args_t g2 = *ga;
+            a2.batch = g2.batch = a->batch - rows;
+            a2.y = a->y + rows;
+            for (int i = 0; i < 4; ++i) a2.add[i] = a->add[i] != nullptr ? a->add[i] + rows : nullptr;
+            g2.ids = reinterpret_cast<const char*>(ga->ids) + rows * ga->ids_stride_b * (ga->ids_is_i64 ? 8 : 4);
+            g2.dense = ga->dense != nullptr ? ga->dense + rows * ga->dense_stride : nullptr;
+            g2.fm_logit = ga->fm_logit != nullptr ? ga->fm_logit + rows : nullptr;
+            g2.lin_logit = ga->lin_logit != nullptr ? ga->lin_logit + rows : nullptr;
+            return mlp_launch(&a2, &g2, fm_used, lin_used, stream);
+        }
+    }
     // fused launches with >= 64 rows per CU (or tile_rows == 64): the streaming kernel, when the model is eligible
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 64)) {
         int rc = DCTR_OK;
@@ -133,7 +159,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     // rows per workgroup.  auto: 16 while that still gives every CU a workgroup (latency), else 32
     int rt = a->tile_rows / 16;
     DCTR_REQUIRE(a->tile_rows == 0 || ((rt == 1 || rt == 2 || rt == 4) && a->tile_rows % 16 == 0), DCTR_E_DIM,
-                 "mlp_fwd: tile_rows %d (0, 16, 32 or 64)", a->tile_rows);
+                 "mlp_fwd: tile_rows %d (0, 16, 32 or 64; 256 with dctr_embed_mlp_fwd)", a->tile_rows);
     if (rt == 0) rt = a->batch > 16 * 2 * 256 ? 2 : 1;
     if (ga != nullptr && rt > 2) rt = 2;
     if (ga != nullptr && lpr == 16) rt = 1;                  // embedding_dim > 32: see produce_chunk
