@@ -36,8 +36,30 @@
 #ifdef DCTR_CHAIN_LAB_TS
 __device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][stamp] of workgroup 0, second pass
 #define CTS(i) do { if (blockIdx.x == 0 && it == 1 && (wave == 0 || wave == 7) && lane == 0) dctr_chain_ts[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
+#define CTS_STEP(b, k) do { if ((b) >= 10 && (b) < 14) CTS(8 + 4 * ((b) - 10) + (k)); } while (0)   // inside layer-0 steps 10..13
 #else
 #define CTS(i) do {} while (0)
+#define CTS_STEP(b, k) do {} while (0)
+#endif
+
+// lab ablations (scripts/chain_lab.cpp): what a step costs without its gather / its weight DMA / its barrier
+#ifdef DCTR_CHAIN_LAB_NOGATHER
+#define CHAIN_GATHER 0
+#else
+#define CHAIN_GATHER 1
+#endif
+#ifdef DCTR_CHAIN_LAB_NODMA
+#define CHAIN_DMA 0
+#else
+#define CHAIN_DMA 1
+#endif
+#ifdef DCTR_CHAIN_LAB_NOBARRIER
+#define CHAIN_BARRIER "s_nop 0"
+#else
+#define CHAIN_BARRIER "s_barrier"
+#endif
+#ifndef CHAIN_PHASE_U
+#define CHAIN_PHASE_U 0                        // micro-step after which a step's request phase is issued
 #endif
 
 namespace dctr_chain {
@@ -88,6 +110,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // address path): the global address space is stated explicitly
 typedef const __attribute__((address_space(1))) f32x4* gbl_f4_t;
 typedef const __attribute__((address_space(1))) float* gbl_f_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x2* gbl_u2_t;
+typedef const __attribute__((address_space(1))) uint32_t* gbl_u_t;
 
 // field descriptor words as they lie in LDS (copied once per launch); decoded to scalars where they are used
 struct FieldRaw {
@@ -126,15 +151,13 @@ __device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][2]) {
     }
 }
 
-// the gathered operand of one k-block for this lane: 16-B piece g of row j's embedding per N tile, and the field's
-// linear-table entry
+// the gathered operand of one k-block for this lane: 16-B piece g of row j's embedding per N tile
 struct XBlk {
     f32x4 x[RT];
-    float lv[RT];
 };
 
-// EB = embedding_dim / 16 k-blocks per field; M0 / M1 / M2 = units[l] / 64 (M2 == 0: two layers)
-template <int EB, int M0, int M1, int M2>
+// EB = embedding_dim / 16 k-blocks per field; I64: int64 ids; M0 / M1 / M2 = units[l] / 64 (M2 == 0: two layers)
+template <int EB, bool I64, int M0, int M1, int M2>
 __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
     constexpr int NL = M2 > 0 ? 3 : 2;
     constexpr int ML = NL == 3 ? M2 : M1;          // M-groups of the last layer
@@ -142,7 +165,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
     constexpr int SL = S1 + S2;
     static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
     constexpr int E = 16 * EB;
-    constexpr int B1_OFF = 64 * M0, B2_OFF = B1_OFF + 64 * M1, HW_OFF = B2_OFF + 64 * M2;
+    constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair
+    constexpr int B1_OFF = 64 * M0, B2_OFF = B1_OFF + 64 * M1, HW_OFF = B2_OFF + 64 * M2, GB_OFF = HW_OFF + 64 * ML;
+    static_assert(GB_OFF < FDESC_OFF, "biases + head weights + global bias must fit the parameter area");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cpar = smem + CPAR_OFF;
     float* fdesc = smem + FDESC_OFF;
@@ -160,6 +185,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
     if constexpr (M2 > 0)
         for (int i = threadIdx.x; i < 64 * M2; i += NT) cpar[B2_OFF + i] = p.bias[2] != nullptr ? p.bias[2][i] : 0.f;
     for (int i = threadIdx.x; i < 64 * ML; i += NT) cpar[HW_OFF + i] = p.head_w[i];
+    if (threadIdx.x == 0) cpar[GB_OFF] = p.global_bias != nullptr ? p.global_bias[0] : 0.f;
     for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
 
     const int NBE = p.n_fields * EB;               // embedding k-blocks
@@ -176,8 +202,8 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
     // can see with s_waitcnt vmcnt(0) (it cannot prove the chunk being filled is not the chunk being read), which would
     // stall each step on the loads it has just requested.  Unseen, the DMA only makes hipcc's own vmcnt bookkeeping for
     // the register loads conservative (more operations in the queue than it counts: it can over-wait, never under-wait).
-    // (the lane index is made opaque per call: otherwise the per-lane source offsets of all ten layer >= 1 chunks are
-    // hoisted out of the persistent loop as loop invariants — live VGPRs across the whole pass, i.e. spills)
+    // Addresses are a scalar base + one per-lane 32-bit offset (the lane index is made opaque per call: otherwise the
+    // offsets of all ten layer >= 1 chunks are hoisted out of the persistent loop — live VGPRs across the pass, i.e. spills)
     auto dma16 = [&](const void* sbase, uint32_t voff, float* dst) {
         const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)dst;
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
@@ -186,28 +212,33 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
         constexpr int ROW_B = 256 * M0;
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);                  // this lane's byte inside piece `wave`
+        if (16 * b + 16 <= p.in_dim) {                                         // a whole block: 16 KiB (M0 = 4) as they lie
+            const char* base = reinterpret_cast<const char*>(p.W[0]) + (size_t)b * (16 * ROW_B);
 #pragma unroll
-        for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW) {
-            const int pc = pc0 + wave;
-            if (pc < 4 * M0) {
-                const int o = pc * 1024 + 16 * ln;
-                const int krow = min(16 * b + o / ROW_B, k_last);      // rows past K: a finite stand-in (x is 0 there)
-                dma16(p.W[0], (uint32_t)(krow * ROW_B + (o % ROW_B)), dst + pc * 256);
-            }
+            for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
+                if (pc0 + wave < 4 * M0) dma16(base + pc0 * 1024, o, dst + (pc0 + wave) * 256);
+        } else {                                                               // K tail: rows past K get a finite stand-in
+#pragma unroll
+            for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
+                if (pc0 + wave < 4 * M0) {
+                    const uint32_t oo = o + pc0 * 1024;
+                    const int krow = min(16 * b + (int)(oo / ROW_B), k_last);
+                    dma16(p.W[0], (uint32_t)krow * ROW_B + (oo % ROW_B), dst + (pc0 + wave) * 256);
+                }
         }
     };
     auto dma_ln = [&](const float* W, int N, int mg, int mg1, float* dst) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);
+        const uint32_t voff = (o >> 8) * (uint32_t)(N * 4) + (o & 255u);       // image row o / 256 <-> weight row, 256 B of it
         const char* base = reinterpret_cast<const char*>(W) + ((size_t)(64 * mg) * N + 64 * mg1) * 4;   // scalar
 #pragma unroll
-        for (int pc0 = 0; pc0 < 16; pc0 += NW) {
-            const int pc = pc0 + wave;
-            const int o = pc * 1024 + 16 * ln;
-            dma16(base, (uint32_t)(o >> 8) * (uint32_t)(N * 4) + (uint32_t)(o & 255), dst + pc * 256);
-        }
+        for (int pc0 = 0; pc0 < 16; pc0 += NW) dma16(base + (size_t)(4 * pc0) * N * 4, voff, dst + (pc0 + wave) * 256);
     };
     auto dma_chunk = [&](int ci, float* dst) {
+        if (!CHAIN_DMA) return;
         if (ci >= STEPS) ci -= STEPS;
         if (ci < NB) {
             dma_l0(ci, dst);
@@ -231,32 +262,62 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
     };
     auto slot_next = [&]() { slot = slot + 1 == NSLOT ? 0 : slot + 1; };
 
-    // ---- rows of this lane in a pass (launches are cut to < 2^31 rows by the host)
+    // ---- rows.  MFMA layout: lane (g, j) works for rows 16 nt + j of the wave's 32 (launches are cut to < 2^31 rows by
+    // the host).  Ids and linear-table entries are handled ROW PER LANE for a PAIR of fields at once: lane l = row (l & 31)
+    // of field 2 pr + (l >> 5) — one id load, one range check, one linear-table load per field pair instead of per k-block
+    // and N tile; a k-block's ids reach the (g, j) lanes through ds_bpermute (the LDS crossbar, no memory traffic)
     auto row_of = [&](int pass, int nt) -> int { return pass * PROWS + 32 * wave + 16 * nt + j; };
     auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), (int)p.batch - 1); };
+    const int q = lane >> 5;                           // which field of the pair this lane serves
     int oor = 0;
-    auto request_ids = [&](int cb, int pass, RawId (&id)[RT]) {
-        const int f = min(cb / EB, p.n_fields - 1);
-#pragma unroll
-        for (int nt = 0; nt < RT; ++nt)
-            id[nt] = load_id(p.ids, (int64_t)f * p.ids_stride_f + (int64_t)brow_of(pass, nt) * p.ids_stride_b, p.ids_is_i64);
+    // request the ids of field pair pr for the rows of `pass`
+    auto request_pair_ids = [&](int pr, int pass, uint32_t& lo, uint32_t& hi) {
+        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const int r = min(pass * PROWS + 32 * wave + (lane & 31), (int)p.batch - 1);
+        const int64_t eo = (int64_t)fi * p.ids_stride_f + (int64_t)r * p.ids_stride_b;
+        if constexpr (I64) {
+            const u32x2 v = *(gbl_u2_t)(reinterpret_cast<const u32x2*>(p.ids) + eo);
+            lo = v[0];
+            hi = v[1];
+        } else {
+            lo = *(gbl_u_t)(reinterpret_cast<const uint32_t*>(p.ids) + eo);
+        }
     };
-    // issue the loads of embedding k-block cb (ids already here) for the rows of `pass`
-    auto issue_x = [&](int cb, int pass, const RawId (&id)[RT], XBlk& X) {
+    // landed ids -> rows: range check against the field's vocabulary, out-of-range ids read row 0 and raise the flag
+    auto fold_pair_ids = [&](int pr, int pass, uint32_t lo, uint32_t hi) -> uint32_t {
+        const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
+        const uint2 va = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 4);
+        const uint2 vb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 4);
+        const uint64_t voc_a = sgpr64(va.x, va.y), voc_b = sgpr64(vb.x, vb.y);
+        const uint32_t lim_a = (voc_a >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_a;
+        const uint32_t lim_b = (voc_b >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_b;
+        const uint32_t lim = q ? lim_b : lim_a;
+        const uint32_t upper = I64 ? hi : (uint32_t)((int32_t)lo >> 31);      // anything but 0: negative or >= 2^32
+        const bool ok = upper == 0u && lo < lim;
+        const bool counts = pass * PROWS + 32 * wave + (lane & 31) < (int)p.batch && 2 * pr + q < p.n_fields;
+        if (!ok && counts) oor = 1;
+        return ok ? lo : 0u;
+    };
+    // linear-table entries of the pair (row per lane); fields without a linear table, or past the last field, give 0
+    auto pair_lin_ptr = [&](int pr, uint32_t idc, bool& has) -> gbl_f_t {
+        const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
+        const uint2 la = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 2);
+        const uint2 lb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 2);
+        const uint64_t lin_a = sgpr64(la.x, la.y), lin_b = sgpr64(lb.x, lb.y);
+        const uint64_t base = q ? lin_b : lin_a;
+        has = base != 0 && 2 * pr + q < p.n_fields;
+        const float* t = has ? reinterpret_cast<const float*>(base) : reinterpret_cast<const float*>(p.fields);
+        return (gbl_f_t)(t + (has ? idc : 0u));
+    };
+    // issue the row loads of embedding k-block cb: its ids are half `half` of the folded pair ids `idc`
+    auto issue_x = [&](int cb, uint32_t idc, int half, XBlk& X) {
         const int f = cb / EB, h = cb % EB;
-        const FieldRaw fr = field_raw(fdesc, f);
-        const float* table = reinterpret_cast<const float*>(sgpr64(fr.a.x, fr.a.y));
-        const float* lin_table = reinterpret_cast<const float*>(sgpr64(fr.a.z, fr.a.w));
-        const int64_t vocab = (int64_t)sgpr64(fr.b.x, fr.b.y);
+        const uint2 tw = *reinterpret_cast<const uint2*>(fdesc + 12 * f);
+        const float* table = reinterpret_cast<const float*>(sgpr64(tw.x, tw.y));
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
-            int64_t idk = id_value(id[nt], p.ids_is_i64);
-            const bool ok = (uint64_t)idk < (uint64_t)vocab;
-            if (!ok && row_of(pass, nt) < (int)p.batch) oor = 1;
-            idk = ok ? idk : 0;
-            X.x[nt] = *(gbl_f4_t)(table + idk * E + 16 * h + 4 * g);
-            X.lv[nt] = 0.f;
-            if (h == 0 && lin_table != nullptr) X.lv[nt] = *(gbl_f_t)(lin_table + idk);
+            const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (32 * half + 16 * nt + j), (int)idc);
+            X.x[nt] = *(gbl_f4_t)(table + (size_t)idv * E + (16 * h + 4 * g));
         }
     };
     // dense features of a pass: requested, then (a step later) written zero-padded to this wave's LDS rows — the dense
@@ -294,35 +355,31 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
     };
 
     // ---- the barrier of a step: everything this wave requested has landed (its share of the chunk after this one, the
-    // next k-block's rows, ids), all eight waves have finished reading the previous chunk.  The in-flight registers are
-    // named so that hipcc places its own bookkeeping wait here and not in front of their first use
-#define CHAIN_TOP_X(X, ID)                                                                                       \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                     \
-                 : "+v"(X.x[0]), "+v"(X.x[1]), "+v"(X.lv[0]), "+v"(X.lv[1]), "+v"(ID[0].lo), "+v"(ID[0].hi),       \
-                   "+v"(ID[1].lo), "+v"(ID[1].hi)                                                                  \
+    // next k-block's rows, ids, linear entries), all eight waves have finished reading the previous chunk.  The in-flight
+    // registers are named so that hipcc places its own bookkeeping wait here and not in front of their first use
+#define CHAIN_TOP_X(X)                                                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER                                                \
+                 : "+v"(X.x[0]), "+v"(X.x[1]), "+v"(lvn), "+v"(idr_lo), "+v"(idr_hi)                               \
                  :                                                                                               \
                  : "memory")
-#define CHAIN_TOP_ID(ID)                                                                                         \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                     \
-                 : "+v"(ID[0].lo), "+v"(ID[0].hi), "+v"(ID[1].lo), "+v"(ID[1].hi)                                  \
-                 :                                                                                               \
-                 : "memory")
-#define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define CHAIN_TOP_ID()                                                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(idr_lo), "+v"(idr_hi) : : "memory")
+#define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER ::: "memory")
 
     // A-operand lane offsets (floats) inside a chunk image
     const int l0off = (4 * g) * (64 * M0) + 4 * j;     // layer 0: k-step t reads row 4g + t, M-group mg at + 64 mg
     const int lnoff = (16 * g) * 64 + 4 * j;           // layers >= 1: k-step (mt, r) reads row 16g + 4r + mt
 
-    // ---- prologue: chunks 0 and 1, the dense values, ids and rows of k-block 0, ids of k-block 1 of the first pass
+    // ---- prologue: chunks 0 and 1, the dense values, ids of field pair 0, rows of k-block 0 of the first pass
     XBlk XA, XB;
-    RawId idn[RT];
+    uint32_t idr_lo = 0u, idr_hi = 0u;                 // raw ids of a field pair between their request and the range check
+    uint32_t idc = 0u;                                 // checked ids (= table rows) of the current field pair
+    float lvn = 0.f;                                   // linear-table entries of the current pair, in flight / landed
     float dlin_n[RT];                                  // dense . dense_lin_w share of this lane for the staged pass
 #pragma unroll
     for (int nt = 0; nt < RT; ++nt) {
         XA.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         XB.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        XA.lv[nt] = XB.lv[nt] = 0.f;
-        idn[nt].lo = idn[nt].hi = 0u;
         dlin_n[nt] = 0.f;
     }
     __syncthreads();                                   // LDS parameters written
@@ -332,16 +389,16 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
         const int pass0 = min((int)blockIdx.x, p.n_pass - 1);
         dma_chunk(0, slot_ptr(0));
         dma_chunk(1, slot_ptr(1));
-        request_ids(0, pass0, idn);
+        request_pair_ids(0, pass0, idr_lo, idr_hi);
         float td[RT][4];
         if (NDB > 0) dense_request(0, pass0, td);
-        CHAIN_TOP_ID(idn);
+        CHAIN_TOP_ID();
         if (NDB > 0) {
             dense_store(0, td, dlin_n);
             dense_rest(pass0, dlin_n);
         }
-        issue_x(0, pass0, idn, XA);
-        request_ids(1, pass0, idn);
+        idc = fold_pair_ids(0, pass0, idr_lo, idr_hi);
+        issue_x(0, idc, 0, XA);
     }
 
     for (int it = 0, pass = blockIdx.x; pass < p.n_pass; ++it, pass += gridDim.x) {
@@ -354,9 +411,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
         for (int mg = 0; mg < M0; ++mg) {
             float bv[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 t = *reinterpret_cast<const float4*>(cpar + 64 * mg + 16 * g + 4 * q);
-                bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 t = *reinterpret_cast<const float4*>(cpar + 64 * mg + 16 * g + 4 * qq);
+                bv[4 * qq] = t.x; bv[4 * qq + 1] = t.y; bv[4 * qq + 2] = t.z; bv[4 * qq + 3] = t.w;
             }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -366,12 +423,14 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
         }
         float dlin[RT];
         f32x4 sum[EB][RT];
-        float sq[RT], lin[RT];
+        float sq[RT];
+        float linacc = 0.f;                            // row-per-lane: this lane's field of every pair
+        uint32_t idcn = 0u;                            // checked ids of the NEXT field pair
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
             dlin[nt] = dlin_n[nt];
             dlin_n[nt] = 0.f;
-            sq[nt] = lin[nt] = 0.f;
+            sq[nt] = 0.f;
 #pragma unroll
             for (int h = 0; h < EB; ++h) sum[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -390,14 +449,12 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
                 for (int nt = 0; nt < RT; ++nt)
                     acc0[4 * mg + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], X.x[nt][t], acc0[4 * mg + mt][nt], 0, 0, 0);
         };
-        // FM / linear bookkeeping of the embedding block being multiplied (lane-local)
+        // FM bookkeeping of the embedding block being multiplied (lane-local)
         auto consume_x = [&](int b, const XBlk& X) {
             const int f = b / EB, h = b % EB;
-            const bool in_fm = (fm_mask >> f) & 1ull;
+            if ((fm_mask >> f) & 1ull) {
 #pragma unroll
-            for (int nt = 0; nt < RT; ++nt) {
-                lin[nt] += X.lv[nt];
-                if (in_fm) {
+                for (int nt = 0; nt < RT; ++nt) {
 #pragma unroll
                     for (int hh = 0; hh < EB; ++hh)
                         if (hh == h) sum[hh][nt] += X.x[nt];
@@ -406,17 +463,44 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
                 }
             }
         };
-        // one layer-0 step: k-block B multiplies with XC while XN (k-block B + 1) and the ids of B + 2 are requested.
-        // A dense k-block takes its operand from the staging rows in LDS instead (uniform branch, once or so per pass)
-#define CHAIN_STEP0(B, XC, XN)                                                                                   \
+        // the request phase of layer-0 step (k-block b_ = step s_ of field pair pr_): DMA share of the chunk after next,
+        // rows of the next k-block, and once per pair: the pair's linear entries (s = 0), the next pair's ids (s = PAIR - 2),
+        // their range check (s = PAIR - 1).  A dense k-block takes its operand from the staging rows in LDS instead
+#define CHAIN_PHASE0(XC, XN)                                                                                     \
         {                                                                                                        \
-            const int b_ = (B);                                                                                  \
-            CHAIN_TOP_X(XC, idn);                                                                                \
+            CTS_STEP(b_, 3);                                                                                     \
+            dma_chunk(b_ + 2, slot_ptr(2));                                                                      \
+            if (CHAIN_GATHER) {                                                                                  \
+                const bool next_pair_ = (pr_ + 1) * PAIR < NBE;                                                  \
+                if (s_ == 1 && b_ - 1 < NBE) {                                                                   \
+                    bool has_;                                                                                   \
+                    (void)pair_lin_ptr(pr_, 0u, has_);                                                           \
+                    linacc += has_ ? lvn : 0.f;                                                                  \
+                }                                                                                                \
+                if (s_ == PAIR - 1 && next_pair_) idcn = fold_pair_ids(pr_ + 1, pass, idr_lo, idr_hi);           \
+                if (b_ + 1 < NBE) {                                                                              \
+                    if (s_ + 1 < PAIR) issue_x(b_ + 1, idc, (s_ + 1) / EB, XN);                                  \
+                    else issue_x(b_ + 1, idcn, 0, XN);                                                           \
+                }                                                                                                \
+                if (s_ == 0 && b_ < NBE) {                                                                       \
+                    bool has_;                                                                                   \
+                    lvn = *pair_lin_ptr(pr_, idc, has_);                                                         \
+                }                                                                                                \
+                if (s_ == PAIR - 2 && next_pair_) request_pair_ids(pr_ + 1, pass, idr_lo, idr_hi);               \
+                if (b_ < NBE) consume_x(b_, XC);                                                                 \
+            }                                                                                                    \
+            CTS_STEP(b_, 2);                                                                                     \
+        }
+#define CHAIN_STEP0(S, XC, XN)                                                                                   \
+        {                                                                                                        \
+            constexpr int s_ = (S);                                                                              \
+            const int b_ = pr_ * PAIR + s_;                                                                      \
+            CTS_STEP(b_, 0);                                                                                     \
+            CHAIN_TOP_X(XC);                                                                                     \
+            CTS_STEP(b_, 1);                                                                                     \
             const float* sb_ = slot_ptr(0);                                                                      \
             if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
-            if (b_ < NBE) {                                                                                      \
-                consume_x(b_, XC);                                                                               \
-            } else {                                                                                             \
+            if (b_ >= NBE) {                                                                                     \
                 _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
                     XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
             }                                                                                                    \
@@ -425,11 +509,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
                 DCTR_SB;                                                                                         \
                 mfma_l0(c0, XC, u_);                                                                             \
                 DCTR_SB;                                                                                         \
-                if (u_ == 0) {                                                                                   \
-                    dma_chunk(b_ + 2, slot_ptr(2));                                                              \
-                    if (b_ + 1 < NBE) issue_x(b_ + 1, pass, idn, XN);                                            \
-                    request_ids(min(b_ + 2, NBE - 1), pass, idn);                                                \
-                }                                                                                                \
+                if (u_ == CHAIN_PHASE_U) CHAIN_PHASE0(XC, XN)                                                    \
                 if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                                  \
                 else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                              \
                 DCTR_SB;                                                                                         \
@@ -438,33 +518,43 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
             }                                                                                                    \
             slot_next();                                                                                         \
         }
-        for (int b = 0; b < NB; b += 2) {
-            CHAIN_STEP0(b, XA, XB);
-            if (b + 1 < NB) CHAIN_STEP0(b + 1, XB, XA);
+        for (int pr_ = 0; pr_ * PAIR < NB; ++pr_) {
+            CHAIN_STEP0(0, XA, XB);
+            if (pr_ * PAIR + 1 < NB) CHAIN_STEP0(1, XB, XA);
+            if constexpr (EB == 2) {
+                if (pr_ * PAIR + 2 < NB) CHAIN_STEP0(2, XA, XB);
+                if (pr_ * PAIR + 3 < NB) CHAIN_STEP0(3, XB, XA);
+            }
+            idc = idcn;
         }
 #undef CHAIN_STEP0
+#undef CHAIN_PHASE0
         CTS(1);
-        // ---- gather epilogue of the pass: FM = 0.5 (sum_d (sum_f e)^2 - sum_{f,d} e^2), linear; lane-local, then over g
+        // ---- gather epilogue of the pass: FM = 0.5 (sum_d (sum_f e)^2 - sum_{f,d} e^2) lane-local, then over g; the linear
+        // terms sit row per lane (lane l and l + 32: the two fields of every pair) and go to the (g, j) lanes by bpermute
         float extras[RT];
+        {
+            const float lin_rows = linacc + __shfl_xor(linacc, 32, 64);
 #pragma unroll
-        for (int nt = 0; nt < RT; ++nt) {
-            float fm = -sq[nt];
+            for (int nt = 0; nt < RT; ++nt) {
+                float fm = -sq[nt];
 #pragma unroll
-            for (int h = 0; h < EB; ++h)
+                for (int h = 0; h < EB; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fm = fmaf(sum[h][nt][e], sum[h][nt][e], fm);
-            fm += __shfl_xor(fm, 16, 64);
-            fm += __shfl_xor(fm, 32, 64);
-            fm *= 0.5f;
-            float dl = dlin[nt];
-            dl += __shfl_xor(dl, 16, 64);
-            dl += __shfl_xor(dl, 32, 64);
-            const float lin_all = lin[nt] + dl;            // every lane of a row loaded the row's linear entries itself
-            extras[nt] = (p.fm_used ? fm : 0.f) + (p.lin_used ? lin_all : 0.f);
-            const int r = row_of(pass, nt);
-            if (g == 0 && r < (int)p.batch) {
-                if (p.fm_logit != nullptr) p.fm_logit[r] = fm;
-                if (p.lin_logit != nullptr) p.lin_logit[r] = lin_all;
+                    for (int e = 0; e < 4; ++e) fm = fmaf(sum[h][nt][e], sum[h][nt][e], fm);
+                fm += __shfl_xor(fm, 16, 64);
+                fm += __shfl_xor(fm, 32, 64);
+                fm *= 0.5f;
+                float dl = dlin[nt];
+                dl += __shfl_xor(dl, 16, 64);
+                dl += __shfl_xor(dl, 32, 64);
+                const float lin_all = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * nt + j), __builtin_bit_cast(int, lin_rows))) + dl;
+                extras[nt] = (p.fm_used ? fm : 0.f) + (p.lin_used ? lin_all : 0.f);
+                const int r = row_of(pass, nt);
+                if (g == 0 && r < (int)p.batch) {
+                    if (p.fm_logit != nullptr) p.fm_logit[r] = fm;
+                    if (p.lin_logit != nullptr) p.lin_logit[r] = lin_all;
+                }
             }
         }
         // activation in place: acc0 is now the B operand of layer 1
@@ -483,9 +573,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
             for (int mg = 0; mg < MGc; ++mg) {
                 float bv[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(cpar + boff + 64 * mg + 16 * g + 4 * q);
-                    bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 t = *reinterpret_cast<const float4*>(cpar + boff + 64 * mg + 16 * g + 4 * qq);
+                    bv[4 * qq] = t.x; bv[4 * qq + 1] = t.y; bv[4 * qq + 2] = t.z; bv[4 * qq + 3] = t.w;
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -502,7 +592,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
                 for (int mg1 = 0; mg1 < MO; ++mg1) {
                     const bool first = sidx == 0;                  // no prefetch across the layer-0 boundary
                     const bool last = sidx == SL - 1;
-                    if (last) CHAIN_TOP_ID(idn);                   // the ids requested in the step before
+                    if (last) CHAIN_TOP_ID();                      // the ids requested in the step before
                     else CHAIN_TOP();
                     const float* sb = slot_ptr(0);
                     if (last && NDB > 0) {                         // the next pass's dense values have landed
@@ -521,16 +611,16 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
                                 accout[4 * mg1 + mt1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                     c0[mt1], accin[4 * mg + (ks >> 2)][nt][ks & 3], accout[4 * mg1 + mt1][nt], 0, 0, 0);
                         DCTR_SB;
-                        if (ks == 0) {
-                            // after the first k-step: the chunk after next, and at the pass's end the next pass's gather
+                        if (ks == CHAIN_PHASE_U) {
+                            // the chunk after next, and at the pass's end the next pass's gather prologue
                             dma_chunk(NB + sidx + 2, slot_ptr(2));
                             if (sidx == SL - 2) {
-                                request_ids(0, pass_n, idn);
+                                request_pair_ids(0, pass_n, idr_lo, idr_hi);
                                 if (NDB > 0) dense_request(0, pass_n, td);
                             }
                             if (last) {
-                                issue_x(0, pass_n, idn, XA);
-                                request_ids(1, pass_n, idn);
+                                idc = fold_pair_ids(0, pass_n, idr_lo, idr_hi);
+                                issue_x(0, idc, 0, XA);
                             }
                         }
                         if (ks + 2 < 16) c0 = read_an(sb, ks + 2);
@@ -564,9 +654,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
             for (int mg = 0; mg < MG; ++mg) {
                 float hw[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(cpar + HW_OFF + 64 * mg + 16 * g + 4 * q);
-                    hw[4 * q] = t.x; hw[4 * q + 1] = t.y; hw[4 * q + 2] = t.z; hw[4 * q + 3] = t.w;
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 t = *reinterpret_cast<const float4*>(cpar + HW_OFF + 64 * mg + 16 * g + 4 * qq);
+                    hw[4 * qq] = t.x; hw[4 * qq + 1] = t.y; hw[4 * qq + 2] = t.z; hw[4 * qq + 3] = t.w;
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -599,7 +689,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (p.add[i] != nullptr) v += p.add[i][r];
-                if (p.global_bias != nullptr) v += p.global_bias[0];
+                v += cpar[GB_OFF];
                 if (p.sigmoid_out) v = dctr::sigmoidf_(v);
                 p.y[r] = v;
             }
@@ -628,12 +718,12 @@ static int n_cus() {
     return n;
 }
 
-template <int EB, int M0, int M1, int M2>
+template <int EB, bool I64, int M0, int M1, int M2>
 static int launch(const ChainParams& p, unsigned blocks, hipStream_t stream) {
     const size_t lds = lds_bytes(p.n_dense);
     static thread_local size_t granted = 0;                            // (the attribute call costs ~10 us: once per size)
     if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<EB, M0, M1, M2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<EB, I64, M0, M1, M2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) {
             dctr_set_error("embed_mlp_fwd(chain): cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
@@ -641,7 +731,7 @@ static int launch(const ChainParams& p, unsigned blocks, hipStream_t stream) {
         }
         granted = lds;
     }
-    DCTR_LAUNCH((chain_kernel<EB, M0, M1, M2>), dim3(blocks), dim3(NT), lds, stream, p);
+    DCTR_LAUNCH((chain_kernel<EB, I64, M0, M1, M2>), dim3(blocks), dim3(NT), lds, stream, p);
     return dctr_launch_status("dctr_embed_mlp_fwd(chain)");
 }
 
@@ -699,8 +789,8 @@ int launch_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm
     const int64_t n_pass = dctr_ceil_div(rows, (int64_t)PROWS);
     p.n_pass = (int)n_pass;
     const unsigned blocks = (unsigned)(n_pass < n_cus() ? n_pass : n_cus());
-    if (g->uniform_dim == 16) return launch<1, 4, 2, 1>(p, blocks, stream);
-    return launch<2, 4, 2, 1>(p, blocks, stream);
+    if (g->uniform_dim == 16) return g->ids_is_i64 ? launch<1, true, 4, 2, 1>(p, blocks, stream) : launch<1, false, 4, 2, 1>(p, blocks, stream);
+    return g->ids_is_i64 ? launch<2, true, 4, 2, 1>(p, blocks, stream) : launch<2, false, 4, 2, 1>(p, blocks, stream);
 }
 
 }  // namespace dctr_chain

@@ -140,8 +140,11 @@ int main(int argc, char** argv) {
     // ---- timing
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flop_row = 2.0 * ((double)in_dim * 256 + 256 * 128 + 128 * 64 + 64);
+    const bool quick = getenv("CHAIN_LAB_QUICK") != nullptr;
     for (int64_t B : {int64_t(65536), int64_t(81920), int64_t(131072), int64_t(262144)}) {
+        if (quick && B != 262144) continue;
         for (int tr : {256, 0, 64}) {
+            if (quick && tr != 256) continue;
             for (int w = 0; w < 3; ++w) if (run(B, tr, y1, 1)) return 1;
             CK(hipStreamSynchronize(st));
             const int R = 10;
