@@ -11,10 +11,13 @@ term + FM -> DNN 429-256-128-64 + Dense(1) + logit sum + sigmoid.  Nothing is sk
 before the timed region, every step reads a DIFFERENT batch of ids (a ring of distinct batches).
 
 How the K steps are issued.  The forward is row-independent and the fused path owns no per-batch buffer, so the product
-(`model.predict`) hands the library spans of many batches per launch; `dctr_embed_mlp_fwd` then runs its persistent
-streaming kernel (csrc/stream_kernels.hip: 64-row tiles, LDS-DMA gather ring, loader + MFMA waves).  The bench does
-the same: the K steps go out as ceil(K / G) launches of G consecutive batches (--launch-batches, default min(K, 64)),
-exactly K * 4096 rows per GPU inside the timed region, bracketed by barrier + synchronize, MAX over ranks.
+(`model.predict`) hands the library spans of many batches per call; `dctr_embed_mlp_fwd` then runs its persistent
+row-chained kernel (csrc/chain_device.h: a wave owns 32 batch rows end to end, weights = MFMA A operand through an LDS-DMA
+ring, a layer's accumulators are the next layer's B operand, gather HBM -> registers).  A call is cut into kernel launches
+(`dctr_embed_mlp_fwd_plan`): whole multiples of 256 rows x CUs in the 256-rows-per-workgroup shape, the rest in the 128- /
+64-row shapes.  The bench does the same: the K steps go out as ceil(K / G) calls of G consecutive batches
+(--launch-batches, default min(K, 64)), exactly K * 4096 rows per GPU inside the timed region, bracketed by barrier +
+synchronize, MAX over ranks.
 `one_launch_per_batch` in the JSON line is the other extreme measured right after (one launch per 4096-row batch, K of
 them in one hipGraph on 8 streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
 
@@ -22,12 +25,14 @@ Multi-GPU: rows shard across ranks, tables replicated, the forward is collective
 all-gathered ONCE (RCCL) inside the timed region — the path's only exchange.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the timed region = stream_kernel (fused gather + DNN).  It is bound by the fp32
-                matrix pipe (301,696 DNN FLOP/sample against 1,928 algorithmic HBM bytes/sample): achieved TFLOP/s =
-                algorithmic FLOP per launch / mean launch duration, measured live: every launch of the timed region goes
-                out through hipExtLaunchKernelGGL with a start/stop event pair on its own stream (dctr_profile_arm) =
-                the quantity rocprofv3 --kernel-trace reports; peak 157.3 TF; its HBM figure (algorithmic bytes / the
-                same duration, of 8 TB/s) is reported next to it as hbm_frac.  `traffic` = FETCH_SIZE + WRITE_SIZE per
+  roofline      the dominant kernel of the timed region = chain_kernel, 256-row shape (fused gather + DNN).  It is bound by
+                the fp32 matrix pipe (301,696 DNN FLOP/sample against 1,928 algorithmic HBM bytes/sample): achieved TFLOP/s =
+                algorithmic FLOP per launch / mean launch duration, measured live: every kernel launch of the timed region
+                goes out through hipExtLaunchKernelGGL with a start/stop event pair on its own stream (dctr_profile_arm) =
+                the quantity rocprofv3 --kernel-trace reports (an identical replay of the region right after the `value`
+                region: the event pairs isolate consecutive kernels, which would cost the value region ~10 %); peak 157.3 TF; its HBM figure (algorithmic bytes / the
+                same duration, of 8 TB/s) is reported next to it as hbm_frac.  `kernel_launches` lists every kernel launch
+                of one call (rows, shape, mean duration).  `traffic` = FETCH_SIZE + WRITE_SIZE per
                 launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json, `traffic_source`), scaled
                 to this launch's rows — not measured in this run.
   kernels       isolated single-batch launches of the 32-row fused kernel and of the two stand-alone kernels of the unfused
@@ -179,8 +184,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-launch-per-batch and long-run measurements")
     ap.add_argument("--streams", type=int, default=8, help="one-launch-per-batch mode: batches in flight (graph branches)")
     ap.add_argument("--tile-rows", type=int, default=0,
-                    help="rows per workgroup of the fused kernel: 0 = library default (streaming 64-row tiles for launches "
-                         "of >= 64 rows per CU, else 16 / 32), 16 / 32 = the tile kernel, 64 = streaming kernel always")
+                    help="rows per workgroup of the fused kernel: 0 = library default (row-chained kernel for launches of "
+                         ">= 64 rows per CU, else 16 / 32), 16 / 32 = the tile kernel, 64 = streaming kernel, 128 / 256 = one "
+                         "shape of the row-chained kernel")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"], help="id distribution (SURVEY 8(d))")
     args = ap.parse_args()
 
@@ -219,6 +225,8 @@ def main():
         lo = (s0 % ring) * B
         launches.append((lo, lo + nb * B, s0 * B, (s0 + nb) * B))
 
+    plans = [model.launch_plan(staged, lo, hi, logits[o0:o1]) if fused else [(hi - lo, "unfused", 0)] for lo, hi, o0, o1 in launches]
+    n_kern = sum(len(pl) for pl in plans) if fused else 2 * len(launches)          # kernel launches of the timed region
     if fused:                                  # argument structs marshalled before the timed region: one ctypes call per launch
         prepared = [model.prepare_launch(staged, lo, hi, logits[o0:o1]) for lo, hi, o0, o1 in launches]
     else:
@@ -232,10 +240,10 @@ def main():
         nb = min(G, W - i)
         model._forward(staged, 0, nb * B, logits[:nb * B])
     if K > 0:                                                              # ... and once through the timed region's own launches,
-        lib.dctr_profile_arm(min(len(launches), 256))                      # armed, so that the event pairs exist beforehand
+        lib.dctr_profile_arm(min(n_kern, 256))                             # armed, so that the event pairs exist beforehand
         run_steps()
         tmp = (ctypes.c_float * 256)()
-        lib.dctr_profile_collect(tmp, min(len(launches), 256))
+        lib.dctr_profile_collect(tmp, min(n_kern, 256))
     torch.cuda.synchronize()
 
     def barrier():
@@ -251,7 +259,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         if arm:
-            lib.dctr_profile_arm(min(len(launches), 256))
+            lib.dctr_profile_arm(min(n_kern, 256))
         t0 = time.perf_counter()
         run_steps()
         if dist is not None:
@@ -260,10 +268,14 @@ def main():
         barrier()
         return time.perf_counter() - t0
 
-    elapsed = timed_region(arm=True)
+    elapsed = timed_region(arm=False)                       # `value`: the K steps, nothing else in the region
+    # the same region once more with an event pair around every kernel launch (hipExtLaunchKernelGGL start / stop events on
+    # the launch's own stream): the per-kernel durations of the roofline object.  Kept out of the `value` region because the
+    # pairs isolate consecutive kernels from each other (no tail / ramp overlap), which costs the region ~10 %.
+    timed_region(arm=True)
     ms = (ctypes.c_float * 256)()
-    n_timed = lib.dctr_profile_collect(ms, min(len(launches), 256)) if K > 0 else 0
-    launch_s = [ms[i] * 1e-3 for i in range(n_timed) if ms[i] > 0]
+    n_timed = lib.dctr_profile_collect(ms, min(n_kern, 256)) if K > 0 else 0
+    launch_s = [ms[i] * 1e-3 if ms[i] > 0 else None for i in range(n_timed)]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -318,21 +330,32 @@ def main():
     result = None
     if rank == 0:
         value = world * B * K / elapsed if K else 0.0
-        rows_launch = (launches[0][1] - launches[0][0]) if launches else 0
-        t_launch = None
-        if launch_s and launches:
-            # mean duration of the launches that cover G batches (a trailing partial launch is left out)
-            full = [t for t, l in zip(launch_s, launches) if l[1] - l[0] == rows_launch]
-            t_launch = float(np.mean(full)) if full else None
-        t_fused32, t_gather, t_mlp = probe_kernels(model, staged, ring)
+        # kernel launches of the region in issue order <-> their event-pair durations; the dominant kernel = the kernel
+        # launch that covers the most rows of a call (the 256-row shape of the row-chained kernel when the call has one)
+        flat = [(ci, r, kname, rpw) for ci, pl in enumerate(plans) for (r, kname, rpw) in pl]
+        timed = [(ci, r, kname, rpw, t) for (ci, r, kname, rpw), t in zip(flat, launch_s) if t is not None] if fused else []
+        kernels, kernel_launches = [], []
+        rows_call = (launches[0][1] - launches[0][0]) if launches else 0
+        rows_launch, t_launch = rows_call, None
+        if timed:
+            first = [e for e in timed if launches[e[0]][1] - launches[e[0]][0] == rows_call]     # calls of G batches
+            shapes = sorted({(r, kname, rpw) for _, r, kname, rpw, _ in first}, key=lambda e: -e[0])
+            for r, kname, rpw in shapes:
+                ts = [t for _, r2, k2, w2, t in first if (r2, k2, w2) == (r, kname, rpw)]
+                kernel_launches.append({"rows": r, "kernel": kname, "rows_per_workgroup": rpw, "us": float(np.mean(ts)) * 1e6,
+                                        "n_timed": len(ts)})
+            rows_launch, dom_name, dom_rpw = shapes[0]
+            t_launch = kernel_launches[0]["us"] * 1e-6
         traffic, traffic_source = load_traffic(rows_launch)
-        kernels = []
+        t_fused32, t_gather, t_mlp = probe_kernels(model, staged, ring)
         if t_launch is not None:
             tf = DNN_FLOP_PER_SAMPLE * rows_launch / t_launch / 1e12
             gbs = ALG_BYTES_PER_SAMPLE * rows_launch / t_launch / 1e9
-            kernels.append({"kernel": "stream_kernel (dctr_embed_mlp_fwd, %d rows per launch: ids -> LDS-DMA ring -> DNN -> head)" % rows_launch
-                            if rows_launch >= 64 * 256 or args.tile_rows == 64 else
-                            "mlp_kernel, fused gather (dctr_embed_mlp_fwd, %d rows per launch)" % rows_launch,
+            label = {"chain": "chain_kernel (dctr_embed_mlp_fwd row-chained, %d rows per workgroup, %d rows per launch: ids -> "
+                              "registers -> DNN (weights through an LDS-DMA ring) -> head)" % (dom_rpw, rows_launch),
+                     "stream": "stream_kernel (dctr_embed_mlp_fwd, %d rows per launch: ids -> LDS-DMA ring -> DNN -> head)" % rows_launch,
+                     "tile": "mlp_kernel, fused gather (dctr_embed_mlp_fwd, %d rows per launch)" % rows_launch}[dom_name]
+            kernels.append({"kernel": label,
                             "in_step": True, "us_per_launch": t_launch * 1e6, "rows_per_launch": rows_launch, "bound": "mfma",
                             "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
                             "hbm_algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
@@ -352,7 +375,8 @@ def main():
         dom = kernels[0]
         roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                     "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
-                    "us_per_launch": dom["us_per_launch"], "launches_timed": len(launch_s),
+                    "us_per_launch": dom["us_per_launch"], "launches_timed": len([t for t in launch_s if t is not None]),
+                    "kernel_launches_of_one_call": kernel_launches,
                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * rows_launch,
                     "algorithmic_flop_per_launch": DNN_FLOP_PER_SAMPLE * rows_launch}
         if "hbm_frac" in dom:
@@ -372,9 +396,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DeepFM forward, 26 sparse x vocab 1e5 + 13 dense, emb_dim 16, "
                                    "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, ids %s, ring of %d "
-                                   "distinct batches, the K steps issued as %d launch(es) of %d consecutive batches (%s)" % (
+                                   "distinct batches, the K steps issued as %d call(s) of %d consecutive batches (%s)" % (
                                        args.dist, ring, len(launches), G,
-                                       "1 launch per span: fused gather+DNN" if fused else "2 launches per span"),
+                                       "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(len(pl)) for pl in plans[:1]) if fused
+                                       else "2 launches per span"),
                        "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
                        "parallelism": "row-sharded x%d, tables replicated, one all-gather of the logits" % world},
             "roofline": roofline, "kernels": kernels,

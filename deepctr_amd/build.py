@@ -32,6 +32,9 @@ SOURCES = [
     "mlp_kernels_rt4.hip",
     "stream_kernels.hip",
     "chain_kernels.hip",
+    "chain_kernels_r2w8.hip",
+    "chain_kernels_r2w4.hip",
+    "chain_kernels_r1w4.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "din_kernels.hip",

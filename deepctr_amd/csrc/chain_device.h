@@ -1,0 +1,770 @@
+// dctr_embed_mlp_fwd, row-chained form — the throughput kernel of the DeepFM-family forward (reference
+// deepctr/inputs.py:101-117 embedding_lookup, feature_column.py:171-210 linear logit, layers/interaction.py:588-604 FM,
+// layers/core.py:189-208 DNN, :250-259 PredictionLayer) for launches that give every CU >= 256 rows.
+//
+// Why a third kernel.  stream_kernel (stream_kernels.hip) splits the layer OUTPUT columns over its 8 MFMA waves: every
+// layer ends in an epilogue that stores the activations to LDS, a barrier of the 8 waves, and a cold start of the next
+// layer's operand pipeline; its MFMA waves alone reach 0.72 of the f32-MFMA rate (profiles/r02_stream_lab_ablation.log),
+// 0.55-0.62 with the loader waves beside them.  Here a wave owns BATCH ROWS end to end and the MLP is computed transposed:
+//   * out^T[n, b] = sum_k W[k, n] * x[b, k]: the WEIGHTS are the MFMA A operand (M = output features), the wave's 32 batch
+//     rows are the N dimension (two 16-wide N tiles).  v_mfma_f32_16x16x4_f32 leaves C[m = 4g + r][n = j] in lane (g, j),
+//     register r — and wants B[k = g][n = j] from lane (g, j): a layer's accumulators ARE the next layer's B operand,
+//     register for register (k-slot g of k-step (M-tile, r) is output feature 4g + r of that M-tile; a K permutation, which
+//     an fp32 fmaf chain does not care about as long as the weight rows are fetched in the same order).  Activations never
+//     leave the register file: no LDS round trip, no epilogue stores, no barrier between layers;
+//   * the 8 waves of a workgroup walk the SAME weight sequence (layer 0 in 16-row k-blocks, layers >= 1 in 64 x 64
+//     sub-blocks), so the weights go L2 -> LDS once per 256 rows (603 KB per 300k cycles = 2 B/clk/CU against the 16 B/clk
+//     the 32-row kernel pulls) through LDS-DMA (global_load_lds_dwordx4, every wave moves 1/8 of a 16-KiB chunk) into a
+//     ring of three chunks; one s_barrier per chunk both publishes the chunk after next and retires the previous one;
+//   * A fragments are ds_read_b128: with M-tile mt of an M-group holding output features 64*mg + 4*i + mt (i = MFMA row),
+//     lane (g, j) reads floats 64*mg + 4j .. + 3 of weight row k: one read feeds FOUR M-tiles, 16 lanes of a group cover
+//     256 contiguous bytes (conflict-free for every lane grouping of ds_read_b128), and the rows need no repacking: the
+//     DMA image of a chunk is the Keras [K, N] rows as they lie in memory;
+//   * the embedding gather goes HBM/MALL -> REGISTERS: lane (g, j) of a wave loads the 16-B piece g of row j's embedding of
+//     one field with one global_load_dwordx4 — which is exactly the B operand of that field's four k-steps.  FM sums and
+//     the linear terms are lane-local adds (reduced over g once per pass).  Rows are requested one k-block (8k cycles)
+//     ahead of their MFMAs, ids two.
+// 8 waves x 32 rows = 256 rows per pass and CU; registers: 128 (layer-0 accumulators: 16 M-tiles x 2 N-tiles) + 64
+// (layer 1) + operand staging -> two waves per SIMD.
+//
+// Eligibility (host, below): uniform embedding_dim 16 or 32, no hashing / identity fields, dense columns right behind the
+// embeddings, every units[l] a multiple of 64 from the instantiated set, a head, no Dice / BatchNormalization / saved
+// activations, and at least 256 rows per CU (or tile_rows == 256).  Everything else takes stream_kernel / mlp_kernel.
+// Same arithmetic as those: v_mfma_f32_16x16x4_f32 = exact fp32; only the summation order over k differs.
+#pragma once
+#include "mlp_device.h"
+
+#ifdef DCTR_CHAIN_LAB_TS
+__device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][stamp] of workgroup 0, second pass
+#define CTS(i) do { if (blockIdx.x == 0 && it == 1 && (wave == 0 || wave == 7) && lane == 0) dctr_chain_ts[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
+#define CTS_STEP(b, k) do { if ((b) >= 10 && (b) < 14) CTS(8 + 4 * ((b) - 10) + (k)); } while (0)   // inside layer-0 steps 10..13
+#else
+#define CTS(i) do {} while (0)
+#define CTS_STEP(b, k) do {} while (0)
+#endif
+
+// lab ablations (scripts/chain_lab.cpp): what a step costs without its gather / its weight DMA / its barrier
+#ifdef DCTR_CHAIN_LAB_NOGATHER
+#define CHAIN_GATHER 0
+#else
+#define CHAIN_GATHER 1
+#endif
+#ifdef DCTR_CHAIN_LAB_NODMA
+#define CHAIN_DMA 0
+#else
+#define CHAIN_DMA 1
+#endif
+#ifdef DCTR_CHAIN_LAB_NOBARRIER
+#define CHAIN_BARRIER "s_nop 0"
+#else
+#define CHAIN_BARRIER "s_barrier"
+#endif
+#ifndef CHAIN_DMA_LATE
+#define CHAIN_DMA_LATE 8                       // (even) micro-step behind which waves 4-7 issue their DMA share (waves 0-3: 0)
+#endif
+
+namespace dctr_chain {
+
+using dctr::f32x4;
+using namespace dctr_mlp;
+
+// A launch shape = (RT 16-row N tiles per wave, NW waves per workgroup): 16 * RT * NW batch rows per pass.  <2, 8> is the
+// throughput shape (256 rows, two waves per SIMD); <2, 4> (128 rows) and <1, 4> (64 rows, one wave per SIMD) take what is
+// left of a launch when the rows do not fill every CU with 256 — every shape walks k in the same order, so a row's result
+// does not depend on the shape (or the position) it was computed in.
+constexpr int NSLOT = 3;
+constexpr int SLOT_F = 4096;                   // floats per ring chunk (16 KiB)
+constexpr int CPAR_OFF = 0;                    // biases of every layer, head weights (<= 1024 floats)
+constexpr int FDESC_OFF = 1024;                // [n_fields <= 64][12 dwords]
+constexpr int DLW_OFF = 1792;                  // dense_lin_w (<= 256 floats, zeros when absent)
+constexpr int RING_OFF = 2048;
+constexpr int DENSE_OFF = RING_OFF + NSLOT * SLOT_F;   // [rows of a pass][16 * dense k-blocks] zero-padded dense values of the pass
+constexpr int MAX_DENSE_BLOCKS = 4;
+// + [NW waves][RT N tiles][64 lanes] shares of dense . dense_lin_w of the staged pass
+static inline size_t lds_bytes(int rt, int nw, int n_dense) {
+    return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64) * sizeof(float);
+}
+
+struct ChainParams {
+    const dctr_field_t* fields;
+    const void* ids;
+    int64_t ids_stride_f, ids_stride_b;
+    int32_t ids_is_i64, n_fields, n_dense, in_dim;
+    const float* dense;
+    int64_t dense_stride;
+    const float* dense_lin_w;
+    int64_t batch;
+    float* fm_logit;
+    float* lin_logit;
+    int32_t* status;
+    int32_t fm_used, lin_used;
+    const float* W[3];
+    const float* bias[3];
+    int32_t activation, sigmoid_out;
+    const float* head_w;
+    const float* add[4];
+    const float* global_bias;
+    float* y;
+    unsigned long long* probe;
+    int32_t n_pass;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// loads through pointers that come out of LDS (field descriptors) would be FLAT instructions (vmcnt AND lgkmcnt, slower
+// address path): the global address space is stated explicitly
+typedef const __attribute__((address_space(1))) f32x4* gbl_f4_t;
+typedef const __attribute__((address_space(1))) float* gbl_f_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x2* gbl_u2_t;
+typedef const __attribute__((address_space(1))) uint32_t* gbl_u_t;
+
+// field descriptor words as they lie in LDS (copied once per launch); decoded to scalars where they are used
+struct FieldRaw {
+    uint4 a;       // table, lin_table
+    uint2 b;       // vocab
+    uint32_t c;    // in_fm
+};
+__device__ __forceinline__ FieldRaw field_raw(const float* fdesc, int f) {
+    FieldRaw r;
+    r.a = *reinterpret_cast<const uint4*>(fdesc + 12 * f);
+    r.b = *reinterpret_cast<const uint2*>(fdesc + 12 * f + 4);
+    r.c = *reinterpret_cast<const uint32_t*>(fdesc + 12 * f + 8);
+    return r;
+}
+__device__ __forceinline__ uint64_t sgpr64(uint32_t lo, uint32_t hi) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+}
+
+// The MFMA goes out as inline asm with the accumulator as a read-write operand: D = C in place, always.  Left to hipcc, the
+// 48 accumulator quads of a pass are renamed from MFMA to MFMA (D != C), the rotation needs spare quads, and with 192 of 256
+// registers holding accumulators the allocator tips into spilling accumulators inside the k-loop (scratch reloads whose
+// vmcnt waits then sit behind the DMA of the step).  What hipcc's hazard recognizer no longer sees is covered by
+// construction: dependent MFMAs on one accumulator are >= 8 MFMAs apart; operands come from LDS / global loads (waitcnt
+// by hipcc, the operands are visible) or from accumulators finished a layer earlier; non-MFMA reads of accumulators come
+// after mfma_drain().
+__device__ __forceinline__ void mfma_ip(f32x4& acc, float a, float b) {
+#ifdef DCTR_CHAIN_ASM_MFMA
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#else
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+// activation of a whole accumulator set in place (one switch per layer, not per element)
+template <int ACT, int NM, int RT>
+__device__ __forceinline__ void act_block_t(f32x4 (&acc)[NM][RT]) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nt][r] = act_t<ACT>(acc[m][nt][r], 0.f, 0.f, 1.f, 0.f);
+}
+template <int NM, int RT>
+__device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][RT]) {
+    switch (act) {
+        case DCTR_ACT_RELU: act_block_t<DCTR_ACT_RELU, NM, RT>(acc); break;
+        case DCTR_ACT_SIGMOID: act_block_t<DCTR_ACT_SIGMOID, NM, RT>(acc); break;
+        case DCTR_ACT_TANH: act_block_t<DCTR_ACT_TANH, NM, RT>(acc); break;
+        default: break;
+    }
+}
+
+// the gathered operand of one k-block for this lane: 16-B piece g of row j's embedding per N tile
+template <int RT>
+struct XBlkT {
+    f32x4 x[RT];
+};
+
+// RT, NW: launch shape (above); EB = embedding_dim / 16 k-blocks per field; I64: int64 ids; M0 / M1 / M2 = units[l] / 64
+// (M2 == 0: two layers)
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2>
+__global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
+    constexpr int NT = 64 * NW;
+    constexpr int WROWS = 16 * RT;                 // batch rows of a wave
+    constexpr int PROWS = NW * WROWS;              // batch rows per pass
+    typedef XBlkT<RT> XBlk;
+    constexpr int NL = M2 > 0 ? 3 : 2;
+    constexpr int ML = NL == 3 ? M2 : M1;          // M-groups of the last layer
+    constexpr int S1 = M0 * M1, S2 = M1 * M2;      // chunks (= steps) of layers 1 and 2
+    constexpr int SL = S1 + S2;
+    static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
+    constexpr int E = 16 * EB;
+    constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair
+    constexpr int B1_OFF = 64 * M0, B2_OFF = B1_OFF + 64 * M1, HW_OFF = B2_OFF + 64 * M2, GB_OFF = HW_OFF + 64 * ML;
+    static_assert(GB_OFF < FDESC_OFF, "biases + head weights + global bias must fit the parameter area");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cpar = smem + CPAR_OFF;
+    float* fdesc = smem + FDESC_OFF;
+    float* dlw = smem + DLW_OFF;
+    float* ring = smem + RING_OFF;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
+
+    // ---- once per launch: descriptors, biases, head weights, dense linear weights -> LDS
+    for (int i = threadIdx.x; i < 12 * p.n_fields; i += NT)
+        reinterpret_cast<uint32_t*>(fdesc)[i] = reinterpret_cast<const uint32_t*>(p.fields)[i];
+    for (int i = threadIdx.x; i < 64 * M0; i += NT) cpar[i] = p.bias[0] != nullptr ? p.bias[0][i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * M1; i += NT) cpar[B1_OFF + i] = p.bias[1] != nullptr ? p.bias[1][i] : 0.f;
+    if constexpr (M2 > 0)
+        for (int i = threadIdx.x; i < 64 * M2; i += NT) cpar[B2_OFF + i] = p.bias[2] != nullptr ? p.bias[2][i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * ML; i += NT) cpar[HW_OFF + i] = p.head_w[i];
+    if (threadIdx.x == 0) cpar[GB_OFF] = p.global_bias != nullptr ? p.global_bias[0] : 0.f;
+    for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
+
+    const int NBE = p.n_fields * EB;               // embedding k-blocks
+    const int NB = (p.in_dim + 15) >> 4;           // k-blocks of the DNN input (= steps of layer 0)
+    const int NDB = NB - NBE;                      // dense k-blocks (0 .. MAX_DENSE_BLOCKS)
+    const int STEPS = NB + SL;
+    const int k_last = p.in_dim - 1;
+    float* dreg = smem + DENSE_OFF + (WROWS * wave) * (16 * NDB);     // this wave's rows of the dense staging area
+    float* dlacc = smem + DENSE_OFF + PROWS * 16 * NDB + wave * (RT * 64) + lane;   // [nt * 64]: this lane's share of dense . w
+
+    // ---- weight chunks.  Chunk ci of a pass: ci < NB: rows 16*ci .. + 15 of W0 (all 64*M0 columns); then the 64 x 64
+    // sub-blocks (mg, mg1) of W1, mg-major; then those of W2; ci >= STEPS wraps to the next pass.  A chunk image is
+    // 16 pieces of 1 KiB (fewer for M0 < 4); wave w moves pieces w, w + 8: lane l's 16 bytes land at piece + 16 l.
+    // The DMA instruction is issued through inline asm on purpose: hipcc orders every later ds_read behind an LDS-DMA it
+    // can see with s_waitcnt vmcnt(0) (it cannot prove the chunk being filled is not the chunk being read), which would
+    // stall each step on the loads it has just requested.  Unseen, the DMA only makes hipcc's own vmcnt bookkeeping for
+    // the register loads conservative (more operations in the queue than it counts: it can over-wait, never under-wait).
+    // Addresses are a scalar base + one per-lane 32-bit offset (the lane index is made opaque per call: otherwise the
+    // offsets of all ten layer >= 1 chunks are hoisted out of the persistent loop — live VGPRs across the pass, i.e. spills)
+    auto dma16 = [&](const void* sbase, uint32_t voff, float* dst) {
+        const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)dst;
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma_l0 = [&](int b, float* dst) {
+        constexpr int ROW_B = 256 * M0;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);                  // this lane's byte inside piece `wave`
+        if (16 * b + 16 <= p.in_dim) {                                         // a whole block: 16 KiB (M0 = 4) as they lie
+            const char* base = reinterpret_cast<const char*>(p.W[0]) + (size_t)b * (16 * ROW_B);
+#pragma unroll
+            for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
+                if (pc0 + wave < 4 * M0) dma16(base + pc0 * 1024, o, dst + (pc0 + wave) * 256);
+        } else {                                                               // K tail: rows past K get a finite stand-in
+#pragma unroll
+            for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
+                if (pc0 + wave < 4 * M0) {
+                    const uint32_t oo = o + pc0 * 1024;
+                    const int krow = min(16 * b + (int)(oo / ROW_B), k_last);
+                    dma16(p.W[0], (uint32_t)krow * ROW_B + (oo % ROW_B), dst + (pc0 + wave) * 256);
+                }
+        }
+    };
+    auto dma_ln = [&](const float* W, int N, int mg, int mg1, float* dst) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);
+        const uint32_t voff = (o >> 8) * (uint32_t)(N * 4) + (o & 255u);       // image row o / 256 <-> weight row, 256 B of it
+        const char* base = reinterpret_cast<const char*>(W) + ((size_t)(64 * mg) * N + 64 * mg1) * 4;   // scalar
+#pragma unroll
+        for (int pc0 = 0; pc0 < 16; pc0 += NW) dma16(base + (size_t)(4 * pc0) * N * 4, voff, dst + (pc0 + wave) * 256);
+    };
+    auto dma_chunk = [&](int ci, float* dst) {
+        if (!CHAIN_DMA) return;
+        if (ci >= STEPS) ci -= STEPS;
+        if (ci < NB) {
+            dma_l0(ci, dst);
+        } else {
+            int c = ci - NB;
+            if (c < S1) {
+                dma_ln(p.W[1], 64 * M1, c / M1, c % M1, dst);
+            } else if constexpr (M2 > 0) {
+                c -= S1;
+                dma_ln(p.W[2], 64 * M2, c / M2, c % M2, dst);
+            }
+        }
+    };
+
+    // ---- ring position: chunk of step s (counted over the whole launch) lives in slot s % 3
+    int slot = 0;                                  // slot of the CURRENT step's chunk
+    auto slot_ptr = [&](int ahead) -> float* {
+        int s = slot + ahead;
+        s = s >= NSLOT ? s - NSLOT : s;
+        return ring + s * SLOT_F;
+    };
+    auto slot_next = [&]() { slot = slot + 1 == NSLOT ? 0 : slot + 1; };
+
+    // ---- rows.  MFMA layout: lane (g, j) works for rows 16 nt + j of the wave's 32 (launches are cut to < 2^31 rows by
+    // the host).  Ids and linear-table entries are handled ROW PER LANE for a PAIR of fields at once: lane l = row (l & 31)
+    // of field 2 pr + (l >> 5) — one id load, one range check, one linear-table load per field pair instead of per k-block
+    // and N tile; a k-block's ids reach the (g, j) lanes through ds_bpermute (the LDS crossbar, no memory traffic)
+    auto row_of = [&](int pass, int nt) -> int { return pass * PROWS + WROWS * wave + 16 * nt + j; };
+    auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), (int)p.batch - 1); };
+    const int q = lane >> 5;                           // which field of the pair this lane serves
+    int oor = 0;
+    // request the ids of field pair pr for the rows of `pass`
+    auto request_pair_ids = [&](int pr, int pass, uint32_t& lo, uint32_t& hi) {
+        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const int r = min(pass * PROWS + WROWS * wave + min(lane & 31, WROWS - 1), (int)p.batch - 1);
+        const int64_t eo = (int64_t)fi * p.ids_stride_f + (int64_t)r * p.ids_stride_b;
+        if constexpr (I64) {
+            const u32x2 v = *(gbl_u2_t)(reinterpret_cast<const u32x2*>(p.ids) + eo);
+            lo = v[0];
+            hi = v[1];
+        } else {
+            lo = *(gbl_u_t)(reinterpret_cast<const uint32_t*>(p.ids) + eo);
+        }
+    };
+    // landed ids -> rows: range check against the field's vocabulary, out-of-range ids read row 0 and raise the flag
+    auto fold_pair_ids = [&](int pr, int pass, uint32_t lo, uint32_t hi) -> uint32_t {
+        const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
+        const uint2 va = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 4);
+        const uint2 vb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 4);
+        const uint64_t voc_a = sgpr64(va.x, va.y), voc_b = sgpr64(vb.x, vb.y);
+        const uint32_t lim_a = (voc_a >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_a;
+        const uint32_t lim_b = (voc_b >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_b;
+        const uint32_t lim = q ? lim_b : lim_a;
+        const uint32_t upper = I64 ? hi : (uint32_t)((int32_t)lo >> 31);      // anything but 0: negative or >= 2^32
+        const bool ok = upper == 0u && lo < lim;
+        const bool counts = (lane & 31) < WROWS && pass * PROWS + WROWS * wave + (lane & 31) < (int)p.batch && 2 * pr + q < p.n_fields;
+        if (__any(!ok && counts)) oor = 1;                 // (wave-uniform flag: a scalar register, not a VGPR)
+        return ok ? lo : 0u;
+    };
+    // linear-table entries of the pair (row per lane); fields without a linear table, or past the last field, give 0
+    auto pair_lin_ptr = [&](int pr, uint32_t idc, bool& has) -> gbl_f_t {
+        const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
+        const uint2 la = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 2);
+        const uint2 lb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 2);
+        const uint64_t lin_a = sgpr64(la.x, la.y), lin_b = sgpr64(lb.x, lb.y);
+        const uint64_t base = q ? lin_b : lin_a;
+        has = base != 0 && 2 * pr + q < p.n_fields;
+        const float* t = has ? reinterpret_cast<const float*>(base) : reinterpret_cast<const float*>(p.fields);
+        return (gbl_f_t)(t + (has ? idc : 0u));
+    };
+    // issue the row loads of embedding k-block cb: its ids are half `half` of the folded pair ids `idc`
+    auto issue_x = [&](int cb, uint32_t idc, int half, XBlk& X) {
+        const int f = cb / EB, h = cb % EB;
+        const uint2 tw = *reinterpret_cast<const uint2*>(fdesc + 12 * f);
+        const char* table = reinterpret_cast<const char*>(sgpr64(tw.x, tw.y));
+        // (lane-derived constants are rebuilt from an opaque copy of the lane index: as loop invariants they would be kept
+        // in scratch and reloaded — with a vmcnt wait behind the DMA just issued — in every step)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t gg = (uint32_t)ln >> 4, jj = (uint32_t)ln & 15u;
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jj + (uint32_t)(32 * half + 16 * nt)) << 2), (int)idc);
+            const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);   // 16-B pieces from the table base
+            X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
+        }
+    };
+    // dense features of a pass: requested, then (a step later) written zero-padded to this wave's LDS rows — the dense
+    // k-blocks of layer 0 read their B operand from there, so the hot loop has ONE kind of global load.  Lane (g, j) moves
+    // columns 4g .. 4g + 3 of dense k-block c for its two rows; the lane's share of dense . dense_lin_w comes out on the way
+    auto dense_request = [&](int c, int pass, float (&td)[RT][4]) {
+        const int d0 = 16 * c + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            gbl_f_t src = (gbl_f_t)(p.dense + (int64_t)brow_of(pass, nt) * p.dense_stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) td[nt][e] = src[min(d0 + e, p.n_dense - 1)];
+        }
+    };
+    auto dense_store = [&](int c, const float (&td)[RT][4]) {
+        const int d0 = 16 * c + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            f32x4 v;
+            float dl = c == 0 ? 0.f : dlacc[nt * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = d0 + e < p.n_dense ? td[nt][e] : 0.f;
+                dl = fmaf(v[e], dlw[min(d0 + e, 255)], dl);
+            }
+            *reinterpret_cast<f32x4*>(dreg + (16 * nt + j) * (16 * NDB) + d0) = v;
+            dlacc[nt * 64] = dl;
+        }
+    };
+    // dense k-blocks 1.. (rare): synchronously
+    auto dense_rest = [&](int pass) {
+        for (int c = 1; c < NDB; ++c) {
+            float td[RT][4];
+            dense_request(c, pass, td);
+            dense_store(c, td);
+        }
+    };
+
+    // ---- the barrier of a step: everything this wave requested has landed (its share of the chunk after this one, the
+    // next k-block's rows, ids, linear entries), all eight waves have finished reading the previous chunk.  The in-flight
+    // registers are named so that hipcc places its own bookkeeping wait here and not in front of their first use
+#define CHAIN_TOP_X(X)                                                                                           \
+    do {                                                                                                         \
+        if constexpr (RT == 2)                                                                                   \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER                                        \
+                         : "+v"(X.x[0]), "+v"(X.x[RT - 1]), "+v"(lvn), "+v"(idr_lo), "+v"(idr_hi)                  \
+                         :                                                                                       \
+                         : "memory");                                                                            \
+        else                                                                                                     \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER                                        \
+                         : "+v"(X.x[0]), "+v"(lvn), "+v"(idr_lo), "+v"(idr_hi)                                     \
+                         :                                                                                       \
+                         : "memory");                                                                            \
+    } while (0)
+#define CHAIN_TOP_ID()                                                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(idr_lo), "+v"(idr_hi) : : "memory")
+#define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER ::: "memory")
+
+    // A-operand lane offsets (floats) inside a chunk image
+    const int l0off = (4 * g) * (64 * M0) + 4 * j;     // layer 0: k-step t reads row 4g + t, M-group mg at + 64 mg
+    const int lnoff = (16 * g) * 64 + 4 * j;           // layers >= 1: k-step (mt, r) reads row 16g + 4r + mt
+
+    // ---- prologue: chunks 0 and 1, the dense values, ids of field pair 0, rows of k-block 0 of the first pass
+    XBlk XA, XB;
+    uint32_t idr_lo = 0u, idr_hi = 0u;                 // raw ids of a field pair between their request and the range check
+    uint32_t idc = 0u;                                 // checked ids (= table rows) of the current field pair
+    float lvn = 0.f;                                   // linear-table entries of the current pair, in flight / landed
+#pragma unroll
+    for (int nt = 0; nt < RT; ++nt) {
+        XA.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        XB.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                                   // LDS parameters written
+    // in_fm of every field as one scalar bit mask (n_fields <= 64)
+    const uint64_t fm_mask = __ballot(lane < p.n_fields && reinterpret_cast<const uint32_t*>(fdesc)[12 * min(lane, p.n_fields - 1) + 8] != 0u);
+    {
+        const int pass0 = min((int)blockIdx.x, p.n_pass - 1);
+        dma_chunk(0, slot_ptr(0));
+        dma_chunk(1, slot_ptr(1));
+        request_pair_ids(0, pass0, idr_lo, idr_hi);
+        float td[RT][4];
+        if (NDB > 0) dense_request(0, pass0, td);
+        CHAIN_TOP_ID();
+        if (NDB > 0) {
+            dense_store(0, td);
+            dense_rest(pass0);
+        }
+        idc = fold_pair_ids(0, pass0, idr_lo, idr_hi);
+        issue_x(0, idc, 0, XA);
+    }
+
+    // Request phase of a step = gather part (rows of the next k-block, ids, linear entries: latency-critical, behind micro-
+    // step 0 for every wave) + DMA part (this wave's share of the chunk after next: L2 hits, latency-tolerant).  The DMA part
+    // sits behind micro-step 0 for waves 0-3 and behind micro-step CHAIN_DMA_LATE for waves 4-7, so that the CU's vector-
+    // memory address path does not get all eight waves' requests in one burst (it has no register results, so placing it
+    // twice costs nothing; the gather part placed twice merges in-flight registers of the two placements and spills).
+    const bool dma_early = wave < NW / 2;
+    for (int it = 0, pass = blockIdx.x; pass < p.n_pass; ++it, pass += gridDim.x) {
+        constexpr int PH = 0;
+        (void)it;
+        const int pass_n = min(pass + (int)gridDim.x, p.n_pass - 1);     // rows the gather prologue at the pass's end is for
+        CTS(0);
+        // ================= layer 0: acc0[4 mg + mt][nt] = C tile of output features 64 mg + 4 i + mt
+        f32x4 acc0[4 * M0][RT];
+#pragma unroll
+        for (int mg = 0; mg < M0; ++mg) {
+            float bv[16];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 t = *reinterpret_cast<const float4*>(cpar + 64 * mg + 16 * g + 4 * qq);
+                bv[4 * qq] = t.x; bv[4 * qq + 1] = t.y; bv[4 * qq + 2] = t.z; bv[4 * qq + 3] = t.w;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt)
+                    acc0[4 * mg + mt][nt] = f32x4{bv[mt], bv[4 + mt], bv[8 + mt], bv[12 + mt]};
+        }
+        f32x4 sum[EB][RT];
+        float sq[RT];
+        float linacc = 0.f;                            // row-per-lane: this lane's field of every pair
+        uint32_t idcn = 0u;                            // checked ids of the NEXT field pair
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            sq[nt] = 0.f;
+#pragma unroll
+            for (int h = 0; h < EB; ++h) sum[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // operand pipeline of every layer: micro-steps of ONE ds_read_b128 (4 A fragments = 4 M-tiles) + 4 x RT MFMAs; the
+        // fragment of micro-step u + 1 is requested before the MFMAs of micro-step u (two 4-register buffers, c0 / c1).
+        // Layer 0, k-block step: micro-step u = (k-step t = u / M0, M-group mg = u % M0) reads weight row 4g + t
+        f32x4 c0, c1;
+        auto read_l0 = [&](const float* sb, int u) -> f32x4 {
+            return *reinterpret_cast<const f32x4*>(sb + l0off + (u / M0) * (64 * M0) + 64 * (u % M0));
+        };
+        auto mfma_l0 = [&](const f32x4& a, const XBlk& X, int u) {
+            const int t = u / M0, mg = u % M0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt)
+                    mfma_ip(acc0[4 * mg + mt][nt], a[mt], X.x[nt][t]);
+        };
+        // FM bookkeeping of the embedding block being multiplied (lane-local)
+        auto consume_x = [&](int b, const XBlk& X) {
+            const int f = b / EB, h = b % EB;
+            if ((fm_mask >> f) & 1ull) {
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt) {
+#pragma unroll
+                    for (int hh = 0; hh < EB; ++hh)
+                        if (hh == h) sum[hh][nt] += X.x[nt];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sq[nt] = fmaf(X.x[nt][e], X.x[nt][e], sq[nt]);
+                }
+            }
+        };
+        // the request phase of layer-0 step (k-block b_ = step s_ of field pair pr_): DMA share of the chunk after next,
+        // rows of the next k-block, and once per pair: the pair's linear entries (s = 0), the next pair's ids (s = PAIR - 2),
+        // their range check (s = PAIR - 1).  A dense k-block takes its operand from the staging rows in LDS instead
+#define CHAIN_PHASE0(XC, XN)                                                                                     \
+        {                                                                                                        \
+            CTS_STEP(b_, 3);                                                                                     \
+            if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                       \
+            if (CHAIN_GATHER) {                                                                                  \
+                /* every request is issued unconditionally (past the last field / pair: a clamped, redundant one):   \
+                   a conditionally written register keeps its old value alive — through layers 1.. where 192 of the   \
+                   256 registers hold accumulators */                                                             \
+                const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                 \
+                if (s_ == 1) {                                                                                   \
+                    bool has_;                                                                                   \
+                    (void)pair_lin_ptr(pr_, 0u, has_);                                                           \
+                    linacc += (has_ && b_ - 1 < NBE) ? lvn : 0.f;                                                \
+                }                                                                                                \
+                if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);                            \
+                if (s_ + 1 < PAIR) issue_x(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN);                        \
+                else issue_x(min(b_ + 1, NBE - 1), idcn, 0, XN);                                                 \
+                if (s_ == 0) {                                                                                   \
+                    bool has_;                                                                                   \
+                    lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
+                }                                                                                                \
+                if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
+                if (b_ < NBE) consume_x(b_, XC);                                                                 \
+            }                                                                                                    \
+            CTS_STEP(b_, 2);                                                                                     \
+        }
+#define CHAIN_STEP0(S, XC, XN)                                                                                   \
+        {                                                                                                        \
+            constexpr int s_ = (S);                                                                              \
+            const int b_ = pr_ * PAIR + s_;                                                                      \
+            CTS_STEP(b_, 0);                                                                                     \
+            CHAIN_TOP_X(XC);                                                                                     \
+            CTS_STEP(b_, 1);                                                                                     \
+            const float* sb_ = slot_ptr(0);                                                                      \
+            if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
+            if (b_ >= NBE) {                                                                                     \
+                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
+                    XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
+            }                                                                                                    \
+            _Pragma("unroll") for (int u_ = 0; u_ < 4 * M0; u_ += 2) {                                           \
+                c1 = read_l0(sb_, u_ + 1);                                                                       \
+                DCTR_SB;                                                                                         \
+                mfma_l0(c0, XC, u_);                                                                             \
+                DCTR_SB;                                                                                         \
+                if (u_ == PH) CHAIN_PHASE0(XC, XN)                                                               \
+                if (u_ == CHAIN_DMA_LATE && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                          \
+                if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                                  \
+                else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                              \
+                DCTR_SB;                                                                                         \
+                mfma_l0(c1, XC, u_ + 1);                                                                         \
+                DCTR_SB;                                                                                         \
+            }                                                                                                    \
+            slot_next();                                                                                         \
+        }
+        for (int pr_ = 0; pr_ * PAIR < NB; ++pr_) {
+            CHAIN_STEP0(0, XA, XB);
+            if (pr_ * PAIR + 1 < NB) CHAIN_STEP0(1, XB, XA);
+            if constexpr (EB == 2) {
+                if (pr_ * PAIR + 2 < NB) CHAIN_STEP0(2, XA, XB);
+                if (pr_ * PAIR + 3 < NB) CHAIN_STEP0(3, XB, XA);
+            }
+            idc = idcn;
+        }
+#undef CHAIN_STEP0
+#undef CHAIN_PHASE0
+        if ((NB - 1) % PAIR == 0 && NB - 1 < NBE) {
+            // the last step was step 0 of a field pair (odd field count, no dense k-block behind it): the pair's linear
+            // entries, added up in a pair's step 1, are still on their way
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(lvn) : : "memory");
+            bool has_;
+            (void)pair_lin_ptr((NB - 1) / PAIR, 0u, has_);
+            linacc += has_ ? lvn : 0.f;
+        }
+        mfma_drain();
+        CTS(1);
+        // ---- gather epilogue of the pass: FM = 0.5 (sum_d (sum_f e)^2 - sum_{f,d} e^2) lane-local, then over g; the linear
+        // terms sit row per lane (lane l and l + 32: the two fields of every pair) and go to the (g, j) lanes by bpermute
+        float extras[RT];
+        {
+            const float lin_rows = linacc + __shfl_xor(linacc, 32, 64);
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) {
+                float fm = -sq[nt];
+#pragma unroll
+                for (int h = 0; h < EB; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fm = fmaf(sum[h][nt][e], sum[h][nt][e], fm);
+                fm += __shfl_xor(fm, 16, 64);
+                fm += __shfl_xor(fm, 32, 64);
+                fm *= 0.5f;
+                float dl = NDB > 0 ? dlacc[nt * 64] : 0.f;
+                dl += __shfl_xor(dl, 16, 64);
+                dl += __shfl_xor(dl, 32, 64);
+                const float lin_all = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * nt + j), __builtin_bit_cast(int, lin_rows))) + dl;
+                extras[nt] = (p.fm_used ? fm : 0.f) + (p.lin_used ? lin_all : 0.f);
+                const int r = row_of(pass, nt);
+                if (g == 0 && r < (int)p.batch) {
+                    if (p.fm_logit != nullptr) p.fm_logit[r] = fm;
+                    if (p.lin_logit != nullptr) p.lin_logit[r] = lin_all;
+                }
+            }
+        }
+        // activation in place: acc0 is now the B operand of layer 1
+        act_block<4 * M0, RT>(p.activation, acc0);
+
+        // ================= layers >= 1: one step per 64 x 64 sub-block (mg, mg1): 16 k-steps (mt, r) of 4 M-tiles x RT MFMAs
+        auto read_an = [&](const float* sb, int ks) -> f32x4 {
+            const int mt = ks >> 2, r = ks & 3;
+            return *reinterpret_cast<const f32x4*>(sb + lnoff + (4 * r + mt) * 64);
+        };
+        int sidx = 0;                                  // step index behind layer 0 (compile-time after unrolling)
+        float td[RT][4];                               // next pass's dense values between its request and its LDS store
+        auto init_acc = [&](auto& acc, int boff, auto MG) {
+            constexpr int MGc = decltype(MG)::value;
+#pragma unroll
+            for (int mg = 0; mg < MGc; ++mg) {
+                float bv[16];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 t = *reinterpret_cast<const float4*>(cpar + boff + 64 * mg + 16 * g + 4 * qq);
+                    bv[4 * qq] = t.x; bv[4 * qq + 1] = t.y; bv[4 * qq + 2] = t.z; bv[4 * qq + 3] = t.w;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) acc[4 * mg + mt][nt] = f32x4{bv[mt], bv[4 + mt], bv[8 + mt], bv[12 + mt]};
+            }
+        };
+        // (the generic lambda is instantiated per layer; MI / MO = M-groups of its input / output)
+        auto dense_layer = [&](auto& accin, auto& accout, auto MIc, auto MOc) {
+            constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
+#pragma unroll
+            for (int mg = 0; mg < MI; ++mg) {
+#pragma unroll
+                for (int mg1 = 0; mg1 < MO; ++mg1) {
+                    const bool first = sidx == 0;                  // no prefetch across the layer-0 boundary
+                    const bool last = sidx == SL - 1;
+                    if (last) CHAIN_TOP_ID();                      // the ids requested in the step before
+                    else CHAIN_TOP();
+                    const float* sb = slot_ptr(0);
+                    if (last && NDB > 0) {                         // the next pass's dense values have landed
+                        dense_store(0, td);
+                        dense_rest(pass_n);
+                    }
+                    if (first) c0 = read_an(sb, 0);
+#pragma unroll
+                    for (int ks = 0; ks < 16; ks += 2) {
+                        c1 = read_an(sb, ks + 1);
+                        DCTR_SB;
+#pragma unroll
+                        for (int mt1 = 0; mt1 < 4; ++mt1)
+#pragma unroll
+                            for (int nt = 0; nt < RT; ++nt)
+                                mfma_ip(accout[4 * mg1 + mt1][nt], c0[mt1], accin[4 * mg + (ks >> 2)][nt][ks & 3]);
+                        DCTR_SB;
+                        if (ks == PH) {
+                            // the chunk after next, and at the pass's end the next pass's gather prologue
+                            if (dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
+                            if (sidx == SL - 2) {
+                                request_pair_ids(0, pass_n, idr_lo, idr_hi);
+                                if (NDB > 0) dense_request(0, pass_n, td);
+                            }
+                            if (last) {
+                                idc = fold_pair_ids(0, pass_n, idr_lo, idr_hi);
+                                issue_x(0, idc, 0, XA);
+                            }
+                        }
+                        if (ks == CHAIN_DMA_LATE && !dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
+                        if (ks + 2 < 16) c0 = read_an(sb, ks + 2);
+                        else if (!last) c0 = read_an(slot_ptr(1), 0);
+                        DCTR_SB;
+#pragma unroll
+                        for (int mt1 = 0; mt1 < 4; ++mt1)
+#pragma unroll
+                            for (int nt = 0; nt < RT; ++nt)
+                                mfma_ip(accout[4 * mg1 + mt1][nt], c1[mt1], accin[4 * mg + ((ks + 1) >> 2)][nt][(ks + 1) & 3]);
+                        DCTR_SB;
+                    }
+                    slot_next();
+                    ++sidx;
+                }
+            }
+        };
+        f32x4 acc1[4 * M1][RT];
+        init_acc(acc1, B1_OFF, std::integral_constant<int, M1>{});
+        dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{});
+        mfma_drain();
+        CTS(2);
+        float hs[RT];
+        // head of the last layer: act(acc) . head_w over this lane's 16 features per M-group, then over g
+        auto head = [&](auto& acc, auto MGc) {
+            constexpr int MG = decltype(MGc)::value;
+            act_block<4 * MG, RT>(p.activation, acc);
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) hs[nt] = 0.f;
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                float hw[16];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 t = *reinterpret_cast<const float4*>(cpar + HW_OFF + 64 * mg + 16 * g + 4 * qq);
+                    hw[4 * qq] = t.x; hw[4 * qq + 1] = t.y; hw[4 * qq + 2] = t.z; hw[4 * qq + 3] = t.w;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < RT; ++nt)
+                            hs[nt] = fmaf(acc[4 * mg + mt][nt][r], hw[4 * r + mt], hs[nt]);
+            }
+        };
+        if constexpr (M2 > 0) {
+            act_block<4 * M1, RT>(p.activation, acc1);
+            f32x4 acc2[4 * (M2 > 0 ? M2 : 1)][RT];
+            init_acc(acc2, B2_OFF, std::integral_constant<int, M2>{});
+            dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{});
+            mfma_drain();
+            head(acc2, std::integral_constant<int, M2>{});
+        } else {
+            head(acc1, std::integral_constant<int, M1>{});
+        }
+        CTS(3);
+        // ---- Dense(1) + linear / FM logits + add[] + global bias, PredictionLayer
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            float v = hs[nt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            v += extras[nt];
+            const int r = row_of(pass, nt);
+            if (g == 0 && r < (int)p.batch) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p.add[i] != nullptr) v += p.add[i][r];
+                v += cpar[GB_OFF];
+                if (p.sigmoid_out) v = dctr::sigmoidf_(v);
+                p.y[r] = v;
+            }
+        }
+        CTS(4);
+    }
+#undef CHAIN_TOP_X
+#undef CHAIN_TOP_ID
+#undef CHAIN_TOP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wrapped-around DMA of the last pass must not outlive the wave
+    if (p.status != nullptr && oor && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
+    if (p.probe != nullptr && lane == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
+}
+
+
+// launchers, one translation unit per launch shape (chain_kernels_r{RT}w{NW}.hip)
+int launch_r2w8(const ChainParams& p, int E, unsigned blocks, hipStream_t stream);
+int launch_r2w4(const ChainParams& p, int E, unsigned blocks, hipStream_t stream);
+int launch_r1w4(const ChainParams& p, int E, unsigned blocks, hipStream_t stream);
+
+}  // namespace dctr_chain

@@ -27,9 +27,12 @@ int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_
                hipStream_t stream, int* rc);   // stream_kernels.hip
 }
 namespace dctr_chain {
-int64_t eligible_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);   // chain_kernels.hip
-int launch_rows(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int64_t rows,
-                hipStream_t stream);
+int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);   // chain_kernels.hip
+int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int shape, hipStream_t stream);
+int plan(int64_t batch, int shape, int64_t* rows, int32_t* rpw, int max);
+}
+namespace dctr_stream {
+int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);
 }
 
 namespace {
@@ -129,26 +132,14 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         return (size_t)NWAVE * (spw >= rows ? 1 : rows / spw) * 6 * 64;
     };
 
-    // fused launches with >= 256 rows per CU (or tile_rows == 256): the row-chained kernel takes whole multiples of
-    // 256 rows x CUs (every CU the same number of passes); what is left goes on below as a launch of its own
-    if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 256)) {
-        const int64_t rows = dctr_chain::eligible_rows(a, ga, a->tile_rows == 256);
-        DCTR_REQUIRE(a->tile_rows != 256 || rows > 0, DCTR_E_UNSUPPORTED,
-                     "embed_mlp_fwd: tile_rows 256 (row-chained kernel) needs uniform embedding_dim 16 / 32, units 256-128-64, a head");
-        if (rows > 0) {
-            const int rc = dctr_chain::launch_rows(a, ga, fm_used, lin_used, rows, (hipStream_t)stream);
-            if (rc != DCTR_OK || rows == a->batch) return rc;
-            dctr_mlp_args_t a2 = *a;
-            dctr_gather_fm_args_t g2 = *ga;
-            a2.batch = g2.batch = a->batch - rows;
-            a2.y = a->y + rows;
-            for (int i = 0; i < 4; ++i) a2.add[i] = a->add[i] != nullptr ? a->add[i] + rows : nullptr;
-            g2.ids = reinterpret_cast<const char*>(ga->ids) + rows * ga->ids_stride_b * (ga->ids_is_i64 ? 8 : 4);
-            g2.dense = ga->dense != nullptr ? ga->dense + rows * ga->dense_stride : nullptr;
-            g2.fm_logit = ga->fm_logit != nullptr ? ga->fm_logit + rows : nullptr;
-            g2.lin_logit = ga->lin_logit != nullptr ? ga->lin_logit + rows : nullptr;
-            return mlp_launch(&a2, &g2, fm_used, lin_used, stream);
-        }
+    // fused launches with >= 64 rows per CU of an eligible model: the row-chained kernel (chain_kernels.hip; tile_rows 256 /
+    // 128 force one of its launch shapes, also for small launches)
+    if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 256 || a->tile_rows == 128)) {
+        const bool forced = a->tile_rows != 0;
+        const int ok = dctr_chain::eligible(a, ga, forced);
+        DCTR_REQUIRE(!forced || ok, DCTR_E_UNSUPPORTED,
+                     "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 16 / 32, units 256-128-64, a head", a->tile_rows);
+        if (ok) return dctr_chain::launch(a, ga, fm_used, lin_used, a->tile_rows, (hipStream_t)stream);
     }
     // fused launches with >= 64 rows per CU (or tile_rows == 64): the streaming kernel, when the model is eligible
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 64)) {
@@ -159,7 +150,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     // rows per workgroup.  auto: 16 while that still gives every CU a workgroup (latency), else 32
     int rt = a->tile_rows / 16;
     DCTR_REQUIRE(a->tile_rows == 0 || ((rt == 1 || rt == 2 || rt == 4) && a->tile_rows % 16 == 0), DCTR_E_DIM,
-                 "mlp_fwd: tile_rows %d (0, 16, 32 or 64; 256 with dctr_embed_mlp_fwd)", a->tile_rows);
+                 "mlp_fwd: tile_rows %d (0, 16, 32 or 64; 128 / 256 with dctr_embed_mlp_fwd)", a->tile_rows);
     if (rt == 0) rt = a->batch > 16 * 2 * 256 ? 2 : 1;
     if (ga != nullptr && rt > 2) rt = 2;
     if (ga != nullptr && lpr == 16) rt = 1;                  // embedding_dim > 32: see produce_chunk
@@ -211,4 +202,27 @@ extern "C" int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp
     DCTR_REQUIRE(m->has_head || (!add_fm_logit && !add_lin_logit), DCTR_E_DIM,
                  "embed_mlp_fwd: the gather logits can only be added by the fused head");
     return mlp_launch(m, g, add_fm_logit ? 1 : 0, add_lin_logit ? 1 : 0, stream);
+}
+
+extern "C" int dctr_embed_mlp_fwd_plan(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int64_t* rows, int32_t* kernel,
+                                       int32_t* rows_per_workgroup, int32_t max) {
+    DCTR_REQUIRE(g != nullptr && m != nullptr && rows != nullptr && kernel != nullptr && rows_per_workgroup != nullptr && max >= 1,
+                 DCTR_E_NULL, "embed_mlp_fwd_plan: null args");
+    if (m->batch <= 0) return 0;
+    if (m->tile_rows == 0 || m->tile_rows == 256 || m->tile_rows == 128) {
+        if (dctr_chain::eligible(m, g, m->tile_rows != 0)) {
+            const int n = dctr_chain::plan(m->batch, m->tile_rows, rows, rows_per_workgroup, max);
+            for (int i = 0; i < n && i < max; ++i) kernel[i] = DCTR_FWD_KERNEL_CHAIN;
+            return n;
+        }
+    }
+    rows[0] = m->batch;
+    if ((m->tile_rows == 0 || m->tile_rows == 64) && dctr_stream::eligible(m, g, m->tile_rows == 64)) {
+        kernel[0] = DCTR_FWD_KERNEL_STREAM;
+        rows_per_workgroup[0] = 64;
+    } else {
+        kernel[0] = DCTR_FWD_KERNEL_TILE;
+        rows_per_workgroup[0] = m->tile_rows;                 // 0: 16 or 32, chosen from the batch size and the LDS the widths need
+    }
+    return 1;
 }

@@ -678,10 +678,39 @@ static int n_cus() {
     return n;
 }
 
+// 1: the streaming kernel can take this call (the same conditions try_launch applies while it marshals); 0: not eligible
+int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
+    const int E = g->uniform_dim;
+    if (E != 16 && E != 32 && E != 64) return 0;
+    if (g->any_hash || !a->has_head || a->n_layers < 1 || a->save_acts != nullptr) return 0;
+    if (a->activation == DCTR_ACT_DICE || a->bn_scale != nullptr) return 0;
+    if (a->units[0] > 256 || a->units[0] < 16) return 0;
+    if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
+    if (a->in_dim != g->n_fields * E + (g->n_dense > 0 ? g->n_dense : 0)) return 0;
+    if ((int64_t)a->in_dim * a->units[0] * 4 >= (1LL << 31)) return 0;
+    const int64_t n_tiles = dctr_ceil_div(a->batch, (int64_t)ROWS);
+    if (!forced && n_tiles < n_cus()) return 0;
+    if (n_tiles > 0x7fffffffLL / 64 || g->n_fields > 64) return 0;
+    size_t act[2] = {0, 0};
+    int off = 0;
+    for (int l = 0; l < a->n_layers; ++l) {
+        const size_t need = (size_t)ROWS * (((a->units[l] + 63) & ~63) + 4);
+        if (need > act[l & 1]) act[l & 1] = need;
+        off += a->biases[l] != nullptr ? a->units[l] : 0;
+    }
+    const int nl = a->units[a->n_layers - 1];
+    if (off + nl > 1024) return 0;
+    const bool wide = a->n_layers == 1 ? (nl % 32 == 0 && nl > 16 * NCONS) : (nl % 32 == 0 && nl >= 32 * NCONS);
+    if ((wide ? (nl + 31) / 32 : (nl + 15) / 16) > 8) return 0;
+    if (((size_t)3072 + NSLOT * SLOT_F + act[0] + act[1]) * sizeof(float) > 160 * 1024) return 0;
+    return 1;
+}
+
 // 0: not eligible (caller falls back to mlp_kernel); 1: launched; < 0 / > 1: error code
 int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, bool forced,
                hipStream_t stream, int* rc) {
     *rc = DCTR_OK;
+    if (!eligible(a, g, forced)) return 0;
     const int E = g->uniform_dim;
     if (E != 16 && E != 32 && E != 64) return 0;
     if (g->any_hash || !a->has_head || a->n_layers < 1 || a->save_acts != nullptr) return 0;

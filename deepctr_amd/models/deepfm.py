@@ -38,7 +38,7 @@ class _DeepFM(FeatureModel):
             lpr *= 2
         passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
         self.fused = bool(sp.fusable and 8 * passes * 6 * 64 <= 16 * lda)
-        self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64), same bits
+        self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64; 128 / 256: row-chained kernel)
         self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
@@ -81,6 +81,20 @@ class _DeepFM(FeatureModel):
         m.probe = None if self.probe is None else self.probe.data_ptr()
         return g, m
 
+    def launch_plan(self, staged, lo, hi, out):
+        """[(rows, kernel, batch rows per workgroup)] of the kernel launches ``dctr_embed_mlp_fwd`` issues for rows [lo, hi)
+        (kernel: 'tile' = mlp_kernel, 'stream', 'chain'; dctr_embed_mlp_fwd_plan)."""
+        import ctypes
+        from .. import _C
+        g, m = self._forward_fast_args(staged, lo, hi, out)
+        rows, kern, rpw = (ctypes.c_int64 * 16)(), (ctypes.c_int32 * 16)(), (ctypes.c_int32 * 16)()
+        n = _C.lib().dctr_embed_mlp_fwd_plan(ctypes.byref(g), ctypes.byref(m), rows, kern, rpw, 16)
+        if n <= 0:
+            msg = _C.lib().dctr_last_error()
+            raise _C.DctrError("dctr_embed_mlp_fwd_plan failed: %s" % (msg.decode() if msg else ""))
+        names = {0: "tile", 1: "stream", 2: "chain"}
+        return [(int(rows[i]), names[int(kern[i])], int(rpw[i])) for i in range(min(n, 16))]
+
     def prepare_launch(self, staged, lo, hi, out):
         """A zero-argument callable that issues the fused launch for rows [lo, hi) -> out with everything marshalled
         beforehand (bench.py: the host cost of a launch inside a short timed region is one ctypes call)."""
@@ -105,7 +119,7 @@ class _DeepFM(FeatureModel):
     def _rows_per_launch(self, staged, batch_size):
         """predict(): rows are independent and the one-launch path owns no per-batch buffer, so ``batch_size`` (a memory
         knob of the reference's graph executor) need not bound a launch: spans of up to 2^20 rows go out as ONE launch —
-        with >= 64 rows per CU the library then runs its persistent streaming kernel (stream_kernels.hip)."""
+        with >= 64 rows per CU the library then runs its persistent kernels (row-chained: chain_device.h; else streaming)."""
         if self._fast_path(staged) and self.span_batches:
             return max(int(batch_size or staged.n), 1 << 20)
         return batch_size

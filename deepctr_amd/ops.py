@@ -471,7 +471,8 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
     ``bn`` = list of (scale, shift) per layer (or None) for DNN(use_bn=True): inference BatchNormalization between bias_add
     and the activation, see dctr_mlp_args_t.bn_scale.
-    ``tile_rows`` (0 = auto, 16, 32, 64) is the batch rows per workgroup — a throughput/latency knob, same bits."""
+    ``tile_rows`` (0 = auto, 16, 32, 64; with a fused gather also 128 / 256 = the row-chained kernel) is the batch rows per
+    workgroup — a throughput/latency knob."""
     _dev_check(x, *kernels, *biases)
     if gather is None:
         if x.dim() != 2:

@@ -145,6 +145,8 @@ typedef struct {
                                      field index * E, identity == 0 (the reference's all-SparseFeat DNN input,
                                      inputs.py:101-117 + layers/utils.py:336-346).  With E in {16, 32, 64} launches of
                                      >= 64 rows per CU take the streaming kernel (LDS-DMA gather ring, 64-row tiles).
+                                     With E in {16, 32} and DNN units 256-128-64 such
+                                     launches take the row-chained kernel instead (csrc/chain_device.h).
                                      0 = unknown / not uniform                                                        */
     int32_t reserved_;
 } dctr_gather_fm_args_t;
@@ -323,7 +325,13 @@ typedef struct {
                                      [B, units[l]] (row stride units[l]) are also written there.  NULL = inference. */
     int32_t tile_rows;            /* batch rows per workgroup: 0 = auto, or 16 / 32 / 64.  Larger tiles re-use every
                                      weight fragment for more rows (less L2->CU weight traffic per row, the bound of
-                                     this kernel) at the price of fewer workgroups; results are bit-identical. */
+                                     this kernel) at the price of fewer workgroups; results are bit-identical.
+                                     dctr_embed_mlp_fwd only: 64 = the streaming kernel (64-row tiles, LDS-DMA gather ring),
+                                     128 / 256 = the row-chained kernel in one launch shape (waves own batch rows end to
+                                     end; needs uniform_dim 16 / 32, units 256-128-64, a head).  0 (auto) sends launches of
+                                     >= 64 rows per CU of such a model to the row-chained kernel, cut into its launch
+                                     shapes so that every CU gets the same number of passes; a row's result does not
+                                     depend on the shape or on the row's position in the launch. */
     int32_t reserved_;
     unsigned long long* probe;    /* measurement aid, normally NULL: DEVICE uint64[2]; every workgroup does
                                      atomicMin(probe[0], t_start) / atomicMax(probe[1], t_end) with the constant-rate
@@ -349,6 +357,14 @@ int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit,
                        int32_t add_lin_logit, void* stream);
+
+/* How dctr_embed_mlp_fwd would issue this call: the row-chained kernel cuts a call into several kernel launches (whole
+ * multiples of 256 rows x CUs in its 256-row launch shape, the rest in the shapes that finish it soonest); every other path is
+ * one launch.  Writes up to `max` entries (rows of the launch, DCTR_FWD_KERNEL_* id, batch rows per workgroup) in launch order
+ * and returns how many launches there are (<= 0: error, see dctr_last_error).  Needs a current HIP device (CU count). */
+enum { DCTR_FWD_KERNEL_TILE = 0, DCTR_FWD_KERNEL_STREAM = 1, DCTR_FWD_KERNEL_CHAIN = 2 };
+int dctr_embed_mlp_fwd_plan(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int64_t* rows, int32_t* kernel,
+                            int32_t* rows_per_workgroup, int32_t max);
 
 /* ------------------------------------------------------------------------------------------------
  * a13 AttentionSequencePoolingLayer.call + LocalActivationUnit.call (DIN)

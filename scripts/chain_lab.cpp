@@ -12,6 +12,13 @@
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
 #include "../deepctr_amd/csrc/stream_kernels.hip"
 #include "../deepctr_amd/csrc/chain_kernels.hip"
+#include "../deepctr_amd/csrc/chain_kernels_r2w8.hip"
+#undef DCTR_CHAIN_RT
+#undef DCTR_CHAIN_NW
+#include "../deepctr_amd/csrc/chain_kernels_r2w4.hip"
+#undef DCTR_CHAIN_RT
+#undef DCTR_CHAIN_NW
+#include "../deepctr_amd/csrc/chain_kernels_r1w4.hip"
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -127,7 +134,7 @@ int main(int argc, char** argv) {
     }
 #endif
     {   // auto split (chained kernel for whole multiples of 256 rows x CUs + the rest) against the 32-row kernel
-        const int64_t Ba = 65536 + 16384 + 77;
+        const int64_t Ba = 65536 + 32768 + 16384 + 77;
         CK(hipMemset(y0, 0xff, BMAX * 4)); CK(hipMemset(y1, 0xff, BMAX * 4));
         if (run(Ba, 32, y0, 0) || run(Ba, 0, y1, 0)) return 1;
         CK(hipStreamSynchronize(st));
@@ -141,10 +148,11 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flop_row = 2.0 * ((double)in_dim * 256 + 256 * 128 + 128 * 64 + 64);
     const bool quick = getenv("CHAIN_LAB_QUICK") != nullptr;
-    for (int64_t B : {int64_t(65536), int64_t(81920), int64_t(131072), int64_t(262144)}) {
+    for (int64_t B : {int64_t(16384), int64_t(32768), int64_t(65536), int64_t(81920), int64_t(131072), int64_t(262144)}) {
         if (quick && B != 262144) continue;
-        for (int tr : {256, 0, 64}) {
+        for (int tr : {256, 128, 0, 64}) {
             if (quick && tr != 256) continue;
+            if (tr == 128 && B > 32768) continue;
             for (int w = 0; w < 3; ++w) if (run(B, tr, y1, 1)) return 1;
             CK(hipStreamSynchronize(st));
             const int R = 10;

@@ -1,0 +1,155 @@
+"""GPU parity tests of the ROW-CHAINED form of dctr_embed_mlp_fwd (csrc/chain_device.h: a wave owns batch rows end to end,
+weights are the MFMA A operand through an LDS-DMA ring, a layer's accumulators feed the next layer as B operand) — the
+kernel DeepFM-family launches of >= 64 rows per CU take.  Checked against the float64 oracle on row samples, against the
+32-row kernel on every row, and through size-independent properties at BASELINE sizes (C2: 26 x 1e5 x 16, 20 batches of 4096
+rows in one launch; the C5 shape E = 32 with int64-range vocabularies): row-permutation equivariance bit for bit, launch
+shape invariance bit for bit (every shape walks k in the same order), launch split invariance."""
+import numpy as np
+import pytest
+
+from oracle import ref_models as RM
+from tests.test_gpu_models import _criteo_like, _randomise, check_probs
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _with(model, **attrs):
+    class _Ctx(object):
+        def __enter__(self_):
+            self_.old = {k: getattr(model, k) for k in attrs}
+            for k, v in attrs.items():
+                setattr(model, k, v)
+
+        def __exit__(self_, *a):
+            for k, v in self_.old.items():
+                setattr(model, k, v)
+    return _Ctx()
+
+
+def _predict(model, feed, batch_size, **attrs):
+    with _with(model, **attrs):
+        return model.predict(feed, batch_size=batch_size)
+
+
+@pytest.mark.parametrize("E,V,n,F,ND", [
+    (16, 100000, 20 * 4096, 26, 13),            # BASELINE C2, the bench's 20-batch launch: shapes <2,8> + <1,4>
+    (32, 50000, 65536 + 32768 + 7, 26, 13),     # C5 shape: <2,8> + <2,4> + a ragged <1,4> pass
+    (16, 3000, 16384 + 129, 7, 0),              # odd field count (last pair has one field), no dense features
+    (16, 3000, 16384 + 64, 5, 20),              # two dense k-blocks (20 columns)
+])
+def test_chain_kernel_vs_oracle_and_tile_kernel(device, E, V, n, F, ND):
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(17 + E + F)
+    cols, feed = _criteo_like(rng, n, F=F, V=V, E=E, ND=ND)
+    model = DeepFM(cols, cols, device=device)
+    assert model.stage_plan.uniform_dim == E
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)                       # ONE launch of n rows -> row-chained kernel, auto shapes
+    assert y.shape == (n, 1) and np.isfinite(y).all() and 0.0 < float(y.min()) and float(y.max()) < 1.0
+    # (1) float64 oracle on a row sample that covers the first / last passes and the ragged tail
+    rows = np.unique(np.concatenate([np.arange(0, 300), np.arange(n - 300, n), rng.choice(n, 256, replace=False)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "chain DeepFM E=%d F=%d" % (E, F))
+    # (2) every row against the 32-row kernel, one launch per 4096 rows (different K order: not bit-equal)
+    y32 = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain vs 32-row kernel")
+    # (3) every launch shape gives the same bits: forced <2,8> and <2,4> on the whole launch, and on a small ragged one
+    for tr in (256, 128):
+        assert np.array_equal(_predict(model, feed, 4096, tile_rows=tr), y), "launch shape %d" % tr
+    m = 256 * 3 + 77
+    for tr in (256, 128):
+        ys = _predict(model, {k: v[:m] for k, v in feed.items()}, m, tile_rows=tr)
+        assert np.array_equal(ys, y[:m]), "forced shape %d, small launch" % tr
+    # (4) a permutation of the rows permutes the outputs bit for bit (other pass / wave / shape membership)
+    perm = rng.permutation(n)
+    yp = model.predict({k: v[perm] for k, v in feed.items()}, batch_size=4096)
+    assert np.array_equal(yp, y[perm])
+    # (5) the launch cut in two (chained launches of other sizes) still gives the same bits
+    cut = 16384 + 4096
+    ya = model.predict({k: v[:cut] for k, v in feed.items()}, batch_size=4096)
+    assert np.array_equal(ya, y[:cut])
+
+
+def test_chain_kernel_model_variants(device):
+    """Terms switched off (WDL: no FM; FNN: no FM, no linear part), int64 ids (host and device), a feature outside the FM
+    group, sigmoid / tanh DNN, regression head — against the float64 oracle or the 32-row kernel."""
+    import torch
+    from deepctr_amd.feature_column import SparseFeat
+    from deepctr_amd.models import FNN, WDL, DeepFM
+    rng = np.random.RandomState(23)
+    n = 16384 + 1000
+    cols, feed = _criteo_like(rng, n, V=2000, E=16)
+    for ctor, fn in ((WDL, RM.wdl), (FNN, RM.fnn)):
+        model = ctor(cols, cols, device=device)
+        w = _randomise(model, rng)
+        y = model.predict(feed, batch_size=1024)
+        rows = rng.choice(n, 200, replace=False)
+        ref = fn(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+        check_probs(y[rows], ref.astype(np.float32), ctor.__name__ + " chain")
+        assert np.array_equal(y, _predict(model, feed, 1024, tile_rows=256)), ctor.__name__ + " forced shape"
+        assert_close(y, _predict(model, feed, 4096, span_batches=False, tile_rows=32), rtol=2e-6, atol=2e-7,
+                     what=ctor.__name__ + " chain vs 32-row")
+    # int64 ids beyond int32 range are out of range for these vocabularies: ids stay int64 on the device; tanh; regression
+    scols = [SparseFeat("C%d" % i, 3000 + i, 32) for i in range(1, 14)]          # 13 fields: the last pair has one field
+    sfeed = {"C%d" % i: rng.randint(0, 3000 + i, n).astype(np.int64) for i in range(1, 14)}
+    for act in ("tanh", "sigmoid"):
+        model = DeepFM(scols, scols, dnn_activation=act, task="regression", device=device)
+        w = _randomise(model, rng)
+        y = model.predict(sfeed, batch_size=512)
+        rows = rng.choice(n, 200, replace=False)
+        ref = RM.deepfm(scols, scols, w, {k: v[rows] for k, v in sfeed.items()}, dnn_activation=act, task="regression",
+                        dtype=np.float64)
+        assert_close(y[rows], ref.astype(np.float32), rtol=1e-4, atol=2e-5, what="chain %s regression" % act)
+        assert model.launch_plan(model.stage(sfeed), 0, n, __import__("torch").empty(n, device=model.device))[0][1] == "chain"
+        staged = model.stage(sfeed)
+        staged.ids = staged.ids.to(torch.int64)                     # (ids that fit int32 are packed to int32 while staging)
+        out = torch.empty(n, dtype=torch.float32, device=model.device)
+        model._begin()
+        model._forward(staged, 0, n, out)
+        model._check_status()
+        assert np.array_equal(out.cpu().numpy().reshape(-1, 1), y)
+
+
+def test_chain_kernel_reports_out_of_range_ids(device):
+    import torch
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(3)
+    n = 16384 + 512
+    cols, feed = _criteo_like(rng, n, V=500, E=16)
+    model = DeepFM(cols, cols, device=device)
+    for field, row, bad in (("C7", n - 5, 500), ("C26", 3, -1), ("C1", 9000, 2 ** 31 - 1)):
+        good = int(feed[field][row])
+        feed[field] = feed[field].copy()
+        feed[field][row] = bad                                      # == vocabulary_size / negative / far out
+        with pytest.raises(IndexError):
+            model.predict(feed, batch_size=4096)
+        feed[field][row] = good
+        assert np.isfinite(model.predict(feed, batch_size=4096)).all()  # the flag was cleared by the raise
+    # int64 ids with a non-zero upper word
+    staged = model.stage(feed)
+    staged.ids = staged.ids.to(torch.int64)
+    staged.ids[4, 77] = (1 << 32) + 5
+    out = torch.empty(n, dtype=torch.float32, device=model.device)
+    model._begin()
+    model._forward(staged, 0, n, out)
+    with pytest.raises(IndexError):
+        model._check_status()
+
+
+def test_streaming_kernel_still_reachable(device):
+    """tile_rows = 64 forces the streaming kernel (the fallback of models the row-chained kernel does not take)."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(5)
+    n = 64 * 300 + 5
+    cols, feed = _criteo_like(rng, n, V=3000, E=16)
+    model = DeepFM(cols, cols, device=device)
+    _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    ys = _predict(model, feed, 4096, tile_rows=64)
+    assert_close(ys, y, rtol=2e-6, atol=2e-7, what="streaming vs chained kernel")
+    # a DNN the chained kernel has no instantiation for goes to the streaming kernel by itself
+    model2 = DeepFM(cols, cols, dnn_hidden_units=(128, 96, 40), device=device)
+    _randomise(model2, rng)
+    y2 = model2.predict(feed, batch_size=4096)
+    assert_close(y2, _predict(model2, feed, 4096, span_batches=False, tile_rows=32), rtol=2e-6, atol=2e-7, what="fallback")
