@@ -28,8 +28,8 @@
 // (layer 1) + operand staging -> two waves per SIMD.
 //
 // Eligibility (host, below): uniform embedding_dim 16 or 32, no hashing / identity fields, dense columns right behind the
-// embeddings, every units[l] a multiple of 64 from the instantiated set, a head, no Dice / BatchNormalization / saved
-// activations, and at least 256 rows per CU (or tile_rows == 256).  Everything else takes stream_kernel / mlp_kernel.
+// embeddings, every units[l] a multiple of 64 from the instantiated set, ReLU or linear activation, a head, no
+// BatchNormalization / saved activations, and at least 64 rows per CU (or tile_rows 128 / 256).  Everything else takes stream_kernel / mlp_kernel.
 // Same arithmetic as those: v_mfma_f32_16x16x4_f32 = exact fp32; only the summation order over k differs.
 #pragma once
 #include "mlp_device.h"
@@ -81,8 +81,9 @@ constexpr int RING_OFF = 2048;
 constexpr int DENSE_OFF = RING_OFF + NSLOT * SLOT_F;   // [rows of a pass][16 * dense k-blocks] zero-padded dense values of the pass
 constexpr int MAX_DENSE_BLOCKS = 4;
 // + [NW waves][RT N tiles][64 lanes] shares of dense . dense_lin_w of the staged pass
+// + [NW waves][4 RT quads][64 lanes] parked accumulators (layer-0 M-group M0 - 1 while layer 1 works on the others)
 static inline size_t lds_bytes(int rt, int nw, int n_dense) {
-    return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64) * sizeof(float);
+    return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64 + nw * 4 * rt * 256) * sizeof(float);
 }
 
 struct ChainParams {
@@ -143,32 +144,29 @@ __device__ __forceinline__ uint64_t sgpr64(uint32_t lo, uint32_t hi) {
 // by hipcc, the operands are visible) or from accumulators finished a layer earlier; non-MFMA reads of accumulators come
 // after mfma_drain().
 __device__ __forceinline__ void mfma_ip(f32x4& acc, float a, float b) {
-#ifdef DCTR_CHAIN_ASM_MFMA
+#ifndef DCTR_CHAIN_BUILTIN_MFMA
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 #else
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 #endif
 }
+// (layers >= 1 keep the builtin: their B operand is an ELEMENT of a previous layer's accumulator quad, and an inline-asm
+// operand cannot be a sub-register — every such operand would be copied out first)
+__device__ __forceinline__ void mfma_bi(f32x4& acc, float a, float b) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-// activation of a whole accumulator set in place (one switch per layer, not per element)
-template <int ACT, int NM, int RT>
-__device__ __forceinline__ void act_block_t(f32x4 (&acc)[NM][RT]) {
+// activation of a whole accumulator set in place.  Only ReLU and linear DNNs take this kernel (the host sends tanh / sigmoid
+// ones to the streaming kernel): the libm code of the other activations, unrolled over 128 accumulator registers, made hipcc
+// spill accumulators around the layer boundaries on the ReLU path as well
+template <int NM, int RT>
+__device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][RT]) {
+    const float floor_ = act == DCTR_ACT_RELU ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[m][nt][r] = act_t<ACT>(acc[m][nt][r], 0.f, 0.f, 1.f, 0.f);
-}
-template <int NM, int RT>
-__device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][RT]) {
-    switch (act) {
-        case DCTR_ACT_RELU: act_block_t<DCTR_ACT_RELU, NM, RT>(acc); break;
-        case DCTR_ACT_SIGMOID: act_block_t<DCTR_ACT_SIGMOID, NM, RT>(acc); break;
-        case DCTR_ACT_TANH: act_block_t<DCTR_ACT_TANH, NM, RT>(acc); break;
-        default: break;
-    }
+            for (int r = 0; r < 4; ++r) acc[m][nt][r] = fmaxf(acc[m][nt][r], floor_);
 }
 
 // the gathered operand of one k-block for this lane: 16-B piece g of row j's embedding per N tile
@@ -202,6 +200,13 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
+    // per-lane constants of cold or once-per-pair code are rebuilt from an opaque copy of the lane index: as invariants of the
+    // k-loop they would be hoisted, kept live across it, and push accumulators into scratch
+    auto opaque_lane = [&]() -> int {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
 
     // ---- once per launch: descriptors, biases, head weights, dense linear weights -> LDS
     for (int i = threadIdx.x; i < 12 * p.n_fields; i += NT)
@@ -220,7 +225,14 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
     const int STEPS = NB + SL;
     const int k_last = p.in_dim - 1;
     float* dreg = smem + DENSE_OFF + (WROWS * wave) * (16 * NDB);     // this wave's rows of the dense staging area
-    float* dlacc = smem + DENSE_OFF + PROWS * 16 * NDB + wave * (RT * 64) + lane;   // [nt * 64]: this lane's share of dense . w
+    // Layer 1 starts with 128 + 64 accumulator registers live (all of layer 0's outputs, its own) and uses layer 0's M-groups
+    // one after the other: the LAST M-group of layer 0 waits in LDS until the first ones are dead (8 x 1 KiB per wave, written
+    // once and read once per pass) — 32 registers less at the peak, which is what keeps hipcc from spilling accumulator
+    // elements to scratch there (reloads whose vmcnt(0) sits behind the DMA of the step)
+    auto park_ptr = [&]() -> f32x4* {
+        return reinterpret_cast<f32x4*>(smem + DENSE_OFF + PROWS * 16 * NDB + NW * RT * 64 + wave * (4 * RT * 256)) + opaque_lane();
+    };
+    auto dlacc_ptr = [&]() -> float* { return smem + DENSE_OFF + PROWS * 16 * NDB + wave * (RT * 64) + opaque_lane(); };   // [nt * 64]
 
     // ---- weight chunks.  Chunk ci of a pass: ci < NB: rows 16*ci .. + 15 of W0 (all 64*M0 columns); then the 64 x 64
     // sub-blocks (mg, mg1) of W1, mg-major; then those of W2; ci >= STEPS wraps to the next pass.  A chunk image is
@@ -295,12 +307,12 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
     // and N tile; a k-block's ids reach the (g, j) lanes through ds_bpermute (the LDS crossbar, no memory traffic)
     auto row_of = [&](int pass, int nt) -> int { return pass * PROWS + WROWS * wave + 16 * nt + j; };
     auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), (int)p.batch - 1); };
-    const int q = lane >> 5;                           // which field of the pair this lane serves
     int oor = 0;
     // request the ids of field pair pr for the rows of `pass`
     auto request_pair_ids = [&](int pr, int pass, uint32_t& lo, uint32_t& hi) {
+        const int ln = opaque_lane(), q = ln >> 5;
         const int fi = min(2 * pr + q, p.n_fields - 1);
-        const int r = min(pass * PROWS + WROWS * wave + min(lane & 31, WROWS - 1), (int)p.batch - 1);
+        const int r = min(pass * PROWS + WROWS * wave + min(ln & 31, WROWS - 1), (int)p.batch - 1);
         const int64_t eo = (int64_t)fi * p.ids_stride_f + (int64_t)r * p.ids_stride_b;
         if constexpr (I64) {
             const u32x2 v = *(gbl_u2_t)(reinterpret_cast<const u32x2*>(p.ids) + eo);
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
     };
     // landed ids -> rows: range check against the field's vocabulary, out-of-range ids read row 0 and raise the flag
     auto fold_pair_ids = [&](int pr, int pass, uint32_t lo, uint32_t hi) -> uint32_t {
+        const int ln = opaque_lane(), q = ln >> 5;
         const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
         const uint2 va = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 4);
         const uint2 vb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 4);
@@ -321,12 +334,13 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
         const uint32_t lim = q ? lim_b : lim_a;
         const uint32_t upper = I64 ? hi : (uint32_t)((int32_t)lo >> 31);      // anything but 0: negative or >= 2^32
         const bool ok = upper == 0u && lo < lim;
-        const bool counts = (lane & 31) < WROWS && pass * PROWS + WROWS * wave + (lane & 31) < (int)p.batch && 2 * pr + q < p.n_fields;
+        const bool counts = (ln & 31) < WROWS && pass * PROWS + WROWS * wave + (ln & 31) < (int)p.batch && 2 * pr + q < p.n_fields;
         if (__any(!ok && counts)) oor = 1;                 // (wave-uniform flag: a scalar register, not a VGPR)
         return ok ? lo : 0u;
     };
     // linear-table entries of the pair (row per lane); fields without a linear table, or past the last field, give 0
     auto pair_lin_ptr = [&](int pr, uint32_t idc, bool& has) -> gbl_f_t {
+        const int q = opaque_lane() >> 5;
         const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
         const uint2 la = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 2);
         const uint2 lb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 2);
@@ -367,6 +381,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
     };
     auto dense_store = [&](int c, const float (&td)[RT][4]) {
         const int d0 = 16 * c + 4 * g;
+        float* dlacc = dlacc_ptr();
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
             f32x4 v;
@@ -394,19 +409,14 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
     // registers are named so that hipcc places its own bookkeeping wait here and not in front of their first use
 #define CHAIN_TOP_X(X)                                                                                           \
     do {                                                                                                         \
-        if constexpr (RT == 2)                                                                                   \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER                                        \
-                         : "+v"(X.x[0]), "+v"(X.x[RT - 1]), "+v"(lvn), "+v"(idr_lo), "+v"(idr_hi)                  \
-                         :                                                                                       \
-                         : "memory");                                                                            \
-        else                                                                                                     \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER                                        \
-                         : "+v"(X.x[0]), "+v"(lvn), "+v"(idr_lo), "+v"(idr_hi)                                     \
-                         :                                                                                       \
-                         : "memory");                                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(lvn), "+v"(idr_lo) : : "memory");   \
+        if constexpr (I64) asm volatile("" : "+v"(idr_hi));                                                      \
     } while (0)
 #define CHAIN_TOP_ID()                                                                                           \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(idr_lo), "+v"(idr_hi) : : "memory")
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(idr_lo) : : "memory");              \
+        if constexpr (I64) asm volatile("" : "+v"(idr_hi));                                                      \
+    } while (0)
 #define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER ::: "memory")
 
     // A-operand lane offsets (floats) inside a chunk image
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
                 fm += __shfl_xor(fm, 16, 64);
                 fm += __shfl_xor(fm, 32, 64);
                 fm *= 0.5f;
-                float dl = NDB > 0 ? dlacc[nt * 64] : 0.f;
+                float dl = NDB > 0 ? dlacc_ptr()[nt * 64] : 0.f;
                 dl += __shfl_xor(dl, 16, 64);
                 dl += __shfl_xor(dl, 32, 64);
                 const float lin_all = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * nt + j), __builtin_bit_cast(int, lin_rows))) + dl;
@@ -615,6 +625,13 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
         }
         // activation in place: acc0 is now the B operand of layer 1
         act_block<4 * M0, RT>(p.activation, acc0);
+        if constexpr (M0 > 1) {
+            f32x4* park = park_ptr();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt) park[(mt * RT + nt) * 64] = acc0[4 * (M0 - 1) + mt][nt];
+        }
 
         // ================= layers >= 1: one step per 64 x 64 sub-block (mg, mg1): 16 k-steps (mt, r) of 4 M-tiles x RT MFMAs
         auto read_an = [&](const float* sb, int ks) -> f32x4 {
@@ -640,8 +657,9 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
             }
         };
         // (the generic lambda is instantiated per layer; MI / MO = M-groups of its input / output)
-        auto dense_layer = [&](auto& accin, auto& accout, auto MIc, auto MOc) {
+        auto dense_layer = [&](auto& accin, auto& accout, auto MIc, auto MOc, auto PARKc) {
             constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
+            constexpr bool PARKED = decltype(PARKc)::value && MI > 1;      // accin's last M-group waits in LDS
 #pragma unroll
             for (int mg = 0; mg < MI; ++mg) {
 #pragma unroll
@@ -656,6 +674,13 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
                         dense_rest(pass_n);
                     }
                     if (first) c0 = read_an(sb, 0);
+                    if (PARKED && mg == MI - 1 && mg1 == 0) {
+                        const f32x4* park = park_ptr();
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < RT; ++nt) accin[4 * mg + mt][nt] = park[(mt * RT + nt) * 64];
+                    }
 #pragma unroll
                     for (int ks = 0; ks < 16; ks += 2) {
                         c1 = read_an(sb, ks + 1);
@@ -664,7 +689,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
                         for (int mt1 = 0; mt1 < 4; ++mt1)
 #pragma unroll
                             for (int nt = 0; nt < RT; ++nt)
-                                mfma_ip(accout[4 * mg1 + mt1][nt], c0[mt1], accin[4 * mg + (ks >> 2)][nt][ks & 3]);
+                                mfma_bi(accout[4 * mg1 + mt1][nt], c0[mt1], accin[4 * mg + (ks >> 2)][nt][ks & 3]);
                         DCTR_SB;
                         if (ks == PH) {
                             // the chunk after next, and at the pass's end the next pass's gather prologue
@@ -686,7 +711,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
                         for (int mt1 = 0; mt1 < 4; ++mt1)
 #pragma unroll
                             for (int nt = 0; nt < RT; ++nt)
-                                mfma_ip(accout[4 * mg1 + mt1][nt], c1[mt1], accin[4 * mg + ((ks + 1) >> 2)][nt][(ks + 1) & 3]);
+                                mfma_bi(accout[4 * mg1 + mt1][nt], c1[mt1], accin[4 * mg + ((ks + 1) >> 2)][nt][(ks + 1) & 3]);
                         DCTR_SB;
                     }
                     slot_next();
@@ -696,7 +721,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
         };
         f32x4 acc1[4 * M1][RT];
         init_acc(acc1, B1_OFF, std::integral_constant<int, M1>{});
-        dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{});
+        dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{}, std::true_type{});
         mfma_drain();
         CTS(2);
         float hs[RT];
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
             act_block<4 * M1, RT>(p.activation, acc1);
             f32x4 acc2[4 * (M2 > 0 ? M2 : 1)][RT];
             init_acc(acc2, B2_OFF, std::integral_constant<int, M2>{});
-            dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{});
+            dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{}, std::false_type{});
             mfma_drain();
             head(acc2, std::integral_constant<int, M2>{});
         } else {

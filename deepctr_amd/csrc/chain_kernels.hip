@@ -20,7 +20,7 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     const int E = g->uniform_dim;
     if (E != 16 && E != 32) return 0;
     if (g->any_hash || !a->has_head || a->save_acts != nullptr) return 0;
-    if (a->activation == DCTR_ACT_DICE || a->bn_scale != nullptr) return 0;
+    if ((a->activation != DCTR_ACT_RELU && a->activation != DCTR_ACT_LINEAR) || a->bn_scale != nullptr) return 0;
     if (a->n_layers != 3 || a->units[0] != 256 || a->units[1] != 128 || a->units[2] != 64) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;

@@ -73,7 +73,7 @@ def test_chain_kernel_vs_oracle_and_tile_kernel(device, E, V, n, F, ND):
 
 def test_chain_kernel_model_variants(device):
     """Terms switched off (WDL: no FM; FNN: no FM, no linear part), int64 ids (host and device), a feature outside the FM
-    group, sigmoid / tanh DNN, regression head — against the float64 oracle or the 32-row kernel."""
+    group, linear / tanh DNN, regression head — against the float64 oracle or the 32-row kernel."""
     import torch
     from deepctr_amd.feature_column import SparseFeat
     from deepctr_amd.models import FNN, WDL, DeepFM
@@ -93,15 +93,16 @@ def test_chain_kernel_model_variants(device):
     # int64 ids beyond int32 range are out of range for these vocabularies: ids stay int64 on the device; tanh; regression
     scols = [SparseFeat("C%d" % i, 3000 + i, 32) for i in range(1, 14)]          # 13 fields: the last pair has one field
     sfeed = {"C%d" % i: rng.randint(0, 3000 + i, n).astype(np.int64) for i in range(1, 14)}
-    for act in ("tanh", "sigmoid"):
+    # (ReLU / linear DNNs take the row-chained kernel; tanh / sigmoid ones the streaming kernel)
+    for act, kern in (("relu", "chain"), ("linear", "chain"), ("tanh", "stream")):
         model = DeepFM(scols, scols, dnn_activation=act, task="regression", device=device)
         w = _randomise(model, rng)
         y = model.predict(sfeed, batch_size=512)
         rows = rng.choice(n, 200, replace=False)
         ref = RM.deepfm(scols, scols, w, {k: v[rows] for k, v in sfeed.items()}, dnn_activation=act, task="regression",
                         dtype=np.float64)
-        assert_close(y[rows], ref.astype(np.float32), rtol=1e-4, atol=2e-5, what="chain %s regression" % act)
-        assert model.launch_plan(model.stage(sfeed), 0, n, __import__("torch").empty(n, device=model.device))[0][1] == "chain"
+        assert_close(y[rows], ref.astype(np.float32), rtol=1e-4, atol=2e-5, what="%s %s regression" % (kern, act))
+        assert model.launch_plan(model.stage(sfeed), 0, n, torch.empty(n, device=model.device))[0][1] == kern
         staged = model.stage(sfeed)
         staged.ids = staged.ids.to(torch.int64)                     # (ids that fit int32 are packed to int32 while staging)
         out = torch.empty(n, dtype=torch.float32, device=model.device)

@@ -43,6 +43,12 @@ def well_conditioned_rows(meta, feed, n):
 
 
 def check_probs(y, ref, what, rows=None):
+    """Probabilities within 1e-4 relative (north_star), and the logits recovered from them within 1e-4 relative + 2e-5.
+    Where the 2e-5 comes from: the kernels hand back fp32 PROBABILITIES; logit(p) turns one ulp of p into
+    2^-24 / (p (1 - p)) of logit — 2.4e-6 at p = 0.975, 6e-6 at p = 0.99 — and the logit itself is lin + FM + DNN, three
+    fp32 sums of opposite signs whose terms reach ~10 (FM: 0.5 * sum_d (S_d^2 - Q_d) over 26 fields), i.e. a few ulp of 10 =
+    1e-5 however the sums are ordered.  The op-level tests bound each sum by the magnitude of ITS terms
+    (tests/util.assert_close_terms, assert_fm_close); at model level only their total is visible."""
     assert y.shape == ref.shape and y.dtype == np.float32
     if rows is not None:
         y, ref = y[rows], ref[rows]
@@ -148,6 +154,71 @@ def test_xdeepfm_dcn_c3_shape_vs_oracle(device):
         w = _randomise(model, rng)
         check_probs(model.predict(feed, batch_size=128),
                     RM.dcn(cols, cols, w, feed, cross_num=2, cross_parameterization=par, dtype=np.float64).astype(np.float32), "DCN " + par)
+
+
+def test_xdeepfm_dcn_c3_full_batch(device):
+    """BASELINE config 3 at its FULL batch (26 tables x 1e5 rows x 16, batch 4096, CIN [128, 128]; DCN beside it): the float64
+    oracle on a row sample (first / last workgroups of the launch grids + random rows), row-permutation equivariance bit for
+    bit, batch-split invariance."""
+    from deepctr_amd.models import DCN, xDeepFM
+    rng = np.random.RandomState(41)
+    B = 4096
+    cols, feed = _criteo_like(rng, B, V=100000)
+    rows = np.unique(np.concatenate([np.arange(0, 20), np.arange(B - 20, B), rng.choice(B, 56, replace=False)]))
+    sub = {k: v[rows] for k, v in feed.items()}
+    perm = rng.permutation(B)
+    for name, ctor, fn, kw in (("xDeepFM C3", xDeepFM, RM.xdeepfm, dict(cin_layer_size=(128, 128))),
+                               ("DCN vector", DCN, RM.dcn, dict(cross_num=2, cross_parameterization="vector")),
+                               ("DCN matrix", DCN, RM.dcn, dict(cross_num=2, cross_parameterization="matrix"))):
+        model = ctor(cols, cols, device=device, **kw)
+        w = _randomise(model, rng)
+        y = model.predict(feed, batch_size=B)
+        assert y.shape == (B, 1) and np.isfinite(y).all() and 0.0 < float(y.min()) and float(y.max()) < 1.0
+        check_probs(y[rows], fn(cols, cols, w, sub, dtype=np.float64, **kw).astype(np.float32), name + " b4096")
+        assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=B), y[perm]), name + " permutation"
+        assert_close(model.predict(feed, batch_size=1000), y, rtol=1e-5, atol=1e-6, what=name + " split")
+
+
+def test_din_c4_full_batch(device):
+    """BASELINE config 4 at its FULL size (behaviour sequence T = 50, item vocabulary 1e6, embedding_dim 32, batch 2048, Dice
+    attention): the float64 oracle on a row sample, permutation equivariance, batch-split invariance."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DIN
+    rng = np.random.RandomState(42)
+    n, T, E, VI, VC = 2048, 50, 32, 1000000, 1001
+    cols = [SparseFeat("user", 100000, E), SparseFeat("gender", 2, E), SparseFeat("item_id", VI, E), SparseFeat("cate_id", VC, E),
+            DenseFeat("pay_score", 1),
+            VarLenSparseFeat(SparseFeat("hist_item_id", VI, E, embedding_name="item_id"), maxlen=T),
+            VarLenSparseFeat(SparseFeat("hist_cate_id", VC, E, embedding_name="cate_id"), maxlen=T)]
+    lens = rng.randint(1, T + 1, n)
+    hi = rng.randint(1, VI, (n, T)).astype(np.int32)
+    hc = rng.randint(1, VC, (n, T)).astype(np.int32)
+    pad = np.arange(T)[None, :] >= lens[:, None]
+    hi[pad] = 0
+    hc[pad] = 0
+    feed = {"user": rng.randint(0, 100000, n).astype(np.int32), "gender": rng.randint(0, 2, n).astype(np.int32),
+            "item_id": rng.randint(1, VI, n).astype(np.int32), "cate_id": rng.randint(1, VC, n).astype(np.int32),
+            "pay_score": rng.rand(n).astype(np.float32), "hist_item_id": hi, "hist_cate_id": hc}
+    model = DIN(cols, ["item_id", "cate_id"], att_activation="dice", device=device)
+    w = _randomise(model, rng)
+    for k in list(w):
+        if k.endswith("moving_variance"):
+            w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
+    model.set_weights_by_name(w)
+    wk = {}
+    for k, v in w.items():                      # the oracle speaks keras names for the BatchNormalization inside Dice
+        lname, wname = k.rsplit("/", 1)
+        if wname in ("moving_mean", "moving_variance"):
+            lname = "batch_normalization" + lname[len("dice"):]
+        wk["%s/%s" % (lname, wname)] = v
+    y = model.predict(feed, batch_size=n)
+    assert y.shape == (n, 1) and np.isfinite(y).all()
+    rows = np.unique(np.concatenate([np.arange(0, 12), np.arange(n - 12, n), rng.choice(n, 40, replace=False)]))
+    ref = RM.din(cols, ["item_id", "cate_id"], wk, {k: v[rows] for k, v in feed.items()}, att_activation="dice", dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "DIN C4 b2048")
+    perm = rng.permutation(n)
+    assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=n), y[perm])
+    assert_close(model.predict(feed, batch_size=500), y, rtol=1e-5, atol=1e-6, what="DIN split")
 
 
 def test_din_c4_shape_vs_oracle(device):

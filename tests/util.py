@@ -44,3 +44,16 @@ def assert_fm_close(got, x, what="fm"):
     err = np.abs(np.asarray(got, dtype=np.float64).reshape(-1) - ref)
     bar = 1e-4 * np.abs(ref) + 1e-6 + 4 * np.finfo(np.float32).eps * scale
     assert (err <= bar).all(), "%s: max err/bar %.3g" % (what, float((err / bar).max()))
+
+
+def assert_close_terms(got, ref, terms, rtol=1e-4, rtol_terms=2e-6, what=""):
+    """fp32 bar for a result that is a SUM of terms which may cancel: 1e-4 of the result (north_star) plus a few fp32 ulp
+    (2e-6 ~ 17 * 2^-23: summation orders of the MFMA path and the reference differ over tens to hundreds of terms) of the
+    magnitude the terms were summed at.  `terms` >= sum of |summands| per output element, from the float64 oracle run on
+    absolute values (an upper bound of every intermediate magnitude for products, sums and ReLU); it replaces blanket
+    absolute tolerances: where nothing cancels, terms ~ |ref| and the bar stays 1e-4 relative."""
+    got, ref, terms = (np.asarray(a, dtype=np.float64) for a in (got, ref, terms))
+    err = np.abs(got - ref)
+    bar = rtol * np.abs(ref) + rtol_terms * np.abs(terms) + 1e-30
+    worst = float((err / bar).max()) if err.size else 0.0
+    assert (err <= bar).all(), "%s: max err / bar = %.3g (rtol=%g, %g of the summed magnitude)" % (what, worst, rtol, rtol_terms)
