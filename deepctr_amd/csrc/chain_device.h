@@ -83,7 +83,12 @@ constexpr int MAX_DENSE_BLOCKS = 4;
 // + [NW waves][RT N tiles][64 lanes] shares of dense . dense_lin_w of the staged pass
 // + [NW waves][4 RT quads][64 lanes] parked accumulators (layer-0 M-group M0 - 1 while layer 1 works on the others)
 static inline size_t lds_bytes(int rt, int nw, int n_dense) {
-    return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64 + nw * 4 * rt * 256) * sizeof(float);
+#ifdef DCTR_CHAIN_W4X2
+    const int park = nw == 8 ? nw * 4 * rt * 256 : 0;
+#else
+    const int park = nw * 4 * rt * 256;
+#endif
+    return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64 + park) * sizeof(float);
 }
 
 struct ChainParams {
@@ -177,8 +182,15 @@ struct XBlkT {
 
 // RT, NW: launch shape (above); EB = embedding_dim / 16 k-blocks per field; I64: int64 ids; M0 / M1 / M2 = units[l] / 64
 // (M2 == 0: two layers)
+#ifdef DCTR_CHAIN_W4X2     // lab: two independent 4-wave workgroups per CU for the <2, 4> shape (no parking: LDS for two)
+#define CHAIN_MIN_BLOCKS(RT, NW) ((RT) == 2 && (NW) == 4 ? 2 : 1)
+#define CHAIN_PARK(RT, NW) ((NW) == 8)
+#else
+#define CHAIN_MIN_BLOCKS(RT, NW) 1
+#define CHAIN_PARK(RT, NW) true
+#endif
 template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2>
-__global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
+__global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     constexpr int WROWS = 16 * RT;                 // batch rows of a wave
     constexpr int PROWS = NW * WROWS;              // batch rows per pass
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
         }
         // activation in place: acc0 is now the B operand of layer 1
         act_block<4 * M0, RT>(p.activation, acc0);
-        if constexpr (M0 > 1) {
+        if constexpr (M0 > 1 && CHAIN_PARK(RT, NW)) {
             f32x4* park = park_ptr();
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(ChainParams p) {
         // (the generic lambda is instantiated per layer; MI / MO = M-groups of its input / output)
         auto dense_layer = [&](auto& accin, auto& accout, auto MIc, auto MOc, auto PARKc) {
             constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
-            constexpr bool PARKED = decltype(PARKc)::value && MI > 1;      // accin's last M-group waits in LDS
+            constexpr bool PARKED = decltype(PARKc)::value && MI > 1 && CHAIN_PARK(RT, NW);      // accin's last M-group waits in LDS
 #pragma unroll
             for (int mg = 0; mg < MI; ++mg) {
 #pragma unroll

@@ -38,7 +38,12 @@ static int launch_shape(int rt, int nw, const ChainParams& p, int E, hipStream_t
     const int64_t n_pass = dctr_ceil_div(p.batch, (int64_t)(16 * rt * nw));
     ChainParams q = p;
     q.n_pass = (int)n_pass;
-    const unsigned blocks = (unsigned)(n_pass < n_cus() ? n_pass : n_cus());
+#ifdef DCTR_CHAIN_W4X2
+    const int64_t slots = (rt == 2 && nw == 4) ? 2 * (int64_t)n_cus() : n_cus();
+#else
+    const int64_t slots = n_cus();
+#endif
+    const unsigned blocks = (unsigned)(n_pass < slots ? n_pass : slots);
     if (rt == 2 && nw == 8) return launch_r2w8(q, E, blocks, stream);
     if (rt == 2 && nw == 4) return launch_r2w4(q, E, blocks, stream);
     return launch_r1w4(q, E, blocks, stream);
@@ -60,8 +65,8 @@ static ChainParams slice(const ChainParams& p, int64_t r0, int64_t n) {
 // The launches of a call of `batch` rows: (rows, batch rows per workgroup = 256 / 128 / 64 <-> shapes <2,8> / <2,4> / <1,4>).
 // shape 256 / 128: that shape for all rows (forced); 0: whole multiples of 256 rows x CUs as <2, 8> launches (every CU the same
 // number of passes), the rest cut into the shapes that finish it soonest.  Relative pass times (measured, C2): a <2, 8> pass of
-// 256 rows = 1; a <2, 4> pass of 128 rows ~ 0.55 (one wave per SIMD: the matrix pipe is not shared, but nothing hides a wave's
-// request phase either); a <1, 4> pass of 64 rows ~ 0.37.
+// 256 rows = 1 (162 us); a <2, 4> pass of 128 rows ~ 0.60 (one wave per SIMD: the matrix pipe is not shared, but nothing hides a
+// wave's request phase either); a <1, 4> pass of 64 rows ~ 0.39.
 int plan(int64_t batch, int shape, int64_t* rows, int32_t* rpw, int max) {
     int n = 0;
     auto push = [&](int64_t r, int w) {
@@ -80,8 +85,8 @@ int plan(int64_t batch, int shape, int64_t* rows, int32_t* rpw, int max) {
         // cost of finishing `left` rows with one shape (in <2, 8> pass times); the cheapest one takes as many whole rounds
         // over the CUs as it has, the loop goes on with what is left
         const double c28 = (double)dctr_ceil_div(left, 256 * cus);
-        const double c24 = 0.55 * (double)dctr_ceil_div(left, 128 * cus);
-        const double c14 = 0.37 * (double)dctr_ceil_div(left, 64 * cus);
+        const double c24 = 0.60 * (double)dctr_ceil_div(left, 128 * cus);
+        const double c14 = 0.39 * (double)dctr_ceil_div(left, 64 * cus);
         int w = 256;
         if (c24 < c28 && c24 <= c14) w = 128;
         else if (c14 < c28 && c14 < c24) w = 64;
