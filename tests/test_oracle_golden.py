@@ -41,6 +41,60 @@ def test_c_and_python_restatements_agree_on_every_length_branch():
         assert fh.fingerprint64(s) == fh.fingerprint64_py(s), n
 
 
+def _abseil_cityhash64():
+    """abseil's CityHash64 as compiled into pyarrow's libarrow (a local symbol: called through its address).  An
+    implementation neither written nor built by this repository."""
+    import ctypes
+    import glob
+    import shutil
+    import subprocess
+    try:
+        import pyarrow
+    except ImportError:
+        return None
+    nm = shutil.which("nm")
+    libs = sorted(glob.glob(os.path.join(os.path.dirname(pyarrow.__file__), "libarrow.so*")))
+    if nm is None or not libs:
+        return None
+    out = subprocess.run([nm, libs[0]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True).stdout
+    addr = [int(line.split()[0], 16) for line in out.splitlines() if line.endswith("hash_internal10CityHash64EPKcm")]
+    if not addr:
+        return None
+    lib = ctypes.CDLL(libs[0])
+    base = min(int(line.split("-")[0], 16) for line in open("/proc/self/maps") if libs[0] in line)
+    fn = ctypes.CFUNCTYPE(ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t)(base + addr[0])
+    fn._keep = lib
+    return fn
+
+
+def test_fingerprint64_against_an_independent_cityhash64_up_to_32_bytes():
+    """External pin of the <= 16 B and the 17-32 B branches of Fingerprint64 (the latter is what int64 ids >= 10^16 take as
+    decimal strings, reference layers/utils.py:103-107): farmhashna::Hash64 is CityHash64 v1.1 for inputs of up to 32 bytes
+    (farmhash.cc keeps HashLen0to16 / HashLen17to32 unchanged; from 33 bytes on the two differ), and abseil carries CityHash64
+    v1.1.  Both restatements (C and Python) and the hash-bucket assignment built on them are checked against it."""
+    city = _abseil_cityhash64()
+    if city is None:
+        pytest.skip("no abseil CityHash64 found in this image (pyarrow's libarrow + nm)")
+    rng = np.random.RandomState(5)
+    cases = [bytes(rng.randint(0, 256, n).astype(np.uint8)) for n in range(0, 33) for _ in range(40)]
+    ids = [10 ** 16, 10 ** 16 + 1, 2 ** 63 - 1, -(2 ** 63), -10 ** 17, 123456789012345678, 99999999999999999, 10 ** 18 + 7]
+    ids += [int(x) for x in rng.randint(10 ** 16, 2 ** 62, 200, dtype=np.int64)] + [-int(x) for x in rng.randint(10 ** 15, 2 ** 62, 100, dtype=np.int64)]
+    cases += [str(i).encode() for i in ids]
+    assert all(17 <= len(str(i)) <= 20 for i in ids)
+    for s in cases:
+        want = city(s, len(s))
+        assert fh.fingerprint64_py(s) == want, (s, "python restatement")
+        assert fh.fingerprint64(s) == want, (s, "C restatement")
+    # ... and the bucket assignment of such ids, as Hash.call computes it: Fingerprint64(decimal string) mod num_buckets
+    for nb, mz in ((1000003, False), (97, True)):
+        got = fh.hash_bucket_int(np.asarray(ids, dtype=np.int64), nb, mask_zero=mz)
+        want = [city(str(i).encode(), len(str(i))) % (nb - 1 if mz else nb) + (1 if mz else 0) for i in ids]
+        assert [int(g) for g in got] == want
+    # sanity of the comparison itself: from 33 bytes on CityHash64 and Fingerprint64 are different functions
+    s = bytes(range(40))
+    assert city(s, 40) != fh.fingerprint64(s)
+
+
 def test_reference_vocabulary_vector():
     """The reference's only known-answer assertion on this path: tests/layers/utils_test.py:15-33."""
     g = load_golden("hash")
