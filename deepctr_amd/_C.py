@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
@@ -100,7 +100,8 @@ class MlpBwdArgs(ctypes.Structure):
                 ("head_w", c_vp), ("dlogit", c_vp), ("d_kernels", c_vp), ("d_biases", c_vp), ("d_head_w", c_vp),
                 ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
                 ("d_out", c_vp), ("d_out_stride", c_i64), ("biases", c_vp), ("dice_alpha", c_vp), ("dice_mean", c_vp),
-                ("dice_var", c_vp), ("d_dice_alpha", c_vp), ("dice_eps", c_f32), ("pad2_", c_i32)]
+                ("dice_var", c_vp), ("d_dice_alpha", c_vp), ("dice_eps", c_f32), ("pad2_", c_i32),
+                ("dice_batch_mean", c_vp), ("dice_batch_var", c_vp)]
 
 
 class CinBwdArgs(ctypes.Structure):
@@ -194,6 +195,7 @@ SYMBOLS = {
     "dctr_cin_bwd": (ctypes.c_int, [ctypes.POINTER(CinBwdArgs), c_vp]),
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
+    "dctr_dice_train_fwd": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_adam_multi": (ctypes.c_int, [c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_opt_multi": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),

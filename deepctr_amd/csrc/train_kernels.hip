@@ -814,6 +814,137 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(float* __restrict__ dh, c
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Dice under training=True (layers/activation.py:51-64: BatchNormalization(center=False, scale=False, epsilon=1e-9) called with
+// the training flag): the statistics are those of THIS batch over every row (biased variance), gradients flow through them,
+// and the stored statistics move towards them with the layer's momentum.
+//   xn = (z - mu) rs,  p = sigmoid(xn),  y = z (alpha + (1 - alpha) p)
+//   dy/dz (direct) = alpha + (1 - alpha) p;   dxn = dy * z (1 - alpha) * p (1 - p);   dalpha = sum dy * z (1 - p)
+//   dz = dy * direct + rs * (dxn - mean_rows(dxn) - xn * mean_rows(dxn * xn))          (BatchNormalization backward)
+// Column statistics: two passes over z (sum -> mean, then sum of squared deviations): E[z^2] - E[z]^2 would cancel in fp32.
+// ---------------------------------------------------------------------------------------------------
+// pass kind 0: acc[n] += sum_b (z + bias);  kind 1: acc[n] += sum_b (z + bias - mean)^2     (mean = acc0 / rows)
+__global__ __launch_bounds__(256) void dice_colstat_kernel(const float* __restrict__ z, int64_t z_stride, const float* __restrict__ bias,
+                                                          int64_t rows, int N, int kind, const float* __restrict__ sum0,
+                                                          float* __restrict__ acc) {
+    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
+    const float inv = 1.f / (float)rows;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float bn = bias != nullptr ? bias[n] : 0.f;
+        const float mu = kind ? sum0[n] * inv : 0.f;
+        float a = 0.f;
+        for (int r = 0; r < BWD_ROWS; ++r) {
+            const int64_t b = r0 + r;
+            if (b >= rows) break;
+            const float v = z[b * z_stride + n] + bn - mu;
+            a += kind ? v * v : v;
+        }
+        unsafeAtomicAdd(acc + n, a);
+    }
+}
+
+// sums -> batch mean / biased variance (in place), stored statistics moved towards them
+__global__ void dice_stat_finish_kernel(float* __restrict__ mean_sum, float* __restrict__ var_sum, int64_t rows, int N, float momentum,
+                                        float* __restrict__ moving_mean, float* __restrict__ moving_var) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float inv = 1.f / (float)rows;
+    const float m = mean_sum[n] * inv, v = var_sum[n] * inv;
+    mean_sum[n] = m;
+    var_sum[n] = v;
+    if (moving_mean != nullptr) moving_mean[n] = moving_mean[n] * momentum + m * (1.f - momentum);
+    if (moving_var != nullptr) moving_var[n] = moving_var[n] * momentum + v * (1.f - momentum);
+}
+
+__global__ __launch_bounds__(256) void dice_apply_kernel(const float* __restrict__ z, int64_t z_stride, const float* __restrict__ bias,
+                                                        const float* __restrict__ alpha, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, float eps, int64_t rows, int N,
+                                                        float* __restrict__ h, int64_t h_stride) {
+    const int64_t total = rows * N;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / N;
+        const int n = (int)(o - b * N);
+        const float zz = z[b * z_stride + n] + (bias != nullptr ? bias[n] : 0.f);
+        const float p = 1.f / (1.f + expf(-(zz - mean[n]) / sqrtf(var[n] + eps)));
+        h[b * h_stride + n] = zz * (alpha[n] + (1.f - alpha[n]) * p);
+    }
+}
+
+// backward pass 1: S1[n] += sum dxn, S2[n] += sum dxn xn, d_alpha[n] += sum dy z (1 - p)      (zw = X W without the bias)
+__global__ __launch_bounds__(256) void dice_train_bwd_reduce_kernel(const float* __restrict__ dh, const float* __restrict__ zw,
+                                                                   const float* __restrict__ bias, const float* __restrict__ alpha,
+                                                                   const float* __restrict__ mean, const float* __restrict__ var,
+                                                                   float eps, int64_t batch, int N, float* __restrict__ s12,
+                                                                   float* __restrict__ d_alpha) {
+    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float bn = bias != nullptr ? bias[n] : 0.f, al = alpha[n], mu = mean[n];
+        const float rs = 1.f / sqrtf(var[n] + eps);
+        float a1 = 0.f, a2 = 0.f, aa = 0.f;
+        for (int r = 0; r < BWD_ROWS; ++r) {
+            const int64_t b = r0 + r;
+            if (b >= batch) break;
+            const float z = zw[b * N + n] + bn;
+            const float xn = (z - mu) * rs;
+            const float p = 1.f / (1.f + expf(-xn));
+            const float d = dh[b * N + n];
+            const float dxn = d * z * (1.f - al) * p * (1.f - p);
+            a1 += dxn;
+            a2 = fmaf(dxn, xn, a2);
+            aa = fmaf(d, z * (1.f - p), aa);
+        }
+        unsafeAtomicAdd(s12 + n, a1);
+        unsafeAtomicAdd(s12 + N + n, a2);
+        if (d_alpha != nullptr) unsafeAtomicAdd(d_alpha + n, aa);
+    }
+}
+
+// backward pass 2, in place: dh (gradient w.r.t. y) -> gradient w.r.t. z
+__global__ __launch_bounds__(256) void dice_train_bwd_apply_kernel(float* __restrict__ dh, const float* __restrict__ zw,
+                                                                  const float* __restrict__ bias, const float* __restrict__ alpha,
+                                                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                                                  float eps, int64_t batch, int N, const float* __restrict__ s12) {
+    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
+    const float inv = 1.f / (float)batch;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float bn = bias != nullptr ? bias[n] : 0.f, al = alpha[n], mu = mean[n];
+        const float rs = 1.f / sqrtf(var[n] + eps);
+        const float m1 = s12[n] * inv, m2 = s12[N + n] * inv;
+        for (int r = 0; r < BWD_ROWS; ++r) {
+            const int64_t b = r0 + r;
+            if (b >= batch) break;
+            const float z = zw[b * N + n] + bn;
+            const float xn = (z - mu) * rs;
+            const float p = 1.f / (1.f + expf(-xn));
+            const float d = dh[b * N + n];
+            const float dxn = d * z * (1.f - al) * p * (1.f - p);
+            dh[b * N + n] = d * (al + (1.f - al) * p) + rs * (dxn - m1 - xn * m2);
+        }
+    }
+}
+
+extern "C" int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float* bias, int64_t rows, int32_t n, const float* alpha,
+                                   float eps, float momentum, float* moving_mean, float* moving_var, float* batch_mean,
+                                   float* batch_var, float* h, int64_t h_stride, void* stream) {
+    DCTR_REQUIRE(z && alpha && batch_mean && batch_var && h, DCTR_E_NULL, "dice_train_fwd: null pointer");
+    DCTR_REQUIRE(rows >= 1 && n >= 1 && z_stride >= n && h_stride >= n, DCTR_E_DIM, "dice_train_fwd: bad sizes (rows=%lld n=%d)",
+                 (long long)rows, n);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(batch_mean, 0, (size_t)n * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(batch_var, 0, (size_t)n * sizeof(float), st);
+    DCTR_REQUIRE(e == hipSuccess, (int)e, "dice_train_fwd: memset failed: %s", hipGetErrorString(e));
+    const unsigned rb = (unsigned)dctr_ceil_div(rows, (int64_t)BWD_ROWS);
+    hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 0, (const float*)nullptr, batch_mean);
+    hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 1, (const float*)batch_mean, batch_var);
+    hipLaunchKernelGGL(dice_stat_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, batch_mean, batch_var, rows, (int)n, momentum,
+                       moving_mean, moving_var);
+    const int64_t total = rows * n;
+    const unsigned blocks = (unsigned)(dctr_ceil_div(total, (int64_t)256) < 4096 ? dctr_ceil_div(total, (int64_t)256) : 4096);
+    hipLaunchKernelGGL(dice_apply_kernel, dim3(blocks), dim3(256), 0, st, z, z_stride, bias, alpha, (const float*)batch_mean,
+                       (const float*)batch_var, eps, rows, (int)n, h, h_stride);
+    return dctr_launch_status("dctr_dice_train_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // DIN's LocalActivationUnit as a training step (layers/core.py:94-108, layers/sequence.py:261-298): the attention input
 // [q, k, q - k, q * k] is materialised once per batch ([B*T, 4E]) so that the attention MLP runs through dctr_mlp_fwd /
 // dctr_mlp_bwd with saved activations; the masked weighted sum and the scatter of the key gradients are kernels here.
@@ -1109,7 +1240,8 @@ extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
     int w = a->in_dim;
     for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
     // two ping-pong buffers [B, widest layer]; Dice needs a third for the recomputed pre-activations
-    return (size_t)(a->activation == DCTR_ACT_DICE ? 3 : 2) * a->batch * w * sizeof(float);
+    // ... and, with batch statistics, 2 x widest for the two column sums of the BatchNormalization backward
+    return ((size_t)(a->activation == DCTR_ACT_DICE ? 3 : 2) * a->batch * w + (a->activation == DCTR_ACT_DICE ? 2 * (size_t)w : 0)) * sizeof(float);
 }
 
 extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
@@ -1148,9 +1280,20 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, N, B, K, &one, a->kernels[l], N, xin, ldx,
                                           &zero, bufZ, N);
         if (rs != rocblas_status_success) return (int)rs;
-        hipLaunchKernelGGL(dice_bwd_kernel, dim3(rb), dim3(256), 0, st, buf, bufZ, a->biases != nullptr ? a->biases[l] : nullptr,
-                           a->dice_alpha[l], a->dice_mean[l], a->dice_var[l], a->dice_eps, a->batch, N,
-                           a->d_dice_alpha != nullptr ? a->d_dice_alpha[l] : nullptr);
+        const float* bl = a->biases != nullptr ? a->biases[l] : nullptr;
+        float* dal = a->d_dice_alpha != nullptr ? a->d_dice_alpha[l] : nullptr;
+        if (a->dice_batch_mean != nullptr && a->dice_batch_var != nullptr && a->dice_batch_mean[l] != nullptr) {
+            // training-mode Dice: this batch's statistics, gradients through them
+            float* s12 = bufZ + (size_t)a->batch * w;
+            if (hipMemsetAsync(s12, 0, (size_t)2 * N * sizeof(float), st) != hipSuccess) return -1;
+            hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)buf, (const float*)bufZ, bl,
+                               a->dice_alpha[l], a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
+            hipLaunchKernelGGL(dice_train_bwd_apply_kernel, dim3(rb), dim3(256), 0, st, buf, (const float*)bufZ, bl, a->dice_alpha[l],
+                               a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, (const float*)s12);
+            return 0;
+        }
+        hipLaunchKernelGGL(dice_bwd_kernel, dim3(rb), dim3(256), 0, st, buf, bufZ, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
+                           a->dice_eps, a->batch, N, dal);
         return 0;
     };
     // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit

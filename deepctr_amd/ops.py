@@ -620,12 +620,26 @@ def embed_gather_fm_bwd(fwd_args, grads_dev, d_dnn_in=None, d_fm=None, d_lin=Non
     _C.check(_C.lib().dctr_embed_gather_fm_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm_bwd")
 
 
+def dice_train_fwd(z, alpha, moving_mean, moving_var, out, eps=1e-9, momentum=0.99, bias=None):
+    """Dice under training=True on pre-activations z [R, n] (2-D, possibly strided): batch statistics (returned as
+    (batch_mean, batch_var)), stored statistics moved in place, activations written to ``out`` (dctr_dice_train_fwd)."""
+    _dev_check(z, alpha, moving_mean, moving_var, out, bias)
+    R, n = z.shape
+    bm = torch.empty(n, dtype=torch.float32, device=z.device)
+    bv = torch.empty(n, dtype=torch.float32, device=z.device)
+    _C.check(_C.lib().dctr_dice_train_fwd(_ptr(z), z.stride(0), _ptr(bias), R, n, _ptr(_f32c(alpha, "alpha")), float(eps), float(momentum),
+                                          _ptr(moving_mean), _ptr(moving_var), _ptr(bm), _ptr(bv), _ptr(out), out.stride(0),
+                                          _C.stream_ptr()), "dctr_dice_train_fwd")
+    return bm, bv
+
+
 def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None, biases=None,
-            dice=None, d_dice_alpha=None, dice_eps=1e-9):
+            dice=None, d_dice_alpha=None, dice_eps=1e-9, dice_batch=None):
     """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written.
     Headless form: head_w = dlogit = d_head_w = None and ``d_out`` [B, >= units[-1]] = gradient w.r.t. the last layer.
     activation "dice": ``biases`` and ``dice`` = [(alpha, mean, var)] per layer as in the forward; ``d_dice_alpha`` (list,
-    accumulated) optional."""
+    accumulated) optional; ``dice_batch`` = [(batch_mean, batch_var)] per layer (dice_train_fwd) switches to training-mode Dice:
+    the gradient flows through the batch statistics."""
     _dev_check(x, *kernels)
     n = len(kernels)
     units = [k.shape[1] for k in kernels]
@@ -641,6 +655,9 @@ def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_b
         extra = dict(biases=ctypes.cast(bp, ctypes.c_void_p), dice_alpha=ctypes.cast(da, ctypes.c_void_p),
                      dice_mean=ctypes.cast(dm, ctypes.c_void_p), dice_var=ctypes.cast(dv, ctypes.c_void_p),
                      d_dice_alpha=None if gp is None else ctypes.cast(gp, ctypes.c_void_p), dice_eps=float(dice_eps))
+        if dice_batch is not None:
+            bmp, bvp = (_ptr_array([_f32c(d[i], "dice batch statistics") for d in dice_batch]) for i in range(2))
+            extra.update(dice_batch_mean=ctypes.cast(bmp, ctypes.c_void_p), dice_batch_var=ctypes.cast(bvp, ctypes.c_void_p))
     a = _C.MlpBwdArgs(x=x.data_ptr(), batch=x.shape[0], x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
                       units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
                       acts=ctypes.cast(ap, ctypes.c_void_p), activation=_C.ACT_CODES[activation],

@@ -22,6 +22,9 @@ import torch
 from . import ops
 
 
+from .training import BN_MOMENTUM  # noqa: E402  (keras BatchNormalization default momentum, as the torch step uses)
+
+
 def supported(model):
     """Can this model train on the HIP step?  (DeepFM family, fixed-length features, relu/linear/sigmoid/tanh DNN.)"""
     sp = getattr(model, "stage_plan", None)
@@ -36,10 +39,9 @@ def supported(model):
             return False
         if not la.dnn.kernels or getattr(la.dnn, "dropout_rate", 0) or getattr(la.dnn, "use_bn", False):
             return False
-        # Dice: this step evaluates it with the STORED statistics, fit()'s torch step with tf.keras' training-mode batch
-        # statistics (training._act); until the batch-statistics reductions exist here, Dice is opt-in (tests, experiments)
-        if la.dnn.activation in ("dice", "Dice") and not getattr(model, "hip_dice_stored_statistics", False):
-            return False
+        # Dice runs as tf.keras runs it under fit(): BatchNormalization in training mode — this batch's statistics, gradients
+        # through them, stored statistics moved (dctr_dice_train_fwd + dctr_mlp_bwd's dice_batch_*);
+        # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
     if sp.lin_only or len(sp.fm_group_names) > 1 or not sp.all_dim4 or sp.max_dim > 64:
         return False
     if kind == "_AFM":                      # no DNN: linear logit + AFMLayer per group (or the gather's FM group)
@@ -304,8 +306,22 @@ class HipTrainer(object):
         act = la.dnn.activation
         dice = la.dnn.dice_params()
         ops.din_att_in(q, k, buf["att_in"])
-        ops.mlp(buf["att_in"], la.dnn.kernels, la.dnn.biases, act, dice=dice, head_w=pa["out_w"].w, global_bias=pa["out_b"].w,
-                in_dim=4 * E, out=buf["score"], save_acts=buf["att_acts"])
+        dice_batch = None
+        if act in ("dice", "Dice") and not getattr(model, "hip_dice_stored_statistics", False):
+            # training-mode Dice needs the statistics of ALL B*T rows of a layer before its activation: layer by layer
+            # (pre-activations by the MLP kernel as a one-layer linear net, then dctr_dice_train_fwd), head last
+            dice_batch, xin, kin = [], buf["att_in"], 4 * E
+            if "att_z" not in buf:
+                buf["att_z"] = [torch.empty_like(t) for t in buf["att_acts"]]
+            for l, (kern, bias) in enumerate(zip(la.dnn.kernels, la.dnn.biases)):
+                ops.mlp(xin, [kern], [bias], "linear", in_dim=kin, out=buf["att_z"][l])
+                alpha, mmean, mvar = dice[l]
+                dice_batch.append(ops.dice_train_fwd(buf["att_z"][l], alpha, mmean, mvar, buf["att_acts"][l], eps=1e-9, momentum=BN_MOMENTUM))
+                xin, kin = buf["att_acts"][l], kern.shape[1]
+            ops.mlp(xin, [], [], "linear", head_w=pa["out_w"].w, global_bias=pa["out_b"].w, in_dim=kin, out=buf["score"])
+        else:
+            ops.mlp(buf["att_in"], la.dnn.kernels, la.dnn.biases, act, dice=dice, head_w=pa["out_w"].w, global_bias=pa["out_b"].w,
+                    in_dim=4 * E, out=buf["score"], save_acts=buf["att_acts"])
         hist_off = sp.extra_offsets["hist"]
         ops.din_wsum(buf["score"], m, k, ws["dnn_in"][:, hist_off:])
         ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
@@ -318,7 +334,8 @@ class HipTrainer(object):
         ops.din_wsum_bwd(dx[:, hist_off:], buf["score"], m, k, buf["d_score"], buf["dk"], d_bias=pa["out_b"].g)
         ops.mlp_bwd(buf["att_in"], 4 * E, la.dnn.kernels, buf["att_acts"], act, pa["out_w"].w, buf["d_score"],
                     [p.g for p in pa["kernels"]], [p.g for p in pa["biases"]], pa["out_w"].g, dx=buf["d_att_in"],
-                    biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None)
+                    biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None,
+                    dice_batch=dice_batch)
         ops.din_att_in_bwd(buf["d_att_in"], q, k, buf["dk"], dx, self.qcol)
         for (fc, idx, hm, col), pt in zip(bufs["key_lookups"], self.p_hist):
             if pt.g is not None:                                   # frozen history table: no scatter

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 2
+#define DCTR_ABI_VERSION 3
 
 enum {
     DCTR_OK = 0,
@@ -484,8 +484,21 @@ typedef struct {
     float* const* d_dice_alpha;       /* accumulated; array or entries may be NULL                        */
     float dice_eps;
     int32_t pad2_;
+    const float* const* dice_batch_mean;  /* Dice under training=True: HOST arrays of DEVICE pointers [out_l] with THIS batch's */
+    const float* const* dice_batch_var;   /* statistics as dctr_dice_train_fwd returned them; the gradient then flows through
+                                             them (BatchNormalization backward).  NULL (arrays or entries): dice_mean / dice_var
+                                             are constants (inference statistics)                                            */
 } dctr_mlp_bwd_args_t;
 size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
+
+/* Dice.call under training=True (deepctr/layers/activation.py:51-64: BatchNormalization(center=False, scale=False,
+ * epsilon) with the training flag, then alpha (1 - p) z + p z):  z [rows, z_stride] pre-activations (+ bias[n] when bias !=
+ * NULL); statistics = those of this batch over all rows (biased variance), written to batch_mean / batch_var [n]; the stored
+ * statistics move towards them (moving = moving * momentum + batch * (1 - momentum); either may be NULL); h [rows, h_stride]
+ * receives the activations.  The matching backward is dctr_mlp_bwd with dice_batch_mean / dice_batch_var. */
+int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float* bias, int64_t rows, int32_t n, const float* alpha,
+                        float eps, float momentum, float* moving_mean, float* moving_var, float* batch_mean, float* batch_var,
+                        float* h, int64_t h_stride, void* stream);
 int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
 
 /* DIN's LocalActivationUnit as a training step (layers/core.py:94-108, layers/sequence.py:261-298, att_weight_normalization

@@ -130,6 +130,70 @@ def test_mlp_bwd_dice_matches_autograd(device, n_layers, head):
         _scaled(ghw, ha.grad, "dhead")
 
 
+@pytest.mark.parametrize("n_layers,head,R", [(2, True, 211), (1, True, 5000), (3, False, 97)])
+def test_dice_training_mode_forward_and_backward_match_autograd(device, n_layers, head, R):
+    """Dice as tf.keras runs it under fit() (BatchNormalization training=True inside Dice, layers/activation.py:51-64): batch
+    statistics over all rows, gradients through them, stored statistics moved — dctr_dice_train_fwd layer by layer and
+    dctr_mlp_bwd(dice_batch_*) against torch autograd over the same formulas."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(18)
+    K = 24
+    units = [12, 6, 5][:n_layers]
+    x = dev((rng.standard_normal((R, K + 3)) + 0.3).astype(np.float32), device)
+    dims = [K] + units
+    Ws = [dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device) for i in range(n_layers)]
+    bs = [dev((rng.standard_normal(n) * 0.5 + 1.0).astype(np.float32), device) for n in units]      # means far from 0: E[z^2]-E[z]^2 would cancel
+    al = [dev((rng.standard_normal(n) * 0.3).astype(np.float32), device) for n in units]
+    mm = [dev((rng.standard_normal(n) * 0.2).astype(np.float32), device) for n in units]
+    mv = [dev(rng.uniform(0.5, 1.5, n).astype(np.float32), device) for n in units]
+    hw = dev(rng.standard_normal((units[-1], 1)).astype(np.float32), device)
+    leaves = [t.clone().requires_grad_(True) for t in [x] + Ws + bs + al + [hw]]
+    xa, Wa, ba, aa, ha = leaves[0], leaves[1:1 + n_layers], leaves[1 + n_layers:1 + 2 * n_layers], \
+        leaves[1 + 2 * n_layers:1 + 3 * n_layers], leaves[-1]
+    h = xa[:, :K]
+    ref_stats = []
+    for i in range(n_layers):
+        z = h @ Wa[i] + ba[i]
+        bm, bv = z.mean(dim=0), z.var(dim=0, unbiased=False)
+        ref_stats.append((bm.detach(), bv.detach()))
+        p = torch.sigmoid((z - bm) / torch.sqrt(bv + 1e-9))
+        h = aa[i] * (1 - p) * z + p * z
+    # forward, layer by layer as the trainer does
+    acts, zs, stats = [torch.empty(R, n, device=device) for n in units], [torch.empty(R, n, device=device) for n in units], []
+    mm2, mv2 = [t.clone() for t in mm], [t.clone() for t in mv]
+    xin, kin = x, K
+    for i in range(n_layers):
+        ops.mlp(xin, [Ws[i]], [bs[i]], "linear", in_dim=kin, out=zs[i])
+        stats.append(ops.dice_train_fwd(zs[i], al[i], mm2[i], mv2[i], acts[i], eps=1e-9, momentum=0.99))
+        xin, kin = acts[i], units[i]
+    for i in range(n_layers):
+        _scaled(stats[i][0], ref_stats[i][0], "batch mean %d" % i, rtol=1e-4)
+        _scaled(stats[i][1], ref_stats[i][1], "batch variance %d" % i, rtol=2e-4)
+        _scaled(mm2[i], mm[i] * 0.99 + ref_stats[i][0] * 0.01, "moving mean %d" % i)
+        _scaled(mv2[i], mv[i] * 0.99 + ref_stats[i][1] * 0.01, "moving variance %d" % i)
+    _scaled(acts[-1], h.detach(), "dice training forward", rtol=2e-4)
+    dice = list(zip(al, mm2, mv2))
+    if head:
+        dl = dev(rng.standard_normal(R).astype(np.float32), device)
+        ((h @ ha).reshape(-1) * dl).sum().backward()
+    else:
+        dout = dev(rng.standard_normal((R, units[-1] + 2)).astype(np.float32), device)
+        (h * dout[:, :units[-1]]).sum().backward()
+    gW, gb, ga = [torch.zeros_like(t) for t in Ws], [torch.zeros_like(t) for t in bs], [torch.zeros_like(t) for t in al]
+    ghw = torch.zeros_like(hw)
+    dx = torch.full((R, K + 2), 4.0, device=device)
+    ops.mlp_bwd(x, K, Ws, acts, "dice", hw if head else None, dl if head else None, gW, gb, ghw if head else None, dx=dx,
+                d_out=None if head else dout, biases=bs, dice=dice, d_dice_alpha=ga, dice_batch=stats)
+    _scaled(dx[:, :K], xa.grad[:, :K], "dx")
+    assert float((dx[:, K:] - 4.0).abs().max()) == 0.0
+    for i in range(n_layers):
+        _scaled(gW[i], Wa[i].grad, "dW%d" % i)
+        _scaled(gb[i], ba[i].grad, "db%d" % i, atol=2e-5)      # (d loss / d bias cancels to ~0 through the batch mean)
+        _scaled(ga[i], aa[i].grad, "dalpha%d" % i)
+    if head:
+        _scaled(ghw, ha.grad, "dhead")
+
+
 def _din(device, act, E=8, T=6):
     from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
     from deepctr_amd.models import DIN
@@ -140,7 +204,6 @@ def _din(device, act, E=8, T=6):
             VarLenSparseFeat(SparseFeat("other_seq", 9, E), maxlen=4, combiner="mean")]
     model = DIN(cols, ["item_id", "cate_id"], att_activation=act, dnn_hidden_units=(16, 8), att_hidden_size=(12, 6),
                 l2_reg_embedding=0, device=device)
-    model.hip_dice_stored_statistics = True          # opt in: Dice with the stored statistics (see training_hip.supported)
     return model, cols
 
 
@@ -157,13 +220,18 @@ def _din_feed(rng, n, T=6):
             "other_seq": rng.randint(0, 9, (n, 4)).astype(np.int32)}
 
 
-@pytest.mark.parametrize("act", ["dice", "sigmoid"])
-def test_din_hip_training_gradients_match_torch_autograd(device, act):
+@pytest.mark.parametrize("act,stored", [("dice", False), ("dice", True), ("sigmoid", False)])
+def test_din_hip_training_gradients_match_torch_autograd(device, act, stored):
+    """The whole DIN step against torch autograd over training.model_logits.  Dice: as fit() runs it (training-mode
+    BatchNormalization: batch statistics, gradients through them, stored statistics moved), and with the stored statistics
+    (model.hip_dice_stored_statistics, the inference-form backward)."""
     from deepctr_amd import training
     from deepctr_amd.training_hip import HipTrainer, supported
     from tests.test_gpu_models import _randomise
     rng = np.random.RandomState(14)
     model, cols = _din(device, act)
+    model.hip_dice_stored_statistics = stored
+    train_mode = act == "dice" and not stored
     assert supported(model)
     w = _randomise(model, rng)
     if act == "dice":
@@ -176,13 +244,17 @@ def test_din_hip_training_gradients_match_torch_autograd(device, act):
     model._begin()
     tr = HipTrainer(model)
     yt = dev(y, device)
+    stat_names = [k for k in model.get_weights_by_name() if k.endswith("moving_mean") or k.endswith("moving_variance")]
+    stats0 = {k: v.copy() for k, v in model.get_weights_by_name().items() if k in stat_names}
     loss = tr.step(staged, 0, n, yt, apply=False)
+    stats_hip = {k: v.copy() for k, v in model.get_weights_by_name().items() if k in stat_names}
+    model.set_weights_by_name(stats0, strict=False)    # the reference starts from the same stored statistics
     params = [p.w for p in tr.params]
     for t in params:
         t.requires_grad_(True)
     try:
         model._begin()
-        logit = training.model_logits(model, staged, 0, n)
+        logit = training.model_logits(model, staged, 0, n, training=train_mode)
         ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
         grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
     finally:
@@ -191,16 +263,21 @@ def test_din_hip_training_gradients_match_torch_autograd(device, act):
     assert_close(loss.cpu().numpy(), [float(ref_loss.detach())], rtol=1e-4, atol=1e-6, what="loss")
     for p, gref in zip(tr.params, grads):
         gref = torch.zeros_like(p.w) if gref is None else gref
-        _scaled(p.g, gref, "grad of %s" % (tuple(p.w.shape),))
-    # the HIP step's forward (materialised attention input + generic MLP) equals predict()'s fused attention kernel
-    with torch.no_grad():
-        p_ref = model.predict(feed, batch_size=64).reshape(-1)
-    assert_close(tr._buffers(n)["pred"].cpu().numpy(), p_ref, rtol=1e-4, atol=1e-6, what="training forward vs predict")
+        _scaled(p.g, gref, "grad of %s" % (tuple(p.w.shape),), atol=2e-5 if train_mode else 2e-6)
+    stats_ref = {k: v for k, v in model.get_weights_by_name().items() if k in stat_names}
+    for k in stat_names:                               # moved by the step in training mode, untouched otherwise
+        assert_close(stats_hip[k], stats_ref[k], rtol=2e-4, atol=1e-6, what=k)
+        assert (np.abs(stats_hip[k] - stats0[k]).max() > 0) == train_mode, k
+    if not train_mode:
+        # the HIP step's forward (materialised attention input + generic MLP) equals predict()'s fused attention kernel
+        with torch.no_grad():
+            p_ref = model.predict(feed, batch_size=64).reshape(-1)
+        assert_close(tr._buffers(n)["pred"].cpu().numpy(), p_ref, rtol=1e-4, atol=1e-6, what="training forward vs predict")
 
 
 def test_din_fit_runs_on_the_hip_step_and_learns(device):
     rng = np.random.RandomState(2)
-    model, cols = _din(device, "sigmoid")
+    model, cols = _din(device, "dice")               # the reference's default att_activation
     n = 2048
     feed = _din_feed(rng, n)
     y = (feed["cate_id"] % 2).astype(np.float32)
