@@ -16,7 +16,7 @@ row-chained kernel (csrc/chain_device.h: a wave owns 32 batch rows end to end, w
 ring, a layer's accumulators are the next layer's B operand, gather HBM -> registers).  A call is cut into kernel launches
 (`dctr_embed_mlp_fwd_plan`): whole multiples of 256 rows x CUs in the 256-rows-per-workgroup shape, the rest in the 128- /
 64-row shapes.  The bench does the same: the K steps go out as ceil(K / G) calls of G consecutive batches
-(--launch-batches, default min(K, 64)), exactly K * 4096 rows per GPU inside the timed region, bracketed by barrier +
+(--launch-batches, default min(K, 256) = predict()'s 2^20-row spans), exactly K * 4096 rows per GPU inside the timed region, bracketed by barrier +
 synchronize, MAX over ranks.
 `one_launch_per_batch` in the JSON line is the other extreme measured right after (one launch per 4096-row batch, K of
 them in one hipGraph on 8 streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
@@ -178,7 +178,8 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--launch-batches", type=int, default=0,
-                    help="consecutive 4096-row batches per launch (0 = min(steps, 64)); 1 = one launch per batch")
+                    help="consecutive 4096-row batches per call (0 = min(steps, 256) = the 2^20-row spans model.predict() hands "
+                         "the library); 1 = one launch per batch")
     ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through (rounded up to whole launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-launch-per-batch and long-run measurements")
@@ -210,7 +211,7 @@ def main():
     model, cols = build_model(device)
     model.tile_rows = args.tile_rows
     K, W = args.steps, args.warmup
-    G = max(1, min(args.launch_batches or 64, max(K, 1)))
+    G = max(1, min(args.launch_batches or 256, max(K, 1)))
     ring = ((max(args.ring, G) + G - 1) // G) * G                          # whole launches
     staged = model.stage(synthetic_feed(ring * B, 1000 + rank, args.dist))       # device-resident before timing
     model._begin()

@@ -86,6 +86,8 @@ class _DeepFM(FeatureModel):
         (kernel: 'tile' = mlp_kernel, 'stream', 'chain'; dctr_embed_mlp_fwd_plan)."""
         import ctypes
         from .. import _C
+        if not hasattr(self.stage_plan, "dense_lin_w"):
+            self._begin()                                   # (what predict() does first: per-call views of the weights)
         g, m = self._forward_fast_args(staged, lo, hi, out)
         rows, kern, rpw = (ctypes.c_int64 * 16)(), (ctypes.c_int32 * 16)(), (ctypes.c_int32 * 16)()
         n = _C.lib().dctr_embed_mlp_fwd_plan(ctypes.byref(g), ctypes.byref(m), rows, kern, rpw, 16)
