@@ -104,6 +104,13 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dice_batch_mean", c_vp), ("dice_batch_var", c_vp)]
 
 
+class CrossMixBwdArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("x_stride", c_i64), ("batch", c_i64), ("dim", c_i32), ("layers", c_i32), ("experts", c_i32),
+                ("low_rank", c_i32), ("U", c_vp), ("V", c_vp), ("C", c_vp), ("gating", c_vp), ("bias", c_vp), ("dy", c_vp),
+                ("dy_stride", c_i64), ("dU", c_vp), ("dV", c_vp), ("dC", c_vp), ("dgating", c_vp), ("dbias", c_vp), ("dx", c_vp),
+                ("dx_stride", c_i64), ("dx_accumulate", c_i32), ("pad_", c_i32), ("workspace", c_vp), ("workspace_bytes", c_sz)]
+
+
 class CinBwdArgs(ctypes.Structure):
     _fields_ = [("fwd", ctypes.POINTER(CinArgs)), ("d_out", c_vp), ("out_dim", c_i32), ("dx_accumulate", c_i32),
                 ("d_filters", c_vp), ("d_bias", c_vp), ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp),
@@ -195,6 +202,8 @@ SYMBOLS = {
     "dctr_cin_bwd": (ctypes.c_int, [ctypes.POINTER(CinBwdArgs), c_vp]),
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
+    "dctr_crossnet_mix_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CrossMixBwdArgs)]),
+    "dctr_crossnet_mix_bwd": (ctypes.c_int, [ctypes.POINTER(CrossMixBwdArgs), c_vp]),
     "dctr_dice_train_fwd": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_adam_multi": (ctypes.c_int, [c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),

@@ -1642,3 +1642,273 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
     }
     return dctr_launch_status("dctr_cin_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// CrossNetMix backward (reference forward: deepctr/layers/interaction.py:511-549, DCNMix):
+//   per layer l, expert e:  v1 = tanh(x_l V_e),  v2 = tanh(v1 C_e^T),  out_e = x_0 .* (v2 U_e^T + b_l),  s_e = x_l . g_e
+//   p = softmax_e(s),  x_{l+1} = sum_e p_e out_e + x_l
+// Nothing is saved by the forward kernel: the intermediates (x_l, v1, v2, uv = v2 U^T, p) are recomputed here into the
+// workspace — the low-rank projections as plain rocBLAS GEMMs, the gating / softmax / combination as one row kernel — and the
+// backward walks the layers in reverse:
+//   dp_e = g . out_e,  ds_e = p_e (dp_e - sum_e' p_e' dp_e'),  t_e = p_e g .* x_0   (gradient of  v2 U^T + b)
+//   d b += sum_b g .* x_0 (sum_e p_e = 1),  d U_e += t_e^T v2,  d v2 = t_e U_e,  a2 = d v2 .* (1 - v2^2),  d C_e += a2^T v1,
+//   d v1 = a2 C_e,  a1 = d v1 .* (1 - v1^2),  d V_e += x_l^T a1,  d g_e += x_l^T ds_e,
+//   d x_l = g + sum_e (ds_e (x) g_e + a1 V_e^T),   d x_0 += sum_e p_e g .* (uv_e + b)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void mix_copy_rows_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int d,
+                                                           float* __restrict__ y) {
+    const int64_t total = batch * d;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / d;
+        y[o] = x[b * x_stride + (o - b * d)];
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_tanh_kernel(float* __restrict__ v, int64_t n) {
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) v[o] = tanhf(v[o]);
+}
+
+// a = d .* (1 - v^2), in place over d
+__global__ __launch_bounds__(256) void mix_tanh_bwd_kernel(float* __restrict__ dv, const float* __restrict__ v, int64_t n) {
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) dv[o] *= 1.f - v[o] * v[o];
+}
+
+__device__ __forceinline__ float mix_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+constexpr int MIX_MAX_EXPERTS = 16;
+
+// forward combination, one wave per row: p = softmax_e(x_l . g_e),  x_next = sum_e p_e x_0 .* (uv_e + b) + x_l
+__global__ __launch_bounds__(256) void mix_combine_kernel(const float* __restrict__ x0, const float* __restrict__ xl,
+                                                         const float* __restrict__ uv, int64_t uv_expert_stride,
+                                                         const float* __restrict__ gating, const float* __restrict__ bias,
+                                                         int64_t batch, int d, int ne, float* __restrict__ p_out,
+                                                         float* __restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    float s[MIX_MAX_EXPERTS];
+    for (int e = 0; e < ne; ++e) {
+        float a = 0.f;
+        for (int i = lane; i < d; i += 64) a = fmaf(xl[b * d + i], gating[(int64_t)e * d + i], a);
+        s[e] = mix_wave_sum(a);
+    }
+    float mx = s[0];
+    for (int e = 1; e < ne; ++e) mx = fmaxf(mx, s[e]);
+    float den = 0.f;
+    for (int e = 0; e < ne; ++e) {
+        s[e] = expf(s[e] - mx);
+        den += s[e];
+    }
+    for (int e = 0; e < ne; ++e) {
+        s[e] /= den;
+        if (lane == 0) p_out[b * ne + e] = s[e];
+    }
+    for (int i = lane; i < d; i += 64) {
+        float acc = 0.f;
+        for (int e = 0; e < ne; ++e) acc = fmaf(s[e], uv[e * uv_expert_stride + b * d + i], acc);
+        xn[b * d + i] = fmaf(x0[b * d + i], acc + bias[i], xl[b * d + i]);        // sum_e p_e = 1: the bias comes out of the sum
+    }
+}
+
+// backward gate part, one wave per row.  In: g (gradient w.r.t. x_{l+1}), x_0, uv_e, p.  Out: ds [B, ne];
+// gx = g + sum_e ds_e g_e;  dx0 += sum_e p_e g .* (uv_e + b);  d_bias[i] += sum_b g x_0 (atomics)
+__global__ __launch_bounds__(256) void mix_bwd_gate_kernel(const float* __restrict__ g, const float* __restrict__ x0,
+                                                          const float* __restrict__ uv, int64_t uv_expert_stride,
+                                                          const float* __restrict__ p, const float* __restrict__ gating,
+                                                          const float* __restrict__ bias, int64_t batch, int d, int ne,
+                                                          float* __restrict__ ds, float* __restrict__ gx, float* __restrict__ dx0,
+                                                          float* __restrict__ d_bias) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    float pe[MIX_MAX_EXPERTS], dp[MIX_MAX_EXPERTS];
+    float mean = 0.f;
+    for (int e = 0; e < ne; ++e) {
+        pe[e] = p[b * ne + e];
+        float a = 0.f;
+        for (int i = lane; i < d; i += 64) a = fmaf(g[b * d + i], x0[b * d + i] * (uv[e * uv_expert_stride + b * d + i] + bias[i]), a);
+        dp[e] = mix_wave_sum(a);
+        mean = fmaf(pe[e], dp[e], mean);
+    }
+    for (int e = 0; e < ne; ++e) {
+        dp[e] = pe[e] * (dp[e] - mean);                                           // now ds_e
+        if (lane == 0) ds[b * ne + e] = dp[e];
+    }
+    for (int i = lane; i < d; i += 64) {
+        const float gi = g[b * d + i];
+        float a = gi, u = 0.f;
+        for (int e = 0; e < ne; ++e) {
+            a = fmaf(dp[e], gating[(int64_t)e * d + i], a);
+            u = fmaf(pe[e], uv[e * uv_expert_stride + b * d + i], u);
+        }
+        gx[b * d + i] = a;
+        dx0[b * d + i] = fmaf(gi, u + bias[i], dx0[b * d + i]);
+        unsafeAtomicAdd(d_bias + i, gi * x0[b * d + i]);
+    }
+}
+
+// t[b, i] = p[b, e] g[b, i] x0[b, i]
+__global__ __launch_bounds__(256) void mix_t_kernel(const float* __restrict__ g, const float* __restrict__ x0, const float* __restrict__ p,
+                                                   int e, int ne, int64_t batch, int d, float* __restrict__ t) {
+    const int64_t total = batch * d;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / d;
+        t[o] = p[b * ne + e] * g[o] * x0[o];
+    }
+}
+
+// dx[b, :] (+)= g[b, :] + dx0[b, :];  also used as a strided copy of dy into g
+__global__ __launch_bounds__(256) void mix_out_kernel(const float* __restrict__ g, const float* __restrict__ dx0, int64_t batch, int d,
+                                                     float* __restrict__ dx, int64_t dx_stride, int accumulate) {
+    const int64_t total = batch * d;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / d;
+        const float v = g[o] + (dx0 != nullptr ? dx0[o] : 0.f);
+        float* dst = dx + b * dx_stride + (o - b * d);
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+struct MixPlan {
+    size_t X, V1, V2, UV, P, G, GX, T, DX0, DV2, DV1, DS, total;
+};
+MixPlan mix_plan(int64_t B, int d, int L, int ne, int r) {
+    MixPlan m{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+    m.X = take((size_t)L * B * d);
+    m.V1 = take((size_t)L * ne * B * r);
+    m.V2 = take((size_t)L * ne * B * r);
+    m.UV = take((size_t)L * ne * B * d);
+    m.P = take((size_t)L * B * ne);
+    m.G = take((size_t)B * d);
+    m.GX = take((size_t)B * d);
+    m.T = take((size_t)B * d);
+    m.DX0 = take((size_t)B * d);
+    m.DV2 = take((size_t)B * r);
+    m.DV1 = take((size_t)B * r);
+    m.DS = take((size_t)B * ne);
+    m.total = o;
+    return m;
+}
+
+}  // namespace
+
+extern "C" size_t dctr_crossnet_mix_bwd_workspace_bytes(const dctr_crossnet_mix_bwd_args_t* a) {
+    if (a == nullptr || a->batch <= 0 || a->dim <= 0 || a->layers <= 0 || a->experts <= 0 || a->low_rank <= 0) return 0;
+    return mix_plan(a->batch, a->dim, a->layers, a->experts, a->low_rank).total * sizeof(float);
+}
+
+extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "crossnet_mix_bwd: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->dim >= 1 && a->layers >= 0 && a->experts >= 1 && a->experts <= MIX_MAX_EXPERTS && a->low_rank >= 1,
+                 DCTR_E_DIM, "crossnet_mix_bwd: bad sizes (batch=%lld dim=%d layers=%d experts=%d (max %d) low_rank=%d)",
+                 (long long)a->batch, a->dim, a->layers, a->experts, MIX_MAX_EXPERTS, a->low_rank);
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->x && a->dy && a->dx && a->x_stride >= a->dim && a->dy_stride >= a->dim && a->dx_stride >= a->dim, DCTR_E_NULL,
+                 "crossnet_mix_bwd: null x / dy / dx or a stride < dim");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t B = a->batch;
+    const int d = a->dim, L = a->layers, ne = a->experts, r = a->low_rank;
+    auto grid = [](int64_t n) { int64_t g = dctr_ceil_div(n, (int64_t)256); return dim3((unsigned)(g < 8192 ? g : 8192)); };
+    if (L == 0) {                                                  // identity: dx (+)= dy
+        DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= (size_t)B * d * sizeof(float), DCTR_E_NULL,
+                     "crossnet_mix_bwd: layers == 0 needs a workspace of batch * dim floats");
+        hipLaunchKernelGGL(mix_copy_rows_kernel, grid(B * d), dim3(256), 0, st, a->dy, a->dy_stride, B, d, (float*)a->workspace);
+        hipLaunchKernelGGL(mix_out_kernel, grid(B * d), dim3(256), 0, st, (const float*)a->workspace, (const float*)nullptr, B, d, a->dx,
+                           a->dx_stride, (int)a->dx_accumulate);
+        return dctr_launch_status("dctr_crossnet_mix_bwd");
+    }
+    DCTR_REQUIRE(a->U && a->V && a->C && a->gating && a->bias && a->dU && a->dV && a->dC && a->dgating && a->dbias, DCTR_E_NULL,
+                 "crossnet_mix_bwd: null weights / gradients");
+    const MixPlan m = mix_plan(B, d, L, ne, r);
+    DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= m.total * sizeof(float), DCTR_E_NULL,
+                 "crossnet_mix_bwd: needs a workspace of dctr_crossnet_mix_bwd_workspace_bytes() bytes");
+    DCTR_REQUIRE(B < 0x7fffffffLL / (d > r ? d : r), DCTR_E_DIM, "crossnet_mix_bwd: batch too large");
+    rocblas_handle h = blas_handle();
+    DCTR_REQUIRE(h != nullptr, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocBLAS handle creation failed");
+    DCTR_REQUIRE(rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocblas_set_stream failed");
+    float* ws = static_cast<float*>(a->workspace);
+    const float one = 1.f, zero = 0.f;
+    const int Bi = (int)B;
+    const int64_t Br = B * r, Bd = B * d;
+    const unsigned row_blocks = (unsigned)dctr_ceil_div(B, (int64_t)4);
+#define MIX_GEMM(ta, tb, mm, nn, kk, A_, lda, B_, ldb, beta, C_, ldc)                                                      \
+    do {                                                                                                                   \
+        rocblas_status rs_ = rocblas_sgemm(h, ta, tb, mm, nn, kk, &one, A_, lda, B_, ldb, beta, C_, ldc);                  \
+        DCTR_REQUIRE(rs_ == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocblas_sgemm failed (%d)", (int)rs_); \
+    } while (0)
+    const rocblas_operation N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+    // ---- forward recompute.  X[0] = x_0 (contiguous copy), X[l+1] needed only for l + 1 < L
+    hipLaunchKernelGGL(mix_copy_rows_kernel, grid(Bd), dim3(256), 0, st, a->x, a->x_stride, B, d, ws + m.X);
+    const float* x0 = ws + m.X;
+    for (int l = 0; l < L; ++l) {
+        const float* xl = ws + m.X + (size_t)l * Bd;
+        for (int e = 0; e < ne; ++e) {
+            const size_t le = (size_t)l * ne + e;
+            const float* Ue = a->U + le * d * r;
+            const float* Ve = a->V + le * d * r;
+            const float* Ce = a->C + le * r * r;
+            float* v1 = ws + m.V1 + le * Br;
+            float* v2 = ws + m.V2 + le * Br;
+            float* uv = ws + m.UV + le * Bd;
+            MIX_GEMM(N_, N_, r, Bi, d, Ve, r, xl, d, &zero, v1, r);          // v1'(r x B) = V'(r x d) x_l'(d x B)
+            hipLaunchKernelGGL(mix_tanh_kernel, grid(Br), dim3(256), 0, st, v1, Br);
+            MIX_GEMM(T_, N_, r, Bi, r, Ce, r, v1, r, &zero, v2, r);          // v2[b, j] = sum_k C[j][k] v1[b, k]
+            hipLaunchKernelGGL(mix_tanh_kernel, grid(Br), dim3(256), 0, st, v2, Br);
+            MIX_GEMM(T_, N_, d, Bi, r, Ue, r, v2, r, &zero, uv, d);          // uv[b, i] = sum_j U[i][j] v2[b, j]
+        }
+        // the last layer's output is not needed (its gradient comes in as dy); the kernel still needs somewhere to write: GX
+        float* xn = l + 1 < L ? ws + m.X + (size_t)(l + 1) * Bd : ws + m.GX;
+        hipLaunchKernelGGL(mix_combine_kernel, dim3(row_blocks), dim3(256), 0, st, x0, xl, (const float*)(ws + m.UV + (size_t)l * ne * Bd),
+                           Bd, a->gating, a->bias + (size_t)l * d, B, d, ne, ws + m.P + (size_t)l * B * ne, xn);
+    }
+    // ---- backward
+    float* g = ws + m.G;
+    float* gx = ws + m.GX;
+    hipLaunchKernelGGL(mix_copy_rows_kernel, grid(Bd), dim3(256), 0, st, a->dy, a->dy_stride, B, d, g);
+    hipError_t me = hipMemsetAsync(ws + m.DX0, 0, (size_t)Bd * sizeof(float), st);
+    DCTR_REQUIRE(me == hipSuccess, (int)me, "crossnet_mix_bwd: memset failed: %s", hipGetErrorString(me));
+    for (int l = L - 1; l >= 0; --l) {
+        const float* xl = ws + m.X + (size_t)l * Bd;
+        const float* p = ws + m.P + (size_t)l * B * ne;
+        const float* uvl = ws + m.UV + (size_t)l * ne * Bd;
+        hipLaunchKernelGGL(mix_bwd_gate_kernel, dim3(row_blocks), dim3(256), 0, st, (const float*)g, x0, uvl, Bd, p, a->gating,
+                           a->bias + (size_t)l * d, B, d, ne, ws + m.DS, gx, ws + m.DX0, a->dbias + (size_t)l * d);
+        // d gating[e][i] += sum_b ds[b, e] x_l[b, i]:  column-major dG'(d x ne) += x_l'(d x B) ds'(ne x B)^T
+        MIX_GEMM(N_, T_, d, ne, Bi, xl, d, (const float*)(ws + m.DS), ne, &one, a->dgating, d);
+        for (int e = 0; e < ne; ++e) {
+            const size_t le = (size_t)l * ne + e;
+            const float* Ue = a->U + le * d * r;
+            const float* Ve = a->V + le * d * r;
+            const float* Ce = a->C + le * r * r;
+            const float* v1 = ws + m.V1 + le * Br;
+            const float* v2 = ws + m.V2 + le * Br;
+            float* t = ws + m.T;
+            float* dv2 = ws + m.DV2;
+            float* dv1 = ws + m.DV1;
+            hipLaunchKernelGGL(mix_t_kernel, grid(Bd), dim3(256), 0, st, (const float*)g, x0, p, e, ne, B, d, t);
+            MIX_GEMM(N_, T_, r, d, Bi, v2, r, (const float*)t, d, &one, a->dU + le * d * r, r);      // dU[i][j] += sum_b t[b,i] v2[b,j]
+            MIX_GEMM(N_, N_, r, Bi, d, Ue, r, (const float*)t, d, &zero, dv2, r);                    // dv2[b,j] = sum_i t[b,i] U[i][j]
+            hipLaunchKernelGGL(mix_tanh_bwd_kernel, grid(Br), dim3(256), 0, st, dv2, v2, Br);        // a2
+            MIX_GEMM(N_, T_, r, r, Bi, v1, r, (const float*)dv2, r, &one, a->dC + le * r * r, r);    // dC[j][k] += sum_b a2[b,j] v1[b,k]
+            MIX_GEMM(N_, N_, r, Bi, r, Ce, r, (const float*)dv2, r, &zero, dv1, r);                  // dv1[b,k] = sum_j a2[b,j] C[j][k]
+            hipLaunchKernelGGL(mix_tanh_bwd_kernel, grid(Br), dim3(256), 0, st, dv1, v1, Br);        // a1
+            MIX_GEMM(N_, T_, r, d, Bi, (const float*)dv1, r, xl, d, &one, a->dV + le * d * r, r);    // dV[i][j] += sum_b x_l[b,i] a1[b,j]
+            MIX_GEMM(T_, N_, d, Bi, r, Ve, r, (const float*)dv1, r, &one, gx, d);                    // gx[b,i] += sum_j a1[b,j] V[i][j]
+        }
+        float* tmp = g;
+        g = gx;
+        gx = tmp;
+    }
+#undef MIX_GEMM
+    hipLaunchKernelGGL(mix_out_kernel, grid(Bd), dim3(256), 0, st, (const float*)g, (const float*)(ws + m.DX0), B, d, a->dx, a->dx_stride,
+                       (int)a->dx_accumulate);
+    return dctr_launch_status("dctr_crossnet_mix_bwd");
+}

@@ -620,6 +620,23 @@ def embed_gather_fm_bwd(fwd_args, grads_dev, d_dnn_in=None, d_fm=None, d_lin=Non
     _C.check(_C.lib().dctr_embed_gather_fm_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm_bwd")
 
 
+def crossnet_mix_bwd(x, dim, packed, dy, grads, dx, accumulate=False):
+    """Backward of crossnet_mix: ``packed`` = (U, V, C, gating, bias) as the forward takes them, ``grads`` the same five shapes
+    (accumulated into), dy [B, >= dim] gradient w.r.t. the output, dx [B, >= dim] written (or added to)."""
+    U, V, C, gating, bias = packed
+    dU, dV, dC, dG, dB = grads
+    _dev_check(x, dy, dx, U, V, C, gating, bias, dU, dV, dC, dG, dB)
+    L, ne, r = (U.shape[0], U.shape[1], U.shape[3]) if U.dim() == 4 and U.shape[0] else (0, max(int(gating.shape[0]), 1), 1)
+    a = _C.CrossMixBwdArgs(x=x.data_ptr(), x_stride=x.stride(0), batch=x.shape[0], dim=dim, layers=L, experts=ne, low_rank=r,
+                           U=_ptr(U), V=_ptr(V), C=_ptr(C), gating=_ptr(gating), bias=_ptr(bias), dy=dy.data_ptr(),
+                           dy_stride=dy.stride(0), dU=_ptr(dU), dV=_ptr(dV), dC=_ptr(dC), dgating=_ptr(dG), dbias=_ptr(dB),
+                           dx=dx.data_ptr(), dx_stride=dx.stride(0), dx_accumulate=int(bool(accumulate)))
+    need = int(_C.lib().dctr_crossnet_mix_bwd_workspace_bytes(ctypes.byref(a))) if L else x.shape[0] * dim * 4
+    ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _C.check(_C.lib().dctr_crossnet_mix_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_mix_bwd")
+
+
 def dice_train_fwd(z, alpha, moving_mean, moving_var, out, eps=1e-9, momentum=0.99, bias=None):
     """Dice under training=True on pre-activations z [R, n] (2-D, possibly strided): batch statistics (returned as
     (batch_mean, batch_var)), stored statistics moved in place, activations written to ``out`` (dctr_dice_train_fwd)."""

@@ -30,7 +30,7 @@ def supported(model):
     sp = getattr(model, "stage_plan", None)
     dnn = getattr(model, "dnn", None)
     kind = type(model).__name__
-    if sp is None or kind not in ("_DeepFM", "_DCN", "_xDeepFM", "_NFM", "_PNN", "_AFM", "_DIN"):
+    if sp is None or kind not in ("_DeepFM", "_DCN", "_DCNMix", "_xDeepFM", "_NFM", "_PNN", "_AFM", "_DIN"):
         return False
     if kind == "_DIN":
         # attention unit: Dice (moving statistics, as the torch step uses) or sigmoid / relu; plain weighted sum only
@@ -140,7 +140,8 @@ class HipTrainer(object):
         if model.linear is not None and sp.n_dense and sp.n_lin_dense and sp.has_linear:
             self.p_dense_lin = param(model.linear.w("linear_kernel"), l2l)
             self.dense_rows = torch.as_tensor(sp.dense_lin_rows, dtype=torch.int32, device=model.device)
-        self.is_dcn = type(model).__name__ == "_DCN"
+        self.is_mix = type(model).__name__ == "_DCNMix"
+        self.is_dcn = type(model).__name__ in ("_DCN", "_DCNMix")
         self.is_afm = type(model).__name__ == "_AFM"
         self.p_afm = []
         if self.is_afm:
@@ -176,7 +177,16 @@ class HipTrainer(object):
             self.p_cin_b = [param(b) for b in model.cin.biases]
             self.p_head1 = param(model.dense_1.w("kernel"))
         self.p_cross_k = self.p_cross_b = None
-        if self.is_dcn and model.cross is not None:
+        self.p_mix = None
+        if self.is_mix and model.cross is not None:
+            # CrossNetMix: U / V / C stacked over layers, the experts' gating kernels, the biases — five packed parameter
+            # tensors in the C ABI's layout; the layer's Keras-named weights become views of them.  l2 on U / V / C only
+            # (the reference regularises U_list / V_list / C_list, interaction.py:481-500)
+            U, V, C, G, Bb = model.cross.packed()
+            l2c = reg.get("cross", 0.0)
+            self.p_mix = [param(U.clone(), l2c), param(V.clone(), l2c), param(C.clone(), l2c), param(G.clone()), param(Bb.clone())]
+            self.bind_cross_views()
+        elif self.is_dcn and model.cross is not None:
             # CrossNet's per-layer kernels / biases become views of one packed tensor each (the layout the C ABI takes),
             # so that one parameter segment covers them and the layer keeps its Keras-named weights
             ks, bs = model.cross.packed()
@@ -224,6 +234,14 @@ class HipTrainer(object):
         """(Re-)point CrossNet's Keras-named per-layer weights at views of the packed parameter tensors."""
         cr = self.model.cross
         d = cr.dim
+        if self.p_mix is not None:
+            U, V, C, G, Bb = (p.w for p in self.p_mix)
+            for i in range(cr.layer_num):
+                cr._weights['U_list%d' % i], cr._weights['V_list%d' % i], cr._weights['C_list%d' % i] = U[i], V[i], C[i]
+                cr._weights['bias%d' % i] = Bb[i].view(d, 1)
+            for e, dense in enumerate(cr.gating):
+                dense._weights['kernel'] = G[e].view(d, 1)
+            return
         for i in range(cr.layer_num):
             cr._weights['kernel%d' % i] = self.p_cross_k.w[i].view(d, -1)
             cr._weights['bias%d' % i] = self.p_cross_b.w[i].view(d, 1)
@@ -380,9 +398,12 @@ class HipTrainer(object):
         if stack is None:
             stack = model._stack[B] = torch.zeros(B, (model.width + 3) // 4 * 4, dtype=torch.float32, device=model.device)
         col = 0
-        par = model.cross.parameterization if model.cross is not None else "vector"
+        par = getattr(model.cross, "parameterization", "vector") if model.cross is not None else "vector"
         if model.cross is not None:
-            self._cross_fwd(ws["dnn_in"], d, par, stack)
+            if self.p_mix is not None:
+                ops.crossnet_mix(ws["dnn_in"], *[p.w for p in self.p_mix], dim=d, out=stack)
+            else:
+                self._cross_fwd(ws["dnn_in"], d, par, stack)
             col = d
         if model.dnn is not None:
             ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, in_dim=d, out=stack[:, col:],
@@ -399,7 +420,10 @@ class HipTrainer(object):
             ops.mlp_bwd(ws["dnn_in"], d, model.dnn.kernels, buf["acts"], model.dnn.activation, None, None,
                         [p.g for p in self.p_kernels], [p.g for p in self.p_biases], None, dx=buf["dx"], d_out=dstack[:, col:])
             have_dx = True
-        if model.cross is not None:
+        if model.cross is not None and self.p_mix is not None:
+            ops.crossnet_mix_bwd(ws["dnn_in"], d, [p.w for p in self.p_mix], dstack, [p.g for p in self.p_mix], buf["dx"],
+                                 accumulate=have_dx)
+        elif model.cross is not None:
             ops.crossnet_bwd(ws["dnn_in"], d, self.p_cross_k.w, self.p_cross_b.w, par, dstack, self.p_cross_k.g, self.p_cross_b.g,
                              buf["dx"], accumulate=have_dx)
 

@@ -572,6 +572,37 @@ typedef struct {
 size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* args);
 int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* args, void* stream);
 
+/* CrossNetMix backward (DCNMix; forward: dctr_crossnet_mix_fwd, deepctr/layers/interaction.py:511-549).  Nothing is saved by
+ * the forward: x_l, the low-rank projections and the gate are recomputed into the workspace.  Weights as in the forward
+ * (U, V [layers, experts, dim, low_rank], C [layers, experts, low_rank, low_rank], gating [experts, dim], bias [layers, dim]);
+ * dU / dV / dC / dgating / dbias have the same shapes and are ACCUMULATED into; dx [B, dx_stride] = gradient w.r.t. x_0. */
+typedef struct {
+    const float* x;               /* [B, x_stride] the forward's input x_0                               */
+    int64_t x_stride;
+    int64_t batch;
+    int32_t dim, layers, experts, low_rank;
+    const float* U;
+    const float* V;
+    const float* C;
+    const float* gating;
+    const float* bias;
+    const float* dy;              /* [B, dy_stride] gradient w.r.t. the output                           */
+    int64_t dy_stride;
+    float* dU;
+    float* dV;
+    float* dC;
+    float* dgating;
+    float* dbias;
+    float* dx;                    /* [B, dx_stride]                                                      */
+    int64_t dx_stride;
+    int32_t dx_accumulate;        /* 1 = add into dx, 0 = overwrite                                      */
+    int32_t pad_;
+    void* workspace;              /* dctr_crossnet_mix_bwd_workspace_bytes() bytes, 16-B aligned         */
+    size_t workspace_bytes;
+} dctr_crossnet_mix_bwd_args_t;
+size_t dctr_crossnet_mix_bwd_workspace_bytes(const dctr_crossnet_mix_bwd_args_t* args);
+int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* args, void* stream);
+
 /* backward of dctr_cin_fwd (interaction.py:277-325), first version: z materialised per layer in the workspace, the
  * three GEMMs per layer (forward recompute, dW = z^T dpre, dz = dpre W^T) are rocBLAS sgemm. */
 typedef struct {

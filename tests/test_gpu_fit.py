@@ -54,9 +54,9 @@ def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
     assert isinstance(model.train_on_batch({k: v[:64] for k, v in feed.items()}, y[:64]), float)
 
 
-@pytest.mark.parametrize("kind,on_hip", [("NFM", True), ("PNN", True), ("AFM", True), ("DCNMix", False)])
+@pytest.mark.parametrize("kind,on_hip", [("NFM", True), ("PNN", True), ("AFM", True), ("DCNMix", True)])
 def test_sibling_models_fit(device, kind, on_hip):
-    """fit() of the sibling models: NFM / PNN / AFM on the HIP training step, DCNMix on the torch-autograd step."""
+    """fit() of the sibling models on the HIP training step."""
     from deepctr_amd import models
     from deepctr_amd.feature_column import DenseFeat, SparseFeat
     rng = np.random.RandomState(3)

@@ -436,6 +436,100 @@ def test_dcn_hip_training_gradients_match_torch_autograd(device, par, cross_num,
     assert getattr(model, "_hip_trainer", None) is not None and h.history["loss"][-1] < h.history["loss"][0]
 
 
+@pytest.mark.parametrize("B,d,L,ne,r", [(300, 429, 2, 4, 32), (70, 45, 3, 2, 4), (5, 7, 1, 1, 3), (130, 64, 2, 3, 8), (9, 6, 0, 2, 2)])
+def test_crossnet_mix_bwd_matches_autograd(device, B, d, L, ne, r):
+    """dctr_crossnet_mix_bwd against float64 autograd over CrossNetMix.call (interaction.py:511-549): every weight gradient and dx;
+    strided x / dy / dx, accumulation into dx."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(33)
+    x = rng.standard_normal((B, d + 3)).astype(np.float32) * 0.7
+    U = (rng.standard_normal((L, ne, d, r)) / np.sqrt(r)).astype(np.float32)
+    V = (rng.standard_normal((L, ne, d, r)) / np.sqrt(d)).astype(np.float32)
+    C = (rng.standard_normal((L, ne, r, r)) / np.sqrt(r)).astype(np.float32)
+    G = (rng.standard_normal((ne, d)) / np.sqrt(d)).astype(np.float32)
+    Bb = (rng.standard_normal((L, d)) * 0.1).astype(np.float32)
+    dy = rng.standard_normal((B, d + 1)).astype(np.float32)
+    t64 = lambda a: torch.tensor(a.astype(np.float64), requires_grad=True)          # noqa: E731
+    xt, Ut, Vt, Ct, Gt, Bt = t64(x[:, :d]), t64(U), t64(V), t64(C), t64(G), t64(Bb)
+    x0 = xl = xt
+    for l in range(L):
+        gate = torch.softmax(xl @ Gt.T, dim=-1)
+        moe = torch.zeros_like(xl)
+        for e in range(ne):
+            v = torch.tanh(torch.tanh(xl @ Vt[l, e]) @ Ct[l, e].T)
+            moe = moe + gate[:, e:e + 1] * (x0 * (v @ Ut[l, e].T + Bt[l]))
+        xl = moe + xl
+    (xl * torch.tensor(dy[:, :d].astype(np.float64))).sum().backward()
+    packed = [dev(a, device) for a in (U, V, C, G, Bb)]
+    # the forward kernel on the same weights (sanity of the comparison)
+    if L:
+        yf = ops.crossnet_mix(dev(x, device), *packed, dim=d)
+        assert_close(yf.cpu().numpy(), xl.detach().numpy(), rtol=1e-4, atol=1e-5, what="crossnet_mix forward")
+    grads = [torch.zeros_like(t) for t in packed]
+    dx = torch.full((B, d + 2), 3.0, device=device)
+    ops.crossnet_mix_bwd(dev(x, device), d, packed, dev(dy, device), grads, dx, accumulate=True)
+    tag = "B=%d d=%d L=%d experts=%d r=%d" % (B, d, L, ne, r)
+
+    def close(got, ref, what):
+        ref = ref.numpy()
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        assert_close(got.cpu().numpy() / scale, ref / scale, rtol=2e-4, atol=2e-5, what=what + " " + tag)
+    close(dx[:, :d] - 3.0, xt.grad, "dx")
+    assert float((dx[:, d:] - 3.0).abs().max()) == 0.0
+    if L:
+        for got, ref, name in zip(grads, (Ut.grad, Vt.grad, Ct.grad, Gt.grad, Bt.grad), ("dU", "dV", "dC", "dgating", "dbias")):
+            close(got, ref, name)
+
+
+@pytest.mark.parametrize("cross_num,hidden", [(2, (32, 16)), (1, ()), (3, (24,))])
+def test_dcnmix_hip_training_gradients_match_torch_autograd(device, cross_num, hidden):
+    """DCNMix on the HIP step (CrossNetMix backward + the headless DNN backward + Dense(1) over the stack) against torch
+    autograd over training.model_logits; then fit() takes the HIP step and learns."""
+    from deepctr_amd import training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DCNMix
+    from deepctr_amd.training_hip import HipTrainer, supported
+    from tests.test_gpu_models import _randomise
+    rng = np.random.RandomState(35)
+    cols = [SparseFeat("C%d" % i, 40 + 3 * i, 8, use_hash=(i == 1)) for i in range(5)] + [DenseFeat("I%d" % i, 1) for i in range(3)]
+    model = DCNMix(cols, cols, cross_num=cross_num, dnn_hidden_units=hidden, low_rank=6, num_experts=3, l2_reg_linear=0,
+                   l2_reg_embedding=0, l2_reg_cross=0, device=device)
+    assert supported(model)
+    _randomise(model, rng)
+    n = 200
+    feed = _feed(rng, cols, n)
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    staged = model.stage(feed)
+    model._begin()
+    tr = HipTrainer(model)
+    yt = dev(y, device)
+    loss = tr.step(staged, 0, n, yt, apply=False)
+    params = [p.w for p in tr.params]
+    for t in params:
+        t.requires_grad_(True)
+    try:
+        tr.bind_cross_views()            # the per-layer views must descend from the grad-tracking packed tensors
+        model._begin()
+        logit = training.model_logits(model, staged, 0, n)
+        ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+        tr.bind_cross_views()
+    assert_close(loss.cpu().numpy(), [float(ref_loss.detach())], rtol=1e-4, atol=1e-6, what="loss")
+    for p, gref in zip(tr.params, grads):
+        gref = torch.zeros_like(p.w) if gref is None else gref
+        scale = max(float(gref.abs().max()), 1e-6)
+        assert_close(p.g.cpu().numpy() / scale, gref.cpu().numpy() / scale, rtol=2e-4, atol=2e-6, what="grad of %s" % (tuple(p.w.shape),))
+    model.compile("adam", "binary_crossentropy")
+    h = model.fit(feed, y, batch_size=64, epochs=6, verbose=0)
+    assert getattr(model, "_hip_trainer", None) is not None and h.history["loss"][-1] < h.history["loss"][0]
+    # the Keras-named weights are views of the trained packed tensors: predict() sees the trained weights
+    w = model.get_weights_by_name()
+    assert any(k.endswith("U_list0") for k in w) and np.isfinite(model.predict(feed, batch_size=64)).all()
+
+
 @pytest.mark.parametrize("B,F0,D,ls,split,act", [(37, 7, 8, (12, 10), True, "relu"), (9, 5, 4, (8, 6, 5), False, "linear"),
                                                  (64, 26, 16, (32, 16), True, "relu"), (20, 6, 6, (8,), True, "sigmoid")])
 def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act):
