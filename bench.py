@@ -256,7 +256,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed_region(arm):
-        """barrier + sync | K steps (+ the one all-gather) | sync + barrier; returns seconds (this rank)."""
+        """barrier + sync | K steps (+ the one all-gather) + sync | barrier; returns this rank's seconds between the bars."""
         barrier()
         torch.cuda.synchronize()
         if arm:
@@ -266,8 +266,9 @@ def main():
         if dist is not None:
             dist.all_gather_into_tensor(gathered, logits)              # the path's one exchange: final logits
         torch.cuda.synchronize()
-        barrier()
-        return time.perf_counter() - t0
+        dt = time.perf_counter() - t0                                  # this rank's K steps + the exchange; MAX over ranks below
+        barrier()                                                      # (closing bracket, outside the clock: one collective
+        return dt                                                      #  latency less inside a sub-millisecond region)
 
     elapsed = timed_region(arm=False)                       # `value`: the K steps, nothing else in the region
     # the same region once more with an event pair around every kernel launch (hipExtLaunchKernelGGL start / stop events on

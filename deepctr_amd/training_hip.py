@@ -2,12 +2,13 @@
 
 Covers the DeepFM family (embedding gather [+ linear] [+ FM] -> DNN -> Dense(1) -> PredictionLayer: DeepFM, WDL, FNN;
 NFM and PNN add their interaction layer's forward / backward kernel in front of the DNN; AFM has its
-AFMLayer instead of the DNN), DCN and xDeepFM,
-sequence features included: forward = ``dctr_embed_pool`` per sequence feature + ``dctr_embed_gather_fm`` +
+AFMLayer instead of the DNN), DCN, DCNMix (``dctr_crossnet_mix_bwd``), xDeepFM and DIN (attention input / weighted sum /
+lookup scatter kernels; Dice as tf.keras runs it under fit(): ``dctr_dice_train_fwd`` + the BatchNormalization backward inside
+``dctr_mlp_bwd``), sequence features included: forward = ``dctr_embed_pool`` per sequence feature + ``dctr_embed_gather_fm`` +
 ``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` → ``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` →
 ``dctr_embed_pool_bwd`` → ``dctr_opt_multi`` (one launch over every parameter).  No torch autograd, no torch
-optimizer: PyTorch only owns the buffers.  Models / options outside that family (DIN, DCNMix, Dice / BatchNormalization /
-dropout in training mode) keep the torch-autograd step of ``training.py``: their attention backward kernels do not exist yet.
+optimizer: PyTorch only owns the buffers.  Options outside that (dropout, ``dnn_use_bn``, softmax-normalised DIN attention,
+several FM groups) keep the torch-autograd step of ``training.py``.
 
 Semantics follow tf.keras as the reference uses it (``model.compile("adam", "binary_crossentropy")``,
 examples/run_classification_criteo.py:44-50; also "adagrad", "rmsprop", "sgd" by name with tf.keras' defaults): Adam lr
