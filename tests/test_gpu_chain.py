@@ -71,6 +71,53 @@ def test_chain_kernel_vs_oracle_and_tile_kernel(device, E, V, n, F, ND):
     assert np.array_equal(ya, y[:cut])
 
 
+@pytest.mark.parametrize("F,ND,E", [(1, 0, 16), (2, 3, 16), (12, 0, 32), (15, 5, 32), (64, 16, 16)])
+def test_chain_kernel_field_count_edges(device, F, ND, E):
+    """One field (a pair with one member, no k-block behind it), two fields + dense, the 64-field limit with a full dense k-block."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(100 + F)
+    n = 700
+    cols, feed = _criteo_like(rng, n, F=F, V=300, E=E, ND=ND)
+    model = DeepFM(cols, cols, device=device)
+    w = _randomise(model, rng)
+    y32 = _predict(model, feed, n, tile_rows=32)
+    y = _predict(model, feed, n, tile_rows=256)
+    ref = RM.deepfm(cols, cols, w, feed, dtype=np.float64)
+    check_probs(y, ref.astype(np.float32), "chain DeepFM F=%d ND=%d" % (F, ND))
+    assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain vs 32-row kernel F=%d" % F)
+    assert np.array_equal(_predict(model, feed, n, tile_rows=128), y)
+
+
+def test_chain_kernel_writes_the_gather_logits(device):
+    """dctr_embed_mlp_fwd with g->fm_logit / g->lin_logit: the row-chained kernel also hands back the gather epilogue's per-row
+    FM and linear logits (the Python fast path never asks for them) — against the stand-alone gather's."""
+    import torch
+    from deepctr_amd import ops
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(9)
+    n = 900
+    cols, feed = _criteo_like(rng, n, V=400, E=16)
+    model = DeepFM(cols, cols, device=device)
+    _randomise(model, rng)
+    sp = model.stage_plan
+    staged = model.stage(feed)
+    model._begin()
+    ws = sp.run(staged, 0, n)                                    # stand-alone gather: dnn_in, fm, lin
+    fm_ref, lin_ref = ws["fm"].clone(), ws["lin"].clone()
+    ws["fm"].fill_(7.0)
+    ws["lin"].fill_(7.0)
+    g = sp.gather_args(staged, 0, n, ws, to_hbm=True)
+    out = torch.empty(n, dtype=torch.float32, device=model.device)
+    ops.mlp(None, model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=model.dense.w("kernel"),
+            global_bias=model.prediction.w("global_bias"), sigmoid_out=True, in_dim=sp.in_dim, out=out, gather=g,
+            add_fm_logit=True, add_lin_logit=True, batch=n, tile_rows=256)
+    model._check_status()
+    assert_close(ws["lin"].cpu().numpy(), lin_ref.cpu().numpy(), rtol=1e-5, atol=1e-6, what="linear logit")
+    fm_scale = float(fm_ref.abs().max()) + 1.0
+    assert_close(ws["fm"].cpu().numpy() / fm_scale, fm_ref.cpu().numpy() / fm_scale, rtol=1e-5, atol=2e-6, what="FM logit")
+    assert_close(out.cpu().numpy().reshape(-1, 1), model.predict(feed, batch_size=n), rtol=1e-6, atol=1e-7, what="fused output")
+
+
 def test_chain_kernel_model_variants(device):
     """Terms switched off (WDL: no FM; FNN: no FM, no linear part), int64 ids (host and device), a feature outside the FM
     group, linear / tanh DNN, regression head — against the float64 oracle or the 32-row kernel."""
