@@ -53,43 +53,54 @@ __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__
 //   d e_f = d dnn_in[b, off_f ..] + d_fm[b] * (S - e_f)     (S = sum over the FM fields of e: FM = 0.5 (S^2 - sum e^2))
 //   d lin_f[row] += d_lin[b]
 // ---------------------------------------------------------------------------------------------------
+// One wave = 64 / LPR samples x LPR 16-B chunks; the workgroup's four waves split the FIELDS (wave w owns fields w, w + 4, ...):
+// B = 4096, E = 16 -> 256 workgroups with 7 independent row reads per lane in flight (the first version walked all fields
+// serially in 64 workgroups: 112 us).  S is summed per wave over its fields and combined through LDS.
 template <int LPR, bool HASH>
 __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_t p, const dctr_field_grad_t* __restrict__ gr,
                                                             const float* __restrict__ d_in, int64_t d_stride,
                                                             const float* __restrict__ d_fm, const float* __restrict__ d_lin,
                                                             float* __restrict__ g_dense_lin_w,
                                                             const int32_t* __restrict__ dense_lin_rows) {
-    constexpr int VEC = 4, SPB = 256 / LPR;
-    const int s = threadIdx.x / LPR, q = threadIdx.x % LPR;
-    const int64_t b = (int64_t)blockIdx.x * SPB + s;
+    constexpr int VEC = 4, SPW = 64 / LPR, NWV = 4;
+    __shared__ float s_part[NWV][64][VEC];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane / LPR, q = lane % LPR;
+    const int64_t b = (int64_t)blockIdx.x * SPW + s;
     const bool valid = b < p.batch;
     cfield_ptr F = (cfield_ptr)p.fields;
     const float dfm = (valid && d_fm != nullptr) ? d_fm[b] : 0.f;
     const float dlin = (valid && d_lin != nullptr) ? d_lin[b] : 0.f;
-    // pass 1: S
+    auto row_of = [&](const FieldRegs& f, int j) -> int64_t {
+        int64_t r = f.identity ? b : read_id(p.ids, (int64_t)j * p.ids_stride_f + (valid ? b : 0) * p.ids_stride_b, p.ids_is_i64);
+        if constexpr (HASH) {
+            if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
+        }
+        return r;
+    };
+    // pass 1: S = sum over the FM fields of e_f (this wave's fields, then the four partial sums)
     float S[VEC] = {0.f, 0.f, 0.f, 0.f};
     if (d_fm != nullptr) {
-        for (int j = 0; j < p.n_fields; ++j) {
+        for (int j = wave; j < p.n_fields; j += NWV) {
             const FieldRegs f = load_field(F, j);
             if (!f.in_fm) continue;
-            int64_t r = f.identity ? b : read_id(p.ids, (int64_t)j * p.ids_stride_f + (valid ? b : 0) * p.ids_stride_b, p.ids_is_i64);
-            if constexpr (HASH) {
-                if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
-            }
+            const int64_t r = row_of(f, j);
             const bool ok = valid && (uint64_t)r < (uint64_t)f.vocab && q * VEC < f.dim;
             float v[VEC];
             load_vec<VEC>(f.table + (ok ? r : 0) * f.dim + (ok ? q * VEC : 0), v);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) S[c] += ok ? v[c] : 0.f;
         }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) s_part[wave][lane][c] = S[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) S[c] = (s_part[0][lane][c] + s_part[1][lane][c]) + (s_part[2][lane][c] + s_part[3][lane][c]);
     }
-    // pass 2: row gradients
-    for (int j = 0; j < p.n_fields; ++j) {
+    // pass 2: row gradients of this wave's fields
+    for (int j = wave; j < p.n_fields; j += NWV) {
         const FieldRegs f = load_field(F, j);
-        int64_t r = f.identity ? b : read_id(p.ids, (int64_t)j * p.ids_stride_f + (valid ? b : 0) * p.ids_stride_b, p.ids_is_i64);
-        if constexpr (HASH) {
-            if (f.hash_mode != 0) r = resolve_row(r, f.hash_mode, p.ids_is_i64, f.vocab);
-        }
+        const int64_t r = row_of(f, j);
         const bool rok = valid && (uint64_t)r < (uint64_t)f.vocab;
         const bool ok = rok && q * VEC < f.dim;
         float* gt = gr[j].g_table;
@@ -112,12 +123,16 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
         }
         if (rok && q == 0 && gl != nullptr && f.lin_table != nullptr) unsafeAtomicAdd(gl + r, dlin);
     }
-    // dense . Linear.kernel: d w[k] += sum_b d_lin[b] * dense[b, k]
-    if (g_dense_lin_w != nullptr && p.n_dense > 0 && valid && q == 0) {
-        const float* src = p.dense + b * p.dense_stride;
-        for (int k = 0; k < p.n_dense; ++k) {
+    // dense . Linear.kernel: d w[k] += sum_b d_lin[b] * dense[b, k]  — dense column k by wave k % 4, the wave's samples summed
+    // before the one atomic (4096 atomics on one address serialise)
+    if (g_dense_lin_w != nullptr && p.n_dense > 0) {
+        for (int k = wave; k < p.n_dense; k += NWV) {
             const int row = dense_lin_rows != nullptr ? dense_lin_rows[k] : k;     // dense column k -> row of Linear.kernel
-            if (row >= 0) unsafeAtomicAdd(g_dense_lin_w + row, dlin * src[k]);
+            if (row < 0) continue;
+            float t = (valid && q == 0) ? dlin * p.dense[b * p.dense_stride + k] : 0.f;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+            if (lane == 0) unsafeAtomicAdd(g_dense_lin_w + row, t);
         }
     }
 }
@@ -265,6 +280,110 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* __restrict__
             acc += d;
         }
         if (db != nullptr) unsafeAtomicAdd(db + n, acc);
+    }
+}
+
+// The two helpers above with 16-B accesses and the rows spread over the workgroup: thread (rl, c) owns columns 4c .. 4c+3 of rows
+// rl, rl + RL, ... (RL = 256 / (N/4) row lanes; a workgroup sweeps RL x N contiguous floats per iteration, grid-stride), the column
+// sums meet in LDS and leave as ONE atomic per column and workgroup (N % 4 == 0, N <= 1024, strides % 4 == 0, 16-B aligned).
+constexpr int COLSUM_MAX_WG = 64;      // workgroups of a pass that ends in one atomic per column and workgroup
+
+__device__ __forceinline__ float4 act_grad4(float4 d, float4 hv, int act) {
+    if (act == DCTR_ACT_RELU) {
+        d.x = hv.x > 0.f ? d.x : 0.f; d.y = hv.y > 0.f ? d.y : 0.f; d.z = hv.z > 0.f ? d.z : 0.f; d.w = hv.w > 0.f ? d.w : 0.f;
+    } else if (act == DCTR_ACT_SIGMOID) {
+        d.x *= hv.x * (1.f - hv.x); d.y *= hv.y * (1.f - hv.y); d.z *= hv.z * (1.f - hv.z); d.w *= hv.w * (1.f - hv.w);
+    } else if (act == DCTR_ACT_TANH) {
+        d.x *= 1.f - hv.x * hv.x; d.y *= 1.f - hv.y * hv.y; d.z *= 1.f - hv.z * hv.z; d.w *= 1.f - hv.w * hv.w;
+    }
+    return d;
+}
+
+__device__ __forceinline__ void colsum4_finish(float4 acc, int N4, int RL, int c, float* __restrict__ out) {
+    __shared__ float4 red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (out != nullptr && (int)threadIdx.x < N4) {
+        float4 t = red[c];
+        for (int r = 1; r < RL; ++r) {
+            const float4 u = red[r * N4 + c];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        unsafeAtomicAdd(out + 4 * c + 0, t.x);
+        unsafeAtomicAdd(out + 4 * c + 1, t.y);
+        unsafeAtomicAdd(out + 4 * c + 2, t.z);
+        unsafeAtomicAdd(out + 4 * c + 3, t.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd4_kernel(const float* __restrict__ dlogit, const float* __restrict__ head_w,
+                                                        const float* __restrict__ h, int64_t h_stride, int64_t batch, int N,
+                                                        int act, float* __restrict__ dz, int64_t dz_stride,
+                                                        float* __restrict__ d_head_w) {
+    const int N4 = N >> 2, RL = 256 / N4;
+    const int c = threadIdx.x % N4, rl = threadIdx.x / N4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < RL) {
+        const float4 hw = *reinterpret_cast<const float4*>(head_w + 4 * c);
+#pragma unroll 4
+        for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < batch; r += (int64_t)gridDim.x * RL) {
+            const float4 hv = *reinterpret_cast<const float4*>(h + r * h_stride + 4 * c);
+            const float dl = dlogit[r];
+            const float4 d = act_grad4(make_float4(dl * hw.x, dl * hw.y, dl * hw.z, dl * hw.w), hv, act);
+            *reinterpret_cast<float4*>(dz + r * dz_stride + 4 * c) = d;
+            acc.x = fmaf(dl, hv.x, acc.x); acc.y = fmaf(dl, hv.y, acc.y); acc.z = fmaf(dl, hv.z, acc.z); acc.w = fmaf(dl, hv.w, acc.w);
+        }
+    }
+    colsum4_finish(acc, N4, RL, c, d_head_w);
+}
+
+__global__ __launch_bounds__(256) void act_bwd_colsum4_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t batch,
+                                                              int N, int act, float* __restrict__ db) {
+    const int N4 = N >> 2, RL = 256 / N4;
+    const int c = threadIdx.x % N4, rl = threadIdx.x / N4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < RL) {
+#pragma unroll 4
+        for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < batch; r += (int64_t)gridDim.x * RL) {
+            float4 d = *reinterpret_cast<const float4*>(dh + r * N + 4 * c);
+            if (h != nullptr) {
+                d = act_grad4(d, *reinterpret_cast<const float4*>(h + r * N + 4 * c), act);
+                *reinterpret_cast<float4*>(dh + r * N + 4 * c) = d;
+            }
+            acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        }
+    }
+    colsum4_finish(acc, N4, RL, c, db);
+}
+
+// launch either form: the 16-B one when the shapes allow it
+static void launch_act_bwd_colsum(hipStream_t st, float* dh, const float* h, int64_t batch, int N, int act, float* db) {
+    if (N % 4 == 0 && N <= 1024 && dctr_aligned16(dh) && (h == nullptr || dctr_aligned16(h))) {
+        const int RL = 256 / (N / 4);
+        int64_t g = dctr_ceil_div(batch, (int64_t)RL * 4);           // >= 4 rows per thread where the batch has them
+        // atomics on ONE address serialise at ~100 ns each on this part (measured: 256 workgroups x 256 columns = 27 us of a
+        // 4-MB pass): with column sums wanted, few workgroups with long row loops; without, as many as the rows give
+        const int64_t cap = db != nullptr ? COLSUM_MAX_WG : 1024;
+        g = g < 1 ? 1 : (g > cap ? cap : g);
+        hipLaunchKernelGGL(act_bwd_colsum4_kernel, dim3((unsigned)g), dim3(256), 0, st, dh, h, batch, N, act, db);
+    } else {
+        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)BWD_ROWS)), dim3(256), 0, st, dh, h,
+                           batch, N, act, db);
+    }
+}
+
+static void launch_head_bwd(hipStream_t st, const float* dlogit, const float* head_w, const float* h, int64_t h_stride, int64_t batch,
+                            int N, int act, float* dz, int64_t dz_stride, float* d_head_w) {
+    if (N % 4 == 0 && N <= 1024 && h_stride % 4 == 0 && dz_stride % 4 == 0 && dctr_aligned16(h) && dctr_aligned16(dz) &&
+        dctr_aligned16(head_w)) {
+        const int RL = 256 / (N / 4);
+        int64_t g = dctr_ceil_div(batch, (int64_t)RL * 4);
+        g = g < 1 ? 1 : (g > COLSUM_MAX_WG ? COLSUM_MAX_WG : g);
+        hipLaunchKernelGGL(head_bwd4_kernel, dim3((unsigned)g), dim3(256), 0, st, dlogit, head_w, h, h_stride, batch, N, act, dz,
+                           dz_stride, d_head_w);
+    } else {
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)BWD_ROWS)), dim3(256), 0, st, dlogit, head_w,
+                           h, h_stride, batch, N, act, dz, dz_stride, d_head_w);
     }
 }
 
@@ -1184,7 +1303,7 @@ extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void
                  "embed_gather_fm_bwd: d_dnn_in must be 16-B aligned with a stride %% 4 == 0");
     int lpr = 1;
     while (lpr * 4 < f->max_dim) lpr <<= 1;
-    const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(256 / lpr));
+    const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(64 / lpr));        // one wave's worth of samples per workgroup
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_gather_fm_bwd: batch too large");
     hipStream_t st = (hipStream_t)stream;
 #define CALL_BWD(L)                                                                                                       \
@@ -1299,16 +1418,15 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit
     const int NL = a->units[L - 1];
     if (a->head_w != nullptr) {
-        hipLaunchKernelGGL(head_bwd_kernel, dim3(rb), dim3(256), 0, st, a->dlogit, a->head_w, a->acts[L - 1], (int64_t)NL,
-                           a->batch, NL, dice ? (int)DCTR_ACT_LINEAR : (int)a->activation, bufA, (int64_t)NL, a->d_head_w);
+        launch_head_bwd(st, a->dlogit, a->head_w, a->acts[L - 1], (int64_t)NL, a->batch, NL,
+                        dice ? (int)DCTR_ACT_LINEAR : (int)a->activation, bufA, (int64_t)NL, a->d_head_w);
     } else {
         // headless (the DNN branch of DCN): the caller hands d(loss)/d(h_last); dZ_last = d_out .* act'(h_last)
         hipError_t ce = hipMemcpy2DAsync(bufA, (size_t)NL * sizeof(float), a->d_out, (size_t)a->d_out_stride * sizeof(float),
                                          (size_t)NL * sizeof(float), (size_t)a->batch, hipMemcpyDeviceToDevice, st);
         DCTR_REQUIRE(ce == hipSuccess, (int)ce, "mlp_bwd: copy of d_out failed: %s", hipGetErrorString(ce));
         if (a->activation != DCTR_ACT_LINEAR && !dice)
-            hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, bufA, a->acts[L - 1], a->batch, NL,
-                               (int)a->activation, (float*)nullptr);
+            launch_act_bwd_colsum(st, bufA, a->acts[L - 1], a->batch, NL, (int)a->activation, (float*)nullptr);
     }
     if (dice) {
         const int rc = dice_bwd(L - 1, bufA);
@@ -1322,8 +1440,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         const int ldx = l == 0 ? (int)a->x_stride : K;
         // d_bias[n] += sum_b dZ[b, n]   (dZ is final here: the head / the previous iteration applied act')
         if (a->d_biases != nullptr && a->d_biases[l] != nullptr)
-            hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, dz, (const float*)nullptr, a->batch, N, 0,
-                               a->d_biases[l]);
+            launch_act_bwd_colsum(st, dz, (const float*)nullptr, a->batch, N, 0, a->d_biases[l]);
         // dW[K, N] (row-major) += X^T dZ:  column-major  dW'(N x K) = dZ'(N x B) * X'(K x B)^T
         rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, dz, N, xin, ldx,
                                           &one, a->d_kernels[l], N);
@@ -1342,8 +1459,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
                 const int rc = dice_bwd(l - 1, other);
                 DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(Z) failed (%d)", rc);
             } else if (a->activation != DCTR_ACT_LINEAR) {
-                hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, other, a->acts[l - 1], a->batch, K,
-                                   (int)a->activation, (float*)nullptr);
+                launch_act_bwd_colsum(st, other, a->acts[l - 1], a->batch, K, (int)a->activation, (float*)nullptr);
             }
             float* t = dz;
             dz = other;
@@ -1398,8 +1514,7 @@ extern "C" int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, 
     DCTR_REQUIRE(batch >= 0 && n >= 1 && x_stride >= n && dx_stride >= n, DCTR_E_DIM, "dense1_bwd: bad sizes");
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && w && dlogit && dx && d_w, DCTR_E_NULL, "dense1_bwd: null pointer");
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)BWD_ROWS)), dim3(256), 0, (hipStream_t)stream,
-                       dlogit, w, x, x_stride, batch, (int)n, (int)DCTR_ACT_LINEAR, dx, dx_stride, d_w);
+    launch_head_bwd((hipStream_t)stream, dlogit, w, x, x_stride, batch, (int)n, (int)DCTR_ACT_LINEAR, dx, dx_stride, d_w);
     return dctr_launch_status("dctr_dense1_bwd");
 }
 
@@ -1472,15 +1587,13 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, a->dy, a->dy_stride, a->batch, d, g, (int64_t)d, 0);
     hipError_t me = hipMemsetAsync(dx0, 0, bd * sizeof(float), st);
     DCTR_REQUIRE(me == hipSuccess, (int)me, "crossnet_bwd: memset failed: %s", hipGetErrorString(me));
-    const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
     for (int l = L - 1; l >= 0; --l) {
         const float* xl; int ldx;
         xl_of(l, xl, ldx);
         const float* W = a->kernels + (size_t)l * d * d;
         hipLaunchKernelGGL(cross_matrix_bwd_elem_kernel, dim3(eb), dim3(256), 0, st, a->x, a->x_stride, g, us + (size_t)l * bd,
                            a->bias + (size_t)l * d, a->batch, d, du, dx0);
-        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(rb), dim3(256), 0, st, du, (const float*)nullptr, a->batch, d, 0,
-                           a->d_bias + (size_t)l * d);
+        launch_act_bwd_colsum(st, du, (const float*)nullptr, a->batch, d, 0, a->d_bias + (size_t)l * d);
         // dW[n][k] += sum_b du[b][n] x_l[b][k]:  column-major  dW'(k x n) = X'(k x B) * du'(n x B)^T
         rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, d, B, &one, xl, ldx, du, d, &one,
                                           a->d_kernels + (size_t)l * d * d, d);
@@ -1596,8 +1709,7 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
         float* dz = ws + p.dz;
         hipLaunchKernelGGL(cin_dpre_kernel, grid(p.R * H), dim3(256), 0, st, ws + p.y[k], dxnext, ldn, p.Hn[k], a->d_out,
                            (int64_t)a->out_dim, p.off[k], p.d0[k], p.R, H, D, (int)f->activation, dpre);
-        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)dctr_ceil_div(p.R, (int64_t)BWD_ROWS)), dim3(256), 0, st, dpre,
-                           (const float*)nullptr, p.R, H, 0, a->d_bias[k]);
+        launch_act_bwd_colsum(st, dpre, (const float*)nullptr, p.R, H, 0, a->d_bias[k]);
         // dW[K,H] += z^T dpre:  column-major  dW'(H x K) = dpre'(H x R) z'(K x R)^T.  The output is small (H x K) and the
         // reduction long (R = B*D): as ONE gemm it runs on ~18 workgroups (1.8 ms at C3); split the rows into `parts`
         // slices computed as a strided batch of partial products in the (now free) dz buffer, then summed.

@@ -500,15 +500,27 @@ class EmbeddingStage(object):
         return ws
 
     def refresh(self, linear_kernel):
-        """Per predict() call: Linear.kernel rows permuted into dense-matrix column order."""
+        """Per predict() call / training step: Linear.kernel rows permuted into dense-matrix column order.  The index
+        tensors and the destination are built once (a boolean-mask assignment here cost two torch.nonzero host
+        synchronisations per call): one index_select into the persistent buffer per refresh."""
         self.dense_lin_w = None
         if self.n_dense and self.n_lin_dense and linear_kernel is not None:
-            rows = torch.as_tensor(self.dense_lin_rows, device=self.device)
+            if getattr(self, "_dl_buf", None) is None:
+                pos = [i for i, r in enumerate(self.dense_lin_rows) if r >= 0]
+                self._dl_pos = torch.as_tensor(pos, dtype=torch.int64, device=self.device)
+                self._dl_src = torch.as_tensor([self.dense_lin_rows[i] for i in pos], dtype=torch.int64, device=self.device)
+                self._dl_all = len(pos) == self.n_dense
+                self._dl_buf = torch.zeros(self.n_dense, dtype=torch.float32, device=self.device)
             k = linear_kernel.reshape(-1)
-            w = torch.zeros(self.n_dense, dtype=torch.float32, device=self.device)
-            sel = rows >= 0
-            w[sel] = k[rows[sel]]
-            self.dense_lin_w = w
+            if k.requires_grad and torch.is_grad_enabled():
+                # the torch-autograd training step (training.model_logits) differentiates through this buffer
+                self.dense_lin_w = torch.zeros_like(self._dl_buf).index_copy(0, self._dl_pos, k.index_select(0, self._dl_src))
+                return
+            if self._dl_all:
+                torch.index_select(k, 0, self._dl_src, out=self._dl_buf)
+            elif len(self._dl_pos):
+                self._dl_buf.index_copy_(0, self._dl_pos, k.index_select(0, self._dl_src))
+            self.dense_lin_w = self._dl_buf
 
     def _pool(self, fc, staged, lo, hi, table, lin_table, out, lin_out, status):
         ids = staged.seq[fc.name][lo:hi]
