@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* _
 //     ds = g . x0;  d b_l += g;  d w_l += ds * x_l;  d x0 += g * s_l;  g += ds * w_l      (l = L-1 .. 0),  d x0 += g
 //   One wave walks CROSS_SPW samples (x_l per layer in LDS), accumulating d w / d b in LDS, flushed once with atomics.
 // ---------------------------------------------------------------------------------------------------
-constexpr int CROSS_SPW = 16;
+constexpr int CROSS_SPW = 4;       // (16 at first: 64 workgroups, 174 us at B = 4096; the accumulators are combined per workgroup now)
 
 __global__ __launch_bounds__(256) void cross_vector_bwd_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int d,
                                                                int L, const float* __restrict__ w, const float* __restrict__ bias,
@@ -552,9 +552,14 @@ __global__ __launch_bounds__(256) void cross_vector_bwd_kernel(const float* __re
             if (i < d) gout[i] = (accumulate ? gout[i] : 0.f) + dx0[r] + g[r];
         }
     }
-    for (int i = lane; i < L * d; i += 64) {
-        unsafeAtomicAdd(dw + i, aw[i]);
-        unsafeAtomicAdd(db + i, ab[i]);
+    // the four waves' accumulators meet here: one atomic per element and WORKGROUP (they serialise per address)
+    __syncthreads();
+    const size_t region = (size_t)3 * L * d + L;
+    for (int i = threadIdx.x; i < L * d; i += 256) {
+        const float* r0 = smem + (size_t)L * d + i;
+        unsafeAtomicAdd(dw + i, (r0[0] + r0[region]) + (r0[2 * region] + r0[3 * region]));
+        const float* r1 = r0 + (size_t)L * d;
+        unsafeAtomicAdd(db + i, (r1[0] + r1[region]) + (r1[2 * region] + r1[3 * region]));
     }
 }
 
@@ -1041,6 +1046,142 @@ __global__ __launch_bounds__(256) void dice_train_bwd_apply_kernel(float* __rest
     }
 }
 
+// The three Dice passes that end in column sums, in the 16-B / row-lane layout of act_bwd_colsum4_kernel (N % 4 == 0, N <= 1024):
+// DIN runs them on B*T = 102,400 rows x 80 / 40 columns, where one workgroup per 16 rows meant 6,400 atomics per column address
+// (140-190 us per pass, all of it the serialised atomics).
+template <int K>
+__device__ __forceinline__ void colsum4_finish_k(const float (&acc)[K][4], int N4, int RL, int c, float* const (&out)[K]) {
+    __shared__ float red[K][256][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[k][threadIdx.x][j] = acc[k][j];
+    __syncthreads();
+    if ((int)threadIdx.x < N4) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (out[k] == nullptr) continue;
+            float t[4] = {red[k][c][0], red[k][c][1], red[k][c][2], red[k][c][3]};
+            for (int r = 1; r < RL; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] += red[k][r * N4 + c][j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(out[k] + 4 * c + j, t[j]);
+        }
+    }
+}
+
+struct DiceCols {            // per-thread constants of its four columns
+    float bn[4], al[4], mu[4], rs[4];
+};
+__device__ __forceinline__ DiceCols dice_cols(const float* bias, const float* alpha, const float* mean, const float* var, float eps, int c) {
+    DiceCols k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = 4 * c + j;
+        k.bn[j] = bias != nullptr ? bias[n] : 0.f;
+        k.al[j] = alpha != nullptr ? alpha[n] : 0.f;
+        k.mu[j] = mean != nullptr ? mean[n] : 0.f;
+        k.rs[j] = var != nullptr ? 1.f / sqrtf(var[n] + eps) : 1.f;
+    }
+    return k;
+}
+
+__global__ __launch_bounds__(256) void dice_colstat4_kernel(const float* __restrict__ z, int64_t z_stride, const float* __restrict__ bias,
+                                                           int64_t rows, int N, int kind, const float* __restrict__ sum0,
+                                                           float* __restrict__ acc_out) {
+    const int N4 = N >> 2, RL = 256 / N4;
+    const int c = threadIdx.x % N4, rl = threadIdx.x / N4;
+    float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+    if (rl < RL) {
+        const float inv = 1.f / (float)rows;
+        float sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[j] = (bias != nullptr ? bias[4 * c + j] : 0.f) - (kind ? sum0[4 * c + j] * inv : 0.f);
+#pragma unroll 4
+        for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < rows; r += (int64_t)gridDim.x * RL) {
+            const float4 t = *reinterpret_cast<const float4*>(z + r * z_stride + 4 * c);
+            const float v[4] = {t.x + sh[0], t.y + sh[1], t.z + sh[2], t.w + sh[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] += kind ? v[j] * v[j] : v[j];
+        }
+    }
+    float* const outs[1] = {acc_out};
+    colsum4_finish_k<1>(acc, N4, RL, c, outs);
+}
+
+__global__ __launch_bounds__(256) void dice_bwd4_kernel(float* __restrict__ dh, const float* __restrict__ zw, const float* __restrict__ bias,
+                                                        const float* __restrict__ alpha, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, float eps, int64_t batch, int N,
+                                                        float* __restrict__ d_alpha) {
+    const int N4 = N >> 2, RL = 256 / N4;
+    const int c = threadIdx.x % N4, rl = threadIdx.x / N4;
+    float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+    if (rl < RL) {
+        const DiceCols k = dice_cols(bias, alpha, mean, var, eps, c);
+#pragma unroll 2
+        for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < batch; r += (int64_t)gridDim.x * RL) {
+            const float4 zt = *reinterpret_cast<const float4*>(zw + r * N + 4 * c);
+            const float4 dt = *reinterpret_cast<const float4*>(dh + r * N + 4 * c);
+            const float zz[4] = {zt.x, zt.y, zt.z, zt.w}, dd[4] = {dt.x, dt.y, dt.z, dt.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = zz[j] + k.bn[j];
+                const float p = 1.f / (1.f + expf(-(z - k.mu[j]) * k.rs[j]));
+                acc[0][j] = fmaf(dd[j], z * (1.f - p), acc[0][j]);
+                o[j] = dd[j] * (k.al[j] + (1.f - k.al[j]) * p + z * (1.f - k.al[j]) * p * (1.f - p) * k.rs[j]);
+            }
+            *reinterpret_cast<float4*>(dh + r * N + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    float* const outs[1] = {d_alpha};
+    colsum4_finish_k<1>(acc, N4, RL, c, outs);
+}
+
+__global__ __launch_bounds__(256) void dice_train_bwd_reduce4_kernel(const float* __restrict__ dh, const float* __restrict__ zw,
+                                                                    const float* __restrict__ bias, const float* __restrict__ alpha,
+                                                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                                                    float eps, int64_t batch, int N, float* __restrict__ s12,
+                                                                    float* __restrict__ d_alpha) {
+    const int N4 = N >> 2, RL = 256 / N4;
+    const int c = threadIdx.x % N4, rl = threadIdx.x / N4;
+    float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (rl < RL) {
+        const DiceCols k = dice_cols(bias, alpha, mean, var, eps, c);
+#pragma unroll 2
+        for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < batch; r += (int64_t)gridDim.x * RL) {
+            const float4 zt = *reinterpret_cast<const float4*>(zw + r * N + 4 * c);
+            const float4 dt = *reinterpret_cast<const float4*>(dh + r * N + 4 * c);
+            const float zz[4] = {zt.x, zt.y, zt.z, zt.w}, dd[4] = {dt.x, dt.y, dt.z, dt.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = zz[j] + k.bn[j];
+                const float xn = (z - k.mu[j]) * k.rs[j];
+                const float p = 1.f / (1.f + expf(-xn));
+                const float dxn = dd[j] * z * (1.f - k.al[j]) * p * (1.f - p);
+                acc[0][j] += dxn;
+                acc[1][j] = fmaf(dxn, xn, acc[1][j]);
+                acc[2][j] = fmaf(dd[j], z * (1.f - p), acc[2][j]);
+            }
+        }
+    }
+    float* const outs[3] = {s12, s12 + N, d_alpha};
+    colsum4_finish_k<3>(acc, N4, RL, c, outs);
+}
+
+// workgroups of a column-sum pass over `rows` rows: enough of them to keep the loads in flight, few enough that the final atomics
+// (one per column and workgroup, ~90 ns each on one address) stay a short tail
+static unsigned colsum_grid(int64_t rows, int RL) {
+    int64_t g = dctr_ceil_div(rows, (int64_t)RL * 4);
+    const int64_t cap = rows >= 32768 ? 128 : COLSUM_MAX_WG;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+static bool rowlane4_ok(int N, const void* a, const void* b, int64_t stride) {
+    return N % 4 == 0 && N >= 4 && N <= 1024 && stride % 4 == 0 && dctr_aligned16(a) && (b == nullptr || dctr_aligned16(b));
+}
+
 extern "C" int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float* bias, int64_t rows, int32_t n, const float* alpha,
                                    float eps, float momentum, float* moving_mean, float* moving_var, float* batch_mean,
                                    float* batch_var, float* h, int64_t h_stride, void* stream) {
@@ -1051,9 +1192,15 @@ extern "C" int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float
     hipError_t e = hipMemsetAsync(batch_mean, 0, (size_t)n * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(batch_var, 0, (size_t)n * sizeof(float), st);
     DCTR_REQUIRE(e == hipSuccess, (int)e, "dice_train_fwd: memset failed: %s", hipGetErrorString(e));
-    const unsigned rb = (unsigned)dctr_ceil_div(rows, (int64_t)BWD_ROWS);
-    hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 0, (const float*)nullptr, batch_mean);
-    hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 1, (const float*)batch_mean, batch_var);
+    if (rowlane4_ok((int)n, z, nullptr, z_stride)) {
+        const unsigned g = colsum_grid(rows, 256 / ((int)n / 4));
+        hipLaunchKernelGGL(dice_colstat4_kernel, dim3(g), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 0, (const float*)nullptr, batch_mean);
+        hipLaunchKernelGGL(dice_colstat4_kernel, dim3(g), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 1, (const float*)batch_mean, batch_var);
+    } else {
+        const unsigned rb = (unsigned)dctr_ceil_div(rows, (int64_t)BWD_ROWS);
+        hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 0, (const float*)nullptr, batch_mean);
+        hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 1, (const float*)batch_mean, batch_var);
+    }
     hipLaunchKernelGGL(dice_stat_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, batch_mean, batch_var, rows, (int)n, momentum,
                        moving_mean, moving_var);
     const int64_t total = rows * n;
@@ -1127,7 +1274,14 @@ __global__ __launch_bounds__(256) void din_wsum_bwd_kernel(const float* __restri
         if (lane == 0) d_score[r] = ds;
         bsum += ds;
     }
-    if (d_bias != nullptr && lane == 0 && bsum != 0.f) unsafeAtomicAdd(d_bias, bsum);
+    // one atomic per workgroup (B*T / 4 of them on ONE address serialised to 0.5 ms at C4)
+    __shared__ float wsum[4];
+    if (lane == 0) wsum[threadIdx.x >> 6] = bsum;
+    __syncthreads();
+    if (d_bias != nullptr && threadIdx.x == 0) {
+        const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (t != 0.f) unsafeAtomicAdd(d_bias, t);
+    }
 }
 
 // da [B*T, 4E] -> dq[b,e] = sum_t (d0 + d2 + d3 k), added into dx[b, qcol[e]];  dk[b,t,e] += d1 - d2 + d3 q
@@ -1168,6 +1322,73 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(dctr_lookup_args_t a, c
     }
 }
 
+// The same scatter for skewed ids (DIN's behaviour sequences: half of the B*T positions are padding id 0, and under training-mode
+// Dice the padded keys DO receive gradient through the batch statistics — 51,000 x 32 atomics on ONE row took 1.6 ms per table):
+// a workgroup sorts a tile of LB_TILE positions by row in LDS (bitonic), then 64 / dimP walkers per wave run over contiguous
+// stretches of the sorted tile, summing runs of equal rows in registers: one atomic per (run, column) instead of one per position.
+constexpr int LB_TILE = 1024;
+__global__ __launch_bounds__(256) void lookup_bwd_tile_kernel(dctr_lookup_args_t a, const float* __restrict__ d_out, int64_t d_stride,
+                                                              float* __restrict__ g_table, int dimP) {
+    __shared__ uint32_t key[LB_TILE];
+    __shared__ uint16_t pos[LB_TILE];
+    constexpr uint32_t NONE = 0xffffffffu;
+    const int64_t base = (int64_t)blockIdx.x * LB_TILE;
+    for (int j = threadIdx.x; j < LB_TILE; j += 256) {
+        const int64_t i = base + j;
+        uint32_t k = NONE;
+        if (i < a.n) {
+            const int64_t row = resolve_row(read_id(a.idx, i, a.idx_is_i64), a.hash_mode, a.idx_is_i64, a.vocab);
+            if ((uint64_t)row < (uint64_t)a.vocab) k = (uint32_t)row;
+        }
+        key[j] = k;
+        pos[j] = (uint16_t)j;
+    }
+    __syncthreads();
+    for (int size = 2; size <= LB_TILE; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < LB_TILE / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t k0 = key[lo], k1 = key[hi];
+                if ((k0 > k1) == up) {
+                    key[lo] = k1; key[hi] = k0;
+                    const uint16_t p0 = pos[lo]; pos[lo] = pos[hi]; pos[hi] = p0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub_n = 64 / dimP, sub = lane / dimP, c = lane % dimP;
+    const int per = LB_TILE / (4 * sub_n);
+    const int j0 = (wave * sub_n + sub) * per;
+    const bool col = c < a.dim;
+    uint32_t cur = NONE;
+    float acc = 0.f;
+    constexpr int U = 8;
+    for (int j = j0; j < j0 + per; j += U) {
+        uint32_t kk[U];
+        float gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kk[u] = key[j + u];
+            const int64_t i = base + pos[j + u];
+            gg[u] = (kk[u] != NONE && col) ? d_out[i * d_stride + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kk[u] != cur) {
+                if (cur != NONE && col && acc != 0.f) unsafeAtomicAdd(g_table + (int64_t)cur * a.dim + c, acc);
+                cur = kk[u];
+                acc = gg[u];
+            } else {
+                acc += gg[u];
+            }
+        }
+    }
+    if (cur != NONE && col && acc != 0.f) unsafeAtomicAdd(g_table + (int64_t)cur * a.dim + c, acc);
+}
+
 }  // namespace
 
 extern "C" int dctr_din_att_in_fwd(const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* a, void* stream) {
@@ -1199,7 +1420,8 @@ extern "C" int dctr_din_wsum_bwd(const float* d_out, int64_t d_stride, const flo
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(d_out && score && mask && k && d_score && dk, DCTR_E_NULL, "din_wsum_bwd: null pointer");
     int64_t blocks = dctr_ceil_div(batch * maxlen, (int64_t)4);
-    if (blocks > 16384) blocks = 16384;
+    const int64_t cap = d_bias != nullptr ? 256 : 16384;         // each workgroup ends in one atomic on d_bias
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(din_wsum_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_out, d_stride, score, mask, k,
                        batch, (int)maxlen, (int)dim, d_score, dk, d_bias);
     return dctr_launch_status("dctr_din_wsum_bwd");
@@ -1222,6 +1444,15 @@ extern "C" int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float*
     DCTR_REQUIRE(fwd->n >= 0 && fwd->dim >= 1 && d_stride >= fwd->dim && fwd->vocab >= 1, DCTR_E_DIM, "embed_lookup_bwd: bad sizes");
     if (fwd->n == 0) return DCTR_OK;
     DCTR_REQUIRE(fwd->idx && d_out && g_table, DCTR_E_NULL, "embed_lookup_bwd: null pointer");
+    if (fwd->dim <= 64 && fwd->vocab < 0xffffffffLL && fwd->n >= LB_TILE) {
+        int dimP = 1;
+        while (dimP < fwd->dim) dimP <<= 1;
+        const int64_t tiles = dctr_ceil_div(fwd->n, (int64_t)LB_TILE);
+        DCTR_REQUIRE(tiles <= 0x7fffffffLL, DCTR_E_DIM, "embed_lookup_bwd: n too large");
+        hipLaunchKernelGGL(lookup_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, *fwd, d_out, d_stride,
+                           g_table, dimP);
+        return dctr_launch_status("dctr_embed_lookup_bwd");
+    }
     int64_t blocks = dctr_ceil_div(fwd->n * fwd->dim, (int64_t)256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(lookup_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *fwd, d_out, d_stride, g_table);
@@ -1405,14 +1636,23 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
             // training-mode Dice: this batch's statistics, gradients through them
             float* s12 = bufZ + (size_t)a->batch * w;
             if (hipMemsetAsync(s12, 0, (size_t)2 * N * sizeof(float), st) != hipSuccess) return -1;
-            hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)buf, (const float*)bufZ, bl,
-                               a->dice_alpha[l], a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
+            if (rowlane4_ok(N, buf, bufZ, N))
+                hipLaunchKernelGGL(dice_train_bwd_reduce4_kernel, dim3(colsum_grid(a->batch, 256 / (N / 4))), dim3(256), 0, st,
+                                   (const float*)buf, (const float*)bufZ, bl, a->dice_alpha[l], a->dice_batch_mean[l],
+                                   a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
+            else
+                hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)buf, (const float*)bufZ, bl,
+                                   a->dice_alpha[l], a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
             hipLaunchKernelGGL(dice_train_bwd_apply_kernel, dim3(rb), dim3(256), 0, st, buf, (const float*)bufZ, bl, a->dice_alpha[l],
                                a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, (const float*)s12);
             return 0;
         }
-        hipLaunchKernelGGL(dice_bwd_kernel, dim3(rb), dim3(256), 0, st, buf, bufZ, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
-                           a->dice_eps, a->batch, N, dal);
+        if (rowlane4_ok(N, buf, bufZ, N))
+            hipLaunchKernelGGL(dice_bwd4_kernel, dim3(colsum_grid(a->batch, 256 / (N / 4))), dim3(256), 0, st, buf, (const float*)bufZ, bl,
+                               a->dice_alpha[l], a->dice_mean[l], a->dice_var[l], a->dice_eps, a->batch, N, dal);
+        else
+            hipLaunchKernelGGL(dice_bwd_kernel, dim3(rb), dim3(256), 0, st, buf, bufZ, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
+                               a->dice_eps, a->batch, N, dal);
         return 0;
     };
     // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit
@@ -1829,7 +2069,7 @@ __global__ __launch_bounds__(256) void mix_combine_kernel(const float* __restric
 }
 
 // backward gate part, one wave per row.  In: g (gradient w.r.t. x_{l+1}), x_0, uv_e, p.  Out: ds [B, ne];
-// gx = g + sum_e ds_e g_e;  dx0 += sum_e p_e g .* (uv_e + b);  d_bias[i] += sum_b g x_0 (atomics)
+// gx = g + sum_e ds_e g_e;  dx0 += sum_e p_e g .* (uv_e + b)      (d_bias[i] += sum_b g x_0: colsum_prod_kernel)
 __global__ __launch_bounds__(256) void mix_bwd_gate_kernel(const float* __restrict__ g, const float* __restrict__ x0,
                                                           const float* __restrict__ uv, int64_t uv_expert_stride,
                                                           const float* __restrict__ p, const float* __restrict__ gating,
@@ -1861,8 +2101,19 @@ __global__ __launch_bounds__(256) void mix_bwd_gate_kernel(const float* __restri
         }
         gx[b * d + i] = a;
         dx0[b * d + i] = fmaf(gi, u + bias[i], dx0[b * d + i]);
-        unsafeAtomicAdd(d_bias + i, gi * x0[b * d + i]);
     }
+}
+
+// out[n] += sum_b a[b, n] * c[b, n]   (the bias gradient of a CrossNetMix layer: one atomic per row and column from the gate kernel
+// put B atomics on each address — 214 us per layer at B = 4096): rows strided over few workgroups, one atomic per column each
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ a, const float* __restrict__ c, int64_t batch, int d,
+                                                         float* __restrict__ out) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= d) return;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) acc = fmaf(a[b * d + n], c[b * d + n], acc);
+    unsafeAtomicAdd(out + n, acc);
 }
 
 // t[b, i] = p[b, e] g[b, i] x0[b, i]
@@ -1993,6 +2244,8 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void
         const float* uvl = ws + m.UV + (size_t)l * ne * Bd;
         hipLaunchKernelGGL(mix_bwd_gate_kernel, dim3(row_blocks), dim3(256), 0, st, (const float*)g, x0, uvl, Bd, p, a->gating,
                            a->bias + (size_t)l * d, B, d, ne, ws + m.DS, gx, ws + m.DX0, a->dbias + (size_t)l * d);
+        hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)(B < COLSUM_MAX_WG ? B : COLSUM_MAX_WG), (unsigned)((d + 255) / 256)), dim3(256),
+                           0, st, (const float*)g, x0, B, d, a->dbias + (size_t)l * d);
         // d gating[e][i] += sum_b ds[b, e] x_l[b, i]:  column-major dG'(d x ne) += x_l'(d x B) ds'(ne x B)^T
         MIX_GEMM(N_, T_, d, ne, Bi, xl, d, (const float*)(ws + m.DS), ne, &one, a->dgating, d);
         for (int e = 0; e < ne; ++e) {

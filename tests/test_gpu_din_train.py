@@ -61,13 +61,16 @@ def test_attention_input_and_weighted_sum_kernels_match_autograd(device, B, T, E
     assert float((dx[:, :E + 1] - 0.25).abs().max()) == 0.0 and float((dx[:, 2 * E + 1:] - 0.25).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(23, 8, 40, 7), (5000, 32, 300, 50), (97, 20, 64, 33), (100000, 64, 32, 40), (11, 4, 129, 16)])
 @pytest.mark.parametrize("hash_mode,i64", [(0, False), (2, False), (1, True)])
-def test_embed_lookup_bwd_scatters_like_index_add(device, hash_mode, i64):
+def test_embed_lookup_bwd_scatters_like_index_add(device, hash_mode, i64, shape):
+    """Small n: one atomic per position; n >= 1024: tiles sorted by row in LDS, runs of equal rows summed before the atomics
+    (half of the positions padding id 0, as DIN's behaviour sequences are)."""
     from deepctr_amd import ops
     rng = np.random.RandomState(5)
-    V, E, B, T = 23, 8, 40, 7
+    V, E, B, T = shape
     raw = rng.randint(0, 10 ** 6 if hash_mode else V, (B, T))
-    raw[rng.rand(B, T) < 0.2] = 0
+    raw[np.arange(T)[None, :] >= rng.randint(1, T + 1, B)[:, None]] = 0
     idx = dev(raw.astype(np.int64 if i64 else np.int32), device)
     d = dev(rng.standard_normal((B, T, E + 4)).astype(np.float32), device)
     table = torch.zeros(V, E, device=device)
@@ -77,7 +80,8 @@ def test_embed_lookup_bwd_scatters_like_index_add(device, hash_mode, i64):
     g = torch.zeros(V, E, device=device)
     ops.embed_lookup_bwd(idx, (V, E), hash_mode, d[:, :, 2:], g)
     ref = torch.zeros(V, E, device=device).index_add_(0, rows[..., 0].reshape(-1).long(), d[:, :, 2:2 + E].reshape(-1, E))
-    assert_close(g.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5, what="lookup_bwd")
+    assert_close(g.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5 + 1.2e-7 * (B * T / 2), what="lookup_bwd")
+    # (row 0 sums ~B*T/2 standard-normal terms in a different order than index_add_: n terms of size 1 -> ~n * 2^-24 of drift)
     del table
 
 
