@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
@@ -68,7 +68,8 @@ class LookupArgs(ctypes.Structure):
 class CinArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("fields", c_i32), ("dim", c_i32),
                 ("n_layers", c_i32), ("split_half", c_i32), ("activation", c_i32), ("pad_", c_i32), ("layer_size", c_vp),
-                ("filters", c_vp), ("bias", c_vp), ("out", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz)]
+                ("filters", c_vp), ("bias", c_vp), ("out", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz),
+                ("save_y", c_vp)]
 
 
 class MlpArgs(ctypes.Structure):
@@ -114,7 +115,7 @@ class CrossMixBwdArgs(ctypes.Structure):
 class CinBwdArgs(ctypes.Structure):
     _fields_ = [("fwd", ctypes.POINTER(CinArgs)), ("d_out", c_vp), ("out_dim", c_i32), ("dx_accumulate", c_i32),
                 ("d_filters", c_vp), ("d_bias", c_vp), ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp),
-                ("workspace_bytes", c_sz)]
+                ("workspace_bytes", c_sz), ("saved_y", c_vp)]
 
 
 class CrossBwdArgs(ctypes.Structure):

@@ -37,6 +37,7 @@ SOURCES = [
     "chain_kernels_r1w4.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
+    "cin_bwd_kernels.hip",
     "din_kernels.hip",
     "train_kernels.hip",
 ]

@@ -31,6 +31,7 @@ struct CinParams {
     int32_t H[CIN_MAX_LAYERS];
     const float* W[CIN_MAX_LAYERS];
     const float* bias[CIN_MAX_LAYERS];
+    float* save[CIN_MAX_LAYERS];     // per layer NULL or [B*D, H] row-major: the activations, for the backward pass
     float* out;
 };
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ void cin_buf_load(__amdgpu_buffer_rsrc_t rsrc, int vo
 //   * sched_barriers pin "issue loads, then MFMAs" (hipcc otherwise sinks each load next to its use).
 // The earlier form (one filter load, four LDS reads, eight MFMAs, wait) ran at 48 % of the nominal f32-MFMA rate; this
 // one at 68 % (C3: 364 us per 4096 samples; a pure-MFMA loop sustains 139 of the nominal 157 TFLOP/s on this part).
-template <int TPW, int RT>
+template <int TPW, int RT, bool SAVE>
 __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float* x0s, const float* xk, int xk_stride,
                                           int Fk, float* ycur, int Hn, int d0, int64_t bbase, int out_off) {
     using dctr::f32x4;
@@ -173,6 +174,15 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
         // (interaction.py:322-323): with reg_reduce that sum is taken here — 4 rows in the lane, lanes 16 / 32 apart
         // (the other k-slots' rows of the same sample), then the D/16 row tiles of a sample — and written straight
         // to `out`; otherwise (D % 4 != 0) every map is stored and cin_kernel sums from LDS.
+        // (SAVE) descriptor over the whole [B*D, H] buffer of this layer, this lane's byte offset of (row 4g of the workgroup, column n_base + TPW*jl)
+        __amdgpu_buffer_rsrc_t save_rsrc = rsrc;
+        int save_voff = 0;
+        if constexpr (SAVE) {
+            if (p.save[k] != nullptr) {
+                save_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save[k], 0, (int)(p.batch * D * H * 4), 0x00020000);
+                save_voff = (int)(((bbase * D + 4 * g) * H + n_base + TPW * jl) * 4);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
             const int n = n_base + TPW * jl + c;
@@ -191,6 +201,19 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
                     if (store && m < M) {
                         const int s = m / D, d = m - s * D;
                         ycur[(s * p.Hmax + n) * D + d] = v[r];
+                    }
+                }
+                if constexpr (SAVE) {
+                    // training: y_k[(b, d), n] (all H maps, row-major) for dctr_cin_bwd.  Buffer stores: lane-constant byte
+                    // offset + a scalar row offset (per-row 64-bit addresses cost 64 VGPRs and spilled), rows past the batch
+                    // fall outside the descriptor and are dropped by the hardware.
+                    if (p.save[k] != nullptr) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = rt * 16 + 4 * g + r;
+                            const int vo = (nok && m < M) ? save_voff + c * 4 : 0x7ffffff0;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), save_rsrc, vo, (rt * 16 + r) * H * 4, 0);
+                        }
                     }
                 }
                 float t = (v[0] + v[1]) + (v[2] + v[3]);
@@ -219,7 +242,10 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
     }
 }
 
-template <int RT>
+// SAVE: the training-mode instantiation that also writes every layer's activations (p.save) — a separate one because keeping the
+// activated accumulators alive for those stores costs the inference kernel registers (580 B of scratch per lane when it was a
+// run-time branch of the one kernel).
+template <int RT, bool SAVE>
 __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = p.D, F0 = p.F0, SB = p.SB;
@@ -266,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
             Hn = last ? 0 : H;
             d0 = 0;
         }
-        if (H % 32 == 0) cin_layer<2, RT>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
-        else cin_layer<1, RT>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
+        if (H % 32 == 0) cin_layer<2, RT, SAVE>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
+        else cin_layer<1, RT, SAVE>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
         __syncthreads();
         const int nd = H - d0;
         if (!p.reg_reduce) {
@@ -341,6 +367,11 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
         p.H[k] = H;
         p.W[k] = a->filters[k];
         p.bias[k] = a->bias[k];
+        p.save[k] = a->save_y != nullptr ? a->save_y[k] : nullptr;
+        DCTR_REQUIRE(p.save[k] == nullptr || a->batch * (int64_t)a->dim * H * 4 < 0x7fffffffLL, DCTR_E_DIM,
+                     "cin_fwd: save_y[%d] of %lld x %d floats exceeds the 2 GiB a buffer descriptor addresses", k,
+                     (long long)(a->batch * a->dim), H);
+        DCTR_REQUIRE((((uintptr_t)p.save[k]) & 7u) == 0, DCTR_E_ALIGN, "cin_fwd: save_y[%d] not 8-B aligned", k);
         // maps kept in LDS: all of them without reg_reduce, else only those the next layer reads
         const int keep = !p.reg_reduce ? H : (last ? 1 : (a->split_half ? H / 2 : H));
         hmax = keep > hmax ? keep : hmax;
@@ -366,14 +397,18 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     DCTR_REQUIRE(p.RT <= rt, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d needs %d row tiles", a->dim, p.RT);
     const size_t lds = lds_of(p.SB);
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "cin_fwd: needs %zu B of LDS (> 160 KiB)", lds);
-    const void* fn = rt == 8 ? (const void*)cin_kernel<8> : (const void*)cin_kernel<4>;
+    const bool save = a->save_y != nullptr;
+    const void* fn = rt == 8 ? (save ? (const void*)cin_kernel<8, true> : (const void*)cin_kernel<8, false>)
+                             : (save ? (const void*)cin_kernel<4, true> : (const void*)cin_kernel<4, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DCTR_REQUIRE(e == hipSuccess, (int)e, "cin_fwd: cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
     }
     const int64_t blocks = dctr_ceil_div(a->batch, p.SB);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "cin_fwd: batch too large");
-    if (rt == 8) DCTR_LAUNCH(cin_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    else DCTR_LAUNCH(cin_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    if (rt == 8 && save) DCTR_LAUNCH((cin_kernel<8, true>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else if (rt == 8) DCTR_LAUNCH((cin_kernel<8, false>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else if (save) DCTR_LAUNCH((cin_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else DCTR_LAUNCH((cin_kernel<4, false>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     return dctr_launch_status("dctr_cin_fwd");
 }

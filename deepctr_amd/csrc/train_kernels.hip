@@ -645,6 +645,21 @@ __global__ __launch_bounds__(256) void cin_outer_kernel(const float* __restrict_
     }
 }
 
+// the same with 16-B stores: thread = four consecutive j of one (row, i)   (Fk % 4 == 0, ldk % 4 == 0, 16-B aligned xk / z)
+__global__ __launch_bounds__(256) void cin_outer4_kernel(const float* __restrict__ x0t, int F0, const float* __restrict__ xk,
+                                                         int64_t ldk, int Fk, int64_t rows, float* __restrict__ z) {
+    const int Fk4 = Fk >> 2, K4 = F0 * Fk4;
+    const int64_t total = rows * K4;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t r = o / K4;
+        const int c = (int)(o - r * K4);
+        const int i = c / Fk4, j4 = c - i * Fk4;
+        const float a = x0t[r * F0 + i];
+        const float4 b = *reinterpret_cast<const float4*>(xk + r * ldk + 4 * j4);
+        *reinterpret_cast<float4*>(z + r * (int64_t)(F0 * Fk) + i * Fk + 4 * j4) = make_float4(a * b.x, a * b.y, a * b.z, a * b.w);
+    }
+}
+
 // Y = act(Y + bias) in place
 __global__ __launch_bounds__(256) void cin_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t rows,
                                                            int H, int act) {
@@ -1849,6 +1864,12 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     return dctr_launch_status("dctr_crossnet_bwd");
 }
 
+namespace dctr_cinbwd {      // cin_bwd_kernels.hip: the z-free dz / outer-product backward of one CIN layer
+bool dz_fused_ok(int F0, int Fk, int H, const float* dpre, const float* W);
+int launch_dz_fused(const float* dpre, const float* W, const float* x0t, const float* xk, int64_t ldk, int F0, int Fk, int H,
+                    int64_t rows, float* dx0t, float* dxk, hipStream_t st);
+}  // namespace dctr_cinbwd
+
 namespace {
 struct CinPlan {
     int L, F0, D;
@@ -1923,14 +1944,20 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
     const float one = 1.f, zero = 0.f;
     float* x0t = ws + p.x0t;
     hipLaunchKernelGGL(cin_to_rows_kernel, grid(p.R * F0), dim3(256), 0, st, f->x, f->x_stride, f->batch, F0, D, x0t);
-    // forward recompute
+    // forward: z per layer (the dW GEMM's operand); the activations y_k come from the forward call (saved_y) or are recomputed
+    const float* yk[8];
+    for (int k = 0; k < p.L; ++k) yk[k] = (a->saved_y != nullptr && a->saved_y[k] != nullptr) ? a->saved_y[k] : ws + p.y[k];
     for (int k = 0; k < p.L; ++k) {
         const int Fk = p.Fk[k], H = p.H[k], K = F0 * Fk;
-        const float* xk = k == 0 ? x0t : ws + p.y[k - 1];
+        const float* xk = k == 0 ? x0t : yk[k - 1];
         const int64_t ldk = k == 0 ? F0 : p.H[k - 1];
         float* z = ws + p.z[k];
         float* y = ws + p.y[k];
-        hipLaunchKernelGGL(cin_outer_kernel, grid(p.R * K), dim3(256), 0, st, x0t, F0, xk, ldk, Fk, p.R, z);
+        if (Fk % 4 == 0 && ldk % 4 == 0 && dctr_aligned16(xk) && dctr_aligned16(z))
+            hipLaunchKernelGGL(cin_outer4_kernel, grid(p.R * (K / 4)), dim3(256), 0, st, x0t, F0, xk, ldk, Fk, p.R, z);
+        else
+            hipLaunchKernelGGL(cin_outer_kernel, grid(p.R * K), dim3(256), 0, st, x0t, F0, xk, ldk, Fk, p.R, z);
+        if (yk[k] != y) continue;
         // Y[R,H] = z[R,K] W[K,H]:  column-major  Y'(H x R) = W'(H x K) z'(K x R)
         rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, H, R, K, &one, f->filters[k], H, z, K,
                                           &zero, y, H);
@@ -1943,11 +1970,11 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
     int64_t ldn = 0;
     for (int k = p.L - 1; k >= 0; --k) {
         const int Fk = p.Fk[k], H = p.H[k], K = F0 * Fk;
-        const float* xk = k == 0 ? x0t : ws + p.y[k - 1];
+        const float* xk = k == 0 ? x0t : yk[k - 1];
         const int64_t ldk = k == 0 ? F0 : p.H[k - 1];
         float* dpre = ws + p.dpre;
         float* dz = ws + p.dz;
-        hipLaunchKernelGGL(cin_dpre_kernel, grid(p.R * H), dim3(256), 0, st, ws + p.y[k], dxnext, ldn, p.Hn[k], a->d_out,
+        hipLaunchKernelGGL(cin_dpre_kernel, grid(p.R * H), dim3(256), 0, st, yk[k], dxnext, ldn, p.Hn[k], a->d_out,
                            (int64_t)a->out_dim, p.off[k], p.d0[k], p.R, H, D, (int)f->activation, dpre);
         launch_act_bwd_colsum(st, dpre, (const float*)nullptr, p.R, H, 0, a->d_bias[k]);
         // dW[K,H] += z^T dpre:  column-major  dW'(H x K) = dpre'(H x R) z'(K x R)^T.  The output is small (H x K) and the
@@ -1970,11 +1997,15 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
                                a->d_filters[k], H);
             DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
         }
-        // dz[R,K] = dpre[R,H] W^T:  column-major  dz'(K x R) = W'(H x K)^T dpre'(H x R)
-        rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, R, H, &one, f->filters[k], H, dpre, H, &zero, dz, K);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dz) failed (%d)", (int)rs);
         float* dxk = ws + p.dxk[k & 1];          // layer 0: x_0 is also its x_k; that second-factor gradient lands in dxk[0]
-        {
+        if (dctr_cinbwd::dz_fused_ok(F0, Fk, H, dpre, f->filters[k])) {
+            // dz = dpre W^T is formed tile by tile on the matrix cores and contracted with x_0 / x_k at once (never stored)
+            const int rc = dctr_cinbwd::launch_dz_fused(dpre, f->filters[k], x0t, xk, ldk, F0, Fk, H, p.R, ws + p.dx0t, dxk, st);
+            DCTR_REQUIRE(rc == 0, rc, "cin_bwd: cannot launch the fused dz kernel (%d)", rc);
+        } else {
+            // dz[R,K] = dpre[R,H] W^T:  column-major  dz'(K x R) = W'(H x K)^T dpre'(H x R)
+            rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, R, H, &one, f->filters[k], H, dpre, H, &zero, dz, K);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dz) failed (%d)", (int)rs);
             const size_t lds = (size_t)4 * (K + F0 + Fk) * sizeof(float);
             DCTR_REQUIRE(lds <= 64 * 1024, DCTR_E_UNSUPPORTED, "cin_bwd: F0*Fk = %d too large for the row-staging kernel", K);
             int64_t nb = dctr_ceil_div(p.R, (int64_t)4);

@@ -333,9 +333,10 @@ def cin_output_dim(layer_size, split_half):
     return sum(layer_size)
 
 
-def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None):
+def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None, save_y=None):
     """CIN.call (reference interaction.py:277-325): x [B,F0,D] (or, with ``fields``/``dim`` given, the leading
-    F0*D columns of a [B, stride] concat buffer read in place); filters[k] [F0*Fk, Hk]; -> [B, featuremap_num]."""
+    F0*D columns of a [B, stride] concat buffer read in place); filters[k] [F0*Fk, Hk]; -> [B, featuremap_num].
+    ``save_y``: per layer a [B*D, H_k] float32 tensor that receives the layer's activations (training: ``cin_bwd(saved_y=)``)."""
     _dev_check(x, *filters, *biases)
     if fields is None:
         if x.dim() != 3:
@@ -358,8 +359,20 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
                    activation=_C.ACT_CODES[activation], layer_size=ctypes.cast(ls, ctypes.c_void_p),
                    filters=ctypes.cast(fp, ctypes.c_void_p), bias=ctypes.cast(bp, ctypes.c_void_p), out=out.data_ptr(),
                    workspace=None, workspace_bytes=0)
+    if save_y is not None:
+        _check_saved_y(save_y, B * D, layer_size, x)
+        sp = _ptr_array(list(save_y))
+        a.save_y = ctypes.cast(sp, ctypes.c_void_p)
     _C.check(_C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_fwd")
     return out
+
+
+def _check_saved_y(ys, rows, layer_size, x):
+    if len(ys) != len(layer_size):
+        raise ValueError("save_y / saved_y: one tensor per CIN layer")
+    for t, h in zip(ys, layer_size):
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (rows, h) or t.device != x.device:
+            raise ValueError("save_y / saved_y: expected a contiguous float32 [%d, %d] tensor on %s" % (rows, h, x.device))
 
 
 def afm(x, attention_W, attention_b, projection_h, projection_p, fields=None, dim=None, out=None):
@@ -816,7 +829,7 @@ def crossnet_bwd(x, d, kernels, bias, parameterization, dy, d_kernels, d_bias, d
 
 
 def cin_bwd(x, filters, biases, layer_size, split_half, activation, d_out, d_filters, d_biases, dx=None, accumulate=False,
-            fields=None, dim=None):
+            fields=None, dim=None, saved_y=None):
     """Backward of dctr_cin_fwd: x as in ``cin`` (3-D, or the leading F0*D columns of a 2-D buffer with fields/dim);
     d_out [B, featuremap_num]; d_filters / d_biases are ACCUMULATED; dx (2-D, same layout as x) written or added to."""
     _dev_check(x, d_out, *filters)
@@ -840,6 +853,10 @@ def cin_bwd(x, filters, biases, layer_size, split_half, activation, d_out, d_fil
     a = _C.CinBwdArgs(fwd=ctypes.pointer(fwd), d_out=d_out.data_ptr(), out_dim=d_out.shape[1], dx_accumulate=int(bool(accumulate)),
                       d_filters=ctypes.cast(dfp, ctypes.c_void_p), d_bias=ctypes.cast(dbp, ctypes.c_void_p),
                       dx=None if dx is None else dx.data_ptr(), dx_stride=0 if dx is None else dx.stride(0))
+    if saved_y is not None:                 # the forward call's cin(save_y=...) tensors: no recompute GEMMs
+        _check_saved_y(saved_y, B * D, layer_size, x)
+        syp = _ptr_array(list(saved_y))
+        a.saved_y = ctypes.cast(syp, ctypes.c_void_p)
     need = int(_C.lib().dctr_cin_bwd_workspace_bytes(ctypes.byref(a)))
     ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), need

@@ -212,6 +212,9 @@ class HipTrainer(object):
                 "maps": torch.empty(B, self.model.cin_out_dim, dtype=torch.float32, device=dev) if self.p_cin_f else None,
                 "dmaps": torch.empty(B, self.model.cin_out_dim, dtype=torch.float32, device=dev) if self.p_cin_f else None,
                 "cin_logit": torch.empty(B, dtype=torch.float32, device=dev) if self.p_cin_f else None,
+                # layer activations written by the forward CIN kernel for dctr_cin_bwd (else one recompute GEMM per layer)
+                "cin_y": [torch.empty(B * self.model.cin_dim, h, dtype=torch.float32, device=dev)
+                          for h in self.model.cin.layer_size] if self.p_cin_f else None,
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
                 "pred": torch.empty(B, dtype=torch.float32, device=dev),
                 "dlogit": torch.empty(B, dtype=torch.float32, device=dev),
@@ -264,7 +267,7 @@ class HipTrainer(object):
             nf, dim = len(sp.fields), model.cin_dim
             filt = [f.reshape(-1, f.shape[-1]) for f in cin.filters]
             ops.cin(ws["dnn_in"], filt, cin.biases, list(cin.layer_size), cin.split_half, cin.activation, fields=nf, dim=dim,
-                    out=buf["maps"])
+                    out=buf["maps"], save_y=buf["cin_y"])
             ops.mlp(buf["maps"], [], [], "linear", head_w=self.p_head1.w, in_dim=model.cin_out_dim, out=buf["cin_logit"])
             add.append(buf["cin_logit"])
         ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w, add=add,
@@ -277,7 +280,7 @@ class HipTrainer(object):
             ops.dense1_bwd(buf["maps"], model.cin_out_dim, self.p_head1.w, buf["dlogit"], buf["dmaps"], self.p_head1.g)
             ops.cin_bwd(ws["dnn_in"], filt, cin.biases, list(cin.layer_size), cin.split_half, cin.activation, buf["dmaps"],
                         [p.g.reshape(-1, p.g.shape[-1]) for p in self.p_cin_f], [p.g for p in self.p_cin_b], dx=buf["dx"],
-                        accumulate=True, fields=nf, dim=dim)
+                        accumulate=True, fields=nf, dim=dim, saved_y=buf["cin_y"])
 
     def _afm_forward_backward(self, ws, buf, y, B, binary):
         """AFM (models/afm.py:45-58): linear logit + one AFMLayer per group (with attention), or the gather's FM term."""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 3
+#define DCTR_ABI_VERSION 4
 
 enum {
     DCTR_OK = 0,
@@ -252,6 +252,9 @@ typedef struct {
     float* out;                   /* [B, featuremap_num] */
     void* workspace;              /* device scratch, dctr_cin_workspace_bytes() bytes, 16-B aligned */
     size_t workspace_bytes;
+    float* const* save_y;         /* NULL, or HOST array of n_layers DEVICE pointers (entries may be NULL): layer k's
+                                   * activations y_k [B*D, H_k] row-major (row b*D + d, ALL H_k maps) are also written there
+                                   * — what dctr_cin_bwd otherwise recomputes with one GEMM per layer (ABI 4) */
 } dctr_cin_args_t;
 size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* args);
 int dctr_cin_fwd(const dctr_cin_args_t* args, void* stream);
@@ -616,6 +619,8 @@ typedef struct {
     int64_t dx_stride;
     void* workspace;              /* dctr_cin_bwd_workspace_bytes() bytes, 16-B aligned                   */
     size_t workspace_bytes;
+    const float* const* saved_y;  /* NULL (the layer activations are recomputed), or HOST array of n_layers DEVICE
+                                   * pointers to what the forward call wrote through fwd->save_y (ABI 4)   */
 } dctr_cin_bwd_args_t;
 size_t dctr_cin_bwd_workspace_bytes(const dctr_cin_bwd_args_t* args);
 int dctr_cin_bwd(const dctr_cin_bwd_args_t* args, void* stream);

@@ -531,8 +531,12 @@ def test_dcnmix_hip_training_gradients_match_torch_autograd(device, cross_num, h
 
 
 @pytest.mark.parametrize("B,F0,D,ls,split,act", [(37, 7, 8, (12, 10), True, "relu"), (9, 5, 4, (8, 6, 5), False, "linear"),
-                                                 (64, 26, 16, (32, 16), True, "relu"), (20, 6, 6, (8,), True, "sigmoid")])
-def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act):
+                                                 (64, 26, 16, (32, 16), True, "relu"), (20, 6, 6, (8,), True, "sigmoid"),
+                                                 (33, 26, 16, (128, 128), True, "relu"), (10, 5, 4, (48, 16), False, "linear")])
+@pytest.mark.parametrize("saved", [False, True])
+def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act, saved):
+    """saved=True: the forward kernel writes the layer activations (cin(save_y=)) and the backward takes them instead of
+    recomputing them with one GEMM per layer."""
     from deepctr_amd import ops
     rng = np.random.RandomState(41)
     x = (rng.standard_normal((B, F0 * D + 5)) * 0.5).astype(np.float32)           # CIN reads the leading F0*D columns
@@ -548,11 +552,13 @@ def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act):
     ft = [torch.tensor(f.astype(np.float64), requires_grad=True) for f in fs]
     bt = [torch.tensor(b.astype(np.float64), requires_grad=True) for b in bs]
     x0 = xt.reshape(B, F0, D)
-    hidden, finals = x0, []
+    hidden, finals, ys = x0, [], []
     f_act = {"relu": torch.relu, "linear": lambda z: z, "sigmoid": torch.sigmoid}[act]
     for k, h in enumerate(ls):
         z = torch.einsum("bid,bjd->bdij", x0, hidden).reshape(B, D, -1)
-        y = f_act(z @ ft[k] + bt[k]).transpose(1, 2)                               # [B, H, D]
+        y = f_act(z @ ft[k] + bt[k])                                               # [B, D, H]
+        ys.append(y.detach().reshape(B * D, h).numpy())
+        y = y.transpose(1, 2)                                                      # [B, H, D]
         if split and k != len(ls) - 1:
             hidden, direct = y[:, :h // 2], y[:, h // 2:]
         else:
@@ -564,9 +570,16 @@ def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act):
     dfs = [torch.zeros(f.shape, device=device) for f in fs]
     dbs = [torch.zeros(b.shape, device=device) for b in bs]
     dx = torch.full((B, F0 * D + 2), 2.0, device=device)
-    ops.cin_bwd(xd, [dev(f, device) for f in fs], [dev(b, device) for b in bs], list(ls), split, act, dev(d_out, device), dfs, dbs,
-                dx=dx, accumulate=True, fields=F0, dim=D)
     tag = "B=%d F0=%d D=%d %s split=%s %s" % (B, F0, D, ls, split, act)
+    sy = None
+    if saved:
+        sy = [torch.full((B * D, h), float("nan"), device=device) for h in ls]
+        out = ops.cin(xd, [dev(f, device) for f in fs], [dev(b, device) for b in bs], list(ls), split, act, fields=F0, dim=D, save_y=sy)
+        assert_close(out.cpu().numpy(), res.detach().numpy(), rtol=2e-4, atol=2e-5, what="cin forward " + tag)
+        for k in range(len(ls)):
+            assert_close(sy[k].cpu().numpy(), ys[k], rtol=2e-4, atol=2e-5, what="saved y%d %s" % (k, tag))
+    ops.cin_bwd(xd, [dev(f, device) for f in fs], [dev(b, device) for b in bs], list(ls), split, act, dev(d_out, device), dfs, dbs,
+                dx=dx, accumulate=True, fields=F0, dim=D, saved_y=sy)
     assert_close((dx[:, :F0 * D] - 2.0).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5, what="dx " + tag)
     assert float((dx[:, F0 * D:] - 2.0).abs().max()) == 0.0
     for k in range(len(ls)):
