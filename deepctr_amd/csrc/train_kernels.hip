@@ -1864,8 +1864,11 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     return dctr_launch_status("dctr_crossnet_bwd");
 }
 
-namespace dctr_cinbwd {      // cin_bwd_kernels.hip: the z-free dz / outer-product backward of one CIN layer
-bool dz_fused_ok(int F0, int Fk, int H, const float* dpre, const float* W);
+namespace dctr_cinbwd {      // cin_bwd_kernels.hip: the z-free backward of one CIN layer (filter gradient; input gradients)
+bool fused_shape_ok(int F0, int Fk, int H);
+int64_t dw_parts_floats(int F0, int Fk, int H, int64_t rows);
+int launch_dw_fused(const float* dpre, const float* x0t, const float* xk, int64_t ldk, int F0, int Fk, int H, int64_t rows,
+                    float* parts, int* n_parts, hipStream_t st);
 int launch_dz_fused(const float* dpre, const float* W, const float* x0t, const float* xk, int64_t ldk, int F0, int Fk, int H,
                     int64_t rows, float* dx0t, float* dxk, hipStream_t st);
 }  // namespace dctr_cinbwd
@@ -1874,8 +1877,10 @@ namespace {
 struct CinPlan {
     int L, F0, D;
     int H[8], Fk[8], Hn[8], d0[8], off[8];
+    bool fused[8];         // layer runs on the z-free kernels of cin_bwd_kernels.hip: no z / dz for it
     int64_t R;
-    size_t x0t, y[8], z[8], dpre, dz, dx0t, dxk[2], total;
+    size_t x0t, y[8], z[8], dpre, dz, dx0t, dxk[2], fwd_out, parts, total;
+    int out_dim;
 };
 bool cin_plan(const dctr_cin_args_t* f, CinPlan& p) {
     p.L = f->n_layers;
@@ -1887,7 +1892,7 @@ bool cin_plan(const dctr_cin_args_t* f, CinPlan& p) {
     size_t cur = 0;
     auto take = [&](size_t n) { size_t o = cur; cur += (n + 3) & ~(size_t)3; return o; };
     p.x0t = take((size_t)p.R * p.F0);
-    size_t zmax = 0, hmax = 0, fkmax = 0;
+    size_t zmax = 0, hmax = 0, fkmax = 0, pmax = 0;
     for (int k = 0; k < p.L; ++k) {
         const int H = f->layer_size[k];
         const bool last = k == p.L - 1;
@@ -1898,14 +1903,22 @@ bool cin_plan(const dctr_cin_args_t* f, CinPlan& p) {
         p.off[k] = off;
         off += H - p.d0[k];
         p.y[k] = take((size_t)p.R * H);
-        p.z[k] = take((size_t)p.R * p.F0 * fk);
-        zmax = (size_t)p.R * p.F0 * fk > zmax ? (size_t)p.R * p.F0 * fk : zmax;
+        p.fused[k] = dctr_cinbwd::fused_shape_ok(p.F0, fk, H);
+        p.z[k] = take(p.fused[k] ? 0 : (size_t)p.R * p.F0 * fk);
+        if (!p.fused[k]) zmax = (size_t)p.R * p.F0 * fk > zmax ? (size_t)p.R * p.F0 * fk : zmax;
+        else {
+            const size_t pf = (size_t)dctr_cinbwd::dw_parts_floats(p.F0, fk, H, p.R);
+            pmax = pf > pmax ? pf : pmax;
+        }
         hmax = (size_t)H > hmax ? H : hmax;
         fkmax = (size_t)fk > fkmax ? fk : fkmax;
         fk = p.Hn[k];
     }
+    p.out_dim = off;
+    p.fwd_out = take((size_t)f->batch * off);          // the forward kernel's [B, featuremap_num] output when it is re-run for y_k
     p.dpre = take((size_t)p.R * hmax);
     p.dz = take(zmax);
+    p.parts = take(pmax);                              // the z-free dW kernel's per-row-slice partial products
     p.dx0t = take((size_t)p.R * p.F0);
     p.dxk[0] = take((size_t)p.R * fkmax);
     p.dxk[1] = take((size_t)p.R * fkmax);
@@ -1944,25 +1957,34 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
     const float one = 1.f, zero = 0.f;
     float* x0t = ws + p.x0t;
     hipLaunchKernelGGL(cin_to_rows_kernel, grid(p.R * F0), dim3(256), 0, st, f->x, f->x_stride, f->batch, F0, D, x0t);
-    // forward: z per layer (the dW GEMM's operand); the activations y_k come from the forward call (saved_y) or are recomputed
+    // the activations y_k: written by the forward call (saved_y), else the forward kernel is re-run here with the workspace as its
+    // save_y (one launch; the first version recomputed them as z W with a GEMM per layer)
     const float* yk[8];
-    for (int k = 0; k < p.L; ++k) yk[k] = (a->saved_y != nullptr && a->saved_y[k] != nullptr) ? a->saved_y[k] : ws + p.y[k];
+    bool rerun = false;
     for (int k = 0; k < p.L; ++k) {
-        const int Fk = p.Fk[k], H = p.H[k], K = F0 * Fk;
+        yk[k] = (a->saved_y != nullptr && a->saved_y[k] != nullptr) ? a->saved_y[k] : ws + p.y[k];
+        rerun = rerun || yk[k] == ws + p.y[k];
+    }
+    if (rerun) {
+        dctr_cin_args_t fa = *f;
+        float* sv[8];
+        for (int k = 0; k < p.L; ++k) sv[k] = yk[k] == ws + p.y[k] ? ws + p.y[k] : nullptr;
+        fa.save_y = sv;
+        fa.out = ws + p.fwd_out;
+        const int rc = dctr_cin_fwd(&fa, stream);
+        if (rc != 0) return rc;
+    }
+    // z only for layers outside the z-free kernels' shapes (the dW GEMM's operand)
+    for (int k = 0; k < p.L; ++k) {
+        if (p.fused[k]) continue;
+        const int Fk = p.Fk[k], K = F0 * Fk;
         const float* xk = k == 0 ? x0t : yk[k - 1];
         const int64_t ldk = k == 0 ? F0 : p.H[k - 1];
         float* z = ws + p.z[k];
-        float* y = ws + p.y[k];
         if (Fk % 4 == 0 && ldk % 4 == 0 && dctr_aligned16(xk) && dctr_aligned16(z))
             hipLaunchKernelGGL(cin_outer4_kernel, grid(p.R * (K / 4)), dim3(256), 0, st, x0t, F0, xk, ldk, Fk, p.R, z);
         else
             hipLaunchKernelGGL(cin_outer_kernel, grid(p.R * K), dim3(256), 0, st, x0t, F0, xk, ldk, Fk, p.R, z);
-        if (yk[k] != y) continue;
-        // Y[R,H] = z[R,K] W[K,H]:  column-major  Y'(H x R) = W'(H x K) z'(K x R)
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, H, R, K, &one, f->filters[k], H, z, K,
-                                          &zero, y, H);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(y) failed (%d)", (int)rs);
-        hipLaunchKernelGGL(cin_bias_act_kernel, grid(p.R * H), dim3(256), 0, st, y, f->bias[k], p.R, H, (int)f->activation);
     }
     hipError_t me = hipMemsetAsync(ws + p.dx0t, 0, (size_t)p.R * F0 * sizeof(float), st);
     DCTR_REQUIRE(me == hipSuccess, (int)me, "cin_bwd: memset failed: %s", hipGetErrorString(me));
@@ -1984,8 +2006,16 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
         int parts = (int)((size_t)p.R * K / (size_t)hk);                 // partials fit the dz buffer: parts*H*K <= R*K
         if (parts > 32) parts = 32;
         while (parts > 1 && R % parts != 0) --parts;
-        rocblas_status rs;
-        if (parts > 1) {
+        rocblas_status rs = rocblas_status_success;
+        if (p.fused[k]) {
+            // z-free: x0[r,i] xk[r,j] formed in registers as the MFMA A operand, rows = the K dimension (cin_bwd_kernels.hip)
+            DCTR_REQUIRE(dctr_aligned16(dpre) && dctr_aligned16(f->filters[k]), DCTR_E_ALIGN,
+                         "cin_bwd: workspace / filters[%d] must be 16-B aligned", k);
+            int n_parts = 0;
+            const int rc = dctr_cinbwd::launch_dw_fused(dpre, x0t, xk, ldk, F0, Fk, H, p.R, ws + p.parts, &n_parts, st);
+            DCTR_REQUIRE(rc == 0, rc, "cin_bwd: cannot launch the fused dW kernel (%d)", rc);
+            hipLaunchKernelGGL(sum_parts_kernel, grid(hk), dim3(256), 0, st, (const float*)(ws + p.parts), hk, n_parts, a->d_filters[k]);
+        } else if (parts > 1) {
             const int rs_ = R / parts;
             rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, H, K, rs_, &one, dpre, H,
                                                (rocblas_stride)rs_ * H, ws + p.z[k], K, (rocblas_stride)rs_ * K, &zero, dz, H,
@@ -1998,7 +2028,7 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
             DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
         }
         float* dxk = ws + p.dxk[k & 1];          // layer 0: x_0 is also its x_k; that second-factor gradient lands in dxk[0]
-        if (dctr_cinbwd::dz_fused_ok(F0, Fk, H, dpre, f->filters[k])) {
+        if (p.fused[k]) {
             // dz = dpre W^T is formed tile by tile on the matrix cores and contracted with x_0 / x_k at once (never stored)
             const int rc = dctr_cinbwd::launch_dz_fused(dpre, f->filters[k], x0t, xk, ldk, F0, Fk, H, p.R, ws + p.dx0t, dxk, st);
             DCTR_REQUIRE(rc == 0, rc, "cin_bwd: cannot launch the fused dz kernel (%d)", rc);
