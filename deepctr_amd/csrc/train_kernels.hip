@@ -64,6 +64,26 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
                                                             const int32_t* __restrict__ dense_lin_rows) {
     constexpr int VEC = 4, SPW = 64 / LPR, NWV = 4;
     __shared__ float s_part[NWV][64][VEC];
+    // low-cardinality fields (DIN's `gender`: 2 rows for 2,048 samples = 1,024 atomics per address, ~90 ns each): their gradient
+    // rows (and linear rows) accumulate in LDS and leave as one atomic per element and workgroup
+    constexpr int SMALL_FLOATS = 2048, SMALL_FIELDS = 128, SMALL_VOCAB = 64;
+    __shared__ float s_small[SMALL_FLOATS];
+    __shared__ int s_soff[SMALL_FIELDS];
+    __shared__ int s_total;
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int j = 0; j < p.n_fields && j < SMALL_FIELDS; ++j) {
+            const int64_t vocab = ((cfield_ptr)p.fields)[j].vocab;
+            const int64_t need = vocab * (((cfield_ptr)p.fields)[j].dim + 1);
+            const bool small = gr[j].g_table != nullptr && vocab <= SMALL_VOCAB && off + need <= SMALL_FLOATS;
+            s_soff[j] = small ? off : -1;
+            if (small) off += (int)need;
+        }
+        s_total = off;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < s_total; i += 256) s_small[i] = 0.f;
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane / LPR, q = lane % LPR;
     const int64_t b = (int64_t)blockIdx.x * SPW + s;
@@ -105,6 +125,7 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
         const bool ok = rok && q * VEC < f.dim;
         float* gt = gr[j].g_table;
         float* gl = gr[j].g_lin_table;
+        const int so = j < SMALL_FIELDS ? s_soff[j] : -1;
         if (ok && gt != nullptr) {
             float g[VEC] = {0.f, 0.f, 0.f, 0.f};
             if (f.out_offset >= 0 && d_in != nullptr) {
@@ -117,11 +138,19 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) g[c] = fmaf(dfm, S[c] - v[c], g[c]);
             }
-            float* dst = gt + r * f.dim + q * VEC;
+            if (so >= 0) {
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) unsafeAtomicAdd(dst + c, g[c]);
+                for (int c = 0; c < VEC; ++c) atomicAdd(&s_small[so + (int)r * f.dim + q * VEC + c], g[c]);
+            } else {
+                float* dst = gt + r * f.dim + q * VEC;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) unsafeAtomicAdd(dst + c, g[c]);
+            }
         }
-        if (rok && q == 0 && gl != nullptr && f.lin_table != nullptr) unsafeAtomicAdd(gl + r, dlin);
+        if (rok && q == 0 && gl != nullptr && f.lin_table != nullptr) {
+            if (so >= 0) atomicAdd(&s_small[so + (int)f.vocab * f.dim + (int)r], dlin);
+            else unsafeAtomicAdd(gl + r, dlin);
+        }
     }
     // dense . Linear.kernel: d w[k] += sum_b d_lin[b] * dense[b, k]  — dense column k by wave k % 4, the wave's samples summed
     // before the one atomic (4096 atomics on one address serialise)
@@ -133,6 +162,26 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
             if (lane == 0) unsafeAtomicAdd(g_dense_lin_w + row, t);
+        }
+    }
+    // the low-cardinality fields' LDS accumulators
+    if (s_total > 0) {
+        __syncthreads();
+        for (int j = 0; j < p.n_fields && j < SMALL_FIELDS; ++j) {
+            const int so = s_soff[j];
+            if (so < 0) continue;
+            const FieldRegs f = load_field(F, j);
+            const int nt = (int)f.vocab * f.dim;
+            for (int i = threadIdx.x; i < nt; i += 256) {
+                const float v = s_small[so + i];
+                if (v != 0.f) unsafeAtomicAdd(gr[j].g_table + i, v);
+            }
+            if (gr[j].g_lin_table != nullptr && f.lin_table != nullptr) {
+                for (int i = threadIdx.x; i < (int)f.vocab; i += 256) {
+                    const float v = s_small[so + nt + i];
+                    if (v != 0.f) unsafeAtomicAdd(gr[j].g_lin_table + i, v);
+                }
+            }
         }
     }
 }
@@ -1299,6 +1348,21 @@ __global__ __launch_bounds__(256) void din_wsum_bwd_kernel(const float* __restri
     }
 }
 
+// out[0] += sum_i v[i]: grid-stride, wave sums, one atomic per workgroup
+__global__ __launch_bounds__(256) void sum_vec_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ out) {
+    __shared__ float ws4[4];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += v[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) ws4[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (ws4[0] + ws4[1]) + (ws4[2] + ws4[3]);
+        if (t != 0.f) unsafeAtomicAdd(out, t);
+    }
+}
+
 // da [B*T, 4E] -> dq[b,e] = sum_t (d0 + d2 + d3 k), added into dx[b, qcol[e]];  dk[b,t,e] += d1 - d2 + d3 q
 __global__ __launch_bounds__(256) void din_att_in_bwd_kernel(const float* __restrict__ da, const float* __restrict__ q,
                                                              const float* __restrict__ k, int64_t batch, int T, int E,
@@ -1435,10 +1499,17 @@ extern "C" int dctr_din_wsum_bwd(const float* d_out, int64_t d_stride, const flo
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(d_out && score && mask && k && d_score && dk, DCTR_E_NULL, "din_wsum_bwd: null pointer");
     int64_t blocks = dctr_ceil_div(batch * maxlen, (int64_t)4);
-    const int64_t cap = d_bias != nullptr ? 256 : 16384;         // each workgroup ends in one atomic on d_bias
-    if (blocks > cap) blocks = cap;
+    if (blocks > 16384) blocks = 16384;
+    // the bias gradient (sum of d_score) is taken by a second small kernel: as one atomic per workgroup of this one it either
+    // serialised thousands of atomics on one address (0.5 ms at C4) or capped the grid at 256 workgroups (86 us)
     hipLaunchKernelGGL(din_wsum_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_out, d_stride, score, mask, k,
-                       batch, (int)maxlen, (int)dim, d_score, dk, d_bias);
+                       batch, (int)maxlen, (int)dim, d_score, dk, (float*)nullptr);
+    if (d_bias != nullptr) {
+        const int64_t n = batch * maxlen;
+        int64_t g = dctr_ceil_div(n, (int64_t)256 * 8);
+        g = g < 1 ? 1 : (g > COLSUM_MAX_WG ? COLSUM_MAX_WG : g);
+        hipLaunchKernelGGL(sum_vec_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)d_score, n, d_bias);
+    }
     return dctr_launch_status("dctr_din_wsum_bwd");
 }
 
