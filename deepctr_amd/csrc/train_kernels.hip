@@ -282,60 +282,63 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const
 // ---------------------------------------------------------------------------------------------------
 // DNN backward helpers
 // ---------------------------------------------------------------------------------------------------
-constexpr int BWD_ROWS = 16;     // batch rows per workgroup of the two helpers below (B = 4096 -> 256 workgroups)
+constexpr int BWD_ROWS = 16;     // batch rows per iteration of the generic Dice passes further down (the 16-B forms take over when N % 4 == 0)
 
 // dZ[b, n] = dlogit[b] * head_w[n] * act'(h[b, n]);   d_head_w[n] += sum_b dlogit[b] * h[b, n]
+// (any N / strides: thread = one column (blockIdx.y * 256 + threadIdx.x), rows grid-strided over blockIdx.x; the 16-B forms below
+// take over when the shapes allow)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ head_w,
                                                        const float* __restrict__ h, int64_t h_stride, int64_t batch, int N,
                                                        int act, float* __restrict__ dz, int64_t dz_stride,
                                                        float* __restrict__ d_head_w) {
-    // block = BWD_ROWS rows x all columns; thread t walks columns t, t+256, ...
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
-    for (int n = threadIdx.x; n < N; n += 256) {
-        const float hw = head_w[n];
-        float acc = 0.f;
-        for (int r = 0; r < BWD_ROWS; ++r) {
-            const int64_t b = r0 + r;
-            if (b >= batch) break;
-            const float hv = h[b * h_stride + n], dl = dlogit[b];
-            float d = dl * hw;
-            if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
-            else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
-            else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
-            dz[b * dz_stride + n] = d;
-            acc = fmaf(dl, hv, acc);
-        }
-        unsafeAtomicAdd(d_head_w + n, acc);
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float hw = head_w[n];
+    float acc = 0.f;
+#pragma unroll 4
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        const float hv = h[b * h_stride + n], dl = dlogit[b];
+        float d = dl * hw;
+        if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
+        else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
+        else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
+        dz[b * dz_stride + n] = d;
+        acc = fmaf(dl, hv, acc);
     }
+    unsafeAtomicAdd(d_head_w + n, acc);
 }
 
 // in place: dh[b, n] *= act'(h[b, n]);  db[n] += sum_b dz[b, n]   (also used with h == NULL: only the column sums)
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t batch,
                                                              int N, int act, float* __restrict__ db) {
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
-    for (int n = threadIdx.x; n < N; n += 256) {
-        float acc = 0.f;
-        for (int r = 0; r < BWD_ROWS; ++r) {
-            const int64_t b = r0 + r;
-            if (b >= batch) break;
-            float d = dh[b * N + n];
-            if (h != nullptr) {
-                const float hv = h[b * N + n];
-                if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
-                else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
-                else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
-                dh[b * N + n] = d;
-            }
-            acc += d;
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        float d = dh[b * N + n];
+        if (h != nullptr) {
+            const float hv = h[b * N + n];
+            if (act == DCTR_ACT_RELU) d = hv > 0.f ? d : 0.f;
+            else if (act == DCTR_ACT_SIGMOID) d *= hv * (1.f - hv);
+            else if (act == DCTR_ACT_TANH) d *= 1.f - hv * hv;
+            dh[b * N + n] = d;
         }
-        if (db != nullptr) unsafeAtomicAdd(db + n, acc);
+        acc += d;
     }
+    if (db != nullptr) unsafeAtomicAdd(db + n, acc);
 }
 
 // The two helpers above with 16-B accesses and the rows spread over the workgroup: thread (rl, c) owns columns 4c .. 4c+3 of rows
 // rl, rl + RL, ... (RL = 256 / (N/4) row lanes; a workgroup sweeps RL x N contiguous floats per iteration, grid-stride), the column
 // sums meet in LDS and leave as ONE atomic per column and workgroup (N % 4 == 0, N <= 1024, strides % 4 == 0, 16-B aligned).
 constexpr int COLSUM_MAX_WG = 64;      // workgroups of a pass that ends in one atomic per column and workgroup
+
+// grid of the BWD_ROWS-rows-per-iteration kernels (grid-stride over row blocks)
+static unsigned rows_grid(int64_t rows, bool column_sums) {
+    const int64_t nb = dctr_ceil_div(rows, (int64_t)BWD_ROWS), cap = column_sums ? COLSUM_MAX_WG : 16384;
+    return (unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+}
 
 __device__ __forceinline__ float4 act_grad4(float4 d, float4 hv, int act) {
     if (act == DCTR_ACT_RELU) {
@@ -416,8 +419,9 @@ static void launch_act_bwd_colsum(hipStream_t st, float* dh, const float* h, int
         g = g < 1 ? 1 : (g > cap ? cap : g);
         hipLaunchKernelGGL(act_bwd_colsum4_kernel, dim3((unsigned)g), dim3(256), 0, st, dh, h, batch, N, act, db);
     } else {
-        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)BWD_ROWS)), dim3(256), 0, st, dh, h,
-                           batch, N, act, db);
+        const int64_t gx = db != nullptr ? COLSUM_MAX_WG : 1024;
+        hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)(batch < gx ? batch : gx), (unsigned)((N + 255) / 256)), dim3(256), 0, st,
+                           dh, h, batch, N, act, db);
     }
 }
 
@@ -431,8 +435,8 @@ static void launch_head_bwd(hipStream_t st, const float* dlogit, const float* he
         hipLaunchKernelGGL(head_bwd4_kernel, dim3((unsigned)g), dim3(256), 0, st, dlogit, head_w, h, h_stride, batch, N, act, dz,
                            dz_stride, d_head_w);
     } else {
-        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)BWD_ROWS)), dim3(256), 0, st, dlogit, head_w,
-                           h, h_stride, batch, N, act, dz, dz_stride, d_head_w);
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(batch < COLSUM_MAX_WG ? batch : COLSUM_MAX_WG), (unsigned)((N + 255) / 256)),
+                           dim3(256), 0, st, dlogit, head_w, h, h_stride, batch, N, act, dz, dz_stride, d_head_w);
     }
 }
 
@@ -709,16 +713,6 @@ __global__ __launch_bounds__(256) void cin_outer4_kernel(const float* __restrict
     }
 }
 
-// Y = act(Y + bias) in place
-__global__ __launch_bounds__(256) void cin_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t rows,
-                                                           int H, int act) {
-    const int64_t total = rows * H;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
-        const float v = y[o] + bias[o % H];
-        y[o] = act == DCTR_ACT_RELU ? fmaxf(v, 0.f) : act == DCTR_ACT_SIGMOID ? 1.f / (1.f + expf(-v)) : act == DCTR_ACT_TANH ? tanhf(v) : v;
-    }
-}
-
 // dpre[r,h] = (hidden part: dxnext[r,h] for h < Hn) + (direct part: d_out[b, off + h - d0] for h >= d0), times act'(Y)
 __global__ __launch_bounds__(256) void cin_dpre_kernel(const float* __restrict__ y, const float* __restrict__ dxnext, int64_t ldn,
                                                        int Hn, const float* __restrict__ d_out, int64_t out_dim, int off, int d0,
@@ -983,11 +977,11 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(float* __restrict__ dh, c
                                                        const float* __restrict__ alpha, const float* __restrict__ mean,
                                                        const float* __restrict__ var, float eps, int64_t batch, int N,
                                                        float* __restrict__ d_alpha) {
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float bn = bias != nullptr ? bias[n] : 0.f, al = alpha[n], mu = mean[n];
         const float rs = 1.f / sqrtf(var[n] + eps);
         float acc = 0.f;
+        for (int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS; r0 < batch; r0 += (int64_t)gridDim.x * BWD_ROWS)     // grid-stride: few workgroups when column sums follow
         for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= batch) break;
@@ -1014,12 +1008,12 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(float* __restrict__ dh, c
 __global__ __launch_bounds__(256) void dice_colstat_kernel(const float* __restrict__ z, int64_t z_stride, const float* __restrict__ bias,
                                                           int64_t rows, int N, int kind, const float* __restrict__ sum0,
                                                           float* __restrict__ acc) {
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     const float inv = 1.f / (float)rows;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float bn = bias != nullptr ? bias[n] : 0.f;
         const float mu = kind ? sum0[n] * inv : 0.f;
         float a = 0.f;
+        for (int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS; r0 < rows; r0 += (int64_t)gridDim.x * BWD_ROWS)     // grid-stride: few workgroups when column sums follow
         for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= rows) break;
@@ -1063,11 +1057,11 @@ __global__ __launch_bounds__(256) void dice_train_bwd_reduce_kernel(const float*
                                                                    const float* __restrict__ mean, const float* __restrict__ var,
                                                                    float eps, int64_t batch, int N, float* __restrict__ s12,
                                                                    float* __restrict__ d_alpha) {
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float bn = bias != nullptr ? bias[n] : 0.f, al = alpha[n], mu = mean[n];
         const float rs = 1.f / sqrtf(var[n] + eps);
         float a1 = 0.f, a2 = 0.f, aa = 0.f;
+        for (int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS; r0 < batch; r0 += (int64_t)gridDim.x * BWD_ROWS)     // grid-stride: few workgroups when column sums follow
         for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= batch) break;
@@ -1091,12 +1085,12 @@ __global__ __launch_bounds__(256) void dice_train_bwd_apply_kernel(float* __rest
                                                                   const float* __restrict__ bias, const float* __restrict__ alpha,
                                                                   const float* __restrict__ mean, const float* __restrict__ var,
                                                                   float eps, int64_t batch, int N, const float* __restrict__ s12) {
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     const float inv = 1.f / (float)batch;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float bn = bias != nullptr ? bias[n] : 0.f, al = alpha[n], mu = mean[n];
         const float rs = 1.f / sqrtf(var[n] + eps);
         const float m1 = s12[n] * inv, m2 = s12[N + n] * inv;
+        for (int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS; r0 < batch; r0 += (int64_t)gridDim.x * BWD_ROWS)     // grid-stride: few workgroups when column sums follow
         for (int r = 0; r < BWD_ROWS; ++r) {
             const int64_t b = r0 + r;
             if (b >= batch) break;
@@ -1261,7 +1255,7 @@ extern "C" int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float
         hipLaunchKernelGGL(dice_colstat4_kernel, dim3(g), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 0, (const float*)nullptr, batch_mean);
         hipLaunchKernelGGL(dice_colstat4_kernel, dim3(g), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 1, (const float*)batch_mean, batch_var);
     } else {
-        const unsigned rb = (unsigned)dctr_ceil_div(rows, (int64_t)BWD_ROWS);
+        const unsigned rb = rows_grid(rows, true);
         hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 0, (const float*)nullptr, batch_mean);
         hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, z, z_stride, bias, rows, (int)n, 1, (const float*)batch_mean, batch_var);
     }
@@ -1727,7 +1721,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
                                    (const float*)buf, (const float*)bufZ, bl, a->dice_alpha[l], a->dice_batch_mean[l],
                                    a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
             else
-                hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)buf, (const float*)bufZ, bl,
+                hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rows_grid(a->batch, true)), dim3(256), 0, st, (const float*)buf, (const float*)bufZ, bl,
                                    a->dice_alpha[l], a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
             hipLaunchKernelGGL(dice_train_bwd_apply_kernel, dim3(rb), dim3(256), 0, st, buf, (const float*)bufZ, bl, a->dice_alpha[l],
                                a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, (const float*)s12);
@@ -1737,7 +1731,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
             hipLaunchKernelGGL(dice_bwd4_kernel, dim3(colsum_grid(a->batch, 256 / (N / 4))), dim3(256), 0, st, buf, (const float*)bufZ, bl,
                                a->dice_alpha[l], a->dice_mean[l], a->dice_var[l], a->dice_eps, a->batch, N, dal);
         else
-            hipLaunchKernelGGL(dice_bwd_kernel, dim3(rb), dim3(256), 0, st, buf, bufZ, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
+            hipLaunchKernelGGL(dice_bwd_kernel, dim3(rows_grid(a->batch, true)), dim3(256), 0, st, buf, bufZ, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
                                a->dice_eps, a->batch, N, dal);
         return 0;
     };
