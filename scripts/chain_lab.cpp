@@ -21,6 +21,7 @@
 #include "../deepctr_amd/csrc/chain_kernels_r1w4.hip"
 #include <algorithm>
 #include <cmath>
+#include <time.h>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -143,6 +144,46 @@ int main(int argc, char** argv) {
         double m = 0; int nn = 0;
         for (int64_t b = 0; b < Ba; ++b) { if (!(a1[b] == a1[b])) ++nn; m = std::max(m, fabs((double)a0[b] - a1[b])); }
         printf("auto split, %lld rows: max |diff| vs mlp_kernel<2> %.3e, NaN rows %d, tail untouched: %s\n", (long long)Ba, m, nn, (a1[Ba] != a1[Ba]) ? "yes" : "NO");
+    }
+    // ---- one-shot region of 20 batches (81,920 rows = 65,536 on <2,8> + 16,384 on <1,4>), as bench.py --steps 20 times it:
+    // host clock around issue + synchronise, idle GPU before.  (a) one call (two launches on one stream), (b) the two parts as
+    // two calls on one stream, (c) the two parts on TWO streams (fork / join with events): does the remainder fill the main
+    // kernel's tail?
+    if (getenv("CHAIN_LAB_ONESHOT") != nullptr) {
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        hipEvent_t ef, ej; CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        auto run_on = [&](hipStream_t s, int64_t row0, int64_t B, float* y) -> int {
+            dctr_mlp_args_t a{};
+            a.batch = B; a.in_dim = in_dim; a.n_layers = 3; a.units = units; a.kernels = ks; a.biases = bs; a.tile_rows = 0;
+            a.activation = DCTR_ACT_RELU; a.has_head = 1; a.sigmoid_out = 1; a.head_w = head; a.global_bias = gb; a.y = y + row0;
+            dctr_gather_fm_args_t g{};
+            g.fields = fields; g.ids = ids + row0; g.ids_stride_f = BMAX; g.ids_stride_b = 1; g.ids_is_i64 = 0; g.n_fields = F; g.max_dim = E; g.all_dim4 = 1;
+            g.any_hash = 0; g.n_dense = ND; g.dense = dense + row0 * ND; g.dense_stride = ND; g.dense_lin_w = densew; g.dense_out_offset = F * E;
+            g.dense_copy_cols = ND; g.batch = B; g.status = status; g.split_col = E == 16 ? 256 : 0; g.split_field = E == 16 ? 16 : 0;
+            g.uniform_dim = E;
+            return dctr_embed_mlp_fwd(&g, &a, 1, 1, s);
+        };
+        auto now_us = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+        for (int mode = 0; mode < 3; ++mode) {
+            std::vector<double> ts;
+            for (int rep = 0; rep < 12; ++rep) {
+                CK(hipDeviceSynchronize());
+                const double t0 = now_us();
+                if (mode == 0) run_on(st, 0, 81920, y1);
+                else if (mode == 1) { run_on(st, 0, 65536, y1); run_on(st, 65536, 16384, y1); }
+                else {
+                    CK(hipEventRecord(ef, st)); CK(hipStreamWaitEvent(st2, ef, 0));
+                    run_on(st2, 65536, 16384, y1);
+                    run_on(st, 0, 65536, y1);
+                    CK(hipEventRecord(ej, st2)); CK(hipStreamWaitEvent(st, ej, 0));
+                }
+                CK(hipStreamSynchronize(st));
+                ts.push_back(now_us() - t0);
+            }
+            std::sort(ts.begin(), ts.end());
+            printf("one-shot 81,920 rows, mode %d (%s): median %.1f us, min %.1f us -> %.1f M samples/s\n", mode,
+                   mode == 0 ? "one call" : mode == 1 ? "two calls, one stream" : "two streams", ts[ts.size() / 2], ts[0], 81920.0 / ts[ts.size() / 2]);
+        }
     }
     // ---- timing
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
