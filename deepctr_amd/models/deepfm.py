@@ -124,7 +124,7 @@ class _DeepFM(FeatureModel):
         with >= 64 rows per CU the library then runs its persistent kernels (row-chained: chain_device.h; else streaming)."""
         if self._fast_path(staged) and self.span_batches:
             return max(int(batch_size or staged.n), 1 << 20)
-        return batch_size
+        return super(_DeepFM, self)._rows_per_launch(staged, batch_size)
 
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan

@@ -105,10 +105,14 @@ def main():
             m.fused = False
             run("C2 DeepFM (2 launches/step)", m, feed, 4096, args.steps, ring)
         del m
-    if "c3" in want:
+    if "c3" in want or "c3_span" in want:
         m = xDeepFM(cols16, cols16, cin_layer_size=(128, 128), device=dev)
         init_on_device(m)
-        run("C3 xDeepFM CIN[128,128]", m, criteo(rng, ring * 4096), 4096, args.steps, ring)
+        feed = criteo(rng, ring * 4096)
+        if "c3" in want:
+            run("C3 xDeepFM CIN[128,128]", m, feed, 4096, args.steps, ring)
+        if "c3_span" in want:
+            run_span("C3 xDeepFM (1 call / %d batches)" % ring, m, feed, 4096)
         del m
     for par, tag in (("vector", "dcn_v"), ("matrix", "dcn_m")):
         if tag in want:
@@ -145,6 +149,8 @@ def main():
         m = DIN(cols, ["item_id", "cate_id"], device=dev)
         init_on_device(m)
         run("C4 DIN T=50 E=32 (dice)", m, feed, B, args.steps, ring)
+        if "c4_span" in want:
+            run_span("C4 DIN (1 call / %d batches)" % ring, m, feed, B)
         del m
     if "c5" in want or "c5_span" in want:
         V, E, B = 10 ** 7, 32, 8192

@@ -73,6 +73,12 @@ def test_model_matches_reference_code(device, name):
     # list-style input in get_feature_names order, as examples/run_classification_criteo.py does
     y = model.predict([feed[n] for n in model.input_names], batch_size=64)
     check_probs(y, g["y"], name + " list feed", rows)
+    # one _forward call per batch_size rows (predict() otherwise lets a call span up to model.span_rows rows)
+    model.span_rows = 0
+    model.span_batches = False
+    y1 = model.predict(feed, batch_size=37)
+    check_probs(y1, g["y"], name + " bs=37, no spans", rows)
+    assert_close(y1, y, rtol=2e-6, atol=2e-7, what=name + ": spans vs per-batch calls")
 
 
 def _criteo_like(rng, n, F=26, V=1000, E=16, ND=13):
