@@ -877,18 +877,59 @@ class Model(object):
     def compile(self, optimizer="adam", loss=None, metrics=None, **kwargs):
         self._compiled = {"optimizer": optimizer, "loss": loss, "metrics": metrics or []}
 
+    @staticmethod
+    def _metric(name, p, y):
+        """One compiled metric on predictions p / labels y (float64 vectors), tf.keras' definitions: binary_crossentropy with the
+        backend epsilon clip, mse, mae, (binary_)accuracy at threshold 0.5, auc as the rank statistic (ties averaged)."""
+        key = name.lower() if isinstance(name, str) else getattr(name, "__name__", str(name)).lower()
+        if key in ("binary_crossentropy", "logloss", "bce"):
+            pc = np.clip(p, 1e-7, 1 - 1e-7)
+            return float(-(y * np.log(pc) + (1 - y) * np.log(1 - pc)).mean())
+        if key in ("mse", "mean_squared_error"):
+            return float(((p - y) ** 2).mean())
+        if key in ("mae", "mean_absolute_error"):
+            return float(np.abs(p - y).mean())
+        if key in ("accuracy", "acc", "binary_accuracy"):
+            return float(((p > 0.5) == (y > 0.5)).mean())
+        if key == "auc":
+            order = np.argsort(p, kind="mergesort")
+            ranks = np.empty(len(p), dtype=np.float64)
+            sp = p[order]
+            i = 0
+            while i < len(sp):                          # average ranks over ties
+                j = i
+                while j + 1 < len(sp) and sp[j + 1] == sp[i]:
+                    j += 1
+                ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+                i = j + 1
+            pos = y > 0.5
+            n_pos, n_neg = int(pos.sum()), int((~pos).sum())
+            if n_pos == 0 or n_neg == 0:
+                return float("nan")
+            return float((ranks[pos].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+        raise NotImplementedError("metric %r is not supported (binary_crossentropy, mse, mae, accuracy, auc)" % (name,))
+
+    @staticmethod
+    def _metric_name(name):
+        return name if isinstance(name, str) else getattr(name, "__name__", str(name))
+
     @on_model_device
-    def evaluate(self, x, y, batch_size=256, verbose=0, **kwargs):
+    def evaluate(self, x, y, batch_size=256, verbose=0, return_dict=False, **kwargs):
+        """Loss of the compiled (or the task's default) loss function, followed by the compiled metrics — a scalar when there are
+        none, a list [loss, metric...] otherwise, or a name -> value dict with ``return_dict=True`` (tf.keras.Model.evaluate)."""
         p = self.predict(x, batch_size).reshape(-1).astype(np.float64)
         y = np.asarray(y, dtype=np.float64).reshape(-1)
-        loss_name = (self._compiled or {}).get("loss") or ("binary_crossentropy" if self.task == "binary" else "mse")
-        if loss_name in ("binary_crossentropy", "logloss"):
-            eps = 1e-7
-            pc = np.clip(p, eps, 1 - eps)
-            loss = float(-(y * np.log(pc) + (1 - y) * np.log(1 - pc)).mean())
-        else:
-            loss = float(((p - y) ** 2).mean())
-        return loss
+        c = self._compiled or {}
+        loss_name = c.get("loss") or ("binary_crossentropy" if self.task == "binary" else "mse")
+        loss = self._metric("binary_crossentropy" if loss_name in ("binary_crossentropy", "logloss") else "mse", p, y)
+        metrics = list(c.get("metrics") or [])
+        vals = [(self._metric_name(m), self._metric(m, p, y)) for m in metrics]
+        if return_dict:
+            return dict([("loss", loss)] + vals)
+        return [loss] + [v for _, v in vals] if vals else loss
+
+    def test_on_batch(self, x, y, **kwargs):
+        return self.evaluate(x, y, batch_size=None, **kwargs)
 
     @on_model_device
     def fit(self, x=None, y=None, batch_size=256, epochs=1, verbose=1, validation_split=0.0, shuffle=True, **kwargs):

@@ -420,8 +420,9 @@ class _EpochEnd(object):
         h.epoch.append(ep)
         logs = {"loss": loss}
         if self.val is not None:
-            logs["val_loss"] = self.model.evaluate(self.val[0], self.val[1], batch_size=self.bs)
-            h.history.setdefault("val_loss", []).append(logs["val_loss"])
+            for k, v in self.model.evaluate(self.val[0], self.val[1], batch_size=self.bs, return_dict=True).items():
+                logs["val_" + k] = v                      # val_loss and val_<metric> of the compiled metrics
+                h.history.setdefault("val_" + k, []).append(v)
         if self.verbose:
             print("Epoch %d/%d - loss: %.4f%s" % (ep + 1, self.epochs, loss,
                                                   (" - val_loss: %.4f" % logs["val_loss"]) if "val_loss" in logs else ""))

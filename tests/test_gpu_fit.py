@@ -43,12 +43,22 @@ def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
     model = DeepFM(cols, cols, dnn_hidden_units=(32, 16), device=device)
     with pytest.raises(RuntimeError):
         model.fit(feed, y)
-    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
-    before = model.evaluate(feed, y, batch_size=512)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc", "accuracy"])
+    before, bce0, auc0, acc0 = model.evaluate(feed, y, batch_size=512)        # tf.keras: [loss, metric, ...] with compiled metrics
+    assert before == bce0 and 0.3 < auc0 < 0.7
     h = model.fit(feed, y, batch_size=256, epochs=8, verbose=0, validation_split=0.25)
-    assert len(h.history["loss"]) == 8 and len(h.history["val_loss"]) == 8
-    after = model.evaluate(feed, y, batch_size=512)
+    assert len(h.history["loss"]) == 8 and len(h.history["val_loss"]) == 8 and len(h.history["val_auc"]) == 8
+    res = model.evaluate(feed, y, batch_size=512, return_dict=True)
+    after = res["loss"]
     assert after < before - 0.05, (before, after)
+    assert res["auc"] > max(auc0, 0.5) + 0.03 and 0.5 <= res["accuracy"] <= 1.0, (res, auc0, acc0)
+    # auc against the pair-counting definition on a sample
+    pz = model.predict(feed, batch_size=512).reshape(-1)[:300].astype(np.float64)
+    yz = y[:300]
+    pairs = [(a > b) + 0.5 * (a == b) for a in pz[yz > 0.5] for b in pz[yz < 0.5]]
+    assert abs(type(model)._metric("auc", pz, yz.astype(np.float64)) - float(np.mean(pairs))) < 1e-12
+    tb = model.test_on_batch({k: v[:64] for k, v in feed.items()}, y[:64])
+    assert isinstance(tb, list) and len(tb) == 4
     p = model.predict(feed, batch_size=512)
     assert p.shape == (n, 1) and np.isfinite(p).all()
     assert isinstance(model.train_on_batch({k: v[:64] for k, v in feed.items()}, y[:64]), float)
