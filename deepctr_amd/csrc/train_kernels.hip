@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__
 // One wave = 64 / LPR samples x LPR 16-B chunks; the workgroup's four waves split the FIELDS (wave w owns fields w, w + 4, ...):
 // B = 4096, E = 16 -> 256 workgroups with 7 independent row reads per lane in flight (the first version walked all fields
 // serially in 64 workgroups: 112 us).  S is summed per wave over its fields and combined through LDS.
+// Measured and dropped (second half of round 2): 16 waves per workgroup (same 76 us: the 1.7 M float atomics run at the part's
+// ~23 G distinct-address atomics/s) and a row census per table that lets rows hit once take a plain 16-B read-modify-write
+// (62 us + two 6.6-us census launches = the same: then the ~640 k random sector accesses of the kernel are the limit, at the
+// rate the forward gather reaches at this launch size).
 template <int LPR, bool HASH>
 __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_t p, const dctr_field_grad_t* __restrict__ gr,
                                                             const float* __restrict__ d_in, int64_t d_stride,
@@ -769,9 +773,16 @@ __global__ __launch_bounds__(256) void cin_outer_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, int64_t n, int n_parts,
                                                         float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float acc = 0.f;
-        for (int s = 0; s < n_parts; ++s) acc += parts[(int64_t)s * n + i];
-        out[i] += acc;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four independent chains: the loads of 4 slices in flight per step
+        int s = 0;
+        for (; s + 4 <= n_parts; s += 4) {
+            a0 += parts[(int64_t)s * n + i];
+            a1 += parts[(int64_t)(s + 1) * n + i];
+            a2 += parts[(int64_t)(s + 2) * n + i];
+            a3 += parts[(int64_t)(s + 3) * n + i];
+        }
+        for (; s < n_parts; ++s) a0 += parts[(int64_t)s * n + i];
+        out[i] += (a0 + a1) + (a2 + a3);
     }
 }
 
