@@ -338,6 +338,14 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* __restrict__
 // sums meet in LDS and leave as ONE atomic per column and workgroup (N % 4 == 0, N <= 1024, strides % 4 == 0, 16-B aligned).
 constexpr int COLSUM_MAX_WG = 64;      // workgroups of a pass that ends in one atomic per column and workgroup
 
+// workgroups of a column-sum pass over `rows` rows: enough of them to keep the loads in flight, few enough that the final atomics
+// (one per column and workgroup, ~90 ns each on one address) stay a short tail
+static unsigned colsum_grid(int64_t rows, int RL) {
+    int64_t g = dctr_ceil_div(rows, (int64_t)RL * 4);
+    const int64_t cap = rows >= 32768 ? 128 : COLSUM_MAX_WG;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
 // grid of the BWD_ROWS-rows-per-iteration kernels (grid-stride over row blocks)
 static unsigned rows_grid(int64_t rows, bool column_sums) {
     const int64_t nb = dctr_ceil_div(rows, (int64_t)BWD_ROWS), cap = column_sums ? COLSUM_MAX_WG : 16384;
@@ -419,7 +427,7 @@ static void launch_act_bwd_colsum(hipStream_t st, float* dh, const float* h, int
         int64_t g = dctr_ceil_div(batch, (int64_t)RL * 4);           // >= 4 rows per thread where the batch has them
         // atomics on ONE address serialise at ~100 ns each on this part (measured: 256 workgroups x 256 columns = 27 us of a
         // 4-MB pass): with column sums wanted, few workgroups with long row loops; without, as many as the rows give
-        const int64_t cap = db != nullptr ? COLSUM_MAX_WG : 1024;
+        const int64_t cap = db != nullptr ? (int64_t)colsum_grid(batch, RL) : 1024;
         g = g < 1 ? 1 : (g > cap ? cap : g);
         hipLaunchKernelGGL(act_bwd_colsum4_kernel, dim3((unsigned)g), dim3(256), 0, st, dh, h, batch, N, act, db);
     } else {
@@ -435,7 +443,7 @@ static void launch_head_bwd(hipStream_t st, const float* dlogit, const float* he
         dctr_aligned16(head_w)) {
         const int RL = 256 / (N / 4);
         int64_t g = dctr_ceil_div(batch, (int64_t)RL * 4);
-        g = g < 1 ? 1 : (g > COLSUM_MAX_WG ? COLSUM_MAX_WG : g);
+        g = colsum_grid(batch, RL);
         hipLaunchKernelGGL(head_bwd4_kernel, dim3((unsigned)g), dim3(256), 0, st, dlogit, head_w, h, h_stride, batch, N, act, dz,
                            dz_stride, d_head_w);
     } else {
@@ -1239,14 +1247,6 @@ __global__ __launch_bounds__(256) void dice_train_bwd_reduce4_kernel(const float
     colsum4_finish_k<3>(acc, N4, RL, c, outs);
 }
 
-// workgroups of a column-sum pass over `rows` rows: enough of them to keep the loads in flight, few enough that the final atomics
-// (one per column and workgroup, ~90 ns each on one address) stay a short tail
-static unsigned colsum_grid(int64_t rows, int RL) {
-    int64_t g = dctr_ceil_div(rows, (int64_t)RL * 4);
-    const int64_t cap = rows >= 32768 ? 128 : COLSUM_MAX_WG;
-    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
-}
-
 static bool rowlane4_ok(int N, const void* a, const void* b, int64_t stride) {
     return N % 4 == 0 && N >= 4 && N <= 1024 && stride % 4 == 0 && dctr_aligned16(a) && (b == nullptr || dctr_aligned16(b));
 }
@@ -1676,13 +1676,34 @@ extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) 
     return dctr_launch_status("dctr_embed_pool_bwd");
 }
 
+// dW = X^T dZ has a small output and a reduction as long as the batch: from 8192 rows on it runs as a strided batch of row slices
+// into partial products + a sum (left to rocBLAS as ONE gemm, B = 65,536 took 1.78 ms per layer on a few workgroups; the
+// library splits K by itself only at small batches)
+static int mlp_dw_parts(int64_t batch) {
+    if (batch < 8192) return 1;
+    int parts = (int)(batch / 2048 > 32 ? 32 : batch / 2048);
+    while (parts > 1 && batch % parts != 0) --parts;
+    return parts;
+}
+
+static size_t mlp_bwd_main_floats(const dctr_mlp_bwd_args_t* a, int w) {
+    // two ping-pong buffers [B, widest layer]; Dice needs a third for the recomputed pre-activations
+    // ... and, with batch statistics, 2 x widest for the two column sums of the BatchNormalization backward
+    return ((size_t)(a->activation == DCTR_ACT_DICE ? 3 : 2) * a->batch * w + (a->activation == DCTR_ACT_DICE ? 2 * (size_t)w : 0) + 3) &
+           ~(size_t)3;
+}
+
 extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
     if (a == nullptr || a->batch <= 0 || a->n_layers < 1 || a->units == nullptr) return 0;
     int w = a->in_dim;
-    for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
-    // two ping-pong buffers [B, widest layer]; Dice needs a third for the recomputed pre-activations
-    // ... and, with batch statistics, 2 x widest for the two column sums of the BatchNormalization backward
-    return ((size_t)(a->activation == DCTR_ACT_DICE ? 3 : 2) * a->batch * w + (a->activation == DCTR_ACT_DICE ? 2 * (size_t)w : 0)) * sizeof(float);
+    size_t kn = 0;
+    for (int l = 0; l < a->n_layers; ++l) {
+        const size_t k = l == 0 ? a->in_dim : a->units[l - 1];
+        kn = k * a->units[l] > kn ? k * a->units[l] : kn;
+        w = a->units[l] > w ? a->units[l] : w;
+    }
+    const int parts = mlp_dw_parts(a->batch);
+    return (mlp_bwd_main_floats(a, w) + (parts > 1 ? (size_t)parts * kn : 0)) * sizeof(float);
 }
 
 extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
@@ -1709,6 +1730,8 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     float* bufA = static_cast<float*>(a->workspace);
     float* bufB = bufA + (size_t)a->batch * w;
     float* bufZ = bufB + (size_t)a->batch * w;                 // dice only
+    float* dw_parts = bufA + mlp_bwd_main_floats(a, w);        // partial dW of the row slices (batch >= 8192)
+    const int n_parts = mlp_dw_parts(a->batch);
     const int B = (int)a->batch;
     const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
     const int L = a->n_layers;
@@ -1773,9 +1796,22 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         if (a->d_biases != nullptr && a->d_biases[l] != nullptr)
             launch_act_bwd_colsum(st, dz, (const float*)nullptr, a->batch, N, 0, a->d_biases[l]);
         // dW[K, N] (row-major) += X^T dZ:  column-major  dW'(N x K) = dZ'(N x B) * X'(K x B)^T
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, dz, N, xin, ldx,
-                                          &one, a->d_kernels[l], N);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        rocblas_status rs;
+        if (n_parts > 1) {
+            const int rs_ = B / n_parts;
+            const int64_t kn = (int64_t)K * N;
+            rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, N, K, rs_, &one, dz, N,
+                                               (rocblas_stride)rs_ * N, xin, ldx, (rocblas_stride)rs_ * ldx, &zero, dw_parts, N,
+                                               (rocblas_stride)kn, n_parts);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            int64_t g = dctr_ceil_div(kn, (int64_t)256);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, (const float*)dw_parts, kn, n_parts,
+                               a->d_kernels[l]);
+        } else {
+            rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, dz, N, xin, ldx, &one,
+                               a->d_kernels[l], N);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        }
         // dH_prev[B, K] = dZ W^T:  column-major  dH'(K x B) = W'(N x K)^T * dZ'(N x B)
         const bool to_dx = l == 0;
         if (to_dx && a->dx == nullptr) break;

@@ -57,7 +57,8 @@ def test_adam_step_matches_torch_adam(device):
 def test_mlp_bwd_matches_autograd(device, act):
     from deepctr_amd import ops
     rng = np.random.RandomState(3)
-    for B, dims in ((37, [13, 8, 5]), (300, [429, 256, 128, 64]), (65, [20, 7])):
+    # (10000 rows: from 8192 on dW runs as a strided batch of row slices + a sum)
+    for B, dims in ((37, [13, 8, 5]), (300, [429, 256, 128, 64]), (65, [20, 7]), (10000, [21, 12, 8])):
         x = rng.standard_normal((B, dims[0] + 3)).astype(np.float32)      # row stride > in_dim
         ks = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
         bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(dims) - 1)]
