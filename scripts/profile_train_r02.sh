@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/train
 MODELS=${MODELS:-"DeepFM xDeepFM DCN DCNM DCNMix DIN"}
-PROF=${PROF:-"DeepFM xDeepFM DCN DIN"}
+PROF=${PROF-"DeepFM xDeepFM DCN DIN"}      # PROF="" = no rocprofv3 passes
 mkdir -p $OUT
 for m in $MODELS; do
   python scripts/bench_train.py --steps 50 --model $m --batches ${BATCHES:-$([ $m = DIN ] && echo 2048 || echo 4096)} > $OUT/$m.log 2>&1
