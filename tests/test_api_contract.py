@@ -292,3 +292,23 @@ def test_product_package_never_touches_the_oracle_or_the_reference():
     from deepctr_amd import _C, ops
     with pytest.raises(_C.DctrExtensionError, match="no CPU path"):
         ops.fm(torch.zeros(2, 3, 4))
+
+
+def test_predict_span_rows_rule():
+    """predict(): one _forward call covers max(batch_size, span_rows) rows; span_rows = 0 or span_batches = False give one call
+    per batch_size rows (engine.Model._rows_per_launch; the DeepFM family's fused launch has its own, larger, span)."""
+    from deepctr_amd.engine import Model
+
+    class Staged(object):
+        n = 100000
+
+    m = object.__new__(Model)
+    assert Model.span_rows == 16384
+    assert m._rows_per_launch(Staged(), 256) == 16384
+    assert m._rows_per_launch(Staged(), 50000) == 50000
+    assert m._rows_per_launch(Staged(), None) == 100000
+    m.span_rows = 0
+    assert m._rows_per_launch(Staged(), 256) == 256
+    m.span_rows = 4096
+    m.span_batches = False
+    assert m._rows_per_launch(Staged(), 256) == 256
