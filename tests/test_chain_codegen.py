@@ -33,3 +33,40 @@ def test_chain_kernel_needs_no_scratch(tmp_path, tu, max_vgprs):
         assert "chain_kernel" in n
         assert s == 0, "%s spills to scratch (%d B/lane)" % (n, s)
         assert v + a <= max_vgprs, "%s needs %d registers" % (n, v + a)
+
+
+def _resource_usage(tmp_path, tu):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "deepctr_amd", "csrc", tu)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "deepctr_amd", "csrc"), "-x", "hip", "--cuda-device-only", "-c", src,
+           "-o", str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, check=True).stdout
+    names = re.findall(r"Function Name: (\S+)", out)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
+    vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", out)]
+    assert names and len(names) == len(scratch) == len(vgprs), out[-2000:]
+    return dict(zip(names, zip(scratch, vgprs)))
+
+
+def test_cin_kernels_register_budget(tmp_path):
+    """CIN forward (csrc/cin_kernels.hip): the inference instantiation must not pay for the training-mode stores of the layer
+    activations (as a run-time branch of one kernel they cost it 580 B of scratch per lane and 25 % of its speed); the z-free
+    backward kernels (csrc/cin_bwd_kernels.hip) keep their accumulators and staging registers out of scratch and fit two
+    workgroups per CU."""
+    fwd = _resource_usage(tmp_path, "cin_kernels.hip")
+    for name, (scratch, vgprs) in fwd.items():
+        if "cin_kernel" in name:
+            assert scratch <= 64, "%s: %d B of scratch per lane" % (name, scratch)
+    bwd = _resource_usage(tmp_path, "cin_bwd_kernels.hip")
+    seen = 0
+    for name, (scratch, vgprs) in bwd.items():
+        if "cin_dz_fused_kernel" in name:
+            assert scratch == 0 and vgprs <= 256, (name, scratch, vgprs)
+            seen += 1
+        elif "cin_dw_fused_kernel" in name:
+            assert scratch <= 64 and vgprs <= 256, (name, scratch, vgprs)
+            seen += 1
+    assert seen >= 16
