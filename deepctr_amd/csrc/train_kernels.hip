@@ -1887,8 +1887,9 @@ extern "C" int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, 
 
 extern "C" size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* a) {
     if (a == nullptr || a->batch <= 0 || a->layers <= 0 || a->mode != DCTR_CROSS_MATRIX) return 0;
-    // x_1 .. x_{L-1}, u_0 .. u_{L-1}, g, du, dx0
-    return (size_t)(2 * a->layers + 2) * a->batch * a->dim * sizeof(float);
+    // x_1 .. x_{L-1}, u_0 .. u_{L-1}, g, du, dx0; from 8192 rows on the partial dW of the row slices (as in dctr_mlp_bwd)
+    const int parts = mlp_dw_parts(a->batch);
+    return ((size_t)(2 * a->layers + 2) * a->batch * a->dim + (parts > 1 ? (size_t)parts * a->dim * a->dim : 0)) * sizeof(float);
 }
 
 extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream) {
@@ -1935,6 +1936,8 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     float* g = us + (size_t)L * bd;
     float* du = g + bd;
     float* dx0 = du + bd;
+    float* dw_parts = dx0 + bd;
+    const int n_parts = mlp_dw_parts(a->batch);
     const float one = 1.f, zero = 0.f;
     auto xl_of = [&](int l, const float*& p, int& ld) {
         if (l == 0) { p = a->x; ld = (int)a->x_stride; }
@@ -1962,9 +1965,22 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
                            a->bias + (size_t)l * d, a->batch, d, du, dx0);
         launch_act_bwd_colsum(st, du, (const float*)nullptr, a->batch, d, 0, a->d_bias + (size_t)l * d);
         // dW[n][k] += sum_b du[b][n] x_l[b][k]:  column-major  dW'(k x n) = X'(k x B) * du'(n x B)^T
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, d, B, &one, xl, ldx, du, d, &one,
-                                          a->d_kernels + (size_t)l * d * d, d);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        rocblas_status rs;
+        if (n_parts > 1) {                     // the long reduction over the batch as a strided batch of row slices + a sum
+            const int rs_ = B / n_parts;
+            const int64_t dd = (int64_t)d * d;
+            rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, d, d, rs_, &one, xl, ldx,
+                                               (rocblas_stride)rs_ * ldx, du, d, (rocblas_stride)rs_ * d, &zero, dw_parts, d,
+                                               (rocblas_stride)dd, n_parts);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            int64_t gp = dctr_ceil_div(dd, (int64_t)256);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(gp > 8192 ? 8192 : gp)), dim3(256), 0, st, (const float*)dw_parts, dd, n_parts,
+                               a->d_kernels + (size_t)l * d * d);
+        } else {
+            rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, d, B, &one, xl, ldx, du, d, &one,
+                               a->d_kernels + (size_t)l * d * d, d);
+            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+        }
         // g[b][k] += sum_n du[b][n] W[n][k]:  column-major  g'(k x B) += W'(k x n) * du'(n x B)
         rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, B, d, &one, W, d, du, d, &one, g, d);
         DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(g) failed (%d)", (int)rs);

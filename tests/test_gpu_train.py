@@ -356,7 +356,7 @@ def test_hip_training_gradients_with_sequence_features(device, fixture):
                      what="grad of %s (scaled by %.3g)" % (tuple(p.w.shape), scale))
 
 
-@pytest.mark.parametrize("par,B,d,L", [("vector", 300, 429, 2), ("vector", 70, 45, 3), ("matrix", 130, 45, 2),
+@pytest.mark.parametrize("par,B,d,L", [("vector", 300, 429, 2), ("vector", 70, 45, 3), ("matrix", 130, 45, 2), ("matrix", 8192, 12, 2),
                                        ("matrix", 300, 429, 2), ("vector", 5, 7, 0)])
 def test_crossnet_bwd_matches_autograd(device, par, B, d, L):
     from deepctr_amd import ops
