@@ -92,3 +92,41 @@ def test_pipeline_planner_takes_only_plain_host_columns(monkeypatch):
     m3 = _model(cols_s)
     monkeypatch.setattr(m3.stage_plan, "device", torch.device("cuda", 0))
     assert m3.stage_plan.pipeline_plan(dict(feed, s=np.zeros((n, 3), np.int64)), n) is None
+
+
+def test_dense_linear_kernel_refresh_maps_rows_without_host_sync():
+    """EmbeddingStage.refresh: Linear.kernel rows permuted into dense-matrix column order through index tensors built once
+    (a boolean-mask assignment cost two torch.nonzero host synchronisations per predict() call / training step).  Dense columns
+    the linear part does not use stay zero; with a grad-tracking kernel the copy stays differentiable (the torch-autograd step)."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM
+    a, b, c = DenseFeat("a", 2), DenseFeat("b", 1), DenseFeat("c", 3)
+    s = SparseFeat("s", 7, 4)
+    # dnn uses a, b, c (dense matrix columns a0 a1 b0 c0 c1 c2); the linear part only c and a, in that order: rows c0 c1 c2 a0 a1
+    m = DeepFM([s, c, a], [s, a, b, c], dnn_hidden_units=(8,), device=torch.device("cpu"))
+    sp = m.stage_plan
+    assert sp.dense_lin_rows == [3, 4, -1, 0, 1, 2]
+    k = m.linear.w("linear_kernel")
+    k.copy_(torch.arange(1, 6, dtype=torch.float32).reshape(5, 1))
+    m._begin()
+    assert sp.dense_lin_w.tolist() == [4.0, 5.0, 0.0, 1.0, 2.0, 3.0]
+    buf = sp.dense_lin_w
+    k.mul_(2.0)
+    m._begin()
+    assert sp.dense_lin_w is buf and buf.tolist() == [8.0, 10.0, 0.0, 2.0, 4.0, 6.0]      # the persistent buffer, refreshed in place
+    # every dense column used by the linear part: the one-kernel index_select path
+    m2 = DeepFM([s, b, a], [s, a, b], dnn_hidden_units=(8,), device=torch.device("cpu"))
+    m2.linear.w("linear_kernel").copy_(torch.tensor([[7.0], [1.0], [2.0]]))                 # rows b0 a0 a1
+    m2._begin()
+    assert m2.stage_plan.dense_lin_w.tolist() == [1.0, 2.0, 7.0]
+    # differentiable when the kernel tracks gradients
+    k.requires_grad_(True)
+    try:
+        m._begin()
+        w = sp.dense_lin_w
+        assert w.requires_grad and w is not buf
+        (w * torch.arange(6, dtype=torch.float32)).sum().backward()
+        assert k.grad.reshape(-1).tolist() == [3.0, 4.0, 5.0, 0.0, 1.0]
+    finally:
+        k.requires_grad_(False)
+        k.grad = None
