@@ -181,3 +181,30 @@ def test_host_packer_is_clean_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", LD_LIBRARY_PATH="/opt/rocm/lib" + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_cin_bwd_workspace_is_z_free_on_the_mfma_shapes():
+    """dctr_cin_bwd_workspace_bytes (host arithmetic only): at C3 (B = 4096, F0 = 26, D = 16, CIN[128,128]) the z-free kernels need
+    neither the [B*D, F0*Fk] outer-product buffers nor its gradient — the reference's formulation materialises 436 MB for the second
+    layer alone (interaction.py:288-295); layer widths outside the kernels' shapes keep the GEMM path and its buffers."""
+    import ctypes
+    from deepctr_amd import _C
+    lib = _C.lib()
+    lib.dctr_cin_bwd_workspace_bytes.restype = ctypes.c_size_t
+
+    def need(B, sizes):
+        n = len(sizes)
+        ls = (ctypes.c_int32 * n)(*sizes)
+        fp, bp = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        f = _C.CinArgs(x=None, batch=B, x_stride=432, fields=26, dim=16, n_layers=n, split_half=1, activation=1,
+                       layer_size=ctypes.cast(ls, ctypes.c_void_p), filters=ctypes.cast(fp, ctypes.c_void_p),
+                       bias=ctypes.cast(bp, ctypes.c_void_p), out=None, workspace=None, workspace_bytes=0)
+        a = _C.CinBwdArgs(fwd=ctypes.pointer(f), d_out=None, out_dim=192, dx_accumulate=0, d_filters=None, d_bias=None, dx=None,
+                          dx_stride=0)
+        return lib.dctr_cin_bwd_workspace_bytes(ctypes.byref(a))
+
+    rows = 4096 * 16
+    z_layers = rows * (26 * 26 + 26 * 64) * 4                       # what materialising z costs at C3
+    fused, fallback = need(4096, (128, 128)), need(4096, (120, 120))
+    assert fused < 0.4 * z_layers, (fused, z_layers)
+    assert fallback > z_layers
