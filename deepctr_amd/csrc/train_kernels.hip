@@ -1535,7 +1535,8 @@ extern "C" int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float*
     DCTR_REQUIRE(fwd->n >= 0 && fwd->dim >= 1 && d_stride >= fwd->dim && fwd->vocab >= 1, DCTR_E_DIM, "embed_lookup_bwd: bad sizes");
     if (fwd->n == 0) return DCTR_OK;
     DCTR_REQUIRE(fwd->idx && d_out && g_table, DCTR_E_NULL, "embed_lookup_bwd: null pointer");
-    if (fwd->dim <= 64 && fwd->vocab < 0xffffffffLL && fwd->n >= LB_TILE) {
+    // (dim >= 3: a walker's stretch of LB_TILE / (4 * 64 / dimP) sorted entries must cover its 8-entry load batches)
+    if (fwd->dim >= 3 && fwd->dim <= 64 && fwd->vocab < 0xffffffffLL && fwd->n >= LB_TILE) {
         int dimP = 1;
         while (dimP < fwd->dim) dimP <<= 1;
         const int64_t tiles = dctr_ceil_div(fwd->n, (int64_t)LB_TILE);
