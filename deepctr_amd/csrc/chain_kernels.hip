@@ -4,16 +4,7 @@
 
 namespace dctr_chain {
 
-static int n_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int n_cus() { return dctr_n_cus(); }
 
 // 1: the row-chained kernel can take this call (all of its rows); 0: not eligible
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {

@@ -381,16 +381,7 @@ bool fused_shape_ok(int F0, int Fk, int H) {
            dw_lds_bytes(F0, Fk, H, sd, s0, sk) <= 80 * 1024;
 }
 
-static int n_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    }
-    return n;
-}
+static int n_cus() { return dctr_n_cus(); }
 
 constexpr int DW_TW = 2;      // (i, j-block) tiles per wave
 

@@ -31,6 +31,36 @@ static inline int64_t dctr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) /
 
 #define DCTR_WAVE 64
 
+// Per-DEVICE host caches (a process may drive several GPUs from one thread: engine.on_model_device switches the current
+// device per model).  dctr_cur_device(): the current device clamped into the cache arrays.
+#define DCTR_MAX_DEVICES 32
+static inline int dctr_cur_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < DCTR_MAX_DEVICES ? dev : DCTR_MAX_DEVICES - 1;
+}
+// compute units of the current device (256 on an MI355X)
+static inline int dctr_n_cus() {
+    static int n[DCTR_MAX_DEVICES] = {0};
+    const int dev = dctr_cur_device();
+    if (n[dev] == 0) {
+        hipDeviceProp_t prop;
+        int v = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+        n[dev] = v > 0 ? v : 256;
+    }
+    return n[dev];
+}
+// Raises a kernel's dynamic-LDS limit once per (kernel instantiation, device, size): `granted` is the caller's
+// static thread_local size_t[DCTR_MAX_DEVICES] (the attribute call costs ~10 us).
+static inline hipError_t dctr_grant_lds(const void* fn, size_t bytes, size_t* granted) {
+    const int dev = dctr_cur_device();
+    if (bytes <= granted[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[dev] = bytes;
+    return e;
+}
+
 // Kernel-duration probe (bench / tests): when armed by dctr_profile_next_launch(), the NEXT launch on this
 // host thread goes out through hipExtLaunchKernelGGL with a start/stop event pair, i.e. the GPU timestamps
 // of that dispatch alone (what rocprofv3 --kernel-trace reports), not an event-to-event period that also

@@ -48,7 +48,8 @@ constexpr int NTHREADS = 64 * (NCONS + NLOAD);
 constexpr int ROWS = 64;
 constexpr int NSLOT = 3;
 constexpr int SLOT_F = 4096;                   // floats per ring slot: 4 column blocks x 4 row groups x 256
-constexpr int SPIN_LIMIT = 1 << 18;
+constexpr int SPIN_CHECK = 1 << 10;            // spins between looks at the wall clock
+constexpr unsigned long long WAIT_LIMIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: a hang, not a memory stall
 #ifdef DCTR_STREAM_LAB_NOLIN
 #define DCTR_LAB_LIN 0
 #else
@@ -105,11 +106,20 @@ __device__ __forceinline__ int sync_load(int* p) {
 __device__ __forceinline__ void wait_ge(int* sync, int word, int target, int32_t* status) {
     asm volatile("" ::: "memory");
     int spins = 0;
+    unsigned long long t0 = 0;
     for (;;) {
         const int v = __builtin_amdgcn_readfirstlane(sync_load(sync + word));
         if (v - target >= 0) break;
         if (__builtin_amdgcn_readfirstlane(sync_load(sync + S_ABORT)) != 0) break;
-        if (++spins > SPIN_LIMIT) {
+        // bounded by WALL-CLOCK time (a long but legitimate stall — contended HBM, first-touch page faults, a shared GPU — must
+        // not discard valid work): the clock is read every SPIN_CHECK spins only
+        bool expired = false;
+        if ((++spins & (SPIN_CHECK - 1)) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            expired = now - t0 > WAIT_LIMIT_TICKS;
+        }
+        if (expired) {
             if ((threadIdx.x & 63) == 0) {
                 __hip_atomic_store(sync + S_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (status != nullptr) atomicOr(status, (int)DCTR_STATUS_TIMEOUT);
@@ -667,16 +677,7 @@ __global__ __launch_bounds__(NTHREADS) void stream_kernel(StreamParams p) {
 // ---------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------
-static int n_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int n_cus() { return dctr_n_cus(); }
 
 // 1: the streaming kernel can take this call (the same conditions try_launch applies while it marshals); 0: not eligible
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
@@ -782,15 +783,14 @@ int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_
     p.y = a->y;
     p.probe = a->probe;
     p.n_tiles = (int)n_tiles;
-    static thread_local size_t lds_granted = 0;                       // the attribute call costs ~10 us: once per size
-    if (lds > lds_granted) {
-        hipError_t e = hipFuncSetAttribute((const void*)stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static thread_local size_t lds_granted[DCTR_MAX_DEVICES] = {0};   // the attribute call costs ~10 us: once per device and size
+    {
+        hipError_t e = dctr_grant_lds((const void*)stream_kernel, lds, lds_granted);
         if (e != hipSuccess) {
             dctr_set_error("embed_mlp_fwd: cannot raise dynamic LDS to %zu B: %s", lds, hipGetErrorString(e));
             *rc = (int)e;
             return 1;
         }
-        lds_granted = lds;
     }
     const unsigned blocks = (unsigned)(n_tiles < n_cus() ? n_tiles : n_cus());
     DCTR_LAUNCH(stream_kernel, dim3(blocks), dim3(NTHREADS), lds, stream, p);

@@ -134,6 +134,11 @@ class DNN(Layer):
     def call(self, inputs, training=None, **kwargs):
         if training and self.dropout_rate > 0:
             raise NotImplementedError("dropout is a training-time op; the HIP path is inference (forward) only")
+        if training and self.use_bn:
+            # keras normalises with the BATCH statistics under training=True (core.py:200-201); this call folds the moving
+            # statistics into a scale / shift, which is the inference form only
+            raise NotImplementedError("DNN(use_bn=True).call(training=True): batch-statistics BatchNormalization is a "
+                                      "training-time op; the layer call is the inference form (model.fit() trains)")
         lead = inputs.shape[:-1]
         x2 = inputs.reshape(-1, inputs.shape[-1])
         if len(self.hidden_units) == 0:
@@ -234,6 +239,16 @@ class LocalActivationUnit(Layer):
     def call(self, inputs, training=None, **kwargs):
         query, keys = inputs
         B, T, E = keys.shape
+        if self.use_bn:
+            # the fused attention kernel has no BatchNormalization slot: the reference's op sequence (core.py:94-108) layer by
+            # layer — att_in = [q, k, q - k, q * k] -> DNN (scale / shift of the moving statistics folded in) -> Dense(1)
+            if training:
+                raise NotImplementedError("LocalActivationUnit(use_bn=True).call(training=True): inference form only")
+            q = query.reshape(B, 1, E).expand(B, T, E)
+            att_in = torch.cat([q, keys, q - keys, q * keys], dim=-1).reshape(B * T, 4 * E).contiguous()
+            h = self.dnn(att_in)
+            score = ops.mlp(h, [self.w("kernel")], [self.w("bias")], "linear")
+            return score.reshape(B, T, 1)
         ones = torch.ones(B, T, dtype=torch.uint8, device=keys.device)
         score = ops.din_attention(query, keys, ones, self.dnn.kernels, self.dnn.biases, self.w("kernel"), self.w("bias"),
                                   self.activation, self.dnn.dice_params(), return_score=True)

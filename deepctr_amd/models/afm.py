@@ -50,6 +50,8 @@ class _AFM(FeatureModel):
         if self.use_attention:
             bufs = self._buf.get(B)
             if bufs is None:
+                if len(self._buf) >= 4:            # ragged remainder sizes (N % span) must not pile up per-B buffers
+                    self._buf.clear()
                 bufs = self._buf[B] = [torch.zeros(B, 1, dtype=torch.float32, device=self.device) for _ in self.groups]
             for g, layer, y in zip(self.groups, self.afm_layers, bufs):
                 first, n, dim = sp.group_slices[g]

@@ -87,6 +87,8 @@ class _DIN(FeatureModel):
         B = hi - lo
         bufs = self._buf.get(B)
         if bufs is None:
+            if len(self._buf) >= 4:            # ragged remainder sizes (N % span) must not pile up per-B buffers
+                self._buf.clear()
             bufs = self._buf[B] = dict(
                 q=torch.zeros(B, self.query_dim, dtype=torch.float32, device=self.device),
                 k=torch.zeros(B, self.T, self.key_dim, dtype=torch.float32, device=self.device),

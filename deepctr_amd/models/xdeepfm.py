@@ -45,6 +45,8 @@ class _xDeepFM(FeatureModel):
         if self.cin is not None:
             bufs = self._buf.get(B)
             if bufs is None:
+                if len(self._buf) >= 4:            # ragged remainder sizes (N % span) must not pile up per-B buffers
+                    self._buf.clear()
                 bufs = self._buf[B] = (torch.zeros(B, self.cin_out_dim, dtype=torch.float32, device=self.device),
                                        torch.zeros(B, dtype=torch.float32, device=self.device))
             maps, logit = bufs

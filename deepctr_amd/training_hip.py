@@ -207,14 +207,18 @@ class HipTrainer(object):
             dev = self.model.device
             sp = self.model.stage_plan
             units = [k.shape[1] for k in self.model.dnn.kernels] if self.model.dnn is not None else []
+            if len(self._buf) >= 4:            # ragged remainder sizes (N % span) must not pile up per-B buffers
+                self._buf.clear()
             b = self._buf[B] = {
                 "dstack": torch.empty(B, (self.model.width + 3) // 4 * 4, dtype=torch.float32, device=dev) if self.is_dcn else None,
                 "maps": torch.empty(B, self.model.cin_out_dim, dtype=torch.float32, device=dev) if self.p_cin_f else None,
                 "dmaps": torch.empty(B, self.model.cin_out_dim, dtype=torch.float32, device=dev) if self.p_cin_f else None,
                 "cin_logit": torch.empty(B, dtype=torch.float32, device=dev) if self.p_cin_f else None,
                 # layer activations written by the forward CIN kernel for dctr_cin_bwd (else one recompute GEMM per layer)
+                # (dctr_cin_fwd rejects save_y beyond the 2-GiB buffer-descriptor range: such steps recompute in dctr_cin_bwd)
                 "cin_y": [torch.empty(B * self.model.cin_dim, h, dtype=torch.float32, device=dev)
-                          for h in self.model.cin.layer_size] if self.p_cin_f else None,
+                          for h in self.model.cin.layer_size]
+                if (self.p_cin_f and B * self.model.cin_dim * max(self.model.cin.layer_size) * 4 < 2 ** 31) else None,
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
                 "pred": torch.empty(B, dtype=torch.float32, device=dev),
                 "dlogit": torch.empty(B, dtype=torch.float32, device=dev),

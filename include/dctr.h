@@ -41,7 +41,9 @@ enum {
 
 /* bits OR-ed into the optional device status word by the gather kernels */
 enum {
-    DCTR_STATUS_INDEX_OOR = 1,   /* an id outside [0, vocabulary): its row was treated as zeros                       */
+    DCTR_STATUS_INDEX_OOR = 1,   /* an id outside [0, vocabulary): the outputs of that ROW are unspecified (the stand-alone
+                                    gather substitutes zeros, the fused dctr_embed_mlp_fwd kernels read table row 0); every
+                                    other row is unaffected, no memory outside the tables is touched                  */
     DCTR_STATUS_TIMEOUT = 2      /* a bounded in-kernel wait of the streaming dctr_embed_mlp_fwd kernel expired: the
                                     outputs of that launch are invalid (a defect, reported instead of a hung GPU)     */
 };

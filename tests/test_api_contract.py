@@ -312,3 +312,14 @@ def test_predict_span_rows_rule():
     m.span_rows = 4096
     m.span_batches = False
     assert m._rows_per_launch(Staged(), 256) == 256
+
+
+def test_training_mode_batchnorm_is_refused_not_silently_inference():
+    """DNN(use_bn=True).call(training=True): keras normalises with the batch statistics there (reference layers/core.py:200-201);
+    the layer call only has the inference form, so it must raise instead of silently using the moving statistics."""
+    import pytest
+    import torch
+    from deepctr_amd.layers import DNN
+    layer = DNN((4, 3), use_bn=True, device=torch.device("cpu")).build_for(5)
+    with pytest.raises(NotImplementedError):
+        layer.call(torch.zeros(2, 5), training=True)

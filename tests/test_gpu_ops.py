@@ -615,3 +615,43 @@ def test_embed_lookup_multi(device):
     np.testing.assert_array_equal(k[:, :, 16:].cpu().numpy(), e2.cpu().numpy())
     np.testing.assert_array_equal(m.cpu().numpy(), (m1 & m2).cpu().numpy())
     assert ((s2.cpu().numpy() != 0) == (m2.cpu().numpy() != 0)).all()      # a mask_zero Hash maps only 0 to 0
+
+
+def test_local_activation_unit_use_bn_matches_the_reference_op_sequence(device):
+    """LocalActivationUnit(use_bn=True) (reference layers/core.py:86-108: DNN(..., use_bn) between the attention input and
+    Dense(1)): the fused attention kernel has no BatchNormalization slot, so the layer takes its layer-by-layer form; the
+    scores are those of the float64 restatement with the moving statistics folded in."""
+    import torch
+    from deepctr_amd.layers import LocalActivationUnit
+    from deepctr_amd.layers.base import name_scope
+    from oracle import ref_numpy as R
+    rng = np.random.RandomState(5)
+    B, T, E = 37, 9, 8
+    with name_scope():
+        layer = LocalActivationUnit(hidden_units=(12, 6), activation="sigmoid", use_bn=True, seed=3, device=device)
+        layer.build_for(E)
+    w = {}
+    for name, t in layer.named_weights():
+        if name.endswith("moving_variance") or name.endswith("gamma"):
+            v = (0.5 + rng.rand(*t.shape)).astype(np.float32)
+        else:
+            v = (rng.standard_normal(tuple(t.shape)) * 0.3).astype(np.float32)
+        w[name] = v
+        with torch.no_grad():
+            t.copy_(dev(v, t.device))
+    q = (rng.standard_normal((B, 1, E)) * 0.7).astype(np.float32)
+    k = (rng.standard_normal((B, T, E)) * 0.7).astype(np.float32)
+    y = layer([dev(q, device), dev(k, device)])
+    assert tuple(y.shape) == (B, T, 1)
+    dnn_name = layer.dnn.name
+    bn = [tuple(w["%s/%s" % (b.name, p)].astype(np.float64) for p in ("gamma", "beta", "moving_mean", "moving_variance"))
+          for b in layer.dnn.bn_layers]
+    qq = np.repeat(q.astype(np.float64), T, axis=1)
+    kk = k.astype(np.float64)
+    att_in = np.concatenate([qq, kk, qq - kk, qq * kk], axis=-1)
+    h = R.dnn(att_in, [w["%s/kernel%d" % (dnn_name, i)].astype(np.float64) for i in range(2)],
+              [w["%s/bias%d" % (dnn_name, i)].astype(np.float64) for i in range(2)], "sigmoid", bn_params=bn)
+    ref = np.tensordot(h, w[layer.name + "/kernel"].astype(np.float64), axes=(-1, 0)) + w[layer.name + "/bias"].astype(np.float64)
+    assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-6, what="LocalActivationUnit use_bn")
+    with pytest.raises(NotImplementedError):
+        layer([dev(q, device), dev(k, device)], training=True)
