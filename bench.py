@@ -259,7 +259,11 @@ def main():
         launches.append((lo, lo + nb * B, s0 * B, (s0 + nb) * B))
 
     plans = [model.launch_plan(staged, lo, hi, logits[o0:o1]) if fused else [(hi - lo, "unfused", 0)] for lo, hi, o0, o1 in launches]
-    n_kern = sum(len(pl) for pl in plans) if fused else 2 * len(launches)          # kernel launches of the timed region
+    # kernel launches of the timed region: a call on the row-chained kernel is ONE launch whatever its plan lists (the plan's
+    # entries are the phases of that launch: 256-row passes, then 64-row tail units inside the same kernel)
+    def launches_of(pl):
+        return 1 if all(k == "chain" for _, k, _ in pl) else len(pl)
+    n_kern = sum(launches_of(pl) for pl in plans) if fused else 2 * len(launches)
     if fused:                                  # argument structs marshalled before the timed region: one ctypes call per launch
         prepared = [model.prepare_launch(staged, lo, hi, logits[o0:o1]) for lo, hi, o0, o1 in launches]
     else:
@@ -372,7 +376,12 @@ def main():
         value = world * B * K / elapsed if K else 0.0
         # kernel launches of the region in issue order <-> their event-pair durations; the dominant kernel = the kernel
         # launch that covers the most rows of a call (the 256-row shape of the row-chained kernel when the call has one)
-        flat = [(ci, r, kname, rpw) for ci, pl in enumerate(plans) for (r, kname, rpw) in pl]
+        flat = []
+        for ci, pl in enumerate(plans):
+            if launches_of(pl) == 1 and len(pl) > 1:            # one row-chained launch: all rows of the call, main-phase shape
+                flat.append((ci, sum(r for r, _, _ in pl), pl[0][1], pl[0][2]))
+            else:
+                flat.extend((ci, r, kname, rpw) for (r, kname, rpw) in pl)
         timed = [(ci, r, kname, rpw, t) for (ci, r, kname, rpw), t in zip(flat, launch_s) if t is not None] if fused else []
         kernels, kernel_launches = [], []
         rows_call = (launches[0][1] - launches[0][0]) if launches else 0
@@ -391,8 +400,10 @@ def main():
         if t_launch is not None:
             tf = DNN_FLOP_PER_SAMPLE * rows_launch / t_launch / 1e12
             gbs = ALG_BYTES_PER_SAMPLE * rows_launch / t_launch / 1e9
-            label = {"chain": "chain_kernel (dctr_embed_mlp_fwd row-chained, %d rows per workgroup, %d rows per launch: ids -> "
-                              "registers -> DNN (weights through an LDS-DMA ring) -> head)" % (dom_rpw, rows_launch),
+            label = {"chain": "chain_kernel (dctr_embed_mlp_fwd row-chained, ONE launch of %d rows: %s; ids -> registers -> DNN "
+                              "(weights through an LDS-DMA ring) -> head)" % (
+                                  rows_launch, " + ".join("%d rows in %d-row %s" % (r, w, "passes" if w != 64 else "tail units")
+                                                          for r, _, w in plans[0])),
                      "stream": "stream_kernel (dctr_embed_mlp_fwd, %d rows per launch: ids -> LDS-DMA ring -> DNN -> head)" % rows_launch,
                      "tile": "mlp_kernel, fused gather (dctr_embed_mlp_fwd, %d rows per launch)" % rows_launch}[dom_name]
             kernels.append({"kernel": label,
@@ -438,7 +449,7 @@ def main():
                                    "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, ids %s, ring of %d "
                                    "distinct batches, the K steps issued as %d call(s) of %d consecutive batches (%s)" % (
                                        args.dist, ring, len(launches), G,
-                                       "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(len(pl)) for pl in plans[:1]) if fused
+                                       "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(launches_of(pl)) for pl in plans[:1]) if fused
                                        else "2 launches per span"),
                        "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
                        "parallelism": "row-sharded x%d, tables replicated, one all-gather of the logits" % world},

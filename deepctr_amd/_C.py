@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
@@ -49,7 +49,7 @@ class GatherFmArgs(ctypes.Structure):
                 ("any_hash", c_i32), ("n_dense", c_i32), ("dense", c_vp), ("dense_stride", c_i64),
                 ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("dense_copy_cols", c_i32), ("batch", c_i64),
                 ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp),
-                ("split_col", c_i32), ("split_field", c_i32), ("uniform_dim", c_i32), ("reserved_", c_i32)]
+                ("split_col", c_i32), ("split_field", c_i32), ("uniform_dim", c_i32), ("any_identity", c_i32)]
 
 
 class PoolArgs(ctypes.Structure):
@@ -183,6 +183,7 @@ SYMBOLS = {
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
     "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),
+    "dctr_embed_mlp_fwd_last_kernel": (ctypes.c_int, []),
     "dctr_embed_mlp_fwd_plan": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), ctypes.POINTER(ctypes.c_int64),
                                                ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_i32]),
     "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),

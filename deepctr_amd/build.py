@@ -32,9 +32,11 @@ SOURCES = [
     "mlp_kernels_rt4.hip",
     "stream_kernels.hip",
     "chain_kernels.hip",
-    "chain_kernels_r2w8.hip",
-    "chain_kernels_r2w4.hip",
-    "chain_kernels_r1w4.hip",
+    "chain_kernels_r2w8_m42.hip",
+    "chain_kernels_r2w8_m41.hip",
+    "chain_kernels_r2w8_m22.hip",
+    "chain_kernels_r2w8_m21.hip",
+    "chain_kernels_r2w4_m42.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "cin_bwd_kernels.hip",

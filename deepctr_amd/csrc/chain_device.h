@@ -27,9 +27,16 @@
 // 8 waves x 32 rows = 256 rows per pass and CU; registers: 128 (layer-0 accumulators: 16 M-tiles x 2 N-tiles) + 64
 // (layer 1) + operand staging -> two waves per SIMD.
 //
-// Eligibility (host, below): uniform embedding_dim 16 or 32, no hashing / identity fields, dense columns right behind the
-// embeddings, every units[l] a multiple of 64 from the instantiated set, ReLU or linear activation, a head, no
-// BatchNormalization / saved activations, and at least 64 rows per CU (or tile_rows 128 / 256).  Everything else takes stream_kernel / mlp_kernel.
+// One launch = a MAIN phase (256-row passes, 8 waves x 32 rows, persistent workgroups) + a TAIL phase in the same kernel: what
+// is left when the rows do not fill every CU with 256 goes out in 64-row units (waves 0-3 x 16 rows; waves 4-7 leave — the
+// hardware barrier counts the surviving waves only), each workgroup taking its units round-robin.  No second launch, no launch
+// gap, the parameters are already in LDS.  Both phases walk k in the same order: a row's bits do not depend on its phase.
+//
+// Eligibility (host, chain_kernels.hip): uniform embedding_dim 16 or 32 (fixed-length SparseFeat, or fields pre-pooled by
+// dctr_embed_pool = identity fields, whose row is the sample index), no in-kernel hashing, dense columns right behind the
+// embeddings, two or three layers with units[0] in {128, 256}, units[1] in {64, 128}, units[2] in {64, 128}, ReLU or linear
+// activation, a head, optional BatchNormalization scale / shift (inference form), no saved activations, and at least 64 rows
+// per CU (or tile_rows 128 / 256).  Everything else takes stream_kernel / mlp_kernel.
 // Same arithmetic as those: v_mfma_f32_16x16x4_f32 = exact fp32; only the summation order over k differs.
 #pragma once
 #include "mlp_device.h"
@@ -41,6 +48,13 @@ __device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][s
 #else
 #define CTS(i) do {} while (0)
 #define CTS_STEP(b, k) do {} while (0)
+#endif
+
+#ifdef DCTR_CHAIN_LAB_WGTS    // lab: wall-clock stamps per workgroup (kernel entry, end of the main phase, end of the tail phase)
+__device__ unsigned long long dctr_chain_wgts[1024][4];
+#define CWG(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) dctr_chain_wgts[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define CWG(i) do {} while (0)
 #endif
 
 // lab ablations (scripts/chain_lab.cpp): what a step costs without its gather / its weight DMA / its barrier
@@ -74,10 +88,10 @@ using namespace dctr_mlp;
 // does not depend on the shape (or the position) it was computed in.
 constexpr int NSLOT = 3;
 constexpr int SLOT_F = 4096;                   // floats per ring chunk (16 KiB)
-constexpr int CPAR_OFF = 0;                    // biases of every layer, head weights (<= 1024 floats)
-constexpr int FDESC_OFF = 1024;                // [n_fields <= 64][12 dwords]
-constexpr int DLW_OFF = 1792;                  // dense_lin_w (<= 256 floats, zeros when absent)
-constexpr int RING_OFF = 2048;
+constexpr int CPAR_OFF = 0;                    // biases of every layer, head weights, BatchNormalization scale / shift (<= 2048 floats)
+constexpr int FDESC_OFF = 2048;                // [n_fields <= 64][12 dwords]
+constexpr int DLW_OFF = 2816;                  // dense_lin_w (<= 256 floats, zeros when absent)
+constexpr int RING_OFF = 3072;
 constexpr int DENSE_OFF = RING_OFF + NSLOT * SLOT_F;   // [rows of a pass][16 * dense k-blocks] zero-padded dense values of the pass
 constexpr int MAX_DENSE_BLOCKS = 4;
 // + [NW waves][RT N tiles][64 lanes] shares of dense . dense_lin_w of the staged pass
@@ -112,7 +126,11 @@ struct ChainParams {
     const float* global_bias;
     float* y;
     unsigned long long* probe;
-    int32_t n_pass;
+    int32_t n_pass;                // main phase: passes of 16 * RT * NW rows over rows [0, main_rows)
+    int32_t n_tail;                // tail phase (kernels instantiated with TAIL): 64-row units over rows [main_rows, batch)
+    int64_t main_rows;
+    const float* bn_scale[3];      // DNN(use_bn=True), inference form: act((x W + b) * bn_scale + bn_shift); NULL = none
+    const float* bn_shift[3];
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -174,6 +192,31 @@ __device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][RT]) {
             for (int r = 0; r < 4; ++r) acc[m][nt][r] = fmaxf(acc[m][nt][r], floor_);
 }
 
+// BatchNormalization (inference form) of a whole accumulator set in place, between bias_add and the activation (reference
+// layers/core.py:200-201): acc = acc * scale + shift per output feature; register r of M-tile mt of M-group mg holds feature
+// 64 mg + 16 g + 4 r + mt (the layout the biases are loaded in)
+template <int NM, int RT>
+__device__ __forceinline__ void bn_block(const float* sc, const float* sh, int g, f32x4 (&acc)[NM][RT]) {
+#pragma unroll
+    for (int mg = 0; mg < NM / 4; ++mg) {
+        float sv[16], tv[16];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const float4 a = *reinterpret_cast<const float4*>(sc + 64 * mg + 16 * g + 4 * qq);
+            const float4 b = *reinterpret_cast<const float4*>(sh + 64 * mg + 16 * g + 4 * qq);
+            sv[4 * qq] = a.x; sv[4 * qq + 1] = a.y; sv[4 * qq + 2] = a.z; sv[4 * qq + 3] = a.w;
+            tv[4 * qq] = b.x; tv[4 * qq + 1] = b.y; tv[4 * qq + 2] = b.z; tv[4 * qq + 3] = b.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[4 * mg + mt][nt][r] = fmaf(acc[4 * mg + mt][nt][r], sv[4 * r + mt], tv[4 * r + mt]);
+    }
+}
+
 // the gathered operand of one k-block for this lane: 16-B piece g of row j's embedding per N tile
 template <int RT>
 struct XBlkT {
@@ -189,29 +232,38 @@ struct XBlkT {
 #define CHAIN_MIN_BLOCKS(RT, NW) 1
 #define CHAIN_PARK(RT, NW) true
 #endif
+// parameter-area offsets (floats) shared by the kernel's once-per-launch loads and the passes
+template <int M0, int M1, int M2>
+struct ChainOff {
+    static constexpr int ML = M2 > 0 ? M2 : M1;
+    static constexpr int B1 = 64 * M0, B2 = B1 + 64 * M1, HW = B2 + 64 * M2, GB = HW + 64 * ML;
+    static constexpr int BN_S = GB + 16;                           // scale of layer 0, 1, 2, then the shifts
+    static constexpr int BN_T = BN_S + 64 * (M0 + M1 + M2);
+    static constexpr int END = BN_T + 64 * (M0 + M1 + M2);
+};
+
+// The passes [first, first + stride, ...) < n_pass of one phase: pass q covers rows row_base + q * (16 RT NW) ... of the launch
+// (absolute row numbers; rows >= row_end do not exist).  Called by all NW waves of the phase, with the launch parameters in LDS.
 template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2>
-__global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
-    constexpr int NT = 64 * NW;
+__device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
+                                             const int row_end, const int first, const int stride, const int n_pass, int& oor) {
+    if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
     constexpr int WROWS = 16 * RT;                 // batch rows of a wave
     constexpr int PROWS = NW * WROWS;              // batch rows per pass
     typedef XBlkT<RT> XBlk;
-    constexpr int NL = M2 > 0 ? 3 : 2;
-    constexpr int ML = NL == 3 ? M2 : M1;          // M-groups of the last layer
     constexpr int S1 = M0 * M1, S2 = M1 * M2;      // chunks (= steps) of layers 1 and 2
     constexpr int SL = S1 + S2;
     static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
     constexpr int E = 16 * EB;
     constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair
-    constexpr int B1_OFF = 64 * M0, B2_OFF = B1_OFF + 64 * M1, HW_OFF = B2_OFF + 64 * M2, GB_OFF = HW_OFF + 64 * ML;
-    static_assert(GB_OFF < FDESC_OFF, "biases + head weights + global bias must fit the parameter area");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef ChainOff<M0, M1, M2> Off;
+    constexpr int B1_OFF = Off::B1, B2_OFF = Off::B2, HW_OFF = Off::HW, GB_OFF = Off::GB;
+    static_assert(Off::END <= FDESC_OFF, "biases + head weights + global bias + BatchNormalization must fit the parameter area");
     float* cpar = smem + CPAR_OFF;
     float* fdesc = smem + FDESC_OFF;
     float* dlw = smem + DLW_OFF;
     float* ring = smem + RING_OFF;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
+    const int g = lane >> 4, j = lane & 15;
     // per-lane constants of cold or once-per-pair code are rebuilt from an opaque copy of the lane index: as invariants of the
     // k-loop they would be hoisted, kept live across it, and push accumulators into scratch
     auto opaque_lane = [&]() -> int {
@@ -219,17 +271,6 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
         asm volatile("" : "+v"(ln));
         return ln;
     };
-
-    // ---- once per launch: descriptors, biases, head weights, dense linear weights -> LDS
-    for (int i = threadIdx.x; i < 12 * p.n_fields; i += NT)
-        reinterpret_cast<uint32_t*>(fdesc)[i] = reinterpret_cast<const uint32_t*>(p.fields)[i];
-    for (int i = threadIdx.x; i < 64 * M0; i += NT) cpar[i] = p.bias[0] != nullptr ? p.bias[0][i] : 0.f;
-    for (int i = threadIdx.x; i < 64 * M1; i += NT) cpar[B1_OFF + i] = p.bias[1] != nullptr ? p.bias[1][i] : 0.f;
-    if constexpr (M2 > 0)
-        for (int i = threadIdx.x; i < 64 * M2; i += NT) cpar[B2_OFF + i] = p.bias[2] != nullptr ? p.bias[2][i] : 0.f;
-    for (int i = threadIdx.x; i < 64 * ML; i += NT) cpar[HW_OFF + i] = p.head_w[i];
-    if (threadIdx.x == 0) cpar[GB_OFF] = p.global_bias != nullptr ? p.global_bias[0] : 0.f;
-    for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
 
     const int NBE = p.n_fields * EB;               // embedding k-blocks
     const int NB = (p.in_dim + 15) >> 4;           // k-blocks of the DNN input (= steps of layer 0)
@@ -317,14 +358,13 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
     // the host).  Ids and linear-table entries are handled ROW PER LANE for a PAIR of fields at once: lane l = row (l & 31)
     // of field 2 pr + (l >> 5) — one id load, one range check, one linear-table load per field pair instead of per k-block
     // and N tile; a k-block's ids reach the (g, j) lanes through ds_bpermute (the LDS crossbar, no memory traffic)
-    auto row_of = [&](int pass, int nt) -> int { return pass * PROWS + WROWS * wave + 16 * nt + j; };
-    auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), (int)p.batch - 1); };
-    int oor = 0;
+    auto row_of = [&](int pass, int nt) -> int { return row_base + pass * PROWS + WROWS * wave + 16 * nt + j; };
+    auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), row_end - 1); };
     // request the ids of field pair pr for the rows of `pass`
     auto request_pair_ids = [&](int pr, int pass, uint32_t& lo, uint32_t& hi) {
         const int ln = opaque_lane(), q = ln >> 5;
         const int fi = min(2 * pr + q, p.n_fields - 1);
-        const int r = min(pass * PROWS + WROWS * wave + min(ln & 31, WROWS - 1), (int)p.batch - 1);
+        const int r = min(row_base + pass * PROWS + WROWS * wave + min(ln & 31, WROWS - 1), row_end - 1);
         const int64_t eo = (int64_t)fi * p.ids_stride_f + (int64_t)r * p.ids_stride_b;
         if constexpr (I64) {
             const u32x2 v = *(gbl_u2_t)(reinterpret_cast<const u32x2*>(p.ids) + eo);
@@ -344,11 +384,16 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
         const uint32_t lim_a = (voc_a >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_a;
         const uint32_t lim_b = (voc_b >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_b;
         const uint32_t lim = q ? lim_b : lim_a;
+        // identity fields (pre-pooled by dctr_embed_pool: dctr_field_t.identity): the row is the sample's index in the launch
+        const uint32_t id_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(fdesc)[12 * fa + 10]);
+        const uint32_t id_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(fdesc)[12 * fb + 10]);
+        const bool ident = (q ? id_b : id_a) != 0u;
+        const int rr = row_base + pass * PROWS + WROWS * wave + (ln & 31);
         const uint32_t upper = I64 ? hi : (uint32_t)((int32_t)lo >> 31);      // anything but 0: negative or >= 2^32
-        const bool ok = upper == 0u && lo < lim;
-        const bool counts = (ln & 31) < WROWS && pass * PROWS + WROWS * wave + (ln & 31) < (int)p.batch && 2 * pr + q < p.n_fields;
+        const bool ok = ident || (upper == 0u && lo < lim);
+        const bool counts = (ln & 31) < WROWS && rr < row_end && 2 * pr + q < p.n_fields;
         if (__any(!ok && counts)) oor = 1;                 // (wave-uniform flag: a scalar register, not a VGPR)
-        return ok ? lo : 0u;
+        return ident ? (uint32_t)min(rr, row_end - 1) : (ok ? lo : 0u);
     };
     // linear-table entries of the pair (row per lane); fields without a linear table, or past the last field, give 0
     auto pair_lin_ptr = [&](int pr, uint32_t idc, bool& has) -> gbl_f_t {
@@ -445,11 +490,10 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
         XA.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         XB.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();                                   // LDS parameters written
     // in_fm of every field as one scalar bit mask (n_fields <= 64)
     const uint64_t fm_mask = __ballot(lane < p.n_fields && reinterpret_cast<const uint32_t*>(fdesc)[12 * min(lane, p.n_fields - 1) + 8] != 0u);
     {
-        const int pass0 = min((int)blockIdx.x, p.n_pass - 1);
+        const int pass0 = first;
         dma_chunk(0, slot_ptr(0));
         dma_chunk(1, slot_ptr(1));
         request_pair_ids(0, pass0, idr_lo, idr_hi);
@@ -470,10 +514,10 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
     // memory address path does not get all eight waves' requests in one burst (it has no register results, so placing it
     // twice costs nothing; the gather part placed twice merges in-flight registers of the two placements and spills).
     const bool dma_early = wave < NW / 2;
-    for (int it = 0, pass = blockIdx.x; pass < p.n_pass; ++it, pass += gridDim.x) {
+    for (int it = 0, pass = first; pass < n_pass; ++it, pass += stride) {
         constexpr int PH = 0;
         (void)it;
-        const int pass_n = min(pass + (int)gridDim.x, p.n_pass - 1);     // rows the gather prologue at the pass's end is for
+        const int pass_n = min(pass + stride, n_pass - 1);               // rows the gather prologue at the pass's end is for
         CTS(0);
         // ================= layer 0: acc0[4 mg + mt][nt] = C tile of output features 64 mg + 4 i + mt
         f32x4 acc0[4 * M0][RT];
@@ -629,13 +673,14 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
                 const float lin_all = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * nt + j), __builtin_bit_cast(int, lin_rows))) + dl;
                 extras[nt] = (p.fm_used ? fm : 0.f) + (p.lin_used ? lin_all : 0.f);
                 const int r = row_of(pass, nt);
-                if (g == 0 && r < (int)p.batch) {
+                if (g == 0 && r < row_end) {
                     if (p.fm_logit != nullptr) p.fm_logit[r] = fm;
                     if (p.lin_logit != nullptr) p.lin_logit[r] = lin_all;
                 }
             }
         }
-        // activation in place: acc0 is now the B operand of layer 1
+        // (BatchNormalization scale / shift,) activation in place: acc0 is now the B operand of layer 1
+        if (p.bn_scale[0] != nullptr) bn_block<4 * M0, RT>(cpar + Off::BN_S, cpar + Off::BN_T, g, acc0);
         act_block<4 * M0, RT>(p.activation, acc0);
         if constexpr (M0 > 1 && CHAIN_PARK(RT, NW)) {
             f32x4* park = park_ptr();
@@ -738,8 +783,9 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
         CTS(2);
         float hs[RT];
         // head of the last layer: act(acc) . head_w over this lane's 16 features per M-group, then over g
-        auto head = [&](auto& acc, auto MGc) {
+        auto head = [&](auto& acc, auto MGc, int layer, int bn_off) {
             constexpr int MG = decltype(MGc)::value;
+            if (p.bn_scale[layer] != nullptr) bn_block<4 * MG, RT>(cpar + Off::BN_S + bn_off, cpar + Off::BN_T + bn_off, g, acc);
             act_block<4 * MG, RT>(p.activation, acc);
 #pragma unroll
             for (int nt = 0; nt < RT; ++nt) hs[nt] = 0.f;
@@ -761,14 +807,15 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
             }
         };
         if constexpr (M2 > 0) {
+            if (p.bn_scale[1] != nullptr) bn_block<4 * M1, RT>(cpar + Off::BN_S + 64 * M0, cpar + Off::BN_T + 64 * M0, g, acc1);
             act_block<4 * M1, RT>(p.activation, acc1);
             f32x4 acc2[4 * (M2 > 0 ? M2 : 1)][RT];
             init_acc(acc2, B2_OFF, std::integral_constant<int, M2>{});
             dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{}, std::false_type{});
             mfma_drain();
-            head(acc2, std::integral_constant<int, M2>{});
+            head(acc2, std::integral_constant<int, M2>{}, 2, 64 * (M0 + M1));
         } else {
-            head(acc1, std::integral_constant<int, M1>{});
+            head(acc1, std::integral_constant<int, M1>{}, 1, 64 * M0);
         }
         CTS(3);
         // ---- Dense(1) + linear / FM logits + add[] + global bias, PredictionLayer
@@ -779,7 +826,7 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
             v += __shfl_xor(v, 32, 64);
             v += extras[nt];
             const int r = row_of(pass, nt);
-            if (g == 0 && r < (int)p.batch) {
+            if (g == 0 && r < row_end) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (p.add[i] != nullptr) v += p.add[i][r];
@@ -793,15 +840,71 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
 #undef CHAIN_TOP_X
 #undef CHAIN_TOP_ID
 #undef CHAIN_TOP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wrapped-around DMA of the last pass must not outlive the wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wrapped-around DMA of the last pass must not outlive the phase
+}
+
+// RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL>
+__global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
+    constexpr int NT = 64 * NW;
+    typedef ChainOff<M0, M1, M2> Off;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cpar = smem + CPAR_OFF;
+    float* fdesc = smem + FDESC_OFF;
+    float* dlw = smem + DLW_OFF;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
+    CWG(0);
+    // ---- once per launch: descriptors, biases, head weights, BatchNormalization scale / shift, dense linear weights -> LDS
+    for (int i = threadIdx.x; i < 12 * p.n_fields; i += NT)
+        reinterpret_cast<uint32_t*>(fdesc)[i] = reinterpret_cast<const uint32_t*>(p.fields)[i];
+    for (int i = threadIdx.x; i < 64 * M0; i += NT) cpar[i] = p.bias[0] != nullptr ? p.bias[0][i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * M1; i += NT) cpar[Off::B1 + i] = p.bias[1] != nullptr ? p.bias[1][i] : 0.f;
+    if constexpr (M2 > 0)
+        for (int i = threadIdx.x; i < 64 * M2; i += NT) cpar[Off::B2 + i] = p.bias[2] != nullptr ? p.bias[2][i] : 0.f;
+    for (int i = threadIdx.x; i < 64 * Off::ML; i += NT) cpar[Off::HW + i] = p.head_w[i];
+    if (threadIdx.x == 0) cpar[Off::GB] = p.global_bias != nullptr ? p.global_bias[0] : 0.f;
+    {
+        constexpr int MS[3] = {M0, M1, M2};
+        int off = 0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            if (MS[l] > 0 && p.bn_scale[l] != nullptr)
+                for (int i = threadIdx.x; i < 64 * MS[l]; i += NT) {
+                    cpar[Off::BN_S + off + i] = p.bn_scale[l][i];
+                    cpar[Off::BN_T + off + i] = p.bn_shift[l] != nullptr ? p.bn_shift[l][i] : 0.f;
+                }
+            off += 64 * MS[l];
+        }
+    }
+    for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
+    __syncthreads();                                   // LDS parameters written
+    int oor = 0;
+    const int main_end = (int)(TAIL ? p.main_rows : p.batch);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    CWG(1);
+    if constexpr (TAIL) {
+        if (p.n_tail > 0) {
+            // every wave is through with the ring and the staging areas of the main phase; waves 4.. leave (s_barrier waits for
+            // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
+            __syncthreads();
+            if (wave < 4)
+                chain_passes<1, 4, EB, I64, M0, M1, M2>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x, (int)gridDim.x,
+                                                        p.n_tail, oor);
+        }
+    }
+    CWG(2);
     if (p.status != nullptr && oor && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
     if (p.probe != nullptr && lane == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
 }
 
 
-// launchers, one translation unit per launch shape (chain_kernels_r{RT}w{NW}.hip)
-int launch_r2w8(const ChainParams& p, int E, unsigned blocks, hipStream_t stream);
-int launch_r2w4(const ChainParams& p, int E, unsigned blocks, hipStream_t stream);
-int launch_r1w4(const ChainParams& p, int E, unsigned blocks, hipStream_t stream);
+// launchers, one translation unit per launch shape and (units[0], units[1]) (chain_kernels_r{RT}w{NW}_m{M0}{M1}.hip); M2 = units[2] / 64
+int launch_r2w8_m42(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
+int launch_r2w8_m41(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
+int launch_r2w8_m22(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
+int launch_r2w8_m21(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
+int launch_r2w4_m42(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
 
 }  // namespace dctr_chain

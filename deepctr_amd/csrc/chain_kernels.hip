@@ -1,18 +1,31 @@
-// dctr_embed_mlp_fwd, row-chained form: eligibility, the split of a launch into launch shapes, argument marshalling.
-// Kernel: chain_device.h, instantiated per launch shape in chain_kernels_r{2w8,2w4,1w4}.hip.
+// dctr_embed_mlp_fwd, row-chained form: eligibility, the split of a call into the kernel's main and tail phases, argument
+// marshalling.  Kernel: chain_device.h, instantiated per launch shape and layer widths in chain_kernels_r{2w8,2w4}_m*.hip.
 #include "chain_device.h"
 
 namespace dctr_chain {
 
 static int n_cus() { return dctr_n_cus(); }
 
+// units -> (M0, M1, M2) of an instantiated kernel, or false
+static bool widths(const dctr_mlp_args_t* a, int shape, int* M) {
+    if (a->n_layers != 2 && a->n_layers != 3) return false;
+    const int u0 = a->units[0], u1 = a->units[1], u2 = a->n_layers == 3 ? a->units[2] : 0;
+    if ((u0 != 128 && u0 != 256) || (u1 != 64 && u1 != 128) || (u2 != 0 && u2 != 64 && u2 != 128)) return false;
+    if (shape == 128 && !(u0 == 256 && u1 == 128 && u2 == 64)) return false;     // the diagnostic shape: units 256-128-64 only
+    M[0] = u0 / 64;
+    M[1] = u1 / 64;
+    M[2] = u2 / 64;
+    return true;
+}
+
 // 1: the row-chained kernel can take this call (all of its rows); 0: not eligible
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
     const int E = g->uniform_dim;
     if (E != 16 && E != 32) return 0;
     if (g->any_hash || !a->has_head || a->save_acts != nullptr) return 0;
-    if ((a->activation != DCTR_ACT_RELU && a->activation != DCTR_ACT_LINEAR) || a->bn_scale != nullptr) return 0;
-    if (a->n_layers != 3 || a->units[0] != 256 || a->units[1] != 128 || a->units[2] != 64) return 0;
+    if (a->activation != DCTR_ACT_RELU && a->activation != DCTR_ACT_LINEAR) return 0;
+    int M[3];
+    if (!widths(a, forced ? a->tile_rows : 0, M)) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
     if (a->in_dim != g->n_fields * E + (g->n_dense > 0 ? g->n_dense : 0)) return 0;
@@ -25,72 +38,47 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     return 1;
 }
 
-static int launch_shape(int rt, int nw, const ChainParams& p, int E, hipStream_t stream) {
-    const int64_t n_pass = dctr_ceil_div(p.batch, (int64_t)(16 * rt * nw));
-    ChainParams q = p;
-    q.n_pass = (int)n_pass;
-#ifdef DCTR_CHAIN_W4X2
-    const int64_t slots = (rt == 2 && nw == 4) ? 2 * (int64_t)n_cus() : n_cus();
-#else
-    const int64_t slots = n_cus();
-#endif
-    const unsigned blocks = (unsigned)(n_pass < slots ? n_pass : slots);
-    if (rt == 2 && nw == 8) return launch_r2w8(q, E, blocks, stream);
-    if (rt == 2 && nw == 4) return launch_r2w4(q, E, blocks, stream);
-    return launch_r1w4(q, E, blocks, stream);
+// How a call of `batch` rows runs (shape 0 = auto): ONE launch of the <2, 8> kernel; its main phase takes the whole multiples of
+// 256 rows x CUs (every CU the same number of 256-row passes), what is left — L < 256 x CUs rows — goes to the tail phase as 64-row
+// units when that finishes sooner than one more (partly filled) round of 256-row passes.  Relative times (measured, C2): a 256-row
+// pass = 1; a 64-row tail unit ~ TAIL_COST (one wave per SIMD: nothing hides a wave's request phase): L <= 64 x CUs x k rows cost
+// k x TAIL_COST.  shape 256: everything in 256-row passes; shape 128: the <2, 4> kernel (its own launch).
+constexpr double TAIL_COST = 0.31;
+static void split(int64_t batch, int shape, int64_t* main_rows, int64_t* tail_rows) {
+    const int64_t cus = n_cus();
+    if (shape == 256 || shape == 128) {
+        *main_rows = batch;
+        *tail_rows = 0;
+        return;
+    }
+    const int64_t full = batch / (256 * cus) * (256 * cus);
+    const int64_t left = batch - full;
+    const int64_t rounds = dctr_ceil_div(left, 64 * cus);
+    if (left > 0 && TAIL_COST * (double)rounds < 1.0) {
+        *main_rows = full;
+        *tail_rows = left;
+    } else {
+        *main_rows = batch;
+        *tail_rows = 0;
+    }
 }
 
-// rows [0, n) of p as their own launch (pointers advanced)
-static ChainParams slice(const ChainParams& p, int64_t r0, int64_t n) {
-    ChainParams q = p;
-    q.ids = reinterpret_cast<const char*>(p.ids) + r0 * p.ids_stride_b * (p.ids_is_i64 ? 8 : 4);
-    q.dense = p.dense != nullptr ? p.dense + r0 * p.dense_stride : nullptr;
-    q.fm_logit = p.fm_logit != nullptr ? p.fm_logit + r0 : nullptr;
-    q.lin_logit = p.lin_logit != nullptr ? p.lin_logit + r0 : nullptr;
-    for (int i = 0; i < 4; ++i) q.add[i] = p.add[i] != nullptr ? p.add[i] + r0 : nullptr;
-    q.y = p.y + r0;
-    q.batch = n;
-    return q;
-}
-
-// The launches of a call of `batch` rows: (rows, batch rows per workgroup = 256 / 128 / 64 <-> shapes <2,8> / <2,4> / <1,4>).
-// shape 256 / 128: that shape for all rows (forced); 0: whole multiples of 256 rows x CUs as <2, 8> launches (every CU the same
-// number of passes), the rest cut into the shapes that finish it soonest.  Relative pass times (measured, C2): a <2, 8> pass of
-// 256 rows = 1 (162 us); a <2, 4> pass of 128 rows ~ 0.60 (one wave per SIMD: the matrix pipe is not shared, but nothing hides a
-// wave's request phase either); a <1, 4> pass of 64 rows ~ 0.39.
+// dctr_embed_mlp_fwd_plan: the phases of the ONE launch as (rows, batch rows per workgroup) entries — 256: main phase (or the
+// forced <2, 8> shape), 128: the forced <2, 4> shape, 64: tail phase
 int plan(int64_t batch, int shape, int64_t* rows, int32_t* rpw, int max) {
     int n = 0;
     auto push = [&](int64_t r, int w) {
         if (n < max) { rows[n] = r; rpw[n] = w; }
         ++n;
     };
-    if (shape == 256 || shape == 128) {
-        push(batch, shape);
-        return n;
-    }
-    const int64_t cus = n_cus();
-    const int64_t full = batch / (256 * cus) * (256 * cus);
-    if (full > 0) push(full, 256);
-    int64_t left = batch - full;
-    while (left > 0) {
-        // cost of finishing `left` rows with one shape (in <2, 8> pass times); the cheapest one takes as many whole rounds
-        // over the CUs as it has, the loop goes on with what is left
-        const double c28 = (double)dctr_ceil_div(left, 256 * cus);
-        const double c24 = 0.60 * (double)dctr_ceil_div(left, 128 * cus);
-        const double c14 = 0.39 * (double)dctr_ceil_div(left, 64 * cus);
-        int w = 256;
-        if (c24 < c28 && c24 <= c14) w = 128;
-        else if (c14 < c28 && c14 < c24) w = 64;
-        const int64_t round_rows = (int64_t)w * cus;
-        int64_t take = left / round_rows * round_rows;
-        if (take == 0) take = left;
-        push(take, w);
-        left -= take;
-    }
+    int64_t main_rows, tail_rows;
+    split(batch, shape, &main_rows, &tail_rows);
+    if (main_rows > 0) push(main_rows, shape == 128 ? 128 : 256);
+    if (tail_rows > 0) push(tail_rows, 64);
     return n;
 }
 
-// The whole call on the row-chained kernel, launch by launch of plan().
+// The whole call on the row-chained kernel: one launch.
 int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int shape, hipStream_t stream) {
     ChainParams p{};
     p.fields = g->fields;
@@ -110,9 +98,16 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     p.status = g->status;
     p.fm_used = fm_used;
     p.lin_used = lin_used;
-    for (int l = 0; l < 3; ++l) {
+    int M[3] = {0, 0, 0};
+    if (!widths(a, shape, M)) {
+        dctr_set_error("embed_mlp_fwd(chain): layer widths not instantiated");
+        return DCTR_E_UNSUPPORTED;
+    }
+    for (int l = 0; l < a->n_layers; ++l) {
         p.W[l] = a->kernels[l];
         p.bias[l] = a->biases[l];
+        p.bn_scale[l] = a->bn_scale != nullptr ? a->bn_scale[l] : nullptr;
+        p.bn_shift[l] = (a->bn_scale != nullptr && a->bn_shift != nullptr) ? a->bn_shift[l] : nullptr;
     }
     p.activation = a->activation;
     p.sigmoid_out = a->sigmoid_out;
@@ -122,16 +117,22 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     p.y = a->y;
     p.probe = a->probe;
     const int E = g->uniform_dim;
-    int64_t rows[16];
-    int32_t rpw[16];
-    const int n = plan(p.batch, shape, rows, rpw, 16);
-    int64_t r0 = 0;
-    for (int i = 0; i < n; ++i) {
-        const int rc = launch_shape(rpw[i] == 64 ? 1 : 2, rpw[i] == 256 ? 8 : 4, slice(p, r0, rows[i]), E, stream);
-        if (rc != DCTR_OK) return rc;
-        r0 += rows[i];
-    }
-    return DCTR_OK;
+    int64_t main_rows, tail_rows;
+    split(p.batch, shape, &main_rows, &tail_rows);
+    const int prows = shape == 128 ? 128 : 256;
+    p.main_rows = main_rows;
+    p.n_pass = (int)dctr_ceil_div(main_rows, (int64_t)prows);
+    p.n_tail = (int)dctr_ceil_div(tail_rows, (int64_t)64);
+#ifdef DCTR_CHAIN_W4X2
+    const int64_t slots = shape == 128 ? 2 * (int64_t)n_cus() : n_cus();
+#else
+    const int64_t slots = n_cus();
+#endif
+    const int64_t want = p.n_pass > p.n_tail ? p.n_pass : p.n_tail;
+    const unsigned blocks = (unsigned)(want < slots ? want : slots);
+    if (shape == 128) return launch_r2w4_m42(p, E, M[2], blocks, stream);
+    if (M[0] == 4) return M[1] == 2 ? launch_r2w8_m42(p, E, M[2], blocks, stream) : launch_r2w8_m41(p, E, M[2], blocks, stream);
+    return M[1] == 2 ? launch_r2w8_m22(p, E, M[2], blocks, stream) : launch_r2w8_m21(p, E, M[2], blocks, stream);
 }
 
 }  // namespace dctr_chain

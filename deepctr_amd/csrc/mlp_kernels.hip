@@ -53,6 +53,8 @@ constexpr size_t LDS_PER_CU = 160 * 1024;
 
 extern "C" size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t*) { return 0; }  // activations live in LDS
 
+static thread_local int g_last_fwd_kernel = -1;   // DCTR_FWD_KERNEL_* of this thread's last dctr_embed_mlp_fwd launch
+
 static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_fwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->in_dim >= 1 && a->n_layers >= 0 && a->n_layers <= MAX_LAYERS, DCTR_E_DIM,
@@ -139,12 +141,19 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         const int ok = dctr_chain::eligible(a, ga, forced);
         DCTR_REQUIRE(!forced || ok, DCTR_E_UNSUPPORTED,
                      "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 16 / 32, units 256-128-64, a head", a->tile_rows);
-        if (ok) return dctr_chain::launch(a, ga, fm_used, lin_used, a->tile_rows, (hipStream_t)stream);
+        if (ok) {
+            const int rc = dctr_chain::launch(a, ga, fm_used, lin_used, a->tile_rows, (hipStream_t)stream);
+            if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_CHAIN;
+            return rc;
+        }
     }
     // fused launches with >= 64 rows per CU (or tile_rows == 64): the streaming kernel, when the model is eligible
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 64)) {
         int rc = DCTR_OK;
-        if (dctr_stream::try_launch(a, ga, fm_used, lin_used, a->tile_rows == 64, (hipStream_t)stream, &rc)) return rc;
+        if (dctr_stream::try_launch(a, ga, fm_used, lin_used, a->tile_rows == 64, (hipStream_t)stream, &rc)) {
+            if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_STREAM;
+            return rc;
+        }
     }
 
     // rows per workgroup.  auto: 16 while that still gives every CU a workgroup (latency), else 32
@@ -189,10 +198,13 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     const size_t lds = mlp_lds_bytes(rows, lda);
     const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)rows);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
+    if (ga != nullptr) g_last_fwd_kernel = DCTR_FWD_KERNEL_TILE;
     if (rt == 1) return launch_rt1(p, fg, (unsigned)blocks, lds, (hipStream_t)stream);
     if (rt == 2) return launch_rt2(p, fg, (unsigned)blocks, lds, (hipStream_t)stream);
     return launch_rt4(p, fg, (unsigned)blocks, lds, (hipStream_t)stream);
 }
+
+extern "C" int dctr_embed_mlp_fwd_last_kernel(void) { return g_last_fwd_kernel; }
 
 extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) { return mlp_launch(a, nullptr, 0, 0, stream); }
 

@@ -221,8 +221,9 @@ class EmbeddingStage(object):
         # dctr_gather_fm_args_t.uniform_dim: every field a fixed-length SparseFeat of one embedding_dim E laid out at
         # out_offset = index * E with the dense columns right behind — the reference's plain DNN input
         # (inputs.py:101-117 + layers/utils.py:336-346).  Lets large fused launches take the streaming kernel.
+        # Pooled sequence features count: dctr_embed_pool writes their vectors, the gather reads them as identity fields.
         e0 = self.fields[0].dim if self.fields else 0
-        self.uniform_dim = int(e0) if (self.fields and not self.pooled_fields and not self.extra_offsets and all(
+        self.uniform_dim = int(e0) if (self.fields and not self.extra_offsets and all(
             f.dim == e0 and f.out_offset == i * e0 for i, f in enumerate(self.fields))) else 0
         self.k_split = self._find_k_split()
         self._status = None
@@ -230,6 +231,7 @@ class EmbeddingStage(object):
         self._pin = {}                # (key, dtype) -> pinned host staging buffer
         self.pool_trace = None        # training: a list that collects (dctr_pool_args_t, tensors) of the forward's pool calls
         self._ws = {}
+        self._wsl = {}
 
     def _find_k_split(self):
         """(split_col, split_field) offered to dctr_embed_mlp_fwd (include/dctr.h): the field boundary on a multiple of
@@ -454,15 +456,21 @@ class EmbeddingStage(object):
                            "status": self.status(), "dnn_in": None, "fm": None, "lin": None}
         return self._light
 
-    def workspace(self, B):
-        ws = self._ws.get(B)
+    def workspace(self, B, light=False):
+        """Per-row buffers of a call of B rows.  ``light``: the fused one-launch path (dctr_embed_mlp_fwd builds the DNN input on
+        chip): pooled-field buffers, descriptors and status only — no dnn_in / fm / lin rows in HBM, so a call may span 2^17 rows."""
+        cache = self._wsl if light else self._ws
+        ws = cache.get(B)
         if ws is not None:
             return ws
         dev = self.device
         ws = {"B": B}
-        ws["dnn_in"] = torch.zeros(B, self.out_stride, dtype=torch.float32, device=dev)
-        ws["fm"] = torch.zeros(B, dtype=torch.float32, device=dev)
-        ws["lin"] = torch.zeros(B, dtype=torch.float32, device=dev)
+        if light:
+            ws["dnn_in"] = ws["fm"] = ws["lin"] = None
+        else:
+            ws["dnn_in"] = torch.zeros(B, self.out_stride, dtype=torch.float32, device=dev)
+            ws["fm"] = torch.zeros(B, dtype=torch.float32, device=dev)
+            ws["lin"] = torch.zeros(B, dtype=torch.float32, device=dev)
         ws["status"] = self.status()
         ws["pooled"], ws["pooled_lin"] = {}, {}
         for f in self.pooled_fields:
@@ -494,9 +502,9 @@ class EmbeddingStage(object):
             ws["desc2"] = ops.make_field_descriptors(f2, dev)
             ws["n_fields2"] = len(f2)
             ws["any_hash2"] = any(d.get("hash_mode", 0) for d in f2)
-        if len(self._ws) > 8:
-            self._ws.clear()
-        self._ws[B] = ws
+        if len(cache) > (2 if light else 8):
+            cache.clear()
+        cache[B] = ws
         return ws
 
     def refresh(self, linear_kernel):
@@ -544,10 +552,10 @@ class EmbeddingStage(object):
                                     out_stride=self.out_stride,
                                     fm_logit=ws["fm"] if (self.fm_group_names and to_hbm) else None,
                                     lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"],
-                                    split=self.k_split, uniform_dim=self.uniform_dim)
+                                    split=self.k_split, uniform_dim=self.uniform_dim, any_identity=bool(self.pooled_fields))
 
-    def run_pools(self, staged, lo, hi):
-        ws = self.workspace(hi - lo)
+    def run_pools(self, staged, lo, hi, light=False):
+        ws = self.workspace(hi - lo, light)
         st = ws["status"]
         for f in self.pooled_fields:
             self._pool(f.fc, staged, lo, hi, f.table, f.lin_table.reshape(-1) if f.lin_table is not None else None,

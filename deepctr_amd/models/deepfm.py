@@ -41,7 +41,65 @@ class _DeepFM(FeatureModel):
         self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64; 128 / 256: row-chained kernel)
         self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
+        self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
+        self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
+
+    # -- DNN widths the row-chained kernel has no instantiation for --------------------------------------------------------
+    _CHAIN_MIN_ROWS = 64 * 256         # launches below 64 rows per CU take the 32-row kernel (csrc/chain_kernels.hip: eligible)
+
+    def _chain_pad_spec(self, units, activation):
+        """Widths (units[0] <= 256, units[1] <= 128, units[2] <= 128, two or three ReLU / linear layers) padded up to the
+        row-chained kernel's instantiations {128, 256} x {64, 128} x {64, 128}: zero weight columns and biases give act(0) = 0 in
+        the padded features, zero rows of the next layer take them out again — the same fp32 chain plus exact zeros.  None when
+        the widths are already instantiated or cannot be."""
+        units = [int(u) for u in units]
+        sp = self.stage_plan
+        if sp.uniform_dim not in (16, 32) or len(units) not in (2, 3) or activation not in ("relu", "linear") or self.dnn.dice_layers:
+            return None
+        if units[0] > 256 or units[1] > 128 or (len(units) == 3 and units[2] > 128):
+            return None
+        target = [128 if units[0] <= 128 else 256, 64 if units[1] <= 64 else 128]
+        if len(units) == 3:
+            target.append(64 if units[2] <= 64 else 128)
+        return None if target == units else target
+
+    def _padded_dnn(self):
+        """(kernels, biases, head_w, bn) at the padded widths: persistent buffers, refreshed in place from the current weights."""
+        import torch
+        tgt = self._pad_spec
+        ks, bs = self.dnn.kernels, self.dnn.biases
+        bn = self.dnn.bn_params()
+        if self._pad is None:
+            dev = self.device
+            dims = [self.stage_plan.in_dim] + tgt
+            self._pad = {"k": [torch.zeros(dims[i], dims[i + 1], dtype=torch.float32, device=dev) for i in range(len(tgt))],
+                         "b": [torch.zeros(dims[i + 1], dtype=torch.float32, device=dev) for i in range(len(tgt))],
+                         "h": torch.zeros(tgt[-1], 1, dtype=torch.float32, device=dev),
+                         "bn": None if bn is None else [(torch.ones(t, dtype=torch.float32, device=dev),
+                                                         torch.zeros(t, dtype=torch.float32, device=dev)) for t in tgt]}
+        pd = self._pad
+        with torch.no_grad():
+            for i, (k, b) in enumerate(zip(ks, bs)):
+                pd["k"][i][:k.shape[0], :k.shape[1]].copy_(k)
+                pd["b"][i][:b.shape[0]].copy_(b)
+                if bn is not None:
+                    pd["bn"][i][0][:bn[i][0].shape[0]].copy_(bn[i][0])
+                    pd["bn"][i][1][:bn[i][1].shape[0]].copy_(bn[i][1])
+            hw = self.dense.w('kernel')
+            pd["h"][:hw.shape[0]].copy_(hw)
+        return pd["k"], pd["b"], pd["h"], pd["bn"]
+
+    def _dnn_operands(self, B):
+        """DNN weights for a fused launch of B rows: padded copies when that launch can take the row-chained kernel."""
+        if self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256):
+            return self._padded_dnn()
+        return self.dnn.kernels, self.dnn.biases, self.dense.w('kernel'), self.dnn.bn_params()
+
+    def _begin(self):
+        super(_DeepFM, self)._begin()
+        if self._pad is not None:
+            self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
 
     def _forward_fast(self, staged, lo, hi, out):
         """Fixed-length features on the fused path: the two argument structs are marshalled once per batch size and only
@@ -57,16 +115,19 @@ class _DeepFM(FeatureModel):
     def _forward_fast_args(self, staged, lo, hi, out):
         import torch
         sp, B = self.stage_plan, hi - lo
-        c = self._fast.get(B)
+        padded = self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256)
+        key = (B, padded)
+        c = self._fast.get(key)
         if c is None:
             ws = sp.light_workspace()          # descriptors + status only: a launch may span any number of rows
             if len(self._fast) > 8:
                 self._fast.clear()
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
-            m, keep = ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
-                              head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
+            ks, bs, hw, bn = self._dnn_operands(B)
+            m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
+                              head_w=hw, global_bias=self.prediction.w('global_bias'),
                               sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out, gather=g, batch=B, launch=False)
-            c = self._fast[B] = (g, m, keep, ws)
+            c = self._fast[key] = (g, m, keep, ws)
         g, m, _keep, _ws = c
         ids = staged.ids
         g.ids = ids.data_ptr() + lo * ids.element_size()
@@ -103,7 +164,8 @@ class _DeepFM(FeatureModel):
         import ctypes
         from .. import _C
         self._forward_fast_args(staged, lo, hi, out)
-        g, m, keep, ws = self._fast[hi - lo]
+        B = hi - lo
+        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256))]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         sp = self.stage_plan
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
@@ -124,6 +186,10 @@ class _DeepFM(FeatureModel):
         with >= 64 rows per CU the library then runs its persistent kernels (row-chained: chain_device.h; else streaming)."""
         if self._fast_path(staged) and self.span_batches:
             return max(int(batch_size or staged.n), 1 << 20)
+        sp = self.stage_plan
+        if sp.fusable and self.fused and self.span_batches and sp.uniform_dim in (16, 32):
+            # pooled sequence features / linear-only features: per-row buffers of the pooling kernels bound the span
+            return max(int(batch_size or staged.n), 1 << 17)
         return super(_DeepFM, self)._rows_per_launch(staged, batch_size)
 
     def _forward(self, staged, lo, hi, out):
@@ -132,11 +198,12 @@ class _DeepFM(FeatureModel):
             return self._forward_fast(staged, lo, hi, out)
         if sp.fusable and self.fused:
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
-            ws = sp.run_pools(staged, lo, hi)
+            ws = sp.run_pools(staged, lo, hi, light=True)
             sp.run_lin_only(staged, lo, hi, ws)
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
-            ops.mlp(None, self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
-                    head_w=self.dense.w('kernel'), add=[ws["lin2"]] if "lin2" in ws else [],
+            ks, bs, hw, bn = self._dnn_operands(hi - lo)
+            ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
+                    head_w=hw, add=[ws["lin2"]] if "lin2" in ws else [],
                     global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
                     out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
                     tile_rows=self.tile_rows, probe=self.probe)

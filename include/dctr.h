@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 4
+#define DCTR_ABI_VERSION 5
 
 enum {
     DCTR_OK = 0,
@@ -143,14 +143,15 @@ typedef struct {
                                      and the dense passthrough only columns >= split_col.  Lets the fused kernel
                                      build the DNN-input tile in two K-halves (half the LDS, two workgroups per CU). */
     int32_t split_field;
-    int32_t uniform_dim;          /* dctr_embed_mlp_fwd only; E > 0 promises: every field has dim == E, out_offset ==
-                                     field index * E, identity == 0 (the reference's all-SparseFeat DNN input,
-                                     inputs.py:101-117 + layers/utils.py:336-346).  With E in {16, 32, 64} launches of
-                                     >= 64 rows per CU take the streaming kernel (LDS-DMA gather ring, 64-row tiles).
-                                     With E in {16, 32} and DNN units 256-128-64 such
-                                     launches take the row-chained kernel instead (csrc/chain_device.h).
-                                     0 = unknown / not uniform                                                        */
-    int32_t reserved_;
+    int32_t uniform_dim;          /* dctr_embed_mlp_fwd only; E > 0 promises: every field has dim == E and out_offset ==
+                                     field index * E (the reference's plain DNN input, inputs.py:101-117 + layers/utils.py:
+                                     336-346; fields pre-pooled by dctr_embed_pool — identity == 1 — included, see any_identity).
+                                     Launches of >= 64 rows per CU then take a persistent kernel: with E in {16, 32} and a DNN
+                                     of two or three layers with units[0] in {128, 256}, units[1] in {64, 128}, units[2] in
+                                     {64, 128} (ReLU / linear, optional BatchNormalization) the row-chained kernel
+                                     (csrc/chain_device.h); else with E in {16, 32, 64} and no identity field the streaming
+                                     kernel (LDS-DMA gather ring, 64-row tiles).  0 = unknown / not uniform              */
+    int32_t any_identity;         /* 1: some field has identity != 0 (host copy of the descriptors' flags)               */
 } dctr_gather_fm_args_t;
 
 int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);
@@ -333,10 +334,11 @@ typedef struct {
                                      this kernel) at the price of fewer workgroups; results are bit-identical.
                                      dctr_embed_mlp_fwd only: 64 = the streaming kernel (64-row tiles, LDS-DMA gather ring),
                                      128 / 256 = the row-chained kernel in one launch shape (waves own batch rows end to
-                                     end; needs uniform_dim 16 / 32, units 256-128-64, a head).  0 (auto) sends launches of
-                                     >= 64 rows per CU of such a model to the row-chained kernel, cut into its launch
-                                     shapes so that every CU gets the same number of passes; a row's result does not
-                                     depend on the shape or on the row's position in the launch. */
+                                     end; needs uniform_dim 16 / 32, a head, units as listed at uniform_dim; 128: units
+                                     256-128-64 only).  0 (auto) sends launches of >= 64 rows per CU of such a model to the
+                                     row-chained kernel as ONE launch: 256-row passes for the whole multiples of 256 rows x CUs,
+                                     64-row units inside the same kernel for what is left; a row's result does not depend on
+                                     the shape, the phase or the row's position in the launch. */
     int32_t reserved_;
     unsigned long long* probe;    /* measurement aid, normally NULL: DEVICE uint64[2]; every workgroup does
                                      atomicMin(probe[0], t_start) / atomicMax(probe[1], t_end) with the constant-rate
@@ -363,13 +365,16 @@ int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
 int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit,
                        int32_t add_lin_logit, void* stream);
 
-/* How dctr_embed_mlp_fwd would issue this call: the row-chained kernel cuts a call into several kernel launches (whole
- * multiples of 256 rows x CUs in its 256-row launch shape, the rest in the shapes that finish it soonest); every other path is
- * one launch.  Writes up to `max` entries (rows of the launch, DCTR_FWD_KERNEL_* id, batch rows per workgroup) in launch order
- * and returns how many launches there are (<= 0: error, see dctr_last_error).  Needs a current HIP device (CU count). */
+/* How dctr_embed_mlp_fwd would run this call.  Every path is ONE kernel launch; the row-chained kernel runs a call in up to two
+ * phases inside that launch (256-row passes for the whole multiples of 256 rows x CUs, 64-row units for what is left).  Writes up
+ * to `max` entries (rows, DCTR_FWD_KERNEL_* id, batch rows per workgroup) — one per phase, in order — and returns their number
+ * (<= 0: error, see dctr_last_error).  Needs a current HIP device (CU count).
+ * dctr_embed_mlp_fwd_last_kernel(): the DCTR_FWD_KERNEL_* id the calling thread's last successful dctr_embed_mlp_fwd call
+ * launched (-1 before the first one). */
 enum { DCTR_FWD_KERNEL_TILE = 0, DCTR_FWD_KERNEL_STREAM = 1, DCTR_FWD_KERNEL_CHAIN = 2 };
 int dctr_embed_mlp_fwd_plan(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int64_t* rows, int32_t* kernel,
                             int32_t* rows_per_workgroup, int32_t max);
+int dctr_embed_mlp_fwd_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * a13 AttentionSequencePoolingLayer.call + LocalActivationUnit.call (DIN)

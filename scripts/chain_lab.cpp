@@ -1,7 +1,7 @@
 // Lab harness for the row-chained dctr_embed_mlp_fwd kernel (chain_kernels.hip) at the C2 / C5 shapes: correctness against
 // mlp_kernel<2>, the streaming kernel and a float64 host reference on a row sample (ragged tail, out-of-range id flag),
 // then launch times over a range of rows per launch for tile_rows 0 (auto: chained + remainder), 256 (chained only), 64.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I deepctr_amd/csrc scripts/chain_lab.cpp -o scripts/_bin/chain_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDCTR_CHAIN_LAB_WGTS -I include -I deepctr_amd/csrc scripts/chain_lab.cpp -o scripts/_bin/chain_lab
 //   chain_lab [E=16] [V=100000]
 #include "../deepctr_amd/csrc/abi.cpp"
 #include "../deepctr_amd/csrc/mlp_kernels.hip"
@@ -12,13 +12,18 @@
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
 #include "../deepctr_amd/csrc/stream_kernels.hip"
 #include "../deepctr_amd/csrc/chain_kernels.hip"
-#include "../deepctr_amd/csrc/chain_kernels_r2w8.hip"
+#include "../deepctr_amd/csrc/chain_kernels_r2w8_m42.hip"
 #undef DCTR_CHAIN_RT
 #undef DCTR_CHAIN_NW
-#include "../deepctr_amd/csrc/chain_kernels_r2w4.hip"
-#undef DCTR_CHAIN_RT
-#undef DCTR_CHAIN_NW
-#include "../deepctr_amd/csrc/chain_kernels_r1w4.hip"
+#undef DCTR_CHAIN_M0
+#undef DCTR_CHAIN_M1
+#undef DCTR_CHAIN_M2SET
+#include "../deepctr_amd/csrc/chain_kernels_r2w4_m42.hip"
+namespace dctr_chain {      // (the lab links the 256-128-64 instantiations only)
+int launch_r2w8_m41(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+int launch_r2w8_m22(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+int launch_r2w8_m21(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+}
 #include <algorithm>
 #include <cmath>
 #include <time.h>
@@ -145,6 +150,31 @@ int main(int argc, char** argv) {
         for (int64_t b = 0; b < Ba; ++b) { if (!(a1[b] == a1[b])) ++nn; m = std::max(m, fabs((double)a0[b] - a1[b])); }
         printf("auto split, %lld rows: max |diff| vs mlp_kernel<2> %.3e, NaN rows %d, tail untouched: %s\n", (long long)Ba, m, nn, (a1[Ba] != a1[Ba]) ? "yes" : "NO");
     }
+#ifdef DCTR_CHAIN_LAB_WGTS
+    // ---- where an isolated launch spends its time: wall-clock stamps (100 MHz) of every workgroup — kernel entry, end of the
+    // main phase, end of the tail phase — against the host-side event pair around the launch
+    for (int64_t Bw : {int64_t(65536), int64_t(81920), int64_t(262144)}) {
+        hipEvent_t w0, w1; CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(w0, st));
+            if (run(Bw, 0, y1, 1)) return 1;
+            CK(hipEventRecord(w1, st)); CK(hipEventSynchronize(w1));
+            float ms; CK(hipEventElapsedTime(&ms, w0, w1));
+            static unsigned long long wg[1024][4];
+            CK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(dctr_chain_wgts), sizeof(wg)));
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < 256; ++b) t0 = std::min(t0, wg[b][0]);
+            std::vector<double> s0, s1, s2;
+            for (int b = 0; b < 256; ++b) { s0.push_back((wg[b][0] - t0) * 0.01); s1.push_back((wg[b][1] - t0) * 0.01); s2.push_back((wg[b][2] - t0) * 0.01); }
+            std::sort(s0.begin(), s0.end()); std::sort(s1.begin(), s1.end()); std::sort(s2.begin(), s2.end());
+            if (rep == 2)
+                printf("stamps %lld rows (us after the first workgroup's entry; min / median / max over 256 workgroups): entry %.1f / %.1f / %.1f, "
+                       "main phase done %.1f / %.1f / %.1f, tail phase done %.1f / %.1f / %.1f; event pair around the launch %.1f us\n",
+                       (long long)Bw, s0[0], s0[128], s0[255], s1[0], s1[128], s1[255], s2[0], s2[128], s2[255], ms * 1e3);
+        }
+    }
+#endif
     // ---- one-shot region of 20 batches (81,920 rows = 65,536 on <2,8> + 16,384 on <1,4>), as bench.py --steps 20 times it:
     // host clock around issue + synchronise, idle GPU before.  (a) one call (two launches on one stream), (b) the two parts as
     // two calls on one stream, (c) the two parts on TWO streams (fork / join with events): does the remainder fill the main

@@ -14,7 +14,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tu,max_vgprs", [("chain_kernels_r2w8.hip", 256), ("chain_kernels_r2w4.hip", 512)])
+@pytest.mark.parametrize("tu,max_vgprs", [("chain_kernels_r2w8_m42.hip", 256), ("chain_kernels_r2w8_m41.hip", 256),
+                                          ("chain_kernels_r2w8_m22.hip", 256), ("chain_kernels_r2w8_m21.hip", 256),
+                                          ("chain_kernels_r2w4_m42.hip", 512)])
 def test_chain_kernel_needs_no_scratch(tmp_path, tu, max_vgprs):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

@@ -201,3 +201,106 @@ def test_streaming_kernel_still_reachable(device):
     _randomise(model2, rng)
     y2 = model2.predict(feed, batch_size=4096)
     assert_close(y2, _predict(model2, feed, 4096, span_batches=False, tile_rows=32), rtol=2e-6, atol=2e-7, what="fallback")
+
+
+def _last_kernel():
+    from deepctr_amd import _C
+    return {0: "tile", 1: "stream", 2: "chain", -1: None}[_C.lib().dctr_embed_mlp_fwd_last_kernel()]
+
+
+@pytest.mark.parametrize("n", [16384, 16384 + 5, 40000, 49152 + 1, 60000, 65536 + 16384, 2 * 65536 + 100])
+def test_chain_one_launch_main_and_tail_phases(device, n):
+    """A call is ONE launch: 256-row passes for the whole multiples of 256 rows x CUs, 64-row tail units inside the same kernel
+    for what is left (tail only / main only / both, ragged ends).  Every row against the forced 256-row shape bit for bit (the
+    phases walk k in the same order) and a row sample against the float64 oracle."""
+    import torch
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(n % 1000)
+    cols, feed = _criteo_like(rng, n, V=5000, E=16)
+    model = DeepFM(cols, cols, device=device)
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain"
+    plan = model.launch_plan(model.stage(feed), 0, n, torch.empty(n, device=model.device))
+    assert all(k == "chain" for _, k, _ in plan) and sum(r for r, _, _ in plan) == n and len(plan) <= 2, plan
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    left = n % (256 * cus)
+    want_tail = 0 < left <= 3 * 64 * cus
+    assert (plan[-1][2] == 64) == want_tail, (plan, left)
+    assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y)
+    rows = np.unique(np.concatenate([np.arange(0, 100), np.arange(n - 200, n), rng.choice(n, 200, replace=False)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "one launch, %d rows" % n)
+
+
+@pytest.mark.parametrize("units,bn,E", [((256, 128), False, 16), ((128, 128), False, 16), ((128, 64), False, 32),
+                                        ((256, 64, 128), False, 16), ((128, 128, 128), True, 16), ((256, 128, 64), True, 32),
+                                        ((200, 80), False, 16), ((100, 100, 100), False, 16), ((250, 33, 7), True, 16)])
+def test_chain_kernel_layer_widths_and_batchnorm(device, units, bn, E):
+    """DNN widths beyond 256-128-64 (reference layers/core.py:123-223 takes any hidden_units): the instantiated widths directly,
+    other widths <= 256 / 128 / 128 zero-padded to them; DNN(use_bn=True) as a per-feature scale / shift between bias_add and the
+    activation (core.py:200-201, inference form).  float64 oracle; the 32-row kernel on the unpadded weights on every row."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(sum(units) + E)
+    n = 16384 + 3000
+    cols, feed = _criteo_like(rng, n, F=9, V=2000, E=E, ND=4)
+    model = DeepFM(cols, cols, dnn_hidden_units=units, dnn_use_bn=bn, device=device)
+    w = _randomise(model, rng)
+    if bn:
+        for k in w:
+            if k.endswith("moving_variance") or k.endswith("gamma"):
+                w[k] = (0.5 + rng.rand(*w[k].shape)).astype(np.float32)
+        model.set_weights_by_name(w)
+    y = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain", units
+    rows = rng.choice(n, 300, replace=False)
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dnn_hidden_units=units, dnn_use_bn=bn, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "chain DNN %r bn=%s" % (units, bn))
+    y32 = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    assert _last_kernel() == "tile"
+    assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain vs 32-row kernel, units %r" % (units,))
+    # weights changed after the first call: the padded copies follow
+    w2 = _randomise(model, rng)
+    y2 = model.predict(feed, batch_size=4096)
+    ref2 = RM.deepfm(cols, cols, w2, {k: v[rows] for k, v in feed.items()}, dnn_hidden_units=units, dnn_use_bn=bn, dtype=np.float64)
+    check_probs(y2[rows], ref2.astype(np.float32), "chain DNN %r after set_weights" % (units,))
+
+
+def test_chain_kernel_takes_pooled_sequence_features(device):
+    """north_star's field mix on the fast kernel: fixed-length SparseFeat + masked mean-pooled / sum / max / weighted
+    VarLenSparseFeat (reference inputs.py:120-158, layers/sequence.py:76-106): dctr_embed_pool writes the pooled vectors, the
+    row-chained kernel reads them as identity fields (row = sample index) in its one launch."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(77)
+    n, T, E = 16384 + 4096 + 11, 20, 16
+    cols = [SparseFeat("C%d" % i, 3000, E) for i in range(12)] + [DenseFeat("I%d" % i, 1) for i in range(5)] + [
+        VarLenSparseFeat(SparseFeat("tags", 500, E), maxlen=T, combiner="mean"),
+        VarLenSparseFeat(SparseFeat("hist", 800, E), maxlen=T, combiner="mean", length_name="hist_len"),
+        VarLenSparseFeat(SparseFeat("cats", 300, E), maxlen=7, combiner="sum", weight_name="cats_w"),
+        VarLenSparseFeat(SparseFeat("top", 200, E), maxlen=5, combiner="max")]
+    feed = {"C%d" % i: rng.randint(0, 3000, n).astype(np.int32) for i in range(12)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(5)})
+
+    def seq(vocab, t, min_len=0):
+        a = rng.randint(1, vocab, (n, t)).astype(np.int32)
+        a[np.arange(t)[None, :] >= rng.randint(min_len, t + 1, n)[:, None]] = 0
+        return a
+    feed["tags"] = seq(500, T)
+    feed["hist"] = rng.randint(1, 800, (n, T)).astype(np.int32)
+    feed["hist_len"] = rng.randint(0, T + 1, n).astype(np.int32)
+    feed["cats"] = seq(300, 7)
+    feed["cats_w"] = rng.rand(n, 7).astype(np.float32)
+    feed["top"] = seq(200, 5, min_len=1)
+    model = DeepFM(cols, cols, device=device)
+    assert model.stage_plan.uniform_dim == E and len(model.stage_plan.pooled_fields) == 4
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain"
+    rows = np.unique(np.concatenate([np.arange(64), np.arange(n - 64, n), rng.choice(n, 300, replace=False)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "chain DeepFM with pooled sequence features")
+    y32 = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    assert _last_kernel() == "tile"
+    assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain vs 32-row kernel, pooled fields")
+    assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y)
