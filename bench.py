@@ -219,6 +219,11 @@ def main():
     ap.add_argument("--regions", type=int, default=5,
                     help="`value` = the MEDIAN of this many one-shot timed regions of exactly K steps each (every region is "
                          "bracketed by barrier + synchronize; all of them are printed as regions_ms)")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed: the K-step region repeated for this long right before the timed regions (and a fifth of it before "
+                         "each further region) so that they run at the clock the part holds under sustained load; an MI355X that "
+                         "has idled ramps its shader clock over tens of milliseconds (2.1 -> 2.4 GHz measured, "
+                         "profiles/r03_chain_lab_clock.log).  0 = off; the cold one-shot region is always reported as well")
     ap.add_argument("--parity-rows", type=int, default=256,
                     help="rows of the timed region's output compared with the float64 oracle after the region (0 = off)")
     args = ap.parse_args()
@@ -310,7 +315,21 @@ def main():
     # (L2 / MALL state, clock ramp): a few per cent of spread from run to run, so the region is taken --regions times — each one
     # complete in itself: barrier + sync | K steps | sync — and the MEDIAN region is the one reported (all are listed).
     n_regions = max(1, args.regions)
-    region_s = [timed_region(arm=False) for _ in range(n_regions)]
+
+    def prewarm(ms):
+        """Untimed sustained load: the region's own launches, back to back, for `ms` milliseconds."""
+        if ms <= 0 or K <= 0:
+            return
+        t_end = time.perf_counter() + ms * 1e-3
+        while time.perf_counter() < t_end:
+            run_steps()
+            torch.cuda.synchronize()
+
+    cold_s = timed_region(arm=False)                        # reported, not `value`: the first region after an idle period
+    region_s = []
+    for r in range(n_regions):
+        prewarm(args.prewarm_ms if r == 0 else args.prewarm_ms / 5.0)
+        region_s.append(timed_region(arm=False))
     # the same region once more with an event pair around every kernel launch (hipExtLaunchKernelGGL start / stop events on
     # the launch's own stream): the per-kernel durations of the roofline object.  Kept out of the `value` region because the
     # pairs isolate consecutive kernels from each other (no tail / ramp overlap), which costs the region ~10 %.
@@ -322,6 +341,9 @@ def main():
         t = torch.tensor(region_s, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.tolist()]
+        t = torch.tensor([cold_s], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cold_s = float(t.item())
     elapsed = float(np.median(region_s))
     model._check_status()
     assert bool(torch.isfinite(logits[:min(K, 4) * B]).all())
@@ -457,7 +479,13 @@ def main():
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
             "fp32_ceiling_of_that_fraction": F32_MFMA_PEAK_TF * 1e12 / DNN_FLOP_PER_SAMPLE * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
             "long_run": long_run, "one_launch_per_batch": per_batch,
-            "regions_ms": [t * 1e3 for t in region_s], "value_is": "median of %d one-shot regions of exactly K steps" % n_regions,
+            "regions_ms": [t * 1e3 for t in region_s],
+            "value_is": "median of %d one-shot regions of exactly K steps (each: barrier + sync | K steps | sync), taken right after "
+                        "%.0f ms (%.0f ms from the second region on) of the same steps untimed, i.e. at the clock the part holds "
+                        "under load" % (n_regions, args.prewarm_ms, args.prewarm_ms / 5.0),
+            "cold_one_shot": {"ms": cold_s * 1e3, "samples_per_s": world * B * K / cold_s if K else 0.0,
+                              "note": "the same region as the first GPU work after an idle period (shader clock still ramping)"},
+            "clock_prewarm_ms": args.prewarm_ms,
             "parity_max_rel": None if parity is None else parity["max_rel"], "parity": parity,
         }
         if parity is not None and not parity["within_1e-4"]:

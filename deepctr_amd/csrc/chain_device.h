@@ -43,7 +43,10 @@
 
 #ifdef DCTR_CHAIN_LAB_TS
 __device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][stamp] of workgroup 0, second pass
-#define CTS(i) do { if (blockIdx.x == 0 && it == 1 && (wave == 0 || wave == 7) && lane == 0) dctr_chain_ts[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
+#ifndef DCTR_CHAIN_TS_RT
+#define DCTR_CHAIN_TS_RT 2                     // 2: stamps of the main phase's second pass; 1: of the tail phase's first unit
+#endif
+#define CTS(i) do { if (RT == DCTR_CHAIN_TS_RT && blockIdx.x == 0 && it == (RT == 2 ? 1 : 0) && (wave == 0 || wave == NW - 1) && lane == 0) dctr_chain_ts[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
 #define CTS_STEP(b, k) do { if ((b) >= 10 && (b) < 14) CTS(8 + 4 * ((b) - 10) + (k)); } while (0)   // inside layer-0 steps 10..13
 #else
 #define CTS(i) do {} while (0)
@@ -51,8 +54,9 @@ __device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][s
 #endif
 
 #ifdef DCTR_CHAIN_LAB_WGTS    // lab: wall-clock stamps per workgroup (kernel entry, end of the main phase, end of the tail phase)
-__device__ unsigned long long dctr_chain_wgts[1024][4];
-#define CWG(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) dctr_chain_wgts[blockIdx.x][i] = wall_clock64(); } while (0)
+__device__ unsigned long long dctr_chain_wgts[1024][8];       // [0..3] wall clock (100 MHz), [4..7] shader cycle counter
+#define CWG(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { dctr_chain_wgts[blockIdx.x][i] = wall_clock64(); \
+                    dctr_chain_wgts[blockIdx.x][4 + (i)] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define CWG(i) do {} while (0)
 #endif
@@ -514,6 +518,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     // memory address path does not get all eight waves' requests in one burst (it has no register results, so placing it
     // twice costs nothing; the gather part placed twice merges in-flight registers of the two placements and spills).
     const bool dma_early = wave < NW / 2;
+    constexpr int DMA_LATE0 = CHAIN_DMA_LATE < 4 * M0 ? CHAIN_DMA_LATE : 2 * M0;     // layer 0 has 4 M0 micro-steps per step (even index)
+    static_assert(DMA_LATE0 % 2 == 0 && DMA_LATE0 < 4 * M0 && CHAIN_DMA_LATE % 2 == 0 && CHAIN_DMA_LATE < 16, "late DMA slot outside the step");
     for (int it = 0, pass = first; pass < n_pass; ++it, pass += stride) {
         constexpr int PH = 0;
         (void)it;
@@ -622,7 +628,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 mfma_l0(c0, XC, u_);                                                                             \
                 DCTR_SB;                                                                                         \
                 if (u_ == PH) CHAIN_PHASE0(XC, XN)                                                               \
-                if (u_ == CHAIN_DMA_LATE && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                          \
+                if (u_ == DMA_LATE0 && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                               \
                 if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                                  \
                 else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                              \
                 DCTR_SB;                                                                                         \

@@ -126,12 +126,12 @@ int main(int argc, char** argv) {
 
 #ifdef DCTR_CHAIN_LAB_TS
     {
-        if (run(262144, 256, y1, 1)) return 1;
+        if (run(DCTR_CHAIN_TS_RT == 2 ? 262144 : 81920, 0, y1, 1)) return 1;       // (RT 1: the tail phase of the 20-batch call)
         CK(hipStreamSynchronize(st));
         unsigned long long ts[2][64];
         CK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(dctr_chain_ts), sizeof(ts)));
         const unsigned long long t0 = ts[0][0];
-        const char* nm[2] = {"wave0", "wave7"};
+        const char* nm[2] = {"wave0", DCTR_CHAIN_TS_RT == 2 ? "wave7" : "wave3"};
         for (int w = 0; w < 2; ++w) {
             printf("stamps %s (cycles after wave 0's pass start):", nm[w]);
             for (int i = 0; i < 64; ++i) if (ts[w][i]) printf(" [%d]%lld", i, (long long)(ts[w][i] - t0));
@@ -151,30 +151,42 @@ int main(int argc, char** argv) {
         printf("auto split, %lld rows: max |diff| vs mlp_kernel<2> %.3e, NaN rows %d, tail untouched: %s\n", (long long)Ba, m, nn, (a1[Ba] != a1[Ba]) ? "yes" : "NO");
     }
 #ifdef DCTR_CHAIN_LAB_WGTS
-    // ---- where an isolated launch spends its time: wall-clock stamps (100 MHz) of every workgroup — kernel entry, end of the
-    // main phase, end of the tail phase — against the host-side event pair around the launch
-    for (int64_t Bw : {int64_t(65536), int64_t(81920), int64_t(262144)}) {
-        hipEvent_t w0, w1; CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1));
-        for (int rep = 0; rep < 3; ++rep) {
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(w0, st));
-            if (run(Bw, 0, y1, 1)) return 1;
-            CK(hipEventRecord(w1, st)); CK(hipEventSynchronize(w1));
-            float ms; CK(hipEventElapsedTime(&ms, w0, w1));
-            static unsigned long long wg[1024][4];
-            CK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(dctr_chain_wgts), sizeof(wg)));
-            unsigned long long t0 = ~0ull;
-            for (int b = 0; b < 256; ++b) t0 = std::min(t0, wg[b][0]);
-            std::vector<double> s0, s1, s2;
-            for (int b = 0; b < 256; ++b) { s0.push_back((wg[b][0] - t0) * 0.01); s1.push_back((wg[b][1] - t0) * 0.01); s2.push_back((wg[b][2] - t0) * 0.01); }
-            std::sort(s0.begin(), s0.end()); std::sort(s1.begin(), s1.end()); std::sort(s2.begin(), s2.end());
-            if (rep == 2)
-                printf("stamps %lld rows (us after the first workgroup's entry; min / median / max over 256 workgroups): entry %.1f / %.1f / %.1f, "
-                       "main phase done %.1f / %.1f / %.1f, tail phase done %.1f / %.1f / %.1f; event pair around the launch %.1f us\n",
-                       (long long)Bw, s0[0], s0[128], s0[255], s1[0], s1[128], s1[255], s2[0], s2[128], s2[255], ms * 1e3);
+    // ---- where an isolated launch spends its time: wall-clock stamps (100 MHz) and shader-cycle stamps of every workgroup — kernel
+    // entry, end of the main phase, end of the tail phase — against the host-side event pair around the launch; `second`: the same
+    // launch issued right behind an identical one (no idle GPU in front of it); stagger: workgroup b waits (b % 16) x S ticks at entry
+    {
+        const int stagger = 0;
+        for (int64_t Bw : {int64_t(65536), int64_t(81920), int64_t(262144)}) {
+            hipEvent_t w0, w1; CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1));
+            for (int second = 0; second < 2; ++second) {
+                float ms = 0;
+                static unsigned long long wg[1024][8];
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipDeviceSynchronize());
+                    if (second && run(Bw, 0, y1, 1)) return 1;
+                    CK(hipEventRecord(w0, st));
+                    if (run(Bw, 0, y1, 1)) return 1;
+                    CK(hipEventRecord(w1, st)); CK(hipEventSynchronize(w1));
+                    CK(hipEventElapsedTime(&ms, w0, w1));
+                    CK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(dctr_chain_wgts), sizeof(wg)));
+                }
+                unsigned long long t0 = ~0ull;
+                for (int b = 0; b < 256; ++b) t0 = std::min(t0, wg[b][0]);
+                std::vector<double> s0, s1, s2, mhz;
+                for (int b = 0; b < 256; ++b) {
+                    s0.push_back((wg[b][0] - t0) * 0.01); s1.push_back((wg[b][1] - t0) * 0.01); s2.push_back((wg[b][2] - t0) * 0.01);
+                    mhz.push_back((double)(wg[b][5] - wg[b][4]) / ((double)(wg[b][1] - wg[b][0]) * 0.01));     // shader cycles per us, main phase
+                }
+                std::sort(s0.begin(), s0.end()); std::sort(s1.begin(), s1.end()); std::sort(s2.begin(), s2.end()); std::sort(mhz.begin(), mhz.end());
+                printf("stamps %6lld rows stagger %3d %s (us after the first entry; min / median / max over 256 workgroups): entry %.1f / %.1f / %.1f, "
+                       "main done %.1f / %.1f / %.1f, tail done %.1f / %.1f / %.1f; event pair %.1f us; shader clock in the main phase %.0f / %.0f / %.0f MHz\n",
+                       (long long)Bw, stagger, second ? "2nd of two" : "isolated  ", s0[0], s0[128], s0[255], s1[0], s1[128], s1[255], s2[0], s2[128], s2[255],
+                       ms * 1e3, mhz[0], mhz[128], mhz[255]);
+            }
         }
     }
 #endif
+    if (getenv("CHAIN_LAB_STAMPS_ONLY") != nullptr) return 0;
     // ---- one-shot region of 20 batches (81,920 rows = 65,536 on <2,8> + 16,384 on <1,4>), as bench.py --steps 20 times it:
     // host clock around issue + synchronise, idle GPU before.  (a) one call (two launches on one stream), (b) the two parts as
     // two calls on one stream, (c) the two parts on TWO streams (fork / join with events): does the remainder fill the main
