@@ -453,6 +453,8 @@ class EmbeddingStage(object):
             fields = [dict(table=f.table, lin_table=f.lin_table, vocab=f.table.shape[0], dim=f.dim, out_offset=f.out_offset,
                            in_fm=f.in_fm, hash_mode=f.hash_mode) for f in self.fields]
             self._light = {"desc": ops.make_field_descriptors(fields, self.device) if fields else None,
+                           "desc0": ops.make_field_descriptors([dict(f, hash_mode=0) for f in fields], self.device)
+                           if (fields and self.any_hash) else None,
                            "status": self.status(), "dnn_in": None, "fm": None, "lin": None}
         return self._light
 
@@ -486,6 +488,8 @@ class EmbeddingStage(object):
                 fields.append(dict(table=ws["pooled"][f.fc.name], lin_table=ws["pooled_lin"].get(f.fc.name), vocab=B,
                                    dim=f.dim, out_offset=f.out_offset, in_fm=f.in_fm, identity=True))
         ws["desc"] = ops.make_field_descriptors(fields, dev) if fields else None
+        # the same fields as plain rows: what the gather sees after dctr_hash_fields has resolved the hashed ids (prehash)
+        ws["desc0"] = ops.make_field_descriptors([dict(f, hash_mode=0) for f in fields], dev) if (fields and self.any_hash) else None
         if self.lin_only:
             ws["lin2"] = torch.zeros(B, dtype=torch.float32, device=dev)
             ws["lin2_pool"] = {fc.name: torch.zeros(B, 1, dtype=torch.float32, device=dev)
@@ -539,14 +543,31 @@ class EmbeddingStage(object):
                        lin_table=lin_table, hash_mode=hm, out=out, out_stride=out.stride(0), lin_out=lin_out, status=status,
                        keep_args=self.pool_trace)
 
-    def gather_args(self, staged, lo, hi, ws, to_hbm=True):
-        """dctr_gather_fm_args_t for rows [lo, hi) (pooled fields must already be in the workspace)."""
+    def prehash(self, staged, lo, hi, ws):
+        """Hash.call for rows [lo, hi) of every hashed field in ONE launch (dctr_hash_fields) into a scratch id matrix: the
+        persistent kernels of dctr_embed_mlp_fwd take plain rows (reference inputs.py:108-110 hashes per feature before the
+        lookup as well).  Returns the [n_fields, B] matrix ``gather_args(prehashed=...)`` takes."""
+        B, nf = hi - lo, len(self.fields)
+        buf = getattr(self, "_hash_ids", None)
+        if buf is None or buf.dtype != staged.ids.dtype or buf.shape[1] < B:
+            buf = self._hash_ids = torch.empty(nf, max(B, 1), dtype=staged.ids.dtype, device=self.device)
+        out = buf[:, :B]
+        ops.hash_fields(ws["desc"], nf, staged.ids[:nf, lo:hi], out)
+        return out
+
+    def gather_args(self, staged, lo, hi, ws, to_hbm=True, prehashed=None):
+        """dctr_gather_fm_args_t for rows [lo, hi) (pooled fields must already be in the workspace).  ``prehashed``: the id
+        matrix ``prehash`` returned — the fields are then described as plain rows."""
         B = hi - lo
         nf = len(self.fields)
         ids = staged.ids[:, lo:hi] if staged.ids is not None else None
+        stride_f = staged.ids.stride(0) if ids is not None else 0
+        desc, any_hash = ws["desc"], self.any_hash
+        if prehashed is not None:
+            ids, stride_f, desc, any_hash = prehashed, prehashed.stride(0), ws["desc0"], False
         dense = staged.dense[lo:hi] if staged.dense is not None else None
-        return ops.make_gather_args(ws["desc"], nf, ids, staged.ids.stride(0) if ids is not None else 0, 1, B, self.max_dim,
-                                    self.all_dim4, self.any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
+        return ops.make_gather_args(desc, nf, ids, stride_f, 1, B, self.max_dim,
+                                    self.all_dim4, any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
                                     dense_out_offset=self.dense_offset if self.n_dense_dnn else -1,
                                     dense_copy_cols=self.n_dense_dnn, dnn_in=ws["dnn_in"] if to_hbm else None,
                                     out_stride=self.out_stride,

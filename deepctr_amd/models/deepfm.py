@@ -96,6 +96,13 @@ class _DeepFM(FeatureModel):
             return self._padded_dnn()
         return self.dnn.kernels, self.dnn.biases, self.dense.w('kernel'), self.dnn.bn_params()
 
+    def _prehash(self, B):
+        """Hashed SparseFeat on launches the persistent kernels can take (>= 64 rows per CU, uniform embedding_dim): the ids are
+        hashed by one dctr_hash_fields launch in front of the fused one, which then sees plain rows.  Smaller launches hash inside
+        the 32-row kernel."""
+        sp = self.stage_plan
+        return bool(sp.any_hash and sp.uniform_dim in (16, 32, 64) and (B >= self._CHAIN_MIN_ROWS or self.tile_rows in (64, 256)))
+
     def _begin(self):
         super(_DeepFM, self)._begin()
         if self._pad is not None:
@@ -116,13 +123,15 @@ class _DeepFM(FeatureModel):
         import torch
         sp, B = self.stage_plan, hi - lo
         padded = self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256)
-        key = (B, padded)
+        pre = self._prehash(B)
+        key = (B, padded, pre)
         c = self._fast.get(key)
+        hashed = sp.prehash(staged, lo, hi, sp.light_workspace()) if pre else None
         if c is None:
             ws = sp.light_workspace()          # descriptors + status only: a launch may span any number of rows
             if len(self._fast) > 8:
                 self._fast.clear()
-            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
+            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
             ks, bs, hw, bn = self._dnn_operands(B)
             m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
                               head_w=hw, global_bias=self.prediction.w('global_bias'),
@@ -130,8 +139,12 @@ class _DeepFM(FeatureModel):
             c = self._fast[key] = (g, m, keep, ws)
         g, m, _keep, _ws = c
         ids = staged.ids
-        g.ids = ids.data_ptr() + lo * ids.element_size()
-        g.ids_stride_f = ids.stride(0)
+        if hashed is not None:
+            g.ids = hashed.data_ptr()
+            g.ids_stride_f = hashed.stride(0)
+        else:
+            g.ids = ids.data_ptr() + lo * ids.element_size()
+            g.ids_stride_f = ids.stride(0)
         g.ids_is_i64 = int(ids.dtype == torch.int64)
         if staged.dense is not None:
             g.dense = staged.dense.data_ptr() + lo * staged.dense.stride(0) * 4
@@ -165,13 +178,17 @@ class _DeepFM(FeatureModel):
         from .. import _C
         self._forward_fast_args(staged, lo, hi, out)
         B = hi - lo
-        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256))]
+        pre = self._prehash(B)
+        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256), pre)]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         sp = self.stage_plan
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
 
         def launch():
+            if pre:                                                      # (the hash launch fills the scratch matrix g.ids points at)
+                h = sp.prehash(staged, lo, hi, ws)
+                g.ids, g.ids_stride_f = h.data_ptr(), h.stride(0)
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
         launch.keep = (g, m, keep, ws, staged, out)
         return launch
@@ -200,7 +217,8 @@ class _DeepFM(FeatureModel):
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
             ws = sp.run_pools(staged, lo, hi, light=True)
             sp.run_lin_only(staged, lo, hi, ws)
-            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False)
+            hashed = sp.prehash(staged, lo, hi, ws) if self._prehash(hi - lo) else None
+            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
             ks, bs, hw, bn = self._dnn_operands(hi - lo)
             ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
                     head_w=hw, add=[ws["lin2"]] if "lin2" in ws else [],

@@ -80,6 +80,16 @@ def hash_bucket(x, num_buckets, mask_zero=False):
     return out
 
 
+def hash_fields(desc, n_fields, ids, out):
+    """Hash.call over the id matrix of a gather in one launch (dctr_hash_fields): ids [F, B] -> out [F, B]; fields whose
+    descriptor says hash_mode 0 are copied."""
+    _dev_check(desc, ids, out)
+    _C.check(_C.lib().dctr_hash_fields(_ptr(desc), int(n_fields), _ptr(ids), ids.stride(0), ids.stride(1),
+                                       int(ids.dtype == torch.int64), ids.shape[1], _ptr(out), out.stride(0),
+                                       int(out.dtype == torch.int64), _C.stream_ptr()), "dctr_hash_fields")
+    return out
+
+
 def pack_strings(values):
     """Host-side packing of a string column: (uint8 bytes, int64 offsets[n+1]) NumPy arrays."""
     flat = [v if isinstance(v, (bytes, np.bytes_)) else str(v).encode("utf-8") for v in values]

@@ -96,6 +96,10 @@ int dctr_hash_bucket_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t
                            int mask_zero, int64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a2 over the id matrix of a gather (declared after dctr_field_t below): dctr_hash_fields.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* ------------------------------------------------------------------------------------------------
  * a3/a4/a6/a7/a8 fused:  embedding_lookup (deepctr/inputs.py:101-117, keras Embedding gather) for
  * every SparseFeat + concat into the DNN-input layout (layers/utils.py:336-346) + Linear.call
  * (layers/utils.py:160-175, the 1-wide `linear0sparse_emb_*` tables of feature_column.py:171-210)
@@ -155,6 +159,14 @@ typedef struct {
 } dctr_gather_fm_args_t;
 
 int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);
+
+/* a2 Hash.call (deepctr/layers/utils.py:89-112, applied per SparseFeat at inputs.py:108-110) over a whole id matrix in one launch:
+ * out[j, b] = Hash(ids[j, b]; vocab_j, mask_zero = (hash_mode_j == 2)) for fields with hash_mode != 0, = ids[j, b] for the others
+ * (and identity fields).  `fields` = the gather's DEVICE descriptors; ids / out: [n_fields, batch] with the given strides (elements),
+ * int32 or int64 each (a 32-bit `out` needs every hashed vocab < 2^31 and unhashed ids that fit).  The persistent kernels of
+ * dctr_embed_mlp_fwd take plain rows: run this first, then the call with descriptors whose hash_mode is 0 and any_hash = 0. */
+int dctr_hash_fields(const dctr_field_t* fields, int32_t n_fields, const void* ids, int64_t ids_stride_f, int64_t ids_stride_b,
+                     int32_t ids_is_i64, int64_t batch, void* out, int64_t out_stride_f, int32_t out_is_i64, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a5  varlen_embedding_lookup + WeightedSequenceLayer + SequencePoolingLayer

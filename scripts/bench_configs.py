@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat  # noqa: E402
-from deepctr_amd.models import DCN, DIN, DCNMix, DeepFM, NFM, xDeepFM  # noqa: E402
+from deepctr_amd.models import AFM, DCN, DIN, PNN, DCNMix, DeepFM, NFM, xDeepFM  # noqa: E402
 
 
 def init_on_device(model, seed=0):
@@ -60,13 +60,14 @@ def run(name, model, feed, B, steps, ring):
     print("%-34s B=%-6d %9.2f us/batch  %10.2f M samples/s" % (name, B, dt * 1e6, B / dt / 1e6), flush=True)
 
 
-def run_span(name, model, feed, B, reps=8):
-    """ONE launch per call over all staged rows (what model.predict does for the DeepFM family): the library's streaming kernel."""
+def run_span(name, model, feed, B, reps=8, dnn_flop=None):
+    """ONE _forward call over all staged rows (what model.predict does for the DeepFM family): the library's persistent kernels
+    (+ the pooling / hashing launches in front of them).  ``dnn_flop``: DNN FLOP per row -> fraction of the f32-MFMA peak."""
     staged = model.stage(feed)
     model._begin()
     n = staged.n
     out = torch.empty(n, device=model.device)
-    for _ in range(2):
+    for _ in range(max(2, reps)):                       # (sustained load before the timed calls: the shader clock ramps)
         model._forward(staged, 0, n, out)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -75,12 +76,15 @@ def run_span(name, model, feed, B, reps=8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     model._check_status()
-    print("%-34s rows/launch=%-7d %9.2f us per %d rows  %10.2f M samples/s" % (name, n, dt * 1e6 * B / n, B, n / dt / 1e6), flush=True)
+    from deepctr_amd import _C
+    kern = {0: "tile", 1: "stream", 2: "chain", -1: "-"}[_C.lib().dctr_embed_mlp_fwd_last_kernel()]
+    frac = "" if dnn_flop is None else "  %.3f of the f32-MFMA peak (DNN FLOP only)" % (dnn_flop * n / dt / 157.3e12)
+    print("%-40s rows/call=%-7d %9.2f us per %d rows  %10.2f M samples/s  [%s]%s" % (name, n, dt * 1e6 * B / n, B, n / dt / 1e6, kern, frac), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c2,c2_span,c2_2launch,c3,dcn_v,dcn_m,dcn_mix,nfm,c4,c5,c5_span")
+    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,dcn_v,dcn_m,dcn_mix,nfm,afm,pnn,c4,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
     args = ap.parse_args()
@@ -104,6 +108,53 @@ def main():
         if "c2_2launch" in want:
             m.fused = False
             run("C2 DeepFM (2 launches/step)", m, feed, 4096, args.steps, ring)
+        del m
+    dnn_flop = lambda in_dim, units=(256, 128, 64): 2.0 * sum(a * b for a, b in zip((in_dim,) + tuple(units), tuple(units) + (1,)))  # noqa: E731
+    if "c1" in want:        # BASELINE configs[0] shape on the GPU (the reference's criteo_sample run is CPU plumbing): E = 4, batch 256
+        cols4 = [SparseFeat("C%d" % i, 1000, 4) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
+        m = DeepFM(cols4, cols4, device=dev)
+        init_on_device(m)
+        run("C1 shape DeepFM E=4 (1 launch/step)", m, criteo(rng, ring * 256, V=1000), 256, args.steps, ring)
+        run_span("C1 shape DeepFM E=4 (65,536 rows/call)", m, criteo(rng, 65536, V=1000), 256)
+        del m
+    if "c2_hash" in want:   # SURVEY 8(d) "Hash variant": every SparseFeat use_hash=True, raw ids uniform int32 in [0, 2^31)
+        colsh = [SparseFeat("C%d" % i, 100000, 16, use_hash=True) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
+        m = DeepFM(colsh, colsh, device=dev)
+        init_on_device(m)
+        for rows in (65536, 131072):
+            run_span("C2 hash DeepFM (hash pre-pass + chain)", m, criteo(rng, rows, V=2 ** 31 - 1), 4096, dnn_flop=dnn_flop(429))
+        m.span_batches = False
+        run("C2 hash DeepFM (1 launch/step, in-kernel hash)", m, criteo(rng, ring * 4096, V=2 ** 31 - 1), 4096, args.steps, ring)
+        del m
+    if "c2_varlen" in want:  # north_star's field mix: 26 SparseFeat + two masked mean-pooled VarLenSparseFeat (T = 20) + 13 dense
+        T = 20
+        colsv = cols16 + [VarLenSparseFeat(SparseFeat("S%d" % i, 100000, 16), maxlen=T, combiner="mean") for i in range(2)]
+        m = DeepFM(colsv, colsv, device=dev)
+        init_on_device(m)
+        for rows in (65536, 131072):
+            feed = criteo(rng, rows)
+            for i in range(2):
+                a = rng.randint(1, 100000, (rows, T)).astype(np.int32)
+                a[np.arange(T)[None, :] >= rng.randint(1, T + 1, rows)[:, None]] = 0
+                feed["S%d" % i] = a
+            run_span("C2 + 2 mean-pooled seq (pool + chain)", m, feed, 4096, dnn_flop=dnn_flop(461))
+        del m
+    if "c2_wide" in want:    # other DNN widths on the row-chained kernel
+        for units in ((128, 128), (256, 128), (200, 80), (256, 128, 128)):
+            m = DeepFM(cols16, cols16, dnn_hidden_units=units, device=dev)
+            init_on_device(m)
+            run_span("C2 DeepFM DNN %s" % "-".join(map(str, units)), m, criteo(rng, 131072), 4096, dnn_flop=dnn_flop(429, units))
+            del m
+    if "afm" in want:       # a11 AFMLayer: 325 pairs x E = 16, attention_factor 8
+        colsa = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)]
+        m = AFM(colsa, colsa, device=dev)
+        init_on_device(m)
+        run("AFM (afm_kernel) 26 fields E=16", m, criteo(rng, ring * 4096, ND=0), 4096, args.steps, ring)
+        del m
+    if "pnn" in want:       # a12 InnerProductLayer: 325 inner products in front of the DNN
+        m = PNN(cols16, use_inner=True, device=dev)
+        init_on_device(m)
+        run("PNN inner (inner_product_kernel)", m, criteo(rng, ring * 4096), 4096, args.steps, ring)
         del m
     if "c3" in want or "c3_span" in want:
         m = xDeepFM(cols16, cols16, cin_layer_size=(128, 128), device=dev)

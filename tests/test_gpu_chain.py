@@ -307,3 +307,76 @@ def test_chain_kernel_takes_pooled_sequence_features(device):
     assert _last_kernel() == "tile"
     assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain vs 32-row kernel, pooled fields")
     assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y)
+
+
+def test_hash_fields_is_bit_exact(device):
+    """dctr_hash_fields (Hash.call over a whole id matrix, reference layers/utils.py:89-112 at inputs.py:108-110) against the
+    per-column dctr_hash_bucket_* kernels and the oracle's FarmHash: bucket counts 1, 2, powers of two, primes, > 2^31;
+    mask_zero; negative ids, zero, int32 extremes, int64 ids of up to 19 digits; unhashed rows are copied."""
+    import torch
+    from deepctr_amd import ops
+    from oracle import farmhash
+    rng = np.random.RandomState(4)
+    B = 5000
+    vocabs = [1, 2, 3, 64, 1 << 20, 100003, (1 << 31) - 1, (1 << 33) + 7, 1000, 77]
+    modes = [1, 1, 2, 1, 2, 1, 1, 1, 0, 2]
+    fields = [dict(table=torch.zeros(4, 4, device=device), lin_table=None, vocab=v, dim=4, out_offset=0, in_fm=1, hash_mode=m)
+              for v, m in zip(vocabs, modes)]
+    desc = ops.make_field_descriptors(fields, device)
+    for dt, lo, hi in ((np.int32, -2 ** 31, 2 ** 31 - 1), (np.int64, -2 ** 62, 2 ** 62)):
+        ids = rng.randint(lo, hi, (len(fields), B), dtype=np.int64).astype(dt)
+        ids[:, :6] = np.array([0, 1, -1, lo, hi, 10 ** 9], dtype=np.int64).astype(dt)
+        if dt == np.int64:
+            ids[:, 6:9] = np.array([10 ** 16, -10 ** 18, 9223372036854775807], dtype=np.int64)
+        t = torch.from_numpy(ids).to(device)
+        out = torch.empty(len(fields), B, dtype=torch.int64, device=device)
+        ops.hash_fields(desc, len(fields), t, out)
+        got = out.cpu().numpy()
+        for j, (v, m) in enumerate(zip(vocabs, modes)):
+            if m == 0:
+                assert np.array_equal(got[j], ids[j].astype(np.int64))
+                continue
+            ref = ops.hash_bucket(t[j].contiguous(), v, mask_zero=(m == 2)).cpu().numpy()
+            assert np.array_equal(got[j], ref), (dt, v, m)
+            for b in (0, 1, 2, 3, 4, 5, 6, 7, 8, 100):              # and the oracle itself on a few ids
+                x = int(ids[j, b])
+                nb = v - (1 if m == 2 else 0)
+                h = farmhash.fingerprint64(str(x).encode()) % nb
+                want = (h + 1) * (x != 0) if m == 2 else h
+                assert int(got[j, b]) == want, (x, v, m)
+        if dt == np.int32:                                          # 32-bit output for vocabularies below 2^31
+            small = [j for j, v in enumerate(vocabs) if v < (1 << 31)]
+            desc_s = ops.make_field_descriptors([fields[j] for j in small], device)
+            out32 = torch.empty(len(small), B, dtype=torch.int32, device=device)
+            ops.hash_fields(desc_s, len(small), t[small].contiguous(), out32)
+            assert np.array_equal(out32.cpu().numpy().astype(np.int64), got[small])
+
+
+def test_chain_kernel_takes_hashed_sparse_features(device):
+    """north_star's 'hash-bucketed SparseFeat' on the fast kernel: raw int32 / int64 ids -> one dctr_hash_fields launch -> the
+    row-chained kernel on plain rows; hashed and plain features mixed, with pooled sequence features, against the float64
+    oracle (which hashes with the oracle's FarmHash) and the 32-row kernel (which hashes inside the gather)."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(31)
+    n, E = 16384 + 2048 + 3, 16
+    cols = [SparseFeat("C%d" % i, 5000 + i, E, use_hash=(i % 2 == 0)) for i in range(14)] + [DenseFeat("I%d" % i, 1) for i in range(3)]
+    feed = {"C%d" % i: (rng.randint(-2 ** 31, 2 ** 31 - 1, n).astype(np.int32) if i % 2 == 0 else rng.randint(0, 5000 + i, n).astype(np.int32))
+            for i in range(14)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(3)})
+    for extra in (False, True):
+        c, f = list(cols), dict(feed)
+        if extra:
+            c.append(VarLenSparseFeat(SparseFeat("tags", 400, E), maxlen=6, combiner="mean"))
+            f["tags"] = rng.randint(0, 400, (n, 6)).astype(np.int32)
+            f["C0"] = rng.randint(-2 ** 60, 2 ** 60, n).astype(np.int64)          # int64 raw ids: the id matrix stays int64
+        model = DeepFM(c, c, device=device)
+        w = _randomise(model, rng)
+        y = model.predict(f, batch_size=4096)
+        assert _last_kernel() == "chain"
+        rows = rng.choice(n, 300, replace=False)
+        ref = RM.deepfm(c, c, w, {k: v[rows] for k, v in f.items()}, dtype=np.float64)
+        check_probs(y[rows], ref.astype(np.float32), "chain DeepFM, hashed features (pooled: %s)" % extra)
+        y32 = _predict(model, f, 4096, span_batches=False, tile_rows=32)
+        assert _last_kernel() == "tile"
+        assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain + hash pre-pass vs 32-row kernel")

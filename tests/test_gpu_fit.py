@@ -46,8 +46,9 @@ def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
     model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc", "accuracy"])
     before, bce0, auc0, acc0 = model.evaluate(feed, y, batch_size=512)        # tf.keras: [loss, metric, ...] with compiled metrics
     assert before == bce0 and 0.3 < auc0 < 0.7
-    h = model.fit(feed, y, batch_size=256, epochs=8, verbose=0, validation_split=0.25)
-    assert len(h.history["loss"]) == 8 and len(h.history["val_loss"]) == 8 and len(h.history["val_auc"]) == 8
+    np.random.seed(20260921)             # fit(shuffle=True) permutes with numpy's global generator, as keras does with its own
+    h = model.fit(feed, y, batch_size=256, epochs=16, verbose=0, validation_split=0.25)
+    assert len(h.history["loss"]) == 16 and len(h.history["val_loss"]) == 16 and len(h.history["val_auc"]) == 16
     res = model.evaluate(feed, y, batch_size=512, return_dict=True)
     after = res["loss"]
     assert after < before - 0.05, (before, after)
