@@ -77,6 +77,9 @@ __device__ unsigned long long dctr_chain_wgts[1024][8];       // [0..3] wall clo
 #else
 #define CHAIN_BARRIER "s_barrier"
 #endif
+#ifndef CHAIN_SPREAD
+#define CHAIN_SPREAD 1                         // 1: the request phase of a layer-0 step is spread over its micro-steps (0: one block)
+#endif
 #ifndef CHAIN_DMA_LATE
 #define CHAIN_DMA_LATE 8                       // (even) micro-step behind which waves 4-7 issue their DMA share (waves 0-3: 0)
 #endif
@@ -428,6 +431,19 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
         }
     };
+    // the same for ONE N tile (the spread request phase issues the tiles in different micro-steps)
+    auto issue_x1 = [&](int cb, uint32_t idc, int half, XBlk& X, auto NTc) {
+        constexpr int nt = decltype(NTc)::value;
+        const int f = cb / EB, h = cb % EB;
+        const uint2 tw = *reinterpret_cast<const uint2*>(fdesc + 12 * f);
+        const char* table = reinterpret_cast<const char*>(sgpr64(tw.x, tw.y));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t gg = (uint32_t)ln >> 4, jj = (uint32_t)ln & 15u;
+        const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jj + (uint32_t)(32 * half + 16 * nt)) << 2), (int)idc);
+        const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);
+        X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
+    };
     // dense features of a pass: requested, then (a step later) written zero-padded to this wave's LDS rows — the dense
     // k-blocks of layer 0 read their B operand from there, so the hot loop has ONE kind of global load.  Lane (g, j) moves
     // columns 4g .. 4g + 3 of dense k-block c for its two rows; the lane's share of dense . dense_lin_w comes out on the way
@@ -609,6 +625,47 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             }                                                                                                    \
             CTS_STEP(b_, 2);                                                                                     \
         }
+        // The same requests SPREAD over the micro-steps of the step (CHAIN_SPREAD): all eight waves leave the step's barrier
+        // together, and as one block the phase puts ~40 vector-memory instructions of the workgroup into the CU's address path at
+        // once — the last wave in the queue waited ~3k cycles inside its phase (cycle stamps, profiles/r03_chain_lab_stamps.log)
+        // with its MFMA stream stopped behind it.  Slot i (behind the MFMAs of micro-step 2 i) of the 2 M0 slots of a step:
+        //   0: DMA share (waves 0-3), linear entries of the previous step's pair, range check of the next pair's ids;
+        //   1 / 2: rows of the next k-block, N tile 0 / 1;  3: the pair's linear entries or the next pair's ids;
+        //   DMA_LATE0 / 2: DMA share (waves 4-7);  last: FM bookkeeping of the block being multiplied (VALU only).
+#define CHAIN_PIECE0(I, XC, XN)                                                                                  \
+        {                                                                                                        \
+            constexpr int i_ = (I);                                                                              \
+            const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                     \
+            if (i_ == 0) {                                                                                       \
+                CTS_STEP(b_, 3);                                                                                 \
+                if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                   \
+                if (CHAIN_GATHER && s_ == 1) {                                                                   \
+                    bool has_;                                                                                   \
+                    (void)pair_lin_ptr(pr_, 0u, has_);                                                           \
+                    linacc += (has_ && b_ - 1 < NBE) ? lvn : 0.f;                                                \
+                }                                                                                                \
+                if (CHAIN_GATHER && s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);            \
+                CTS_STEP(b_, 2);                                                                                 \
+            }                                                                                                    \
+            if (CHAIN_GATHER && i_ == 1) {                                                                       \
+                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN, std::integral_constant<int, 0>{});      \
+                else issue_x1(min(b_ + 1, NBE - 1), idcn, 0, XN, std::integral_constant<int, 0>{});             \
+            }                                                                                                    \
+            if (CHAIN_GATHER && i_ == 2 && RT > 1) {                                                             \
+                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN, std::integral_constant<int, RT - 1>{}); \
+                else issue_x1(min(b_ + 1, NBE - 1), idcn, 0, XN, std::integral_constant<int, RT - 1>{});        \
+            }                                                                                                    \
+            if (CHAIN_GATHER && i_ == 3) {                                                                       \
+                if (s_ == 0) {                                                                                   \
+                    bool has_;                                                                                   \
+                    lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
+                }                                                                                                \
+                if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
+            }                                                                                                    \
+            if (CHAIN_GATHER && i_ == 2 * M0 - 1) {                                                              \
+                if (b_ < NBE) consume_x(b_, XC);                                                                 \
+            }                                                                                                    \
+        }
 #define CHAIN_STEP0(S, XC, XN)                                                                                   \
         {                                                                                                        \
             constexpr int s_ = (S);                                                                              \
@@ -627,7 +684,13 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 DCTR_SB;                                                                                         \
                 mfma_l0(c0, XC, u_);                                                                             \
                 DCTR_SB;                                                                                         \
-                if (u_ == PH) CHAIN_PHASE0(XC, XN)                                                               \
+                if (CHAIN_SPREAD) {                                                                              \
+                    if (u_ == 0) CHAIN_PIECE0(0, XC, XN)                                                         \
+                    if (u_ == 2) CHAIN_PIECE0(1, XC, XN)                                                         \
+                    if (u_ == 4) CHAIN_PIECE0(2, XC, XN)                                                         \
+                    if (u_ == 6) CHAIN_PIECE0(3, XC, XN)                                                         \
+                    if (u_ == 4 * M0 - 2 && u_ > 6) CHAIN_PIECE0(2 * M0 - 1, XC, XN)                             \
+                } else if (u_ == PH) CHAIN_PHASE0(XC, XN)                                                        \
                 if (u_ == DMA_LATE0 && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                               \
                 if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                                  \
                 else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                              \
@@ -647,6 +710,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             idc = idcn;
         }
 #undef CHAIN_STEP0
+#undef CHAIN_PIECE0
 #undef CHAIN_PHASE0
         if ((NB - 1) % PAIR == 0 && NB - 1 < NBE) {
             // the last step was step 0 of a field pair (odd field count, no dense k-block behind it): the pair's linear
