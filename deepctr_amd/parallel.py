@@ -61,3 +61,45 @@ def predict_distributed(model, x, batch_size=256, group=None):
     def local(shard):
         return model.predict_tensor(shard, batch_size)
     return sharded_predict(local, feed, n, group)
+
+
+def sharded_loss(local_loss_sums, n, group=None):
+    """The other exchange of the path ("all_reduce(sum) of the scalar loss for fit / evaluate"): every rank hands
+    in the SUMS of its shard (a 1-D float64 tensor: per-sample loss sum, any further additive statistics), one all-reduce over
+    the process group adds them up; returns the sums divided by ``n`` (the row count of the whole feed) as a numpy array."""
+    import torch.distributed as dist
+    t = local_loss_sums.to(torch.float64)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return (t / float(max(int(n), 1))).cpu().numpy()
+
+
+def evaluate_distributed(model, x, y, batch_size=256, group=None):
+    """``model.evaluate`` with the rows sharded across the ranks: each rank scores its contiguous shard (tables replicated, no
+    collective in the forward) and ONE all-reduce of [sum of per-sample losses, sum of squared errors, sum of absolute errors,
+    count of correct 0.5-threshold decisions] over RCCL / gloo gives every rank the loss of the whole feed — additive
+    statistics only; rank-order metrics (auc) need the gathered predictions: ``predict_distributed``.
+    Returns {"loss", "mse", "mae", "accuracy"} (loss = the compiled loss: binary_crossentropy or mse)."""
+    import torch.distributed as dist
+    feed = model._as_feed(x)
+    n = model._num_rows(feed)
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 or (dist.is_available() and dist.is_initialized()) else 0
+    lo, hi = shard_bounds(n, rank, world)
+    yt = torch.as_tensor(np.asarray(y, dtype=np.float64).reshape(-1)[lo:hi])
+    if hi > lo:
+        p = model.predict_tensor(slice_feed(feed, lo, hi), batch_size).reshape(-1).to(torch.float64)
+        yt = yt.to(p.device)
+    else:
+        p = torch.zeros(0, dtype=torch.float64, device=model.device)
+        yt = yt.to(p.device)
+    c = model._compiled or {}
+    loss_name = c.get("loss") or ("binary_crossentropy" if model.task == "binary" else "mse")
+    pc = p.clamp(1e-7, 1 - 1e-7)                              # tf.keras: backend epsilon clip
+    bce = -(yt * torch.log(pc) + (1 - yt) * torch.log(1 - pc)).sum()
+    se = ((p - yt) ** 2).sum()
+    ae = (p - yt).abs().sum()
+    acc = ((p > 0.5) == (yt > 0.5)).to(torch.float64).sum()
+    first = bce if loss_name in ("binary_crossentropy", "logloss") else se
+    out = sharded_loss(torch.stack([first, se, ae, acc]), n, group)
+    return {"loss": float(out[0]), "mse": float(out[1]), "mae": float(out[2]), "accuracy": float(out[3])}

@@ -58,3 +58,43 @@ def test_sharded_predict_gloo_world2(n):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(ok and shape == (n, 1) for _, ok, shape in res)
+
+
+def _loss_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(1)
+        p = rng.rand(n)
+        y = (rng.rand(n) > 0.5).astype(np.float64)
+        lo, hi = parallel.shard_bounds(n, rank, world)
+        pc = np.clip(p[lo:hi], 1e-7, 1 - 1e-7)
+        sums = torch.tensor([-(y[lo:hi] * np.log(pc) + (1 - y[lo:hi]) * np.log(1 - pc)).sum(), ((p[lo:hi] - y[lo:hi]) ** 2).sum()])
+        got = parallel.sharded_loss(sums, n)
+        pc = np.clip(p, 1e-7, 1 - 1e-7)
+        want = np.array([-(y * np.log(pc) + (1 - y) * np.log(1 - pc)).mean(), ((p - y) ** 2).mean()])
+        q.put((rank, bool(np.allclose(got, want, rtol=1e-12, atol=0))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 10, 257])
+def test_sharded_loss_all_reduce_gloo_world2(n):
+    """The loss exchange of the N > 1 path (one all-reduce of the shards' loss sums): world 2 over gloo reproduces the
+    unsharded mean, also when a rank's shard is empty (n = 1)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1] and all(ok for _, ok in res)

@@ -2,7 +2,8 @@
   * bench.py launched exactly as the driver launches it for N > 1 — `python -m torch.distributed.run --nproc-per-node 1 ...` —
     initialises RCCL ("nccl"), takes the rank path (barrier, all_gather_into_tensor of the logits inside the timed region,
     all_reduce(MAX) of the region times), prints one parsable line whose value agrees with the plain run;
-  * deepctr_amd.parallel.predict_distributed under an initialised "nccl" group (world 1) returns model.predict's bits.
+  * deepctr_amd.parallel.predict_distributed under an initialised "nccl" group (world 1) returns model.predict's bits, and
+    evaluate_distributed (one all-reduce of the shards' loss sums) model.evaluate's loss.
 The reference's only multi-GPU form is keras multi_gpu_model's CPU-side concat of the replicas' outputs
 (/root/reference/examples/run_classification_criteo_multi_gpu.py:47); rows shard, tables replicate.
 Each case runs in a child process (its own process group, a timeout around RCCL)."""
@@ -93,6 +94,13 @@ for ctor, kw in ((DeepFM, {}), (xDeepFM, {"cin_layer_size": (16, 16)})):
     same = yd.shape == y.shape and yd.dtype == y.dtype and bool(np.array_equal(y, yd))
     print("%%s nccl world 1: equal=%%s" %% (ctor.__name__, same), flush=True)
     ok = ok and same
+    labels = (rng.rand(n) > 0.5).astype(np.float32)
+    m.compile("adam", "binary_crossentropy")
+    ev = parallel.evaluate_distributed(m, feed, labels, batch_size=4096)      # loss all-reduce over RCCL
+    want = m.evaluate(feed, labels, batch_size=4096)
+    close = abs(ev["loss"] - want) <= 1e-9 * max(1.0, abs(want))
+    print("%%s evaluate_distributed: %%r vs evaluate %%r" %% (ctor.__name__, ev["loss"], want), flush=True)
+    ok = ok and close
 dist.barrier(device_ids=[0])
 dist.destroy_process_group()
 print("RANK_PATH_OK" if ok else "RANK_PATH_MISMATCH", flush=True)
