@@ -247,6 +247,99 @@ __global__ __launch_bounds__(256) void pool_kernel(dctr_pool_args_t a) {
     if (a.status != nullptr && __any(oor) && lane == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
 }
 
+// The common case of the same pooling — int32 ids in rows of T <= 32 (T % 4 == 0, 16-B aligned), embedding_dim 16 or 32, no
+// per-position weights, no hashing — with every memory round trip taken once: the T ids of a sample arrive as 16-B chunks spread
+// over the sample's LPR lanes and reach the row loads through the LDS crossbar (the general kernel reads each id in each of the
+// LPR lanes, 8 at a time), and up to 16 row loads per lane are in flight at once (8 there).  Same arithmetic in the same order.
+template <int LPR, int TQ>
+__global__ __launch_bounds__(256) void pool_fast_kernel(dctr_pool_args_t a) {
+    constexpr int SPW = 64 / LPR;
+    constexpr int NR = (TQ + LPR - 1) / LPR;       // 16-B id chunks per lane
+    constexpr int TT = 4 * TQ;                     // = maxlen
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = lane / LPR, q = lane % LPR;
+    const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * SPW + s;
+    const bool valid = b < a.batch;
+    const int64_t bb = valid ? b : a.batch - 1;
+    const bool by_len = a.length != nullptr;
+    const int len = (by_len && valid) ? a.length[b] : 0;
+    const int4* ids = reinterpret_cast<const int4*>(reinterpret_cast<const int32_t*>(a.idx) + bb * a.idx_stride);
+    int4 chunk[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int c = r * LPR + q;
+        chunk[r] = c < TQ ? ids[c] : int4{0, 0, 0, 0};
+    }
+    const bool is_max = a.combiner == DCTR_POOL_MAX;
+    float acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = is_max ? -INFINITY : 0.f;
+    float lacc = is_max ? -INFINITY : 0.f;
+    float cnt = 0.f;
+    int oor = 0;
+#pragma unroll
+    for (int h0 = 0; h0 < TT; h0 += 16) {
+        constexpr int U = 16;
+        int row[U];
+        bool ok[U];
+        float v[U][4], lv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = h0 + u;
+            row[u] = 0;
+            ok[u] = false;
+            if (t < TT) {
+                const int c = t >> 2;                                   // chunk c sits in lane (c % LPR) of the sample, register c / LPR
+                const int4 ch = chunk[c / LPR];
+                const int mine = (t & 3) == 0 ? ch.x : (t & 3) == 1 ? ch.y : (t & 3) == 2 ? ch.z : ch.w;
+                row[u] = __shfl(mine, (lane - q) + (c % LPR), 64);
+                ok[u] = valid && (uint64_t)(int64_t)row[u] < (uint64_t)a.vocab;
+                if (valid && !ok[u]) oor = 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u][c] = 0.f;
+            lv[u] = 0.f;
+            if (h0 + u < TT && ok[u]) {
+                load_vec<4>(a.table + (int64_t)row[u] * a.dim + q * 4, v[u]);
+                if (q == 0 && a.lin_table != nullptr) lv[u] = a.lin_table[row[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = h0 + u;
+            if (t < TT && valid) {
+                const float mk = (by_len ? (t < len) : (row[u] != 0)) ? 1.f : 0.f;
+                cnt += mk;
+                if (is_max) {
+                    const float pen = (1.f - mk) * 1e9f;  // layers/sequence.py:97
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], v[u][c] * 1.f - pen);
+                    lacc = fmaxf(lacc, lv[u] * 1.f - pen);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] += v[u][c] * 1.f * mk;
+                    lacc += lv[u] * 1.f * mk;
+                }
+            }
+        }
+    }
+    if (a.combiner == DCTR_POOL_MEAN) {
+        const float denom = (by_len ? (float)len : cnt) + 1e-8f;  // layers/sequence.py:65,103
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = acc[c] / denom;
+        lacc = lacc / denom;
+    }
+    if (valid) {
+        store_vec<4>(a.out + b * a.out_stride + q * 4, acc);
+        if (q == 0 && a.lin_out != nullptr) a.lin_out[b] = lacc;
+    }
+    if (a.status != nullptr && __any(oor) && lane == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // plain lookup: n ids -> n rows (+ mask)
 // ---------------------------------------------------------------------------------------------------
@@ -436,6 +529,21 @@ extern "C" int dctr_embed_pool(const dctr_pool_args_t* a, void* stream) {
     const int64_t blocks = dctr_ceil_div(dctr_ceil_div(a->batch, 64 / lpr), 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool: batch too large");
     hipStream_t st = (hipStream_t)stream;
+    // the fast kernel: int32 ids in 16-B aligned rows of T <= 32 (T % 4 == 0), embedding_dim 16 / 32, no weights, no hashing
+    if (v4 && (a->dim == 16 || a->dim == 32) && !a->idx_is_i64 && a->weight == nullptr && a->hash_mode == 0 && a->maxlen % 4 == 0 &&
+        a->maxlen <= 32 && a->idx_stride % 4 == 0 && dctr_aligned16(a->idx)) {
+#define CALL_PF(L, Q) DCTR_LAUNCH((pool_fast_kernel<L, Q>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
+#define CALL_PFQ(L)                                                                                     \
+        switch (a->maxlen / 4) {                                                                        \
+            case 1: CALL_PF(L, 1); break; case 2: CALL_PF(L, 2); break; case 3: CALL_PF(L, 3); break;   \
+            case 4: CALL_PF(L, 4); break; case 5: CALL_PF(L, 5); break; case 6: CALL_PF(L, 6); break;   \
+            case 7: CALL_PF(L, 7); break; default: CALL_PF(L, 8); break;                                \
+        }
+        if (a->dim == 16) { CALL_PFQ(4) } else { CALL_PFQ(8) }
+#undef CALL_PFQ
+#undef CALL_PF
+        return dctr_launch_status("dctr_embed_pool");
+    }
 #define CALL_P(VECV, L) DCTR_LAUNCH((pool_kernel<VECV, L>), dim3((unsigned)blocks), dim3(256), 0, st, *a)
     if (vec == 4) { DCTR_DISPATCH_LPR(4, lpr, CALL_P) } else { DCTR_DISPATCH_LPR(1, lpr, CALL_P) }
 #undef CALL_P

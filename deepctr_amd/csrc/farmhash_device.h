@@ -107,6 +107,42 @@ __device__ __forceinline__ Packed24 decimal_ascii_i32(int32_t x) {
     return s;
 }
 
+// The same rendering of an int32 without loops or variable-position byte stores: all ten digits by constant divisions, packed as a
+// ten-byte string with leading zeros, which one 128-bit shift then drops ("%d": no padding); the sign goes in front afterwards.
+__device__ __forceinline__ Packed24 decimal_ascii_i32_fast(int32_t x) {
+    const bool neg = x < 0;
+    const uint32_t u = neg ? (0u - (uint32_t)x) : (uint32_t)x;
+    const uint32_t hi = u / 100000u, lo = u - hi * 100000u;           // hi <= 42949, lo <= 99999
+    const uint32_t h4 = hi / 10000u, h3 = hi / 1000u - h4 * 10u, h2 = hi / 100u - (hi / 1000u) * 10u, h1 = hi / 10u - (hi / 100u) * 10u,
+                   h0 = hi - (hi / 10u) * 10u;
+    const uint32_t l4 = lo / 10000u, l3 = lo / 1000u - l4 * 10u, l2 = lo / 100u - (lo / 1000u) * 10u, l1 = lo / 10u - (lo / 100u) * 10u,
+                   l0 = lo - (lo / 10u) * 10u;
+    // string order = most significant digit first = lowest byte
+    const uint32_t b0 = h4 | (h3 << 8) | (h2 << 16) | (h1 << 24);    // bytes 0-3
+    const uint32_t b1 = h0 | (l4 << 8) | (l3 << 16) | (l2 << 24);    // bytes 4-7
+    const uint32_t b2 = l1 | (l0 << 8);                              // bytes 8-9
+    uint64_t w0 = (((uint64_t)b1 << 32) | b0) | 0x3030303030303030ull;
+    uint64_t w1 = (uint64_t)(b2 | 0x3030u);
+    int nd = 10;                                                      // significant digits: 10 minus the leading zeros
+    nd -= (u < 1000000000u) + (u < 100000000u) + (u < 10000000u) + (u < 1000000u) + (u < 100000u) + (u < 10000u) + (u < 1000u) +
+          (u < 100u) + (u < 10u);
+    const int drop = 8 * (10 - nd);                                   // bits to shift out at the string's front: 0 .. 72
+    if (drop >= 64) {
+        w0 = w1 >> (drop - 64);
+        w1 = 0;
+    } else if (drop > 0) {
+        w0 = (w0 >> drop) | (w1 << (64 - drop));
+        w1 >>= drop;
+    }
+    Packed24 s{w0, w1, 0, nd};
+    if (neg) {                                                        // (at most 11 characters)
+        s.w1 = (w1 << 8) | (w0 >> 56);
+        s.w0 = (w0 << 8) | (uint64_t)'-';
+        s.len = nd + 1;
+    }
+    return s;
+}
+
 // farmhashna::Hash64 restricted to len <= 24 (HashLen0to16 and HashLen17to32)
 __device__ __forceinline__ uint64_t dctr_fp64_packed(const Packed24& s) {
     const uint64_t len = (uint64_t)s.len;

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void hash_fields_kernel(const dctr_field_t* __
 #pragma unroll
     for (int k = 0; k < HF_IPT; ++k) {
         const int64_t b = b0 + 256 * k;
-        const dctr::Packed24 s = sizeof(TI) == 4 ? dctr::decimal_ascii_i32((int32_t)x[k]) : dctr::decimal_ascii((int64_t)x[k]);
+        const dctr::Packed24 s = sizeof(TI) == 4 ? dctr::decimal_ascii_i32_fast((int32_t)x[k]) : dctr::decimal_ascii((int64_t)x[k]);
         const uint64_t h = dctr::dctr_fp64_packed(s);
         uint64_t r = h - __umul64hi(h, magic) * nb;
         while (r >= nb) r -= nb;

@@ -655,3 +655,41 @@ def test_local_activation_unit_use_bn_matches_the_reference_op_sequence(device):
     assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-6, what="LocalActivationUnit use_bn")
     with pytest.raises(NotImplementedError):
         layer([dev(q, device), dev(k, device)], training=True)
+
+
+@pytest.mark.parametrize("combiner", ["sum", "mean", "max"])
+@pytest.mark.parametrize("by_len", [False, True])
+def test_embed_pool_fast_kernel_equals_the_general_one(device, combiner, by_len):
+    """pool_fast_kernel (int32 ids in rows of T <= 32 with T % 4 == 0, embedding_dim 16 / 32, no weights, no hashing: ids as 16-B
+    chunks, 16 row loads in flight) against the oracle, and bit for bit against the general kernel, which the same ids as int64
+    take; out-of-range ids raise the status flag in both."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(8)
+    for (B, T, E, V) in ((1, 4, 16, 9), (67, 20, 16, 1000), (130, 32, 32, 5000), (1000, 8, 32, 77), (33, 28, 16, 40)):
+        table = rng.standard_normal((V, E)).astype(np.float32) * 0.5
+        lin = rng.standard_normal(V).astype(np.float32)
+        ids = rng.randint(1, V, (B, T)).astype(np.int32)
+        lens = rng.randint(0, T + 1, B).astype(np.int32)
+        lens[0] = T
+        if B > 1:
+            lens[1] = 0
+        ids[np.arange(T)[None, :] >= lens[:, None]] = 0
+        if not by_len and B > 2:
+            ids[2, 1] = 0
+        kw = dict(lengths=lens) if by_len else dict(mask=ids != 0)
+        ref = R.sequence_pooling(table[ids], combiner, **kw)[:, 0, :]
+        ref1 = R.sequence_pooling(lin[ids][:, :, None], combiner, **kw)[:, 0, 0]
+        t_dev, l_dev, len_dev = dev(table, device), dev(lin, device), dev(lens, device) if by_len else None
+        st = ops.new_status(device)
+        out, lout = ops.embed_pool(dev(ids, device), t_dev, combiner, length=len_dev, lin_table=l_dev, status=st)
+        out64, lout64 = ops.embed_pool(dev(ids.astype(np.int64), device), t_dev, combiner, length=len_dev, lin_table=l_dev, status=st)
+        ops.check_status(st)
+        assert_close(out.cpu().numpy(), ref, what="fast pool %s T=%d" % (combiner, T))
+        assert_close(lout.cpu().numpy(), ref1, what="fast pool lin %s" % combiner)
+        assert torch.equal(out, out64) and torch.equal(lout, lout64), (combiner, by_len, B, T, E)
+    bad = ids.copy()
+    bad[3, 0] = V
+    st = ops.new_status(device)
+    ops.embed_pool(dev(bad, device), t_dev, combiner, length=len_dev, lin_table=l_dev, status=st)
+    with pytest.raises(IndexError):
+        ops.check_status(st)
