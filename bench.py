@@ -13,19 +13,23 @@ before the timed region, every step reads a DIFFERENT batch of ids (a ring of di
 How the K steps are issued.  The forward is row-independent and the fused path owns no per-batch buffer, so the product
 (`model.predict`) hands the library spans of many batches per call; `dctr_embed_mlp_fwd` then runs its persistent
 row-chained kernel (csrc/chain_device.h: a wave owns 32 batch rows end to end, weights = MFMA A operand through an LDS-DMA
-ring, a layer's accumulators are the next layer's B operand, gather HBM -> registers).  A call is cut into kernel launches
-(`dctr_embed_mlp_fwd_plan`): whole multiples of 256 rows x CUs in the 256-rows-per-workgroup shape, the rest in the 128- /
-64-row shapes.  The bench does the same: the K steps go out as ceil(K / G) calls of G consecutive batches
-(--launch-batches, default min(K, 256) = predict()'s 2^20-row spans), exactly K * 4096 rows per GPU inside the timed region, bracketed by barrier +
-synchronize, MAX over ranks.
-`one_launch_per_batch` in the JSON line is the other extreme measured right after (one launch per 4096-row batch, K of
-them in one hipGraph on 8 streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
+ring, a layer's accumulators are the next layer's B operand, gather HBM -> registers) as ONE launch per call: 256-row
+passes for the whole multiples of 256 rows x CUs, then — inside the same kernel — 64-row tail units for what is left
+(`dctr_embed_mlp_fwd_plan` lists the phases).  The bench does the same: the K steps go out as ceil(K / G) calls of G
+consecutive batches (--launch-batches, default min(K, 256) = predict()'s 2^20-row spans), exactly K * 4096 rows per GPU inside
+the timed region, bracketed by barrier + synchronize, MAX over ranks.
+`value` = the MEDIAN of --regions (5) such one-shot regions, each taken right after --prewarm-ms of the same steps untimed: an
+MI355X that has idled ramps its shader clock over tens of milliseconds (2.1 -> 2.4 GHz, profiles/r03_chain_lab_clock.log), and
+a 0.25 ms region after an idle period measures that ramp, not the kernel; the cold region is reported as `cold_one_shot`.
+After the regions a sample of the rows the timed launches wrote is compared with the float64 oracle (`parity`, the 1e-4 bar).
+`one_launch_per_batch` in the JSON line is the other extreme (one launch per 4096-row batch, K of them in one hipGraph on 8
+streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
 
 Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free; the logits of the K steps are
 all-gathered ONCE (RCCL) inside the timed region — the path's only exchange.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the timed region = chain_kernel, 256-row shape (fused gather + DNN).  It is bound by
+  roofline      the dominant kernel of the timed region = chain_kernel (fused gather + DNN; one launch per call).  It is bound by
                 the fp32 matrix pipe (301,696 DNN FLOP/sample against 1,928 algorithmic HBM bytes/sample): achieved TFLOP/s =
                 algorithmic FLOP per launch / mean launch duration, measured live: every kernel launch of the timed region
                 goes out through hipExtLaunchKernelGGL with a start/stop event pair on its own stream (dctr_profile_arm) =
@@ -33,7 +37,7 @@ Extra objects on the JSON line:
                 region: the event pairs isolate consecutive kernels, which would cost the value region ~10 %); peak 157.3 TF; its HBM figure (algorithmic bytes / the
                 same duration, of 8 TB/s) is reported next to it as hbm_frac.  `kernel_launches` lists every kernel launch
                 of one call (rows, shape, mean duration).  `traffic` = FETCH_SIZE + WRITE_SIZE per
-                launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json, `traffic_source`), scaled
+                launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json, `traffic_source`), scaled
                 to this launch's rows — not measured in this run.
   kernels       isolated single-batch launches of the 32-row fused kernel and of the two stand-alone kernels of the unfused
                 path: gather_fm_kernel (the HBM-bound kernel north_star names) and mlp_kernel (MFMA-bound).
@@ -189,12 +193,12 @@ def check_parity(model, cols, staged, launches, logits, n_rows, rank):
 
 def load_traffic(rows):
     """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch."""
-    tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(tp):
         return None, None
     try:
         j = json.load(open(tp))
-        return float(j["bytes_per_row"]) * rows, "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s rows per launch)" % j.get("rows_per_launch")
+        return float(j["bytes_per_row"]) * rows, "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s rows per launch)" % j.get("rows_per_launch")
     except Exception:
         return None, None
 
