@@ -14,27 +14,34 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tu,max_vgprs", [("chain_kernels_r2w8_m42.hip", 256), ("chain_kernels_r2w8_m41.hip", 256),
-                                          ("chain_kernels_r2w8_m22.hip", 256), ("chain_kernels_r2w8_m21.hip", 256),
-                                          ("chain_kernels_r2w4_m42.hip", 512)])
-def test_chain_kernel_needs_no_scratch(tmp_path, tu, max_vgprs):
+CHAIN_UNITS = [("chain_kernels_r2w8_m42.hip", 256), ("chain_kernels_r2w8_m41.hip", 256), ("chain_kernels_r2w8_m22.hip", 256),
+               ("chain_kernels_r2w8_m21.hip", 256), ("chain_kernels_r2w4_m42.hip", 512)]
+
+
+def test_chain_kernel_needs_no_scratch(tmp_path):
+    """Every translation unit of the row-chained kernel (compiled concurrently: ~1 minute each)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "deepctr_amd", "csrc", tu)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
-           "-I", os.path.join(ROOT, "deepctr_amd", "csrc"), "-x", "hip", "--cuda-device-only", "-c", src,
-           "-o", str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"]
-    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, check=True).stdout
-    names = re.findall(r"Function Name: (\S+)", out)
-    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
-    vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", out)]
-    agprs = [int(x) for x in re.findall(r" AGPRs: (\d+)", out)]
-    assert len(names) >= 4 and len(names) == len(scratch) == len(vgprs) == len(agprs), out[-2000:]
-    for n, s, v, a in zip(names, scratch, vgprs, agprs):
-        assert "chain_kernel" in n
-        assert s == 0, "%s spills to scratch (%d B/lane)" % (n, s)
-        assert v + a <= max_vgprs, "%s needs %d registers" % (n, v + a)
+    procs = []
+    for tu, max_vgprs in CHAIN_UNITS:
+        src = os.path.join(ROOT, "deepctr_amd", "csrc", tu)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+               "-I", os.path.join(ROOT, "deepctr_amd", "csrc"), "-x", "hip", "--cuda-device-only", "-c", src,
+               "-o", str(tmp_path / (tu + ".o")), "-Rpass-analysis=kernel-resource-usage"]
+        procs.append((tu, max_vgprs, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)))
+    for tu, max_vgprs, proc in procs:
+        out = proc.communicate()[0]
+        assert proc.returncode == 0, out[-2000:]
+        names = re.findall(r"Function Name: (\S+)", out)
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
+        vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", out)]
+        agprs = [int(x) for x in re.findall(r" AGPRs: (\d+)", out)]
+        assert len(names) >= 4 and len(names) == len(scratch) == len(vgprs) == len(agprs), (tu, out[-2000:])
+        for n, sc, v, a in zip(names, scratch, vgprs, agprs):
+            assert "chain_kernel" in n
+            assert sc == 0, "%s: %s spills to scratch (%d B/lane)" % (tu, n, sc)
+            assert v + a <= max_vgprs, "%s: %s needs %d registers" % (tu, n, v + a)
 
 
 def _resource_usage(tmp_path, tu):
