@@ -41,6 +41,7 @@ SOURCES = [
     "cin_kernels.hip",
     "cin_bwd_kernels.hip",
     "din_kernels.hip",
+    "din_chain_kernels.hip",
     "train_kernels.hip",
 ]
 

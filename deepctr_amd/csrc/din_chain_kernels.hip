@@ -1,0 +1,380 @@
+// a13 — LocalActivationUnit.call over all B*T (sample, position) rows (reference deepctr/layers/core.py:94-108, Dice
+// layers/activation.py:59-64), row-chained form: the attention MLP computed TRANSPOSED, as chain_device.h does for the DNN.
+//
+// din_score_kernel (din_kernels.hip) keeps a wave's activations in a wave-private LDS tile between the layers and reads the
+// weights as the MFMA B operand, one ds_read_b32 per MFMA: 0.46 of the f32-MFMA rate.  Here
+//   * out^T[n, row] = sum_k W'[k, n] x[row, k]: the WEIGHTS are the MFMA A operand (M = output features), a wave's 32 rows are
+//     two 16-wide N tiles.  v_mfma_f32_16x16x4_f32 leaves C[m = 4g + r][n = j] in lane (g, j), register r, and wants
+//     B[k = g][n = j] from lane (g, j): layer 0's accumulators ARE layer 1's B operand, register for register (k-slot g of
+//     k-step (tile, r) is whatever output feature that register holds — a K permutation, matched by the weight row each lane
+//     reads).  No activation ever touches LDS;
+//   * all weights stay resident in LDS (the attention MLP is small: 3E x 80 + 80 x 40 floats = 74 KB at E = 64): no ring, no
+//     DMA, NO barrier after the prologue — every wave runs its 32-row units on its own, four waves per SIMD hide each other's
+//     global-load and LDS latencies;
+//   * A fragments: the first 64 output features of layer 0 are read with ONE ds_read_b128 per k-step (lane (g, j) takes floats
+//     4j .. 4j + 3 of weight row k: M-tile mt = feature 4 i + mt, four M-tiles x two N-tiles = 8 MFMAs per LDS instruction),
+//     the remaining features (80 = 64 + 16) and layer 1 as 16-feature tiles of one ds_read_b32 each (2 MFMAs per instruction):
+//     exact tile counts, no padding of 80 to 128;
+//   * att_input = [q, k, q - k, q * k] W is evaluated as q (Wq + Wd) + k (Wk - Wd) + (q * k) Wp (K = 3E, as din_score_kernel
+//     does; the two sums are formed while the weights are copied to LDS).  Lane (g, j) loads the 16-B piece g of row j's key /
+//     query block with one global_load_dwordx4 — which IS the B operand of that block's four k-steps; the block after next is
+//     requested before the current block's 120 MFMAs.
+// Per row: raw score = Dense(1)(act(act(x W0 + b0) W1 + b1)); masking / softmax / the weighted sum of the keys stay in
+// din_pool_kernel.  Eligibility (host, below): two layers, units[0] = 64 a + 16 b (a <= 1, b <= 3), units[1] <= 64,
+// embedding_dim in {16, 32, 64}.  Everything else keeps din_score_kernel.
+#include <math.h>
+
+#include "dctr_common.h"
+#include "mfma_tile.h"
+
+namespace dctr_din_chain {
+
+using dctr::f32x4;
+
+constexpr int NW = 16;                 // waves per workgroup: four per SIMD (<= 128 VGPRs)
+constexpr int RT = 2;                  // 16-row N tiles per wave
+constexpr int UROWS = 16 * RT;         // rows of a wave's unit
+
+struct Params {
+    const float* query;                // [B, E]
+    const float* keys;                 // [B * T, E]
+    int64_t rows;                      // B * T
+    int32_t T, E, activation;
+    int32_t n0, n1;                    // units
+    const float* W0;                   // [4E, n0]
+    const float* W1;                   // [n0, n1]
+    const float* bias[2];
+    const float* dice_alpha[2];
+    const float* dice_mean[2];
+    const float* dice_var[2];
+    float dice_eps;
+    const float* out_kernel;           // [n1]
+    const float* out_bias;             // [1]
+    float* raw;                        // [B * T]
+    int64_t n_units;
+};
+
+typedef const __attribute__((address_space(1))) f32x4* gbl_f4_t;
+
+#define DC_SB __builtin_amdgcn_sched_barrier(0)
+
+// EB = E / 16; NB0 = 64-feature groups of layer 0 (ds_read_b128), NS0 = further 16-feature tiles of layer 0, NS1 = 16-feature
+// tiles of layer 1
+template <int EB, int NB0, int NS0, int NS1>
+struct Lay {
+    static constexpr int E = 16 * EB;
+    static constexpr int K0 = 3 * E;                       // rows of the folded layer-0 weights
+    static constexpr int NT0 = 4 * NB0 + NS0;              // accumulator tiles of layer 0
+    static constexpr int N0P = 64 * NB0 + 16 * NS0;        // features of layer 0 incl. zero padding = K of layer 1
+    static constexpr int S0A = 64 * NB0;                   // row stride of the b128 part (0 mod 64 floats: conflict-free)
+    static constexpr int S0B = NS0 > 0 ? 16 * NS0 + 4 : 0; // row stride of the b32 part (4 mod 8: the four k-slots on distinct banks)
+    static constexpr int N1P = 16 * NS1;
+    static constexpr int S1 = N1P + 4;
+    // the small arrays first: their reads carry compile-time offsets from the LDS base, and a ds_read offset field holds 64 KiB
+    // (behind 63 KB of layer-0 weights every such offset became a per-lane address register, hoisted out of the unit loop: spills)
+    static constexpr int PB0 = 0;                          // bias, alpha, inv, shift of layer 0: [N0P] each
+    static constexpr int PB1 = PB0 + 4 * N0P;              // ... of layer 1: [N1P] each
+    static constexpr int OK = PB1 + 4 * N1P;               // out_kernel [N1P], out_bias
+    static constexpr int W1 = OK + N1P + 4;
+    static constexpr int W0B = W1 + N0P * S1;
+    static constexpr int W0A = ((W0B + K0 * S0B + 63) / 64) * 64;     // (256-B aligned rows for the b128 reads)
+    static constexpr int END = W0A + K0 * S0A;
+};
+
+template <int EB, int NB0, int NS0, int NS1>
+__global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
+    typedef Lay<EB, NB0, NS0, NS1> L;
+    constexpr int E = L::E, NT0 = L::NT0, N0P = L::N0P;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTHR = 64 * NW;
+    // ---- once per workgroup: weights -> LDS.  Layer-0 row k of the folded matrix: k < E: Wq + Wd; k < 2E: Wk - Wd; else Wp
+    for (int idx = threadIdx.x; idx < L::K0 * N0P; idx += NTHR) {
+        const int k = idx / N0P, n = idx - k * N0P;
+        float v = 0.f;
+        if (n < p.n0) {
+            int r1 = k, r2 = k;
+            float sg = 0.f;
+            if (k < E) { r2 = 2 * E + k; sg = 1.f; }
+            else if (k < 2 * E) { r2 = E + k; sg = -1.f; }
+            else { r1 = E + k; r2 = r1; }
+            v = p.W0[(size_t)r1 * p.n0 + n] + sg * p.W0[(size_t)r2 * p.n0 + n];
+        }
+        if (n < L::S0A) smem[L::W0A + k * L::S0A + n] = v;
+        else smem[L::W0B + k * L::S0B + (n - L::S0A)] = v;
+    }
+    for (int idx = threadIdx.x; idx < N0P * L::N1P; idx += NTHR) {
+        const int k = idx / L::N1P, n = idx - k * L::N1P;
+        smem[L::W1 + k * L::S1 + n] = (k < p.n0 && n < p.n1) ? p.W1[(size_t)k * p.n1 + n] : 0.f;
+    }
+    const bool dice = p.activation == DCTR_ACT_DICE;
+    for (int n = threadIdx.x; n < N0P; n += NTHR) {
+        const bool in = n < p.n0;
+        float al = 0.f, inv = 0.f, sh = 0.f;
+        if (in && dice) {
+            al = p.dice_alpha[0][n];
+            inv = 1.f / sqrtf(p.dice_var[0][n] + p.dice_eps);
+            sh = -p.dice_mean[0][n] * inv;
+        }
+        smem[L::PB0 + n] = (in && p.bias[0] != nullptr) ? p.bias[0][n] : 0.f;
+        smem[L::PB0 + N0P + n] = al;
+        smem[L::PB0 + 2 * N0P + n] = inv;
+        smem[L::PB0 + 3 * N0P + n] = sh;
+    }
+    for (int n = threadIdx.x; n < L::N1P; n += NTHR) {
+        const bool in = n < p.n1;
+        float al = 0.f, inv = 0.f, sh = 0.f;
+        if (in && dice) {
+            al = p.dice_alpha[1][n];
+            inv = 1.f / sqrtf(p.dice_var[1][n] + p.dice_eps);
+            sh = -p.dice_mean[1][n] * inv;
+        }
+        smem[L::PB1 + n] = (in && p.bias[1] != nullptr) ? p.bias[1][n] : 0.f;
+        smem[L::PB1 + L::N1P + n] = al;
+        smem[L::PB1 + 2 * L::N1P + n] = inv;
+        smem[L::PB1 + 3 * L::N1P + n] = sh;
+        smem[L::OK + n] = in ? p.out_kernel[n] : 0.f;
+    }
+    if (threadIdx.x == 0) smem[L::OK + L::N1P] = p.out_bias[0];
+    __syncthreads();                                       // the only barrier
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    // lane bases of the A-operand reads: k-step t of a 16-row k-block reads weight row 4g + t (k-slot g)
+    const float* a0A = smem + L::W0A + (4 * g) * L::S0A + 4 * j;       // + row * S0A
+    const float* a0B = smem + L::W0B + (4 * g) * L::S0B + j;           // + row * S0B + 16 * s
+    // layer 1: k-slot g of k-step (tile, r): feature 16g + 4r + mt for a b128 tile mt of group 0, 64 NB0 + 16 s + 4g + r else
+    const float* a1G = smem + L::W1 + (16 * g) * L::S1 + j;            // + (4r + mt) * S1 + 16 * s1
+    const float* a1S = smem + L::W1 + (64 * NB0 + 4 * g) * L::S1 + j;  // + (16 s + r) * S1 + 16 * s1
+
+    for (int64_t unit = (int64_t)blockIdx.x * NW + wave; unit < p.n_units; unit += (int64_t)gridDim.x * NW) {
+        const int64_t R0 = unit * UROWS;
+        // rows of this lane's two N tiles; query rows
+        const float* kp[RT];
+        const float* qp[RT];
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            const int64_t R = min(R0 + 16 * nt + j, p.rows - 1);
+            const int64_t b = (int64_t)((uint32_t)R / (uint32_t)p.T);      // host: rows < 2^31
+            kp[nt] = p.keys + R * E + 4 * g;
+            qp[nt] = p.query + b * E + 4 * g;
+        }
+        // ---- layer 0.  Accumulators start at the bias: tile tt < 4 NB0 (b128 tile mt of group 0): feature 16g + 4r + mt;
+        // tile 4 NB0 + s: feature 64 NB0 + 16 s + 4g + r
+        f32x4 acc0[NT0][RT];
+#pragma unroll
+        for (int tt = 0; tt < NT0; ++tt) {
+            f32x4 bv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = tt < 4 * NB0 ? 16 * g + 4 * r + tt : 64 * NB0 + 16 * (tt - 4 * NB0) + 4 * g + r;
+                bv[r] = smem[L::PB0 + f];
+            }
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) acc0[tt][nt] = bv;
+        }
+        f32x4 qc[RT], kc[RT], qn[RT], kn[RT];
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            qc[nt] = *(gbl_f4_t)(qp[nt]);
+            kc[nt] = *(gbl_f4_t)(kp[nt]);
+            qn[nt] = qc[nt];
+            kn[nt] = kc[nt];
+        }
+        f32x4 fa, fan;                                     // A fragments of the b128 group: current / next k-step
+        float fb[NS0 > 0 ? NS0 : 1], fbn[NS0 > 0 ? NS0 : 1];
+        // (block pointers advance with the rolled block loop: every row offset inside a block is an immediate)
+        const float* pA = a0A;
+        const float* pB = a0B;
+        auto read_a0 = [&](int row, f32x4& a, float (&b)[NS0 > 0 ? NS0 : 1]) {
+            if constexpr (NB0 > 0) a = *reinterpret_cast<const f32x4*>(pA + row * L::S0A);
+#pragma unroll
+            for (int s = 0; s < NS0; ++s) b[s] = pB[row * L::S0B + 16 * s];
+        };
+        read_a0(0, fa, fb);
+        // (the block loop stays rolled: unrolled over E = 64 hipcc keeps the raw rows of several blocks in flight and spills)
+#pragma unroll 1
+        for (int c = 0; c < EB; ++c) {
+            const int c1 = min(c + 1, EB - 1);             // raw rows of the next block: in flight during this block's MFMAs
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) {
+                qn[nt] = *(gbl_f4_t)(qp[nt] + 16 * c1);
+                kn[nt] = *(gbl_f4_t)(kp[nt] + 16 * c1);
+            }
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    // next k-step's fragments first (its row: same block / next part / next block; past the last block: a
+                    // redundant read of row 0, dropped)
+                    const int nrel = part * 4 + t + 1;     // within this block: 1 .. 12
+                    const int nrow = nrel < 12 ? (nrel / 4) * E + (nrel % 4) : 16;      // relative to the block's first row
+                    read_a0(nrow, fan, fbn);
+                    DC_SB;
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) {
+                        const float bq = qc[nt][t], bk = kc[nt][t];
+                        const float b = part == 0 ? bq : part == 1 ? bk : bq * bk;
+                        if constexpr (NB0 > 0) {
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+                                acc0[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], b, acc0[mt][nt], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS0; ++s)
+                            acc0[4 * NB0 + s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[s], b, acc0[4 * NB0 + s][nt], 0, 0, 0);
+                    }
+                    DC_SB;
+                    fa = fan;
+#pragma unroll
+                    for (int s = 0; s < NS0; ++s) fb[s] = fbn[s];
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) {
+                qc[nt] = qn[nt];
+                kc[nt] = kn[nt];
+            }
+            pA += 16 * L::S0A;
+            pB += 16 * L::S0B;
+        }
+        // ---- activation of layer 0 in place (padded features: weights and bias 0 -> the activation of 0, taken out again by
+        // the zero rows of W1)
+#pragma unroll
+        for (int tt = 0; tt < NT0; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = tt < 4 * NB0 ? 16 * g + 4 * r + tt : 64 * NB0 + 16 * (tt - 4 * NB0) + 4 * g + r;
+                const float al = smem[L::PB0 + N0P + f], inv = smem[L::PB0 + 2 * N0P + f], sh = smem[L::PB0 + 3 * N0P + f];
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt) {
+                    const float x = acc0[tt][nt][r];
+                    acc0[tt][nt][r] = dice ? dctr::dice_pre(x, al, inv, sh) : dctr::apply_act(x, p.activation);
+                }
+            }
+        // ---- layer 1: k-steps (tile tt, r) of layer 0's accumulators; A = W1 rows of the features those registers hold
+        f32x4 acc1[NS1][RT];
+#pragma unroll
+        for (int s1 = 0; s1 < NS1; ++s1) {
+            f32x4 bv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = smem[L::PB1 + 16 * s1 + 4 * g + r];
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) acc1[s1][nt] = bv;
+        }
+        float w1c[NS1], w1n[NS1];
+        auto read_a1 = [&](int ks, float (&w)[NS1]) {      // k-step ks = 4 tt + r
+            const int tt = ks >> 2, r = ks & 3;
+            const float* src = tt < 4 * NB0 ? a1G + (4 * r + tt) * L::S1 : a1S + (16 * (tt - 4 * NB0) + r) * L::S1;
+#pragma unroll
+            for (int s1 = 0; s1 < NS1; ++s1) w[s1] = src[16 * s1];
+        };
+        read_a1(0, w1c);
+#pragma unroll
+        for (int ks = 0; ks < 4 * NT0; ++ks) {
+            if (ks + 1 < 4 * NT0) read_a1(ks + 1, w1n);
+            DC_SB;
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt)
+#pragma unroll
+                for (int s1 = 0; s1 < NS1; ++s1)
+                    acc1[s1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1c[s1], acc0[ks >> 2][nt][ks & 3], acc1[s1][nt], 0, 0, 0);
+            DC_SB;
+#pragma unroll
+            for (int s1 = 0; s1 < NS1; ++s1) w1c[s1] = w1n[s1];
+        }
+        // ---- activation of layer 1, Dense(1): this lane's features 16 s1 + 4g + r of rows 16 nt + j, then over g
+        float part[RT];
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) part[nt] = 0.f;
+#pragma unroll
+        for (int s1 = 0; s1 < NS1; ++s1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * s1 + 4 * g + r;
+                const float al = smem[L::PB1 + L::N1P + f], inv = smem[L::PB1 + 2 * L::N1P + f], sh = smem[L::PB1 + 3 * L::N1P + f];
+                const float ok = smem[L::OK + f];
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt) {
+                    const float x = acc1[s1][nt][r];
+                    const float h = dice ? dctr::dice_pre(x, al, inv, sh) : dctr::apply_act(x, p.activation);
+                    part[nt] = fmaf(f < p.n1 ? h : 0.f, ok, part[nt]);
+                }
+            }
+        const float ob = smem[L::OK + L::N1P];
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            float v = part[nt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int64_t R = R0 + 16 * nt + j;
+            if (g == 0 && R < p.rows) p.raw[R] = v + ob;
+        }
+    }
+}
+
+template <int EB, int NB0, int NS0, int NS1>
+static int launch_one(const Params& p, hipStream_t stream) {
+    typedef Lay<EB, NB0, NS0, NS1> L;
+    const size_t lds = (size_t)L::END * sizeof(float);
+    if (lds > 160 * 1024) return 0;
+    static thread_local size_t granted[DCTR_MAX_DEVICES] = {0};
+    if (dctr_grant_lds((const void*)din_chain_kernel<EB, NB0, NS0, NS1>, lds, granted) != hipSuccess) return 0;
+    int64_t grid = dctr_ceil_div(p.n_units, (int64_t)NW);
+    const int64_t cus = dctr_n_cus();
+    if (grid > cus) grid = cus;
+    DCTR_LAUNCH((din_chain_kernel<EB, NB0, NS0, NS1>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
+    return 1;
+}
+
+template <int EB>
+static int launch_e(const Params& p, int nb0, int ns0, int ns1, hipStream_t stream) {
+#define DC_CASE(A, B, C) if (nb0 == A && ns0 == B && ns1 == C) return launch_one<EB, A, B, C>(p, stream)
+    DC_CASE(1, 1, 3);      // 80-40 (DIN's att_hidden_size default)
+    DC_CASE(1, 0, 2);      // 64-32 (LocalActivationUnit's default)
+    DC_CASE(1, 0, 1);      // 64-16
+    DC_CASE(0, 2, 1);      // 32-16
+    DC_CASE(1, 0, 4);      // 64-64
+#undef DC_CASE
+    return 0;
+}
+
+// 1: the chained kernel was launched (raw scores of all rows -> raw); 0: shape not covered, nothing launched
+int try_launch(const float* query, const float* keys, int64_t batch, int T, int E, int n_layers, const int32_t* units,
+               const float* const* kernels, const float* const* biases, int activation, const float* const* dice_alpha,
+               const float* const* dice_mean, const float* const* dice_var, float dice_eps, const float* out_kernel,
+               const float* out_bias, float* raw, hipStream_t stream) {
+    if (n_layers != 2 || (E != 16 && E != 32 && E != 64)) return 0;
+    const int n0 = units[0], n1 = units[1];
+    if (n0 < 1 || n1 < 1 || n1 > 64) return 0;
+    const int nb0 = n0 >= 64 ? 1 : 0;
+    const int ns0 = (n0 - 64 * nb0 + 15) / 16;
+    const int ns1 = (n1 + 15) / 16;
+    if (n0 > 64 + 48) return 0;
+    Params p{};
+    p.query = query;
+    p.keys = keys;
+    p.rows = batch * (int64_t)T;
+    p.T = T;
+    p.E = E;
+    p.activation = activation;
+    p.n0 = n0;
+    p.n1 = n1;
+    p.W0 = kernels[0];
+    p.W1 = kernels[1];
+    for (int l = 0; l < 2; ++l) {
+        p.bias[l] = biases[l];
+        p.dice_alpha[l] = dice_alpha != nullptr ? dice_alpha[l] : nullptr;
+        p.dice_mean[l] = dice_mean != nullptr ? dice_mean[l] : nullptr;
+        p.dice_var[l] = dice_var != nullptr ? dice_var[l] : nullptr;
+    }
+    p.dice_eps = dice_eps;
+    p.out_kernel = out_kernel;
+    p.out_bias = out_bias;
+    p.raw = raw;
+    p.n_units = dctr_ceil_div(p.rows, (int64_t)UROWS);
+    if (E == 16) return launch_e<1>(p, nb0, ns0, ns1, stream);
+    if (E == 32) return launch_e<2>(p, nb0, ns0, ns1, stream);
+    return launch_e<4>(p, nb0, ns0, ns1, stream);
+}
+
+}  // namespace dctr_din_chain

@@ -10,8 +10,17 @@
 // HBM, once more from L2 for the weighted sum) and [B,E] is written.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "dctr_common.h"
 #include "mfma_tile.h"
+
+namespace dctr_din_chain {      // din_chain_kernels.hip: the row-chained form of the score kernel (two-layer attention MLPs)
+int try_launch(const float* query, const float* keys, int64_t batch, int T, int E, int n_layers, const int32_t* units,
+               const float* const* kernels, const float* const* biases, int activation, const float* const* dice_alpha,
+               const float* const* dice_mean, const float* const* dice_var, float dice_eps, const float* out_kernel,
+               const float* out_bias, float* raw, hipStream_t stream);
+}
 
 #ifdef DCTR_LAB_TIMING
 __device__ unsigned long long dctr_din_ts[64];
@@ -765,6 +774,18 @@ extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* strea
             f.out_kernel = a->out_kernel;
             f.out_bias = a->out_bias;
             f.raw = static_cast<float*>(a->workspace);
+            // the row-chained score kernel for the shapes it is instantiated for (DCTR_DIN_NO_CHAIN=1: lab switch back)
+            static const bool no_chain = getenv("DCTR_DIN_NO_CHAIN") != nullptr;
+            const size_t pool_lds0 = (size_t)4 * a->maxlen * sizeof(float);
+            if (!no_chain && pool_lds0 <= 64 * 1024 &&
+                dctr_din_chain::try_launch(a->query, a->keys, a->batch, a->maxlen, a->dim, a->n_layers, a->units, a->kernels, a->biases,
+                                           a->activation, a->dice_alpha, a->dice_mean, a->dice_var, a->dice_eps, a->out_kernel,
+                                           a->out_bias, f.raw, (hipStream_t)stream)) {
+                hipLaunchKernelGGL(din_pool_kernel, dim3((unsigned)dctr_ceil_div(a->batch, (int64_t)4)), dim3(256), pool_lds0,
+                                   (hipStream_t)stream, f.raw, a->keys, a->key_mask, a->batch, a->maxlen, a->dim,
+                                   a->weight_normalization, a->out, a->out_stride, a->scores);
+                return dctr_launch_status("dctr_din_attn_pool_fwd");
+            }
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)din_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 DCTR_REQUIRE(e == hipSuccess, (int)e, "din_attn_pool_fwd: cannot raise dynamic LDS to %zu B: %s", lds,

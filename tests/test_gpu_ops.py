@@ -537,7 +537,11 @@ def test_din_attention_c4_shape(device):
 
 @pytest.mark.parametrize("B,T,E,hid", [(2048, 50, 64, (80, 40)), (37, 21, 32, (96, 48, 20)), (9, 3, 16, (8,)),
                                        (21, 17, 48, (36, 20)),              # three k-step groups per part (odd)
-                                       (37, 21, 32, (128, 48, 20))])      # the last one is too wide for the row kernel
+                                       (37, 21, 32, (128, 48, 20)),         # the last one is too wide for the row kernel
+                                       # two-layer shapes of the row-chained score kernel (din_chain_kernels.hip): tile mixes
+                                       # 64 + 16 / 64 / 32 features, widths that are no multiples of 16, every embedding_dim
+                                       (300, 7, 16, (64, 32)), (129, 33, 32, (32, 16)), (77, 50, 64, (64, 64)),
+                                       (50, 10, 32, (72, 33)), (64, 20, 16, (80, 40)), (33, 9, 64, (64, 16))])
 def test_din_attention_row_kernel_matches_per_sample_kernel(device, B, T, E, hid):
     """The weights-in-LDS row kernel (workspace given) against the one-workgroup-per-sample kernel and the oracle,
     outputs and scores, with and without weight_normalization; B*T is not a multiple of the 16-row tile."""
