@@ -164,6 +164,8 @@ SYMBOLS = {
     "dctr_hash_bucket_i64": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_hash_bucket_bytes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     "dctr_embed_gather_fm": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), c_vp]),
+    "dctr_sgemm": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, ctypes.c_float, c_vp, c_i32,
+                                  c_i64, c_i32, c_vp]),
     "dctr_hash_fields": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_embed_pool": (ctypes.c_int, [ctypes.POINTER(PoolArgs), c_vp]),
     "dctr_embed_lookup": (ctypes.c_int, [ctypes.POINTER(LookupArgs), c_vp]),

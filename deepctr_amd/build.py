@@ -42,6 +42,7 @@ SOURCES = [
     "cin_bwd_kernels.hip",
     "din_kernels.hip",
     "din_chain_kernels.hip",
+    "gemm_kernels.hip",
     "train_kernels.hip",
 ]
 
@@ -91,7 +92,7 @@ def build(force=False, verbose=True):
         # hipcc's --hip-link would add RUNPATH=/opt/rocm-*/lib, which could pull a second HIP runtime
         # next to the one PyTorch ships; without it NEEDED libamdhip64.so.7 binds to the loaded one.
         rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
-        cmd = ["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + rocm_lib, "-lamdhip64", "-lrocblas", "-pthread"]
+        cmd = ["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + rocm_lib, "-lamdhip64", "-pthread"]
         if verbose:
             print("[dctr build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -1,0 +1,21 @@
+// Plain fp32 GEMMs of the training step (dW = X^T dZ, dH = dZ W^T, the recomputed pre-activations, CrossNet / CrossNetMix
+// projections) on v_mfma_f32_16x16x4_f32 — own kernels (gemm_kernels.hip), no BLAS library behind the C ABI.
+// Column-major BLAS semantics, so that the call sites read like the algebra they implement:
+//     C (m x n, ldc) = op(A) (m x k) * op(B) (k x n) + beta * C,      beta in {0, 1}
+// with op = none / transpose of a column-major matrix with leading dimension lda / ldb.  Exact fp32 products, fp32 accumulation
+// in the MFMA's order; results of different tile shapes differ in summation order only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dctr_gemm {
+
+enum Op { OP_N = 0, OP_T = 1 };
+
+// 0 on success, a negative DCTR_E_* / positive hipError_t otherwise
+int sgemm(hipStream_t stream, Op op_a, Op op_b, int m, int n, int k, const float* A, int lda, const float* B, int ldb, float beta,
+          float* C, int ldc);
+int sgemm_strided_batched(hipStream_t stream, Op op_a, Op op_b, int m, int n, int k, const float* A, int lda, int64_t stride_a,
+                          const float* B, int ldb, int64_t stride_b, float beta, float* C, int ldc, int64_t stride_c, int batch);
+
+}  // namespace dctr_gemm

@@ -4,12 +4,12 @@
 //                             layers/utils.py:336-346), get_linear_logit (feature_column.py:171-210) and FM
 //                             (layers/interaction.py:588-604): row gradients scatter-added into dense gradient tables
 //   dctr_mlp_bwd              backward of DNN.call + Dense(1) head (layers/core.py:189-208): the two GEMMs per layer
-//                             are plain library GEMMs (rocBLAS); masks, bias sums and the head are kernels here
+//                             are plain GEMMs on the own MFMA kernel of gemm_kernels.hip (dctr_gemm; rocBLAS until round 3); masks, bias sums and the head are kernels here
 //   dctr_adam_step            Keras Adam (non-lazy: every row of a table moves every step, as TF's
 //                             _resource_apply_sparse does) with the reference's l2 regulariser folded in
 // The reference has no code of its own for any of this (Keras autodiff + tf.keras.optimizers); the formulas are the
 // derivatives of the forward expressions cited above.
-#include <rocblas/rocblas.h>
+#include "dctr_gemm.h"
 
 #include "dctr_common.h"
 #include "embed_device.h"
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void cross_vector_bwd_kernel(const float* __re
     }
 }
 
-// matrix form, elementwise parts (the GEMMs are rocBLAS): forward  x_next = x0 .* (u + b) + x_l
+// matrix form, elementwise parts (the GEMMs are dctr_gemm): forward  x_next = x0 .* (u + b) + x_l
 __global__ __launch_bounds__(256) void cross_matrix_fwd_elem_kernel(const float* __restrict__ x0, int64_t x_stride,
                                                                     const float* __restrict__ xl, int64_t xl_stride,
                                                                     const float* __restrict__ u, const float* __restrict__ bias,
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
 // CIN backward (interaction.py:277-325), first version: the reference's own formulation — z materialised per layer,
 // 1x1 conv = GEMM — in the (b,d)-major row layout R = B*D:  X0t [R,F0],  X_k = Y_{k-1}[:, :Hn] [R,F_k],
 //   z_k[r, i*F_k+j] = X0t[r,i] X_k[r,j];   Y_k = act(z_k W_k + b_k) [R,H_k];   out[b, .] = sum_d of the direct maps.
-// The GEMMs (forward recompute, dW = z^T dpre, dz = dpre W^T) are rocBLAS; the rest are the kernels below.
+// The GEMMs (forward recompute, dW = z^T dpre, dz = dpre W^T) are dctr_gemm; the rest are the kernels below.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cin_to_rows_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F0,
                                                           int D, float* __restrict__ xt) {
@@ -792,14 +792,6 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
         for (; s < n_parts; ++s) a0 += parts[(int64_t)s * n + i];
         out[i] += (a0 + a1) + (a2 + a3);
     }
-}
-
-rocblas_handle blas_handle() {
-    static thread_local rocblas_handle h = nullptr;
-    if (h == nullptr) {
-        if (rocblas_create_handle(&h) != rocblas_status_success) h = nullptr;
-    }
-    return h;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1722,10 +1714,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_mlp_bwd_workspace_bytes(a), DCTR_E_NULL,
                  "mlp_bwd: needs a workspace of dctr_mlp_bwd_workspace_bytes() bytes");
     DCTR_REQUIRE(a->batch < 0x7fffffffLL, DCTR_E_DIM, "mlp_bwd: batch too large");
-    rocblas_handle h = blas_handle();
-    DCTR_REQUIRE(h != nullptr, DCTR_E_UNSUPPORTED, "mlp_bwd: rocBLAS handle creation failed");
     hipStream_t st = (hipStream_t)stream;
-    DCTR_REQUIRE(rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_set_stream failed");
     int w = a->in_dim;
     for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
     float* bufA = static_cast<float*>(a->workspace);
@@ -1736,15 +1725,13 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     const int B = (int)a->batch;
     const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
     const int L = a->n_layers;
-    const float one = 1.f, zero = 0.f;
     // Dice: dH of layer l (in `buf`, in place) -> dZ.  Z_l = X_l W_l is recomputed (column-major Z'(N x B) = W'(N x K) X'(K x B)).
     auto dice_bwd = [&](int l, float* buf) -> int {
         const int N = a->units[l], K = l == 0 ? a->in_dim : a->units[l - 1];
         const float* xin = l == 0 ? a->x : a->acts[l - 1];
         const int ldx = l == 0 ? (int)a->x_stride : K;
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, N, B, K, &one, a->kernels[l], N, xin, ldx,
-                                          &zero, bufZ, N);
-        if (rs != rocblas_status_success) return (int)rs;
+        int rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, N, B, K, a->kernels[l], N, xin, ldx, 0.f, bufZ, N);
+        if (rs != 0) return (int)rs;
         const float* bl = a->biases != nullptr ? a->biases[l] : nullptr;
         float* dal = a->d_dice_alpha != nullptr ? a->d_dice_alpha[l] : nullptr;
         if (a->dice_batch_mean != nullptr && a->dice_batch_var != nullptr && a->dice_batch_mean[l] != nullptr) {
@@ -1785,7 +1772,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     }
     if (dice) {
         const int rc = dice_bwd(L - 1, bufA);
-        DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(Z) failed (%d)", rc);
+        DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(Z) failed (%d)", rc);
     }
     float* dz = bufA;
     float* other = bufB;
@@ -1797,35 +1784,31 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         if (a->d_biases != nullptr && a->d_biases[l] != nullptr)
             launch_act_bwd_colsum(st, dz, (const float*)nullptr, a->batch, N, 0, a->d_biases[l]);
         // dW[K, N] (row-major) += X^T dZ:  column-major  dW'(N x K) = dZ'(N x B) * X'(K x B)^T
-        rocblas_status rs;
+        int rs;
         if (n_parts > 1) {
             const int rs_ = B / n_parts;
             const int64_t kn = (int64_t)K * N;
-            rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, N, K, rs_, &one, dz, N,
-                                               (rocblas_stride)rs_ * N, xin, ldx, (rocblas_stride)rs_ * ldx, &zero, dw_parts, N,
-                                               (rocblas_stride)kn, n_parts);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm_strided_batched(st, dctr_gemm::OP_N, dctr_gemm::OP_T, N, K, rs_, dz, N, (int64_t)rs_ * N, xin, ldx, (int64_t)rs_ * ldx, 0.f, dw_parts, N, (int64_t)kn, n_parts);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm_strided_batched(dW) failed (%d)", (int)rs);
             int64_t g = dctr_ceil_div(kn, (int64_t)256);
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, (const float*)dw_parts, kn, n_parts,
                                a->d_kernels[l]);
         } else {
-            rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, dz, N, xin, ldx, &one,
-                               a->d_kernels[l], N);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_T, N, K, B, dz, N, xin, ldx, 1.f, a->d_kernels[l], N);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(dW) failed (%d)", (int)rs);
         }
         // dH_prev[B, K] = dZ W^T:  column-major  dH'(K x B) = W'(N x K)^T * dZ'(N x B)
         const bool to_dx = l == 0;
         if (to_dx && a->dx == nullptr) break;
         float* dst = to_dx ? a->dx : other;
         const int ldd = to_dx ? (int)a->dx_stride : K;
-        rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, B, N, &one, a->kernels[l], N, dz, N, &zero,
-                           dst, ldd);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(dX) failed (%d)", (int)rs);
+        rs = dctr_gemm::sgemm(st, dctr_gemm::OP_T, dctr_gemm::OP_N, K, B, N, a->kernels[l], N, dz, N, 0.f, dst, ldd);
+        DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(dX) failed (%d)", (int)rs);
         if (!to_dx) {
             // dZ_prev = dH_prev .* act'(h_prev)
             if (dice) {
                 const int rc = dice_bwd(l - 1, other);
-                DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: rocblas_sgemm(Z) failed (%d)", rc);
+                DCTR_REQUIRE(rc == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(Z) failed (%d)", rc);
             } else if (a->activation != DCTR_ACT_LINEAR) {
                 launch_act_bwd_colsum(st, other, a->acts[l - 1], a->batch, K, (int)a->activation, (float*)nullptr);
             }
@@ -1923,12 +1906,9 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
                            (int)a->dx_accumulate);
         return dctr_launch_status("dctr_crossnet_bwd");
     }
-    // matrix: rocBLAS GEMMs + elementwise kernels, intermediates in the workspace
+    // matrix: dctr_gemm GEMMs + elementwise kernels, intermediates in the workspace
     DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_crossnet_bwd_workspace_bytes(a) && a->batch < 0x7fffffffLL,
                  DCTR_E_NULL, "crossnet_bwd(matrix): needs a workspace of dctr_crossnet_bwd_workspace_bytes() bytes");
-    rocblas_handle h = blas_handle();
-    DCTR_REQUIRE(h != nullptr && rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED,
-                 "crossnet_bwd: rocBLAS handle / stream failed");
     const int B = (int)a->batch;
     const size_t bd = (size_t)a->batch * d;
     float* ws = static_cast<float*>(a->workspace);
@@ -1939,7 +1919,6 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     float* dx0 = du + bd;
     float* dw_parts = dx0 + bd;
     const int n_parts = mlp_dw_parts(a->batch);
-    const float one = 1.f, zero = 0.f;
     auto xl_of = [&](int l, const float*& p, int& ld) {
         if (l == 0) { p = a->x; ld = (int)a->x_stride; }
         else { p = xsave + (size_t)(l - 1) * bd; ld = d; }
@@ -1948,9 +1927,8 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
         const float* xl; int ldx;
         xl_of(l, xl, ldx);
         const float* W = a->kernels + (size_t)l * d * d;
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, d, B, d, &one, W, d, xl, ldx, &zero,
-                                          us + (size_t)l * bd, d);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(u) failed (%d)", (int)rs);
+        int rs = dctr_gemm::sgemm(st, dctr_gemm::OP_T, dctr_gemm::OP_N, d, B, d, W, d, xl, ldx, 0.f, us + (size_t)l * bd, d);
+        DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm(u) failed (%d)", (int)rs);
         if (l + 1 < L)
             hipLaunchKernelGGL(cross_matrix_fwd_elem_kernel, dim3(eb), dim3(256), 0, st, a->x, a->x_stride, xl, (int64_t)ldx,
                                us + (size_t)l * bd, a->bias + (size_t)l * d, a->batch, d, xsave + (size_t)l * bd);
@@ -1966,25 +1944,22 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
                            a->bias + (size_t)l * d, a->batch, d, du, dx0);
         launch_act_bwd_colsum(st, du, (const float*)nullptr, a->batch, d, 0, a->d_bias + (size_t)l * d);
         // dW[n][k] += sum_b du[b][n] x_l[b][k]:  column-major  dW'(k x n) = X'(k x B) * du'(n x B)^T
-        rocblas_status rs;
+        int rs;
         if (n_parts > 1) {                     // the long reduction over the batch as a strided batch of row slices + a sum
             const int rs_ = B / n_parts;
             const int64_t dd = (int64_t)d * d;
-            rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, d, d, rs_, &one, xl, ldx,
-                                               (rocblas_stride)rs_ * ldx, du, d, (rocblas_stride)rs_ * d, &zero, dw_parts, d,
-                                               (rocblas_stride)dd, n_parts);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm_strided_batched(st, dctr_gemm::OP_N, dctr_gemm::OP_T, d, d, rs_, xl, ldx, (int64_t)rs_ * ldx, du, d, (int64_t)rs_ * d, 0.f, dw_parts, d, (int64_t)dd, n_parts);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm_strided_batched(dW) failed (%d)", (int)rs);
             int64_t gp = dctr_ceil_div(dd, (int64_t)256);
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(gp > 8192 ? 8192 : gp)), dim3(256), 0, st, (const float*)dw_parts, dd, n_parts,
                                a->d_kernels + (size_t)l * d * d);
         } else {
-            rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, d, B, &one, xl, ldx, du, d, &one,
-                               a->d_kernels + (size_t)l * d * d, d);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_T, d, d, B, xl, ldx, du, d, 1.f, a->d_kernels + (size_t)l * d * d, d);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm(dW) failed (%d)", (int)rs);
         }
         // g[b][k] += sum_n du[b][n] W[n][k]:  column-major  g'(k x B) += W'(k x n) * du'(n x B)
-        rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, B, d, &one, W, d, du, d, &one, g, d);
-        DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_bwd: rocblas_sgemm(g) failed (%d)", (int)rs);
+        rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, d, B, d, W, d, du, d, 1.f, g, d);
+        DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm(g) failed (%d)", (int)rs);
     }
     // d x0 = dx0 + g  (x_0 is also the first x_l)
     hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, g, (int64_t)d, a->batch, d, dx0, (int64_t)d, 1);
@@ -2076,14 +2051,10 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
     DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= p.total * sizeof(float), DCTR_E_NULL,
                  "cin_bwd: needs a workspace of dctr_cin_bwd_workspace_bytes() bytes");
     DCTR_REQUIRE(p.R < 0x7fffffffLL, DCTR_E_DIM, "cin_bwd: batch * dim too large");
-    rocblas_handle h = blas_handle();
     hipStream_t st = (hipStream_t)stream;
-    DCTR_REQUIRE(h != nullptr && rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED,
-                 "cin_bwd: rocBLAS handle / stream failed");
     float* ws = static_cast<float*>(a->workspace);
     const int R = (int)p.R, F0 = p.F0, D = p.D;
     auto grid = [](int64_t n) { int64_t b = dctr_ceil_div(n, (int64_t)256); return dim3((unsigned)(b > 8192 ? 8192 : b)); };
-    const float one = 1.f, zero = 0.f;
     float* x0t = ws + p.x0t;
     hipLaunchKernelGGL(cin_to_rows_kernel, grid(p.R * F0), dim3(256), 0, st, f->x, f->x_stride, f->batch, F0, D, x0t);
     // the activations y_k: written by the forward call (saved_y), else the forward kernel is re-run here with the workspace as its
@@ -2135,7 +2106,7 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
         int parts = (int)((size_t)p.R * K / (size_t)hk);                 // partials fit the dz buffer: parts*H*K <= R*K
         if (parts > 32) parts = 32;
         while (parts > 1 && R % parts != 0) --parts;
-        rocblas_status rs = rocblas_status_success;
+        int rs = 0;
         if (p.fused[k]) {
             // z-free: x0[r,i] xk[r,j] formed in registers as the MFMA A operand, rows = the K dimension (cin_bwd_kernels.hip)
             DCTR_REQUIRE(dctr_aligned16(dpre) && dctr_aligned16(f->filters[k]), DCTR_E_ALIGN,
@@ -2146,15 +2117,12 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
             hipLaunchKernelGGL(sum_parts_kernel, grid(hk), dim3(256), 0, st, (const float*)(ws + p.parts), hk, n_parts, a->d_filters[k]);
         } else if (parts > 1) {
             const int rs_ = R / parts;
-            rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, H, K, rs_, &one, dpre, H,
-                                               (rocblas_stride)rs_ * H, ws + p.z[k], K, (rocblas_stride)rs_ * K, &zero, dz, H,
-                                               (rocblas_stride)hk, parts);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm_strided_batched(st, dctr_gemm::OP_N, dctr_gemm::OP_T, H, K, rs_, dpre, H, (int64_t)rs_ * H, ws + p.z[k], K, (int64_t)rs_ * K, 0.f, dz, H, (int64_t)hk, parts);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "cin_bwd: sgemm_strided_batched(dW) failed (%d)", (int)rs);
             hipLaunchKernelGGL(sum_parts_kernel, grid(hk), dim3(256), 0, st, dz, hk, parts, a->d_filters[k]);
         } else {
-            rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, H, K, R, &one, dpre, H, ws + p.z[k], K, &one,
-                               a->d_filters[k], H);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_T, H, K, R, dpre, H, ws + p.z[k], K, 1.f, a->d_filters[k], H);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "cin_bwd: sgemm(dW) failed (%d)", (int)rs);
         }
         float* dxk = ws + p.dxk[k & 1];          // layer 0: x_0 is also its x_k; that second-factor gradient lands in dxk[0]
         if (p.fused[k]) {
@@ -2163,8 +2131,8 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
             DCTR_REQUIRE(rc == 0, rc, "cin_bwd: cannot launch the fused dz kernel (%d)", rc);
         } else {
             // dz[R,K] = dpre[R,H] W^T:  column-major  dz'(K x R) = W'(H x K)^T dpre'(H x R)
-            rs = rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, R, H, &one, f->filters[k], H, dpre, H, &zero, dz, K);
-            DCTR_REQUIRE(rs == rocblas_status_success, DCTR_E_UNSUPPORTED, "cin_bwd: rocblas_sgemm(dz) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm(st, dctr_gemm::OP_T, dctr_gemm::OP_N, K, R, H, f->filters[k], H, dpre, H, 0.f, dz, K);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "cin_bwd: sgemm(dz) failed (%d)", (int)rs);
             const size_t lds = (size_t)4 * (K + F0 + Fk) * sizeof(float);
             DCTR_REQUIRE(lds <= 64 * 1024, DCTR_E_UNSUPPORTED, "cin_bwd: F0*Fk = %d too large for the row-staging kernel", K);
             int64_t nb = dctr_ceil_div(p.R, (int64_t)4);
@@ -2190,7 +2158,7 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
 //   per layer l, expert e:  v1 = tanh(x_l V_e),  v2 = tanh(v1 C_e^T),  out_e = x_0 .* (v2 U_e^T + b_l),  s_e = x_l . g_e
 //   p = softmax_e(s),  x_{l+1} = sum_e p_e out_e + x_l
 // Nothing is saved by the forward kernel: the intermediates (x_l, v1, v2, uv = v2 U^T, p) are recomputed here into the
-// workspace — the low-rank projections as plain rocBLAS GEMMs, the gating / softmax / combination as one row kernel — and the
+// workspace — the low-rank projections as plain GEMMs (dctr_gemm), the gating / softmax / combination as one row kernel — and the
 // backward walks the layers in reverse:
 //   dp_e = g . out_e,  ds_e = p_e (dp_e - sum_e' p_e' dp_e'),  t_e = p_e g .* x_0   (gradient of  v2 U^T + b)
 //   d b += sum_b g .* x_0 (sum_e p_e = 1),  d U_e += t_e^T v2,  d v2 = t_e U_e,  a2 = d v2 .* (1 - v2^2),  d C_e += a2^T v1,
@@ -2385,9 +2353,6 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void
     DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= m.total * sizeof(float), DCTR_E_NULL,
                  "crossnet_mix_bwd: needs a workspace of dctr_crossnet_mix_bwd_workspace_bytes() bytes");
     DCTR_REQUIRE(B < 0x7fffffffLL / (d > r ? d : r), DCTR_E_DIM, "crossnet_mix_bwd: batch too large");
-    rocblas_handle h = blas_handle();
-    DCTR_REQUIRE(h != nullptr, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocBLAS handle creation failed");
-    DCTR_REQUIRE(rocblas_set_stream(h, st) == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocblas_set_stream failed");
     float* ws = static_cast<float*>(a->workspace);
     const float one = 1.f, zero = 0.f;
     const int Bi = (int)B;
@@ -2395,16 +2360,16 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void
     const unsigned row_blocks = (unsigned)dctr_ceil_div(B, (int64_t)4);
 #define MIX_GEMM(ta, tb, mm, nn, kk, A_, lda, B_, ldb, beta, C_, ldc)                                                      \
     do {                                                                                                                   \
-        rocblas_status rs_ = rocblas_sgemm(h, ta, tb, mm, nn, kk, &one, A_, lda, B_, ldb, beta, C_, ldc);                  \
-        DCTR_REQUIRE(rs_ == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocblas_sgemm failed (%d)", (int)rs_); \
+        int rs_ = dctr_gemm::sgemm(st, ta, tb, mm, nn, kk, A_, lda, B_, ldb, *(beta), C_, ldc);                  \
+        DCTR_REQUIRE(rs_ == 0, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: sgemm failed (%d)", (int)rs_); \
     } while (0)
 #define MIX_BGEMM(ta, tb, mm, nn, kk, A_, lda, sa, B_, ldb, sb, beta, C_, ldc, sc)                                            \
     do {                                                                                                                   \
-        rocblas_status rs_ = rocblas_sgemm_strided_batched(h, ta, tb, mm, nn, kk, &one, A_, lda, (rocblas_stride)(sa), B_, ldb, \
-                                                           (rocblas_stride)(sb), beta, C_, ldc, (rocblas_stride)(sc), ne);     \
-        DCTR_REQUIRE(rs_ == rocblas_status_success, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: rocblas_sgemm_strided_batched failed (%d)", (int)rs_); \
+        int rs_ = dctr_gemm::sgemm_strided_batched(st, ta, tb, mm, nn, kk, A_, lda, (int64_t)(sa), B_, ldb, \
+                                                           (int64_t)(sb), *(beta), C_, ldc, (int64_t)(sc), ne);     \
+        DCTR_REQUIRE(rs_ == 0, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: sgemm_strided_batched failed (%d)", (int)rs_); \
     } while (0)
-    const rocblas_operation N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+    const dctr_gemm::Op N_ = dctr_gemm::OP_N, T_ = dctr_gemm::OP_T;
     // ---- forward recompute.  X[0] = x_0 (contiguous copy), X[l+1] needed only for l + 1 < L
     hipLaunchKernelGGL(mix_copy_rows_kernel, grid(Bd), dim3(256), 0, st, a->x, a->x_stride, B, d, ws + m.X);
     const float* x0 = ws + m.X;

@@ -90,6 +90,26 @@ def hash_fields(desc, n_fields, ids, out):
     return out
 
 
+def sgemm(a, b, trans_a=False, trans_b=False, out=None, accumulate=False):
+    """Row-major convenience over dctr_sgemm (the training step's own MFMA GEMM): out [M, N] (+)= op(a) @ op(b) for 2-D (or batched
+    3-D) contiguous float32 tensors; op = transpose of the last two dimensions when the flag is set."""
+    _dev_check(a, b, out)
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    batch = a.shape[0] if a.dim() == 3 else 1
+    am, ak = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    bk, bn = (b.shape[-1], b.shape[-2]) if trans_b else (b.shape[-2], b.shape[-1])
+    if ak != bk:
+        raise ValueError("sgemm: inner dimensions %d and %d differ" % (ak, bk))
+    shape = (batch, am, bn) if a.dim() == 3 else (am, bn)
+    if out is None:
+        out = torch.zeros(shape, dtype=torch.float32, device=a.device)
+    # row-major out = op(a) op(b)  <=>  column-major out^T (bn x am) = op(b)^T op(a)^T: the BLAS call with (A, B) = (b, a)
+    _C.check(_C.lib().dctr_sgemm(int(trans_b), int(trans_a), bn, am, ak, _ptr(b), b.shape[-1], b.shape[-2] * b.shape[-1], _ptr(a),
+                                 a.shape[-1], a.shape[-2] * a.shape[-1], 1.0 if accumulate else 0.0, _ptr(out), bn, am * bn, batch,
+                                 _C.stream_ptr()), "dctr_sgemm")
+    return out
+
+
 def pack_strings(values):
     """Host-side packing of a string column: (uint8 bytes, int64 offsets[n+1]) NumPy arrays."""
     flat = [v if isinstance(v, (bytes, np.bytes_)) else str(v).encode("utf-8") for v in values]

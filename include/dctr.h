@@ -673,6 +673,17 @@ enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_RMSPROP = 2, DCTR_OPT_S
 int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
                    float beta2, float eps, int32_t zero_grad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * the plain fp32 contractions of the backward step — dW = X^T dZ, dH = dZ W^T of DNN.call
+ * (deepctr/layers/core.py:189-208 under Keras autodiff), the matrix CrossNet and CrossNetMix projections
+ * (layers/interaction.py:405-424, :511-549) — on the library's own v_mfma_f32_16x16x4_f32 GEMM (csrc/gemm_kernels.hip; no BLAS
+ * library behind this ABI).  Column-major BLAS semantics:  C (m x n, ldc) = op(A) (m x k) * op(B) (k x n) + beta * C, beta in {0, 1},
+ * trans_x != 0: op = transpose; `batch` problems at the given element strides (batch 1: strides unused).  Exact fp32 products.
+ * ------------------------------------------------------------------------------------------------ */
+int dctr_sgemm(int32_t trans_a, int32_t trans_b, int32_t m, int32_t n, int32_t k, const float* A, int32_t lda, int64_t stride_a,
+               const float* B, int32_t ldb, int64_t stride_b, float beta, float* C, int32_t ldc, int64_t stride_c, int32_t batch,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -629,3 +629,32 @@ def test_xdeepfm_hip_training_gradients_match_torch_autograd(device, split, cin_
     model.compile("adam", "binary_crossentropy")
     h = model.fit(feed, y, batch_size=50, epochs=6, verbose=0)
     assert getattr(model, "_hip_trainer", None) is not None and h.history["loss"][-1] < h.history["loss"][0]
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (429, 256, 4096), (4096, 429, 256), (77, 33, 5), (128, 128, 16), (130, 257, 1000), (64, 8, 300)])
+def test_own_sgemm_matches_float64(device, m, n, k):
+    """dctr_sgemm (csrc/gemm_kernels.hip: the training step's contractions on the library's own f32 MFMA kernel; rocBLAS until round 3):
+    every transpose combination, beta 0 / 1, batched, sizes that are no tile multiples, against float64 matmul."""
+    import torch
+    from deepctr_amd import ops
+    rng = np.random.RandomState(m + n + k)
+    for ta in (False, True):
+        for tb in (False, True):
+            a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+            b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+            ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+            mag = np.abs(a.T if ta else a).astype(np.float64) @ np.abs(b.T if tb else b).astype(np.float64)
+            got = ops.sgemm(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), ta, tb)
+            err = np.abs(got.cpu().numpy() - ref)
+            assert (err <= 2e-6 * mag + 1e-30).all(), (m, n, k, ta, tb, float((err / (mag + 1e-30)).max()))
+            c0 = rng.standard_normal((m, n)).astype(np.float32)
+            got2 = ops.sgemm(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), ta, tb,
+                             out=torch.from_numpy(c0.copy()).to(device), accumulate=True)
+            err2 = np.abs(got2.cpu().numpy() - (ref + c0))
+            assert (err2 <= 2e-6 * (mag + np.abs(c0)) + 1e-30).all(), (m, n, k, ta, tb, "accumulate")
+    ab = rng.standard_normal((3, m, k)).astype(np.float32)
+    bb = rng.standard_normal((3, k, n)).astype(np.float32)
+    gotb = ops.sgemm(torch.from_numpy(ab).to(device), torch.from_numpy(bb).to(device))
+    refb = ab.astype(np.float64) @ bb.astype(np.float64)
+    magb = np.abs(ab).astype(np.float64) @ np.abs(bb).astype(np.float64)
+    assert (np.abs(gotb.cpu().numpy() - refb) <= 2e-6 * magb + 1e-30).all()
