@@ -25,7 +25,8 @@ struct Params {
     int64_t bx, by, bd;            // batch strides
     int M, N, K;
     int accumulate;                // beta == 1
-};
+    int ksplit, kchunk;            // > 1: blockIdx.z = batch * ksplit + s, slice s multiplies k in [s * kchunk, (s + 1) * kchunk) and
+};                                 // ADDS its product to D with float atomics (D zeroed beforehand when beta == 0)
 
 template <int TW>
 __device__ __forceinline__ int perm(int x) { return TW * (x & 15) + ((x >> 4) % TW) + 16 * TW * (x / (16 * TW)); }
@@ -42,9 +43,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t i0 = (int64_t)blockIdx.y * BT, j0 = (int64_t)blockIdx.x * BT;
-    const float* X = p.X + (int64_t)blockIdx.z * p.bx;
-    const float* Y = p.Y + (int64_t)blockIdx.z * p.by;
-    float* D = p.D + (int64_t)blockIdx.z * p.bd;
+    const int bz = (int)blockIdx.z / p.ksplit, ks = (int)blockIdx.z % p.ksplit;
+    const int kbeg = ks * p.kchunk;
+    const float* X = p.X + (int64_t)bz * p.bx + (int64_t)kbeg * p.sxk;
+    const float* Y = p.Y + (int64_t)bz * p.by + (int64_t)kbeg * p.syk;
+    float* D = p.D + (int64_t)bz * p.bd;
+    const int KL = min(p.kchunk, p.K - kbeg);      // this slice's reduction length (the whole K without a split)
     const bool x_kfast = p.sxk == 1;               // X rows contiguous along k
     const bool y_jfast = p.syj == 1;               // Y rows contiguous along j
     const bool x_vec = x_kfast ? ((p.sxi & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0)
@@ -67,16 +71,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(Params p) {
             if (kfast) {
                 if (rr < n_rows) {
                     const float* src = base + rr * s_row + kk;
-                    if (vec && kk + 3 < p.K) t = *reinterpret_cast<const float4*>(src);
+                    if (vec && kk + 3 < KL) t = *reinterpret_cast<const float4*>(src);
                     else {
-                        if (kk < p.K) t.x = src[0];
-                        if (kk + 1 < p.K) t.y = src[1];
-                        if (kk + 2 < p.K) t.z = src[2];
-                        if (kk + 3 < p.K) t.w = src[3];
+                        if (kk < KL) t.x = src[0];
+                        if (kk + 1 < KL) t.y = src[1];
+                        if (kk + 2 < KL) t.z = src[2];
+                        if (kk + 3 < KL) t.w = src[3];
                     }
                 }
             } else {
-                if (kk < p.K) {
+                if (kk < KL) {
                     const float* src = base + kk * s_k + rr;
                     if (vec && rr + 3 < n_rows) t = *reinterpret_cast<const float4*>(src);
                     else {
@@ -110,17 +114,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(Params p) {
 #pragma unroll
         for (int b = 0; b < TW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkb = (p.K + BK - 1) / BK;
+    // Pipeline: k-block kb is multiplied out of LDS while block kb + 1 sits in registers (xv / yv) on its way to the other LDS
+    // buffer and block kb + 2 is in flight from memory (xw / yw): with few workgroups per CU (small outputs with a long reduction)
+    // nothing else hides a ~2 us global round trip, and one block of MFMAs is ~0.2 us
+    float4 xw[NV], yw[NV];
+    const int nkb = (KL + BK - 1) / BK;
     load_tile(X, p.sxi, p.sxk, x_kfast, x_vec, i0, p.M, 0, xv);
     load_tile(Y, p.syj, p.syk, !y_jfast, y_vec, j0, p.N, 0, yv);          // (Y's "rows" are its columns j: row stride syj, k stride syk)
+    load_tile(X, p.sxi, p.sxk, x_kfast, x_vec, i0, p.M, BK, xw);          // (past K: zeros)
+    load_tile(Y, p.syj, p.syk, !y_jfast, y_vec, j0, p.N, BK, yw);
     store_tile(Xs[0], x_kfast, xv);
     store_tile(Ys[0], !y_jfast, yv);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const int cur = kb & 1;
-        if (kb + 1 < nkb) {
-            load_tile(X, p.sxi, p.sxk, x_kfast, x_vec, i0, p.M, (kb + 1) * BK, xv);
-            load_tile(Y, p.syj, p.syk, !y_jfast, y_vec, j0, p.N, (kb + 1) * BK, yv);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            xv[u] = xw[u];
+            yv[u] = yw[u];
+        }
+        if (kb + 2 < nkb) {
+            load_tile(X, p.sxi, p.sxk, x_kfast, x_vec, i0, p.M, (kb + 2) * BK, xw);
+            load_tile(Y, p.syj, p.syk, !y_jfast, y_vec, j0, p.N, (kb + 2) * BK, yw);
         }
         // lane (g, j): A[i = j][k = g] of M-tile a = Xs[k][16 TW wm + TW j + a];  B[k = g][n = j] of N-tile b likewise
 #pragma unroll
@@ -160,7 +175,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(Params p) {
                 const int64_t jj = j0 + 16 * TW * wn + 16 * b + j;
                 if (jj < p.N) {
                     float* d = D + i * p.ldd + jj;
-                    *d = p.accumulate ? *d + acc[a][b][r] : acc[a][b][r];
+                    if (p.ksplit > 1) unsafeAtomicAdd(d, acc[a][b][r]);
+                    else *d = p.accumulate ? *d + acc[a][b][r] : acc[a][b][r];
                 }
             }
         }
@@ -188,9 +204,30 @@ static int launch(hipStream_t stream, Op op_a, Op op_b, int m, int n, int k, con
     p.bd = stride_c;
     p.accumulate = beta == 1.f ? 1 : 0;
     const int64_t t128 = dctr_ceil_div(p.M, 128) * dctr_ceil_div(p.N, 128) * batch;
-    const bool small = t128 < (int64_t)dctr_n_cus();           // the 128 x 128 tiling would leave CUs idle: 64 x 64 tiles
+    const bool small = t128 < 2 * (int64_t)dctr_n_cus();       // the 128 x 128 tiling would leave CUs (or their second workgroup slot) idle: 64 x 64 tiles
     const int bt = small ? 64 : 128;
-    const dim3 grid((unsigned)dctr_ceil_div(p.N, bt), (unsigned)dctr_ceil_div(p.M, bt), (unsigned)batch);
+    // a small output with a long reduction (dW = X^T dZ over the batch, the CrossNetMix projections' gradients): split K over
+    // workgroups until the chip is filled (>= 256 k per slice), partial products added with float atomics
+    const int64_t tiles = dctr_ceil_div(p.N, bt) * dctr_ceil_div(p.M, bt) * batch;
+    int ksplit = 1;
+    if (tiles * 2 <= (int64_t)dctr_n_cus() && k >= 1024) {
+        int64_t want = 2 * (int64_t)dctr_n_cus() / tiles;
+        if (want > k / 256) want = k / 256;
+        if (want > 32) want = 32;
+        ksplit = want > 1 ? (int)want : 1;
+    }
+    p.ksplit = ksplit;
+    p.kchunk = ksplit > 1 ? (int)(dctr_ceil_div(dctr_ceil_div(k, ksplit), 16) * 16) : k;
+    if (ksplit > 1) {
+        p.ksplit = (int)dctr_ceil_div(k, p.kchunk);            // (no empty slices)
+        if (!p.accumulate) {                                   // atomics add to zero
+            for (int b = 0; b < batch; ++b) {
+                hipError_t e = hipMemset2DAsync(C + (int64_t)b * stride_c, (size_t)ldc * sizeof(float), 0, (size_t)m * sizeof(float), (size_t)n, stream);
+                DCTR_REQUIRE(e == hipSuccess, (int)e, "sgemm: clearing C failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    const dim3 grid((unsigned)dctr_ceil_div(p.N, bt), (unsigned)dctr_ceil_div(p.M, bt), (unsigned)(batch * p.ksplit));
     DCTR_REQUIRE(grid.y <= 65535 && grid.z <= 65535, DCTR_E_DIM, "sgemm: grid too large (n=%d, batch=%d)", n, batch);
     if (small) hipLaunchKernelGGL(gemm_kernel<2>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(gemm_kernel<4>, grid, dim3(256), 0, stream, p);

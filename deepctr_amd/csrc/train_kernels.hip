@@ -1669,12 +1669,13 @@ extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) 
     return dctr_launch_status("dctr_embed_pool_bwd");
 }
 
-// dW = X^T dZ has a small output and a reduction as long as the batch: from 8192 rows on it runs as a strided batch of row slices
-// into partial products + a sum (left to rocBLAS as ONE gemm, B = 65,536 took 1.78 ms per layer on a few workgroups; the
-// library splits K by itself only at small batches)
+// dW = X^T dZ has a small output and a reduction as long as the batch: it runs as a strided batch of row slices into partial
+// products + a sum (deterministic), 512 rows per slice from 1024 rows on, at most 32 slices (as ONE gemm a 429 x 256 output is 28
+// workgroups walking the whole batch: 64 us per layer at B = 4096; round 2's rocBLAS call split K by itself at small batches and took
+// 1.78 ms per layer at B = 65,536)
 static int mlp_dw_parts(int64_t batch) {
-    if (batch < 8192) return 1;
-    int parts = (int)(batch / 2048 > 32 ? 32 : batch / 2048);
+    if (batch < 1024) return 1;
+    int parts = (int)(batch / 512 > 32 ? 32 : batch / 512);
     while (parts > 1 && batch % parts != 0) --parts;
     return parts;
 }

@@ -384,7 +384,8 @@ def test_crossnet_bwd_matches_autograd(device, par, B, d, L):
     assert_close((dx[:, :d] - 3.0).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5, what="dx " + tag)
     assert float((dx[:, d:] - 3.0).abs().max()) == 0.0
     if L:
-        assert_close(dk.cpu().numpy(), kt.grad.numpy(), rtol=2e-4, atol=2e-5, what="dW " + tag)
+        # (dW sums B products of O(1) x O(10) terms: a few fp32 ulp of that sum is ~3e-5 whatever the summation order)
+        assert_close(dk.cpu().numpy(), kt.grad.numpy(), rtol=2e-4, atol=5e-5, what="dW " + tag)
         assert_close(dbv.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-5, what="db " + tag)
 
 
