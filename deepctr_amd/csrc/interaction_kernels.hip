@@ -293,6 +293,96 @@ __global__ __launch_bounds__(256) void afm_kernel(const float* __restrict__ x, i
     if (lane == 0) y[b] = out;
 }
 
+// The same layer on the matrix pipe (embedding_dim % 16 == 0, attention_factor <= 15).  Per sample the attention net is a
+// [P pairs, E] x [E, A] product: tiles of 16 pairs are the MFMA M dimension, the pair products e_i * e_j are formed in registers
+// as the A operand (two ds_read_b128 + four multiplies per four k-steps: k-slot g of k-step t is dimension 4g + t, a K permutation
+// the B operand follows), the B operand [E, 16] = [attention_W | projection_p | zeros] stays in registers for the whole sample:
+// column n < A of a C tile is a pair's pre-activation, column A its projected product p . (e_i * e_j).  ReLU, the dot with
+// projection_h over the 16 lanes of a pair's row (DPP adds), then softmax over the pairs and the weighted sum of column A —
+// (P / 16) x (E / 4) MFMAs per sample where the VALU form spent ~150 fused multiply-adds and 2 E LDS reads PER PAIR
+// (149 -> 14 us per 4096 samples of 26 fields x 16, profiles/r03_*).  One wave per sample, four samples per workgroup.
+template <int EB>
+__global__ __launch_bounds__(256) void afm_mfma_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
+                                                       const float* __restrict__ att_w, const float* __restrict__ att_b,
+                                                       const float* __restrict__ proj_h, const float* __restrict__ proj_p,
+                                                       int A, float* __restrict__ y) {
+    constexpr int E = 16 * EB;
+    using dctr::f32x4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = F * (F - 1) / 2;
+    const int PT = (P + 15) / 16;                // pair tiles
+    int* ptab = reinterpret_cast<int*>(smem);    // [16 PT] (i << 8) | j per pair (the last pair repeated past P)
+    float* per_wave = smem + 16 * PT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    float* xs = per_wave + wave * (F * E + 2 * 16 * PT);   // [F * E] sample tile
+    float* logit = xs + F * E;                              // [16 PT]
+    float* zs = logit + 16 * PT;                            // [16 PT] projected pair products
+    for (int pidx = threadIdx.x; pidx < 16 * PT; pidx += 256) {
+        int pi, pj;
+        pair_ij(min(pidx, P - 1), F, pi, pj);
+        ptab[pidx] = (pi << 8) | pj;
+    }
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    const bool valid = b < batch;
+    if (valid) {
+        const float4* src = reinterpret_cast<const float4*>(x + b * x_stride);
+        for (int i = lane; i < F * E / 4; i += 64) reinterpret_cast<float4*>(xs)[i] = src[i];
+    }
+    // B operand: lane (g, j) holds column n = j of rows e = 16 c + 4g + t (k-step (c, t), k-slot g)
+    float bw[EB][4];
+#pragma unroll
+    for (int c = 0; c < EB; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = 16 * c + 4 * g + t;
+            bw[c][t] = j < A ? att_w[e * A + j] : (j == A ? proj_p[e] : 0.f);
+        }
+    const float bj = j < A ? att_b[j] : 0.f, hj = j < A ? proj_h[j] : 0.f;
+    __syncthreads();
+    if (!valid) return;
+    // pass 1: per pair tile, pre-activations of the attention net and the projected product
+    for (int q = 0; q < PT; ++q) {
+        const int pr = ptab[16 * q + j];
+        const float* ei = xs + (pr >> 8) * E + 4 * g;
+        const float* ej = xs + (pr & 255) * E + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < EB; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(ei + 16 * c), d = *reinterpret_cast<const float4*>(ej + 16 * c);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x * d.x, bw[c][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y * d.y, bw[c][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z * d.z, bw[c][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w * d.w, bw[c][3], acc, 0, 0, 0);
+        }
+        // lane (g, j), register r: pair 16 q + 4g + r, column j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = fmaxf(acc[r] + bj, 0.f) * hj;              // columns >= A: hj = 0
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);   // over the 16 columns of the row
+            if (j == 0) logit[16 * q + 4 * g + r] = v;
+            if (j == A) zs[16 * q + 4 * g + r] = acc[r];
+        }
+    }
+    // pass 2: softmax over the pairs, weighted sum of the projected products (interaction.py:138-145)
+    float mx = -INFINITY;
+    for (int p = lane; p < P; p += 64) mx = fmaxf(mx, logit[p]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float den = 0.f, num = 0.f;
+    for (int p = lane; p < P; p += 64) {
+        const float e_ = expf(logit[p] - mx);
+        den += e_;
+        num = fmaf(e_, zs[p], num);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        den += __shfl_xor(den, m, 64);
+        num += __shfl_xor(num, m, 64);
+    }
+    if (lane == 0) y[b] = num / den;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // InnerProduct: one wave per sample.
 // ---------------------------------------------------------------------------------------------------
@@ -669,6 +759,29 @@ extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && att_w && att_b && proj_h && proj_p && y, DCTR_E_NULL, "afm_fwd: null pointer");
     const int P = fields * (fields - 1) / 2;
+    // the matrix-pipe form: embedding_dim 16 / 32 / 64, attention_factor <= 15, 16-B aligned rows
+    if ((dim == 16 || dim == 32 || dim == 64) && att_factor <= 15 && fields <= 255 && x_stride % 4 == 0 && dctr_aligned16(x)) {
+        const int PT = (P + 15) / 16;
+        const size_t lds_m = ((size_t)16 * PT + 4 * ((size_t)fields * dim + 2 * 16 * PT)) * sizeof(float);
+        if (lds_m <= 160 * 1024) {
+            const int64_t blocks_m = dctr_ceil_div(batch, 4);
+            DCTR_REQUIRE(blocks_m <= 0x7fffffffLL, DCTR_E_DIM, "afm_fwd: batch too large");
+#define AFM_M(EBV)                                                                                                              \
+            do {                                                                                                                \
+                if (lds_m > 64 * 1024) {                                                                                        \
+                    hipError_t e = hipFuncSetAttribute((const void*)afm_mfma_kernel<EBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m); \
+                    DCTR_REQUIRE(e == hipSuccess, (int)e, "afm_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));       \
+                }                                                                                                               \
+                DCTR_LAUNCH(afm_mfma_kernel<EBV>, dim3((unsigned)blocks_m), dim3(256), lds_m, (hipStream_t)stream, x, x_stride, batch, fields, \
+                            att_w, att_b, proj_h, proj_p, att_factor, y);                                                       \
+            } while (0)
+            if (dim == 16) AFM_M(1);
+            else if (dim == 32) AFM_M(2);
+            else AFM_M(4);
+#undef AFM_M
+            return dctr_launch_status("dctr_afm_fwd");
+        }
+    }
     const size_t lds = ((size_t)dim * att_factor + 2 * att_factor + dim + 4 * ((size_t)fields * dim + P)) * sizeof(float);
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "afm_fwd: needs %zu B of LDS", lds);
     if (lds > 64 * 1024) {

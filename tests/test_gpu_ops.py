@@ -699,3 +699,28 @@ def test_embed_pool_fast_kernel_equals_the_general_one(device, combiner, by_len)
     ops.embed_pool(dev(bad, device), t_dev, combiner, length=len_dev, lin_table=l_dev, status=st)
     with pytest.raises(IndexError):
         ops.check_status(st)
+
+
+@pytest.mark.parametrize("B,F,E,A", [(4096 + 3, 26, 16, 8), (65, 5, 32, 4), (7, 2, 64, 15), (130, 13, 16, 1), (33, 26, 16, 16), (9, 7, 8, 4)])
+def test_afm_matrix_pipe_kernel(device, B, F, E, A):
+    """AFMLayer (reference layers/interaction.py:116-146) on the matrix pipe (embedding_dim % 16 == 0, attention_factor <= 15;
+    the last two shapes keep the one-wave-per-sample VALU kernel): float64 oracle, pair counts that are no multiple of the 16-pair
+    tile, a strided input (a slice of a wider row, as the AFM model hands it)."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(B + F + E + A)
+    x = (rng.standard_normal((B, F, E)) * 0.5).astype(np.float32)
+    W = (rng.standard_normal((E, A)) / np.sqrt(E)).astype(np.float32)
+    b = (rng.standard_normal(A) * 0.1).astype(np.float32)
+    h = rng.standard_normal((A, 1)).astype(np.float32)
+    pvec = rng.standard_normal((E, 1)).astype(np.float32)
+    ref = R.afm([x[:, i:i + 1, :].astype(np.float64) for i in range(F)], W.astype(np.float64), b.astype(np.float64), h.astype(np.float64),
+                pvec.astype(np.float64))
+    y = ops.afm(dev(x, device), dev(W, device), dev(b, device), dev(h, device), dev(pvec, device))
+    # out = sum_p softmax_p (bi_p . p): a sum of P terms of either sign -> a few fp32 ulp of sum_p |bi_p . p| besides 1e-4 relative
+    bi = np.stack([x[:, i].astype(np.float64) * x[:, jj].astype(np.float64) for i in range(F) for jj in range(i + 1, F)], axis=1)
+    mag = np.abs(bi @ pvec.astype(np.float64)).max(axis=1)
+    assert_close_terms(y.cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1), mag.reshape(-1), rtol_terms=4e-6, what="afm F=%d E=%d A=%d" % (F, E, A))
+    wide = torch.zeros(B, F * E + 8, device=device)
+    wide[:, 4:4 + F * E] = dev(x.reshape(B, -1), device)
+    ys = ops.afm(wide[:, 4:4 + F * E], dev(W, device), dev(b, device), dev(h, device), dev(pvec, device), fields=F, dim=E)
+    assert_close(ys.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6, what="afm strided input")
