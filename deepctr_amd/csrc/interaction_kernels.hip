@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void afm_mfma_kernel(const float* __restrict__
         const float4* src = reinterpret_cast<const float4*>(x + b * x_stride);
         for (int i = lane; i < F * E / 4; i += 64) reinterpret_cast<float4*>(xs)[i] = src[i];
     }
-    // B operand: lane (g, j) holds column n = j of rows e = 16 c + 4g + t (k-step (c, t), k-slot g)
+    // weight operand: lane (g, j) holds column n = j of rows e = 16 c + 4g + t (k-step (c, t), k-slot g)
     float bw[EB][4];
 #pragma unroll
     for (int c = 0; c < EB; ++c)
@@ -337,7 +337,15 @@ __global__ __launch_bounds__(256) void afm_mfma_kernel(const float* __restrict__
             const int e = 16 * c + 4 * g + t;
             bw[c][t] = j < A ? att_w[e * A + j] : (j == A ? proj_p[e] : 0.f);
         }
-    const float bj = j < A ? att_b[j] : 0.f, hj = j < A ? proj_h[j] : 0.f;
+    // the product is taken TRANSPOSED — C'[column][pair] = Wext^T (A operand) x products^T (B operand): lane (g, j), register r then
+    // holds column 4g + r of pair j, and a pair's dot with projection_h is four local terms + two cross-lane adds (over g)
+    float b4[4], h4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 4 * g + r;
+        b4[r] = n < A ? att_b[n] : 0.f;
+        h4[r] = n < A ? proj_h[n] : 0.f;
+    }
     __syncthreads();
     if (!valid) return;
     // pass 1: per pair tile, pre-activations of the attention net and the projected product
@@ -349,20 +357,19 @@ __global__ __launch_bounds__(256) void afm_mfma_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < EB; ++c) {
             const float4 a = *reinterpret_cast<const float4*>(ei + 16 * c), d = *reinterpret_cast<const float4*>(ej + 16 * c);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x * d.x, bw[c][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y * d.y, bw[c][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z * d.z, bw[c][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w * d.w, bw[c][3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[c][0], a.x * d.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[c][1], a.y * d.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[c][2], a.z * d.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[c][3], a.w * d.w, acc, 0, 0, 0);
         }
-        // lane (g, j), register r: pair 16 q + 4g + r, column j
+        // lane (g, j), register r: column 4g + r of pair 16 q + j
+        float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = fmaxf(acc[r] + bj, 0.f) * hj;              // columns >= A: hj = 0
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);   // over the 16 columns of the row
-            if (j == 0) logit[16 * q + 4 * g + r] = v;
-            if (j == A) zs[16 * q + 4 * g + r] = acc[r];
-        }
+        for (int r = 0; r < 4; ++r) v = fmaf(fmaxf(acc[r] + b4[r], 0.f), h4[r], v);        // columns >= A: h = 0
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) logit[16 * q + j] = v;
+        if (g == (A >> 2)) zs[16 * q + j] = (A & 3) == 0 ? acc[0] : (A & 3) == 1 ? acc[1] : (A & 3) == 2 ? acc[2] : acc[3];
     }
     // pass 2: softmax over the pairs, weighted sum of the projected products (interaction.py:138-145)
     float mx = -INFINITY;
