@@ -571,6 +571,11 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         // fragment of micro-step u + 1 is requested before the MFMAs of micro-step u (two 4-register buffers, c0 / c1).
         // Layer 0, k-block step: micro-step u = (k-step t = u / M0, M-group mg = u % M0) reads weight row 4g + t
         f32x4 c0, c1;
+        // RT = 1 (the tail phase): a micro-step is 4 MFMAs = 128 cycles, about one LDS round trip — a fragment requested one
+        // micro-step ahead arrives as its MFMAs want to issue (stamps: ~60 cycles lost per micro-step).  There the fragments are
+        // requested TWO micro-steps ahead (c2 / c3 = the next pair)
+        constexpr bool DEEP = RT == 1;
+        f32x4 c2, c3;
         auto read_l0 = [&](const float* sb, int u) -> f32x4 {
             return *reinterpret_cast<const f32x4*>(sb + l0off + (u / M0) * (64 * M0) + 64 * (u % M0));
         };
@@ -675,12 +680,15 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             CTS_STEP(b_, 1);                                                                                     \
             const float* sb_ = slot_ptr(0);                                                                      \
             if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
+            if (DEEP && b_ == 0) c1 = read_l0(sb_, 1);                                                           \
             if (b_ >= NBE) {                                                                                     \
                 _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
                     XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
             }                                                                                                    \
             _Pragma("unroll") for (int u_ = 0; u_ < 4 * M0; u_ += 2) {                                           \
-                c1 = read_l0(sb_, u_ + 1);                                                                       \
+                if (!DEEP) c1 = read_l0(sb_, u_ + 1);                                                            \
+                else if (u_ + 2 < 4 * M0) c2 = read_l0(sb_, u_ + 2);                                             \
+                else if (b_ + 1 < NB) c2 = read_l0(slot_ptr(1), 0);                                              \
                 DCTR_SB;                                                                                         \
                 mfma_l0(c0, XC, u_);                                                                             \
                 DCTR_SB;                                                                                         \
@@ -692,11 +700,20 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                     if (u_ == 4 * M0 - 2 && u_ > 6) CHAIN_PIECE0(2 * M0 - 1, XC, XN)                             \
                 } else if (u_ == PH) CHAIN_PHASE0(XC, XN)                                                        \
                 if (u_ == DMA_LATE0 && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                               \
-                if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                                  \
-                else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                              \
+                if (!DEEP) {                                                                                     \
+                    if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                              \
+                    else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                          \
+                } else {                                                                                         \
+                    if (u_ + 3 < 4 * M0) c3 = read_l0(sb_, u_ + 3);                                              \
+                    else if (b_ + 1 < NB) c3 = read_l0(slot_ptr(1), 1);                                          \
+                }                                                                                                \
                 DCTR_SB;                                                                                         \
                 mfma_l0(c1, XC, u_ + 1);                                                                         \
                 DCTR_SB;                                                                                         \
+                if (DEEP && (u_ + 2 < 4 * M0 || b_ + 1 < NB)) {                                                  \
+                    c0 = c2;                                                                                     \
+                    c1 = c3;                                                                                     \
+                }                                                                                                \
             }                                                                                                    \
             slot_next();                                                                                         \
         }
@@ -801,6 +818,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                         dense_rest(pass_n);
                     }
                     if (first) c0 = read_an(sb, 0);
+                    if (DEEP && first) c1 = read_an(sb, 1);
                     if (PARKED && mg == MI - 1 && mg1 == 0) {
                         const f32x4* park = park_ptr();
 #pragma unroll
@@ -810,7 +828,9 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                     }
 #pragma unroll
                     for (int ks = 0; ks < 16; ks += 2) {
-                        c1 = read_an(sb, ks + 1);
+                        if (!DEEP) c1 = read_an(sb, ks + 1);
+                        else if (ks + 2 < 16) c2 = read_an(sb, ks + 2);
+                        else if (!last) c2 = read_an(slot_ptr(1), 0);
                         DCTR_SB;
 #pragma unroll
                         for (int mt1 = 0; mt1 < 4; ++mt1)
@@ -831,8 +851,13 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                             }
                         }
                         if (ks == CHAIN_DMA_LATE && !dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
-                        if (ks + 2 < 16) c0 = read_an(sb, ks + 2);
-                        else if (!last) c0 = read_an(slot_ptr(1), 0);
+                        if (!DEEP) {
+                            if (ks + 2 < 16) c0 = read_an(sb, ks + 2);
+                            else if (!last) c0 = read_an(slot_ptr(1), 0);
+                        } else {
+                            if (ks + 3 < 16) c3 = read_an(sb, ks + 3);
+                            else if (!last) c3 = read_an(slot_ptr(1), 1);
+                        }
                         DCTR_SB;
 #pragma unroll
                         for (int mt1 = 0; mt1 < 4; ++mt1)
@@ -840,6 +865,10 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                             for (int nt = 0; nt < RT; ++nt)
                                 mfma_bi(accout[4 * mg1 + mt1][nt], c1[mt1], accin[4 * mg + ((ks + 1) >> 2)][nt][(ks + 1) & 3]);
                         DCTR_SB;
+                        if (DEEP && (ks + 2 < 16 || !last)) {
+                            c0 = c2;
+                            c1 = c3;
+                        }
                     }
                     slot_next();
                     ++sidx;
