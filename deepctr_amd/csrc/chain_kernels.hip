@@ -43,7 +43,7 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
 // units when that finishes sooner than one more (partly filled) round of 256-row passes.  Relative times (measured, C2): a 256-row
 // pass = 1; a 64-row tail unit ~ TAIL_COST (one wave per SIMD: nothing hides a wave's request phase): L <= 64 x CUs x k rows cost
 // k x TAIL_COST.  shape 256: everything in 256-row passes; shape 128: the <2, 4> kernel (its own launch).
-constexpr double TAIL_COST = 0.375;     // measured: 62 us per unit round against 165 us per pass (profiles/r03_chain_lab_clock.log)
+constexpr double TAIL_COST = 0.35;      // measured: 55-57 us per unit round against 162 us per pass (profiles/r03_chain_lab_clock.log)
 static void split(int64_t batch, int shape, int64_t* main_rows, int64_t* tail_rows) {
     const int64_t cus = n_cus();
     if (shape == 256 || shape == 128) {

@@ -225,7 +225,7 @@ def test_chain_one_launch_main_and_tail_phases(device, n):
     assert all(k == "chain" for _, k, _ in plan) and sum(r for r, _, _ in plan) == n and len(plan) <= 2, plan
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     left = n % (256 * cus)
-    want_tail = 0 < left <= 2 * 64 * cus          # a 64-row unit costs 0.375 of a 256-row pass: up to two rounds of units
+    want_tail = 0 < left <= 2 * 64 * cus          # a 64-row unit costs 0.35 of a 256-row pass: up to two rounds of units
     assert (plan[-1][2] == 64) == want_tail, (plan, left)
     assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y)
     rows = np.unique(np.concatenate([np.arange(0, 100), np.arange(n - 200, n), rng.choice(n, 200, replace=False)]))
