@@ -27,6 +27,7 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     int M[3];
     if (!widths(a, forced ? a->tile_rows : 0, M)) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
+    if (lds_bytes(2, 8, g->n_dense > 0 ? g->n_dense : 0) > 160 * 1024) return 0;       // (dense staging area: <= 32 dense columns)
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
     if (a->in_dim != g->n_fields * E + (g->n_dense > 0 ? g->n_dense : 0)) return 0;
     if (g->ids_stride_f < 0 || g->ids_stride_b < 0) return 0;

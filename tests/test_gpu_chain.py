@@ -196,11 +196,18 @@ def test_streaming_kernel_still_reachable(device):
     y = model.predict(feed, batch_size=4096)
     ys = _predict(model, feed, 4096, tile_rows=64)
     assert_close(ys, y, rtol=2e-6, atol=2e-7, what="streaming vs chained kernel")
-    # a DNN the chained kernel has no instantiation for goes to the streaming kernel by itself
-    model2 = DeepFM(cols, cols, dnn_hidden_units=(128, 96, 40), device=device)
+    # a DNN the chained kernel cannot take even padded (a first layer wider than 256) goes to the streaming / tile kernels by itself
+    model2 = DeepFM(cols, cols, dnn_hidden_units=(320, 96, 40), device=device)
     _randomise(model2, rng)
     y2 = model2.predict(feed, batch_size=4096)
     assert_close(y2, _predict(model2, feed, 4096, span_batches=False, tile_rows=32), rtol=2e-6, atol=2e-7, what="fallback")
+    # more dense columns than the row-chained kernel's LDS staging area holds (> 32): the streaming kernel takes the call
+    cols3, feed3 = _criteo_like(rng, n, F=6, V=3000, E=16, ND=40)
+    model3 = DeepFM(cols3, cols3, device=device)
+    _randomise(model3, rng)
+    y3 = model3.predict(feed3, batch_size=4096)
+    assert _last_kernel() == "stream"
+    assert_close(y3, _predict(model3, feed3, 4096, span_batches=False, tile_rows=32), rtol=2e-6, atol=2e-7, what="40 dense columns")
 
 
 def _last_kernel():
