@@ -63,6 +63,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b"optimizer kind 9" in lib.dctr_last_error()
     assert lib.dctr_mlp_bwd(None, None) == -1 and lib.dctr_cin_bwd(None, None) == -1 and lib.dctr_crossnet_bwd(None, None) == -1
     assert lib.dctr_embed_gather_fm_bwd(None, None) == -1 and lib.dctr_embed_pool_bwd(None, None) == -1
+    # round 3: Hash over an id matrix, the library's own GEMM
+    assert lib.dctr_hash_fields(None, 3, None, 8, 1, 0, 8, None, 8, 0, None) == -1
+    assert lib.dctr_hash_fields(None, -1, None, 8, 1, 0, 8, None, 8, 0, None) == -2
+    assert lib.dctr_hash_fields(None, 0, None, 8, 1, 0, 8, None, 8, 0, None) == 0         # nothing to hash
+    assert lib.dctr_sgemm(0, 0, 4, 4, 4, None, 4, 0, None, 4, 0, 0.0, None, 4, 0, 1, None) == -1
+    assert lib.dctr_sgemm(0, 0, -4, 4, 4, None, 4, 0, None, 4, 0, 0.0, None, 4, 0, 1, None) == -2
+    assert lib.dctr_sgemm(0, 0, 4, 4, 4, None, 4, 0, None, 4, 0, 0.5, None, 4, 0, 1, None) == -5     # beta other than 0 / 1
+    assert lib.dctr_sgemm(0, 0, 4, 4, 4, None, 4, 0, None, 4, 0, 0.0, None, 2, 0, 1, None) == -2      # ldc < m
+    assert lib.dctr_sgemm(0, 0, 0, 4, 4, None, 4, 0, None, 4, 0, 0.0, None, 4, 0, 1, None) == 0       # empty product
+    assert lib.dctr_embed_mlp_fwd_last_kernel() == -1                                                 # no fused launch on this thread yet
 
 
 def test_host_pack_columns_converts_like_numpy():
