@@ -78,7 +78,7 @@ class MlpArgs(ctypes.Structure):
                 ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
                 ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
                 ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
-                ("save_acts", c_vp), ("tile_rows", c_i32), ("reserved_", c_i32), ("probe", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp)]
+                ("save_acts", c_vp), ("tile_rows", c_i32), ("precision", c_i32), ("probe", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp)]
 
 
 class FieldGrad(ctypes.Structure):

@@ -26,6 +26,7 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     if (a->activation != DCTR_ACT_RELU && a->activation != DCTR_ACT_LINEAR) return 0;
     int M[3];
     if (!widths(a, forced ? a->tile_rows : 0, M)) return 0;
+    if (a->precision != 0 && !(M[0] == 4 && M[1] == 2 && M[2] == 1 && a->tile_rows != 128 && a->bn_scale == nullptr)) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
     if (lds_bytes(2, 8, g->n_dense > 0 ? g->n_dense : 0) > 160 * 1024) return 0;       // (dense staging area: <= 32 dense columns)
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
@@ -131,6 +132,14 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
 #endif
     const int64_t want = p.n_pass > p.n_tail ? p.n_pass : p.n_tail;
     const unsigned blocks = (unsigned)(want < slots ? want : slots);
+    if (a->precision != 0) {                               // exploratory bf16 x 3 variant (eligible() admitted 256-128-64 only)
+        const size_t need = bf3_workspace_bytes(p.in_dim);
+        if (a->workspace == nullptr || a->workspace_bytes < need || !dctr_aligned16(a->workspace)) {
+            dctr_set_error("embed_mlp_fwd(chain, bf16x3): needs a 16-B aligned workspace of %zu B for the packed weights", need);
+            return DCTR_E_NULL;
+        }
+        return launch_r2w8_m42_bf3(p, E, a->workspace, a->precision == 1, blocks, stream);
+    }
     if (shape == 128) return launch_r2w4_m42(p, E, M[2], blocks, stream);
     if (M[0] == 4) return M[1] == 2 ? launch_r2w8_m42(p, E, M[2], blocks, stream) : launch_r2w8_m41(p, E, M[2], blocks, stream);
     return M[1] == 2 ? launch_r2w8_m22(p, E, M[2], blocks, stream) : launch_r2w8_m21(p, E, M[2], blocks, stream);

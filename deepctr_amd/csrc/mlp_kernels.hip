@@ -30,6 +30,7 @@ namespace dctr_chain {
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);   // chain_kernels.hip
 int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int shape, hipStream_t stream);
 int plan(int64_t batch, int shape, int64_t* rows, int32_t* rpw, int max);
+size_t bf3_workspace_bytes(int in_dim);                                                 // chain_kernels_r2w8_m42_bf3.hip
 }
 namespace dctr_stream {
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);
@@ -51,11 +52,17 @@ constexpr size_t LDS_PER_CU = 160 * 1024;
 
 }  // namespace
 
-extern "C" size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t*) { return 0; }  // activations live in LDS
+// activations live in LDS; only the exploratory bf16x3 precision keeps a packed copy of the weights in HBM
+extern "C" size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* a) {
+    if (a == nullptr || a->precision < 1 || a->precision > 2 || a->in_dim < 1) return 0;
+    return dctr_chain::bf3_workspace_bytes(a->in_dim);
+}
 
 static thread_local int g_last_fwd_kernel = -1;   // DCTR_FWD_KERNEL_* of this thread's last dctr_embed_mlp_fwd launch
 
 static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream) {
+    DCTR_REQUIRE(a == nullptr || a->precision == 0 || ((a->precision == 1 || a->precision == 2) && ga != nullptr), DCTR_E_UNSUPPORTED,
+                 "mlp_fwd: precision %d (0 = fp32; 1 / 2 = bf16x3 with dctr_embed_mlp_fwd only)", a != nullptr ? a->precision : 0);
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_fwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->in_dim >= 1 && a->n_layers >= 0 && a->n_layers <= MAX_LAYERS, DCTR_E_DIM,
                  "mlp_fwd: bad sizes (batch=%lld in_dim=%d layers=%d, max %d layers)", (long long)a->batch, a->in_dim,
@@ -139,6 +146,8 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 256 || a->tile_rows == 128)) {
         const bool forced = a->tile_rows != 0;
         const int ok = dctr_chain::eligible(a, ga, forced);
+        DCTR_REQUIRE(a->precision == 0 || ok, DCTR_E_UNSUPPORTED,
+                     "embed_mlp_fwd: precision 1 / 2 (bf16x3, exploratory) exists for the row-chained kernel with DNN 256-128-64 only");
         DCTR_REQUIRE(!forced || ok, DCTR_E_UNSUPPORTED,
                      "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 16 / 32, units 256-128-64, a head", a->tile_rows);
         if (ok) {

@@ -44,6 +44,10 @@ class _DeepFM(FeatureModel):
         self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
         self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
+        # "fp32" (exact, the only supported mode) | "bf16x3": EXPLORATORY (include/dctr.h: dctr_mlp_args_t.precision) — the row-chained
+        # kernel's products as three bf16 MFMAs each; applies to launches that kernel takes (>= 64 rows per CU, DNN 256-128-64)
+        self.matrix_precision = "fp32"
+        self._bf3 = None            # {"ws": packed weight images, "fresh": they match the current weights}
 
     # -- DNN widths the row-chained kernel has no instantiation for --------------------------------------------------------
     _CHAIN_MIN_ROWS = 64 * 256         # launches below 64 rows per CU take the 32-row kernel (csrc/chain_kernels.hip: eligible)
@@ -107,6 +111,15 @@ class _DeepFM(FeatureModel):
         super(_DeepFM, self)._begin()
         if self._pad is not None:
             self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
+        if self._bf3 is not None:
+            self._bf3["fresh"] = False  # weights may have changed since the last predict(): the next launch repacks
+
+    def _bf3_on(self, B):
+        if self.matrix_precision == "fp32":
+            return False
+        if self.matrix_precision != "bf16x3":
+            raise ValueError("matrix_precision must be 'fp32' or 'bf16x3' (exploratory), got %r" % (self.matrix_precision,))
+        return B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256
 
     def _forward_fast(self, staged, lo, hi, out):
         """Fixed-length features on the fused path: the two argument structs are marshalled once per batch size and only
@@ -118,13 +131,18 @@ class _DeepFM(FeatureModel):
         sp = self.stage_plan
         _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear),
                                              _C.stream_ptr()), "dctr_embed_mlp_fwd")
+        if m.precision:
+            self._bf3["fresh"] = True
 
     def _forward_fast_args(self, staged, lo, hi, out):
+        import ctypes
         import torch
+        from .. import _C
         sp, B = self.stage_plan, hi - lo
         padded = self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256)
         pre = self._prehash(B)
-        key = (B, padded, pre)
+        bf3 = self._bf3_on(B)
+        key = (B, padded, pre, bf3)
         c = self._fast.get(key)
         hashed = sp.prehash(staged, lo, hi, sp.light_workspace()) if pre else None
         if c is None:
@@ -136,6 +154,12 @@ class _DeepFM(FeatureModel):
             m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
                               head_w=hw, global_bias=self.prediction.w('global_bias'),
                               sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out, gather=g, batch=B, launch=False)
+            if bf3:
+                if self._bf3 is None:
+                    m.precision = 1
+                    need = int(_C.lib().dctr_mlp_workspace_bytes(ctypes.byref(m)))
+                    self._bf3 = {"ws": torch.empty(need, dtype=torch.uint8, device=self.device), "fresh": False}
+                m.workspace, m.workspace_bytes = self._bf3["ws"].data_ptr(), self._bf3["ws"].numel()
             c = self._fast[key] = (g, m, keep, ws)
         g, m, _keep, _ws = c
         ids = staged.ids
@@ -153,6 +177,7 @@ class _DeepFM(FeatureModel):
         m.y = out.data_ptr()
         m.tile_rows = int(self.tile_rows)
         m.probe = None if self.probe is None else self.probe.data_ptr()
+        m.precision = 0 if not bf3 else (2 if self._bf3["fresh"] else 1)
         return g, m
 
     def launch_plan(self, staged, lo, hi, out):
@@ -179,7 +204,8 @@ class _DeepFM(FeatureModel):
         self._forward_fast_args(staged, lo, hi, out)
         B = hi - lo
         pre = self._prehash(B)
-        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256), pre)]
+        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256), pre,
+                                     self._bf3_on(B))]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         sp = self.stage_plan
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
@@ -190,6 +216,8 @@ class _DeepFM(FeatureModel):
                 h = sp.prehash(staged, lo, hi, ws)
                 g.ids, g.ids_stride_f = h.data_ptr(), h.stride(0)
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
+            if m.precision == 1:                                         # bf16x3: the first launch packed the weights
+                m.precision = 2
         launch.keep = (g, m, keep, ws, staged, out)
         return launch
 
@@ -213,6 +241,9 @@ class _DeepFM(FeatureModel):
         sp = self.stage_plan
         if self._fast_path(staged):
             return self._forward_fast(staged, lo, hi, out)
+        if self.matrix_precision != "fp32":
+            raise ValueError("matrix_precision %r (bf16x3 is exploratory) exists on the row-chained one-launch path only: fixed-length "
+                             "features, fused=True" % (self.matrix_precision,))
         if sp.fusable and self.fused:
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
             ws = sp.run_pools(staged, lo, hi, light=True)

@@ -509,7 +509,7 @@ def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
         sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
-        tile_rows=0, save_acts=None, probe=None, launch=True, bn=None):
+        tile_rows=0, save_acts=None, probe=None, launch=True, bn=None, precision=0, workspace=None):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
@@ -562,7 +562,10 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    add=add_arr,
                    global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
                    y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0,
-                   tile_rows=int(tile_rows))
+                   tile_rows=int(tile_rows), precision=int(precision))
+    if workspace is not None:           # precision 1 (exploratory bf16x3): the packed weight images live here
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        keep.append(workspace)
     if probe is not None:               # measurement aid: uint64[2] {min start, max end} wall-clock stamps (dctr.h)
         a.probe = probe.data_ptr()
     if bn is not None and n > 0 and any(b_ is not None for b_ in bn):

@@ -387,3 +387,44 @@ def test_chain_kernel_takes_hashed_sparse_features(device):
         y32 = _predict(model, f, 4096, span_batches=False, tile_rows=32)
         assert _last_kernel() == "tile"
         assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain + hash pre-pass vs 32-row kernel")
+
+
+@pytest.mark.parametrize("E,n,F,ND", [(16, 20 * 4096, 26, 13), (32, 16384 + 4096 + 77, 26, 13), (16, 16384 + 129, 7, 0), (32, 700, 3, 20)])
+def test_chain_bf16x3_exploratory_precision(device, E, n, F, ND):
+    """The EXPLORATORY precision (dctr_mlp_args_t.precision = 1 / 2; model.matrix_precision = "bf16x3"): every MLP product as three
+    bf16 MFMAs.  Not bit-comparable with the fp32 kernels — it must stay inside the same 1e-4 bar against the float64 oracle, stay
+    close to the fp32 chain (2^-16 per product), keep the kernel's invariances (row permutation, main / tail membership), see weight
+    updates (repacking) and refuse DNNs it has no instantiation for."""
+    from deepctr_amd import _C
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(900 + E + F)
+    cols, feed = _criteo_like(rng, n, F=F, V=5000, E=E, ND=ND)
+    model = DeepFM(cols, cols, device=device)
+    w = _randomise(model, rng)
+    force = {} if n >= 16384 else {"tile_rows": 256}
+    y32 = _predict(model, feed, 4096, **force)
+    yb = _predict(model, feed, 4096, matrix_precision="bf16x3", **force)
+    assert _last_kernel() == "chain" and model._bf3 is not None and model._bf3["fresh"]
+    assert np.isfinite(yb).all()
+    rows = np.unique(np.concatenate([np.arange(0, min(n, 300)), np.arange(max(0, n - 300), n)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    check_probs(yb[rows], ref.astype(np.float32), "bf16x3 chain E=%d F=%d" % (E, F))
+    assert_close(yb, y32, rtol=3e-5, atol=3e-6, what="bf16x3 vs fp32 chain")
+    assert not np.array_equal(yb, y32)                              # (it is a different arithmetic: the flag must have taken effect)
+    # second call: the packed images are reused inside a predict(), repacked across predicts; same bits either way
+    assert np.array_equal(_predict(model, feed, 4096, matrix_precision="bf16x3", **force), yb)
+    perm = rng.permutation(n)
+    yp = _predict(model, {k: v[perm] for k, v in feed.items()}, 4096, matrix_precision="bf16x3", **force)
+    assert np.array_equal(yp, yb[perm])
+    # new weights are seen (the first launch of a predict() repacks)
+    w2 = _randomise(model, np.random.RandomState(5))
+    y2 = _predict(model, feed, 4096, matrix_precision="bf16x3", **force)
+    ref2 = RM.deepfm(cols, cols, w2, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    check_probs(y2[rows], ref2.astype(np.float32), "bf16x3 chain, new weights")
+    # other widths: refused loudly, never silently fp32
+    other = DeepFM(cols, cols, dnn_hidden_units=(128, 64), device=device)
+    _randomise(other, rng)
+    with pytest.raises((_C.DctrError, ValueError), match="bf16x3"):
+        _predict(other, feed, 4096, matrix_precision="bf16x3", tile_rows=256)
+    with pytest.raises(ValueError):
+        _predict(model, feed, 4096, matrix_precision="fp16")
