@@ -25,7 +25,7 @@ struct CinParams {
     int32_t F0, D, n_layers, split_half, activation;
     int32_t SB;        // samples per workgroup
     int32_t RT;        // row tiles = ceil(SB*D/16)
-    int32_t Hmax;      // LDS per-sample stride of the y buffers, in maps
+    int32_t Hmax;      // maps a y buffer in LDS holds
     int32_t reg_reduce;  // 1: the direct maps are summed over D in registers and never stored (D % 4 == 0)
     int32_t out_dim;   // featuremap_num
     int32_t H[CIN_MAX_LAYERS];
@@ -33,6 +33,11 @@ struct CinParams {
     const float* bias[CIN_MAX_LAYERS];
     float* save[CIN_MAX_LAYERS];     // per layer NULL or [B*D, H] row-major: the activations, for the backward pass
     float* out;
+    // layer 0 folded over its symmetry (x_k = x_0 there: z[i,j] = z[j,i]) — see cin_fold_kernel; NULL = plain layer 0
+    const float* Wsym;               // [4 * sym_ks, H[0]] folded filter rows, pair p = j (j + 1) / 2 + i  (i <= j)
+    const unsigned* sym_tab;         // [4 * sym_ks] per pair: i | j << 16
+    int32_t sym_ks;                  // k-steps of the folded layer (a multiple of 4)
+    int32_t two_y;                   // 1: two y buffers in LDS (a layer reads one while it writes the other)
 };
 
 typedef unsigned int cin_u32x2 __attribute__((ext_vector_type(2)));
@@ -49,43 +54,44 @@ __device__ __forceinline__ void cin_buf_load(__amdgpu_buffer_rsrc_t rsrc, int vo
 
 #define CIN_SB __builtin_amdgcn_sched_barrier(0)
 
+// LDS layout (round 3): every tile is FIELD-major — x0t[i][m], y[n][m] with m = s*D + d the workgroup's GEMM row and a row stride of
+// ROWS_P = 16*RT + 16 floats.  A lane's row inside a 16-row tile is its only per-lane address part, the tile is an immediate
+// offset (64 B * rt) and the field a scalar (or, in the folded layer, one table value): no per-tile address registers, no integer
+// division by D in the loop set-up, the epilogue's four rows of a lane leave as one ds_write_b128.  The 16 floats of padding
+// put consecutive fields 16 banks apart: the folded layer's four k-slots read four different fields in one ds_read.
+// Rows >= M (padding of the last tile) hold finite junk whose results are dropped; rows never mix in this GEMM.
+//
 // One CIN layer for the workgroup's M = SB*D rows.  K = F0*Fk is walked in STAGES of SS k-steps of one i:
 // stage (c, i) covers j = 4*(SS*c + tt) + g, tt < SS (slot g of the MFMA takes j = 4*jt + g).  Software pipeline:
 //   * B (filter rows i*Fk + j, a wave's 16*TPW-column slice) comes from L2 through raw buffer loads — lane-constant
-//     offset, scalar row offset, zero VALU — into THREE rotating register stages (two stages of MFMAs of cover);
+//     offset, scalar row offset, zero VALU — into NB rotating register stages (NB - 1 stages of MFMAs of cover);
 //   * the A operand x0[row,i] * x_k[row,j] is formed in registers: its LDS reads for stage s+1 are issued before the
 //     MFMAs of stage s and multiplied after them;
 //   * sched_barriers pin "issue loads, then MFMAs" (hipcc otherwise sinks each load next to its use).
 // The earlier form (one filter load, four LDS reads, eight MFMAs, wait) ran at 48 % of the nominal f32-MFMA rate; this
 // one at 68 % (C3: 364 us per 4096 samples; a pure-MFMA loop sustains 139 of the nominal 157 TFLOP/s on this part).
-template <int TPW, int RT, bool SAVE>
-__device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float* x0s, const float* xk, int xk_stride,
-                                          int Fk, float* ycur, int Hn, int d0, int64_t bbase, int out_off) {
+#ifndef CIN_NB
+#define CIN_NB 4
+#endif
+template <int TPW, int RT, bool SAVE, bool SYM>
+__device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float* x0t, const float* xk, int Fk, float* ycur, int Hn,
+                                          int d0, int64_t bbase, int out_off, const unsigned* tab) {
     using dctr::f32x4;
+    constexpr int ROWS_P = RT * 16 + 16;
+    constexpr int NB = CIN_NB;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, g = lane >> 4, jl = lane & 15;
     const int D = p.D, F0 = p.F0, H = p.H[k];
     const int M = p.SB * D;
-    // per row tile: LDS offsets of this lane's row (s,d) in the x0 tile and in the x_k tile
-    int off0[RT], offk[RT];
-    bool rowok[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int m = rt * 16 + jl;
-        rowok[rt] = m < M;
-        const int mm = rowok[rt] ? m : 0;
-        const int s = mm / D, d = mm % D;
-        off0[rt] = s * F0 * D + d;
-        offk[rt] = s * xk_stride + d;
-    }
+    const float* x0l = x0t + jl;          // this lane's row of tile 0, field 0
+    const float* xkl = xk + jl;
     const int n_tiles = (H + 16 * TPW - 1) / (16 * TPW);
     constexpr int SS = RT > 4 ? 2 : 4;    // k-steps per stage: 16*TPW... = SS*RT*TPW MFMAs; fewer with 8 row tiles (VGPRs)
     const int JT = (Fk + 3) / 4;          // k-steps per i
     const int NC = (JT + SS - 1) / SS;    // stages per i
-    const int n_stage = F0 * NC;
-    const float* Wk = p.W[k];
+    const float* Wk = SYM ? p.Wsym : p.W[k];
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wk), 0, F0 * Fk * H * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wk), 0, (SYM ? 4 * p.sym_ks : F0 * Fk) * H * 4, 0x00020000);
     for (int wt = wave; wt < n_tiles; wt += 4) {
         const int n_base = wt * 16 * TPW;
         int n0 = n_base + TPW * jl;
@@ -96,46 +102,8 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // Stage order: chunk c of the j range OUTER, i INNER — stage (c, i) multiplies x0[:, i] with the chunk's SS x 4 values
-        // of x_k, which therefore stay in registers for F0 stages (read from LDS once per chunk, masked there), and only
-        // x0[:, i] (RT values) is read per stage.  (i outer / c inner read 3x as much LDS per stage.)  The order only
-        // permutes the terms of the K sum.  Stage counters of the two prefetch streams (scalar): B runs two stages ahead,
-        // the A reads one.
-        int iB = 0, cB = 0, iR = 0, cR = 0;
-        auto load_b = [&](float (&b)[SS][TPW]) {      // stage (cB, iB), then advance
-#pragma unroll
-            for (int tt = 0; tt < SS; ++tt) {
-                const int jt = min(SS * cB + tt, JT - 1);             // steps past JT are masked on the A side
-                cin_buf_load<TPW>(rsrc, voff, (iB * Fk + 4 * jt) * H * 4, b[tt]);
-            }
-            if (++iB == F0) { iB = 0; cB = min(cB + 1, NC - 1); }
-        };
-        float rxi[RT], rxk[SS][RT];
-        auto load_raw = [&]() {                       // stage (cR, iR), then advance
-            if (iR == 0) {                            // new chunk: its x_k values, zero where j >= Fk or the row is padding
-#pragma unroll
-                for (int tt = 0; tt < SS; ++tt) {
-                    const int j = 4 * (SS * cR + tt) + g;
-                    const int jc = min(j, Fk - 1);
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const float v = xk[offk[rt] + jc * D];
-                        rxk[tt][rt] = (j < Fk && rowok[rt]) ? v : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) rxi[rt] = x0s[off0[rt] + iR * D];      // rows past M read sample 0 (finite), x_k is 0 there
-            if (++iR == F0) { iR = 0; cR = min(cR + 1, NC - 1); }
-        };
         float a[SS][RT];
-        auto make_a = [&]() {
-#pragma unroll
-            for (int tt = 0; tt < SS; ++tt)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[tt][rt] = rxi[rt] * rxk[tt][rt];
-        };
+        float bq[NB][SS][TPW];
         auto mfmas = [&](const float (&b)[SS][TPW]) {
 #pragma unroll
             for (int tt = 0; tt < SS; ++tt)
@@ -145,32 +113,131 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
                     for (int c = 0; c < TPW; ++c)
                         acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][rt], b[tt][c], acc[rt][c], 0, 0, 0);
         };
-        float b0[SS][TPW], b1[SS][TPW], b2[SS][TPW];
-        load_b(b0);
-        load_b(b1);
-        load_raw();
-        make_a();
-        // stage s: B of stage s+2 -> BZ and the A reads of stage s+1 are issued, then the MFMAs of stage s, then the
-        // products of stage s+1 overwrite `a` (its last reader has issued).  Interleaving those products with the
-        // MFMAs instead (double-buffered a, sched_group_barrier 1:1) measured 6 % SLOWER.
-#define CIN_STAGE(BX, BZ)        \
-    do {                         \
-        load_b(BZ);              \
-        load_raw();              \
-        CIN_SB;                  \
-        mfmas(BX);               \
-        CIN_SB;                  \
-        make_a();                \
-        CIN_SB;                  \
-    } while (0)
-        for (int s = 0; s < n_stage; s += 3) {
-            CIN_STAGE(b0, b2);
-            if (s + 1 < n_stage) CIN_STAGE(b1, b0);
-            if (s + 2 < n_stage) CIN_STAGE(b2, b1);
+
+        if constexpr (SYM) {
+            // Folded layer 0 (x_k = x_0): K walks the F0 (F0 + 1) / 2 pairs i <= j, four consecutive pairs per k-step (slot g takes
+            // pair 4 t + g), against filter rows W[i F0 + j] + W[j F0 + i] (W[i F0 + i] on the diagonal) that cin_fold_kernel
+            // wrote: 88 k-steps at F0 = 26 where the plain walk takes 26 x 8.  Per k-step a lane reads its pair's two x_0 values
+            // per row tile (field offsets from the pair table in LDS, fetched one stage ahead of the reads that use them).
+            const int n_st = p.sym_ks / SS;
+            int sB = 0, sE = 0;
+            auto load_b = [&](float (&b)[SS][TPW]) {
+#pragma unroll
+                for (int tt = 0; tt < SS; ++tt) cin_buf_load<TPW>(rsrc, voff, 4 * (SS * sB + tt) * H * 4, b[tt]);
+                sB = min(sB + 1, n_st - 1);
+            };
+            unsigned ent[SS];
+            auto load_ent = [&]() {
+#pragma unroll
+                for (int tt = 0; tt < SS; ++tt) ent[tt] = tab[4 * (SS * sE + tt) + g];
+                sE = min(sE + 1, n_st - 1);
+            };
+            float ri[SS][RT], rj[SS][RT];
+            auto load_raw = [&]() {
+#pragma unroll
+                for (int tt = 0; tt < SS; ++tt) {
+                    const float* qi = x0l + (ent[tt] & 0xffffu);
+                    const float* qj = x0l + (ent[tt] >> 16);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        ri[tt][rt] = qi[rt * 16];
+                        rj[tt][rt] = qj[rt * 16];
+                    }
+                }
+            };
+            auto make_a = [&]() {
+#pragma unroll
+                for (int tt = 0; tt < SS; ++tt)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) a[tt][rt] = ri[tt][rt] * rj[tt][rt];
+            };
+#pragma unroll
+            for (int u = 0; u < NB - 1; ++u) load_b(bq[u]);
+            load_ent();
+            load_raw();
+            load_ent();
+            make_a();
+            for (int s = 0; s < n_st; s += NB) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (s + u < n_st) {
+                        load_b(bq[(u + NB - 1) % NB]);
+                        load_raw();
+                        load_ent();
+                        CIN_SB;
+                        mfmas(bq[u]);
+                        CIN_SB;
+                        make_a();
+                        CIN_SB;
+                    }
+                }
+            }
+        } else {
+            // Stage order: chunk c of the j range OUTER, i INNER — stage (c, i) multiplies x0[:, i] with the chunk's SS x 4 values
+            // of x_k, which therefore stay in registers for F0 stages (read from LDS once per chunk, masked there), and only
+            // x0[:, i] (RT values) is read per stage.  (i outer / c inner read 3x as much LDS per stage.)  The order only
+            // permutes the terms of the K sum.  Stage counters of the two prefetch streams (scalar): B runs NB - 1 stages ahead,
+            // the A reads one.
+            const int n_stage = F0 * NC;
+            int iB = 0, cB = 0, iR = 0, cR = 0;
+            auto load_b = [&](float (&b)[SS][TPW]) {      // stage (cB, iB), then advance
+#pragma unroll
+                for (int tt = 0; tt < SS; ++tt) {
+                    const int jt = min(SS * cB + tt, JT - 1);             // steps past JT are masked on the A side
+                    cin_buf_load<TPW>(rsrc, voff, (iB * Fk + 4 * jt) * H * 4, b[tt]);
+                }
+                if (++iB == F0) { iB = 0; cB = min(cB + 1, NC - 1); }
+            };
+            float rxi[RT], rxk[SS][RT];
+            auto load_raw = [&]() {                       // stage (cR, iR), then advance
+                if (iR == 0) {                            // new chunk: its x_k values, zero where j >= Fk
+#pragma unroll
+                    for (int tt = 0; tt < SS; ++tt) {
+                        const int j = 4 * (SS * cR + tt) + g;
+                        const float* q = xkl + min(j, Fk - 1) * ROWS_P;
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const float v = q[rt * 16];
+                            rxk[tt][rt] = j < Fk ? v : 0.f;
+                        }
+                    }
+                }
+                const float* q0 = x0l + iR * ROWS_P;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) rxi[rt] = q0[rt * 16];
+                if (++iR == F0) { iR = 0; cR = min(cR + 1, NC - 1); }
+            };
+            auto make_a = [&]() {
+#pragma unroll
+                for (int tt = 0; tt < SS; ++tt)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) a[tt][rt] = rxi[rt] * rxk[tt][rt];
+            };
+#pragma unroll
+            for (int u = 0; u < NB - 1; ++u) load_b(bq[u]);
+            load_raw();
+            make_a();
+            // stage s: B of stage s+NB-1 and the A reads of stage s+1 are issued, then the MFMAs of stage s, then the
+            // products of stage s+1 overwrite `a` (its last reader has issued).  Interleaving those products with the
+            // MFMAs instead (double-buffered a, sched_group_barrier 1:1) measured 6 % SLOWER.
+            for (int s = 0; s < n_stage; s += NB) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (s + u < n_stage) {
+                        load_b(bq[(u + NB - 1) % NB]);
+                        load_raw();
+                        CIN_SB;
+                        mfmas(bq[u]);
+                        CIN_SB;
+                        make_a();
+                        CIN_SB;
+                    }
+                }
+            }
         }
-#undef CIN_STAGE
         // epilogue: bias + activation (C layout: row m = 16rt + 4g + r = (sample s, d), col n = n_base + TPW*jl + c).
-        // Maps [0, Hn) feed the next layer -> y[s][n][d] in LDS.  Maps [d0, H) go to the output summed over d
+        // Maps [0, Hn) feed the next layer -> y[n][m] in LDS (the lane's four rows as one 16-B store; rows >= M are junk
+        // nobody reads).  Maps [d0, H) go to the output summed over d
         // (interaction.py:322-323): with reg_reduce that sum is taken here — 4 rows in the lane, lanes 16 / 32 apart
         // (the other k-slots' rows of the same sample), then the D/16 row tiles of a sample — and written straight
         // to `out`; otherwise (D % 4 != 0) every map is stored and cin_kernel sums from LDS.
@@ -195,14 +262,7 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dctr::apply_act(acc[rt][c][r] + bv, p.activation);
                 const bool store = nok && (!p.reg_reduce || n < Hn);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = rt * 16 + 4 * g + r;
-                    if (store && m < M) {
-                        const int s = m / D, d = m - s * D;
-                        ycur[(s * p.Hmax + n) * D + d] = v[r];
-                    }
-                }
+                if (store) *reinterpret_cast<float4*>(ycur + n * ROWS_P + rt * 16 + 4 * g) = float4{v[0], v[1], v[2], v[3]};
                 if constexpr (SAVE) {
                     // training: y_k[(b, d), n] (all H maps, row-major) for dctr_cin_bwd.  Buffer stores: lane-constant byte
                     // offset + a scalar row offset (per-row 64-bit addresses cost 64 VGPRs and spilled), rows past the batch
@@ -248,11 +308,19 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
 template <int RT, bool SAVE>
 __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS_P = RT * 16 + 16;
     const int D = p.D, F0 = p.F0, SB = p.SB;
-    float* x0s = smem;                              // [SB][F0][D]
-    float* y0 = x0s + ((SB * F0 * D + 3) & ~3);     // [SB][Hmax][D]
-    float* y1 = y0 + SB * p.Hmax * D;
+    const int M = SB * D;
+    float* x0t = smem;                              // [F0][ROWS_P]
+    float* y0 = x0t + F0 * ROWS_P;                  // [Hmax][ROWS_P]
+    float* y1 = y0 + p.Hmax * ROWS_P;               // (only when a layer reads one y buffer while writing the other: p.two_y)
+    unsigned* tab = reinterpret_cast<unsigned*>(y1 + (p.two_y ? p.Hmax * ROWS_P : 0));      // [4 * sym_ks] pair table of the folded layer 0
     const int64_t b0 = (int64_t)blockIdx.x * SB;
+    if (p.Wsym != nullptr)                          // (i, j) of the fold kernel's table -> float offsets of the two fields' rows in x0t
+        for (int t = threadIdx.x; t < 4 * p.sym_ks; t += 256) {
+            const unsigned e = p.sym_tab[t];
+            tab[t] = (e & 0xffffu) * ROWS_P | ((e >> 16) * ROWS_P) << 16;
+        }
     {
         // x0 tile: all global loads of a pass in flight before the LDS stores
         const int total = SB * F0 * D, fd = F0 * D;
@@ -269,16 +337,22 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * 256 + threadIdx.x;
-                if (i < total) x0s[i] = v[u];
+                if (i < total) {
+                    const int s = i / fd, r = i - s * fd;
+                    const int f = r / D, d = r - f * D;
+                    x0t[f * ROWS_P + s * D + d] = v[u];
+                }
             }
         }
+        const int padr = RT * 16 - M;               // rows of the last tile past M: zeros
+        for (int t = threadIdx.x; t < F0 * padr; t += 256) x0t[(t / padr) * ROWS_P + M + t % padr] = 0.f;
     }
     __syncthreads();
 
-    const float* xk = x0s;
-    int xk_stride = F0 * D, Fk = F0;
+    const float* xk = x0t;
+    int Fk = F0;
     float* ycur = y0;
-    float* ynext = y1;
+    float* ynext = p.two_y ? y1 : y0;
     int out_off = 0;
     for (int k = 0; k < p.n_layers; ++k) {
         const int H = p.H[k];
@@ -292,8 +366,11 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
             Hn = last ? 0 : H;
             d0 = 0;
         }
-        if (H % 32 == 0) cin_layer<2, RT, SAVE>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
-        else cin_layer<1, RT, SAVE>(p, k, x0s, xk, xk_stride, Fk, ycur, Hn, d0, b0, out_off);
+        if (k == 0 && p.Wsym != nullptr) {
+            if (H % 32 == 0) cin_layer<2, RT, SAVE, true>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
+            else cin_layer<1, RT, SAVE, true>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
+        } else if (H % 32 == 0) cin_layer<2, RT, SAVE, false>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
+        else cin_layer<1, RT, SAVE, false>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
         __syncthreads();
         const int nd = H - d0;
         if (!p.reg_reduce) {
@@ -301,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
             for (int t = threadIdx.x; t < SB * nd; t += 256) {
                 const int s = t / nd, n = d0 + t % nd;
                 if (b0 + s < p.batch) {
-                    const float* yp = ycur + (s * p.Hmax + n) * D;
+                    const float* yp = ycur + n * ROWS_P + s * D;
                     float acc = 0.f;
                     for (int d = 0; d < D; ++d) acc += yp[d];
                     p.out[(b0 + s) * p.out_dim + out_off + (n - d0)] = acc;
@@ -310,13 +387,42 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
         }
         out_off += nd;
         xk = ycur;
-        xk_stride = p.Hmax * D;
         Fk = Hn;
         float* t = ycur;
         ycur = ynext;
         ynext = t;
         // no barrier needed here: the next layer writes the OTHER y buffer and only reads this one
     }
+}
+
+// Layer 0 of a CIN multiplies x_0 with itself: z[i F0 + j] = z[j F0 + i], so  sum_{i,j} z_ij W[ij, h] = sum_{i <= j} x_i x_j Wf[p(i,j), h]
+// with Wf = W[ij] + W[ji] (W[ii] on the diagonal), p = j (j + 1) / 2 + i.  This kernel writes Wf (rows >= the pair count: zeros) and the
+// pair table the forward kernel walks; it runs in front of every dctr_cin_fwd that was given a workspace (the filters may have moved).
+__global__ __launch_bounds__(256) void cin_fold_kernel(const float* __restrict__ W, int F0, int H, int rows, float* __restrict__ Wf,
+                                                       unsigned* __restrict__ tab) {
+    const int P = F0 * (F0 + 1) / 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)rows * H; e += (int64_t)gridDim.x * 256) {
+        const int pr = (int)(e / H), h = (int)(e % H);
+        int i = 0, j = 0;
+        if (pr < P) {
+            j = (int)((sqrtf(8.f * pr + 1.f) - 1.f) * 0.5f);
+            while ((j + 1) * (j + 2) / 2 <= pr) ++j;          // (float rounding of the root, either way)
+            while (j * (j + 1) / 2 > pr) --j;
+            i = pr - j * (j + 1) / 2;
+        }
+        float v = 0.f;
+        if (pr < P) v = i == j ? W[(int64_t)(i * F0 + i) * H + h] : W[(int64_t)(i * F0 + j) * H + h] + W[(int64_t)(j * F0 + i) * H + h];
+        Wf[e] = v;
+        if (h == 0) tab[pr] = (unsigned)i | ((unsigned)j << 16);
+    }
+}
+
+// k-steps of the folded layer 0 (multiple of 4: a whole number of stages whatever the stage length), 0 = cannot fold
+int cin_sym_ksteps(int F0, int D) {
+    (void)D;
+    if (F0 * 144 > 0xffff) return 0;                       // (field offsets in the LDS tile as 16-bit halves of a table word)
+    const int P = F0 * (F0 + 1) / 2;
+    return ((P + 3) / 4 + 3) & ~3;
 }
 
 int cin_out_dim(const dctr_cin_args_t* a) {
@@ -331,7 +437,13 @@ int cin_out_dim(const dctr_cin_args_t* a) {
 
 }  // namespace
 
-extern "C" size_t dctr_cin_workspace_bytes(const dctr_cin_args_t*) { return 0; }  // intermediates live in LDS
+// intermediates live in LDS; the workspace holds layer 0's folded filter rows + pair table (optional: without it layer 0 walks all
+// F0 x F0 products — same result up to the rounding of W[ij] + W[ji], ~1.2x the time at C3)
+extern "C" size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* a) {
+    if (a == nullptr || a->fields < 1 || a->dim < 1 || a->n_layers < 1 || a->layer_size == nullptr || a->layer_size[0] < 1) return 0;
+    const size_t ks = (size_t)cin_sym_ksteps(a->fields, a->dim);
+    return ks * 4 * ((size_t)a->layer_size[0] + 1) * sizeof(float);
+}
 
 extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "cin_fwd: null args");
@@ -382,20 +494,39 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     // rows per workgroup: 128 (eight 16-row tiles, every filter fragment feeds eight MFMAs per column tile: the
     // filter stream from L2, 851 KB per workgroup at C3 layer 2, is what bounds this kernel) when two workgroups
     // still fit a CU's LDS, else 64
-    auto lds_of = [&](int sb) {
-        return ((size_t)((sb * p.F0 * p.D + 3) & ~3) + (size_t)2 * sb * p.Hmax * p.D) * sizeof(float);
+    // layer 0 folded over its symmetry when the caller brought the workspace for it
+    const size_t sym_need = dctr_cin_workspace_bytes(a);
+    if (a->workspace != nullptr && sym_need > 0) {
+        DCTR_REQUIRE(a->workspace_bytes >= sym_need && dctr_aligned16(a->workspace), DCTR_E_DIM,
+                     "cin_fwd: workspace of %zu B (16-B aligned) needed, got %zu B", sym_need, a->workspace_bytes);
+        p.sym_ks = cin_sym_ksteps(p.F0, p.D);
+        float* wf = static_cast<float*>(a->workspace);
+        unsigned* tb = reinterpret_cast<unsigned*>(wf + (size_t)4 * p.sym_ks * p.H[0]);
+        const int64_t n = (int64_t)4 * p.sym_ks * p.H[0];
+        hipLaunchKernelGGL(cin_fold_kernel, dim3((unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           p.W[0], p.F0, p.H[0], 4 * p.sym_ks, wf, tb);
+        p.Wsym = wf;
+        p.sym_tab = tb;
+    }
+    p.two_y = (p.n_layers >= 3 || (p.n_layers == 2 && !p.reg_reduce)) ? 1 : 0;   // (the last layer of a reg_reduce net stores nothing)
+    auto lds_of = [&](int rt_) {
+        const size_t rows_p = (size_t)rt_ * 16 + 16;
+        return (((size_t)p.F0 + (size_t)(p.two_y ? 2 : 1) * p.Hmax) * rows_p + (size_t)4 * p.sym_ks) * sizeof(float);
     };
     int rt = 8;
     p.SB = 128 / a->dim;
     if (p.SB < 1) p.SB = 1;
-    if (lds_of(p.SB) > 80 * 1024 || p.SB * a->dim > 128) {
+    if (lds_of(8) > 80 * 1024 || p.SB * a->dim > 128) {
         rt = 4;
         p.SB = 64 / a->dim;
         if (p.SB < 1) p.SB = 1;
     }
     p.RT = (p.SB * a->dim + 15) / 16;
     DCTR_REQUIRE(p.RT <= rt, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d needs %d row tiles", a->dim, p.RT);
-    const size_t lds = lds_of(p.SB);
+#ifndef CIN_LDS_PAD
+#define CIN_LDS_PAD 0           // lab: extra dynamic LDS, to pin the number of workgroups per CU
+#endif
+    const size_t lds = lds_of(rt) + CIN_LDS_PAD;
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "cin_fwd: needs %zu B of LDS (> 160 KiB)", lds);
     const bool save = a->save_y != nullptr;
     const void* fn = rt == 8 ? (save ? (const void*)cin_kernel<8, true> : (const void*)cin_kernel<8, false>)

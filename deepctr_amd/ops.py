@@ -364,10 +364,12 @@ def cin_output_dim(layer_size, split_half):
     return sum(layer_size)
 
 
-def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None, save_y=None):
+def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None, save_y=None, fold=True):
     """CIN.call (reference interaction.py:277-325): x [B,F0,D] (or, with ``fields``/``dim`` given, the leading
     F0*D columns of a [B, stride] concat buffer read in place); filters[k] [F0*Fk, Hk]; -> [B, featuremap_num].
-    ``save_y``: per layer a [B*D, H_k] float32 tensor that receives the layer's activations (training: ``cin_bwd(saved_y=)``)."""
+    ``save_y``: per layer a [B*D, H_k] float32 tensor that receives the layer's activations (training: ``cin_bwd(saved_y=)``).
+    ``fold``: hand the library the workspace for layer 0's symmetry fold (x_k = x_0 there: the F0 (F0 + 1) / 2 pairs i <= j against
+    W[ij] + W[ji]); False walks all F0 x F0 products (same result up to the rounding of that sum)."""
     _dev_check(x, *filters, *biases)
     if fields is None:
         if x.dim() != 3:
@@ -394,6 +396,11 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
         _check_saved_y(save_y, B * D, layer_size, x)
         sp = _ptr_array(list(save_y))
         a.save_y = ctypes.cast(sp, ctypes.c_void_p)
+    if fold:
+        need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
+        if need:
+            ws = _scratch(x.device, need)       # rewritten by every call (the filters may have moved): stream order keeps calls apart
+            a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _C.check(_C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_fwd")
     return out
 

@@ -389,7 +389,7 @@ def test_chain_kernel_takes_hashed_sparse_features(device):
         assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain + hash pre-pass vs 32-row kernel")
 
 
-@pytest.mark.parametrize("E,n,F,ND", [(16, 20 * 4096, 26, 13), (32, 16384 + 4096 + 77, 26, 13), (16, 16384 + 129, 7, 0), (32, 700, 3, 20)])
+@pytest.mark.parametrize("E,n,F,ND", [(16, 20 * 4096, 26, 13), (32, 16384 + 4096 + 77, 26, 13), (16, 16384 + 129, 7, 0), (32, 700, 12, 20)])
 def test_chain_bf16x3_exploratory_precision(device, E, n, F, ND):
     """The EXPLORATORY precision (dctr_mlp_args_t.precision = 1 / 2; model.matrix_precision = "bf16x3"): every MLP product as three
     bf16 MFMAs.  Not bit-comparable with the fp32 kernels — it must stay inside the same 1e-4 bar against the float64 oracle, stay

@@ -294,6 +294,10 @@ def test_cin(device):
     mag = R.cin(np.abs(x[rows]).astype(np.float64), [np.abs(f).astype(np.float64) for f in fs], [np.abs(b).astype(np.float64) for b in bs], True, "relu")
     y = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, True, "relu")
     assert_close_terms(y.cpu().numpy()[rows], ref, mag, what="cin C3 b4096")
+    # the same launch without the workspace: layer 0 walks all F0 x F0 products instead of the folded pairs i <= j
+    y0 = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, True, "relu", fold=False)
+    assert_close_terms(y0.cpu().numpy()[rows], ref, mag, what="cin C3 b4096, plain layer 0")
+    assert_close(y.cpu().numpy(), y0.cpu().numpy(), rtol=2e-5, atol=2e-5, what="cin folded vs plain layer 0")
 
 
 def test_afm_inner_product(device):
@@ -594,8 +598,33 @@ def test_cin_embedding_dims(device, D):
             fk = h // 2 if (split and k != len(ls) - 1) else h
         bs = [rng.standard_normal(h).astype(np.float32) * 0.1 for h in ls]
         ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], split, act)
-        y = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, act)
-        assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="cin D=%d layers=%s split=%s" % (D, ls, split))
+        for fold in (True, False):                          # layer 0 over the pairs i <= j (workspace) / over all F0 x F0 products
+            y = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, act, fold=fold)
+            assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="cin D=%d layers=%s split=%s fold=%s" % (D, ls, split, fold))
+
+
+@pytest.mark.parametrize("F0,ls,split", [(1, (8, 4), True), (2, (6,), False), (3, (16, 16, 16), True), (26, (128, 128, 64), True),
+                                         (39, (100, 100), False)])
+def test_cin_folded_layer0_shapes(device, F0, ls, split):
+    """Layer 0's symmetry fold (dctr_cin_fwd with a workspace) at field counts whose pair count is / is not a multiple of the k-step
+    and stage sizes (1, 3, 6, 351, 780 pairs), three-layer nets (two y buffers in LDS) and map counts off the 32-column tiles —
+    against the float64 oracle and against the plain walk."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(70 + F0)
+    B, D = 261, 16
+    x = (rng.standard_normal((B, F0, D)) * 0.5).astype(np.float32)
+    fk, fs = F0, []
+    for k, h in enumerate(ls):
+        fs.append((rng.standard_normal((1, F0 * fk, h)) / np.sqrt(F0 * fk)).astype(np.float32))
+        fk = h // 2 if (split and k != len(ls) - 1) else h
+    bs = [rng.standard_normal(h).astype(np.float32) * 0.1 for h in ls]
+    ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], split, "relu")
+    mag = R.cin(np.abs(x).astype(np.float64), [np.abs(f).astype(np.float64) for f in fs], [np.abs(b).astype(np.float64) for b in bs], split, "relu")
+    args = (dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, "relu")
+    y1, y0 = ops.cin(*args), ops.cin(*args, fold=False)
+    assert_close_terms(y1.cpu().numpy(), ref, mag, what="cin folded F0=%d %s" % (F0, ls))
+    assert_close_terms(y0.cpu().numpy(), ref, mag, what="cin plain F0=%d %s" % (F0, ls))
+    assert torch.equal(ops.cin(*args), y1)                      # the scratch workspace is rewritten per call: same bits
 
 
 def test_embed_lookup_multi(device):
