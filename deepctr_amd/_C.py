@@ -67,7 +67,7 @@ class LookupArgs(ctypes.Structure):
 
 class CinArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("fields", c_i32), ("dim", c_i32),
-                ("n_layers", c_i32), ("split_half", c_i32), ("activation", c_i32), ("pad_", c_i32), ("layer_size", c_vp),
+                ("n_layers", c_i32), ("split_half", c_i32), ("activation", c_i32), ("workspace_ready", c_i32), ("layer_size", c_vp),
                 ("filters", c_vp), ("bias", c_vp), ("out", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz),
                 ("save_y", c_vp)]
 
@@ -93,6 +93,14 @@ class GatherFmBwdArgs(ctypes.Structure):
 class PoolBwdArgs(ctypes.Structure):
     _fields_ = [("fwd", ctypes.POINTER(PoolArgs)), ("d_out", c_vp), ("d_stride", c_i64), ("d_lin_out", c_vp),
                 ("g_table", c_vp), ("g_lin_table", c_vp)]
+
+
+class DnnTrainLayer(ctypes.Structure):
+    _fields_ = [("z", c_vp), ("z_stride", c_i64), ("rows", c_i64), ("n", c_i32), ("activation", c_i32), ("use_bn", c_i32),
+                ("bn_eps", c_f32), ("bn_momentum", c_f32), ("dropout_rate", c_f32), ("dropout_seed", ctypes.c_uint64),
+                ("bn_gamma", c_vp), ("bn_beta", c_vp), ("bn_moving_mean", c_vp), ("bn_moving_var", c_vp), ("bn_batch_mean", c_vp),
+                ("bn_batch_var", c_vp), ("h", c_vp), ("h_stride", c_i64), ("dh", c_vp), ("dh_stride", c_i64), ("dz", c_vp),
+                ("d_gamma", c_vp), ("d_beta", c_vp), ("workspace", c_vp)]
 
 
 class MlpBwdArgs(ctypes.Structure):
@@ -209,6 +217,11 @@ SYMBOLS = {
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
     "dctr_crossnet_mix_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CrossMixBwdArgs)]),
     "dctr_crossnet_mix_bwd": (ctypes.c_int, [ctypes.POINTER(CrossMixBwdArgs), c_vp]),
+    "dctr_fm_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "dctr_din_softmax_fwd": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "dctr_din_softmax_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "dctr_dnn_train_layer_fwd": (ctypes.c_int, [ctypes.POINTER(DnnTrainLayer), c_vp]),
+    "dctr_dnn_train_layer_bwd": (ctypes.c_int, [ctypes.POINTER(DnnTrainLayer), c_vp]),
     "dctr_dice_train_fwd": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_adam_multi": (ctypes.c_int, [c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
 
 // Layer 0 of a CIN multiplies x_0 with itself: z[i F0 + j] = z[j F0 + i], so  sum_{i,j} z_ij W[ij, h] = sum_{i <= j} x_i x_j Wf[p(i,j), h]
 // with Wf = W[ij] + W[ji] (W[ii] on the diagonal), p = j (j + 1) / 2 + i.  This kernel writes Wf (rows >= the pair count: zeros) and the
-// pair table the forward kernel walks; it runs in front of every dctr_cin_fwd that was given a workspace (the filters may have moved).
+// pair table the forward kernel walks; it runs in front of a dctr_cin_fwd that was given a workspace (unless the caller vouches it is current).
 __global__ __launch_bounds__(256) void cin_fold_kernel(const float* __restrict__ W, int F0, int H, int rows, float* __restrict__ Wf,
                                                        unsigned* __restrict__ tab) {
     const int P = F0 * (F0 + 1) / 2;
@@ -503,7 +503,8 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
         float* wf = static_cast<float*>(a->workspace);
         unsigned* tb = reinterpret_cast<unsigned*>(wf + (size_t)4 * p.sym_ks * p.H[0]);
         const int64_t n = (int64_t)4 * p.sym_ks * p.H[0];
-        hipLaunchKernelGGL(cin_fold_kernel, dim3((unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        if (!a->workspace_ready)
+            hipLaunchKernelGGL(cin_fold_kernel, dim3((unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            p.W[0], p.F0, p.H[0], 4 * p.sym_ks, wf, tb);
         p.Wsym = wf;
         p.sym_tab = tb;

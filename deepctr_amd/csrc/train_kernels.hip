@@ -799,9 +799,11 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 // One thread per (row, e); the F embeddings of the row are re-read from the forward's input (HBM/L2, F*E*4 B per row).
 // ---------------------------------------------------------------------------------------------------
 // y[b,e] = 0.5((sum_f x)^2 - sum_f x^2)  =>  dx[b,f,e] = dy[b,e] * (sum_f' x[b,f',e] - x[b,f,e])
+// (dy_estride 1: dy [B, E] — BiInteractionPooling; 0: dy [B] broadcast over e — FM, whose logit is that pooling summed over e)
 __global__ __launch_bounds__(256) void bi_interaction_bwd_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
                                                                  int E, const float* __restrict__ dy, int64_t dy_stride,
-                                                                 float* __restrict__ dx, int64_t dx_stride, int accumulate) {
+                                                                 float* __restrict__ dx, int64_t dx_stride, int accumulate,
+                                                                 int dy_estride = 1) {
     const int64_t total = batch * E;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
         const int64_t b = o / E;
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256) void bi_interaction_bwd_kernel(const float* __
         const float* xb = x + b * x_stride + e;
         float s = 0.f;
         for (int f = 0; f < F; ++f) s += xb[(int64_t)f * E];
-        const float g = dy[b * dy_stride + e];
+        const float g = dy[b * dy_stride + (int64_t)e * dy_estride];
         float* db = dx + b * dx_stride + e;
         for (int f = 0; f < F; ++f) {
             const float v = g * (s - xb[(int64_t)f * E]);
@@ -1272,6 +1274,171 @@ extern "C" int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float
 }
 
 // ---------------------------------------------------------------------------------------------------
+// DNN layer under training=True with BatchNormalization / Dropout (include/dctr.h: dctr_dnn_train_layer_t; reference
+// layers/core.py:196-208).  Elementwise passes: thread = column, rows grid-strided over blockIdx.x (coalesced along n); the column
+// sums of the BatchNormalization backward leave as one atomic per column and workgroup (few workgroups, long row loops).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float rate) {
+    unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;                    // splitmix64 finaliser over (seed, element)
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (float)(unsigned)(x >> 40) * (1.f / 16777216.f) >= rate;               // 24 uniform bits
+}
+
+struct TrainLayerCol {
+    float mu, rs, g, bt;
+};
+__device__ __forceinline__ TrainLayerCol train_layer_col(const dctr_dnn_train_layer_t& a, int n) {
+    TrainLayerCol c{0.f, 1.f, 1.f, 0.f};
+    if (a.use_bn) {
+        c.mu = a.bn_batch_mean[n];
+        c.rs = 1.f / sqrtf(a.bn_batch_var[n] + a.bn_eps);
+        c.g = a.bn_gamma != nullptr ? a.bn_gamma[n] : 1.f;
+        c.bt = a.bn_beta != nullptr ? a.bn_beta[n] : 0.f;
+    }
+    return c;
+}
+__device__ __forceinline__ float act_value(float y, int act) {
+    if (act == DCTR_ACT_RELU) return fmaxf(y, 0.f);
+    if (act == DCTR_ACT_SIGMOID) return 1.f / (1.f + expf(-y));
+    if (act == DCTR_ACT_TANH) return tanhf(y);
+    return y;
+}
+__device__ __forceinline__ float act_deriv(float y, int act) {
+    if (act == DCTR_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == DCTR_ACT_SIGMOID) { const float s = 1.f / (1.f + expf(-y)); return s * (1.f - s); }
+    if (act == DCTR_ACT_TANH) { const float t = tanhf(y); return 1.f - t * t; }
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void train_layer_fwd_kernel(dctr_dnn_train_layer_t a) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= a.n) return;
+    const TrainLayerCol c = train_layer_col(a, n);
+    const float scale = a.dropout_rate > 0.f ? 1.f / (1.f - a.dropout_rate) : 1.f;
+    for (int64_t b = blockIdx.x; b < a.rows; b += gridDim.x) {
+        const float z = a.z[b * a.z_stride + n];
+        const float y = a.use_bn ? c.g * ((z - c.mu) * c.rs) + c.bt : z;
+        float h = act_value(y, a.activation);
+        if (a.dropout_rate > 0.f) h = dropout_keep(a.dropout_seed, (unsigned long long)b * a.n + n, a.dropout_rate) ? h * scale : 0.f;
+        a.h[b * a.h_stride + n] = h;
+    }
+}
+
+// dy of one element (shared by the two backward passes)
+__device__ __forceinline__ float train_layer_dy(const dctr_dnn_train_layer_t& a, const TrainLayerCol& c, int64_t b, int n, float scale,
+                                                float& xh) {
+    const float z = a.z[b * a.z_stride + n];
+    xh = (z - c.mu) * c.rs;
+    const float y = a.use_bn ? c.g * xh + c.bt : z;
+    float d = a.dh[b * a.dh_stride + n];
+    if (a.dropout_rate > 0.f) d = dropout_keep(a.dropout_seed, (unsigned long long)b * a.n + n, a.dropout_rate) ? d * scale : 0.f;
+    return d * act_deriv(y, a.activation);
+}
+
+// BatchNormalization backward, pass 1: ws[n] += sum_b dy, ws[N + n] += sum_b dy xhat
+__global__ __launch_bounds__(256) void train_layer_bwd_reduce_kernel(dctr_dnn_train_layer_t a) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= a.n) return;
+    const TrainLayerCol c = train_layer_col(a, n);
+    const float scale = a.dropout_rate > 0.f ? 1.f / (1.f - a.dropout_rate) : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t b = blockIdx.x; b < a.rows; b += gridDim.x) {
+        float xh;
+        const float dy = train_layer_dy(a, c, b, n, scale, xh);
+        s1 += dy;
+        s2 = fmaf(dy, xh, s2);
+    }
+    unsafeAtomicAdd(a.workspace + n, s1);
+    unsafeAtomicAdd(a.workspace + a.n + n, s2);
+}
+
+// pass 2 (the only pass without BatchNormalization): dz; blockIdx.x == 0 also adds the sums to d_beta / d_gamma
+__global__ __launch_bounds__(256) void train_layer_bwd_apply_kernel(dctr_dnn_train_layer_t a) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= a.n) return;
+    const TrainLayerCol c = train_layer_col(a, n);
+    const float scale = a.dropout_rate > 0.f ? 1.f / (1.f - a.dropout_rate) : 1.f;
+    float m1 = 0.f, m2 = 0.f;
+    if (a.use_bn) {
+        const float s1 = a.workspace[n], s2 = a.workspace[a.n + n];
+        m1 = s1 / (float)a.rows;
+        m2 = s2 / (float)a.rows;
+        if (blockIdx.x == 0) {
+            if (a.d_beta != nullptr) a.d_beta[n] += s1;
+            if (a.d_gamma != nullptr) a.d_gamma[n] += s2;
+        }
+    }
+    for (int64_t b = blockIdx.x; b < a.rows; b += gridDim.x) {
+        float xh;
+        const float dy = train_layer_dy(a, c, b, n, scale, xh);
+        a.dz[b * a.n + n] = a.use_bn ? c.g * c.rs * (dy - m1 - xh * m2) : dy;
+    }
+}
+
+static int train_layer_check(const dctr_dnn_train_layer_t* a, const char* what) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "%s: null args", what);
+    DCTR_REQUIRE(a->rows >= 0 && a->n >= 1 && a->z_stride >= a->n, DCTR_E_DIM, "%s: bad sizes (rows=%lld n=%d z_stride=%lld)", what,
+                 (long long)a->rows, a->n, (long long)a->z_stride);
+    DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "%s: activation %d", what, a->activation);
+    DCTR_REQUIRE(a->dropout_rate >= 0.f && a->dropout_rate < 1.f, DCTR_E_DIM, "%s: dropout_rate %g outside [0, 1)", what, (double)a->dropout_rate);
+    DCTR_REQUIRE(a->z != nullptr, DCTR_E_NULL, "%s: null z", what);
+    DCTR_REQUIRE(!a->use_bn || (a->bn_batch_mean != nullptr && a->bn_batch_var != nullptr), DCTR_E_NULL,
+                 "%s: use_bn needs bn_batch_mean / bn_batch_var", what);
+    return DCTR_OK;
+}
+
+extern "C" int dctr_dnn_train_layer_fwd(const dctr_dnn_train_layer_t* a, void* stream) {
+    const int rc = train_layer_check(a, "dnn_train_layer_fwd");
+    if (rc != DCTR_OK) return rc;
+    if (a->rows == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->h != nullptr && a->h_stride >= a->n, DCTR_E_NULL, "dnn_train_layer_fwd: h missing or h_stride < n");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = a->n;
+    if (a->use_bn) {
+        // this batch's statistics: two passes (sum -> mean, then squared deviations), then the stored statistics move towards them
+        hipError_t e = hipMemsetAsync(a->bn_batch_mean, 0, (size_t)n * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(a->bn_batch_var, 0, (size_t)n * sizeof(float), st);
+        DCTR_REQUIRE(e == hipSuccess, (int)e, "dnn_train_layer_fwd: memset failed: %s", hipGetErrorString(e));
+        if (rowlane4_ok(n, a->z, nullptr, a->z_stride)) {
+            const unsigned g = colsum_grid(a->rows, 256 / (n / 4));
+            hipLaunchKernelGGL(dice_colstat4_kernel, dim3(g), dim3(256), 0, st, a->z, a->z_stride, (const float*)nullptr, a->rows, n, 0, (const float*)nullptr, a->bn_batch_mean);
+            hipLaunchKernelGGL(dice_colstat4_kernel, dim3(g), dim3(256), 0, st, a->z, a->z_stride, (const float*)nullptr, a->rows, n, 1, (const float*)a->bn_batch_mean, a->bn_batch_var);
+        } else {
+            const unsigned rb = rows_grid(a->rows, true);
+            hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, a->z, a->z_stride, (const float*)nullptr, a->rows, n, 0, (const float*)nullptr, a->bn_batch_mean);
+            hipLaunchKernelGGL(dice_colstat_kernel, dim3(rb), dim3(256), 0, st, a->z, a->z_stride, (const float*)nullptr, a->rows, n, 1, (const float*)a->bn_batch_mean, a->bn_batch_var);
+        }
+        hipLaunchKernelGGL(dice_stat_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a->bn_batch_mean, a->bn_batch_var, a->rows, n,
+                           a->bn_momentum, a->bn_moving_mean, a->bn_moving_var);
+    }
+    const unsigned gx = (unsigned)(a->rows < 2048 ? a->rows : 2048);
+    hipLaunchKernelGGL(train_layer_fwd_kernel, dim3(gx, (unsigned)((n + 255) / 256)), dim3(256), 0, st, *a);
+    return dctr_launch_status("dctr_dnn_train_layer_fwd");
+}
+
+extern "C" int dctr_dnn_train_layer_bwd(const dctr_dnn_train_layer_t* a, void* stream) {
+    const int rc = train_layer_check(a, "dnn_train_layer_bwd");
+    if (rc != DCTR_OK) return rc;
+    if (a->rows == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->dh != nullptr && a->dz != nullptr && a->dh_stride >= a->n, DCTR_E_NULL, "dnn_train_layer_bwd: dh / dz missing or dh_stride < n");
+    DCTR_REQUIRE(a->dz != a->dh || a->dh_stride == a->n, DCTR_E_DIM, "dnn_train_layer_bwd: in place needs dh_stride == n");
+    DCTR_REQUIRE(!a->use_bn || a->workspace != nullptr, DCTR_E_NULL, "dnn_train_layer_bwd: use_bn needs a workspace of 2 n floats");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = a->n;
+    const unsigned gy = (unsigned)((n + 255) / 256);
+    if (a->use_bn) {
+        hipError_t e = hipMemsetAsync(a->workspace, 0, (size_t)2 * n * sizeof(float), st);
+        DCTR_REQUIRE(e == hipSuccess, (int)e, "dnn_train_layer_bwd: memset failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(train_layer_bwd_reduce_kernel, dim3((unsigned)(a->rows < COLSUM_MAX_WG ? a->rows : COLSUM_MAX_WG), gy), dim3(256), 0, st, *a);
+    }
+    const unsigned gx = (unsigned)(a->rows < 2048 ? a->rows : 2048);
+    hipLaunchKernelGGL(train_layer_bwd_apply_kernel, dim3(gx, gy), dim3(256), 0, st, *a);
+    return dctr_launch_status("dctr_dnn_train_layer_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // DIN's LocalActivationUnit as a training step (layers/core.py:94-108, layers/sequence.py:261-298): the attention input
 // [q, k, q - k, q * k] is materialised once per batch ([B*T, 4E]) so that the attention MLP runs through dctr_mlp_fwd /
 // dctr_mlp_bwd with saved activations; the masked weighted sum and the scatter of the key gradients are kernels here.
@@ -1510,6 +1677,65 @@ extern "C" int dctr_din_wsum_bwd(const float* d_out, int64_t d_stride, const flo
     return dctr_launch_status("dctr_din_wsum_bwd");
 }
 
+// att_weight_normalization=True (layers/sequence.py:283-289): p = softmax over ALL T positions of where(mask, score, -2^32 + 1) — a
+// row without valid positions gets the uniform 1/T, as tf.nn.softmax gives it — and the weighted sum then runs over every position.
+// One wave per row.  Backward: ds = p (dp - <p, dp>), kept where the mask is set (a padded position's input is the constant).
+__global__ __launch_bounds__(256) void din_softmax_kernel(const float* __restrict__ score, const uint8_t* __restrict__ mask, int64_t batch,
+                                                          int T, float* __restrict__ p) {
+    const int lane = threadIdx.x & 63;
+    const float pad = -4294967295.f;                       // float(-2 ** 32 + 1)
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < batch; b += (int64_t)gridDim.x * 4) {
+        float mx = -__builtin_inff();
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, mask[b * T + t] ? score[b * T + t] : pad);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int t = lane; t < T; t += 64) sum += expf((mask[b * T + t] ? score[b * T + t] : pad) - mx);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        for (int t = lane; t < T; t += 64) p[b * T + t] = expf((mask[b * T + t] ? score[b * T + t] : pad) - mx) / sum;
+    }
+}
+__global__ __launch_bounds__(256) void din_softmax_bwd_kernel(const float* __restrict__ p, const uint8_t* __restrict__ mask,
+                                                              const float* __restrict__ dp, int64_t batch, int T, float* __restrict__ ds) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < batch; b += (int64_t)gridDim.x * 4) {
+        float dot = 0.f;
+        for (int t = lane; t < T; t += 64) dot = fmaf(p[b * T + t], dp[b * T + t], dot);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        for (int t = lane; t < T; t += 64) ds[b * T + t] = mask[b * T + t] ? p[b * T + t] * (dp[b * T + t] - dot) : 0.f;
+    }
+}
+
+extern "C" int dctr_din_softmax_fwd(const float* score, const uint8_t* mask, int64_t batch, int32_t maxlen, float* p, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1, DCTR_E_DIM, "din_softmax_fwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(score && mask && p, DCTR_E_NULL, "din_softmax_fwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch, (int64_t)4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(din_softmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, score, mask, batch, (int)maxlen, p);
+    return dctr_launch_status("dctr_din_softmax_fwd");
+}
+
+// d_score (may alias dp) = softmax backward masked; d_bias (NULL ok) += sum d_score
+extern "C" int dctr_din_softmax_bwd(const float* p, const uint8_t* mask, const float* dp, int64_t batch, int32_t maxlen, float* d_score,
+                                    float* d_bias, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && maxlen >= 1, DCTR_E_DIM, "din_softmax_bwd: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(p && mask && dp && d_score, DCTR_E_NULL, "din_softmax_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch, (int64_t)4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(din_softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, mask, dp, batch, (int)maxlen, d_score);
+    if (d_bias != nullptr) {
+        const int64_t n = batch * maxlen;
+        int64_t g = dctr_ceil_div(n, (int64_t)256 * 8);
+        g = g < 1 ? 1 : (g > COLSUM_MAX_WG ? COLSUM_MAX_WG : g);
+        hipLaunchKernelGGL(sum_vec_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)d_score, n, d_bias);
+    }
+    return dctr_launch_status("dctr_din_softmax_bwd");
+}
+
 extern "C" int dctr_din_att_in_bwd(const float* da, const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim,
                                    float* dk, float* dx, int64_t dx_stride, const int32_t* qcol, void* stream) {
     DCTR_REQUIRE(batch >= 0 && maxlen >= 1 && dim >= 1, DCTR_E_DIM, "din_att_in_bwd: bad sizes");
@@ -1579,6 +1805,20 @@ extern "C" int dctr_bi_interaction_bwd(const float* x, int64_t batch, int64_t x_
     hipLaunchKernelGGL(bi_interaction_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch,
                        (int)fields, (int)dim, dy, dy_stride, dx, dx_stride, (int)accumulate);
     return dctr_launch_status("dctr_bi_interaction_bwd");
+}
+
+// FM.call backward (interaction.py:588-604) on a strided [B, >= F*E] buffer: dx[b,f,:] (+)= dlogit[b] * (sum_f' x[b,f',:] - x[b,f,:])
+extern "C" int dctr_fm_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dlogit, float* dx,
+                           int64_t dx_stride, int32_t accumulate, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && fields >= 1 && dim >= 1, DCTR_E_DIM, "fm_bwd: bad sizes");
+    DCTR_REQUIRE(x_stride >= (int64_t)fields * dim && dx_stride >= (int64_t)fields * dim, DCTR_E_DIM, "fm_bwd: stride < fields*dim");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x && dlogit && dx, DCTR_E_NULL, "fm_bwd: null pointer");
+    int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bi_interaction_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch, (int)fields,
+                       (int)dim, dlogit, (int64_t)1, dx, dx_stride, (int)accumulate, 0);
+    return dctr_launch_status("dctr_fm_bwd");
 }
 
 extern "C" int dctr_inner_product_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,

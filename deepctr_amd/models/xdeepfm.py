@@ -37,6 +37,15 @@ class _xDeepFM(FeatureModel):
                 self.dense_1 = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(self.cin_out_dim))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
         self._buf = {}
+        self._cin_ws = None         # layer 0's folded filter rows (dctr_cin_args_t.workspace): written by the first CIN launch after _begin()
+        self._cin_ws_ready = False
+
+    # CIN's persistent-round efficiency grows with the launch (C3: 300 us per 4096-row launch, 257 us per 4096 rows at 65,536)
+    span_rows = 65536
+
+    def _begin(self):
+        super(_xDeepFM, self)._begin()
+        self._cin_ws_ready = False  # the filters may have moved since the last call
 
     def _forward(self, staged, lo, hi, out):
         ws = self.stage_plan.run(staged, lo, hi)
@@ -50,9 +59,13 @@ class _xDeepFM(FeatureModel):
                 bufs = self._buf[B] = (torch.zeros(B, self.cin_out_dim, dtype=torch.float32, device=self.device),
                                        torch.zeros(B, dtype=torch.float32, device=self.device))
             maps, logit = bufs
+            if self._cin_ws is None:
+                need = ops.cin_workspace_bytes(len(self.stage_plan.fields), self.cin_dim, list(self.cin.layer_size))
+                self._cin_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=self.device)
             ops.cin(ws["dnn_in"], [f.reshape(-1, f.shape[-1]) for f in self.cin.filters], self.cin.biases,
                     list(self.cin.layer_size), self.cin.split_half, self.cin.activation, fields=len(self.stage_plan.fields),
-                    dim=self.cin_dim, out=maps)
+                    dim=self.cin_dim, out=maps, workspace=self._cin_ws, workspace_ready=self._cin_ws_ready)
+            self._cin_ws_ready = True
             ops.mlp(maps, [], [], "linear", head_w=self.dense_1.w('kernel'), in_dim=self.cin_out_dim, out=logit)
             add.append(logit)
         ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),

@@ -364,12 +364,15 @@ def cin_output_dim(layer_size, split_half):
     return sum(layer_size)
 
 
-def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None, save_y=None, fold=True):
+def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fields=None, dim=None, out=None, save_y=None, fold=True,
+        workspace=None, workspace_ready=False):
     """CIN.call (reference interaction.py:277-325): x [B,F0,D] (or, with ``fields``/``dim`` given, the leading
     F0*D columns of a [B, stride] concat buffer read in place); filters[k] [F0*Fk, Hk]; -> [B, featuremap_num].
     ``save_y``: per layer a [B*D, H_k] float32 tensor that receives the layer's activations (training: ``cin_bwd(saved_y=)``).
     ``fold``: hand the library the workspace for layer 0's symmetry fold (x_k = x_0 there: the F0 (F0 + 1) / 2 pairs i <= j against
-    W[ij] + W[ji]); False walks all F0 x F0 products (same result up to the rounding of that sum)."""
+    W[ij] + W[ji]); False walks all F0 x F0 products (same result up to the rounding of that sum).  ``workspace``: a caller-owned
+    float32 tensor of ``cin_workspace_bytes`` for the fold (default: the per-stream scratch, rewritten by every call);
+    ``workspace_ready``: it still holds an earlier call's fold of the same filter values (no fold launch)."""
     _dev_check(x, *filters, *biases)
     if fields is None:
         if x.dim() != 3:
@@ -399,10 +402,22 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
     if fold:
         need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
         if need:
-            ws = _scratch(x.device, need)       # rewritten by every call (the filters may have moved): stream order keeps calls apart
+            if workspace is not None:
+                if workspace.dtype != torch.float32 or not workspace.is_contiguous() or workspace.numel() * 4 < need or workspace.device != x.device:
+                    raise ValueError("cin: workspace must be a contiguous float32 tensor of >= %d bytes on %s" % (need, x.device))
+                ws, a.workspace_ready = workspace, int(bool(workspace_ready))
+            else:
+                ws = _scratch(x.device, need)   # rewritten by every call (the filters may have moved): stream order keeps calls apart
             a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _C.check(_C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_fwd")
     return out
+
+
+def cin_workspace_bytes(fields, dim, layer_size):
+    """Bytes of the fold workspace dctr_cin_fwd takes for a CIN over ``fields`` embeddings of width ``dim`` (0: no fold)."""
+    ls = _i32_array(layer_size)
+    a = _C.CinArgs(fields=int(fields), dim=int(dim), n_layers=len(layer_size), layer_size=ctypes.cast(ls, ctypes.c_void_p))
+    return int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
 
 
 def _check_saved_y(ys, rows, layer_size, x):
@@ -704,6 +719,40 @@ def dice_train_fwd(z, alpha, moving_mean, moving_var, out, eps=1e-9, momentum=0.
     return bm, bv
 
 
+def dnn_train_layer(z, activation, h=None, bn=None, dropout_rate=0.0, dropout_seed=0, dh=None, dz=None, d_gamma=None, d_beta=None):
+    """One DNN layer under training=True behind its dense part (dctr_dnn_train_layer_fwd / _bwd; reference layers/core.py:196-208):
+    z [R, n] = x W + b -> BatchNormalization(training) -> activation -> Dropout(training).
+    Forward (``h`` given, a 2-D possibly strided [R, n] view): writes h; with ``bn`` = dict(gamma, beta, moving_mean, moving_var,
+    eps, momentum, batch_mean, batch_var) the batch statistics are written to batch_mean / batch_var and the stored ones moved.
+    Backward (``dh`` given): dz [R, n] contiguous (may be dh itself) from dh, the same ``bn`` dict (batch statistics as the forward left
+    them) and the same dropout_rate / dropout_seed; d_gamma / d_beta are accumulated."""
+    R, n = z.shape
+    a = _C.DnnTrainLayer(z=z.data_ptr(), z_stride=z.stride(0), rows=R, n=n, activation=_C.ACT_CODES[activation],
+                         dropout_rate=float(dropout_rate), dropout_seed=int(dropout_seed) & 0xFFFFFFFFFFFFFFFF)
+    keep = [z]
+    if bn is not None:
+        a.use_bn, a.bn_eps, a.bn_momentum = 1, float(bn["eps"]), float(bn["momentum"])
+        a.bn_gamma, a.bn_beta = _ptr(bn.get("gamma")), _ptr(bn.get("beta"))
+        a.bn_moving_mean, a.bn_moving_var = _ptr(bn.get("moving_mean")), _ptr(bn.get("moving_var"))
+        a.bn_batch_mean, a.bn_batch_var = _ptr(bn["batch_mean"]), _ptr(bn["batch_var"])
+    if dh is None:
+        _dev_check(z, h)
+        a.h, a.h_stride = h.data_ptr(), h.stride(0)
+        _C.check(_C.lib().dctr_dnn_train_layer_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_dnn_train_layer_fwd")
+        return h
+    _dev_check(z, dh, dz)
+    if not dz.is_contiguous() or tuple(dz.shape) != (R, n):
+        raise ValueError("dnn_train_layer: dz must be a contiguous [%d, %d] tensor" % (R, n))
+    a.dh, a.dh_stride, a.dz = dh.data_ptr(), dh.stride(0), dz.data_ptr()
+    a.d_gamma, a.d_beta = _ptr(d_gamma), _ptr(d_beta)
+    if bn is not None:
+        ws = _scratch(z.device, 2 * n * 4)
+        a.workspace = ws.data_ptr()
+        keep.append(ws)
+    _C.check(_C.lib().dctr_dnn_train_layer_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_dnn_train_layer_bwd")
+    return dz
+
+
 def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None, biases=None,
             dice=None, d_dice_alpha=None, dice_eps=1e-9, dice_batch=None):
     """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written.
@@ -760,6 +809,28 @@ def din_wsum(score, mask, k, out):
     _C.check(_C.lib().dctr_din_wsum_fwd(_ptr(score), _ptr(mask), _ptr(k), B, T, E, _ptr(out), out.stride(0), _C.stream_ptr()),
              "dctr_din_wsum_fwd")
     return out
+
+
+def fm_bwd(x, fields, dim, dlogit, dx, accumulate=True):
+    """Backward of FM.call on a strided [B, >= F*E] slice of the DNN input: dx[b,f,:] (+)= dlogit[b] (sum_f' x[b,f',:] - x[b,f,:])."""
+    _dev_check(x, dlogit, dx)
+    _C.check(_C.lib().dctr_fm_bwd(_ptr(x), x.shape[0], x.stride(0), int(fields), int(dim), _ptr(dlogit), _ptr(dx), dx.stride(0),
+                                  int(bool(accumulate)), _C.stream_ptr()), "dctr_fm_bwd")
+
+
+def din_softmax(score, mask, out):
+    """softmax over all T positions of where(mask, score, -2^32 + 1) (att_weight_normalization=True): score / out [B*T] or [B, T]."""
+    _dev_check(score, mask, out)
+    B, T = mask.shape
+    _C.check(_C.lib().dctr_din_softmax_fwd(_ptr(score), _ptr(mask), B, T, _ptr(out), _C.stream_ptr()), "dctr_din_softmax_fwd")
+    return out
+
+
+def din_softmax_bwd(p, mask, dp, d_score, d_bias=None):
+    _dev_check(p, mask, dp, d_score, d_bias)
+    B, T = mask.shape
+    _C.check(_C.lib().dctr_din_softmax_bwd(_ptr(p), _ptr(mask), _ptr(dp), B, T, _ptr(d_score), _ptr(d_bias), _C.stream_ptr()),
+             "dctr_din_softmax_bwd")
 
 
 def din_wsum_bwd(d_out, score, mask, k, d_score, dk, d_bias=None):

@@ -36,15 +36,19 @@ def supported(model):
     if kind == "_DIN":
         # attention unit: Dice (moving statistics, as the torch step uses) or sigmoid / relu; plain weighted sum only
         la = model.attention.local_att
-        if model.attention.weight_normalization or la.dnn.activation not in ("dice", "Dice", "sigmoid", "relu", "tanh", "linear"):
+        if la.dnn.activation not in ("dice", "Dice", "sigmoid", "relu", "tanh", "linear"):
             return False
         if not la.dnn.kernels or getattr(la.dnn, "dropout_rate", 0) or getattr(la.dnn, "use_bn", False):
             return False
         # Dice runs as tf.keras runs it under fit(): BatchNormalization in training mode — this batch's statistics, gradients
         # through them, stored statistics moved (dctr_dice_train_fwd + dctr_mlp_bwd's dice_batch_*);
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
-    if sp.lin_only or len(sp.fm_group_names) > 1 or not sp.all_dim4 or sp.max_dim > 64:
+    if sp.lin_only or not sp.all_dim4 or sp.max_dim > 64:
         return False
+    if len(sp.fm_group_names) > 1:          # further FM groups (DeepFM / AFM fm_group): their logits ride on the head's four `add` slots
+        n_add = int(bool(sp.has_linear)) + len(sp.fm_group_names)
+        if kind not in ("_DeepFM", "_AFM") or n_add > 4:
+            return False
     if kind == "_AFM":                      # no DNN: linear logit + AFMLayer per group (or the gather's FM group)
         return not any(getattr(layer, "dropout_rate", 0) for layer in model.afm_layers)
     if sp.extra_offsets and kind not in ("_NFM", "_PNN", "_DIN"):   # the interaction columns those reserve in dnn_in
@@ -56,9 +60,10 @@ def supported(model):
     if getattr(model, "bi_dropout", 0):
         return False
     if dnn is not None:
-        if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or getattr(dnn, "use_bn", False) or not dnn.kernels:
+        # dnn_dropout > 0 / dnn_use_bn=True: the DNN runs layer by layer (dctr_dnn_train_layer_fwd / _bwd behind each dense part)
+        if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or not dnn.kernels:
             return False
-        if getattr(dnn, "dropout_rate", 0):
+        if getattr(dnn, "output_activation", None) not in (None, dnn.activation):
             return False
     return True
 
@@ -171,6 +176,15 @@ class HipTrainer(object):
         self.p_kernels = [param(k, l2d) for k in model.dnn.kernels] if model.dnn is not None else []
         self.p_biases = [param(b) for b in model.dnn.biases] if model.dnn is not None else []
         self.p_head = param(model.dense.w("kernel")) if getattr(model, "dense", None) is not None else None
+        # DNN(dropout_rate > 0 / use_bn=True): training-mode BatchNormalization (gamma / beta trained, stored statistics moved by the
+        # forward) and Dropout (reference layers/core.py:196-208) — the layer-by-layer form of _dnn_forward / _dnn_backward
+        dnn = model.dnn
+        self.drop_rate = float(getattr(dnn, "dropout_rate", 0) or 0) if dnn is not None else 0.0
+        self.bn_layers = list(getattr(dnn, "bn_layers", None) or []) if dnn is not None else []
+        self.slow_dnn = bool(self.drop_rate > 0 or self.bn_layers)
+        self.p_bn = [(param(b.w("gamma")) if b.scale else None, param(b.w("beta")) if b.center else None) for b in self.bn_layers]
+        self.drop_base = int(getattr(dnn, "seed", 1024) or 0) * 0x9E3779B1 + 12345 if dnn is not None else 0
+        self.n_steps = 0            # forward passes so far: the dropout masks of a step are a function of (drop_base, n_steps, layer)
         self.is_xdeepfm = type(model).__name__ == "_xDeepFM"
         self.p_cin_f = self.p_cin_b = self.p_head1 = None
         if self.is_xdeepfm and model.cin is not None:
@@ -220,6 +234,10 @@ class HipTrainer(object):
                           for h in self.model.cin.layer_size]
                 if (self.p_cin_f and B * self.model.cin_dim * max(self.model.cin.layer_size) * 4 < 2 ** 31) else None,
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
+                "pre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if self.slow_dnn else None,
+                "dpre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if self.slow_dnn else None,
+                "bn_stat": [(torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev))
+                            for n in units] if self.bn_layers else None,
                 "pred": torch.empty(B, dtype=torch.float32, device=dev),
                 "dlogit": torch.empty(B, dtype=torch.float32, device=dev),
                 "dx": torch.empty(B, sp.out_stride, dtype=torch.float32, device=dev),
@@ -254,6 +272,73 @@ class HipTrainer(object):
             cr._weights['kernel%d' % i] = self.p_cross_k.w[i].view(d, -1)
             cr._weights['bias%d' % i] = self.p_cross_b.w[i].view(d, 1)
 
+    # ---- the model's DNN (+ Dense(1) head) ------------------------------------------------------------------------------
+    def dropout_seed(self, layer):
+        """Seed of DNN layer ``layer``'s dropout mask in the CURRENT step (dctr_dnn_train_layer_t.dropout_seed)."""
+        return (self.drop_base + self.n_steps * 1000003 + layer * 7919) & 0xFFFFFFFFFFFFFFFF
+
+    def _bn_dict(self, l, buf):
+        if not self.bn_layers:
+            return None
+        b = self.bn_layers[l]
+        return dict(gamma=b.w("gamma") if b.scale else None, beta=b.w("beta") if b.center else None,
+                    moving_mean=b.w("moving_mean"), moving_var=b.w("moving_variance"), eps=b.epsilon, momentum=b.momentum,
+                    batch_mean=buf["bn_stat"][l][0], batch_var=buf["bn_stat"][l][1])
+
+    def _dnn_forward(self, x, in_dim, buf, out, head=True, add=(), binary=False):
+        """model.dnn over x[:, :in_dim] with the activations saved in buf["acts"]; ``head``: + Dense(1) + add + global bias (+ sigmoid)
+        -> out [B]; headless: the last layer's activations -> out (a 2-D view)."""
+        model, dnn = self.model, self.model.dnn
+        gb = None if self.p_gbias is None else self.p_gbias.w
+        if not self.slow_dnn:
+            if head:
+                ops.mlp(x, dnn.kernels, dnn.biases, dnn.activation, head_w=self.p_head.w, add=list(add), global_bias=gb,
+                        sigmoid_out=binary, in_dim=in_dim, out=out, save_acts=buf["acts"])
+            else:
+                ops.mlp(x, dnn.kernels, dnn.biases, dnn.activation, in_dim=in_dim, out=out, save_acts=buf["acts"])
+            return
+        # training-mode BatchNormalization / Dropout: dense part (one-layer linear launch) -> dctr_dnn_train_layer_fwd, layer by layer
+        L = len(dnn.kernels)
+        xin, kin = x, in_dim
+        for l, (W, b) in enumerate(zip(dnn.kernels, dnn.biases)):
+            ops.mlp(xin, [W], [b], "linear", in_dim=kin, out=buf["pre"][l])
+            h = out if (not head and l == L - 1) else buf["acts"][l]
+            ops.dnn_train_layer(buf["pre"][l], dnn.activation, h=h, bn=self._bn_dict(l, buf), dropout_rate=self.drop_rate,
+                                dropout_seed=self.dropout_seed(l))
+            xin, kin = h, W.shape[1]
+        if head:
+            ops.mlp(xin, [], [], "linear", head_w=self.p_head.w, add=list(add), global_bias=gb, sigmoid_out=binary, in_dim=kin, out=out)
+
+    def _dnn_backward(self, x, in_dim, buf, dx, dlogit=None, d_out=None):
+        """Backward of _dnn_forward: weight gradients accumulated, dx [B, >= in_dim] written.  With a head ``dlogit`` [B] comes in,
+        headless ``d_out`` (2-D view) = gradient w.r.t. the last layer's activations."""
+        model, dnn = self.model, self.model.dnn
+        dk, db = [p.g for p in self.p_kernels], [p.g for p in self.p_biases]
+        if not self.slow_dnn:
+            if dlogit is not None:
+                ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], dnn.activation, self.p_head.w, dlogit, dk, db, self.p_head.g, dx=dx)
+            else:
+                ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], dnn.activation, None, None, dk, db, None, dx=dx, d_out=d_out)
+            return
+        L = len(dnn.kernels)
+        units = [k.shape[1] for k in dnn.kernels]
+        if dlogit is not None:              # Dense(1): dH_last = dlogit (x) head_w, d_head_w += h_last^T dlogit
+            dh = buf["dpre"][L - 1]
+            ops.dense1_bwd(buf["acts"][L - 1], units[-1], self.p_head.w, dlogit, dh, self.p_head.g)
+        else:
+            dh = d_out
+        for l in range(L - 1, -1, -1):
+            dz = buf["dpre"][l]
+            pg = self.p_bn[l] if self.p_bn else (None, None)
+            ops.dnn_train_layer(buf["pre"][l], dnn.activation, bn=self._bn_dict(l, buf), dropout_rate=self.drop_rate,
+                                dropout_seed=self.dropout_seed(l), dh=dh, dz=dz,
+                                d_gamma=None if pg[0] is None else pg[0].g, d_beta=None if pg[1] is None else pg[1].g)
+            xin, kin = (x, in_dim) if l == 0 else (buf["acts"][l - 1], units[l - 1])
+            dst = dx if l == 0 else buf["dpre"][l - 1]
+            # dense part of the layer: d_bias += colsum(dz), dW += x^T dz, dH_{l-1} = dz W^T  (one-layer headless linear dctr_mlp_bwd)
+            ops.mlp_bwd(xin, kin, [dnn.kernels[l]], [buf["acts"][l]], "linear", None, None, [dk[l]], [db[l]], None, dx=dst, d_out=dz)
+            dh = dst
+
     def _loss_grad(self, buf, y, binary):
         buf["loss"].zero_()
         ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"],
@@ -266,6 +351,7 @@ class HipTrainer(object):
             add.append(ws["lin"])
         if sp.fm_group_names:
             add.append(ws["fm"])
+            add.extend(ws["fm_extra"])      # DeepFM(fm_group=(...)): FM over further embedding groups (models/deepfm.py:53-54)
         cin = model.cin if self.p_cin_f else None
         if cin is not None:             # xDeepFM (models/xdeepfm.py:52-66): CIN over the embeddings -> Dense(1) -> extra logit
             nf, dim = len(sp.fields), model.cin_dim
@@ -274,12 +360,9 @@ class HipTrainer(object):
                     out=buf["maps"], save_y=buf["cin_y"])
             ops.mlp(buf["maps"], [], [], "linear", head_w=self.p_head1.w, in_dim=model.cin_out_dim, out=buf["cin_logit"])
             add.append(buf["cin_logit"])
-        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w, add=add,
-                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
-                out=buf["pred"], save_acts=buf["acts"])
+        self._dnn_forward(ws["dnn_in"], sp.in_dim, buf, buf["pred"], head=True, add=add, binary=binary)
         self._loss_grad(buf, y, binary)
-        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
-                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=buf["dx"])
+        self._dnn_backward(ws["dnn_in"], sp.in_dim, buf, buf["dx"], dlogit=buf["dlogit"])
         if cin is not None:
             ops.dense1_bwd(buf["maps"], model.cin_out_dim, self.p_head1.w, buf["dlogit"], buf["dmaps"], self.p_head1.g)
             ops.cin_bwd(ws["dnn_in"], filt, cin.biases, list(cin.layer_size), cin.split_half, cin.activation, buf["dmaps"],
@@ -292,6 +375,7 @@ class HipTrainer(object):
         add = [ws["lin"]] if sp.has_linear else []
         if sp.fm_group_names:
             add.append(ws["fm"])
+            add.extend(ws["fm_extra"])
         if "afm_out" not in buf:
             buf["afm_out"] = [torch.zeros(B, 1, dtype=torch.float32, device=model.device) for _ in model.afm_layers]
         outs = buf["afm_out"]
@@ -349,15 +433,24 @@ class HipTrainer(object):
             ops.mlp(buf["att_in"], la.dnn.kernels, la.dnn.biases, act, dice=dice, head_w=pa["out_w"].w, global_bias=pa["out_b"].w,
                     in_dim=4 * E, out=buf["score"], save_acts=buf["att_acts"])
         hist_off = sp.extra_offsets["hist"]
-        ops.din_wsum(buf["score"], m, k, ws["dnn_in"][:, hist_off:])
-        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
-                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
-                out=buf["pred"], save_acts=buf["acts"])
+        softmax = bool(model.attention.weight_normalization)
+        if softmax:                     # att_weight_normalization=True: masked softmax over the positions, then the sum over ALL of them
+            if "att_p" not in buf:
+                buf.update(att_p=torch.empty(B * T, dtype=torch.float32, device=model.device),
+                           ones=torch.ones(B, T, dtype=torch.uint8, device=model.device))
+            ops.din_softmax(buf["score"], m, buf["att_p"])
+            ops.din_wsum(buf["att_p"], buf["ones"], k, ws["dnn_in"][:, hist_off:])
+        else:
+            ops.din_wsum(buf["score"], m, k, ws["dnn_in"][:, hist_off:])
+        self._dnn_forward(ws["dnn_in"], sp.in_dim, buf, buf["pred"], head=True, binary=binary)
         self._loss_grad(buf, y, binary)
         dx = buf["dx"]
-        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
-                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=dx)
-        ops.din_wsum_bwd(dx[:, hist_off:], buf["score"], m, k, buf["d_score"], buf["dk"], d_bias=pa["out_b"].g)
+        self._dnn_backward(ws["dnn_in"], sp.in_dim, buf, dx, dlogit=buf["dlogit"])
+        if softmax:
+            ops.din_wsum_bwd(dx[:, hist_off:], buf["att_p"], buf["ones"], k, buf["d_score"], buf["dk"])
+            ops.din_softmax_bwd(buf["att_p"], m, buf["d_score"], buf["d_score"], d_bias=pa["out_b"].g)
+        else:
+            ops.din_wsum_bwd(dx[:, hist_off:], buf["score"], m, k, buf["d_score"], buf["dk"], d_bias=pa["out_b"].g)
         ops.mlp_bwd(buf["att_in"], 4 * E, la.dnn.kernels, buf["att_acts"], act, pa["out_w"].w, buf["d_score"],
                     [p.g for p in pa["kernels"]], [p.g for p in pa["biases"]], pa["out_w"].g, dx=buf["d_att_in"],
                     biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None,
@@ -373,13 +466,10 @@ class HipTrainer(object):
         off = sp.extra_offsets["bi_interaction"]
         x = ws["dnn_in"][:, off:]
         ops.bi_interaction(ws["dnn_in"], fields=model.n_emb, dim=model.emb_dim, out=x)
-        ops.mlp(x, model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
-                add=[ws["lin"]] if sp.has_linear else [], global_bias=None if self.p_gbias is None else self.p_gbias.w,
-                sigmoid_out=binary, in_dim=model.dnn_in_dim, out=buf["pred"], save_acts=buf["acts"])
+        self._dnn_forward(x, model.dnn_in_dim, buf, buf["pred"], head=True, add=[ws["lin"]] if sp.has_linear else [], binary=binary)
         self._loss_grad(buf, y, binary)
         dx = buf["dx"]
-        ops.mlp_bwd(x, model.dnn_in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
-                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=dx[:, off:])
+        self._dnn_backward(x, model.dnn_in_dim, buf, dx[:, off:], dlogit=buf["dlogit"])
         ops.bi_interaction_bwd(ws["dnn_in"], model.n_emb, model.emb_dim, dx[:, off:], dx)
 
     def _pnn_forward_backward(self, ws, buf, y, binary):
@@ -388,13 +478,10 @@ class HipTrainer(object):
         if model.use_inner:
             off = sp.extra_offsets["inner_product"]
             ops.inner_product(ws["dnn_in"], True, fields=model.n_emb, dim=model.emb_dim, out=ws["dnn_in"][:, off:])
-        ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, head_w=self.p_head.w,
-                global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=sp.in_dim,
-                out=buf["pred"], save_acts=buf["acts"])
+        self._dnn_forward(ws["dnn_in"], sp.in_dim, buf, buf["pred"], head=True, binary=binary)
         self._loss_grad(buf, y, binary)
         dx = buf["dx"]
-        ops.mlp_bwd(ws["dnn_in"], sp.in_dim, model.dnn.kernels, buf["acts"], model.dnn.activation, self.p_head.w, buf["dlogit"],
-                    [p.g for p in self.p_kernels], [p.g for p in self.p_biases], self.p_head.g, dx=dx)
+        self._dnn_backward(ws["dnn_in"], sp.in_dim, buf, dx, dlogit=buf["dlogit"])
         if model.use_inner:
             ops.inner_product_bwd(ws["dnn_in"], model.n_emb, model.emb_dim, dx[:, off:], dx, accumulate=True)
 
@@ -414,8 +501,7 @@ class HipTrainer(object):
                 self._cross_fwd(ws["dnn_in"], d, par, stack)
             col = d
         if model.dnn is not None:
-            ops.mlp(ws["dnn_in"], model.dnn.kernels, model.dnn.biases, model.dnn.activation, in_dim=d, out=stack[:, col:],
-                    save_acts=buf["acts"])
+            self._dnn_forward(ws["dnn_in"], d, buf, stack[:, col:], head=False)
         add = [ws["lin"]] if sp.has_linear else []
         ops.mlp(stack, [], [], "linear", head_w=self.p_head.w, add=add,
                 global_bias=None if self.p_gbias is None else self.p_gbias.w, sigmoid_out=binary, in_dim=model.width,
@@ -425,8 +511,7 @@ class HipTrainer(object):
         ops.dense1_bwd(stack, model.width, self.p_head.w, buf["dlogit"], dstack, self.p_head.g)
         have_dx = False
         if model.dnn is not None:
-            ops.mlp_bwd(ws["dnn_in"], d, model.dnn.kernels, buf["acts"], model.dnn.activation, None, None,
-                        [p.g for p in self.p_kernels], [p.g for p in self.p_biases], None, dx=buf["dx"], d_out=dstack[:, col:])
+            self._dnn_backward(ws["dnn_in"], d, buf, buf["dx"], d_out=dstack[:, col:])
             have_dx = True
         if model.cross is not None and self.p_mix is not None:
             ops.crossnet_mix_bwd(ws["dnn_in"], d, [p.w for p in self.p_mix], dstack, [p.g for p in self.p_mix], buf["dx"],
@@ -455,6 +540,7 @@ class HipTrainer(object):
         after the backward pass and leaves the gradients in the ``g`` buffers (tests)."""
         model, sp = self.model, self.model.stage_plan
         model._begin()                      # weight-derived forward buffers follow the last update
+        self.n_steps += 1
         B = hi - lo
         buf = self._buffers(B)
         binary = model.task == "binary"
@@ -480,6 +566,9 @@ class HipTrainer(object):
         # embedding / linear / FM backward
         for t in list(buf["pooled_g"].values()) + list(buf["pooled_lin_g"].values()):
             t.zero_()
+        for gname in sp.fm_group_names[1:]:      # FM groups beyond the gather's own: d e_f += dlogit (S_g - e_f) on their slice of dnn_in
+            first, nf_g, dim_g = sp.group_slices[gname]
+            ops.fm_bwd(ws["dnn_in"][:, first:], nf_g, dim_g, buf["dlogit"], buf["dx"][:, first:], accumulate=True)
         g = sp.gather_args(staged, lo, hi, ws)
         ops.embed_gather_fm_bwd(g, buf["field_grads"], d_dnn_in=buf["dx"], d_fm=buf["dlogit"] if sp.fm_group_names else None,
                                 d_lin=buf["dlogit"] if sp.has_linear else None,

@@ -260,12 +260,17 @@ typedef struct {
     int32_t n_layers;
     int32_t split_half;
     int32_t activation;           /* DCTR_ACT_LINEAR | RELU | SIGMOID | TANH */
-    int32_t pad_;
+    int32_t workspace_ready;      /* 0: the call (re)writes `workspace` from filters[0] (one small launch in front of the kernel).
+                                     1: the caller vouches `workspace` still holds what an earlier call with the same filters[0]
+                                     VALUES, fields and layer_size[0] wrote: the fold launch is skipped (predict() over many batches) */
     const int32_t* layer_size;    /* HOST array [n_layers] */
     const float* const* filters;  /* HOST array of n_layers DEVICE pointers */
     const float* const* bias;     /* HOST array of n_layers DEVICE pointers */
     float* out;                   /* [B, featuremap_num] */
-    void* workspace;              /* device scratch, dctr_cin_workspace_bytes() bytes, 16-B aligned */
+    void* workspace;              /* NULL, or device scratch of dctr_cin_workspace_bytes() bytes, 16-B aligned: layer 0 multiplies x_0
+                                     with itself (z[i,j] = z[j,i]), so with a workspace the kernel walks the F0 (F0 + 1) / 2 pairs
+                                     i <= j against W[ij] + W[ji] folded there (same result up to the rounding of that sum; 1.3x
+                                     faster at C3).  Without it layer 0 walks all F0 x F0 products. */
     size_t workspace_bytes;
     float* const* save_y;         /* NULL, or HOST array of n_layers DEVICE pointers (entries may be NULL): layer k's
                                    * activations y_k [B*D, H_k] row-major (row b*D + d, ALL H_k maps) are also written there
@@ -530,6 +535,46 @@ int dctr_dice_train_fwd(const float* z, int64_t z_stride, const float* bias, int
                         float* h, int64_t h_stride, void* stream);
 int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* args, void* stream);
 
+/* One DNN layer under training=True with the regularisers of the reference's DNN.call (deepctr/layers/core.py:196-208):
+ *     fc = x W + b  ->  BatchNormalization(training) when use_bn  ->  activation  ->  Dropout(training) when dropout_rate > 0.
+ * The dense part (z = x W + b) is a one-layer linear dctr_mlp_fwd; these two entries are what sits behind it and its backward:
+ *   fwd:  [use_bn: batch mean / biased variance of z over all rows -> bn_batch_mean / bn_batch_var, stored statistics moved with
+ *         bn_momentum (tf.keras: moving = moving * momentum + batch * (1 - momentum))]
+ *         y = gamma (z - mean) rsqrt(var + eps) + beta   (y = z without BatchNormalization)
+ *         h = keep(b, n) ? act(y) / (1 - rate) : 0        (keras' inverted dropout; keep = counter-based generator over
+ *                                                          (dropout_seed, b * n + column): the backward regenerates it)
+ *   bwd:  dy = dh * keep / (1 - rate) * act'(y);  d_beta += sum_b dy;  d_gamma += sum_b dy xhat;
+ *         dz = gamma rsqrt(var + eps) (dy - mean_b(dy) - xhat mean_b(dy xhat))    (dz = dy without BatchNormalization)
+ * The generator is this library's, not TensorFlow's: masks differ from a TF run with the same seed (as any two TF versions do). */
+typedef struct {
+    const float* z;               /* [rows, z_stride] pre-activations x W + b                              */
+    int64_t z_stride;
+    int64_t rows;
+    int32_t n;                    /* columns (units of the layer)                                          */
+    int32_t activation;           /* DCTR_ACT_LINEAR | RELU | SIGMOID | TANH                               */
+    int32_t use_bn;
+    float bn_eps;
+    float bn_momentum;
+    float dropout_rate;           /* in [0, 1); 0 = no dropout                                             */
+    unsigned long long dropout_seed;
+    const float* bn_gamma;        /* [n] or NULL (scale=False: 1)                                          */
+    const float* bn_beta;         /* [n] or NULL (center=False: 0)                                         */
+    float* bn_moving_mean;        /* [n] updated by the forward; NULL = leave                              */
+    float* bn_moving_var;
+    float* bn_batch_mean;         /* [n] written by the forward, read by the backward (use_bn)             */
+    float* bn_batch_var;
+    float* h;                     /* forward: [rows, h_stride] out                                         */
+    int64_t h_stride;
+    const float* dh;              /* backward: [rows, dh_stride] gradient w.r.t. h                         */
+    int64_t dh_stride;
+    float* dz;                    /* backward: [rows, n] contiguous out (may alias dh when dh_stride == n) */
+    float* d_gamma;               /* backward: accumulated [n]; NULL ok                                    */
+    float* d_beta;
+    float* workspace;             /* backward with use_bn: 2 * n floats                                    */
+} dctr_dnn_train_layer_t;
+int dctr_dnn_train_layer_fwd(const dctr_dnn_train_layer_t* a, void* stream);
+int dctr_dnn_train_layer_bwd(const dctr_dnn_train_layer_t* a, void* stream);
+
 /* DIN's LocalActivationUnit as a training step (layers/core.py:94-108, layers/sequence.py:261-298, att_weight_normalization
  * = False): the attention input a[b*T+t, :] = [q_b, k_bt, q_b - k_bt, q_b * k_bt] ([B*T, 4*dim]) is materialised so that the
  * unit's MLP runs through dctr_mlp_fwd (save_acts) / dctr_mlp_bwd; out[b,:] = sum_t (mask ? score : 0) k[b,t,:].
@@ -542,6 +587,12 @@ int dctr_din_wsum_fwd(const float* score, const uint8_t* mask, const float* k, i
                       float* out, int64_t out_stride, void* stream);
 int dctr_din_wsum_bwd(const float* d_out, int64_t d_stride, const float* score, const uint8_t* mask, const float* k, int64_t batch,
                       int32_t maxlen, int32_t dim, float* d_score, float* dk, float* d_bias, void* stream);
+/* att_weight_normalization=True (layers/sequence.py:283-289): p [B, T] = softmax over all T positions of where(mask, score, -2^32 + 1);
+ * the weighted sum over the keys then takes p with an all-ones mask (dctr_din_wsum_fwd / _bwd).  Backward: d_score = mask ? p (dp - <p, dp>)
+ * : 0 (d_score may alias dp), d_bias (NULL ok) += sum d_score. */
+int dctr_din_softmax_fwd(const float* score, const uint8_t* mask, int64_t batch, int32_t maxlen, float* p, void* stream);
+int dctr_din_softmax_bwd(const float* p, const uint8_t* mask, const float* dp, int64_t batch, int32_t maxlen, float* d_score, float* d_bias,
+                         void* stream);
 int dctr_din_att_in_bwd(const float* da, const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* dk,
                         float* dx, int64_t dx_stride, const int32_t* qcol, void* stream);
 int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, void* stream);
@@ -557,6 +608,10 @@ int dctr_bi_interaction_bwd(const float* x, int64_t batch, int64_t x_stride, int
                             int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream);
 int dctr_inner_product_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dy,
                            int64_t dy_stride, float* dx, int64_t dx_stride, int32_t accumulate, void* stream);
+/* backward of FM.call (interaction.py:588-604; dctr_fm_fwd / the gather's FM epilogue) for an FM group that is a slice of the DNN input
+ * (DeepFM(fm_group=...) beyond the first group): dx[b,f,:] = dlogit[b] * (sum_f' x[b,f',:] - x[b,f,:]), written or added to. */
+int dctr_fm_bwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim, const float* dlogit, float* dx,
+                int64_t dx_stride, int32_t accumulate, void* stream);
 
 /* backward of dctr_afm_fwd (AFMLayer.call, interaction.py:116-146); the attention is recomputed, nothing is saved by the
  * forward.  dy [B] = gradient w.r.t. the layer's [B,1] output; dx [B, dx_stride]: first fields*dim columns written (or

@@ -146,7 +146,7 @@ def test_every_ctypes_mirror_has_the_layout_the_c_compiler_gives_the_header(tmp_
     pairs = {"FieldDesc": "dctr_field_t", "GatherFmArgs": "dctr_gather_fm_args_t", "PoolArgs": "dctr_pool_args_t",
              "LookupArgs": "dctr_lookup_args_t", "CinArgs": "dctr_cin_args_t", "MlpArgs": "dctr_mlp_args_t",
              "FieldGrad": "dctr_field_grad_t", "GatherFmBwdArgs": "dctr_gather_fm_bwd_args_t", "PoolBwdArgs": "dctr_pool_bwd_args_t",
-             "MlpBwdArgs": "dctr_mlp_bwd_args_t", "CinBwdArgs": "dctr_cin_bwd_args_t", "CrossBwdArgs": "dctr_crossnet_bwd_args_t", "CrossMixBwdArgs": "dctr_crossnet_mix_bwd_args_t",
+             "MlpBwdArgs": "dctr_mlp_bwd_args_t", "DnnTrainLayer": "dctr_dnn_train_layer_t", "CinBwdArgs": "dctr_cin_bwd_args_t", "CrossBwdArgs": "dctr_crossnet_bwd_args_t", "CrossMixBwdArgs": "dctr_crossnet_mix_bwd_args_t",
              "AfmBwdArgs": "dctr_afm_bwd_args_t", "HostCol": "dctr_host_col_t", "AdamSeg": "dctr_adam_seg_t",
              "DinAttnArgs": "dctr_din_attn_args_t"}
     mirrors = [n for n in dir(_C) if isinstance(getattr(_C, n), type) and issubclass(getattr(_C, n), ctypes.Structure)

@@ -625,6 +625,10 @@ def test_cin_folded_layer0_shapes(device, F0, ls, split):
     assert_close_terms(y1.cpu().numpy(), ref, mag, what="cin folded F0=%d %s" % (F0, ls))
     assert_close_terms(y0.cpu().numpy(), ref, mag, what="cin plain F0=%d %s" % (F0, ls))
     assert torch.equal(ops.cin(*args), y1)                      # the scratch workspace is rewritten per call: same bits
+    # a caller-owned workspace: folded by the first call, reused (no fold launch) by the second
+    ws = torch.empty(max(ops.cin_workspace_bytes(F0, D, ls) // 4, 1), dtype=torch.float32, device=device)
+    assert torch.equal(ops.cin(*args, workspace=ws), y1)
+    assert torch.equal(ops.cin(*args, workspace=ws, workspace_ready=True), y1)
 
 
 def test_embed_lookup_multi(device):
