@@ -57,8 +57,6 @@ def supported(model):
         return False
     if kind == "_xDeepFM" and model.cin is not None and model.cin.activation not in ("relu", "linear", "sigmoid", "tanh"):
         return False
-    if getattr(model, "bi_dropout", 0):
-        return False
     if dnn is not None:
         # dnn_dropout > 0 / dnn_use_bn=True: the DNN runs layer by layer (dctr_dnn_train_layer_fwd / _bwd behind each dense part)
         if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or not dnn.kernels:
@@ -461,16 +459,27 @@ class HipTrainer(object):
                 ops.embed_lookup_bwd(idx, tuple(pt.w.shape), hm, buf["dk"][:, :, col:], pt.g)
 
     def _nfm_forward_backward(self, ws, buf, y, binary):
-        """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) | dense] -> Dense(1) + linear logit."""
+        """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) (+ Dropout(bi_dropout)) | dense] -> Dense(1) + linear logit."""
         model, sp = self.model, self.model.stage_plan
         off = sp.extra_offsets["bi_interaction"]
         x = ws["dnn_in"][:, off:]
-        ops.bi_interaction(ws["dnn_in"], fields=model.n_emb, dim=model.emb_dim, out=x)
+        E = model.emb_dim
+        bi_rate = float(getattr(model, "bi_dropout", 0) or 0)
+        ops.bi_interaction(ws["dnn_in"], fields=model.n_emb, dim=E, out=x)
+        if bi_rate > 0:                 # nfm.py:52-53: Dropout on the pooled vector, in place (layer slot 100 of the step's mask seeds)
+            xe = x[:, :E]
+            ops.dnn_train_layer(xe, "linear", h=xe, dropout_rate=bi_rate, dropout_seed=self.dropout_seed(100))
         self._dnn_forward(x, model.dnn_in_dim, buf, buf["pred"], head=True, add=[ws["lin"]] if sp.has_linear else [], binary=binary)
         self._loss_grad(buf, y, binary)
         dx = buf["dx"]
         self._dnn_backward(x, model.dnn_in_dim, buf, dx[:, off:], dlogit=buf["dlogit"])
-        ops.bi_interaction_bwd(ws["dnn_in"], model.n_emb, model.emb_dim, dx[:, off:], dx)
+        dy = dx[:, off:]
+        if bi_rate > 0:
+            if "bi_dz" not in buf:
+                buf["bi_dz"] = torch.empty(x.shape[0], E, dtype=torch.float32, device=model.device)
+            dy = ops.dnn_train_layer(x[:, :E], "linear", dropout_rate=bi_rate, dropout_seed=self.dropout_seed(100), dh=dx[:, off:off + E],
+                                     dz=buf["bi_dz"])
+        ops.bi_interaction_bwd(ws["dnn_in"], model.n_emb, E, dy, dx)
 
     def _pnn_forward_backward(self, ws, buf, y, binary):
         """PNN, inner-product form (models/pnn.py:52-72): DNN over [embeddings | pair inner products | dense] -> Dense(1)."""

@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batches", default="4096,16384")
-    ap.add_argument("--model", default="DeepFM", help="DeepFM | WDL | FNN | DCN | DCNM (matrix) | DCNMix | xDeepFM | DIN (BASELINE C4: T=50, E=32; default batch 2048)")
+    ap.add_argument("--model", default="DeepFM", help="DeepFM | DeepFMdrop (dnn_dropout 0.5) | DeepFMbn (dnn_use_bn) | WDL | FNN | DCN | DCNM (matrix) | DCNMix | xDeepFM | DIN (BASELINE C4: T=50, E=32; default batch 2048)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rng = np.random.RandomState(0)
@@ -35,8 +35,8 @@ def main():
             args.batches = "2048"
     else:
         cols = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
-        kw = {"DCNM": dict(cross_parameterization="matrix")}.get(args.model, {})
-        model = getattr(models, {"DCNM": "DCN"}.get(args.model, args.model))(cols, cols, device=dev, **kw)
+        kw = {"DCNM": dict(cross_parameterization="matrix"), "DeepFMdrop": dict(dnn_dropout=0.5), "DeepFMbn": dict(dnn_use_bn=True)}.get(args.model, {})
+        model = getattr(models, {"DCNM": "DCN", "DeepFMdrop": "DeepFM", "DeepFMbn": "DeepFM"}.get(args.model, args.model))(cols, cols, device=dev, **kw)
     tr = HipTrainer(model)
     n_param = sum(p.w.numel() for p in tr.params)
     for B in [int(b) for b in args.batches.split(",")]:

@@ -95,13 +95,16 @@ def _build(kind, device, use_bn, rate):
         return models.DCNMix(cols, cols, cross_num=2, low_rank=4, num_experts=2, l2_reg_cross=0, **kw), cols
     if kind == "PNN":                   # (no dnn_use_bn in the reference's PNN / WDL / NFM signatures)
         return models.PNN(cols, dnn_hidden_units=(32, 16), dnn_dropout=rate, l2_reg_embedding=0, device=device), cols
+    if kind == "NFMbi":
+        kw.pop("dnn_use_bn")
+        return models.NFM(cols, cols, bi_dropout=0.4, **kw), cols
     if kind in ("WDL", "NFM"):
         kw.pop("dnn_use_bn")
     return getattr(models, kind)(cols, cols, **kw), cols
 
 
 @pytest.mark.parametrize("kind,use_bn,rate", [("DeepFM", False, 0.3), ("DeepFM", True, 0.0), ("DeepFM", True, 0.2), ("DCN", True, 0.25),
-                                              ("xDeepFM", True, 0.0), ("PNN", False, 0.5), ("WDL", False, 0.1), ("NFM", False, 0.3), ("DCNMix", True, 0.0)])
+                                              ("xDeepFM", True, 0.0), ("PNN", False, 0.5), ("WDL", False, 0.1), ("NFM", False, 0.3), ("DCNMix", True, 0.0), ("NFMbi", False, 0.2), ("NFMbi", False, 0.0)])
 def test_hip_step_with_dropout_and_batchnorm_matches_autograd(device, kind, use_bn, rate, monkeypatch):
     from deepctr_amd import training
     from deepctr_amd.training_hip import HipTrainer, supported
@@ -117,7 +120,7 @@ def test_hip_step_with_dropout_and_batchnorm_matches_autograd(device, kind, use_
     staged = model.stage(feed)
     model._begin()
     tr = HipTrainer(model)
-    assert tr.slow_dnn
+    assert tr.slow_dnn or kind == "NFMbi"
     moving0 = [(b.w("moving_mean").clone(), b.w("moving_variance").clone()) for b in tr.bn_layers]
     yt = dev(y, device)
     loss = tr.step(staged, 0, n, yt, apply=False)
@@ -125,6 +128,8 @@ def test_hip_step_with_dropout_and_batchnorm_matches_autograd(device, kind, use_
     # the masks of this step, layer by layer, as the kernel generated them -> the restatement's Dropout
     units = [k.shape[1] for k in model.dnn.kernels]
     masks = [_mask_scale(n, u, rate, tr.dropout_seed(l), device) for l, u in enumerate(units)] if rate > 0 else []
+    if kind == "NFMbi":                 # the restatement drops the pooled vector first (models/nfm.py:52-53), then the DNN's layers
+        masks.insert(0, _mask_scale(n, model.emb_dim, 0.4, tr.dropout_seed(100), device))
     it = iter(masks)
     monkeypatch.setattr(training, "_dropout", lambda x, r, training_: x * next(it) if (training_ and r and r > 0) else x)
     for b, (m0, v0) in zip(tr.bn_layers, moving0):                  # the restatement moves the stored statistics once more: rewind
@@ -152,7 +157,7 @@ def test_hip_step_with_dropout_and_batchnorm_matches_autograd(device, kind, use_
     for b, (m1, v1) in zip(tr.bn_layers, moving1):                  # stored statistics: moved exactly as tf.keras moves them
         assert_close(m1.cpu().numpy(), b.w("moving_mean").cpu().numpy(), rtol=1e-5, atol=1e-6, what="moving mean")
         assert_close(v1.cpu().numpy(), b.w("moving_variance").cpu().numpy(), rtol=1e-4, atol=1e-6, what="moving variance")
-    if rate > 0:                                                    # the next step draws other masks
+    if rate > 0 and kind != "NFMbi":                                # the next step draws other masks
         tr.step(staged, 0, n, yt, apply=False)
         assert not torch.equal(_mask_scale(n, units[0], rate, tr.dropout_seed(0), device), masks[0])
 
