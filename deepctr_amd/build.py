@@ -44,6 +44,7 @@ SOURCES = [
     "din_kernels.hip",
     "din_chain_kernels.hip",
     "gemm_kernels.hip",
+    "mlp_bwd_kernels.hip",
     "train_kernels.hip",
 ]
 

@@ -50,7 +50,23 @@ struct MlpParams {
     unsigned long long* probe;  // measurement aid (NULL normally): {min start, max end} wall-clock stamps of this launch
     int32_t lda;      // LDS row stride (floats) = pad64(max tile width) + 4
     int32_t k_split;  // 0, or the column (multiple of 64) at which the layer-0 input tile is built in two halves
+    // backward chain (mlp_bwd_kernels.hip, ACT_BWD): the output of layer l is multiplied by act'(deriv_h[l][b, n]) — the forward's
+    // saved activation of that width — before it feeds the next layer (NULL: passed on as it is); deriv_act = the FORWARD's activation
+    const float* deriv_h[MAX_LAYERS];
+    int32_t deriv_act;
 };
+
+constexpr int ACT_BWD = 64;     // internal epilogue mode of the backward chain (not a DCTR_ACT_* value of the ABI)
+
+// act'(h) from the activation's OUTPUT h (relu, sigmoid, tanh, linear — the forms dctr_mlp_bwd's row kernels use)
+__device__ __forceinline__ float act_deriv_from_output(int act, float h) {
+    switch (act) {
+        case DCTR_ACT_RELU: return h > 0.f ? 1.f : 0.f;
+        case DCTR_ACT_SIGMOID: return h * (1.f - h);
+        case DCTR_ACT_TANH: return 1.f - h * h;
+        default: return 1.f;
+    }
+}
 
 // gather arguments of the fused path; lpr == 0 selects the plain x-staging path
 struct GatherFused : dctr_gather_fm_args_t {
@@ -193,6 +209,27 @@ __device__ __forceinline__ void tile_epilogue(const MlpParams& p, int l, float* 
     const int KQn = pad64(N) / 4;
     float* const sv = p.save[l];
     const int64_t row0 = (int64_t)blockIdx.x * (16 * RT);
+    if constexpr (ACT == ACT_BWD) {
+        // dZ_prev = (dZ W^T) .* act'(h_prev): no bias; the product goes to the next layer's tile and (save) to HBM for dW
+        const float* const dh = p.deriv_h[l];
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) {
+            const int n = n_base + TPW * j + c;
+            if (n < N) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t b = row0 + rt * 16 + 4 * g + r;
+                        float v = acc[rt][c][r];
+                        if (dh != nullptr) v *= b < p.batch ? act_deriv_from_output(p.deriv_act, dh[b * N + n]) : 0.f;
+                        out[(rt * 16 + 4 * g + r) * p.lda + lds_pos(n, KQn)] = v;
+                        if (sv != nullptr && b < p.batch) sv[b * N + n] = v;
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
         const int n = n_base + TPW * j + c;
@@ -725,5 +762,11 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
 int launch_rt1(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_rt2(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_rt4(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
+
+// backward chain of dctr_mlp_bwd (mlp_bwd_kernels.hip): dz_in [B, units_fwd[L-1]] -> dZ of every earlier layer (-> dz_out[l], dense
+// [B, units_fwd[l]]) and, with dx != NULL, the gradient of the DNN input; Wt[l] = W_l^T ([units_fwd[l], K_l] row-major, 16-B aligned)
+int launch_bwd_chain(hipStream_t stream, int64_t batch, int in_dim, int n_layers, const int32_t* units_fwd, const float* const* Wt,
+                     const float* const* acts, int activation, const float* dz_in, float* const* dz_out, float* dx, int64_t dx_stride);
+bool bwd_chain_fits(int in_dim, int n_layers, const int32_t* units_fwd);
 
 }  // namespace dctr_mlp

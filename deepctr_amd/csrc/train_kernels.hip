@@ -9,10 +9,18 @@
 //                             _resource_apply_sparse does) with the reference's l2 regulariser folded in
 // The reference has no code of its own for any of this (Keras autodiff + tf.keras.optimizers); the formulas are the
 // derivatives of the forward expressions cited above.
+#include <stdlib.h>
+
 #include "dctr_gemm.h"
 
 #include "dctr_common.h"
 #include "embed_device.h"
+
+namespace dctr_mlp {   // mlp_bwd_kernels.hip
+int launch_bwd_chain(hipStream_t stream, int64_t batch, int in_dim, int n_layers, const int32_t* units_fwd, const float* const* Wt,
+                     const float* const* acts, int activation, const float* dz_in, float* const* dz_out, float* dx, int64_t dx_stride);
+bool bwd_chain_fits(int in_dim, int n_layers, const int32_t* units_fwd);
+}
 
 namespace {
 
@@ -1909,6 +1917,98 @@ extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) 
     return dctr_launch_status("dctr_embed_pool_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// dctr_mlp_bwd, chained form (relu / linear / sigmoid / tanh): head -> dZ_{L-1};  W_l^T of every layer (one launch);  the backward
+// chain (mlp_bwd_kernels.hip: every dZ_l and dX in ONE launch);  dW_l (+ d_bias_l as one more output row) of every layer as row
+// slices in ONE grouped GEMM launch;  one launch that sums the slices into the gradient buffers.  Five launches per step where the
+// layer-by-layer form below took 4 L + 1 (a 3-layer DNN at B = 4096: ~60 us against ~210).
+// ---------------------------------------------------------------------------------------------------
+struct TransposeGroups {
+    const float* src[8];
+    float* dst[8];
+    int rows[8], cols[8];       // src is [rows, cols] row-major, dst [cols, rows]
+};
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeGroups tg) {
+    __shared__ float tile[32][33];
+    const int gi = blockIdx.y;
+    const int R = tg.rows[gi], C = tg.cols[gi];
+    const int tc = (C + 31) / 32, n_tiles = ((R + 31) / 32) * tc;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ty + 8 * i, c = c0 + tx;
+            tile[ty + 8 * i][tx] = (r < R && c < C) ? tg.src[gi][(int64_t)r * C + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;
+            if (c < C && r < R) tg.dst[gi][(int64_t)c * R + r] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
+    }
+}
+
+// dst_w[i] += sum_s parts[s * n + i] (i < n_w);  dst_b[i - n_w] += the same for the bias row behind the kernel's rows
+struct SumGroups {
+    const float* parts[8];
+    float* dst_w[8];
+    float* dst_b[8];
+    int64_t n[8], n_w[8];
+    int n_parts[8];
+};
+__global__ __launch_bounds__(256) void sum_parts_multi_kernel(SumGroups sg) {
+    const int gi = blockIdx.y;
+    const float* __restrict__ parts = sg.parts[gi];
+    const int64_t n = sg.n[gi], n_w = sg.n_w[gi];
+    const int n_parts = sg.n_parts[gi];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= n_parts; s += 4) {
+            a0 += parts[(int64_t)s * n + i];
+            a1 += parts[(int64_t)(s + 1) * n + i];
+            a2 += parts[(int64_t)(s + 2) * n + i];
+            a3 += parts[(int64_t)(s + 3) * n + i];
+        }
+        for (; s < n_parts; ++s) a0 += parts[(int64_t)s * n + i];
+        const float v = (a0 + a1) + (a2 + a3);
+        if (i < n_w) sg.dst_w[gi][i] += v;
+        else sg.dst_b[gi][i - n_w] += v;
+    }
+}
+
+// rows per dW slice of the chained form (DCTR_DW_ROWS overrides: scripts/gemm_lab.py)
+static int chain_dw_rows() {
+    static const int v = [] {
+        const char* e = getenv("DCTR_DW_ROWS");
+        const int x = e != nullptr ? atoi(e) : 0;
+        return x >= 32 ? x : 256;
+    }();
+    return v;
+}
+static bool chain_disabled() {
+    static const bool v = [] { const char* e = getenv("DCTR_MLP_BWD_CHAIN"); return e != nullptr && atoi(e) == 0; }();
+    return v;
+}
+static bool mlp_bwd_chained(const dctr_mlp_bwd_args_t* a) {
+    return !chain_disabled() && a->activation != DCTR_ACT_DICE && a->n_layers <= 8 && dctr_mlp::bwd_chain_fits(a->in_dim, a->n_layers, a->units);
+}
+// workspace of the chained form, in floats: dZ_l [B, units[l]] | W_l^T | dW slices [(K_l + 1) units[l]] x slices   (each 4-float aligned)
+static size_t mlp_bwd_chain_floats(const dctr_mlp_bwd_args_t* a) {
+    size_t f = 0;
+    const int slices = dctr_gemm::k_slices((int)a->batch, chain_dw_rows());
+    for (int l = 0; l < a->n_layers; ++l) {
+        const size_t K = l == 0 ? a->in_dim : a->units[l - 1], N = a->units[l];
+        f += ((size_t)a->batch * N + 3) & ~(size_t)3;
+        f += (K * N + 3) & ~(size_t)3;
+        f += ((size_t)slices * (K + 1) * N + 3) & ~(size_t)3;
+    }
+    return f;
+}
+
 // dW = X^T dZ has a small output and a reduction as long as the batch: it runs as a strided batch of row slices into partial
 // products + a sum (deterministic), 512 rows per slice from 1024 rows on, at most 32 slices (as ONE gemm a 429 x 256 output is 28
 // workgroups walking the whole batch: 64 us per layer at B = 4096; round 2's rocBLAS call split K by itself at small batches and took
@@ -1937,7 +2037,9 @@ extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
         w = a->units[l] > w ? a->units[l] : w;
     }
     const int parts = mlp_dw_parts(a->batch);
-    return (mlp_bwd_main_floats(a, w) + (parts > 1 ? (size_t)parts * kn : 0)) * sizeof(float);
+    const size_t layered = mlp_bwd_main_floats(a, w) + (parts > 1 ? (size_t)parts * kn : 0);
+    const size_t chained = (a->n_layers <= 8 && a->in_dim >= 1 && a->batch < 0x7fffffffLL && mlp_bwd_chained(a)) ? mlp_bwd_chain_floats(a) : 0;
+    return (layered > chained ? layered : chained) * sizeof(float);
 }
 
 extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
@@ -1956,6 +2058,87 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
                  "mlp_bwd: needs a workspace of dctr_mlp_bwd_workspace_bytes() bytes");
     DCTR_REQUIRE(a->batch < 0x7fffffffLL, DCTR_E_DIM, "mlp_bwd: batch too large");
     hipStream_t st = (hipStream_t)stream;
+    if (mlp_bwd_chained(a)) {
+        const int L = a->n_layers, B = (int)a->batch;
+        const int slices = dctr_gemm::k_slices(B, chain_dw_rows());
+        float* dz[8];
+        float* wt[8];
+        float* parts[8];
+        float* ws = static_cast<float*>(a->workspace);
+        for (int l = 0; l < L; ++l) {
+            const size_t K = l == 0 ? a->in_dim : a->units[l - 1], N = a->units[l];
+            dz[l] = ws; ws += ((size_t)a->batch * N + 3) & ~(size_t)3;
+            wt[l] = ws; ws += (K * N + 3) & ~(size_t)3;
+            parts[l] = ws; ws += ((size_t)slices * (K + 1) * N + 3) & ~(size_t)3;
+        }
+        // head: dZ_last = dlogit (x) head_w .* act'(h_last);  d_head_w = h_last^T dlogit   (headless: d_out .* act'(h_last))
+        const int NL = a->units[L - 1];
+        if (a->head_w != nullptr) {
+            launch_head_bwd(st, a->dlogit, a->head_w, a->acts[L - 1], (int64_t)NL, a->batch, NL, (int)a->activation, dz[L - 1], (int64_t)NL,
+                            a->d_head_w);
+        } else {
+            hipError_t ce = hipMemcpy2DAsync(dz[L - 1], (size_t)NL * sizeof(float), a->d_out, (size_t)a->d_out_stride * sizeof(float),
+                                             (size_t)NL * sizeof(float), (size_t)a->batch, hipMemcpyDeviceToDevice, st);
+            DCTR_REQUIRE(ce == hipSuccess, (int)ce, "mlp_bwd: copy of d_out failed: %s", hipGetErrorString(ce));
+            if (a->activation != DCTR_ACT_LINEAR)
+                launch_act_bwd_colsum(st, dz[L - 1], a->acts[L - 1], a->batch, NL, (int)a->activation, (float*)nullptr);
+        }
+        const int l_first = a->dx != nullptr ? 0 : 1;       // layers whose transposed kernel the chain multiplies by
+        if (l_first < L) {
+            TransposeGroups tg{};
+            int ng = 0, max_tiles = 1;
+            for (int l = l_first; l < L; ++l, ++ng) {
+                const int K = l == 0 ? a->in_dim : a->units[l - 1], N = a->units[l];
+                tg.src[ng] = a->kernels[l];
+                tg.dst[ng] = wt[l];
+                tg.rows[ng] = K;
+                tg.cols[ng] = N;
+                const int t = ((K + 31) / 32) * ((N + 31) / 32);
+                max_tiles = t > max_tiles ? t : max_tiles;
+            }
+            hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)max_tiles, (unsigned)ng), dim3(256), 0, st, tg);
+            const int rc = dctr_mlp::launch_bwd_chain(st, a->batch, a->in_dim, L, a->units, wt, a->acts, (int)a->activation, dz[L - 1], dz,
+                                                      a->dx, a->dx_stride);
+            if (rc != DCTR_OK) return rc;
+        }
+        // dW_l[K, N] (row-major) += X_l^T dZ_l, d_bias_l += colsum(dZ_l): column-major  dW'(N x (K + 1)) = dZ'(N x rows) * [X' ; 1](.. x rows)^T
+        dctr_gemm::GroupDesc gd[8];
+        SumGroups sg{};
+        int64_t max_n = 0;
+        for (int l = 0; l < L; ++l) {
+            const int N = a->units[l], K = l == 0 ? a->in_dim : a->units[l - 1];
+            const bool bias = a->d_biases != nullptr && a->d_biases[l] != nullptr;
+            dctr_gemm::GroupDesc& d = gd[l];
+            d = dctr_gemm::GroupDesc{};
+            d.op_a = dctr_gemm::OP_N;
+            d.op_b = dctr_gemm::OP_T;
+            d.m = N;
+            d.n = K + (bias ? 1 : 0);
+            d.k = B;
+            d.A = dz[l];
+            d.lda = N;
+            d.B = l == 0 ? a->x : a->acts[l - 1];
+            d.ldb = l == 0 ? (int)a->x_stride : K;
+            d.C = parts[l];
+            d.ldc = N;
+            d.batch = 1;
+            d.ones_last = bias ? 1 : 0;
+            d.k_slices = slices;
+            d.slice_stride_c = (int64_t)d.n * N;            // (sum_parts_multi reads slice s at parts + s * n)
+            sg.parts[l] = parts[l];
+            sg.dst_w[l] = a->d_kernels[l];
+            sg.dst_b[l] = bias ? a->d_biases[l] : nullptr;
+            sg.n[l] = (int64_t)d.n * N;
+            sg.n_w[l] = (int64_t)K * N;
+            sg.n_parts[l] = slices;
+            max_n = sg.n[l] > max_n ? sg.n[l] : max_n;
+        }
+        const int rg = dctr_gemm::sgemm_grouped(st, gd, L);
+        DCTR_REQUIRE(rg == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm_grouped(dW) failed (%d)", rg);
+        int64_t gx = dctr_ceil_div(max_n, (int64_t)256);
+        hipLaunchKernelGGL(sum_parts_multi_kernel, dim3((unsigned)(gx > 512 ? 512 : gx), (unsigned)L), dim3(256), 0, st, sg);
+        return dctr_launch_status("dctr_mlp_bwd");
+    }
     int w = a->in_dim;
     for (int l = 0; l < a->n_layers; ++l) w = a->units[l] > w ? a->units[l] : w;
     float* bufA = static_cast<float*>(a->workspace);
