@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
@@ -82,7 +82,7 @@ class MlpArgs(ctypes.Structure):
 
 
 class FieldGrad(ctypes.Structure):
-    _fields_ = [("g_table", c_vp), ("g_lin_table", c_vp)]
+    _fields_ = [("g_table", c_vp), ("g_lin_table", c_vp), ("touched", c_vp)]
 
 
 class GatherFmBwdArgs(ctypes.Structure):
@@ -92,7 +92,7 @@ class GatherFmBwdArgs(ctypes.Structure):
 
 class PoolBwdArgs(ctypes.Structure):
     _fields_ = [("fwd", ctypes.POINTER(PoolArgs)), ("d_out", c_vp), ("d_stride", c_i64), ("d_lin_out", c_vp),
-                ("g_table", c_vp), ("g_lin_table", c_vp)]
+                ("g_table", c_vp), ("g_lin_table", c_vp), ("touched", c_vp)]
 
 
 class DnnTrainLayer(ctypes.Structure):
@@ -147,7 +147,7 @@ HOST_KINDS = {"int32": 0, "int64": 1, "float32": 2, "float64": 3}
 
 
 class AdamSeg(ctypes.Structure):
-    _fields_ = [("w", c_vp), ("m", c_vp), ("v", c_vp), ("g", c_vp), ("n", c_i64), ("l2", c_f32), ("pad_", c_i32)]
+    _fields_ = [("w", c_vp), ("m", c_vp), ("v", c_vp), ("g", c_vp), ("n", c_i64), ("l2", c_f32), ("pad_", c_i32), ("touched", c_vp)]
 
 
 class DinAttnArgs(ctypes.Structure):
@@ -205,7 +205,7 @@ SYMBOLS = {
     "dctr_din_wsum_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_din_wsum_bwd": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dctr_din_att_in_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    "dctr_embed_lookup_bwd": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dctr_embed_lookup_bwd": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dctr_bi_interaction_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_inner_product_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "dctr_dense1_bwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),

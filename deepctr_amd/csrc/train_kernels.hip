@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) g[c] = fmaf(dfm, S[c] - v[c], g[c]);
             }
+            if (gr[j].touched != nullptr) gr[j].touched[(r * f.dim) / VEC + q] = 1;      // (dim % 4 == 0: all_dim4 of the launch)
             if (so >= 0) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) atomicAdd(&s_small[so + (int)r * f.dim + q * VEC + c], g[c]);
@@ -512,41 +513,108 @@ __device__ __forceinline__ void opt_update(float& w, float& m, float& v, float g
     }
 }
 
-// all parameters of a model in ONE launch: blockIdx.y = segment, blockIdx.x walks the segment (blocks past its end exit)
-template <int KIND>
+// all parameters of a model in ONE launch: blockIdx.y = segment, blockIdx.x walks the segment (blocks past its end exit).
+// sg.touched (embedding tables): one byte per 16-B group of the gradient table, set by the backward kernels where they added
+// something — groups with a clear byte have a ZERO gradient, which is then neither read nor cleared (a 4096-row batch touches
+// < 4 % of a 1e5-row table: 24 instead of 32 bytes of traffic per element; the update itself stays non-lazy, every element moves).
+// Two 16-B groups per thread and trip, all their loads issued before the first use.
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4* p) {
+    if constexpr (NT) {
+        const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float4* p, const float4& v) {
+    if constexpr (NT) __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
+    else *p = v;
+}
+
+template <int KIND, int U = 2, bool NT = false>
 __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* __restrict__ segs, float lr, float b1, float b2,
                                                         float eps, int zero_grad) {
     const dctr_adam_seg_t sg = segs[blockIdx.y];
-    float* __restrict__ w = sg.w;
-    float* __restrict__ m = sg.m;
-    float* __restrict__ v = sg.v;
-    float* __restrict__ g = sg.g;
+    float4* __restrict__ w = reinterpret_cast<float4*>(sg.w);
+    float4* __restrict__ m = reinterpret_cast<float4*>(sg.m);
+    float4* __restrict__ v = reinterpret_cast<float4*>(sg.v);
+    float4* __restrict__ g = reinterpret_cast<float4*>(sg.g);
+    uint8_t* __restrict__ tch = sg.touched;
     const float l2 = sg.l2;
     const int64_t n = sg.n, n4 = n / 4;
     const int64_t stride = (int64_t)gridDim.x * 256;
     constexpr bool USE_M = KIND == DCTR_OPT_ADAM, USE_V = KIND != DCTR_OPT_SGD;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 wv = reinterpret_cast<float4*>(w)[i];
-        float4 mv = USE_M ? reinterpret_cast<float4*>(m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 vv = USE_V ? reinterpret_cast<float4*>(v)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 gv = reinterpret_cast<float4*>(g)[i];
-        float* wp = &wv.x; float* mp = &mv.x; float* vp = &vv.x; const float* gp = &gv.x;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
+        bool in[U], has[U];
+        float4 wv[U], mv[U], vv[U], gv[U];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) opt_update<KIND>(wp[c], mp[c], vp[c], fmaf(2.f * l2, wp[c], gp[c]), lr, b1, b2, eps);
-        reinterpret_cast<float4*>(w)[i] = wv;
-        if (USE_M) reinterpret_cast<float4*>(m)[i] = mv;
-        if (USE_V) reinterpret_cast<float4*>(v)[i] = vv;
-        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            in[u] = i < n4;
+            has[u] = in[u] && (tch == nullptr || tch[i] != 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = in[u] ? i0 + u * stride : i0;
+            wv[u] = ld4<NT>(w + i);
+            mv[u] = USE_M ? ld4<NT>(m + i) : z4;
+            vv[u] = USE_V ? ld4<NT>(v + i) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) gv[u] = has[u] ? g[i0 + u * stride] : z4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!in[u]) continue;
+            const int64_t i = i0 + u * stride;
+            float* wp = &wv[u].x; float* mp = &mv[u].x; float* vp = &vv[u].x; const float* gp = &gv[u].x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) opt_update<KIND>(wp[c], mp[c], vp[c], fmaf(2.f * l2, wp[c], gp[c]), lr, b1, b2, eps);
+            st4<NT>(w + i, wv[u]);
+            if (USE_M) st4<NT>(m + i, mv[u]);
+            if (USE_V) st4<NT>(v + i, vv[u]);
+            if (zero_grad && has[u]) {
+                g[i] = z4;
+                if (tch != nullptr) tch[i] = 0;
+            }
+        }
     }
     if (blockIdx.x == 0) {
         for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
-            float mm = USE_M ? m[i] : 0.f, vv = USE_V ? v[i] : 0.f;
-            opt_update<KIND>(w[i], mm, vv, fmaf(2.f * l2, w[i], g[i]), lr, b1, b2, eps);
-            if (USE_M) m[i] = mm;
-            if (USE_V) v[i] = vv;
-            if (zero_grad) g[i] = 0.f;
+            float mm = USE_M ? sg.m[i] : 0.f, vv = USE_V ? sg.v[i] : 0.f;
+            opt_update<KIND>(sg.w[i], mm, vv, fmaf(2.f * l2, sg.w[i], sg.g[i]), lr, b1, b2, eps);
+            if (USE_M) sg.m[i] = mm;
+            if (USE_V) sg.v[i] = vv;
+            if (zero_grad) sg.g[i] = 0.f;
         }
     }
+}
+
+// touched bytes of the rows a scatter kernel adds to (dctr_embed_lookup_bwd / dctr_embed_pool_bwd): every valid row an id
+// resolves to — a superset of the rows that receive a non-zero gradient, which only costs the optimizer a read
+__global__ __launch_bounds__(256) void mark_rows_kernel(const void* __restrict__ ids, int64_t n_rows, int n_cols, int64_t row_stride,
+                                                        int is_i64, int hash_mode, int64_t vocab, int dim4, uint8_t* __restrict__ touched) {
+    const int64_t total = n_rows * n_cols * dim4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t e = t / dim4;
+        const int q = (int)(t - e * dim4);
+        const int64_t rr = e / n_cols;
+        const int cc = (int)(e - rr * n_cols);
+        const int64_t r = resolve_row(read_id(ids, rr * row_stride + cc, is_i64), hash_mode, is_i64, vocab);
+        if ((uint64_t)r < (uint64_t)vocab) touched[r * dim4 + q] = 1;
+    }
+}
+static void launch_mark_rows(hipStream_t st, const void* ids, int64_t n_rows, int n_cols, int64_t row_stride, int is_i64, int hash_mode,
+                             int64_t vocab, int dim, uint8_t* touched) {
+    const int dim4 = dim / 4;
+    int64_t blocks = dctr_ceil_div(n_rows * n_cols * dim4, (int64_t)256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, n_rows, n_cols, row_stride, is_i64, hash_mode, vocab,
+                       dim4, touched);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1756,11 +1824,16 @@ extern "C" int dctr_din_att_in_bwd(const float* da, const float* q, const float*
     return dctr_launch_status("dctr_din_att_in_bwd");
 }
 
-extern "C" int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, void* stream) {
+extern "C" int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, uint8_t* touched,
+                                     void* stream) {
     DCTR_REQUIRE(fwd != nullptr, DCTR_E_NULL, "embed_lookup_bwd: null args");
     DCTR_REQUIRE(fwd->n >= 0 && fwd->dim >= 1 && d_stride >= fwd->dim && fwd->vocab >= 1, DCTR_E_DIM, "embed_lookup_bwd: bad sizes");
     if (fwd->n == 0) return DCTR_OK;
     DCTR_REQUIRE(fwd->idx && d_out && g_table, DCTR_E_NULL, "embed_lookup_bwd: null pointer");
+    if (touched != nullptr) {
+        DCTR_REQUIRE(fwd->dim % 4 == 0, DCTR_E_DIM, "embed_lookup_bwd: touched bytes need dim %% 4 == 0 (dim %d)", fwd->dim);
+        launch_mark_rows((hipStream_t)stream, fwd->idx, fwd->n, 1, 1, fwd->idx_is_i64, fwd->hash_mode, fwd->vocab, fwd->dim, touched);
+    }
     // (dim >= 3: a walker's stretch of LB_TILE / (4 * 64 / dimP) sorted entries must cover its 8-entry load batches)
     if (fwd->dim >= 3 && fwd->dim <= 64 && fwd->vocab < 0xffffffffLL && fwd->n >= LB_TILE) {
         int dimP = 1;
@@ -1903,6 +1976,8 @@ extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) 
     const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(256 / lpr));
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool_bwd: batch too large");
     hipStream_t st = (hipStream_t)stream;
+    if (a->touched != nullptr && a->g_table != nullptr)
+        launch_mark_rows(st, f->idx, f->batch, f->maxlen, f->idx_stride, f->idx_is_i64, f->hash_mode, f->vocab, f->dim, a->touched);
 #define CALL_PB(L) \
     hipLaunchKernelGGL((pool_bwd_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, *f, a->d_out, a->d_stride, a->d_lin_out, \
                        a->g_table, a->g_lin_table)
@@ -2264,16 +2339,31 @@ extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t
     DCTR_REQUIRE(n_segs >= 0 && n_segs <= 65535 && max_n >= 0, DCTR_E_DIM, "opt_multi: bad n_segs / max_n");
     if (n_segs == 0 || max_n == 0) return DCTR_OK;
     DCTR_REQUIRE(segs != nullptr, DCTR_E_NULL, "opt_multi: null segment array");
-    int64_t bx = dctr_ceil_div(max_n / 4 + 1, (int64_t)(256 * 4));      // four float4 per thread in the largest segment
+    // Two 16-B groups per trip, non-temporal loads / stores, four groups per thread in the largest segment: 175 us for the C2 DeepFM
+    // parameter set with touched bytes (6.15 TB/s) against 215 us with default-policy accesses and 205 us with four groups per trip
+    // (profiles/r03c_opt_lab.log).  DCTR_OPT_VARIANT / DCTR_OPT_F4 re-run that lab (scripts/opt_lab.py).
+    const char* ef = getenv("DCTR_OPT_F4");
+    const char* ev = getenv("DCTR_OPT_VARIANT");
+    const int f4 = ef != nullptr && atoi(ef) >= 1 ? atoi(ef) : 4;
+    const int variant = ev != nullptr ? atoi(ev) : 2;
+    int64_t bx = dctr_ceil_div(max_n / 4 + 1, (int64_t)(256 * f4));
     if (bx > 4096) bx = 4096;
     const dim3 grid((unsigned)bx, (unsigned)n_segs);
     hipStream_t st = (hipStream_t)stream;
+#define DCTR_OPT_LAUNCH(K)                                                                                                                     \
+    do {                                                                                                                                       \
+        if (variant == 0) hipLaunchKernelGGL((opt_multi_kernel<K, 2, false>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad);      \
+        else if (variant == 1) hipLaunchKernelGGL((opt_multi_kernel<K, 4, false>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); \
+        else if (variant == 3) hipLaunchKernelGGL((opt_multi_kernel<K, 4, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad);  \
+        else hipLaunchKernelGGL((opt_multi_kernel<K, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad);                    \
+    } while (0)
     switch (kind) {
-        case DCTR_OPT_ADAM: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_ADAM>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
-        case DCTR_OPT_ADAGRAD: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_ADAGRAD>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
-        case DCTR_OPT_RMSPROP: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_RMSPROP>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
-        default: hipLaunchKernelGGL(opt_multi_kernel<DCTR_OPT_SGD>, grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        case DCTR_OPT_ADAM: DCTR_OPT_LAUNCH(DCTR_OPT_ADAM); break;
+        case DCTR_OPT_ADAGRAD: hipLaunchKernelGGL((opt_multi_kernel<DCTR_OPT_ADAGRAD, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        case DCTR_OPT_RMSPROP: hipLaunchKernelGGL((opt_multi_kernel<DCTR_OPT_RMSPROP, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        default: hipLaunchKernelGGL((opt_multi_kernel<DCTR_OPT_SGD, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
     }
+#undef DCTR_OPT_LAUNCH
     return dctr_launch_status("dctr_opt_multi");
 }
 

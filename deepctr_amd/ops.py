@@ -236,13 +236,14 @@ def embed_pool(idx, table, combiner="mean", length=None, weight=None, weight_nor
     return out, lin_out
 
 
-def embed_pool_bwd(fwd_args, d_out=None, d_lin_out=None, g_table=None, g_lin_table=None):
+def embed_pool_bwd(fwd_args, d_out=None, d_lin_out=None, g_table=None, g_lin_table=None, touched=None):
     """Backward of dctr_embed_pool: scatter-adds into the dense gradient tables (see include/dctr.h)."""
     a = _C.PoolBwdArgs(fwd=ctypes.pointer(fwd_args), d_out=None if d_out is None else d_out.data_ptr(),
                        d_stride=0 if d_out is None else d_out.stride(0),
                        d_lin_out=None if d_lin_out is None else d_lin_out.data_ptr(),
                        g_table=None if g_table is None else g_table.data_ptr(),
-                       g_lin_table=None if g_lin_table is None else g_lin_table.data_ptr())
+                       g_lin_table=None if g_lin_table is None else g_lin_table.data_ptr(),
+                       touched=None if (touched is None or g_table is None) else touched.data_ptr())
     _C.check(_C.lib().dctr_embed_pool_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_pool_bwd")
 
 
@@ -669,11 +670,14 @@ def bce_grad(pred, y, dlogit, loss_sum=None, dlogit_sum=None, task="binary"):
 
 
 def make_field_grads(entries, device):
-    """DEVICE array of dctr_field_grad_t from [(g_table or None, g_lin_table or None), ...]."""
+    """DEVICE array of dctr_field_grad_t from [(g_table or None, g_lin_table or None[, touched bytes or None]), ...]."""
     arr = (_C.FieldGrad * max(1, len(entries)))()
-    for i, (gt, gl) in enumerate(entries):
+    for i, e in enumerate(entries):
+        gt, gl = e[0], e[1]
+        tch = e[2] if len(e) > 2 else None
         arr[i].g_table = None if gt is None else gt.data_ptr()
         arr[i].g_lin_table = None if gl is None else gl.data_ptr()
+        arr[i].touched = None if (tch is None or gt is None) else tch.data_ptr()
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return host.to(device)
 
@@ -847,14 +851,15 @@ def din_att_in_bwd(da, q, k, dk, dx, qcol):
                                           _C.stream_ptr()), "dctr_din_att_in_bwd")
 
 
-def embed_lookup_bwd(idx, table_shape, hash_mode, d_out, g_table):
-    """g_table[row(idx[i])] += d_out[i]: idx any shape with n ids, d_out a view whose second-to-last stride is the row stride."""
+def embed_lookup_bwd(idx, table_shape, hash_mode, d_out, g_table, touched=None):
+    """g_table[row(idx[i])] += d_out[i]: idx any shape with n ids, d_out a view whose second-to-last stride is the row stride;
+    touched: the table's touched bytes (include/dctr.h, dctr_field_grad_t) or None."""
     _dev_check(idx, d_out, g_table)
     ic, is64 = _ids(idx, "idx")
     vocab, dim = table_shape
     a = _C.LookupArgs(idx=ic.data_ptr(), table=None, vocab=int(vocab), n=ic.numel(), idx_is_i64=is64, dim=int(dim),
                       hash_mode=int(hash_mode), out=None, out_stride=0, mask=None, status=None)
-    _C.check(_C.lib().dctr_embed_lookup_bwd(ctypes.byref(a), _ptr(d_out), d_out.stride(-2), _ptr(g_table), _C.stream_ptr()),
+    _C.check(_C.lib().dctr_embed_lookup_bwd(ctypes.byref(a), _ptr(d_out), d_out.stride(-2), _ptr(g_table), _ptr(touched), _C.stream_ptr()),
              "dctr_embed_lookup_bwd")
 
 
@@ -866,12 +871,18 @@ def adam_step(w, m, v, g, alpha, beta1=0.9, beta2=0.999, eps=1e-7, l2=0.0, zero_
 
 
 def make_adam_segments(params, device):
-    """DEVICE array of dctr_adam_seg_t from [(w, m, v, g, l2), ...]; returns (tensor, n_segs, max_n)."""
+    """DEVICE array of dctr_adam_seg_t from [(w, m, v, g, l2[, touched bytes or None]), ...]; returns (tensor, n_segs, max_n)."""
     arr = (_C.AdamSeg * max(1, len(params)))()
     mx = 0
-    for i, (w, m, v, g, l2) in enumerate(params):
+    for i, e in enumerate(params):
+        w, m, v, g, l2 = e[:5]
+        tch = e[5] if len(e) > 5 else None
         arr[i].w, arr[i].m, arr[i].v, arr[i].g = w.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr()
         arr[i].n, arr[i].l2 = w.numel(), float(l2)
+        if tch is not None:
+            if tch.dtype != torch.uint8 or tch.numel() != w.numel() // 4 or w.numel() % 4:
+                raise ValueError("touched: uint8 [n / 4] beside a parameter of n %% 4 == 0 elements")
+            arr[i].touched = tch.data_ptr()
         mx = max(mx, w.numel())
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(params), mx
 

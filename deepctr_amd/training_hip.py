@@ -67,7 +67,7 @@ def supported(model):
 
 
 class _Param(object):
-    __slots__ = ("w", "m", "v", "g", "l2")
+    __slots__ = ("w", "m", "v", "g", "l2", "touched")
 
     def __init__(self, w, l2=0.0):
         self.w = w
@@ -75,14 +75,25 @@ class _Param(object):
         self.v = torch.zeros_like(w)
         self.g = torch.zeros_like(w)
         self.l2 = float(l2)
+        self.touched = None     # embedding tables: one byte per 16-B group of g (include/dctr.h, dctr_field_grad_t)
+
+    def track_rows(self):
+        """Embedding table [vocab, dim % 4 == 0]: the scatter kernels mark the 16-B groups of ``g`` they add to, and the optimizer
+        step reads / clears only those (a 4096-row batch touches a few percent of a 1e5-row table)."""
+        if self.touched is None and self.w.dim() == 2 and self.w.shape[1] % 4 == 0 and self.w.is_contiguous():
+            self.touched = torch.zeros(self.w.numel() // 4, dtype=torch.uint8, device=self.w.device)
+        return self
 
 
 class _Frozen(object):
     """A weight that takes no part in training (Embedding.trainable == False): ``g`` is None = a NULL gradient table."""
-    __slots__ = ("w", "g", "l2")
+    __slots__ = ("w", "g", "l2", "touched")
 
     def __init__(self, w):
-        self.w, self.g, self.l2 = w, None, 0.0
+        self.w, self.g, self.l2, self.touched = w, None, 0.0, None
+
+    def track_rows(self):
+        return self
 
 
 # tf.keras defaults of the optimizers model.compile() takes by name (optimizer_v2/*.py)
@@ -135,7 +146,7 @@ class HipTrainer(object):
         # (_buffers) and dctr_embed_pool_bwd scatters them on to the tables.
         self.field_params = []
         for f in sp.fields:
-            pt = param(f.table, l2e)
+            pt = param(f.table, l2e).track_rows()
             pl = param(f.lin_table, l2l) if f.lin_table is not None else None
             self.field_params.append((f, pt, pl))
         # Linear.kernel (dense features of the linear part): the forward reads a copy permuted into dense-matrix column
@@ -162,7 +173,7 @@ class HipTrainer(object):
                               alphas=[param(d[0]) for d in dice] if dice else None, out_w=param(la.w("kernel")),
                               out_b=param(la.w("bias")))
             # history tables receive the key gradients through dctr_embed_lookup_bwd
-            self.p_hist = [param(model.tables[fc.embedding_name].embeddings, l2e) for fc in model.history_cols]
+            self.p_hist = [param(model.tables[fc.embedding_name].embeddings, l2e).track_rows() for fc in model.history_cols]
             # columns of the query embeddings inside the DNN input (dq is added there; the gather backward scatters it)
             qcol = []
             for fc in model.query_cols:
@@ -210,7 +221,7 @@ class HipTrainer(object):
         if self.init_acc:
             for p in self.params:
                 p.v.fill_(self.init_acc)            # Adagrad's initial_accumulator_value
-        self.segs, self.n_segs, self.max_n = ops.make_adam_segments([(p.w, p.m, p.v, p.g, p.l2) for p in self.params],
+        self.segs, self.n_segs, self.max_n = ops.make_adam_segments([(p.w, p.m, p.v, p.g, p.l2, p.touched) for p in self.params],
                                                                     model.device)
 
     def _buffers(self, B):
@@ -250,7 +261,7 @@ class HipTrainer(object):
                         b["pooled_lin_g"][f.fc.name] = torch.zeros(B, dtype=torch.float32, device=dev)
                     entries.append((b["pooled_g"][f.fc.name], b["pooled_lin_g"].get(f.fc.name)))
                 else:
-                    entries.append((pt.g, None if pl is None else pl.g))
+                    entries.append((pt.g, None if pl is None else pl.g, pt.touched))
             b["field_grads"] = ops.make_field_grads(entries, dev)
         return b
 
@@ -456,7 +467,7 @@ class HipTrainer(object):
         ops.din_att_in_bwd(buf["d_att_in"], q, k, buf["dk"], dx, self.qcol)
         for (fc, idx, hm, col), pt in zip(bufs["key_lookups"], self.p_hist):
             if pt.g is not None:                                   # frozen history table: no scatter
-                ops.embed_lookup_bwd(idx, tuple(pt.w.shape), hm, buf["dk"][:, :, col:], pt.g)
+                ops.embed_lookup_bwd(idx, tuple(pt.w.shape), hm, buf["dk"][:, :, col:], pt.g, touched=pt.touched)
 
     def _nfm_forward_backward(self, ws, buf, y, binary):
         """NFM (models/nfm.py:49-58): DNN over [BiInteractionPooling(embeddings) (+ Dropout(bi_dropout)) | dense] -> Dense(1) + linear logit."""
@@ -588,7 +599,7 @@ class HipTrainer(object):
         assert len(pool_calls) == len(pooled)
         for (args, _keep), (f, pt, pl) in zip(pool_calls, pooled):
             ops.embed_pool_bwd(args, d_out=buf["pooled_g"][f.fc.name], d_lin_out=buf["pooled_lin_g"].get(f.fc.name),
-                               g_table=pt.g, g_lin_table=None if pl is None else pl.g)
+                               g_table=pt.g, g_lin_table=None if pl is None else pl.g, touched=pt.touched)
         if not apply:
             return buf["loss"] / B
         # optimizer: one launch over every parameter

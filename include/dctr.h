@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 5
+#define DCTR_ABI_VERSION 6
 
 enum {
     DCTR_OK = 0,
@@ -450,9 +450,13 @@ int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* args, void* stream);
 int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
                   float* dlogit_sum, void* stream);
 
+/* `touched` (ABI 6; optional, tables with dim % 4 == 0): one byte per 16-B group of g_table ([vocab * dim / 4] bytes, zero-initialised
+ * by the caller).  The scatter kernels set the bytes of the groups they add to; dctr_opt_multi then treats groups with a clear byte as a
+ * ZERO gradient it neither reads nor clears (see dctr_adam_seg_t).  Invariant the caller keeps: g_table is zero wherever its byte is. */
 typedef struct {
     float* g_table;       /* [vocab, dim] gradient of the field's table, or NULL (frozen / absent)  */
     float* g_lin_table;   /* [vocab] gradient of its 1-wide linear table, or NULL                   */
+    uint8_t* touched;     /* [vocab * dim / 4] bytes beside g_table, or NULL                        */
 } dctr_field_grad_t;
 
 /* backward of dctr_embed_gather_fm (inputs.py:101-117, layers/utils.py:336-346, feature_column.py:171-210,
@@ -481,6 +485,7 @@ typedef struct {
     const float* d_lin_out;        /* [B] gradient w.r.t. lin_out, or NULL                              */
     float* g_table;                /* [vocab, dim] accumulated, or NULL                                 */
     float* g_lin_table;            /* [vocab] accumulated, or NULL                                      */
+    uint8_t* touched;              /* touched bytes of g_table (dctr_field_grad_t), or NULL (ABI 6)     */
 } dctr_pool_bwd_args_t;
 int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* args, void* stream);
 
@@ -581,7 +586,8 @@ int dctr_dnn_train_layer_bwd(const dctr_dnn_train_layer_t* a, void* stream);
  *   dctr_din_wsum_bwd:   d_score [B*T], dk [B,T,dim] WRITTEN (= masked score * d_out), d_bias += sum d_score (or NULL)
  *   dctr_din_att_in_bwd: da [B*T, 4*dim] -> dk ADDED to, dq added into dx[b, qcol[e]] (qcol: DEVICE int32 [dim], the columns of
  *                        the query embeddings inside the DNN input)
- *   dctr_embed_lookup_bwd: g_table[row(idx[i]), :] += d_out[i, :dim] with the forward's id resolution (hash, range check) */
+ *   dctr_embed_lookup_bwd: g_table[row(idx[i]), :] += d_out[i, :dim] with the forward's id resolution (hash, range check);
+ *                        touched: the touched bytes of g_table (dctr_field_grad_t), or NULL (ABI 6) */
 int dctr_din_att_in_fwd(const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* a, void* stream);
 int dctr_din_wsum_fwd(const float* score, const uint8_t* mask, const float* k, int64_t batch, int32_t maxlen, int32_t dim,
                       float* out, int64_t out_stride, void* stream);
@@ -595,7 +601,8 @@ int dctr_din_softmax_bwd(const float* p, const uint8_t* mask, const float* dp, i
                          void* stream);
 int dctr_din_att_in_bwd(const float* da, const float* q, const float* k, int64_t batch, int32_t maxlen, int32_t dim, float* dk,
                         float* dx, int64_t dx_stride, const int32_t* qcol, void* stream);
-int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, void* stream);
+int dctr_embed_lookup_bwd(const dctr_lookup_args_t* fwd, const float* d_out, int64_t d_stride, float* g_table, uint8_t* touched,
+                          void* stream);
 
 /* backward of Dense(1, use_bias=False) on a strided [B, n] input: dx[b,:] = dlogit[b] * w (written), d_w += x^T dlogit. */
 int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, int32_t n, const float* w, const float* dlogit, float* dx,
@@ -715,7 +722,9 @@ int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n, float alph
                    float l2, int32_t zero_grad, void* stream);
 
 /* the same for every parameter of a model in ONE launch: a DEVICE array of segments (16-B aligned buffers);
- * max_n = the largest segment's n (sizes the grid). */
+ * max_n = the largest segment's n (sizes the grid).  touched (ABI 6): NULL, or [n / 4] bytes — byte i clear means g[4i .. 4i+3] is
+ * zero: the step does not read it (nor clear it); set bytes are cleared together with their gradient (zero_grad).  The update is the
+ * same non-lazy one either way — every element of w / m / v moves. */
 typedef struct {
     float* w;
     float* m;
@@ -724,6 +733,7 @@ typedef struct {
     int64_t n;
     float l2;
     int32_t pad_;
+    uint8_t* touched;
 } dctr_adam_seg_t;
 int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float alpha, float beta1, float beta2,
                     float eps, int32_t zero_grad, void* stream);

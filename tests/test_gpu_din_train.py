@@ -78,9 +78,17 @@ def test_embed_lookup_bwd_scatters_like_index_add(device, hash_mode, i64, shape)
     ops.embed_lookup_multi([dict(idx=idx, table=torch.arange(V, device=device, dtype=torch.float32)[:, None].repeat(1, E).contiguous(),
                                  hash_mode=hash_mode, out=rows)])                       # rows[..., 0] = the resolved row id
     g = torch.zeros(V, E, device=device)
-    ops.embed_lookup_bwd(idx, (V, E), hash_mode, d[:, :, 2:], g)
+    touched = torch.zeros(V * E // 4, dtype=torch.uint8, device=device)
+    ops.embed_lookup_bwd(idx, (V, E), hash_mode, d[:, :, 2:], g, touched=touched)
     ref = torch.zeros(V, E, device=device).index_add_(0, rows[..., 0].reshape(-1).long(), d[:, :, 2:2 + E].reshape(-1, E))
     assert_close(g.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5 + 1.2e-7 * (B * T / 2), what="lookup_bwd")
+    # the touched bytes (one per 16-B group) cover every group that received something, and only rows an id resolved to
+    t = touched.cpu().numpy().reshape(V, E // 4).astype(bool)
+    nz = (g.cpu().numpy().reshape(V, E // 4, 4) != 0).any(-1)
+    assert not (nz & ~t).any()
+    hit = np.zeros(V, bool)
+    hit[rows[..., 0].reshape(-1).long().cpu().numpy()] = True
+    assert (t.any(1) == hit).all() and (t.all(1) == hit).all()
     # (row 0 sums ~B*T/2 standard-normal terms in a different order than index_add_: n terms of size 1 -> ~n * 2^-24 of drift)
     del table
 

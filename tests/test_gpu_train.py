@@ -272,6 +272,89 @@ def test_adam_multi_matches_adam_step(device):
             np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
 
 
+@pytest.mark.parametrize("kind", ["adam", "adagrad", "rmsprop", "sgd"])
+def test_opt_multi_with_touched_bytes_is_the_dense_step(device, kind):
+    """dctr_adam_seg_t.touched: 16-B groups with a clear byte are a zero gradient that is neither read nor cleared — the step
+    is bit-identical to the dense one, set bytes are cleared with their gradient, clear groups of g are left alone."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(21)
+    sizes = [(1000, 16), (257, 4), (3, 64)]
+    dense, sparse, flags = [], [], []
+    for vocab, dim in sizes:
+        n = vocab * dim
+        w = dev(rng.standard_normal(n).astype(np.float32), device)
+        m = dev(rng.standard_normal(n).astype(np.float32) * 0.01, device)
+        v = dev((rng.rand(n) * 0.01 + (0.1 if kind == "adagrad" else 0.0)).astype(np.float32), device)
+        g0 = np.zeros((vocab, dim), np.float32)
+        rows = rng.choice(vocab, max(1, vocab // 20), replace=False)
+        g0[rows] = rng.standard_normal((len(rows), dim)).astype(np.float32) * 0.1
+        t0 = np.zeros((vocab, dim // 4), np.uint8)
+        t0[rows] = 1
+        t0[rows[0], 0] = 0                        # a group whose byte is clear must hold zeros (the caller's invariant)
+        g0[rows[0], :4] = 0.0
+        extra = (rows[0] + 1) % vocab             # a set byte over a zero gradient only costs a read
+        t0[extra, -1] = 1
+        g = dev(g0.reshape(-1), device)
+        dense.append((w.clone(), m.clone(), v.clone(), g.clone(), 1e-3))
+        tch = torch.from_numpy(t0.reshape(-1)).to(device)
+        sparse.append((w, m, v, g, 1e-3, tch))
+        flags.append(tch)
+    sd, nd, md = ops.make_adam_segments(dense, device)
+    ss, ns, ms = ops.make_adam_segments(sparse, device)
+    for _ in range(2):                            # second step: every byte clear, g all zero
+        ops.opt_multi(kind, sd, nd, md, 1e-2, 0.9, 0.999, 1e-7)
+        ops.opt_multi(kind, ss, ns, ms, 1e-2, 0.9, 0.999, 1e-7)
+        for a, b in zip(dense, sparse):
+            for x, y in zip(a[:4], b[:4]):
+                np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+        for tch in flags:
+            assert int(tch.sum()) == 0
+    with pytest.raises(ValueError):
+        ops.make_adam_segments([(dense[0][0], dense[0][1], dense[0][2], dense[0][3], 0.0, flags[1])], device)
+
+
+def test_hip_step_with_touched_bytes_equals_the_dense_step(device):
+    """HipTrainer marks the 16-B groups of the embedding gradient tables its scatter kernels add to (gather backward, pooled
+    sequence features) and the optimizer reads only those: five steps give the same weights, bit for bit in the embedding
+    tables' untouched rows and to summation order (atomics) elsewhere, as a trainer whose tables carry no bytes."""
+    from deepctr_amd import models
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.training_hip import HipTrainer
+    rng = np.random.RandomState(5)
+    cols = [SparseFeat("a", 500, 8), SparseFeat("b", 3, 8), SparseFeat("c", 2000, 8, use_hash=True), DenseFeat("d", 2),
+            VarLenSparseFeat(SparseFeat("s", 300, 8), maxlen=6, combiner="mean")]
+    n = 256
+    seq = rng.randint(1, 300, (n, 6)).astype(np.int32)
+    seq[rng.rand(n, 6) < 0.4] = 0
+    feed = {"a": rng.randint(0, 500, n).astype(np.int32), "b": rng.randint(0, 3, n).astype(np.int32),
+            "c": rng.randint(0, 2 ** 31 - 1, n).astype(np.int32), "d": rng.rand(n, 2).astype(np.float32), "s": seq}
+    y = torch.from_numpy((rng.rand(n) > 0.5).astype(np.float32)).to(device)
+    results = []
+    for track in (True, False):
+        torch.manual_seed(0)
+        model = models.DeepFM(cols, cols, dnn_hidden_units=(32, 16), device=device, seed=3)
+        tr = HipTrainer(model)
+        if not track:
+            for p in tr.params:
+                p.touched = None
+            from deepctr_amd import ops
+            tr.segs, tr.n_segs, tr.max_n = ops.make_adam_segments([(p.w, p.m, p.v, p.g, p.l2) for p in tr.params], device)
+            tr._buf.clear()
+        else:
+            assert sum(p.touched is not None for p in tr.params) == 4
+        staged = model.stage(feed)
+        for i in range(5):
+            lo = (i % 2) * 128
+            tr.step(staged, lo, lo + 128, y[lo:lo + 128])
+        model._check_status()
+        if track:
+            assert all(int(p.touched.sum()) == 0 for p in tr.params if p.touched is not None)
+            assert all(float(p.g.abs().max()) == 0.0 for p in tr.params)
+        results.append([p.w.detach().cpu().numpy().copy() for p in tr.params])
+    for a, b in zip(*results):
+        assert_close(a, b, rtol=2e-5, atol=2e-6, what="weights after 5 steps, touched bytes vs dense")
+
+
 @pytest.mark.parametrize("kind", ["adagrad", "rmsprop", "sgd"])
 def test_opt_multi_matches_torch_optimizers(device, kind):
     from deepctr_amd import ops
