@@ -2208,10 +2208,26 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
             sg.n_parts[l] = slices;
             max_n = sg.n[l] > max_n ? sg.n[l] : max_n;
         }
-        const int rg = dctr_gemm::sgemm_grouped(st, gd, L);
+        // the weight-gradient half: on the caller's second stream when it gave one (behind an event on `stream`; the caller joins)
+        hipStream_t dws = st;
+        if (a->dw_stream != nullptr && (hipStream_t)a->dw_stream != st) {
+            static thread_local hipEvent_t ev[16] = {};
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
+            DCTR_REQUIRE(e == hipSuccess && dev >= 0 && dev < 16, DCTR_E_UNSUPPORTED, "mlp_bwd: dw_stream on device %d", dev);
+            if (ev[dev] == nullptr) {
+                e = hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming);
+                DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_bwd: hipEventCreate failed: %s", hipGetErrorString(e));
+            }
+            dws = (hipStream_t)a->dw_stream;
+            e = hipEventRecord(ev[dev], st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(dws, ev[dev], 0);
+            DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_bwd: cannot order dw_stream behind stream: %s", hipGetErrorString(e));
+        }
+        const int rg = dctr_gemm::sgemm_grouped(dws, gd, L);
         DCTR_REQUIRE(rg == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm_grouped(dW) failed (%d)", rg);
         int64_t gx = dctr_ceil_div(max_n, (int64_t)256);
-        hipLaunchKernelGGL(sum_parts_multi_kernel, dim3((unsigned)(gx > 512 ? 512 : gx), (unsigned)L), dim3(256), 0, st, sg);
+        hipLaunchKernelGGL(sum_parts_multi_kernel, dim3((unsigned)(gx > 512 ? 512 : gx), (unsigned)L), dim3(256), 0, dws, sg);
         return dctr_launch_status("dctr_mlp_bwd");
     }
     int w = a->in_dim;

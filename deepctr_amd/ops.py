@@ -758,12 +758,14 @@ def dnn_train_layer(z, activation, h=None, bn=None, dropout_rate=0.0, dropout_se
 
 
 def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None, biases=None,
-            dice=None, d_dice_alpha=None, dice_eps=1e-9, dice_batch=None):
+            dice=None, d_dice_alpha=None, dice_eps=1e-9, dice_batch=None, dw_stream=None, workspace=None):
     """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written.
     Headless form: head_w = dlogit = d_head_w = None and ``d_out`` [B, >= units[-1]] = gradient w.r.t. the last layer.
     activation "dice": ``biases`` and ``dice`` = [(alpha, mean, var)] per layer as in the forward; ``d_dice_alpha`` (list,
     accumulated) optional; ``dice_batch`` = [(batch_mean, batch_var)] per layer (dice_train_fwd) switches to training-mode Dice:
-    the gradient flows through the batch statistics."""
+    the gradient flows through the batch statistics.
+    ``dw_stream`` (a torch.cuda.Stream) sends the weight-gradient launches of the chained form there (include/dctr.h); it needs a
+    ``workspace`` the caller keeps alive (a dict: the tensor is cached under "ws") and a join by the caller."""
     _dev_check(x, *kernels)
     n = len(kernels)
     units = [k.shape[1] for k in kernels]
@@ -792,7 +794,16 @@ def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_b
                       d_out=None if d_out is None else d_out.data_ptr(), d_out_stride=0 if d_out is None else d_out.stride(0),
                       **extra)
     need = int(_C.lib().dctr_mlp_bwd_workspace_bytes(ctypes.byref(a)))
-    ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
+    if workspace is not None:
+        ws = workspace.get("ws")
+        if ws is None or ws.numel() * 4 < need or ws.device != x.device:
+            ws = workspace["ws"] = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
+        if dw_stream is not None:
+            a.dw_stream = dw_stream.cuda_stream
+    else:
+        if dw_stream is not None:
+            raise ValueError("mlp_bwd: dw_stream needs a caller-owned workspace")
+        ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _C.check(_C.lib().dctr_mlp_bwd(ctypes.byref(a), _C.stream_ptr()), "dctr_mlp_bwd")
 

@@ -324,10 +324,17 @@ class HipTrainer(object):
         model, dnn = self.model, self.model.dnn
         dk, db = [p.g for p in self.p_kernels], [p.g for p in self.p_biases]
         if not self.slow_dnn:
+            # the weight-gradient launches go to a second stream (dctr_mlp_bwd_args_t.dw_stream): they run beside the embedding
+            # scatter / CIN / CrossNet backward that follow on the main stream; step() joins before the optimizer
+            side = self._side_stream()
+            wsd = buf.setdefault("mlp_bwd_ws", {})
             if dlogit is not None:
-                ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], dnn.activation, self.p_head.w, dlogit, dk, db, self.p_head.g, dx=dx)
+                ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], dnn.activation, self.p_head.w, dlogit, dk, db, self.p_head.g, dx=dx,
+                            dw_stream=side, workspace=wsd)
             else:
-                ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], dnn.activation, None, None, dk, db, None, dx=dx, d_out=d_out)
+                ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], dnn.activation, None, None, dk, db, None, dx=dx, d_out=d_out,
+                            dw_stream=side, workspace=wsd)
+            self._side_used = side is not None
             return
         L = len(dnn.kernels)
         units = [k.shape[1] for k in dnn.kernels]
@@ -347,6 +354,20 @@ class HipTrainer(object):
             # dense part of the layer: d_bias += colsum(dz), dW += x^T dz, dH_{l-1} = dz W^T  (one-layer headless linear dctr_mlp_bwd)
             ops.mlp_bwd(xin, kin, [dnn.kernels[l]], [buf["acts"][l]], "linear", None, None, [dk[l]], [db[l]], None, dx=dst, d_out=dz)
             dh = dst
+
+    side_stream = True          # False: everything on the caller's stream (A/B in scripts/bench_train.py --no-side-stream)
+
+    def _side_stream(self):
+        if not self.side_stream or self.model.device.type != "cuda":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.model.device)
+        return self._side
+
+    def _join_side(self):
+        if getattr(self, "_side_used", False):
+            torch.cuda.current_stream(self.model.device).wait_stream(self._side)
+            self._side_used = False
 
     def _loss_grad(self, buf, y, binary):
         buf["loss"].zero_()
@@ -600,6 +621,7 @@ class HipTrainer(object):
         for (args, _keep), (f, pt, pl) in zip(pool_calls, pooled):
             ops.embed_pool_bwd(args, d_out=buf["pooled_g"][f.fc.name], d_lin_out=buf["pooled_lin_g"].get(f.fc.name),
                                g_table=pt.g, g_lin_table=None if pl is None else pl.g, touched=pt.touched)
+        self._join_side()
         if not apply:
             return buf["loss"] / B
         # optimizer: one launch over every parameter

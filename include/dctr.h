@@ -490,7 +490,10 @@ typedef struct {
 int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* args, void* stream);
 
 /* backward of dctr_mlp_fwd with has_head (layers/core.py:189-208 + Dense(1, use_bias=False)): needs the activations the
- * forward saved through save_acts.  The two GEMMs per layer are plain rocBLAS sgemm calls on `stream`. */
+ * forward saved through save_acts.  relu / linear / sigmoid / tanh: FIVE launches whatever the depth — head, W_l^T of every layer,
+ * the backward chain (every dZ_l and dX in one launch on the forward's whole-MLP kernel), the dW_l (+ d_bias_l) row slices of every
+ * layer as one grouped GEMM, the slice sum.  Dice: layer by layer (two GEMMs + the recomputed pre-activations per layer) on dctr_sgemm's
+ * kernel. */
 typedef struct {
     const float* x;               /* [B, x_stride] the forward's input (dnn_in)                          */
     int64_t batch;
@@ -527,6 +530,10 @@ typedef struct {
     const float* const* dice_batch_var;   /* statistics as dctr_dice_train_fwd returned them; the gradient then flows through
                                              them (BatchNormalization backward).  NULL (arrays or entries): dice_mean / dice_var
                                              are constants (inference statistics)                                            */
+    void* dw_stream;              /* ABI 6.  NULL, or a second hipStream_t: the weight-gradient half of the chained form (the grouped
+                                     dW / d_bias GEMM and its slice sum) is launched there behind an event on `stream`, so that it
+                                     runs beside what the caller launches next on `stream` (the embedding scatter, atomics-bound).
+                                     The CALLER joins the two streams before it reads d_kernels / d_biases or reuses the workspace. */
 } dctr_mlp_bwd_args_t;
 size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batches", default="4096,16384")
     ap.add_argument("--model", default="DeepFM", help="DeepFM | DeepFMdrop (dnn_dropout 0.5) | DeepFMbn (dnn_use_bn) | WDL | FNN | DCN | DCNM (matrix) | DCNMix | xDeepFM | DIN (BASELINE C4: T=50, E=32; default batch 2048)")
+    ap.add_argument("--no-side-stream", action="store_true", help="weight-gradient launches of the DNN backward on the main stream")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rng = np.random.RandomState(0)
@@ -38,6 +39,7 @@ def main():
         kw = {"DCNM": dict(cross_parameterization="matrix"), "DeepFMdrop": dict(dnn_dropout=0.5), "DeepFMbn": dict(dnn_use_bn=True)}.get(args.model, {})
         model = getattr(models, {"DCNM": "DCN", "DeepFMdrop": "DeepFM", "DeepFMbn": "DeepFM"}.get(args.model, args.model))(cols, cols, device=dev, **kw)
     tr = HipTrainer(model)
+    tr.side_stream = not args.no_side_stream
     n_param = sum(p.w.numel() for p in tr.params)
     for B in [int(b) for b in args.batches.split(",")]:
         ring = 8
