@@ -8,6 +8,7 @@
 // reference materialises [B, F(F-1)/2, E] pair tensors in HBM for AFM / InnerProduct.
 #include <math.h>
 
+#include <stdlib.h>
 #include "dctr_common.h"
 #include "mfma_tile.h"
 
@@ -116,16 +117,38 @@ __global__ __launch_bounds__(256) void cross_repack_kernel(const float* __restri
     }
 }
 
-__device__ __forceinline__ void cross_mfma_stage(const float4 (&a)[2], const float4 (&b)[2], dctr::f32x4& acc) {
+// RT row tiles of 16 samples per workgroup.  RT = 1 (x_0, x_l, x_{l+1} in LDS): every CU has a workgroup from 4096 rows on, but
+// each weight fragment feeds ONE MFMA tile.  RT = 2 (launches of >= 32 rows per CU, i.e. predict()'s 16,384-row spans): the weight
+// stream per row halves — a B fragment feeds both row tiles — and x_0 is re-read from the input (L2) in the epilogue instead of
+// holding a third LDS tile, so that the two 32-row tiles still fit the 160 KiB.
+template <int RT>
+__device__ __forceinline__ void cross_load_stage_rt(__amdgpu_buffer_rsrc_t rsrc, int voff, const float* arow, int lda, int s,
+                                                    float4 (&b)[2], float4 (&a)[RT][2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].x, b[h].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].y, b[h].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].z, b[h].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h].w, b[h].w, acc, 0, 0, 0);
+        const cross_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (2 * s + h) * 64, 0);
+        b[h] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt][h] = *reinterpret_cast<const float4*>(arow + rt * 16 * lda + (2 * s + h) * 16);
     }
 }
 
+template <int RT>
+__device__ __forceinline__ void cross_mfma_stage_rt(const float4 (&a)[RT][2], const float4 (&b)[2], dctr::f32x4 (&acc)[RT]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][h].x, b[h].x, acc[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][h].y, b[h].y, acc[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][h].z, b[h].z, acc[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][h].w, b[h].w, acc[rt], 0, 0, 0);
+    }
+}
+
+template <int RT>
 __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const float* __restrict__ x, int64_t batch, int d,
                                                                         int64_t x_stride, const float* __restrict__ w,
                                                                         int wstride, const float* __restrict__ bias,
@@ -133,18 +156,20 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
                                                                         int lda) {
     using dctr::f32x4;
     constexpr int NTHR = 64 * CROSS_WAVES;
+    constexpr int ROWS = 16 * RT;
+    constexpr bool X0_LDS = RT == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* x0 = smem;                 // [16][lda], columns >= d zero up to the next multiple of 32
-    float* xa = smem + 16 * lda;      // x_l
-    float* xb = smem + 32 * lda;      // x_{l+1}
-    const int64_t b0 = (int64_t)blockIdx.x * 16;
+    float* xa = smem;                                   // x_l       [ROWS][lda], columns >= d zero up to the next multiple of 32
+    float* xb = smem + ROWS * lda;                      // x_{l+1}
+    float* x0 = smem + 2 * ROWS * lda;                  // x_0 (RT == 1 only)
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     const int KP = (d + 31) & ~31;
-    for (int base = 0; base < 16 * KP; base += NTHR * 4) {
+    for (int base = 0; base < ROWS * KP; base += NTHR * 4) {
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = base + u * NTHR + threadIdx.x;
-            const int r = (i / KP) & 15, c = i % KP;
+            const int r = min(i / KP, ROWS - 1), c = i % KP;
             const int64_t b = min(b0 + r, batch - 1);
             v[u] = x[b * x_stride + min(c, d - 1)];
             if (b0 + r >= batch || c >= d) v[u] = 0.f;
@@ -152,9 +177,9 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = base + u * NTHR + threadIdx.x;
-            if (i < 16 * KP) {
+            if (i < ROWS * KP) {
                 const int r = i / KP, c = i % KP;
-                x0[r * lda + c] = v[u];
+                if constexpr (X0_LDS) x0[r * lda + c] = v[u];
                 xa[r * lda + c] = v[u];
                 xb[r * lda + c] = 0.f;
             }
@@ -173,33 +198,51 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
         for (int wt = wave; wt < n_tiles; wt += CROSS_WAVES) {
             const int n = wt * 16 + j;
             const int voff = (min(n, d - 1) * wstride + 4 * g) * 4;   // row n, first k of this lane's slot
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            float4 bA[2], bB[2], bC[2], aA[2], aB[2], aC[2];
+            f32x4 acc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 bA[2], bB[2], bC[2], aA[RT][2], aB[RT][2], aC[RT][2];
             const int s_last = n_stage - 1;
-            cross_load_stage(rsrc, voff, arow, 0, bA, aA);
-            cross_load_stage(rsrc, voff, arow, min(1, s_last), bB, aB);
+            // x_0 of this wave-tile (RT > 1): requested now, used after the k loop
+            float x0v[RT][4];
+            if constexpr (!X0_LDS) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t bb = min(b0 + rt * 16 + 4 * g + r, batch - 1);
+                        x0v[rt][r] = x[bb * x_stride + min(n, d - 1)];
+                    }
+            }
+            cross_load_stage_rt<RT>(rsrc, voff, arow, lda, 0, bA, aA);
+            cross_load_stage_rt<RT>(rsrc, voff, arow, lda, min(1, s_last), bB, aB);
             for (int s = 0; s < n_stage; s += 3) {
-                cross_load_stage(rsrc, voff, arow, min(s + 2, s_last), bC, aC);
+                cross_load_stage_rt<RT>(rsrc, voff, arow, lda, min(s + 2, s_last), bC, aC);
                 __builtin_amdgcn_sched_barrier(0);
-                cross_mfma_stage(aA, bA, acc);
+                cross_mfma_stage_rt<RT>(aA, bA, acc);
                 __builtin_amdgcn_sched_barrier(0);
-                cross_load_stage(rsrc, voff, arow, min(s + 3, s_last), bA, aA);
+                cross_load_stage_rt<RT>(rsrc, voff, arow, lda, min(s + 3, s_last), bA, aA);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s + 1 < n_stage) cross_mfma_stage(aB, bB, acc);
+                if (s + 1 < n_stage) cross_mfma_stage_rt<RT>(aB, bB, acc);
                 __builtin_amdgcn_sched_barrier(0);
-                cross_load_stage(rsrc, voff, arow, min(s + 4, s_last), bB, aB);
+                cross_load_stage_rt<RT>(rsrc, voff, arow, lda, min(s + 4, s_last), bB, aB);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s + 2 < n_stage) cross_mfma_stage(aC, bC, acc);
+                if (s + 2 < n_stage) cross_mfma_stage_rt<RT>(aC, bC, acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (n < d) {
                 const float bv = bias[(int64_t)l * d + n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * g + r;
-                    // interaction.py:419-420: x_l = x_0 * (W x_l + b) + x_l
-                    xb[row * lda + n] = x0[row * lda + n] * (acc[r] + bv) + xa[row * lda + n];
-                }
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + 4 * g + r;
+                        float x0e;
+                        if constexpr (X0_LDS) x0e = x0[row * lda + n];
+                        else x0e = b0 + row < batch ? x0v[rt][r] : 0.f;
+                        // interaction.py:419-420: x_l = x_0 * (W x_l + b) + x_l
+                        xb[row * lda + n] = x0e * (acc[rt][r] + bv) + xa[row * lda + n];
+                    }
             }
         }
         __syncthreads();
@@ -207,7 +250,7 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
         xa = xb;
         xb = t;
     }
-    for (int i = threadIdx.x; i < 16 * d; i += NTHR) {
+    for (int i = threadIdx.x; i < ROWS * d; i += NTHR) {
         const int r = i / d, c = i % d;
         if (b0 + r < batch) y[(b0 + r) * y_stride + c] = xa[r * lda + c];
     }
@@ -729,14 +772,18 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
 #undef CALL_CV
     } else {
         const int lda = ((dim + 31) & ~31) + 4;
-        const size_t lds = (size_t)3 * 16 * lda * sizeof(float);
+        // 32 rows per workgroup (two row tiles per weight fragment, x_0 from L2) once that still gives every CU a workgroup
+        const size_t lds2 = (size_t)2 * 32 * lda * sizeof(float);
+        static const bool rt1_forced = [] { const char* e = getenv("DCTR_CROSS_RT"); return e != nullptr && atoi(e) == 1; }();   // A/B switch
+        const bool rt2 = !rt1_forced && batch >= (int64_t)32 * dctr_n_cus() && lds2 <= 160 * 1024;
+        const size_t lds = rt2 ? lds2 : (size_t)3 * 16 * lda * sizeof(float);
         DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d needs %zu B of LDS", dim, lds);
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)cross_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds);
+            hipError_t e = hipFuncSetAttribute(rt2 ? (const void*)cross_matrix_kernel<2> : (const void*)cross_matrix_kernel<1>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DCTR_REQUIRE(e == hipSuccess, (int)e, "crossnet_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));
         }
-        const int64_t blocks = dctr_ceil_div(batch, 16);
+        const int64_t blocks = dctr_ceil_div(batch, rt2 ? 32 : 16);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
         DCTR_REQUIRE((int64_t)dim * (dim + 3) * 4 < 0x7fffffffLL, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d too large", dim);
         const size_t need = dctr_crossnet_workspace_bytes(dim, layers, mode, kernels);
@@ -752,8 +799,12 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
                                wstride, rows, static_cast<float*>(workspace));
             wk = static_cast<const float*>(workspace);
         }
-        DCTR_LAUNCH(cross_matrix_kernel, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
-                           bias, layers, y, y_stride, lda);
+        if (rt2)
+            DCTR_LAUNCH(cross_matrix_kernel<2>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
+                        bias, layers, y, y_stride, lda);
+        else
+            DCTR_LAUNCH(cross_matrix_kernel<1>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
+                        bias, layers, y, y_stride, lda);
     }
     return dctr_launch_status("dctr_crossnet_fwd");
 }

@@ -169,7 +169,10 @@ def main():
         if tag in want:
             m = DCN(cols16, cols16, cross_num=2, cross_parameterization=par, device=dev)
             init_on_device(m)
-            run("DCN cross_num=2 %s" % par, m, criteo(rng, ring * 4096), 4096, args.steps, ring)
+            feed = criteo(rng, ring * 4096)
+            run("DCN cross_num=2 %s" % par, m, feed, 4096, args.steps, ring)
+            if tag + "_span" in want:
+                run_span("DCN cross_num=2 %s (1 call / %d batches)" % (par, ring), m, feed, 4096)
             del m
     if "dcn_mix" in want:
         m = DCNMix(cols16, cols16, cross_num=2, device=dev)

@@ -253,7 +253,10 @@ def test_crossnet(device):
                          [np.abs(b).reshape(d, 1).astype(np.float64) for b in bs] if n else [], m["parameterization"])
         assert_close_terms(y.cpu().numpy(), g["cross_%s_y" % tag], mag, what="crossnet " + tag)
     rng = np.random.RandomState(7)
-    for par, B, d, L in (("vector", 4096, 429, 2), ("matrix", 300, 429, 2), ("vector", 9, 1500, 3), ("matrix", 17, 64, 4)):
+    # (matrix, >= 32 rows per CU: the 32-row workgroups of cross_matrix_kernel<2> — two row tiles per weight fragment, x_0 re-read
+    #  from the input; 8219 / 8200 rows leave a partial last workgroup, d = 45 / 430 are off the 16-B grid: the re-packed weights)
+    for par, B, d, L in (("vector", 4096, 429, 2), ("matrix", 300, 429, 2), ("vector", 9, 1500, 3), ("matrix", 17, 64, 4),
+                         ("matrix", 8219, 429, 2), ("matrix", 16384, 64, 3), ("matrix", 8200, 45, 1), ("matrix", 8192, 430, 2)):
         x = rng.standard_normal((B, d)).astype(np.float32)
         ks = (rng.standard_normal((L, d) if par == "vector" else (L, d, d)) / np.sqrt(d)).astype(np.float32)
         bs = rng.standard_normal((L, d)).astype(np.float32) * 0.1
