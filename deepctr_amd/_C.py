@@ -146,6 +146,12 @@ class HostCol(ctypes.Structure):
 HOST_KINDS = {"int32": 0, "int64": 1, "float32": 2, "float64": 3}
 
 
+class CrossnetArgs(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("dim", c_i32), ("layers", c_i32), ("mode", c_i32),
+                ("workspace_ready", c_i32), ("kernels", c_vp), ("bias", c_vp), ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp),
+                ("workspace_bytes", c_sz), ("head_w", c_vp), ("logit", c_vp)]
+
+
 class AdamSeg(ctypes.Structure):
     _fields_ = [("w", c_vp), ("m", c_vp), ("v", c_vp), ("g", c_vp), ("n", c_i64), ("l2", c_f32), ("pad_", c_i32), ("touched", c_vp)]
 
@@ -182,6 +188,7 @@ SYMBOLS = {
     "dctr_fm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "dctr_crossnet_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp]),
     "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "dctr_crossnet_head_fwd": (ctypes.c_int, [ctypes.POINTER(CrossnetArgs), c_vp]),
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
     "dctr_afm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),

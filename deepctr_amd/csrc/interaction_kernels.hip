@@ -48,7 +48,8 @@ template <int NR>
 __global__ __launch_bounds__(256) void cross_vector_kernel(const float* __restrict__ x, int64_t batch, int d,
                                                            int64_t x_stride, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int layers,
-                                                           float* __restrict__ y, int64_t y_stride) {
+                                                           float* __restrict__ y, int64_t y_stride,
+                                                           const float* __restrict__ head_w, float* __restrict__ logit) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= batch) return;
@@ -75,10 +76,23 @@ __global__ __launch_bounds__(256) void cross_vector_kernel(const float* __restri
             xl[r] = x0[r] * dot + bv + xl[r];   // interaction.py:415-416: dot_ + bias + x_l
         }
     }
+    if (y != nullptr) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int i = lane + 64 * r;
-        if (i < d) y[b * y_stride + i] = xl[r];
+        for (int r = 0; r < NR; ++r) {
+            const int i = lane + 64 * r;
+            if (i < d) y[b * y_stride + i] = xl[r];
+        }
+    }
+    if (head_w != nullptr) {            // this branch's share of the model's Dense(1): logit[b] = x_L[b, :] . head_w
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = lane + 64 * r;
+            dot = fmaf(xl[r], i < d ? head_w[i] : 0.f, dot);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+        if (lane == 0) logit[b] = dot;
     }
 }
 
@@ -153,7 +167,8 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
                                                                         int64_t x_stride, const float* __restrict__ w,
                                                                         int wstride, const float* __restrict__ bias,
                                                                         int layers, float* __restrict__ y, int64_t y_stride,
-                                                                        int lda) {
+                                                                        int lda, const float* __restrict__ head_w,
+                                                                        float* __restrict__ logit) {
     using dctr::f32x4;
     constexpr int NTHR = 64 * CROSS_WAVES;
     constexpr int ROWS = 16 * RT;
@@ -250,9 +265,20 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
         xa = xb;
         xb = t;
     }
-    for (int i = threadIdx.x; i < ROWS * d; i += NTHR) {
-        const int r = i / d, c = i % d;
-        if (b0 + r < batch) y[(b0 + r) * y_stride + c] = xa[r * lda + c];
+    if (y != nullptr) {
+        for (int i = threadIdx.x; i < ROWS * d; i += NTHR) {
+            const int r = i / d, c = i % d;
+            if (b0 + r < batch) y[(b0 + r) * y_stride + c] = xa[r * lda + c];
+        }
+    }
+    if (head_w != nullptr) {            // this branch's share of the model's Dense(1): TPR consecutive lanes per row
+        constexpr int TPR = NTHR / ROWS;
+        const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;
+        float dot = 0.f;
+        for (int n = part; n < d; n += TPR) dot = fmaf(xa[r * lda + n], head_w[n], dot);
+#pragma unroll
+        for (int m = TPR / 2; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+        if (part == 0 && b0 + r < batch) logit[b0 + r] = dot;
     }
 }
 
@@ -744,14 +770,22 @@ extern "C" size_t dctr_crossnet_workspace_bytes(int32_t dim, int32_t layers, int
     return (size_t)layers * dim * ((dim + 3) & ~3) * sizeof(float);
 }
 
-extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* kernels,
-                                 const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
+    DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "crossnet_fwd: null args");
+    const float* x = a->x;
+    const int64_t batch = a->batch, x_stride = a->x_stride, y_stride = a->y_stride;
+    const int32_t dim = a->dim, layers = a->layers, mode = a->mode;
+    const float* kernels = a->kernels;
+    const float* bias = a->bias;
+    float* y = a->y;
+    void* workspace = a->workspace;
+    const size_t workspace_bytes = a->workspace_bytes;
     DCTR_REQUIRE(batch >= 0 && dim >= 1 && layers >= 0, DCTR_E_DIM, "crossnet_fwd: bad sizes");
     DCTR_REQUIRE(mode == DCTR_CROSS_VECTOR || mode == DCTR_CROSS_MATRIX, DCTR_E_ENUM, "crossnet_fwd: mode %d", mode);
     if (batch == 0) return DCTR_OK;
-    DCTR_REQUIRE(x && y && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
-    DCTR_REQUIRE(x_stride >= dim && y_stride >= dim, DCTR_E_DIM, "crossnet_fwd: stride < dim");
+    DCTR_REQUIRE(x && (y || a->head_w) && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
+    DCTR_REQUIRE((a->head_w == nullptr) == (a->logit == nullptr), DCTR_E_NULL, "crossnet_fwd: head_w and logit go together");
+    DCTR_REQUIRE(x_stride >= dim && (y == nullptr || y_stride >= dim), DCTR_E_DIM, "crossnet_fwd: stride < dim");
     hipStream_t st = (hipStream_t)stream;
     if (mode == DCTR_CROSS_VECTOR || layers == 0) {
         DCTR_REQUIRE(dim <= 64 * 32, DCTR_E_UNSUPPORTED, "crossnet_fwd(vector): dim %d > 2048", dim);
@@ -760,7 +794,7 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
         const int nr = pow2_at_least((dim + 63) / 64, 32);
 #define CALL_CV(N)                                                                                                  \
     DCTR_LAUNCH((cross_vector_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, \
-                       kernels, bias, layers, y, y_stride)
+                       kernels, bias, layers, y, y_stride, a->head_w, a->logit)
         switch (nr) {
             case 1: CALL_CV(1); break;
             case 2: CALL_CV(2); break;
@@ -793,21 +827,34 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
             DCTR_REQUIRE(workspace != nullptr && workspace_bytes >= need && dctr_aligned16(workspace), DCTR_E_NULL,
                          "crossnet_fwd(matrix): needs a 16-B aligned workspace of %zu B (dctr_crossnet_workspace_bytes)", need);
             wstride = (dim + 3) & ~3;
-            const int64_t rows = (int64_t)layers * dim;
-            const int64_t rb = dctr_ceil_div(rows * wstride, (int64_t)256);
-            hipLaunchKernelGGL(cross_repack_kernel, dim3((unsigned)(rb > 2048 ? 2048 : rb)), dim3(256), 0, st, kernels, dim,
-                               wstride, rows, static_cast<float*>(workspace));
+            if (!a->workspace_ready) {                          // (the caller keeps the re-packed rows while the kernels do not change)
+                const int64_t rows = (int64_t)layers * dim;
+                const int64_t rb = dctr_ceil_div(rows * wstride, (int64_t)256);
+                hipLaunchKernelGGL(cross_repack_kernel, dim3((unsigned)(rb > 2048 ? 2048 : rb)), dim3(256), 0, st, kernels, dim,
+                                   wstride, rows, static_cast<float*>(workspace));
+            }
             wk = static_cast<const float*>(workspace);
         }
         if (rt2)
             DCTR_LAUNCH(cross_matrix_kernel<2>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
-                        bias, layers, y, y_stride, lda);
+                        bias, layers, y, y_stride, lda, a->head_w, a->logit);
         else
             DCTR_LAUNCH(cross_matrix_kernel<1>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
-                        bias, layers, y, y_stride, lda);
+                        bias, layers, y, y_stride, lda, a->head_w, a->logit);
     }
     return dctr_launch_status("dctr_crossnet_fwd");
 }
+
+extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* kernels,
+                                 const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    dctr_crossnet_args_t a = {};
+    a.x = x; a.batch = batch; a.dim = dim; a.x_stride = x_stride; a.kernels = kernels; a.bias = bias; a.layers = layers; a.mode = mode;
+    a.y = y; a.y_stride = y_stride; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    return crossnet_launch(&a, stream);
+}
+
+extern "C" int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* a, void* stream) { return crossnet_launch(a, stream); }
 
 extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim,
                             const float* att_w, const float* att_b, const float* proj_h, const float* proj_p,

@@ -43,11 +43,29 @@ class _DCN(FeatureModel):
         super(_DCN, self)._begin()
         self._cross_packed = self.cross.packed() if self.cross is not None else None
         self._cross_ws = getattr(self, "_cross_ws", None)
+        self._cross_ws_fresh = False        # the re-packed kernel rows in _cross_ws follow THIS call's weights from its first launch on
+
+    # Dense(1, use_bias=False) over Concatenate([cross_out, deep_out]) (reference models/dcn.py:61-64) splits into
+    # cross_out . kernel[:d] + deep_out . kernel[d:]: the cross kernel writes its share as a [B] logit (its [B, d] output never
+    # goes to HBM) and the DNN's fused head adds it — one launch and the 493-wide stack's round trip less per call
+    fuse_head = True
 
     def _forward(self, staged, lo, hi, out):
         ws = self.stage_plan.run(staged, lo, hi)
         B = hi - lo
         d = self.stage_plan.in_dim
+        if self.fuse_head and self.cross is not None and self.dnn is not None and len(self._logits_to_add(ws)) <= 3:
+            cl = self._cross_logit.get(B) if getattr(self, "_cross_logit", None) is not None else None
+            if cl is None:
+                if getattr(self, "_cross_logit", None) is None or len(self._cross_logit) > 8:
+                    self._cross_logit = {}
+                cl = self._cross_logit[B] = torch.empty(B, dtype=torch.float32, device=self.device)
+            hw = self.dense.w('kernel').reshape(-1)
+            self._run_cross(ws["dnn_in"], B, d, None, head_w=hw[:d], logit=cl)
+            ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
+                    head_w=hw[d:], add=self._logits_to_add(ws) + [cl], global_bias=self.prediction.w('global_bias'),
+                    sigmoid_out=self.task == "binary", in_dim=d, out=out)
+            return
         stack = self._stack.get(B)
         if stack is None:
             stack = self._stack[B] = torch.zeros(B, (self.width + 3) // 4 * 4, dtype=torch.float32, device=self.device)
@@ -61,20 +79,23 @@ class _DCN(FeatureModel):
         ops.mlp(stack, [], [], "linear", head_w=self.dense.w('kernel'), add=self._logits_to_add(ws),
                 global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=self.width, out=out)
 
-    def _run_cross(self, dnn_in, B, d, stack):
+    def _run_cross(self, dnn_in, B, d, stack, head_w=None, logit=None):
         ks, bs = self._cross_packed
         import ctypes
         from .. import _C
         mode = _C.CROSS_VECTOR if self.cross.parameterization == "vector" else _C.CROSS_MATRIX
         need = int(_C.lib().dctr_crossnet_workspace_bytes(d, self.cross.layer_num, mode, ctypes.c_void_p(ks.data_ptr())))
+        ready = 1 if getattr(self, "_cross_ws_fresh", False) else 0
         if need and (self._cross_ws is None or self._cross_ws.numel() * 4 < need):
             self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)   # re-packed W rows
-        _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(dnn_in.data_ptr()), B, d, dnn_in.stride(0),
-                                            ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()),
-                                            self.cross.layer_num, mode, ctypes.c_void_p(stack.data_ptr()),
-                                            stack.stride(0),
-                                            ctypes.c_void_p(self._cross_ws.data_ptr()) if need else None, need,
-                                            _C.stream_ptr()), "dctr_crossnet_fwd")
+            ready = 0
+        self._cross_ws_fresh = True
+        a = _C.CrossnetArgs(x=dnn_in.data_ptr(), batch=B, x_stride=dnn_in.stride(0), dim=d, layers=self.cross.layer_num, mode=mode,
+                            workspace_ready=ready if need else 0, kernels=ks.data_ptr(), bias=bs.data_ptr(),
+                            y=None if stack is None else stack.data_ptr(), y_stride=0 if stack is None else stack.stride(0),
+                            workspace=self._cross_ws.data_ptr() if need else None, workspace_bytes=need,
+                            head_w=None if head_w is None else head_w.data_ptr(), logit=None if logit is None else logit.data_ptr())
+        _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
 
 
 def DCN(linear_feature_columns, dnn_feature_columns, cross_num=2, cross_parameterization='vector',

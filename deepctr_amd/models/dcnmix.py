@@ -7,6 +7,8 @@ from .dcn import _DCN
 
 
 class _DCNMix(_DCN):
+    fuse_head = False       # (dctr_crossnet_mix_fwd has no fused head: the [cross, deep] stack goes through the Dense(1) launch)
+
     def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num, dnn_hidden_units, low_rank, num_experts, seed,
                  dnn_dropout, dnn_use_bn, dnn_activation, task, device):
         self._mix = (low_rank, num_experts)

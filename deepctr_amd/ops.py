@@ -359,6 +359,38 @@ def crossnet(x, kernels, bias, parameterization="vector"):
     return y
 
 
+def crossnet_head(x, kernels, bias, parameterization, head_w, want_y=False, workspace=None):
+    """CrossNet.call with the branch's share of the model's Dense(1) fused in (dctr_crossnet_head_fwd): returns (logit [B] =
+    x_L . head_w, y [B,d] or None).  ``workspace``: a dict that keeps the re-packed kernel rows of the matrix form between calls —
+    the caller clears it when the kernels change (``workspace_ready``)."""
+    _dev_check(x, kernels, bias, head_w)
+    x = _f32c(x, "x")
+    B, d = x.shape
+    L = 0 if kernels is None else kernels.shape[0]
+    mode = _C.CROSS_VECTOR if parameterization == "vector" else _C.CROSS_MATRIX
+    kernels = None if kernels is None else _f32c(kernels, "kernels")
+    bias = None if bias is None else _f32c(bias, "bias")
+    head_w = _f32c(head_w, "head_w")
+    need = int(_C.lib().dctr_crossnet_workspace_bytes(d, L, mode, _ptr(kernels)))
+    ready = 0
+    ws = None
+    if need:
+        ws = workspace.get("ws") if workspace is not None else None
+        ready = 1 if (ws is not None and ws.numel() * 4 >= need) else 0
+        if not ready:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+            if workspace is not None:
+                workspace["ws"] = ws
+    y = torch.empty(B, d, dtype=torch.float32, device=x.device) if want_y else None
+    logit = torch.empty(B, dtype=torch.float32, device=x.device)
+    a = _C.CrossnetArgs(x=x.data_ptr(), batch=B, x_stride=x.stride(0), dim=d, layers=L, mode=mode, workspace_ready=ready,
+                        kernels=None if kernels is None else kernels.data_ptr(), bias=None if bias is None else bias.data_ptr(),
+                        y=None if y is None else y.data_ptr(), y_stride=d, workspace=None if ws is None else ws.data_ptr(),
+                        workspace_bytes=need, head_w=head_w.data_ptr(), logit=logit.data_ptr())
+    _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
+    return logit, y
+
+
 def cin_output_dim(layer_size, split_half):
     if split_half:
         return sum(layer_size[:-1]) // 2 + layer_size[-1]

@@ -244,6 +244,29 @@ size_t dctr_crossnet_workspace_bytes(int32_t dim, int32_t layers, int32_t mode, 
 int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int64_t x_stride, const float* kernels,
                       const float* bias, int32_t layers, int32_t mode, float* y, int64_t y_stride, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same with the branch's share of the model's head fused in (ABI 6; models/dcn.py:61-64: Dense(1, use_bias=False) over
+ * Concatenate([cross_out, deep_out]) = cross_out . kernel[:d] + deep_out . kernel[d:]):  logit[b] = x_L[b, :] . head_w  is written
+ * beside the layer output (y != NULL) or instead of it (y == NULL: the [B, d] output never goes to HBM); the caller hands `logit` to
+ * the DNN's fused head as one of dctr_mlp_args_t.add.  workspace_ready: the workspace already holds the re-packed rows of THESE
+ * kernels (the re-pack launch is skipped; inference with fixed weights). */
+typedef struct {
+    const float* x;               /* [B, x_stride]                                                        */
+    int64_t batch;
+    int64_t x_stride;
+    int32_t dim;
+    int32_t layers;
+    int32_t mode;                 /* DCTR_CROSS_VECTOR | DCTR_CROSS_MATRIX                                */
+    int32_t workspace_ready;
+    const float* kernels;
+    const float* bias;
+    float* y;                     /* [B, y_stride] or NULL (then head_w / logit are required)             */
+    int64_t y_stride;
+    void* workspace;              /* dctr_crossnet_workspace_bytes() bytes, 16-B aligned (or NULL when 0) */
+    size_t workspace_bytes;
+    const float* head_w;          /* [dim] or NULL                                                        */
+    float* logit;                 /* [B] written, or NULL                                                 */
+} dctr_crossnet_args_t;
+int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10 CIN.call — deepctr/layers/interaction.py:277-325   (outer product + 1x1 conv on f32 MFMA)

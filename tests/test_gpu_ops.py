@@ -268,6 +268,31 @@ def test_crossnet(device):
         assert_close_terms(y.cpu().numpy(), ref, mag, what="crossnet %s d=%d" % (par, d))
 
 
+@pytest.mark.parametrize("par,B,d,L", [("vector", 300, 429, 2), ("vector", 5, 70, 0), ("matrix", 300, 429, 2), ("matrix", 8219, 429, 2),
+                                       ("matrix", 33, 64, 3), ("matrix", 8200, 45, 1)])
+def test_crossnet_head_logit(device, par, B, d, L):
+    """dctr_crossnet_head_fwd: the branch's share of Dense(1) over [cross_out, deep_out] (reference models/dcn.py:61-64) as a [B]
+    logit = x_L . head_w — with and without the [B, d] output, bit-equal layer outputs to dctr_crossnet_fwd, and the re-packed kernel
+    rows kept between calls (workspace_ready)."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(17)
+    x = rng.standard_normal((B, d)).astype(np.float32)
+    ks = (rng.standard_normal((L, d) if par == "vector" else (L, d, d)) / np.sqrt(d)).astype(np.float32) if L else None
+    bs = (rng.standard_normal((L, d)).astype(np.float32) * 0.1) if L else None
+    hw = rng.standard_normal(d).astype(np.float32)
+    xd, kd, bd, hd = dev(x, device), (dev(ks, device) if L else None), (dev(bs, device) if L else None), dev(hw, device)
+    y_ref = ops.crossnet(xd, kd, bd, par)
+    keep = {}
+    logit, y = ops.crossnet_head(xd, kd, bd, par, hd, want_y=True, workspace=keep)
+    np.testing.assert_array_equal(y.cpu().numpy(), y_ref.cpu().numpy())
+    ref = y_ref.cpu().numpy().astype(np.float64) @ hw.astype(np.float64)
+    mag = np.abs(y_ref.cpu().numpy()).astype(np.float64) @ np.abs(hw).astype(np.float64)
+    assert float(np.max(np.abs(logit.cpu().numpy() - ref) / (mag + 1e-30))) < 2e-6, "logit against float64 over the kernel's own x_L"
+    logit2, none = ops.crossnet_head(xd, kd, bd, par, hd, want_y=False, workspace=keep)      # second call: rows already re-packed
+    assert none is None
+    np.testing.assert_array_equal(logit2.cpu().numpy(), logit.cpu().numpy())
+
+
 def test_cin(device):
     from deepctr_amd import ops
     g = load_golden("interaction")
