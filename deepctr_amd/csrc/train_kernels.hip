@@ -2088,9 +2088,14 @@ static size_t mlp_bwd_chain_floats(const dctr_mlp_bwd_args_t* a) {
 // products + a sum (deterministic), 512 rows per slice from 1024 rows on, at most 32 slices (as ONE gemm a 429 x 256 output is 28
 // workgroups walking the whole batch: 64 us per layer at B = 4096; round 2's rocBLAS call split K by itself at small batches and took
 // 1.78 ms per layer at B = 65,536)
-static int mlp_dw_parts(int64_t batch) {
+// (a SMALL output under a very long reduction — DIN's attention unit: 256 x 80 over 102,400 rows — gets up to 128 slices: as 32 slices
+//  of 3,200 rows on 10 tiles it ran 268 us per layer on 320 workgroups)
+static int mlp_dw_parts(int64_t batch, int64_t out_elems) {
     if (batch < 1024) return 1;
-    int parts = (int)(batch / 512 > 32 ? 32 : batch / 512);
+    const int64_t tiles = out_elems / 4096 > 1 ? out_elems / 4096 : 1;
+    int64_t cap = 1024 / tiles;
+    cap = cap < 32 ? 32 : (cap > 128 ? 128 : cap);
+    int parts = (int)(batch / 512 > cap ? cap : batch / 512);
     while (parts > 1 && batch % parts != 0) --parts;
     return parts;
 }
@@ -2111,8 +2116,13 @@ extern "C" size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* a) {
         kn = k * a->units[l] > kn ? k * a->units[l] : kn;
         w = a->units[l] > w ? a->units[l] : w;
     }
-    const int parts = mlp_dw_parts(a->batch);
-    const size_t layered = mlp_bwd_main_floats(a, w) + (parts > 1 ? (size_t)parts * kn : 0);
+    size_t parts_floats = 0;
+    for (int l = 0; l < a->n_layers; ++l) {
+        const size_t k = l == 0 ? a->in_dim : a->units[l - 1], knl = k * a->units[l];
+        const int parts = mlp_dw_parts(a->batch, (int64_t)knl);
+        if (parts > 1 && (size_t)parts * knl > parts_floats) parts_floats = (size_t)parts * knl;
+    }
+    const size_t layered = mlp_bwd_main_floats(a, w) + parts_floats;
     const size_t chained = (a->n_layers <= 8 && a->in_dim >= 1 && a->batch < 0x7fffffffLL && mlp_bwd_chained(a)) ? mlp_bwd_chain_floats(a) : 0;
     return (layered > chained ? layered : chained) * sizeof(float);
 }
@@ -2235,8 +2245,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
     float* bufA = static_cast<float*>(a->workspace);
     float* bufB = bufA + (size_t)a->batch * w;
     float* bufZ = bufB + (size_t)a->batch * w;                 // dice only
-    float* dw_parts = bufA + mlp_bwd_main_floats(a, w);        // partial dW of the row slices (batch >= 8192)
-    const int n_parts = mlp_dw_parts(a->batch);
+    float* dw_parts = bufA + mlp_bwd_main_floats(a, w);        // partial dW of the row slices (batch >= 1024)
     const int B = (int)a->batch;
     const unsigned rb = (unsigned)dctr_ceil_div(a->batch, (int64_t)BWD_ROWS);
     const int L = a->n_layers;
@@ -2300,6 +2309,7 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
             launch_act_bwd_colsum(st, dz, (const float*)nullptr, a->batch, N, 0, a->d_biases[l]);
         // dW[K, N] (row-major) += X^T dZ:  column-major  dW'(N x K) = dZ'(N x B) * X'(K x B)^T
         int rs;
+        const int n_parts = mlp_dw_parts(a->batch, (int64_t)K * N);
         if (n_parts > 1) {
             const int rs_ = B / n_parts;
             const int64_t kn = (int64_t)K * N;
@@ -2402,7 +2412,7 @@ extern "C" int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, 
 extern "C" size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* a) {
     if (a == nullptr || a->batch <= 0 || a->layers <= 0 || a->mode != DCTR_CROSS_MATRIX) return 0;
     // x_1 .. x_{L-1}, u_0 .. u_{L-1}, g, du, dx0; from 8192 rows on the partial dW of the row slices (as in dctr_mlp_bwd)
-    const int parts = mlp_dw_parts(a->batch);
+    const int parts = mlp_dw_parts(a->batch, (int64_t)a->dim * a->dim);
     return ((size_t)(2 * a->layers + 2) * a->batch * a->dim + (parts > 1 ? (size_t)parts * a->dim * a->dim : 0)) * sizeof(float);
 }
 
@@ -2448,7 +2458,7 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     float* du = g + bd;
     float* dx0 = du + bd;
     float* dw_parts = dx0 + bd;
-    const int n_parts = mlp_dw_parts(a->batch);
+    const int n_parts = mlp_dw_parts(a->batch, (int64_t)a->dim * a->dim);
     auto xl_of = [&](int l, const float*& p, int& ld) {
         if (l == 0) { p = a->x; ld = (int)a->x_stride; }
         else { p = xsave + (size_t)(l - 1) * bd; ld = d; }
