@@ -2368,10 +2368,8 @@ extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t
     // Two 16-B groups per trip, non-temporal loads / stores, four groups per thread in the largest segment: 175 us for the C2 DeepFM
     // parameter set with touched bytes (6.15 TB/s) against 215 us with default-policy accesses and 205 us with four groups per trip
     // (profiles/r03c_opt_lab.log).  DCTR_OPT_VARIANT / DCTR_OPT_F4 re-run that lab (scripts/opt_lab.py).
-    const char* ef = getenv("DCTR_OPT_F4");
-    const char* ev = getenv("DCTR_OPT_VARIANT");
-    const int f4 = ef != nullptr && atoi(ef) >= 1 ? atoi(ef) : 4;
-    const int variant = ev != nullptr ? atoi(ev) : 2;
+    static const int f4 = [] { const char* e = getenv("DCTR_OPT_F4"); return e != nullptr && atoi(e) >= 1 ? atoi(e) : 4; }();
+    static const int variant = [] { const char* e = getenv("DCTR_OPT_VARIANT"); return e != nullptr ? atoi(e) : 2; }();
     int64_t bx = dctr_ceil_div(max_n / 4 + 1, (int64_t)(256 * f4));
     if (bx > 4096) bx = 4096;
     const dim3 grid((unsigned)bx, (unsigned)n_segs);

@@ -30,10 +30,14 @@ def run(segs, reps=30):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for variant in (0, 1, 2, 3):
-    for f4 in (2, 4, 8, 16):
-        os.environ["DCTR_OPT_VARIANT"], os.environ["DCTR_OPT_F4"] = str(variant), str(f4)
-        us_t = run((tr.segs, tr.n_segs, tr.max_n))
-        us_d = run(dense_segs)
-        print("variant %d  f4 %2d   touched bytes (all clear) %7.1f us = %.2f TB/s of 24.25 B/elem   dense %7.1f us = %.2f TB/s of 32 B/elem"
-              % (variant, f4, us_t, n * 24.25 / us_t / 1e6, us_d, n * 32 / us_d / 1e6), flush=True)
+if "--one" in sys.argv:                     # (the library reads the switches once per process)
+    us_t = run((tr.segs, tr.n_segs, tr.max_n))
+    us_d = run(dense_segs)
+    print("variant %s  f4 %2s   touched bytes (all clear) %7.1f us = %.2f TB/s of 24.25 B/elem   dense %7.1f us = %.2f TB/s of 32 B/elem"
+          % (os.environ.get("DCTR_OPT_VARIANT", "2"), os.environ.get("DCTR_OPT_F4", "4"), us_t, n * 24.25 / us_t / 1e6, us_d, n * 32 / us_d / 1e6), flush=True)
+else:
+    import subprocess
+    for variant in (0, 1, 2, 3):
+        for f4 in (2, 4, 8, 16):
+            env = dict(os.environ, DCTR_OPT_VARIANT=str(variant), DCTR_OPT_F4=str(f4))
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, check=False)

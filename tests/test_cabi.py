@@ -73,6 +73,32 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.dctr_sgemm(0, 0, 4, 4, 4, None, 4, 0, None, 4, 0, 0.0, None, 2, 0, 1, None) == -2      # ldc < m
     assert lib.dctr_sgemm(0, 0, 0, 4, 4, None, 4, 0, None, 4, 0, 0.0, None, 4, 0, 1, None) == 0       # empty product
     assert lib.dctr_embed_mlp_fwd_last_kernel() == -1                                                 # no fused launch on this thread yet
+    # round 3, third part (ABI 6): CrossNet with the fused head, touched bytes, the chained DNN backward's workspace
+    assert lib.dctr_crossnet_head_fwd(None, None) == -1
+    fake = ctypes.c_void_p(4096)                                       # a non-NULL pointer the argument checks never dereference
+    ca = _C.CrossnetArgs(x=fake, batch=4, x_stride=8, dim=8, layers=1, mode=0, kernels=fake, bias=fake, y=None, head_w=None, logit=None)
+    assert lib.dctr_crossnet_head_fwd(ctypes.byref(ca), None) == -1    # neither an output nor a head
+    ca.head_w = fake
+    assert lib.dctr_crossnet_head_fwd(ctypes.byref(ca), None) == -1 and b"head_w and logit" in lib.dctr_last_error()
+    ca.logit, ca.mode = fake, 7
+    assert lib.dctr_crossnet_head_fwd(ctypes.byref(ca), None) == -4
+    ca.mode, ca.x_stride = 1, 4
+    assert lib.dctr_crossnet_head_fwd(ctypes.byref(ca), None) == -2    # row stride smaller than dim
+    ca.batch = 0
+    assert lib.dctr_crossnet_head_fwd(ctypes.byref(ca), None) == 0
+    la = _C.LookupArgs(idx=fake, table=None, vocab=10, n=5, idx_is_i64=0, dim=6, hash_mode=0, out=None, out_stride=0, mask=None, status=None)
+    assert lib.dctr_embed_lookup_bwd(ctypes.byref(la), fake, 8, fake, fake, None) == -2 and b"touched" in lib.dctr_last_error()
+    la.n = 0
+    assert lib.dctr_embed_lookup_bwd(ctypes.byref(la), fake, 8, fake, fake, None) == 0
+    units = (ctypes.c_int32 * 3)(256, 128, 64)
+    ba = _C.MlpBwdArgs(x=fake, batch=4096, x_stride=432, in_dim=429, n_layers=3, units=ctypes.cast(units, ctypes.c_void_p), activation=1)
+    relu_ws = lib.dctr_mlp_bwd_workspace_bytes(ctypes.byref(ba))
+    # chained form: dZ_l [B, units] + W_l^T + 16 slices of (K + 1) x N per layer (4-float aligned each)
+    want = sum(((4096 * n + 3) // 4 * 4) + ((k * n + 3) // 4 * 4) + ((16 * (k + 1) * n + 3) // 4 * 4) for k, n in ((429, 256), (256, 128), (128, 64))) * 4
+    assert relu_ws == max(want, (2 * 4096 * 429 + 8 * 429 * 256) * 4), (relu_ws, want)
+    ba.activation = 4                                                  # Dice keeps the layer-by-layer form: three buffers + statistics + slices
+    assert lib.dctr_mlp_bwd_workspace_bytes(ctypes.byref(ba)) == ((3 * 4096 * 429 + 2 * 429 + 3) // 4 * 4 + 8 * 429 * 256) * 4
+    assert lib.dctr_mlp_bwd_workspace_bytes(None) == 0
 
 
 def test_host_pack_columns_converts_like_numpy():
