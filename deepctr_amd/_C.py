@@ -110,7 +110,7 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
                 ("d_out", c_vp), ("d_out_stride", c_i64), ("biases", c_vp), ("dice_alpha", c_vp), ("dice_mean", c_vp),
                 ("dice_var", c_vp), ("d_dice_alpha", c_vp), ("dice_eps", c_f32), ("pad2_", c_i32),
-                ("dice_batch_mean", c_vp), ("dice_batch_var", c_vp), ("dw_stream", c_vp)]
+                ("dice_batch_mean", c_vp), ("dice_batch_var", c_vp), ("dw_stream", c_vp), ("saved_z", c_vp)]
 
 
 class CrossMixBwdArgs(ctypes.Structure):

@@ -2254,30 +2254,37 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         const int N = a->units[l], K = l == 0 ? a->in_dim : a->units[l - 1];
         const float* xin = l == 0 ? a->x : a->acts[l - 1];
         const int ldx = l == 0 ? (int)a->x_stride : K;
-        int rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, N, B, K, a->kernels[l], N, xin, ldx, 0.f, bufZ, N);
-        if (rs != 0) return (int)rs;
+        // (saved_z: the forward's own pre-activations, bias included — no recompute, no bias in the kernels below)
+        const float* zsrc = bufZ;
         const float* bl = a->biases != nullptr ? a->biases[l] : nullptr;
+        if (a->saved_z != nullptr && a->saved_z[l] != nullptr) {
+            zsrc = a->saved_z[l];
+            bl = nullptr;
+        } else {
+            int rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, N, B, K, a->kernels[l], N, xin, ldx, 0.f, bufZ, N);
+            if (rs != 0) return (int)rs;
+        }
         float* dal = a->d_dice_alpha != nullptr ? a->d_dice_alpha[l] : nullptr;
         if (a->dice_batch_mean != nullptr && a->dice_batch_var != nullptr && a->dice_batch_mean[l] != nullptr) {
             // training-mode Dice: this batch's statistics, gradients through them
             float* s12 = bufZ + (size_t)a->batch * w;
             if (hipMemsetAsync(s12, 0, (size_t)2 * N * sizeof(float), st) != hipSuccess) return -1;
-            if (rowlane4_ok(N, buf, bufZ, N))
+            if (rowlane4_ok(N, buf, zsrc, N))
                 hipLaunchKernelGGL(dice_train_bwd_reduce4_kernel, dim3(colsum_grid(a->batch, 256 / (N / 4))), dim3(256), 0, st,
-                                   (const float*)buf, (const float*)bufZ, bl, a->dice_alpha[l], a->dice_batch_mean[l],
+                                   (const float*)buf, zsrc, bl, a->dice_alpha[l], a->dice_batch_mean[l],
                                    a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
             else
-                hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rows_grid(a->batch, true)), dim3(256), 0, st, (const float*)buf, (const float*)bufZ, bl,
+                hipLaunchKernelGGL(dice_train_bwd_reduce_kernel, dim3(rows_grid(a->batch, true)), dim3(256), 0, st, (const float*)buf, zsrc, bl,
                                    a->dice_alpha[l], a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, s12, dal);
-            hipLaunchKernelGGL(dice_train_bwd_apply_kernel, dim3(rb), dim3(256), 0, st, buf, (const float*)bufZ, bl, a->dice_alpha[l],
+            hipLaunchKernelGGL(dice_train_bwd_apply_kernel, dim3(rb), dim3(256), 0, st, buf, zsrc, bl, a->dice_alpha[l],
                                a->dice_batch_mean[l], a->dice_batch_var[l], a->dice_eps, a->batch, N, (const float*)s12);
             return 0;
         }
-        if (rowlane4_ok(N, buf, bufZ, N))
-            hipLaunchKernelGGL(dice_bwd4_kernel, dim3(colsum_grid(a->batch, 256 / (N / 4))), dim3(256), 0, st, buf, (const float*)bufZ, bl,
+        if (rowlane4_ok(N, buf, zsrc, N))
+            hipLaunchKernelGGL(dice_bwd4_kernel, dim3(colsum_grid(a->batch, 256 / (N / 4))), dim3(256), 0, st, buf, zsrc, bl,
                                a->dice_alpha[l], a->dice_mean[l], a->dice_var[l], a->dice_eps, a->batch, N, dal);
         else
-            hipLaunchKernelGGL(dice_bwd_kernel, dim3(rows_grid(a->batch, true)), dim3(256), 0, st, buf, bufZ, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
+            hipLaunchKernelGGL(dice_bwd_kernel, dim3(rows_grid(a->batch, true)), dim3(256), 0, st, buf, zsrc, bl, a->dice_alpha[l], a->dice_mean[l], a->dice_var[l],
                                a->dice_eps, a->batch, N, dal);
         return 0;
     };

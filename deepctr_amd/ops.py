@@ -790,12 +790,12 @@ def dnn_train_layer(z, activation, h=None, bn=None, dropout_rate=0.0, dropout_se
 
 
 def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_biases, d_head_w, dx=None, d_out=None, biases=None,
-            dice=None, d_dice_alpha=None, dice_eps=1e-9, dice_batch=None, dw_stream=None, workspace=None):
+            dice=None, d_dice_alpha=None, dice_eps=1e-9, dice_batch=None, dw_stream=None, workspace=None, saved_z=None):
     """Backward of dctr_mlp_fwd (+ head).  Gradients are ACCUMULATED into d_kernels / d_biases / d_head_w; dx is written.
     Headless form: head_w = dlogit = d_head_w = None and ``d_out`` [B, >= units[-1]] = gradient w.r.t. the last layer.
     activation "dice": ``biases`` and ``dice`` = [(alpha, mean, var)] per layer as in the forward; ``d_dice_alpha`` (list,
     accumulated) optional; ``dice_batch`` = [(batch_mean, batch_var)] per layer (dice_train_fwd) switches to training-mode Dice:
-    the gradient flows through the batch statistics.
+    the gradient flows through the batch statistics; ``saved_z`` = the layers' pre-activations (bias included) when a forward kept them.
     ``dw_stream`` (a torch.cuda.Stream) sends the weight-gradient launches of the chained form there (include/dctr.h); it needs a
     ``workspace`` the caller keeps alive (a dict: the tensor is cached under "ws") and a join by the caller."""
     _dev_check(x, *kernels)
@@ -816,6 +816,12 @@ def mlp_bwd(x, in_dim, kernels, acts, activation, head_w, dlogit, d_kernels, d_b
         if dice_batch is not None:
             bmp, bvp = (_ptr_array([_f32c(d[i], "dice batch statistics") for d in dice_batch]) for i in range(2))
             extra.update(dice_batch_mean=ctypes.cast(bmp, ctypes.c_void_p), dice_batch_var=ctypes.cast(bvp, ctypes.c_void_p))
+        if saved_z is not None:       # the forward's pre-activations (bias included), dense [B, units[l]]: no recompute GEMM
+            for z, u in zip(saved_z, units):
+                if z is not None and (z.dtype != torch.float32 or not z.is_contiguous() or z.shape[-1] != u or z.numel() != x.shape[0] * u):
+                    raise ValueError("mlp_bwd: saved_z entries must be dense float32 [B, units[l]]")
+            szp = _ptr_array(list(saved_z))
+            extra.update(saved_z=ctypes.cast(szp, ctypes.c_void_p))
     a = _C.MlpBwdArgs(x=x.data_ptr(), batch=x.shape[0], x_stride=x.stride(0), in_dim=in_dim, n_layers=n,
                       units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
                       acts=ctypes.cast(ap, ctypes.c_void_p), activation=_C.ACT_CODES[activation],

@@ -484,7 +484,7 @@ class HipTrainer(object):
         ops.mlp_bwd(buf["att_in"], 4 * E, la.dnn.kernels, buf["att_acts"], act, pa["out_w"].w, buf["d_score"],
                     [p.g for p in pa["kernels"]], [p.g for p in pa["biases"]], pa["out_w"].g, dx=buf["d_att_in"],
                     biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None,
-                    dice_batch=dice_batch)
+                    dice_batch=dice_batch, saved_z=buf["att_z"] if dice_batch is not None else None)
         ops.din_att_in_bwd(buf["d_att_in"], q, k, buf["dk"], dx, self.qcol)
         for (fc, idx, hm, col), pt in zip(bufs["key_lookups"], self.p_hist):
             if pt.g is not None:                                   # frozen history table: no scatter

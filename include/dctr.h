@@ -557,6 +557,9 @@ typedef struct {
                                      dW / d_bias GEMM and its slice sum) is launched there behind an event on `stream`, so that it
                                      runs beside what the caller launches next on `stream` (the embedding scatter, atomics-bound).
                                      The CALLER joins the two streams before it reads d_kernels / d_biases or reuses the workspace. */
+    const float* const* saved_z;  /* ABI 6, DCTR_ACT_DICE.  NULL, or HOST array of DEVICE pointers [out_l] (entries may be NULL): layer l's
+                                     pre-activations z_l = x_l W_l + b_l, dense [B, units[l]], as a forward launch wrote them (training-mode
+                                     Dice runs the layers one by one and has them): the recompute GEMM of that layer is skipped         */
 } dctr_mlp_bwd_args_t;
 size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
 

@@ -204,6 +204,19 @@ def test_dice_training_mode_forward_and_backward_match_autograd(device, n_layers
         _scaled(ga[i], aa[i].grad, "dalpha%d" % i)
     if head:
         _scaled(ghw, ha.grad, "dhead")
+    # saved_z (the forward's pre-activations, bias included): same gradients without the recompute GEMM of each layer
+    gW2, gb2, ga2 = [torch.zeros_like(t) for t in Ws], [torch.zeros_like(t) for t in bs], [torch.zeros_like(t) for t in al]
+    ghw2 = torch.zeros_like(hw)
+    dx2 = torch.full((R, K + 2), 4.0, device=device)
+    ops.mlp_bwd(x, K, Ws, acts, "dice", hw if head else None, dl if head else None, gW2, gb2, ghw2 if head else None, dx=dx2,
+                d_out=None if head else dout, biases=bs, dice=dice, d_dice_alpha=ga2, dice_batch=stats, saved_z=zs)
+    for a_, b_, what in [(dx2, dx, "dx")] + [(u, v, "dW") for u, v in zip(gW2, gW)] + [(u, v, "db") for u, v in zip(gb2, gb)] + \
+            [(u, v, "dalpha") for u, v in zip(ga2, ga)]:
+        scale = float(b_.abs().max()) or 1.0
+        assert float((a_ - b_).abs().max()) <= 2e-5 * scale + 1e-6, "saved_z against the recomputed pre-activations: " + what
+    with pytest.raises(ValueError):
+        ops.mlp_bwd(x, K, Ws, acts, "dice", hw if head else None, dl if head else None, gW2, gb2, ghw2 if head else None, dx=dx2,
+                    d_out=None if head else dout, biases=bs, dice=dice, d_dice_alpha=ga2, dice_batch=stats, saved_z=[z[:, :-1] for z in zs])
 
 
 def _din(device, act, E=8, T=6):
