@@ -130,7 +130,7 @@ class CrossBwdArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("x_stride", c_i64), ("batch", c_i64), ("dim", c_i32), ("layers", c_i32), ("mode", c_i32),
                 ("dx_accumulate", c_i32), ("kernels", c_vp), ("bias", c_vp), ("dy", c_vp), ("dy_stride", c_i64),
                 ("d_kernels", c_vp), ("d_bias", c_vp), ("dx", c_vp), ("dx_stride", c_i64), ("workspace", c_vp),
-                ("workspace_bytes", c_sz)]
+                ("workspace_bytes", c_sz), ("saved_u", c_vp), ("saved_x", c_vp)]
 
 
 class AfmBwdArgs(ctypes.Structure):
@@ -149,7 +149,7 @@ HOST_KINDS = {"int32": 0, "int64": 1, "float32": 2, "float64": 3}
 class CrossnetArgs(ctypes.Structure):
     _fields_ = [("x", c_vp), ("batch", c_i64), ("x_stride", c_i64), ("dim", c_i32), ("layers", c_i32), ("mode", c_i32),
                 ("workspace_ready", c_i32), ("kernels", c_vp), ("bias", c_vp), ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp),
-                ("workspace_bytes", c_sz), ("head_w", c_vp), ("logit", c_vp)]
+                ("workspace_bytes", c_sz), ("head_w", c_vp), ("logit", c_vp), ("save_u", c_vp), ("save_x", c_vp)]
 
 
 class AdamSeg(ctypes.Structure):

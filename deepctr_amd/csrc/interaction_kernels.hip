@@ -168,7 +168,8 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
                                                                         int wstride, const float* __restrict__ bias,
                                                                         int layers, float* __restrict__ y, int64_t y_stride,
                                                                         int lda, const float* __restrict__ head_w,
-                                                                        float* __restrict__ logit) {
+                                                                        float* __restrict__ logit, float* __restrict__ save_u,
+                                                                        float* __restrict__ save_x) {
     using dctr::f32x4;
     constexpr int NTHR = 64 * CROSS_WAVES;
     constexpr int ROWS = 16 * RT;
@@ -256,7 +257,13 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
                         if constexpr (X0_LDS) x0e = x0[row * lda + n];
                         else x0e = b0 + row < batch ? x0v[rt][r] : 0.f;
                         // interaction.py:419-420: x_l = x_0 * (W x_l + b) + x_l
-                        xb[row * lda + n] = x0e * (acc[rt][r] + bv) + xa[row * lda + n];
+                        const float xn = x0e * (acc[rt][r] + bv) + xa[row * lda + n];
+                        xb[row * lda + n] = xn;
+                        if (save_u != nullptr && b0 + row < batch) {     // training: what dctr_crossnet_bwd would recompute
+                            const int64_t o = ((int64_t)l * batch + b0 + row) * d + n;
+                            save_u[o] = acc[rt][r];
+                            if (save_x != nullptr && l + 1 < layers) save_x[o] = xn;
+                        }
                     }
             }
         }
@@ -786,6 +793,8 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
     DCTR_REQUIRE(x && (y || a->head_w) && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
     DCTR_REQUIRE((a->head_w == nullptr) == (a->logit == nullptr), DCTR_E_NULL, "crossnet_fwd: head_w and logit go together");
     DCTR_REQUIRE(x_stride >= dim && (y == nullptr || y_stride >= dim), DCTR_E_DIM, "crossnet_fwd: stride < dim");
+    DCTR_REQUIRE(a->save_u == nullptr || (mode == DCTR_CROSS_MATRIX && layers >= 1 && (layers == 1 || a->save_x != nullptr)), DCTR_E_UNSUPPORTED,
+                 "crossnet_fwd: save_u / save_x exist for the matrix form (save_x with more than one layer)");
     hipStream_t st = (hipStream_t)stream;
     if (mode == DCTR_CROSS_VECTOR || layers == 0) {
         DCTR_REQUIRE(dim <= 64 * 32, DCTR_E_UNSUPPORTED, "crossnet_fwd(vector): dim %d > 2048", dim);
@@ -837,10 +846,10 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
         }
         if (rt2)
             DCTR_LAUNCH(cross_matrix_kernel<2>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
-                        bias, layers, y, y_stride, lda, a->head_w, a->logit);
+                        bias, layers, y, y_stride, lda, a->head_w, a->logit, a->save_u, a->save_x);
         else
             DCTR_LAUNCH(cross_matrix_kernel<1>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
-                        bias, layers, y, y_stride, lda, a->head_w, a->logit);
+                        bias, layers, y, y_stride, lda, a->head_w, a->logit, a->save_u, a->save_x);
     }
     return dctr_launch_status("dctr_crossnet_fwd");
 }

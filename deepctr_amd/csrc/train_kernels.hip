@@ -2464,11 +2464,15 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     float* dx0 = du + bd;
     float* dw_parts = dx0 + bd;
     const int n_parts = mlp_dw_parts(a->batch, (int64_t)a->dim * a->dim);
+    // (saved_u / saved_x: the forward kernel's own u_l and x_l — no recompute)
+    const bool saved = a->saved_u != nullptr && (L == 1 || a->saved_x != nullptr);
+    const float* us_r = saved ? a->saved_u : us;
+    const float* xs_r = saved ? a->saved_x : xsave;
     auto xl_of = [&](int l, const float*& p, int& ld) {
         if (l == 0) { p = a->x; ld = (int)a->x_stride; }
-        else { p = xsave + (size_t)(l - 1) * bd; ld = d; }
+        else { p = xs_r + (size_t)(l - 1) * bd; ld = d; }
     };
-    for (int l = 0; l < L; ++l) {            // forward recompute: u_l = x_l W_l^T;  x_{l+1} = x0 .* (u_l + b_l) + x_l
+    for (int l = 0; l < L && !saved; ++l) {  // forward recompute: u_l = x_l W_l^T;  x_{l+1} = x0 .* (u_l + b_l) + x_l
         const float* xl; int ldx;
         xl_of(l, xl, ldx);
         const float* W = a->kernels + (size_t)l * d * d;
@@ -2485,7 +2489,7 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
         const float* xl; int ldx;
         xl_of(l, xl, ldx);
         const float* W = a->kernels + (size_t)l * d * d;
-        hipLaunchKernelGGL(cross_matrix_bwd_elem_kernel, dim3(eb), dim3(256), 0, st, a->x, a->x_stride, g, us + (size_t)l * bd,
+        hipLaunchKernelGGL(cross_matrix_bwd_elem_kernel, dim3(eb), dim3(256), 0, st, a->x, a->x_stride, g, us_r + (size_t)l * bd,
                            a->bias + (size_t)l * d, a->batch, d, du, dx0);
         launch_act_bwd_colsum(st, du, (const float*)nullptr, a->batch, d, 0, a->d_bias + (size_t)l * d);
         // dW[n][k] += sum_b du[b][n] x_l[b][k]:  column-major  dW'(k x n) = X'(k x B) * du'(n x B)^T

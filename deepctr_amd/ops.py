@@ -359,7 +359,7 @@ def crossnet(x, kernels, bias, parameterization="vector"):
     return y
 
 
-def crossnet_head(x, kernels, bias, parameterization, head_w, want_y=False, workspace=None):
+def crossnet_head(x, kernels, bias, parameterization, head_w, want_y=False, workspace=None, save_u=None, save_x=None):
     """CrossNet.call with the branch's share of the model's Dense(1) fused in (dctr_crossnet_head_fwd): returns (logit [B] =
     x_L . head_w, y [B,d] or None).  ``workspace``: a dict that keeps the re-packed kernel rows of the matrix form between calls —
     the caller clears it when the kernels change (``workspace_ready``)."""
@@ -386,7 +386,7 @@ def crossnet_head(x, kernels, bias, parameterization, head_w, want_y=False, work
     a = _C.CrossnetArgs(x=x.data_ptr(), batch=B, x_stride=x.stride(0), dim=d, layers=L, mode=mode, workspace_ready=ready,
                         kernels=None if kernels is None else kernels.data_ptr(), bias=None if bias is None else bias.data_ptr(),
                         y=None if y is None else y.data_ptr(), y_stride=d, workspace=None if ws is None else ws.data_ptr(),
-                        workspace_bytes=need, head_w=head_w.data_ptr(), logit=logit.data_ptr())
+                        workspace_bytes=need, head_w=head_w.data_ptr(), logit=logit.data_ptr(), save_u=_ptr(save_u), save_x=_ptr(save_x))
     _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
     return logit, y
 
@@ -984,16 +984,17 @@ def inner_product_bwd(x, fields, dim, dy, dx, accumulate=False):
              "dctr_inner_product_bwd")
 
 
-def crossnet_bwd(x, d, kernels, bias, parameterization, dy, d_kernels, d_bias, dx, accumulate=False):
+def crossnet_bwd(x, d, kernels, bias, parameterization, dy, d_kernels, d_bias, dx, accumulate=False, saved_u=None, saved_x=None):
     """Backward of dctr_crossnet_fwd: x [B, >= d] the forward input, dy [B, >= d]; d_kernels / d_bias are ACCUMULATED,
-    dx [B, >= d] is written (or added to with ``accumulate``)."""
+    dx [B, >= d] is written (or added to with ``accumulate``).  saved_u [L, B, d] / saved_x [L - 1, B, d] (matrix form): what the
+    forward wrote through dctr_crossnet_args_t.save_u / save_x — the backward then recomputes nothing."""
     _dev_check(x, dy, dx, kernels, bias)
     L = 0 if kernels is None else kernels.shape[0]
     mode = _C.CROSS_VECTOR if parameterization == "vector" else _C.CROSS_MATRIX
     a = _C.CrossBwdArgs(x=x.data_ptr(), x_stride=x.stride(0), batch=x.shape[0], dim=int(d), layers=L, mode=mode,
                         dx_accumulate=int(bool(accumulate)), kernels=_ptr(kernels), bias=_ptr(bias), dy=dy.data_ptr(),
                         dy_stride=dy.stride(0), d_kernels=_ptr(d_kernels), d_bias=_ptr(d_bias), dx=dx.data_ptr(),
-                        dx_stride=dx.stride(0))
+                        dx_stride=dx.stride(0), saved_u=_ptr(saved_u), saved_x=_ptr(saved_x))
     need = int(_C.lib().dctr_crossnet_bwd_workspace_bytes(ctypes.byref(a)))
     ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), need

@@ -539,7 +539,7 @@ class HipTrainer(object):
             if self.p_mix is not None:
                 ops.crossnet_mix(ws["dnn_in"], *[p.w for p in self.p_mix], dim=d, out=stack)
             else:
-                self._cross_fwd(ws["dnn_in"], d, par, stack)
+                self._cross_fwd(ws["dnn_in"], d, par, stack, buf)
             col = d
         if model.dnn is not None:
             self._dnn_forward(ws["dnn_in"], d, buf, stack[:, col:], head=False)
@@ -559,9 +559,10 @@ class HipTrainer(object):
                                  accumulate=have_dx)
         elif model.cross is not None:
             ops.crossnet_bwd(ws["dnn_in"], d, self.p_cross_k.w, self.p_cross_b.w, par, dstack, self.p_cross_k.g, self.p_cross_b.g,
-                             buf["dx"], accumulate=have_dx)
+                             buf["dx"], accumulate=have_dx, saved_u=buf.get("cross_u") if par == "matrix" else None,
+                             saved_x=buf.get("cross_x") if par == "matrix" else None)
 
-    def _cross_fwd(self, dnn_in, d, par, stack):
+    def _cross_fwd(self, dnn_in, d, par, stack, buf=None):
         import ctypes
         from . import _C
         mode = _C.CROSS_VECTOR if par == "vector" else _C.CROSS_MATRIX
@@ -569,11 +570,20 @@ class HipTrainer(object):
         need = int(_C.lib().dctr_crossnet_workspace_bytes(d, ks.shape[0], mode, ctypes.c_void_p(ks.data_ptr())))
         if need and (getattr(self, "_cross_ws", None) is None or self._cross_ws.numel() * 4 < need):
             self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=ks.device)
-        _C.check(_C.lib().dctr_crossnet_fwd(ctypes.c_void_p(dnn_in.data_ptr()), dnn_in.shape[0], d, dnn_in.stride(0),
-                                            ctypes.c_void_p(ks.data_ptr()), ctypes.c_void_p(bs.data_ptr()), ks.shape[0], mode,
-                                            ctypes.c_void_p(stack.data_ptr()), stack.stride(0),
-                                            ctypes.c_void_p(self._cross_ws.data_ptr()) if need else None, need,
-                                            _C.stream_ptr()), "dctr_crossnet_fwd")
+        su = sx = None
+        if par == "matrix" and buf is not None and ks.shape[0] >= 1:
+            # the forward kernel writes u_l = W_l x_l and x_1 .. x_{L-1} for the backward (dctr_crossnet_bwd_args_t.saved_u / saved_x:
+            # no recompute GEMM + elementwise launch per layer there)
+            L, B = ks.shape[0], dnn_in.shape[0]
+            if "cross_u" not in buf:
+                buf["cross_u"] = torch.empty(L, B, d, dtype=torch.float32, device=ks.device)
+                buf["cross_x"] = torch.empty(max(L - 1, 1), B, d, dtype=torch.float32, device=ks.device)
+            su, sx = buf["cross_u"], buf["cross_x"]
+        a = _C.CrossnetArgs(x=dnn_in.data_ptr(), batch=dnn_in.shape[0], x_stride=dnn_in.stride(0), dim=d, layers=ks.shape[0], mode=mode,
+                            workspace_ready=0, kernels=ks.data_ptr(), bias=bs.data_ptr(), y=stack.data_ptr(), y_stride=stack.stride(0),
+                            workspace=self._cross_ws.data_ptr() if need else None, workspace_bytes=need,
+                            save_u=None if su is None else su.data_ptr(), save_x=None if sx is None else sx.data_ptr())
+        _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
 
     def step(self, staged, lo, hi, y, apply=True):
         """One optimizer step on rows [lo, hi) of the staged inputs; y: device float tensor [hi-lo].  Returns the mean

@@ -265,6 +265,9 @@ typedef struct {
     size_t workspace_bytes;
     const float* head_w;          /* [dim] or NULL                                                        */
     float* logit;                 /* [B] written, or NULL                                                 */
+    float* save_u;                /* training, matrix form: NULL, or [layers, B, dim] — u_l = W_l x_l (bias excluded) written for
+                                     dctr_crossnet_bwd_args_t.saved_u                                                       */
+    float* save_x;                /* ... and [layers - 1, B, dim] — x_1 .. x_{L-1} for saved_x (NULL with one layer)        */
 } dctr_crossnet_args_t;
 int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* args, void* stream);
 
@@ -675,8 +678,8 @@ typedef struct {
 } dctr_afm_bwd_args_t;
 int dctr_afm_bwd(const dctr_afm_bwd_args_t* args, void* stream);
 
-/* backward of dctr_crossnet_fwd (interaction.py:405-424); x_l are recomputed, nothing is saved by the forward.
- * vector: one fused kernel.  matrix: rocBLAS GEMMs + elementwise kernels through the workspace. */
+/* backward of dctr_crossnet_fwd (interaction.py:405-424).  vector: one fused kernel (x_l recomputed).  matrix: GEMMs on dctr_sgemm's
+ * kernel + elementwise kernels through the workspace; u_l / x_l recomputed unless the forward saved them (saved_u / saved_x). */
 typedef struct {
     const float* x;               /* [B, x_stride] the forward's input x_0                               */
     int64_t x_stride;
@@ -692,6 +695,8 @@ typedef struct {
     int64_t dx_stride;
     void* workspace;              /* dctr_crossnet_bwd_workspace_bytes() bytes (matrix form), 16-B aligned */
     size_t workspace_bytes;
+    const float* saved_u;         /* ABI 6, matrix form: NULL (u_l and x_l are recomputed: one GEMM + one elementwise launch per layer),   */
+    const float* saved_x;         /* or what the forward wrote through dctr_crossnet_args_t.save_u / save_x (saved_x may be NULL: 1 layer) */
 } dctr_crossnet_bwd_args_t;
 size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* args);
 int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* args, void* stream);

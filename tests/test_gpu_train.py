@@ -470,6 +470,20 @@ def test_crossnet_bwd_matches_autograd(device, par, B, d, L):
         # (dW sums B products of O(1) x O(10) terms: a few fp32 ulp of that sum is ~3e-5 whatever the summation order)
         assert_close(dk.cpu().numpy(), kt.grad.numpy(), rtol=2e-4, atol=5e-5, what="dW " + tag)
         assert_close(dbv.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-5, what="db " + tag)
+    if L and par == "matrix":
+        # saved_u / saved_x: u_l and x_l as the forward kernel wrote them (dctr_crossnet_args_t.save_u / save_x) instead of the recompute
+        xd, kd, bd_ = dev(x, device), dev(ks, device), dev(bs, device)
+        su = torch.empty(L, B, d, device=device)
+        sx = torch.empty(max(L - 1, 1), B, d, device=device)
+        hw = torch.ones(d, device=device)
+        logit, y = ops.crossnet_head(xd[:, :d].contiguous(), kd, bd_, par, hw, want_y=True, save_u=su, save_x=sx)
+        np.testing.assert_array_equal(y.cpu().numpy(), ops.crossnet(xd[:, :d].contiguous(), kd, bd_, par).cpu().numpy())
+        dk2, db2 = torch.zeros(ks.shape, device=device), torch.zeros(bs.shape, device=device)
+        dx2 = torch.full((B, d + 2), 3.0, device=device)
+        ops.crossnet_bwd(xd, d, kd, bd_, par, dev(dy, device), dk2, db2, dx2, accumulate=True, saved_u=su, saved_x=sx if L > 1 else None)
+        for a_, b_, what in ((dx2, dx, "dx"), (dk2, dk, "dW"), (db2, dbv, "db")):
+            scale = float(b_.abs().max()) or 1.0
+            assert float((a_ - b_).abs().max()) <= 3e-5 * scale + 1e-6, "saved u / x against the recompute: %s %s" % (what, tag)
 
 
 @pytest.mark.parametrize("par,cross_num,hidden", [("vector", 2, (32, 16)), ("matrix", 2, (32, 16)), ("vector", 3, ()),
