@@ -35,6 +35,7 @@ struct GroupDesc {
     int64_t stride_c;
     int batch;
     int ones_last;
+    int accumulate;             // 1: C += the product (beta = 1; not together with k_slices)
     int k_slices;               // > 1: k is cut into k_slices slices (as dctr_gemm::k_slices counts them) and slice s STORES its partial
     int64_t slice_stride_c;     //      product at C + s * slice_stride_c (the caller sums the slices: deterministic, no atomics)
 };

@@ -324,6 +324,8 @@ int sgemm_grouped(hipStream_t stream, const GroupDesc* g, int n_groups) {
         Params& p = gp.p[ng];
         fill_params(p, d.op_a, d.op_b, d.m, d.n, d.k, d.A, d.lda, d.stride_a, d.B, d.ldb, d.stride_b, 0.f, d.C, d.ldc, d.stride_c);
         if (d.ones_last) p.ones_row = d.n - 1;
+        DCTR_REQUIRE(!(d.accumulate && d.k_slices > 1), DCTR_E_UNSUPPORTED, "sgemm_grouped[%d]: accumulate with k_slices", i);
+        p.accumulate = d.accumulate ? 1 : 0;
         int slices = 1;
         if (d.k_slices > 1 && d.k > 0) {                       // k cut into slices of a multiple of 32, each stored to its own C
             p.kchunk = (int)(dctr_ceil_div(dctr_ceil_div(d.k, d.k_slices), 32) * 32);

@@ -2493,22 +2493,32 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
                            a->bias + (size_t)l * d, a->batch, d, du, dx0);
         launch_act_bwd_colsum(st, du, (const float*)nullptr, a->batch, d, 0, a->d_bias + (size_t)l * d);
         // dW[n][k] += sum_b du[b][n] x_l[b][k]:  column-major  dW'(k x n) = X'(k x B) * du'(n x B)^T
+        // g[b][k] += sum_n du[b][n] W[n][k]:  column-major  g'(k x B) += W'(k x n) * du'(n x B)
+        // both read du and nothing of each other: ONE grouped launch (the dW reduction over the batch as row slices + a sum)
         int rs;
-        if (n_parts > 1) {                     // the long reduction over the batch as a strided batch of row slices + a sum
+        if (n_parts > 1) {
             const int rs_ = B / n_parts;
             const int64_t dd = (int64_t)d * d;
-            rs = dctr_gemm::sgemm_strided_batched(st, dctr_gemm::OP_N, dctr_gemm::OP_T, d, d, rs_, xl, ldx, (int64_t)rs_ * ldx, du, d, (int64_t)rs_ * d, 0.f, dw_parts, d, (int64_t)dd, n_parts);
-            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            dctr_gemm::GroupDesc gd[2];
+            gd[0] = dctr_gemm::GroupDesc{};
+            gd[0].op_a = dctr_gemm::OP_N; gd[0].op_b = dctr_gemm::OP_T; gd[0].m = d; gd[0].n = d; gd[0].k = rs_;
+            gd[0].A = xl; gd[0].lda = ldx; gd[0].stride_a = (int64_t)rs_ * ldx;
+            gd[0].B = du; gd[0].ldb = d; gd[0].stride_b = (int64_t)rs_ * d;
+            gd[0].C = dw_parts; gd[0].ldc = d; gd[0].stride_c = dd; gd[0].batch = n_parts;
+            gd[1] = dctr_gemm::GroupDesc{};
+            gd[1].op_a = dctr_gemm::OP_N; gd[1].op_b = dctr_gemm::OP_N; gd[1].m = d; gd[1].n = B; gd[1].k = d;
+            gd[1].A = W; gd[1].lda = d; gd[1].B = du; gd[1].ldb = d; gd[1].C = g; gd[1].ldc = d; gd[1].batch = 1; gd[1].accumulate = 1;
+            rs = dctr_gemm::sgemm_grouped(st, gd, 2);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm_grouped(dW, g) failed (%d)", (int)rs);
             int64_t gp = dctr_ceil_div(dd, (int64_t)256);
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(gp > 8192 ? 8192 : gp)), dim3(256), 0, st, (const float*)dw_parts, dd, n_parts,
                                a->d_kernels + (size_t)l * d * d);
         } else {
             rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_T, d, d, B, xl, ldx, du, d, 1.f, a->d_kernels + (size_t)l * d * d, d);
             DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm(dW) failed (%d)", (int)rs);
+            rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, d, B, d, W, d, du, d, 1.f, g, d);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm(g) failed (%d)", (int)rs);
         }
-        // g[b][k] += sum_n du[b][n] W[n][k]:  column-major  g'(k x B) += W'(k x n) * du'(n x B)
-        rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, d, B, d, W, d, du, d, 1.f, g, d);
-        DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "crossnet_bwd: sgemm(g) failed (%d)", (int)rs);
     }
     // d x0 = dx0 + g  (x_0 is also the first x_l)
     hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, g, (int64_t)d, a->batch, d, dx0, (int64_t)d, 1);
