@@ -2317,25 +2317,37 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         // dW[K, N] (row-major) += X^T dZ:  column-major  dW'(N x K) = dZ'(N x B) * X'(K x B)^T
         int rs;
         const int n_parts = mlp_dw_parts(a->batch, (int64_t)K * N);
+        const bool to_dx = l == 0;
+        const bool want_dx = !(to_dx && a->dx == nullptr);
+        float* dst = to_dx ? a->dx : other;
+        const int ldd = to_dx ? (int)a->dx_stride : K;
         if (n_parts > 1) {
+            // dW slices and dH_prev[B, K] = dZ W^T (column-major dH'(K x B) = W'(N x K)^T * dZ'(N x B)) read dZ and nothing of each
+            // other: ONE grouped launch (two latency-bound problems side by side: DCN-matrix's pair went from 2 x 35 to 45 us)
             const int rs_ = B / n_parts;
             const int64_t kn = (int64_t)K * N;
-            rs = dctr_gemm::sgemm_strided_batched(st, dctr_gemm::OP_N, dctr_gemm::OP_T, N, K, rs_, dz, N, (int64_t)rs_ * N, xin, ldx, (int64_t)rs_ * ldx, 0.f, dw_parts, N, (int64_t)kn, n_parts);
-            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm_strided_batched(dW) failed (%d)", (int)rs);
+            dctr_gemm::GroupDesc gd[2];
+            gd[0] = dctr_gemm::GroupDesc{};
+            gd[0].op_a = dctr_gemm::OP_N; gd[0].op_b = dctr_gemm::OP_T; gd[0].m = N; gd[0].n = K; gd[0].k = rs_;
+            gd[0].A = dz; gd[0].lda = N; gd[0].stride_a = (int64_t)rs_ * N;
+            gd[0].B = xin; gd[0].ldb = ldx; gd[0].stride_b = (int64_t)rs_ * ldx;
+            gd[0].C = dw_parts; gd[0].ldc = N; gd[0].stride_c = kn; gd[0].batch = n_parts;
+            gd[1] = dctr_gemm::GroupDesc{};
+            gd[1].op_a = dctr_gemm::OP_T; gd[1].op_b = dctr_gemm::OP_N; gd[1].m = K; gd[1].n = B; gd[1].k = N;
+            gd[1].A = a->kernels[l]; gd[1].lda = N; gd[1].B = dz; gd[1].ldb = N; gd[1].C = dst; gd[1].ldc = ldd; gd[1].batch = 1;
+            rs = dctr_gemm::sgemm_grouped(st, gd, want_dx ? 2 : 1);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm_grouped(dW, dX) failed (%d)", (int)rs);
             int64_t g = dctr_ceil_div(kn, (int64_t)256);
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, (const float*)dw_parts, kn, n_parts,
                                a->d_kernels[l]);
+            if (!want_dx) break;
         } else {
             rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_T, N, K, B, dz, N, xin, ldx, 1.f, a->d_kernels[l], N);
             DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(dW) failed (%d)", (int)rs);
+            if (!want_dx) break;
+            rs = dctr_gemm::sgemm(st, dctr_gemm::OP_T, dctr_gemm::OP_N, K, B, N, a->kernels[l], N, dz, N, 0.f, dst, ldd);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(dX) failed (%d)", (int)rs);
         }
-        // dH_prev[B, K] = dZ W^T:  column-major  dH'(K x B) = W'(N x K)^T * dZ'(N x B)
-        const bool to_dx = l == 0;
-        if (to_dx && a->dx == nullptr) break;
-        float* dst = to_dx ? a->dx : other;
-        const int ldd = to_dx ? (int)a->dx_stride : K;
-        rs = dctr_gemm::sgemm(st, dctr_gemm::OP_T, dctr_gemm::OP_N, K, B, N, a->kernels[l], N, dz, N, 0.f, dst, ldd);
-        DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "mlp_bwd: sgemm(dX) failed (%d)", (int)rs);
         if (!to_dx) {
             // dZ_prev = dH_prev .* act'(h_prev)
             if (dice) {
