@@ -35,7 +35,7 @@ struct GroupDesc {
     int64_t stride_c;
     int batch;
     int ones_last;
-    int accumulate;             // 1: C += the product (beta = 1; not together with k_slices)
+    int accumulate;             // 1: C += the product (beta = 1); with k_slices > 1 and slice_stride_c == 0 the slices add with float atomics
     int k_slices;               // > 1: k is cut into k_slices slices (as dctr_gemm::k_slices counts them) and slice s STORES its partial
     int64_t slice_stride_c;     //      product at C + s * slice_stride_c (the caller sums the slices: deterministic, no atomics)
 };

@@ -324,10 +324,13 @@ int sgemm_grouped(hipStream_t stream, const GroupDesc* g, int n_groups) {
         Params& p = gp.p[ng];
         fill_params(p, d.op_a, d.op_b, d.m, d.n, d.k, d.A, d.lda, d.stride_a, d.B, d.ldb, d.stride_b, 0.f, d.C, d.ldc, d.stride_c);
         if (d.ones_last) p.ones_row = d.n - 1;
-        DCTR_REQUIRE(!(d.accumulate && d.k_slices > 1), DCTR_E_UNSUPPORTED, "sgemm_grouped[%d]: accumulate with k_slices", i);
+        // k_slices with slice_stride_c == 0: the slices ADD their products to the one C with float atomics — beta = 1 semantics
+        // (accumulate must be set: C holds what is added to)
+        DCTR_REQUIRE(!(d.k_slices > 1 && (d.slice_stride_c == 0) != (d.accumulate != 0)), DCTR_E_UNSUPPORTED,
+                     "sgemm_grouped[%d]: k_slices store to their own C (slice_stride_c, no accumulate) or add atomically to one C (accumulate)", i);
         p.accumulate = d.accumulate ? 1 : 0;
         int slices = 1;
-        if (d.k_slices > 1 && d.k > 0) {                       // k cut into slices of a multiple of 32, each stored to its own C
+        if (d.k_slices > 1 && d.k > 0) {                       // k cut into slices of a multiple of 32, each stored to its own C (or added)
             p.kchunk = (int)(dctr_ceil_div(dctr_ceil_div(d.k, d.k_slices), 32) * 32);
             slices = (int)dctr_ceil_div(d.k, p.kchunk);
             DCTR_REQUIRE(slices == d.k_slices, DCTR_E_DIM, "sgemm_grouped[%d]: k=%d does not cut into %d slices of a multiple of 32 (use dctr_gemm::k_slices)", i, d.k, d.k_slices);

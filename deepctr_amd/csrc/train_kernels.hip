@@ -2981,9 +2981,10 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void
                            a->bias + (size_t)l * d, B, d, ne, ws + m.DS, gx, ws + m.DX0, a->dbias + (size_t)l * d);
         hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)(B < COLSUM_MAX_WG ? B : COLSUM_MAX_WG), (unsigned)((d + 255) / 256)), dim3(256),
                            0, st, (const float*)g, x0, B, d, a->dbias + (size_t)l * d);
-        // d gating[e][i] += sum_b ds[b, e] x_l[b, i]:  column-major dG'(d x ne) += x_l'(d x B) ds'(ne x B)^T
-        MIX_GEMM(N_, T_, d, ne, Bi, xl, d, (const float*)(ws + m.DS), ne, &one, a->dgating, d);
         {
+            // Independent products share a launch (dctr_gemm::sgemm_grouped): {d gating, dU, dv2}, {dC, dv1}, {dV, gx of expert 0} —
+            // 13 GEMM launches per layer were 6 + ne; the small outputs under the batch-long reduction (d gating, dU, dC, dV) add
+            // their k slices with float atomics as dctr_gemm::sgemm does for such shapes
             const size_t l0 = (size_t)l * ne;
             const float* Ul = a->U + l0 * d * r;
             const float* Vl = a->V + l0 * d * r;
@@ -2993,15 +2994,43 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void
             float* t = ws + m.T;
             float* dv2 = ws + m.DV2;
             float* dv1 = ws + m.DV1;
+            const int ks = dctr_gemm::k_slices(Bi, 256) > 16 ? 16 : dctr_gemm::k_slices(Bi, 256);
+            auto desc = [&](dctr_gemm::Op ta, dctr_gemm::Op tb, int mm, int nn, int kk, const float* A_, int lda, int64_t sa, const float* B_,
+                            int ldb, int64_t sb, float* C_, int ldc, int64_t sc, int batch, bool acc, bool long_k) {
+                dctr_gemm::GroupDesc gd_ = dctr_gemm::GroupDesc{};
+                gd_.op_a = ta; gd_.op_b = tb; gd_.m = mm; gd_.n = nn; gd_.k = kk; gd_.A = A_; gd_.lda = lda; gd_.stride_a = sa;
+                gd_.B = B_; gd_.ldb = ldb; gd_.stride_b = sb; gd_.C = C_; gd_.ldc = ldc; gd_.stride_c = sc; gd_.batch = batch;
+                gd_.accumulate = acc ? 1 : 0;
+                if (long_k && acc) gd_.k_slices = dctr_gemm::k_slices(kk, (kk + ks - 1) / ks);
+                return gd_;
+            };
             hipLaunchKernelGGL(mix_t_all_kernel, grid(ne * Bd), dim3(256), 0, st, (const float*)g, x0, p, ne, B, d, t);
-            MIX_BGEMM(N_, T_, r, d, Bi, v2, r, Br, (const float*)t, d, Bd, &one, a->dU + l0 * d * r, r, (int64_t)d * r);   // dU[i][j] += sum_b t[b,i] v2[b,j]
-            MIX_BGEMM(N_, N_, r, Bi, d, Ul, r, (int64_t)d * r, (const float*)t, d, Bd, &zero, dv2, r, Br);                 // dv2[b,j] = sum_i t[b,i] U[i][j]
+            dctr_gemm::GroupDesc g1[3] = {
+                // d gating[e][i] += sum_b ds[b, e] x_l[b, i]:  column-major dG'(d x ne) += x_l'(d x B) ds'(ne x B)^T
+                desc(N_, T_, d, ne, Bi, xl, d, 0, (const float*)(ws + m.DS), ne, 0, a->dgating, d, 0, 1, true, true),
+                // dU[i][j] += sum_b t[b,i] v2[b,j]
+                desc(N_, T_, r, d, Bi, v2, r, Br, (const float*)t, d, Bd, a->dU + l0 * d * r, r, (int64_t)d * r, ne, true, true),
+                // dv2[b,j] = sum_i t[b,i] U[i][j]
+                desc(N_, N_, r, Bi, d, Ul, r, (int64_t)d * r, (const float*)t, d, Bd, dv2, r, Br, ne, false, false)};
+            int rsg = dctr_gemm::sgemm_grouped(st, g1, 3);
+            DCTR_REQUIRE(rsg == 0, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: sgemm_grouped(1) failed (%d)", rsg);
             hipLaunchKernelGGL(mix_tanh_bwd_kernel, grid(ne * Br), dim3(256), 0, st, dv2, v2, ne * Br);                    // a2
-            MIX_BGEMM(N_, T_, r, r, Bi, v1, r, Br, (const float*)dv2, r, Br, &one, a->dC + l0 * r * r, r, (int64_t)r * r); // dC[j][k] += sum_b a2[b,j] v1[b,k]
-            MIX_BGEMM(N_, N_, r, Bi, r, Cl, r, (int64_t)r * r, (const float*)dv2, r, Br, &zero, dv1, r, Br);               // dv1[b,k] = sum_j a2[b,j] C[j][k]
+            dctr_gemm::GroupDesc g2[2] = {
+                // dC[j][k] += sum_b a2[b,j] v1[b,k]
+                desc(N_, T_, r, r, Bi, v1, r, Br, (const float*)dv2, r, Br, a->dC + l0 * r * r, r, (int64_t)r * r, ne, true, true),
+                // dv1[b,k] = sum_j a2[b,j] C[j][k]
+                desc(N_, N_, r, Bi, r, Cl, r, (int64_t)r * r, (const float*)dv2, r, Br, dv1, r, Br, ne, false, false)};
+            rsg = dctr_gemm::sgemm_grouped(st, g2, 2);
+            DCTR_REQUIRE(rsg == 0, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: sgemm_grouped(2) failed (%d)", rsg);
             hipLaunchKernelGGL(mix_tanh_bwd_kernel, grid(ne * Br), dim3(256), 0, st, dv1, v1, ne * Br);                    // a1
-            MIX_BGEMM(N_, T_, r, d, Bi, (const float*)dv1, r, Br, xl, d, 0, &one, a->dV + l0 * d * r, r, (int64_t)d * r);  // dV[i][j] += sum_b x_l[b,i] a1[b,j]
-            for (int e = 0; e < ne; ++e)                                   // gx[b,i] += sum_j a1[b,j] V[i][j]: one output, expert by expert
+            dctr_gemm::GroupDesc g3[2] = {
+                // dV[i][j] += sum_b x_l[b,i] a1[b,j]
+                desc(N_, T_, r, d, Bi, (const float*)dv1, r, Br, xl, d, 0, a->dV + l0 * d * r, r, (int64_t)d * r, ne, true, true),
+                // gx[b,i] += sum_j a1[b,j] V[i][j]: one output, expert by expert — expert 0 here, the others behind it
+                desc(T_, N_, d, Bi, r, Vl, r, 0, (const float*)dv1, r, 0, gx, d, 0, 1, true, false)};
+            rsg = dctr_gemm::sgemm_grouped(st, g3, 2);
+            DCTR_REQUIRE(rsg == 0, DCTR_E_UNSUPPORTED, "crossnet_mix_bwd: sgemm_grouped(3) failed (%d)", rsg);
+            for (int e = 1; e < ne; ++e)
                 MIX_GEMM(T_, N_, d, Bi, r, Vl + (size_t)e * d * r, r, (const float*)(dv1 + (size_t)e * Br), r, &one, gx, d);
         }
         float* tmp = g;
