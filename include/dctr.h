@@ -734,7 +734,7 @@ int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* args, void* stream
 
 /* backward of dctr_cin_fwd (interaction.py:277-325).  Layers with H % 16 == 0, H <= 128, F0 <= 32, Fk <= 64 run z-free on two
  * MFMA kernels (filter gradient with x0*xk formed in registers; dz = dpre W^T contracted with x0 / xk tile by tile); other
- * shapes materialise z in the workspace and use rocBLAS sgemm.  The layer activations come from the forward call
+ * shapes materialise z in the workspace and use dctr_sgemm's kernel.  The layer activations come from the forward call
  * (fwd->save_y -> saved_y) or are recomputed by re-running the forward kernel into the workspace. */
 typedef struct {
     const dctr_cin_args_t* fwd;   /* the forward call's arguments (out / workspace unused)                */
