@@ -522,11 +522,16 @@ class EmbeddingStage(object):
                 self._dl_pos = torch.as_tensor(pos, dtype=torch.int64, device=self.device)
                 self._dl_src = torch.as_tensor([self.dense_lin_rows[i] for i in pos], dtype=torch.int64, device=self.device)
                 self._dl_all = len(pos) == self.n_dense
+                # every dense column feeds the linear part, in the kernel's own row order: the kernel IS the permuted copy
+                self._dl_identity = self._dl_all and [self.dense_lin_rows[i] for i in pos] == list(range(self.n_dense))
                 self._dl_buf = torch.zeros(self.n_dense, dtype=torch.float32, device=self.device)
             k = linear_kernel.reshape(-1)
             if k.requires_grad and torch.is_grad_enabled():
                 # the torch-autograd training step (training.model_logits) differentiates through this buffer
                 self.dense_lin_w = torch.zeros_like(self._dl_buf).index_copy(0, self._dl_pos, k.index_select(0, self._dl_src))
+                return
+            if self._dl_identity and k.numel() == self.n_dense and k.is_contiguous() and k.dtype == torch.float32:
+                self.dense_lin_w = k                  # (no launch; the training step updates the kernel in place)
                 return
             if self._dl_all:
                 torch.index_select(k, 0, self._dl_src, out=self._dl_buf)

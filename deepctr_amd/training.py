@@ -371,14 +371,16 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
     for ep in range(epochs):
         if shuffle:
             permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
-        tot = torch.zeros(1, dtype=torch.float64, device=model.device)
-        for lo in range(0, n_tr, bs):
+        # the epoch's loss: dctr_bce_grad adds every batch's summed loss into that batch's element of ONE device vector (summed in
+        # float64 at the end of the epoch; step() refreshes the weight-derived buffers itself) — no per-step zero / divide / add launches
+        # and no host round trip for it
+        n_steps = (n_tr + bs - 1) // bs
+        tot = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=model.device)
+        for i, lo in enumerate(range(0, n_tr, bs)):
             hi = min(n_tr, lo + bs)
-            model._begin()
-            loss = tr.step(staged, int(lo), int(hi), yt[lo:hi])
-            tot += loss.double() * (hi - lo)
+            tr.step(staged, int(lo), int(hi), yt[lo:hi], loss_acc=tot[i:i + 1])
         model._check_status()
-        if epoch_end(ep, float(tot.item()) / max(n_tr, 1)):
+        if epoch_end(ep, float(tot.double().sum().item()) / max(n_tr, 1)):
             break
     return epoch_end.finish()
 

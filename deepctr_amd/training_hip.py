@@ -370,8 +370,10 @@ class HipTrainer(object):
             self._side_used = False
 
     def _loss_grad(self, buf, y, binary):
-        buf["loss"].zero_()
-        ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"],
+        acc = getattr(self, "_loss_acc", None)        # fit(): the epoch's running sum of per-sample losses (no per-step launches for it)
+        if acc is None:
+            buf["loss"].zero_()
+        ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"] if acc is None else acc,
                      dlogit_sum=None if self.p_gbias is None else self.p_gbias.g, task="binary" if binary else "regression")
 
     def _deepfm_forward_backward(self, ws, buf, y, binary):
@@ -585,10 +587,13 @@ class HipTrainer(object):
                             save_u=None if su is None else su.data_ptr(), save_x=None if sx is None else sx.data_ptr())
         _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
 
-    def step(self, staged, lo, hi, y, apply=True):
+    def step(self, staged, lo, hi, y, apply=True, loss_acc=None):
         """One optimizer step on rows [lo, hi) of the staged inputs; y: device float tensor [hi-lo].  Returns the mean
         loss of the batch BEFORE the update (a device tensor; no host synchronisation here).  ``apply=False`` stops
-        after the backward pass and leaves the gradients in the ``g`` buffers (tests)."""
+        after the backward pass and leaves the gradients in the ``g`` buffers (tests).  ``loss_acc`` (a device float32 tensor of
+        one element): the batch's SUMMED loss is added to it instead — no per-step zero / divide launches, nothing returned
+        (fit() keeps one accumulator per epoch)."""
+        self._loss_acc = loss_acc
         model, sp = self.model, self.model.stage_plan
         model._begin()                      # weight-derived forward buffers follow the last update
         self.n_steps += 1
@@ -633,11 +638,11 @@ class HipTrainer(object):
                                g_table=pt.g, g_lin_table=None if pl is None else pl.g, touched=pt.touched)
         self._join_side()
         if not apply:
-            return buf["loss"] / B
+            return None if loss_acc is not None else buf["loss"] / B
         # optimizer: one launch over every parameter
         self.t += 1
         lr = self.lr
         if self.kind == "adam":
             lr = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         ops.opt_multi(self.kind, self.segs, self.n_segs, self.max_n, lr, self.b1, self.b2, self.eps)
-        return buf["loss"] / B
+        return None if loss_acc is not None else buf["loss"] / B

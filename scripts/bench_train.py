@@ -61,13 +61,15 @@ def main():
         staged = model.stage(feed)
         for i in range(4):
             tr.step(staged, (i % ring) * B, (i % ring) * B + B, y[(i % ring) * B:(i % ring) * B + B])
+        acc = torch.zeros(args.steps, dtype=torch.float32, device=dev)   # as fit() runs the step: one loss element per step, summed per epoch
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             lo = (i % ring) * B
-            loss = tr.step(staged, lo, lo + B, y[lo:lo + B])
+            tr.step(staged, lo, lo + B, y[lo:lo + B], loss_acc=acc[i:i + 1])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
+        loss = acc.double().sum() / (args.steps * B)
         model._check_status()
         # Adam traffic: w, m, v, g read + w, m, v, g written per parameter element
         print(("C4 " if din else "C2 ") + args.model + " train step  B=%-6d %8.1f us/step  %8.2f M samples/s   (%.1f M parameters: Adam moves %.2f GB/step = %.0f us at 8 TB/s; loss %.4f)"
