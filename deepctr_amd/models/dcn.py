@@ -41,7 +41,10 @@ class _DCN(FeatureModel):
 
     def _begin(self):
         super(_DCN, self)._begin()
-        self._cross_packed = self.cross.packed() if self.cross is not None else None
+        # (the HIP training step works on its own packed parameter tensors — the layer's weights are views of them — and reads
+        #  nothing of this: no torch.stack launches per step there)
+        if not getattr(self, "_trainer_owns_cross", False):
+            self._cross_packed = self.cross.packed() if self.cross is not None else None
         self._cross_ws = getattr(self, "_cross_ws", None)
         self._cross_ws_fresh = False        # the re-packed kernel rows in _cross_ws follow THIS call's weights from its first launch on
 

@@ -595,7 +595,11 @@ class HipTrainer(object):
         (fit() keeps one accumulator per epoch)."""
         self._loss_acc = loss_acc
         model, sp = self.model, self.model.stage_plan
-        model._begin()                      # weight-derived forward buffers follow the last update
+        model._trainer_owns_cross = self.is_dcn            # (_DCN._begin: no re-packing of the cross weights for this call)
+        try:
+            model._begin()                  # weight-derived forward buffers follow the last update
+        finally:
+            model._trainer_owns_cross = False
         self.n_steps += 1
         B = hi - lo
         buf = self._buffers(B)
