@@ -7,8 +7,9 @@ lookup scatter kernels; Dice as tf.keras runs it under fit(): ``dctr_dice_train_
 ``dctr_mlp_bwd``), sequence features included: forward = ``dctr_embed_pool`` per sequence feature + ``dctr_embed_gather_fm`` +
 ``dctr_mlp_fwd`` (activations saved), then ``dctr_bce_grad`` → ``dctr_mlp_bwd`` → ``dctr_embed_gather_fm_bwd`` →
 ``dctr_embed_pool_bwd`` → ``dctr_opt_multi`` (one launch over every parameter).  No torch autograd, no torch
-optimizer: PyTorch only owns the buffers.  Options outside that (dropout, ``dnn_use_bn``, softmax-normalised DIN attention,
-several FM groups) keep the torch-autograd step of ``training.py``.
+optimizer: PyTorch only owns the buffers.  ``dnn_dropout``, ``dnn_use_bn``, a Dice DNN, softmax-normalised DIN attention and
+several FM groups run on this step as well (layer-by-layer forms of the DNN); ``afm_dropout`` and a PReLU DNN keep the
+torch-autograd step of ``training.py``.
 
 Semantics follow tf.keras as the reference uses it (``model.compile("adam", "binary_crossentropy")``,
 examples/run_classification_criteo.py:44-50; also "adagrad", "rmsprop", "sgd" by name with tf.keras' defaults): Adam lr
@@ -59,7 +60,14 @@ def supported(model):
         return False
     if dnn is not None:
         # dnn_dropout > 0 / dnn_use_bn=True: the DNN runs layer by layer (dctr_dnn_train_layer_fwd / _bwd behind each dense part)
-        if dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or not dnn.kernels:
+        # dnn_activation="dice" (layers/activation.py:37-64 under training=True): layer by layer as well — dctr_dice_train_fwd behind
+        # each dense part, dctr_mlp_bwd's Dice form with the batch statistics and the saved pre-activations on the way back
+        if dnn.activation in ("dice", "Dice"):
+            if getattr(dnn, "dropout_rate", 0) or getattr(dnn, "bn_layers", None) or not dnn.kernels:
+                return False
+            if getattr(dnn, "output_activation", None) not in (None, dnn.activation) or dnn.dice_params() is None:
+                return False
+        elif dnn.activation not in ("relu", "linear", "sigmoid", "tanh") or not dnn.kernels:
             return False
         if getattr(dnn, "output_activation", None) not in (None, dnn.activation):
             return False
@@ -191,6 +199,8 @@ class HipTrainer(object):
         self.drop_rate = float(getattr(dnn, "dropout_rate", 0) or 0) if dnn is not None else 0.0
         self.bn_layers = list(getattr(dnn, "bn_layers", None) or []) if dnn is not None else []
         self.slow_dnn = bool(self.drop_rate > 0 or self.bn_layers)
+        self.dice_dnn = dnn is not None and dnn.activation in ("dice", "Dice")
+        self.p_dice_alpha = [param(d[0]) for d in dnn.dice_params()] if self.dice_dnn else []
         self.p_bn = [(param(b.w("gamma")) if b.scale else None, param(b.w("beta")) if b.center else None) for b in self.bn_layers]
         self.drop_base = int(getattr(dnn, "seed", 1024) or 0) * 0x9E3779B1 + 12345 if dnn is not None else 0
         self.n_steps = 0            # forward passes so far: the dropout masks of a step are a function of (drop_base, n_steps, layer)
@@ -243,7 +253,7 @@ class HipTrainer(object):
                           for h in self.model.cin.layer_size]
                 if (self.p_cin_f and B * self.model.cin_dim * max(self.model.cin.layer_size) * 4 < 2 ** 31) else None,
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
-                "pre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if self.slow_dnn else None,
+                "pre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if (self.slow_dnn or self.dice_dnn) else None,
                 "dpre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if self.slow_dnn else None,
                 "bn_stat": [(torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev))
                             for n in units] if self.bn_layers else None,
@@ -299,6 +309,21 @@ class HipTrainer(object):
         -> out [B]; headless: the last layer's activations -> out (a 2-D view)."""
         model, dnn = self.model, self.model.dnn
         gb = None if self.p_gbias is None else self.p_gbias.w
+        if self.dice_dnn:
+            # Dice under training=True needs the statistics of ALL rows of a layer before its activation: layer by layer
+            dice = dnn.dice_params()
+            stats, xin, kin = [], x, in_dim
+            for l, (W, b) in enumerate(zip(dnn.kernels, dnn.biases)):
+                ops.mlp(xin, [W], [b], "linear", in_dim=kin, out=buf["pre"][l])
+                alpha, mmean, mvar = dice[l]
+                stats.append(ops.dice_train_fwd(buf["pre"][l], alpha, mmean, mvar, buf["acts"][l], eps=1e-9, momentum=BN_MOMENTUM))
+                xin, kin = buf["acts"][l], W.shape[1]
+            buf["dice_batch"] = stats
+            if head:
+                ops.mlp(xin, [], [], "linear", head_w=self.p_head.w, add=list(add), global_bias=gb, sigmoid_out=binary, in_dim=kin, out=out)
+            else:
+                out[:, :kin].copy_(xin)             # (the stack's tail may carry alignment padding)
+            return
         if not self.slow_dnn:
             if head:
                 ops.mlp(x, dnn.kernels, dnn.biases, dnn.activation, head_w=self.p_head.w, add=list(add), global_bias=gb,
@@ -323,6 +348,11 @@ class HipTrainer(object):
         headless ``d_out`` (2-D view) = gradient w.r.t. the last layer's activations."""
         model, dnn = self.model, self.model.dnn
         dk, db = [p.g for p in self.p_kernels], [p.g for p in self.p_biases]
+        if self.dice_dnn:
+            ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], "dice", self.p_head.w if dlogit is not None else None, dlogit, dk, db,
+                        self.p_head.g if dlogit is not None else None, dx=dx, d_out=d_out, biases=dnn.biases, dice=dnn.dice_params(),
+                        d_dice_alpha=[p.g for p in self.p_dice_alpha], dice_batch=buf["dice_batch"], saved_z=buf["pre"])
+            return
         if not self.slow_dnn:
             # the weight-gradient launches go to a second stream (dctr_mlp_bwd_args_t.dw_stream): they run beside the embedding
             # scatter / CIN / CrossNet backward that follow on the main stream; step() joins before the optimizer

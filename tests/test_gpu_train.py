@@ -111,6 +111,60 @@ def _feed(rng, cols, n, hashed=False):
     return feed
 
 
+@pytest.mark.parametrize("kind", ["DeepFM", "DCN"])
+def test_hip_training_with_a_dice_dnn_matches_torch_autograd(device, kind):
+    """dnn_activation="dice" on the HIP step (reference layers/activation.py:37-64 as tf.keras runs it under fit(): the Dice layer's
+    BatchNormalization normalises with the statistics of the batch, gradients flow through them, the stored statistics move): every
+    gradient incl. the Dice alphas against torch autograd over training.model_logits(training=True); DCN takes the headless form."""
+    from deepctr_amd import models, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.training_hip import HipTrainer, supported
+    from tests.test_gpu_models import _randomise
+    rng = np.random.RandomState(31)
+    cols = [SparseFeat("a", 40, 8), SparseFeat("b", 7, 8), SparseFeat("c", 300, 8, use_hash=True), DenseFeat("d", 2)]
+    kw = dict(dnn_hidden_units=(24, 12), dnn_activation="dice", device=device)
+    model = models.DeepFM(cols, cols, **kw) if kind == "DeepFM" else models.DCN(cols, cols, cross_num=2, **kw)
+    _randomise(model, rng)
+    assert supported(model)
+    n = 211
+    feed = {"a": rng.randint(0, 40, n).astype(np.int32), "b": rng.randint(0, 7, n).astype(np.int32),
+            "c": rng.randint(0, 2 ** 31 - 1, n).astype(np.int32), "d": rng.rand(n, 2).astype(np.float32)}
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    staged = model.stage(feed)
+    tr = HipTrainer(model)
+    assert tr.dice_dnn and len(tr.p_dice_alpha) == 2
+    stats0 = [(d[1].clone(), d[2].clone()) for d in model.dnn.dice_params()]
+    yt = dev(y, device)
+    loss = tr.step(staged, 0, n, yt, apply=False)
+    moved = [(d[1].clone(), d[2].clone()) for d in model.dnn.dice_params()]
+    for (m0, v0), (d_) in zip(stats0, model.dnn.dice_params()):           # the checker moves them once more from the same start
+        d_[1].copy_(m0)
+        d_[2].copy_(v0)
+    params = [p.w for p in tr.params]
+    for t in params:
+        t.requires_grad_(True)
+    try:
+        if tr.is_dcn:
+            tr.bind_cross_views()        # the per-layer views must descend from the grad-tracking packed tensors
+        model._begin()
+        logit = training.model_logits(model, staged, 0, n, training=True)
+        ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt)
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    finally:
+        for t in params:
+            t.requires_grad_(False)
+        if tr.is_dcn:
+            tr.bind_cross_views()
+    assert_close(loss.cpu().numpy(), [float(ref_loss.detach())], rtol=1e-4, atol=1e-6, what="loss")
+    for (m1, v1), d_ in zip(moved, model.dnn.dice_params()):
+        assert_close(m1.cpu().numpy(), d_[1].cpu().numpy(), rtol=1e-4, atol=1e-6, what="moved mean")
+        assert_close(v1.cpu().numpy(), d_[2].cpu().numpy(), rtol=2e-4, atol=1e-6, what="moved variance")
+    for p, gref in zip(tr.params, grads):
+        gref = torch.zeros_like(p.w) if gref is None else gref
+        scale = max(float(gref.abs().max()), 1e-4)
+        assert_close(p.g.cpu().numpy() / scale, gref.cpu().numpy() / scale, rtol=2e-4, atol=5e-6, what="grad of %s (scaled by %.3g)" % (tuple(p.w.shape), scale))
+
+
 @pytest.mark.parametrize("E,hashed,kind", [(16, False, "DeepFM"), (8, True, "DeepFM"), (32, False, "DeepFM"),
                                            (16, True, "WDL"), (16, False, "FNN")])
 def test_hip_training_gradients_match_torch_autograd(device, E, hashed, kind):
