@@ -244,3 +244,36 @@ def test_cin_bwd_workspace_is_z_free_on_the_mfma_shapes():
     fused, fallback = need(4096, (128, 128)), need(4096, (120, 120))
     assert fused < 0.4 * z_layers, (fused, z_layers)
     assert fallback > z_layers
+
+
+def test_training_descriptor_arrays_pack_like_the_header():
+    """Host logic of the ABI-6 training descriptors (no GPU): ops.make_adam_segments / make_field_grads lay dctr_adam_seg_t /
+    dctr_field_grad_t arrays out as the header declares them — pointer, length, l2 and the optional touched bytes per entry —
+    and reject touched bytes that do not cover a parameter's 16-B groups."""
+    import ctypes
+    import torch
+    from deepctr_amd import _C, ops
+    cpu = torch.device("cpu")
+    w = [torch.zeros(40, 16), torch.zeros(7, 4), torch.zeros(5)]
+    m, v, g = ([torch.zeros_like(t) for t in w] for _ in range(3))
+    tch = [torch.zeros(40 * 16 // 4, dtype=torch.uint8), None, None]
+    segs, n, mx = ops.make_adam_segments([(w[i], m[i], v[i], g[i], 0.5 * i, tch[i]) for i in range(3)], cpu)
+    assert (n, mx) == (3, 640) and segs.numel() == 3 * ctypes.sizeof(_C.AdamSeg)
+    arr = (_C.AdamSeg * 3).from_buffer_copy(bytes(segs.numpy()))
+    for i in range(3):
+        assert (arr[i].w, arr[i].m, arr[i].v, arr[i].g) == (w[i].data_ptr(), m[i].data_ptr(), v[i].data_ptr(), g[i].data_ptr())
+        assert arr[i].n == w[i].numel() and abs(arr[i].l2 - 0.5 * i) < 1e-7
+        assert (arr[i].touched or 0) == (0 if tch[i] is None else tch[i].data_ptr())
+    # five-tuples (no touched entry) stay valid: the dense step of ABI 5
+    segs5, _, _ = ops.make_adam_segments([(w[0], m[0], v[0], g[0], 0.0)], cpu)
+    assert (_C.AdamSeg * 1).from_buffer_copy(bytes(segs5.numpy()))[0].touched in (None, 0)
+    for bad in (torch.zeros(10, dtype=torch.uint8), torch.zeros(160, dtype=torch.float32)):
+        with pytest.raises(ValueError):
+            ops.make_adam_segments([(w[0], m[0], v[0], g[0], 0.0, bad)], cpu)
+    with pytest.raises(ValueError):                       # a parameter whose length is no multiple of 4 has no 16-B groups to flag
+        ops.make_adam_segments([(w[2], m[2], v[2], g[2], 0.0, torch.zeros(1, dtype=torch.uint8))], cpu)
+    fg = ops.make_field_grads([(g[0], None, tch[0]), (None, g[2], tch[0]), (g[1], g[2])], cpu)
+    fa = (_C.FieldGrad * 3).from_buffer_copy(bytes(fg.numpy()))
+    assert (fa[0].g_table, fa[0].g_lin_table or 0, fa[0].touched) == (g[0].data_ptr(), 0, tch[0].data_ptr())
+    assert (fa[1].g_table or 0, fa[1].g_lin_table, fa[1].touched or 0) == (0, g[2].data_ptr(), 0)      # no table gradient: no bytes either
+    assert (fa[2].g_table, fa[2].g_lin_table, fa[2].touched or 0) == (g[1].data_ptr(), g[2].data_ptr(), 0)
