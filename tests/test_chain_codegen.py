@@ -79,3 +79,38 @@ def test_cin_kernels_register_budget(tmp_path):
             assert scratch <= 64 and vgprs <= 256, (name, scratch, vgprs)
             seen += 1
     assert seen >= 16
+
+
+def test_training_step_kernels_register_budget(tmp_path):
+    """The kernels the third part of round 3 added to the training step, and the forward kernels they share templates with:
+    * csrc/mlp_bwd_kernels.hip — the backward chain runs on mlp_device.h's whole-MLP machinery: no scratch, and the 16- / 32-row
+      shapes must keep two 8-wave workgroups per CU (<= 128 VGPRs), as the forward kernels of mlp_kernels_rt{1,2}.hip do — the
+      backward epilogue (ACT_BWD) is compiled into its own kernels so that it cannot push the inference kernels over that line;
+    * csrc/gemm_kernels.hip — plain and grouped f32 MFMA GEMM: accumulators (128 VGPRs at 128 x 128 tiles) stay out of scratch;
+    * csrc/interaction_kernels.hip — cross_matrix_kernel<1 / 2>: one 8-wave workgroup per CU (its LDS tiles), i.e. two waves per
+      SIMD: three pipeline stages of (both row tiles') operands in registers without scratch, <= 256 VGPRs."""
+    bwd = _resource_usage(tmp_path, "mlp_bwd_kernels.hip")
+    seen = 0
+    for name, (scratch, vgprs) in bwd.items():
+        if "mlp_bwd_kernel" in name:
+            seen += 1
+            assert scratch == 0, (name, scratch)
+            if "ILi4E" not in name:                      # RT = 1 / 2: four waves per SIMD
+                assert vgprs <= 128, (name, vgprs)
+    assert seen == 3
+    for tu in ("mlp_kernels_rt1.hip", "mlp_kernels_rt2.hip"):
+        for name, (scratch, vgprs) in _resource_usage(tmp_path, tu).items():
+            if "mlp_kernel" in name:
+                assert scratch == 0 and vgprs <= 128, (tu, name, scratch, vgprs)
+    gemm = _resource_usage(tmp_path, "gemm_kernels.hip")
+    seen = 0
+    for name, (scratch, vgprs) in gemm.items():
+        if "gemm_kernel" in name or "gemm_grouped_kernel" in name:
+            seen += 1
+            assert scratch == 0 and vgprs <= 256, (name, scratch, vgprs)
+    assert seen >= 5
+    inter = _resource_usage(tmp_path, "interaction_kernels.hip")
+    cross = {n: v for n, v in inter.items() if "cross_matrix_kernel" in n}
+    assert len(cross) == 2
+    for name, (scratch, vgprs) in cross.items():
+        assert scratch == 0 and vgprs <= 256, (name, scratch, vgprs)
