@@ -23,6 +23,8 @@ namespace dctr_chain {      // (the lab links the 256-128-64 instantiations only
 int launch_r2w8_m41(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m22(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m21(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+size_t bf3_workspace_bytes(int) { return 0; }
+int launch_r2w8_m42_bf3(const ChainParams&, int, void*, bool, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 }
 #include <algorithm>
 #include <cmath>
@@ -149,6 +151,22 @@ int main(int argc, char** argv) {
         double m = 0; int nn = 0;
         for (int64_t b = 0; b < Ba; ++b) { if (!(a1[b] == a1[b])) ++nn; m = std::max(m, fabs((double)a0[b] - a1[b])); }
         printf("auto split, %lld rows: max |diff| vs mlp_kernel<2> %.3e, NaN rows %d, tail untouched: %s\n", (long long)Ba, m, nn, (a1[Ba] != a1[Ba]) ? "yes" : "NO");
+    }
+    {   // the tail phase against the forced 256-row shape: the same bits (every phase walks k in the same order)
+        for (int64_t Bt : {int64_t(81920), int64_t(65536 + 16384 - 77), int64_t(65536 + 100), int64_t(65536 + 32768 - 5), int64_t(131072 + 16384)}) {
+            CK(hipMemset(y0, 0xff, BMAX * 4)); CK(hipMemset(y1, 0xff, BMAX * 4));
+            if (run(Bt, 256, y0, 0) || run(Bt, 0, y1, 0)) return 1;
+            CK(hipStreamSynchronize(st));
+            std::vector<uint32_t> b0(Bt + 8), b1(Bt + 8);
+            CK(hipMemcpy(b0.data(), y0, (Bt + 8) * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b1.data(), y1, (Bt + 8) * 4, hipMemcpyDeviceToHost));
+            int64_t nd = 0, firstd = -1;
+            for (int64_t b = 0; b < Bt; ++b) if (b0[b] != b1[b]) { if (firstd < 0) firstd = b; ++nd; }
+            int64_t pr[4]; int32_t pw[4];
+            const int np = dctr_chain::plan(Bt, 0, pr, pw, 4);
+            printf("tail vs forced 256-row passes, %7lld rows (plan:", (long long)Bt);
+            for (int i = 0; i < np; ++i) printf(" %lld x %d", (long long)pr[i], pw[i]);
+            printf("): %lld rows differ (first %lld), tail untouched: %s\n", (long long)nd, (long long)firstd, (b1[Bt] == 0xffffffffu) ? "yes" : "NO");
+        }
     }
 #ifdef DCTR_CHAIN_LAB_WGTS
     // ---- where an isolated launch spends its time: wall-clock stamps (100 MHz) and shader-cycle stamps of every workgroup — kernel
