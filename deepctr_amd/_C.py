@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
@@ -78,7 +78,8 @@ class MlpArgs(ctypes.Structure):
                 ("dice_alpha", c_vp), ("dice_mean", c_vp), ("dice_var", c_vp), ("dice_eps", c_f32),
                 ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
                 ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
-                ("save_acts", c_vp), ("tile_rows", c_i32), ("precision", c_i32), ("probe", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp)]
+                ("save_acts", c_vp), ("tile_rows", c_i32), ("precision", c_i32), ("probe", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp),
+                ("cross_w", c_vp), ("cross_b", c_vp), ("cross_head", c_vp), ("cross_layers", c_i32)]
 
 
 class FieldGrad(ctypes.Structure):

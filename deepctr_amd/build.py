@@ -38,6 +38,7 @@ SOURCES = [
     "chain_kernels_r2w8_m21.hip",
     "chain_kernels_r2w4_m42.hip",
     "chain_kernels_r2w8_m42_bf3.hip",
+    "chain_kernels_r2w8_m42_x.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "cin_bwd_kernels.hip",

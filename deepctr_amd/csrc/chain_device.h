@@ -112,6 +112,9 @@ static inline size_t lds_bytes(int rt, int nw, int n_dense) {
     return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64 + park) * sizeof(float);
 }
 
+// CROSS kernels: [CROSS_NV][16 NB] zero-padded cross vectors + the CROSS_NV constants, behind everything else in LDS
+static inline int cross_lds_floats(int in_dim) { return dctr_mlp::CROSS_NV * 16 * ((in_dim + 15) >> 4) + 8; }
+
 struct ChainParams {
     const dctr_field_t* fields;
     const void* ids;
@@ -138,6 +141,13 @@ struct ChainParams {
     int64_t main_rows;
     const float* bn_scale[3];      // DNN(use_bn=True), inference form: act((x W + b) * bn_scale + bn_shift); NULL = none
     const float* bn_shift[3];
+    // CrossNet, vector parameterization, folded into the pass (kernels instantiated with CROSS; mlp_device.h: cross_logit): the
+    // L + 1 vectors w_0 .. w_{L-1}, k_c lie zero-padded in LDS at xv_off ([CROSS_NV][16 NB] floats + the CROSS_NV constants)
+    const float* cross_w;
+    const float* cross_b;
+    const float* cross_head;
+    int32_t cross_layers;
+    int32_t xv_off;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -275,7 +285,7 @@ struct ChainOff {
 
 // The passes [first, first + stride, ...) < n_pass of one phase: pass q covers rows row_base + q * (16 RT NW) ... of the launch
 // (absolute row numbers; rows >= row_end do not exist).  Called by all NW waves of the phase, with the launch parameters in LDS.
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false>
 __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
                                              const int row_end, const int first, const int stride, const int n_pass, int& oor) {
     if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
@@ -589,6 +599,25 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         }
         f32x4 sum[EB][RT];
         float sq[RT];
+        // CROSS: this lane's share of the row's dot products with the cross vectors (reduced over g after layer 0)
+        float cp[CROSS ? CROSS_NV : 1][RT];
+#pragma unroll
+        for (int v = 0; v < (CROSS ? CROSS_NV : 1); ++v)
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) cp[v][nt] = 0.f;
+        auto cross_x = [&](int b, const XBlk& X) {
+            if constexpr (CROSS) {
+                const float* xv = smem + p.xv_off + 16 * b + 4 * (opaque_lane() >> 4);
+#pragma unroll
+                for (int v = 0; v < CROSS_NV; ++v) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(xv + v * (16 * NB));
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cp[v][nt] = fmaf(X.x[nt][e], w[e], cp[v][nt]);
+                }
+            }
+        };
         float linacc = 0.f;                            // row-per-lane: this lane's field of every pair
         uint32_t idcn = 0u;                            // checked ids of the NEXT field pair
 #pragma unroll
@@ -657,6 +686,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 }                                                                                                \
                 if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
                 if (b_ < NBE) consume_x(b_, XC);                                                                 \
+                cross_x(b_, XC);                                                                                 \
             }                                                                                                    \
             CTS_STEP(b_, 2);                                                                                     \
         }
@@ -699,6 +729,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             }                                                                                                    \
             if (CHAIN_GATHER && i_ == 2 * M0 - 1) {                                                              \
                 if (b_ < NBE) consume_x(b_, XC);                                                                 \
+                cross_x(b_, XC);                                                                                 \
             }                                                                                                    \
         }
 #define CHAIN_STEP0(S, XC, XN)                                                                                   \
@@ -863,6 +894,19 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 dl += __shfl_xor(dl, 32, 64);
                 const float lin_all = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * nt + j), __builtin_bit_cast(int, lin_rows))) + dl;
                 extras[nt] = (p.fm_used ? fm : 0.f) + (p.lin_used ? lin_all : 0.f);
+                if constexpr (CROSS) {
+                    const float* cq = smem + p.xv_off + CROSS_NV * 16 * NB;
+                    float dots[CROSS_NV], cst[CROSS_NV];
+#pragma unroll
+                    for (int v = 0; v < CROSS_NV; ++v) {
+                        float d = cp[v][nt];
+                        d += __shfl_xor(d, 16, 64);
+                        d += __shfl_xor(d, 32, 64);
+                        dots[v] = d;
+                        cst[v] = cq[v];
+                    }
+                    extras[nt] += cross_logit(dots, cst, p.cross_layers);
+                }
                 const int r = row_of(pass, nt);
                 if (g == 0 && r < row_end) {
                     if (p.fm_logit != nullptr) p.fm_logit[r] = fm;
@@ -1151,7 +1195,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 }
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false>
 __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
@@ -1186,10 +1230,27 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
         }
     }
     for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
+    if constexpr (CROSS) {
+        // the cross vectors, zero-padded to whole k-blocks, and the row-independent constants of the recurrence
+        float* xv = smem + p.xv_off;
+        const int XVS = 16 * ((p.in_dim + 15) >> 4), L = p.cross_layers, d = p.in_dim;
+        for (int i = threadIdx.x; i < CROSS_NV * XVS; i += NT) {
+            const int v = i / XVS, k = i - v * XVS;
+            xv[i] = (v <= L && k < d) ? (v < L ? p.cross_w[(size_t)v * d + k] : p.cross_head[k]) : 0.f;
+        }
+        if (wave == 0) {
+            float cst[CROSS_NV];
+            cross_constants(p.cross_w, p.cross_b, p.cross_head, L, d, lane, cst);
+            if (lane == 0) {
+#pragma unroll
+                for (int v = 0; v < CROSS_NV; ++v) xv[CROSS_NV * XVS + v] = cst[v];
+            }
+        }
+    }
     __syncthreads();                                   // LDS parameters written
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
-    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
     CWG(1);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
@@ -1197,8 +1258,8 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
             // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
             __syncthreads();
             if (wave < 4)
-                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x, (int)gridDim.x,
-                                                        p.n_tail, oor);
+                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x, (int)gridDim.x,
+                                                               p.n_tail, oor);
         }
     }
     CWG(2);
@@ -1213,6 +1274,7 @@ int launch_r2w8_m41(const ChainParams& p, int E, int M2, unsigned blocks, hipStr
 int launch_r2w8_m22(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
 int launch_r2w8_m21(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
 int launch_r2w4_m42(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
+int launch_r2w8_m42x(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // CROSS (chain_kernels_r2w8_m42_x.hip)
 // the exploratory bf16 x 3 variant (chain_kernels_r2w8_m42_bf3.hip): packs the weights into `ws` (if `pack`), then launches
 size_t bf3_workspace_bytes(int in_dim);
 int launch_r2w8_m42_bf3(const ChainParams& p, int E, void* ws, bool pack, unsigned blocks, hipStream_t stream);

@@ -28,7 +28,10 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     if (!widths(a, forced ? a->tile_rows : 0, M)) return 0;
     if (a->precision != 0 && !(M[0] == 4 && M[1] == 2 && M[2] == 1 && a->tile_rows != 128 && a->bn_scale == nullptr)) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
-    if (lds_bytes(2, 8, g->n_dense > 0 ? g->n_dense : 0) > 160 * 1024) return 0;       // (dense staging area: <= 32 dense columns)
+    if (a->cross_layers > 0 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128)) return 0;   // CROSS: the m42 kernels
+    if (lds_bytes(2, 8, g->n_dense > 0 ? g->n_dense : 0) + (a->cross_layers > 0 ? cross_lds_floats(a->in_dim) * sizeof(float) : 0) >
+        160 * 1024)
+        return 0;                                                                       // (dense staging area: <= 32 dense columns)
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
     if (a->in_dim != g->n_fields * E + (g->n_dense > 0 ? g->n_dense : 0)) return 0;
     if (g->ids_stride_f < 0 || g->ids_stride_b < 0) return 0;
@@ -118,6 +121,11 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     p.global_bias = a->global_bias;
     p.y = a->y;
     p.probe = a->probe;
+    p.cross_w = a->cross_w;
+    p.cross_b = a->cross_b;
+    p.cross_head = a->cross_head;
+    p.cross_layers = a->cross_layers;
+    p.xv_off = (int32_t)(lds_bytes(2, 8, p.n_dense) / sizeof(float));
     const int E = g->uniform_dim;
     int64_t main_rows, tail_rows;
     split(p.batch, shape, &main_rows, &tail_rows);
@@ -140,6 +148,7 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
         }
         return launch_r2w8_m42_bf3(p, E, a->workspace, a->precision == 1, blocks, stream);
     }
+    if (a->cross_layers > 0) return launch_r2w8_m42x(p, E, M[2], blocks, stream);
     if (shape == 128) return launch_r2w4_m42(p, E, M[2], blocks, stream);
     if (M[0] == 4) return M[1] == 2 ? launch_r2w8_m42(p, E, M[2], blocks, stream) : launch_r2w8_m41(p, E, M[2], blocks, stream);
     return M[1] == 2 ? launch_r2w8_m22(p, E, M[2], blocks, stream) : launch_r2w8_m21(p, E, M[2], blocks, stream);

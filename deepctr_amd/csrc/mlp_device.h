@@ -54,7 +54,60 @@ struct MlpParams {
     // saved activation of that width — before it feeds the next layer (NULL: passed on as it is); deriv_act = the FORWARD's activation
     const float* deriv_h[MAX_LAYERS];
     int32_t deriv_act;
+    // CrossNet, vector parameterization, folded into the forward (below): kernels [L, in_dim], bias [L, in_dim], the cross branch's
+    // share of the head's Dense(1) kernel [in_dim]; cross_layers = L (0: none, <= CROSS_MAXL)
+    const float* cross_w;
+    const float* cross_b;
+    const float* cross_head;
+    int32_t cross_layers;
 };
+
+// ---- CrossNet (vector parameterization) inside the one-launch forward — reference layers/interaction.py:405-424 (CrossNet.call),
+// models/dcn.py:48-66 (Dense(1) over Concatenate([cross_out, deep_out])).
+//     x_{l+1} = x_0 (x_l . w_l) + b_l + x_l
+// keeps every x_l in span{x_0} + a constant vector: x_l = a_l x_0 + c_l with c_l = b_0 + .. + b_{l-1}, a_0 = 1 and
+//     s_l = x_l . w_l = a_l (x_0 . w_l) + c_l . w_l,      a_{l+1} = a_l + s_l,
+// so the whole network and the cross branch's share of DCN's final Dense(1), x_L . k_c = a_L (x_0 . k_c) + c_L . k_c, need only the
+// L + 1 dot products of the input row with w_0 .. w_{L-1}, k_c — taken from the DNN-input tile while the forward has it on chip — and
+// L + 1 row-independent constants.  Same real-number function as the layer-by-layer form (cross_vector_kernel, the oracle); in fp32
+// the two differ by rounding only (the dots are fmaf chains over the same 429 products).  Slot l < L holds w_l, slot L holds k_c.
+constexpr int CROSS_MAXL = 3;
+constexpr int CROSS_NV = CROSS_MAXL + 1;
+
+// the row-independent constants cst[l] = c_l . v_l (v_l = w_l for l < L, k_c for l = L); one wave, result in every lane
+__device__ __forceinline__ void cross_constants(const float* w, const float* b, const float* head, int L, int d, int lane,
+                                                float (&cst)[CROSS_NV]) {
+#pragma unroll
+    for (int l = 0; l < CROSS_NV; ++l) cst[l] = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        float pre = 0.f;                                   // c_l[k]
+#pragma unroll
+        for (int l = 0; l < CROSS_NV; ++l) {
+            if (l <= L) {
+                const float v = l < L ? w[(size_t)l * d + k] : head[k];
+                cst[l] = fmaf(pre, v, cst[l]);
+                if (l < L) pre += b[(size_t)l * d + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < CROSS_NV; ++l)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) cst[l] += __shfl_xor(cst[l], m, 64);
+}
+
+// the cross branch's logit of one row from its L + 1 dot products
+__device__ __forceinline__ float cross_logit(const float (&dots)[CROSS_NV], const float (&cst)[CROSS_NV], int L) {
+    float a = 1.f;
+#pragma unroll
+    for (int l = 0; l < CROSS_MAXL; ++l)
+        if (l < L) a += fmaf(a, dots[l], cst[l]);
+    float out = 0.f;
+#pragma unroll
+    for (int l = 0; l < CROSS_NV; ++l)
+        if (l == L) out = fmaf(a, dots[l], cst[l]);
+    return out;
+}
 
 constexpr int ACT_BWD = 64;     // internal epilogue mode of the backward chain (not a DCTR_ACT_* value of the ABI)
 
@@ -317,6 +370,47 @@ struct Chunk {
     int f_lo, f_hi;  // gather fields of this chunk (fused path)
     bool first, last;
 };
+
+// The dot products of this chunk's columns of the input tile with the cross vectors, added to xp [CROSS_NV][ROWS] (stored by the
+// first chunk).  Wave w takes rows w * RPW ..; lanes walk the tile positions (position i holds local column 4 (i % KQ) + i / KQ).
+template <int RT>
+__device__ __forceinline__ void cross_partial(const MlpParams& p, const float* tile, const Chunk& ck, float* xp) {
+    constexpr int ROWS = 16 * RT, RPW = ROWS / NWAVE;
+    static_assert(ROWS % NWAVE == 0, "rows per wave");
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int L = p.cross_layers, d = p.in_dim;
+    float acc[RPW][CROSS_NV];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int l = 0; l < CROSS_NV; ++l) acc[r][l] = 0.f;
+    for (int i = lane; i < 4 * ck.KQ; i += 64) {
+        const int k = ck.c0 + 4 * (i % ck.KQ) + i / ck.KQ;
+        float v[CROSS_NV];
+#pragma unroll
+        for (int l = 0; l < CROSS_NV; ++l)
+            v[l] = (l <= L && k < d) ? (l < L ? p.cross_w[(size_t)l * d + k] : p.cross_head[k]) : 0.f;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float x = tile[(wave * RPW + r) * p.lda + i];
+#pragma unroll
+            for (int l = 0; l < CROSS_NV; ++l) acc[r][l] = fmaf(x, v[l], acc[r][l]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int l = 0; l < CROSS_NV; ++l) {
+            float a = acc[r][l];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+            if (lane == 0) {
+                float* q = xp + l * ROWS + wave * RPW + r;
+                *q = ck.first ? a : *q + a;
+            }
+        }
+}
 
 // Plain path: x rows from HBM (rows beyond the batch and the K padding are zero).  Division-free mapping: wave w
 // takes rows w, w+NWAVE, ...; lanes walk the float4 groups of a row.  Loads are unconditional (clamped address,
@@ -634,6 +728,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
     float* buf0 = smem;
     float* buf1 = smem + ROWS * p.lda;
     float* extra = smem + 2 * ROWS * p.lda;                        // [2*ROWS]: per-row fused logits, dense partials
+    float* xp = extra + 2 * ROWS;                                  // [CROSS_NV][ROWS] cross dot products (cross_layers > 0 only)
     const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LAB_TS(0);
@@ -647,6 +742,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
     if (p.k_split == 0) {
         const Chunk ck{0, pad64(p.in_dim) / 4, 0, n_fields, true, true};
         produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);       // partial sums live in the (still unused) 2nd tile
+        if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp);
         LAB_TS(1);
     } else {
         // layer 0 in two K-halves: every wave owns ONE wave-tile of the layer output (host guarantees it) and keeps
@@ -667,6 +763,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         {
             const Chunk ck{0, cw0 / 4, 0, f_mid, true, false};
             produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
+            if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp);
             LAB_TS(1);
             if (wave < n_tiles) {
                 if (wide) tile_gemm_pipe<2, RT, SD>(buf0, p.lda, cw0 / 4, cw0, W0, N, n_base, acc2);
@@ -677,6 +774,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         {
             const Chunk ck{cw0, cw1 / 4, f_mid, n_fields, false, true};
             produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
+            if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp);
             if (wave < n_tiles) {
                 const int k_rows = p.in_dim - cw0;
                 const float* W = W0 + (size_t)cw0 * N;
@@ -729,6 +827,8 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         // logit[row] = h[row,:] . head_w (+ extra logits + global bias), sigmoid for task == binary
         const int part = threadIdx.x & 15;
         const int KQh = pad64(K) / 4;
+        float xcst[CROSS_NV];
+        if (p.cross_layers > 0) cross_constants(p.cross_w, p.cross_b, p.cross_head, p.cross_layers, p.in_dim, threadIdx.x & 63, xcst);
         for (int row = threadIdx.x >> 4; row < ROWS; row += NTHR / 16) {
             float acc = 0.f;
             for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);
@@ -738,6 +838,12 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
             if (part == 0 && b < p.batch) {
                 float v = acc;
                 if (fg.lpr != 0) v += extra[row];
+                if (p.cross_layers > 0) {
+                    float dots[CROSS_NV];
+#pragma unroll
+                    for (int l = 0; l < CROSS_NV; ++l) dots[l] = xp[l * ROWS + row];
+                    v += cross_logit(dots, xcst, p.cross_layers);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (p.add[i] != nullptr) v += p.add[i][b];

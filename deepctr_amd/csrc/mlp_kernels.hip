@@ -46,7 +46,9 @@ int mlp_lda(const dctr_mlp_args_t* a, int k_split) {
     return ((w + 63) & ~63) + 4;
 }
 
-size_t mlp_lds_bytes(int rows, int lda) { return ((size_t)2 * rows * lda + 2 * rows) * sizeof(float); }
+size_t mlp_lds_bytes(int rows, int lda, bool cross = false) {
+    return ((size_t)2 * rows * lda + 2 * rows + (cross ? CROSS_NV * rows : 0)) * sizeof(float);
+}
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
@@ -112,6 +114,20 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     p.global_bias = a->global_bias;
     p.y = a->y;
     p.y_stride = a->y_stride;
+    const bool cross = a->cross_layers > 0;
+    if (cross) {
+        DCTR_REQUIRE(a->cross_layers <= CROSS_MAXL, DCTR_E_UNSUPPORTED, "mlp_fwd: cross_layers %d (the folded vector CrossNet takes <= %d)",
+                     a->cross_layers, CROSS_MAXL);
+        DCTR_REQUIRE(a->cross_w && a->cross_b && a->cross_head, DCTR_E_NULL, "mlp_fwd: cross_layers without cross_w / cross_b / cross_head");
+        DCTR_REQUIRE(a->has_head, DCTR_E_DIM, "mlp_fwd: the folded CrossNet adds the cross branch's logit to the head (has_head)");
+        DCTR_REQUIRE(a->save_acts == nullptr && a->precision == 0, DCTR_E_UNSUPPORTED, "mlp_fwd: cross_layers with save_acts / bf16x3");
+        p.cross_w = a->cross_w;
+        p.cross_b = a->cross_b;
+        p.cross_head = a->cross_head;
+        p.cross_layers = a->cross_layers;
+    } else {
+        DCTR_REQUIRE(a->cross_layers == 0, DCTR_E_DIM, "mlp_fwd: cross_layers %d", a->cross_layers);
+    }
     FusedGather fg{};
     int lpr = 0;
     if (ga != nullptr) {
@@ -193,8 +209,8 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     for (;; rt >>= 1) {
         const int rows = 16 * rt;
         const int lda_full = mlp_lda(a, 0), lda_split = split ? mlp_lda(a, split) : lda_full;
-        auto fits = [&](int ld) { return mlp_lds_bytes(rows, ld) <= LDS_PER_CU && red_floats(rows) <= (size_t)rows * ld; };
-        auto per_cu = [&](int ld) { return fits(ld) ? (mlp_lds_bytes(rows, ld) * 2 <= LDS_PER_CU ? 2 : 1) : 0; };
+        auto fits = [&](int ld) { return mlp_lds_bytes(rows, ld, cross) <= LDS_PER_CU && red_floats(rows) <= (size_t)rows * ld; };
+        auto per_cu = [&](int ld) { return fits(ld) ? (mlp_lds_bytes(rows, ld, cross) * 2 <= LDS_PER_CU ? 2 : 1) : 0; };
         const int full = per_cu(lda_full), half = split ? per_cu(lda_split) : 0;
         if (half > full) { p.k_split = split; lda = lda_split; break; }
         if (full > 0) { p.k_split = 0; lda = lda_full; break; }
@@ -204,7 +220,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
                  "mlp_fwd: layer widths do not fit the 160 KiB LDS tile (or are too small for the gather partial sums)");
     p.lda = lda;
     const int rows = 16 * rt;
-    const size_t lds = mlp_lds_bytes(rows, lda);
+    const size_t lds = mlp_lds_bytes(rows, lda, cross);
     const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)rows);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
     if (ga != nullptr) g_last_fwd_kernel = DCTR_FWD_KERNEL_TILE;

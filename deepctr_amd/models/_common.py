@@ -77,3 +77,247 @@ class FeatureModel(Model):
         if "lin2" in ws:
             add.append(ws["lin2"])
         return add
+
+
+class FusedForward(object):
+    """The one-launch forward (``dctr_embed_mlp_fwd``: ids -> on-chip row -> DNN -> head) shared by the models whose graph is
+    "gather + DNN + a head that sums logits": DeepFM / WDL / FNN, DCN with the vector CrossNet (folded into the launch:
+    dctr_mlp_args_t.cross_*), xDeepFM (the CIN logit joins through the head's ``add``).  Mixed in FRONT of FeatureModel; the model
+    provides ``stage_plan``, ``dnn``, ``dense``, ``prediction`` and may override the three hooks below."""
+
+    # (defaults of a model that never calls _init_fused, e.g. a DCN without a DNN branch)
+    fused = False
+    tile_rows = 0
+    span_batches = True
+    probe = None
+    matrix_precision = "fp32"
+    _pad = _pad_spec = _bf3 = None
+
+    # ---- hooks --------------------------------------------------------------------------------------------------------------
+    def _head_weights(self):
+        """The Dense(1) weights the DNN's output meets ([units[-1], 1])."""
+        return self.dense.w('kernel')
+
+    def _cross_operands(self):
+        """None, or (kernels [L, in_dim], bias [L, in_dim], head [in_dim]) of a vector CrossNet folded into the launch
+        (PERSISTENT tensors: marshalled launches keep their addresses)."""
+        return None
+
+    def _extra_logits(self, staged, lo, hi):
+        """[B] logit vectors of other launches (issued here, on the current stream) that the fused head adds."""
+        return []
+
+    def _init_fused(self, dnn_hidden_units, dnn_activation):
+        sp = self.stage_plan
+        # use dctr_embed_mlp_fwd when the plan allows it (set False for the 2-launch path); the gather's partial sums
+        # alias the second 16-row activation tile in LDS, which must be large enough for them
+        width = max([sp.in_dim] + list(dnn_hidden_units))
+        lda = (width + 63) // 64 * 64 + 4
+        lpr = 4
+        while lpr * 4 < sp.max_dim:
+            lpr *= 2
+        passes = 1 if 64 // lpr >= 16 else 16 // (64 // lpr)
+        self.fused = bool(sp.fusable and 8 * passes * 6 * 64 <= 16 * lda)
+        self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64; 128 / 256: row-chained kernel)
+        self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
+        self._fast = {}             # batch size -> marshalled argument structs of the fused launch
+        self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
+        self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
+        self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
+        # "fp32" (exact, the only supported mode) | "bf16x3": EXPLORATORY (include/dctr.h: dctr_mlp_args_t.precision) — the row-chained
+        # kernel's products as three bf16 MFMAs each; applies to launches that kernel takes (>= 64 rows per CU, DNN 256-128-64)
+        self.matrix_precision = "fp32"
+        self._bf3 = None            # {"ws": packed weight images, "fresh": they match the current weights}
+
+    # -- DNN widths the row-chained kernel has no instantiation for --------------------------------------------------------
+    _CHAIN_MIN_ROWS = 64 * 256         # launches below 64 rows per CU take the 32-row kernel (csrc/chain_kernels.hip: eligible)
+
+    def _chain_pad_spec(self, units, activation):
+        """Widths (units[0] <= 256, units[1] <= 128, units[2] <= 128, two or three ReLU / linear layers) padded up to the
+        row-chained kernel's instantiations {128, 256} x {64, 128} x {64, 128}: zero weight columns and biases give act(0) = 0 in
+        the padded features, zero rows of the next layer take them out again — the same fp32 chain plus exact zeros.  None when
+        the widths are already instantiated or cannot be."""
+        units = [int(u) for u in units]
+        sp = self.stage_plan
+        if sp.uniform_dim not in (16, 32) or len(units) not in (2, 3) or activation not in ("relu", "linear") or self.dnn.dice_layers:
+            return None
+        if units[0] > 256 or units[1] > 128 or (len(units) == 3 and units[2] > 128):
+            return None
+        target = [128 if units[0] <= 128 else 256, 64 if units[1] <= 64 else 128]
+        if len(units) == 3:
+            target.append(64 if units[2] <= 64 else 128)
+        return None if target == units else target
+
+    def _padded_dnn(self):
+        """(kernels, biases, head_w, bn) at the padded widths: persistent buffers, refreshed in place from the current weights."""
+        import torch
+        tgt = self._pad_spec
+        ks, bs = self.dnn.kernels, self.dnn.biases
+        bn = self.dnn.bn_params()
+        if self._pad is None:
+            dev = self.device
+            dims = [self.stage_plan.in_dim] + tgt
+            self._pad = {"k": [torch.zeros(dims[i], dims[i + 1], dtype=torch.float32, device=dev) for i in range(len(tgt))],
+                         "b": [torch.zeros(dims[i + 1], dtype=torch.float32, device=dev) for i in range(len(tgt))],
+                         "h": torch.zeros(tgt[-1], 1, dtype=torch.float32, device=dev),
+                         "bn": None if bn is None else [(torch.ones(t, dtype=torch.float32, device=dev),
+                                                         torch.zeros(t, dtype=torch.float32, device=dev)) for t in tgt]}
+        pd = self._pad
+        with torch.no_grad():
+            for i, (k, b) in enumerate(zip(ks, bs)):
+                pd["k"][i][:k.shape[0], :k.shape[1]].copy_(k)
+                pd["b"][i][:b.shape[0]].copy_(b)
+                if bn is not None:
+                    pd["bn"][i][0][:bn[i][0].shape[0]].copy_(bn[i][0])
+                    pd["bn"][i][1][:bn[i][1].shape[0]].copy_(bn[i][1])
+            hw = self._head_weights()
+            pd["h"][:hw.shape[0]].copy_(hw)
+        return pd["k"], pd["b"], pd["h"], pd["bn"]
+
+    def _dnn_operands(self, B):
+        """DNN weights for a fused launch of B rows: padded copies when that launch can take the row-chained kernel."""
+        if self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256):
+            return self._padded_dnn()
+        return self.dnn.kernels, self.dnn.biases, self._head_weights(), self.dnn.bn_params()
+
+    def _prehash(self, B):
+        """Hashed SparseFeat on launches the persistent kernels can take (>= 64 rows per CU, uniform embedding_dim): the ids are
+        hashed by one dctr_hash_fields launch in front of the fused one, which then sees plain rows.  Smaller launches hash inside
+        the 32-row kernel."""
+        sp = self.stage_plan
+        return bool(sp.any_hash and sp.uniform_dim in (16, 32, 64) and (B >= self._CHAIN_MIN_ROWS or self.tile_rows in (64, 256)))
+
+    def _begin(self):
+        super(FusedForward, self)._begin()
+        if self._pad is not None:
+            self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
+        if self._bf3 is not None:
+            self._bf3["fresh"] = False  # weights may have changed since the last predict(): the next launch repacks
+
+    def _bf3_on(self, B):
+        if self.matrix_precision == "fp32":
+            return False
+        if self.matrix_precision != "bf16x3":
+            raise ValueError("matrix_precision must be 'fp32' or 'bf16x3' (exploratory), got %r" % (self.matrix_precision,))
+        return B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256
+
+    def _forward_fast(self, staged, lo, hi, out):
+        """Fixed-length features on the fused path: the two argument structs are marshalled once per batch size and only
+        the per-batch pointers are patched (ctypes marshalling was ~30 us per 4096-row batch, more than the kernel's
+        share of a pipelined predict)."""
+        import ctypes
+        from .. import _C
+        g, m = self._forward_fast_args(staged, lo, hi, out)
+        sp = self.stage_plan
+        _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear),
+                                             _C.stream_ptr()), "dctr_embed_mlp_fwd")
+        if m.precision:
+            self._bf3["fresh"] = True
+
+    def _forward_fast_args(self, staged, lo, hi, out):
+        import ctypes
+        import torch
+        from .. import _C
+        sp, B = self.stage_plan, hi - lo
+        padded = self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256)
+        pre = self._prehash(B)
+        bf3 = self._bf3_on(B)
+        key = (B, padded, pre, bf3)
+        c = self._fast.get(key)
+        hashed = sp.prehash(staged, lo, hi, sp.light_workspace()) if pre else None
+        if c is None:
+            ws = sp.light_workspace()          # descriptors + status only: a launch may span any number of rows
+            if len(self._fast) > 8:
+                self._fast.clear()
+            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
+            ks, bs, hw, bn = self._dnn_operands(B)
+            m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
+                              head_w=hw, global_bias=self.prediction.w('global_bias'),
+                              sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out, gather=g, batch=B, launch=False,
+                              cross=self._cross_operands())
+            if bf3:
+                if self._bf3 is None:
+                    m.precision = 1
+                    need = int(_C.lib().dctr_mlp_workspace_bytes(ctypes.byref(m)))
+                    self._bf3 = {"ws": torch.empty(need, dtype=torch.uint8, device=self.device), "fresh": False}
+                m.workspace, m.workspace_bytes = self._bf3["ws"].data_ptr(), self._bf3["ws"].numel()
+            c = self._fast[key] = (g, m, keep, ws)
+        g, m, _keep, _ws = c
+        ids = staged.ids
+        if hashed is not None:
+            g.ids = hashed.data_ptr()
+            g.ids_stride_f = hashed.stride(0)
+        else:
+            g.ids = ids.data_ptr() + lo * ids.element_size()
+            g.ids_stride_f = ids.stride(0)
+        g.ids_is_i64 = int(ids.dtype == torch.int64)
+        if staged.dense is not None:
+            g.dense = staged.dense.data_ptr() + lo * staged.dense.stride(0) * 4
+            g.dense_stride = staged.dense.stride(0)
+        g.dense_lin_w = None if sp.dense_lin_w is None else sp.dense_lin_w.data_ptr()
+        m.y = out.data_ptr()
+        m.tile_rows = int(self.tile_rows)
+        m.probe = None if self.probe is None else self.probe.data_ptr()
+        m.precision = 0 if not bf3 else (2 if self._bf3["fresh"] else 1)
+        for i, t in enumerate(self._extra_logits(staged, lo, hi)):      # (their launches go out here, in front of the fused one)
+            m.add[i] = t.data_ptr()
+        return g, m
+
+    def launch_plan(self, staged, lo, hi, out):
+        """[(rows, kernel, batch rows per workgroup)] of the kernel launches ``dctr_embed_mlp_fwd`` issues for rows [lo, hi)
+        (kernel: 'tile' = mlp_kernel, 'stream', 'chain'; dctr_embed_mlp_fwd_plan)."""
+        import ctypes
+        from .. import _C
+        if not hasattr(self.stage_plan, "dense_lin_w"):
+            self._begin()                                   # (what predict() does first: per-call views of the weights)
+        g, m = self._forward_fast_args(staged, lo, hi, out)
+        rows, kern, rpw = (ctypes.c_int64 * 16)(), (ctypes.c_int32 * 16)(), (ctypes.c_int32 * 16)()
+        n = _C.lib().dctr_embed_mlp_fwd_plan(ctypes.byref(g), ctypes.byref(m), rows, kern, rpw, 16)
+        if n <= 0:
+            msg = _C.lib().dctr_last_error()
+            raise _C.DctrError("dctr_embed_mlp_fwd_plan failed: %s" % (msg.decode() if msg else ""))
+        names = {0: "tile", 1: "stream", 2: "chain"}
+        return [(int(rows[i]), names[int(kern[i])], int(rpw[i])) for i in range(min(n, 16))]
+
+    def prepare_launch(self, staged, lo, hi, out):
+        """A zero-argument callable that issues the fused launch for rows [lo, hi) -> out with everything marshalled
+        beforehand (bench.py: the host cost of a launch inside a short timed region is one ctypes call)."""
+        import ctypes
+        from .. import _C
+        self._forward_fast_args(staged, lo, hi, out)
+        B = hi - lo
+        pre = self._prehash(B)
+        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256), pre,
+                                     self._bf3_on(B))]
+        g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
+        sp = self.stage_plan
+        fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
+        a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
+
+        def launch():
+            if pre:                                                      # (the hash launch fills the scratch matrix g.ids points at)
+                h = sp.prehash(staged, lo, hi, ws)
+                g.ids, g.ids_stride_f = h.data_ptr(), h.stride(0)
+            for i, t in enumerate(self._extra_logits(staged, lo, hi)):
+                m.add[i] = t.data_ptr()
+            _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
+            if m.precision == 1:                                         # bf16x3: the first launch packed the weights
+                m.precision = 2
+        launch.keep = (g, m, keep, ws, staged, out)
+        return launch
+
+    def _fast_path(self, staged):
+        sp = self.stage_plan
+        return bool(sp.fusable and self.fused and not sp.pooled_fields and not sp.lin_only and staged.ids is not None)
+
+    def _rows_per_launch(self, staged, batch_size):
+        """predict(): rows are independent and the one-launch path owns no per-batch buffer, so ``batch_size`` (a memory
+        knob of the reference's graph executor) need not bound a launch: spans of up to 2^20 rows go out as ONE launch —
+        with >= 64 rows per CU the library then runs its persistent kernels (row-chained: chain_device.h; else streaming)."""
+        if self._fast_path(staged) and self.span_batches:
+            return max(int(batch_size or staged.n), 1 << 20)
+        sp = self.stage_plan
+        if sp.fusable and self.fused and self.span_batches and sp.uniform_dim in (16, 32):
+            # pooled sequence features / linear-only features: per-row buffers of the pooling kernels bound the span
+            return max(int(batch_size or staged.n), 1 << 17)
+        return super(FusedForward, self)._rows_per_launch(staged, batch_size)

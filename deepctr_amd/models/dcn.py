@@ -9,10 +9,10 @@ from ..engine import EmbeddingStage
 from ..layers.base import name_scope
 from ..layers.core import DNN, Dense, PredictionLayer
 from ..layers.interaction import CrossNet
-from ._common import FeatureModel
+from ._common import FeatureModel, FusedForward
 
 
-class _DCN(FeatureModel):
+class _DCN(FusedForward, FeatureModel):
     def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units,
                  seed, dnn_dropout, dnn_use_bn, dnn_activation, task, device, name="DCN"):
         super(_DCN, self).__init__(name, list(dnn_feature_columns), device, task)
@@ -35,12 +35,66 @@ class _DCN(FeatureModel):
             self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(width))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
         self._stack = {}
+        # The one-launch forward (reference models/dcn.py:45-78 in ONE kernel): with the vector parameterization every x_l of
+        # CrossNet is a_l x_0 + (b_0 + .. + b_{l-1}), so the cross branch and its share of the final Dense(1) reduce to L + 1 dot
+        # products of the gathered row, taken on chip beside the DNN (dctr_mlp_args_t.cross_*; csrc/mlp_device.h: cross_logit)
+        self._xops = None           # persistent (kernels [L, d], bias [L, d], head [d]) buffers the marshalled launches point at
+        if self.dnn is not None:
+            self._init_fused(dnn_hidden_units, dnn_activation)
+        else:
+            self.fused = False
+        self.fold_cross = True      # False: the layer-by-layer cross kernels (gather -> HBM -> cross / DNN launches)
+
+    def _fold_ok(self):
+        return bool(self.fold_cross and self.fused and self.cross is not None and self.dnn is not None and
+                    getattr(self.cross, "parameterization", None) == "vector" and 1 <= self.cross.layer_num <= 3 and
+                    not self.dnn.dice_layers)
+
+    def _fast_path(self, staged):
+        return self._fold_ok() and super(_DCN, self)._fast_path(staged)
+
+    def _chain_pad_spec(self, units, activation):
+        """The row-chained kernel carries the folded CrossNet in its 256-128-x instantiations only: narrower DNNs go there
+        zero-padded (the padding rule of FusedForward._chain_pad_spec)."""
+        if self.cross is None or getattr(self.cross, "parameterization", None) != "vector":
+            return super(_DCN, self)._chain_pad_spec(units, activation)
+        units = [int(u) for u in units]
+        sp = self.stage_plan
+        if sp.uniform_dim not in (16, 32) or len(units) not in (2, 3) or activation not in ("relu", "linear") or self.dnn.dice_layers:
+            return None
+        if units[0] > 256 or units[1] > 128 or (len(units) == 3 and units[2] > 128):
+            return None
+        target = [256, 128] + ([64 if units[2] <= 64 else 128] if len(units) == 3 else [])
+        return None if target == units else target
+
+    def _rows_per_launch(self, staged, batch_size):
+        if self._fast_path(staged):
+            return super(_DCN, self)._rows_per_launch(staged, batch_size)       # the one-launch path owns no per-batch buffer
+        return FeatureModel._rows_per_launch(self, staged, batch_size)
+
+    def _head_weights(self):
+        d = self.stage_plan.in_dim if self.cross is not None else 0
+        return self.dense.w('kernel')[d:]
+
+    def _cross_operands(self):
+        import torch
+        ks, bs = self.cross.packed()
+        d = self.stage_plan.in_dim
+        hw = self.dense.w('kernel').reshape(-1)[:d]
+        if self._xops is None:
+            self._xops = (torch.empty_like(ks), torch.empty_like(bs), torch.empty_like(hw))
+        with torch.no_grad():
+            for dst, src in zip(self._xops, (ks, bs, hw)):
+                dst.copy_(src)
+        return self._xops
 
     def _make_cross(self, cross_num, cross_parameterization):
         return CrossNet(cross_num, parameterization=cross_parameterization, device=self.device)
 
     def _begin(self):
         super(_DCN, self)._begin()
+        if self._xops is not None:
+            self._cross_operands()      # refresh in place: marshalled launches keep pointing at the buffers
         # (the HIP training step works on its own packed parameter tensors — the layer's weights are views of them — and reads
         #  nothing of this: no torch.stack launches per step there)
         if not getattr(self, "_trainer_owns_cross", False):
@@ -54,6 +108,8 @@ class _DCN(FeatureModel):
     fuse_head = True
 
     def _forward(self, staged, lo, hi, out):
+        if self._fast_path(staged):
+            return self._forward_fast(staged, lo, hi, out)
         ws = self.stage_plan.run(staged, lo, hi)
         B = hi - lo
         d = self.stage_plan.in_dim

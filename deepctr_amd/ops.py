@@ -564,14 +564,16 @@ def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
 # ---------------------------------------------------------------------------------------------
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
         sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
-        tile_rows=0, save_acts=None, probe=None, launch=True, bn=None, precision=0, workspace=None):
+        tile_rows=0, save_acts=None, probe=None, launch=True, bn=None, precision=0, workspace=None, cross=None):
     """DNN.call (reference core.py:189-208) for x [B, >=in_dim]; optional fused head:
     logit = h . head_w + sum(add) + global_bias, sigmoid (Dense(1) + add_func + PredictionLayer).
     ``dice`` = list of (alpha, moving_mean, moving_variance) per layer when activation == 'dice'.
     ``bn`` = list of (scale, shift) per layer (or None) for DNN(use_bn=True): inference BatchNormalization between bias_add
     and the activation, see dctr_mlp_args_t.bn_scale.
     ``tile_rows`` (0 = auto, 16, 32, 64; with a fused gather also 128 / 256 = the row-chained kernel) is the batch rows per
-    workgroup — a throughput/latency knob."""
+    workgroup — a throughput/latency knob.
+    ``cross`` = (kernels [L, in_dim], bias [L, in_dim], head [in_dim]): CrossNet in its vector parameterization over the row the
+    DNN reads (reference interaction.py:405-424) folded into the launch; the head adds x_L . head (dctr_mlp_args_t.cross_*)."""
     _dev_check(x, *kernels, *biases)
     if gather is None:
         if x.dim() != 2:
@@ -628,6 +630,12 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
         bsh = _ptr_array([None if b_ is None else _f32c(b_[1], "bn_shift") for b_ in bn])
         keep.append((bsc, bsh, bn))
         a.bn_scale, a.bn_shift = ctypes.cast(bsc, ctypes.c_void_p), ctypes.cast(bsh, ctypes.c_void_p)
+    if cross is not None:
+        cw, cb, ch = (_f32c(t_, "cross") for t_ in cross)
+        if cw.dim() != 2 or cw.shape != cb.shape or cw.shape[1] != in_dim or ch.numel() != in_dim:
+            raise ValueError("cross = (kernels [L, in_dim], bias [L, in_dim], head [in_dim])")
+        keep.append((cw, cb, ch))
+        a.cross_w, a.cross_b, a.cross_head, a.cross_layers = cw.data_ptr(), cb.data_ptr(), ch.data_ptr(), int(cw.shape[0])
     if save_acts is not None:           # training: layer outputs [B, units[l]] also go to HBM (dctr_mlp_bwd reads them)
         sa = _ptr_array(list(save_acts))
         keep.append(sa)

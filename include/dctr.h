@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 6
+#define DCTR_ABI_VERSION 7
 
 enum {
     DCTR_OK = 0,
@@ -400,6 +400,17 @@ typedef struct {
                                      the arrays may be NULL = no BN on that layer): y = act((x W + b) * bn_scale + bn_shift) with
                                      bn_scale = gamma * rsqrt(moving_variance + epsilon), bn_shift = beta - moving_mean * bn_scale */
     const float* const* bn_shift;
+    /* ABI 7 — CrossNet, vector parameterization (deepctr/layers/interaction.py:405-424), and the cross branch's share of DCN's
+     * Dense(1) over Concatenate([cross_out, deep_out]) (deepctr/models/dcn.py:61-64), folded into the forward: with cross_layers = L
+     * in 1 .. 3 the head also adds x_L . cross_head, where x_0 = the row the DNN reads (the gathered row of dctr_embed_mlp_fwd, or x)
+     * and x_{l+1} = x_0 (x_l . cross_w[l]) + cross_b[l] + x_l.  Every x_l = a_l x_0 + (b_0 + .. + b_{l-1}), so the kernels take
+     * L + 1 dot products of the row while it is on chip and run the scalar recurrence — the same real-number function as
+     * dctr_crossnet_head_fwd, rounded differently (fp32 fmaf chains over the same products).  Needs has_head; not with save_acts or
+     * precision != 0.  cross_w, cross_b: DEVICE [L, in_dim] row-major; cross_head: DEVICE [in_dim]. */
+    const float* cross_w;
+    const float* cross_b;
+    const float* cross_head;
+    int32_t cross_layers;         /* 0 (default): none */
 } dctr_mlp_args_t;
 size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
 int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
