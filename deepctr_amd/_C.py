@@ -79,7 +79,7 @@ class MlpArgs(ctypes.Structure):
                 ("sigmoid_out", c_i32), ("head_w", c_vp), ("add", c_vp * 4), ("global_bias", c_vp),
                 ("y", c_vp), ("y_stride", c_i64), ("workspace", c_vp), ("workspace_bytes", c_sz),
                 ("save_acts", c_vp), ("tile_rows", c_i32), ("precision", c_i32), ("probe", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp),
-                ("cross_w", c_vp), ("cross_b", c_vp), ("cross_head", c_vp), ("cross_layers", c_i32)]
+                ("cross_w", c_vp), ("cross_b", c_vp), ("cross_head", c_vp), ("cross_layers", c_i32), ("cross_const", c_vp)]
 
 
 class FieldGrad(ctypes.Structure):
@@ -200,6 +200,7 @@ SYMBOLS = {
     "dctr_bi_interaction_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_inner_product_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
+    "dctr_crossnet_fold_consts": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
     "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),
     "dctr_embed_mlp_fwd_last_kernel": (ctypes.c_int, []),

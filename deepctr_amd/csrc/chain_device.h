@@ -146,6 +146,7 @@ struct ChainParams {
     const float* cross_w;
     const float* cross_b;
     const float* cross_head;
+    const float* cross_const;      // [CROSS_NV] precomputed (dctr_crossnet_fold_consts) or NULL: wave 0 computes them
     int32_t cross_layers;
     int32_t xv_off;
 };
@@ -1238,7 +1239,9 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
             const int v = i / XVS, k = i - v * XVS;
             xv[i] = (v <= L && k < d) ? (v < L ? p.cross_w[(size_t)v * d + k] : p.cross_head[k]) : 0.f;
         }
-        if (wave == 0) {
+        if (p.cross_const != nullptr) {
+            if (threadIdx.x < CROSS_NV) xv[CROSS_NV * XVS + threadIdx.x] = p.cross_const[threadIdx.x];
+        } else if (wave == 0) {
             float cst[CROSS_NV];
             cross_constants(p.cross_w, p.cross_b, p.cross_head, L, d, lane, cst);
             if (lane == 0) {

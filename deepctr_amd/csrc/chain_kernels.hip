@@ -124,6 +124,7 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     p.cross_w = a->cross_w;
     p.cross_b = a->cross_b;
     p.cross_head = a->cross_head;
+    p.cross_const = a->cross_const;
     p.cross_layers = a->cross_layers;
     p.xv_off = (int32_t)(lds_bytes(2, 8, p.n_dense) / sizeof(float));
     const int E = g->uniform_dim;

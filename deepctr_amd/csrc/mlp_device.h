@@ -59,6 +59,7 @@ struct MlpParams {
     const float* cross_w;
     const float* cross_b;
     const float* cross_head;
+    const float* cross_const;     // [CROSS_NV] precomputed constants of the recurrence (dctr_crossnet_fold_consts) or NULL
     int32_t cross_layers;
 };
 
@@ -374,12 +375,12 @@ struct Chunk {
 // The dot products of this chunk's columns of the input tile with the cross vectors, added to xp [CROSS_NV][ROWS] (stored by the
 // first chunk).  Wave w takes rows w * RPW ..; lanes walk the tile positions (position i holds local column 4 (i % KQ) + i / KQ).
 template <int RT>
-__device__ __forceinline__ void cross_partial(const MlpParams& p, const float* tile, const Chunk& ck, float* xp) {
+__device__ __forceinline__ void cross_partial(const MlpParams& p, const float* tile, const Chunk& ck, float* xp, const float* xv) {
     constexpr int ROWS = 16 * RT, RPW = ROWS / NWAVE;
     static_assert(ROWS % NWAVE == 0, "rows per wave");
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int L = p.cross_layers, d = p.in_dim;
+    const int kpad = pad64(p.in_dim);                       // xv: [CROSS_NV][kpad], zero beyond the layers / the input width
     float acc[RPW][CROSS_NV];
 #pragma unroll
     for (int r = 0; r < RPW; ++r)
@@ -389,8 +390,7 @@ __device__ __forceinline__ void cross_partial(const MlpParams& p, const float* t
         const int k = ck.c0 + 4 * (i % ck.KQ) + i / ck.KQ;
         float v[CROSS_NV];
 #pragma unroll
-        for (int l = 0; l < CROSS_NV; ++l)
-            v[l] = (l <= L && k < d) ? (l < L ? p.cross_w[(size_t)l * d + k] : p.cross_head[k]) : 0.f;
+        for (int l = 0; l < CROSS_NV; ++l) v[l] = xv[l * kpad + k];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const float x = tile[(wave * RPW + r) * p.lda + i];
@@ -729,11 +729,32 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
     float* buf1 = smem + ROWS * p.lda;
     float* extra = smem + 2 * ROWS * p.lda;                        // [2*ROWS]: per-row fused logits, dense partials
     float* xp = extra + 2 * ROWS;                                  // [CROSS_NV][ROWS] cross dot products (cross_layers > 0 only)
+    float* xcs = xp + CROSS_NV * ROWS;                             // [8] constants of the recurrence
+    float* xv = xcs + 8;                                           // [CROSS_NV][pad64(in_dim)] the cross vectors, zero-padded
     const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LAB_TS(0);
     if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
 
+    if (p.cross_layers > 0) {
+        // the cross vectors go to LDS while the gather's requests are in flight (published by produce_chunk's barriers); the
+        // constants come precomputed (cross_const) or are computed here by the last wave
+        const int kpad = pad64(p.in_dim), L = p.cross_layers, d = p.in_dim;
+        for (int i = threadIdx.x; i < CROSS_NV * kpad; i += NTHR) {
+            const int v = i / kpad, k = i - v * kpad;
+            xv[i] = (v <= L && k < d) ? (v < L ? p.cross_w[(size_t)v * d + k] : p.cross_head[k]) : 0.f;
+        }
+        if (p.cross_const != nullptr) {
+            if (threadIdx.x < CROSS_NV) xcs[threadIdx.x] = p.cross_const[threadIdx.x];
+        } else if (wave == NWAVE - 1) {
+            float cst[CROSS_NV];
+            cross_constants(p.cross_w, p.cross_b, p.cross_head, L, d, threadIdx.x & 63, cst);
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int v = 0; v < CROSS_NV; ++v) xcs[v] = cst[v];
+            }
+        }
+    }
     float* in = buf0;
     float* out = buf1;
     int K = p.in_dim;
@@ -742,7 +763,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
     if (p.k_split == 0) {
         const Chunk ck{0, pad64(p.in_dim) / 4, 0, n_fields, true, true};
         produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);       // partial sums live in the (still unused) 2nd tile
-        if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp);
+        if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
         LAB_TS(1);
     } else {
         // layer 0 in two K-halves: every wave owns ONE wave-tile of the layer output (host guarantees it) and keeps
@@ -763,7 +784,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         {
             const Chunk ck{0, cw0 / 4, 0, f_mid, true, false};
             produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
-            if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp);
+            if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
             LAB_TS(1);
             if (wave < n_tiles) {
                 if (wide) tile_gemm_pipe<2, RT, SD>(buf0, p.lda, cw0 / 4, cw0, W0, N, n_base, acc2);
@@ -774,7 +795,7 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         {
             const Chunk ck{cw0, cw1 / 4, f_mid, n_fields, false, true};
             produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
-            if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp);
+            if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
             if (wave < n_tiles) {
                 const int k_rows = p.in_dim - cw0;
                 const float* W = W0 + (size_t)cw0 * N;
@@ -828,7 +849,10 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         const int part = threadIdx.x & 15;
         const int KQh = pad64(K) / 4;
         float xcst[CROSS_NV];
-        if (p.cross_layers > 0) cross_constants(p.cross_w, p.cross_b, p.cross_head, p.cross_layers, p.in_dim, threadIdx.x & 63, xcst);
+        if (p.cross_layers > 0) {
+#pragma unroll
+            for (int v = 0; v < CROSS_NV; ++v) xcst[v] = xcs[v];
+        }
         for (int row = threadIdx.x >> 4; row < ROWS; row += NTHR / 16) {
             float acc = 0.f;
             for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);

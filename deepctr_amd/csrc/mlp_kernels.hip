@@ -46,8 +46,9 @@ int mlp_lda(const dctr_mlp_args_t* a, int k_split) {
     return ((w + 63) & ~63) + 4;
 }
 
-size_t mlp_lds_bytes(int rows, int lda, bool cross = false) {
-    return ((size_t)2 * rows * lda + 2 * rows + (cross ? CROSS_NV * rows : 0)) * sizeof(float);
+// cross_bytes: the folded CrossNet's share ([CROSS_NV][rows] dot products + 8 constants + [CROSS_NV][pad64(in_dim)] vectors), 0 = none
+size_t mlp_lds_bytes(int rows, int lda, size_t cross_bytes = 0) {
+    return ((size_t)2 * rows * lda + 2 * rows) * sizeof(float) + cross_bytes;
 }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
@@ -124,6 +125,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         p.cross_w = a->cross_w;
         p.cross_b = a->cross_b;
         p.cross_head = a->cross_head;
+        p.cross_const = a->cross_const;
         p.cross_layers = a->cross_layers;
     } else {
         DCTR_REQUIRE(a->cross_layers == 0, DCTR_E_DIM, "mlp_fwd: cross_layers %d", a->cross_layers);
@@ -209,8 +211,9 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     for (;; rt >>= 1) {
         const int rows = 16 * rt;
         const int lda_full = mlp_lda(a, 0), lda_split = split ? mlp_lda(a, split) : lda_full;
-        auto fits = [&](int ld) { return mlp_lds_bytes(rows, ld, cross) <= LDS_PER_CU && red_floats(rows) <= (size_t)rows * ld; };
-        auto per_cu = [&](int ld) { return fits(ld) ? (mlp_lds_bytes(rows, ld, cross) * 2 <= LDS_PER_CU ? 2 : 1) : 0; };
+        const size_t xb = cross ? ((size_t)CROSS_NV * rows + 8 + (size_t)CROSS_NV * ((a->in_dim + 63) & ~63)) * sizeof(float) : 0;
+        auto fits = [&](int ld) { return mlp_lds_bytes(rows, ld, xb) <= LDS_PER_CU && red_floats(rows) <= (size_t)rows * ld; };
+        auto per_cu = [&](int ld) { return fits(ld) ? (mlp_lds_bytes(rows, ld, xb) * 2 <= LDS_PER_CU ? 2 : 1) : 0; };
         const int full = per_cu(lda_full), half = split ? per_cu(lda_split) : 0;
         if (half > full) { p.k_split = split; lda = lda_split; break; }
         if (full > 0) { p.k_split = 0; lda = lda_full; break; }
@@ -220,7 +223,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
                  "mlp_fwd: layer widths do not fit the 160 KiB LDS tile (or are too small for the gather partial sums)");
     p.lda = lda;
     const int rows = 16 * rt;
-    const size_t lds = mlp_lds_bytes(rows, lda, cross);
+    const size_t lds = mlp_lds_bytes(rows, lda, cross ? ((size_t)CROSS_NV * rows + 8 + (size_t)CROSS_NV * ((a->in_dim + 63) & ~63)) * sizeof(float) : 0);
     const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)rows);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
     if (ga != nullptr) g_last_fwd_kernel = DCTR_FWD_KERNEL_TILE;
@@ -230,6 +233,27 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
 }
 
 extern "C" int dctr_embed_mlp_fwd_last_kernel(void) { return g_last_fwd_kernel; }
+
+// the row-independent constants of the folded vector CrossNet (dctr_mlp_args_t.cross_const): one wave
+namespace {
+__global__ __launch_bounds__(64) void cross_consts_kernel(const float* w, const float* b, const float* head, int L, int d, float* out) {
+    float cst[CROSS_NV];
+    cross_constants(w, b, head, L, d, (int)threadIdx.x, cst);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int v = 0; v < CROSS_NV; ++v) out[v] = cst[v];
+    }
+}
+}  // namespace
+
+extern "C" int dctr_crossnet_fold_consts(const float* cross_w, const float* cross_b, const float* cross_head, int32_t layers, int32_t dim,
+                                         float* consts, void* stream) {
+    DCTR_REQUIRE(cross_w && cross_b && cross_head && consts, DCTR_E_NULL, "crossnet_fold_consts: null pointer");
+    DCTR_REQUIRE(layers >= 1 && layers <= CROSS_MAXL && dim >= 1, DCTR_E_DIM, "crossnet_fold_consts: layers %d (1 .. %d), dim %d", layers,
+                 CROSS_MAXL, dim);
+    DCTR_LAUNCH(cross_consts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cross_w, cross_b, cross_head, layers, dim, consts);
+    return dctr_launch_status("dctr_crossnet_fold_consts");
+}
 
 extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) { return mlp_launch(a, nullptr, 0, 0, stream); }
 

@@ -82,10 +82,12 @@ class _DCN(FusedForward, FeatureModel):
         d = self.stage_plan.in_dim
         hw = self.dense.w('kernel').reshape(-1)[:d]
         if self._xops is None:
-            self._xops = (torch.empty_like(ks), torch.empty_like(bs), torch.empty_like(hw))
+            self._xops = (torch.empty_like(ks), torch.empty_like(bs), torch.empty_like(hw),
+                          torch.zeros(4, dtype=torch.float32, device=self.device))
         with torch.no_grad():
             for dst, src in zip(self._xops, (ks, bs, hw)):
                 dst.copy_(src)
+        ops.crossnet_fold_consts(*self._xops)       # the recurrence's constants follow the weights: once per predict(), not per launch
         return self._xops
 
     def _make_cross(self, cross_num, cross_parameterization):

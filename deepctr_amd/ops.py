@@ -559,6 +559,17 @@ def inner_product(x, reduce_sum=True, fields=None, dim=None, out=None):
     return y
 
 
+def crossnet_fold_consts(kernels, bias, head, out=None):
+    """The row-independent constants of the folded vector CrossNet (dctr_crossnet_fold_consts): float[4] for ``mlp(cross=(.., consts))``."""
+    _dev_check(kernels, bias, head)
+    kernels, bias, head = _f32c(kernels, "kernels"), _f32c(bias, "bias"), _f32c(head, "head")
+    if out is None:
+        out = torch.zeros(4, dtype=torch.float32, device=kernels.device)
+    _C.check(_C.lib().dctr_crossnet_fold_consts(_ptr(kernels), _ptr(bias), _ptr(head), int(kernels.shape[0]), int(kernels.shape[1]), _ptr(out),
+                                                _C.stream_ptr()), "dctr_crossnet_fold_consts")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # adjacent: DNN (+ head), DIN attention
 # ---------------------------------------------------------------------------------------------
@@ -631,11 +642,14 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
         keep.append((bsc, bsh, bn))
         a.bn_scale, a.bn_shift = ctypes.cast(bsc, ctypes.c_void_p), ctypes.cast(bsh, ctypes.c_void_p)
     if cross is not None:
-        cw, cb, ch = (_f32c(t_, "cross") for t_ in cross)
+        cw, cb, ch = (_f32c(t_, "cross") for t_ in cross[:3])
         if cw.dim() != 2 or cw.shape != cb.shape or cw.shape[1] != in_dim or ch.numel() != in_dim:
-            raise ValueError("cross = (kernels [L, in_dim], bias [L, in_dim], head [in_dim])")
+            raise ValueError("cross = (kernels [L, in_dim], bias [L, in_dim], head [in_dim][, consts [4] from crossnet_fold_consts])")
         keep.append((cw, cb, ch))
         a.cross_w, a.cross_b, a.cross_head, a.cross_layers = cw.data_ptr(), cb.data_ptr(), ch.data_ptr(), int(cw.shape[0])
+        if len(cross) > 3 and cross[3] is not None:
+            keep.append(cross[3])
+            a.cross_const = cross[3].data_ptr()
     if save_acts is not None:           # training: layer outputs [B, units[l]] also go to HBM (dctr_mlp_bwd reads them)
         sa = _ptr_array(list(save_acts))
         keep.append(sa)

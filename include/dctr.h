@@ -411,8 +411,16 @@ typedef struct {
     const float* cross_b;
     const float* cross_head;
     int32_t cross_layers;         /* 0 (default): none */
+    const float* cross_const;     /* NULL, or DEVICE float[4] written by dctr_crossnet_fold_consts() for THESE cross_w / cross_b /
+                                   * cross_head: the L + 1 row-independent constants of the recurrence, which the kernels otherwise
+                                   * compute at the start of every launch (one wave, ~7 dependent L2 round trips: a few us of a
+                                   * 4096-row launch) */
 } dctr_mlp_args_t;
 size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
+/* consts[l] = (cross_b[0] + .. + cross_b[l-1]) . v_l with v_l = cross_w[l] for l < layers and cross_head for l = layers (consts has
+ * room for 4 floats; layers in 1 .. 3).  One tiny launch per change of the weights, not per batch. */
+int dctr_crossnet_fold_consts(const float* cross_w, const float* cross_b, const float* cross_head, int32_t layers, int32_t dim,
+                              float* consts, void* stream);
 int dctr_mlp_fwd(const dctr_mlp_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -84,7 +84,8 @@ def run_span(name, model, feed, B, reps=8, dnn_flop=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,dcn_v,dcn_m,dcn_mix,nfm,afm,pnn,c4,c5,c5_span")
+    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,c3_span,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
+                                         "dcn_mix,nfm,afm,pnn,c4,c4_span,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
     args = ap.parse_args()
@@ -173,6 +174,11 @@ def main():
             run("DCN cross_num=2 %s" % par, m, feed, 4096, args.steps, ring)
             if tag + "_span" in want:
                 run_span("DCN cross_num=2 %s (1 call / %d batches)" % (par, ring), m, feed, 4096)
+            if tag + "_unfolded" in want:                      # the layer-by-layer route: gather -> HBM -> cross kernel -> DNN kernel
+                m.fold_cross = False
+                m._fast.clear()
+                run("DCN cross_num=2 %s, layer-by-layer route" % par, m, feed, 4096, args.steps, ring)
+                run_span("DCN cross_num=2 %s, layer-by-layer route (1 call / %d batches)" % (par, ring), m, feed, 4096)
             del m
     if "dcn_mix" in want:
         m = DCNMix(cols16, cols16, cross_num=2, device=dev)

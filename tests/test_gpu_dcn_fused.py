@@ -51,6 +51,14 @@ def test_folded_crossnet_op_vs_layer_by_layer_oracle(device, B, d, L, units, til
     ref = _ref_logit(x, ks, bs, hx, Ws, Bs, hd)
     mag = _ref_logit(x, ks, bs, hx, Ws, Bs, hd, absolute=True)
     assert_close_terms(y.cpu().numpy(), ref, mag, rtol_terms=4e-6, what="folded crossnet B=%d d=%d L=%d" % (B, d, L))
+    # the recurrence's constants precomputed once (dctr_crossnet_fold_consts) instead of per launch: the same bits
+    cst = ops.crossnet_fold_consts(dev(ks, device), dev(bs, device), dev(hx, device))
+    y1 = ops.mlp(dev(x, device), [dev(W, device) for W in Ws], [dev(b, device) for b in Bs], "relu", head_w=dev(hd.reshape(-1, 1), device),
+                 cross=(dev(ks, device), dev(bs, device), dev(hx, device), cst), sigmoid_out=False, tile_rows=tile_rows)
+    assert torch.equal(y, y1)
+    cb = np.cumsum(np.concatenate([np.zeros((1, d)), bs.astype(np.float64)]), axis=0)         # c_l = b_0 + .. + b_{l-1}
+    vs = np.concatenate([ks.astype(np.float64), hx.astype(np.float64)[None]])
+    assert_close(cst.cpu().numpy()[:L + 1], (cb[:L + 1] * vs).sum(1), rtol=1e-5, atol=1e-6, what="fold constants")
     # the cross term alone (no DNN layers: head over the input row is not part of DCN; zero DNN head isolates the cross logit)
     y0 = ops.mlp(dev(x, device), [dev(W, device) for W in Ws], [dev(b, device) for b in Bs], "relu", head_w=dev(np.zeros((units[-1], 1), np.float32), device),
                  cross=(dev(ks, device), dev(bs, device), dev(hx, device)), sigmoid_out=False, tile_rows=tile_rows)
