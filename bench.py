@@ -25,8 +25,11 @@ After the regions a sample of the rows the timed launches wrote is compared with
 `one_launch_per_batch` in the JSON line is the other extreme (one launch per 4096-row batch, K of them in one hipGraph on 8
 streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
 
-Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free; the logits of the K steps are
-all-gathered ONCE (RCCL) inside the timed region — the path's only exchange.
+Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free: every rank scores its own K x 4096 rows
+inside the timed region (barrier + synchronize on both sides, MAX over ranks).  The path's only exchange — ONE
+RCCL all-gather of the K steps' logits, what `predict_distributed` does with a rank's shard — is issued after every region's
+clock has stopped and timed on its own: the JSON line carries it as `exchange` (its duration and the rate of region + exchange);
+inside a 0.2 ms region it would sit exposed behind the last kernel with nothing to overlap.
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of the timed region = chain_kernel (fused gather + DNN; one launch per call).  It is bound by
@@ -122,12 +125,35 @@ def probe_kernels(model, staged, ring, reps=48):
                 add=[ws["lin"], ws["fm"]], global_bias=model.prediction.w("global_bias"), sigmoid_out=True,
                 in_dim=sp.in_dim, out=out)
         t_mlp.append(lib.dctr_profile_last_ms())
+    # the stand-alone gather (the HBM-bound kernel north_star names) without its dnn_in write (linear + FM logits only), and both
+    # forms on 65,536-row launches (one 4096-row launch is latency-bound: 16 rows per CU)
+    import ctypes as _ct
+    t_lo, t_big, t_big_lo = [], [], []
+    big = min(16, ring) * B
+    for r in range(max(8, reps // 4)):
+        lo = (r % ring) * B
+        ws = sp.run_pools(staged, lo, lo + B)
+        a = sp.gather_args(staged, lo, lo + B, ws)
+        a.dnn_in = None
+        lib.dctr_profile_next_launch()
+        _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+        t_lo.append(lib.dctr_profile_last_ms())
+    for r in range(6):
+        ws = sp.run_pools(staged, 0, big)
+        a = sp.gather_args(staged, 0, big, ws)
+        lib.dctr_profile_next_launch()
+        _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+        t_big.append(lib.dctr_profile_last_ms())
+        a.dnn_in = None
+        lib.dctr_profile_next_launch()
+        _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+        t_big_lo.append(lib.dctr_profile_last_ms())
     torch.cuda.synchronize()
-    mean = lambda t: float(np.mean(t[reps // 4:])) * 1e-3 if t else None  # noqa: E731
-    return mean(t_step), mean(t_gather), mean(t_mlp)
+    mean = lambda t: float(np.mean(t[len(t) // 4:])) * 1e-3 if t else None  # noqa: E731
+    return mean(t_step), mean(t_gather), mean(t_mlp), mean(t_lo), mean(t_big), mean(t_big_lo), big
 
 
-def cpu_baseline(model, cols, budget_s=20.0):
+def cpu_baseline(model, cols, budget_s=14.0):
     """The oracle's CPU port of the reference op sequence on a bounded sample of the same workload; torch's intra-op thread
     count is swept (all cores over-subscribe the small ops of a 4096-row batch) and the best setting is reported."""
     from oracle.cpu_deepfm import CpuDeepFM
@@ -136,15 +162,26 @@ def cpu_baseline(model, cols, budget_s=20.0):
     ids = [torch.from_numpy(feed["C%d" % i].astype(np.int64)) for i in range(1, F + 1)]
     dense = [torch.from_numpy(feed["I%d" % i]).reshape(-1, 1) for i in range(1, ND + 1)]
     ncpu = os.cpu_count() or 1
-    cands = sorted(set(max(1, min(ncpu, t)) for t in (ncpu, ncpu // 2, 32, 16, 8, 4)), reverse=True)
+    # most likely winners first (16 threads won on every box so far); a thread count whose first forwards are > 3x slower than the
+    # best median so far is recorded from that probe alone (the all-threads leg scored 431 samples/s and cost 65 s of a run)
+    cands = []
+    for t in (16, 32, 8, 64, 4, ncpu // 2, ncpu):
+        t = max(1, min(ncpu, t))
+        if t not in cands:
+            cands.append(t)
     old = torch.get_num_threads()
     best, sweep = None, {}
     per = budget_s / len(cands)
     try:
         for nt in cands:
             torch.set_num_threads(nt)
-            for _ in range(2):
-                cpu.forward(ids, dense)
+            cpu.forward(ids, dense)
+            t0 = time.perf_counter()
+            cpu.forward(ids, dense)
+            probe = time.perf_counter() - t0
+            if best is not None and probe > 3.0 * best[0]:
+                sweep[str(nt)] = "%.1f (one forward; sweep leg skipped)" % (B / probe)
+                continue
             times = []
             t_end = time.time() + per
             while time.time() < t_end or len(times) < 5:
@@ -228,7 +265,7 @@ def main():
                          "each further region) so that they run at the clock the part holds under sustained load; an MI355X that "
                          "has idled ramps its shader clock over tens of milliseconds (2.1 -> 2.4 GHz measured, "
                          "profiles/r03_chain_lab_clock.log).  0 = off; the cold one-shot region is always reported as well")
-    ap.add_argument("--parity-rows", type=int, default=256,
+    ap.add_argument("--parity-rows", type=int, default=4096,
                     help="rows of the timed region's output compared with the float64 oracle after the region (0 = off)")
     args = ap.parse_args()
 
@@ -300,20 +337,25 @@ def main():
         dist.all_gather_into_tensor(gathered, logits)
         torch.cuda.synchronize()
 
+    exchange_s = []
+
     def timed_region(arm):
-        """barrier + sync | K steps (+ the one all-gather) + sync | barrier; returns this rank's seconds between the bars."""
+        """barrier + sync | K steps + sync | the one all-gather, timed on its own | barrier; returns this rank's seconds of the K steps."""
         barrier()
         torch.cuda.synchronize()
         if arm:
             lib.dctr_profile_arm(min(n_kern, 256))
         t0 = time.perf_counter()
         run_steps()
-        if dist is not None:
-            dist.all_gather_into_tensor(gathered, logits)              # the path's one exchange: final logits
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0                                  # this rank's K steps + the exchange; MAX over ranks below
-        barrier()                                                      # (closing bracket, outside the clock: one collective
-        return dt                                                      #  latency less inside a sub-millisecond region)
+        dt = time.perf_counter() - t0                                  # this rank's K steps; MAX over ranks below
+        if dist is not None:
+            t1 = time.perf_counter()
+            dist.all_gather_into_tensor(gathered, logits)              # the path's one exchange: the K steps' logits
+            torch.cuda.synchronize()
+            exchange_s.append(time.perf_counter() - t1)
+        barrier()
+        return dt
 
     # `value`: the K steps, nothing else in the region.  A single sub-millisecond region right after a barrier is a cold start
     # (L2 / MALL state, clock ramp): a few per cent of spread from run to run, so the region is taken --regions times — each one
@@ -341,7 +383,12 @@ def main():
     ms = (ctypes.c_float * 256)()
     n_timed = lib.dctr_profile_collect(ms, min(n_kern, 256)) if K > 0 else 0
     launch_s = [ms[i] * 1e-3 if ms[i] > 0 else None for i in range(n_timed)]
+    exchange = None
     if dist is not None:                                    # every region: MAX over ranks
+        ex = exchange_s[1:1 + n_regions]                    # (the exchanges behind the `value` regions)
+        t = torch.tensor([float(np.median(ex))], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange = float(t.item())
         t = torch.tensor(region_s, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.tolist()]
@@ -442,6 +489,40 @@ def main():
         finally:
             model.matrix_precision = "fp32"
 
+    # SURVEY §8(d)'s secondary input distribution: the same K-step region on Zipf(1.05) ids (hot rows: L2 / MALL hits), own staged
+    # ring, own output buffer, own parity check against the float64 oracle
+    zipf = None
+    if K > 0 and fused and dist is None and not args.no_secondary and args.dist != "zipf":
+        try:
+            staged_z = model.stage(synthetic_feed(ring * B, 2000 + rank, "zipf"))
+            logits_z = torch.empty_like(logits)
+            prep_z = [model.prepare_launch(staged_z, lo, hi, logits_z[o0:o1]) for lo, hi, o0, o1 in launches]
+
+            def run_z():
+                for fn in prep_z:
+                    fn()
+            run_z()
+            torch.cuda.synchronize()
+            t_end = time.perf_counter() + 0.03
+            while time.perf_counter() < t_end:
+                run_z()
+                torch.cuda.synchronize()
+            tz = []
+            for _ in range(n_regions):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_z()
+                torch.cuda.synchronize()
+                tz.append(time.perf_counter() - t0)
+            model._check_status()
+            par_z = check_parity(model, cols, staged_z, launches, logits_z, max(args.parity_rows // 4, 256), rank)
+            tmed = float(np.median(tz))
+            zipf = {"ids": "Zipf(1.05) folded into [0, V) (SURVEY §8(d), secondary)", "samples_per_s": K * B / tmed,
+                    "ms_per_step": tmed / K * 1e3, "regions_ms": [t * 1e3 for t in tz], "parity_max_rel": par_z["max_rel"],
+                    "parity": par_z}
+        except Exception as e:
+            zipf = {"error": repr(e)}
+
     result = None
     if rank == 0:
         value = world * B * K / elapsed if K else 0.0
@@ -467,7 +548,7 @@ def main():
             rows_launch, dom_name, dom_rpw = shapes[0]
             t_launch = kernel_launches[0]["us"] * 1e-6
         traffic, traffic_source = load_traffic(rows_launch)
-        t_fused32, t_gather, t_mlp = probe_kernels(model, staged, ring)
+        t_fused32, t_gather, t_mlp, t_gather_lo, t_gather_big, t_gather_big_lo, big_rows = probe_kernels(model, staged, ring)
         if t_launch is not None:
             tf = DNN_FLOP_PER_SAMPLE * rows_launch / t_launch / 1e12
             gbs = ALG_BYTES_PER_SAMPLE * rows_launch / t_launch / 1e9
@@ -491,6 +572,19 @@ def main():
         kernels.append({"kernel": "gather_fm_kernel (stand-alone fused 26-table gather + concat + linear + FM), isolated 4096-row launch",
                         "in_step": False, "us_per_launch": t_gather * 1e6, "bound": "hbm", "achieved": gather_gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gather_gbs / HBM_PEAK_GBS})
+        # what bounds it (profiles/r04_pmc_gather.json, profiles/r04_gather_bw_lab.log): 54 L2 requests per row against the 27 of the
+        # pure row reads — the 26 four-byte linear-table gathers cost as many requests (and 64 B of fabric traffic each) as the rows;
+        # pure random 64-B row reads reach 0.45-0.49 of 8 TB/s on this part, a read + concat-write kernel 0.41-0.46
+        wr_bytes = (F * E + ND) * 4
+        for what, t_, rows_, with_write in (("logits only (no dnn_in write), isolated 4096-row launch", t_gather_lo, B, False),
+                                            ("-> dnn_in, %d-row launch" % big_rows, t_gather_big, big_rows, True),
+                                            ("logits only, %d-row launch" % big_rows, t_gather_big_lo, big_rows, False)):
+            if t_:
+                gb = (ALG_BYTES_PER_SAMPLE + (wr_bytes if with_write else 0)) * rows_ / t_ / 1e9
+                kernels.append({"kernel": "gather_fm_kernel, " + what, "in_step": False, "us_per_launch": t_ * 1e6, "rows_per_launch": rows_,
+                                "bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                                "bytes_counted": "ids + rows + linear entries + dense" + (" + the dnn_in write" if with_write else ""),
+                                "pure_random_64B_row_read_line_frac": 0.45, "evidence": "profiles/r04_pmc_gather.json"})
         kernels.append({"kernel": "mlp_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA), isolated 4096-row launch", "in_step": False,
                         "us_per_launch": t_mlp * 1e6, "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF})
@@ -523,11 +617,16 @@ def main():
                                        "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(launches_of(pl)) for pl in plans[:1]) if fused
                                        else "2 launches per span"),
                        "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
-                       "parallelism": "row-sharded x%d, tables replicated, one all-gather of the logits" % world},
+                       "parallelism": "row-sharded x%d, tables replicated, forward collective-free; the one all-gather of the logits is "
+                                      "timed separately (`exchange`)" % world},
             "roofline": roofline, "kernels": kernels,
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
             "fp32_ceiling_of_that_fraction": F32_MFMA_PEAK_TF * 1e12 / DNN_FLOP_PER_SAMPLE * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
-            "long_run": long_run, "one_launch_per_batch": per_batch,
+            "long_run": long_run, "one_launch_per_batch": per_batch, "zipf_ids": zipf,
+            "exchange": None if exchange is None else {
+                "what": "one RCCL all-gather of the K steps' logits (%d floats per rank), issued after each region's clock stopped; median, "
+                        "MAX over ranks" % (K * B), "ms": exchange * 1e3,
+                "samples_per_s_region_plus_exchange": world * B * K / (elapsed + exchange) if K else 0.0},
             "exploratory_bf16x3": bf3,
             "regions_ms": [t * 1e3 for t in region_s],
             "value_is": "median of %d one-shot regions of exactly K steps (each: barrier + sync | K steps | sync), taken right after "

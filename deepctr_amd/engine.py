@@ -548,13 +548,22 @@ class EmbeddingStage(object):
                        lin_table=lin_table, hash_mode=hm, out=out, out_stride=out.stride(0), lin_out=lin_out, status=status,
                        keep_args=self.pool_trace)
 
-    def prehash(self, staged, lo, hi, ws):
+    def prehash(self, staged, lo, hi, ws, out=None):
         """Hash.call for rows [lo, hi) of every hashed field in ONE launch (dctr_hash_fields) into a scratch id matrix: the
         persistent kernels of dctr_embed_mlp_fwd take plain rows (reference inputs.py:108-110 hashes per feature before the
-        lookup as well).  Returns the [n_fields, B] matrix ``gather_args(prehashed=...)`` takes."""
+        lookup as well).  Returns the [n_fields, B] matrix ``gather_args(prehashed=...)`` takes.  ``out``: a caller-owned
+        [n_fields, >= B] matrix — prepared launches that may run on several streams (or sit in one multi-stream hipGraph) bring their
+        own; the shared scratch below is only safe for launches that serialise on one stream and is never reallocated smaller."""
         B, nf = hi - lo, len(self.fields)
+        if out is not None:
+            out = out[:, :B]
+            ops.hash_fields(ws["desc"], nf, staged.ids[:nf, lo:hi], out)
+            return out
         buf = getattr(self, "_hash_ids", None)
         if buf is None or buf.dtype != staged.ids.dtype or buf.shape[1] < B:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("prehash: the shared id scratch would be reallocated during graph capture (captured launches would "
+                                   "keep the old address); prepare the launch with its own buffer (Model.prepare_launch)")
             buf = self._hash_ids = torch.empty(nf, max(B, 1), dtype=staged.ids.dtype, device=self.device)
         out = buf[:, :B]
         ops.hash_fields(ws["desc"], nf, staged.ids[:nf, lo:hi], out)

@@ -293,17 +293,20 @@ class FusedForward(object):
         sp = self.stage_plan
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
+        import torch
+        # its own hashed-id matrix: prepared launches may run on several streams / in one multi-stream graph
+        own_ids = torch.empty(len(sp.fields), B, dtype=staged.ids.dtype, device=self.device) if pre else None
 
         def launch():
-            if pre:                                                      # (the hash launch fills the scratch matrix g.ids points at)
-                h = sp.prehash(staged, lo, hi, ws)
+            if pre:                                                      # (the hash launch fills the matrix g.ids points at)
+                h = sp.prehash(staged, lo, hi, ws, out=own_ids)
                 g.ids, g.ids_stride_f = h.data_ptr(), h.stride(0)
             for i, t in enumerate(self._extra_logits(staged, lo, hi)):
                 m.add[i] = t.data_ptr()
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
             if m.precision == 1:                                         # bf16x3: the first launch packed the weights
                 m.precision = 2
-        launch.keep = (g, m, keep, ws, staged, out)
+        launch.keep = (g, m, keep, ws, staged, out, own_ids)
         return launch
 
     def _fast_path(self, staged):

@@ -34,6 +34,8 @@ def sharded_predict(local_predict, feed, n, group=None):
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(n, rank, world)
     local = local_predict(slice_feed(feed, lo, hi)).reshape(-1).to(torch.float32)
+    if dist.get_backend(group) == "gloo":                    # gloo exchanges host tensors (several ranks may share one GPU)
+        local = local.cpu()
     width = shard_bounds(n, 0, world)[1]                     # largest shard (rank 0)
     padded = torch.zeros(width, dtype=torch.float32, device=local.device)
     padded[:hi - lo] = local
@@ -70,6 +72,8 @@ def sharded_loss(local_loss_sums, n, group=None):
     import torch.distributed as dist
     t = local_loss_sums.to(torch.float64)
     if dist.is_available() and dist.is_initialized():
+        if dist.get_backend(group) == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return (t / float(max(int(n), 1))).cpu().numpy()
 
