@@ -6,8 +6,8 @@ import pytest
 
 from oracle import ref_models as RM
 from tests.spec import columns_from_spec
-from tests.test_oracle_golden import MODEL_FIXTURES
-from tests.util import assert_close, golden_meta, load_golden, sigmoid_inv
+from tests.test_oracle_golden import MODEL_FIXTURES, run_oracle_model
+from tests.util import assert_close, assert_close_terms, golden_meta, load_golden, sigmoid_inv
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,21 @@ def check_probs(y, ref, what, rows=None):
         assert_close(sigmoid_inv(y[ok]), sigmoid_inv(ref[ok]), rtol=1e-4, atol=2e-5, what=what + " logit")
 
 
+# models whose logit is made of sums, products and ReLU of the weights and inputs: the oracle over |weights| bounds the magnitude every
+# sum is taken at (softmax / sigmoid / Dice attention, BatchNormalization and the -1e9 max-pooling quirk are not of that kind)
+LOGIT_TERM_MODELS = ("DeepFM", "WDL", "FNN", "DCN", "xDeepFM", "NFM", "PNN")
+
+
+def check_logits(got, ref, mag, what, rows=None, rtol_terms=4e-6):
+    """north_star's bar on the LOGIT: 1e-4 of the result + a few fp32 ulp of the magnitude its terms are summed at (no blanket
+    absolute tolerance).  got: model.predict_logits; ref / mag: the float64 oracle with task='regression' over the weights / over
+    their magnitudes."""
+    got, ref, mag = (np.asarray(a).reshape(-1) for a in (got, ref, mag))
+    if rows is not None:
+        got, ref, mag = got[rows], ref[rows], mag[rows]
+    assert_close_terms(got, ref, mag, rtol_terms=rtol_terms, what=what + " logit")
+
+
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
 def test_model_matches_reference_code(device, name):
     g = load_golden(name)
@@ -70,6 +85,10 @@ def test_model_matches_reference_code(device, name):
     for bs in (256, 5):
         y = model.predict(feed, batch_size=bs)
         check_probs(y, g["y"], "%s bs=%d" % (name, bs), rows)
+    if meta["model"] in LOGIT_TERM_MODELS and "_bn" not in name and meta["kwargs"].get("task", "binary") == "binary":
+        # raw logits against the float64 oracle (pinned to this fixture's reference output by tests/test_oracle_golden.py)
+        check_logits(model.predict_logits(feed, batch_size=256), run_oracle_model(g, np.float64, task="regression"),
+                     run_oracle_model(g, np.float64, task="regression", abs_weights=True), name, rows)
     # list-style input in get_feature_names order, as examples/run_classification_criteo.py does
     y = model.predict([feed[n] for n in model.input_names], batch_size=64)
     check_probs(y, g["y"], name + " list feed", rows)
@@ -115,6 +134,9 @@ def test_deepfm_c2_shape_vs_oracle(device):
     y = model.predict(feed, batch_size=4096)
     ref = RM.deepfm(cols, cols, w, feed, dtype=np.float64)
     check_probs(y, ref.astype(np.float32), "DeepFM C2")
+    wa = {k: np.abs(v) for k, v in w.items()}
+    check_logits(model.predict_logits(feed, batch_size=4096), RM.deepfm(cols, cols, w, feed, dtype=np.float64, task="regression"),
+                 RM.deepfm(cols, cols, wa, feed, dtype=np.float64, task="regression"), "DeepFM C2")
 
 
 def test_deepfm_c2_full_size_properties(device):
@@ -131,8 +153,11 @@ def test_deepfm_c2_full_size_properties(device):
     assert y.shape == (B, 1) and np.isfinite(y).all() and 0.02 < float(y.std()) and 0.0 < float(y.min()) and float(y.max()) < 1.0
     # (1) oracle on a sample of rows (tables at full size on the host)
     rows = rng.choice(B, 192, replace=False)
-    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+    sub = {k: v[rows] for k, v in feed.items()}
+    ref = RM.deepfm(cols, cols, w, sub, dtype=np.float64)
     check_probs(y[rows], ref.astype(np.float32), "DeepFM C2 full size")
+    check_logits(model.predict_logits(feed, batch_size=B)[rows], RM.deepfm(cols, cols, w, sub, dtype=np.float64, task="regression"),
+                 RM.deepfm(cols, cols, {k: np.abs(v) for k, v in w.items()}, sub, dtype=np.float64, task="regression"), "DeepFM C2 full size")
     # (2) a permutation of the rows permutes the outputs, bit for bit
     perm = rng.permutation(B)
     yp = model.predict({k: v[perm] for k, v in feed.items()}, batch_size=B)
@@ -181,8 +206,31 @@ def test_xdeepfm_dcn_c3_full_batch(device):
         y = model.predict(feed, batch_size=B)
         assert y.shape == (B, 1) and np.isfinite(y).all() and 0.0 < float(y.min()) and float(y.max()) < 1.0
         check_probs(y[rows], fn(cols, cols, w, sub, dtype=np.float64, **kw).astype(np.float32), name + " b4096")
+        check_logits(model.predict_logits(feed, batch_size=B)[rows], fn(cols, cols, w, sub, dtype=np.float64, task="regression", **kw),
+                     fn(cols, cols, {k: np.abs(v) for k, v in w.items()}, sub, dtype=np.float64, task="regression", **kw), name + " b4096")
         assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=B), y[perm]), name + " permutation"
         assert_close(model.predict(feed, batch_size=1000), y, rtol=1e-5, atol=1e-6, what=name + " split")
+
+
+def test_xdeepfm_c3_65536_rows_logits(device):
+    """BASELINE config 3 in ONE 65,536-row predict() span (the launch shape of the 14.7 M samples/s figure; the CIN lab saw its
+    largest deviation from float64 there): raw logits of a row sample from the first / last workgroups and random rows against the
+    float64 oracle, bar = 1e-4 of the logit + ulps of the summed magnitudes."""
+    from deepctr_amd.models import xDeepFM
+    rng = np.random.RandomState(43)
+    n = 65536
+    cols, feed = _criteo_like(rng, n, V=100000)
+    model = xDeepFM(cols, cols, cin_layer_size=(128, 128), device=device)
+    w = _randomise(model, rng)
+    rows = np.unique(np.concatenate([np.arange(0, 16), np.arange(n - 16, n), rng.choice(n, 96, replace=False)]))
+    sub = {k: v[rows] for k, v in feed.items()}
+    z = model.predict_logits(feed, batch_size=n)
+    assert z.shape == (n, 1) and np.isfinite(z).all()
+    kw = dict(cin_layer_size=(128, 128), dtype=np.float64, task="regression")
+    check_logits(z[rows], RM.xdeepfm(cols, cols, w, sub, **kw), RM.xdeepfm(cols, cols, {k: np.abs(v) for k, v in w.items()}, sub, **kw),
+                 "xDeepFM C3, 65,536-row span")
+    y = model.predict(feed, batch_size=n)
+    check_probs(y[rows], RM.xdeepfm(cols, cols, w, sub, cin_layer_size=(128, 128), dtype=np.float64).astype(np.float32), "xDeepFM C3, 65,536-row span")
 
 
 def test_din_c4_full_batch(device):

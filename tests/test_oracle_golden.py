@@ -286,14 +286,19 @@ MODEL_FIXTURES = ["model_deepfm_mixed", "model_deepfm_hash", "model_dcn_vector",
                   "model_din_bn_dice", "model_din_bn_sigmoid"]
 
 
-def run_oracle_model(g, dtype=np.float32):
+def run_oracle_model(g, dtype=np.float32, task=None, abs_weights=False):
+    """task: override the fixture's task ('regression' = the logit PredictionLayer receives); abs_weights: every weight replaced by
+    its magnitude — for models made of sums, products and ReLU an upper bound of the magnitude every sum is taken at
+    (tests/util.assert_close_terms)."""
     meta = golden_meta(g)
-    weights = {k[2:]: v for k, v in g.items() if k.startswith("w/")}
+    weights = {k[2:]: (np.abs(v) if abs_weights else v) for k, v in g.items() if k.startswith("w/")}
     feed = {k[5:]: v for k, v in g.items() if k.startswith("feed/")}
     dnn_cols = columns_from_spec(meta["dnn"])
     lin_cols = columns_from_spec(meta["linear"])
     kw = dict(meta["kwargs"])
     kw["dtype"] = dtype
+    if task is not None:
+        kw["task"] = task
     name = meta["model"]
     if name == "DeepFM":
         return RM.deepfm(lin_cols, dnn_cols, weights, feed, **kw)
