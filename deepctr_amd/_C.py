@@ -15,6 +15,7 @@ c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
 ABI_VERSION = 7
 
+E_UNSUPPORTED = -5               # DCTR_E_UNSUPPORTED: valid request this build does not implement
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1
 OPT_CODES = {"adam": 0, "adagrad": 1, "rmsprop": 2, "sgd": 3}
@@ -165,6 +166,12 @@ class DinAttnArgs(ctypes.Structure):
                 ("out_stride", c_i64), ("scores", c_vp), ("workspace", c_vp), ("workspace_bytes", c_sz)]
 
 
+class DinGatherArgs(ctypes.Structure):
+    _fields_ = [("n_feats", c_i32), ("ids_is_i64", c_i32), ("hist_ids", c_vp * 2), ("hist_stride", c_i64), ("query_ids", c_vp * 2),
+                ("query_stride", c_i64), ("hist_table", c_vp * 2), ("query_table", c_vp * 2), ("hist_vocab", c_i64 * 2),
+                ("query_vocab", c_i64 * 2), ("mask_zero", c_i32 * 2), ("status", c_vp)]
+
+
 # every symbol include/dctr.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dctr_abi_version": (ctypes.c_int, []),
@@ -237,6 +244,7 @@ SYMBOLS = {
     "dctr_opt_multi": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_din_attn_workspace_bytes": (c_sz, [ctypes.POINTER(DinAttnArgs)]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
+    "dctr_din_attn_gather_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), ctypes.POINTER(DinGatherArgs), c_vp]),
 }
 
 _LIB = None

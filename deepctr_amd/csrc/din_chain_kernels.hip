@@ -52,6 +52,16 @@ struct Params {
     const float* out_bias;             // [1]
     float* raw;                        // [B * T]
     int64_t n_units;
+    // GATHER instantiations (dctr_din_attn_gather_fwd): query / keys are NULL, the rows come straight from the embedding tables —
+    // key row (b, t) = concat_h table_h[hist_ids_h[b, t]], query row b = concat_h qtable_h[query_ids_h[b]]; every feature E / NF wide
+    int32_t nf, ids_i64;
+    const void* hist_ids[2];
+    const void* query_ids[2];
+    int64_t hist_stride, query_stride;
+    const float* hist_table[2];
+    const float* query_table[2];
+    int64_t hist_vocab[2], query_vocab[2];
+    int32_t* status;
 };
 
 typedef const __attribute__((address_space(1))) f32x4* gbl_f4_t;
@@ -81,7 +91,11 @@ struct Lay {
     static constexpr int END = W0A + K0 * S0A;
 };
 
-template <int EB, int NB0, int NS0, int NS1>
+__device__ __forceinline__ int64_t load_any_id(const void* base, int64_t idx, int i64) {
+    return i64 ? reinterpret_cast<const int64_t*>(base)[idx] : (int64_t)reinterpret_cast<const int32_t*>(base)[idx];
+}
+
+template <int EB, int NB0, int NS0, int NS1, bool GATHER = false>
 __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
     typedef Lay<EB, NB0, NS0, NS1> L;
     constexpr int E = L::E, NT0 = L::NT0, N0P = L::N0P;
@@ -151,13 +165,55 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
         // rows of this lane's two N tiles; query rows
         const float* kp[RT];
         const float* qp[RT];
+        // GATHER: the table rows of this lane's (sample, position) rows per feature (as float offsets from the table base; an id
+        // outside the vocabulary reads row 0 and raises the status flag)
+        int64_t kro[RT][2], qro[RT][2];
+        const int EH = GATHER ? E / max(p.nf, 1) : E;       // embedding_dim of one history feature
+        const int EBH = EH / 16;                            // its 16-wide blocks
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
             const int64_t R = min(R0 + 16 * nt + j, p.rows - 1);
             const int64_t b = (int64_t)((uint32_t)R / (uint32_t)p.T);      // host: rows < 2^31
-            kp[nt] = p.keys + R * E + 4 * g;
-            qp[nt] = p.query + b * E + 4 * g;
+            if constexpr (GATHER) {
+                const int64_t t = R - b * p.T;
+                bool bad = false;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h < p.nf) {
+                        const int64_t ik = load_any_id(p.hist_ids[h], b * p.hist_stride + t, p.ids_i64);
+                        const int64_t iq = load_any_id(p.query_ids[h], b * p.query_stride, p.ids_i64);
+                        const bool okk = (uint64_t)ik < (uint64_t)p.hist_vocab[h], okq = (uint64_t)iq < (uint64_t)p.query_vocab[h];
+                        bad = bad || !okk || !okq;
+                        kro[nt][h] = (okk ? ik : 0) * EH + 4 * g;
+                        qro[nt][h] = (okq ? iq : 0) * EH + 4 * g;
+                    } else {
+                        kro[nt][h] = qro[nt][h] = 0;
+                    }
+                }
+                if (bad && p.status != nullptr && R0 + 16 * nt + j < p.rows) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
+                kp[nt] = qp[nt] = nullptr;
+            } else {
+                kp[nt] = p.keys + R * E + 4 * g;
+                qp[nt] = p.query + b * E + 4 * g;
+            }
         }
+        // the 16-B piece of block c of this lane's key / query row
+        auto load_k = [&](int nt, int c) -> f32x4 {
+            if constexpr (GATHER) {
+                const int h = c >= EBH ? 1 : 0;
+                return *(gbl_f4_t)(p.hist_table[h] + kro[nt][h] + 16 * (c - h * EBH));
+            } else {
+                return *(gbl_f4_t)(kp[nt] + 16 * c);
+            }
+        };
+        auto load_q = [&](int nt, int c) -> f32x4 {
+            if constexpr (GATHER) {
+                const int h = c >= EBH ? 1 : 0;
+                return *(gbl_f4_t)(p.query_table[h] + qro[nt][h] + 16 * (c - h * EBH));
+            } else {
+                return *(gbl_f4_t)(qp[nt] + 16 * c);
+            }
+        };
         // ---- layer 0.  Accumulators start at the bias: tile tt < 4 NB0 (b128 tile mt of group 0): feature 16g + 4r + mt;
         // tile 4 NB0 + s: feature 64 NB0 + 16 s + 4g + r
         f32x4 acc0[NT0][RT];
@@ -175,8 +231,8 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
         f32x4 qc[RT], kc[RT], qn[RT], kn[RT];
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
-            qc[nt] = *(gbl_f4_t)(qp[nt]);
-            kc[nt] = *(gbl_f4_t)(kp[nt]);
+            qc[nt] = load_q(nt, 0);
+            kc[nt] = load_k(nt, 0);
             qn[nt] = qc[nt];
             kn[nt] = kc[nt];
         }
@@ -197,8 +253,8 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
             const int c1 = min(c + 1, EB - 1);             // raw rows of the next block: in flight during this block's MFMAs
 #pragma unroll
             for (int nt = 0; nt < RT; ++nt) {
-                qn[nt] = *(gbl_f4_t)(qp[nt] + 16 * c1);
-                kn[nt] = *(gbl_f4_t)(kp[nt] + 16 * c1);
+                qn[nt] = load_q(nt, c1);
+                kn[nt] = load_k(nt, c1);
             }
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
@@ -312,18 +368,23 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
     }
 }
 
-template <int EB, int NB0, int NS0, int NS1>
-static int launch_one(const Params& p, hipStream_t stream) {
+template <int EB, int NB0, int NS0, int NS1, bool GATHER>
+static int launch_one_g(const Params& p, hipStream_t stream) {
     typedef Lay<EB, NB0, NS0, NS1> L;
     const size_t lds = (size_t)L::END * sizeof(float);
     if (lds > 160 * 1024) return 0;
     static thread_local size_t granted[DCTR_MAX_DEVICES] = {0};
-    if (dctr_grant_lds((const void*)din_chain_kernel<EB, NB0, NS0, NS1>, lds, granted) != hipSuccess) return 0;
+    if (dctr_grant_lds((const void*)din_chain_kernel<EB, NB0, NS0, NS1, GATHER>, lds, granted) != hipSuccess) return 0;
     int64_t grid = dctr_ceil_div(p.n_units, (int64_t)NW);
     const int64_t cus = dctr_n_cus();
     if (grid > cus) grid = cus;
-    DCTR_LAUNCH((din_chain_kernel<EB, NB0, NS0, NS1>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
+    DCTR_LAUNCH((din_chain_kernel<EB, NB0, NS0, NS1, GATHER>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
     return 1;
+}
+
+template <int EB, int NB0, int NS0, int NS1>
+static int launch_one(const Params& p, hipStream_t stream) {
+    return p.nf > 0 ? launch_one_g<EB, NB0, NS0, NS1, true>(p, stream) : launch_one_g<EB, NB0, NS0, NS1, false>(p, stream);
 }
 
 template <int EB>
@@ -342,8 +403,9 @@ static int launch_e(const Params& p, int nb0, int ns0, int ns1, hipStream_t stre
 int try_launch(const float* query, const float* keys, int64_t batch, int T, int E, int n_layers, const int32_t* units,
                const float* const* kernels, const float* const* biases, int activation, const float* const* dice_alpha,
                const float* const* dice_mean, const float* const* dice_var, float dice_eps, const float* out_kernel,
-               const float* out_bias, float* raw, hipStream_t stream) {
+               const float* out_bias, float* raw, hipStream_t stream, const dctr_din_gather_t* gd) {
     if (n_layers != 2 || (E != 16 && E != 32 && E != 64)) return 0;
+    if (gd != nullptr && (gd->n_feats < 1 || gd->n_feats > 2 || E % (16 * gd->n_feats) != 0)) return 0;
     const int n0 = units[0], n1 = units[1];
     if (n0 < 1 || n1 < 1 || n1 > 64) return 0;
     const int nb0 = n0 >= 64 ? 1 : 0;
@@ -371,6 +433,21 @@ int try_launch(const float* query, const float* keys, int64_t batch, int T, int 
     p.out_kernel = out_kernel;
     p.out_bias = out_bias;
     p.raw = raw;
+    if (gd != nullptr) {
+        p.nf = gd->n_feats;
+        p.ids_i64 = gd->ids_is_i64;
+        p.hist_stride = gd->hist_stride;
+        p.query_stride = gd->query_stride;
+        p.status = gd->status;
+        for (int h = 0; h < gd->n_feats; ++h) {
+            p.hist_ids[h] = gd->hist_ids[h];
+            p.query_ids[h] = gd->query_ids[h];
+            p.hist_table[h] = gd->hist_table[h];
+            p.query_table[h] = gd->query_table[h];
+            p.hist_vocab[h] = gd->hist_vocab[h];
+            p.query_vocab[h] = gd->query_vocab[h];
+        }
+    }
     p.n_units = dctr_ceil_div(p.rows, (int64_t)UROWS);
     if (E == 16) return launch_e<1>(p, nb0, ns0, ns1, stream);
     if (E == 32) return launch_e<2>(p, nb0, ns0, ns1, stream);

@@ -19,7 +19,7 @@ namespace dctr_din_chain {      // din_chain_kernels.hip: the row-chained form o
 int try_launch(const float* query, const float* keys, int64_t batch, int T, int E, int n_layers, const int32_t* units,
                const float* const* kernels, const float* const* biases, int activation, const float* const* dice_alpha,
                const float* const* dice_mean, const float* const* dice_var, float dice_eps, const float* out_kernel,
-               const float* out_bias, float* raw, hipStream_t stream);
+               const float* out_bias, float* raw, hipStream_t stream, const dctr_din_gather_t* gd = nullptr);
 }
 
 #ifdef DCTR_LAB_TIMING
@@ -683,6 +683,67 @@ __global__ __launch_bounds__(256) void din_pool_kernel(const float* raw, const f
     }
 }
 
+// the same with the keys read from the embedding tables (dctr_din_attn_gather_fwd): the sample's ids sit in LDS, position t counts
+// iff every mask_zero feature's id != 0 (keras Concat.compute_mask over the history features, reference layers/utils.py:198-228)
+struct DinPoolGather {
+    int32_t nf, ids_i64;
+    const void* hist_ids[2];
+    int64_t hist_stride;
+    const float* hist_table[2];
+    int64_t hist_vocab[2];
+    int32_t mask_zero[2];
+};
+__global__ __launch_bounds__(256) void din_pool_gather_kernel(const float* raw, DinPoolGather gd, int64_t batch, int T, int E,
+                                                              int weight_normalization, float* out, int64_t out_stride, float* scores) {
+    extern __shared__ float sc_all[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    float* sc = sc_all + wave * (3 * T);
+    int* row = reinterpret_cast<int*>(sc + T);              // [nf][T] table rows (vocabularies < 2^31 on this path: host)
+    const int EH = E / gd.nf;
+    for (int t = lane; t < T; t += 64) {
+        bool m = true;
+        for (int h = 0; h < gd.nf; ++h) {
+            const int64_t idx = b * gd.hist_stride + t;
+            const int64_t id = gd.ids_i64 ? reinterpret_cast<const int64_t*>(gd.hist_ids[h])[idx]
+                                          : (int64_t)reinterpret_cast<const int32_t*>(gd.hist_ids[h])[idx];
+            if (gd.mask_zero[h]) m = m && id != 0;
+            row[h * T + t] = (uint64_t)id < (uint64_t)gd.hist_vocab[h] ? (int)id : 0;
+        }
+        sc[t] = m ? raw[b * (int64_t)T + t] : (weight_normalization ? -4294967296.f : 0.f);
+    }
+    if (weight_normalization) {
+        float mx = -INFINITY;
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, sc[t]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        float den = 0.f;
+        for (int t = lane; t < T; t += 64) den += expf(sc[t] - mx);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) den += __shfl_xor(den, m, 64);
+        for (int t = lane; t < T; t += 64) sc[t] = expf(sc[t] - mx) / den;
+    }
+    if (scores != nullptr)
+        for (int t = lane; t < T; t += 64) scores[b * (int64_t)T + t] = sc[t];
+    for (int e = lane; e < E; e += 64) {
+        const int h = e / EH, eo = e - h * EH;
+        const float* tb = gd.hist_table[h] + eo;
+        const int* rw = row + h * T;
+        float acc = 0.f;
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+            float kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kv[u] = tb[(int64_t)rw[t + u] * EH];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[t + u], kv[u], acc);
+        }
+        for (; t < T; ++t) acc = fmaf(sc[t], tb[(int64_t)rw[t] * EH], acc);
+        out[b * out_stride + e] = acc;
+    }
+}
+
 // LDS plan of the fast path; returns false when the shape does not qualify
 bool din_fast_plan(const dctr_din_attn_args_t* a, DinFastParams& p, size_t& lds_bytes) {
     if (a->n_layers < 1 || a->dim % 16 != 0 || a->dim > 64) return false;   // <= 4 float4 chunks per lane and tile
@@ -846,4 +907,55 @@ extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* strea
     DCTR_REQUIRE(a->batch <= 0x7fffffffLL, DCTR_E_DIM, "din_attn_pool_fwd: batch too large");
     DCTR_LAUNCH(din_attn_kernel, dim3((unsigned)a->batch), dim3(256), lds, (hipStream_t)stream, p);
     return dctr_launch_status("dctr_din_attn_pool_fwd");
+}
+
+// a13 with the lookups folded in (reference models/sequence/din.py:62-76 + layers/sequence.py:261-298): the behaviour sequences'
+// key rows and the query rows are read from the embedding tables inside the kernels, [B, T, E] keys never exist in HBM.
+extern "C" int dctr_din_attn_gather_fwd(const dctr_din_attn_args_t* a, const dctr_din_gather_t* g, void* stream) {
+    DCTR_REQUIRE(a != nullptr && g != nullptr, DCTR_E_NULL, "din_attn_gather_fwd: null args");
+    DCTR_REQUIRE(a->batch >= 0 && a->maxlen >= 1 && a->dim >= 1 && a->n_layers >= 0 && a->n_layers <= DIN_MAX_LAYERS, DCTR_E_DIM,
+                 "din_attn_gather_fwd: bad sizes (B=%lld T=%d E=%d layers=%d)", (long long)a->batch, a->maxlen, a->dim, a->n_layers);
+    if (a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->out && a->out_kernel && a->out_bias && a->units && a->kernels && a->biases, DCTR_E_NULL, "din_attn_gather_fwd: null pointer");
+    DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_DICE, DCTR_E_ENUM, "din_attn_gather_fwd: activation %d",
+                 a->activation);
+    DCTR_REQUIRE(a->out_stride >= a->dim, DCTR_E_DIM, "din_attn_gather_fwd: out_stride < dim");
+    DCTR_REQUIRE(g->n_feats >= 1 && g->n_feats <= 2, DCTR_E_UNSUPPORTED, "din_attn_gather_fwd: %d history features (1 or 2)", g->n_feats);
+    DCTR_REQUIRE(a->dim % (16 * g->n_feats) == 0, DCTR_E_UNSUPPORTED,
+                 "din_attn_gather_fwd: every history feature must be dim / n_feats wide, a multiple of 16 (dim %d, %d features)", a->dim, g->n_feats);
+    const int64_t rows = a->batch * (int64_t)a->maxlen;
+    DCTR_REQUIRE(rows < 0x7fffffffLL, DCTR_E_DIM, "din_attn_gather_fwd: batch x maxlen too large");
+    for (int h = 0; h < g->n_feats; ++h) {
+        DCTR_REQUIRE(g->hist_ids[h] && g->query_ids[h] && g->hist_table[h] && g->query_table[h], DCTR_E_NULL, "din_attn_gather_fwd: feature %d null", h);
+        DCTR_REQUIRE(g->hist_vocab[h] >= 1 && g->hist_vocab[h] < 0x7fffffffLL && g->query_vocab[h] >= 1, DCTR_E_DIM,
+                     "din_attn_gather_fwd: vocabulary of feature %d", h);
+        DCTR_REQUIRE(dctr_aligned16(g->hist_table[h]) && dctr_aligned16(g->query_table[h]), DCTR_E_ALIGN, "din_attn_gather_fwd: tables 16-B aligned");
+    }
+    DCTR_REQUIRE(g->hist_stride >= a->maxlen && g->query_stride >= 1, DCTR_E_DIM, "din_attn_gather_fwd: id strides");
+    DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= (size_t)rows * sizeof(float), DCTR_E_NULL,
+                 "din_attn_gather_fwd: needs the [B * T] float workspace (dctr_din_attn_workspace_bytes)");
+    if (a->activation == DCTR_ACT_DICE)
+        DCTR_REQUIRE(a->dice_alpha && a->dice_mean && a->dice_var, DCTR_E_NULL, "din_attn_gather_fwd: dice without parameters");
+    const size_t pool_lds = (size_t)4 * 3 * a->maxlen * sizeof(float);
+    DCTR_REQUIRE(pool_lds <= 64 * 1024, DCTR_E_UNSUPPORTED, "din_attn_gather_fwd: maxlen %d too long", a->maxlen);
+    float* raw = static_cast<float*>(a->workspace);
+    const int ok = dctr_din_chain::try_launch(nullptr, nullptr, a->batch, a->maxlen, a->dim, a->n_layers, a->units, a->kernels, a->biases,
+                                              a->activation, a->dice_alpha, a->dice_mean, a->dice_var, a->dice_eps, a->out_kernel,
+                                              a->out_bias, raw, (hipStream_t)stream, g);
+    DCTR_REQUIRE(ok, DCTR_E_UNSUPPORTED,
+                 "din_attn_gather_fwd: the row-chained score kernel takes two-layer attention MLPs (units[0] <= 112, units[1] <= 64) and "
+                 "dim 16 / 32 / 64 — use the lookups + dctr_din_attn_pool_fwd");
+    DinPoolGather pg{};
+    pg.nf = g->n_feats;
+    pg.ids_i64 = g->ids_is_i64;
+    pg.hist_stride = g->hist_stride;
+    for (int h = 0; h < g->n_feats; ++h) {
+        pg.hist_ids[h] = g->hist_ids[h];
+        pg.hist_table[h] = g->hist_table[h];
+        pg.hist_vocab[h] = g->hist_vocab[h];
+        pg.mask_zero[h] = g->mask_zero[h];
+    }
+    hipLaunchKernelGGL(din_pool_gather_kernel, dim3((unsigned)dctr_ceil_div(a->batch, (int64_t)4)), dim3(256), pool_lds, (hipStream_t)stream,
+                       raw, pg, a->batch, a->maxlen, a->dim, a->weight_normalization, a->out, a->out_stride, a->scores);
+    return dctr_launch_status("dctr_din_attn_gather_fwd");
 }

@@ -57,6 +57,36 @@ class _DIN(FeatureModel):
             self.dense = self._add(Dense(1, use_bias=False, seed=seed, device=self.device).build_for(last))
             self.prediction = self._add(PredictionLayer(task, device=self.device).build_for())
         self._buf = {}
+        # query / key lookups folded into the attention kernels (dctr_din_attn_gather_fwd: the [B, T, E] keys never reach HBM);
+        # False, or a shape outside those kernels: dctr_embed_lookup_multi + dctr_din_attn_pool_fwd
+        self.fold_lookups = True
+        self._fold_failed = False
+
+    def _fold_lookups_ok(self):
+        if not self.fold_lookups or self._fold_failed or len(self.history_cols) > 2 or len(self.history_cols) != len(self.query_cols):
+            return False
+        cols = list(self.history_cols) + list(self.query_cols)
+        if any(fc.use_hash and not prehashed_on_host(fc) for fc in cols):
+            return False
+        dims = set(fc.embedding_dim for fc in cols)
+        return len(dims) == 1 and dims.pop() % 16 == 0 and not self.attention.return_score
+
+    def _attention_folded(self, staged, lo, hi, ws, out):
+        """AttentionSequencePoolingLayer over rows [lo, hi) with the lookups inside the kernels; False when the library declines."""
+        q_ids = [staged.ids[row, lo:hi] for row in self._query_rows]
+        h_ids = [staged.seq[fc.name][lo:hi] for fc in self.history_cols]
+        h_tab = [self.tables[fc.embedding_name].embeddings for fc in self.history_cols]
+        q_tab = [self.tables[fc.embedding_name].embeddings for fc in self.query_cols]
+        mz = [bool(self.tables[fc.embedding_name].mask_zero) for fc in self.history_cols]
+        la = self.attention.local_att
+        r = ops.din_attention_gather(h_ids, q_ids, h_tab, q_tab, mz, la.dnn.kernels, la.dnn.biases, la.w("kernel"), la.w("bias"),
+                                     self.attention.att_activation, la.dnn.dice_params(),
+                                     weight_normalization=self.attention.weight_normalization, out=out,
+                                     out_stride=self.stage_plan.out_stride, status=ws["status"])
+        if r is None:
+            self._fold_failed = True
+            return False
+        return True
 
     def _stage_inputs(self, feed, staged):
         self.stage_plan.stage(feed, staged)
@@ -73,9 +103,10 @@ class _DIN(FeatureModel):
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
         ws = sp.run(staged, lo, hi)
-        bufs = self._attention_inputs(staged, lo, hi, ws)
         hist_off = sp.extra_offsets["hist"]
-        self.attention.run(bufs["q"], bufs["k"], bufs["m"], out=ws["dnn_in"][:, hist_off:], out_stride=sp.out_stride)
+        if not (self._fold_lookups_ok() and self._attention_folded(staged, lo, hi, ws, ws["dnn_in"][:, hist_off:])):
+            bufs = self._attention_inputs(staged, lo, hi, ws)
+            self.attention.run(bufs["q"], bufs["k"], bufs["m"], out=ws["dnn_in"][:, hist_off:], out_stride=sp.out_stride)
         ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
                 head_w=self.dense.w('kernel'), global_bias=self.prediction.w('global_bias'),
                 sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out)

@@ -712,6 +712,66 @@ def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, 
     return out.reshape(B, 1, E) if own_out else out
 
 
+def din_attention_gather(hist_ids, query_ids, hist_tables, query_tables, mask_zero, kernels, biases, out_kernel, out_bias, activation="sigmoid",
+                         dice=None, dice_eps=1e-9, weight_normalization=False, out=None, out_stride=None, status=None):
+    """AttentionSequencePoolingLayer.call with the query / key lookups folded in (dctr_din_attn_gather_fwd): ``hist_ids`` = list of
+    [B, T] id tensors (one per history feature, int32 or int64 alike), ``query_ids`` = list of [B] id tensors (strided views
+    allowed), ``*_tables`` = the features' [vocab, E_h] embedding tables, ``mask_zero`` = per feature whether id 0 masks the
+    position.  Returns out [B, sum E_h], or None when the shape is outside the fused kernels (caller falls back to the lookups)."""
+    nf = len(hist_ids)
+    if nf < 1 or nf > 2 or len(query_ids) != nf:
+        return None
+    EH = hist_tables[0].shape[1]
+    E = EH * nf
+    if any(t.shape[1] != EH for t in list(hist_tables) + list(query_tables)) or EH % 16 != 0 or E not in (16, 32, 64) or len(kernels) != 2:
+        return None
+    B, T = hist_ids[0].shape
+    i64 = hist_ids[0].dtype == torch.int64
+    if any(t.dtype != hist_ids[0].dtype or t.stride(1) != 1 or t.stride(0) != hist_ids[0].stride(0) for t in hist_ids):
+        return None
+    if any(t.dtype != hist_ids[0].dtype or t.stride(0) != query_ids[0].stride(0) for t in query_ids):
+        return None
+    units = [k.shape[1] for k in kernels]
+    kernels = [_f32c(k, "kernel") for k in kernels]
+    biases = [None if b is None else _f32c(b, "bias") for b in biases]
+    act = _C.ACT_CODES[activation]
+    if out is None:
+        out = torch.empty(B, E, dtype=torch.float32, device=hist_tables[0].device)
+        out_stride = E
+    da = dm = dv = None
+    if act == _C.ACT_DICE:
+        da = _ptr_array([_f32c(d[0], "alpha") for d in dice])
+        dm = _ptr_array([_f32c(d[1], "mean") for d in dice])
+        dv = _ptr_array([_f32c(d[2], "var") for d in dice])
+    ua, kp, bp = _i32_array(units), _ptr_array(kernels), _ptr_array(biases)
+    ws = torch.empty(max(1, B * T), dtype=torch.float32, device=out.device)
+    a = _C.DinAttnArgs(query=None, keys=None, key_mask=None, batch=B, maxlen=T, dim=E, n_layers=2, activation=act,
+                       units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
+                       biases=ctypes.cast(bp, ctypes.c_void_p),
+                       dice_alpha=None if da is None else ctypes.cast(da, ctypes.c_void_p),
+                       dice_mean=None if dm is None else ctypes.cast(dm, ctypes.c_void_p),
+                       dice_var=None if dv is None else ctypes.cast(dv, ctypes.c_void_p), dice_eps=float(dice_eps),
+                       weight_normalization=int(bool(weight_normalization)),
+                       out_kernel=_f32c(out_kernel, "out_kernel").reshape(-1).data_ptr(),
+                       out_bias=_f32c(out_bias, "out_bias").data_ptr(), out=out.data_ptr(), out_stride=out_stride, scores=None,
+                       workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4)
+    g = _C.DinGatherArgs(n_feats=nf, ids_is_i64=int(i64), hist_stride=hist_ids[0].stride(0), query_stride=query_ids[0].stride(0),
+                         status=None if status is None else status.data_ptr())
+    for h in range(nf):
+        g.hist_ids[h] = hist_ids[h].data_ptr()
+        g.query_ids[h] = query_ids[h].data_ptr()
+        g.hist_table[h] = _f32c(hist_tables[h], "table").data_ptr()
+        g.query_table[h] = _f32c(query_tables[h], "table").data_ptr()
+        g.hist_vocab[h] = hist_tables[h].shape[0]
+        g.query_vocab[h] = query_tables[h].shape[0]
+        g.mask_zero[h] = int(bool(mask_zero[h]))
+    rc = _C.lib().dctr_din_attn_gather_fwd(ctypes.byref(a), ctypes.byref(g), _C.stream_ptr())
+    if rc == _C.E_UNSUPPORTED:
+        return None
+    _C.check(rc, "dctr_din_attn_gather_fwd")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY §8(f) rank 1: backward + optimizer (include/dctr.h, last section)
 # ---------------------------------------------------------------------------------------------

@@ -482,6 +482,31 @@ typedef struct {
 size_t dctr_din_attn_workspace_bytes(const dctr_din_attn_args_t* args);
 int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* args, void* stream);
 
+/* ABI 7 — a13 with the lookups of the behaviour sequences and of the query features folded in (deepctr/models/sequence/din.py:62-76
+ * embedding_lookup of query / keys + concat_func, layers/sequence.py:261-298): key row (b, t) = concat_h hist_table[h][hist_ids[h][b, t]],
+ * query row b = concat_h query_table[h][query_ids[h][b]], read inside the score and pooling kernels — the [B, T, dim] key tensor and
+ * the key mask never exist in HBM.  args->query / keys / key_mask are ignored; args->workspace ([B * T] floats) is required.
+ * Position t of sample b counts iff hist_ids[h][b, t] != 0 for every feature with mask_zero[h] (keras Concat.compute_mask: the
+ * conjunction of the mask_zero embeddings' masks); no mask_zero feature: every position counts.  An id outside its vocabulary reads
+ * row 0 and raises DCTR_STATUS_INDEX_OOR in *status.  Plain ids only (hashed features: hash first, or use the lookups).
+ * Covered: 1 or 2 features of equal width (dim / n_feats, a multiple of 16), dim in {16, 32, 64}, two-layer attention MLPs of the
+ * row-chained score kernel; else DCTR_E_UNSUPPORTED (use dctr_embed_lookup_multi + dctr_din_attn_pool_fwd). */
+typedef struct {
+    int32_t n_feats;
+    int32_t ids_is_i64;
+    const void* hist_ids[2];      /* [B, maxlen] ids, row stride hist_stride (elements) */
+    int64_t hist_stride;
+    const void* query_ids[2];     /* [B] ids, element stride query_stride */
+    int64_t query_stride;
+    const float* hist_table[2];   /* [hist_vocab, dim / n_feats] fp32, 16-B aligned */
+    const float* query_table[2];  /* [query_vocab, dim / n_feats] (usually the same table: shared embedding_name) */
+    int64_t hist_vocab[2];
+    int64_t query_vocab[2];
+    int32_t mask_zero[2];
+    int32_t* status;              /* DEVICE int or NULL */
+} dctr_din_gather_t;
+int dctr_din_attn_gather_fwd(const dctr_din_attn_args_t* args, const dctr_din_gather_t* gather, void* stream);
+
 /* ================================================================================================
  * SURVEY.md §8(f) rank 1 — backward + optimizer of the hot path ("next" row; forward entry points above are
  * unchanged).  The reference has no code for these (Keras autodiff, tf.keras.optimizers.Adam): each entry is the

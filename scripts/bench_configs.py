@@ -85,7 +85,7 @@ def run_span(name, model, feed, B, reps=8, dnn_flop=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,c3_span,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
-                                         "dcn_mix,nfm,afm,pnn,c4,c4_span,c5,c5_span")
+                                         "dcn_mix,nfm,afm,pnn,c4,c4_span,c4_lookups,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
     args = ap.parse_args()
@@ -211,6 +211,10 @@ def main():
         run("C4 DIN T=50 E=32 (dice)", m, feed, B, args.steps, ring)
         if "c4_span" in want:
             run_span("C4 DIN (1 call / %d batches)" % ring, m, feed, B)
+        if "c4_lookups" in want:                             # the lookup route: dctr_embed_lookup_multi -> keys in HBM -> attention
+            m.fold_lookups = False
+            run("C4 DIN, lookup route (keys through HBM)", m, feed, B, args.steps, ring)
+            run_span("C4 DIN, lookup route (1 call / %d batches)" % ring, m, feed, B)
         del m
     if "c5" in want or "c5_span" in want:
         V, E, B = 10 ** 7, 32, 8192

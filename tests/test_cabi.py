@@ -174,7 +174,7 @@ def test_every_ctypes_mirror_has_the_layout_the_c_compiler_gives_the_header(tmp_
              "FieldGrad": "dctr_field_grad_t", "GatherFmBwdArgs": "dctr_gather_fm_bwd_args_t", "PoolBwdArgs": "dctr_pool_bwd_args_t",
              "MlpBwdArgs": "dctr_mlp_bwd_args_t", "DnnTrainLayer": "dctr_dnn_train_layer_t", "CinBwdArgs": "dctr_cin_bwd_args_t", "CrossBwdArgs": "dctr_crossnet_bwd_args_t", "CrossMixBwdArgs": "dctr_crossnet_mix_bwd_args_t",
              "AfmBwdArgs": "dctr_afm_bwd_args_t", "HostCol": "dctr_host_col_t", "AdamSeg": "dctr_adam_seg_t",
-             "DinAttnArgs": "dctr_din_attn_args_t", "CrossnetArgs": "dctr_crossnet_args_t"}
+             "DinAttnArgs": "dctr_din_attn_args_t", "CrossnetArgs": "dctr_crossnet_args_t", "DinGatherArgs": "dctr_din_gather_t"}
     mirrors = [n for n in dir(_C) if isinstance(getattr(_C, n), type) and issubclass(getattr(_C, n), ctypes.Structure)
                and getattr(_C, n) is not ctypes.Structure]
     assert sorted(mirrors) == sorted(pairs), "a ctypes mirror without a header struct in this test: %s" % (set(mirrors) ^ set(pairs))

@@ -273,6 +273,29 @@ def test_din_c4_full_batch(device):
     perm = rng.permutation(n)
     assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=n), y[perm])
     assert_close(model.predict(feed, batch_size=500), y, rtol=1e-5, atol=1e-6, what="DIN split")
+    # the route above folds the query / key lookups into the attention kernels (dctr_din_attn_gather_fwd: no [B, T, E] keys in
+    # HBM); the lookup route (dctr_embed_lookup_multi -> keys -> dctr_din_attn_pool_fwd) runs the same arithmetic on the same
+    # values: the same bits — also with softmax-normalised scores, int64 ids and an out-of-range id raising the status flag
+    assert model._fold_lookups_ok() and not model._fold_failed
+    model.fold_lookups = False
+    assert np.array_equal(model.predict(feed, batch_size=n), y)
+    model.fold_lookups = True
+    feed64 = {k: (v.astype(np.int64) if v.dtype == np.int32 else v) for k, v in feed.items()}
+    assert np.array_equal(model.predict(feed64, batch_size=n), y) and not model._fold_failed
+    m2 = DIN(cols, ["item_id", "cate_id"], att_activation="sigmoid", att_weight_normalization=True, att_hidden_size=(64, 32), device=device)
+    w2 = _randomise(m2, rng)
+    y2 = m2.predict(feed, batch_size=n)
+    assert not m2._fold_failed
+    m2.fold_lookups = False
+    assert np.array_equal(m2.predict(feed, batch_size=n), y2)
+    ref2 = RM.din(cols, ["item_id", "cate_id"], w2, {k: v[rows] for k, v in feed.items()}, att_activation="sigmoid", att_hidden_size=(64, 32),
+                  att_weight_normalization=True, dtype=np.float64)
+    check_probs(y2[rows], ref2.astype(np.float32), "DIN softmax attention, folded lookups")
+    bad = dict(feed)
+    bad["hist_cate_id"] = hc.copy()
+    bad["hist_cate_id"][7, 0] = VC + 5
+    with pytest.raises(IndexError):
+        model.predict(bad, batch_size=n)
 
 
 def test_din_c4_shape_vs_oracle(device):
