@@ -230,6 +230,7 @@ SYMBOLS = {
     "dctr_cin_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CinBwdArgs)]),
     "dctr_cin_bwd": (ctypes.c_int, [ctypes.POINTER(CinBwdArgs), c_vp]),
     "dctr_mlp_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(MlpBwdArgs)]),
+    "dctr_mlp_bwd_join": (ctypes.c_int, [c_vp, c_vp]),
     "dctr_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(MlpBwdArgs), c_vp]),
     "dctr_crossnet_mix_bwd_workspace_bytes": (c_sz, [ctypes.POINTER(CrossMixBwdArgs)]),
     "dctr_crossnet_mix_bwd": (ctypes.c_int, [ctypes.POINTER(CrossMixBwdArgs), c_vp]),

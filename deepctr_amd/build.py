@@ -52,6 +52,8 @@ SOURCES = [
 ARCH = "gfx950"
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(ROOT, "include"), "-I", SRC]
+if os.environ.get("DCTR_BUILD_LAB") == "1":      # lab build: the DCTR_* A/B environment switches are compiled in (dctr_common.h)
+    CFLAGS.append("-DDCTR_LAB")
 
 
 def _hipcc():

@@ -5,6 +5,19 @@
 #include <stdint.h>
 
 #include "dctr.h"
+#include <stdlib.h>
+
+// A/B switches of the lab scripts (scripts/gemm_lab.sh, opt_lab.py, bench_train.py): read from the process environment ONLY in a
+// lab build (python -m deepctr_amd.build with DCTR_BUILD_LAB=1 -> -DDCTR_LAB).  The shipped library ignores the environment: its
+// kernel choice, workspace sizing and summation order do not depend on ambient state.
+static inline const char* dctr_lab_env(const char* name) {
+#ifdef DCTR_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 void dctr_set_error(const char* fmt, ...);
 

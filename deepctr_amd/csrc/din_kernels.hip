@@ -836,7 +836,7 @@ extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* strea
             f.out_bias = a->out_bias;
             f.raw = static_cast<float*>(a->workspace);
             // the row-chained score kernel for the shapes it is instantiated for (DCTR_DIN_NO_CHAIN=1: lab switch back)
-            static const bool no_chain = getenv("DCTR_DIN_NO_CHAIN") != nullptr;
+            static const bool no_chain = dctr_lab_env("DCTR_DIN_NO_CHAIN") != nullptr;
             const size_t pool_lds0 = (size_t)4 * a->maxlen * sizeof(float);
             if (!no_chain && pool_lds0 <= 64 * 1024 &&
                 dctr_din_chain::try_launch(a->query, a->keys, a->batch, a->maxlen, a->dim, a->n_layers, a->units, a->kernels, a->biases,

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(Grouped gp) {
 // at B = 4096 and 3 % slower at B = 16,384 on the DeepFM step, profiles/r03c_gemm_lab.log)
 static int small_bk() {
     static const int v = [] {
-        const char* e = getenv("DCTR_GEMM_BK");
+        const char* e = dctr_lab_env("DCTR_GEMM_BK");
         return (e != nullptr && atoi(e) == 32) ? 32 : 16;
     }();
     return v;

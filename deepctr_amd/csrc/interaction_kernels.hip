@@ -817,7 +817,7 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
         const int lda = ((dim + 31) & ~31) + 4;
         // 32 rows per workgroup (two row tiles per weight fragment, x_0 from L2) once that still gives every CU a workgroup
         const size_t lds2 = (size_t)2 * 32 * lda * sizeof(float);
-        static const bool rt1_forced = [] { const char* e = getenv("DCTR_CROSS_RT"); return e != nullptr && atoi(e) == 1; }();   // A/B switch
+        static const bool rt1_forced = [] { const char* e = dctr_lab_env("DCTR_CROSS_RT"); return e != nullptr && atoi(e) == 1; }();   // A/B switch
         const bool rt2 = !rt1_forced && batch >= (int64_t)32 * dctr_n_cus() && lds2 <= 160 * 1024;
         const size_t lds = rt2 ? lds2 : (size_t)3 * 16 * lda * sizeof(float);
         DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d needs %zu B of LDS", dim, lds);

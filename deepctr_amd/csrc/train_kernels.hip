@@ -2058,14 +2058,14 @@ __global__ __launch_bounds__(256) void sum_parts_multi_kernel(SumGroups sg) {
 // rows per dW slice of the chained form (DCTR_DW_ROWS overrides: scripts/gemm_lab.py)
 static int chain_dw_rows() {
     static const int v = [] {
-        const char* e = getenv("DCTR_DW_ROWS");
+        const char* e = dctr_lab_env("DCTR_DW_ROWS");
         const int x = e != nullptr ? atoi(e) : 0;
-        return x >= 32 ? x : 256;
+        return (x >= 32 && x <= 4096 && x % 32 == 0) ? x : 256;      // (whole 32-row tiles, bounded: the value sizes a workspace)
     }();
     return v;
 }
 static bool chain_disabled() {
-    static const bool v = [] { const char* e = getenv("DCTR_MLP_BWD_CHAIN"); return e != nullptr && atoi(e) == 0; }();
+    static const bool v = [] { const char* e = dctr_lab_env("DCTR_MLP_BWD_CHAIN"); return e != nullptr && atoi(e) == 0; }();
     return v;
 }
 static bool mlp_bwd_chained(const dctr_mlp_bwd_args_t* a) {
@@ -2221,10 +2221,11 @@ extern "C" int dctr_mlp_bwd(const dctr_mlp_bwd_args_t* a, void* stream) {
         // the weight-gradient half: on the caller's second stream when it gave one (behind an event on `stream`; the caller joins)
         hipStream_t dws = st;
         if (a->dw_stream != nullptr && (hipStream_t)a->dw_stream != st) {
-            static thread_local hipEvent_t ev[16] = {};
+            // (one event per device and calling thread, alive as long as the process: hipEventRecord re-arms it on every call)
+            static thread_local hipEvent_t ev[DCTR_MAX_DEVICES] = {};
             int dev = 0;
             hipError_t e = hipGetDevice(&dev);
-            DCTR_REQUIRE(e == hipSuccess && dev >= 0 && dev < 16, DCTR_E_UNSUPPORTED, "mlp_bwd: dw_stream on device %d", dev);
+            DCTR_REQUIRE(e == hipSuccess && dev >= 0 && dev < DCTR_MAX_DEVICES, DCTR_E_UNSUPPORTED, "mlp_bwd: dw_stream on device %d", dev);
             if (ev[dev] == nullptr) {
                 e = hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming);
                 DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_bwd: hipEventCreate failed: %s", hipGetErrorString(e));
@@ -2387,8 +2388,8 @@ extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t
     // Two 16-B groups per trip, non-temporal loads / stores, four groups per thread in the largest segment: 175 us for the C2 DeepFM
     // parameter set with touched bytes (6.15 TB/s) against 215 us with default-policy accesses and 205 us with four groups per trip
     // (profiles/r03c_opt_lab.log).  DCTR_OPT_VARIANT / DCTR_OPT_F4 re-run that lab (scripts/opt_lab.py).
-    static const int f4 = [] { const char* e = getenv("DCTR_OPT_F4"); return e != nullptr && atoi(e) >= 1 ? atoi(e) : 4; }();
-    static const int variant = [] { const char* e = getenv("DCTR_OPT_VARIANT"); return e != nullptr ? atoi(e) : 2; }();
+    static const int f4 = [] { const char* e = dctr_lab_env("DCTR_OPT_F4"); return e != nullptr && atoi(e) >= 1 ? atoi(e) : 4; }();
+    static const int variant = [] { const char* e = dctr_lab_env("DCTR_OPT_VARIANT"); return e != nullptr ? atoi(e) : 2; }();
     int64_t bx = dctr_ceil_div(max_n / 4 + 1, (int64_t)(256 * f4));
     if (bx > 4096) bx = 4096;
     const dim3 grid((unsigned)bx, (unsigned)n_segs);
@@ -3042,4 +3043,21 @@ extern "C" int dctr_crossnet_mix_bwd(const dctr_crossnet_mix_bwd_args_t* a, void
     hipLaunchKernelGGL(mix_out_kernel, grid(Bd), dim3(256), 0, st, (const float*)g, (const float*)(ws + m.DX0), B, d, a->dx, a->dx_stride,
                        (int)a->dx_accumulate);
     return dctr_launch_status("dctr_crossnet_mix_bwd");
+}
+
+// The join dctr_mlp_bwd_args_t.dw_stream asks of the caller, as one call: `stream` waits for everything issued to `dw_stream` so far.
+extern "C" int dctr_mlp_bwd_join(void* stream, void* dw_stream) {
+    if (dw_stream == nullptr || dw_stream == stream) return DCTR_OK;
+    static thread_local hipEvent_t ev[DCTR_MAX_DEVICES] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    DCTR_REQUIRE(e == hipSuccess && dev >= 0 && dev < DCTR_MAX_DEVICES, DCTR_E_UNSUPPORTED, "mlp_bwd_join: device %d", dev);
+    if (ev[dev] == nullptr) {
+        e = hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming);
+        DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_bwd_join: hipEventCreate failed: %s", hipGetErrorString(e));
+    }
+    e = hipEventRecord(ev[dev], (hipStream_t)dw_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, ev[dev], 0);
+    DCTR_REQUIRE(e == hipSuccess, (int)e, "mlp_bwd_join: %s", hipGetErrorString(e));
+    return DCTR_OK;
 }

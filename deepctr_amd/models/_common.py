@@ -64,7 +64,7 @@ class FeatureModel(Model):
     def _begin(self):
         self.stage_plan.refresh(self.linear.w('linear_kernel') if self.linear is not None else None)
         dnn = getattr(self, "dnn", None)
-        if dnn is not None and getattr(dnn, "bn_layers", None):
+        if dnn is not None and getattr(dnn, "bn_layers", None) and not getattr(self, "_trainer_step", False):
             dnn.bn_params()             # BatchNormalization scale / shift follow the current weights (in place)
 
     def _check_status(self):
@@ -189,6 +189,8 @@ class FusedForward(object):
 
     def _begin(self):
         super(FusedForward, self)._begin()
+        if getattr(self, "_trainer_step", False):
+            return                      # (the HIP training step reads neither the padded copies nor the bf16x3 images)
         if self._pad is not None:
             self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
         if self._bf3 is not None:

@@ -95,7 +95,7 @@ class _DCN(FusedForward, FeatureModel):
 
     def _begin(self):
         super(_DCN, self)._begin()
-        if self._xops is not None:
+        if self._xops is not None and not getattr(self, "_trainer_step", False):
             self._cross_operands()      # refresh in place: marshalled launches keep pointing at the buffers
         # (the HIP training step works on its own packed parameter tensors — the layer's weights are views of them — and reads
         #  nothing of this: no torch.stack launches per step there)

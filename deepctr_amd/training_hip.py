@@ -351,7 +351,8 @@ class HipTrainer(object):
         if self.dice_dnn:
             ops.mlp_bwd(x, in_dim, dnn.kernels, buf["acts"], "dice", self.p_head.w if dlogit is not None else None, dlogit, dk, db,
                         self.p_head.g if dlogit is not None else None, dx=dx, d_out=d_out, biases=dnn.biases, dice=dnn.dice_params(),
-                        d_dice_alpha=[p.g for p in self.p_dice_alpha], dice_batch=buf["dice_batch"], saved_z=buf["pre"])
+                        d_dice_alpha=[p.g for p in self.p_dice_alpha], dice_batch=buf["dice_batch"], saved_z=buf["pre"],
+                        workspace=buf.setdefault("mlp_bwd_ws_dice", {}))
             return
         if not self.slow_dnn:
             # the weight-gradient launches go to a second stream (dctr_mlp_bwd_args_t.dw_stream): they run beside the embedding
@@ -382,7 +383,9 @@ class HipTrainer(object):
             xin, kin = (x, in_dim) if l == 0 else (buf["acts"][l - 1], units[l - 1])
             dst = dx if l == 0 else buf["dpre"][l - 1]
             # dense part of the layer: d_bias += colsum(dz), dW += x^T dz, dH_{l-1} = dz W^T  (one-layer headless linear dctr_mlp_bwd)
-            ops.mlp_bwd(xin, kin, [dnn.kernels[l]], [buf["acts"][l]], "linear", None, None, [dk[l]], [db[l]], None, dx=dst, d_out=dz)
+            # (one cached workspace per layer: the call would otherwise allocate one per layer and step)
+            ops.mlp_bwd(xin, kin, [dnn.kernels[l]], [buf["acts"][l]], "linear", None, None, [dk[l]], [db[l]], None, dx=dst, d_out=dz,
+                        workspace=buf.setdefault("mlp_bwd_ws_l%d" % l, {}))
             dh = dst
 
     side_stream = True          # False: everything on the caller's stream (A/B in scripts/bench_train.py --no-side-stream)
@@ -516,7 +519,8 @@ class HipTrainer(object):
         ops.mlp_bwd(buf["att_in"], 4 * E, la.dnn.kernels, buf["att_acts"], act, pa["out_w"].w, buf["d_score"],
                     [p.g for p in pa["kernels"]], [p.g for p in pa["biases"]], pa["out_w"].g, dx=buf["d_att_in"],
                     biases=la.dnn.biases, dice=dice, d_dice_alpha=[p.g for p in pa["alphas"]] if pa["alphas"] else None,
-                    dice_batch=dice_batch, saved_z=buf["att_z"] if dice_batch is not None else None)
+                    dice_batch=dice_batch, saved_z=buf["att_z"] if dice_batch is not None else None,
+                    workspace=buf.setdefault("mlp_bwd_ws_att", {}))
         ops.din_att_in_bwd(buf["d_att_in"], q, k, buf["dk"], dx, self.qcol)
         for (fc, idx, hm, col), pt in zip(bufs["key_lookups"], self.p_hist):
             if pt.g is not None:                                   # frozen history table: no scatter
@@ -626,10 +630,12 @@ class HipTrainer(object):
         self._loss_acc = loss_acc
         model, sp = self.model, self.model.stage_plan
         model._trainer_owns_cross = self.is_dcn            # (_DCN._begin: no re-packing of the cross weights for this call)
-        try:
+        model._trainer_step = True          # (_begin: only what the step reads — no inference-form BatchNormalization scale / shift, no
+        try:                                #  zero-padded DNN copies, no packed cross operands; predict() refreshes them itself)
             model._begin()                  # weight-derived forward buffers follow the last update
         finally:
             model._trainer_owns_cross = False
+            model._trainer_step = False
         self.n_steps += 1
         B = hi - lo
         buf = self._buffers(B)

@@ -603,12 +603,16 @@ typedef struct {
     void* dw_stream;              /* ABI 6.  NULL, or a second hipStream_t: the weight-gradient half of the chained form (the grouped
                                      dW / d_bias GEMM and its slice sum) is launched there behind an event on `stream`, so that it
                                      runs beside what the caller launches next on `stream` (the embedding scatter, atomics-bound).
-                                     The CALLER joins the two streams before it reads d_kernels / d_biases or reuses the workspace. */
+                                     The CALLER joins the two streams (dctr_mlp_bwd_join) before it reads d_kernels / d_biases or
+                                     reuses the workspace — and before anything on `stream` OVERWRITES what the side stream still
+                                     reads: x, acts[l] (the layers' inputs X_l) and the dZ_l slices inside the workspace. */
     const float* const* saved_z;  /* ABI 6, DCTR_ACT_DICE.  NULL, or HOST array of DEVICE pointers [out_l] (entries may be NULL): layer l's
                                      pre-activations z_l = x_l W_l + b_l, dense [B, units[l]], as a forward launch wrote them (training-mode
                                      Dice runs the layers one by one and has them): the recompute GEMM of that layer is skipped         */
 } dctr_mlp_bwd_args_t;
 size_t dctr_mlp_bwd_workspace_bytes(const dctr_mlp_bwd_args_t* args);
+/* `stream` waits (event record + wait, no host synchronisation) for everything issued to `dw_stream` so far.  No-op for NULL / equal streams. */
+int dctr_mlp_bwd_join(void* stream, void* dw_stream);
 
 /* Dice.call under training=True (deepctr/layers/activation.py:51-64: BatchNormalization(center=False, scale=False,
  * epsilon) with the training flag, then alpha (1 - p) z + p z):  z [rows, z_stride] pre-activations (+ bias[n] when bias !=
