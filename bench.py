@@ -40,7 +40,7 @@ Extra objects on the JSON line:
                 region: the event pairs isolate consecutive kernels, which would cost the value region ~10 %); peak 157.3 TF; its HBM figure (algorithmic bytes / the
                 same duration, of 8 TB/s) is reported next to it as hbm_frac.  `kernel_launches` lists every kernel launch
                 of one call (rows, shape, mean duration).  `traffic` = FETCH_SIZE + WRITE_SIZE per
-                launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json, `traffic_source`), scaled
+                launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json, `traffic_source`), scaled
                 to this launch's rows — not measured in this run.
   kernels       isolated single-batch launches of the 32-row fused kernel and of the two stand-alone kernels of the unfused
                 path: gather_fm_kernel (the HBM-bound kernel north_star names) and mlp_kernel (MFMA-bound).
@@ -230,12 +230,12 @@ def check_parity(model, cols, staged, launches, logits, n_rows, rank):
 
 def load_traffic(rows):
     """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch."""
-    tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     if not os.path.exists(tp):
         return None, None
     try:
         j = json.load(open(tp))
-        return float(j["bytes_per_row"]) * rows, "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s rows per launch)" % j.get("rows_per_launch")
+        return float(j["bytes_per_row"]) * rows, "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s rows per launch)" % j.get("rows_per_launch")
     except Exception:
         return None, None
 
