@@ -286,7 +286,13 @@ struct ChainOff {
 
 // The passes [first, first + stride, ...) < n_pass of one phase: pass q covers rows row_base + q * (16 RT NW) ... of the launch
 // (absolute row numbers; rows >= row_end do not exist).  Called by all NW waves of the phase, with the launch parameters in LDS.
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false>
+// FPB > 1 (embedding_dim 16 / FPB = 8 or 4, the reference's default is 4): SEVERAL fields share a 16-wide k-block — lane group g
+// gathers field FPB b + fb (fb = g for E = 4, g >> 1 for E = 8), the 16-B piece g & 1 of its row for E = 8.  A block then needs the ids
+// of FPB / 2 field PAIRS (two id registers for E = 4), per-lane table pointers (read from the descriptors in LDS), the FM sums reduced
+// over the lane groups BEFORE squaring, and dense k-blocks addressed from row n_fields E of W0 (the embedding part need not end on a
+// k-block boundary: the slots past the last field are zeroed and meet finite weight rows).  Every block: its pairs' linear entries, the
+// next block's range check, the ids of the block after next.  Same arithmetic, same k order as the tile kernels' layer 0.
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false, int FPB = 1>
 __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
                                              const int row_end, const int first, const int stride, const int n_pass, int& oor) {
     if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
@@ -296,8 +302,10 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     constexpr int S1 = M0 * M1, S2 = M1 * M2;      // chunks (= steps) of layers 1 and 2
     constexpr int SL = S1 + S2;
     static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
-    constexpr int E = 16 * EB;
-    constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair
+    static_assert(FPB == 1 || (EB == 1 && (FPB == 2 || FPB == 4) && !BF3 && !CROSS), "several fields per k-block: E = 8 / 4, plain fp32 kernels");
+    constexpr int E = FPB > 1 ? 16 / FPB : 16 * EB;
+    constexpr int PPB = FPB / 2;                   // field pairs per k-block (FPB > 1)
+    constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair (FPB == 1)
     typedef ChainOff<M0, M1, M2> Off;
     constexpr int B1_OFF = Off::B1, B2_OFF = Off::B2, HW_OFF = Off::HW, GB_OFF = Off::GB;
     static_assert(Off::END <= FDESC_OFF, "biases + head weights + global bias + BatchNormalization must fit the parameter area");
@@ -314,9 +322,10 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         return ln;
     };
 
-    const int NBE = p.n_fields * EB;               // embedding k-blocks
-    const int NB = (p.in_dim + 15) >> 4;           // k-blocks of the DNN input (= steps of layer 0)
+    const int NBE = FPB > 1 ? (p.n_fields + FPB - 1) / FPB : p.n_fields * EB;         // embedding k-blocks
+    const int NB = FPB > 1 ? NBE + ((p.n_dense + 15) >> 4) : (p.in_dim + 15) >> 4;     // k-blocks of the DNN input (= steps of layer 0)
     const int NDB = NB - NBE;                      // dense k-blocks (0 .. MAX_DENSE_BLOCKS)
+    const int emb_rows = p.n_fields * E;           // rows of W0 the embedding part takes (FPB > 1: not necessarily whole k-blocks)
     const int STEPS = NB + SL;
     const int k_last = p.in_dim - 1;
     float* dreg = smem + DENSE_OFF + (WROWS * wave) * (16 * NDB);     // this wave's rows of the dense staging area
@@ -347,8 +356,9 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);                  // this lane's byte inside piece `wave`
-        if (BF3 || 16 * b + 16 <= p.in_dim) {                                  // a whole block: 16 KiB (M0 = 4) as they lie (BF3: the packed image is zero-padded)
-            const char* base = reinterpret_cast<const char*>(p.W[0]) + (size_t)b * (16 * ROW_B);
+        const int row0 = (FPB > 1 && b >= NBE) ? emb_rows + 16 * (b - NBE) : 16 * b;     // first W0 row of the block
+        if (BF3 || row0 + 16 <= p.in_dim) {                                    // a whole block: 16 KiB (M0 = 4) as they lie (BF3: the packed image is zero-padded)
+            const char* base = reinterpret_cast<const char*>(p.W[0]) + (size_t)row0 * ROW_B;
 #pragma unroll
             for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
                 if (pc0 + wave < 4 * M0) dma16(base + pc0 * 1024, o, dst + (pc0 + wave) * 256);
@@ -357,7 +367,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
                 if (pc0 + wave < 4 * M0) {
                     const uint32_t oo = o + pc0 * 1024;
-                    const int krow = min(16 * b + (int)(oo / ROW_B), k_last);
+                    const int krow = min(row0 + (int)(oo / ROW_B), k_last);
                     dma16(p.W[0], (uint32_t)krow * ROW_B + (oo % ROW_B), dst + (pc0 + wave) * 256);
                 }
         }
@@ -485,6 +495,29 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);
         X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
     };
+    // FPB > 1: the rows of embedding k-block cb, one N tile: lane group g = field slot fb (and 16-B piece pc for E = 8); the slot's ids
+    // are half fb & 1 of pair fb >> 1's register (idA: the block's first pair, idB: its second, E = 4)
+    auto issue_xq1 = [&](int cb, uint32_t idA, uint32_t idB, XBlk& X, auto NTc) {
+        constexpr int nt = decltype(NTc)::value;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t gg = (uint32_t)ln >> 4, jj = (uint32_t)ln & 15u;
+        const uint32_t fb = FPB == 4 ? gg : (gg >> 1), pc = FPB == 4 ? 0u : (gg & 1u);
+        const int f = min(FPB * cb + (int)fb, p.n_fields - 1);
+        const uint2 tw = *reinterpret_cast<const uint2*>(fdesc + 12 * f);                      // (per lane: this slot's table)
+        const int src = (int)(((fb & 1u) * 32u + (uint32_t)(16 * nt) + jj) << 2);
+        uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)idA);
+        if constexpr (FPB == 4) {
+            const uint32_t idb = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)idB);
+            idv = (fb >> 1) ? idb : idv;
+        }
+        const uint64_t base = ((uint64_t)tw.y << 32) | tw.x;
+        X.x[nt] = *(gbl_f4_t)(base + (uint64_t)idv * (uint32_t)(E * 4) + 16u * pc);
+    };
+    auto issue_xq = [&](int cb, uint32_t idA, uint32_t idB, XBlk& X) {
+        issue_xq1(cb, idA, idB, X, std::integral_constant<int, 0>{});
+        if constexpr (RT > 1) issue_xq1(cb, idA, idB, X, std::integral_constant<int, RT - 1>{});
+    };
     // dense features of a pass: requested, then (a step later) written zero-padded to this wave's LDS rows — the dense
     // k-blocks of layer 0 read their B operand from there, so the hot loop has ONE kind of global load.  Lane (g, j) moves
     // columns 4g .. 4g + 3 of dense k-block c for its two rows; the lane's share of dense . dense_lin_w comes out on the way
@@ -536,6 +569,12 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         if constexpr (I64) asm volatile("" : "+v"(idr_hi));                                                      \
     } while (0)
 #define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER ::: "memory")
+    // FPB > 1: also the second pair's in-flight registers
+#define CHAIN_TOP_Q()                                                                                            \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(lvn), "+v"(idr_lo), "+v"(lvnB), "+v"(idrB_lo) : : "memory");   \
+        if constexpr (I64) asm volatile("" : "+v"(idr_hi), "+v"(idrB_hi));                                       \
+    } while (0)
 
     // A-operand lane offsets (floats) inside a chunk image
     const int l0off = (4 * g) * (64 * M0) + 4 * j;     // layer 0: k-step t reads row 4g + t, M-group mg at + 64 mg
@@ -546,6 +585,9 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     uint32_t idr_lo = 0u, idr_hi = 0u;                 // raw ids of a field pair between their request and the range check
     uint32_t idc = 0u;                                 // checked ids (= table rows) of the current field pair
     float lvn = 0.f;                                   // linear-table entries of the current pair, in flight / landed
+    // FPB > 1: a block's SECOND pair (E = 4) has its own raw / checked ids and linear entries; idc / idr_* / lvn serve the first
+    uint32_t idrB_lo = 0u, idrB_hi = 0u, idcB = 0u;
+    float lvnB = 0.f;
 #pragma unroll
     for (int nt = 0; nt < RT; ++nt) {
         XA.x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -565,8 +607,22 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             dense_store(0, td);
             dense_rest(pass0);
         }
+        if constexpr (FPB > 1) {
+            // block 0's pairs (the second pair's ids are requested and waited for here: once per phase), block 1's ids, block 0's rows
+            if constexpr (PPB > 1) {
+                request_pair_ids(1, pass0, idrB_lo, idrB_hi);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(idrB_lo) : : "memory");
+                if constexpr (I64) asm volatile("" : "+v"(idrB_hi));
+                idcB = fold_pair_ids(1, pass0, idrB_lo, idrB_hi);
+            }
+            idc = fold_pair_ids(0, pass0, idr_lo, idr_hi);
+            request_pair_ids(PPB, pass0, idr_lo, idr_hi);
+            if constexpr (PPB > 1) request_pair_ids(PPB + 1, pass0, idrB_lo, idrB_hi);
+            issue_xq(0, idc, idcB, XA);
+        } else {
         idc = fold_pair_ids(0, pass0, idr_lo, idr_hi);
         issue_x(0, idc, 0, XA);
+        }
     }
 
     // Request phase of a step = gather part (rows of the next k-block, ids, linear entries: latency-critical, behind micro-
@@ -649,6 +705,21 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         };
         // FM bookkeeping of the embedding block being multiplied (lane-local)
         auto consume_x = [&](int b, const XBlk& X) {
+            if constexpr (FPB > 1) {
+                // the lane's field slot: in_fm per lane (slots past the last field hold zeros)
+                const int gq = opaque_lane() >> 4;
+                const int f = FPB * b + (FPB == 4 ? gq : (gq >> 1));
+                const bool in = f < p.n_fields && ((fm_mask >> (f & 63)) & 1ull) != 0ull;
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = in ? X.x[nt][e] : 0.f;
+                        sum[0][nt][e] += v;
+                        sq[nt] = fmaf(v, v, sq[nt]);
+                    }
+                return;
+            }
             const int f = b / EB, h = b % EB;
             if ((fm_mask >> f) & 1ull) {
 #pragma unroll
@@ -843,6 +914,111 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             }                                                                                                    \
             slot_next();                                                                                         \
         }
+        // FPB > 1: a step = one k-block of FPB fields.  Slot i behind the MFMAs of micro-step 2 i: 0: DMA share (waves 0-3), range check
+        // of the NEXT block's ids (requested a step ago), the previous block's linear entries; 1 / 2: rows of the next block, N tile
+        // 0 / 1; 3: this block's linear entries, the ids of the block after next; last: FM bookkeeping
+        uint32_t idcnB = 0u;                           // (idcn: the next block's first pair)
+#define CHAIN_PIECEQ(I, XC, XN)                                                                                  \
+        {                                                                                                        \
+            constexpr int i_ = (I);                                                                              \
+            if (i_ == 0) {                                                                                       \
+                if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                   \
+                if (CHAIN_GATHER) {                                                                              \
+                    idcn = fold_pair_ids(PPB * (b_ + 1), pass, idr_lo, idr_hi);                                  \
+                    if constexpr (PPB > 1) idcnB = fold_pair_ids(PPB * (b_ + 1) + 1, pass, idrB_lo, idrB_hi);    \
+                    bool has_;                                                                                   \
+                    (void)pair_lin_ptr(PPB * max(b_ - 1, 0), 0u, has_);                                          \
+                    linacc += (has_ && b_ >= 1 && b_ - 1 < NBE) ? lvn : 0.f;                                     \
+                    if constexpr (PPB > 1) {                                                                     \
+                        (void)pair_lin_ptr(PPB * max(b_ - 1, 0) + 1, 0u, has_);                                  \
+                        linacc += (has_ && b_ >= 1 && b_ - 1 < NBE) ? lvnB : 0.f;                                \
+                    }                                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+            if (CHAIN_GATHER && i_ == 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, 0>{});         \
+            if (CHAIN_GATHER && i_ == 2 && RT > 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, RT - 1>{}); \
+            if (CHAIN_GATHER && i_ == 3) {                                                                       \
+                bool has_;                                                                                       \
+                lvn = *pair_lin_ptr(PPB * b_, idc, has_);                                                        \
+                if constexpr (PPB > 1) lvnB = *pair_lin_ptr(PPB * b_ + 1, idcB, has_);                           \
+                request_pair_ids(PPB * (b_ + 2), pass, idr_lo, idr_hi);                                          \
+                if constexpr (PPB > 1) request_pair_ids(PPB * (b_ + 2) + 1, pass, idrB_lo, idrB_hi);             \
+            }                                                                                                    \
+            if (CHAIN_GATHER && i_ == 2 * M0 - 1) {                                                              \
+                if (b_ < NBE) consume_x(b_, XC);                                                                 \
+            }                                                                                                    \
+        }
+#define CHAIN_STEPQ(XC, XN)                                                                                      \
+        {                                                                                                        \
+            CHAIN_TOP_Q();                                                                                       \
+            const float* sb_ = slot_ptr(0);                                                                      \
+            if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
+            if (DEEP && b_ == 0) c1 = read_l0(sb_, 1);                                                           \
+            if (b_ >= NBE) {                                                                                     \
+                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
+                    XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
+            } else if (b_ == NBE - 1 && p.n_fields % FPB != 0) {                                                 \
+                /* field slots past the last field: zeros (their loads were clamped to the last field) */        \
+                const int gq_ = opaque_lane() >> 4;                                                              \
+                const bool ok_ = FPB * b_ + (FPB == 4 ? gq_ : (gq_ >> 1)) < p.n_fields;                          \
+                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) XC.x[nt_][e_] = ok_ ? XC.x[nt_][e_] : 0.f;  \
+            }                                                                                                    \
+            _Pragma("unroll") for (int u_ = 0; u_ < 4 * M0; u_ += 2) {                                           \
+                if (!DEEP) c1 = read_l0(sb_, u_ + 1);                                                            \
+                else if (u_ + 2 < 4 * M0) c2 = read_l0(sb_, u_ + 2);                                             \
+                else if (b_ + 1 < NB) c2 = read_l0(slot_ptr(1), 0);                                              \
+                DCTR_SB;                                                                                         \
+                mfma_l0(c0, XC, u_);                                                                             \
+                DCTR_SB;                                                                                         \
+                if (u_ == 0) CHAIN_PIECEQ(0, XC, XN)                                                             \
+                if (u_ == 2) CHAIN_PIECEQ(1, XC, XN)                                                             \
+                if (u_ == 4) CHAIN_PIECEQ(2, XC, XN)                                                             \
+                if (u_ == 6) CHAIN_PIECEQ(3, XC, XN)                                                             \
+                if (u_ == 4 * M0 - 2 && u_ > 6) CHAIN_PIECEQ(2 * M0 - 1, XC, XN)                                 \
+                if (u_ == DMA_LATE0 && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                               \
+                if (!DEEP) {                                                                                     \
+                    if (u_ + 2 < 4 * M0) c0 = read_l0(sb_, u_ + 2);                                              \
+                    else if (b_ + 1 < NB) c0 = read_l0(slot_ptr(1), 0);                                          \
+                } else {                                                                                         \
+                    if (u_ + 3 < 4 * M0) c3 = read_l0(sb_, u_ + 3);                                              \
+                    else if (b_ + 1 < NB) c3 = read_l0(slot_ptr(1), 1);                                          \
+                }                                                                                                \
+                DCTR_SB;                                                                                         \
+                mfma_l0(c1, XC, u_ + 1);                                                                         \
+                DCTR_SB;                                                                                         \
+                if (DEEP && (u_ + 2 < 4 * M0 || b_ + 1 < NB)) {                                                  \
+                    c0 = c2;                                                                                     \
+                    c1 = c3;                                                                                     \
+                }                                                                                                \
+            }                                                                                                    \
+            slot_next();                                                                                         \
+            idc = idcn;                                                                                          \
+            idcB = idcnB;                                                                                        \
+        }
+        if constexpr (FPB > 1) {
+            for (int b0_ = 0; b0_ < NB; b0_ += 2) {
+                {
+                    const int b_ = b0_;
+                    CHAIN_STEPQ(XA, XB);
+                }
+                if (b0_ + 1 < NB) {
+                    const int b_ = b0_ + 1;
+                    CHAIN_STEPQ(XB, XA);
+                }
+            }
+            // the last block's linear entries (added a block later, which never came)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(lvn), "+v"(lvnB) : : "memory");
+            {
+                bool has_;
+                (void)pair_lin_ptr(PPB * (NB - 1), 0u, has_);
+                linacc += (has_ && NB - 1 < NBE) ? lvn : 0.f;
+                if constexpr (PPB > 1) {
+                    (void)pair_lin_ptr(PPB * (NB - 1) + 1, 0u, has_);
+                    linacc += (has_ && NB - 1 < NBE) ? lvnB : 0.f;
+                }
+            }
+        } else {
         for (int pr_ = 0; pr_ * PAIR < NB; ++pr_) {
             if constexpr (BF3) {
                 CHAIN_STEP0_BF(0, XA, XB);
@@ -861,11 +1037,14 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             }
             idc = idcn;
         }
+        }
+#undef CHAIN_STEPQ
+#undef CHAIN_PIECEQ
 #undef CHAIN_STEP0_BF
 #undef CHAIN_STEP0
 #undef CHAIN_PIECE0
 #undef CHAIN_PHASE0
-        if ((NB - 1) % PAIR == 0 && NB - 1 < NBE) {
+        if (FPB == 1 && (NB - 1) % PAIR == 0 && NB - 1 < NBE) {
             // the last step was step 0 of a field pair (odd field count, no dense k-block behind it): the pair's linear
             // entries, added up in a pair's step 1, are still on their way
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lvn) : : "memory");
@@ -883,10 +1062,24 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #pragma unroll
             for (int nt = 0; nt < RT; ++nt) {
                 float fm = -sq[nt];
+                if constexpr (FPB > 1) {
+                    // the lane groups of one 16-B piece hold different FIELDS' shares of the same dimensions: sum them first, square,
+                    // and count each square once (FPB lane groups hold the same sum)
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float sv = sum[0][nt][e];
+                        if constexpr (FPB == 4) sv += __shfl_xor(sv, 16, 64);
+                        sv += __shfl_xor(sv, 32, 64);
+                        s2 = fmaf(sv, sv, s2);
+                    }
+                    fm = fmaf(s2, 1.f / FPB, fm);
+                } else {
 #pragma unroll
                 for (int h = 0; h < EB; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) fm = fmaf(sum[h][nt][e], sum[h][nt][e], fm);
+                }
                 fm += __shfl_xor(fm, 16, 64);
                 fm += __shfl_xor(fm, 32, 64);
                 fm *= 0.5f;
@@ -1006,11 +1199,19 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                             if (dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
                             if (sidx == SL - 2) {
                                 request_pair_ids(0, pass_n, idr_lo, idr_hi);
+                                if constexpr (FPB > 1 && PPB > 1) request_pair_ids(1, pass_n, idrB_lo, idrB_hi);
                                 if (NDB > 0) dense_request(0, pass_n, td);
                             }
                             if (last) {
                                 idc = fold_pair_ids(0, pass_n, idr_lo, idr_hi);
-                                issue_x(0, idc, 0, XA);
+                                if constexpr (FPB > 1) {
+                                    if constexpr (PPB > 1) idcB = fold_pair_ids(1, pass_n, idrB_lo, idrB_hi);
+                                    request_pair_ids(PPB, pass_n, idr_lo, idr_hi);
+                                    if constexpr (PPB > 1) request_pair_ids(PPB + 1, pass_n, idrB_lo, idrB_hi);
+                                    issue_xq(0, idc, idcB, XA);
+                                } else {
+                                    issue_x(0, idc, 0, XA);
+                                }
                             }
                         }
                         if (ks == CHAIN_DMA_LATE && !dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
@@ -1192,11 +1393,12 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #undef CHAIN_TOP_X
 #undef CHAIN_TOP_ID
 #undef CHAIN_TOP
+#undef CHAIN_TOP_Q
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wrapped-around DMA of the last pass must not outlive the phase
 }
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1>
 __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
@@ -1253,7 +1455,7 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
     __syncthreads();                                   // LDS parameters written
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
-    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
     CWG(1);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
@@ -1261,8 +1463,8 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
             // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
             __syncthreads();
             if (wave < 4)
-                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x, (int)gridDim.x,
-                                                               p.n_tail, oor);
+                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS, FPB>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
+                                                                    (int)gridDim.x, p.n_tail, oor);
         }
     }
     CWG(2);
@@ -1278,6 +1480,7 @@ int launch_r2w8_m22(const ChainParams& p, int E, int M2, unsigned blocks, hipStr
 int launch_r2w8_m21(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
 int launch_r2w4_m42(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
 int launch_r2w8_m42x(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // CROSS (chain_kernels_r2w8_m42_x.hip)
+int launch_r2w8_m42q(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 8 / 4 (chain_kernels_r2w8_m42_q.hip)
 // the exploratory bf16 x 3 variant (chain_kernels_r2w8_m42_bf3.hip): packs the weights into `ws` (if `pack`), then launches
 size_t bf3_workspace_bytes(int in_dim);
 int launch_r2w8_m42_bf3(const ChainParams& p, int E, void* ws, bool pack, unsigned blocks, hipStream_t stream);

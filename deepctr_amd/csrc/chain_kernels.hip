@@ -21,14 +21,16 @@ static bool widths(const dctr_mlp_args_t* a, int shape, int* M) {
 // 1: the row-chained kernel can take this call (all of its rows); 0: not eligible
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
     const int E = g->uniform_dim;
-    if (E != 16 && E != 32) return 0;
+    if (E != 16 && E != 32 && E != 8 && E != 4) return 0;
     if (g->any_hash || !a->has_head || a->save_acts != nullptr) return 0;
     if (a->activation != DCTR_ACT_RELU && a->activation != DCTR_ACT_LINEAR) return 0;
     int M[3];
     if (!widths(a, forced ? a->tile_rows : 0, M)) return 0;
     if (a->precision != 0 && !(M[0] == 4 && M[1] == 2 && M[2] == 1 && a->tile_rows != 128 && a->bn_scale == nullptr)) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
-    if (a->cross_layers > 0 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128)) return 0;   // CROSS: the m42 kernels
+    if (a->cross_layers > 0 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && E >= 16)) return 0;   // CROSS: the m42 kernels
+    // embedding_dim 8 / 4 (several fields per k-block): the m42 kernels, fp32, no identity (pre-pooled) fields, <= 4 dense k-blocks
+    if (E < 16 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && !g->any_identity)) return 0;
     if (lds_bytes(2, 8, g->n_dense > 0 ? g->n_dense : 0) + (a->cross_layers > 0 ? cross_lds_floats(a->in_dim) * sizeof(float) : 0) >
         160 * 1024)
         return 0;                                                                       // (dense staging area: <= 32 dense columns)
@@ -150,6 +152,7 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
         return launch_r2w8_m42_bf3(p, E, a->workspace, a->precision == 1, blocks, stream);
     }
     if (a->cross_layers > 0) return launch_r2w8_m42x(p, E, M[2], blocks, stream);
+    if (E < 16) return launch_r2w8_m42q(p, E, M[2], blocks, stream);
     if (shape == 128) return launch_r2w4_m42(p, E, M[2], blocks, stream);
     if (M[0] == 4) return M[1] == 2 ? launch_r2w8_m42(p, E, M[2], blocks, stream) : launch_r2w8_m41(p, E, M[2], blocks, stream);
     return M[1] == 2 ? launch_r2w8_m22(p, E, M[2], blocks, stream) : launch_r2w8_m21(p, E, M[2], blocks, stream);

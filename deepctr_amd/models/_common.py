@@ -139,11 +139,13 @@ class FusedForward(object):
         the widths are already instantiated or cannot be."""
         units = [int(u) for u in units]
         sp = self.stage_plan
-        if sp.uniform_dim not in (16, 32) or len(units) not in (2, 3) or activation not in ("relu", "linear") or self.dnn.dice_layers:
+        if sp.uniform_dim not in (4, 8, 16, 32) or len(units) not in (2, 3) or activation not in ("relu", "linear") or self.dnn.dice_layers:
             return None
         if units[0] > 256 or units[1] > 128 or (len(units) == 3 and units[2] > 128):
             return None
         target = [128 if units[0] <= 128 else 256, 64 if units[1] <= 64 else 128]
+        if sp.uniform_dim < 16:             # embedding_dim 4 / 8: the row-chained kernel has them in its 256-128-x instantiations only
+            target = [256, 128]
         if len(units) == 3:
             target.append(64 if units[2] <= 64 else 128)
         return None if target == units else target
@@ -185,7 +187,7 @@ class FusedForward(object):
         hashed by one dctr_hash_fields launch in front of the fused one, which then sees plain rows.  Smaller launches hash inside
         the 32-row kernel."""
         sp = self.stage_plan
-        return bool(sp.any_hash and sp.uniform_dim in (16, 32, 64) and (B >= self._CHAIN_MIN_ROWS or self.tile_rows in (64, 256)))
+        return bool(sp.any_hash and sp.uniform_dim in (4, 8, 16, 32, 64) and (B >= self._CHAIN_MIN_ROWS or self.tile_rows in (64, 256)))
 
     def _begin(self):
         super(FusedForward, self)._begin()

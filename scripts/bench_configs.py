@@ -116,7 +116,8 @@ def main():
         m = DeepFM(cols4, cols4, device=dev)
         init_on_device(m)
         run("C1 shape DeepFM E=4 (1 launch/step)", m, criteo(rng, ring * 256, V=1000), 256, args.steps, ring)
-        run_span("C1 shape DeepFM E=4 (65,536 rows/call)", m, criteo(rng, 65536, V=1000), 256)
+        for rows in (65536, 262144):
+            run_span("C1 shape DeepFM E=4 (%d rows/call)" % rows, m, criteo(rng, rows, V=1000), 256, dnn_flop=dnn_flop(117))
         del m
     if "c2_hash" in want:   # SURVEY 8(d) "Hash variant": every SparseFeat use_hash=True, raw ids uniform int32 in [0, 2^31)
         colsh = [SparseFeat("C%d" % i, 100000, 16, use_hash=True) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]

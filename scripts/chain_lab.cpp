@@ -19,10 +19,17 @@
 #undef DCTR_CHAIN_M1
 #undef DCTR_CHAIN_M2SET
 #include "../deepctr_amd/csrc/chain_kernels_r2w4_m42.hip"
+#undef DCTR_CHAIN_RT
+#undef DCTR_CHAIN_NW
+#undef DCTR_CHAIN_M0
+#undef DCTR_CHAIN_M1
+#undef DCTR_CHAIN_M2SET
+#include "../deepctr_amd/csrc/chain_kernels_r2w8_m42_q.hip"
 namespace dctr_chain {      // (the lab links the 256-128-64 instantiations only)
 int launch_r2w8_m41(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m22(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m21(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+int launch_r2w8_m42x(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 size_t bf3_workspace_bytes(int) { return 0; }
 int launch_r2w8_m42_bf3(const ChainParams&, int, void*, bool, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 }

@@ -428,3 +428,82 @@ def test_chain_bf16x3_exploratory_precision(device, E, n, F, ND):
         _predict(other, feed, 4096, matrix_precision="bf16x3", tile_rows=256)
     with pytest.raises(ValueError):
         _predict(model, feed, 4096, matrix_precision="fp16")
+
+
+@pytest.mark.parametrize("E,V,n,F,ND,units", [
+    (4, 3000, 65536 + 16384 + 77, 26, 13, (256, 128, 64)),      # the reference's default embedding_dim: 7 k-blocks of 4 fields (last: 2)
+    (8, 3000, 65536 + 300, 26, 13, (256, 128, 64)),             # 13 k-blocks of 2 fields
+    (4, 500, 16384 + 129, 7, 0, (256, 128)),                    # no dense features; embedding part ends inside a k-block
+    (8, 500, 16384 + 64, 5, 20, (256, 64, 64)),                 # two dense k-blocks behind a half-filled one; zero-padded widths
+    (4, 500, 16384 + 5, 64, 16, (200, 80)),                     # the 64-field limit, a full dense k-block
+])
+def test_chain_kernel_small_embedding_dims(device, E, V, n, F, ND, units):
+    """embedding_dim 4 / 8 on the row-chained kernel (chain_device.h: FPB — several fields share a 16-wide k-block): float64 oracle
+    on a row sample, every row against the 32-row kernel, the forced 256-row shape, row permutations and launch splits bit for bit."""
+    import torch
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(31 + E + F)
+    cols, feed = _criteo_like(rng, n, F=F, V=V, E=E, ND=ND)
+    model = DeepFM(cols, cols, dnn_hidden_units=units, device=device)
+    assert model.stage_plan.uniform_dim == E
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain"
+    plan = model.launch_plan(model.stage(feed), 0, n, torch.empty(n, device=model.device))
+    assert all(k == "chain" for _, k, _ in plan) and sum(r for r, _, _ in plan) == n, plan
+    assert y.shape == (n, 1) and np.isfinite(y).all()
+    rows = np.unique(np.concatenate([np.arange(0, 300), np.arange(n - 300, n), rng.choice(n, 256, replace=False)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dnn_hidden_units=units, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "chain DeepFM E=%d F=%d" % (E, F))
+    y32 = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain (E=%d) vs 32-row kernel" % E)
+    assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y), "forced 256-row shape"
+    m = 256 * 3 + 77
+    ys = _predict(model, {k: v[:m] for k, v in feed.items()}, m, tile_rows=256)
+    assert np.array_equal(ys, y[:m]), "forced shape, small launch"
+    perm = rng.permutation(n)
+    yp = model.predict({k: v[perm] for k, v in feed.items()}, batch_size=4096)
+    assert np.array_equal(yp, y[perm])
+    cut = 16384 + 4096
+    ya = model.predict({k: v[:cut] for k, v in feed.items()}, batch_size=4096)
+    assert np.array_equal(ya, y[:cut])
+
+
+@pytest.mark.parametrize("F,ND,E", [(1, 0, 4), (2, 3, 8), (3, 0, 4), (4, 1, 4), (5, 16, 4), (9, 5, 8), (63, 17, 4)])
+def test_chain_kernel_small_embedding_dims_field_count_edges(device, F, ND, E):
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(200 + F)
+    n = 700
+    cols, feed = _criteo_like(rng, n, F=F, V=300, E=E, ND=ND)
+    model = DeepFM(cols, cols, device=device)
+    w = _randomise(model, rng)
+    y32 = _predict(model, feed, n, tile_rows=32)
+    y = _predict(model, feed, n, tile_rows=256)
+    assert _last_kernel() == "chain"
+    ref = RM.deepfm(cols, cols, w, feed, dtype=np.float64)
+    check_probs(y, ref.astype(np.float32), "chain DeepFM E=%d F=%d ND=%d" % (E, F, ND))
+    assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain vs 32-row kernel E=%d F=%d" % (E, F))
+
+
+def test_chain_kernel_small_embedding_dims_int64_ids_and_out_of_range(device):
+    """int64 ids on the device for E = 4 (two id register pairs per k-block), WDL / FNN term switches, an out-of-range id reported."""
+    import torch
+    from deepctr_amd.models import FNN, WDL, DeepFM
+    rng = np.random.RandomState(77)
+    n = 16384 + 300
+    cols, feed = _criteo_like(rng, n, F=11, V=900, E=4, ND=3)
+    for ctor, fn in ((DeepFM, RM.deepfm), (WDL, RM.wdl), (FNN, RM.fnn)):
+        model = ctor(cols, cols, device=device)
+        w = _randomise(model, rng)
+        y = model.predict(feed, batch_size=2048)
+        assert _last_kernel() == "chain"
+        rows = rng.choice(n, 200, replace=False)
+        ref = fn(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+        check_probs(y[rows], ref.astype(np.float32), ctor.__name__ + " chain E=4")
+        feed64 = {k: (v.astype(np.int64) if v.dtype == np.int32 else v) for k, v in feed.items()}
+        assert np.array_equal(model.predict(feed64, batch_size=2048), y), ctor.__name__ + " int64 ids"
+    bad = {k: v.copy() for k, v in feed.items()}
+    bad["C7"][n - 5] = 900
+    with pytest.raises(IndexError):
+        model.predict(bad, batch_size=2048)
+    assert np.isfinite(model.predict(feed, batch_size=2048)).all()
