@@ -38,6 +38,17 @@ struct CinParams {
     const unsigned* sym_tab;         // [4 * sym_ks] per pair: i | j << 16
     int32_t sym_ks;                  // k-steps of the folded layer (a multiple of 4)
     int32_t two_y;                   // 1: two y buffers in LDS (a layer reads one while it writes the other)
+    // dctr_cin_gather_fwd: x == NULL, the workgroup's x_0 tile is read from the embedding tables (field f of sample b = row
+    // ids[f, b] of gfields[f].table: inputs.py:101-117 inside the kernel; D % 4 == 0, plain ids)
+    const dctr_field_t* gfields;
+    const void* ids;
+    int64_t ids_stride_f, ids_stride_b;
+    int32_t ids_i64;
+    int32_t* status;
+    // ... and the Dense(1) over the summed maps (models/xdeepfm.py:64-66) taken on chip: the maps of the workgroup's samples wait in
+    // LDS, logit[b] = maps[b, :] . head_w leaves instead of `out`
+    const float* head_w;             // [out_dim] or NULL
+    float* logit;                    // [B]
 };
 
 typedef unsigned int cin_u32x2 __attribute__((ext_vector_type(2)));
@@ -75,7 +86,7 @@ __device__ __forceinline__ void cin_buf_load(__amdgpu_buffer_rsrc_t rsrc, int vo
 #endif
 template <int TPW, int RT, bool SAVE, bool SYM>
 __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float* x0t, const float* xk, int Fk, float* ycur, int Hn,
-                                          int d0, int64_t bbase, int out_off, const unsigned* tab) {
+                                          int d0, int64_t bbase, int out_off, const unsigned* tab, float* outl) {
     using dctr::f32x4;
     constexpr int ROWS_P = RT * 16 + 16;
     constexpr int NB = CIN_NB;
@@ -294,7 +305,8 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
                     const bool lead = D >= 16 ? g == 0 : (4 * g) % D == 0;
                     if (lead && m < M) {
                         const int64_t b = bbase + m / D;
-                        if (b < p.batch) p.out[b * p.out_dim + out_off + (n - d0)] = t;
+                        if (outl != nullptr) outl[(m / D) * p.out_dim + out_off + (n - d0)] = t;      // (fused head: the maps wait in LDS)
+                        else if (b < p.batch) p.out[b * p.out_dim + out_off + (n - d0)] = t;
                     }
                 }
             }
@@ -315,13 +327,53 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
     float* y0 = x0t + F0 * ROWS_P;                  // [Hmax][ROWS_P]
     float* y1 = y0 + p.Hmax * ROWS_P;               // (only when a layer reads one y buffer while writing the other: p.two_y)
     unsigned* tab = reinterpret_cast<unsigned*>(y1 + (p.two_y ? p.Hmax * ROWS_P : 0));      // [4 * sym_ks] pair table of the folded layer 0
+    float* outl = p.head_w != nullptr ? reinterpret_cast<float*>(tab + 4 * p.sym_ks) : nullptr;   // [SB][out_dim] summed maps (fused head)
     const int64_t b0 = (int64_t)blockIdx.x * SB;
     if (p.Wsym != nullptr)                          // (i, j) of the fold kernel's table -> float offsets of the two fields' rows in x0t
         for (int t = threadIdx.x; t < 4 * p.sym_ks; t += 256) {
             const unsigned e = p.sym_tab[t];
             tab[t] = (e & 0xffffu) * ROWS_P | ((e >> 16) * ROWS_P) << 16;
         }
-    {
+    if (p.gfields != nullptr) {
+        // x0 tile from the tables: item (sample s, field f, 16-B piece q) — ids of eight items, then their rows, in flight together;
+        // an id outside the vocabulary reads row 0 and raises the status flag; samples past the batch: zeros
+        const int Q = D >> 2, fq = F0 * Q, total = SB * fq;
+        for (int base = 0; base < total; base += 256 * 8) {
+            int64_t id[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * 256 + (int)threadIdx.x, total - 1);
+                const int s = i / fq, f = (i - s * fq) / Q;
+                const int64_t b = min(b0 + s, p.batch - 1);
+                const int64_t eo = (int64_t)f * p.ids_stride_f + b * p.ids_stride_b;
+                id[u] = p.ids_i64 ? reinterpret_cast<const int64_t*>(p.ids)[eo] : (int64_t)reinterpret_cast<const int32_t*>(p.ids)[eo];
+            }
+            float4 v[8];
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * 256 + (int)threadIdx.x, total - 1);
+                const int s = i / fq, r = i - s * fq;
+                const int f = r / Q, q = r - f * Q;
+                const bool ok = (uint64_t)id[u] < (uint64_t)p.gfields[f].vocab;
+                bad = bad || (!ok && base + u * 256 + (int)threadIdx.x < total && b0 + s < p.batch);
+                v[u] = *reinterpret_cast<const float4*>(p.gfields[f].table + (ok ? id[u] : 0) * D + 4 * q);
+                if (b0 + s >= p.batch) v[u] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (bad && p.status != nullptr) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                if (i < total) {
+                    const int s = i / fq, r = i - s * fq;
+                    const int f = r / Q, q = r - f * Q;
+                    *reinterpret_cast<float4*>(x0t + f * ROWS_P + s * D + 4 * q) = v[u];
+                }
+            }
+        }
+        const int padr = RT * 16 - M;               // rows of the last tile past M: zeros
+        for (int t = threadIdx.x; t < F0 * padr; t += 256) x0t[(t / padr) * ROWS_P + M + t % padr] = 0.f;
+    } else {
         // x0 tile: all global loads of a pass in flight before the LDS stores
         const int total = SB * F0 * D, fd = F0 * D;
         for (int base = 0; base < total; base += 256 * 8) {
@@ -367,10 +419,10 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
             d0 = 0;
         }
         if (k == 0 && p.Wsym != nullptr) {
-            if (H % 32 == 0) cin_layer<2, RT, SAVE, true>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
-            else cin_layer<1, RT, SAVE, true>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
-        } else if (H % 32 == 0) cin_layer<2, RT, SAVE, false>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
-        else cin_layer<1, RT, SAVE, false>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab);
+            if (H % 32 == 0) cin_layer<2, RT, SAVE, true>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab, outl);
+            else cin_layer<1, RT, SAVE, true>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab, outl);
+        } else if (H % 32 == 0) cin_layer<2, RT, SAVE, false>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab, outl);
+        else cin_layer<1, RT, SAVE, false>(p, k, x0t, xk, Fk, ycur, Hn, d0, b0, out_off, tab, outl);
         __syncthreads();
         const int nd = H - d0;
         if (!p.reg_reduce) {
@@ -392,6 +444,18 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
         ycur = ynext;
         ynext = t;
         // no barrier needed here: the next layer writes the OTHER y buffer and only reads this one
+    }
+    if (outl != nullptr) {
+        // fused head: one wave per sample, lanes over the maps in a fixed order (deterministic)
+        __syncthreads();
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int s = wave; s < SB; s += 4) {
+            float acc = 0.f;
+            for (int c = lane; c < p.out_dim; c += 64) acc = fmaf(outl[s * p.out_dim + c], p.head_w[c], acc);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            if (lane == 0 && b0 + s < p.batch) p.logit[b0 + s] = acc;
+        }
     }
 }
 
@@ -445,19 +509,48 @@ extern "C" size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* a) {
     return ks * 4 * ((size_t)a->layer_size[0] + 1) * sizeof(float);
 }
 
-extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
+static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream);
+
+extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) { return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream); }
+
+// ABI 8 — CIN.call over the embeddings of a gather (models/xdeepfm.py:52-66): exFM_in = concat of the fields' rows is read from the
+// tables inside the kernel (g: plain ids, every field `dim` wide, dim % 4 == 0, no pre-pooled field; g->dnn_in etc. unused), and with
+// head_w / logit the Dense(1, use_bias=False) over the summed maps is taken on chip: logit[b] leaves, `out` may be NULL
+extern "C" int dctr_cin_gather_fwd(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream) {
+    DCTR_REQUIRE(a != nullptr && g != nullptr, DCTR_E_NULL, "cin_gather_fwd: null args");
+    DCTR_REQUIRE((head_w == nullptr) == (logit == nullptr), DCTR_E_NULL, "cin_gather_fwd: head_w and logit come together");
+    DCTR_REQUIRE(g->fields != nullptr && g->ids != nullptr, DCTR_E_NULL, "cin_gather_fwd: null descriptors / ids");
+    DCTR_REQUIRE(g->n_fields == a->fields && g->batch == a->batch, DCTR_E_DIM, "cin_gather_fwd: gather of %d fields x %lld rows against CIN over %d x %lld",
+                 g->n_fields, (long long)g->batch, a->fields, (long long)a->batch);
+    DCTR_REQUIRE(a->dim % 4 == 0 && g->uniform_dim == a->dim && g->all_dim4 && !g->any_hash && !g->any_identity, DCTR_E_UNSUPPORTED,
+                 "cin_gather_fwd: every field must be a plain (unhashed, not pre-pooled) lookup of width dim = %d, a multiple of 4", a->dim);
+    DCTR_REQUIRE(a->save_y == nullptr, DCTR_E_UNSUPPORTED, "cin_gather_fwd: inference only (save_y: use dctr_embed_gather_fm + dctr_cin_fwd)");
+    return cin_fwd_impl(a, g, head_w, logit, stream);
+}
+
+static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "cin_fwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->fields >= 1 && a->dim >= 1 && a->n_layers >= 1 && a->n_layers <= CIN_MAX_LAYERS,
                  DCTR_E_DIM, "cin_fwd: bad sizes (B=%lld F=%d D=%d layers=%d)", (long long)a->batch, a->fields, a->dim,
                  a->n_layers);
     if (a->batch == 0) return DCTR_OK;
-    DCTR_REQUIRE(a->x && a->out && a->layer_size && a->filters && a->bias, DCTR_E_NULL, "cin_fwd: null pointer");
+    DCTR_REQUIRE((a->x || g) && (a->out || logit) && a->layer_size && a->filters && a->bias, DCTR_E_NULL, "cin_fwd: null pointer");
     DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "cin_fwd: activation %d",
                  a->activation);
-    DCTR_REQUIRE(a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
+    DCTR_REQUIRE(g != nullptr || a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
     DCTR_REQUIRE(a->dim <= 64, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d > 64 not supported", a->dim);
     CinParams p{};
-    p.x = a->x;
+    p.x = g != nullptr ? nullptr : a->x;
+    if (g != nullptr) {
+        p.gfields = g->fields;
+        p.ids = g->ids;
+        p.ids_stride_f = g->ids_stride_f;
+        p.ids_stride_b = g->ids_stride_b;
+        p.ids_i64 = g->ids_is_i64;
+        p.status = g->status;
+    }
+    p.head_w = head_w;
+    p.logit = logit;
     p.batch = a->batch;
     p.x_stride = a->x_stride;
     p.F0 = a->fields;
@@ -512,7 +605,9 @@ extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) {
     p.two_y = (p.n_layers >= 3 || (p.n_layers == 2 && !p.reg_reduce)) ? 1 : 0;   // (the last layer of a reg_reduce net stores nothing)
     auto lds_of = [&](int rt_) {
         const size_t rows_p = (size_t)rt_ * 16 + 16;
-        return (((size_t)p.F0 + (size_t)(p.two_y ? 2 : 1) * p.Hmax) * rows_p + (size_t)4 * p.sym_ks) * sizeof(float);
+        const size_t sb = (size_t)(rt_ == 8 ? 128 : 64) / (size_t)a->dim + 1;                   // (>= SB)
+        return (((size_t)p.F0 + (size_t)(p.two_y ? 2 : 1) * p.Hmax) * rows_p + (size_t)4 * p.sym_ks + (head_w != nullptr ? sb * p.out_dim : 0)) *
+               sizeof(float);
     };
     int rt = 8;
     p.SB = 128 / a->dim;

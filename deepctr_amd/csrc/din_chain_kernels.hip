@@ -22,6 +22,13 @@
 // Per row: raw score = Dense(1)(act(act(x W0 + b0) W1 + b1)); masking / softmax / the weighted sum of the keys stay in
 // din_pool_kernel.  Eligibility (host, below): two layers, units[0] = 64 a + 16 b (a <= 1, b <= 3), units[1] <= 64,
 // embedding_dim in {16, 32, 64}.  Everything else keeps din_score_kernel.
+//
+// Masked positions are SKIPPED (round 4): the reference scores every (sample, position) row and then replaces the masked scores
+// (sequence.py:280-285: where(mask, score, 0 or -2^32 + 1)), so a masked row's MLP never reaches the output.  din_compact_kernel
+// writes the list of rows that count — per CHUNK of `chunk_rows` consecutive rows: the chunk's valid rows, in row order, at
+// pos[chunk * chunk_rows ..) and their number in cnt[chunk]; no atomics, the same list every run — and the score kernel walks 32-row
+// units of that list (a chunk's last unit may be partly filled).  With behaviour sequences padded to maxlen (C4: lengths uniform on
+// [1, 50]) that is half the rows.  A unit's rows are independent MFMA columns: a row's score does not depend on its place in the list.
 #include <math.h>
 
 #include "dctr_common.h"
@@ -62,6 +69,28 @@ struct Params {
     const float* query_table[2];
     int64_t hist_vocab[2], query_vocab[2];
     int32_t* status;
+    // compacted row list (din_compact_kernel) or NULL: rows pos[c * chunk_rows + i], i < cnt[c], of chunk c < n_chunks
+    const int32_t* pos;
+    const int32_t* cnt;
+    int32_t chunk_rows, n_chunks;
+    // the workgroups' LDS image (weights folded and laid out, biases, Dice constants: fill_image) written once per launch by
+    // din_prep_kernel, or NULL: every workgroup folds the weights itself (≈ 20 us of prologue)
+    float* image;
+};
+
+constexpr int CMP_MAX_CHUNKS = 1024;   // (the score kernel keeps the chunks' unit prefix in LDS)
+constexpr size_t IMAGE_BYTES = 160 * 1024;
+constexpr int CMP_THREADS = 1024;
+
+// what decides whether a row counts: the key mask bytes (dctr_din_attn_pool_fwd) or the history ids (dctr_din_attn_gather_fwd)
+struct CompactSrc {
+    const uint8_t* key_mask;
+    int32_t nf, ids_i64, T;
+    const void* hist_ids[2];
+    int64_t hist_stride;
+    int32_t mask_zero[2];
+    int64_t hist_vocab[2];       // ids are range-checked here at EVERY position (the score kernel only sees the positions that count)
+    int32_t* status;
 };
 
 typedef const __attribute__((address_space(1))) f32x4* gbl_f4_t;
@@ -95,14 +124,69 @@ __device__ __forceinline__ int64_t load_any_id(const void* base, int64_t idx, in
     return i64 ? reinterpret_cast<const int64_t*>(base)[idx] : (int64_t)reinterpret_cast<const int32_t*>(base)[idx];
 }
 
-template <int EB, int NB0, int NS0, int NS1, bool GATHER = false>
-__global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
+// one workgroup per chunk: tiles of 1024 rows, four tiles' masks in flight; a row's slot = valid rows before it in the chunk
+__device__ __forceinline__ void compact_chunk(const CompactSrc& s, int64_t rows, int32_t chunk_rows, int32_t* __restrict__ pos,
+                                              int32_t* __restrict__ cnt, int (*wave_cnt)[CMP_THREADS / 64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = r0 + chunk_rows < rows ? r0 + chunk_rows : rows;
+    int32_t* out = pos + r0;
+    int base = 0;
+    for (int64_t t0 = r0; t0 < r1; t0 += 4 * CMP_THREADS) {
+        bool m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t R = t0 + u * CMP_THREADS + threadIdx.x;
+            m[u] = false;
+            if (R < r1) {
+                if (s.key_mask != nullptr) {
+                    m[u] = s.key_mask[R] != 0;
+                } else {
+                    const uint32_t b = (uint32_t)R / (uint32_t)s.T, t = (uint32_t)R - b * (uint32_t)s.T;     // host: rows < 2^31
+                    bool ok = true, bad = false;
+                    for (int h = 0; h < s.nf; ++h) {
+                        const int64_t id = load_any_id(s.hist_ids[h], (int64_t)b * s.hist_stride + t, s.ids_i64);
+                        if (s.mask_zero[h]) ok = ok && id != 0;
+                        bad = bad || (uint64_t)id >= (uint64_t)s.hist_vocab[h];
+                    }
+                    if (bad && s.status != nullptr) atomicOr(s.status, (int)DCTR_STATUS_INDEX_OOR);
+                    m[u] = ok;
+                }
+            }
+        }
+        int before[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t bal = __ballot(m[u]);
+            before[u] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[u][wave] = __popcll(bal);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int off = base, tot = 0;
+#pragma unroll
+            for (int w = 0; w < CMP_THREADS / 64; ++w) {
+                const int cw = wave_cnt[u][w];
+                off += w < wave ? cw : 0;
+                tot += cw;
+            }
+            if (m[u]) out[off + before[u]] = (int32_t)(t0 + u * CMP_THREADS + threadIdx.x);
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[blockIdx.x] = base;
+}
+
+
+// The LDS image of a workgroup (Lay<>): dst = the workgroup's LDS (thread tid of nthr) or the launch's image in HBM.
+// Layer-0 row k of the folded matrix: k < E: Wq + Wd; k < 2E: Wk - Wd; else Wp
+template <int EB, int NB0, int NS0, int NS1>
+__device__ __forceinline__ void fill_image(const Params& p, float* dst, int tid, int nthr) {
     typedef Lay<EB, NB0, NS0, NS1> L;
-    constexpr int E = L::E, NT0 = L::NT0, N0P = L::N0P;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTHR = 64 * NW;
-    // ---- once per workgroup: weights -> LDS.  Layer-0 row k of the folded matrix: k < E: Wq + Wd; k < 2E: Wk - Wd; else Wp
-    for (int idx = threadIdx.x; idx < L::K0 * N0P; idx += NTHR) {
+    constexpr int E = L::E, N0P = L::N0P;
+    for (int idx = tid; idx < L::K0 * N0P; idx += nthr) {
         const int k = idx / N0P, n = idx - k * N0P;
         float v = 0.f;
         if (n < p.n0) {
@@ -113,15 +197,15 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
             else { r1 = E + k; r2 = r1; }
             v = p.W0[(size_t)r1 * p.n0 + n] + sg * p.W0[(size_t)r2 * p.n0 + n];
         }
-        if (n < L::S0A) smem[L::W0A + k * L::S0A + n] = v;
-        else smem[L::W0B + k * L::S0B + (n - L::S0A)] = v;
+        if (n < L::S0A) dst[L::W0A + k * L::S0A + n] = v;
+        else dst[L::W0B + k * L::S0B + (n - L::S0A)] = v;
     }
-    for (int idx = threadIdx.x; idx < N0P * L::N1P; idx += NTHR) {
+    for (int idx = tid; idx < N0P * L::N1P; idx += nthr) {
         const int k = idx / L::N1P, n = idx - k * L::N1P;
-        smem[L::W1 + k * L::S1 + n] = (k < p.n0 && n < p.n1) ? p.W1[(size_t)k * p.n1 + n] : 0.f;
+        dst[L::W1 + k * L::S1 + n] = (k < p.n0 && n < p.n1) ? p.W1[(size_t)k * p.n1 + n] : 0.f;
     }
     const bool dice = p.activation == DCTR_ACT_DICE;
-    for (int n = threadIdx.x; n < N0P; n += NTHR) {
+    for (int n = tid; n < N0P; n += nthr) {
         const bool in = n < p.n0;
         float al = 0.f, inv = 0.f, sh = 0.f;
         if (in && dice) {
@@ -129,12 +213,12 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
             inv = 1.f / sqrtf(p.dice_var[0][n] + p.dice_eps);
             sh = -p.dice_mean[0][n] * inv;
         }
-        smem[L::PB0 + n] = (in && p.bias[0] != nullptr) ? p.bias[0][n] : 0.f;
-        smem[L::PB0 + N0P + n] = al;
-        smem[L::PB0 + 2 * N0P + n] = inv;
-        smem[L::PB0 + 3 * N0P + n] = sh;
+        dst[L::PB0 + n] = (in && p.bias[0] != nullptr) ? p.bias[0][n] : 0.f;
+        dst[L::PB0 + N0P + n] = al;
+        dst[L::PB0 + 2 * N0P + n] = inv;
+        dst[L::PB0 + 3 * N0P + n] = sh;
     }
-    for (int n = threadIdx.x; n < L::N1P; n += NTHR) {
+    for (int n = tid; n < L::N1P; n += nthr) {
         const bool in = n < p.n1;
         float al = 0.f, inv = 0.f, sh = 0.f;
         if (in && dice) {
@@ -142,13 +226,75 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
             inv = 1.f / sqrtf(p.dice_var[1][n] + p.dice_eps);
             sh = -p.dice_mean[1][n] * inv;
         }
-        smem[L::PB1 + n] = (in && p.bias[1] != nullptr) ? p.bias[1][n] : 0.f;
-        smem[L::PB1 + L::N1P + n] = al;
-        smem[L::PB1 + 2 * L::N1P + n] = inv;
-        smem[L::PB1 + 3 * L::N1P + n] = sh;
-        smem[L::OK + n] = in ? p.out_kernel[n] : 0.f;
+        dst[L::PB1 + n] = (in && p.bias[1] != nullptr) ? p.bias[1][n] : 0.f;
+        dst[L::PB1 + L::N1P + n] = al;
+        dst[L::PB1 + 2 * L::N1P + n] = inv;
+        dst[L::PB1 + 3 * L::N1P + n] = sh;
+        dst[L::OK + n] = in ? p.out_kernel[n] : 0.f;
     }
-    if (threadIdx.x == 0) smem[L::OK + L::N1P] = p.out_bias[0];
+    if (tid == 0) dst[L::OK + L::N1P] = p.out_bias[0];
+}
+
+// one launch in front of the score kernel: workgroups [0, n_chunks) compact their chunk of rows (when p.pos), the other
+// PREP_IMAGE_BLOCKS write the LDS image (when p.image)
+constexpr int PREP_IMAGE_BLOCKS = 16;
+template <int EB, int NB0, int NS0, int NS1>
+__global__ __launch_bounds__(CMP_THREADS) void din_prep_kernel(Params p, CompactSrc s) {
+    __shared__ int wave_cnt[4][CMP_THREADS / 64];
+    const int nc = p.pos != nullptr ? p.n_chunks : 0;
+    if ((int)blockIdx.x < nc) {
+        compact_chunk(s, p.rows, p.chunk_rows, const_cast<int32_t*>(p.pos), const_cast<int32_t*>(p.cnt), wave_cnt);
+    } else if (p.image != nullptr) {
+        fill_image<EB, NB0, NS0, NS1>(p, p.image, ((int)blockIdx.x - nc) * CMP_THREADS + (int)threadIdx.x, PREP_IMAGE_BLOCKS * CMP_THREADS);
+    }
+}
+
+template <int EB, int NB0, int NS0, int NS1, bool GATHER = false>
+__global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
+    typedef Lay<EB, NB0, NS0, NS1> L;
+    constexpr int E = L::E, NT0 = L::NT0, N0P = L::N0P;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTHR = 64 * NW;
+    // ---- once per workgroup: the LDS image — copied from the launch's image (din_prep_kernel), else folded here
+    if (p.image != nullptr) {
+        constexpr int N4 = L::END / 4, IT = (N4 + NTHR - 1) / NTHR;
+        static_assert(L::END % 4 == 0, "the image is copied in 16-B pieces");
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.image);
+        f32x4 v[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) v[i] = src[min(i * NTHR + (int)threadIdx.x, N4 - 1)];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            if (i * NTHR + (int)threadIdx.x < N4) reinterpret_cast<f32x4*>(smem)[i * NTHR + threadIdx.x] = v[i];
+    } else {
+        fill_image<EB, NB0, NS0, NS1>(p, smem, (int)threadIdx.x, NTHR);
+    }
+    const bool dice = p.activation == DCTR_ACT_DICE;
+    // compacted rows: upre[c] = 32-row units of the chunks before c (upre[n_chunks] = all units); one wave, <= 16 chunks per lane
+    int* const upre = reinterpret_cast<int*>(smem + L::END);
+    if (p.pos != nullptr && threadIdx.x < 64) {
+        const int ln = threadIdx.x, per = (p.n_chunks + 63) >> 6;
+        int local = 0;
+        for (int i = 0; i < per; ++i) {
+            const int c = ln * per + i;
+            local += c < p.n_chunks ? (p.cnt[c] + UROWS - 1) / UROWS : 0;
+        }
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            incl += ln >= d ? v : 0;
+        }
+        int run = incl - local;
+        for (int i = 0; i < per; ++i) {
+            const int c = ln * per + i;
+            if (c < p.n_chunks) {
+                upre[c] = run;
+                run += (p.cnt[c] + UROWS - 1) / UROWS;
+            }
+        }
+        if (ln == 63) upre[p.n_chunks] = incl;
+    }
     __syncthreads();                                       // the only barrier
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -160,19 +306,30 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
     const float* a1G = smem + L::W1 + (16 * g) * L::S1 + j;            // + (4r + mt) * S1 + 16 * s1
     const float* a1S = smem + L::W1 + (64 * NB0 + 4 * g) * L::S1 + j;  // + (16 s + r) * S1 + 16 * s1
 
-    for (int64_t unit = (int64_t)blockIdx.x * NW + wave; unit < p.n_units; unit += (int64_t)gridDim.x * NW) {
-        const int64_t R0 = unit * UROWS;
+    // units go round the workgroups first (unit u: workgroup u mod grid, wave u / grid): a launch with fewer units than wave slots
+    // still spreads over every CU and every SIMD
+    const int64_t n_units = p.pos != nullptr ? (int64_t)upre[p.n_chunks] : p.n_units;
+    int cc = 0;                                            // compacted: the chunk of the current unit (units of a wave ascend)
+    for (int64_t unit = (int64_t)wave * gridDim.x + blockIdx.x; unit < n_units; unit += (int64_t)gridDim.x * NW) {
+        // rows [R0, Rlim) of the row list (compacted: of the chunk's part of pos) are this unit's
+        int64_t R0 = unit * UROWS, Rlim = p.rows;
+        if (p.pos != nullptr) {
+            while (upre[cc + 1] <= (int)unit) ++cc;
+            R0 = (int64_t)cc * p.chunk_rows + (int64_t)((int)unit - upre[cc]) * UROWS;
+            Rlim = (int64_t)cc * p.chunk_rows + p.cnt[cc];
+        }
         // rows of this lane's two N tiles; query rows
         const float* kp[RT];
         const float* qp[RT];
         // GATHER: the table rows of this lane's (sample, position) rows per feature (as float offsets from the table base; an id
         // outside the vocabulary reads row 0 and raises the status flag)
-        int64_t kro[RT][2], qro[RT][2];
+        uint32_t kro[RT][2], qro[RT][2];                    // (table ROWS: vocabularies < 2^31, host; the float offset is formed per load)
         const int EH = GATHER ? E / max(p.nf, 1) : E;       // embedding_dim of one history feature
         const int EBH = EH / 16;                            // its 16-wide blocks
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
-            const int64_t R = min(R0 + 16 * nt + j, p.rows - 1);
+            const int64_t Rl = min(R0 + 16 * nt + j, Rlim - 1);
+            const int64_t R = p.pos != nullptr ? (int64_t)p.pos[Rl] : Rl;
             const int64_t b = (int64_t)((uint32_t)R / (uint32_t)p.T);      // host: rows < 2^31
             if constexpr (GATHER) {
                 const int64_t t = R - b * p.T;
@@ -184,13 +341,13 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
                         const int64_t iq = load_any_id(p.query_ids[h], b * p.query_stride, p.ids_i64);
                         const bool okk = (uint64_t)ik < (uint64_t)p.hist_vocab[h], okq = (uint64_t)iq < (uint64_t)p.query_vocab[h];
                         bad = bad || !okk || !okq;
-                        kro[nt][h] = (okk ? ik : 0) * EH + 4 * g;
-                        qro[nt][h] = (okq ? iq : 0) * EH + 4 * g;
+                        kro[nt][h] = okk ? (uint32_t)ik : 0u;
+                        qro[nt][h] = okq ? (uint32_t)iq : 0u;
                     } else {
-                        kro[nt][h] = qro[nt][h] = 0;
+                        kro[nt][h] = qro[nt][h] = 0u;
                     }
                 }
-                if (bad && p.status != nullptr && R0 + 16 * nt + j < p.rows) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
+                if (bad && p.status != nullptr && R0 + 16 * nt + j < Rlim) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
                 kp[nt] = qp[nt] = nullptr;
             } else {
                 kp[nt] = p.keys + R * E + 4 * g;
@@ -201,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
         auto load_k = [&](int nt, int c) -> f32x4 {
             if constexpr (GATHER) {
                 const int h = c >= EBH ? 1 : 0;
-                return *(gbl_f4_t)(p.hist_table[h] + kro[nt][h] + 16 * (c - h * EBH));
+                return *(gbl_f4_t)(p.hist_table[h] + ((int64_t)kro[nt][h] * EH + 4 * g + 16 * (c - h * EBH)));
             } else {
                 return *(gbl_f4_t)(kp[nt] + 16 * c);
             }
@@ -209,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
         auto load_q = [&](int nt, int c) -> f32x4 {
             if constexpr (GATHER) {
                 const int h = c >= EBH ? 1 : 0;
-                return *(gbl_f4_t)(p.query_table[h] + qro[nt][h] + 16 * (c - h * EBH));
+                return *(gbl_f4_t)(p.query_table[h] + ((int64_t)qro[nt][h] * EH + 4 * g + 16 * (c - h * EBH)));
             } else {
                 return *(gbl_f4_t)(qp[nt] + 16 * c);
             }
@@ -362,34 +519,41 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
             float v = part[nt];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            const int64_t R = R0 + 16 * nt + j;
-            if (g == 0 && R < p.rows) p.raw[R] = v + ob;
+            const int64_t Rl = R0 + 16 * nt + j;
+            if (g == 0 && Rl < Rlim) p.raw[p.pos != nullptr ? (int64_t)p.pos[Rl] : Rl] = v + ob;
         }
     }
 }
 
 template <int EB, int NB0, int NS0, int NS1, bool GATHER>
-static int launch_one_g(const Params& p, hipStream_t stream) {
+static int launch_one_g(const Params& p, const CompactSrc& cs, hipStream_t stream) {
     typedef Lay<EB, NB0, NS0, NS1> L;
-    const size_t lds = (size_t)L::END * sizeof(float);
+    const size_t lds = (size_t)L::END * sizeof(float) + (p.pos != nullptr ? (size_t)(p.n_chunks + 1) * sizeof(int) : 0);
     if (lds > 160 * 1024) return 0;
+    static_assert((size_t)L::END * sizeof(float) <= IMAGE_BYTES, "the image area of the workspace holds a workgroup's LDS image");
     static thread_local size_t granted[DCTR_MAX_DEVICES] = {0};
     if (dctr_grant_lds((const void*)din_chain_kernel<EB, NB0, NS0, NS1, GATHER>, lds, granted) != hipSuccess) return 0;
-    int64_t grid = dctr_ceil_div(p.n_units, (int64_t)NW);
+    if (p.pos != nullptr || p.image != nullptr) {
+        const unsigned blocks = (unsigned)((p.pos != nullptr ? p.n_chunks : 0) + (p.image != nullptr ? PREP_IMAGE_BLOCKS : 0));
+        hipLaunchKernelGGL((din_prep_kernel<EB, NB0, NS0, NS1>), dim3(blocks), dim3(CMP_THREADS), 0, stream, p, cs);
+    }
+    // units go round the workgroups (unit u: workgroup u mod grid): one workgroup per CU as soon as there are that many units —
+    // 1,632 units of a compacted C4 call are 6.4 per CU, two per SIMD, where 16 per workgroup would fill 102 CUs
     const int64_t cus = dctr_n_cus();
-    if (grid > cus) grid = cus;
+    const int64_t units_max = p.n_units + p.n_chunks;                       // (compacted: an upper bound, a partly filled unit per chunk)
+    int64_t grid = units_max < cus ? units_max : cus;
     DCTR_LAUNCH((din_chain_kernel<EB, NB0, NS0, NS1, GATHER>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
     return 1;
 }
 
 template <int EB, int NB0, int NS0, int NS1>
-static int launch_one(const Params& p, hipStream_t stream) {
-    return p.nf > 0 ? launch_one_g<EB, NB0, NS0, NS1, true>(p, stream) : launch_one_g<EB, NB0, NS0, NS1, false>(p, stream);
+static int launch_one(const Params& p, const CompactSrc& cs, hipStream_t stream) {
+    return p.nf > 0 ? launch_one_g<EB, NB0, NS0, NS1, true>(p, cs, stream) : launch_one_g<EB, NB0, NS0, NS1, false>(p, cs, stream);
 }
 
 template <int EB>
-static int launch_e(const Params& p, int nb0, int ns0, int ns1, hipStream_t stream) {
-#define DC_CASE(A, B, C) if (nb0 == A && ns0 == B && ns1 == C) return launch_one<EB, A, B, C>(p, stream)
+static int launch_e(const Params& p, const CompactSrc& cs, int nb0, int ns0, int ns1, hipStream_t stream) {
+#define DC_CASE(A, B, C) if (nb0 == A && ns0 == B && ns1 == C) return launch_one<EB, A, B, C>(p, cs, stream)
     DC_CASE(1, 1, 3);      // 80-40 (DIN's att_hidden_size default)
     DC_CASE(1, 0, 2);      // 64-32 (LocalActivationUnit's default)
     DC_CASE(1, 0, 1);      // 64-16
@@ -399,11 +563,31 @@ static int launch_e(const Params& p, int nb0, int ns0, int ns1, hipStream_t stre
     return 0;
 }
 
-// 1: the chained kernel was launched (raw scores of all rows -> raw); 0: shape not covered, nothing launched
+// rows of a compaction chunk: 4096, doubled until the launch has <= CMP_MAX_CHUNKS of them
+static int32_t compact_chunk_rows(int64_t rows) {
+    int64_t c = 4 * CMP_THREADS;
+    while (dctr_ceil_div(rows, c) > CMP_MAX_CHUNKS) c *= 2;
+    return (int32_t)c;
+}
+
+// bytes of the row list + the chunk counts behind the [rows] raw scores in the attention workspace
+size_t compact_bytes(int64_t rows) {
+    if (rows <= 0 || rows >= 0x7fffffffLL) return 0;
+    const int64_t chunk = compact_chunk_rows(rows);
+    return (size_t)(dctr_ceil_div(rows, chunk) * chunk + CMP_MAX_CHUNKS) * sizeof(int32_t);
+}
+
+size_t image_bytes() { return IMAGE_BYTES; }
+
+// 1: the chained kernel was launched (raw scores of the rows that count -> raw; all rows without `compact_ws`); 0: shape not covered,
+// nothing launched.  compact_ws: compact_bytes(rows) bytes, 4-B aligned (NULL: every row is scored); key_mask: what counts on the
+// lookup route (the gather route reads the history ids; without a mask_zero feature every row counts and nothing is compacted);
+// image_ws: image_bytes() bytes, 16-B aligned, for the workgroups' LDS image (NULL: every workgroup folds the weights itself)
 int try_launch(const float* query, const float* keys, int64_t batch, int T, int E, int n_layers, const int32_t* units,
                const float* const* kernels, const float* const* biases, int activation, const float* const* dice_alpha,
                const float* const* dice_mean, const float* const* dice_var, float dice_eps, const float* out_kernel,
-               const float* out_bias, float* raw, hipStream_t stream, const dctr_din_gather_t* gd) {
+               const float* out_bias, float* raw, hipStream_t stream, const dctr_din_gather_t* gd, const uint8_t* key_mask,
+               void* compact_ws, void* image_ws) {
     if (n_layers != 2 || (E != 16 && E != 32 && E != 64)) return 0;
     if (gd != nullptr && (gd->n_feats < 1 || gd->n_feats > 2 || E % (16 * gd->n_feats) != 0)) return 0;
     const int n0 = units[0], n1 = units[1];
@@ -449,9 +633,35 @@ int try_launch(const float* query, const float* keys, int64_t batch, int T, int 
         }
     }
     p.n_units = dctr_ceil_div(p.rows, (int64_t)UROWS);
-    if (E == 16) return launch_e<1>(p, nb0, ns0, ns1, stream);
-    if (E == 32) return launch_e<2>(p, nb0, ns0, ns1, stream);
-    return launch_e<4>(p, nb0, ns0, ns1, stream);
+    const bool masked = gd != nullptr ? (gd->mask_zero[0] || (gd->n_feats > 1 && gd->mask_zero[1])) : key_mask != nullptr;
+    CompactSrc cs{};
+    p.image = static_cast<float*>(image_ws);
+    if (compact_ws != nullptr && masked && p.rows < 0x7fffffffLL) {
+        {
+            cs.key_mask = gd != nullptr ? nullptr : key_mask;
+            cs.T = T;
+            if (gd != nullptr) {
+                cs.nf = gd->n_feats;
+                cs.ids_i64 = gd->ids_is_i64;
+                cs.hist_stride = gd->hist_stride;
+                cs.status = gd->status;
+                for (int h = 0; h < gd->n_feats; ++h) {
+                    cs.hist_ids[h] = gd->hist_ids[h];
+                    cs.mask_zero[h] = gd->mask_zero[h];
+                    cs.hist_vocab[h] = gd->hist_vocab[h];
+                }
+            }
+            p.chunk_rows = compact_chunk_rows(p.rows);
+            p.n_chunks = (int32_t)dctr_ceil_div(p.rows, (int64_t)p.chunk_rows);
+            int32_t* pos = static_cast<int32_t*>(compact_ws);
+            int32_t* cnt = pos + (int64_t)p.n_chunks * p.chunk_rows;
+            p.pos = pos;
+            p.cnt = cnt;
+        }
+    }
+    if (E == 16) return launch_e<1>(p, cs, nb0, ns0, ns1, stream);
+    if (E == 32) return launch_e<2>(p, cs, nb0, ns0, ns1, stream);
+    return launch_e<4>(p, cs, nb0, ns0, ns1, stream);
 }
 
 }  // namespace dctr_din_chain

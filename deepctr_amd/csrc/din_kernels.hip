@@ -19,7 +19,10 @@ namespace dctr_din_chain {      // din_chain_kernels.hip: the row-chained form o
 int try_launch(const float* query, const float* keys, int64_t batch, int T, int E, int n_layers, const int32_t* units,
                const float* const* kernels, const float* const* biases, int activation, const float* const* dice_alpha,
                const float* const* dice_mean, const float* const* dice_var, float dice_eps, const float* out_kernel,
-               const float* out_bias, float* raw, hipStream_t stream, const dctr_din_gather_t* gd = nullptr);
+               const float* out_bias, float* raw, hipStream_t stream, const dctr_din_gather_t* gd, const uint8_t* key_mask,
+               void* compact_ws, void* image_ws);
+size_t compact_bytes(int64_t rows);
+size_t image_bytes();
 }
 
 #ifdef DCTR_LAB_TIMING
@@ -783,9 +786,27 @@ bool din_fast_plan(const dctr_din_attn_args_t* a, DinFastParams& p, size_t& lds_
 
 }  // namespace
 
+// [B * T] raw scores, then the list of the rows that count (din_chain_kernels.hip: masked positions are skipped)
+static size_t din_raw_bytes(int64_t rows) { return (((size_t)rows * sizeof(float)) + 15) & ~(size_t)15; }
+
 extern "C" size_t dctr_din_attn_workspace_bytes(const dctr_din_attn_args_t* a) {
     if (a == nullptr || a->batch <= 0 || a->maxlen <= 0) return 0;
-    return (size_t)a->batch * (size_t)a->maxlen * sizeof(float);
+    const int64_t rows = a->batch * (int64_t)a->maxlen;
+    return din_raw_bytes(rows) + dctr_din_chain::compact_bytes(rows) + dctr_din_chain::image_bytes();
+}
+
+// the compaction area of a workspace that is large enough for it, else NULL (a [B * T]-float workspace of earlier ABIs: all rows scored)
+static void* din_compact_area(const dctr_din_attn_args_t* a, int64_t rows) {
+    const size_t cb = dctr_din_chain::compact_bytes(rows);
+    if (cb == 0 || a->workspace == nullptr || a->workspace_bytes < din_raw_bytes(rows) + cb) return nullptr;
+    return static_cast<char*>(a->workspace) + din_raw_bytes(rows);
+}
+
+// the LDS-image area behind it (workspaces of dctr_din_attn_workspace_bytes), else NULL
+static void* din_image_area(const dctr_din_attn_args_t* a, int64_t rows) {
+    const size_t off = din_raw_bytes(rows) + dctr_din_chain::compact_bytes(rows);
+    if (dctr_din_chain::compact_bytes(rows) == 0 || a->workspace == nullptr || a->workspace_bytes < off + dctr_din_chain::image_bytes()) return nullptr;
+    return static_cast<char*>(a->workspace) + off;
 }
 
 extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* stream) {
@@ -841,7 +862,8 @@ extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* strea
             if (!no_chain && pool_lds0 <= 64 * 1024 &&
                 dctr_din_chain::try_launch(a->query, a->keys, a->batch, a->maxlen, a->dim, a->n_layers, a->units, a->kernels, a->biases,
                                            a->activation, a->dice_alpha, a->dice_mean, a->dice_var, a->dice_eps, a->out_kernel,
-                                           a->out_bias, f.raw, (hipStream_t)stream)) {
+                                           a->out_bias, f.raw, (hipStream_t)stream, nullptr, a->key_mask, din_compact_area(a, rows),
+                                           din_image_area(a, rows))) {
                 hipLaunchKernelGGL(din_pool_kernel, dim3((unsigned)dctr_ceil_div(a->batch, (int64_t)4)), dim3(256), pool_lds0,
                                    (hipStream_t)stream, f.raw, a->keys, a->key_mask, a->batch, a->maxlen, a->dim,
                                    a->weight_normalization, a->out, a->out_stride, a->scores);
@@ -927,7 +949,7 @@ extern "C" int dctr_din_attn_gather_fwd(const dctr_din_attn_args_t* a, const dct
     DCTR_REQUIRE(rows < 0x7fffffffLL, DCTR_E_DIM, "din_attn_gather_fwd: batch x maxlen too large");
     for (int h = 0; h < g->n_feats; ++h) {
         DCTR_REQUIRE(g->hist_ids[h] && g->query_ids[h] && g->hist_table[h] && g->query_table[h], DCTR_E_NULL, "din_attn_gather_fwd: feature %d null", h);
-        DCTR_REQUIRE(g->hist_vocab[h] >= 1 && g->hist_vocab[h] < 0x7fffffffLL && g->query_vocab[h] >= 1, DCTR_E_DIM,
+        DCTR_REQUIRE(g->hist_vocab[h] >= 1 && g->hist_vocab[h] < 0x7fffffffLL && g->query_vocab[h] >= 1 && g->query_vocab[h] < 0x7fffffffLL, DCTR_E_DIM,
                      "din_attn_gather_fwd: vocabulary of feature %d", h);
         DCTR_REQUIRE(dctr_aligned16(g->hist_table[h]) && dctr_aligned16(g->query_table[h]), DCTR_E_ALIGN, "din_attn_gather_fwd: tables 16-B aligned");
     }
@@ -941,7 +963,8 @@ extern "C" int dctr_din_attn_gather_fwd(const dctr_din_attn_args_t* a, const dct
     float* raw = static_cast<float*>(a->workspace);
     const int ok = dctr_din_chain::try_launch(nullptr, nullptr, a->batch, a->maxlen, a->dim, a->n_layers, a->units, a->kernels, a->biases,
                                               a->activation, a->dice_alpha, a->dice_mean, a->dice_var, a->dice_eps, a->out_kernel,
-                                              a->out_bias, raw, (hipStream_t)stream, g);
+                                              a->out_bias, raw, (hipStream_t)stream, g, nullptr, din_compact_area(a, rows),
+                                              din_image_area(a, rows));
     DCTR_REQUIRE(ok, DCTR_E_UNSUPPORTED,
                  "din_attn_gather_fwd: the row-chained score kernel takes two-layer attention MLPs (units[0] <= 112, units[1] <= 64) and "
                  "dim 16 / 32 / 64 — use the lookups + dctr_din_attn_pool_fwd");

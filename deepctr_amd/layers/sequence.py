@@ -132,11 +132,14 @@ class AttentionSequencePoolingLayer(Layer):
         self.built = True
         return self
 
+    # masked positions are skipped by the score kernel (csrc/din_chain_kernels.hip); False scores every position (A/B switch)
+    compact_positions = True
+
     def run(self, queries, keys, key_masks, out=None, out_stride=None):
         la = self.local_att
         return ops.din_attention(queries, keys, key_masks, la.dnn.kernels, la.dnn.biases, la.w("kernel"), la.w("bias"),
                                  self.att_activation, la.dnn.dice_params(), weight_normalization=self.weight_normalization,
-                                 return_score=self.return_score, out=out, out_stride=out_stride)
+                                 return_score=self.return_score, out=out, out_stride=out_stride, compact=self.compact_positions)
 
     def call(self, inputs, mask=None, training=None, **kwargs):
         if self.supports_masking:

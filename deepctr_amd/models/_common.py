@@ -263,6 +263,7 @@ class FusedForward(object):
         m.tile_rows = int(self.tile_rows)
         m.probe = None if self.probe is None else self.probe.data_ptr()
         m.precision = 0 if not bf3 else (2 if self._bf3["fresh"] else 1)
+        self._fast_g = g                                                # (xDeepFM: the CIN launch reads the same gather arguments)
         for i, t in enumerate(self._extra_logits(staged, lo, hi)):      # (their launches go out here, in front of the fused one)
             m.add[i] = t.data_ptr()
         return g, m
@@ -305,6 +306,7 @@ class FusedForward(object):
             if pre:                                                      # (the hash launch fills the matrix g.ids points at)
                 h = sp.prehash(staged, lo, hi, ws, out=own_ids)
                 g.ids, g.ids_stride_f = h.data_ptr(), h.stride(0)
+            self._fast_g = g
             for i, t in enumerate(self._extra_logits(staged, lo, hi)):
                 m.add[i] = t.data_ptr()
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")

@@ -82,7 +82,8 @@ class _DIN(FeatureModel):
         r = ops.din_attention_gather(h_ids, q_ids, h_tab, q_tab, mz, la.dnn.kernels, la.dnn.biases, la.w("kernel"), la.w("bias"),
                                      self.attention.att_activation, la.dnn.dice_params(),
                                      weight_normalization=self.attention.weight_normalization, out=out,
-                                     out_stride=self.stage_plan.out_stride, status=ws["status"])
+                                     out_stride=self.stage_plan.out_stride, status=ws["status"],
+                                     compact=self.attention.compact_positions)
         if r is None:
             self._fold_failed = True
             return False

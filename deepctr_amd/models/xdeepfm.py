@@ -1,6 +1,8 @@
 """xDeepFM — same signature as ``deepctr.models.xdeepfm.xDeepFM`` (reference deepctr/models/xdeepfm.py:18-70).
-Launches per batch: fused gather (+ linear logit) -> CIN kernel (all layers, f32 MFMA, reads the embedding
-part of the DNN input in place) -> Dense(1) on the CIN maps -> DNN kernel with the fused head."""
+Fixed-length features (round 4): TWO launches per call and no DNN input in HBM — ``dctr_cin_gather_fwd`` (CIN kernel: all layers on
+f32 MFMA, its [samples, F0, D] tile read from the embedding tables, the Dense(1) over the maps taken on chip -> one logit per row)
+and ``dctr_embed_mlp_fwd`` (ids -> DNN -> head, + linear logit + the CIN logit).  Otherwise (pooled / hashed-in-kernel features,
+``fuse_cin = False``): fused gather (+ linear logit) -> dnn_in -> CIN kernel -> Dense(1) on the CIN maps -> DNN kernel with the head."""
 import torch
 
 from .. import ops
@@ -8,10 +10,10 @@ from ..engine import EmbeddingStage
 from ..layers.base import name_scope
 from ..layers.core import DNN, Dense, PredictionLayer
 from ..layers.interaction import CIN
-from ._common import FeatureModel
+from ._common import FeatureModel, FusedForward
 
 
-class _xDeepFM(FeatureModel):
+class _xDeepFM(FusedForward, FeatureModel):
     def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units, cin_layer_size, cin_split_half,
                  cin_activation, seed, dnn_dropout, dnn_activation, dnn_use_bn, task, device):
         super(_xDeepFM, self).__init__("xDeepFM", list(linear_feature_columns) + list(dnn_feature_columns), device, task)
@@ -39,6 +41,49 @@ class _xDeepFM(FeatureModel):
         self._buf = {}
         self._cin_ws = None         # layer 0's folded filter rows (dctr_cin_args_t.workspace): written by the first CIN launch after _begin()
         self._cin_ws_ready = False
+        self._fast_g = None         # the marshalled gather arguments of the fused launch being issued (FusedForward)
+        self.fuse_cin = True        # False: the route through dnn_in (gather -> HBM -> CIN / DNN launches)
+        if len(dnn_hidden_units) > 0:
+            self._init_fused(dnn_hidden_units, dnn_activation)
+
+    def _cin_fuse_ok(self):
+        sp = self.stage_plan
+        return bool(self.fuse_cin and self.fused and (self.cin is None or (self.cin_dim % 4 == 0 and sp.uniform_dim == self.cin_dim)))
+
+    def _prehash(self, B):
+        # hashed SparseFeat: ALWAYS hashed by the dctr_hash_fields launch in front (the CIN launch takes plain rows only)
+        sp = self.stage_plan
+        return bool(sp.any_hash and sp.uniform_dim in (4, 8, 16, 32, 64))
+
+    def _fast_path(self, staged):
+        return self._cin_fuse_ok() and super(_xDeepFM, self)._fast_path(staged) and (not self.stage_plan.any_hash or self._prehash(0))
+
+    def _rows_per_launch(self, staged, batch_size):
+        # CIN's persistent-round efficiency peaks around 65,536 rows per launch; the one-launch DNN takes any span
+        return FeatureModel._rows_per_launch(self, staged, batch_size)
+
+    def _cin_workspace(self):
+        if self._cin_ws is None:
+            need = ops.cin_workspace_bytes(len(self.stage_plan.fields), self.cin_dim, list(self.cin.layer_size))
+            self._cin_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=self.device)
+        return self._cin_ws
+
+    def _extra_logits(self, staged, lo, hi):
+        """The CIN logit of rows [lo, hi): dctr_cin_gather_fwd on the gather arguments of the fused launch (issued in front of it)."""
+        if self.cin is None:
+            return []
+        B = hi - lo
+        bufs = self._buf.get(("logit", B))
+        if bufs is None:
+            if len(self._buf) >= 8:
+                self._buf.clear()
+            bufs = self._buf[("logit", B)] = torch.zeros(B, dtype=torch.float32, device=self.device)
+        ok = ops.cin_gather(self._fast_g, self.cin.filters, self.cin.biases, list(self.cin.layer_size), self.cin.split_half,
+                            self.cin.activation, self.cin_dim, self.dense_1.w('kernel'), bufs, self._cin_workspace(), self._cin_ws_ready)
+        if not ok:
+            raise RuntimeError("dctr_cin_gather_fwd declined a shape _cin_fuse_ok() admitted")
+        self._cin_ws_ready = True
+        return [bufs]
 
     # CIN's persistent-round efficiency grows with the launch (C3: 300 us per 4096-row launch, 257 us per 4096 rows at 65,536)
     span_rows = 65536
@@ -48,6 +93,8 @@ class _xDeepFM(FeatureModel):
         self._cin_ws_ready = False  # the filters may have moved since the last call
 
     def _forward(self, staged, lo, hi, out):
+        if self._fast_path(staged):
+            return self._forward_fast(staged, lo, hi, out)
         ws = self.stage_plan.run(staged, lo, hi)
         B = hi - lo
         add = self._logits_to_add(ws)
@@ -59,9 +106,7 @@ class _xDeepFM(FeatureModel):
                 bufs = self._buf[B] = (torch.zeros(B, self.cin_out_dim, dtype=torch.float32, device=self.device),
                                        torch.zeros(B, dtype=torch.float32, device=self.device))
             maps, logit = bufs
-            if self._cin_ws is None:
-                need = ops.cin_workspace_bytes(len(self.stage_plan.fields), self.cin_dim, list(self.cin.layer_size))
-                self._cin_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=self.device)
+            self._cin_workspace()
             ops.cin(ws["dnn_in"], [f.reshape(-1, f.shape[-1]) for f in self.cin.filters], self.cin.biases,
                     list(self.cin.layer_size), self.cin.split_half, self.cin.activation, fields=len(self.stage_plan.fields),
                     dim=self.cin_dim, out=maps, workspace=self._cin_ws, workspace_ready=self._cin_ws_ready)

@@ -446,6 +446,37 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
     return out
 
 
+def cin_gather(gather, filters, biases, layer_size, split_half, activation, dim, head_w, logit, workspace, workspace_ready=False, out=None):
+    """CIN over the embeddings of a gather with the Dense(1) head fused (dctr_cin_gather_fwd; reference models/xdeepfm.py:52-66):
+    ``gather`` = the marshalled dctr_gather_fm_args_t of the batch (EmbeddingStage.gather_args), ``head_w`` [featuremap_num(, 1)],
+    ``logit`` [B] float32 receives maps . head_w, ``workspace`` = the caller-owned fold workspace (cin_workspace_bytes).
+    Without a head (``head_w`` / ``logit`` None) the summed maps go to ``out`` [B, featuremap_num] as ``cin`` writes them.
+    Returns False when the library declines the shape (hashed / pooled fields, dim % 4 != 0): the caller takes dnn_in + ``cin``."""
+    n = len(layer_size)
+    filters = [_f32c(f, "filter").reshape(-1, h) for f, h in zip(filters, layer_size)]
+    biases = [_f32c(b, "bias") for b in biases]
+    ls = _i32_array(layer_size)
+    fp, bp = _ptr_array(filters), _ptr_array(biases)
+    if activation not in _C.ACT_CODES or _C.ACT_CODES[activation] == _C.ACT_DICE:
+        raise ValueError("CIN activation %r is not supported" % (activation,))
+    a = _C.CinArgs(x=None, batch=int(gather.batch), x_stride=0, fields=int(gather.n_fields), dim=int(dim), n_layers=n,
+                   split_half=int(bool(split_half)), activation=_C.ACT_CODES[activation], layer_size=ctypes.cast(ls, ctypes.c_void_p),
+                   filters=ctypes.cast(fp, ctypes.c_void_p), bias=ctypes.cast(bp, ctypes.c_void_p),
+                   out=None if out is None else out.data_ptr(), workspace=None, workspace_bytes=0)
+    need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
+    if need and workspace is not None:
+        if workspace.numel() * 4 < need:
+            raise ValueError("cin_gather: workspace of >= %d bytes needed" % need)
+        a.workspace, a.workspace_bytes, a.workspace_ready = workspace.data_ptr(), need, int(bool(workspace_ready))
+    hw = None if head_w is None else _f32c(head_w, "head_w").reshape(-1)
+    rc = _C.lib().dctr_cin_gather_fwd(ctypes.byref(a), ctypes.byref(gather), None if hw is None else hw.data_ptr(),
+                                      None if logit is None else logit.data_ptr(), _C.stream_ptr())
+    if rc == _C.E_UNSUPPORTED:
+        return False
+    _C.check(rc, "dctr_cin_gather_fwd")
+    return True
+
+
 def cin_workspace_bytes(fields, dim, layer_size):
     """Bytes of the fold workspace dctr_cin_fwd takes for a CIN over ``fields`` embeddings of width ``dim`` (0: no fold)."""
     ls = _i32_array(layer_size)
@@ -667,10 +698,11 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
 
 def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, activation="sigmoid", dice=None,
                   dice_eps=1e-9, weight_normalization=False, return_score=False, out=None, out_stride=None,
-                  workspace=True):
+                  workspace=True, compact=True):
     """AttentionSequencePoolingLayer.call (reference sequence.py:261-298): query [B,1,E] / [B,E], keys [B,T,E],
     key_mask [B,T] (bool/uint8) -> [B,1,E] (or the scores [B,1,T]).  ``workspace=False`` withholds the [B*T]
-    scratch and thereby selects the one-workgroup-per-sample kernel (see include/dctr.h)."""
+    scratch and thereby selects the one-workgroup-per-sample kernel (see include/dctr.h); ``compact=False`` hands over the [B*T]
+    floats only, without the row-list area: every position is scored, masked or not (A/B of the compaction)."""
     _dev_check(query, keys, key_mask, out_kernel, out_bias)
     keys = _f32c(keys, "keys")
     B, T, E = keys.shape
@@ -703,8 +735,8 @@ def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, 
                        out_bias=_f32c(out_bias, "out_bias").data_ptr(), out=out.data_ptr(), out_stride=out_stride,
                        scores=None if scores is None else scores.data_ptr())
     if workspace:                      # [B*T] raw scores: enables the weights-in-LDS row kernel (include/dctr.h)
-        ws = torch.empty(max(1, int(_C.lib().dctr_din_attn_workspace_bytes(ctypes.byref(a))) // 4), dtype=torch.float32,
-                         device=keys.device)
+        need = int(_C.lib().dctr_din_attn_workspace_bytes(ctypes.byref(a))) if compact else B * T * 4
+        ws = torch.empty(max(1, (need + 3) // 4), dtype=torch.float32, device=keys.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _C.check(_C.lib().dctr_din_attn_pool_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_din_attn_pool_fwd")
     if return_score:
@@ -713,7 +745,7 @@ def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, 
 
 
 def din_attention_gather(hist_ids, query_ids, hist_tables, query_tables, mask_zero, kernels, biases, out_kernel, out_bias, activation="sigmoid",
-                         dice=None, dice_eps=1e-9, weight_normalization=False, out=None, out_stride=None, status=None):
+                         dice=None, dice_eps=1e-9, weight_normalization=False, out=None, out_stride=None, status=None, compact=True):
     """AttentionSequencePoolingLayer.call with the query / key lookups folded in (dctr_din_attn_gather_fwd): ``hist_ids`` = list of
     [B, T] id tensors (one per history feature, int32 or int64 alike), ``query_ids`` = list of [B] id tensors (strided views
     allowed), ``*_tables`` = the features' [vocab, E_h] embedding tables, ``mask_zero`` = per feature whether id 0 masks the
@@ -744,7 +776,6 @@ def din_attention_gather(hist_ids, query_ids, hist_tables, query_tables, mask_ze
         dm = _ptr_array([_f32c(d[1], "mean") for d in dice])
         dv = _ptr_array([_f32c(d[2], "var") for d in dice])
     ua, kp, bp = _i32_array(units), _ptr_array(kernels), _ptr_array(biases)
-    ws = torch.empty(max(1, B * T), dtype=torch.float32, device=out.device)
     a = _C.DinAttnArgs(query=None, keys=None, key_mask=None, batch=B, maxlen=T, dim=E, n_layers=2, activation=act,
                        units=ctypes.cast(ua, ctypes.c_void_p), kernels=ctypes.cast(kp, ctypes.c_void_p),
                        biases=ctypes.cast(bp, ctypes.c_void_p),
@@ -753,8 +784,11 @@ def din_attention_gather(hist_ids, query_ids, hist_tables, query_tables, mask_ze
                        dice_var=None if dv is None else ctypes.cast(dv, ctypes.c_void_p), dice_eps=float(dice_eps),
                        weight_normalization=int(bool(weight_normalization)),
                        out_kernel=_f32c(out_kernel, "out_kernel").reshape(-1).data_ptr(),
-                       out_bias=_f32c(out_bias, "out_bias").data_ptr(), out=out.data_ptr(), out_stride=out_stride, scores=None,
-                       workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4)
+                       out_bias=_f32c(out_bias, "out_bias").data_ptr(), out=out.data_ptr(), out_stride=out_stride, scores=None)
+    # [B*T] raw scores + the list of the positions that count (compact=False: the scores only, every position is scored)
+    need = int(_C.lib().dctr_din_attn_workspace_bytes(ctypes.byref(a))) if compact else B * T * 4
+    ws = torch.empty(max(1, (need + 3) // 4), dtype=torch.float32, device=out.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g = _C.DinGatherArgs(n_feats=nf, ids_is_i64=int(i64), hist_stride=hist_ids[0].stride(0), query_stride=query_ids[0].stride(0),
                          status=None if status is None else status.data_ptr())
     for h in range(nf):

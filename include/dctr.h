@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 7
+#define DCTR_ABI_VERSION 8
 
 enum {
     DCTR_OK = 0,
@@ -305,6 +305,15 @@ typedef struct {
 size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* args);
 int dctr_cin_fwd(const dctr_cin_args_t* args, void* stream);
 
+/* ABI 8 — CIN.call over the embeddings of a gather, as deepctr/models/xdeepfm.py:52-66 wires it: exFM_in = concat_func(sparse_embedding_list,
+ * axis=1) -> CIN -> Dense(1, use_bias=False).  The workgroup's [samples, F0, D] tile is read from the embedding tables inside the kernel
+ * (gather: the dctr_embed_gather_fm arguments of the same batch — fields / ids / strides / status are used; every field a plain lookup
+ * of width args->dim, dim % 4 == 0, no hashed and no pre-pooled field, else DCTR_E_UNSUPPORTED), args->x / x_stride are ignored and the
+ * DNN input never has to exist in HBM.  head_w [featuremap_num] + logit [B] (both or neither): the Dense(1) over the summed maps is taken
+ * on chip and only logit[b] leaves (args->out may then be NULL); without them args->out receives the maps as in dctr_cin_fwd.
+ * An id outside its vocabulary reads row 0 and raises DCTR_STATUS_INDEX_OOR in *gather->status.  Inference only (save_y must be NULL). */
+int dctr_cin_gather_fwd(const dctr_cin_args_t* args, const dctr_gather_fm_args_t* gather, const float* head_w, float* logit, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a11 AFMLayer.call — deepctr/layers/interaction.py:116-146 (inference: dropout inactive)
  *     x [B,F,E] (sample stride x_stride); W [E,A]; b [A]; h [A]; p [E]  ->  y [B]
@@ -475,8 +484,12 @@ typedef struct {
     float* scores;                /* optional [B,T] (return_score) */
     void* workspace;              /* optional device scratch of dctr_din_attn_workspace_bytes() bytes, 16-B aligned.
                                      With it (and dim % 16 == 0 and <= 64, layer widths <= 96, query / keys 16-B aligned) the
-                                     attention MLP runs as one row problem over all B*T positions with the weights
-                                     resident in LDS (two launches); without it, one workgroup per sample. */
+                                     attention MLP runs as one row problem over the B*T positions with the weights
+                                     resident in LDS; without it, one workgroup per sample.  Layout (ABI 8): [B*T] raw scores,
+                                     then the list of the positions that COUNT (masked positions are skipped by the row-chained
+                                     score kernel: their scores never reach the output, sequence.py:280-285), then the
+                                     workgroups' LDS image.  A workspace of only B*T floats (ABI <= 7 callers) still works: every
+                                     position is scored and each workgroup folds the weights itself. */
     size_t workspace_bytes;
 } dctr_din_attn_args_t;
 size_t dctr_din_attn_workspace_bytes(const dctr_din_attn_args_t* args);

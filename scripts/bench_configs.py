@@ -84,8 +84,8 @@ def run_span(name, model, feed, B, reps=8, dnn_flop=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,c3_span,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
-                                         "dcn_mix,nfm,afm,pnn,c4,c4_span,c4_lookups,c5,c5_span")
+    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,c3_span,c3_dnn_in,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
+                                         "dcn_mix,nfm,afm,pnn,c4,c4_span,c4_allpos,c4_lookups,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
     args = ap.parse_args()
@@ -166,6 +166,12 @@ def main():
             run("C3 xDeepFM CIN[128,128]", m, feed, 4096, args.steps, ring)
         if "c3_span" in want:
             run_span("C3 xDeepFM (1 call / %d batches)" % ring, m, feed, 4096)
+        if "c3_dnn_in" in want:                               # A/B: the route through dnn_in (gather -> HBM -> CIN -> Dense(1) -> DNN)
+            m.fuse_cin = False
+            run("C3 xDeepFM, route through dnn_in", m, feed, 4096, args.steps, ring)
+            run_span("C3 xDeepFM, route through dnn_in (1 call / %d batches)" % ring, m, feed, 4096)
+            m.fuse_cin = True
+            run_span("C3 xDeepFM (1 call / %d batches) again" % ring, m, feed, 4096)
         del m
     for par, tag in (("vector", "dcn_v"), ("matrix", "dcn_m")):
         if tag in want:
@@ -212,6 +218,11 @@ def main():
         run("C4 DIN T=50 E=32 (dice)", m, feed, B, args.steps, ring)
         if "c4_span" in want:
             run_span("C4 DIN (1 call / %d batches)" % ring, m, feed, B)
+        if "c4_allpos" in want:                              # A/B: every (sample, position) row scored, masked or not (round 3 / 4a)
+            m.attention.compact_positions = False
+            run("C4 DIN, every position scored", m, feed, B, args.steps, ring)
+            run_span("C4 DIN, every position scored (1 call / %d batches)" % ring, m, feed, B)
+            m.attention.compact_positions = True
         if "c4_lookups" in want:                             # the lookup route: dctr_embed_lookup_multi -> keys in HBM -> attention
             m.fold_lookups = False
             run("C4 DIN, lookup route (keys through HBM)", m, feed, B, args.steps, ring)

@@ -612,6 +612,99 @@ def test_din_attention_row_kernel_matches_per_sample_kernel(device, B, T, E, hid
                            what="din row kernel vs oracle %s B=%d" % (act, B))
 
 
+def _att_params(rng, E, hid, device):
+    dims = [4 * E] + list(hid)
+    ks = [dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device) for i in range(len(hid))]
+    bs = [dev(rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1, device) for i in range(len(hid))]
+    ok = dev(rng.standard_normal((dims[-1], 1)).astype(np.float32) * 0.3, device)
+    ob = dev(np.array([0.05], np.float32), device)
+    dice = [tuple(dev(a, device) for a in (rng.standard_normal(h).astype(np.float32) * 0.3, rng.standard_normal(h).astype(np.float32) * 0.1,
+                                            rng.uniform(0.5, 1.5, h).astype(np.float32))) for h in hid]
+    return ks, bs, ok, ob, dice
+
+
+def _masks(rng, B, T):
+    lens = rng.randint(0, T + 1, B)
+    yield "prefix lengths 0..T", np.arange(T)[None, :] < lens[:, None]
+    yield "random holes", rng.rand(B, T) < 0.4
+    yield "nothing counts", np.zeros((B, T), bool)
+    yield "everything counts", np.ones((B, T), bool)
+    one = np.zeros((B, T), bool)
+    one[B // 2, T - 1] = True
+    yield "one position", one
+
+
+@pytest.mark.parametrize("B,T,E,hid", [(2048, 50, 64, (80, 40)),        # C4: 102,400 rows = 25 compaction chunks
+                                       (700, 13, 32, (64, 32)),         # 9,100 rows: three chunks, the last one ragged
+                                       (90, 45, 16, (32, 16)),          # less than one chunk
+                                       (10000, 50, 16, (64, 16))])      # 500,000 rows (a span of batches)
+def test_din_attention_skips_masked_positions_bit_for_bit(device, B, T, E, hid):
+    """The row-chained score kernel walks the compacted list of positions that count (din_compact_kernel); a position's score does
+    not depend on its place in that list: outputs and returned scores equal the all-positions launch bit for bit, whatever the mask."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(5 + B)
+    q = dev(rng.standard_normal((B, 1, E)).astype(np.float32) * 0.5, device)
+    k = dev(rng.standard_normal((B, T, E)).astype(np.float32) * 0.5, device)
+    ks, bs, ok, ob, dice = _att_params(rng, E, hid, device)
+    for name, km in _masks(rng, B, T):
+        for act, wn in (("dice", False), ("sigmoid", True)):
+            d = dice if act == "dice" else None
+            for rs in (False, True):
+                a = ops.din_attention(q, k, dev(km, device), ks, bs, ok, ob, act, d, weight_normalization=wn, return_score=rs)
+                b = ops.din_attention(q, k, dev(km, device), ks, bs, ok, ob, act, d, weight_normalization=wn, return_score=rs, compact=False)
+                assert np.array_equal(a.cpu().numpy(), b.cpu().numpy()), "%s, %s, wn=%s, scores=%s" % (name, act, wn, rs)
+
+
+@pytest.mark.parametrize("B,T,EH,nf,hid,i64", [(2048, 50, 32, 2, (80, 40), False), (333, 20, 16, 1, (64, 32), True), (5000, 30, 16, 2, (32, 16), False)])
+def test_din_attention_gather_skips_masked_positions_bit_for_bit(device, B, T, EH, nf, hid, i64):
+    """The same on the folded-lookups route (ids -> table rows inside the kernels): compacted = all positions = the lookup route on
+    keys gathered by torch, bit for bit; holes in the middle of a sequence; the second feature without mask_zero; a bad id at a
+    MASKED position still raises the status flag."""
+    import torch
+    from deepctr_amd import ops
+    rng = np.random.RandomState(11 + B)
+    V = [5000, 300][:nf]
+    E = EH * nf
+    tabs = [dev(rng.standard_normal((v, EH)).astype(np.float32) * 0.5, device) for v in V]
+    ks, bs, ok, ob, dice = _att_params(rng, E, hid, device)
+    dt = np.int64 if i64 else np.int32
+    lens = rng.randint(0, T + 1, B)
+    pad = np.arange(T)[None, :] >= lens[:, None]
+    hole = rng.rand(B, T) < 0.1
+    h_np = []
+    for v in V:
+        ids = rng.randint(1, v, (B, T)).astype(dt)
+        ids[pad] = 0
+        h_np.append(ids)
+    h_np[0][hole] = 0                                   # holes: positions masked by the first feature only
+    q_np = [rng.randint(1, v, B).astype(dt) for v in V]
+    h_ids = [dev(x, device) for x in h_np]
+    q_ids = [dev(x, device) for x in q_np]
+    for mz in ([True] * nf, [True, False][:nf]):
+        mask = np.ones((B, T), bool)
+        for h in range(nf):
+            if mz[h]:
+                mask &= h_np[h] != 0
+        keys = torch.cat([tabs[h][h_ids[h].long()] for h in range(nf)], dim=2)
+        query = torch.cat([tabs[h][q_ids[h].long()] for h in range(nf)], dim=1)
+        for act, wn in (("dice", False), ("sigmoid", True)):
+            d = dice if act == "dice" else None
+            st = torch.zeros(1, dtype=torch.int32, device=device)
+            a = ops.din_attention_gather(h_ids, q_ids, tabs, tabs, mz, ks, bs, ok, ob, act, d, weight_normalization=wn, status=st)
+            b = ops.din_attention_gather(h_ids, q_ids, tabs, tabs, mz, ks, bs, ok, ob, act, d, weight_normalization=wn, status=st, compact=False)
+            c = ops.din_attention(query, keys, dev(mask, device), ks, bs, ok, ob, act, d, weight_normalization=wn).reshape(B, E)
+            assert a is not None and b is not None and int(st.item()) == 0
+            assert np.array_equal(a.cpu().numpy(), b.cpu().numpy()), "compacted vs all positions (%s, mask_zero %s)" % (act, mz)
+            assert np.array_equal(a.cpu().numpy(), c.cpu().numpy()), "folded lookups vs keys in HBM (%s, mask_zero %s)" % (act, mz)
+    # an id outside the vocabulary at a masked position (feature 0 holds the mask value there)
+    rb, tb = np.argwhere(pad | hole)[0]
+    bad = h_np[-1].copy()
+    bad[rb, tb] = V[-1] + 3
+    st = torch.zeros(1, dtype=torch.int32, device=device)
+    ops.din_attention_gather(h_ids[:-1] + [dev(bad, device)], q_ids, tabs, tabs, [True] * nf, ks, bs, ok, ob, "sigmoid", None, status=st)
+    assert int(st.item()) != 0
+
+
 @pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 6])
 def test_cin_embedding_dims(device, D):
     """Row-tile / register-reduction layouts of the CIN kernel: D below, at and above the 16-row MFMA tile, D % 4 != 0
