@@ -196,11 +196,38 @@ __device__ __forceinline__ void mfma_ip(f32x4& acc, float a, float b) {
 __device__ __forceinline__ void mfma_bi(f32x4& acc, float a, float b) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-// activation of a whole accumulator set in place.  Only ReLU and linear DNNs take this kernel (the host sends tanh / sigmoid
-// ones to the streaming kernel): the libm code of the other activations, unrolled over 128 accumulator registers, made hipcc
-// spill accumulators around the layer boundaries on the ReLU path as well
-template <int NM, int RT>
+// activation of a whole accumulator set in place.  ReLU / linear in the plain instantiations; sigmoid / tanh DNNs (reference
+// layers/activation.py:75-85 -> tf.keras.layers.Activation) take the EXPACT instantiations (chain_kernels_r2w8_m42_t.hip) — their own
+// kernels: libm code unrolled over 128 accumulator registers made hipcc spill around the layer boundaries on the ReLU path as well.
+// Their forms run on the transcendental units (v_exp_f32, v_rcp_f32: a few fp32 ulp): sigmoid = 1 / (1 + e^{-x}); tanh = its odd
+// series through x^9 for |x| < 1/4 (next term < 1e-8 of the result), else 1 - 2 / (1 + e^{2|x|}) with the sign put back
+template <int NM, int RT, bool EXPACT = false>
 __device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][RT]) {
+    if constexpr (EXPACT) {
+        // one accumulator quad at a time (sched_barrier: hipcc otherwise starts every element's v_exp early and keeps hundreds of
+        // temporaries alive over the 128 registers — scratch)
+        const bool sig = act == DCTR_ACT_SIGMOID;
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int nt = 0; nt < RT; ++nt) {
+                f32x4 v = acc[m][nt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // sigmoid(x) = 1 / (1 + e^{-x});  tanh(x) = 2 sigmoid(2x) - 1 away from 0, its odd series near 0
+                    const float x = v[r];
+                    const float ax = fabsf(x), x2 = x * x;
+                    const float e = __expf(sig ? -x : 2.f * ax);
+                    const float q = __frcp_rn(1.f + e);
+                    const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+                    const float th = ax < 0.25f ? small : copysignf(fmaf(-2.f, q, 1.f), x);
+                    v[r] = sig ? q : th;
+                }
+                acc[m][nt] = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        return;
+    }
     const float floor_ = act == DCTR_ACT_RELU ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int m = 0; m < NM; ++m)
@@ -292,7 +319,7 @@ struct ChainOff {
 // over the lane groups BEFORE squaring, and dense k-blocks addressed from row n_fields E of W0 (the embedding part need not end on a
 // k-block boundary: the slots past the last field are zeroed and meet finite weight rows).  Every block: its pairs' linear entries, the
 // next block's range check, the ids of the block after next.  Same arithmetic, same k order as the tile kernels' layer 0.
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false, int FPB = 1>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false>
 __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
                                              const int row_end, const int first, const int stride, const int n_pass, int& oor) {
     if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
@@ -1110,7 +1137,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         }
         // (BatchNormalization scale / shift,) activation in place: acc0 is now the B operand of layer 1
         if (p.bn_scale[0] != nullptr) bn_block<4 * M0, RT>(cpar + Off::BN_S, cpar + Off::BN_T, g, acc0);
-        act_block<4 * M0, RT>(p.activation, acc0);
+        act_block<4 * M0, RT, EXPACT>(p.activation, acc0);
         // BF3: an accumulator tile's four registers (features 16g + 4r + mt of a row) become {hi pair, hi pair, lo pair, lo pair} in
         // place — the B operand of ONE bf16 MFMA per output M-tile
         auto pack_bf = [&](auto& acc, auto NMc) {
@@ -1334,7 +1361,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         auto head = [&](auto& acc, auto MGc, int layer, int bn_off) {
             constexpr int MG = decltype(MGc)::value;
             if (p.bn_scale[layer] != nullptr) bn_block<4 * MG, RT>(cpar + Off::BN_S + bn_off, cpar + Off::BN_T + bn_off, g, acc);
-            act_block<4 * MG, RT>(p.activation, acc);
+            act_block<4 * MG, RT, EXPACT>(p.activation, acc);
 #pragma unroll
             for (int nt = 0; nt < RT; ++nt) hs[nt] = 0.f;
 #pragma unroll
@@ -1356,7 +1383,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         };
         if constexpr (M2 > 0) {
             if (p.bn_scale[1] != nullptr) bn_block<4 * M1, RT>(cpar + Off::BN_S + 64 * M0, cpar + Off::BN_T + 64 * M0, g, acc1);
-            act_block<4 * M1, RT>(p.activation, acc1);
+            act_block<4 * M1, RT, EXPACT>(p.activation, acc1);
             f32x4 acc2[4 * (M2 > 0 ? M2 : 1)][RT];
             init_acc(acc2, B2_OFF, std::integral_constant<int, M2>{});
             if constexpr (BF3) {
@@ -1398,7 +1425,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 }
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false>
 __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
@@ -1455,7 +1482,7 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
     __syncthreads();                                   // LDS parameters written
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
-    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
     CWG(1);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
@@ -1463,7 +1490,7 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
             // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
             __syncthreads();
             if (wave < 4)
-                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS, FPB>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
+                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
                                                                     (int)gridDim.x, p.n_tail, oor);
         }
     }
@@ -1481,6 +1508,7 @@ int launch_r2w8_m21(const ChainParams& p, int E, int M2, unsigned blocks, hipStr
 int launch_r2w4_m42(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);
 int launch_r2w8_m42x(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // CROSS (chain_kernels_r2w8_m42_x.hip)
 int launch_r2w8_m42q(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 8 / 4 (chain_kernels_r2w8_m42_q.hip)
+int launch_r2w8_m42t(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // sigmoid / tanh DNNs (chain_kernels_r2w8_m42_t.hip)
 // the exploratory bf16 x 3 variant (chain_kernels_r2w8_m42_bf3.hip): packs the weights into `ws` (if `pack`), then launches
 size_t bf3_workspace_bytes(int in_dim);
 int launch_r2w8_m42_bf3(const ChainParams& p, int E, void* ws, bool pack, unsigned blocks, hipStream_t stream);

@@ -84,7 +84,7 @@ def run_span(name, model, feed, B, reps=8, dnn_flop=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c3,c3_span,c3_dnn_in,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
+    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c2_act,c3,c3_span,c3_dnn_in,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
                                          "dcn_mix,nfm,afm,pnn,c4,c4_span,c4_allpos,c4_lookups,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
@@ -146,6 +146,12 @@ def main():
             m = DeepFM(cols16, cols16, dnn_hidden_units=units, device=dev)
             init_on_device(m)
             run_span("C2 DeepFM DNN %s" % "-".join(map(str, units)), m, criteo(rng, 131072), 4096, dnn_flop=dnn_flop(429, units))
+            del m
+    if "c2_act" in want:     # sigmoid / tanh DNNs (row-chained kernel, EXPACT instantiations) beside ReLU on the same box
+        for act in ("relu", "tanh", "sigmoid"):
+            m = DeepFM(cols16, cols16, dnn_activation=act, device=dev)
+            init_on_device(m)
+            run_span("C2 DeepFM DNN 256-128-64 %s" % act, m, criteo(rng, 131072), 4096, dnn_flop=dnn_flop(429))
             del m
     if "afm" in want:       # a11 AFMLayer: 325 pairs x E = 16, attention_factor 8
         colsa = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)]

@@ -140,8 +140,8 @@ def test_chain_kernel_model_variants(device):
     # int64 ids beyond int32 range are out of range for these vocabularies: ids stay int64 on the device; tanh; regression
     scols = [SparseFeat("C%d" % i, 3000 + i, 32) for i in range(1, 14)]          # 13 fields: the last pair has one field
     sfeed = {"C%d" % i: rng.randint(0, 3000 + i, n).astype(np.int64) for i in range(1, 14)}
-    # (ReLU / linear DNNs take the row-chained kernel; tanh / sigmoid ones the streaming kernel)
-    for act, kern in (("relu", "chain"), ("linear", "chain"), ("tanh", "stream")):
+    # (ReLU / linear DNNs take the row-chained kernel, tanh / sigmoid ones its EXPACT instantiations — round 4)
+    for act, kern in (("relu", "chain"), ("linear", "chain"), ("tanh", "chain")):
         model = DeepFM(scols, scols, dnn_activation=act, task="regression", device=device)
         w = _randomise(model, rng)
         y = model.predict(sfeed, batch_size=512)
@@ -507,3 +507,40 @@ def test_chain_kernel_small_embedding_dims_int64_ids_and_out_of_range(device):
     with pytest.raises(IndexError):
         model.predict(bad, batch_size=2048)
     assert np.isfinite(model.predict(feed, batch_size=2048)).all()
+
+
+@pytest.mark.parametrize("act,units,bn,E", [("sigmoid", (256, 128, 64), False, 16), ("tanh", (256, 128, 64), False, 16),
+                                            ("tanh", (256, 128), False, 32), ("sigmoid", (200, 80), False, 16),
+                                            ("tanh", (100, 100, 100), True, 16), ("sigmoid", (256, 128, 128), True, 32)])
+def test_chain_kernel_sigmoid_tanh_dnn(device, act, units, bn, E):
+    """sigmoid / tanh DNNs (reference layers/activation.py:75-85) on the row-chained kernel's EXPACT instantiations: float64 oracle on
+    a row sample (probabilities and logits), every row against the 32-row kernel (libm tanhf there, the transcendental units here),
+    forced shape / permutation / split invariance bit for bit; zero-padded widths (sigmoid(0) = 1/2 in the padded features meets zero
+    rows of the next kernel) and BatchNormalization."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(61 + E + len(units))
+    n = 65536 + 16384 + 200
+    cols, feed = _criteo_like(rng, n, V=3000, E=E)
+    model = DeepFM(cols, cols, dnn_hidden_units=units, dnn_activation=act, dnn_use_bn=bn, device=device)
+    w = _randomise(model, rng)
+    if bn:
+        for k in w:
+            if k.endswith("moving_variance") or k.endswith("gamma"):
+                w[k] = (0.5 + rng.rand(*w[k].shape)).astype(np.float32)
+        model.set_weights_by_name(w)
+    y = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain"
+    rows = np.unique(np.concatenate([np.arange(0, 200), np.arange(n - 200, n), rng.choice(n, 200, replace=False)]))
+    sub = {k: v[rows] for k, v in feed.items()}
+    kw = dict(dnn_hidden_units=units, dnn_activation=act, dnn_use_bn=bn, dtype=np.float64)
+    check_probs(y[rows], RM.deepfm(cols, cols, w, sub, **kw).astype(np.float32), "chain DeepFM %s %s" % (act, units))
+    from tests.test_gpu_models import check_logits
+    check_logits(model.predict_logits(feed, batch_size=4096)[rows], RM.deepfm(cols, cols, w, sub, task="regression", **kw),
+                 RM.deepfm(cols, cols, {k: np.abs(v) for k, v in w.items()}, sub, task="regression", **kw), "chain DeepFM %s" % act)
+    y32 = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    assert_close(y, y32, rtol=4e-6, atol=4e-7, what="chain (%s) vs 32-row kernel" % act)
+    assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y), "forced 256-row shape"
+    perm = rng.permutation(n)
+    assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=4096), y[perm])
+    cut = 16384 + 4096
+    assert np.array_equal(model.predict({k: v[:cut] for k, v in feed.items()}, batch_size=4096), y[:cut])

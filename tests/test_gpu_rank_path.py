@@ -146,20 +146,18 @@ for ctor, kw in ((DeepFM, {}), (xDeepFM, {"cin_layer_size": (16, 16)})):
     m.set_weights_by_name(w)
     lo, hi = parallel.shard_bounds(n, rank, world)
     assert (hi - lo) in (10007, 10006)
-    if ctor is DeepFM:
-        m.tile_rows = 32                            # one kernel route for shard and whole: bit equality
+    m.tile_rows = 32                                # one kernel route for shard and whole: bit equality
     y = m.predict(feed, batch_size=4096)
     yd = parallel.predict_distributed(m, feed, batch_size=4096)
     same = yd.shape == y.shape and yd.dtype == y.dtype and bool(np.array_equal(y, yd))
     print("rank %%d %%s gloo world 2: equal=%%s" %% (rank, ctor.__name__, same), flush=True)
     ok = ok and same
-    if ctor is DeepFM:
-        m.tile_rows = 0                             # default routes: the whole runs the row-chained kernel, the shards the tile kernel
-        y0 = m.predict(feed, batch_size=4096)
-        yd0 = parallel.predict_distributed(m, feed, batch_size=4096)
-        close = bool(np.allclose(y0, yd0, rtol=1e-5, atol=1e-6))
-        print("rank %%d DeepFM default routes: close=%%s" %% (rank, close), flush=True)
-        ok = ok and close
+    m.tile_rows = 0                                 # default routes: the whole runs the row-chained kernel, the shards the tile kernel
+    y0 = m.predict(feed, batch_size=4096)           # (xDeepFM since round 4 as well: its DNN + linear part is the one-launch forward)
+    yd0 = parallel.predict_distributed(m, feed, batch_size=4096)
+    close = bool(np.allclose(y0, yd0, rtol=1e-5, atol=1e-6))
+    print("rank %%d %%s default routes: close=%%s" %% (rank, ctor.__name__, close), flush=True)
+    ok = ok and close
     m.compile("adam", "binary_crossentropy")
     ev = parallel.evaluate_distributed(m, feed, labels, batch_size=4096)
     want = m.evaluate(feed, labels, batch_size=4096)
