@@ -99,6 +99,30 @@ def test_argument_errors_are_reported_without_a_gpu():
     ba.activation = 4                                                  # Dice keeps the layer-by-layer form: three buffers + statistics + slices
     assert lib.dctr_mlp_bwd_workspace_bytes(ctypes.byref(ba)) == ((3 * 4096 * 429 + 2 * 429 + 3) // 4 * 4 + 8 * 429 * 256) * 4
     assert lib.dctr_mlp_bwd_workspace_bytes(None) == 0
+    # round 4 (ABI 8): the attention workspace = raw scores + the list of the positions that count (chunks of 4096 rows, doubled until
+    # there are <= 1024 of them) + 1024 chunk counts + the workgroups' 160-KiB LDS image; CIN over a gather
+    da = _C.DinAttnArgs(batch=2048, maxlen=50, dim=64)
+    assert lib.dctr_din_attn_workspace_bytes(ctypes.byref(da)) == 2048 * 50 * 4 + (25 * 4096 + 1024) * 4 + 160 * 1024
+    da.batch = 100000                                                   # 5,000,000 rows: 8192-row chunks (611 of them)
+    assert lib.dctr_din_attn_workspace_bytes(ctypes.byref(da)) == 5000000 * 4 + (611 * 8192 + 1024) * 4 + 160 * 1024
+    da.batch = 0
+    assert lib.dctr_din_attn_workspace_bytes(ctypes.byref(da)) == 0
+    assert lib.dctr_cin_gather_fwd(None, None, None, None, None) == -1
+    ls = (ctypes.c_int32 * 1)(32)
+    ptrs = (ctypes.c_void_p * 1)(4096)
+    cin = _C.CinArgs(x=None, batch=64, x_stride=0, fields=5, dim=16, n_layers=1, split_half=1, activation=1,
+                     layer_size=ctypes.cast(ls, ctypes.c_void_p), filters=ctypes.cast(ptrs, ctypes.c_void_p), bias=ctypes.cast(ptrs, ctypes.c_void_p),
+                     out=fake)
+    ga = _C.GatherFmArgs(fields=fake, ids=fake, ids_stride_f=64, ids_stride_b=1, n_fields=5, max_dim=16, all_dim4=1, batch=64, uniform_dim=16)
+    assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), fake, None, None) == -1 and b"come together" in lib.dctr_last_error()
+    ga.n_fields = 4
+    assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), None, None, None) == -2       # a gather of other fields
+    ga.n_fields, ga.any_hash = 5, 1
+    assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), None, None, None) == _C.E_UNSUPPORTED
+    ga.any_hash, ga.uniform_dim = 0, 8
+    assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), None, None, None) == _C.E_UNSUPPORTED
+    ga.uniform_dim, cin.batch, ga.batch = 16, 0, 0
+    assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), None, None, None) == 0       # nothing to do
 
 
 def test_host_pack_columns_converts_like_numpy():
