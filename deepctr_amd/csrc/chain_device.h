@@ -218,7 +218,7 @@ __device__ __forceinline__ void act_block(int act, f32x4 (&acc)[NM][RT]) {
                     const float x = v[r];
                     const float ax = fabsf(x), x2 = x * x;
                     const float e = __expf(sig ? -x : 2.f * ax);
-                    const float q = __frcp_rn(1.f + e);
+                    const float q = __builtin_amdgcn_rcpf(1.f + e);
                     const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
                     const float th = ax < 0.25f ? small : copysignf(fmaf(-2.f, q, 1.f), x);
                     v[r] = sig ? q : th;

@@ -111,14 +111,42 @@ struct Lay {
     static constexpr int S1 = N1P + 4;
     // the small arrays first: their reads carry compile-time offsets from the LDS base, and a ds_read offset field holds 64 KiB
     // (behind 63 KB of layer-0 weights every such offset became a per-lane address register, hoisted out of the unit loop: spills)
-    static constexpr int PB0 = 0;                          // bias, alpha, inv, shift of layer 0: [N0P] each
-    static constexpr int PB1 = PB0 + 4 * N0P;              // ... of layer 1: [N1P] each
-    static constexpr int OK = PB1 + 4 * N1P;               // out_kernel [N1P], out_bias
+    static constexpr int PB0 = 0;                          // layer 0: bias [N0P], then the Dice constants of a feature as ONE 16-B
+                                                           // group {alpha, 1 - alpha, -inv log2e, -shift log2e} [N0P][4]
+    static constexpr int PB1 = PB0 + 5 * N0P;              // ... of layer 1: [N1P] + [N1P][4]
+    static constexpr int OK = PB1 + 5 * N1P;               // out_kernel [N1P], out_bias
     static constexpr int W1 = OK + N1P + 4;
     static constexpr int W0B = W1 + N0P * S1;
     static constexpr int W0A = ((W0B + K0 * S0B + 63) / 64) * 64;     // (256-B aligned rows for the b128 reads)
     static constexpr int END = W0A + K0 * S0A;
 };
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Dice, inference form (layers/activation.py:59-64: x_p = sigmoid((x - mean) / sqrt(var + eps)), y = alpha (1 - x_p) x + x_p x) from
+// the feature's 16-B constant group c = {alpha, 1 - alpha, -inv log2e, -shift log2e}:  x_p = 1 / (1 + 2^(x c.z + c.w)),
+// y = x (alpha + x_p (1 - alpha)) — six instructions, two of them on the transcendental units.  (Round 4: as a per-element
+// `dice ? .. : switch (activation)` the epilogues were ~20 VALU instructions and a handful of branches per element — 1,750 VALU
+// instructions per 32-row unit beside its 600 MFMAs, and fp32 MFMAs share the vector lanes: 63 % matrix-pipe utilisation.)
+__device__ __forceinline__ float dice_c(float x, const f32x4& c) {
+    const float xp = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(x, c[2], c[3])));
+    return x * fmaf(xp, c[1], c[0]);
+}
+
+// the other activations of an accumulator register pair, `act` uniform: one branch per call site, none per element
+template <int RTN>
+__device__ __forceinline__ void act_plain(int act, float (&x)[RTN]) {
+    if (act == DCTR_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < RTN; ++i) x[i] = fmaxf(x[i], 0.f);
+    } else if (act == DCTR_ACT_SIGMOID) {
+#pragma unroll
+        for (int i = 0; i < RTN; ++i) x[i] = dctr::sigmoidf_(x[i]);
+    } else if (act == DCTR_ACT_TANH) {
+#pragma unroll
+        for (int i = 0; i < RTN; ++i) x[i] = dctr::tanh_fast(x[i]);
+    }
+}
 
 __device__ __forceinline__ int64_t load_any_id(const void* base, int64_t idx, int i64) {
     return i64 ? reinterpret_cast<const int64_t*>(base)[idx] : (int64_t)reinterpret_cast<const int32_t*>(base)[idx];
@@ -214,9 +242,10 @@ __device__ __forceinline__ void fill_image(const Params& p, float* dst, int tid,
             sh = -p.dice_mean[0][n] * inv;
         }
         dst[L::PB0 + n] = (in && p.bias[0] != nullptr) ? p.bias[0][n] : 0.f;
-        dst[L::PB0 + N0P + n] = al;
-        dst[L::PB0 + 2 * N0P + n] = inv;
-        dst[L::PB0 + 3 * N0P + n] = sh;
+        dst[L::PB0 + N0P + 4 * n] = al;
+        dst[L::PB0 + N0P + 4 * n + 1] = 1.f - al;
+        dst[L::PB0 + N0P + 4 * n + 2] = -inv * LOG2E;
+        dst[L::PB0 + N0P + 4 * n + 3] = -sh * LOG2E;
     }
     for (int n = tid; n < L::N1P; n += nthr) {
         const bool in = n < p.n1;
@@ -227,9 +256,10 @@ __device__ __forceinline__ void fill_image(const Params& p, float* dst, int tid,
             sh = -p.dice_mean[1][n] * inv;
         }
         dst[L::PB1 + n] = (in && p.bias[1] != nullptr) ? p.bias[1][n] : 0.f;
-        dst[L::PB1 + L::N1P + n] = al;
-        dst[L::PB1 + 2 * L::N1P + n] = inv;
-        dst[L::PB1 + 3 * L::N1P + n] = sh;
+        dst[L::PB1 + L::N1P + 4 * n] = al;
+        dst[L::PB1 + L::N1P + 4 * n + 1] = 1.f - al;
+        dst[L::PB1 + L::N1P + 4 * n + 2] = -inv * LOG2E;
+        dst[L::PB1 + L::N1P + 4 * n + 3] = -sh * LOG2E;
         dst[L::OK + n] = in ? p.out_kernel[n] : 0.f;
     }
     if (tid == 0) dst[L::OK + L::N1P] = p.out_bias[0];
@@ -451,19 +481,34 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
             pB += 16 * L::S0B;
         }
         // ---- activation of layer 0 in place (padded features: weights and bias 0 -> the activation of 0, taken out again by
-        // the zero rows of W1)
+        // the zero rows of W1).  ONE uniform branch for the whole accumulator set
+        // (the constants' lane bases come from an OPAQUE copy of g: with the known-zero low bits of g << k hipcc turns base + constant
+        //  into base | constant, materialises one address register per constant, hoists all of them out of the unit loop and spills)
+        int go = g;
+        asm volatile("" : "+v"(go));
+        const float* const cA = smem + L::PB0 + N0P + 64 * go;                  // b128 tiles: feature 16 g + (4 r + tt)
+        const float* const cB = smem + L::PB0 + N0P + 256 * NB0 + 16 * go;      // b32 tiles: feature 64 NB0 + 16 s + 4 g + r
+        if (dice) {
 #pragma unroll
-        for (int tt = 0; tt < NT0; ++tt)
+            for (int tt = 0; tt < NT0; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = tt < 4 * NB0 ? 16 * g + 4 * r + tt : 64 * NB0 + 16 * (tt - 4 * NB0) + 4 * g + r;
-                const float al = smem[L::PB0 + N0P + f], inv = smem[L::PB0 + 2 * N0P + f], sh = smem[L::PB0 + 3 * N0P + f];
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(tt < 4 * NB0 ? cA + 4 * (4 * r + tt) : cB + 64 * (tt - 4 * NB0) + 4 * r);
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) acc0[tt][nt][r] = dice_c(acc0[tt][nt][r], c);
+                    if (r == 3) DC_SB;                     // (a tile at a time: hipcc otherwise keeps every tile's constants in flight)
+                }
+        } else if (p.activation != DCTR_ACT_LINEAR) {
+#pragma unroll
+            for (int tt = 0; tt < NT0; ++tt)
 #pragma unroll
                 for (int nt = 0; nt < RT; ++nt) {
-                    const float x = acc0[tt][nt][r];
-                    acc0[tt][nt][r] = dice ? dctr::dice_pre(x, al, inv, sh) : dctr::apply_act(x, p.activation);
+                    float x[4] = {acc0[tt][nt][0], acc0[tt][nt][1], acc0[tt][nt][2], acc0[tt][nt][3]};
+                    act_plain<4>(p.activation, x);
+                    acc0[tt][nt] = f32x4{x[0], x[1], x[2], x[3]};
+                    DC_SB;
                 }
-            }
+        }
         // ---- layer 1: k-steps (tile tt, r) of layer 0's accumulators; A = W1 rows of the features those registers hold
         f32x4 acc1[NS1][RT];
 #pragma unroll
@@ -499,20 +544,40 @@ __global__ __launch_bounds__(64 * NW) void din_chain_kernel(Params p) {
         float part[RT];
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) part[nt] = 0.f;
+        int go1 = g;
+        asm volatile("" : "+v"(go1));
+        const float* const c1 = smem + L::PB1 + L::N1P + 16 * go1;             // feature 16 s1 + 4 g + r
+        const float* const ok1 = smem + L::OK + 4 * go1;
+        if (dice) {
 #pragma unroll
-        for (int s1 = 0; s1 < NS1; ++s1)
+            for (int s1 = 0; s1 < NS1; ++s1)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * s1 + 4 * g + r;
-                const float al = smem[L::PB1 + L::N1P + f], inv = smem[L::PB1 + 2 * L::N1P + f], sh = smem[L::PB1 + 3 * L::N1P + f];
-                const float ok = smem[L::OK + f];
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(c1 + 64 * s1 + 4 * r);
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) acc1[s1][nt][r] = dice_c(acc1[s1][nt][r], c);
+                    if (r == 3) DC_SB;
+                }
+        } else if (p.activation != DCTR_ACT_LINEAR) {
+#pragma unroll
+            for (int s1 = 0; s1 < NS1; ++s1)
 #pragma unroll
                 for (int nt = 0; nt < RT; ++nt) {
-                    const float x = acc1[s1][nt][r];
-                    const float h = dice ? dctr::dice_pre(x, al, inv, sh) : dctr::apply_act(x, p.activation);
-                    part[nt] = fmaf(f < p.n1 ? h : 0.f, ok, part[nt]);
+                    float x[4] = {acc1[s1][nt][0], acc1[s1][nt][1], acc1[s1][nt][2], acc1[s1][nt][3]};
+                    act_plain<4>(p.activation, x);
+                    acc1[s1][nt] = f32x4{x[0], x[1], x[2], x[3]};
+                    DC_SB;
                 }
-            }
+        }
+        // (padded features f >= n1: out_kernel is 0 there and the activation of 0 is finite)
+#pragma unroll
+        for (int s1 = 0; s1 < NS1; ++s1) {
+            const f32x4 okv = *reinterpret_cast<const f32x4*>(ok1 + 16 * s1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < RT; ++nt) part[nt] = fmaf(acc1[s1][nt][r], okv[r], part[nt]);
+        }
         const float ob = smem[L::OK + L::N1P];
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {

@@ -90,9 +90,20 @@ __device__ __forceinline__ void tile_gemm_nk(const float* A, int lda, int K, int
     }
 }
 
-// sigmoid on the hardware transcendental units: v_exp_f32 (via __expf) and v_rcp_f32, ~2 ulp; the IEEE expf +
-// division pair costs ~40 VALU instructions = 160 cycles per wave64 element, which dominated the Dice epilogues.
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// sigmoid on the hardware transcendental units: v_exp_f32 (via __expf) and the RAW v_rcp_f32 (__builtin_amdgcn_rcpf, 1 ulp), ~2 ulp
+// together; the IEEE expf + division pair costs ~40 VALU instructions = 160 cycles per wave64 element, which dominated the Dice
+// epilogues.  (Until round 4 this read __frcp_rn, which hipcc expands to the correctly rounded division — v_div_scale, v_rcp, three
+// Newton steps, v_div_fmas, v_div_fixup: ten instructions where one was meant.)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+// tanh on the same units: |x| < 1/4 by its odd series through x^9 (next term < 1e-8 of the result), else 1 - 2 / (1 + e^{2|x|}) with
+// the sign put back — a few fp32 ulp of the result, a dozen instructions where libm's tanhf is ~40 with branches
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float big = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * ax)), 1.f);
+    return ax < 0.25f ? small : copysignf(big, x);
+}
 
 // activation codes = DCTR_ACT_* (include/dctr.h)
 __device__ __forceinline__ float apply_act(float v, int act) {

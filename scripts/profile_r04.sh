@@ -11,7 +11,7 @@ B20="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondar
 B256="python $ROOT/bench.py --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench20 -o bench20 -- $B20 > $OUT/bench20_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench256 -o bench256 -- $B256 > $OUT/bench256_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/configs -o configs -- python $ROOT/scripts/bench_configs.py --configs c3,c3_span,dcn_v,dcn_v_span,dcn_m,c4,c4_span --steps 16 > $OUT/configs_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/configs -o configs -- python $ROOT/scripts/bench_configs.py --configs c1,c3,c3_span,dcn_v,dcn_v_span,dcn_m,c4,c4_span --steps 16 > $OUT/configs_under_rocprof.log 2>&1
 PM="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --prewarm-ms 10 --regions 3"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
@@ -21,7 +21,7 @@ python $ROOT/scripts/pmc_summary.py $OUT/pmc_bench_summary.json $OUT/pmc_* > $OU
 # PMC on the DCN one-launch span and the DIN folded-lookup call (FETCH / WRITE / MFMA busy)
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/cfgpmc_$tag -o p -- python $ROOT/scripts/bench_configs.py --configs dcn_v_span,c4_span --steps 8 > $OUT/cfgpmc_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/cfgpmc_$tag -o p -- python $ROOT/scripts/bench_configs.py --configs dcn_v,dcn_v_span,c4,c4_span --steps 8 > $OUT/cfgpmc_$tag.log 2>&1
 done
 python $ROOT/scripts/pmc_summary.py $OUT/pmc_configs_summary.json $OUT/cfgpmc_* > $OUT/pmc_configs_summary.txt 2>&1
 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
