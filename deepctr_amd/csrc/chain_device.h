@@ -447,10 +447,16 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     auto brow_of = [&](int pass, int nt) -> int { return min(row_of(pass, nt), row_end - 1); };
     // request the ids of field pair pr for the rows of `pass`
     auto request_pair_ids = [&](int pr, int pass, uint32_t& lo, uint32_t& hi) {
+        // element (field fi = min(2 pr + q, n_fields - 1), row r) of the id matrix: the pair's first field and the step to its second
+        // one are SCALAR 64-bit products (pr is uniform), the lane adds its half's step and its row — rows are contiguous
+        // (ids_stride_b == 1: chain_kernels.hip, eligible), so no per-lane 64-bit multiply (they were 6 quarter-rate instructions
+        // per pair, and fp32 MFMAs share the vector lanes)
         const int ln = opaque_lane(), q = ln >> 5;
-        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const int f0 = min(2 * pr, p.n_fields - 1);
+        const int64_t sbase = (int64_t)f0 * p.ids_stride_f;
+        const int64_t qstep = 2 * pr + 1 <= p.n_fields - 1 ? p.ids_stride_f : (int64_t)0;
         const int r = min(row_base + pass * PROWS + WROWS * wave + min(ln & 31, WROWS - 1), row_end - 1);
-        const int64_t eo = (int64_t)fi * p.ids_stride_f + (int64_t)r * p.ids_stride_b;
+        const int64_t eo = sbase + (q ? qstep : (int64_t)0) + (int64_t)r;
         if constexpr (I64) {
             const u32x2 v = *(gbl_u2_t)(reinterpret_cast<const u32x2*>(p.ids) + eo);
             lo = v[0];
@@ -461,18 +467,14 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     };
     // landed ids -> rows: range check against the field's vocabulary, out-of-range ids read row 0 and raise the flag
     auto fold_pair_ids = [&](int pr, int pass, uint32_t lo, uint32_t hi) -> uint32_t {
+        // the lane's field of the pair: its vocabulary and identity flag come from the descriptors in LDS PER LANE (two reads; as
+        // scalars of both fields + per-lane selects they were ~10 more vector instructions per pair)
         const int ln = opaque_lane(), q = ln >> 5;
-        const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
-        const uint2 va = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 4);
-        const uint2 vb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 4);
-        const uint64_t voc_a = sgpr64(va.x, va.y), voc_b = sgpr64(vb.x, vb.y);
-        const uint32_t lim_a = (voc_a >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_a;
-        const uint32_t lim_b = (voc_b >> 32) != 0 ? 0xffffffffu : (uint32_t)voc_b;
-        const uint32_t lim = q ? lim_b : lim_a;
+        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const uint2 vv = *reinterpret_cast<const uint2*>(fdesc + 12 * fi + 4);
+        const uint32_t lim = vv.y != 0u ? 0xffffffffu : vv.x;
         // identity fields (pre-pooled by dctr_embed_pool: dctr_field_t.identity): the row is the sample's index in the launch
-        const uint32_t id_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(fdesc)[12 * fa + 10]);
-        const uint32_t id_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(fdesc)[12 * fb + 10]);
-        const bool ident = (q ? id_b : id_a) != 0u;
+        const bool ident = reinterpret_cast<const uint32_t*>(fdesc)[12 * fi + 10] != 0u;
         const int rr = row_base + pass * PROWS + WROWS * wave + (ln & 31);
         const uint32_t upper = I64 ? hi : (uint32_t)((int32_t)lo >> 31);      // anything but 0: negative or >= 2^32
         const bool ok = ident || (upper == 0u && lo < lim);
@@ -483,11 +485,9 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     // linear-table entries of the pair (row per lane); fields without a linear table, or past the last field, give 0
     auto pair_lin_ptr = [&](int pr, uint32_t idc, bool& has) -> gbl_f_t {
         const int q = opaque_lane() >> 5;
-        const int fa = min(2 * pr, p.n_fields - 1), fb = min(2 * pr + 1, p.n_fields - 1);
-        const uint2 la = *reinterpret_cast<const uint2*>(fdesc + 12 * fa + 2);
-        const uint2 lb = *reinterpret_cast<const uint2*>(fdesc + 12 * fb + 2);
-        const uint64_t lin_a = sgpr64(la.x, la.y), lin_b = sgpr64(lb.x, lb.y);
-        const uint64_t base = q ? lin_b : lin_a;
+        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const uint2 l = *reinterpret_cast<const uint2*>(fdesc + 12 * fi + 2);          // (per lane: its field's linear table)
+        const uint64_t base = ((uint64_t)l.y << 32) | l.x;
         has = base != 0 && 2 * pr + q < p.n_fields;
         const float* t = has ? reinterpret_cast<const float*>(base) : reinterpret_cast<const float*>(p.fields);
         return (gbl_f_t)(t + (has ? idc : 0u));
@@ -612,6 +612,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     uint32_t idr_lo = 0u, idr_hi = 0u;                 // raw ids of a field pair between their request and the range check
     uint32_t idc = 0u;                                 // checked ids (= table rows) of the current field pair
     float lvn = 0.f;                                   // linear-table entries of the current pair, in flight / landed
+    bool lvn_has = false, lvnB_has = false;            // ... and whether the lane's field has a linear table at all (kept from the
+                                                       // request: asking the descriptors again a step later was ~15 instructions)
     // FPB > 1: a block's SECOND pair (E = 4) has its own raw / checked ids and linear entries; idc / idr_* / lvn serve the first
     uint32_t idrB_lo = 0u, idrB_hi = 0u, idcB = 0u;
     float lvnB = 0.f;
@@ -771,17 +773,14 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                    a conditionally written register keeps its old value alive — through layers 1.. where 192 of the   \
                    256 registers hold accumulators */                                                             \
                 const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                 \
-                if (s_ == 1) {                                                                                   \
-                    bool has_;                                                                                   \
-                    (void)pair_lin_ptr(pr_, 0u, has_);                                                           \
-                    linacc += (has_ && b_ - 1 < NBE) ? lvn : 0.f;                                                \
-                }                                                                                                \
+                if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                                    \
                 if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);                            \
                 if (s_ + 1 < PAIR) issue_x(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN);                        \
                 else issue_x(min(b_ + 1, NBE - 1), idcn, 0, XN);                                                 \
                 if (s_ == 0) {                                                                                   \
                     bool has_;                                                                                   \
                     lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
+                    lvn_has = has_;                                                                              \
                 }                                                                                                \
                 if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
                 if (b_ < NBE) consume_x(b_, XC);                                                                 \
@@ -803,11 +802,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             if (i_ == 0) {                                                                                       \
                 CTS_STEP(b_, 3);                                                                                 \
                 if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                   \
-                if (CHAIN_GATHER && s_ == 1) {                                                                   \
-                    bool has_;                                                                                   \
-                    (void)pair_lin_ptr(pr_, 0u, has_);                                                           \
-                    linacc += (has_ && b_ - 1 < NBE) ? lvn : 0.f;                                                \
-                }                                                                                                \
+                if (CHAIN_GATHER && s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                    \
                 if (CHAIN_GATHER && s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);            \
                 CTS_STEP(b_, 2);                                                                                 \
             }                                                                                                    \
@@ -823,6 +818,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 if (s_ == 0) {                                                                                   \
                     bool has_;                                                                                   \
                     lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
+                    lvn_has = has_;                                                                              \
                 }                                                                                                \
                 if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
             }                                                                                                    \
@@ -953,13 +949,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 if (CHAIN_GATHER) {                                                                              \
                     idcn = fold_pair_ids(PPB * (b_ + 1), pass, idr_lo, idr_hi);                                  \
                     if constexpr (PPB > 1) idcnB = fold_pair_ids(PPB * (b_ + 1) + 1, pass, idrB_lo, idrB_hi);    \
-                    bool has_;                                                                                   \
-                    (void)pair_lin_ptr(PPB * max(b_ - 1, 0), 0u, has_);                                          \
-                    linacc += (has_ && b_ >= 1 && b_ - 1 < NBE) ? lvn : 0.f;                                     \
-                    if constexpr (PPB > 1) {                                                                     \
-                        (void)pair_lin_ptr(PPB * max(b_ - 1, 0) + 1, 0u, has_);                                  \
-                        linacc += (has_ && b_ >= 1 && b_ - 1 < NBE) ? lvnB : 0.f;                                \
-                    }                                                                                            \
+                    linacc += (lvn_has && b_ >= 1 && b_ - 1 < NBE) ? lvn : 0.f;                                  \
+                    if constexpr (PPB > 1) linacc += (lvnB_has && b_ >= 1 && b_ - 1 < NBE) ? lvnB : 0.f;         \
                 }                                                                                                \
             }                                                                                                    \
             if (CHAIN_GATHER && i_ == 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, 0>{});         \
@@ -967,7 +958,11 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             if (CHAIN_GATHER && i_ == 3) {                                                                       \
                 bool has_;                                                                                       \
                 lvn = *pair_lin_ptr(PPB * b_, idc, has_);                                                        \
-                if constexpr (PPB > 1) lvnB = *pair_lin_ptr(PPB * b_ + 1, idcB, has_);                           \
+                lvn_has = has_;                                                                                  \
+                if constexpr (PPB > 1) {                                                                         \
+                    lvnB = *pair_lin_ptr(PPB * b_ + 1, idcB, has_);                                              \
+                    lvnB_has = has_;                                                                             \
+                }                                                                                                \
                 request_pair_ids(PPB * (b_ + 2), pass, idr_lo, idr_hi);                                          \
                 if constexpr (PPB > 1) request_pair_ids(PPB * (b_ + 2) + 1, pass, idrB_lo, idrB_hi);             \
             }                                                                                                    \
@@ -1036,15 +1031,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             }
             // the last block's linear entries (added a block later, which never came)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lvn), "+v"(lvnB) : : "memory");
-            {
-                bool has_;
-                (void)pair_lin_ptr(PPB * (NB - 1), 0u, has_);
-                linacc += (has_ && NB - 1 < NBE) ? lvn : 0.f;
-                if constexpr (PPB > 1) {
-                    (void)pair_lin_ptr(PPB * (NB - 1) + 1, 0u, has_);
-                    linacc += (has_ && NB - 1 < NBE) ? lvnB : 0.f;
-                }
-            }
+            linacc += (lvn_has && NB - 1 < NBE) ? lvn : 0.f;
+            if constexpr (PPB > 1) linacc += (lvnB_has && NB - 1 < NBE) ? lvnB : 0.f;
         } else {
         for (int pr_ = 0; pr_ * PAIR < NB; ++pr_) {
             if constexpr (BF3) {
@@ -1075,9 +1063,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             // the last step was step 0 of a field pair (odd field count, no dense k-block behind it): the pair's linear
             // entries, added up in a pair's step 1, are still on their way
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lvn) : : "memory");
-            bool has_;
-            (void)pair_lin_ptr((NB - 1) / PAIR, 0u, has_);
-            linacc += has_ ? lvn : 0.f;
+            linacc += lvn_has ? lvn : 0.f;
         }
         mfma_drain();
         CTS(1);

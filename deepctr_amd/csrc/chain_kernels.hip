@@ -23,6 +23,7 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     const int E = g->uniform_dim;
     if (E != 16 && E != 32 && E != 8 && E != 4) return 0;
     if (g->any_hash || !a->has_head || a->save_acts != nullptr) return 0;
+    if (g->ids_stride_b != 1) return 0;                     // (rows of the id matrix contiguous: chain_device.h, request_pair_ids)
     const bool expact = a->activation == DCTR_ACT_SIGMOID || a->activation == DCTR_ACT_TANH;
     if (a->activation != DCTR_ACT_RELU && a->activation != DCTR_ACT_LINEAR && !expact) return 0;
     int M[3];

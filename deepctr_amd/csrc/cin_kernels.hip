@@ -52,6 +52,7 @@ struct CinParams {
 };
 
 typedef unsigned int cin_u32x2 __attribute__((ext_vector_type(2)));
+typedef float cin_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int TPW>
 __device__ __forceinline__ void cin_buf_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float (&b)[TPW]) {
@@ -222,7 +223,12 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
 #pragma unroll
                 for (int tt = 0; tt < SS; ++tt)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) a[tt][rt] = rxi[rt] * rxk[tt][rt];
+                    for (int rt = 0; rt < RT; rt += 2) {
+                        // two row tiles per v_pk_mul_f32: fp32 MFMAs share the vector lanes, every VALU instruction is matrix time
+                        const cin_f32x2 pr = cin_f32x2{rxi[rt], rxi[rt + 1]} * cin_f32x2{rxk[tt][rt], rxk[tt][rt + 1]};
+                        a[tt][rt] = pr[0];
+                        a[tt][rt + 1] = pr[1];
+                    }
             };
 #pragma unroll
             for (int u = 0; u < NB - 1; ++u) load_b(bq[u]);
