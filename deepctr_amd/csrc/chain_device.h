@@ -685,6 +685,11 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         }
         f32x4 sum[EB][RT];
         float sq[RT];
+        // FPB == 1: the sum of squares as TWO partial sums per N tile (elements 0, 2 / 1, 3 of every 16-B piece): its fmas then pair up
+        // on registers that already lie side by side (v_pk_fma_f32 on X.x[nt][0..1], [2..3]); as one chain per tile hipcc packed
+        // ACROSS the tiles and paid eight register moves per k-block to line the operands up (same-box A/B: + 0.4 %)
+        typedef float sq2_t __attribute__((ext_vector_type(2)));
+        sq2_t sq2[RT];
         // CROSS: this lane's share of the row's dot products with the cross vectors (reduced over g after layer 0)
         float cp[CROSS ? CROSS_NV : 1][RT];
 #pragma unroll
@@ -709,6 +714,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
             sq[nt] = 0.f;
+            sq2[nt] = sq2_t{0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < EB; ++h) sum[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -756,8 +762,11 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #pragma unroll
                     for (int hh = 0; hh < EB; ++hh)
                         if (hh == h) sum[hh][nt] += X.x[nt];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sq[nt] = fmaf(X.x[nt][e], X.x[nt][e], sq[nt]);
+                    {
+                        const sq2_t lo = sq2_t{X.x[nt][0], X.x[nt][1]}, hi = sq2_t{X.x[nt][2], X.x[nt][3]};
+                        sq2[nt] = __builtin_elementwise_fma(lo, lo, sq2[nt]);
+                        sq2[nt] = __builtin_elementwise_fma(hi, hi, sq2[nt]);
+                    }
                 }
             }
         };
@@ -1074,7 +1083,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             const float lin_rows = linacc + __shfl_xor(linacc, 32, 64);
 #pragma unroll
             for (int nt = 0; nt < RT; ++nt) {
-                float fm = -sq[nt];
+                float fm = FPB > 1 ? -sq[nt] : -(sq2[nt][0] + sq2[nt][1]);
                 if constexpr (FPB > 1) {
                     // the lane groups of one 16-B piece hold different FIELDS' shares of the same dimensions: sum them first, square,
                     // and count each square once (FPB lane groups hold the same sum)
