@@ -510,17 +510,28 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         }
     };
     // the same for ONE N tile (the spread request phase issues the tiles in different micro-steps)
+    // lane constants of the spread row requests, PERSISTENT (the block-form issue_x above rebuilds them from an opaque lane copy: round 2's
+    // register budget; with ~25 registers to spare since then, keeping the two costs six registers and saves four vector instructions
+    // per request — + 0.5 % in a same-box A/B, scripts/ab_libs.sh; the same treatment of the id / linear-entry requests measured - 1.7 %)
+    const uint32_t bp4_ = ((uint32_t)lane & 15u) << 2;
+    const uint64_t gg16_ = (uint64_t)(((uint32_t)lane >> 4) << 4);
+    constexpr bool KEEP_LC = !CROSS && !BF3;          // (the folded-CrossNet and bf16x3 instantiations sit at 252 - 256 registers: they rebuild)
     auto issue_x1 = [&](int cb, uint32_t idc, int half, XBlk& X, auto NTc) {
         constexpr int nt = decltype(NTc)::value;
         const int f = cb / EB, h = cb % EB;
         const uint2 tw = *reinterpret_cast<const uint2*>(fdesc + 12 * f);
         const char* table = reinterpret_cast<const char*>(sgpr64(tw.x, tw.y));
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const uint32_t gg = (uint32_t)ln >> 4, jj = (uint32_t)ln & 15u;
-        const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jj + (uint32_t)(32 * half + 16 * nt)) << 2), (int)idc);
-        const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);
-        X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
+        if constexpr (KEEP_LC) {
+            const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bp4_ + (uint32_t)((32 * half + 16 * nt) << 2)), (int)idc);
+            X.x[nt] = *(gbl_f4_t)(table + (((uint64_t)idv << (E == 16 ? 6 : 7)) + (uint64_t)(64 * h) + gg16_));
+        } else {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const uint32_t gg = (uint32_t)ln >> 4, jj = (uint32_t)ln & 15u;
+            const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jj + (uint32_t)(32 * half + 16 * nt)) << 2), (int)idc);
+            const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);
+            X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
+        }
     };
     // FPB > 1: the rows of embedding k-block cb, one N tile: lane group g = field slot fb (and 16-B piece pc for E = 8); the slot's ids
     // are half fb & 1 of pair fb >> 1's register (idA: the block's first pair, idB: its second, E = 4)

@@ -12,7 +12,7 @@ cp $ROOT/deepctr_amd/lib/libdctr_hip.so $OUT/_current.so
 for r in $(seq 1 $REPS); do
   for kv in $LIBS; do
     name=${kv%%=*}; path=${kv#*=}
-    cp $ROOT/$path $ROOT/deepctr_amd/lib/libdctr_hip.so
+    if [ "$path" = "deepctr_amd/lib/libdctr_hip.so" ]; then cp $OUT/_current.so $ROOT/deepctr_amd/lib/libdctr_hip.so; else cp $ROOT/$path $ROOT/deepctr_amd/lib/libdctr_hip.so; fi
     for K in 20 256; do
       W=$([ $K = 20 ] && echo 5 || echo 32)
       python $ROOT/bench.py --steps $K --warmup $W --no-cpu-baseline --no-secondary > $OUT/${name}_k${K}_r${r}.json 2> $OUT/${name}_k${K}_r${r}.err
