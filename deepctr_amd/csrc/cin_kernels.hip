@@ -161,7 +161,13 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
 #pragma unroll
                 for (int tt = 0; tt < SS; ++tt)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) a[tt][rt] = ri[tt][rt] * rj[tt][rt];
+                    for (int rt = 0; rt < RT; rt += 2) {
+                        // (explicit pairs: each comes out of ONE ds_read2_b32; left to itself hipcc pairs across the reads and pays a
+                        //  register move per product)
+                        const cin_f32x2 pr = cin_f32x2{ri[tt][rt], ri[tt][rt + 1]} * cin_f32x2{rj[tt][rt], rj[tt][rt + 1]};
+                        a[tt][rt] = pr[0];
+                        a[tt][rt + 1] = pr[1];
+                    }
             };
 #pragma unroll
             for (int u = 0; u < NB - 1; ++u) load_b(bq[u]);
