@@ -289,6 +289,140 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
     }
 }
 
+// Four row tiles (64 rows) per workgroup, x_{l+1} IN PLACE (round 4b; launches of >= 64 rows per CU).  A weight fragment feeds four
+// MFMAs: the stream from L2 per row halves again (RT = 2 asks ~32 B/clk of a CU at the full matrix rate where ~20 arrive).  Two 64-row
+// tiles do not fit the 160 KiB, so a layer's results wait in REGISTERS — a wave owns column tiles wave, wave + 8, ... (<= MAXT of
+// them: d <= 128 MAXT) — until every wave has finished reading x_l (one barrier), and are then written over it.  x_0 comes from the
+// input (L2) in the epilogue, as with RT = 2.  Same arithmetic per element as the other forms: the same fmaf chain over k, then
+// x_0 (u + b) + x_l.
+template <int MAXT>
+__global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_inplace_kernel(const float* __restrict__ x, int64_t batch, int d,
+                                                                                int64_t x_stride, const float* __restrict__ w,
+                                                                                int wstride, const float* __restrict__ bias,
+                                                                                int layers, float* __restrict__ y, int64_t y_stride,
+                                                                                int lda, const float* __restrict__ head_w,
+                                                                                float* __restrict__ logit, float* __restrict__ save_u,
+                                                                                float* __restrict__ save_x) {
+    using dctr::f32x4;
+    constexpr int RT = 4;
+    constexpr int NTHR = 64 * CROSS_WAVES;
+    constexpr int ROWS = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xa = smem;                                   // x_l [ROWS][lda], columns >= d zero up to the next multiple of 32
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
+    const int KP = (d + 31) & ~31;
+    // the workgroup's rows of the input as a buffer: [rows_here, x_stride] floats from its first row (< 2^31 B: host)
+    const int rows_here = (int)(batch - b0 < ROWS ? batch - b0 : ROWS);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + b0 * x_stride), 0,
+                                                                           (int)(((int64_t)(rows_here - 1) * x_stride + d) * 4), 0x00020000);
+    for (int base = 0; base < ROWS * KP; base += NTHR * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NTHR + threadIdx.x;
+            const int r = min(i / KP, ROWS - 1), c = i % KP;
+            v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (r * (int)x_stride + min(c, d - 1)) * 4, 0, 0));
+            if (c >= d) v[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NTHR + threadIdx.x;
+            if (i < ROWS * KP) xa[(i / KP) * lda + i % KP] = v[u];
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int n_tiles = (d + 15) / 16;
+    const int n_stage = KP / 32;
+    for (int l = 0; l < layers; ++l) {
+        const float* W = w + (int64_t)l * d * wstride;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, d * wstride * 4, 0x00020000);
+        const float* arow = xa + j * lda + 4 * g;
+        f32x4 res[MAXT][RT];
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+            const int wt = wave + CROSS_WAVES * ti;
+            if (wt < n_tiles) {                              // (wave-uniform)
+                const int n = wt * 16 + j;
+                const int voff = (min(n, d - 1) * wstride + 4 * g) * 4;
+                f32x4 acc[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // two register stages (a stage is 32 MFMAs per wave = 2k cycles for the two waves of a SIMD: one stage of cover is
+                // an L2 round trip; three stages of four row tiles' operands would be 120 registers beside the 64 of `res`)
+                float4 bA[2], bB[2], aA[RT][2], aB[RT][2];
+                const int s_last = n_stage - 1;
+                cross_load_stage_rt<RT>(rsrc, voff, arow, lda, 0, bA, aA);
+                for (int s = 0; s < n_stage; s += 2) {
+                    cross_load_stage_rt<RT>(rsrc, voff, arow, lda, min(s + 1, s_last), bB, aB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cross_mfma_stage_rt<RT>(aA, bA, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cross_load_stage_rt<RT>(rsrc, voff, arow, lda, min(s + 2, s_last), bA, aA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < n_stage) cross_mfma_stage_rt<RT>(aB, bB, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float bv = bias[(int64_t)l * d + min(n, d - 1)];
+                // x_0 of this wave-tile from the input (L2): buffer loads off the workgroup's first row (lane offset < 64 rows: 32
+                // bits; rows past the batch fall outside the descriptor and read 0)
+                const int nc = min(n, d - 1);
+                // (lane parts of the epilogue's addresses from an OPAQUE copy of g, rebuilt per tile and layer: as loop invariants of
+                //  the layer loop hipcc keeps 32 address registers per column tile alive — 128 of the 256 at MAXT = 4)
+                int go = g;
+                asm volatile("" : "+v"(go));
+                const int xlane = (4 * go * (int)x_stride + nc) * 4;
+                const float* xal = xa + 4 * go * lda + nc;
+                float x0v[RT][4];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x0v[rt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, xlane, (rt * 16 + r) * (int)x_stride * 4, 0));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)       // interaction.py:419-420: x_l = x_0 * (W x_l + b) + x_l
+                        res[ti][rt][r] = x0v[rt][r] * (acc[rt][r] + bv) + xal[(rt * 16 + r) * lda];
+                __builtin_amdgcn_sched_barrier(0);           // (a tile at a time: the next tile's operand stages must not overlap this epilogue)
+            }
+        }
+        __syncthreads();                                     // every wave has read x_l for the last time
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+            const int wt = wave + CROSS_WAVES * ti;
+            const int n = wt * 16 + j;
+            if (wt < n_tiles && n < d) {
+                int go = g;
+                asm volatile("" : "+v"(go));
+                float* xal = xa + 4 * go * lda + n;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xal[(rt * 16 + r) * lda] = res[ti][rt][r];
+            }
+        }
+        __syncthreads();
+    }
+    if (y != nullptr) {
+        for (int i = threadIdx.x; i < ROWS * d; i += NTHR) {
+            const int r = i / d, c = i % d;
+            if (b0 + r < batch) y[(b0 + r) * y_stride + c] = xa[r * lda + c];
+        }
+    }
+    if (head_w != nullptr) {            // this branch's share of the model's Dense(1): TPR consecutive lanes per row
+        constexpr int TPR = NTHR / ROWS;
+        const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;
+        float dot = 0.f;
+        for (int n = part; n < d; n += TPR) dot = fmaf(xa[r * lda + n], head_w[n], dot);
+#pragma unroll
+        for (int m = TPR / 2; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+        if (part == 0 && b0 + r < batch) logit[b0 + r] = dot;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // AFM: one wave per sample; the [F,E] tile, W, b, h, p in LDS; lanes walk the F(F-1)/2 pairs.
 // ---------------------------------------------------------------------------------------------------
@@ -819,14 +953,22 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
         const size_t lds2 = (size_t)2 * 32 * lda * sizeof(float);
         static const bool rt1_forced = [] { const char* e = dctr_lab_env("DCTR_CROSS_RT"); return e != nullptr && atoi(e) == 1; }();   // A/B switch
         const bool rt2 = !rt1_forced && batch >= (int64_t)32 * dctr_n_cus() && lds2 <= 160 * 1024;
-        const size_t lds = rt2 ? lds2 : (size_t)3 * 16 * lda * sizeof(float);
+        // 64 rows per workgroup, the layer's output written in place (cross_matrix_inplace_kernel): from 64 rows per CU on, dim <= 512
+        const size_t lds4 = (size_t)64 * lda * sizeof(float);
+        static const bool rt4_off = [] { const char* e = dctr_lab_env("DCTR_CROSS_RT"); return e != nullptr && atoi(e) == 2; }();     // A/B switch
+        const bool rt4 = rt2 && !rt4_off && batch >= (int64_t)64 * dctr_n_cus() && dim <= 128 * 4 && lds4 <= 160 * 1024 && a->save_u == nullptr &&
+                         (int64_t)64 * x_stride * 4 < 0x7fffffffLL;          // (inference; a workgroup's rows addressable in 32 bits)
+        const size_t lds = rt4 ? lds4 : rt2 ? lds2 : (size_t)3 * 16 * lda * sizeof(float);
         DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d needs %zu B of LDS", dim, lds);
+        const int maxt = dim <= 128 ? 1 : dim <= 256 ? 2 : 4;          // column tiles a wave of the in-place kernel holds in registers
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(rt2 ? (const void*)cross_matrix_kernel<2> : (const void*)cross_matrix_kernel<1>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const void* fn = rt4 ? (maxt == 1 ? (const void*)cross_matrix_inplace_kernel<1> : maxt == 2 ? (const void*)cross_matrix_inplace_kernel<2>
+                                                                                                        : (const void*)cross_matrix_inplace_kernel<4>)
+                                 : rt2 ? (const void*)cross_matrix_kernel<2> : (const void*)cross_matrix_kernel<1>;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DCTR_REQUIRE(e == hipSuccess, (int)e, "crossnet_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));
         }
-        const int64_t blocks = dctr_ceil_div(batch, rt2 ? 32 : 16);
+        const int64_t blocks = dctr_ceil_div(batch, rt4 ? 64 : rt2 ? 32 : 16);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
         DCTR_REQUIRE((int64_t)dim * (dim + 3) * 4 < 0x7fffffffLL, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d too large", dim);
         const size_t need = dctr_crossnet_workspace_bytes(dim, layers, mode, kernels);
@@ -844,12 +986,20 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
             }
             wk = static_cast<const float*>(workspace);
         }
-        if (rt2)
+#define CALL_IP(N)                                                                                                         \
+    DCTR_LAUNCH(cross_matrix_inplace_kernel<N>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride, \
+                bias, layers, y, y_stride, lda, a->head_w, a->logit, a->save_u, a->save_x)
+        if (rt4) {
+            if (maxt == 1) CALL_IP(1);
+            else if (maxt == 2) CALL_IP(2);
+            else CALL_IP(4);
+        } else if (rt2)
             DCTR_LAUNCH(cross_matrix_kernel<2>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
                         bias, layers, y, y_stride, lda, a->head_w, a->logit, a->save_u, a->save_x);
         else
             DCTR_LAUNCH(cross_matrix_kernel<1>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride,
                         bias, layers, y, y_stride, lda, a->head_w, a->logit, a->save_u, a->save_x);
+#undef CALL_IP
     }
     return dctr_launch_status("dctr_crossnet_fwd");
 }

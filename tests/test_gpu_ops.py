@@ -256,7 +256,12 @@ def test_crossnet(device):
     # (matrix, >= 32 rows per CU: the 32-row workgroups of cross_matrix_kernel<2> — two row tiles per weight fragment, x_0 re-read
     #  from the input; 8219 / 8200 rows leave a partial last workgroup, d = 45 / 430 are off the 16-B grid: the re-packed weights)
     for par, B, d, L in (("vector", 4096, 429, 2), ("matrix", 300, 429, 2), ("vector", 9, 1500, 3), ("matrix", 17, 64, 4),
-                         ("matrix", 8219, 429, 2), ("matrix", 16384, 64, 3), ("matrix", 8200, 45, 1), ("matrix", 8192, 430, 2)):
+                         ("matrix", 8219, 429, 2), ("matrix", 16384, 64, 3), ("matrix", 8200, 45, 1), ("matrix", 8192, 430, 2),
+                         # >= 64 rows per CU: cross_matrix_inplace_kernel (64-row workgroups, the layer's output held in registers and
+                         # written over x_l): one / two / four column tiles per wave, ragged last workgroup, off-grid d, the d = 512 limit
+                         # and d = 513 back on the 32-row kernel
+                         ("matrix", 16384 + 37, 429, 2), ("matrix", 16500, 200, 3), ("matrix", 16385, 430, 2), ("matrix", 16400, 512, 1),
+                         ("matrix", 16400, 513, 1), ("matrix", 16384 + 5, 45, 2)):
         x = rng.standard_normal((B, d)).astype(np.float32)
         ks = (rng.standard_normal((L, d) if par == "vector" else (L, d, d)) / np.sqrt(d)).astype(np.float32)
         bs = rng.standard_normal((L, d)).astype(np.float32) * 0.1
@@ -266,10 +271,14 @@ def test_crossnet(device):
                          [np.abs(b).reshape(d, 1).astype(np.float64) for b in bs], par)
         y = ops.crossnet(dev(x, device), dev(ks, device), dev(bs, device), par)
         assert_close_terms(y.cpu().numpy(), ref, mag, what="crossnet %s d=%d" % (par, d))
+        if par == "matrix" and B >= 16384:
+            # every workgroup shape walks k in the same order: the first 8,200 rows through the 32-row kernel give the same bits
+            y2 = ops.crossnet(dev(x[:8200], device), dev(ks, device), dev(bs, device), par)
+            assert np.array_equal(y2.cpu().numpy(), y.cpu().numpy()[:8200]), "in-place 64-row kernel vs 32-row kernel, d=%d" % d
 
 
 @pytest.mark.parametrize("par,B,d,L", [("vector", 300, 429, 2), ("vector", 5, 70, 0), ("matrix", 300, 429, 2), ("matrix", 8219, 429, 2),
-                                       ("matrix", 33, 64, 3), ("matrix", 8200, 45, 1)])
+                                       ("matrix", 33, 64, 3), ("matrix", 8200, 45, 1), ("matrix", 16384 + 77, 429, 2), ("matrix", 16390, 100, 3)])
 def test_crossnet_head_logit(device, par, B, d, L):
     """dctr_crossnet_head_fwd: the branch's share of Dense(1) over [cross_out, deep_out] (reference models/dcn.py:61-64) as a [B]
     logit = x_L . head_w — with and without the [B, d] output, bit-equal layer outputs to dctr_crossnet_fwd, and the re-packed kernel
