@@ -197,6 +197,7 @@ SYMBOLS = {
     "dctr_crossnet_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp]),
     "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "dctr_crossnet_head_fwd": (ctypes.c_int, [ctypes.POINTER(CrossnetArgs), c_vp]),
+    "dctr_crossnet_gather_head_fwd": (ctypes.c_int, [ctypes.POINTER(CrossnetArgs), ctypes.POINTER(GatherFmArgs), c_vp]),
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
     "dctr_cin_gather_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), ctypes.POINTER(GatherFmArgs), c_vp, c_vp, c_vp]),

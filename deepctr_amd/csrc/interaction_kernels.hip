@@ -292,11 +292,24 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_kernel(const fl
 // Four row tiles (64 rows) per workgroup, x_{l+1} IN PLACE (round 4b; launches of >= 64 rows per CU).  A weight fragment feeds four
 // MFMAs: the stream from L2 per row halves again (RT = 2 asks ~32 B/clk of a CU at the full matrix rate where ~20 arrive).  Two 64-row
 // tiles do not fit the 160 KiB, so a layer's results wait in REGISTERS — a wave owns column tiles wave, wave + 8, ... (<= MAXT of
-// them: d <= 128 MAXT) — until every wave has finished reading x_l (one barrier), and are then written over it.  x_0 comes from the
-// input (L2) in the epilogue, as with RT = 2.  Same arithmetic per element as the other forms: the same fmaf chain over k, then
+// them: d <= 128 MAXT) — until every wave has finished reading x_l (one barrier), and are then written over it.  x_0 of a wave's column
+// tiles stays in registers for the whole network.  Same arithmetic per element as the other forms: the same fmaf chain over k, then
 // x_0 (u + b) + x_l.
+// dctr_crossnet_gather_head_fwd: fields == NULL reads the rows from x; else the workgroup's [64, d] tile is gathered from the embedding
+// tables (field f of row b = E floats at column f E: inputs.py:101-117 + layers/utils.py:336-346 inside the kernel) and the dense columns
+struct CrossGather {
+    const dctr_field_t* fields;
+    const void* ids;
+    int64_t ids_stride_f;
+    int32_t ids_i64, n_fields, E;
+    const float* dense;
+    int64_t dense_stride;
+    int32_t n_dense, dense_off;
+    int32_t* status;
+};
+
 template <int MAXT>
-__global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_inplace_kernel(const float* __restrict__ x, int64_t batch, int d,
+__global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_inplace_kernel(CrossGather cg, const float* __restrict__ x, int64_t batch, int d,
                                                                                 int64_t x_stride, const float* __restrict__ w,
                                                                                 int wstride, const float* __restrict__ bias,
                                                                                 int layers, float* __restrict__ y, int64_t y_stride,
@@ -315,19 +328,64 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_inplace_kernel(
     const int rows_here = (int)(batch - b0 < ROWS ? batch - b0 : ROWS);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + b0 * x_stride), 0,
                                                                            (int)(((int64_t)(rows_here - 1) * x_stride + d) * 4), 0x00020000);
-    for (int base = 0; base < ROWS * KP; base += NTHR * 4) {
-        float v[4];
+    if (cg.fields != nullptr) {
+        // item (row r, field f, 16-B piece q): four ids, then their rows, in flight together; ids outside the vocabulary read row 0 and
+        // raise the status flag; rows past the batch: zeros
+        const int Q = cg.E >> 2, fq = cg.n_fields * Q, total = ROWS * fq;
+        for (int base = 0; base < total; base += NTHR * 4) {
+            int64_t id[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * NTHR + threadIdx.x;
-            const int r = min(i / KP, ROWS - 1), c = i % KP;
-            v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (r * (int)x_stride + min(c, d - 1)) * 4, 0, 0));
-            if (c >= d) v[u] = 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(base + u * NTHR + (int)threadIdx.x, total - 1);
+                const int r = i / fq, f = (i - r * fq) / Q;
+                const int64_t eo = (int64_t)f * cg.ids_stride_f + min(b0 + r, batch - 1);
+                id[u] = cg.ids_i64 ? reinterpret_cast<const int64_t*>(cg.ids)[eo] : (int64_t)reinterpret_cast<const int32_t*>(cg.ids)[eo];
+            }
+            float4 v[4];
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(base + u * NTHR + (int)threadIdx.x, total - 1);
+                const int r = i / fq, rem = i - r * fq;
+                const int f = rem / Q, q = rem - f * Q;
+                const bool ok = (uint64_t)id[u] < (uint64_t)cg.fields[f].vocab;
+                bad = bad || (!ok && base + u * NTHR + (int)threadIdx.x < total && b0 + r < batch);
+                v[u] = *reinterpret_cast<const float4*>(cg.fields[f].table + (ok ? id[u] : 0) * cg.E + 4 * q);
+                if (b0 + r >= batch) v[u] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (bad && cg.status != nullptr) atomicOr(cg.status, (int)DCTR_STATUS_INDEX_OOR);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NTHR + threadIdx.x;
+                if (i < total) {
+                    const int r = i / fq, rem = i - r * fq;
+                    const int f = rem / Q, q = rem - f * Q;
+                    *reinterpret_cast<float4*>(xa + r * lda + f * cg.E + 4 * q) = v[u];
+                }
+            }
         }
+        const int tail0 = cg.n_fields * cg.E;               // dense columns, then zeros up to KP
+        for (int i = threadIdx.x; i < ROWS * (KP - tail0); i += NTHR) {
+            const int r = i / (KP - tail0), c = tail0 + i % (KP - tail0);
+            float v = 0.f;
+            if (c >= cg.dense_off && c < cg.dense_off + cg.n_dense && b0 + r < batch) v = cg.dense[(b0 + r) * cg.dense_stride + (c - cg.dense_off)];
+            xa[r * lda + c] = v;
+        }
+    } else {
+        for (int base = 0; base < ROWS * KP; base += NTHR * 4) {
+            float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * NTHR + threadIdx.x;
-            if (i < ROWS * KP) xa[(i / KP) * lda + i % KP] = v[u];
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NTHR + threadIdx.x;
+                const int r = min(i / KP, ROWS - 1), c = i % KP;
+                v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (r * (int)x_stride + min(c, d - 1)) * 4, 0, 0));
+                if (c >= d) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NTHR + threadIdx.x;
+                if (i < ROWS * KP) xa[(i / KP) * lda + i % KP] = v[u];
+            }
         }
     }
     __syncthreads();
@@ -335,6 +393,16 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_inplace_kernel(
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int n_tiles = (d + 15) / 16;
     const int n_stage = KP / 32;
+    // x_0 of this wave's column tiles: registers for the whole network (the tile in LDS is overwritten layer by layer)
+    f32x4 x0r[MAXT][RT];
+#pragma unroll
+    for (int ti = 0; ti < MAXT; ++ti) {
+        const int nc = min((wave + CROSS_WAVES * ti) * 16 + j, d - 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x0r[ti][rt][r] = xa[(rt * 16 + 4 * g + r) * lda + nc];
+    }
     for (int l = 0; l < layers; ++l) {
         const float* W = w + (int64_t)l * d * wstride;
         const __amdgpu_buffer_rsrc_t rsrc =
@@ -366,26 +434,17 @@ __global__ __launch_bounds__(64 * CROSS_WAVES) void cross_matrix_inplace_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float bv = bias[(int64_t)l * d + min(n, d - 1)];
-                // x_0 of this wave-tile from the input (L2): buffer loads off the workgroup's first row (lane offset < 64 rows: 32
-                // bits; rows past the batch fall outside the descriptor and read 0)
                 const int nc = min(n, d - 1);
                 // (lane parts of the epilogue's addresses from an OPAQUE copy of g, rebuilt per tile and layer: as loop invariants of
                 //  the layer loop hipcc keeps 32 address registers per column tile alive — 128 of the 256 at MAXT = 4)
                 int go = g;
                 asm volatile("" : "+v"(go));
-                const int xlane = (4 * go * (int)x_stride + nc) * 4;
                 const float* xal = xa + 4 * go * lda + nc;
-                float x0v[RT][4];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        x0v[rt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, xlane, (rt * 16 + r) * (int)x_stride * 4, 0));
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)       // interaction.py:419-420: x_l = x_0 * (W x_l + b) + x_l
-                        res[ti][rt][r] = x0v[rt][r] * (acc[rt][r] + bv) + xal[(rt * 16 + r) * lda];
+                        res[ti][rt][r] = x0r[ti][rt][r] * (acc[rt][r] + bv) + xal[(rt * 16 + r) * lda];
                 __builtin_amdgcn_sched_barrier(0);           // (a tile at a time: the next tile's operand stages must not overlap this epilogue)
             }
         }
@@ -911,7 +970,7 @@ extern "C" size_t dctr_crossnet_workspace_bytes(int32_t dim, int32_t layers, int
     return (size_t)layers * dim * ((dim + 3) & ~3) * sizeof(float);
 }
 
-static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
+static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dctr_gather_fm_args_t* gg = nullptr) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "crossnet_fwd: null args");
     const float* x = a->x;
     const int64_t batch = a->batch, x_stride = a->x_stride, y_stride = a->y_stride;
@@ -924,9 +983,9 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
     DCTR_REQUIRE(batch >= 0 && dim >= 1 && layers >= 0, DCTR_E_DIM, "crossnet_fwd: bad sizes");
     DCTR_REQUIRE(mode == DCTR_CROSS_VECTOR || mode == DCTR_CROSS_MATRIX, DCTR_E_ENUM, "crossnet_fwd: mode %d", mode);
     if (batch == 0) return DCTR_OK;
-    DCTR_REQUIRE(x && (y || a->head_w) && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
+    DCTR_REQUIRE((x || gg) && (y || a->head_w) && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
     DCTR_REQUIRE((a->head_w == nullptr) == (a->logit == nullptr), DCTR_E_NULL, "crossnet_fwd: head_w and logit go together");
-    DCTR_REQUIRE(x_stride >= dim && (y == nullptr || y_stride >= dim), DCTR_E_DIM, "crossnet_fwd: stride < dim");
+    DCTR_REQUIRE((gg != nullptr || x_stride >= dim) && (y == nullptr || y_stride >= dim), DCTR_E_DIM, "crossnet_fwd: stride < dim");
     DCTR_REQUIRE(a->save_u == nullptr || (mode == DCTR_CROSS_MATRIX && layers >= 1 && (layers == 1 || a->save_x != nullptr)), DCTR_E_UNSUPPORTED,
                  "crossnet_fwd: save_u / save_x exist for the matrix form (save_x with more than one layer)");
     hipStream_t st = (hipStream_t)stream;
@@ -957,7 +1016,24 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
         const size_t lds4 = (size_t)64 * lda * sizeof(float);
         static const bool rt4_off = [] { const char* e = dctr_lab_env("DCTR_CROSS_RT"); return e != nullptr && atoi(e) == 2; }();     // A/B switch
         const bool rt4 = rt2 && !rt4_off && batch >= (int64_t)64 * dctr_n_cus() && dim <= 128 * 4 && lds4 <= 160 * 1024 && a->save_u == nullptr &&
-                         (int64_t)64 * x_stride * 4 < 0x7fffffffLL;          // (inference; a workgroup's rows addressable in 32 bits)
+                         (gg != nullptr || (int64_t)64 * x_stride * 4 < 0x7fffffffLL);   // (inference; a workgroup's rows addressable in 32 bits)
+        CrossGather cg{};
+        if (gg != nullptr) {
+            // the gather of the same batch inside the kernel: plain lookups of one width, the reference's DNN-input layout
+            DCTR_REQUIRE(rt4, DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: the 64-row kernel takes launches of >= %lld rows, dim <= 512 "
+                         "(got %lld rows, dim %d): use dctr_embed_gather_fm + dctr_crossnet_head_fwd", (long long)(64 * dctr_n_cus()), (long long)batch, dim);
+            cg.fields = gg->fields;
+            cg.ids = gg->ids;
+            cg.ids_stride_f = gg->ids_stride_f;
+            cg.ids_i64 = gg->ids_is_i64;
+            cg.n_fields = gg->n_fields;
+            cg.E = gg->uniform_dim;
+            cg.dense = gg->dense;
+            cg.dense_stride = gg->dense_stride;
+            cg.n_dense = gg->dense_copy_cols;
+            cg.dense_off = gg->dense_out_offset;
+            cg.status = gg->status;
+        }
         const size_t lds = rt4 ? lds4 : rt2 ? lds2 : (size_t)3 * 16 * lda * sizeof(float);
         DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d needs %zu B of LDS", dim, lds);
         const int maxt = dim <= 128 ? 1 : dim <= 256 ? 2 : 4;          // column tiles a wave of the in-place kernel holds in registers
@@ -987,7 +1063,7 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream) {
             wk = static_cast<const float*>(workspace);
         }
 #define CALL_IP(N)                                                                                                         \
-    DCTR_LAUNCH(cross_matrix_inplace_kernel<N>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, x, batch, dim, x_stride, wk, wstride, \
+    DCTR_LAUNCH(cross_matrix_inplace_kernel<N>, dim3((unsigned)blocks), dim3(64 * CROSS_WAVES), lds, st, cg, x, batch, dim, x_stride, wk, wstride, \
                 bias, layers, y, y_stride, lda, a->head_w, a->logit, a->save_u, a->save_x)
         if (rt4) {
             if (maxt == 1) CALL_IP(1);
@@ -1014,6 +1090,23 @@ extern "C" int dctr_crossnet_fwd(const float* x, int64_t batch, int32_t dim, int
 }
 
 extern "C" int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* a, void* stream) { return crossnet_launch(a, stream); }
+
+// ABI 8 — CrossNet (matrix parameterization) + the branch's share of DCN's Dense(1) over the embeddings of a gather (reference
+// models/dcn.py:48-66, layers/interaction.py:405-424): the workgroup's [64, dim] tile of the DNN input is read from the tables and the
+// dense matrix inside the kernel (a->x is ignored), logit[b] = x_L[b] . head_w leaves (y optional).  Spans only: >= 64 rows per CU.
+extern "C" int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* a, const dctr_gather_fm_args_t* g, void* stream) {
+    DCTR_REQUIRE(a != nullptr && g != nullptr, DCTR_E_NULL, "crossnet_gather_head_fwd: null args");
+    DCTR_REQUIRE(a->mode == DCTR_CROSS_MATRIX && a->layers >= 1, DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: matrix parameterization, >= 1 layer");
+    DCTR_REQUIRE(g->fields != nullptr && g->ids != nullptr && g->batch == a->batch, DCTR_E_NULL, "crossnet_gather_head_fwd: gather of another batch / null");
+    DCTR_REQUIRE(g->uniform_dim > 0 && g->uniform_dim % 4 == 0 && g->all_dim4 && !g->any_hash && !g->any_identity && g->ids_stride_b == 1,
+                 DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: plain (unhashed, not pre-pooled) lookups of one width, contiguous id rows");
+    const int n_dense = g->dense_copy_cols > 0 ? g->dense_copy_cols : 0;
+    DCTR_REQUIRE(a->dim == g->n_fields * g->uniform_dim + n_dense && (n_dense == 0 || (g->dense != nullptr && g->dense_out_offset == g->n_fields * g->uniform_dim)),
+                 DCTR_E_DIM, "crossnet_gather_head_fwd: dim %d is not the gather's DNN-input width (%d fields x %d + %d dense)", a->dim, g->n_fields,
+                 g->uniform_dim, n_dense);
+    DCTR_REQUIRE(a->save_u == nullptr, DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: inference only");
+    return crossnet_launch(a, stream, g);
+}
 
 extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim,
                             const float* att_w, const float* att_b, const float* proj_h, const float* proj_p,

@@ -70,6 +70,8 @@ class _DCN(FusedForward, FeatureModel):
     def _rows_per_launch(self, staged, batch_size):
         if self._fast_path(staged):
             return super(_DCN, self)._rows_per_launch(staged, batch_size)       # the one-launch path owns no per-batch buffer
+        if self._matrix_gather_ok(staged, 1 << 20):
+            return max(int(batch_size or staged.n), 65536)                      # the 64-row cross kernel wants >= 64 rows per CU
         return FeatureModel._rows_per_launch(self, staged, batch_size)
 
     def _head_weights(self):
@@ -78,6 +80,8 @@ class _DCN(FusedForward, FeatureModel):
 
     def _cross_operands(self):
         import torch
+        if not self._fold_ok():
+            return None                     # (matrix CrossNet on the one-launch DNN: the cross logit arrives through the head's add)
         ks, bs = self.cross.packed()
         d = self.stage_plan.in_dim
         hw = self.dense.w('kernel').reshape(-1)[:d]
@@ -109,8 +113,37 @@ class _DCN(FusedForward, FeatureModel):
     # goes to HBM) and the DNN's fused head adds it — one launch and the 493-wide stack's round trip less per call
     fuse_head = True
 
+    # matrix CrossNet on the embeddings of the gather (dctr_crossnet_gather_head_fwd, ABI 8: the 64-row kernel reads its tile of the DNN
+    # input from the tables, its share of Dense(1) leaves as a logit) + the one-launch DNN: no DNN input in HBM.  Spans of >= 64 rows per CU
+    fuse_matrix = True
+
+    def _matrix_gather_ok(self, staged, B):
+        import torch
+        if not (self.fuse_matrix and self.fuse_head and self.fused and self.cross is not None and self.dnn is not None and
+                getattr(self.cross, "parameterization", None) == "matrix" and not getattr(self, "_matrix_failed", False)):
+            return False
+        sp = self.stage_plan
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        return bool(FusedForward._fast_path(self, staged) and sp.uniform_dim and sp.uniform_dim % 4 == 0 and sp.in_dim <= 512 and
+                    B >= 64 * cus and (not sp.any_hash or self._prehash(B)) and not self.dnn.dice_layers)
+
+    def _extra_logits(self, staged, lo, hi):
+        if self.cross is None or getattr(self.cross, "parameterization", None) != "matrix":
+            return []
+        import torch
+        B, d = hi - lo, self.stage_plan.in_dim
+        cl = self._cross_logit.get(B) if getattr(self, "_cross_logit", None) is not None else None
+        if cl is None:
+            if getattr(self, "_cross_logit", None) is None or len(self._cross_logit) > 8:
+                self._cross_logit = {}
+            cl = self._cross_logit[B] = torch.empty(B, dtype=torch.float32, device=self.device)
+        self._run_cross(None, B, d, None, head_w=self.dense.w('kernel').reshape(-1)[:d], logit=cl, gather=self._fast_g)
+        return [cl]
+
     def _forward(self, staged, lo, hi, out):
         if self._fast_path(staged):
+            return self._forward_fast(staged, lo, hi, out)
+        if self._matrix_gather_ok(staged, hi - lo):
             return self._forward_fast(staged, lo, hi, out)
         ws = self.stage_plan.run(staged, lo, hi)
         B = hi - lo
@@ -140,7 +173,7 @@ class _DCN(FusedForward, FeatureModel):
         ops.mlp(stack, [], [], "linear", head_w=self.dense.w('kernel'), add=self._logits_to_add(ws),
                 global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=self.width, out=out)
 
-    def _run_cross(self, dnn_in, B, d, stack, head_w=None, logit=None):
+    def _run_cross(self, dnn_in, B, d, stack, head_w=None, logit=None, gather=None):
         ks, bs = self._cross_packed
         import ctypes
         from .. import _C
@@ -151,11 +184,15 @@ class _DCN(FusedForward, FeatureModel):
             self._cross_ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)   # re-packed W rows
             ready = 0
         self._cross_ws_fresh = True
-        a = _C.CrossnetArgs(x=dnn_in.data_ptr(), batch=B, x_stride=dnn_in.stride(0), dim=d, layers=self.cross.layer_num, mode=mode,
+        a = _C.CrossnetArgs(x=None if dnn_in is None else dnn_in.data_ptr(), batch=B, x_stride=0 if dnn_in is None else dnn_in.stride(0), dim=d,
+                            layers=self.cross.layer_num, mode=mode,
                             workspace_ready=ready if need else 0, kernels=ks.data_ptr(), bias=bs.data_ptr(),
                             y=None if stack is None else stack.data_ptr(), y_stride=0 if stack is None else stack.stride(0),
                             workspace=self._cross_ws.data_ptr() if need else None, workspace_bytes=need,
                             head_w=None if head_w is None else head_w.data_ptr(), logit=None if logit is None else logit.data_ptr())
+        if gather is not None:
+            _C.check(_C.lib().dctr_crossnet_gather_head_fwd(ctypes.byref(a), ctypes.byref(gather), _C.stream_ptr()), "dctr_crossnet_gather_head_fwd")
+            return
         _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
 
 

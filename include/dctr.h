@@ -270,6 +270,14 @@ typedef struct {
     float* save_x;                /* ... and [layers - 1, B, dim] — x_1 .. x_{L-1} for saved_x (NULL with one layer)        */
 } dctr_crossnet_args_t;
 int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* args, void* stream);
+/* ABI 8 — the same over the embeddings of a gather (models/dcn.py:48-66: dnn_input = combined_dnn_input(sparse embeddings, dense values)
+ * -> CrossNet -> its share of Dense(1)): matrix parameterization; the workgroup's [64, dim] tile of the DNN input is read from the
+ * embedding tables and the dense matrix inside the kernel (gather: the dctr_embed_gather_fm arguments of the same batch — fields / ids /
+ * strides / dense / status are used; every field a plain lookup of width uniform_dim % 4 == 0 at column field * uniform_dim, the dense
+ * columns behind them; args->x / x_stride are ignored), so the DNN input never has to exist in HBM.  Launches of >= 64 rows per CU with
+ * dim <= 512 (the 64-row kernel whose layer outputs wait in registers); anything else returns DCTR_E_UNSUPPORTED — use
+ * dctr_embed_gather_fm + dctr_crossnet_head_fwd.  Inference only (save_u / save_x must be NULL). */
+int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* args, const dctr_gather_fm_args_t* gather, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10 CIN.call — deepctr/layers/interaction.py:277-325   (outer product + 1x1 conv on f32 MFMA)

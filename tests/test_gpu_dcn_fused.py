@@ -11,7 +11,7 @@ import torch
 
 from oracle import ref_models as RM
 from oracle import ref_numpy as R
-from tests.test_gpu_models import _criteo_like, _randomise, check_probs
+from tests.test_gpu_models import _criteo_like, _randomise, check_logits, check_probs
 from tests.util import assert_close, assert_close_terms
 
 pytestmark = pytest.mark.gpu
@@ -128,3 +128,47 @@ def test_dcn_vector_row_chained_main_and_tail_full_size(device):
     assert np.array_equal(model.predict(feed64, batch_size=4096), y)
     model.fold_cross = False
     assert_close(model.predict(feed, batch_size=4096), y, rtol=2e-5, atol=4e-6, what="folded vs layer-by-layer route")
+
+
+@pytest.mark.parametrize("E,F,ND,layers,hashed", [(16, 26, 13, 2, False), (8, 12, 0, 3, False), (32, 12, 5, 1, True), (16, 30, 30, 2, False)])
+def test_dcn_matrix_cross_on_the_gather(device, E, F, ND, layers, hashed):
+    """DCN with the MATRIX CrossNet in spans (round 4b): dctr_crossnet_gather_head_fwd — the 64-row cross kernel reads its tile of the DNN
+    input from the embedding tables and the dense matrix, x_0 of a wave's column tiles in registers, layer outputs written in place — in
+    front of the one-launch DNN; no DNN input in HBM.  Float64 oracle on a row sample (probabilities and logits), the route through
+    dnn_in on every row (the cross logit is the same bits: same tile, same k order), permutation equivariance, ragged spans."""
+    import torch
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DCN
+    rng = np.random.RandomState(3 + E + F)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n = 64 * cus + 4096 + 37
+    V = 3000
+    cols = [SparseFeat("C%d" % i, V, E, use_hash=hashed and i % 3 == 0) for i in range(1, F + 1)] + [DenseFeat("I%d" % i, 1) for i in range(1, ND + 1)]
+    feed = {"C%d" % i: rng.randint(0, (2 ** 31 - 1) if (hashed and i % 3 == 0) else V, n).astype(np.int32) for i in range(1, F + 1)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(1, ND + 1)})
+    model = DCN(cols, cols, cross_num=layers, cross_parameterization="matrix", device=device)
+    w = _randomise(model, rng)
+    staged = model.stage(feed)
+    assert model._matrix_gather_ok(staged, n) and not model._matrix_gather_ok(staged, 4096)
+    y = model.predict(feed, batch_size=4096)            # spans of 65,536 rows; the ragged rest (< 64 rows per CU) takes the dnn_in route
+    z = model.predict_logits(feed, batch_size=n)        # ONE span of n rows
+    assert y.shape == (n, 1) and np.isfinite(y).all()
+    rows = np.unique(np.concatenate([np.arange(0, 70), np.arange(n - 70, n), rng.choice(n, 150, replace=False)]))
+    sub = {k: v[rows] for k, v in feed.items()}
+    kw = dict(cross_num=layers, cross_parameterization="matrix", dtype=np.float64)
+    check_probs(y[rows], RM.dcn(cols, cols, w, sub, **kw).astype(np.float32), "DCN matrix on the gather, E=%d" % E)
+    check_logits(z[rows], RM.dcn(cols, cols, w, sub, task="regression", **kw),
+                 RM.dcn(cols, cols, {k: np.abs(v) for k, v in w.items()}, sub, task="regression", **kw), "DCN matrix on the gather, E=%d" % E)
+    model.fuse_matrix = False
+    z0 = model.predict_logits(feed, batch_size=n)
+    model.fuse_matrix = True
+    scale = np.abs(z0).max() + 1.0
+    assert_close(z / scale, z0 / scale, rtol=0, atol=2e-6, what="cross on the gather vs the route through dnn_in (logits)")
+    perm = rng.permutation(n)
+    zp = model.predict_logits({k: v[perm] for k, v in feed.items()}, batch_size=n)
+    assert np.array_equal(zp, z[perm])
+    bad = {k: v.copy() for k, v in feed.items()}
+    plain = [i for i in range(1, F + 1) if not (hashed and i % 3 == 0)][0]
+    bad["C%d" % plain][n - 3] = V
+    with pytest.raises(IndexError):
+        model.predict(bad, batch_size=n)
