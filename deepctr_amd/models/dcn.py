@@ -124,7 +124,7 @@ class _DCN(FusedForward, FeatureModel):
             return False
         sp = self.stage_plan
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        return bool(FusedForward._fast_path(self, staged) and sp.uniform_dim and sp.uniform_dim % 4 == 0 and sp.in_dim <= 512 and
+        return bool(FusedForward._fast_path(self, staged) and sp.uniform_dim in (4, 8, 16, 32, 64) and sp.in_dim <= 512 and
                     B >= 64 * cus and (not sp.any_hash or self._prehash(B)) and not self.dnn.dice_layers)
 
     def _extra_logits(self, staged, lo, hi):
