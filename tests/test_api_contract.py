@@ -323,3 +323,42 @@ def test_training_mode_batchnorm_is_refused_not_silently_inference():
     layer = DNN((4, 3), use_bn=True, device=torch.device("cpu")).build_for(5)
     with pytest.raises(NotImplementedError):
         layer.call(torch.zeros(2, 5), training=True)
+
+
+def test_round4_kernel_routes_are_chosen_from_the_model_shape():
+    """Host logic of the round-4 routes, no GPU: which DNN widths / activations / embedding dims reach the row-chained kernel
+    zero-padded (FusedForward._chain_pad_spec), xDeepFM's two-launch forward (CIN on the gather) and DCN's matrix CrossNet on the gather
+    are switched by model attributes, hashed features of xDeepFM always take the hash pre-pass."""
+    import torch
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DCN, DeepFM, xDeepFM
+    cpu = torch.device("cpu")
+
+    def cols(E, F=6, use_hash=False):
+        return [SparseFeat("C%d" % i, 50, E, use_hash=use_hash) for i in range(F)] + [DenseFeat("I0", 1)]
+
+    # embedding_dim 4 / 8: the 256-128-x instantiations only; 16 / 32: the narrowest instantiation that holds the widths
+    assert DeepFM(cols(4), cols(4), dnn_hidden_units=(100, 50), device=cpu)._pad_spec == [256, 128]
+    assert DeepFM(cols(8), cols(8), dnn_hidden_units=(256, 128, 64), device=cpu)._pad_spec is None
+    assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50), device=cpu)._pad_spec == [128, 64]
+    assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50, 7), device=cpu)._pad_spec == [128, 64, 64]
+    # sigmoid / tanh DNNs: the EXPACT instantiations (256-128-x, embedding_dim 16 / 32); other activations stay off the kernel
+    assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50), dnn_activation="tanh", device=cpu)._pad_spec == [256, 128]
+    assert DeepFM(cols(32), cols(32), dnn_hidden_units=(256, 128, 64), dnn_activation="sigmoid", device=cpu)._pad_spec is None
+    assert DeepFM(cols(4), cols(4), dnn_hidden_units=(100, 50), dnn_activation="tanh", device=cpu)._pad_spec is None
+    assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50), dnn_activation="dice", device=cpu)._pad_spec is None
+    assert DeepFM(cols(16), cols(16), dnn_hidden_units=(300, 50), device=cpu)._pad_spec is None      # wider than any instantiation
+    # xDeepFM: two launches when every field is a plain lookup of one width (a multiple of 4); fuse_cin switches back
+    x = xDeepFM(cols(16, F=26), cols(16, F=26), cin_layer_size=(16, 16), device=cpu)
+    assert x._cin_fuse_ok()
+    x.fuse_cin = False
+    assert not x._cin_fuse_ok()
+    xh = xDeepFM(cols(16, F=26, use_hash=True), cols(16, F=26, use_hash=True), cin_layer_size=(16,), device=cpu)
+    assert xh._prehash(1) and xh._prehash(1 << 20)          # hashed ids never reach the CIN launch unhashed
+    assert not xDeepFM(cols(16, F=26), cols(16, F=26), dnn_hidden_units=(), cin_layer_size=(16,), device=cpu)._cin_fuse_ok()
+    # DCN: the vector CrossNet folds into the one-launch forward; the matrix one has its own switch and no folded operands
+    dv = DCN(cols(16, F=26), cols(16, F=26), cross_parameterization="vector", device=cpu)
+    dm = DCN(cols(16, F=26), cols(16, F=26), cross_parameterization="matrix", device=cpu)
+    assert dv._fold_ok() and not dm._fold_ok() and dm.fuse_matrix
+    assert dm._cross_operands() is None
+    assert dm._extra_logits.__func__ is not DeepFM(cols(16), cols(16), device=cpu)._extra_logits.__func__
