@@ -646,7 +646,8 @@ def _masks(rng, B, T):
 @pytest.mark.parametrize("B,T,E,hid", [(2048, 50, 64, (80, 40)),        # C4: 102,400 rows = 25 compaction chunks
                                        (700, 13, 32, (64, 32)),         # 9,100 rows: three chunks, the last one ragged
                                        (90, 45, 16, (32, 16)),          # less than one chunk
-                                       (10000, 50, 16, (64, 16))])      # 500,000 rows (a span of batches)
+                                       (10000, 50, 16, (64, 16)),       # 500,000 rows (a span of batches)
+                                       (110000, 40, 16, (32, 16))])     # 4,400,000 rows: 8192-row chunks (more than 1024 chunks of 4096)
 def test_din_attention_skips_masked_positions_bit_for_bit(device, B, T, E, hid):
     """The row-chained score kernel walks the compacted list of positions that count (din_compact_kernel); a position's score does
     not depend on its place in that list: outputs and returned scores equal the all-positions launch bit for bit, whatever the mask."""
