@@ -123,6 +123,18 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), None, None, None) == _C.E_UNSUPPORTED
     ga.uniform_dim, cin.batch, ga.batch = 16, 0, 0
     assert lib.dctr_cin_gather_fwd(ctypes.byref(cin), ctypes.byref(ga), None, None, None) == 0       # nothing to do
+    # DCN's matrix CrossNet over a gather: matrix form only, the gather's DNN-input width, plain lookups of a power-of-two width
+    assert lib.dctr_crossnet_gather_head_fwd(None, None, None) == -1
+    ga2 = _C.GatherFmArgs(fields=fake, ids=fake, ids_stride_f=70000, ids_stride_b=1, n_fields=5, max_dim=16, all_dim4=1, batch=70000, uniform_dim=16,
+                          n_dense=3, dense=fake, dense_stride=3, dense_out_offset=80, dense_copy_cols=3)
+    xa = _C.CrossnetArgs(x=None, batch=70000, x_stride=0, dim=83, layers=2, mode=0, kernels=fake, bias=fake, y=None, head_w=fake, logit=fake)
+    assert lib.dctr_crossnet_gather_head_fwd(ctypes.byref(xa), ctypes.byref(ga2), None) == _C.E_UNSUPPORTED      # vector parameterization
+    xa.mode, xa.dim = 1, 84
+    assert lib.dctr_crossnet_gather_head_fwd(ctypes.byref(xa), ctypes.byref(ga2), None) == -2 and b"DNN-input width" in lib.dctr_last_error()
+    xa.dim, ga2.uniform_dim = 83, 12
+    assert lib.dctr_crossnet_gather_head_fwd(ctypes.byref(xa), ctypes.byref(ga2), None) == _C.E_UNSUPPORTED      # 12 is no power of two
+    ga2.uniform_dim, ga2.any_hash = 16, 1
+    assert lib.dctr_crossnet_gather_head_fwd(ctypes.byref(xa), ctypes.byref(ga2), None) == _C.E_UNSUPPORTED
 
 
 def test_host_pack_columns_converts_like_numpy():
