@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 E_UNSUPPORTED = -5               # DCTR_E_UNSUPPORTED: valid request this build does not implement
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
@@ -216,6 +216,7 @@ SYMBOLS = {
     "dctr_embed_mlp_fwd_plan": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), ctypes.POINTER(ctypes.c_int64),
                                                ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_i32]),
     "dctr_bce_grad": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "dctr_bce_grad_w": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dctr_embed_gather_fm_bwd": (ctypes.c_int, [ctypes.POINTER(GatherFmBwdArgs), c_vp]),
     "dctr_embed_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolBwdArgs), c_vp]),
     "dctr_afm_bwd": (ctypes.c_int, [c_vp, c_vp]),

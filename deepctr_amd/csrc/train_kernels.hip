@@ -27,8 +27,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // loss
 // ---------------------------------------------------------------------------------------------------
+// weight (optional): tf.keras' sample_weight — loss = sum_b w_b l_b / B (reduction SUM_OVER_BATCH_SIZE), so l_b and d l_b scale by w_b
 __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__ pred, const float* __restrict__ y,
-                                                       int64_t batch, int task, float* __restrict__ dlogit,
+                                                       const float* __restrict__ weight, int64_t batch, int task,
+                                                       float* __restrict__ dlogit,
                                                        float* __restrict__ loss_sum, float* __restrict__ dlogit_sum) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float l = 0.f, ds = 0.f;
@@ -42,6 +44,11 @@ __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__
         } else {
             l = (p - t) * (p - t);
             ds = 2.f * (p - t) / (float)batch;
+        }
+        if (weight != nullptr) {
+            const float w = weight[b];
+            l *= w;
+            ds *= w;
         }
         dlogit[b] = ds;
     }
@@ -1917,14 +1924,19 @@ extern "C" int dctr_inner_product_bwd(const float* x, int64_t batch, int64_t x_s
     return dctr_launch_status("dctr_inner_product_bwd");
 }
 
-extern "C" int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
-                             float* dlogit_sum, void* stream) {
+extern "C" int dctr_bce_grad_w(const float* pred, const float* y, const float* weight, int64_t batch, int32_t task, float* dlogit,
+                               float* loss_sum, float* dlogit_sum, void* stream) {
     DCTR_REQUIRE(batch >= 0 && (task == 0 || task == 1), DCTR_E_DIM, "bce_grad: bad batch / task");
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(pred && y && dlogit, DCTR_E_NULL, "bce_grad: null pointer");
     hipLaunchKernelGGL(bce_grad_kernel, dim3((unsigned)dctr_ceil_div(batch, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, pred,
-                       y, batch, (int)task, dlogit, loss_sum, dlogit_sum);
+                       y, weight, batch, (int)task, dlogit, loss_sum, dlogit_sum);
     return dctr_launch_status("dctr_bce_grad");
+}
+
+extern "C" int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
+                             float* dlogit_sum, void* stream) {
+    return dctr_bce_grad_w(pred, y, nullptr, batch, task, dlogit, loss_sum, dlogit_sum, stream);
 }
 
 extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void* stream) {

@@ -999,5 +999,6 @@ class Model(object):
     @on_model_device
     def train_on_batch(self, x, y, **kwargs):
         from .training import fit_model
-        h = fit_model(self, x, y, batch_size=None, epochs=1, verbose=0, shuffle=False)
+        extra = {k: kwargs[k] for k in ("sample_weight", "class_weight") if kwargs.get(k) is not None}
+        h = fit_model(self, x, y, batch_size=None, epochs=1, verbose=0, shuffle=False, **extra)
         return h.history["loss"][-1]

@@ -809,12 +809,17 @@ def din_attention_gather(hist_ids, query_ids, hist_tables, query_tables, mask_ze
 # ---------------------------------------------------------------------------------------------
 # backward + optimizer (include/dctr.h, last section)
 # ---------------------------------------------------------------------------------------------
-def bce_grad(pred, y, dlogit, loss_sum=None, dlogit_sum=None, task="binary"):
+def bce_grad(pred, y, dlogit, loss_sum=None, dlogit_sum=None, task="binary", weight=None):
     """d(mean loss)/d(logit) for PredictionLayer + binary_crossentropy (or mse); the optional device floats accumulate
-    the summed loss and the summed dlogit (= gradient of the global bias)."""
+    the summed loss and the summed dlogit (= gradient of the global bias).  ``weight`` [B] float32: tf.keras' per-sample
+    weights (loss = sum w_b l_b / B)."""
     _dev_check(pred, y, dlogit)
-    _C.check(_C.lib().dctr_bce_grad(_ptr(pred), _ptr(y), pred.numel(), 0 if task == "binary" else 1, _ptr(dlogit),
-                                    _ptr(loss_sum), _ptr(dlogit_sum), _C.stream_ptr()), "dctr_bce_grad")
+    if weight is not None:
+        _dev_check(weight)
+        if weight.dtype != torch.float32 or weight.numel() != pred.numel() or not weight.is_contiguous():
+            raise ValueError("bce_grad: weight must be a contiguous float32 tensor of the batch's length")
+    _C.check(_C.lib().dctr_bce_grad_w(_ptr(pred), _ptr(y), _ptr(weight), pred.numel(), 0 if task == "binary" else 1, _ptr(dlogit),
+                                      _ptr(loss_sum), _ptr(dlogit_sum), _C.stream_ptr()), "dctr_bce_grad_w")
 
 
 def make_field_grads(entries, device):

@@ -346,10 +346,10 @@ _OPTS = {"adam": lambda p: torch.optim.Adam(p, lr=1e-3, eps=1e-7), "adagrad": la
          "sgd": lambda p: torch.optim.SGD(p, lr=1e-2), "rmsprop": lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.9, eps=1e-7)}
 
 
-def permute_staged_(staged, yt, perm):
+def permute_staged_(staged, yt, perm, wt=None):
     """Row permutation, IN PLACE, of everything staged per sample (id matrix [F,N], dense [N,ND], sequences, lengths, weights)
-    and of the labels: tf.keras' fit(shuffle=True) permutes samples each epoch.  In place so that device pointers cached by
-    the launch-argument structs stay valid; ``perm``: int64 tensor on the staged tensors' device."""
+    and of the labels (and per-sample loss weights ``wt``): tf.keras' fit(shuffle=True) permutes samples each epoch.  In place so
+    that device pointers cached by the launch-argument structs stay valid; ``perm``: int64 tensor on the staged tensors' device."""
     if staged.ids is not None:
         staged.ids.copy_(staged.ids.index_select(1, perm))
     if staged.dense is not None:
@@ -358,9 +358,11 @@ def permute_staged_(staged, yt, perm):
         for k in group:
             group[k].copy_(group[k].index_select(0, perm))
     yt.copy_(yt.index_select(0, perm))
+    if wt is not None:
+        wt.copy_(wt.index_select(0, perm))
 
 
-def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
+def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, steps=None, initial_epoch=0):
     """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
     moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation.
     The reported loss is the data loss (the l2 penalties enter the gradients, not this number)."""
@@ -368,24 +370,29 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
     tr = getattr(model, "_hip_trainer", None)
     if tr is None or tr.kind != model._compiled["optimizer"].lower():
         tr = model._hip_trainer = HipTrainer(model, model._compiled["optimizer"])
-    for ep in range(epochs):
+    for ep in range(initial_epoch, epochs):
         if shuffle:
-            permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
+            permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device), wt)
         # the epoch's loss: dctr_bce_grad adds every batch's summed loss into that batch's element of ONE device vector (summed in
         # float64 at the end of the epoch; step() refreshes the weight-derived buffers itself) — no per-step zero / divide / add launches
         # and no host round trip for it
-        n_steps = (n_tr + bs - 1) // bs
+        n_steps = (n_tr + bs - 1) // bs if steps is None else steps
         tot = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=model.device)
+        seen = 0
         for i, lo in enumerate(range(0, n_tr, bs)):
+            if i >= n_steps:
+                break
             hi = min(n_tr, lo + bs)
-            tr.step(staged, int(lo), int(hi), yt[lo:hi], loss_acc=tot[i:i + 1])
+            tr.step(staged, int(lo), int(hi), yt[lo:hi], loss_acc=tot[i:i + 1], weight=None if wt is None else wt[lo:hi])
+            seen += hi - lo
         model._check_status()
-        if epoch_end(ep, float(tot.double().sum().item()) / max(n_tr, 1)):
+        if epoch_end(ep, float(tot.double().sum().item()) / max(seen, 1)):
             break
     return epoch_end.finish()
 
 
-_FIT_UNSUPPORTED = ("sample_weight", "class_weight", "steps_per_epoch", "validation_steps", "initial_epoch")
+_FIT_UNSUPPORTED = ("validation_steps",)
+_FIT_OPTIONS = ("sample_weight", "class_weight", "steps_per_epoch", "initial_epoch")
 _FIT_IGNORED = ("workers", "use_multiprocessing", "max_queue_size", "validation_batch_size", "validation_freq")
 
 
@@ -447,10 +454,10 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     if model._compiled is None:
         raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
     for k, v in kwargs.items():
-        if k in _FIT_IGNORED:
+        if k in _FIT_IGNORED or k in _FIT_OPTIONS:
             continue
         if k in _FIT_UNSUPPORTED:
-            if v is None or (k == "initial_epoch" and v == 0):
+            if v is None:
                 continue
             raise NotImplementedError("fit(%s=...) is not implemented by this build (it would silently train on a different "
                                       "objective if ignored)" % k)
@@ -463,6 +470,8 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     tr = {k: np.asarray(v)[:n_tr] for k, v in feed.items()}
     staged = model.stage(tr)
     yt = torch.from_numpy(y[:n_tr]).to(model.device)
+    w = loss_weights(y[:n_tr], kwargs.get("sample_weight"), kwargs.get("class_weight"), n, n_tr)
+    wt = None if w is None else torch.from_numpy(w).to(model.device)
     loss_name0 = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
     from . import training_hip
     if (getattr(model, "hip_training", True) and isinstance(model._compiled["optimizer"], str)
@@ -473,11 +482,44 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     else:
         fit = _fit_torch
     bs = int(batch_size) if batch_size else n_tr
+    steps, initial_epoch = kwargs.get("steps_per_epoch"), int(kwargs.get("initial_epoch") or 0)
+    if steps is not None:
+        steps = int(steps)
+        if steps < 1 or steps > (n_tr + bs - 1) // max(bs, 1):
+            # tf.keras re-creates the iterator over the arrays every epoch and stops training with "Your input ran out of data" when an
+            # epoch asks for more batches than they hold: an error here instead of a silently shorter run
+            raise ValueError("fit(steps_per_epoch=%d): the arrays hold %d batches of %d" % (steps, (n_tr + bs - 1) // max(bs, 1), bs))
+    if initial_epoch < 0:
+        raise ValueError("fit(initial_epoch=%d)" % initial_epoch)
     return fit(model, staged, yt, n_tr, bs, epochs, shuffle,
-               _EpochEnd(model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks))
+               _EpochEnd(model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks),
+               wt=wt, steps=steps, initial_epoch=initial_epoch)
 
 
-def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
+def loss_weights(y, sample_weight, class_weight, n, n_tr):
+    """The per-sample loss weights of tf.keras.Model.fit (the reference's models are Keras Models; fit is inherited): ``sample_weight``
+    [n] (sliced like the inputs by validation_split) times ``class_weight[label]`` (a dict label -> weight; every label present must
+    have an entry, as Keras requires).  None when neither is given.  float32 [n_tr]."""
+    if sample_weight is None and not class_weight:
+        return None
+    w = np.ones(n_tr, dtype=np.float32)
+    if sample_weight is not None:
+        sw = np.asarray(sample_weight, dtype=np.float32).reshape(-1)
+        if sw.shape[0] != n:
+            raise ValueError("fit(sample_weight=...): %d weights for %d samples" % (sw.shape[0], n))
+        w *= sw[:n_tr]
+    if class_weight:
+        cw = {float(k): float(v) for k, v in dict(class_weight).items()}
+        labels = np.unique(y)
+        missing = [float(v) for v in labels if float(v) not in cw]
+        if missing:
+            raise ValueError("fit(class_weight=...): no weight for the labels %s" % missing)
+        for lab in labels:
+            w[y == lab] *= np.float32(cw[float(lab)])
+    return w
+
+
+def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, steps=None, initial_epoch=0):
     """fit() on torch autograd over ``model_logits`` (models / options outside the HIP step).  Device-agnostic torch code: the
     CPU suite drives it directly on CPU-built models; evaluate() of a validation split needs the GPU forward."""
     frozen = frozen_weights(model)
@@ -494,19 +536,22 @@ def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end):
     loss_name = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
     regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
     try:
-        for ep in range(epochs):
+        for ep in range(initial_epoch, epochs):
             if shuffle:
-                permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device))
+                permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device), wt)
             tot, cnt = 0.0, 0
-            for lo in range(0, n_tr, bs):
+            for i, lo in enumerate(range(0, n_tr, bs)):
+                if steps is not None and i >= steps:
+                    break
                 hi = min(n_tr, lo + bs)
                 model._begin()
                 logit = model_logits(model, staged, int(lo), int(hi), training=True)
                 if loss_name in ("binary_crossentropy", "logloss") and model.task == "binary":
-                    loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt[lo:hi])
+                    loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt[lo:hi], reduction="none")
                 else:
                     pred = torch.sigmoid(logit) if model.task == "binary" else logit
-                    loss = torch.nn.functional.mse_loss(pred, yt[lo:hi])
+                    loss = torch.nn.functional.mse_loss(pred, yt[lo:hi], reduction="none")
+                loss = (loss if wt is None else loss * wt[lo:hi]).mean()      # Keras: sum_b w_b l_b / B
                 for t, l2 in regs:                                  # keras adds the regularisation losses to the loss
                     loss = loss + l2 * (t * t).sum()
                 opt.zero_grad(set_to_none=True)

@@ -407,7 +407,8 @@ class HipTrainer(object):
         if acc is None:
             buf["loss"].zero_()
         ops.bce_grad(buf["pred"], y, buf["dlogit"], loss_sum=buf["loss"] if acc is None else acc,
-                     dlogit_sum=None if self.p_gbias is None else self.p_gbias.g, task="binary" if binary else "regression")
+                     dlogit_sum=None if self.p_gbias is None else self.p_gbias.g, task="binary" if binary else "regression",
+                     weight=getattr(self, "_sample_weight", None))
 
     def _deepfm_forward_backward(self, ws, buf, y, binary):
         model, sp = self.model, self.model.stage_plan
@@ -621,13 +622,15 @@ class HipTrainer(object):
                             save_u=None if su is None else su.data_ptr(), save_x=None if sx is None else sx.data_ptr())
         _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
 
-    def step(self, staged, lo, hi, y, apply=True, loss_acc=None):
+    def step(self, staged, lo, hi, y, apply=True, loss_acc=None, weight=None):
         """One optimizer step on rows [lo, hi) of the staged inputs; y: device float tensor [hi-lo].  Returns the mean
         loss of the batch BEFORE the update (a device tensor; no host synchronisation here).  ``apply=False`` stops
         after the backward pass and leaves the gradients in the ``g`` buffers (tests).  ``loss_acc`` (a device float32 tensor of
         one element): the batch's SUMMED loss is added to it instead — no per-step zero / divide launches, nothing returned
-        (fit() keeps one accumulator per epoch)."""
+        (fit() keeps one accumulator per epoch).  ``weight``: device float32 [hi-lo], tf.keras' per-sample weights of the batch
+        (loss = sum w_b l_b / B: dctr_bce_grad_w)."""
         self._loss_acc = loss_acc
+        self._sample_weight = weight
         model, sp = self.model, self.model.stage_plan
         model._trainer_owns_cross = self.is_dcn            # (_DCN._begin: no re-packing of the cross weights for this call)
         model._trainer_step = True          # (_begin: only what the step reads — no inference-form BatchNormalization scale / shift, no

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 8
+#define DCTR_ABI_VERSION 9
 
 enum {
     DCTR_OK = 0,
@@ -540,6 +540,11 @@ int dctr_din_attn_gather_fwd(const dctr_din_attn_args_t* args, const dctr_din_ga
  * dlogit_sum += sum_b dlogit[b] (= gradient of PredictionLayer's global_bias, layers/core.py:250-259). */
 int dctr_bce_grad(const float* pred, const float* y, int64_t batch, int32_t task, float* dlogit, float* loss_sum,
                   float* dlogit_sum, void* stream);
+/* ABI 9 — the same with tf.keras' per-sample weights (Model.fit(sample_weight=, class_weight=), which the reference's models inherit):
+ * loss = sum_b weight[b] * loss_b / batch (Keras' SUM_OVER_BATCH_SIZE reduction divides by the batch size, not by the summed weights),
+ * so loss_sum += sum_b weight[b] loss_b and dlogit[b] = weight[b] * d(loss_b)/d(logit_b) / batch.  weight == NULL: dctr_bce_grad. */
+int dctr_bce_grad_w(const float* pred, const float* y, const float* weight, int64_t batch, int32_t task, float* dlogit,
+                    float* loss_sum, float* dlogit_sum, void* stream);
 
 /* `touched` (ABI 6; optional, tables with dim % 4 == 0): one byte per 16-B group of g_table ([vocab * dim / 4] bytes, zero-initialised
  * by the caller).  The scatter kernels set the bytes of the groups they add to; dctr_opt_multi then treats groups with a clear byte as a

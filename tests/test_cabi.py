@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, s), "libdctr_hip.so does not export %s" % s
         assert s in _C.SYMBOLS, "deepctr_amd/_C.py has no binding for %s" % s
     assert set(_C.SYMBOLS) == set(syms)
-    assert lib.dctr_abi_version() == _C.ABI_VERSION == 8
+    assert lib.dctr_abi_version() == _C.ABI_VERSION == 9
     assert lib.dctr_target_arch() == b"gfx950"
 
 
@@ -59,6 +59,9 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.dctr_bi_interaction_fwd(None, 0, 8, 2, 4, None, 4, None) == 0
     assert lib.dctr_bce_grad(None, None, 4, 0, None, None, None, None) == -1
     assert lib.dctr_bce_grad(None, None, 4, 5, None, None, None, None) == -2
+    assert lib.dctr_bce_grad_w(None, None, None, 4, 0, None, None, None, None) == -1
+    assert lib.dctr_bce_grad_w(None, None, None, -1, 0, None, None, None, None) == -2
+    assert lib.dctr_bce_grad_w(None, None, None, 0, 1, None, None, None, None) == 0
     assert lib.dctr_opt_multi(9, None, 0, 0, 0.001, 0.9, 0.999, 1e-7, 1, None) == -4
     assert b"optimizer kind 9" in lib.dctr_last_error()
     assert lib.dctr_mlp_bwd(None, None) == -1 and lib.dctr_cin_bwd(None, None) == -1 and lib.dctr_crossnet_bwd(None, None) == -1
@@ -178,7 +181,7 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     src.write_text('#include <stdio.h>\n#include <string.h>\n#include "dctr.h"\n'
                    "int main(void) {\n"
                    "    dctr_gather_fm_args_t g; memset(&g, 0, sizeof g); g.batch = 4;\n"
-                   "    if (dctr_abi_version() != DCTR_ABI_VERSION || DCTR_ABI_VERSION != 8 || strcmp(dctr_target_arch(), \"gfx950\") != 0) return 1;\n"
+                   "    if (dctr_abi_version() != DCTR_ABI_VERSION || DCTR_ABI_VERSION != 9 || strcmp(dctr_target_arch(), \"gfx950\") != 0) return 1;\n"
                    "    if (dctr_fm_fwd(NULL, 4, 8, 2, 4, NULL, NULL) != DCTR_E_NULL) return 2;      /* rejected before any launch */\n"
                    "    if (dctr_embed_gather_fm(&g, NULL) != DCTR_E_DIM) return 3;\n"
                    "    if (strlen(dctr_last_error()) == 0) return 4;\n"

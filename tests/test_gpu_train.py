@@ -32,6 +32,65 @@ def test_bce_grad(device):
         assert_close(dl.cpu().numpy(), 2 * (p.astype(np.float64) - y) / B, rtol=1e-6, atol=1e-9, what="mse dlogit")
 
 
+def test_bce_grad_with_sample_weights(device):
+    """dctr_bce_grad_w: tf.keras' per-sample weights, loss = sum_b w_b l_b / B (fit(sample_weight=, class_weight=))."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(21)
+    for B in (1, 300, 4097):
+        p = rng.uniform(0.001, 0.999, B).astype(np.float32)
+        y = (rng.rand(B) > 0.5).astype(np.float32)
+        w = rng.uniform(0, 3, B).astype(np.float32)
+        w[B // 2] = 0
+        dl, dl0 = torch.empty(B, device=device), torch.empty(B, device=device)
+        ls, ds = torch.zeros(1, device=device), torch.zeros(1, device=device)
+        ops.bce_grad(dev(p, device), dev(y, device), dl, ls, ds, weight=dev(w, device))
+        ops.bce_grad(dev(p, device), dev(y, device), dl0, None, None)
+        assert torch.equal(dl, dl0 * dev(w, device))                              # the unweighted gradient times w, bit for bit
+        pc = np.clip(p.astype(np.float64), 1e-7, 1 - 1e-7)
+        per = -(y * np.log(pc) + (1 - y) * np.log(1 - pc))
+        assert_close(ls.cpu().numpy(), [(per * w).sum()], rtol=1e-4, atol=1e-5, what="weighted loss")
+        assert_close(ds.cpu().numpy(), [(w * (p.astype(np.float64) - y) / B).sum()], rtol=1e-4, atol=1e-6, what="weighted dlogit sum")
+        ops.bce_grad(dev(p, device), dev(y, device), dl, None, None, task="regression", weight=dev(w, device))
+        assert_close(dl.cpu().numpy(), w * 2 * (p.astype(np.float64) - y) / B, rtol=1e-6, atol=1e-9, what="weighted mse dlogit")
+        with pytest.raises(ValueError):
+            ops.bce_grad(dev(p, device), dev(y, device), dl, None, None, weight=dev(np.ones(B + 1, np.float32), device))
+
+
+def test_fit_sample_and_class_weights_on_the_hip_step(device):
+    """fit(sample_weight=, class_weight=, steps_per_epoch=, initial_epoch=) on the HIP training step against the torch-autograd
+    step from the same start (SGD, no shuffle: the same batches in the same order)."""
+    rng = np.random.RandomState(22)
+    n = 1024
+    model, cols = _deepfm(device, E=16, hidden=(64, 32))
+    feed = _feed(rng, cols, n)
+    y = ((feed["C0"] % 2) ^ (feed["I0"] > 0.5)).astype(np.float32)
+    sw = rng.uniform(0.2, 2.0, n).astype(np.float32)
+    cw = {0: 0.5, 1: 2.0}
+    kw = dict(batch_size=256, epochs=3, verbose=0, shuffle=False, sample_weight=sw, class_weight=cw, steps_per_epoch=3, initial_epoch=1)
+    model.compile("sgd", "binary_crossentropy")
+    h = model.fit(feed, y, **kw)
+    assert getattr(model, "_hip_trainer", None) is not None, "fit() did not take the HIP training step"
+    ref, _ = _deepfm(device, E=16, hidden=(64, 32))
+    ref.hip_training = False
+    ref.compile("sgd", "binary_crossentropy")
+    h2 = ref.fit(feed, y, **kw)
+    assert h.epoch == h2.epoch == [1, 2]
+    # the first record: mean over the 768 rows of the epoch of w_b l_b, before most of the movement — and the two paths agree
+    assert_close(np.array(h.history["loss"]), np.array(h2.history["loss"]), rtol=2e-4, atol=1e-5, what="weighted epoch losses")
+    a, b = model.get_weights_by_name(), ref.get_weights_by_name()
+    for k in a:
+        assert_close(a[k], b[k], rtol=1e-3, atol=2e-5, what=k)
+    # an unweighted run from the same start ends somewhere else
+    plain, _ = _deepfm(device, E=16, hidden=(64, 32))
+    plain.compile("sgd", "binary_crossentropy")
+    plain.fit(feed, y, batch_size=256, epochs=3, verbose=0, shuffle=False, steps_per_epoch=3, initial_epoch=1)
+    c = plain.get_weights_by_name()
+    assert any(not np.allclose(a[k], c[k], rtol=1e-3, atol=2e-5) for k in a)
+    # train_on_batch takes the weights as well (tf.keras.Model.train_on_batch(x, y, sample_weight, class_weight))
+    l0 = model.train_on_batch(feed, y, sample_weight=sw)
+    assert np.isfinite(l0)
+
+
 def test_adam_step_matches_torch_adam(device):
     from deepctr_amd import ops
     rng = np.random.RandomState(2)

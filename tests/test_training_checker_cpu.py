@@ -283,9 +283,84 @@ def test_frozen_embedding_and_fit_keyword_contract():
     real = _C.require_device
     _C.require_device = lambda: None
     try:
-        with pytest.raises(NotImplementedError, match="sample_weight"):
-            training.fit_model(model, feed, y, sample_weight=np.ones(n))
+        with pytest.raises(NotImplementedError, match="validation_steps"):
+            training.fit_model(model, feed, y, validation_steps=3)
         with pytest.raises(TypeError, match="bogus"):
             training.fit_model(model, feed, y, bogus=1)
+    finally:
+        _C.require_device = real
+
+
+def test_fit_loss_weights_steps_and_initial_epoch():
+    """tf.keras.Model.fit's sample_weight / class_weight / steps_per_epoch / initial_epoch (the reference's models inherit fit):
+    loss = sum_b w_b l_b / B (SUM_OVER_BATCH_SIZE), class weights looked up by label and multiplied into the sample weights,
+    an epoch of ``steps_per_epoch`` batches, epochs numbered from ``initial_epoch``."""
+    import pytest
+    from deepctr_amd import engine, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM
+    y = np.array([0, 1, 1, 0, 1, 0], dtype=np.float32)
+    sw = np.array([1, 2, 3, 4, 5, 6, 7, 8], dtype=np.float32)
+    assert training.loss_weights(y, None, None, 8, 6) is None
+    assert np.array_equal(training.loss_weights(y, sw, None, 8, 6), sw[:6])
+    assert np.array_equal(training.loss_weights(y, None, {0: 0.5, 1: 3}, 8, 6), [0.5, 3, 3, 0.5, 3, 0.5])
+    assert np.array_equal(training.loss_weights(y, sw, {0: 0.5, 1: 3}, 8, 6), sw[:6] * [0.5, 3, 3, 0.5, 3, 0.5])
+    with pytest.raises(ValueError, match="no weight for the labels"):
+        training.loss_weights(y, None, {1: 3}, 8, 6)
+    with pytest.raises(ValueError, match="5 weights for 8"):
+        training.loss_weights(y, sw[:5], None, 8, 6)
+
+    rng = np.random.RandomState(11)
+    n, E = 96, 4
+    cols = [SparseFeat("a", 20, E), SparseFeat("b", 9, E), DenseFeat("d", 2)]
+    feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 9, n), "d": rng.rand(n, 2).astype(np.float32)}
+    yv = (feed["b"] % 2).astype(np.float32)
+    w = (0.25 + rng.rand(n)).astype(np.float32)
+
+    def run(wt, steps=None, initial_epoch=0, epochs=1, bs=n):
+        model = DeepFM(cols, cols, dnn_hidden_units=(8,), l2_reg_linear=0, l2_reg_embedding=0, seed=7, device=torch.device("cpu"))
+        model.compile("sgd", "binary_crossentropy")
+        staged = engine.Staged(n)
+        model._stage_inputs(feed, staged)
+        h = training._fit_torch(model, staged, torch.from_numpy(yv.copy()), n, bs, epochs, False,
+                                training._EpochEnd(model, feed, yv, n, 0, bs, epochs, 0, None, None),
+                                wt=None if wt is None else torch.from_numpy(wt.copy()), steps=steps, initial_epoch=initial_epoch)
+        return model, staged, h
+
+    # one full-batch step: the reported loss is the loss BEFORE the update -> sum w l / B against the per-sample losses of the same weights
+    model, staged, h = run(w)
+    ref, staged0, h0 = run(None)
+    fresh = DeepFM(cols, cols, dnn_hidden_units=(8,), l2_reg_linear=0, l2_reg_embedding=0, seed=7, device=torch.device("cpu"))
+    st = engine.Staged(n)
+    fresh._stage_inputs(feed, st)
+    fresh._begin()
+    with torch.no_grad():
+        per = torch.nn.functional.binary_cross_entropy_with_logits(training.model_logits(fresh, st, 0, n), torch.from_numpy(yv),
+                                                                   reduction="none").numpy()
+    assert abs(h0.history["loss"][0] - per.mean()) < 1e-6
+    assert abs(h.history["loss"][0] - (per * w).sum() / n) < 1e-6
+    # a weight of zero takes a sample out of the gradient: rows of table "a" only zero-weight samples touch do not move
+    wz = np.ones(n, dtype=np.float32)
+    wz[feed["a"] == feed["a"][0]] = 0
+    mz, _, _ = run(wz)
+    row = int(feed["a"][0])
+    assert np.array_equal(mz.get_weights_by_name()["sparse_emb_a/embeddings"][row], fresh.get_weights_by_name()["sparse_emb_a/embeddings"][row])
+    assert not np.array_equal(ref.get_weights_by_name()["sparse_emb_a/embeddings"][row],
+                              fresh.get_weights_by_name()["sparse_emb_a/embeddings"][row])
+    # steps_per_epoch = 2 of the 3 batches, epochs 1..3 of 4: three records numbered 1, 2, 3; the first equals the mean over 64 rows
+    _, _, hs = run(None, steps=2, initial_epoch=1, epochs=4, bs=32)
+    assert hs.epoch == [1, 2, 3] and len(hs.history["loss"]) == 3
+    _, _, hf = run(None, steps=None, epochs=1, bs=32)
+    assert hs.history["loss"][0] != hf.history["loss"][0]
+    # fit_model's argument checks (before anything touches a device)
+    from deepctr_amd import _C
+    real = _C.require_device
+    _C.require_device = lambda: None
+    try:
+        ref.compile("sgd", "binary_crossentropy")
+        with pytest.raises(ValueError, match="steps_per_epoch=9"):
+            training.fit_model(ref, feed, yv, batch_size=32, steps_per_epoch=9)
+        with pytest.raises(ValueError, match="weights for"):
+            training.fit_model(ref, feed, yv, batch_size=32, sample_weight=np.ones(3))
     finally:
         _C.require_device = real
