@@ -41,6 +41,7 @@ SOURCES = [
     "chain_kernels_r2w8_m42_x.hip",
     "chain_kernels_r2w8_m42_q.hip",
     "chain_kernels_r2w8_m42_t.hip",
+    "chain_kernels_r2w8_m42_w.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "cin_bwd_kernels.hip",

@@ -523,7 +523,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         const char* table = reinterpret_cast<const char*>(sgpr64(tw.x, tw.y));
         if constexpr (KEEP_LC) {
             const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bp4_ + (uint32_t)((32 * half + 16 * nt) << 2)), (int)idc);
-            X.x[nt] = *(gbl_f4_t)(table + (((uint64_t)idv << (E == 16 ? 6 : 7)) + (uint64_t)(64 * h) + gg16_));
+            X.x[nt] = *(gbl_f4_t)(table + (((uint64_t)idv << (E == 16 ? 6 : E == 32 ? 7 : 8)) + (uint64_t)(64 * h) + gg16_));
         } else {
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -1058,16 +1058,22 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             if constexpr (BF3) {
                 CHAIN_STEP0_BF(0, XA, XB);
                 if (pr_ * PAIR + 1 < NB) CHAIN_STEP0_BF(1, XB, XA);
-                if constexpr (EB == 2) {
+                if constexpr (EB >= 2) {
                     if (pr_ * PAIR + 2 < NB) CHAIN_STEP0_BF(2, XA, XB);
                     if (pr_ * PAIR + 3 < NB) CHAIN_STEP0_BF(3, XB, XA);
                 }
             } else {
                 CHAIN_STEP0(0, XA, XB);
                 if (pr_ * PAIR + 1 < NB) CHAIN_STEP0(1, XB, XA);
-                if constexpr (EB == 2) {
+                if constexpr (EB >= 2) {
                     if (pr_ * PAIR + 2 < NB) CHAIN_STEP0(2, XA, XB);
                     if (pr_ * PAIR + 3 < NB) CHAIN_STEP0(3, XB, XA);
+                }
+                if constexpr (EB == 4) {               // embedding_dim 64: eight k-blocks per field pair
+                    if (pr_ * PAIR + 4 < NB) CHAIN_STEP0(4, XA, XB);
+                    if (pr_ * PAIR + 5 < NB) CHAIN_STEP0(5, XB, XA);
+                    if (pr_ * PAIR + 6 < NB) CHAIN_STEP0(6, XA, XB);
+                    if (pr_ * PAIR + 7 < NB) CHAIN_STEP0(7, XB, XA);
                 }
             }
             idc = idcn;
@@ -1515,6 +1521,7 @@ int launch_r2w4_m42(const ChainParams& p, int E, int M2, unsigned blocks, hipStr
 int launch_r2w8_m42x(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // CROSS (chain_kernels_r2w8_m42_x.hip)
 int launch_r2w8_m42q(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 8 / 4 (chain_kernels_r2w8_m42_q.hip)
 int launch_r2w8_m42t(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // sigmoid / tanh DNNs (chain_kernels_r2w8_m42_t.hip)
+int launch_r2w8_m42w(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 64 (chain_kernels_r2w8_m42_w.hip)
 // the exploratory bf16 x 3 variant (chain_kernels_r2w8_m42_bf3.hip): packs the weights into `ws` (if `pack`), then launches
 size_t bf3_workspace_bytes(int in_dim);
 int launch_r2w8_m42_bf3(const ChainParams& p, int E, void* ws, bool pack, unsigned blocks, hipStream_t stream);

@@ -21,7 +21,7 @@ static bool widths(const dctr_mlp_args_t* a, int shape, int* M) {
 // 1: the row-chained kernel can take this call (all of its rows); 0: not eligible
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
     const int E = g->uniform_dim;
-    if (E != 16 && E != 32 && E != 8 && E != 4) return 0;
+    if (E != 16 && E != 32 && E != 8 && E != 4 && E != 64) return 0;
     if (g->any_hash || !a->has_head || a->save_acts != nullptr) return 0;
     if (g->ids_stride_b != 1) return 0;                     // (rows of the id matrix contiguous: chain_device.h, request_pair_ids)
     const bool expact = a->activation == DCTR_ACT_SIGMOID || a->activation == DCTR_ACT_TANH;
@@ -29,7 +29,9 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     int M[3];
     if (!widths(a, forced ? a->tile_rows : 0, M)) return 0;
     // sigmoid / tanh DNNs: the m42 kernels, fp32, embedding_dim 16 / 32, no folded CrossNet
-    if (expact && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && E >= 16 && a->cross_layers == 0)) return 0;
+    if (expact && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && (E == 16 || E == 32) && a->cross_layers == 0)) return 0;
+    // embedding_dim 64 (four k-blocks per field): the m42 kernels, fp32, ReLU / linear, no folded CrossNet
+    if (E == 64 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && a->cross_layers == 0)) return 0;
     if (a->precision != 0 && !(M[0] == 4 && M[1] == 2 && M[2] == 1 && a->tile_rows != 128 && a->bn_scale == nullptr)) return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
     if (a->cross_layers > 0 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && E >= 16)) return 0;   // CROSS: the m42 kernels
@@ -158,6 +160,7 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     if (a->cross_layers > 0) return launch_r2w8_m42x(p, E, M[2], blocks, stream);
     if (a->activation == DCTR_ACT_SIGMOID || a->activation == DCTR_ACT_TANH) return launch_r2w8_m42t(p, E, M[2], blocks, stream);
     if (E < 16) return launch_r2w8_m42q(p, E, M[2], blocks, stream);
+    if (E == 64) return launch_r2w8_m42w(p, E, M[2], blocks, stream);
     if (shape == 128) return launch_r2w4_m42(p, E, M[2], blocks, stream);
     if (M[0] == 4) return M[1] == 2 ? launch_r2w8_m42(p, E, M[2], blocks, stream) : launch_r2w8_m41(p, E, M[2], blocks, stream);
     return M[1] == 2 ? launch_r2w8_m22(p, E, M[2], blocks, stream) : launch_r2w8_m21(p, E, M[2], blocks, stream);

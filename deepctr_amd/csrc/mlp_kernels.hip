@@ -167,7 +167,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         DCTR_REQUIRE(a->precision == 0 || ok, DCTR_E_UNSUPPORTED,
                      "embed_mlp_fwd: precision 1 / 2 (bf16x3, exploratory) exists for the row-chained kernel with DNN 256-128-64 only");
         DCTR_REQUIRE(!forced || ok, DCTR_E_UNSUPPORTED,
-                     "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 16 / 32, units 256-128-64, a head", a->tile_rows);
+                     "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 4 / 8 / 16 / 32 / 64, instantiated units, a head", a->tile_rows);
         if (ok) {
             const int rc = dctr_chain::launch(a, ga, fm_used, lin_used, a->tile_rows, (hipStream_t)stream);
             if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_CHAIN;
@@ -218,6 +218,13 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         if (half > full) { p.k_split = split; lda = lda_split; break; }
         if (full > 0) { p.k_split = 0; lda = lda_full; break; }
         if (rt == 1) break;
+    }
+    if (lda == 0 && ga != nullptr && a->tile_rows == 0 && dctr_chain::eligible(a, ga, true)) {
+        // a DNN input too wide for the LDS tile (e.g. 33 fields of embedding_dim 64: [16, 2128] x 2 floats) on a launch below 64 rows
+        // per CU: the row-chained kernel streams layer 0 by k-block and holds no input tile — its tail phase takes the rows
+        const int rc = dctr_chain::launch(a, ga, fm_used, lin_used, 0, (hipStream_t)stream);
+        if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_CHAIN;
+        return rc;
     }
     DCTR_REQUIRE(lda > 0, DCTR_E_UNSUPPORTED,
                  "mlp_fwd: layer widths do not fit the 160 KiB LDS tile (or are too small for the gather partial sums)");

@@ -139,16 +139,16 @@ class FusedForward(object):
         the widths are already instantiated or cannot be."""
         units = [int(u) for u in units]
         sp = self.stage_plan
-        if (sp.uniform_dim not in (4, 8, 16, 32) or len(units) not in (2, 3) or activation not in ("relu", "linear", "sigmoid", "tanh")
+        if (sp.uniform_dim not in (4, 8, 16, 32, 64) or len(units) not in (2, 3) or activation not in ("relu", "linear", "sigmoid", "tanh")
                 or self.dnn.dice_layers):
             return None
-        if activation in ("sigmoid", "tanh") and sp.uniform_dim < 16:
+        if activation in ("sigmoid", "tanh") and sp.uniform_dim not in (16, 32):
             return None
         if units[0] > 256 or units[1] > 128 or (len(units) == 3 and units[2] > 128):
             return None
         target = [128 if units[0] <= 128 else 256, 64 if units[1] <= 64 else 128]
-        if sp.uniform_dim < 16 or activation in ("sigmoid", "tanh"):
-            # embedding_dim 4 / 8, sigmoid / tanh DNNs: the row-chained kernel has them in its 256-128-x instantiations only (a padded
+        if sp.uniform_dim not in (16, 32) or activation in ("sigmoid", "tanh"):
+            # embedding_dim 4 / 8 / 64, sigmoid / tanh DNNs: the row-chained kernel has them in its 256-128-x instantiations only (a padded
             # feature's act(0) meets zero rows of the next layer's kernel, whatever the activation)
             target = [256, 128]
         if len(units) == 3:

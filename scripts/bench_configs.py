@@ -157,6 +157,19 @@ def main():
             init_on_device(m)
             run_span("C2 DeepFM DNN 256-128-64 %s" % act, m, criteo(rng, 131072), 4096, dnn_flop=dnn_flop(429))
             del m
+    if "c2_e64" in want:     # embedding_dim 64 (row-chained kernel, EB = 4) beside the streaming kernel it took before, on the same box
+        cols64 = [SparseFeat("C%d" % i, 100000, 64) for i in range(1, 27)] + [DenseFeat("I%d" % i, 1) for i in range(1, 14)]
+        m = DeepFM(cols64, cols64, device=dev)
+        init_on_device(m)
+        feed = criteo(rng, 131072)
+        run_span("C2 DeepFM E=64", m, feed, 4096, dnn_flop=dnn_flop(1677))
+        for tr in (64, 32):                            # what the same call ran on before: the streaming kernel if it takes the shape, else the tile kernel
+            m.tile_rows = tr
+            try:
+                run_span("C2 DeepFM E=64 (tile_rows=%d)" % tr, m, feed, 4096, dnn_flop=dnn_flop(1677))
+            except Exception as e:                     # noqa: BLE001 — a lab script: report and go on
+                print("C2 DeepFM E=64 (tile_rows=%d): %s" % (tr, e), flush=True)
+        del m
     if "afm" in want:       # a11 AFMLayer: 325 pairs x E = 16, attention_factor 8
         colsa = [SparseFeat("C%d" % i, 100000, 16) for i in range(1, 27)]
         m = AFM(colsa, colsa, device=dev)

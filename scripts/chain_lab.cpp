@@ -31,6 +31,7 @@ int launch_r2w8_m22(const ChainParams&, int, int, unsigned, hipStream_t) { retur
 int launch_r2w8_m21(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m42x(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m42t(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+int launch_r2w8_m42w(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 size_t bf3_workspace_bytes(int) { return 0; }
 int launch_r2w8_m42_bf3(const ChainParams&, int, void*, bool, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 }

@@ -342,6 +342,10 @@ def test_round4_kernel_routes_are_chosen_from_the_model_shape():
     assert DeepFM(cols(8), cols(8), dnn_hidden_units=(256, 128, 64), device=cpu)._pad_spec is None
     assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50), device=cpu)._pad_spec == [128, 64]
     assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50, 7), device=cpu)._pad_spec == [128, 64, 64]
+    # embedding_dim 64 (four k-blocks per field): the 256-128-x instantiations, ReLU / linear
+    assert DeepFM(cols(64, F=12), cols(64, F=12), dnn_hidden_units=(100, 50), device=cpu)._pad_spec == [256, 128]
+    assert DeepFM(cols(64, F=12), cols(64, F=12), dnn_hidden_units=(256, 128, 64), device=cpu)._pad_spec is None
+    assert DeepFM(cols(64, F=12), cols(64, F=12), dnn_hidden_units=(100, 50), dnn_activation="tanh", device=cpu)._pad_spec is None
     # sigmoid / tanh DNNs: the EXPACT instantiations (256-128-x, embedding_dim 16 / 32); other activations stay off the kernel
     assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50), dnn_activation="tanh", device=cpu)._pad_spec == [256, 128]
     assert DeepFM(cols(32), cols(32), dnn_hidden_units=(256, 128, 64), dnn_activation="sigmoid", device=cpu)._pad_spec is None

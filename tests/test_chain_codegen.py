@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHAIN_UNITS = [("chain_kernels_r2w8_m42.hip", 256), ("chain_kernels_r2w8_m41.hip", 256), ("chain_kernels_r2w8_m22.hip", 256),
                ("chain_kernels_r2w8_m21.hip", 256), ("chain_kernels_r2w4_m42.hip", 512), ("chain_kernels_r2w8_m42_bf3.hip", 256),
-               ("chain_kernels_r2w8_m42_x.hip", 256), ("chain_kernels_r2w8_m42_q.hip", 256), ("chain_kernels_r2w8_m42_t.hip", 256)]
+               ("chain_kernels_r2w8_m42_x.hip", 256), ("chain_kernels_r2w8_m42_q.hip", 256), ("chain_kernels_r2w8_m42_t.hip", 256),
+               ("chain_kernels_r2w8_m42_w.hip", 256)]
 
 
 def test_chain_kernel_needs_no_scratch(tmp_path):

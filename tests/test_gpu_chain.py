@@ -509,6 +509,83 @@ def test_chain_kernel_small_embedding_dims_int64_ids_and_out_of_range(device):
     assert np.isfinite(model.predict(feed, batch_size=2048)).all()
 
 
+@pytest.mark.parametrize("V,n,F,ND,units", [
+    (3000, 65536 + 16384 + 77, 26, 13, (256, 128, 64)),         # the Criteo field set at embedding_dim 64: 104 embedding k-blocks + 1 dense
+    (500, 16384 + 129, 13, 0, (200, 80)),                       # odd field count (the last pair has one field), no dense features; padded widths
+    (500, 16384 + 64, 12, 20, (256, 64, 64)),                   # two dense k-blocks; zero-padded widths
+    (300, 16384 + 5, 33, 16, (256, 128, 64)),                   # odd field count + a full dense k-block; the tile kernel needs its K split
+    (300, 16384 + 5, 41, 16, (256, 128, 64)),                   # a DNN input (2640) the tile kernel cannot hold in LDS even split
+])
+def test_chain_kernel_embedding_dim_64(device, V, n, F, ND, units):
+    """embedding_dim 64 on the row-chained kernel (chain_device.h: EB = 4 — four k-blocks per field, eight layer-0 steps per field
+    pair, FM sums of four k-blocks): float64 oracle on a row sample, every row against the 16-row kernel, the forced 256-row shape,
+    row permutations and launch splits bit for bit."""
+    import torch
+    from deepctr_amd.models import DeepFM
+    E = 64
+    rng = np.random.RandomState(64 + F)
+    cols, feed = _criteo_like(rng, n, F=F, V=V, E=E, ND=ND)
+    model = DeepFM(cols, cols, dnn_hidden_units=units, device=device)
+    assert model.stage_plan.uniform_dim == E and model.fused
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain"
+    plan = model.launch_plan(model.stage(feed), 0, n, torch.empty(n, device=model.device))
+    assert all(k == "chain" for _, k, _ in plan) and sum(r for r, _, _ in plan) == n, plan
+    assert y.shape == (n, 1) and np.isfinite(y).all()
+    rows = np.unique(np.concatenate([np.arange(0, 300), np.arange(n - 300, n), rng.choice(n, 256, replace=False)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dnn_hidden_units=units, dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "chain DeepFM E=64 F=%d" % F)
+    m = 256 * 3 + 77
+    from deepctr_amd import _C
+    try:
+        y32 = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    except _C.DctrError as e:
+        # the tile kernel cannot hold this DNN input in LDS ([16, in_dim / 2] twice even with its K split): asked for by name it declines
+        assert "do not fit" in str(e) and F * E > 2500, e
+        y32 = None
+    if y32 is not None:
+        assert _last_kernel() == "tile"
+        k = max(1.0, F * E / 1024.0)                   # (two fp32 summation orders over in_dim terms)
+        assert_close(y, y32, rtol=2e-6 * k, atol=2e-7 * k, what="chain (E=64) vs the tile kernel")
+    else:
+        # ... and small default-route launches go to the row-chained kernel's tail phase instead of failing
+        ysm = model.predict({k: v[:m] for k, v in feed.items()}, batch_size=m)
+        assert _last_kernel() == "chain" and np.array_equal(ysm, y[:m]), "small launch of a DNN input too wide for the tile kernel"
+    assert np.array_equal(_predict(model, feed, 4096, tile_rows=256), y), "forced 256-row shape"
+    ys = _predict(model, {k: v[:m] for k, v in feed.items()}, m, tile_rows=256)
+    assert np.array_equal(ys, y[:m]), "forced shape, small launch"
+    perm = rng.permutation(n)
+    yp = model.predict({k: v[perm] for k, v in feed.items()}, batch_size=4096)
+    assert np.array_equal(yp, y[perm])
+    cut = 16384 + 4096
+    ya = model.predict({k: v[:cut] for k, v in feed.items()}, batch_size=4096)
+    assert np.array_equal(ya, y[:cut])
+
+
+def test_chain_kernel_embedding_dim_64_int64_ids_terms_and_out_of_range(device):
+    """int64 ids on the device for E = 64, WDL / FNN term switches (no FM / no linear part), an out-of-range id reported."""
+    from deepctr_amd.models import FNN, WDL, DeepFM
+    rng = np.random.RandomState(164)
+    n = 16384 + 300
+    cols, feed = _criteo_like(rng, n, F=13, V=900, E=64, ND=3)
+    for ctor, fn in ((DeepFM, RM.deepfm), (WDL, RM.wdl), (FNN, RM.fnn)):
+        model = ctor(cols, cols, device=device)
+        w = _randomise(model, rng)
+        y = model.predict(feed, batch_size=2048)
+        assert _last_kernel() == "chain"
+        rows = rng.choice(n, 200, replace=False)
+        ref = fn(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
+        check_probs(y[rows], ref.astype(np.float32), ctor.__name__ + " chain E=64")
+        feed64 = {k: (v.astype(np.int64) if v.dtype == np.int32 else v) for k, v in feed.items()}
+        assert np.array_equal(model.predict(feed64, batch_size=2048), y), ctor.__name__ + " int64 ids"
+    bad = {k: v.copy() for k, v in feed.items()}
+    bad["C7"][n - 5] = 900
+    with pytest.raises(IndexError):
+        model.predict(bad, batch_size=2048)
+    assert np.isfinite(model.predict(feed, batch_size=2048)).all()
+
+
 @pytest.mark.parametrize("act,units,bn,E", [("sigmoid", (256, 128, 64), False, 16), ("tanh", (256, 128, 64), False, 16),
                                             ("tanh", (256, 128), False, 32), ("sigmoid", (200, 80), False, 16),
                                             ("tanh", (100, 100, 100), True, 16), ("sigmoid", (256, 128, 128), True, 32)])
