@@ -181,9 +181,26 @@ class FusedForward(object):
             pd["h"][:hw.shape[0]].copy_(hw)
         return pd["k"], pd["b"], pd["h"], pd["bn"]
 
+    # widest DNN input the 16-row tile kernel holds in LDS without its layer-0 K split (csrc/mlp_kernels.hip: two [16, pad64 + 4] tiles in
+    # 160 KiB); the split needs a first layer of <= 128 or exactly 256 units (every wave at most one wave-tile of layer 0)
+    _TILE_MAX_UNSPLIT = 1216
+
+    def _use_padded(self, B):
+        """Zero-padded DNN copies for a fused launch of B rows?  Launches the row-chained kernel can take — and, at any size, models
+        whose DNN input the tile kernel can only hold split while their first layer (129 .. 255 units) does not allow the split: padded
+        to 256 it does (e.g. 26 fields of embedding_dim 64 in front of a 200-80 DNN), and inputs wider still go to the row-chained
+        kernel's tail phase (csrc/mlp_kernels.hip)."""
+        if self._pad_spec is None:
+            return False
+        if B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256:
+            return True
+        u0 = int(self.dnn.kernels[0].shape[1])
+        return bool(self.stage_plan.in_dim > self._TILE_MAX_UNSPLIT and 128 < u0 < 256 and self._pad_spec[0] == 256
+                    and self.tile_rows in (0, 16, 32))
+
     def _dnn_operands(self, B):
-        """DNN weights for a fused launch of B rows: padded copies when that launch can take the row-chained kernel."""
-        if self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256):
+        """DNN weights for a fused launch of B rows: padded copies when that launch can take the row-chained kernel (_use_padded)."""
+        if self._use_padded(B):
             return self._padded_dnn()
         return self.dnn.kernels, self.dnn.biases, self._head_weights(), self.dnn.bn_params()
 
@@ -228,7 +245,7 @@ class FusedForward(object):
         import torch
         from .. import _C
         sp, B = self.stage_plan, hi - lo
-        padded = self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256)
+        padded = self._use_padded(B)
         pre = self._prehash(B)
         bf3 = self._bf3_on(B)
         key = (B, padded, pre, bf3)
@@ -297,7 +314,7 @@ class FusedForward(object):
         self._forward_fast_args(staged, lo, hi, out)
         B = hi - lo
         pre = self._prehash(B)
-        g, m, keep, ws = self._fast[(B, self._pad_spec is not None and (B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256), pre,
+        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre,
                                      self._bf3_on(B))]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         sp = self.stage_plan

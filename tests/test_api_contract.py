@@ -346,6 +346,13 @@ def test_round4_kernel_routes_are_chosen_from_the_model_shape():
     assert DeepFM(cols(64, F=12), cols(64, F=12), dnn_hidden_units=(100, 50), device=cpu)._pad_spec == [256, 128]
     assert DeepFM(cols(64, F=12), cols(64, F=12), dnn_hidden_units=(256, 128, 64), device=cpu)._pad_spec is None
     assert DeepFM(cols(64, F=12), cols(64, F=12), dnn_hidden_units=(100, 50), dnn_activation="tanh", device=cpu)._pad_spec is None
+    # padded copies at every launch size where the tile kernel needs its K split and the first layer (129 .. 255 units) rules it out
+    wide = DeepFM(cols(64, F=26), cols(64, F=26), dnn_hidden_units=(200, 80), device=cpu)
+    assert wide._use_padded(256) and wide._use_padded(1 << 20)
+    assert not DeepFM(cols(64, F=26), cols(64, F=26), dnn_hidden_units=(100, 50), device=cpu)._use_padded(256)      # <= 128 units: splittable
+    assert not DeepFM(cols(16, F=26), cols(16, F=26), dnn_hidden_units=(200, 80), device=cpu)._use_padded(256)      # 417 columns fit unsplit
+    assert DeepFM(cols(16, F=26), cols(16, F=26), dnn_hidden_units=(200, 80), device=cpu)._use_padded(1 << 14)
+    assert not DeepFM(cols(64, F=26), cols(64, F=26), dnn_hidden_units=(256, 128, 64), device=cpu)._use_padded(1 << 20)   # nothing to pad
     # sigmoid / tanh DNNs: the EXPACT instantiations (256-128-x, embedding_dim 16 / 32); other activations stay off the kernel
     assert DeepFM(cols(16), cols(16), dnn_hidden_units=(100, 50), dnn_activation="tanh", device=cpu)._pad_spec == [256, 128]
     assert DeepFM(cols(32), cols(32), dnn_hidden_units=(256, 128, 64), dnn_activation="sigmoid", device=cpu)._pad_spec is None

@@ -563,6 +563,27 @@ def test_chain_kernel_embedding_dim_64(device, V, n, F, ND, units):
     assert np.array_equal(ya, y[:cut])
 
 
+def test_small_launches_of_wide_dnn_inputs_take_the_padded_widths(device):
+    """26 fields of embedding_dim 64 in front of a 200-80 DNN: the tile kernel holds a 1677-wide input only with its layer-0 K split, which a
+    200-unit first layer does not allow (csrc/mlp_kernels.hip) — launches below 64 rows per CU take the zero-padded 256-128 copies as the
+    large ones do (FusedForward._use_padded) instead of failing."""
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(7)
+    n = 3000
+    cols, feed = _criteo_like(rng, n, F=26, V=2000, E=64, ND=13)
+    model = DeepFM(cols, cols, dnn_hidden_units=(200, 80), device=device)
+    assert model._use_padded(1024) and model._use_padded(1 << 17)
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=1024)
+    assert _last_kernel() == "tile"
+    rows = np.arange(0, n, 5)
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dnn_hidden_units=(200, 80), dtype=np.float64)
+    check_probs(y[rows], ref.astype(np.float32), "tile kernel on padded widths, E=64 F=26")
+    yc = _predict(model, feed, n, tile_rows=256)
+    assert _last_kernel() == "chain"
+    assert_close(y, yc, rtol=4e-6, atol=4e-7, what="tile (padded widths) vs chain")
+
+
 def test_chain_kernel_embedding_dim_64_int64_ids_terms_and_out_of_range(device):
     """int64 ids on the device for E = 64, WDL / FNN term switches (no FM / no linear part), an out-of-range id reported."""
     from deepctr_amd.models import FNN, WDL, DeepFM
