@@ -54,8 +54,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # multi-process GPU work on this pool: dmabuf IPC only (before HIP initialises)
+
+import numpy as np       # noqa: E402
+import torch             # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
