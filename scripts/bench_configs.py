@@ -88,7 +88,7 @@ def run_span(name, model, feed, B, reps=8, dnn_flop=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c2_act,c3,c3_span,c3_dnn_in,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
+    ap.add_argument("--configs", default="c1,c2,c2_span,c2_2launch,c2_hash,c2_varlen,c2_wide,c2_act,c2_e64,c3,c3_span,c3_dnn_in,dcn_v,dcn_v_span,dcn_v_unfolded,dcn_m,dcn_m_span,"
                                          "dcn_mix,nfm,afm,pnn,c4,c4_span,c4_allpos,c4_lookups,c5,c5_span")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--quick", action="store_true", help="few steps, no C5 (for counter-collection passes)")
