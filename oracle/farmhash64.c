@@ -17,7 +17,7 @@
  * published algorithm.  All arithmetic is unsigned 64-bit wrap-around, loads are
  * little-endian and unaligned.
  *
- * Pinned by known-answer vectors in tests/test_oracle_hash.py:
+ * Pinned by known-answer vectors in tests/test_oracle_golden.py (KATS, test_to_hash_bucket_fast_doc_examples):
  *   - TensorFlow's own frozen fingerprints (tensorflow/core/platform/fingerprint_test.cc):
  *       Fingerprint64("Hello") = 15404698994557526151, ("World") = 18308117990299812472
  *   - TensorFlow's string_to_hash_bucket_op_test.py comments:

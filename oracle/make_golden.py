@@ -443,7 +443,7 @@ def gen_criteo_sample():
     # the 200-row DATA file itself (not source code), so that the example flow can run from the CSV on the GPU box,
     # where /root/reference does not exist (tests/test_gpu_facade.py)
     import shutil
-    shutil.copyfile(os.path.join(REF, "examples", "criteo_sample.txt"), os.path.join(GOLDEN, "criteo_sample.txt"))
+    shutil.copyfile(os.path.join(REF, "examples", "criteo_sample.txt"), os.path.join(OUT, "criteo_sample.txt"))
 
 
 def _run_pnn(name, spec_dnn, feed, kwargs):
@@ -568,12 +568,21 @@ def gen_bn():
         _save("dnn_" + name, **arrays)
 
 
-def main():
+def main(argv=None):
+    """``python -m oracle.make_golden [--out DIR] [siblings | bn]``: every generator (or one add-on group) into DIR
+    (default tests/golden).  tests/test_oracle_golden.py::test_recipe_regenerates_every_fixture runs it into a scratch
+    directory and compares every file with the committed one, so the recipe cannot rot unnoticed."""
+    global OUT
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
     S.install(REF)
     S.WEIGHT_HOOK = weight_hook
-    if len(sys.argv) > 1 and sys.argv[1] == "siblings":      # add-on fixtures only (the others stay byte-identical)
+    if argv and argv[0] == "siblings":      # add-on fixtures only (the others stay byte-identical)
         return gen_siblings()
-    if len(sys.argv) > 1 and sys.argv[1] == "bn":
+    if argv and argv[0] == "bn":
         return gen_bn()
     gen_hash()
     gen_interaction()

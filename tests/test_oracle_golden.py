@@ -350,3 +350,31 @@ def test_dnn_layer_with_bn_and_output_activation(name, kw):
               for i in range(n)]
     y = R.dnn(g["x"], ks, bs, kw["activation"], output_activation=kw["output_activation"], bn_params=bn)
     assert_close(y, g["y"], rtol=1e-5, atol=1e-6, what=name)
+
+
+# ---------------------------------------------------------------------------------------------
+# the recipe itself
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not os.path.isdir("/root/reference/deepctr"), reason="needs /root/reference (build container only)")
+def test_recipe_regenerates_every_fixture(tmp_path):
+    """`python -m oracle.make_golden` (every generator, through main()) into a scratch directory: every committed fixture comes
+    out again byte for byte, and nothing is committed that the recipe does not produce (main() had rotted)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "golden")
+    r = subprocess.run([sys.executable, "-m", "oracle.make_golden", "--out", out], cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    committed = sorted(os.listdir(os.path.join(root, "tests", "golden")))
+    assert sorted(os.listdir(out)) == committed
+    for name in committed:
+        a = open(os.path.join(root, "tests", "golden", name), "rb").read()
+        b = open(os.path.join(out, name), "rb").read()
+        if a == b:
+            continue
+        assert name.endswith(".npz"), name + " differs"
+        za, zb = np.load(os.path.join(root, "tests", "golden", name)), np.load(os.path.join(out, name))   # (container bytes may differ with zlib)
+        assert sorted(za.files) == sorted(zb.files), name
+        for k in za.files:
+            assert za[k].dtype == zb[k].dtype and za[k].shape == zb[k].shape and za[k].tobytes() == zb[k].tobytes(), "%s[%s]" % (name, k)

@@ -46,6 +46,9 @@ def assert_fm_close(got, x, what="fm"):
     assert (err <= bar).all(), "%s: max err/bar %.3g" % (what, float((err / bar).max()))
 
 
+TERMS_REPORT = []     # (what, elements, elements outside 1e-4 * |ref|, worst err / (1e-4 * |ref|), worst err / bar)
+
+
 def assert_close_terms(got, ref, terms, rtol=1e-4, rtol_terms=2e-6, what=""):
     """fp32 bar for a result that is a SUM of terms which may cancel: 1e-4 of the result (north_star) plus a few fp32 ulp
     (2e-6 ~ 17 * 2^-23: summation orders of the MFMA path and the reference differ over tens to hundreds of terms) of the
@@ -56,4 +59,8 @@ def assert_close_terms(got, ref, terms, rtol=1e-4, rtol_terms=2e-6, what=""):
     err = np.abs(got - ref)
     bar = rtol * np.abs(ref) + rtol_terms * np.abs(terms) + 1e-30
     worst = float((err / bar).max()) if err.size else 0.0
+    # how much of the comparison leaned on the extra term: elements outside north_star's literal bar (1e-4 of the result), and the
+    # worst error in units of that literal bar — collected here, printed at the end of the session (tests/conftest.py)
+    lit = rtol * np.abs(ref) + 1e-30
+    TERMS_REPORT.append((what, int(err.size), int((err > lit).sum()), float((err / lit).max()) if err.size else 0.0, worst))
     assert (err <= bar).all(), "%s: max err / bar = %.3g (rtol=%g, %g of the summed magnitude)" % (what, worst, rtol, rtol_terms)
