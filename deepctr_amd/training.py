@@ -362,6 +362,29 @@ def permute_staged_(staged, yt, perm, wt=None):
         wt.copy_(wt.index_select(0, perm))
 
 
+class _BatchCursor(object):
+    """The batch order of tf.keras.Model.fit over ARRAYS.  Keras feeds them through ONE iterator for the whole fit()
+    (TensorLikeDataAdapter: ``should_recreate_iterator()`` is False; the index dataset is ``range(n).repeat(epochs)``, shuffled per
+    PASS): with ``steps_per_epoch`` below the batches of a pass, epoch e + 1 continues with the NEXT batches of the same pass — rows
+    past ``steps * batch_size`` are trained on, in later epochs — and a new permutation is drawn each time a pass over the arrays
+    completes, not at every epoch.  Without ``steps_per_epoch`` an epoch is one pass: permute, then every batch in order."""
+
+    def __init__(self, n_tr, bs, steps, permute):
+        self.n_tr, self.bs, self.permute = int(n_tr), int(bs), permute
+        self.per_pass = (self.n_tr + self.bs - 1) // self.bs
+        self.steps = self.per_pass if steps is None else int(steps)
+        self.pos = 0                                     # next batch of the current pass
+
+    def epoch(self):
+        """(lo, hi) of this epoch's batches; the cursor stays where the epoch ended."""
+        for _ in range(self.steps):
+            if self.pos == 0 and self.permute is not None:
+                self.permute()                           # a pass begins
+            lo = self.pos * self.bs
+            yield lo, min(self.n_tr, lo + self.bs)
+            self.pos = (self.pos + 1) % self.per_pass
+
+
 def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, steps=None, initial_epoch=0):
     """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
     moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation.
@@ -370,19 +393,15 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
     tr = getattr(model, "_hip_trainer", None)
     if tr is None or tr.kind != model._compiled["optimizer"].lower():
         tr = model._hip_trainer = HipTrainer(model, model._compiled["optimizer"])
+    cursor = _BatchCursor(n_tr, bs, steps, (lambda: permute_staged_(
+        staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device), wt)) if shuffle else None)
     for ep in range(initial_epoch, epochs):
-        if shuffle:
-            permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device), wt)
         # the epoch's loss: dctr_bce_grad adds every batch's summed loss into that batch's element of ONE device vector (summed in
         # float64 at the end of the epoch; step() refreshes the weight-derived buffers itself) — no per-step zero / divide / add launches
         # and no host round trip for it
-        n_steps = (n_tr + bs - 1) // bs if steps is None else steps
-        tot = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=model.device)
+        tot = torch.zeros(max(cursor.steps, 1), dtype=torch.float32, device=model.device)
         seen = 0
-        for i, lo in enumerate(range(0, n_tr, bs)):
-            if i >= n_steps:
-                break
-            hi = min(n_tr, lo + bs)
+        for i, (lo, hi) in enumerate(cursor.epoch()):
             tr.step(staged, int(lo), int(hi), yt[lo:hi], loss_acc=tot[i:i + 1], weight=None if wt is None else wt[lo:hi])
             seen += hi - lo
         model._check_status()
@@ -486,8 +505,8 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     if steps is not None:
         steps = int(steps)
         if steps < 1 or steps > (n_tr + bs - 1) // max(bs, 1):
-            # tf.keras re-creates the iterator over the arrays every epoch and stops training with "Your input ran out of data" when an
-            # epoch asks for more batches than they hold: an error here instead of a silently shorter run
+            # tf.keras builds ONE iterator of `epochs` passes over the arrays (_BatchCursor) and stops training with "Your input ran out
+            # of data" when the epochs together ask for more batches than that holds: an error here instead of a silently shorter run
             raise ValueError("fit(steps_per_epoch=%d): the arrays hold %d batches of %d" % (steps, (n_tr + bs - 1) // max(bs, 1), bs))
     if initial_epoch < 0:
         raise ValueError("fit(initial_epoch=%d)" % initial_epoch)
@@ -535,15 +554,12 @@ def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None,
         opt = opt(params)
     loss_name = model._compiled["loss"] or ("binary_crossentropy" if model.task == "binary" else "mse")
     regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
+    cursor = _BatchCursor(n_tr, bs, steps, (lambda: permute_staged_(
+        staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device), wt)) if shuffle else None)
     try:
         for ep in range(initial_epoch, epochs):
-            if shuffle:
-                permute_staged_(staged, yt, torch.from_numpy(np.random.permutation(n_tr)).to(yt.device), wt)
             tot, cnt = 0.0, 0
-            for i, lo in enumerate(range(0, n_tr, bs)):
-                if steps is not None and i >= steps:
-                    break
-                hi = min(n_tr, lo + bs)
+            for lo, hi in cursor.epoch():
                 model._begin()
                 logit = model_logits(model, staged, int(lo), int(hi), training=True)
                 if loss_name in ("binary_crossentropy", "logloss") and model.task == "binary":

@@ -352,6 +352,19 @@ def test_fit_loss_weights_steps_and_initial_epoch():
     assert hs.epoch == [1, 2, 3] and len(hs.history["loss"]) == 3
     _, _, hf = run(None, steps=None, epochs=1, bs=32)
     assert hs.history["loss"][0] != hf.history["loss"][0]
+    # tf.keras keeps ONE iterator over the arrays for the whole fit(): with steps_per_epoch = 2 of 3 batches, epoch 1 continues with
+    # batch 2 and then batch 0 of the next pass -> six steps = two full passes in order, the same weights as 2 plain epochs
+    m_steps, _, _ = run(None, steps=2, epochs=3, bs=32)
+    m_plain, _, _ = run(None, steps=None, epochs=2, bs=32)
+    for k, v in m_plain.get_weights_by_name().items():
+        assert np.array_equal(v, m_steps.get_weights_by_name()[k]), k
+    cur = training._BatchCursor(70, 32, 2, None)
+    assert [list(cur.epoch()) for _ in range(3)] == [[(0, 32), (32, 64)], [(64, 70), (0, 32)], [(32, 64), (64, 70)]]
+    n_perm = []
+    cur = training._BatchCursor(70, 32, 2, lambda: n_perm.append(1))          # a permutation per PASS, not per epoch
+    for _ in range(3):
+        list(cur.epoch())
+    assert len(n_perm) == 2
     # fit_model's argument checks (before anything touches a device)
     from deepctr_amd import _C
     real = _C.require_device
