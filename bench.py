@@ -25,11 +25,20 @@ After the regions a sample of the rows the timed launches wrote is compared with
 `one_launch_per_batch` in the JSON line is the other extreme (one launch per 4096-row batch, K of them in one hipGraph on 8
 streams — round 1's headline mode), `long_run` repeats the K-step region until >= 50 ms.
 
-Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free: every rank scores its own K x 4096 rows
-inside the timed region (barrier + synchronize on both sides, MAX over ranks).  The path's only exchange — ONE
-RCCL all-gather of the K steps' logits, what `predict_distributed` does with a rank's shard — is issued after every region's
-clock has stopped and timed on its own: the JSON line carries it as `exchange` (its duration and the rate of region + exchange);
-inside a 0.2 ms region it would sit exposed behind the last kernel with nothing to overlap.
+Multi-GPU: rows shard across ranks, tables replicated, the forward is collective-free: every rank scores its own K x 4096 rows.
+The path's only exchange — ONE RCCL all-gather of the K steps' logits, what `predict_distributed` does with a rank's
+shard — is INSIDE the timed region when world > 1 (barrier + sync | K steps + all-gather + sync |, MAX over ranks): `value` at N > 1 is
+what a caller of the distributed predict sees.  `exchange` carries the collective-free part of the same regions (`forward_only_*`) and
+the all-gather's own duration, each timed inside the region by a perf_counter stamp after a synchronize between the two.
+
+`long_run` (K-step regions back to back, no host synchronize between them, >= 50 ms) is taken right after the `value` regions and
+reports TWO clocks: the host's (perf_counter around issue + synchronize) and the device's (the kernels' own constant-rate wall clock,
+dctr_mlp_args_t.probe: first workgroup's entry -> last wave's exit).  They differ when the host thread is descheduled while it waits:
+the GPU boxes of this pool run the job in a container with a CFS CPU quota (cpu.max 1600000 100000 = 16 CPUs), and 64 spin-yielding
+OpenBLAS workers (the float64 oracle's matmuls, the CPU baseline) burn a 100 ms period's quota in a few ms — the waiting thread then
+sleeps until the next period (profiles/r05_longrun_diagnosis.md: round 4's "long_run = 49 % of value" was that, the kernels ran back to
+back at 213 us).  `host` in the JSON line carries the quota and the throttle counters of the run.  `predict_e2e` = model.predict_tensor
+/ model.predict over >= 16 M device-staged rows right after >= 2 s of host-only preprocessing work (the product's entry point).
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of the timed region = chain_kernel (fused gather + DNN; one launch per call).  It is bound by
@@ -230,6 +239,50 @@ def check_parity(model, cols, staged, launches, logits, n_rows, rank):
             "against": "oracle/ref_models.deepfm, float64, same ids / dense values / weights as the timed region"}
 
 
+def cgroup_cpu():
+    """The container's CFS bandwidth state: {"cpu_max": "quota period" | None, nr_periods, nr_throttled, throttled_usec}."""
+    out = {"cpu_max": None}
+    for pth in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        if os.path.exists(pth):
+            try:
+                out["cpu_max"] = open(pth).read().strip()
+            except OSError:
+                pass
+            break
+    for pth in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        if os.path.exists(pth):
+            try:
+                for line in open(pth):
+                    k, v = line.split()
+                    if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time"):
+                        out["throttled_usec" if k == "throttled_time" else k] = int(v) // (1000 if k == "throttled_time" else 1)
+            except (OSError, ValueError):
+                pass
+            break
+    return out
+
+
+def quiesce(seconds=0.15):
+    """Host-side: let the BLAS / OpenMP workers of earlier host work (oracle matmuls, torch CPU ops) stop spinning before a timed
+    leg — they burn the container's CPU quota, and a throttled host thread cannot see the GPU finish (module docstring)."""
+    time.sleep(seconds)
+
+
+def host_preprocess(seconds, rows=200000):
+    """>= `seconds` of HOST-ONLY, single-threaded preprocessing of the kind examples/run_classification_criteo.py:23-41 does in
+    front of predict(): label-encoding of id columns (np.unique + searchsorted) and min-max scaling of dense columns."""
+    rng = np.random.RandomState(5)
+    raw = rng.randint(0, 1 << 30, rows)
+    dense = rng.rand(rows)
+    t_end, n = time.perf_counter() + seconds, 0
+    while time.perf_counter() < t_end:
+        classes = np.unique(raw)
+        np.searchsorted(classes, raw)
+        (dense - dense.min()) / (dense.max() - dense.min())
+        n += 1
+    return n
+
+
 def load_traffic(rows):
     """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch."""
     tp = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
@@ -339,10 +392,11 @@ def main():
         dist.all_gather_into_tensor(gathered, logits)
         torch.cuda.synchronize()
 
-    exchange_s = []
+    exchange_s = {}                     # region kind -> [(forward seconds, all-gather seconds)] of this rank
 
-    def timed_region(arm):
-        """barrier + sync | K steps + sync | the one all-gather, timed on its own | barrier; returns this rank's seconds of the K steps."""
+    def timed_region(arm, kind):
+        """barrier + sync | K steps + sync + the one all-gather + sync | barrier.  Returns this rank's seconds of the WHOLE region when
+        world > 1 (steps + exchange: what `value` is made of), of the K steps alone otherwise; the split is kept per region kind."""
         barrier()
         torch.cuda.synchronize()
         if arm:
@@ -350,14 +404,17 @@ def main():
         t0 = time.perf_counter()
         run_steps()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0                                  # this rank's K steps; MAX over ranks below
+        t1 = time.perf_counter()                                       # this rank's K steps
         if dist is not None:
-            t1 = time.perf_counter()
             dist.all_gather_into_tensor(gathered, logits)              # the path's one exchange: the K steps' logits
             torch.cuda.synchronize()
-            exchange_s.append(time.perf_counter() - t1)
+            t2 = time.perf_counter()
+            exchange_s.setdefault(kind, []).append((t1 - t0, t2 - t1))
+            if world > 1:
+                barrier()
+                return t2 - t0
         barrier()
-        return dt
+        return t1 - t0
 
     # `value`: the K steps, nothing else in the region.  A single sub-millisecond region right after a barrier is a cold start
     # (L2 / MALL state, clock ramp): a few per cent of spread from run to run, so the region is taken --regions times — each one
@@ -373,24 +430,25 @@ def main():
             run_steps()
             torch.cuda.synchronize()
 
-    cold_s = timed_region(arm=False)                        # reported, not `value`: the first region after an idle period
+    cg0 = cgroup_cpu()
+    cold_s = timed_region(arm=False, kind="cold")           # reported, not `value`: the first region after an idle period
     region_s = []
     for r in range(n_regions):
         prewarm(args.prewarm_ms if r == 0 else args.prewarm_ms / 5.0)
-        region_s.append(timed_region(arm=False))
+        region_s.append(timed_region(arm=False, kind="value"))
     # the same region once more with an event pair around every kernel launch (hipExtLaunchKernelGGL start / stop events on
     # the launch's own stream): the per-kernel durations of the roofline object.  Kept out of the `value` region because the
     # pairs isolate consecutive kernels from each other (no tail / ramp overlap), which costs the region ~10 %.
-    timed_region(arm=True)
+    timed_region(arm=True, kind="armed")
     ms = (ctypes.c_float * 256)()
     n_timed = lib.dctr_profile_collect(ms, min(n_kern, 256)) if K > 0 else 0
     launch_s = [ms[i] * 1e-3 if ms[i] > 0 else None for i in range(n_timed)]
-    exchange = None
+    exchange = forward_only = None
     if dist is not None:                                    # every region: MAX over ranks
-        ex = exchange_s[1:1 + n_regions]                    # (the exchanges behind the `value` regions)
-        t = torch.tensor([float(np.median(ex))], dtype=torch.float64, device=device)
+        ex = exchange_s["value"]                            # (forward, all-gather) of the `value` regions
+        t = torch.tensor([float(np.median([e for _, e in ex])), float(np.median([f for f, _ in ex]))], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        exchange = float(t.item())
+        exchange, forward_only = float(t[0].item()), float(t[1].item())
         t = torch.tensor(region_s, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.tolist()]
@@ -400,21 +458,50 @@ def main():
     elapsed = float(np.median(region_s))
     model._check_status()
     assert bool(torch.isfinite(logits[:min(K, 4) * B]).all())
-    parity = check_parity(model, cols, staged, launches, logits, args.parity_rows, rank) if (K > 0 and args.parity_rows > 0) else None
 
-    # secondary measurements (not `value`): the same region repeated until >= 50 ms, and one launch per batch
+    # secondary measurements (not `value`).  FIRST, while the host has done nothing but issue launches: the same K steps repeated back
+    # to back (no host synchronize in between) until >= 50 ms, on two clocks — the host's and the kernels' own (module docstring)
     long_run = per_batch = None
     if K > 0 and not args.no_secondary:
-        reps = max(2, int(0.05 / max(elapsed, 1e-6)) + 1)
+        reps = max(2, int(0.05 / max(elapsed if world == 1 else (forward_only or elapsed), 1e-6)) + 1)
+        probe = torch.tensor([-1, 0], dtype=torch.int64, device=device) if fused else None     # [min entry, max exit], uint64 ticks
+        if fused:
+            model.probe = probe
+            prep_p = [model.prepare_launch(staged, lo, hi, logits[o0:o1]) for lo, hi, o0, o1 in launches]
+            model.probe = None
+        else:
+            prep_p = prepared
+        for fn in prep_p:
+            fn()
+        if probe is not None:
+            probe.copy_(torch.tensor([-1, 0], dtype=torch.int64))
+        cgl0 = cgroup_cpu()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            run_steps()
+            for fn in prep_p:
+                fn()
+        t_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         tl = time.perf_counter() - t0
+        cgl1 = cgroup_cpu()
         long_run = {"repeats_of_the_K_step_region": reps, "seconds": tl, "samples_per_s_per_gpu": reps * K * B / tl,
-                    "ms_per_step": tl / (reps * K) * 1e3}
+                    "ms_per_step": tl / (reps * K) * 1e3, "host_issue_seconds": t_issue,
+                    "host_throttled_during": cgl1.get("nr_throttled", 0) - cgl0.get("nr_throttled", 0)}
+        if probe is not None:
+            pr = probe.cpu().numpy().astype(np.uint64)
+            khz = lib.dctr_wall_clock_khz()
+            if khz > 0 and pr[1] > pr[0]:
+                td = float(pr[1] - pr[0]) / khz * 1e-3
+                long_run.update({"device_seconds": td, "device_samples_per_s_per_gpu": reps * K * B / td,
+                                 "device_clock": "the kernels' constant-rate wall clock (%d kHz): first workgroup entry -> last wave exit" % khz})
+        long_run["ratio_to_value_region_rate"] = long_run["samples_per_s_per_gpu"] / (K * B / (elapsed if world == 1 else (forward_only or elapsed)))
+
+    parity = check_parity(model, cols, staged, launches, logits, args.parity_rows, rank) if (K > 0 and args.parity_rows > 0) else None
+    quiesce()
+
+    if K > 0 and not args.no_secondary:
         if fused and dist is None:
             n_streams = max(1, args.streams)
             model.span_batches, tr = False, model.tile_rows
@@ -445,6 +532,65 @@ def main():
             per_batch = {"mode": "one launch per 4096-row batch (32-row tile kernel), K launches in one hipGraph on %d streams" % n_streams,
                          "samples_per_s": K * B / tp, "ms_per_step": tp / K * 1e3,
                          "aggregate_frac_of_f32_mfma_peak": K * B / tp * DNN_FLOP_PER_SAMPLE / 1e12 / F32_MFMA_PEAK_TF}
+
+    # model.predict over >= 16 M device-staged rows right after >= 2 s of host-only work: the product's entry point on a device that
+    # has idled behind host preprocessing.  predict_tensor leaves the logits on the device, predict returns numpy.
+    e2e = None
+    if K > 0 and fused and dist is None and not args.no_secondary:
+        try:
+            from deepctr_amd.engine import Staged
+            times = -(-(1 << 24) // staged.n)
+            big = Staged(staged.n * times)
+            big.ids = staged.ids.repeat(1, times).contiguous()
+            big.dense = None if staged.dense is None else staged.dense.repeat(times, 1).contiguous()
+            probe_e = torch.tensor([-1, 0], dtype=torch.int64, device=device)
+            khz = lib.dctr_wall_clock_khz()
+            model.predict_tensor(big, batch_size=B)                     # untimed: buffers, marshalled launches
+            torch.cuda.synchronize()
+            legs = {}
+            for leg, host_work in (("predict_tensor", "single"), ("predict", "single"), ("predict_tensor_after_blas", "blas")):
+                if host_work == "single":
+                    n_pre = host_preprocess(2.0)
+                    work = "%d rounds of single-threaded label-encoding / min-max scaling of 200,000-row columns (2.0 s)" % n_pre
+                else:
+                    a64 = np.random.RandomState(1).rand(1200, 1200)
+                    t_end = time.time() + 0.5
+                    while time.time() < t_end:
+                        a64 @ a64
+                    work = "0.5 s of multi-threaded float64 matmuls (OpenBLAS workers keep spinning behind it: the container's CPU quota)"
+                probe_e.copy_(torch.tensor([-1, 0], dtype=torch.int64))
+                torch.cuda.synchronize()
+                model.probe = probe_e
+                c0 = cgroup_cpu()
+                t0 = time.perf_counter()
+                if leg == "predict":
+                    y_e = model.predict(big, batch_size=B)
+                else:
+                    y_e = model.predict_tensor(big, batch_size=B)
+                    torch.cuda.synchronize()
+                te = time.perf_counter() - t0
+                c1 = cgroup_cpu()
+                model.probe = None
+                pr = probe_e.cpu().numpy().astype(np.uint64)
+                td = float(pr[1] - pr[0]) / khz * 1e-3 if khz > 0 and pr[1] > pr[0] else None
+                legs[leg] = {"seconds": te, "samples_per_s": big.n / te, "ratio_to_value": big.n / te / (B * K / elapsed),
+                             "device_seconds": td, "device_samples_per_s": None if td is None else big.n / td,
+                             "host_work_before": work, "host_throttled_during": c1.get("nr_throttled", 0) - c0.get("nr_throttled", 0)}
+                if leg == "predict":
+                    assert y_e.shape == (big.n, 1) and y_e.dtype == np.float32
+                quiesce()
+            y_t = model.predict_tensor(big, batch_size=B)
+            par_e = check_parity(model, cols, big, [(0, big.n, 0, big.n)], y_t, 1024, rank)
+            same = bool(torch.equal(y_t[:staged.n], y_t[(times - 1) * staged.n:]))        # a row's bits do not depend on its position
+            quiesce()
+            e2e = {"rows": big.n, "batch_size": B, "inputs": "device-staged (the %d-row ring tiled %d times)" % (staged.n, times),
+                   "launches": "predict()'s own spans (up to 2^20 rows per dctr_embed_mlp_fwd call)", "legs": legs,
+                   "parity_max_rel": par_e["max_rel"], "parity": par_e, "tiled_rows_bit_identical": same}
+            del big, y_t, y_e
+        except Exception as e:                              # a secondary leg never takes the bench line down
+            e2e = {"error": repr(e)}
+        finally:
+            model.probe = None
 
     # EXPLORATORY line (never `value`, never the library's default): the same K-step region with the DNN products as three bf16
     # MFMAs each (dctr_mlp_args_t.precision; model.matrix_precision = "bf16x3") — what the one-launch kernel's gather side
@@ -619,21 +765,25 @@ def main():
                                        "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(launches_of(pl)) for pl in plans[:1]) if fused
                                        else "2 launches per span"),
                        "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
-                       "parallelism": "row-sharded x%d, tables replicated, forward collective-free; the one all-gather of the logits is "
-                                      "timed separately (`exchange`)" % world},
+                       "parallelism": "row-sharded x%d, tables replicated, forward collective-free; the one all-gather of the K steps' "
+                                      "logits is %s" % (world, "inside the timed region (`exchange` splits it out)" if world > 1 else
+                                                        "not part of a 1-GPU region")},
             "roofline": roofline, "kernels": kernels,
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
             "fp32_ceiling_of_that_fraction": F32_MFMA_PEAK_TF * 1e12 / DNN_FLOP_PER_SAMPLE * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
-            "long_run": long_run, "one_launch_per_batch": per_batch, "zipf_ids": zipf,
+            "long_run": long_run, "predict_e2e": e2e, "one_launch_per_batch": per_batch, "zipf_ids": zipf,
             "exchange": None if exchange is None else {
-                "what": "one RCCL all-gather of the K steps' logits (%d floats per rank), issued after each region's clock stopped; median, "
-                        "MAX over ranks" % (K * B), "ms": exchange * 1e3,
-                "samples_per_s_region_plus_exchange": world * B * K / (elapsed + exchange) if K else 0.0},
+                "what": "one RCCL all-gather of the K steps' logits (%d floats per rank) behind the K steps, %s; median over the value "
+                        "regions, MAX over ranks" % (K * B, "INSIDE the timed region" if world > 1 else "outside the 1-GPU region"),
+                "ms": exchange * 1e3, "forward_only_ms": forward_only * 1e3,
+                "forward_only_samples_per_s": world * B * K / forward_only if K else 0.0,
+                "samples_per_s_region_plus_exchange": world * B * K / (forward_only + exchange) if K else 0.0},
             "exploratory_bf16x3": bf3,
             "regions_ms": [t * 1e3 for t in region_s],
-            "value_is": "median of %d one-shot regions of exactly K steps (each: barrier + sync | K steps | sync), taken right after "
+            "value_is": "median of %d one-shot regions of exactly K steps (each: barrier + sync | K steps | sync%s), taken right after "
                         "%.0f ms (%.0f ms from the second region on) of the same steps untimed, i.e. at the clock the part holds "
-                        "under load" % (n_regions, args.prewarm_ms, args.prewarm_ms / 5.0),
+                        "under load" % (n_regions, " | all-gather of the logits | sync" if world > 1 else "", args.prewarm_ms,
+                                        args.prewarm_ms / 5.0),
             "cold_one_shot": {"ms": cold_s * 1e3, "samples_per_s": world * B * K / cold_s if K else 0.0,
                               "note": "the same region as the first GPU work after an idle period (shader clock still ramping)"},
             "clock_prewarm_ms": args.prewarm_ms,
@@ -643,6 +793,11 @@ def main():
             raise SystemExit("bench.py: the timed region's output is outside the 1e-4 parity bar: %r" % (parity,))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(model, cols)
+        cg1 = cgroup_cpu()
+        result["host"] = {"cpu_count": os.cpu_count(), "container_cpu_max": cg1.get("cpu_max"),
+                          "cfs_periods_throttled_during_run": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                          "note": "host-side only: a throttled waiting thread lengthens a host-clock measurement, never a kernel "
+                                  "(profiles/r05_longrun_diagnosis.md); timed legs are taken with the BLAS workers of earlier host work asleep"}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier(device_ids=[local_rank])

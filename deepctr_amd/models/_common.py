@@ -103,9 +103,13 @@ class FusedForward(object):
         (PERSISTENT tensors: marshalled launches keep their addresses)."""
         return None
 
-    def _extra_logits(self, staged, lo, hi):
-        """[B] logit vectors of other launches (issued here, on the current stream) that the fused head adds."""
+    def _extra_logit_buffers(self, B):
+        """The [B] logit vectors of other launches that the fused head adds (shared per B: launches on ONE stream; a prepared launch
+        gets its own — prepare_launch).  Allocation only: nothing is launched here."""
         return []
+
+    def _launch_extra(self, staged, lo, hi, bufs):
+        """Issues, on the current stream, the launches that fill ``bufs`` (= _extra_logit_buffers) for rows [lo, hi)."""
 
     def _init_fused(self, dnn_hidden_units, dnn_activation):
         sp = self.stage_plan
@@ -234,6 +238,7 @@ class FusedForward(object):
         import ctypes
         from .. import _C
         g, m = self._forward_fast_args(staged, lo, hi, out)
+        self._launch_extra(staged, lo, hi, self._extra_logit_buffers(hi - lo))      # (CIN / matrix CrossNet: in front of the fused launch)
         sp = self.stage_plan
         _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear),
                                              _C.stream_ptr()), "dctr_embed_mlp_fwd")
@@ -241,6 +246,8 @@ class FusedForward(object):
             self._bf3["fresh"] = True
 
     def _forward_fast_args(self, staged, lo, hi, out):
+        """The two argument structs of the fused launch for rows [lo, hi) -> out.  Marshalling only, apart from the hash pre-pass of a
+        hashed model (its output is an argument): the launches of _launch_extra are the caller's."""
         import ctypes
         import torch
         from .. import _C
@@ -286,7 +293,7 @@ class FusedForward(object):
         m.probe = None if self.probe is None else self.probe.data_ptr()
         m.precision = 0 if not bf3 else (2 if self._bf3["fresh"] else 1)
         self._fast_g = g                                                # (xDeepFM: the CIN launch reads the same gather arguments)
-        for i, t in enumerate(self._extra_logits(staged, lo, hi)):      # (their launches go out here, in front of the fused one)
+        for i, t in enumerate(self._extra_logit_buffers(B)):
             m.add[i] = t.data_ptr()
         return g, m
 
@@ -321,20 +328,23 @@ class FusedForward(object):
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
         import torch
-        # its own hashed-id matrix: prepared launches may run on several streams / in one multi-stream graph
+        # its own hashed-id matrix and its own extra-logit vectors: prepared launches may run on several streams / in one multi-stream
+        # graph (the per-B vectors of _extra_logit_buffers serve ONE stream)
         own_ids = torch.empty(len(sp.fields), B, dtype=staged.ids.dtype, device=self.device) if pre else None
+        own_add = [torch.empty_like(t) for t in self._extra_logit_buffers(B)]
+        for i, t in enumerate(own_add):
+            m.add[i] = t.data_ptr()
 
         def launch():
             if pre:                                                      # (the hash launch fills the matrix g.ids points at)
                 h = sp.prehash(staged, lo, hi, ws, out=own_ids)
                 g.ids, g.ids_stride_f = h.data_ptr(), h.stride(0)
             self._fast_g = g
-            for i, t in enumerate(self._extra_logits(staged, lo, hi)):
-                m.add[i] = t.data_ptr()
+            self._launch_extra(staged, lo, hi, own_add)
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
             if m.precision == 1:                                         # bf16x3: the first launch packed the weights
                 m.precision = 2
-        launch.keep = (g, m, keep, ws, staged, out, own_ids)
+        launch.keep = (g, m, keep, ws, staged, out, own_ids, own_add)
         return launch
 
     def _fast_path(self, staged):

@@ -12,6 +12,10 @@ from ..layers.interaction import CrossNet
 from ._common import FeatureModel, FusedForward
 
 
+class _GatherUnsupported(Exception):
+    """dctr_crossnet_gather_head_fwd answered DCTR_E_UNSUPPORTED: the model takes its dnn_in route from then on."""
+
+
 class _DCN(FusedForward, FeatureModel):
     def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units,
                  seed, dnn_dropout, dnn_use_bn, dnn_activation, task, device, name="DCN"):
@@ -44,6 +48,8 @@ class _DCN(FusedForward, FeatureModel):
         else:
             self.fused = False
         self.fold_cross = True      # False: the layer-by-layer cross kernels (gather -> HBM -> cross / DNN launches)
+        self._matrix_failed = False  # set when the library refuses the gather form of the matrix CrossNet (DCTR_E_UNSUPPORTED)
+        self._cus = None
 
     def _fold_ok(self):
         return bool(self.fold_cross and self.fused and self.cross is not None and self.dnn is not None and
@@ -123,28 +129,38 @@ class _DCN(FusedForward, FeatureModel):
                 getattr(self.cross, "parameterization", None) == "matrix" and not getattr(self, "_matrix_failed", False)):
             return False
         sp = self.stage_plan
-        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if self._cus is None:
+            self._cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        cus = self._cus
         return bool(FusedForward._fast_path(self, staged) and sp.uniform_dim in (4, 8, 16, 32, 64) and sp.in_dim <= 512 and
                     B >= 64 * cus and (not sp.any_hash or self._prehash(B)) and not self.dnn.dice_layers)
 
-    def _extra_logits(self, staged, lo, hi):
+    def _extra_logit_buffers(self, B):
+        """The matrix CrossNet's share of Dense(1), a [B] logit the fused head adds."""
         if self.cross is None or getattr(self.cross, "parameterization", None) != "matrix":
             return []
         import torch
-        B, d = hi - lo, self.stage_plan.in_dim
         cl = self._cross_logit.get(B) if getattr(self, "_cross_logit", None) is not None else None
         if cl is None:
             if getattr(self, "_cross_logit", None) is None or len(self._cross_logit) > 8:
                 self._cross_logit = {}
             cl = self._cross_logit[B] = torch.empty(B, dtype=torch.float32, device=self.device)
-        self._run_cross(None, B, d, None, head_w=self.dense.w('kernel').reshape(-1)[:d], logit=cl, gather=self._fast_g)
         return [cl]
+
+    def _launch_extra(self, staged, lo, hi, bufs):
+        if not bufs:
+            return
+        B, d = hi - lo, self.stage_plan.in_dim
+        self._run_cross(None, B, d, None, head_w=self.dense.w('kernel').reshape(-1)[:d], logit=bufs[0], gather=self._fast_g)
 
     def _forward(self, staged, lo, hi, out):
         if self._fast_path(staged):
             return self._forward_fast(staged, lo, hi, out)
         if self._matrix_gather_ok(staged, hi - lo):
-            return self._forward_fast(staged, lo, hi, out)
+            try:
+                return self._forward_fast(staged, lo, hi, out)
+            except _GatherUnsupported:              # the library is the authority on what its gather form takes: the gate above mirrors
+                self._matrix_failed = True          # it, and where the two disagree the model falls back for good (as DIN's _fold_failed)
         ws = self.stage_plan.run(staged, lo, hi)
         B = hi - lo
         d = self.stage_plan.in_dim
@@ -191,7 +207,10 @@ class _DCN(FusedForward, FeatureModel):
                             workspace=self._cross_ws.data_ptr() if need else None, workspace_bytes=need,
                             head_w=None if head_w is None else head_w.data_ptr(), logit=None if logit is None else logit.data_ptr())
         if gather is not None:
-            _C.check(_C.lib().dctr_crossnet_gather_head_fwd(ctypes.byref(a), ctypes.byref(gather), _C.stream_ptr()), "dctr_crossnet_gather_head_fwd")
+            rc = _C.lib().dctr_crossnet_gather_head_fwd(ctypes.byref(a), ctypes.byref(gather), _C.stream_ptr())
+            if rc == _C.E_UNSUPPORTED:
+                raise _GatherUnsupported()
+            _C.check(rc, "dctr_crossnet_gather_head_fwd")
             return
         _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
 

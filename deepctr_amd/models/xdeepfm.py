@@ -68,22 +68,26 @@ class _xDeepFM(FusedForward, FeatureModel):
             self._cin_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=self.device)
         return self._cin_ws
 
-    def _extra_logits(self, staged, lo, hi):
-        """The CIN logit of rows [lo, hi): dctr_cin_gather_fwd on the gather arguments of the fused launch (issued in front of it)."""
+    def _extra_logit_buffers(self, B):
+        """The CIN logit vector the fused head adds."""
         if self.cin is None:
             return []
-        B = hi - lo
         bufs = self._buf.get(("logit", B))
         if bufs is None:
             if len(self._buf) >= 8:
                 self._buf.clear()
             bufs = self._buf[("logit", B)] = torch.zeros(B, dtype=torch.float32, device=self.device)
+        return [bufs]
+
+    def _launch_extra(self, staged, lo, hi, bufs):
+        """The CIN logit of rows [lo, hi): dctr_cin_gather_fwd on the gather arguments of the fused launch (issued in front of it)."""
+        if self.cin is None:
+            return
         ok = ops.cin_gather(self._fast_g, self.cin.filters, self.cin.biases, list(self.cin.layer_size), self.cin.split_half,
-                            self.cin.activation, self.cin_dim, self.dense_1.w('kernel'), bufs, self._cin_workspace(), self._cin_ws_ready)
+                            self.cin.activation, self.cin_dim, self.dense_1.w('kernel'), bufs[0], self._cin_workspace(), self._cin_ws_ready)
         if not ok:
             raise RuntimeError("dctr_cin_gather_fwd declined a shape _cin_fuse_ok() admitted")
         self._cin_ws_ready = True
-        return [bufs]
 
     # CIN's persistent-round efficiency grows with the launch (C3: 300 us per 4096-row launch, 257 us per 4096 rows at 65,536)
     span_rows = 65536

@@ -372,4 +372,7 @@ def test_round4_kernel_routes_are_chosen_from_the_model_shape():
     dm = DCN(cols(16, F=26), cols(16, F=26), cross_parameterization="matrix", device=cpu)
     assert dv._fold_ok() and not dm._fold_ok() and dm.fuse_matrix
     assert dm._cross_operands() is None
-    assert dm._extra_logits.__func__ is not DeepFM(cols(16), cols(16), device=cpu)._extra_logits.__func__
+    assert dm._launch_extra.__func__ is not DeepFM(cols(16), cols(16), device=cpu)._launch_extra.__func__
+    # allocation and launch are separate hooks: marshalling (launch_plan / prepare_launch) only allocates
+    assert [tuple(t.shape) for t in dm._extra_logit_buffers(7)] == [(7,)] and dv._extra_logit_buffers(7) == []
+    assert dm._extra_logit_buffers(7)[0] is dm._extra_logit_buffers(7)[0] and not dm._matrix_failed
