@@ -528,7 +528,7 @@ def main():
             graph.replay()
             torch.cuda.synchronize()
             tp = time.perf_counter() - t0
-            model.tile_rows = tr
+            model.tile_rows, model.span_batches = tr, True
             per_batch = {"mode": "one launch per 4096-row batch (32-row tile kernel), K launches in one hipGraph on %d streams" % n_streams,
                          "samples_per_s": K * B / tp, "ms_per_step": tp / K * 1e3,
                          "aggregate_frac_of_f32_mfma_peak": K * B / tp * DNN_FLOP_PER_SAMPLE / 1e12 / F32_MFMA_PEAK_TF}

@@ -35,6 +35,7 @@ class Staged(object):
     def __init__(self, n):
         self.n = n
         self.ids = None          # [R, N] int32|int64: one row per gather field
+        self.hashed = None       # [n_fields, N]: the gather fields' ids with Hash.call already applied (EmbeddingStage.hash_staged)
         self.dense = None        # [N, ND] float32
         self.seq = {}            # varlen feature name -> [N, T] ids
         self.length = {}         # length_name -> [N] int32
@@ -332,7 +333,31 @@ class EmbeddingStage(object):
         for fc in self.varlen_features():
             self.stage_varlen(x, staged, fc)
         if dev.type == "cuda":
+            self.hash_staged(staged, 0, staged.n)
             torch.cuda.current_stream(dev).synchronize()      # the pinned buffers are re-used by the next call
+
+    # Hash.call once, where the ids arrive (reference inputs.py:108-110 hashes each feature right behind its Input as well): the
+    # staged id matrix of a model with hashed SparseFeat gets a second matrix of bucket indices, filled by ONE dctr_hash_fields launch
+    # per staged range — on the copy stream for chunked feeds, i.e. under the scoring of the previous chunk — and every fused launch
+    # on those rows sees plain rows: no hash launch in front of a forward, no hashing inside the 32-row kernel.  False: the ids are
+    # hashed per forward call (the pre-pass launch of `prehash`, or in-kernel on small launches)
+    hash_at_stage = True
+
+    def _hash_desc(self):
+        if getattr(self, "_hdesc", None) is None:
+            fields = [dict(table=f.table, lin_table=f.lin_table, vocab=f.table.shape[0], dim=f.dim, out_offset=f.out_offset,
+                           in_fm=f.in_fm, hash_mode=f.hash_mode) for f in self.fields]
+            self._hdesc = ops.make_field_descriptors(fields, self.device)
+        return self._hdesc
+
+    def hash_staged(self, staged, lo, hi):
+        """Rows [lo, hi) of the staged ids -> ``staged.hashed`` (allocated on first use), on the current stream."""
+        if not (self.hash_at_stage and self.any_hash and self.fields and staged.ids is not None and hi > lo):
+            return
+        nf = len(self.fields)
+        if staged.hashed is None:
+            staged.hashed = torch.empty(nf, staged.n, dtype=staged.ids.dtype, device=self.device)
+        ops.hash_fields(self._hash_desc(), nf, staged.ids[:nf, lo:hi], staged.hashed[:, lo:hi])
 
     # -- chunked staging: pack chunk k+1 on the host while chunk k crosses PCIe and chunk k-1 is being scored --------
     def pipeline_plan(self, x, n):
@@ -399,6 +424,8 @@ class EmbeddingStage(object):
                     tmp = self._dev_tmp(("dense", k % 2), (ND, m), torch.float32)
                     tmp.copy_(pin, non_blocking=True)
                     staged.dense[lo:hi].copy_(tmp.t())
+                if F:
+                    self.hash_staged(staged, lo, hi)        # (copy stream: under the scoring of the previous chunk)
                 ev.record(cs)
             cur.wait_event(ev)
             yield lo, hi
@@ -555,6 +582,8 @@ class EmbeddingStage(object):
         [n_fields, >= B] matrix — prepared launches that may run on several streams (or sit in one multi-stream hipGraph) bring their
         own; the shared scratch below is only safe for launches that serialise on one stream and is never reallocated smaller."""
         B, nf = hi - lo, len(self.fields)
+        if staged.hashed is not None:                      # hashed when staged (hash_staged): a view, no launch
+            return staged.hashed[:, lo:hi]
         if out is not None:
             out = out[:, :B]
             ops.hash_fields(ws["desc"], nf, staged.ids[:nf, lo:hi], out)
@@ -878,9 +907,10 @@ class Model(object):
         return max(bs, span) if span > 0 else bs
 
     @on_model_device
-    def predict_tensor(self, x, batch_size=256):
+    def predict_tensor(self, x, batch_size=256, _span_done=None):
         """predict() that leaves the [N] result on the device (used by the distributed path).  ``x``: the reference's feed (dict /
-        list of columns), or a ``Staged`` object from ``stage()`` — rows already resident on the device are scored where they lie."""
+        list of columns), or a ``Staged`` object from ``stage()`` — rows already resident on the device are scored where they lie.
+        ``_span_done(lo, hi, out)`` is called behind every _forward call (predict(): the result's copy-out under the next span)."""
         pipe = None if isinstance(x, Staged) else self._pipeline(x, batch_size)
         if pipe is not None:
             staged, chunks, bs = pipe
@@ -891,6 +921,8 @@ class Model(object):
                 for lo in range(c_lo, c_hi, bs):
                     hi = min(c_hi, lo + bs)
                     self._forward(staged, lo, hi, out[lo:hi])
+                    if _span_done is not None:
+                        _span_done(lo, hi, out)
             self._check_status()
             return out
         staged = x if isinstance(x, Staged) else self.stage(x)
@@ -902,19 +934,32 @@ class Model(object):
         for lo in range(0, staged.n, bs):
             hi = min(staged.n, lo + bs)
             self._forward(staged, lo, hi, out[lo:hi])
+            if _span_done is not None:
+                _span_done(lo, hi, out)
         self._check_status()
         return out
 
     _PINNED_RESULT_ROWS = 1 << 18     # results of at least this many rows come back through a pinned buffer (pageable D2H: ~5 GB/s)
 
     def predict(self, x, batch_size=256, verbose=0, **kwargs):
-        out = self.predict_tensor(x, batch_size)
-        if out.numel() >= self._PINNED_RESULT_ROWS:
-            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-            host.copy_(out, non_blocking=True)
-            torch.cuda.current_stream(self.device).synchronize()
-            return host.numpy().reshape(-1, 1)
-        return out.cpu().numpy().reshape(-1, 1)
+        n = x.n if isinstance(x, Staged) else self._num_rows(self._as_feed(x))
+        if n < self._PINNED_RESULT_ROWS:
+            return self.predict_tensor(x, batch_size).cpu().numpy().reshape(-1, 1)
+        # large results: every span's probabilities leave on a copy stream, into pinned memory, while the next span is scored
+        host = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream(self.device)
+
+            def span_done(lo, hi, out):
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    host[lo:hi].copy_(out[lo:hi], non_blocking=True)
+            out = self.predict_tensor(x, batch_size, _span_done=span_done)
+            side.synchronize()
+            del out
+        return host.numpy().reshape(-1, 1)
 
     def predict_on_batch(self, x):
         return self.predict(x, batch_size=None)

@@ -253,7 +253,7 @@ class FusedForward(object):
         from .. import _C
         sp, B = self.stage_plan, hi - lo
         padded = self._use_padded(B)
-        pre = self._prehash(B)
+        pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)     # (ids hashed at stage(): plain rows at every size)
         bf3 = self._bf3_on(B)
         key = (B, padded, pre, bf3)
         c = self._fast.get(key)
@@ -320,16 +320,18 @@ class FusedForward(object):
         from .. import _C
         self._forward_fast_args(staged, lo, hi, out)
         B = hi - lo
-        pre = self._prehash(B)
+        sp = self.stage_plan
+        pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)
         g, m, keep, ws = self._fast[(B, self._use_padded(B), pre,
                                      self._bf3_on(B))]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
-        sp = self.stage_plan
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
         import torch
         # its own hashed-id matrix and its own extra-logit vectors: prepared launches may run on several streams / in one multi-stream
         # graph (the per-B vectors of _extra_logit_buffers serve ONE stream)
+        # (ids hashed at stage(): the struct already points into staged.hashed, nothing to launch)
+        pre = pre and staged.hashed is None
         own_ids = torch.empty(len(sp.fields), B, dtype=staged.ids.dtype, device=self.device) if pre else None
         own_add = [torch.empty_like(t) for t in self._extra_logit_buffers(B)]
         for i, t in enumerate(own_add):

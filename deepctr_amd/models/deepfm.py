@@ -41,7 +41,7 @@ class _DeepFM(FusedForward, FeatureModel):
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
             ws = sp.run_pools(staged, lo, hi, light=True)
             sp.run_lin_only(staged, lo, hi, ws)
-            hashed = sp.prehash(staged, lo, hi, ws) if self._prehash(hi - lo) else None
+            hashed = sp.prehash(staged, lo, hi, ws) if (self._prehash(hi - lo) or (staged.hashed is not None and sp.any_hash)) else None
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
             ks, bs, hw, bn = self._dnn_operands(hi - lo)
             ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,

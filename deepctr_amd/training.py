@@ -354,6 +354,8 @@ def permute_staged_(staged, yt, perm, wt=None):
         staged.ids.copy_(staged.ids.index_select(1, perm))
     if staged.dense is not None:
         staged.dense.copy_(staged.dense.index_select(0, perm))
+    if getattr(staged, "hashed", None) is not None:
+        staged.hashed.copy_(staged.hashed.index_select(1, perm))
     for group in (staged.seq, staged.length, staged.weight):
         for k in group:
             group[k].copy_(group[k].index_select(0, perm))

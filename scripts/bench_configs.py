@@ -128,8 +128,27 @@ def main():
         m = DeepFM(colsh, colsh, device=dev)
         init_on_device(m)
         for rows in (65536, 131072):
-            run_span("C2 hash DeepFM (hash pre-pass + chain)", m, criteo(rng, rows, V=2 ** 31 - 1), 4096, dnn_flop=dnn_flop(429))
+            feed = criteo(rng, rows, V=2 ** 31 - 1)
+            # ids hashed where they are staged (EmbeddingStage.hash_staged: ONE dctr_hash_fields launch per staged range, on the copy
+            # stream for chunked feeds): the forward call is the chain kernel alone; the hash launch's own duration is printed beside it
+            run_span("C2 hash DeepFM (hashed at stage() + chain)", m, feed, 4096, dnn_flop=dnn_flop(429))
+            st = m.stage(feed)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ts = []
+            for _ in range(5):
+                e0.record()
+                m.stage_plan.hash_staged(st, 0, st.n)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            print("%-40s rows=%-7d %9.2f us per launch = %.2f us per 4096 rows (once per staged range, not per forward)" % (
+                "   dctr_hash_fields at stage()", rows, float(np.median(ts)), float(np.median(ts)) * 4096 / rows), flush=True)
+            m.stage_plan.hash_at_stage = False          # A/B: the round-4 route, a hash launch in front of every forward call
+            run_span("C2 hash DeepFM (hash pre-pass per call + chain)", m, feed, 4096, dnn_flop=dnn_flop(429))
+            m.stage_plan.hash_at_stage = True
         m.span_batches = False
+        run("C2 hash DeepFM (1 launch/step, hashed at stage())", m, criteo(rng, ring * 4096, V=2 ** 31 - 1), 4096, args.steps, ring)
+        m.stage_plan.hash_at_stage = False
         run("C2 hash DeepFM (1 launch/step, in-kernel hash)", m, criteo(rng, ring * 4096, V=2 ** 31 - 1), 4096, args.steps, ring)
         del m
     if "c2_varlen" in want:  # north_star's field mix: 26 SparseFeat + two masked mean-pooled VarLenSparseFeat (T = 20) + 13 dense

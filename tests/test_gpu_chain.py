@@ -389,6 +389,66 @@ def test_chain_kernel_takes_hashed_sparse_features(device):
         assert_close(y, y32, rtol=2e-6, atol=2e-7, what="chain + hash pre-pass vs 32-row kernel")
 
 
+def test_ids_hashed_at_stage_give_the_bits_of_the_per_call_hash_routes(device):
+    """Hash.call where the ids are staged (EmbeddingStage.hash_staged: one dctr_hash_fields launch per staged range) against the two
+    per-forward routes it replaces — the hash launch in front of the row-chained kernel and the hashing inside the 32-row kernel's
+    gather: the same bucket for every id (staged.hashed vs the oracle's FarmHash), the same output BITS on every route, at launch
+    sizes on both sides of the row-chained threshold, through the chunked staging pipeline, and in a prepared launch."""
+    import torch
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM, xDeepFM
+    from oracle import farmhash as fh
+    rng = np.random.RandomState(77)
+    n, E = 16384 + 4096 + 5, 16
+    cols = [SparseFeat("C%d" % i, 3000 + 7 * i, E, use_hash=(i % 3 != 1)) for i in range(9)] + [DenseFeat("I%d" % i, 1) for i in range(4)]
+    feed = {"C%d" % i: (rng.randint(-2 ** 31, 2 ** 31 - 1, n).astype(np.int32) if i % 3 != 1 else rng.randint(0, 3000 + 7 * i, n).astype(np.int32))
+            for i in range(9)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(4)})
+    model = DeepFM(cols, cols, device=device)
+    _randomise(model, rng)
+    sp = model.stage_plan
+    staged = model.stage(feed)
+    assert staged.hashed is not None and tuple(staged.hashed.shape) == (9, n)
+    h = staged.hashed.cpu().numpy()
+    for i in (0, 2, 8):                                   # bit-exact bucket assignment (north_star), first / last 200 rows
+        rows = np.r_[0:200, n - 200:n]
+        want = fh.hash_bucket_int(feed["C%d" % i][rows], 3000 + 7 * i)
+        assert np.array_equal(h[i][rows].astype(np.int64), np.asarray(want, dtype=np.int64).reshape(-1))
+    assert np.array_equal(h[1], feed["C1"])               # a plain field is copied through
+    out = torch.empty(n, device=device)
+    plan = model.launch_plan(staged, 0, n, out)
+    assert all(k == "chain" for _, k, _ in plan)
+    y_stage = model.predict(feed, batch_size=4096)
+    assert _last_kernel() == "chain"
+    y_stage_tile = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+    assert _last_kernel() == "tile"
+    sp.hash_at_stage = False
+    try:
+        assert model.stage(feed).hashed is None
+        y_pre = model.predict(feed, batch_size=4096)      # hash launch in front of the chain kernel
+        y_in = _predict(model, feed, 4096, span_batches=False, tile_rows=32)      # hashing inside the 32-row kernel
+    finally:
+        sp.hash_at_stage = True
+    assert np.array_equal(y_stage, y_pre) and np.array_equal(y_stage_tile, y_in)
+    # a prepared launch on hashed-at-stage rows points into staged.hashed: no scratch id matrix of its own
+    fn = model.prepare_launch(staged, 0, n, out)
+    assert fn.keep[6] is None
+    fn()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(-1, 1), y_stage)
+    # the chunked staging pipeline (>= 2^18 rows of host columns) hashes every chunk on the copy stream
+    big = 2 ** 18 + 4096 + 3
+    fb = {k: np.resize(v, big) for k, v in feed.items()}
+    yb = model.predict(fb, batch_size=4096)
+    assert np.array_equal(yb[:n], y_stage) and np.array_equal(yb[n:2 * n], y_stage)
+    # xDeepFM: the CIN launch reads the same hashed matrix
+    x = xDeepFM(cols, cols, cin_layer_size=(16, 16), device=device)
+    _randomise(x, rng)
+    yx = x.predict(feed, batch_size=4096)
+    x.stage_plan.hash_at_stage = False
+    assert np.array_equal(x.predict(feed, batch_size=4096), yx)
+
+
 @pytest.mark.parametrize("E,n,F,ND", [(16, 20 * 4096, 26, 13), (32, 16384 + 4096 + 77, 26, 13), (16, 16384 + 129, 7, 0), (32, 700, 12, 20)])
 def test_chain_bf16x3_exploratory_precision(device, E, n, F, ND):
     """The EXPLORATORY precision (dctr_mlp_args_t.precision = 1 / 2; model.matrix_precision = "bf16x3"): every MLP product as three
