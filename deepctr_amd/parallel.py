@@ -107,3 +107,24 @@ def evaluate_distributed(model, x, y, batch_size=256, group=None):
     first = bce if loss_name in ("binary_crossentropy", "logloss") else se
     out = sharded_loss(torch.stack([first, se, ae, acc]), n, group)
     return {"loss": float(out[0]), "mse": float(out[1]), "mae": float(out[2]), "accuracy": float(out[3])}
+
+
+def fit_distributed(model, x, y, batch_size=256, epochs=1, verbose=0, shuffle=True, group=None, seed=None, **kwargs):
+    """``model.fit`` with every GLOBAL batch of ``batch_size`` rows split across the ranks of the process group (the reference's
+    multi-GPU example trains: examples/run_classification_criteo_multi_gpu.py:47-52).  Every rank passes the same ``x`` / ``y`` and
+    holds the same weights; gradients are exchanged once per step (training._DataParallel: the touched rows of the embedding tables
+    + the dense gradients in one all-reduce) and every rank applies the same update, so the replicas stay identical.  Returns the
+    History of ``fit`` (the loss is the mean over all ranks' rows)."""
+    from .training import _DataParallel, fit_model
+    dp = _DataParallel(group, seed)
+    with torch.cuda.device(model.device) if model.device.type == "cuda" else _null():
+        return fit_model(model, x, y, batch_size=batch_size, epochs=epochs, verbose=verbose if dp.rank == 0 else 0, shuffle=shuffle,
+                         _dp=dp, **kwargs)
+
+
+class _null(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -680,12 +680,22 @@ class HipTrainer(object):
             ops.embed_pool_bwd(args, d_out=buf["pooled_g"][f.fc.name], d_lin_out=buf["pooled_lin_g"].get(f.fc.name),
                                g_table=pt.g, g_lin_table=None if pl is None else pl.g, touched=pt.touched)
         self._join_side()
-        if not apply:
-            return None if loss_acc is not None else buf["loss"] / B
-        # optimizer: one launch over every parameter
+        if apply:
+            self.apply_update()
+        return None if loss_acc is not None else buf["loss"] / B
+
+    def apply_update(self):
+        """The optimizer step over every parameter in one launch (the gradients are zeroed behind it).  Separate from ``step`` so
+        that a data-parallel fit can exchange the gradients of a step between its backward and its update (training._DataParallel)."""
         self.t += 1
         lr = self.lr
         if self.kind == "adam":
             lr = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         ops.opt_multi(self.kind, self.segs, self.n_segs, self.max_n, lr, self.b1, self.b2, self.eps)
-        return None if loss_acc is not None else buf["loss"] / B
+
+    def batch_statistics(self):
+        """True when the step takes statistics over the BATCH (training-mode BatchNormalization / Dice): a rank's shard of a global batch
+        then sees other statistics than the whole batch would — data-parallel fit refuses such models instead of training something else."""
+        la = self.model.attention.local_att if self.is_din else None
+        din_dice = la is not None and la.dnn.activation in ("dice", "Dice") and not getattr(self.model, "hip_dice_stored_statistics", False)
+        return bool(self.bn_layers or self.dice_dnn or din_dice)

@@ -98,3 +98,69 @@ def test_sharded_loss_all_reduce_gloo_world2(n):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(ok for _, ok in res)
+
+
+def _fit_worker(rank, world, port, q):
+    """Data-parallel fit (training._DataParallel) on the torch-autograd step, CPU models, gloo."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deepctr_amd import engine, training
+        from deepctr_amd.feature_column import DenseFeat, SparseFeat
+        from deepctr_amd.models import DeepFM
+        torch.set_num_threads(1)
+        rng = np.random.RandomState(11)
+        n, bs = 101, 32                                   # last batch: 5 rows (3 + 2); the 1-row case is covered by n = 97 below
+        cols = [SparseFeat("a", 20, 4), SparseFeat("b", 9, 4), DenseFeat("d", 2)]
+        feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 9, n), "d": rng.rand(n, 2).astype(np.float32)}
+        yv = (feed["b"] % 2).astype(np.float32)
+
+        def run(dp, n_rows, shuffle, epochs=2):
+            fd = {k: v[:n_rows] for k, v in feed.items()}
+            model = DeepFM(cols, cols, dnn_hidden_units=(8,), l2_reg_linear=1e-4, l2_reg_embedding=1e-4, seed=7, device=torch.device("cpu"))
+            model.compile("sgd", "binary_crossentropy")
+            staged = engine.Staged(n_rows)
+            model._stage_inputs(fd, staged)
+            h = training._fit_torch(model, staged, torch.from_numpy(yv[:n_rows].copy()), n_rows, bs, epochs, shuffle,
+                                    training._EpochEnd(model, fd, yv[:n_rows], n_rows, 0, bs, epochs, 0, None, None),
+                                    **({} if dp is None else {"dp": dp}))
+            return model.get_weights_by_name(), h.history["loss"]
+
+        ok = True
+        for n_rows in (101, 97):                         # 97 = 3 * 32 + 1: rank 1's shard of the last batch is EMPTY
+            w_dp, loss_dp = run(training._DataParallel(seed=5), n_rows, False)
+            w_1, loss_1 = run(None, n_rows, False)       # the same global batches in one process
+            ok = ok and all(np.allclose(w_dp[k], w_1[k], rtol=2e-5, atol=2e-7) for k in w_1)
+            ok = ok and np.allclose(loss_dp, loss_1, rtol=1e-5)
+        # shuffled: both ranks draw the same permutation (seed broadcast from rank 0) -> identical replicas
+        w_s, _ = run(training._DataParallel(seed=None), 101, True)
+        flat = torch.from_numpy(np.concatenate([v.reshape(-1) for v in w_s.values()]).astype(np.float64))
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        ok = ok and bool(torch.equal(flat, other))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_fit_gloo_world2_equals_single_process():
+    """fit() across ranks (the reference's multi-GPU example trains: examples/run_classification_criteo_multi_gpu.py:47-52): two
+    gloo ranks, each on its shard of every global batch, gradients exchanged per step -> the weights and the epoch losses of ONE
+    process on the same global batches (up to the summation order of the two half-batch gradients), also when a rank's shard of
+    the last batch is empty; with shuffling the replicas stay bit-identical with each other."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1] and all(ok for _, ok in res)

@@ -190,3 +190,93 @@ def test_two_ranks_on_one_gpu_gloo_predict_and_evaluate_equal_single_process(dev
     for r, (rc, out, err) in enumerate(outs):
         assert rc == 0, (r, out[-2000:], err[-3000:])
         assert "RANK%d_OK" % r in out, (r, out[-2000:])
+
+
+# ---- fit() across ranks: two processes on the one GPU (gloo), the HIP training step on each rank's shard of every global batch,
+# gradients exchanged per step (training._DataParallel: touched rows of the tables + dense gradients in one all-reduce).  Against ONE
+# process on the same global batches: the two half-batch gradients add up in another order, so weights agree to fp32 rounding, not bits;
+# the two replicas agree with each other bit for bit.
+_CHILD_FIT = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from deepctr_amd import parallel
+from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+from deepctr_amd.models import DCN, DeepFM, xDeepFM
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.RandomState(5)
+n, bs = 3 * 2048 + 777, 2048                        # the last global batch is ragged: 389 + 388 rows
+cols = [SparseFeat("C%%d" %% i, 300 + 40 * i, 8, use_hash=(i == 3)) for i in range(6)] + [DenseFeat("I%%d" %% i, 1) for i in range(3)]
+cols.append(VarLenSparseFeat(SparseFeat("tags", 60, 8), maxlen=5, combiner="mean"))
+feed = {"C%%d" %% i: rng.randint(0, 300 + 40 * i, n).astype(np.int32) for i in range(6)}
+feed.update({"I%%d" %% i: rng.rand(n).astype(np.float32) for i in range(3)})
+feed["tags"] = rng.randint(0, 60, (n, 5)).astype(np.int32)
+labels = ((feed["C1"] + feed["C2"]) %% 2).astype(np.float32)
+ok = True
+for ctor, kw in ((DeepFM, {}), (DCN, {"cross_num": 2}), (xDeepFM, {"cin_layer_size": (8, 8)})):
+    ws = {}
+    for mode in ("dp", "single"):
+        m = ctor(cols, cols, dnn_hidden_units=(32, 16), device=dev, **kw)
+        r2 = np.random.RandomState(9)
+        m.set_weights_by_name({k: (r2.standard_normal(v.shape) * (0.05 if k.endswith("embeddings") else 0.1)).astype(np.float32)
+                               for k, v in m.get_weights_by_name().items()})
+        m.compile("adam", "binary_crossentropy")
+        if mode == "dp":
+            h = parallel.fit_distributed(m, feed, labels, batch_size=bs, epochs=2, shuffle=False)
+        else:
+            h = m.fit(feed, labels, batch_size=bs, epochs=2, shuffle=False, verbose=0)
+        assert getattr(m, "_hip_trainer", None) is not None, "the HIP training step did not run"
+        ws[mode] = (m.get_weights_by_name(), h.history["loss"])
+    for k, v in ws["single"][0].items():
+        d = np.abs(ws["dp"][0][k] - v).max()
+        good = bool(np.allclose(ws["dp"][0][k], v, rtol=2e-4, atol=2e-6))
+        if not good:
+            print("rank %%d %%s %%s: max diff %%.3e" %% (rank, ctor.__name__, k, d), flush=True)
+        ok = ok and good
+    ok = ok and bool(np.allclose(ws["dp"][1], ws["single"][1], rtol=1e-4))
+    print("rank %%d %%s losses dp %%r single %%r" %% (rank, ctor.__name__, ws["dp"][1], ws["single"][1]), flush=True)
+    flat = torch.from_numpy(np.concatenate([v.reshape(-1) for v in ws["dp"][0].values()]).astype(np.float64))
+    other = flat.clone()
+    dist.broadcast(other, src=0)
+    same = bool(torch.equal(flat, other))           # the replicas: bit-identical with each other
+    print("rank %%d %%s replicas identical: %%s" %% (rank, ctor.__name__, same), flush=True)
+    ok = ok and same
+    # shuffled epochs: both ranks must draw the same permutation
+    m = ctor(cols, cols, dnn_hidden_units=(32, 16), device=dev, **kw)
+    m.compile("adam", "binary_crossentropy")
+    h = parallel.fit_distributed(m, feed, labels, batch_size=bs, epochs=2, shuffle=True)
+    flat = torch.from_numpy(np.concatenate([v.reshape(-1) for v in m.get_weights_by_name().values()]).astype(np.float64))
+    other = flat.clone()
+    dist.broadcast(other, src=0)
+    ok = ok and bool(torch.equal(flat, other)) and h.history["loss"][1] < h.history["loss"][0]
+dist.barrier()
+dist.destroy_process_group()
+print("RANK%%d_OK" %% rank if ok else "RANK%%d_MISMATCH" %% rank, flush=True)
+'''
+
+
+def test_two_ranks_on_one_gpu_data_parallel_fit_matches_single_process(device):
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = _env()
+        env.update({"MASTER_PORT": port, "RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+        procs.append(subprocess.Popen([sys.executable, "-c", _CHILD_FIT % {"root": ROOT}], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    for r, (rc, out, err) in enumerate(outs):
+        assert rc == 0, (r, out[-2000:], err[-3000:])
+        assert "RANK%d_OK" % r in out, (r, out[-3000:])
