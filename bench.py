@@ -48,9 +48,11 @@ Extra objects on the JSON line:
                 the quantity rocprofv3 --kernel-trace reports (an identical replay of the region right after the `value`
                 region: the event pairs isolate consecutive kernels, which would cost the value region ~10 %); peak 157.3 TF; its HBM figure (algorithmic bytes / the
                 same duration, of 8 TB/s) is reported next to it as hbm_frac.  `kernel_launches` lists every kernel launch
-                of one call (rows, shape, mean duration).  `traffic` = FETCH_SIZE + WRITE_SIZE per
-                launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json, `traffic_source`), scaled
-                to this launch's rows — not measured in this run.
+                of one call (rows, shape, mean duration).  `traffic` = FETCH_SIZE + WRITE_SIZE per launch MEASURED IN THIS RUN: two
+                rocprofv3 counter passes (`--kernel-trace --pmc FETCH_SIZE`, then `WRITE_SIZE`) over a child of this command with the
+                same K and launch shape (measure_traffic; `traffic_source` says so and carries the two figures).  Without rocprofv3 on
+                PATH, with --no-traffic / --no-secondary or at N > 1 it falls back to the committed passes
+                (profiles/r04_pmc_traffic.json) scaled to this launch's rows, and says that instead.
   kernels       isolated single-batch launches of the 32-row fused kernel and of the two stand-alone kernels of the unfused
                 path: gather_fm_kernel (the HBM-bound kernel north_star names) and mlp_kernel (MFMA-bound).
   cpu_baseline  the oracle's torch-CPU restatement of the reference op sequence on the host cores, best of a sweep over
@@ -283,8 +285,58 @@ def host_preprocess(seconds, rows=200000):
     return n
 
 
+def measure_traffic(K, rows_launch, dist_name, timeout_s=240):
+    """roofline.traffic measured IN THIS RUN: FETCH_SIZE and WRITE_SIZE of the timed region's kernel from two rocprofv3 counter passes
+    over a child of this script (same K, same launch shape; `--kernel-trace --pmc <one counter>` only — counters are never combined
+    with API traces; cwd and TMPDIR = /tmp as the profiling recipe asks).  Returns (bytes per launch, description) or (None, reason).
+    Units as in rounds 1-4: the counters are KB at the L2's memory side (Infinity-Cache hits included); on this kernel's 64-B row reads
+    FETCH_SIZE was calibrated at 0.992x of a known byte count (profiles/r04_pmc_gather.json), so no correction factor is applied."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dctr_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", str(K), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic",
+               "--prewarm-ms", "10", "--regions", "2", "--parity-rows", "0", "--dist", dist_name]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=timeout_s)
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr and "chain_kernel" in row.get("Kernel_Name", ""):
+                        key = (row.get("Dispatch_Id"), row.get("Grid_Size"))
+                        vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])       # (one row per dispatch and dimension)
+            if r.returncode != 0 or not vals:
+                return None, "rocprofv3 --pmc %s pass gave no chain_kernel rows (rc %d)" % (ctr, r.returncode)
+            grids = [g for _, g in vals]
+            top = max(set(grids), key=grids.count)                                         # the K-step launches (every launch of the child)
+            got[ctr] = float(np.median([v for (_, g), v in vals.items() if g == top])), len([1 for g in grids if g == top])
+        except Exception as e:                                                             # noqa: BLE001 — never take the line down
+            return None, "rocprofv3 --pmc %s pass failed: %r" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = (got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
+    return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child of this "
+                   "command, median over %d / %d launches of %d rows; FETCH %.1f MB + WRITE %.1f MB per launch" % (
+                       got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], rows_launch, got["FETCH_SIZE"][0] * 1024 / 1e6, got["WRITE_SIZE"][0] * 1024 / 1e6))
+
+
+def dom_ok(timed):
+    """The in-run traffic pass looks for chain_kernel dispatches: only when the region's dominant kernel is the row-chained one."""
+    return bool(timed) and all(e[2] == "chain" for e in timed)
+
+
 def load_traffic(rows):
-    """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch."""
+    """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch (the fallback when the
+    in-run measurement is not available)."""
     tp = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     if not os.path.exists(tp):
         return None, None
@@ -306,6 +358,8 @@ def main():
     ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through (rounded up to whole launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-launch-per-batch and long-run measurements")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 counter passes "
+                                                              "over a child of this command); use the committed constant")
     ap.add_argument("--streams", type=int, default=8, help="one-launch-per-batch mode: batches in flight (graph branches)")
     ap.add_argument("--tile-rows", type=int, default=0,
                     help="rows per workgroup of the fused kernel: 0 = library default (row-chained kernel for launches of "
@@ -695,7 +749,14 @@ def main():
                                         "n_timed": len(ts)})
             rows_launch, dom_name, dom_rpw = shapes[0]
             t_launch = kernel_launches[0]["us"] * 1e-6
-        traffic, traffic_source = load_traffic(rows_launch)
+        traffic = traffic_source = None
+        if world == 1 and fused and K > 0 and not args.no_traffic and not args.no_secondary and dom_ok(timed):
+            traffic, traffic_source = measure_traffic(K, rows_launch, args.dist)
+        if traffic is None:
+            why = traffic_source
+            traffic, traffic_source = load_traffic(rows_launch)
+            if traffic_source and why:
+                traffic_source += "; not measured in this run: " + why
         t_fused32, t_gather, t_mlp, t_gather_lo, t_gather_big, t_gather_big_lo, big_rows = probe_kernels(model, staged, ring)
         if t_launch is not None:
             tf = DNN_FLOP_PER_SAMPLE * rows_launch / t_launch / 1e12

@@ -968,17 +968,12 @@ class Model(object):
         """The value PredictionLayer receives (reference layers/core.py:250-259: the logit before the sigmoid of task='binary') —
         not part of the reference's surface; the parity tests compare LOGITS with the oracle (BASELINE north_star: "fp32 logits
         within 1e-4 relative"), which the fp32 probabilities only show through logit(p)'s loss of digits near 0 and 1."""
-        task = self.task
-        fast = getattr(self, "_fast", None)
-        try:
+        task = self.task                    # (marshalled launches are keyed by the task, FusedForward._forward_fast_args: nothing to clear;
+        try:                                #  like tf.keras models, one model object serves one thread at a time)
             self.task = "regression"
-            if fast:
-                fast.clear()                # marshalled launches carry sigmoid_out
             return self.predict(x, batch_size)
         finally:
             self.task = task
-            if fast:
-                fast.clear()
 
     def __call__(self, x, training=False):
         return torch.from_numpy(self.predict(x, batch_size=None))

@@ -255,13 +255,13 @@ class FusedForward(object):
         padded = self._use_padded(B)
         pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)     # (ids hashed at stage(): plain rows at every size)
         bf3 = self._bf3_on(B)
-        key = (B, padded, pre, bf3)
+        key = (B, padded, pre, bf3, self.task)           # (the marshalled struct carries sigmoid_out: predict_logits has its own entries)
         c = self._fast.get(key)
         hashed = sp.prehash(staged, lo, hi, sp.light_workspace()) if pre else None
         if c is None:
             ws = sp.light_workspace()          # descriptors + status only: a launch may span any number of rows
-            if len(self._fast) > 8:
-                self._fast.clear()
+            while len(self._fast) >= 16:                 # least recently used out: a caller with ragged batch sizes keeps its
+                self._fast.pop(next(iter(self._fast)))   # frequent sizes marshalled (a wholesale clear() re-marshalled them all, forever)
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
             ks, bs, hw, bn = self._dnn_operands(B)
             m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
@@ -275,6 +275,8 @@ class FusedForward(object):
                     self._bf3 = {"ws": torch.empty(need, dtype=torch.uint8, device=self.device), "fresh": False}
                 m.workspace, m.workspace_bytes = self._bf3["ws"].data_ptr(), self._bf3["ws"].numel()
             c = self._fast[key] = (g, m, keep, ws)
+        else:
+            self._fast[key] = self._fast.pop(key)        # (dicts keep insertion order: most recently used last)
         g, m, _keep, _ws = c
         ids = staged.ids
         if hashed is not None:
@@ -322,8 +324,7 @@ class FusedForward(object):
         B = hi - lo
         sp = self.stage_plan
         pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)
-        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre,
-                                     self._bf3_on(B))]
+        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre, self._bf3_on(B), self.task)]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)

@@ -32,6 +32,38 @@ __global__ __launch_bounds__(256) void k_read(const int* __restrict__ ids, const
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// row reads + the linear-table entry of the same id (the product's request pattern: a 4-B read from a separate [V] table per field),
+// and the RECORD forms of VERDICT r04 item 4: the linear weight stored behind the row, PITCH floats per record (20: 80-B records, 1.25x
+// the memory, half of them straddle a 128-B line; 32: 128-B records, 2x the memory, never straddle) — lane q == 0 reads the fifth piece
+template <int U, int PITCH>
+__global__ __launch_bounds__(256) void k_read_lin(const int* __restrict__ ids, const float* __restrict__ tables, const float* __restrict__ lin,
+                                                  int F, int64_t V, int E, int64_t B, float* __restrict__ out) {
+    const int lpr = E / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = t / lpr;
+    const int q = (int)(t % lpr);
+    if (b >= B) return;
+    float acc = 0.f;
+    const int pitch = PITCH > 0 ? PITCH : E;
+    for (int f0 = 0; f0 < F; f0 += U) {
+        int id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) id[u] = ids[(int64_t)min(f0 + u, F - 1) * B + b];
+        float4 v[U];
+        float l[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rec = (int64_t)min(f0 + u, F - 1) * V + id[u];
+            v[u] = *reinterpret_cast<const float4*>(tables + rec * pitch + 4 * q);
+            if (PITCH > 0) l[u] = q == 0 ? tables[rec * pitch + E] : 0.f;
+            else l[u] = q == 0 ? lin[rec] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w + l[u];
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
 // the same reads + the concat write (what the stand-alone gather must do at least)
 template <int U>
 __global__ __launch_bounds__(256) void k_read_write(const int* __restrict__ ids, const float* __restrict__ tables, int F, int64_t V, int E,
@@ -104,6 +136,18 @@ int main(int argc, char** argv) {
     timeit("random row reads, 4 in flight per lane", B * (row_b + id_b), [&] { hipLaunchKernelGGL(k_read<4>, dim3(blocks), dim3(256), 0, st, ids, tables, F, V, E, B, fm); });
     timeit("random row reads, 8 in flight per lane", B * (row_b + id_b), [&] { hipLaunchKernelGGL(k_read<8>, dim3(blocks), dim3(256), 0, st, ids, tables, F, V, E, B, fm); });
     timeit("random row reads, 13 in flight per lane", B * (row_b + id_b), [&] { hipLaunchKernelGGL(k_read<13>, dim3(blocks), dim3(256), 0, st, ids, tables, F, V, E, B, fm); });
+    {
+        timeit("row reads + separate 4-B linear reads, 8 in flight", B * (row_b + 2 * id_b), [&] { hipLaunchKernelGGL((k_read_lin<8, 0>), dim3(blocks), dim3(256), 0, st, ids, tables, lin, F, V, E, B, fm); });
+        timeit("row reads + separate 4-B linear reads, 13 in flight", B * (row_b + 2 * id_b), [&] { hipLaunchKernelGGL((k_read_lin<13, 0>), dim3(blocks), dim3(256), 0, st, ids, tables, lin, F, V, E, B, fm); });
+        if (E == 16) {
+            float* rec;
+            CK(hipMalloc(&rec, (size_t)F * V * 32 * 4)); CK(hipMemset(rec, 0, (size_t)F * V * 32 * 4));
+            timeit("80-B records [V, 20] (row + linear weight), 8 in flight", B * (row_b + 2 * id_b), [&] { hipLaunchKernelGGL((k_read_lin<8, 20>), dim3(blocks), dim3(256), 0, st, ids, rec, lin, F, V, E, B, fm); });
+            timeit("80-B records [V, 20], 13 in flight", B * (row_b + 2 * id_b), [&] { hipLaunchKernelGGL((k_read_lin<13, 20>), dim3(blocks), dim3(256), 0, st, ids, rec, lin, F, V, E, B, fm); });
+            timeit("128-B records [V, 32] (2x memory), 8 in flight", B * (row_b + 2 * id_b), [&] { hipLaunchKernelGGL((k_read_lin<8, 32>), dim3(blocks), dim3(256), 0, st, ids, rec, lin, F, V, E, B, fm); });
+            CK(hipFree(rec));
+        }
+    }
     timeit("streaming write of dnn_in", (double)B * stride * 4, [&] { hipLaunchKernelGGL(k_write, dim3(256 * 8), dim3(256), 0, st, dnn_in, B * stride / 4); });
     timeit("row reads (8 in flight) + concat write", B * (2 * row_b + id_b), [&] { hipLaunchKernelGGL(k_read_write<8>, dim3(blocks), dim3(256), 0, st, ids, tables, F, V, E, B, dnn_in, stride); });
     timeit("row reads (13 in flight) + concat write", B * (2 * row_b + id_b), [&] { hipLaunchKernelGGL(k_read_write<13>, dim3(blocks), dim3(256), 0, st, ids, tables, F, V, E, B, dnn_in, stride); });
