@@ -41,42 +41,7 @@
 #pragma once
 #include "mlp_device.h"
 
-#ifdef DCTR_CHAIN_LAB_TS
-__device__ unsigned long long dctr_chain_ts[2][64];       // [wave 0 | wave 7][stamp] of workgroup 0, second pass
-#ifndef DCTR_CHAIN_TS_RT
-#define DCTR_CHAIN_TS_RT 2                     // 2: stamps of the main phase's second pass; 1: of the tail phase's first unit
-#endif
-#define CTS(i) do { if (RT == DCTR_CHAIN_TS_RT && blockIdx.x == 0 && it == (RT == 2 ? 1 : 0) && (wave == 0 || wave == NW - 1) && lane == 0) dctr_chain_ts[wave == 0 ? 0 : 1][i] = __builtin_readcyclecounter(); } while (0)
-#define CTS_STEP(b, k) do { if ((b) >= 10 && (b) < 14) CTS(8 + 4 * ((b) - 10) + (k)); } while (0)   // inside layer-0 steps 10..13
-#else
-#define CTS(i) do {} while (0)
-#define CTS_STEP(b, k) do {} while (0)
-#endif
-
-#ifdef DCTR_CHAIN_LAB_WGTS    // lab: wall-clock stamps per workgroup (kernel entry, end of the main phase, end of the tail phase)
-__device__ unsigned long long dctr_chain_wgts[1024][8];       // [0..3] wall clock (100 MHz), [4..7] shader cycle counter
-#define CWG(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { dctr_chain_wgts[blockIdx.x][i] = wall_clock64(); \
-                    dctr_chain_wgts[blockIdx.x][4 + (i)] = __builtin_readcyclecounter(); } } while (0)
-#else
-#define CWG(i) do {} while (0)
-#endif
-
-// lab ablations (scripts/chain_lab.cpp): what a step costs without its gather / its weight DMA / its barrier
-#ifdef DCTR_CHAIN_LAB_NOGATHER
-#define CHAIN_GATHER 0
-#else
-#define CHAIN_GATHER 1
-#endif
-#ifdef DCTR_CHAIN_LAB_NODMA
-#define CHAIN_DMA 0
-#else
-#define CHAIN_DMA 1
-#endif
-#ifdef DCTR_CHAIN_LAB_NOBARRIER
-#define CHAIN_BARRIER "s_nop 0"
-#else
-#define CHAIN_BARRIER "s_barrier"
-#endif
+// two schedule constants of a layer-0 step (A/B history: DESIGN.md §4)
 #ifndef CHAIN_SPREAD
 #define CHAIN_SPREAD 1                         // 1: the request phase of a layer-0 step is spread over its micro-steps (0: one block)
 #endif
@@ -104,11 +69,7 @@ constexpr int MAX_DENSE_BLOCKS = 4;
 // + [NW waves][RT N tiles][64 lanes] shares of dense . dense_lin_w of the staged pass
 // + [NW waves][4 RT quads][64 lanes] parked accumulators (layer-0 M-group M0 - 1 while layer 1 works on the others)
 static inline size_t lds_bytes(int rt, int nw, int n_dense) {
-#ifdef DCTR_CHAIN_W4X2
-    const int park = nw == 8 ? nw * 4 * rt * 256 : 0;
-#else
     const int park = nw * 4 * rt * 256;
-#endif
     return (size_t)(DENSE_OFF + nw * 16 * rt * ((n_dense + 15) & ~15) + nw * rt * 64 + park) * sizeof(float);
 }
 
@@ -185,11 +146,7 @@ __device__ __forceinline__ uint64_t sgpr64(uint32_t lo, uint32_t hi) {
 // by hipcc, the operands are visible) or from accumulators finished a layer earlier; non-MFMA reads of accumulators come
 // after mfma_drain().
 __device__ __forceinline__ void mfma_ip(f32x4& acc, float a, float b) {
-#ifndef DCTR_CHAIN_BUILTIN_MFMA
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-#else
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-#endif
 }
 // (layers >= 1 keep the builtin: their B operand is an ELEMENT of a previous layer's accumulator quad, and an inline-asm
 // operand cannot be a sub-register — every such operand would be copied out first)
@@ -270,13 +227,6 @@ struct XBlkT {
 
 // RT, NW: launch shape (above); EB = embedding_dim / 16 k-blocks per field; I64: int64 ids; M0 / M1 / M2 = units[l] / 64
 // (M2 == 0: two layers)
-#ifdef DCTR_CHAIN_W4X2     // lab: two independent 4-wave workgroups per CU for the <2, 4> shape (no parking: LDS for two)
-#define CHAIN_MIN_BLOCKS(RT, NW) ((RT) == 2 && (NW) == 4 ? 2 : 1)
-#define CHAIN_PARK(RT, NW) ((NW) == 8)
-#else
-#define CHAIN_MIN_BLOCKS(RT, NW) 1
-#define CHAIN_PARK(RT, NW) true
-#endif
 // ---- bf16 x 3 split (EXPLORATORY variant, BF3: never the default, never the headline number; dctr_mlp_args_t.precision == 1).
 // An fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|); a product x w is evaluated as
 // hi_w hi_x + hi_w lo_x + lo_w hi_x on v_mfma_f32_16x16x16_bf16 with fp32 accumulation (the lo_w lo_x term, 2^-16 relative, is dropped).
@@ -415,7 +365,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         for (int pc0 = 0; pc0 < 16; pc0 += NW) dma16(base + (size_t)(4 * pc0) * N * 4, voff, dst + (pc0 + wave) * 256);
     };
     auto dma_chunk = [&](int ci, float* dst) {
-        if (!CHAIN_DMA) return;
         if (ci >= STEPS) ci -= STEPS;
         if (ci < NB) {
             dma_l0(ci, dst);
@@ -598,19 +547,19 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     // registers are named so that hipcc places its own bookkeeping wait here and not in front of their first use
 #define CHAIN_TOP_X(X)                                                                                           \
     do {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(lvn), "+v"(idr_lo) : : "memory");   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(lvn), "+v"(idr_lo) : : "memory");   \
         if constexpr (I64) asm volatile("" : "+v"(idr_hi));                                                      \
     } while (0)
 #define CHAIN_TOP_ID()                                                                                           \
     do {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(idr_lo) : : "memory");              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(idr_lo) : : "memory");              \
         if constexpr (I64) asm volatile("" : "+v"(idr_hi));                                                      \
     } while (0)
-#define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER ::: "memory")
+#define CHAIN_TOP() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
     // FPB > 1: also the second pair's in-flight registers
 #define CHAIN_TOP_Q()                                                                                            \
     do {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" CHAIN_BARRIER : "+v"(lvn), "+v"(idr_lo), "+v"(lvnB), "+v"(idrB_lo) : : "memory");   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(lvn), "+v"(idr_lo), "+v"(lvnB), "+v"(idrB_lo) : : "memory");   \
         if constexpr (I64) asm volatile("" : "+v"(idr_hi), "+v"(idrB_hi));                                       \
     } while (0)
 
@@ -677,7 +626,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         constexpr int PH = 0;
         (void)it;
         const int pass_n = min(pass + stride, n_pass - 1);               // rows the gather prologue at the pass's end is for
-        CTS(0);
         // ================= layer 0: acc0[4 mg + mt][nt] = C tile of output features 64 mg + 4 i + mt
         f32x4 acc0[4 * M0][RT];
 #pragma unroll
@@ -786,9 +734,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         // their range check (s = PAIR - 1).  A dense k-block takes its operand from the staging rows in LDS instead
 #define CHAIN_PHASE0(XC, XN)                                                                                     \
         {                                                                                                        \
-            CTS_STEP(b_, 3);                                                                                     \
             if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                       \
-            if (CHAIN_GATHER) {                                                                                  \
+            {                                                                                  \
                 /* every request is issued unconditionally (past the last field / pair: a clamped, redundant one):   \
                    a conditionally written register keeps its old value alive — through layers 1.. where 192 of the   \
                    256 registers hold accumulators */                                                             \
@@ -806,7 +753,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 if (b_ < NBE) consume_x(b_, XC);                                                                 \
                 cross_x(b_, XC);                                                                                 \
             }                                                                                                    \
-            CTS_STEP(b_, 2);                                                                                     \
         }
         // The same requests SPREAD over the micro-steps of the step (CHAIN_SPREAD): all eight waves leave the step's barrier
         // together, and as one block the phase puts ~40 vector-memory instructions of the workgroup into the CU's address path at
@@ -820,21 +766,19 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             constexpr int i_ = (I);                                                                              \
             const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                     \
             if (i_ == 0) {                                                                                       \
-                CTS_STEP(b_, 3);                                                                                 \
                 if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                   \
-                if (CHAIN_GATHER && s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                    \
-                if (CHAIN_GATHER && s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);            \
-                CTS_STEP(b_, 2);                                                                                 \
+                if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                    \
+                if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);            \
             }                                                                                                    \
-            if (CHAIN_GATHER && i_ == 1) {                                                                       \
+            if (i_ == 1) {                                                                       \
                 if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN, std::integral_constant<int, 0>{});      \
                 else issue_x1(min(b_ + 1, NBE - 1), idcn, 0, XN, std::integral_constant<int, 0>{});             \
             }                                                                                                    \
-            if (CHAIN_GATHER && i_ == 2 && RT > 1) {                                                             \
+            if (i_ == 2 && RT > 1) {                                                             \
                 if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN, std::integral_constant<int, RT - 1>{}); \
                 else issue_x1(min(b_ + 1, NBE - 1), idcn, 0, XN, std::integral_constant<int, RT - 1>{});        \
             }                                                                                                    \
-            if (CHAIN_GATHER && i_ == 3) {                                                                       \
+            if (i_ == 3) {                                                                       \
                 if (s_ == 0) {                                                                                   \
                     bool has_;                                                                                   \
                     lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
@@ -842,7 +786,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 }                                                                                                \
                 if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
             }                                                                                                    \
-            if (CHAIN_GATHER && i_ == 2 * M0 - 1) {                                                              \
+            if (i_ == 2 * M0 - 1) {                                                              \
                 if (b_ < NBE) consume_x(b_, XC);                                                                 \
                 cross_x(b_, XC);                                                                                 \
             }                                                                                                    \
@@ -851,9 +795,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         {                                                                                                        \
             constexpr int s_ = (S);                                                                              \
             const int b_ = pr_ * PAIR + s_;                                                                      \
-            CTS_STEP(b_, 0);                                                                                     \
             CHAIN_TOP_X(XC);                                                                                     \
-            CTS_STEP(b_, 1);                                                                                     \
             const float* sb_ = slot_ptr(0);                                                                      \
             if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
             if (DEEP && b_ == 0) c1 = read_l0(sb_, 1);                                                           \
@@ -966,16 +908,16 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             constexpr int i_ = (I);                                                                              \
             if (i_ == 0) {                                                                                       \
                 if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                   \
-                if (CHAIN_GATHER) {                                                                              \
+                {                                                                              \
                     idcn = fold_pair_ids(PPB * (b_ + 1), pass, idr_lo, idr_hi);                                  \
                     if constexpr (PPB > 1) idcnB = fold_pair_ids(PPB * (b_ + 1) + 1, pass, idrB_lo, idrB_hi);    \
                     linacc += (lvn_has && b_ >= 1 && b_ - 1 < NBE) ? lvn : 0.f;                                  \
                     if constexpr (PPB > 1) linacc += (lvnB_has && b_ >= 1 && b_ - 1 < NBE) ? lvnB : 0.f;         \
                 }                                                                                                \
             }                                                                                                    \
-            if (CHAIN_GATHER && i_ == 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, 0>{});         \
-            if (CHAIN_GATHER && i_ == 2 && RT > 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, RT - 1>{}); \
-            if (CHAIN_GATHER && i_ == 3) {                                                                       \
+            if (i_ == 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, 0>{});         \
+            if (i_ == 2 && RT > 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, RT - 1>{}); \
+            if (i_ == 3) {                                                                       \
                 bool has_;                                                                                       \
                 lvn = *pair_lin_ptr(PPB * b_, idc, has_);                                                        \
                 lvn_has = has_;                                                                                  \
@@ -986,7 +928,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 request_pair_ids(PPB * (b_ + 2), pass, idr_lo, idr_hi);                                          \
                 if constexpr (PPB > 1) request_pair_ids(PPB * (b_ + 2) + 1, pass, idrB_lo, idrB_hi);             \
             }                                                                                                    \
-            if (CHAIN_GATHER && i_ == 2 * M0 - 1) {                                                              \
+            if (i_ == 2 * M0 - 1) {                                                              \
                 if (b_ < NBE) consume_x(b_, XC);                                                                 \
             }                                                                                                    \
         }
@@ -1092,7 +1034,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             linacc += lvn_has ? lvn : 0.f;
         }
         mfma_drain();
-        CTS(1);
         // ---- gather epilogue of the pass: FM = 0.5 (sum_d (sum_f e)^2 - sum_{f,d} e^2) lane-local, then over g; the linear
         // terms sit row per lane (lane l and l + 32: the two fields of every pair) and go to the (g, j) lanes by bpermute
         float extras[RT];
@@ -1164,7 +1105,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 }
         };
         if constexpr (BF3) pack_bf(acc0, std::integral_constant<int, 4 * M0>{});
-        if constexpr (M0 > 1 && CHAIN_PARK(RT, NW)) {
+        if constexpr (M0 > 1) {
             f32x4* park = park_ptr();
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -1198,7 +1139,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         // (the generic lambda is instantiated per layer; MI / MO = M-groups of its input / output)
         auto dense_layer = [&](auto& accin, auto& accout, auto MIc, auto MOc, auto PARKc) {
             constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
-            constexpr bool PARKED = decltype(PARKc)::value && MI > 1 && CHAIN_PARK(RT, NW);      // accin's last M-group waits in LDS
+            constexpr bool PARKED = decltype(PARKc)::value && MI > 1;      // accin's last M-group waits in LDS
 #pragma unroll
             for (int mg = 0; mg < MI; ++mg) {
 #pragma unroll
@@ -1290,7 +1231,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         };
         auto dense_layer_bf = [&](auto& accin, auto& accout, auto MIc, auto MOc, auto PARKc) {
             constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
-            constexpr bool PARKED = decltype(PARKc)::value && MI > 1 && CHAIN_PARK(RT, NW);
+            constexpr bool PARKED = decltype(PARKc)::value && MI > 1;
 #pragma unroll
             for (int mg = 0; mg < MI; ++mg) {
 #pragma unroll
@@ -1367,7 +1308,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         if constexpr (BF3) dense_layer_bf(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{}, std::true_type{});
         else dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{}, std::true_type{});
         mfma_drain();
-        CTS(2);
         float hs[RT];
         // head of the last layer: act(acc) . head_w over this lane's 16 features per M-group, then over g
         auto head = [&](auto& acc, auto MGc, int layer, int bn_off) {
@@ -1409,7 +1349,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         } else {
             head(acc1, std::integral_constant<int, M1>{}, 1, 64 * M0);
         }
-        CTS(3);
         // ---- Dense(1) + linear / FM logits + add[] + global bias, PredictionLayer
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
@@ -1427,7 +1366,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 p.y[r] = v;
             }
         }
-        CTS(4);
     }
 #undef CHAIN_TOP_X
 #undef CHAIN_TOP_ID
@@ -1438,7 +1376,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
 template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false>
-__global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kernel(ChainParams p) {
+__global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1448,7 +1386,6 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
-    CWG(0);
     // ---- once per launch: descriptors, biases, head weights, BatchNormalization scale / shift, dense linear weights -> LDS
     for (int i = threadIdx.x; i < 12 * p.n_fields; i += NT)
         reinterpret_cast<uint32_t*>(fdesc)[i] = reinterpret_cast<const uint32_t*>(p.fields)[i];
@@ -1495,7 +1432,6 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
     chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
-    CWG(1);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
             // every wave is through with the ring and the staging areas of the main phase; waves 4.. leave (s_barrier waits for
@@ -1506,7 +1442,6 @@ __global__ __launch_bounds__(64 * NW, CHAIN_MIN_BLOCKS(RT, NW)) void chain_kerne
                                                                     (int)gridDim.x, p.n_tail, oor);
         }
     }
-    CWG(2);
     if (p.status != nullptr && oor && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
     if (p.probe != nullptr && lane == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
 }

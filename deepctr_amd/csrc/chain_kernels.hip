@@ -142,11 +142,7 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     p.main_rows = main_rows;
     p.n_pass = (int)dctr_ceil_div(main_rows, (int64_t)prows);
     p.n_tail = (int)dctr_ceil_div(tail_rows, (int64_t)64);
-#ifdef DCTR_CHAIN_W4X2
-    const int64_t slots = shape == 128 ? 2 * (int64_t)n_cus() : n_cus();
-#else
     const int64_t slots = n_cus();
-#endif
     const int64_t want = p.n_pass > p.n_tail ? p.n_pass : p.n_tail;
     const unsigned blocks = (unsigned)(want < slots ? want : slots);
     if (a->precision != 0) {                               // exploratory bf16 x 3 variant (eligible() admitted 256-128-64 only)

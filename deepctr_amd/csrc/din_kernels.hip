@@ -25,12 +25,6 @@ size_t compact_bytes(int64_t rows);
 size_t image_bytes();
 }
 
-#ifdef DCTR_LAB_TIMING
-__device__ unsigned long long dctr_din_ts[64];
-#define DIN_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) dctr_din_ts[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DIN_TS(i) do {} while (0)
-#endif
 
 namespace {
 
@@ -484,7 +478,6 @@ __device__ __forceinline__ void din_layer(const DinFastParams& p, int l, const f
 
 __global__ __launch_bounds__(512) void din_score_kernel(DinFastParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    DIN_TS(0);
     const int nthr = blockDim.x;
     // weights -> LDS, zero-padded to [kp][np]; batches of loads in flight per thread, then the stores.
     // LDS row k of layer 0 = W[r1] + sg * W[r2]:  k < E: Wq + Wd;  k < 2E: Wk - Wd;  k < 3E: Wp   (see din_layer0_part)
@@ -566,9 +559,7 @@ __global__ __launch_bounds__(512) void din_score_kernel(DinFastParams p) {
             reinterpret_cast<int*>(smem)[p.ok_off + NP + 1] = p.n_waves;       // first tickets = the waves' own indices
         }
     }
-    DIN_TS(1);
     __syncthreads();
-    DIN_TS(2);
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -623,13 +614,11 @@ __global__ __launch_bounds__(512) void din_score_kernel(DinFastParams p) {
         if (lane == 0) nxt = atomicAdd(ticket, 1);
         const int64_t t_next = t_lo + __builtin_amdgcn_readfirstlane(nxt);
         fetch_rows(t_next);
-        DIN_TS(3);
         const int nt0 = (p.units[0] + 15) / 16;
         if (p.n_layers == 1) {
             DIN_NT_SWITCH(nt0, (din_layer0<NT, true>(p, smem, qt, kt, tile, R0)));
         } else {
             DIN_NT_SWITCH(nt0, (din_layer0<NT, false>(p, smem, qt, kt, tile, R0)));
-            DIN_TS(4);
             for (int l = 1; l < p.n_layers; ++l) {
                 const int ntl = (p.units[l] + 15) / 16;
                 if (l == p.n_layers - 1) {
@@ -639,7 +628,6 @@ __global__ __launch_bounds__(512) void din_score_kernel(DinFastParams p) {
                 }
             }
         }
-        DIN_TS(5);
         t = t_next;
     }
 }

@@ -7,12 +7,6 @@
 #include "embed_device.h"
 #include "mfma_tile.h"
 
-#ifdef DCTR_LAB_TIMING
-extern __device__ unsigned long long dctr_lab_ts[64];
-#define LAB_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) dctr_lab_ts[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define LAB_TS(i) do {} while (0)
-#endif
 
 namespace dctr_mlp {
 
@@ -203,11 +197,7 @@ __device__ __forceinline__ void mfmas(const float (&av)[RT][SD], const float (&b
 // stage s issues its MFMAs (>= 2 x 256*TPW cycles of cover for the L2 latency of the weight stream).  The
 // sched_barriers pin the order "issue loads, then MFMAs" — without them hipcc sinks each load next to its first
 // use and the wave alternates load-wait / MFMA (measured: 62 cycles per 32-cycle MFMA).
-#ifdef DCTR_LAB_NO_SB
-#define DCTR_SB do {} while (0)
-#else
 #define DCTR_SB __builtin_amdgcn_sched_barrier(0)
-#endif
 template <int TPW, int RT, int SD>
 __device__ __forceinline__ void tile_gemm_pipe(const float* A, int lda, int KQ, int k_rows, const float* __restrict__ W,
                                                int N, int n_base, dctr::f32x4 (&acc)[RT][TPW], int lane = threadIdx.x & 63) {
@@ -339,12 +329,7 @@ __device__ __forceinline__ void layer_tiles(const MlpParams& p, int l, const flo
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int c = 0; c < TPW; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef DCTR_LAB_COPIES
-        tile_gemm_pipe<TPW, RT, StageDepth<RT>::value>(in, p.lda, pad64(K) / 4, K,
-                                                       p.W[l] + (size_t)((blockIdx.x / 8) % DCTR_LAB_COPIES) * 110080, N, n_base, acc);
-#else
         tile_gemm_pipe<TPW, RT, StageDepth<RT>::value>(in, p.lda, pad64(K) / 4, K, p.W[l], N, n_base, acc);
-#endif
         tile_epilogue<TPW, ACT, RT>(p, l, out, N, n_base, acc);
     }
     zero_k_padding<RT>(p, out, N);
@@ -516,7 +501,6 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
         for (int m = 0; m < 16; ++m) dx[m] = src[min(m, g.n_dense - 1)];
     }
 
-    LAB_TS(ck.first ? 20 : 30);
     // The wave's work items are (field, pass) pairs: field f_lo + wave + NWAVE*fi, samples pass*SPW + s.  They are
     // processed eight at a time in branch-free phases — 8 id loads, then 8 row + 8 linear loads, then use — so a chunk
     // costs two memory round trips whatever PASSES is (one pass at a time cost 2*PASSES of them).
@@ -612,10 +596,8 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
         rp[(VEC + 1) * 64] = lin[ps];
     }
     if (g.status != nullptr && __any(oor) && lane == 0) atomicOr(g.status, (int)DCTR_STATUS_INDEX_OOR);
-    LAB_TS(ck.first ? 21 : 31);
     if (!ck.last) {
         __syncthreads();
-        LAB_TS(22);
         return;
     }
 
@@ -655,7 +637,6 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
     }
     __syncthreads();
 
-    LAB_TS(32);
     // combine the waves' partial sums: FM = 0.5 * (sum_d (sum_f e)^2 - sum_d sum_f e^2), linear = sum of 1-wide rows
     if (threadIdx.x < PASSES * 64) {
         const int pass = threadIdx.x >> 6;
@@ -686,7 +667,6 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
         }
     }
     __syncthreads();     // `red` aliases the tile the first layer writes
-    LAB_TS(33);
 }
 
 template <int RT>
@@ -733,7 +713,6 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
     float* xv = xcs + 8;                                           // [CROSS_NV][pad64(in_dim)] the cross vectors, zero-padded
     const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    LAB_TS(0);
     if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
 
     if (p.cross_layers > 0) {
@@ -764,7 +743,6 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         const Chunk ck{0, pad64(p.in_dim) / 4, 0, n_fields, true, true};
         produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);       // partial sums live in the (still unused) 2nd tile
         if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
-        LAB_TS(1);
     } else {
         // layer 0 in two K-halves: every wave owns ONE wave-tile of the layer output (host guarantees it) and keeps
         // its accumulators in registers while the second half of the input tile replaces the first in LDS
@@ -785,7 +763,6 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
             const Chunk ck{0, cw0 / 4, 0, f_mid, true, false};
             produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
             if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
-            LAB_TS(1);
             if (wave < n_tiles) {
                 if (wide) tile_gemm_pipe<2, RT, SD>(buf0, p.lda, cw0 / 4, cw0, W0, N, n_base, acc2);
                 else tile_gemm_pipe<1, RT, SD>(buf0, p.lda, cw0 / 4, cw0, W0, N, n_base, acc1);
@@ -820,7 +797,6 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
         }
         zero_k_padding<RT>(p, buf1, N);
         __syncthreads();
-        LAB_TS(2);
         in = buf1;
         out = buf0;
         K = N;
@@ -837,7 +813,6 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
             default: layer_dispatch<DCTR_ACT_LINEAR, RT>(p, l, in, out, K, N); break;
         }
         __syncthreads();
-        LAB_TS(2 + l);
         float* t = in;
         in = out;
         out = t;
@@ -883,7 +858,6 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
             if (b < p.batch) p.y[b * p.y_stride + c] = in[r * p.lda + lds_pos(c, pad64(K) / 4)];
         }
     }
-    LAB_TS(10);
     if (p.probe != nullptr && threadIdx.x == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
 }
 

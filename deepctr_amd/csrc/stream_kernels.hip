@@ -30,12 +30,6 @@
 // takes mlp_kernel.  Same arithmetic: v_mfma_f32_16x16x4_f32 = exact fp32.
 #include "mlp_device.h"
 
-#ifdef DCTR_STREAM_LAB_TS
-__device__ unsigned long long dctr_stream_ts[3][64];      // [wave 0 | wave 7 | loader][stamp] of workgroup 0, third tile
-#define STS(w, i) do { if (blockIdx.x == 0 && it == 2 && (threadIdx.x & 63) == 0) dctr_stream_ts[w][i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STS(w, i) do {} while (0)
-#endif
 
 namespace dctr_stream {
 
@@ -50,16 +44,6 @@ constexpr int NSLOT = 3;
 constexpr int SLOT_F = 4096;                   // floats per ring slot: 4 column blocks x 4 row groups x 256
 constexpr int SPIN_CHECK = 1 << 10;            // spins between looks at the wall clock
 constexpr unsigned long long WAIT_LIMIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: a hang, not a memory stall
-#ifdef DCTR_STREAM_LAB_NOLIN
-#define DCTR_LAB_LIN 0
-#else
-#define DCTR_LAB_LIN 1
-#endif
-#ifdef DCTR_STREAM_LAB_THROTTLE
-#define DCTR_LAB_THROTTLE asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define DCTR_LAB_THROTTLE do {} while (0)
-#endif
 #ifndef DCTR_STREAM_DMA_AUX
 #define DCTR_STREAM_DMA_AUX 0                  // cache policy bits of the gather DMA (lab: 2 = nt, 16 = sc1)
 #endif
@@ -353,27 +337,18 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
         // is hoisted out of this persistent loop, stays live across the MFMA loops and spills (~60 VGPRs)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int tsw = wave == 0 ? 0 : 1;
-        (void)tsw;
-        const bool tson = wave == 0 || wave == NCONS - 1;
-        if (tson) STS(tsw, 0);
         // ---- layer 0: stream the ring
         float* out = smem + p.act_off[0];
         int lda_out = pad64(N0) + 4;
         float* hpart = smem + p.hpart_off + (it & 1) * 8 * ROWS;     // [column tile <= 8][row] head partials of this tile
         const float* bias0 = p.bias_off[0] >= 0 ? cpar + p.bias_off[0] : nullptr;
         const bool single = p.n_layers == 1;
-#ifdef DCTR_STREAM_LAB_NOMFMA
-        if (false) {
-#else
         if (n_base0 < N0) {
-#endif
             if (wide0) {
                 f32x4 acc[4][2];
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) { acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 l0_stream<2>(p, ring, sync, seq0, NB, n_base0, acc, tid);
-                if (tson) STS(tsw, 1);
                 if (single) epilogue_head_act<2, 4>(p.activation, bias0, cpar + p.headw_off, hpart + wave * ROWS, N0, n_base0, acc, tid);
                 else epilogue_act<2, 4>(p.activation, bias0, out, lda_out, N0, n_base0, acc, tid);
             } else {
@@ -388,9 +363,7 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
             l0_idle(p, sync, seq0, NCH);
         }
         if (!single) zero_pad_cols(out, lda_out, N0, tid);
-        if (tson) STS(tsw, 2);
         cons_barrier(sync, epoch, p.status);
-        if (tson) STS(tsw, 3);
         // ---- layers 1..
         const float* in = out;
         int lda_in = lda_out, K = N0;
@@ -400,18 +373,12 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
             out = smem + p.act_off[l & 1];
             lda_out = pad64(N) + 4;
             const int n_ct16 = (N + 15) / 16;
-#ifdef DCTR_STREAM_LAB_NOMFMA
-            if (false) {}
-            else
-#endif
             if (N % 32 == 0 && N >= 32 * NCONS) layer_units<2, 4>(p, l, in, lda_in, out, lda_out, K, N, wave, tid, cpar, hpart);
             else if (n_ct16 > NCONS / 2) layer_units<1, 4>(p, l, in, lda_in, out, lda_out, K, N, wave, tid, cpar, hpart);
             else layer_units<1, 2>(p, l, in, lda_in, out, lda_out, K, N, wave, tid, cpar, hpart);
             n_ct_last = (N % 32 == 0 && N >= 32 * NCONS) ? N / 32 : n_ct16;
             if (l + 1 < p.n_layers) zero_pad_cols(out, lda_out, N, tid);
-            if (tson) STS(tsw, 2 + 2 * l);
             cons_barrier(sync, epoch, p.status);
-            if (tson) STS(tsw, 3 + 2 * l);
             in = out;
             lda_in = lda_out;
             K = N;
@@ -421,7 +388,6 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
         // (hpart and extras are double-buffered by tile parity: the other waves are already in the next tile's layer 0)
         if (wave == 0) {
             wait_ge(sync, S_XREADY, NLOAD * (it + 1), p.status);
-            if (tson) STS(tsw, 20);
             const int row = tid & 63;
             float v = extras[(it & 1) * ROWS + row];
             for (int ct = 0; ct < n_ct_last; ++ct) v += hpart[ct * ROWS + row];
@@ -434,7 +400,6 @@ __device__ __forceinline__ void consumer(const StreamParams& p, float* smem, int
                 if (p.sigmoid_out) v = dctr::sigmoidf_(v);
                 p.y[b] = v;
             }
-            if (tson) STS(tsw, 21);
             sig_set(sync, S_XDONE, it + 1);
         }
         seq0 += NCH;
@@ -521,14 +486,11 @@ __device__ __forceinline__ void loader(const StreamParams& p, float* smem, int w
         for (int c = 0; c < NCH; ++c) {
             const int sq_ = seq0 + c;
             const int slot = sq_ % NSLOT;
-            STS(2, 4 * c);
             wait_ge(sync, S_FREED + slot, NCONS * (sq_ / NSLOT), p.status);
-            STS(2, 4 * c + 1);
             float* sbase = ring + slot * SLOT_F + w * 256;             // + k * 1024: block k, this wave's row group
             const RawId cid = nid;
             float lv[4];
             int fm_on[4] = {0, 0, 0, 0};
-#ifndef DCTR_STREAM_LAB_NOLOAD
 #define DCTR_LD_BLOCK(K)                                                                                          \
             {                                                                                                         \
                 const int cb = 4 * c + K;                                                                             \
@@ -549,9 +511,7 @@ __device__ __forceinline__ void loader(const StreamParams& p, float* smem, int w
                     idk = ok ? idk : 0;                                                                               \
                     const float* src = table + idk * E + h * 16 + piece * 4;                                          \
                     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sbase + K * 1024), 16, 0, DCTR_STREAM_DMA_AUX); \
-                    if (DCTR_LAB_LIN && h == 0 && lin_table != nullptr && q == K) lv[K] = lin_table[idk];             \
-                    DCTR_LAB_THROTTLE;                                                                                \
-                    STS(2, 32 + 4 * c + K);                                                                           \
+                    if (h == 0 && lin_table != nullptr && q == K) lv[K] = lin_table[idk];             \
                 } else if (cb < NB) {                                                                                 \
                     /* dense passthrough block: lane (s, q) supplies floats 4*piece .. 4*piece + 3 of its sample */   \
                     const int d0 = (cb - NBE) * 16 + 4 * piece;                                                       \
@@ -573,15 +533,11 @@ __device__ __forceinline__ void loader(const StreamParams& p, float* smem, int w
             DCTR_LD_BLOCK(2)
             DCTR_LD_BLOCK(3)
 #undef DCTR_LD_BLOCK
-#else
-            lv[0] = lv[1] = lv[2] = lv[3] = 0.f;
-#endif
             {   // ids of the next chunk (of this tile, or the first of this workgroup's next tile)
                 const bool last_c = c + 1 == NCH;
                 const int tile_n = last_c ? min(tile + (int)gridDim.x, p.n_tiles - 1) : tile;
                 nid = request_ids(tile_n, last_c ? 0 : c + 1);
             }
-            STS(2, 4 * c + 2);
             // the chunk's DMA has landed (and the next ids, the linear rows).  The registers are named as operands so that
             // hipcc knows they are valid from here on: it cannot see an asm wait, and would otherwise put its own
             // vmcnt(0) in front of every later use — i.e. between the DMA instructions of the next chunk
@@ -589,9 +545,7 @@ __device__ __forceinline__ void loader(const StreamParams& p, float* smem, int w
                          : "+v"(nid.lo), "+v"(nid.hi), "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3])
                          :
                          : "memory");
-            STS(2, 4 * c + 3);
             // FM partial sums from the landed image: this lane's 16 B of block k are floats 4*piece.. of sample s
-#ifndef DCTR_STREAM_LAB_NOLOAD
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cb = 4 * c + k;
@@ -611,7 +565,6 @@ __device__ __forceinline__ void loader(const StreamParams& p, float* smem, int w
                     }
                 }
             }
-#endif
             sig_add(sync, S_READY + slot);
         }
         // ---- per-row logits of the gather epilogue: FM = 0.5 * (sum_d (sum_f e)^2 - sum_{f,d} e^2), linear
@@ -640,7 +593,6 @@ __device__ __forceinline__ void loader(const StreamParams& p, float* smem, int w
             }
         }
         sig_add(sync, S_XREADY);
-        STS(2, 60);
         seq0 += NCH;
     }
     if (p.status != nullptr && __any(oor) && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
@@ -662,9 +614,6 @@ __global__ __launch_bounds__(NTHREADS) void stream_kernel(StreamParams p) {
     }
     __syncthreads();
     if (wave < NCONS) {
-#ifdef DCTR_STREAM_LAB_PRIO
-        __builtin_amdgcn_s_setprio(DCTR_STREAM_LAB_PRIO);
-#endif
         consumer(p, smem, wave);
     } else {
         if (p.dim == 16) loader<1>(p, smem, wave - NCONS);
