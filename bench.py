@@ -151,6 +151,7 @@ def probe_kernels(model, staged, ring, reps=48):
         lib.dctr_profile_next_launch()
         _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
         t_lo.append(lib.dctr_profile_last_ms())
+    t_rec, t_rec_lo = [], []
     for r in range(6):
         ws = sp.run_pools(staged, 0, big)
         a = sp.gather_args(staged, 0, big, ws)
@@ -161,9 +162,18 @@ def probe_kernels(model, staged, ring, reps=48):
         lib.dctr_profile_next_launch()
         _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
         t_big_lo.append(lib.dctr_profile_last_ms())
+        if sp.records_ready(staged):          # the same launches on the record-form copies of the tables (dctr_field_t.row_pitch)
+            a = sp.gather_args(staged, 0, big, ws, records=True)
+            lib.dctr_profile_next_launch()
+            _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+            t_rec.append(lib.dctr_profile_last_ms())
+            a.dnn_in = None
+            lib.dctr_profile_next_launch()
+            _C.check(lib.dctr_embed_gather_fm(_ct.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
+            t_rec_lo.append(lib.dctr_profile_last_ms())
     torch.cuda.synchronize()
     mean = lambda t: float(np.mean(t[len(t) // 4:])) * 1e-3 if t else None  # noqa: E731
-    return mean(t_step), mean(t_gather), mean(t_mlp), mean(t_lo), mean(t_big), mean(t_big_lo), big
+    return mean(t_step), mean(t_gather), mean(t_mlp), mean(t_lo), mean(t_big), mean(t_big_lo), big, mean(t_rec), mean(t_rec_lo)
 
 
 def cpu_baseline(model, cols, budget_s=14.0):
@@ -757,7 +767,8 @@ def main():
             traffic, traffic_source = load_traffic(rows_launch)
             if traffic_source and why:
                 traffic_source += "; not measured in this run: " + why
-        t_fused32, t_gather, t_mlp, t_gather_lo, t_gather_big, t_gather_big_lo, big_rows = probe_kernels(model, staged, ring)
+        t_fused32, t_gather, t_mlp, t_gather_lo, t_gather_big, t_gather_big_lo, big_rows, t_rec_big, t_rec_big_lo = probe_kernels(
+            model, staged, ring)
         if t_launch is not None:
             tf = DNN_FLOP_PER_SAMPLE * rows_launch / t_launch / 1e12
             gbs = ALG_BYTES_PER_SAMPLE * rows_launch / t_launch / 1e9
@@ -787,13 +798,17 @@ def main():
         wr_bytes = (F * E + ND) * 4
         for what, t_, rows_, with_write in (("logits only (no dnn_in write), isolated 4096-row launch", t_gather_lo, B, False),
                                             ("-> dnn_in, %d-row launch" % big_rows, t_gather_big, big_rows, True),
-                                            ("logits only, %d-row launch" % big_rows, t_gather_big_lo, big_rows, False)):
+                                            ("logits only, %d-row launch" % big_rows, t_gather_big_lo, big_rows, False),
+                                            ("RECORD-form tables (row + linear weight in one 128-B record) -> dnn_in, %d-row launch" % big_rows,
+                                             t_rec_big, big_rows, True),
+                                            ("RECORD-form tables, logits only, %d-row launch" % big_rows, t_rec_big_lo, big_rows, False)):
             if t_:
                 gb = (ALG_BYTES_PER_SAMPLE + (wr_bytes if with_write else 0)) * rows_ / t_ / 1e9
                 kernels.append({"kernel": "gather_fm_kernel, " + what, "in_step": False, "us_per_launch": t_ * 1e6, "rows_per_launch": rows_,
                                 "bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
                                 "bytes_counted": "ids + rows + linear entries + dense" + (" + the dnn_in write" if with_write else ""),
-                                "pure_random_64B_row_read_line_frac": 0.45, "evidence": "profiles/r04_pmc_gather.json"})
+                                "pure_random_64B_row_read_line_frac": 0.45,
+                                "evidence": "profiles/r04_pmc_gather.json, profiles/r05_gather_records_lab.log (requests per row: 54 plain, 28 records)"})
         kernels.append({"kernel": "mlp_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA), isolated 4096-row launch", "in_step": False,
                         "us_per_launch": t_mlp * 1e6, "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF})

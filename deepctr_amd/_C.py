@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 E_UNSUPPORTED = -5               # DCTR_E_UNSUPPORTED: valid request this build does not implement
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
@@ -41,7 +41,7 @@ class DctrError(RuntimeError):
 # ---------------------------------------------------------------------------------------------
 class FieldDesc(ctypes.Structure):
     _fields_ = [("table", c_vp), ("lin_table", c_vp), ("vocab", c_i64), ("dim", c_i32), ("out_offset", c_i32),
-                ("in_fm", c_i32), ("hash_mode", c_i32), ("identity", c_i32), ("pad_", c_i32)]
+                ("in_fm", c_i32), ("hash_mode", c_i32), ("identity", c_i32), ("row_pitch", c_i32)]
 
 
 class GatherFmArgs(ctypes.Structure):
@@ -50,7 +50,8 @@ class GatherFmArgs(ctypes.Structure):
                 ("any_hash", c_i32), ("n_dense", c_i32), ("dense", c_vp), ("dense_stride", c_i64),
                 ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("dense_copy_cols", c_i32), ("batch", c_i64),
                 ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp),
-                ("split_col", c_i32), ("split_field", c_i32), ("uniform_dim", c_i32), ("any_identity", c_i32)]
+                ("split_col", c_i32), ("split_field", c_i32), ("uniform_dim", c_i32), ("any_identity", c_i32),
+                ("any_pitch", c_i32), ("pad_", c_i32)]
 
 
 class PoolArgs(ctypes.Structure):

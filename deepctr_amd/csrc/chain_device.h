@@ -269,7 +269,10 @@ struct ChainOff {
 // over the lane groups BEFORE squaring, and dense k-blocks addressed from row n_fields E of W0 (the embedding part need not end on a
 // k-block boundary: the slots past the last field are zeroed and meet finite weight rows).  Every block: its pairs' linear entries, the
 // next block's range check, the ids of the block after next.  Same arithmetic, same k order as the tile kernels' layer 0.
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false>
+// REC (dctr_field_t.row_pitch, the RECORD form of embedding_dim-16 tables: a row's linear weight lies behind it, records 32 floats apart):
+// row r of a field lies at table + 128 r bytes and its linear entry at lin_table + 128 r — compile-time shifts, no instruction more
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false,
+          bool REC = false>
 __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
                                              const int row_end, const int first, const int stride, const int n_pass, int& oor) {
     if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
@@ -280,6 +283,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     constexpr int SL = S1 + S2;
     static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
     static_assert(FPB == 1 || (EB == 1 && (FPB == 2 || FPB == 4) && !BF3 && !CROSS), "several fields per k-block: E = 8 / 4, plain fp32 kernels");
+    static_assert(!REC || (EB == 1 && FPB == 1 && !BF3 && !CROSS && !EXPACT), "record-form tables: embedding_dim 16, plain fp32 kernels");
     constexpr int E = FPB > 1 ? 16 / FPB : 16 * EB;
     constexpr int PPB = FPB / 2;                   // field pairs per k-block (FPB > 1)
     constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair (FPB == 1)
@@ -439,7 +443,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         const uint64_t base = ((uint64_t)l.y << 32) | l.x;
         has = base != 0 && 2 * pr + q < p.n_fields;
         const float* t = has ? reinterpret_cast<const float*>(base) : reinterpret_cast<const float*>(p.fields);
-        return (gbl_f_t)(t + (has ? idc : 0u));
+        return (gbl_f_t)(t + (has ? (REC ? idc << 5 : idc) : 0u));            // (REC: linear entries lie 32 floats apart, as the rows)
     };
     // issue the row loads of embedding k-block cb: its ids are half `half` of the folded pair ids `idc`
     auto issue_x = [&](int cb, uint32_t idc, int half, XBlk& X) {
@@ -454,7 +458,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #pragma unroll
         for (int nt = 0; nt < RT; ++nt) {
             const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jj + (uint32_t)(32 * half + 16 * nt)) << 2), (int)idc);
-            const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);   // 16-B pieces from the table base
+            const uint64_t piece = (uint64_t)idv * (uint32_t)(REC ? E / 2 : E / 4) + (uint64_t)(4u * (uint32_t)h + gg);   // 16-B pieces from the table base
             X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
         }
     };
@@ -472,13 +476,13 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         const char* table = reinterpret_cast<const char*>(sgpr64(tw.x, tw.y));
         if constexpr (KEEP_LC) {
             const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bp4_ + (uint32_t)((32 * half + 16 * nt) << 2)), (int)idc);
-            X.x[nt] = *(gbl_f4_t)(table + (((uint64_t)idv << (E == 16 ? 6 : E == 32 ? 7 : 8)) + (uint64_t)(64 * h) + gg16_));
+            X.x[nt] = *(gbl_f4_t)(table + (((uint64_t)idv << ((E == 16 ? 6 : E == 32 ? 7 : 8) + (REC ? 1 : 0))) + (uint64_t)(64 * h) + gg16_));
         } else {
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const uint32_t gg = (uint32_t)ln >> 4, jj = (uint32_t)ln & 15u;
             const uint32_t idv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jj + (uint32_t)(32 * half + 16 * nt)) << 2), (int)idc);
-            const uint64_t piece = (uint64_t)idv * (uint32_t)(E / 4) + (uint64_t)(4u * (uint32_t)h + gg);
+            const uint64_t piece = (uint64_t)idv * (uint32_t)(REC ? E / 2 : E / 4) + (uint64_t)(4u * (uint32_t)h + gg);
             X.x[nt] = *(gbl_f4_t)(table + (piece << 4));
         }
     };
@@ -1375,7 +1379,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 }
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false,
+          bool REC = false>
 __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
@@ -1431,15 +1436,15 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     __syncthreads();                                   // LDS parameters written
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
-    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
             // every wave is through with the ring and the staging areas of the main phase; waves 4.. leave (s_barrier waits for
             // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
             __syncthreads();
             if (wave < 4)
-                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
-                                                                    (int)gridDim.x, p.n_tail, oor);
+                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
+                                                                         (int)gridDim.x, p.n_tail, oor);
         }
     }
     if (p.status != nullptr && oor && lane == 0) atomicOr(p.status, (int)DCTR_STATUS_INDEX_OOR);
@@ -1457,6 +1462,7 @@ int launch_r2w8_m42x(const ChainParams& p, int E, int M2, unsigned blocks, hipSt
 int launch_r2w8_m42q(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 8 / 4 (chain_kernels_r2w8_m42_q.hip)
 int launch_r2w8_m42t(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // sigmoid / tanh DNNs (chain_kernels_r2w8_m42_t.hip)
 int launch_r2w8_m42w(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 64 (chain_kernels_r2w8_m42_w.hip)
+int launch_r2w8_m42r(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // record-form tables, embedding_dim 16 (chain_kernels_r2w8_m42_r.hip)
 // the exploratory bf16 x 3 variant (chain_kernels_r2w8_m42_bf3.hip): packs the weights into `ws` (if `pack`), then launches
 size_t bf3_workspace_bytes(int in_dim);
 int launch_r2w8_m42_bf3(const ChainParams& p, int E, void* ws, bool pack, unsigned blocks, hipStream_t stream);

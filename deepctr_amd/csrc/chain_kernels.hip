@@ -33,6 +33,10 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     // embedding_dim 64 (four k-blocks per field): the m42 kernels, fp32, ReLU / linear, no folded CrossNet
     if (E == 64 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && a->cross_layers == 0)) return 0;
     if (a->precision != 0 && !(M[0] == 4 && M[1] == 2 && M[2] == 1 && a->tile_rows != 128 && a->bn_scale == nullptr)) return 0;
+    // record-form tables (row_pitch 32, embedding_dim 16): the m42 kernels, fp32, ReLU / linear, no identity fields, no folded CrossNet
+    if (g->any_pitch && !(E == 16 && M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && a->cross_layers == 0 && !expact &&
+                          !g->any_identity))
+        return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
     if (a->cross_layers > 0 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && E >= 16)) return 0;   // CROSS: the m42 kernels
     // embedding_dim 8 / 4 (several fields per k-block): the m42 kernels, fp32, no identity (pre-pooled) fields, <= 4 dense k-blocks
@@ -153,6 +157,7 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
         }
         return launch_r2w8_m42_bf3(p, E, a->workspace, a->precision == 1, blocks, stream);
     }
+    if (g->any_pitch) return launch_r2w8_m42r(p, E, M[2], blocks, stream);
     if (a->cross_layers > 0) return launch_r2w8_m42x(p, E, M[2], blocks, stream);
     if (a->activation == DCTR_ACT_SIGMOID || a->activation == DCTR_ACT_TANH) return launch_r2w8_m42t(p, E, M[2], blocks, stream);
     if (E < 16) return launch_r2w8_m42q(p, E, M[2], blocks, stream);

@@ -534,7 +534,7 @@ extern "C" int dctr_cin_gather_fwd(const dctr_cin_args_t* a, const dctr_gather_f
     DCTR_REQUIRE(g->fields != nullptr && g->ids != nullptr, DCTR_E_NULL, "cin_gather_fwd: null descriptors / ids");
     DCTR_REQUIRE(g->n_fields == a->fields && g->batch == a->batch, DCTR_E_DIM, "cin_gather_fwd: gather of %d fields x %lld rows against CIN over %d x %lld",
                  g->n_fields, (long long)g->batch, a->fields, (long long)a->batch);
-    DCTR_REQUIRE(a->dim % 4 == 0 && g->uniform_dim == a->dim && g->all_dim4 && !g->any_hash && !g->any_identity, DCTR_E_UNSUPPORTED,
+    DCTR_REQUIRE(a->dim % 4 == 0 && g->uniform_dim == a->dim && g->all_dim4 && !g->any_hash && !g->any_identity && !g->any_pitch, DCTR_E_UNSUPPORTED,
                  "cin_gather_fwd: every field must be a plain (unhashed, not pre-pooled) lookup of width dim = %d, a multiple of 4", a->dim);
     DCTR_REQUIRE(a->save_y == nullptr, DCTR_E_UNSUPPORTED, "cin_gather_fwd: inference only (save_y: use dctr_embed_gather_fm + dctr_cin_fwd)");
     return cin_fwd_impl(a, g, head_w, logit, stream);

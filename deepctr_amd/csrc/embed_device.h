@@ -77,6 +77,7 @@ struct FieldRegs {
     const float* lin_table;
     int64_t vocab;
     int dim, out_offset, in_fm, hash_mode, identity;
+    int pitch, lin_pitch;      // floats between consecutive rows / linear entries (dctr_field_t.row_pitch: the record form)
 };
 __device__ __forceinline__ FieldRegs load_field(cfield_ptr F, int j) {
     FieldRegs r;
@@ -88,6 +89,9 @@ __device__ __forceinline__ FieldRegs load_field(cfield_ptr F, int j) {
     r.in_fm = F[j].in_fm;
     r.hash_mode = F[j].hash_mode;
     r.identity = F[j].identity;
+    const int rp = F[j].row_pitch;
+    r.pitch = rp != 0 ? rp : r.dim;
+    r.lin_pitch = rp != 0 ? rp : 1;
     return r;
 }
 
@@ -136,8 +140,8 @@ __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int 
     for (int u = 0; u < U; ++u) {
         const FieldRegs& f = fr[u];
         const int qq = (q * VEC < f.dim) ? q * VEC : 0;
-        load_vec<VEC>(f.table + row[u] * f.dim + qq, v[u]);
-        const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] : reinterpret_cast<const float*>(p.fields);
+        load_vec<VEC>(f.table + row[u] * f.pitch + qq, v[u]);
+        const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] * f.lin_pitch : reinterpret_cast<const float*>(p.fields);
         lv[u] = *lp;
     }
 #pragma unroll

@@ -1097,7 +1097,7 @@ extern "C" int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* a, cons
     DCTR_REQUIRE(a->mode == DCTR_CROSS_MATRIX && a->layers >= 1, DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: matrix parameterization, >= 1 layer");
     DCTR_REQUIRE(g->fields != nullptr && g->ids != nullptr && g->batch == a->batch, DCTR_E_NULL, "crossnet_gather_head_fwd: gather of another batch / null");
     DCTR_REQUIRE(g->uniform_dim >= 4 && (g->uniform_dim & (g->uniform_dim - 1)) == 0 && g->all_dim4 && !g->any_hash && !g->any_identity &&
-                     g->ids_stride_b == 1,
+                     !g->any_pitch && g->ids_stride_b == 1,
                  DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: plain (unhashed, not pre-pooled) lookups of one width (a power of two >= 4), contiguous id rows");
     const int n_dense = g->dense_copy_cols > 0 ? g->dense_copy_cols : 0;
     DCTR_REQUIRE(a->dim == g->n_fields * g->uniform_dim + n_dense && (n_dense == 0 || (g->dense != nullptr && g->dense_out_offset == g->n_fields * g->uniform_dim)),

@@ -553,8 +553,8 @@ __device__ __forceinline__ void fused_gather_chunk(const MlpParams& p, const Gat
         for (int u = 0; u < U; ++u) {
             const FieldRegs& f = fr[u / PASSES];
             const int qq = (q * VEC < f.dim) ? q * VEC : 0;
-            load_vec<VEC>(f.table + row[u] * f.dim + qq, v[u]);
-            const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] : reinterpret_cast<const float*>(g.fields);
+            load_vec<VEC>(f.table + row[u] * f.pitch + qq, v[u]);
+            const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] * f.lin_pitch : reinterpret_cast<const float*>(g.fields);
             lv[u] = *lp;
         }
 #pragma unroll

@@ -632,7 +632,7 @@ static int n_cus() { return dctr_n_cus(); }
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced) {
     const int E = g->uniform_dim;
     if (E != 16 && E != 32 && E != 64) return 0;
-    if (g->any_hash || g->any_identity || !a->has_head || a->n_layers < 1 || a->save_acts != nullptr || a->cross_layers > 0) return 0;
+    if (g->any_hash || g->any_identity || g->any_pitch || !a->has_head || a->n_layers < 1 || a->save_acts != nullptr || a->cross_layers > 0) return 0;
     if (a->activation == DCTR_ACT_DICE || a->bn_scale != nullptr) return 0;
     if (a->units[0] > 256 || a->units[0] < 16) return 0;
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;
@@ -663,7 +663,7 @@ int try_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_
     if (!eligible(a, g, forced)) return 0;
     const int E = g->uniform_dim;
     if (E != 16 && E != 32 && E != 64) return 0;
-    if (g->any_hash || g->any_identity || !a->has_head || a->n_layers < 1 || a->save_acts != nullptr || a->cross_layers > 0) return 0;
+    if (g->any_hash || g->any_identity || g->any_pitch || !a->has_head || a->n_layers < 1 || a->save_acts != nullptr || a->cross_layers > 0) return 0;
     if (a->activation == DCTR_ACT_DICE || a->bn_scale != nullptr) return 0;
     if (a->units[0] > 256 || a->units[0] < 16) return 0;
     if (g->n_dense > 0 && (g->dense_out_offset != g->n_fields * E || g->dense_copy_cols != g->n_dense)) return 0;

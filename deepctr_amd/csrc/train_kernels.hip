@@ -1945,8 +1945,8 @@ extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void
     DCTR_REQUIRE(f->batch >= 0 && f->n_fields >= 0, DCTR_E_DIM, "embed_gather_fm_bwd: bad sizes");
     if (f->batch == 0 || f->n_fields == 0) return DCTR_OK;
     DCTR_REQUIRE(f->fields && f->ids && a->grads, DCTR_E_NULL, "embed_gather_fm_bwd: null fields / ids / grads");
-    DCTR_REQUIRE(f->all_dim4 && f->max_dim <= 64, DCTR_E_UNSUPPORTED,
-                 "embed_gather_fm_bwd: needs every embedding_dim %% 4 == 0 and <= 64");
+    DCTR_REQUIRE(f->all_dim4 && f->max_dim <= 64 && !f->any_pitch, DCTR_E_UNSUPPORTED,
+                 "embed_gather_fm_bwd: needs every embedding_dim %% 4 == 0 and <= 64, plain (not record-form) tables");
     DCTR_REQUIRE(a->d_dnn_in == nullptr || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_dnn_in)), DCTR_E_ALIGN,
                  "embed_gather_fm_bwd: d_dnn_in must be 16-B aligned with a stride %% 4 == 0");
     int lpr = 1;

@@ -538,6 +538,69 @@ class EmbeddingStage(object):
         cache[B] = ws
         return ws
 
+    # ---- RECORD-form copies of embedding_dim-16 tables (dctr_field_t.row_pitch): [vocab, 32] floats per table = the 16 values of a row,
+    # the row's first-order weight (feature_column.py:171-210: the 1-wide `linear` table of the same feature) and padding — ONE 128-B
+    # line serves both reads of a field.  The stand-alone gather then issues 28 L2 requests per sample instead of 54 and runs at the
+    # rate of pure row reads (profiles/r05_gather_records_lab.log: 205 -> 128 us per 262,144 rows; the request rate is what bounds
+    # it); the row-chained kernel's traffic drops to the algorithmic bytes.  Inference only: the copies follow the weights by
+    # version (torch's in-place counter + the model's count of raw-pointer updates by the HIP training step), the weights the API
+    # shows stay [vocab, 16] / [vocab, 1].  2x the tables' memory: skipped beyond `records_budget` of the device.
+    use_records = True
+    records_budget = 0.10
+
+    def records_eligible(self):
+        if getattr(self, "_rec_ok", None) is None:
+            ok = bool(self.use_records and self.device.type == "cuda" and self.uniform_dim == 16 and self.fields and
+                      not self.pooled_fields and not self.lin_only and all(f.kind == "sparse" for f in self.fields))
+            lin_of, total = {}, 0
+            for f in self.fields if ok else ():
+                key = f.table.data_ptr()
+                lt = None if f.lin_table is None else f.lin_table.data_ptr()
+                if key in lin_of and lin_of[key] != lt:
+                    ok = False                  # one embedding table shared by features with different linear tables
+                if f.lin_table is not None and f.lin_table.shape[0] != f.table.shape[0]:
+                    ok = False
+                if key not in lin_of:
+                    total += f.table.shape[0] * 128
+                lin_of[key] = lt
+            if ok and total > self.records_budget * torch.cuda.get_device_properties(self.device).total_memory:
+                ok = False
+            self._rec_ok = ok
+        return self._rec_ok
+
+    def refresh_records(self, enabled, raw_writes=0):
+        """Bring the record copies up to the current weights (a no-op when nothing changed); sets ``records_current``."""
+        self.records_current = False
+        if not enabled or not self.records_eligible():
+            return
+        recs = getattr(self, "_rec", None)
+        if recs is None:
+            recs = self._rec = {}
+        with torch.no_grad():
+            for f in self.fields:
+                key = f.table.data_ptr()
+                ver = (f.table._version, -1 if f.lin_table is None else f.lin_table._version, int(raw_writes))
+                ent = recs.get(key)
+                if ent is None:
+                    ent = recs[key] = [torch.zeros(f.table.shape[0], 32, dtype=torch.float32, device=self.device), None]
+                if ent[1] != ver:
+                    ent[0][:, :16].copy_(f.table)
+                    if f.lin_table is not None:
+                        ent[0][:, 16].copy_(f.lin_table.reshape(-1))
+                    ent[1] = ver
+        if getattr(self, "_rec_desc", None) is None:
+            fields = []
+            for f in self.fields:
+                rec = recs[f.table.data_ptr()][0]
+                fields.append(dict(table=rec, lin_table=None if f.lin_table is None else rec.view(-1)[16:], vocab=f.table.shape[0],
+                                   dim=f.dim, out_offset=f.out_offset, in_fm=f.in_fm, hash_mode=0, row_pitch=32))
+            self._rec_desc = ops.make_field_descriptors(fields, self.device)
+        self.records_current = True
+
+    def records_ready(self, staged):
+        """Record descriptors may serve a launch on these staged rows: the copies are current and the ids are plain (or hashed at stage())."""
+        return bool(getattr(self, "records_current", False) and (not self.any_hash or staged.hashed is not None))
+
     def refresh(self, linear_kernel):
         """Per predict() call / training step: Linear.kernel rows permuted into dense-matrix column order.  The index
         tensors and the destination are built once (a boolean-mask assignment here cost two torch.nonzero host
@@ -598,9 +661,10 @@ class EmbeddingStage(object):
         ops.hash_fields(ws["desc"], nf, staged.ids[:nf, lo:hi], out)
         return out
 
-    def gather_args(self, staged, lo, hi, ws, to_hbm=True, prehashed=None):
+    def gather_args(self, staged, lo, hi, ws, to_hbm=True, prehashed=None, records=False):
         """dctr_gather_fm_args_t for rows [lo, hi) (pooled fields must already be in the workspace).  ``prehashed``: the id
-        matrix ``prehash`` returned — the fields are then described as plain rows."""
+        matrix ``prehash`` returned — the fields are then described as plain rows.  ``records``: the record-form copies of the tables
+        (refresh_records; the caller has checked records_ready(): plain or pre-hashed ids only)."""
         B = hi - lo
         nf = len(self.fields)
         ids = staged.ids[:, lo:hi] if staged.ids is not None else None
@@ -608,6 +672,10 @@ class EmbeddingStage(object):
         desc, any_hash = ws["desc"], self.any_hash
         if prehashed is not None:
             ids, stride_f, desc, any_hash = prehashed, prehashed.stride(0), ws["desc0"], False
+        if records:
+            if any_hash:
+                raise ValueError("gather_args(records=True): hashed ids must be resolved first (prehashed=...)")
+            desc = self._rec_desc
         dense = staged.dense[lo:hi] if staged.dense is not None else None
         return ops.make_gather_args(desc, nf, ids, stride_f, 1, B, self.max_dim,
                                     self.all_dim4, any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
@@ -616,7 +684,8 @@ class EmbeddingStage(object):
                                     out_stride=self.out_stride,
                                     fm_logit=ws["fm"] if (self.fm_group_names and to_hbm) else None,
                                     lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"],
-                                    split=self.k_split, uniform_dim=self.uniform_dim, any_identity=bool(self.pooled_fields))
+                                    split=self.k_split, uniform_dim=self.uniform_dim, any_identity=bool(self.pooled_fields),
+                                    any_pitch=bool(records))
 
     def run_pools(self, staged, lo, hi, light=False):
         ws = self.workspace(hi - lo, light)
@@ -632,14 +701,17 @@ class EmbeddingStage(object):
         return (len(self.fields) > 0 and self.all_dim4 and self.max_dim <= 64 and len(self.fm_group_names) <= 1
                 and not self.extra_offsets)
 
-    def run(self, staged, lo, hi):
+    def run(self, staged, lo, hi, records=False):
         """Launch the pooling kernels and the fused gather for rows [lo, hi).  Returns the workspace dict:
         'dnn_in' [B, out_stride], 'lin' [B] (None-equivalent when the model has no linear part), 'fm' [B]."""
         B = hi - lo
         ws = self.run_pools(staged, lo, hi)
         st = ws["status"]
         nf = len(self.fields)
-        a = self.gather_args(staged, lo, hi, ws)
+        if records and self.records_ready(staged):
+            a = self.gather_args(staged, lo, hi, ws, prehashed=self.prehash(staged, lo, hi, ws) if self.any_hash else None, records=True)
+        else:
+            a = self.gather_args(staged, lo, hi, ws)
         _C.check(_C.lib().dctr_embed_gather_fm(ctypes.byref(a), _C.stream_ptr()), "dctr_embed_gather_fm")
         ws["fm_extra"] = []
         for g in self.fm_group_names[1:]:       # further FM groups read their slice of dnn_in in place

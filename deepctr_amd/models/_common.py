@@ -215,10 +215,31 @@ class FusedForward(object):
         sp = self.stage_plan
         return bool(sp.any_hash and sp.uniform_dim in (4, 8, 16, 32, 64) and (B >= self._CHAIN_MIN_ROWS or self.tile_rows in (64, 256)))
 
+    # record-form copies of the embedding tables (EmbeddingStage.refresh_records) behind the fused launch and the stand-alone gather.
+    # Only where they cannot change which kernel a launch takes: the row-chained kernel has its record instantiations for the
+    # 256-128-x ReLU / linear DNN (plain or zero-padded to it), fp32, without a folded CrossNet; models whose other launches read the
+    # same gather arguments (xDeepFM's CIN, the matrix CrossNet) keep plain tables
+    gather_records = True
+    _records_capable = True
+
+    def _records_allowed(self):
+        """Record descriptors behind the FUSED launch (the stand-alone gather takes them whenever the plan keeps them current)."""
+        if not (self.gather_records and self._records_capable and getattr(self, "fused", False)):
+            return False
+        sp = self.stage_plan
+        units = list(self._pad_spec) if self._pad_spec else [int(k.shape[1]) for k in self.dnn.kernels]
+        return bool(sp.uniform_dim == 16 and self.dnn.activation in ("relu", "linear") and not self.dnn.dice_layers and
+                    len(units) in (2, 3) and units[0] == 256 and units[1] == 128 and self.matrix_precision == "fp32" and
+                    self.tile_rows in (0, 16, 32, 256))
+
+    def _records_on(self, staged):
+        return bool(self.stage_plan.records_ready(staged) and self._records_allowed())
+
     def _begin(self):
         super(FusedForward, self)._begin()
         if getattr(self, "_trainer_step", False):
             return                      # (the HIP training step reads neither the padded copies nor the bf16x3 images)
+        self.stage_plan.refresh_records(self.gather_records and self._records_capable, getattr(self, "_raw_weight_writes", 0))
         if self._pad is not None:
             self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
         if self._bf3 is not None:
@@ -255,14 +276,15 @@ class FusedForward(object):
         padded = self._use_padded(B)
         pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)     # (ids hashed at stage(): plain rows at every size)
         bf3 = self._bf3_on(B)
-        key = (B, padded, pre, bf3, self.task)           # (the marshalled struct carries sigmoid_out: predict_logits has its own entries)
+        rec = self._records_on(staged) and (pre or not sp.any_hash)
+        key = (B, padded, pre, bf3, self.task, rec)      # (the marshalled struct carries sigmoid_out: predict_logits has its own entries)
         c = self._fast.get(key)
         hashed = sp.prehash(staged, lo, hi, sp.light_workspace()) if pre else None
         if c is None:
             ws = sp.light_workspace()          # descriptors + status only: a launch may span any number of rows
             while len(self._fast) >= 16:                 # least recently used out: a caller with ragged batch sizes keeps its
                 self._fast.pop(next(iter(self._fast)))   # frequent sizes marshalled (a wholesale clear() re-marshalled them all, forever)
-            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
+            g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed, records=rec)
             ks, bs, hw, bn = self._dnn_operands(B)
             m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
                               head_w=hw, global_bias=self.prediction.w('global_bias'),
@@ -324,7 +346,8 @@ class FusedForward(object):
         B = hi - lo
         sp = self.stage_plan
         pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)
-        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre, self._bf3_on(B), self.task)]
+        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre, self._bf3_on(B), self.task,
+                                     self._records_on(staged) and (pre or not sp.any_hash))]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)

@@ -17,6 +17,7 @@ class _GatherUnsupported(Exception):
 
 
 class _DCN(FusedForward, FeatureModel):
+    _records_capable = False     # (the CIN / matrix-CrossNet launches read the fused launch's gather arguments: plain tables)
     def __init__(self, linear_feature_columns, dnn_feature_columns, cross_num, cross_parameterization, dnn_hidden_units,
                  seed, dnn_dropout, dnn_use_bn, dnn_activation, task, device, name="DCN"):
         super(_DCN, self).__init__(name, list(dnn_feature_columns), device, task)

@@ -50,7 +50,7 @@ class _DeepFM(FusedForward, FeatureModel):
                     out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
                     tile_rows=self.tile_rows, probe=self.probe)
             return
-        ws = self.stage_plan.run(staged, lo, hi)
+        ws = self.stage_plan.run(staged, lo, hi, records=self.gather_records and self._records_capable)
         add = self._logits_to_add(ws)
         if self.stage_plan.fm_group_names:
             add.append(ws["fm"])

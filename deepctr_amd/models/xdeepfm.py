@@ -14,6 +14,7 @@ from ._common import FeatureModel, FusedForward
 
 
 class _xDeepFM(FusedForward, FeatureModel):
+    _records_capable = False     # (the CIN / matrix-CrossNet launches read the fused launch's gather arguments: plain tables)
     def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units, cin_layer_size, cin_split_half,
                  cin_activation, seed, dnn_dropout, dnn_activation, dnn_use_bn, task, device):
         super(_xDeepFM, self).__init__("xDeepFM", list(linear_feature_columns) + list(dnn_feature_columns), device, task)

@@ -274,12 +274,13 @@ def make_field_descriptors(fields, device):
         arr[j].in_fm = int(bool(f.get("in_fm", False)))
         arr[j].hash_mode = int(f.get("hash_mode", 0))
         arr[j].identity = int(bool(f.get("identity", False)))
+        arr[j].row_pitch = int(f.get("row_pitch", 0))
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
 def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
                      dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0,
-                     fm_logit=None, lin_logit=None, status=None, split=(0, 0), uniform_dim=0, any_identity=False):
+                     fm_logit=None, lin_logit=None, status=None, split=(0, 0), uniform_dim=0, any_identity=False, any_pitch=False):
     """Fill a dctr_gather_fm_args_t (see include/dctr.h).  The caller keeps every tensor alive.
     ``split`` = (split_col, split_field), see the header; (0, 0) = none."""
     _dev_check(desc, ids, dense, dnn_in)
@@ -303,7 +304,7 @@ def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max
                            lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
                            status=None if status is None else status.data_ptr(),
                            split_col=int(split[0]), split_field=int(split[1]), uniform_dim=int(uniform_dim),
-                           any_identity=int(bool(any_identity)))
+                           any_identity=int(bool(any_identity)), any_pitch=int(bool(any_pitch)))
 
 
 def embed_gather_fm(*args, **kwargs):

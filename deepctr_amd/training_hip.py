@@ -692,6 +692,8 @@ class HipTrainer(object):
         if self.kind == "adam":
             lr = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         ops.opt_multi(self.kind, self.segs, self.n_segs, self.max_n, lr, self.b1, self.b2, self.eps)
+        # the weights moved through raw pointers (torch's version counters did not): derived inference copies are stale
+        self.model._raw_weight_writes = getattr(self.model, "_raw_weight_writes", 0) + 1
 
     def batch_statistics(self):
         """True when the step takes statistics over the BATCH (training-mode BatchNormalization / Dice): a rank's shard of a global batch

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 9
+#define DCTR_ABI_VERSION 10
 
 enum {
     DCTR_OK = 0,
@@ -114,7 +114,13 @@ typedef struct {
     int32_t in_fm;           /* 1: participates in the FM term                                          */
     int32_t hash_mode;       /* 0: id is the row; 1: Hash(vocab); 2: Hash(vocab, mask_zero=True)        */
     int32_t identity;        /* 1: row = sample index b (field pre-pooled by dctr_embed_pool); id unused */
-    int32_t pad_;
+    int32_t row_pitch;       /* 0: rows are `dim` floats apart and the linear table is a separate [vocab] vector.
+                                != 0 (ABI 10, the RECORD form; a multiple of 4, >= dim + 1): row r lies at table + r * row_pitch
+                                and its linear entry at lin_table[r * row_pitch] — the caller keeps the first-order weight behind
+                                the embedding row (lin_table = table + dim), so that one 128-B line serves both reads of a
+                                dim-16 field: 2 x row_pitch = 32 floats.  Honoured by dctr_embed_gather_fm and dctr_embed_mlp_fwd
+                                (tile and row-chained kernels; there dim 16 and row_pitch 32 only); every other entry point that
+                                takes descriptors rejects args->any_pitch (DCTR_E_UNSUPPORTED)                           */
 } dctr_field_t;
 
 typedef struct {
@@ -156,6 +162,8 @@ typedef struct {
                                      (csrc/chain_device.h); else with E in {16, 32, 64} and no identity field the streaming
                                      kernel (LDS-DMA gather ring, 64-row tiles).  0 = unknown / not uniform              */
     int32_t any_identity;         /* 1: some field has identity != 0 (host copy of the descriptors' flags)               */
+    int32_t any_pitch;            /* 1: some field has row_pitch != 0 (host copy; ABI 10)                                 */
+    int32_t pad_;
 } dctr_gather_fm_args_t;
 
 int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);

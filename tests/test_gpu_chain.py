@@ -449,6 +449,81 @@ def test_ids_hashed_at_stage_give_the_bits_of_the_per_call_hash_routes(device):
     assert np.array_equal(x.predict(feed, batch_size=4096), yx)
 
 
+def test_record_form_tables_give_the_bits_of_plain_tables(device):
+    """dctr_field_t.row_pitch (ABI 10): embedding_dim-16 tables kept as [vocab, 32] records — the row, its first-order weight behind
+    it — serve the stand-alone gather, the 32-row kernel and the row-chained kernel (REC instantiations) with the SAME values, so every
+    output is bit-identical to the plain-table route; the copies follow set_weights and the HIP training step; entry points that do
+    not take records refuse them."""
+    import ctypes
+    import torch
+    from deepctr_amd import _C
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM, xDeepFM
+    rng = np.random.RandomState(123)
+    n = 16384 + 4096 + 37
+    cols = [SparseFeat("C%d" % i, 2000 + 13 * i, 16, use_hash=(i == 4)) for i in range(11)] + [DenseFeat("I%d" % i, 1) for i in range(5)]
+    feed = {"C%d" % i: rng.randint(0, 2000 + 13 * i, n).astype(np.int32) for i in range(11)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(5)})
+    model = DeepFM(cols, cols, device=device)
+    _randomise(model, rng)
+    sp = model.stage_plan
+    assert sp.records_eligible() and model._records_allowed()
+    lib = _C.lib()
+
+    def routes():
+        out = {}
+        out["chain"] = model.predict(feed, batch_size=4096)
+        kern = _last_kernel()
+        out["tile"] = _predict(model, feed, 4096, span_batches=False, tile_rows=32)
+        out["unfused"] = _predict(model, feed, 4096, fused=False)
+        return out, kern
+    on, kern = routes()
+    assert kern == "chain" and sp.records_current
+    staged = model.stage(feed)
+    model._begin()
+    g, m = model._forward_fast_args(staged, 0, n, torch.empty(n, device=device))
+    assert g.any_pitch == 1                                         # the marshalled launch really carries record descriptors
+    model.gather_records = False
+    off, kern0 = routes()
+    assert kern0 == "chain" and not sp.records_current
+    for k in on:
+        assert np.array_equal(on[k], off[k]), k
+    # the stand-alone gather on both descriptor sets: dnn_in, FM and linear logits bit for bit
+    model.gather_records = True
+    model._begin()
+    ws_r = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sp.run(staged, 0, 4096, records=True).items() if k in ("dnn_in", "fm", "lin")}
+    ws_p = sp.run(staged, 0, 4096, records=False)
+    for k in ("dnn_in", "fm", "lin"):
+        assert torch.equal(ws_r[k], ws_p[k]), k
+    # the copies follow the weights: set_weights (torch's version counter) ...
+    w2 = _randomise(model, np.random.RandomState(7))
+    y2 = model.predict(feed, batch_size=4096)
+    assert not np.array_equal(y2, on["chain"])
+    model.gather_records = False
+    assert np.array_equal(model.predict(feed, batch_size=4096), y2)
+    model.gather_records = True
+    # ... and the HIP training step (raw-pointer updates: the model's own counter)
+    model.compile("adam", "binary_crossentropy")
+    labels = (feed["C1"] % 2).astype(np.float32)
+    model.fit({k: v[:8192] for k, v in feed.items()}, labels[:8192], batch_size=4096, epochs=1, verbose=0)
+    assert getattr(model, "_raw_weight_writes", 0) >= 2
+    y3 = model.predict(feed, batch_size=4096)
+    model.gather_records = False
+    assert np.array_equal(model.predict(feed, batch_size=4096), y3) and not np.array_equal(y3, y2)
+    # entry points without a record form refuse the descriptors
+    x = xDeepFM(cols, cols, cin_layer_size=(16,), device=device)
+    assert not x._records_allowed()
+    model.gather_records = True
+    model._begin()
+    g, m = model._forward_fast_args(staged, 0, n, torch.empty(n, device=device))
+    from deepctr_amd import ops
+    xs = x.stage(feed)
+    x._begin()
+    ok = ops.cin_gather(g, x.cin.filters, x.cin.biases, list(x.cin.layer_size), x.cin.split_half, x.cin.activation, x.cin_dim,
+                        x.dense_1.w("kernel"), torch.empty(n, device=device), x._cin_workspace(), False)
+    assert not ok                                                   # DCTR_E_UNSUPPORTED -> the op reports "declined"
+
+
 @pytest.mark.parametrize("E,n,F,ND", [(16, 20 * 4096, 26, 13), (32, 16384 + 4096 + 77, 26, 13), (16, 16384 + 129, 7, 0), (32, 700, 12, 20)])
 def test_chain_bf16x3_exploratory_precision(device, E, n, F, ND):
     """The EXPLORATORY precision (dctr_mlp_args_t.precision = 1 / 2; model.matrix_precision = "bf16x3"): every MLP product as three
