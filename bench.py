@@ -295,7 +295,7 @@ def host_preprocess(seconds, rows=200000):
     return n
 
 
-def measure_traffic(K, rows_launch, dist_name, timeout_s=240):
+def measure_traffic(K, rows_launch, dist_name, timeout_s=240, fused_records=False):
     """roofline.traffic measured IN THIS RUN: FETCH_SIZE and WRITE_SIZE of the timed region's kernel from two rocprofv3 counter passes
     over a child of this script (same K, same launch shape; `--kernel-trace --pmc <one counter>` only — counters are never combined
     with API traces; cwd and TMPDIR = /tmp as the profiling recipe asks).  Returns (bytes per launch, description) or (None, reason).
@@ -314,7 +314,7 @@ def measure_traffic(K, rows_launch, dist_name, timeout_s=240):
         d = tempfile.mkdtemp(prefix="dctr_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", str(K), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic",
-               "--prewarm-ms", "10", "--regions", "2", "--parity-rows", "0", "--dist", dist_name]
+               "--prewarm-ms", "10", "--regions", "2", "--parity-rows", "0", "--dist", dist_name] + (["--fused-records"] if fused_records else [])
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                timeout=timeout_s)
@@ -368,6 +368,9 @@ def main():
     ap.add_argument("--ring", type=int, default=64, help="distinct id batches cycled through (rounded up to whole launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-launch-per-batch and long-run measurements")
+    ap.add_argument("--fused-records", action="store_true", help="A/B: the record-form copies of the tables ([vocab, 32]: row + linear weight) "
+                                                                 "behind the fused launch too (model.fused_records = True; default: plain "
+                                                                 "tables there, records behind the stand-alone gather only)")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 counter passes "
                                                               "over a child of this command); use the committed constant")
     ap.add_argument("--streams", type=int, default=8, help="one-launch-per-batch mode: batches in flight (graph branches)")
@@ -407,6 +410,8 @@ def main():
     lib = _C.lib()
     model, cols = build_model(device)
     model.tile_rows = args.tile_rows
+    if args.fused_records:
+        model.fused_records = True
     K, W = args.steps, args.warmup
     G = max(1, min(args.launch_batches or 256, max(K, 1)))
     ring = ((max(args.ring, G) + G - 1) // G) * G                          # whole launches
@@ -761,7 +766,7 @@ def main():
             t_launch = kernel_launches[0]["us"] * 1e-6
         traffic = traffic_source = None
         if world == 1 and fused and K > 0 and not args.no_traffic and not args.no_secondary and dom_ok(timed):
-            traffic, traffic_source = measure_traffic(K, rows_launch, args.dist)
+            traffic, traffic_source = measure_traffic(K, rows_launch, args.dist, fused_records=args.fused_records)
         if traffic is None:
             why = traffic_source
             traffic, traffic_source = load_traffic(rows_launch)
@@ -841,6 +846,10 @@ def main():
                                        "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(launches_of(pl)) for pl in plans[:1]) if fused
                                        else "2 launches per span"),
                        "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
+                       "table_layout": ("record-form inference copies [vocab, 32] fp32 (embedding row + its first-order weight in one 128-B "
+                                        "record: dctr_field_t.row_pitch, 2 x 166 MB) behind the launches; the model's weights stay [vocab, 16] + "
+                                        "[vocab, 1]" if model._records_allowed() and model.stage_plan.records_ready(staged) else
+                                        "plain [vocab, 16] embedding tables + separate [vocab, 1] linear tables"),
                        "parallelism": "row-sharded x%d, tables replicated, forward collective-free; the one all-gather of the K steps' "
                                       "logits is %s" % (world, "inside the timed region (`exchange` splits it out)" if world > 1 else
                                                         "not part of a 1-GPU region")},

@@ -568,9 +568,16 @@ class EmbeddingStage(object):
             self._rec_ok = ok
         return self._rec_ok
 
+    def begin_records(self, wanted, raw_writes=0):
+        """Per predict() call (model._begin): the copies are brought up to date by the FIRST launch of the call that asks for them
+        (records_ready), never for a model whose launches do not use them."""
+        self.records_current = False
+        self._rec_wanted, self._rec_writes = bool(wanted), int(raw_writes)
+
     def refresh_records(self, enabled, raw_writes=0):
         """Bring the record copies up to the current weights (a no-op when nothing changed); sets ``records_current``."""
         self.records_current = False
+        self._rec_wanted = False                      # (checked once per call)
         if not enabled or not self.records_eligible():
             return
         recs = getattr(self, "_rec", None)
@@ -598,8 +605,13 @@ class EmbeddingStage(object):
         self.records_current = True
 
     def records_ready(self, staged):
-        """Record descriptors may serve a launch on these staged rows: the copies are current and the ids are plain (or hashed at stage())."""
-        return bool(getattr(self, "records_current", False) and (not self.any_hash or staged.hashed is not None))
+        """Record descriptors may serve a launch on these staged rows: the copies are current (refreshed here, once per predict() call,
+        when the model wants them) and the ids are plain (or hashed at stage())."""
+        if self.any_hash and staged.hashed is None:
+            return False
+        if getattr(self, "_rec_wanted", False):
+            self.refresh_records(True, getattr(self, "_rec_writes", 0))
+        return bool(getattr(self, "records_current", False))
 
     def refresh(self, linear_kernel):
         """Per predict() call / training step: Linear.kernel rows permuted into dense-matrix column order.  The index

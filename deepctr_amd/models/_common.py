@@ -219,12 +219,15 @@ class FusedForward(object):
     # Only where they cannot change which kernel a launch takes: the row-chained kernel has its record instantiations for the
     # 256-128-x ReLU / linear DNN (plain or zero-padded to it), fp32, without a folded CrossNet; models whose other launches read the
     # same gather arguments (xDeepFM's CIN, the matrix CrossNet) keep plain tables
-    gather_records = True
+    gather_records = True       # the stand-alone gather (dctr_embed_gather_fm) reads record-form copies: 52 -> 36 us per 65,536 rows at C2
+    fused_records = False       # the fused launch does NOT by default: same-box A/B - 1.0 % (profiles/r05_records_chain_ab.log) — its
+                                # gather hides under the fp32 MFMAs either way, and 2 x 166 MB of tables no longer fit the 256-MiB
+                                # Infinity Cache; True: the REC instantiations of the row-chained kernel / the 32-row kernel on records
     _records_capable = True
 
     def _records_allowed(self):
         """Record descriptors behind the FUSED launch (the stand-alone gather takes them whenever the plan keeps them current)."""
-        if not (self.gather_records and self._records_capable and getattr(self, "fused", False)):
+        if not (self.gather_records and self.fused_records and self._records_capable and getattr(self, "fused", False)):
             return False
         sp = self.stage_plan
         units = list(self._pad_spec) if self._pad_spec else [int(k.shape[1]) for k in self.dnn.kernels]
@@ -233,13 +236,13 @@ class FusedForward(object):
                     self.tile_rows in (0, 16, 32, 256))
 
     def _records_on(self, staged):
-        return bool(self.stage_plan.records_ready(staged) and self._records_allowed())
+        return bool(self._records_allowed() and self.stage_plan.records_ready(staged))
 
     def _begin(self):
         super(FusedForward, self)._begin()
         if getattr(self, "_trainer_step", False):
             return                      # (the HIP training step reads neither the padded copies nor the bf16x3 images)
-        self.stage_plan.refresh_records(self.gather_records and self._records_capable, getattr(self, "_raw_weight_writes", 0))
+        self.stage_plan.begin_records(self.gather_records and self._records_capable, getattr(self, "_raw_weight_writes", 0))
         if self._pad is not None:
             self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
         if self._bf3 is not None:

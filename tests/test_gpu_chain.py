@@ -467,7 +467,9 @@ def test_record_form_tables_give_the_bits_of_plain_tables(device):
     model = DeepFM(cols, cols, device=device)
     _randomise(model, rng)
     sp = model.stage_plan
-    assert sp.records_eligible() and model._records_allowed()
+    assert sp.records_eligible() and not model._records_allowed()   # the fused launch keeps plain tables by default (same-box A/B: - 1 %)
+    model.fused_records = True                                       # ... here: every route on the records
+    assert model._records_allowed()
     lib = _C.lib()
 
     def routes():
@@ -478,7 +480,7 @@ def test_record_form_tables_give_the_bits_of_plain_tables(device):
         out["unfused"] = _predict(model, feed, 4096, fused=False)
         return out, kern
     on, kern = routes()
-    assert kern == "chain" and sp.records_current
+    assert kern == "chain" and sp.records_current and len(sp._rec) == 11
     staged = model.stage(feed)
     model._begin()
     g, m = model._forward_fast_args(staged, 0, n, torch.empty(n, device=device))
