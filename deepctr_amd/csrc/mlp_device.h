@@ -862,10 +862,217 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// The 16-row kernel with a SHARED weight stream (mlp_kernels_ring.hip) — launches below 64 rows per CU, where every CU works on
+// 16 rows and the whole DNN's weights (603 KB at C2) must reach every CU.
+// mlp_kernel<1> lets each wave stream its own column slice of W from L2 into a three-stage REGISTER pipeline: the bytes a wave can keep
+// in flight are bounded by its registers (8 KB), and 8 waves x 8 KB per L2 round trip is ~20 B/clk/CU — the 12.5 us that bound a
+// 4096-row launch (§4).  The part itself delivers the same 603 KB to all 256 CUs in 3.7 us (profiles/r05_wstream_lab.log: 40+ B/clk/CU by
+// LDS-DMA or wide register loads).  Here the workgroup's 8 waves pull every 32-row chunk of W_l ONCE, by LDS-DMA
+// (global_load_lds_dwordx4: no registers, 64 KB in flight per CU), into a ring of three 32-KiB slots; one barrier per chunk publishes
+// chunk c and frees the slot of chunk c - 1 for chunk c + 2; every wave then takes its column slice of the chunk from LDS (ds_read_b64 /
+// _b32 B fragments) and the activations from the LDS tile (A fragments) exactly as mlp_kernel does.  Same MFMAs on the same operands in
+// the same k order as mlp_kernel<RT>: the results are bit-identical to the tile kernel's.  Gather front end, epilogues (every activation,
+// BatchNormalization, Dice, saved activations), folded CrossNet and head are the tile kernel's own code.
+// Shapes: every layer width N <= 128 with N % 16 == 0, or N <= 256 with N % 32 == 0 (each wave owns at most one wave-tile), no layer-0
+// K split (the input tile fits LDS beside the ring).
+constexpr int RING_SLOT_F = 8192;       // floats per ring slot (32 KiB = 32 weight rows of a 256-wide layer)
+constexpr int RING_SLOTS = 3;
+constexpr int RING_KS = 8;              // k-steps (of 4 weight rows) per chunk
+
+__device__ __forceinline__ int ring_chunks(int K) { return pad64(K) / (4 * RING_KS); }
+
+// this wave's share of chunk i of layer weights W [K, N] -> slot: 1-KiB pieces wave, wave + 8, ...; lane l's 16 bytes land at piece + 16 l.
+// Rows past K (the zero-padded tail of the activation tile multiplies them) read row K - 1: finite stand-ins.
+__device__ __forceinline__ void ring_dma(const float* W, int K, int N, int i, float* slot, int wave, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int pieces = N / 8;                                        // 32 rows x N floats x 4 B / 1024
+    const uint32_t row_b = (uint32_t)N * 4u;
+    for (int pc = wave; pc < pieces; pc += NWAVE) {
+        const uint32_t o = (uint32_t)pc * 1024u + 16u * (uint32_t)lane;
+        const uint32_t r = o / row_b, cb = o - r * row_b;
+        const uint32_t gr = (uint32_t)min(32 * i + (int)r, K - 1);
+        const uint32_t voff = gr * row_b + cb;
+        const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)(slot + pc * 256);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(W), "s"(lds_addr) : "memory");
+    }
+}
+
+// the MFMAs of one chunk for this wave's tile: A = 8 k-steps of the activation tile, B = the chunk's rows 4 tt + g, columns n_base + TPW j
+template <int TPW>
+__device__ __forceinline__ void ring_chunk_mfma(const float* arow, const float* slot, int N, int n_base, int lane, dctr::f32x4 (&acc)[1][TPW]) {
+    const int g = lane >> 4, j = lane & 15;
+    float a[1][RING_KS];
+    load_as<RING_KS>(arow, a[0]);
+    float b[RING_KS][TPW];
+    const float* brow = slot + g * N + n_base + TPW * j;
+#pragma unroll
+    for (int tt = 0; tt < RING_KS; ++tt) {
+        if constexpr (TPW == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(brow + 4 * tt * N);
+            b[tt][0] = v.x;
+            b[tt][1] = v.y;
+        } else {
+            b[tt][0] = brow[4 * tt * N];
+        }
+    }
+    mfmas<TPW, 1, RING_KS>(a, b, acc);
+}
+
+template <int UNUSED = 0>      // (a template so that the header may be included by several translation units; instantiated in mlp_kernels_ring.hip)
+__global__ __launch_bounds__(NTHR, 1) void mlp_ring_kernel(MlpParams p, FusedGather fg, int ring_off) {
+    constexpr int RT = 1, ROWS = 16;
+    using dctr::f32x4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf0 = smem;
+    float* buf1 = smem + ROWS * p.lda;
+    float* extra = smem + 2 * ROWS * p.lda;
+    float* xp = extra + 2 * ROWS;
+    float* xcs = xp + CROSS_NV * ROWS;
+    float* xv = xcs + 8;
+    float* ring = smem + ring_off;
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
+
+    // the flat chunk list of the launch: layer 0's chunks, then layer 1's, ...; chunk c (counted over the launch) lives in slot c % 3
+    int total = 0;
+    for (int l = 0; l < p.n_layers; ++l) total += ring_chunks(l == 0 ? p.in_dim : p.units[l - 1]);
+    auto dma_global = [&](int c) {
+        if (c >= total) return;
+        float* slot = ring + (c % RING_SLOTS) * RING_SLOT_F;
+        int l = 0, K = p.in_dim;
+        for (;; ++l) {
+            const int n = ring_chunks(K);
+            if (c < n) break;
+            c -= n;
+            K = p.units[l];
+        }
+        ring_dma(p.W[l], K, p.units[l], c, slot, wave, lane);
+    };
+    dma_global(0);                                                 // the first two chunks travel under the gather
+    dma_global(1);
+
+    if (p.cross_layers > 0) {
+        const int kpad = pad64(p.in_dim), L = p.cross_layers, d = p.in_dim;
+        for (int i = threadIdx.x; i < CROSS_NV * kpad; i += NTHR) {
+            const int v = i / kpad, k = i - v * kpad;
+            xv[i] = (v <= L && k < d) ? (v < L ? p.cross_w[(size_t)v * d + k] : p.cross_head[k]) : 0.f;
+        }
+        if (p.cross_const != nullptr) {
+            if (threadIdx.x < CROSS_NV) xcs[threadIdx.x] = p.cross_const[threadIdx.x];
+        } else if (wave == NWAVE - 1) {
+            float cst[CROSS_NV];
+            cross_constants(p.cross_w, p.cross_b, p.cross_head, L, d, lane, cst);
+            if (lane == 0) {
+#pragma unroll
+                for (int v = 0; v < CROSS_NV; ++v) xcs[v] = cst[v];
+            }
+        }
+    }
+    float* in = buf0;
+    float* out = buf1;
+    int K = p.in_dim;
+    {
+        const int n_fields = fg.lpr != 0 ? fg.g.n_fields : 0;
+        const Chunk ck{0, pad64(p.in_dim) / 4, 0, n_fields, true, true};
+        produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
+        if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
+    }
+    int cg = 0;
+    for (int l = 0; l < p.n_layers; ++l) {
+        const int N = p.units[l];
+        const bool wide = N > 128;                                     // (host: then N % 32 == 0 and N <= 256; else N % 16 == 0)
+        const int n_tiles = wide ? N / 32 : N / 16;
+        const int n_base = wave * (wide ? 32 : 16);
+        const bool mine = wave < n_tiles;
+        f32x4 acc2[1][2], acc1[1][1];
+        zero_acc<2, 1>(acc2);
+        zero_acc<1, 1>(acc1);
+        const int KQ = pad64(K) / 4;
+        const float* arow = in + (lane & 15) * p.lda + (lane >> 4) * KQ;
+        const int nch = ring_chunks(K);
+        for (int i = 0; i < nch; ++i, ++cg) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's shares of chunks cg and cg + 1 have landed
+            __syncthreads();                                          // ... everyone's have; everyone is through with chunk cg - 1
+            dma_global(cg + 2);                                       // (into the slot of chunk cg - 1)
+            if (mine) {
+                const float* slot = ring + (cg % RING_SLOTS) * RING_SLOT_F;
+                if (wide) ring_chunk_mfma<2>(arow + RING_KS * i, slot, N, n_base, lane, acc2);
+                else ring_chunk_mfma<1>(arow + RING_KS * i, slot, N, n_base, lane, acc1);
+            }
+        }
+        if (mine) {
+#define DCTR_EPI(ACT)                                                              \
+    do {                                                                           \
+        if (wide) tile_epilogue<2, ACT, RT>(p, l, out, N, n_base, acc2);           \
+        else tile_epilogue<1, ACT, RT>(p, l, out, N, n_base, acc1);                \
+    } while (0)
+            switch (p.activation) {
+                case DCTR_ACT_RELU: DCTR_EPI(DCTR_ACT_RELU); break;
+                case DCTR_ACT_SIGMOID: DCTR_EPI(DCTR_ACT_SIGMOID); break;
+                case DCTR_ACT_TANH: DCTR_EPI(DCTR_ACT_TANH); break;
+                case DCTR_ACT_DICE: DCTR_EPI(DCTR_ACT_DICE); break;
+                default: DCTR_EPI(DCTR_ACT_LINEAR); break;
+            }
+#undef DCTR_EPI
+        }
+        zero_k_padding<RT>(p, out, N);
+        __syncthreads();
+        float* t = in;
+        in = out;
+        out = t;
+        K = N;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (p.has_head) {
+        const int part = threadIdx.x & 15;
+        const int KQh = pad64(K) / 4;
+        float xcst[CROSS_NV];
+        if (p.cross_layers > 0) {
+#pragma unroll
+            for (int v = 0; v < CROSS_NV; ++v) xcst[v] = xcs[v];
+        }
+        for (int row = threadIdx.x >> 4; row < ROWS; row += NTHR / 16) {
+            float acc = 0.f;
+            for (int n = part; n < K; n += 16) acc = fmaf(in[row * p.lda + lds_pos(n, KQh)], p.head_w[n], acc);
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            const int64_t b = b0 + row;
+            if (part == 0 && b < p.batch) {
+                float v = acc;
+                if (fg.lpr != 0) v += extra[row];
+                if (p.cross_layers > 0) {
+                    float dots[CROSS_NV];
+#pragma unroll
+                    for (int l = 0; l < CROSS_NV; ++l) dots[l] = xp[l * ROWS + row];
+                    v += cross_logit(dots, xcst, p.cross_layers);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p.add[i] != nullptr) v += p.add[i][b];
+                if (p.global_bias != nullptr) v += p.global_bias[0];
+                if (p.sigmoid_out) v = dctr::sigmoidf_(v);
+                p.y[b] = v;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < ROWS * K; i += NTHR) {
+            const int r = i / K, c = i % K;
+            const int64_t b = b0 + r;
+            if (b < p.batch) p.y[b * p.y_stride + c] = in[r * p.lda + lds_pos(c, pad64(K) / 4)];
+        }
+    }
+    if (p.probe != nullptr && threadIdx.x == 0) atomicMax(p.probe + 1, (unsigned long long)wall_clock64());
+}
+
 // launchers, one per translation unit mlp_kernels_rt{1,2,4}.hip
 int launch_rt1(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_rt2(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_rt4(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
+int launch_rt1_ring(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, int ring_off, hipStream_t stream);   // mlp_kernels_ring.hip
 
 // backward chain of dctr_mlp_bwd (mlp_bwd_kernels.hip): dz_in [B, units_fwd[L-1]] -> dZ of every earlier layer (-> dz_out[l], dense
 // [B, units_fwd[l]]) and, with dx != NULL, the gradient of the DNN input; Wt[l] = W_l^T ([units_fwd[l], K_l] row-major, 16-B aligned)

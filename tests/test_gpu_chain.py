@@ -779,3 +779,48 @@ def test_chain_kernel_sigmoid_tanh_dnn(device, act, units, bn, E):
     assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=4096), y[perm])
     cut = 16384 + 4096
     assert np.array_equal(model.predict({k: v[:cut] for k, v in feed.items()}, batch_size=4096), y[:cut])
+
+
+@pytest.mark.parametrize("n", [4096, 4099, 1000, 17])
+def test_small_launch_kernel_with_the_shared_weight_stream_gives_the_tile_kernels_bits(device, n):
+    """Launches of at most 16 rows per CU take mlp_ring_kernel (csrc/mlp_device.h: the DNN's weights cross L2 -> LDS once per workgroup,
+    by LDS-DMA into a ring its eight waves share).  It issues the tile kernel's MFMAs on the tile kernel's operands in the tile kernel's
+    k order: BIT-identical to the 32-row tile kernel (tile_rows = 32), on every front end / epilogue they share — hashed + pooled +
+    dense features, BatchNormalization, sigmoid and Dice DNNs, the folded vector CrossNet — and inside the 1e-4 bar of the float64 oracle."""
+    import torch
+    from deepctr_amd import _C
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DCN, DeepFM
+    rng = np.random.RandomState(1000 + n)
+    cols = [SparseFeat("C%d" % i, 3000 + i, 16, use_hash=(i == 2)) for i in range(26)] + [DenseFeat("I%d" % i, 1) for i in range(13)]
+    feed = {"C%d" % i: rng.randint(0, 3000 + i, n).astype(np.int32) for i in range(26)}
+    feed.update({"I%d" % i: rng.rand(n).astype(np.float32) for i in range(13)})
+    colsv = cols + [VarLenSparseFeat(SparseFeat("tags", 90, 16), maxlen=5, combiner="mean")]
+    feedv = dict(feed, tags=rng.randint(0, 90, (n, 5)).astype(np.int32))
+    cases = [("C2 shape", DeepFM, cols, feed, {}),
+             ("+ pooled sequence", DeepFM, colsv, feedv, {}),
+             ("BatchNormalization, 128-64", DeepFM, cols, feed, {"dnn_use_bn": True, "dnn_hidden_units": (128, 64)}),
+             ("sigmoid DNN 256-128", DeepFM, cols, feed, {"dnn_activation": "sigmoid", "dnn_hidden_units": (256, 128)}),
+             ("Dice DNN 192-96-48", DeepFM, cols, feed, {"dnn_activation": "dice", "dnn_hidden_units": (192, 96, 48)}),
+             ("DCN vector (folded CrossNet)", DCN, cols, feed, {"cross_num": 2})]
+    for what, ctor, c, f, kw in cases:
+        model = ctor(c, c, device=device, **kw)
+        w = _randomise(model, rng)
+        y_ring = _predict(model, f, 4096, span_batches=False)          # auto: <= 16 rows per CU -> the shared-stream kernel
+        assert _C.lib().dctr_embed_mlp_fwd_last_kernel() == 0           # (reported as the tile family)
+        y_tile = _predict(model, f, 4096, span_batches=False, tile_rows=32)
+        assert np.array_equal(y_ring, y_tile), what
+        y16 = _predict(model, f, 4096, span_batches=False, tile_rows=16)
+        assert np.array_equal(y16, y_tile), what
+        if ctor is DeepFM and not kw:
+            rows = np.unique(np.r_[0:min(n, 64), max(0, n - 64):n])
+            ref = RM.deepfm(c, c, w, {k: v[rows] for k, v in f.items()}, dtype=np.float64)
+            check_probs(y_ring[rows], ref.astype(np.float32), "shared-stream kernel, " + what)
+    # a width it has no shape for (200-80) stays on the tile kernel; a plain dctr_mlp_fwd (no gather) takes it as well
+    from deepctr_amd import ops
+    x = torch.from_numpy(rng.standard_normal((n, 300)).astype(np.float32)).to(device)
+    ks = [torch.from_numpy((rng.standard_normal(s) * 0.1).astype(np.float32)).to(device) for s in ((300, 256), (256, 64))]
+    bs = [torch.from_numpy((rng.standard_normal(s) * 0.1).astype(np.float32)).to(device) for s in ((256,), (64,))]
+    y_a = ops.mlp(x, ks, bs, "relu", in_dim=300)
+    y_b = ops.mlp(x, ks, bs, "relu", in_dim=300, tile_rows=32)
+    assert torch.equal(y_a, y_b)
