@@ -863,60 +863,182 @@ __global__ __launch_bounds__(NTHR, RT <= 2 ? 4 : 2) void mlp_kernel(MlpParams p,
 
 
 // ---------------------------------------------------------------------------------------------------
-// The 16-row kernel with a SHARED weight stream (mlp_kernels_ring.hip) — launches below 64 rows per CU, where every CU works on
+// The 16-row kernel with LDS-DMA weight streams (mlp_kernels_ring.hip) — launches of at most 16 rows per CU, where every CU works on
 // 16 rows and the whole DNN's weights (603 KB at C2) must reach every CU.
-// mlp_kernel<1> lets each wave stream its own column slice of W from L2 into a three-stage REGISTER pipeline: the bytes a wave can keep
-// in flight are bounded by its registers (8 KB), and 8 waves x 8 KB per L2 round trip is ~20 B/clk/CU — the 12.5 us that bound a
-// 4096-row launch (§4).  The part itself delivers the same 603 KB to all 256 CUs in 3.7 us (profiles/r05_wstream_lab.log: 40+ B/clk/CU by
-// LDS-DMA or wide register loads).  Here the workgroup's 8 waves pull every 32-row chunk of W_l ONCE, by LDS-DMA
-// (global_load_lds_dwordx4: no registers, 64 KB in flight per CU), into a ring of three 32-KiB slots; one barrier per chunk publishes
-// chunk c and frees the slot of chunk c - 1 for chunk c + 2; every wave then takes its column slice of the chunk from LDS (ds_read_b64 /
-// _b32 B fragments) and the activations from the LDS tile (A fragments) exactly as mlp_kernel does.  Same MFMAs on the same operands in
-// the same k order as mlp_kernel<RT>: the results are bit-identical to the tile kernel's.  Gather front end, epilogues (every activation,
+// mlp_kernel<1> streams each wave's column slice of W from L2 into a three-stage REGISTER pipeline: the bytes a wave keeps in flight
+// are bounded by its registers (8 KB), and 8 waves x 8 KB per L2 round trip is ~20 B/clk/CU — the 12.5 us that bound a 4096-row launch
+// (§4).  The part itself delivers the same 603 KB to all 256 CUs in 3.7 us (profiles/r05_wstream_lab.log: 40+ B/clk/CU).
+// Here every wave pulls ITS OWN column slice (16 TPW columns of 32 weight rows = one chunk of 2 / 4 KiB) by LDS-DMA
+// (global_load_lds_dwordx4: no registers; per-lane source addresses, so eight (four) lanes fetch the 128 (64) contiguous bytes of a row's
+// slice and one instruction lays 8 (16) rows down as a dense [row][column] image) into a private ring of three chunks in LDS, two chunks
+// ahead of its MFMAs.  Nothing is shared between waves: NO barrier inside a layer, a wave waits on its own vmcnt only, and the two waves
+// of a SIMD fill each other's LDS / DMA waits.  (A first form with ONE ring shared by the eight waves and a barrier per 32-KiB chunk lost
+// ~1,350 cycles per chunk to the lockstep — DMA issue, barrier skew, exposed LDS latency — against 1,024 of MFMA: 30.8 us, slower than
+// the kernel it was to replace; profiles/r05_ring_lab.log.)
+// B fragments: ds_read_b64 / _b32 from the dense image (rows 4 tt + g of a lane group g lie 128 / 64 B apart: the two groups of a read
+// cover 256 / 128 contiguous bytes — conflict-free); A fragments from the activation tile as mlp_kernel reads them.  Same MFMAs on the same
+// operands in the same k order as mlp_kernel<RT>: bit-identical results.  Gather front end, epilogues (every activation,
 // BatchNormalization, Dice, saved activations), folded CrossNet and head are the tile kernel's own code.
-// Shapes: every layer width N <= 128 with N % 16 == 0, or N <= 256 with N % 32 == 0 (each wave owns at most one wave-tile), no layer-0
-// K split (the input tile fits LDS beside the ring).
-constexpr int RING_SLOT_F = 8192;       // floats per ring slot (32 KiB = 32 weight rows of a 256-wide layer)
-constexpr int RING_SLOTS = 3;
+// Shapes: every layer width a multiple of 16 (a wave's slice is whole 16-B pieces), the input tile whole (no layer-0 K split).
 constexpr int RING_KS = 8;              // k-steps (of 4 weight rows) per chunk
+constexpr int RING_WAVE_F = 2 * 1024;   // floats of LDS per wave: two chunks of 32 rows x 32 columns (a third chunk sits in registers)
 
-__device__ __forceinline__ int ring_chunks(int K) { return pad64(K) / (4 * RING_KS); }
+// the DMA side of a wave's weight stream for one wave-tile (columns n0 .. n0 + 16 TPW of W [k_rows, N]): per-lane offsets inside a chunk are
+// constants (the chunk's base moves as a SCALAR) — fp32 MFMAs run on the vector lanes, every VALU instruction of either wave of a SIMD is
+// matrix time lost (~4 cycles each; 40-60 of them per chunk held the first form of this loop at 65 % of the MFMA rate)
+template <int TPW>
+struct RingStream {
+    static constexpr int LPR = 4 * TPW;                 // lanes per row slice (16 B each)
+    static constexpr int RPI = 64 / LPR;                // weight rows per DMA instruction
+    static constexpr int NI = 32 / RPI;                 // DMA instructions per chunk
+    static constexpr int CF = 32 * 16 * TPW;            // floats per chunk
+    const float* W;
+    float* wring;
+    uint32_t row_b, col_b, rl;
+    int nch, k_rows;
+    uint32_t vq[NI];                                    // per-lane offsets inside a chunk whose 32 rows all exist
 
-// this wave's share of chunk i of layer weights W [K, N] -> slot: 1-KiB pieces wave, wave + 8, ...; lane l's 16 bytes land at piece + 16 l.
-// Rows past K (the zero-padded tail of the activation tile multiplies them) read row K - 1: finite stand-ins.
-__device__ __forceinline__ void ring_dma(const float* W, int K, int N, int i, float* slot, int wave, int lane) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int pieces = N / 8;                                        // 32 rows x N floats x 4 B / 1024
-    const uint32_t row_b = (uint32_t)N * 4u;
-    for (int pc = wave; pc < pieces; pc += NWAVE) {
-        const uint32_t o = (uint32_t)pc * 1024u + 16u * (uint32_t)lane;
-        const uint32_t r = o / row_b, cb = o - r * row_b;
-        const uint32_t gr = (uint32_t)min(32 * i + (int)r, K - 1);
-        const uint32_t voff = gr * row_b + cb;
-        const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)(slot + pc * 256);
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(W), "s"(lds_addr) : "memory");
+    __device__ __forceinline__ RingStream(const float* W_, int N, int k_rows_, int n_base, float* wring_, int lane)
+        : W(W_), wring(wring_), k_rows(k_rows_) {
+        int n0 = n_base;
+        if (n0 + 16 * TPW > N) n0 = N - 16 * TPW;       // (host: N % 16 == 0; TPW = 2 only when N % 32 == 0)
+        nch = pad64(k_rows) / (4 * RING_KS);
+        rl = (uint32_t)lane / LPR;
+        const uint32_t pc = (uint32_t)lane % LPR;
+        row_b = (uint32_t)N * 4u;
+        col_b = (uint32_t)(n0 + 4 * (int)pc) * 4u;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) vq[q] = ((uint32_t)(RPI * q) + rl) * row_b + col_b;
+    }
+    __device__ __forceinline__ void issue(int i, int slot) const {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        if (32 * i + 32 <= k_rows) {                                                           // (scalar branch: no per-lane select)
+            const char* Wc = reinterpret_cast<const char*>(W) + (size_t)(32 * i) * row_b;      // (scalar)
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)(wring + slot * CF + q * 256);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vq[q]), "s"(Wc), "s"(lds_addr) : "memory");
+            }
+        } else {                     // the zero-padded K tail (the layer's last one or two chunks): rows past K read row K - 1 — x is 0 there
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const uint32_t voff = (uint32_t)min(32 * i + RPI * q + (int)rl, k_rows - 1) * row_b + col_b;
+                const uint32_t lds_addr = (uint32_t)(size_t)(lds_ptr_t)(wring + slot * CF + q * 256);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(W), "s"(lds_addr) : "memory");
+            }
+        }
+    }
+    // chunks 0 and 1 -> slots 0 and 1 (the wave's earlier reads of its ring must be complete: the caller waits lgkmcnt(0))
+    __device__ __forceinline__ void prologue() const {
+        issue(0, 0);
+        if (nch > 1) issue(1, 1);
+    }
+};
+
+// C[16 x 16 TPW] = A[16 x K] * W[K x N] for one wave-tile: A fragments from the activation tile (as tile_gemm_pipe reads them), B
+// fragments from the wave's own LDS-DMA ring.  `prefetched`: the caller has issued st.prologue() earlier (under the gather / the previous
+// layer's epilogue) and nothing of this loop's accounting was in flight before it.
+template <int TPW>
+__device__ __forceinline__ void tile_gemm_dma(const float* A, int lda, int KQ, const RingStream<TPW>& st, bool prefetched,
+                                              dctr::f32x4 (&acc)[1][TPW], int lane) {
+    constexpr int NI = RingStream<TPW>::NI, CF = RingStream<TPW>::CF;
+    const int g = lane >> 4, j = lane & 15;
+    const int nch = st.nch;
+    const float* const bbase0 = st.wring + g * (16 * TPW) + TPW * j;       // two precomputed bases + immediate offsets: no address VALU
+    const float* const bbase1 = bbase0 + CF;
+    const float* ap = A + j * lda + g * KQ;
+    auto frags = [&](int slot, float (&a)[1][RING_KS], float (&b)[RING_KS][TPW]) {
+        load_as<RING_KS>(ap, a[0]);
+        ap += RING_KS;
+        const float* brow = slot ? bbase1 : bbase0;
+#pragma unroll
+        for (int tt = 0; tt < RING_KS; ++tt) {
+            if constexpr (TPW == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(brow + 4 * tt * (16 * TPW));
+                b[tt][0] = v.x;
+                b[tt][1] = v.y;
+            } else {
+                b[tt][0] = brow[4 * tt * (16 * TPW)];
+            }
+        }
+    };
+    // (splitting even / odd k-steps over two accumulator sets — longer distances between dependent MFMAs — measured no gain and would
+    //  give up the tile kernel's summation order: one set, the tile kernel's bits)
+    auto mfma2 = [&](const float (&a)[1][RING_KS], const float (&b)[RING_KS][TPW]) { mfmas<TPW, 1, RING_KS>(a, b, acc); };
+    // Software pipeline, per wave.  Invariant at the top of step i: chunk i sits in REGISTERS (ac, bc); LDS slot (i + 1) % 2 holds
+    // chunk i + 1 (landed or landing), slot i % 2 chunk i + 2.  Step i: chunk i + 1 -> the other register set (its LDS latency runs
+    // under this step's MFMAs), the MFMAs of chunk i, then the DMA of chunk i + 3 into the slot chunk i + 1 has just left.
+    float a0[1][RING_KS], b0[RING_KS][TPW], a1[1][RING_KS], b1[RING_KS][TPW];
+    if (!prefetched) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a clean counter: only this loop's DMAs are counted from here on
+        st.prologue();
+        if (nch > 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunks 0 and 1 (issued long ago) and whatever the epilogue loaded since
+    }
+    frags(0, a0, b0);
+    if (nch > 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st.issue(2, 0);
+    }
+    auto step = [&](int i, int slot_n, float (&ac)[1][RING_KS], float (&bc)[RING_KS][TPW], float (&an)[1][RING_KS], float (&bn)[RING_KS][TPW]) {
+        if (i + 1 < nch) {
+            if (i + 2 < nch) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NI) : "memory");      // chunk i + 1 landed (i + 2 may be on its way)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            frags(slot_n, an, bn);
+        }
+        mfma2(ac, bc);
+        if (i + 3 < nch) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (chunk i + 1 is in registers: its slot is free)
+            st.issue(i + 3, slot_n);
+        }
+    };
+    for (int i = 0; i < nch; i += 2) {
+        step(i, 1, a0, b0, a1, b1);
+        if (i + 1 < nch) step(i + 1, 0, a1, b1, a0, b0);
     }
 }
 
-// the MFMAs of one chunk for this wave's tile: A = 8 k-steps of the activation tile, B = the chunk's rows 4 tt + g, columns n_base + TPW j
-template <int TPW>
-__device__ __forceinline__ void ring_chunk_mfma(const float* arow, const float* slot, int N, int n_base, int lane, dctr::f32x4 (&acc)[1][TPW]) {
-    const int g = lane >> 4, j = lane & 15;
-    float a[1][RING_KS];
-    load_as<RING_KS>(arow, a[0]);
-    float b[RING_KS][TPW];
-    const float* brow = slot + g * N + n_base + TPW * j;
-#pragma unroll
-    for (int tt = 0; tt < RING_KS; ++tt) {
-        if constexpr (TPW == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(brow + 4 * tt * N);
-            b[tt][0] = v.x;
-            b[tt][1] = v.y;
-        } else {
-            b[tt][0] = brow[4 * tt * N];
-        }
+// the wave-tile rule of a layer (the tile kernel's: layer_dispatch): 32-column tiles when they give every wave one, else 16
+__device__ __forceinline__ bool ring_wide(int N) { return N % 32 == 0 && N >= 32 * NWAVE; }
+
+// chunks 0 and 1 of this wave's FIRST tile of layer l, issued ahead of time (before the gather; under the previous layer's epilogue)
+__device__ __forceinline__ void ring_prefetch(const MlpParams& p, int l, float* wring, int wave, int lane) {
+    const int N = p.units[l], K = l == 0 ? p.in_dim : p.units[l - 1];
+    if (ring_wide(N)) {
+        if (wave * 32 < N) RingStream<2>(p.W[l], N, K, wave * 32, wring, lane).prologue();
+    } else {
+        if (wave * 16 < N) RingStream<1>(p.W[l], N, K, wave * 16, wring, lane).prologue();
     }
-    mfmas<TPW, 1, RING_KS>(a, b, acc);
+}
+
+template <int TPW, int ACT>
+__device__ __forceinline__ void layer_tiles_dma(const MlpParams& p, int l, const float* in, float* out, int K, int N, float* wring, bool prefetched) {
+    using dctr::f32x4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int n_tiles = (N + 16 * TPW - 1) / (16 * TPW);
+    for (int wt = wave; wt < n_tiles; wt += NWAVE) {
+        const int n_base = wt * 16 * TPW;
+        f32x4 acc[1][TPW];
+        zero_acc<TPW, 1>(acc);
+        const RingStream<TPW> st(p.W[l], N, K, n_base, wring, lane);
+        tile_gemm_dma<TPW>(in, p.lda, pad64(K) / 4, st, prefetched && wt == wave, acc, lane);
+        if (wt + NWAVE >= n_tiles && l + 1 < p.n_layers) {            // this wave's last tile of the layer: the next layer's first chunks
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // travel under the epilogue and the barrier (the ring is read out)
+            ring_prefetch(p, l + 1, wring, wave, lane);
+        }
+        tile_epilogue<TPW, ACT, 1>(p, l, out, N, n_base, acc);
+    }
+    if (wave >= n_tiles && l + 1 < p.n_layers) ring_prefetch(p, l + 1, wring, wave, lane);     // (a wave without a tile in this layer)
+    zero_k_padding<1>(p, out, N);
+}
+
+template <int ACT>
+__device__ __forceinline__ void layer_dispatch_dma(const MlpParams& p, int l, const float* in, float* out, int K, int N, float* wring, bool prefetched) {
+    if (ring_wide(N)) layer_tiles_dma<2, ACT>(p, l, in, out, K, N, wring, prefetched);
+    else layer_tiles_dma<1, ACT>(p, l, in, out, K, N, wring, prefetched);
 }
 
 template <int UNUSED = 0>      // (a template so that the header may be included by several translation units; instantiated in mlp_kernels_ring.hip)
@@ -930,29 +1052,11 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_ring_kernel(MlpParams p, FusedGat
     float* xp = extra + 2 * ROWS;
     float* xcs = xp + CROSS_NV * ROWS;
     float* xv = xcs + 8;
-    float* ring = smem + ring_off;
     const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
+    float* wring = smem + ring_off + wave * RING_WAVE_F;
     if (p.probe != nullptr && threadIdx.x == 0) atomicMin(p.probe, (unsigned long long)wall_clock64());
-
-    // the flat chunk list of the launch: layer 0's chunks, then layer 1's, ...; chunk c (counted over the launch) lives in slot c % 3
-    int total = 0;
-    for (int l = 0; l < p.n_layers; ++l) total += ring_chunks(l == 0 ? p.in_dim : p.units[l - 1]);
-    auto dma_global = [&](int c) {
-        if (c >= total) return;
-        float* slot = ring + (c % RING_SLOTS) * RING_SLOT_F;
-        int l = 0, K = p.in_dim;
-        for (;; ++l) {
-            const int n = ring_chunks(K);
-            if (c < n) break;
-            c -= n;
-            K = p.units[l];
-        }
-        ring_dma(p.W[l], K, p.units[l], c, slot, wave, lane);
-    };
-    dma_global(0);                                                 // the first two chunks travel under the gather
-    dma_global(1);
 
     if (p.cross_layers > 0) {
         const int kpad = pad64(p.in_dim), L = p.cross_layers, d = p.in_dim;
@@ -974,58 +1078,28 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_ring_kernel(MlpParams p, FusedGat
     float* in = buf0;
     float* out = buf1;
     int K = p.in_dim;
+    // (layer 0's first chunks are NOT requested ahead of the gather: measured, they lengthen it by more than they save)
     {
         const int n_fields = fg.lpr != 0 ? fg.g.n_fields : 0;
         const Chunk ck{0, pad64(p.in_dim) / 4, 0, n_fields, true, true};
         produce_chunk<RT>(p, fg, buf0, buf1, extra, b0, ck);
         if (p.cross_layers > 0) cross_partial<RT>(p, buf0, ck, xp, xv);
     }
-    int cg = 0;
     for (int l = 0; l < p.n_layers; ++l) {
         const int N = p.units[l];
-        const bool wide = N > 128;                                     // (host: then N % 32 == 0 and N <= 256; else N % 16 == 0)
-        const int n_tiles = wide ? N / 32 : N / 16;
-        const int n_base = wave * (wide ? 32 : 16);
-        const bool mine = wave < n_tiles;
-        f32x4 acc2[1][2], acc1[1][1];
-        zero_acc<2, 1>(acc2);
-        zero_acc<1, 1>(acc1);
-        const int KQ = pad64(K) / 4;
-        const float* arow = in + (lane & 15) * p.lda + (lane >> 4) * KQ;
-        const int nch = ring_chunks(K);
-        for (int i = 0; i < nch; ++i, ++cg) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's shares of chunks cg and cg + 1 have landed
-            __syncthreads();                                          // ... everyone's have; everyone is through with chunk cg - 1
-            dma_global(cg + 2);                                       // (into the slot of chunk cg - 1)
-            if (mine) {
-                const float* slot = ring + (cg % RING_SLOTS) * RING_SLOT_F;
-                if (wide) ring_chunk_mfma<2>(arow + RING_KS * i, slot, N, n_base, lane, acc2);
-                else ring_chunk_mfma<1>(arow + RING_KS * i, slot, N, n_base, lane, acc1);
-            }
+        switch (p.activation) {
+            case DCTR_ACT_RELU: layer_dispatch_dma<DCTR_ACT_RELU>(p, l, in, out, K, N, wring, l > 0); break;
+            case DCTR_ACT_SIGMOID: layer_dispatch_dma<DCTR_ACT_SIGMOID>(p, l, in, out, K, N, wring, l > 0); break;
+            case DCTR_ACT_TANH: layer_dispatch_dma<DCTR_ACT_TANH>(p, l, in, out, K, N, wring, l > 0); break;
+            case DCTR_ACT_DICE: layer_dispatch_dma<DCTR_ACT_DICE>(p, l, in, out, K, N, wring, l > 0); break;
+            default: layer_dispatch_dma<DCTR_ACT_LINEAR>(p, l, in, out, K, N, wring, l > 0); break;
         }
-        if (mine) {
-#define DCTR_EPI(ACT)                                                              \
-    do {                                                                           \
-        if (wide) tile_epilogue<2, ACT, RT>(p, l, out, N, n_base, acc2);           \
-        else tile_epilogue<1, ACT, RT>(p, l, out, N, n_base, acc1);                \
-    } while (0)
-            switch (p.activation) {
-                case DCTR_ACT_RELU: DCTR_EPI(DCTR_ACT_RELU); break;
-                case DCTR_ACT_SIGMOID: DCTR_EPI(DCTR_ACT_SIGMOID); break;
-                case DCTR_ACT_TANH: DCTR_EPI(DCTR_ACT_TANH); break;
-                case DCTR_ACT_DICE: DCTR_EPI(DCTR_ACT_DICE); break;
-                default: DCTR_EPI(DCTR_ACT_LINEAR); break;
-            }
-#undef DCTR_EPI
-        }
-        zero_k_padding<RT>(p, out, N);
         __syncthreads();
         float* t = in;
         in = out;
         out = t;
         K = N;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (p.has_head) {
         const int part = threadIdx.x & 15;

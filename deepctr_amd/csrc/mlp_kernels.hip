@@ -234,17 +234,14 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     const int64_t blocks = dctr_ceil_div(a->batch, (int64_t)rows);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
     if (ga != nullptr) g_last_fwd_kernel = DCTR_FWD_KERNEL_TILE;
-    // 16-row workgroups that are alone on their CU (at most one per CU: a launch of <= 16 x CUs rows, or tile_rows 16): the kernel with
-    // the SHARED weight stream (mlp_device.h: mlp_ring_kernel) — every layer width <= 128 (multiple of 16) or <= 256 (multiple of 32),
-    // the input tile whole (no K split), ring + tiles inside 160 KiB.  Same bits as the tile kernel.
+    // 16-row workgroups that are alone on their CU (at most one per CU: a launch of <= 16 x CUs rows, or tile_rows 16): the kernel whose
+    // waves pull their weight slices by LDS-DMA (mlp_device.h: mlp_ring_kernel) — every layer width a multiple of 16, the input tile
+    // whole (no K split), tiles + 8 x 12 KiB of rings inside 160 KiB.  Same bits as the tile kernel.
     if (rt == 1 && p.k_split == 0 && a->n_layers >= 1 && (a->tile_rows == 16 || blocks <= (int64_t)dctr_n_cus())) {
         bool ok = true;
-        for (int l = 0; l < a->n_layers; ++l) {
-            const int n = a->units[l];
-            ok = ok && ((n <= 128 && n % 16 == 0) || (n <= 256 && n % 32 == 0));
-        }
+        for (int l = 0; l < a->n_layers; ++l) ok = ok && a->units[l] % 16 == 0;
         const size_t ring_off = (lds + 1023) & ~(size_t)1023;
-        const size_t total = ring_off + (size_t)RING_SLOTS * RING_SLOT_F * sizeof(float);
+        const size_t total = ring_off + (size_t)NWAVE * RING_WAVE_F * sizeof(float);
         if (ok && total <= LDS_PER_CU) return launch_rt1_ring(p, fg, (unsigned)blocks, total, (int)(ring_off / sizeof(float)), (hipStream_t)stream);
     }
     if (rt == 1) return launch_rt1(p, fg, (unsigned)blocks, lds, (hipStream_t)stream);

@@ -806,11 +806,19 @@ def test_small_launch_kernel_with_the_shared_weight_stream_gives_the_tile_kernel
     for what, ctor, c, f, kw in cases:
         model = ctor(c, c, device=device, **kw)
         w = _randomise(model, rng)
+        if any(k.endswith("moving_variance") for k in w):               # (Dice / BatchNormalization statistics: a variance is positive)
+            w = {k: (np.abs(v) + 0.5 if k.endswith("moving_variance") else v) for k, v in w.items()}
+            model.set_weights_by_name(w)
         y_ring = _predict(model, f, 4096, span_batches=False)          # auto: <= 16 rows per CU -> the shared-stream kernel
+        assert np.isfinite(y_ring).all(), what
         assert _C.lib().dctr_embed_mlp_fwd_last_kernel() == 0           # (reported as the tile family)
         y_tile = _predict(model, f, 4096, span_batches=False, tile_rows=32)
-        assert np.array_equal(y_ring, y_tile), what
         y16 = _predict(model, f, 4096, span_batches=False, tile_rows=16)
+        if ctor is DCN:        # (the 32-row kernel builds its input tile in two K halves: the folded CrossNet's dots are sums of two partial
+            assert_close(y_ring, y_tile, rtol=2e-6, atol=2e-7, what=what)        #  dots there, one dot here — same DNN bits, other rounding)
+            assert_close(y16, y_tile, rtol=2e-6, atol=2e-7, what=what)
+            continue
+        assert np.array_equal(y_ring, y_tile), what
         assert np.array_equal(y16, y_tile), what
         if ctor is DeepFM and not kw:
             rows = np.unique(np.r_[0:min(n, 64), max(0, n - 64):n])
