@@ -789,7 +789,8 @@ def main():
                             "hbm_algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
         if t_fused32 is not None:
             tf = DNN_FLOP_PER_SAMPLE * B / t_fused32 / 1e12
-            kernels.append({"kernel": "mlp_kernel<2>, fused gather, ONE isolated 4096-row launch (128 workgroups = half the CUs)",
+            kernels.append({"kernel": "mlp_ring_kernel, fused gather, ONE isolated 4096-row launch (256 workgroups x 16 rows, every wave's weight "
+                                      "slice by LDS-DMA; rounds 1-4: mlp_kernel<2>, 128 workgroups x 32 rows, 26.8 us)",
                             "in_step": False, "us_per_launch": t_fused32 * 1e6, "bound": "mfma", "achieved": tf,
                             "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF})
         gather_gbs = ALG_BYTES_PER_SAMPLE * B / t_gather / 1e9
@@ -814,7 +815,7 @@ def main():
                                 "bytes_counted": "ids + rows + linear entries + dense" + (" + the dnn_in write" if with_write else ""),
                                 "pure_random_64B_row_read_line_frac": 0.45,
                                 "evidence": "profiles/r04_pmc_gather.json, profiles/r05_gather_records_lab.log (requests per row: 54 plain, 28 records)"})
-        kernels.append({"kernel": "mlp_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA), isolated 4096-row launch", "in_step": False,
+        kernels.append({"kernel": "mlp_ring_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA, 16-row workgroups), isolated 4096-row launch", "in_step": False,
                         "us_per_launch": t_mlp * 1e6, "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF})
         dom = kernels[0]

@@ -464,7 +464,9 @@ int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m,
  * to `max` entries (rows, DCTR_FWD_KERNEL_* id, batch rows per workgroup) — one per phase, in order — and returns their number
  * (<= 0: error, see dctr_last_error).  Needs a current HIP device (CU count).
  * dctr_embed_mlp_fwd_last_kernel(): the DCTR_FWD_KERNEL_* id the calling thread's last successful dctr_embed_mlp_fwd call
- * launched (-1 before the first one). */
+ * launched (-1 before the first one).  DCTR_FWD_KERNEL_TILE covers both forms of the tile family: 16- / 32-row workgroups whose waves
+ * stream their weight slices into registers, and — launches of at most 16 rows per CU (or tile_rows 16) with every layer width a
+ * multiple of 16 — 16-row workgroups whose waves pull them by LDS-DMA (csrc/mlp_device.h: mlp_ring_kernel; same bits). */
 enum { DCTR_FWD_KERNEL_TILE = 0, DCTR_FWD_KERNEL_STREAM = 1, DCTR_FWD_KERNEL_CHAIN = 2 };
 int dctr_embed_mlp_fwd_plan(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int64_t* rows, int32_t* kernel,
                             int32_t* rows_per_workgroup, int32_t max);
