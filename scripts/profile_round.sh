@@ -28,6 +28,7 @@ python $ROOT/scripts/pmc_summary.py $OUT/pmc_configs_summary.json $OUT/cfgpmc_* 
 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
 python $ROOT/bench.py > $OUT/bench_steps256.json 2> $OUT/bench_steps256.err
 python $ROOT/scripts/bench_configs.py > $OUT/bench_configs.log 2>&1
+for m in DeepFM DCN DCNM xDeepFM DIN; do python $ROOT/scripts/bench_train.py --model $m --batches $([ $m = DIN ] && echo 2048 || echo 4096) >> $OUT/train_steps.log 2>&1; done
 find $OUT -name "*kernel_trace.csv" -size +1M -delete
 find $OUT -name "*counter_collection.csv" -size +1M -delete
 find $OUT -name "*agent_info.csv" -delete
