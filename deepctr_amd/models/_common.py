@@ -199,6 +199,9 @@ class FusedForward(object):
         if B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256:
             return True
         u0 = int(self.dnn.kernels[0].shape[1])
+        if self.stage_plan.in_dim > 2 * self._TILE_MAX_UNSPLIT and self.tile_rows in (0, 16, 32):
+            return True      # too wide for the tile kernel even split: small launches go to the row-chained kernel's tail phase, which
+                             # has the padded widths only (e.g. 39 fields of embedding_dim 64 in front of a 128-80 DNN)
         return bool(self.stage_plan.in_dim > self._TILE_MAX_UNSPLIT and 128 < u0 < 256 and self._pad_spec[0] == 256
                     and self.tile_rows in (0, 16, 32))
 

@@ -832,3 +832,23 @@ def test_small_launch_kernel_with_the_shared_weight_stream_gives_the_tile_kernel
     y_a = ops.mlp(x, ks, bs, "relu", in_dim=300)
     y_b = ops.mlp(x, ks, bs, "relu", in_dim=300, tile_rows=32)
     assert torch.equal(y_a, y_b)
+
+
+def test_wide_input_with_uninstantiated_widths_runs_at_every_launch_size(device):
+    """A DNN input too wide for the tile kernel even K-split (39 fields of embedding_dim 64 = 2,496 columns) in front of widths the
+    row-chained kernel has no instantiation for (128-80): small launches must take the zero-padded copies too — the same
+    model that works in 16,384-row spans must not raise DCTR_E_UNSUPPORTED at 300 rows."""
+    from deepctr_amd.feature_column import SparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(404)
+    n = 16384 + 300
+    cols = [SparseFeat("C%d" % i, 700 + i, 64) for i in range(39)]
+    feed = {"C%d" % i: rng.randint(0, 700 + i, n).astype(np.int32) for i in range(39)}
+    model = DeepFM(cols, cols, dnn_hidden_units=(128, 80), device=device)
+    w = _randomise(model, rng)
+    y = model.predict(feed, batch_size=4096)
+    small = {k: v[:300] for k, v in feed.items()}
+    ys = model.predict(small, batch_size=256)
+    ref = RM.deepfm(cols, cols, w, small, dnn_hidden_units=(128, 80), dtype=np.float64)
+    check_probs(ys, ref.astype(np.float32), "wide input, 128-80 DNN, 300 rows")
+    assert_close(ys, y[:300], rtol=2e-6, atol=2e-7, what="small launch vs span")
