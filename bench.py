@@ -295,7 +295,7 @@ def host_preprocess(seconds, rows=200000):
     return n
 
 
-def measure_traffic(K, rows_launch, dist_name, timeout_s=240, fused_records=False):
+def measure_traffic(K, rows_launch, dist_name, timeout_s=120, fused_records=False):
     """roofline.traffic measured IN THIS RUN: FETCH_SIZE and WRITE_SIZE of the timed region's kernel from two rocprofv3 counter passes
     over a child of this script (same K, same launch shape; `--kernel-trace --pmc <one counter>` only — counters are never combined
     with API traces; cwd and TMPDIR = /tmp as the profiling recipe asks).  Returns (bytes per launch, description) or (None, reason).

@@ -30,3 +30,18 @@ def test_cpu_port_matches_oracle():
                     [torch.from_numpy(feed["I%d" % i]).reshape(-1, 1) for i in range(1, ND + 1)]).numpy()
     ref = RM.deepfm(cols, cols, w, feed, dnn_hidden_units=(16, 8))
     assert_close(y, ref, what="cpu port")
+
+
+def test_bench_host_helpers_run_without_a_gpu():
+    """bench.py's host-side helpers (no device): the cgroup reader returns the fields the JSON line prints whatever the container
+    exposes, the single-threaded preprocessing load really runs for its time, and the throttle pause is a plain sleep."""
+    import time
+    import bench
+    cg = bench.cgroup_cpu()
+    assert "cpu_max" in cg and all(isinstance(v, (int, str, type(None))) for v in cg.values())
+    t0 = time.perf_counter()
+    n = bench.host_preprocess(0.2, rows=20000)
+    assert n >= 1 and time.perf_counter() - t0 >= 0.2
+    assert bench.dom_ok([(0, 4096, "chain", 256, 1e-4)]) and not bench.dom_ok([]) and not bench.dom_ok([(0, 4096, "tile", 32, 1e-4)])
+    tr, src = bench.load_traffic(81920)
+    assert tr is None or (tr > 1.0e8 and "r04_pmc_traffic" in src)
