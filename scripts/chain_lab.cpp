@@ -1,3 +1,5 @@
+// NOTE (round 5): the -DDCTR_*_LAB_* / -DDCTR_LAB_TIMING ablation and stamp switches this harness mentions were removed from the product kernels
+// (they live in git history up to 5db6128); without them it still builds and times the shipped kernels.
 // Lab harness for the row-chained dctr_embed_mlp_fwd kernel (chain_kernels.hip) at the C2 / C5 shapes: correctness against
 // mlp_kernel<2>, the streaming kernel and a float64 host reference on a row sample (ragged tail, out-of-range id flag),
 // then launch times over a range of rows per launch for tile_rows 0 (auto: chained + remainder), 256 (chained only), 64.
@@ -10,6 +12,7 @@
 #include "../deepctr_amd/csrc/mlp_kernels_rt2.hip"
 #undef DCTR_MLP_RT
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
+#include "../deepctr_amd/csrc/mlp_kernels_ring.hip"
 #include "../deepctr_amd/csrc/stream_kernels.hip"
 #include "../deepctr_amd/csrc/chain_kernels.hip"
 #include "../deepctr_amd/csrc/chain_kernels_r2w8_m42.hip"
@@ -32,6 +35,7 @@ int launch_r2w8_m21(const ChainParams&, int, int, unsigned, hipStream_t) { retur
 int launch_r2w8_m42x(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m42t(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 int launch_r2w8_m42w(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
+int launch_r2w8_m42r(const ChainParams&, int, int, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 size_t bf3_workspace_bytes(int) { return 0; }
 int launch_r2w8_m42_bf3(const ChainParams&, int, void*, bool, unsigned, hipStream_t) { return DCTR_E_UNSUPPORTED; }
 }

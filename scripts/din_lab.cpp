@@ -1,3 +1,5 @@
+// NOTE (round 5): the -DDCTR_*_LAB_* / -DDCTR_LAB_TIMING ablation and stamp switches this harness mentions were removed from the product kernels
+// (they live in git history up to 5db6128); without them it still builds and times the shipped kernels.
 // Lab harness for dctr_din_attn_pool_fwd (bring-up tool): per-dispatch time and cycle stamps of the C4 shape.
 #include "../deepctr_amd/csrc/abi.cpp"
 #include "../deepctr_amd/csrc/din_kernels.hip"

@@ -1,3 +1,5 @@
+// NOTE (round 5): the -DDCTR_*_LAB_* / -DDCTR_LAB_TIMING ablation and stamp switches this harness mentions were removed from the product kernels
+// (they live in git history up to 5db6128); without them it still builds and times the shipped kernels.
 // Lab harness for dctr_mlp_fwd (bring-up tool): per-dispatch time of the C2 DNN at B=4096 under -DDCTR_LAB_* ablations.
 #include "../deepctr_amd/csrc/abi.cpp"
 #include "../deepctr_amd/csrc/mlp_kernels.hip"
@@ -9,6 +11,7 @@ __device__ unsigned long long dctr_lab_ts[64];
 #include "../deepctr_amd/csrc/mlp_kernels_rt2.hip"
 #undef DCTR_MLP_RT
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
+#include "../deepctr_amd/csrc/mlp_kernels_ring.hip"
 #include <vector>
 #include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)

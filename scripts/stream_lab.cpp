@@ -1,3 +1,5 @@
+// NOTE (round 5): the -DDCTR_*_LAB_* / -DDCTR_LAB_TIMING ablation and stamp switches this harness mentions were removed from the product kernels
+// (they live in git history up to 5db6128); without them it still builds and times the shipped kernels.
 // Lab harness for the streaming dctr_embed_mlp_fwd kernel (stream_kernels.hip) at the C2 / C5 shapes: correctness against
 // mlp_kernel<2> and a float64 host reference on a row sample, then launch times over a range of rows per launch.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I deepctr_amd/csrc scripts/stream_lab.cpp -o scripts/_bin/stream_lab
@@ -9,6 +11,7 @@
 #include "../deepctr_amd/csrc/mlp_kernels_rt2.hip"
 #undef DCTR_MLP_RT
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
+#include "../deepctr_amd/csrc/mlp_kernels_ring.hip"
 #include "../deepctr_amd/csrc/stream_kernels.hip"
 #include <algorithm>
 #include <cmath>
