@@ -12,6 +12,9 @@ __device__ unsigned long long dctr_lab_ts[64];
 #undef DCTR_MLP_RT
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
 #include "../deepctr_amd/csrc/mlp_kernels_ring.hip"
+namespace dctr_stream { int try_launch(const dctr_mlp_args_t*, const dctr_gather_fm_args_t*, int, int, bool, hipStream_t, int*) { return 0; } int eligible(const dctr_mlp_args_t*, const dctr_gather_fm_args_t*, bool) { return 0; } }
+namespace dctr_chain { int eligible(const dctr_mlp_args_t*, const dctr_gather_fm_args_t*, bool) { return 0; } int launch(const dctr_mlp_args_t*, const dctr_gather_fm_args_t*, int, int, int, hipStream_t) { return -5; }
+int plan(int64_t, int, int64_t*, int32_t*, int) { return 0; } size_t bf3_workspace_bytes(int) { return 0; } }
 #include <vector>
 #include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
