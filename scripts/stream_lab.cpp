@@ -13,6 +13,8 @@
 #include "../deepctr_amd/csrc/mlp_kernels_rt4.hip"
 #include "../deepctr_amd/csrc/mlp_kernels_ring.hip"
 #include "../deepctr_amd/csrc/stream_kernels.hip"
+namespace dctr_chain { int eligible(const dctr_mlp_args_t*, const dctr_gather_fm_args_t*, bool) { return 0; } int launch(const dctr_mlp_args_t*, const dctr_gather_fm_args_t*, int, int, int, hipStream_t) { return -5; }
+int plan(int64_t, int, int64_t*, int32_t*, int) { return 0; } size_t bf3_workspace_bytes(int) { return 0; } }
 #include <algorithm>
 #include <cmath>
 #include <vector>
