@@ -400,6 +400,8 @@ class EmbeddingStage(object):
         idesc, ddesc = _host_cols(cols), _host_cols(dense)
         staged.ids = torch.empty(F, n, dtype=dt, device=dev) if F else None
         staged.dense = torch.empty(n, ND, dtype=torch.float32, device=dev) if ND else None
+        if F and self.hash_at_stage and self.any_hash and self.fields:      # (allocated here, on the caller's stream, as the other two)
+            staged.hashed = torch.empty(len(self.fields), n, dtype=dt, device=dev)
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream(dev)
             self._slot_events = [torch.cuda.Event(), torch.cuda.Event()]
