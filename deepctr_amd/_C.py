@@ -33,7 +33,8 @@ class DctrExtensionError(RuntimeError):
 
 
 class DctrError(RuntimeError):
-    """A dctr_* entry point returned non-zero."""
+    """A dctr_* entry point returned non-zero (``rc``: its return code, e.g. E_UNSUPPORTED)."""
+    rc = None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -288,7 +289,9 @@ def lib():
 def check(rc, what):
     if rc != 0:
         msg = lib().dctr_last_error()
-        raise DctrError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+        err = DctrError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+        err.rc = int(rc)
+        raise err
 
 
 def require_device():

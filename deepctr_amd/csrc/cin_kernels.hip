@@ -263,7 +263,7 @@ __device__ __forceinline__ void cin_layer(const CinParams& p, int k, const float
         // nobody reads).  Maps [d0, H) go to the output summed over d
         // (interaction.py:322-323): with reg_reduce that sum is taken here — 4 rows in the lane, lanes 16 / 32 apart
         // (the other k-slots' rows of the same sample), then the D/16 row tiles of a sample — and written straight
-        // to `out`; otherwise (D % 4 != 0) every map is stored and cin_kernel sums from LDS.
+        // to `out`; otherwise (D not 4, 8 or a multiple of 16) every map is stored and cin_kernel sums from LDS.
         // (SAVE) descriptor over the whole [B*D, H] buffer of this layer, this lane's byte offset of (row 4g of the workgroup, column n_base + TPW*jl)
         __amdgpu_buffer_rsrc_t save_rsrc = rsrc;
         int save_voff = 0;
@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256, 2) void cin_kernel(CinParams p) {
                     const float* yp = ycur + n * ROWS_P + s * D;
                     float acc = 0.f;
                     for (int d = 0; d < D; ++d) acc += yp[d];
-                    p.out[(b0 + s) * p.out_dim + out_off + (n - d0)] = acc;
+                    if (outl != nullptr) outl[s * p.out_dim + out_off + (n - d0)] = acc;      // (fused head: the maps wait in LDS)
+                    else p.out[(b0 + s) * p.out_dim + out_off + (n - d0)] = acc;
                 }
             }
         }
@@ -570,7 +571,9 @@ static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g
     p.n_layers = a->n_layers;
     p.split_half = a->split_half ? 1 : 0;
     p.activation = a->activation;
-    p.reg_reduce = a->dim % 4 == 0 ? 1 : 0;
+    // the in-register sum over d pairs lanes 16 / 32 apart: a sample's rows must be 4, 8 or whole 16-row tiles (D = 12, 20, 24 ...
+    // straddle them: those sum from LDS)
+    p.reg_reduce = (a->dim == 4 || a->dim == 8 || a->dim % 16 == 0) ? 1 : 0;
     int hmax = 1;
     for (int k = 0; k < a->n_layers; ++k) {
         const int H = a->layer_size[k];

@@ -988,10 +988,10 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
                  "crossnet_fwd: save_u / save_x exist for the matrix form (save_x with more than one layer)");
     hipStream_t st = (hipStream_t)stream;
     if (mode == DCTR_CROSS_VECTOR || layers == 0) {
-        DCTR_REQUIRE(dim <= 64 * 32, DCTR_E_UNSUPPORTED, "crossnet_fwd(vector): dim %d > 2048", dim);
+        DCTR_REQUIRE(dim <= 64 * 128, DCTR_E_UNSUPPORTED, "crossnet_fwd(vector): dim %d > 8192", dim);
         const int64_t blocks = dctr_ceil_div(batch, 4);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
-        const int nr = pow2_at_least((dim + 63) / 64, 32);
+        const int nr = pow2_at_least((dim + 63) / 64, 128);      // values of x_0 / x_l per lane (one wave per sample; 128: 256 VGPRs)
 #define CALL_CV(N)                                                                                                  \
     DCTR_LAUNCH((cross_vector_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, \
                        kernels, bias, layers, y, y_stride, a->head_w, a->logit)
@@ -1001,7 +1001,9 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
             case 4: CALL_CV(4); break;
             case 8: CALL_CV(8); break;
             case 16: CALL_CV(16); break;
-            default: CALL_CV(32); break;
+            case 32: CALL_CV(32); break;
+            case 64: CALL_CV(64); break;
+            default: CALL_CV(128); break;
         }
 #undef CALL_CV
     } else {

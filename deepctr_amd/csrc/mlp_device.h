@@ -1147,6 +1147,7 @@ int launch_rt1(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_
 int launch_rt2(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_rt4(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_rt1_ring(const MlpParams& p, const FusedGather& fg, unsigned blocks, size_t lds, int ring_off, hipStream_t stream);   // mlp_kernels_ring.hip
+int launch_wide(const MlpParams& p, int kc, unsigned blocks, size_t lds, hipStream_t stream);                                         // mlp_kernels_wide.hip
 
 // backward chain of dctr_mlp_bwd (mlp_bwd_kernels.hip): dz_in [B, units_fwd[L-1]] -> dZ of every earlier layer (-> dz_out[l], dense
 // [B, units_fwd[l]]) and, with dx != NULL, the gradient of the DNN input; Wt[l] = W_l^T ([units_fwd[l], K_l] row-major, 16-B aligned)

@@ -226,6 +226,20 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_CHAIN;
         return rc;
     }
+    if (lda == 0 && ga == nullptr && !cross && a->precision == 0 && (a->n_layers >= 1 || a->has_head)) {
+        // an input row wider than the tile, read from HBM: 16-row workgroups that walk it in K chunks (mlp_kernels_wide.hip)
+        int wmax = 0;
+        for (int l = 0; l < a->n_layers; ++l) wmax = a->units[l] > wmax ? a->units[l] : wmax;
+        int kc = 512;
+        while (kc > 64 && mlp_lds_bytes(16, (((kc > wmax ? kc : wmax) + 63) & ~63) + 4) > LDS_PER_CU) kc >>= 1;
+        const int wl = (((kc > wmax ? kc : wmax) + 63) & ~63) + 4;
+        DCTR_REQUIRE(mlp_lds_bytes(16, wl) <= LDS_PER_CU, DCTR_E_UNSUPPORTED, "mlp_fwd: a layer of %d units does not fit the 160 KiB LDS tile", wmax);
+        p.lda = wl;
+        p.k_split = 0;
+        const int64_t wblocks = dctr_ceil_div(a->batch, (int64_t)16);
+        DCTR_REQUIRE(wblocks <= 0x7fffffffLL, DCTR_E_DIM, "mlp_fwd: batch too large");
+        return launch_wide(p, kc, (unsigned)wblocks, mlp_lds_bytes(16, wl), (hipStream_t)stream);
+    }
     DCTR_REQUIRE(lda > 0, DCTR_E_UNSUPPORTED,
                  "mlp_fwd: layer widths do not fit the 160 KiB LDS tile (or are too small for the gather partial sums)");
     p.lda = lda;

@@ -328,6 +328,8 @@ class EmbeddingStage(object):
                 # (numpy copies on purpose: torch's multi-threaded CPU copy_ leaves its OpenMP workers spinning, which
                 # slowed the per-batch launch loop that follows 7x on the GPU box)
                 staged.dense = pin.to(dev, non_blocking=True).t().contiguous()
+                if staged.n == 1:             # (torch leaves a single row's stride arbitrary: the launches read stride(0))
+                    staged.dense = staged.dense.as_strided((1, nd), (nd, 1))
             else:
                 staged.dense = torch.from_numpy(np.ascontiguousarray(np.concatenate(parts, axis=1))).to(dev)
         for fc in self.varlen_features():

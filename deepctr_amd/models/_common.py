@@ -92,6 +92,7 @@ class FusedForward(object):
     probe = None
     matrix_precision = "fp32"
     _pad = _pad_spec = _bf3 = None
+    _declined = frozenset()     # launch sizes dctr_embed_mlp_fwd declined (_forward_fast)
 
     # ---- hooks --------------------------------------------------------------------------------------------------------------
     def _head_weights(self):
@@ -125,6 +126,7 @@ class FusedForward(object):
         self.tile_rows = 0          # batch rows per workgroup of the DNN kernel (0 = auto; 16 / 32 / 64; 128 / 256: row-chained kernel)
         self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
+        self._declined = set()      # launch sizes the library declined (DCTR_E_UNSUPPORTED): these go through dnn_in
         self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
         self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
@@ -261,16 +263,28 @@ class FusedForward(object):
     def _forward_fast(self, staged, lo, hi, out):
         """Fixed-length features on the fused path: the two argument structs are marshalled once per batch size and only
         the per-batch pointers are patched (ctypes marshalling was ~30 us per 4096-row batch, more than the kernel's
-        share of a pipelined predict)."""
+        share of a pipelined predict).  False: the library declined a launch of this size (DCTR_E_UNSUPPORTED) — the caller takes its
+        route through dnn_in."""
         import ctypes
         from .. import _C
+        B = hi - lo
+        if B in self._declined:
+            return False
         g, m = self._forward_fast_args(staged, lo, hi, out)
-        self._launch_extra(staged, lo, hi, self._extra_logit_buffers(hi - lo))      # (CIN / matrix CrossNet: in front of the fused launch)
+        self._launch_extra(staged, lo, hi, self._extra_logit_buffers(B))      # (CIN / matrix CrossNet: in front of the fused launch)
         sp = self.stage_plan
-        _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear),
-                                             _C.stream_ptr()), "dctr_embed_mlp_fwd")
+        rc = _C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear), _C.stream_ptr())
+        if rc == _C.E_UNSUPPORTED and m.precision == 0 and self.tile_rows == 0:
+            # the library is the authority on what its fused kernels take (e.g. a DNN input wider than every LDS tile in front of widths
+            # the row-chained kernel is not instantiated for): launches of this size go through dnn_in from now on
+            if len(self._declined) >= 64:
+                self._declined.clear()
+            self._declined.add(B)
+            return False
+        _C.check(rc, "dctr_embed_mlp_fwd")
         if m.precision:
             self._bf3["fresh"] = True
+        return True
 
     def _forward_fast_args(self, staged, lo, hi, out):
         """The two argument structs of the fused launch for rows [lo, hi) -> out.  Marshalling only, apart from the hash pre-pass of a
@@ -315,8 +329,8 @@ class FusedForward(object):
             g.ids_stride_f = ids.stride(0)
         g.ids_is_i64 = int(ids.dtype == torch.int64)
         if staged.dense is not None:
-            g.dense = staged.dense.data_ptr() + lo * staged.dense.stride(0) * 4
-            g.dense_stride = staged.dense.stride(0)
+            g.dense = staged.dense.data_ptr() + lo * ops.row_stride(staged.dense) * 4
+            g.dense_stride = ops.row_stride(staged.dense)
         g.dense_lin_w = None if sp.dense_lin_w is None else sp.dense_lin_w.data_ptr()
         m.y = out.data_ptr()
         m.tile_rows = int(self.tile_rows)
@@ -387,6 +401,8 @@ class FusedForward(object):
         """predict(): rows are independent and the one-launch path owns no per-batch buffer, so ``batch_size`` (a memory
         knob of the reference's graph executor) need not bound a launch: spans of up to 2^20 rows go out as ONE launch —
         with >= 64 rows per CU the library then runs its persistent kernels (row-chained: chain_device.h; else streaming)."""
+        if self._declined:                        # (the route through dnn_in owns a [rows, in_dim] buffer: the base class's spans)
+            return super(FusedForward, self)._rows_per_launch(staged, batch_size)
         if self._fast_path(staged) and self.span_batches:
             return max(int(batch_size or staged.n), 1 << 20)
         sp = self.stage_plan

@@ -155,11 +155,12 @@ class _DCN(FusedForward, FeatureModel):
         self._run_cross(None, B, d, None, head_w=self.dense.w('kernel').reshape(-1)[:d], logit=bufs[0], gather=self._fast_g)
 
     def _forward(self, staged, lo, hi, out):
-        if self._fast_path(staged):
-            return self._forward_fast(staged, lo, hi, out)
+        if self._fast_path(staged) and self._forward_fast(staged, lo, hi, out):
+            return
         if self._matrix_gather_ok(staged, hi - lo):
             try:
-                return self._forward_fast(staged, lo, hi, out)
+                if self._forward_fast(staged, lo, hi, out):
+                    return
             except _GatherUnsupported:              # the library is the authority on what its gather form takes: the gate above mirrors
                 self._matrix_failed = True          # it, and where the two disagree the model falls back for good (as DIN's _fold_failed)
         ws = self.stage_plan.run(staged, lo, hi)

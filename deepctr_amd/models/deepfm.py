@@ -8,7 +8,7 @@ from ..engine import EmbeddingStage
 from ..feature_column import DEFAULT_GROUP_NAME
 from ..layers.base import name_scope
 from ..layers.core import DNN, Dense, PredictionLayer
-from .. import ops
+from .. import _C, ops
 from ._common import FeatureModel, FusedForward
 
 
@@ -32,24 +32,29 @@ class _DeepFM(FusedForward, FeatureModel):
 
     def _forward(self, staged, lo, hi, out):
         sp = self.stage_plan
-        if self._fast_path(staged):
-            return self._forward_fast(staged, lo, hi, out)
+        if self._fast_path(staged) and self._forward_fast(staged, lo, hi, out):
+            return
         if self.matrix_precision != "fp32":
             raise ValueError("matrix_precision %r (bf16x3 is exploratory) exists on the row-chained one-launch path only: fixed-length "
                              "features, fused=True" % (self.matrix_precision,))
-        if sp.fusable and self.fused:
+        if sp.fusable and self.fused and (hi - lo) not in self._declined:
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
             ws = sp.run_pools(staged, lo, hi, light=True)
             sp.run_lin_only(staged, lo, hi, ws)
             hashed = sp.prehash(staged, lo, hi, ws) if (self._prehash(hi - lo) or (staged.hashed is not None and sp.any_hash)) else None
             g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, prehashed=hashed)
             ks, bs, hw, bn = self._dnn_operands(hi - lo)
-            ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
-                    head_w=hw, add=[ws["lin2"]] if "lin2" in ws else [],
-                    global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
-                    out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
-                    tile_rows=self.tile_rows, probe=self.probe)
-            return
+            try:
+                ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn,
+                        head_w=hw, add=[ws["lin2"]] if "lin2" in ws else [],
+                        global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim,
+                        out=out, gather=g, add_fm_logit=bool(sp.fm_group_names), add_lin_logit=sp.has_linear, batch=hi - lo,
+                        tile_rows=self.tile_rows, probe=self.probe)
+                return
+            except _C.DctrError as e:               # (a shape no fused kernel takes: through dnn_in, as _forward_fast)
+                if e.rc != _C.E_UNSUPPORTED or self.tile_rows != 0:
+                    raise
+                self._declined.add(hi - lo)
         ws = self.stage_plan.run(staged, lo, hi, records=self.gather_records and self._records_capable)
         add = self._logits_to_add(ws)
         if self.stage_plan.fm_group_names:

@@ -98,8 +98,8 @@ class _xDeepFM(FusedForward, FeatureModel):
         self._cin_ws_ready = False  # the filters may have moved since the last call
 
     def _forward(self, staged, lo, hi, out):
-        if self._fast_path(staged):
-            return self._forward_fast(staged, lo, hi, out)
+        if self._fast_path(staged) and self._forward_fast(staged, lo, hi, out):
+            return
         ws = self.stage_plan.run(staged, lo, hi)
         B = hi - lo
         add = self._logits_to_add(ws)

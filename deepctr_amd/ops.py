@@ -278,6 +278,12 @@ def make_field_descriptors(fields, device):
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
+def row_stride(t):
+    """Elements between consecutive rows of a 2-D tensor with unit column stride.  torch leaves the stride of a size-1 dimension
+    arbitrary (a [1, n] result of ``.t().contiguous()`` reports stride(0) = 1): a single row gets its width."""
+    return int(t.stride(0)) if t.shape[0] != 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
 def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
                      dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0,
                      fm_logit=None, lin_logit=None, status=None, split=(0, 0), uniform_dim=0, any_identity=False, any_pitch=False):
@@ -295,7 +301,7 @@ def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max
                            ids_stride_f=ids_stride_f, ids_stride_b=ids_stride_b, ids_is_i64=is64, n_fields=n_fields,
                            max_dim=max_dim, all_dim4=int(bool(all_dim4)), any_hash=int(bool(any_hash)), n_dense=n_dense,
                            dense=None if dense is None else dense.data_ptr(),
-                           dense_stride=0 if dense is None else dense.stride(0),
+                           dense_stride=0 if dense is None else row_stride(dense),
                            dense_lin_w=None if dense_lin_w is None else dense_lin_w.data_ptr(),
                            dense_out_offset=dense_out_offset,
                            dense_copy_cols=n_dense if dense_copy_cols is None else dense_copy_cols, batch=batch,

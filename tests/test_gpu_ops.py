@@ -337,6 +337,25 @@ def test_cin(device):
     assert_close(y.cpu().numpy(), y0.cpu().numpy(), rtol=2e-5, atol=2e-5, what="cin folded vs plain layer 0")
 
 
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 28, 32, 36, 48, 64])
+def test_cin_every_embedding_width(device, D):
+    """CIN over embeddings of any width (interaction.py:277-325 has no constraint on D): the kernel sums the maps over d in registers only
+    where a sample's rows are 4, 8 or whole 16-row MFMA tiles — D = 12, 20, 24 ... straddle them and sum from LDS.  Float64 oracle,
+    split_half on / off, a ragged batch."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(100 + D)
+    B, F0 = 203, 7
+    for split, ls in ((True, (16, 8)), (False, (10, 6, 4))):
+        x = (rng.standard_normal((B, F0, D)) * 0.5).astype(np.float32)
+        fk = [F0] + [(h // 2 if split else h) for h in ls[:-1]]
+        fs = [(rng.standard_normal((1, F0 * fk[k], ls[k])) / np.sqrt(F0 * fk[k])).astype(np.float32) for k in range(len(ls))]
+        bs = [rng.standard_normal(ls[k]).astype(np.float32) * 0.1 for k in range(len(ls))]
+        ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], split, "relu")
+        mag = R.cin(np.abs(x).astype(np.float64), [np.abs(f).astype(np.float64) for f in fs], [np.abs(b).astype(np.float64) for b in bs], split, "relu")
+        y = ops.cin(dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, "relu")
+        assert_close_terms(y.cpu().numpy(), ref, mag, what="cin D=%d split=%s" % (D, split))
+
+
 def test_afm_inner_product(device):
     from deepctr_amd import ops
     g = load_golden("interaction")
@@ -519,6 +538,36 @@ def test_mlp_c2_with_head(device, B):
     ref = R.dnn(x2.astype(np.float64), [k.astype(np.float64) for k in ks2], [b.astype(np.float64) for b in bs2], "tanh")
     y = ops.mlp(dev(x2, device), [dev(k, device) for k in ks2], [dev(b, device) for b in bs2], "tanh")
     assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="mlp odd widths")
+
+
+@pytest.mark.parametrize("in_dim,units,act", [(1539, (200, 80), "sigmoid"), (2112, (400, 400), "relu"), (5003, (17, 9, 5), "tanh"),
+                                              (1600, (1100, 64), "relu"), (3001, (), "relu"), (2500, (256, 128, 64), "relu")])
+def test_mlp_input_wider_than_the_lds_tile(device, in_dim, units, act):
+    """DNN.call takes any input width (deepctr/layers/core.py:189-208): rows wider than mlp_kernel's LDS tile are walked in K chunks
+    (csrc/mlp_kernels_wide.hip), with and without the head, at ragged batch sizes; float64 oracle."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(in_dim)
+    dims = [in_dim] + list(units)
+    for B in (1, 37, 1000):
+        stride = (in_dim + 3) // 4 * 4 + 4
+        x = np.full((B, stride), np.nan, np.float32)           # stride padding must never be read
+        x[:, :in_dim] = rng.standard_normal((B, in_dim)).astype(np.float32)
+        ks = [(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / (dims[i] + dims[i + 1]))).astype(np.float32) for i in range(len(units))]
+        bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(units))]
+        hw = rng.standard_normal(dims[-1]).astype(np.float32) * (0.2 if units else 0.02)
+        a0 = rng.standard_normal(B).astype(np.float32)
+        gb = np.array([0.3], np.float32)
+        h = R.dnn(x[:, :in_dim].astype(np.float64), [k.astype(np.float64) for k in ks], [b.astype(np.float64) for b in bs], act) if units \
+            else x[:, :in_dim].astype(np.float64)
+        logit = h @ hw.astype(np.float64) + a0 + gb[0]
+        mag = np.abs(h) @ np.abs(hw.astype(np.float64)) + np.abs(a0) + 0.3
+        y = ops.mlp(dev(x, device), [dev(k, device) for k in ks], [dev(b, device) for b in bs], act, head_w=dev(hw, device),
+                    add=(dev(a0, device),), global_bias=dev(gb, device), sigmoid_out=False, in_dim=in_dim)
+        assert_close_terms(y.cpu().numpy(), logit, mag, what="wide mlp head logits B=%d" % B)
+        if units:
+            y = ops.mlp(dev(x, device), [dev(k, device) for k in ks], [dev(b, device) for b in bs], act, in_dim=in_dim)
+            # (a layer-0 output is a sum of up to 5,003 products of O(1) magnitude: a few fp32 ulp of that sum where ReLU / tanh leaves ~0)
+            assert_close(y.cpu().numpy(), h, rtol=1e-4, atol=1e-5, what="wide mlp activations B=%d" % B)
 
 
 def _att_weights(g, prefix, n_layers, act, device):
