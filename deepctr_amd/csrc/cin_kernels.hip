@@ -551,7 +551,7 @@ static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g
     DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "cin_fwd: activation %d",
                  a->activation);
     DCTR_REQUIRE(g != nullptr || a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
-    DCTR_REQUIRE(a->dim <= 64, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d > 64 not supported", a->dim);
+    DCTR_REQUIRE(a->dim <= 128, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d > 128 not supported (a sample's rows are one workgroup's MFMA tiles)", a->dim);
     CinParams p{};
     p.x = g != nullptr ? nullptr : a->x;
     if (g != nullptr) {
@@ -627,7 +627,7 @@ static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g
     int rt = 8;
     p.SB = 128 / a->dim;
     if (p.SB < 1) p.SB = 1;
-    if (lds_of(8) > 80 * 1024 || p.SB * a->dim > 128) {
+    if ((lds_of(8) > 80 * 1024 || p.SB * a->dim > 128) && a->dim <= 64) {      // (embedding_dim 65 .. 128: one sample = up to eight row tiles)
         rt = 4;
         p.SB = 64 / a->dim;
         if (p.SB < 1) p.SB = 1;

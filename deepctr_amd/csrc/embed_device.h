@@ -104,9 +104,11 @@ __device__ __forceinline__ FieldRegs load_field(cfield_ptr F, int j) {
 //   4. FM / linear accumulation and the concat write.
 // `store(out_offset_plus_chunk, v)` receives the column of the first element inside a DNN-input row and the VEC
 // values: the stand-alone gather writes them to dnn_in in HBM, the fused gather->DNN kernel to its LDS tile.
+// `e0`: first element of the pass (rows wider than LPR * VEC elements are walked in passes of that width; the linear entry counts in pass 0).
 template <int VEC, int LPR, int U, bool HASH, typename Store>
 __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int step, int f_end, int64_t b, bool valid,
-                                             int q, float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc, Store store) {
+                                             int q, float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc, Store store, int e0 = 0) {
+    const int qe = e0 + q * VEC;                      // this lane's first element of a row
     const int last = f_end - 1;
     const int64_t bb = valid ? b : 0;
     RawId raw[U];
@@ -139,7 +141,7 @@ __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const FieldRegs& f = fr[u];
-        const int qq = (q * VEC < f.dim) ? q * VEC : 0;
+        const int qq = (qe < f.dim) ? qe : 0;
         load_vec<VEC>(f.table + row[u] * f.pitch + qq, v[u]);
         const float* lp = f.lin_table != nullptr ? f.lin_table + row[u] * f.lin_pitch : reinterpret_cast<const float*>(p.fields);
         lv[u] = *lp;
@@ -147,8 +149,8 @@ __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const FieldRegs& f = fr[u];
-        const bool act = ok[u] && q * VEC < f.dim;
-        if (ok[u] && q == 0 && f.lin_table != nullptr) acc.lin += lv[u];
+        const bool act = ok[u] && qe < f.dim;
+        if (ok[u] && qe == 0 && f.lin_table != nullptr) acc.lin += lv[u];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) v[u][c] = act ? v[u][c] : 0.f;
         if (f.in_fm) {
@@ -158,7 +160,7 @@ __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int 
                 sq[c] = fmaf(v[u][c], v[u][c], sq[c]);
             }
         }
-        if (f.out_offset >= 0 && valid && (j0 + u * step) <= last && q * VEC < f.dim) store(f.out_offset + q * VEC, v[u]);
+        if (f.out_offset >= 0 && valid && (j0 + u * step) <= last && qe < f.dim) store(f.out_offset + qe, v[u]);
     }
 }
 
@@ -166,15 +168,15 @@ __device__ __forceinline__ void gather_chunk(const GatherParams& p, int j0, int 
 template <int VEC, int LPR, bool HASH, typename Store>
 __device__ __forceinline__ void gather_fields(const GatherParams& p, int f_begin, int f_step, int f_end, int64_t b,
                                               bool valid, int q, float (&sum)[VEC], float (&sq)[VEC], GatherAcc& acc,
-                                              Store store) {
+                                              Store store, int e0 = 0) {
     int j = f_begin;
     for (; j + 7 * f_step < f_end; j += 8 * f_step)
-        gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
+        gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store, e0);
     if (j < f_end) {
         const int left = (f_end - j + f_step - 1) / f_step;   // 1..7, wave-uniform
-        if (left > 4) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
-        else if (left > 2) gather_chunk<VEC, LPR, 4, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
-        else gather_chunk<VEC, LPR, 2, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store);
+        if (left > 4) gather_chunk<VEC, LPR, 8, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store, e0);
+        else if (left > 2) gather_chunk<VEC, LPR, 4, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store, e0);
+        else gather_chunk<VEC, LPR, 2, HASH>(p, j, f_step, f_end, b, valid, q, sum, sq, acc, store, e0);
     }
 }
 

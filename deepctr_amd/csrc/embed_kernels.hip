@@ -61,6 +61,20 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
         if (out_row != nullptr) store_vec<VEC>(out_row + col, v);
     };
     gather_fields<VEC, LPR, HASH>(p, f_begin, f_step, p.n_fields, b, valid, q, sum, sq, acc, store);
+    // embedding_dim > LPR * VEC (e.g. "auto" = 102 for a 1e5 vocabulary, feature_column.py:44-45): further passes over the fields for
+    // elements [e0, e0 + LPR * VEC) of every row — FM is a sum over d, so a pass's share is closed before the next starts (host: no
+    // FSPLIT then, a wave sees all the fields of its samples)
+    float fm_more = 0.f;
+    if constexpr (!FSPLIT) {
+        for (int e0 = LPR * VEC; e0 < p.max_dim; e0 += LPR * VEC) {
+            float s2[VEC], q2[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) s2[c] = q2[c] = 0.f;
+            gather_fields<VEC, LPR, HASH>(p, f_begin, f_step, p.n_fields, b, valid, q, s2, q2, acc, store, e0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) fm_more += s2[c] * s2[c] - q2[c];
+        }
+    }
     float lin = acc.lin;
 
     // dense features: passthrough into the concat + dense . Linear.kernel
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(GatherParams p) {
         float fm = 0.f;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) fm += sum[c] * sum[c] - sq[c];
-        fm = 0.5f * reduce_lpr<LPR>(fm);
+        fm = 0.5f * reduce_lpr<LPR>(fm + fm_more);
         lin = reduce_lpr<LPR>(lin);
         if (valid && q == 0) {
             if (p.fm_logit != nullptr) p.fm_logit[b] = fm;
@@ -175,8 +189,11 @@ __global__ __launch_bounds__(256) void pool_kernel(dctr_pool_args_t a) {
         }
     }
 
-    float acc[VEC];
     const bool is_max = a.combiner == DCTR_POOL_MAX;
+    // rows wider than LPR * VEC elements (host: LPR = 64 then) are pooled in passes of that width
+    for (int e0 = 0; e0 < a.dim; e0 += LPR * VEC) {
+    const int qe = e0 + q * VEC;
+    float acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = is_max ? -INFINITY : 0.f;
     float lacc = is_max ? -INFINITY : 0.f;
@@ -213,8 +230,8 @@ __global__ __launch_bounds__(256) void pool_kernel(dctr_pool_args_t a) {
 #pragma unroll
             for (int c = 0; c < VEC; ++c) v[u][c] = 0.f;
             lv[u] = 0.f;
-            if (ok[u] && q * VEC < a.dim) load_vec<VEC>(a.table + row[u] * a.dim + q * VEC, v[u]);
-            if (ok[u] && q == 0 && a.lin_table != nullptr) lv[u] = a.lin_table[row[u]];
+            if (ok[u] && qe < a.dim) load_vec<VEC>(a.table + row[u] * a.dim + qe, v[u]);
+            if (ok[u] && qe == 0 && a.lin_table != nullptr) lv[u] = a.lin_table[row[u]];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -241,8 +258,9 @@ __global__ __launch_bounds__(256) void pool_kernel(dctr_pool_args_t a) {
         lacc = lacc / denom;
     }
     if (valid) {
-        if (q * VEC < a.dim) store_vec<VEC>(a.out + b * a.out_stride + q * VEC, acc);
-        if (q == 0 && a.lin_out != nullptr) a.lin_out[b] = lacc;
+        if (qe < a.dim) store_vec<VEC>(a.out + b * a.out_stride + qe, acc);
+        if (qe == 0 && a.lin_out != nullptr) a.lin_out[b] = lacc;
+    }
     }
     if (a.status != nullptr && __any(oor) && lane == 0) atomicOr(a.status, (int)DCTR_STATUS_INDEX_OOR);
 }
@@ -355,9 +373,9 @@ __global__ __launch_bounds__(256) void lookup_kernel(dctr_lookup_args_t a) {
         float v[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) v[c] = 0.f;
-        if (q * VEC < a.dim) {
-            if (ok) load_vec<VEC>(a.table + row * a.dim + q * VEC, v);
-            store_vec<VEC>(a.out + i * a.out_stride + q * VEC, v);
+        for (int qe = q * VEC; qe < a.dim; qe += LPR * VEC) {          // (rows wider than LPR * VEC elements: several steps)
+            if (ok) load_vec<VEC>(a.table + row * a.dim + qe, v);
+            store_vec<VEC>(a.out + i * a.out_stride + qe, v);
         }
         if (q == 0 && a.mask != nullptr) a.mask[i] = row != 0 ? 1 : 0;
     }
@@ -389,9 +407,9 @@ __global__ __launch_bounds__(256) void lookup_multi_kernel(LookupMulti m) {
         float v[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) v[c] = 0.f;
-        if (q * VEC < a.dim) {
-            if (ok) load_vec<VEC>(a.table + row * a.dim + q * VEC, v);
-            store_vec<VEC>(a.out + i * a.out_stride + q * VEC, v);
+        for (int qe = q * VEC; qe < a.dim; qe += LPR * VEC) {          // (rows wider than LPR * VEC elements: several steps)
+            if (ok) load_vec<VEC>(a.table + row * a.dim + qe, v);
+            store_vec<VEC>(a.out + i * a.out_stride + qe, v);
         }
         if (q == 0 && a.mask != nullptr) {
             bool nz = row != 0;
@@ -447,7 +465,7 @@ __global__ __launch_bounds__(256) void seq_weight_kernel(const float* __restrict
 // lanes per row for (max_dim, VEC): smallest power of two with LPR * VEC >= max_dim
 int lanes_per_row(int max_dim, int vec) {
     int l = 1;
-    while (l * vec < max_dim) l <<= 1;
+    while (l * vec < max_dim && l < 64) l <<= 1;
     return l;
 }
 
@@ -478,15 +496,14 @@ extern "C" int dctr_embed_gather_fm(const dctr_gather_fm_args_t* a, void* stream
                  "embed_gather_fm: dense_copy_cols outside [0, n_dense]");
     const int vec = (a->all_dim4 && a->n_fields > 0) ? 4 : 1;
     const int max_dim = a->max_dim > 0 ? a->max_dim : 1;
-    DCTR_REQUIRE(max_dim <= 64 * vec, DCTR_E_UNSUPPORTED,
-                 "embed_gather_fm: embedding_dim %d > %d not supported by the lane layout", max_dim, 64 * vec);
+    DCTR_REQUIRE(max_dim <= 65536, DCTR_E_UNSUPPORTED, "embed_gather_fm: embedding_dim %d", max_dim);
     if (a->dnn_in != nullptr && vec == 4)
         DCTR_REQUIRE(dctr_aligned16(a->dnn_in) && a->out_stride % 4 == 0, DCTR_E_ALIGN,
                      "embed_gather_fm: dnn_in must be 16-B aligned with out_stride %% 4 == 0 when all_dim4");
-    const int lpr = lanes_per_row(max_dim, vec);
+    const int lpr = lanes_per_row(max_dim, vec);             // (<= 64: wider rows take several passes)
     const int spw = 64 / lpr;
     const int64_t waves_plain = dctr_ceil_div(a->batch, spw);
-    const bool fsplit = waves_plain < 256 * 8 && a->n_fields >= 8;
+    const bool fsplit = waves_plain < 256 * 8 && a->n_fields >= 8 && max_dim <= 64 * vec;
     GatherParams p = *a;
     if (p.n_fields == 0) {  // dense-only call: keep the dummy-address reads valid
         p.fields = reinterpret_cast<const dctr_field_t*>(a->dense);
@@ -524,7 +541,7 @@ extern "C" int dctr_embed_pool(const dctr_pool_args_t* a, void* stream) {
     DCTR_REQUIRE(a->hash_mode == 0 || a->hash_mode == 2, DCTR_E_ENUM, "embed_pool: hash_mode %d", a->hash_mode);
     const bool v4 = a->dim % 4 == 0 && dctr_aligned16(a->table) && dctr_aligned16(a->out) && a->out_stride % 4 == 0;
     const int vec = v4 ? 4 : 1;
-    DCTR_REQUIRE(a->dim <= 64 * vec, DCTR_E_UNSUPPORTED, "embed_pool: embedding_dim %d too large", a->dim);
+    DCTR_REQUIRE(a->dim <= 65536, DCTR_E_UNSUPPORTED, "embed_pool: embedding_dim %d too large", a->dim);
     const int lpr = lanes_per_row(a->dim, vec);
     const int64_t blocks = dctr_ceil_div(dctr_ceil_div(a->batch, 64 / lpr), 4);
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool: batch too large");
@@ -558,7 +575,7 @@ extern "C" int dctr_embed_lookup(const dctr_lookup_args_t* a, void* stream) {
     DCTR_REQUIRE(a->out_stride >= a->dim, DCTR_E_DIM, "embed_lookup: out_stride < dim");
     const bool v4 = a->dim % 4 == 0 && dctr_aligned16(a->table) && dctr_aligned16(a->out) && a->out_stride % 4 == 0;
     const int vec = v4 ? 4 : 1;
-    DCTR_REQUIRE(a->dim <= 64 * vec, DCTR_E_UNSUPPORTED, "embed_lookup: embedding_dim %d too large", a->dim);
+    DCTR_REQUIRE(a->dim <= 65536, DCTR_E_UNSUPPORTED, "embed_lookup: embedding_dim %d too large", a->dim);
     const int lpr = lanes_per_row(a->dim, vec);
     int64_t blocks = dctr_ceil_div(a->n, 256 / lpr);
     if (blocks > 8192) blocks = 8192;
@@ -611,7 +628,7 @@ extern "C" int dctr_embed_lookup_multi(const dctr_lookup_args_t* args, int32_t n
     }
     if (max_n == 0) return DCTR_OK;
     const int vec = v4 ? 4 : 1;
-    DCTR_REQUIRE(max_dim <= 64 * vec, DCTR_E_UNSUPPORTED, "embed_lookup_multi: embedding_dim %d too large", max_dim);
+    DCTR_REQUIRE(max_dim <= 65536, DCTR_E_UNSUPPORTED, "embed_lookup_multi: embedding_dim %d too large", max_dim);
     const int lpr = lanes_per_row(max_dim, vec);
     int64_t blocks = dctr_ceil_div(max_n, 256 / lpr);
     if (blocks > 4096) blocks = 4096;

@@ -1109,6 +1109,32 @@ extern "C" int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* a, cons
     return crossnet_launch(a, stream, g);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void cross_matrix_step_kernel(const float* __restrict__ x0, int64_t x0_stride, const float* xl, int64_t xl_stride,
+                                                                const float* __restrict__ u, const float* __restrict__ bias, int64_t batch, int d,
+                                                                float* xn, int64_t xn_stride) {
+    const int64_t total = batch * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / d;
+        const int c = (int)(i - b * d);
+        xn[b * xn_stride + c] = x0[b * x0_stride + c] * (u[i] + bias[c]) + xl[b * xl_stride + c];
+    }
+}
+}  // namespace
+
+extern "C" int dctr_crossnet_matrix_step(const float* x0, int64_t x0_stride, const float* xl, int64_t xl_stride, const float* u, const float* bias,
+                                         int64_t batch, int32_t dim, float* x_next, int64_t x_next_stride, void* stream) {
+    DCTR_REQUIRE(batch >= 0 && dim >= 1, DCTR_E_DIM, "crossnet_matrix_step: bad sizes");
+    if (batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(x0 && xl && u && bias && x_next, DCTR_E_NULL, "crossnet_matrix_step: null pointer");
+    DCTR_REQUIRE(x0_stride >= dim && xl_stride >= dim && x_next_stride >= dim, DCTR_E_DIM, "crossnet_matrix_step: stride < dim");
+    int64_t blocks = dctr_ceil_div(batch * dim, (int64_t)256);
+    if (blocks > 8192) blocks = 8192;
+    DCTR_LAUNCH(cross_matrix_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x0, x0_stride, xl, xl_stride, u, bias, batch,
+                (int)dim, x_next, x_next_stride);
+    return dctr_launch_status("dctr_crossnet_matrix_step");
+}
+
 extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int32_t fields, int32_t dim,
                             const float* att_w, const float* att_b, const float* proj_h, const float* proj_p,
                             int32_t att_factor, float* y, void* stream) {

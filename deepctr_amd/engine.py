@@ -895,7 +895,17 @@ class Model(object):
         self.set_weights_by_name({n: v for (n, _), v in zip(ws, values)})
 
     def get_weights_by_name(self):
-        return OrderedDict((n, t.detach().cpu().numpy()) for n, t in self.named_weights())
+        """{"<keras layer name>/<weight name>": array}, in the reference's variable names: the moving statistics of a Dice layer are
+        those of the BatchNormalization keras builds inside it (``batch_normalization_1/moving_mean``; layers/activation.py:51-53) —
+        the keys set_weights_by_name takes."""
+        keras = {v: k for k, v in _bn_aliases(self.layers).items()}
+        out = OrderedDict()
+        for n, t in self.named_weights():
+            lname, wname = n.rsplit("/", 1)
+            if wname in ("moving_mean", "moving_variance") and lname in keras:
+                n = "%s/%s" % (keras[lname], wname)
+            out[n] = t.detach().cpu().numpy()
+        return out
 
     def set_weights_by_name(self, mapping, strict=True):
         """Load weights keyed "<keras layer name>/<weight name>" (the reference's layer names, e.g.

@@ -214,7 +214,42 @@ class _DCN(FusedForward, FeatureModel):
                 raise _GatherUnsupported()
             _C.check(rc, "dctr_crossnet_gather_head_fwd")
             return
-        _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
+        rc = _C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr())
+        if rc == _C.E_UNSUPPORTED and mode == _C.CROSS_MATRIX and dnn_in is not None:
+            return self._run_cross_wide(dnn_in, B, d, stack, head_w, logit)
+        _C.check(rc, "dctr_crossnet_head_fwd")
+
+    def _run_cross_wide(self, dnn_in, B, d, stack, head_w, logit):
+        """The matrix CrossNet of an input wider than the on-chip kernels hold (their x_0 / x_l / x_{l+1} tiles live in LDS: ~800 columns):
+        layer by layer, u = x_l W_l^T on the library's MFMA GEMM (dctr_sgemm), the elementwise half by dctr_crossnet_matrix_step
+        (interaction.py:416-420); x_L goes to ``stack`` and / or its share of Dense(1) to ``logit``."""
+        import ctypes
+        from .. import _C
+        ks, bs = self._cross_packed                       # [L, d, d] (W_l: [out n, in k]), [L, d]
+        L = self.cross.layer_num
+        bufs = self._wide_bufs.get(B) if getattr(self, "_wide_bufs", None) else None
+        if bufs is None:
+            self._wide_bufs = {}                          # (one batch size at a time: [B, d] x 3)
+            bufs = self._wide_bufs[B] = [torch.empty(B, d, dtype=torch.float32, device=self.device) for _ in range(3)]
+        u, ping, pong = bufs
+        st = _C.stream_ptr()
+        xl, xl_stride = dnn_in, ops.row_stride(dnn_in)
+        for l in range(L):
+            W = ks[l]
+            # column-major BLAS view: u^T (d x B) = W^T-view (k x n)^T . x_l^T (k x B)
+            _C.check(_C.lib().dctr_sgemm(1, 0, d, B, d, W.data_ptr(), d, 0, xl.data_ptr(), int(xl_stride), 0, 0.0, u.data_ptr(), d, 0, 1, st),
+                     "dctr_sgemm")
+            last = l == L - 1
+            if last and stack is not None:
+                nxt, nxt_stride = stack, ops.row_stride(stack)
+            else:
+                nxt = ping if xl is not ping else pong
+                nxt_stride = d
+            _C.check(_C.lib().dctr_crossnet_matrix_step(dnn_in.data_ptr(), ops.row_stride(dnn_in), xl.data_ptr(), int(xl_stride), u.data_ptr(),
+                                                        bs[l].data_ptr(), B, d, nxt.data_ptr(), int(nxt_stride), st), "dctr_crossnet_matrix_step")
+            xl, xl_stride = nxt, nxt_stride
+        if logit is not None:
+            ops.mlp(xl, [], [], "linear", head_w=head_w, in_dim=d, out=logit)
 
 
 def DCN(linear_feature_columns, dnn_feature_columns, cross_num=2, cross_parameterization='vector',

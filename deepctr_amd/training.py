@@ -341,7 +341,35 @@ def model_logits(model, staged, lo, hi, training=False):
     return logit + model.prediction.w("global_bias")
 
 
-_OPTS = {"adam": lambda p: torch.optim.Adam(p, lr=1e-3, eps=1e-7), "adagrad": lambda p: torch.optim.Adagrad(p, lr=1e-3, eps=1e-7,
+class KerasAdam(torch.optim.Optimizer):
+    """Adam as tf.keras applies it (optimizer_v2/adam.py, _resource_apply_dense; also what the HIP step's optimizer launch computes):
+        lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);   m = beta1 m + (1 - beta1) g;   v = beta2 v + (1 - beta2) g^2;
+        w -= lr_t m / (sqrt(v) + epsilon)
+    — epsilon sits beside sqrt(v), NOT beside sqrt(v / (1 - beta2^t)) as in torch.optim.Adam: for gradients around 1e-6 (an l2 penalty's
+    2 l w on a row no sample touched) the two move a weight by 0.4 lr and 0.95 lr in the first step."""
+
+    def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+        super(KerasAdam, self).__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["beta1"], group["beta2"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["t"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["t"] += 1
+                g = p.grad
+                st["m"].mul_(b1).add_(g, alpha=1.0 - b1)
+                st["v"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                lr_t = group["lr"] * (1.0 - b2 ** st["t"]) ** 0.5 / (1.0 - b1 ** st["t"])
+                p.addcdiv_(st["m"], st["v"].sqrt().add_(group["eps"]), value=-lr_t)
+
+
+_OPTS = {"adam": lambda p: KerasAdam(p, lr=1e-3, eps=1e-7), "adagrad": lambda p: torch.optim.Adagrad(p, lr=1e-3, eps=1e-7,
                                                                                                          initial_accumulator_value=0.1),
          "sgd": lambda p: torch.optim.SGD(p, lr=1e-2), "rmsprop": lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.9, eps=1e-7)}
 
@@ -527,7 +555,9 @@ class _DataParallel(object):
 def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, steps=None, initial_epoch=0, dp=None):
     """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
     moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation.
-    The reported loss is the data loss (the l2 penalties enter the gradients, not this number)."""
+    The reported loss is what tf.keras reports: the data loss plus the l2 penalties l * sum(w^2) of the constructor's regularisers.  The
+    penalties (they also enter the gradients, as 2 l w inside the optimizer launch) are taken at the epoch's two ends and averaged —
+    keras averages them over the epoch's steps; the two differ in the second order of an epoch's weight change."""
     from .training_hip import HipTrainer
     tr = getattr(model, "_hip_trainer", None)
     if tr is None or tr.kind != model._compiled["optimizer"].lower():
@@ -538,6 +568,12 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
     perm_of = np.random.permutation if dp is None else dp.permutation
     cursor = _BatchCursor(n_tr, bs, steps, (lambda: permute_staged_(
         staged, yt, torch.from_numpy(perm_of(n_tr)).to(yt.device), wt)) if shuffle else None)
+    frozen = frozen_weights(model)
+    regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
+
+    def penalty():
+        return float(sum(l2 * float((t.double() * t.double()).sum().item()) for t, l2 in regs)) if regs else 0.0
+    pen0 = penalty()
     for ep in range(initial_epoch, epochs):
         # the epoch's loss: dctr_bce_grad adds every batch's summed loss into that batch's element of ONE device vector (summed in
         # float64 at the end of the epoch; step() refreshes the weight-derived buffers itself) — no per-step zero / divide / add launches
@@ -558,6 +594,9 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
         model._check_status()
         total = float(tot.double().sum().item())
         mean = total / max(seen, 1) if dp is None else dp.loss_mean(total, seen)
+        pen1 = penalty()
+        mean += 0.5 * (pen0 + pen1)
+        pen0 = pen1
         if epoch_end(ep, mean):
             break
     return epoch_end.finish()
@@ -723,19 +762,28 @@ def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None,
                 model._begin()
                 logit = model_logits(model, staged, int(lo), int(hi), training=True)
                 if loss_name in ("binary_crossentropy", "logloss") and model.task == "binary":
+                    # gradient (p - y) / B from the logit; the VALUE as keras' backend.binary_crossentropy reports it on probabilities
+                    # (clipped to [1e-7, 1 - 1e-7]: a saturated row costs 16.1, not |logit|) — the pair the HIP step's dctr_bce_grad forms
                     loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, yt[lo:hi], reduction="none")
+                    with torch.no_grad():
+                        pc = torch.sigmoid(logit).clamp(1e-7, 1.0 - 1e-7)
+                        shown = -(yt[lo:hi] * torch.log(pc) + (1.0 - yt[lo:hi]) * torch.log(1.0 - pc))
                 else:
                     pred = torch.sigmoid(logit) if model.task == "binary" else logit
                     loss = torch.nn.functional.mse_loss(pred, yt[lo:hi], reduction="none")
+                    shown = loss.detach()
                 loss = (loss if wt is None else loss * wt[lo:hi]).mean()      # Keras: sum_b w_b l_b / B
+                shown = (shown if wt is None else shown * wt[lo:hi]).mean()
                 for t, l2 in regs:                                  # keras adds the regularisation losses to the loss
-                    loss = loss + l2 * (t * t).sum()
+                    pen = l2 * (t * t).sum()
+                    loss = loss + pen
+                    shown = shown + pen.detach()
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
                 if dp is not None:
                     dp.exchange_torch(params, hi - lo, g_hi - g_lo)
                 opt.step()
-                tot += float(loss.item()) * (hi - lo)
+                tot += float(shown.item()) * (hi - lo)
                 cnt += hi - lo
             for t in params:
                 t.requires_grad_(False)

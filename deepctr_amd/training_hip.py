@@ -46,8 +46,11 @@ def supported(model):
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
     if sp.lin_only or not sp.all_dim4 or sp.max_dim > 64:
         return False
-    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector" and sp.in_dim > 2048:
-        return False                        # (dctr_crossnet_bwd's vector form holds a row's gradient in registers: <= 2048 columns)
+    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector":
+        # dctr_crossnet_bwd's vector form holds a row's gradient in registers (<= 2048 columns) and every layer's x_l in LDS
+        n_l = int(getattr(model.cross, "layer_num", 0))
+        if sp.in_dim > 2048 or 16 * (3 * n_l * sp.in_dim + n_l) > 160 * 1024:
+            return False
     if len(sp.fm_group_names) > 1:          # further FM groups (DeepFM / AFM fm_group): their logits ride on the head's four `add` slots
         n_add = int(bool(sp.has_linear)) + len(sp.fm_group_names)
         if kind not in ("_DeepFM", "_AFM") or n_add > 4:

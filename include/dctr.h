@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 10
+#define DCTR_ABI_VERSION 11
 
 enum {
     DCTR_OK = 0,
@@ -286,6 +286,12 @@ int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* args, void* stream);
  * dim <= 512 (the 64-row kernel whose layer outputs wait in registers); anything else returns DCTR_E_UNSUPPORTED — use
  * dctr_embed_gather_fm + dctr_crossnet_head_fwd.  Inference only (save_u / save_x must be NULL). */
 int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* args, const dctr_gather_fm_args_t* gather, void* stream);
+/* ABI 11 — the elementwise half of ONE matrix-form layer (interaction.py:416-420) for inputs wider than the kernels above hold on chip
+ * (their [16, dim] tiles of x_0 / x_l / x_{l+1} live in LDS: dim <= ~800; wider calls return DCTR_E_UNSUPPORTED):
+ *     x_next[b, c] = x0[b, c] * (u[b, c] + bias[c]) + xl[b, c],     u = x_l W_l^T from dctr_sgemm ([B, dim], contiguous).
+ * x_next may alias xl (not x0 unless xl == x0 is no longer needed). */
+int dctr_crossnet_matrix_step(const float* x0, int64_t x0_stride, const float* xl, int64_t xl_stride, const float* u, const float* bias,
+                              int64_t batch, int32_t dim, float* x_next, int64_t x_next_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10 CIN.call — deepctr/layers/interaction.py:277-325   (outer product + 1x1 conv on f32 MFMA)

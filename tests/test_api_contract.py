@@ -109,6 +109,10 @@ def test_din_names_and_validation():
     assert n["dnn/kernel0"].shape == (48, 80) and n["dnn/kernel1"].shape == (80, 40) and n["dice/dice_alpha"].shape == (80,)
     assert n["dice_1/moving_variance"].shape == (40,) and n["local_activation_unit/kernel"].shape == (40, 1)
     assert n["dnn_1/kernel0"].shape == (10 + 4 + 8 + 4 + 12 + 1, 4)
+    # get_weights_by_name speaks the reference's variable names: Dice's statistics live in the BatchNormalization keras builds inside it
+    by_name = m.get_weights_by_name()
+    assert by_name["batch_normalization_1/moving_variance"].shape == (40,) and "dice_1/moving_variance" not in by_name
+    m.set_weights_by_name(by_name)
     assert m.input_names == ['user', 'gender', 'item_id', 'cate_id', 'pay_score', 'hist_item_id', 'seq_length', 'hist_cate_id']
     assert m.get_layer("sparse_emb_item_id").mask_zero is True
     with pytest.raises(ValueError):

@@ -21,23 +21,30 @@ DNN_SHAPES = [(8,), (32, 16), (256, 128, 64), (200, 80), (128, 128), (64,), (400
 ROW_COUNTS = [1, 7, 300, 1000, 4099, 20011, 70001, 2, 65, 16384, 16383, 8192]
 
 
-def random_config(seed):
+def random_config(seed, rows=None):
     """-> (meta dict in the golden fixtures' format, feed, n rows)."""
     rng = np.random.RandomState(1000 + seed)
     model = ALL_MODELS[seed % len(ALL_MODELS)]
     fm = model in FM_MODELS
-    n = int(ROW_COUNTS[(seed // len(ALL_MODELS) + seed) % len(ROW_COUNTS)])
+    n = int(ROW_COUNTS[(seed // len(ALL_MODELS) + seed) % len(ROW_COUNTS)]) if rows is None else int(rows)
     if model in ("xDeepFM", "AFM", "PNN") and n > 20011:
         n = 20011
+    exotic = seed >= 240                  # the second family: widths past 64 / "auto", up to 60 fields, FM groups, linear-only features
     uniform = int(rng.choice([4, 8, 16, 32, 12, 6] if fm else [4, 8, 16, 5, 10, 3, 64]))
+    if exotic:
+        uniform = int(rng.choice([20, 24, 48, 2, 1, 28, 80] if fm else [20, 48, 102, 1, 2, 80]))
     n_sparse = int(rng.randint(1, 31 if not fm else 27))
+    if exotic and not fm and rng.rand() < 0.4:
+        n_sparse = int(rng.randint(31, 61))
     if model in ("AFM", "PNN", "xDeepFM"):
         n_sparse = max(2, min(n_sparse, 12))
     mixed_dims = (not fm) and rng.rand() < 0.5
     dnn, feed = [], {}
 
     def dim():
-        return int(rng.choice([4, 8, 16, 5, 10, 3, 32])) if mixed_dims else uniform
+        if mixed_dims:
+            return int(rng.choice([4, 8, 16, 5, 10, 3, 32] + ([102, 20, 1, 72] if exotic else [])))
+        return uniform
 
     shared = None
     for i in range(n_sparse):
@@ -49,7 +56,7 @@ def random_config(seed):
             feed[d["name"]] = rng.randint(0, 10 ** 6, n).astype(d["dtype"])
         else:
             feed[d["name"]] = rng.randint(0, v, n).astype(np.int64 if rng.rand() < 0.3 else np.int32)
-        if rng.rand() < 0.15 and not fm:
+        if rng.rand() < 0.15 and (not fm or (exotic and model == "DeepFM")):
             d["group_name"] = "g%d" % rng.randint(2)
         if shared is not None and rng.rand() < 0.15 and not d.get("use_hash"):
             d["embedding_name"] = shared["name"]
@@ -89,12 +96,23 @@ def random_config(seed):
     linear = list(dnn) if r < 0.6 else ([d for d in dnn if rng.rand() < 0.5] if r < 0.85 else [])
     if model == "AFM":
         linear = linear + dense
+    if exotic and rng.rand() < 0.4:       # features only the linear part sees (linear_feature_columns is its own list in every constructor)
+        for i in range(int(rng.randint(1, 4))):
+            v = int(rng.choice([5, 300]))
+            linear.append({"type": "sparse", "name": "l%d" % i, "vocabulary_size": v, "embedding_dim": 4})
+            feed["l%d" % i] = rng.randint(0, v, n).astype(np.int32)
+        if rng.rand() < 0.5:
+            linear.append({"type": "dense", "name": "ld", "dimension": 2})
+            feed["ld"] = rng.rand(n, 2).astype(np.float32)
     units = DNN_SHAPES[int(rng.randint(len(DNN_SHAPES)))]
     act = str(rng.choice(["relu", "relu", "tanh", "sigmoid"]))
     kw = {"seed": 1024 + seed}
     name = model
     if model in ("DeepFM", "WDL", "FNN", "NFM"):
         kw.update(dnn_hidden_units=units, dnn_activation=act)
+        if model == "DeepFM" and exotic:
+            groups = sorted(set(d.get("group_name", "default_group") for d in dnn if d["type"] == "sparse"))
+            kw["fm_group"] = [g for g in groups if rng.rand() < 0.7] or groups[:1]
     elif model in ("DCN", "DCNM"):
         name = "DCN"
         kw.update(dnn_hidden_units=units if rng.rand() < 0.85 else (), dnn_activation=act, cross_num=int(rng.randint(1, 4)),
@@ -117,12 +135,12 @@ def random_config(seed):
     return json.loads(json.dumps(meta)), feed, n
 
 
-def run_case(seed, device):
-    meta, feed, n = random_config(seed)
+def run_case(seed, device, config=None):
+    meta, feed, n = (config or random_config)(seed)
     model = build_model(meta, device)
     rng = np.random.RandomState(seed)
     w = _randomise(model, rng)
-    bn = {k: v for k, v in w.items() if k.startswith("batch_normalization")}
+    bn = {k: v for k, v in w.items() if "batch_normalization" in k}
     if bn:                              # inference-mode BatchNormalization: a positive moving variance, gamma around 1
         for k, v in bn.items():
             if k.endswith("moving_variance"):
@@ -137,7 +155,7 @@ def run_case(seed, device):
     return meta, model, feed, n, ref
 
 
-SEEDS = [int(t) for t in os.environ.get("DCTR_FUZZ_SEEDS", "").split(",") if t] or list(range(240))     # (a subset while debugging)
+SEEDS = [int(t) for t in os.environ.get("DCTR_FUZZ_SEEDS", "").split(",") if t] or list(range(400))     # (a subset while debugging)
 
 
 @pytest.mark.gpu
@@ -160,12 +178,153 @@ def test_random_configuration_matches_the_oracle(device, seed):
             check_probs(y, ref, "%s bs=%d" % (what, bs), ok)
 
 
+DIN_ROWS = [1, 7, 300, 2048, 5000, 33000]
+
+
+def random_din_config(seed):
+    """DIN (deepctr/models/sequence/din.py:25-98): behaviour features with their history sequences on shared tables, further sparse /
+    dense / pooled-sequence features, the attention unit's shape and activation, weight normalisation."""
+    rng = np.random.RandomState(5000 + seed)
+    n = int(DIN_ROWS[seed % len(DIN_ROWS)])
+    T = int(rng.choice([1, 4, 10, 50]))
+    if n > 5000:
+        T = min(T, 10)
+    use_hash = bool(rng.rand() < 0.25)
+    with_len = bool(rng.rand() < 0.5)
+    dnn, feed, hist = [], {}, []
+    for i in range(int(rng.randint(0, 4))):
+        v = int(rng.choice([3, 50, 1000]))
+        dnn.append({"type": "sparse", "name": "u%d" % i, "vocabulary_size": v, "embedding_dim": int(rng.choice([4, 8, 10, 3, 16])), "use_hash": use_hash})
+        feed["u%d" % i] = rng.randint(0, v, n).astype(np.int32)
+    lens = rng.randint(0, T + 1, n)
+    for i in range(int(rng.randint(1, 4))):
+        v = int(rng.choice([5, 60, 2000]))
+        e = int(rng.choice([4, 8, 16, 32, 6, 10]))
+        dnn.append({"type": "sparse", "name": "b%d" % i, "vocabulary_size": v, "embedding_dim": e, "use_hash": use_hash})
+        feed["b%d" % i] = rng.randint(1, v, n).astype(np.int32)
+        hist.append("b%d" % i)
+    for i in range(int(rng.choice([0, 0, 1, 2]))):
+        dnn.append({"type": "dense", "name": "d%d" % i, "dimension": int(rng.choice([1, 3]))})
+        feed["d%d" % i] = rng.rand(n, dnn[-1]["dimension"]).astype(np.float32)
+    for name in hist:
+        src = [d for d in dnn if d.get("name") == name][0]
+        sf = {"type": "sparse", "name": "hist_" + name, "vocabulary_size": src["vocabulary_size"], "embedding_dim": src["embedding_dim"],
+              "use_hash": use_hash, "embedding_name": name}
+        d = {"type": "varlen", "sparsefeat": sf, "maxlen": T}
+        if with_len:
+            d["length_name"] = "seq_length"
+        ids = rng.randint(1, src["vocabulary_size"], (n, T)).astype(np.int32)
+        ids[np.arange(T)[None, :] >= lens[:, None]] = 0
+        feed["hist_" + name] = ids
+        dnn.append(d)
+    if with_len:
+        feed["seq_length"] = lens.astype(np.int32).reshape(n, 1)
+    if rng.rand() < 0.3:                  # a pooled sequence beside the attended ones (din.py:73-78)
+        v, T2 = 40, int(rng.choice([3, 8]))
+        sf = {"type": "sparse", "name": "tags", "vocabulary_size": v, "embedding_dim": int(rng.choice([4, 8])), "use_hash": use_hash}
+        dnn.append({"type": "varlen", "sparsefeat": sf, "maxlen": T2, "combiner": str(rng.choice(["mean", "sum"]))})
+        l2 = rng.randint(1, T2 + 1, n)
+        ids = rng.randint(1, v, (n, T2)).astype(np.int32)
+        ids[np.arange(T2)[None, :] >= l2[:, None]] = 0
+        feed["tags"] = ids
+    kw = {"seed": 1024 + seed, "dnn_hidden_units": DNN_SHAPES[int(rng.randint(len(DNN_SHAPES)))],
+          "dnn_activation": str(rng.choice(["relu", "relu", "tanh", "sigmoid"])),
+          "att_hidden_size": [(80, 40), (8,), (64, 16), (36, 20, 4)][int(rng.randint(4))],
+          "att_activation": str(rng.choice(["dice", "dice", "sigmoid", "relu"])),
+          "att_weight_normalization": bool(rng.rand() < 0.5)}
+    if rng.rand() < 0.2:
+        kw["dnn_use_bn"] = True
+    if rng.rand() < 0.1:
+        kw["task"] = "regression"
+    meta = {"model": "DIN", "linear": [], "dnn": dnn, "kwargs": kw, "extra_args": [hist]}
+    return json.loads(json.dumps(meta)), feed, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [int(t) for t in os.environ.get("DCTR_FUZZ_DIN_SEEDS", "").split(",") if t] or list(range(90)))
+def test_random_din_configuration_matches_the_oracle(device, seed):
+    meta, model, feed, n, ref = run_case(seed, device, random_din_config)
+    what = "fuzz DIN %d n=%d" % (seed, n)
+    for bs in (2048, 333):
+        y = model.predict(feed, batch_size=bs)
+        if meta["kwargs"].get("task") == "regression":
+            assert y.shape == ref.shape and y.dtype == np.float32
+            assert_close(y, ref, rtol=1e-4, atol=2e-5, what="%s bs=%d" % (what, bs))
+        else:
+            check_probs(y, ref, "%s bs=%d" % (what, bs))
+
+
+def _fit_once(meta, feed, y, weights, device, hip, optimizer, bs):
+    model = build_model(meta, device)
+    model.set_weights_by_name(weights)
+    model.hip_training = hip
+    model.compile(optimizer, "binary_crossentropy" if meta["kwargs"].get("task", "binary") == "binary" else "mse")
+    h = model.fit(feed, y, batch_size=bs, epochs=1, verbose=0, shuffle=False)
+    return model, h.history["loss"][-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [int(t) for t in os.environ.get("DCTR_FUZZ_FIT_SEEDS", "").split(",") if t] or list(range(100)))
+def test_random_configuration_trains_alike_on_the_hip_and_the_autograd_step(device, seed):
+    """fit() — three consecutive batches, the last one ragged — on the HIP training step against the torch-autograd step (the checker:
+    autograd over the restatement of the forward that tests/test_training_checker_cpu.py pins to the fixtures) from the same weights:
+    the same loss and the same updated weights.  SGD shows every gradient linearly (two of three seeds), Adam the optimizer's own path."""
+    from deepctr_amd import training_hip
+    bs = [64, 256, 1000][seed % 3]
+    n = 2 * bs + max(1, bs // 3)
+    if seed % 2:
+        meta, feed, n = random_config(seed, rows=n)
+    else:
+        meta, feed, n = random_din_config(seed)
+        n = min(n, 2 * bs + max(1, bs // 3), 700)
+        feed = {k: v[:n] for k, v in feed.items()}
+    rng = np.random.RandomState(seed)
+    probe = build_model(meta, device)
+    if not training_hip.supported(probe):
+        pytest.skip("%s: outside the HIP training step's family (fit() takes the autograd step)" % meta["model"])
+    w = _randomise(probe, rng)
+    for k, v in w.items():
+        if "batch_normalization" in k and k.endswith("moving_variance"):
+            w[k] = (0.5 + rng.rand(*v.shape)).astype(np.float32)
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    optimizer = "adam" if seed % 3 == 2 else "sgd"
+    m_hip, loss_hip = _fit_once(meta, feed, y, w, device, True, optimizer, bs)
+    assert getattr(m_hip, "_hip_trainer", None) is not None, "fit() did not take the HIP training step"
+    m_ref, loss_ref = _fit_once(meta, feed, y, w, device, False, optimizer, bs)
+    assert getattr(m_ref, "_hip_trainer", None) is None
+    what = "fit fuzz %d %s %s bs=%d" % (seed, meta["model"], optimizer, bs)
+    if not (np.isfinite(loss_ref) and loss_ref < 50.0):
+        pytest.skip("%s: the random weights diverge under this optimizer (loss %.3g): nothing to compare" % (what, loss_ref))
+    # (the HIP step takes the l2 penalties at the epoch's two ends, the autograd step at every batch: second order in the weight change)
+    assert_close(np.array([loss_hip]), np.array([loss_ref]), rtol=5e-4, atol=1e-6, what=what + " loss")
+    w_hip, w_ref = m_hip.get_weights_by_name(), m_ref.get_weights_by_name()
+    for k in w_ref:
+        d_hip, d_ref = (w_hip[k] - w[k]).astype(np.float64), (w_ref[k] - w[k]).astype(np.float64)
+        moved = float(np.abs(d_ref).max())
+        scale = max(moved, 1e-6)          # (updates below 1e-6: a saturated layer's gradient is rounding noise)
+        err = np.abs(d_hip - d_ref) / scale
+        if optimizer == "sgd":
+            # three SGD steps: the update is the sum of three gradients — within 1 % of the tensor's largest update everywhere (a wrong
+            # or missing term is O(1); cancelling sums of either step leave a few 1e-3)
+            assert float(err.max()) < 1e-2, "%s: update of %s (largest %.3g): off by %.3g of it" % (what, k, moved, float(err.max()))
+        else:
+            # Adam's steps are ~ lr * sign(g): an element whose gradient is rounding noise may take either sign — all but 0.5 % agree to 10 %
+            bad = float((err > 0.1).mean())
+            assert bad < 5e-3, "%s: update of %s (largest %.3g): %.2f %% of the elements differ by > 10 %% of it" % (what, k, moved, 100 * bad)
+
+
 def test_random_configurations_are_valid_for_the_oracle():
     """CPU: the generator's configurations build (CPU-resident weights) and the oracle scores them — the GPU test's inputs are sound."""
     import torch
-    for seed in range(0, 240, 7):
+    for seed in range(0, 400, 7):
         meta, feed, n = random_config(seed)
         if n > 1000:
             continue
         _, _, _, n, ref = run_case(seed, torch.device("cpu"))
+        assert ref.shape == (n, 1) and np.isfinite(ref).all()
+    for seed in range(0, 90, 6):
+        meta, feed, n = random_din_config(seed)
+        if n > 1000:
+            continue
+        _, _, _, n, ref = run_case(seed, torch.device("cpu"), random_din_config)
         assert ref.shape == (n, 1) and np.isfinite(ref).all()

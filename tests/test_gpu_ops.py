@@ -337,7 +337,7 @@ def test_cin(device):
     assert_close(y.cpu().numpy(), y0.cpu().numpy(), rtol=2e-5, atol=2e-5, what="cin folded vs plain layer 0")
 
 
-@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 28, 32, 36, 48, 64])
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 28, 32, 36, 48, 64, 72, 80, 102, 128])
 def test_cin_every_embedding_width(device, D):
     """CIN over embeddings of any width (interaction.py:277-325 has no constraint on D): the kernel sums the maps over d in registers only
     where a sample's rows are 4, 8 or whole 16-row MFMA tiles — D = 12, 20, 24 ... straddle them and sum from LDS.  Float64 oracle,

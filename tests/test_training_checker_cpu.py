@@ -377,3 +377,32 @@ def test_fit_loss_weights_steps_and_initial_epoch():
             training.fit_model(ref, feed, yv, batch_size=32, sample_weight=np.ones(3))
     finally:
         _C.require_device = real
+
+
+def test_keras_adam_is_the_tf_keras_update():
+    """training.KerasAdam against optimizer_v2/adam.py's dense update written out in float64 — epsilon beside sqrt(v), the bias correction
+    folded into the step size — over five steps, with gradients from 1e-8 (where the placement of epsilon decides the step) to 1."""
+    import numpy as np
+    import torch
+    from deepctr_amd.training import KerasAdam
+    rng = np.random.RandomState(0)
+    w0 = rng.standard_normal(64)
+    grads = [rng.standard_normal(64) * 10.0 ** rng.randint(-8, 1, 64) for _ in range(5)]
+    p = torch.nn.Parameter(torch.tensor(w0, dtype=torch.float64))
+    opt = KerasAdam([p], lr=1e-3, eps=1e-7)
+    w, m, v = w0.copy(), np.zeros(64), np.zeros(64)
+    for t, g in enumerate(grads, 1):
+        p.grad = torch.tensor(g, dtype=torch.float64)
+        opt.step()
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        w = w - 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
+        np.testing.assert_allclose(p.detach().numpy(), w, rtol=1e-12, atol=1e-15)
+    # and it is NOT torch.optim.Adam's update where gradients are tiny
+    q = torch.nn.Parameter(torch.tensor(w0, dtype=torch.float64))
+    ref = torch.optim.Adam([q], lr=1e-3, eps=1e-7)
+    q.grad = torch.tensor(grads[0], dtype=torch.float64)
+    ref.step()
+    first = w0 - 1e-3 * np.sqrt(0.001) / 0.1 * (0.1 * grads[0]) / (np.sqrt(0.001 * grads[0] ** 2) + 1e-7)
+    tiny = np.abs(grads[0]) < 1e-6
+    assert tiny.any() and np.abs((q.detach().numpy() - w0)[tiny]).max() > 1.5 * np.abs((first - w0)[tiny]).max()
