@@ -746,8 +746,10 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                 \
                 if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                                    \
                 if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);                            \
-                if (s_ + 1 < PAIR) issue_x(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN);                        \
-                else issue_x(min(b_ + 1, NBE - 1), idcn, 0, XN);                                                 \
+                /* (past the last embedding block the clamped request would pair the LAST field's table with another field's ids — \
+                   beyond the table where that field's vocabulary is the larger one: such a request reads row 0) */                \
+                if (s_ + 1 < PAIR) issue_x(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idc, (s_ + 1) / EB, XN);                  \
+                else issue_x(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, 0, XN);                                           \
                 if (s_ == 0) {                                                                                   \
                     bool has_;                                                                                   \
                     lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
@@ -775,12 +777,12 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);            \
             }                                                                                                    \
             if (i_ == 1) {                                                                       \
-                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN, std::integral_constant<int, 0>{});      \
-                else issue_x1(min(b_ + 1, NBE - 1), idcn, 0, XN, std::integral_constant<int, 0>{});             \
+                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idc, (s_ + 1) / EB, XN, std::integral_constant<int, 0>{});      \
+                else issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, 0, XN, std::integral_constant<int, 0>{});             \
             }                                                                                                    \
             if (i_ == 2 && RT > 1) {                                                             \
-                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), idc, (s_ + 1) / EB, XN, std::integral_constant<int, RT - 1>{}); \
-                else issue_x1(min(b_ + 1, NBE - 1), idcn, 0, XN, std::integral_constant<int, RT - 1>{});        \
+                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idc, (s_ + 1) / EB, XN, std::integral_constant<int, RT - 1>{}); \
+                else issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, 0, XN, std::integral_constant<int, RT - 1>{});        \
             }                                                                                                    \
             if (i_ == 3) {                                                                       \
                 if (s_ == 0) {                                                                                   \
@@ -919,8 +921,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                     if constexpr (PPB > 1) linacc += (lvnB_has && b_ >= 1 && b_ - 1 < NBE) ? lvnB : 0.f;         \
                 }                                                                                                \
             }                                                                                                    \
-            if (i_ == 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, 0>{});         \
-            if (i_ == 2 && RT > 1) issue_xq1(min(b_ + 1, NBE - 1), idcn, idcnB, XN, std::integral_constant<int, RT - 1>{}); \
+            if (i_ == 1) issue_xq1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, b_ + 1 > NBE - 1 ? 0u : idcnB, XN, std::integral_constant<int, 0>{});         \
+            if (i_ == 2 && RT > 1) issue_xq1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, b_ + 1 > NBE - 1 ? 0u : idcnB, XN, std::integral_constant<int, RT - 1>{}); \
             if (i_ == 3) {                                                                       \
                 bool has_;                                                                                       \
                 lvn = *pair_lin_ptr(PPB * b_, idc, has_);                                                        \

@@ -46,6 +46,8 @@ def supported(model):
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
     if sp.lin_only or not sp.all_dim4 or sp.max_dim > 64:
         return False
+    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "matrix" and sp.in_dim > 832:
+        return False                        # (the training forward's matrix CrossNet keeps [16, dim] tiles of x_0 / x_l / x_{l+1} in LDS)
     if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector":
         # dctr_crossnet_bwd's vector form holds a row's gradient in registers (<= 2048 columns) and every layer's x_l in LDS
         n_l = int(getattr(model.cross, "layer_num", 0))

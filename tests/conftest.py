@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("DCTR_POISON_EMPTY"):
+        # debugging aid: every torch.empty() comes back filled with NaN / the largest integer, so that a kernel reading a buffer nobody
+        # wrote shows up as a wrong result / an index-out-of-range flag instead of depending on what the allocator hands out
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
 
 
 @pytest.fixture(scope="session")

@@ -259,12 +259,8 @@ def test_din_c4_full_batch(device):
         if k.endswith("moving_variance"):
             w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
     model.set_weights_by_name(w)
-    wk = {}
-    for k, v in w.items():                      # the oracle speaks keras names for the BatchNormalization inside Dice
-        lname, wname = k.rsplit("/", 1)
-        if wname in ("moving_mean", "moving_variance"):
-            lname = "batch_normalization" + lname[len("dice"):]
-        wk["%s/%s" % (lname, wname)] = v
+    wk = w                                      # (get_weights_by_name speaks keras names for the BatchNormalization inside Dice, as the oracle)
+    assert "batch_normalization/moving_mean" in wk
     y = model.predict(feed, batch_size=n)
     assert y.shape == (n, 1) and np.isfinite(y).all()
     rows = np.unique(np.concatenate([np.arange(0, 12), np.arange(n - 12, n), rng.choice(n, 40, replace=False)]))
@@ -324,13 +320,7 @@ def test_din_c4_shape_vs_oracle(device):
                 if k.endswith("moving_variance"):
                     w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
             model.set_weights_by_name(w)
-        # oracle speaks keras names for the BatchNormalization inside Dice
-        wk = {}
-        for k, v in w.items():
-            lname, wname = k.rsplit("/", 1)
-            if wname in ("moving_mean", "moving_variance"):
-                lname = "batch_normalization" + lname[len("dice"):]
-            wk["%s/%s" % (lname, wname)] = v
+        wk = w                                  # (keras names for the BatchNormalization inside Dice, as the oracle reads them)
         ref = RM.din(cols, ["item_id", "cate_id"], wk, feed, att_activation=act, dtype=np.float64)
         check_probs(model.predict(feed, batch_size=64), ref.astype(np.float32), "DIN " + act)
 
