@@ -312,15 +312,15 @@ def test_random_configuration_trains_alike_on_the_hip_and_the_autograd_step(devi
         scale = max(moved, 1e-6)          # (updates below 1e-6: a saturated layer's gradient is rounding noise)
         err = np.abs(d_hip - d_ref) / scale
         if optimizer == "sgd":
-            # three SGD steps: the update is the sum of three gradients — within 1 % of the tensor's largest update everywhere (a wrong
+            # three SGD steps: the update is the sum of three gradients — within 2 % of the tensor's largest update everywhere (a wrong
             # or missing term is O(1); cancelling sums of either step leave a few 1e-3)
-            assert float(err.max()) < 1e-2, "%s: update of %s (largest %.3g): off by %.3g of it" % (what, k, moved, float(err.max()))
+            assert float(err.max()) < 2e-2, "%s: update of %s (largest %.3g): off by %.3g of it" % (what, k, moved, float(err.max()))
         else:
-            # Adam's steps are ~ lr * sign(g): an element whose gradient is rounding noise may take either sign — all but 0.5 % agree to 10 %
+            # Adam's steps are ~ lr * sign(g): an element whose gradient is rounding noise may take either sign — all but 1 % agree to 10 %
             if moved < 3e-4:              # (a tensor whose largest step in three is a tenth of lr: gradients around epsilon, i.e. noise)
                 continue
             bad = float((err > 0.1).mean())
-            assert bad < 5e-3, "%s: update of %s (largest %.3g): %.2f %% of the elements differ by > 10 %% of it" % (what, k, moved, 100 * bad)
+            assert bad < 1e-2, "%s: update of %s (largest %.3g): %.2f %% of the elements differ by > 10 %% of it" % (what, k, moved, 100 * bad)
 
 
 def test_random_configurations_are_valid_for_the_oracle():

@@ -130,3 +130,15 @@ def test_dense_linear_kernel_refresh_maps_rows_without_host_sync():
     finally:
         k.requires_grad_(False)
         k.grad = None
+
+
+def test_row_stride_of_a_single_row_is_its_width():
+    """torch leaves the stride of a size-1 dimension arbitrary: ``x.t().contiguous()`` of an [n, 1] tensor is [1, n] with stride(0) = 1 —
+    what a 1-row dense matrix looked like to dctr_embed_gather_fm ("dense_stride < n_dense": found by tests/test_gpu_fuzz.py)."""
+    import torch
+    from deepctr_amd import ops
+    t = torch.zeros(13, 1).t().contiguous()
+    assert t.shape == (1, 13) and ops.row_stride(t) >= 13
+    assert ops.row_stride(torch.zeros(5, 13)) == 13
+    assert ops.row_stride(torch.zeros(5, 16)[:, :13]) == 16
+    assert ops.row_stride(torch.zeros(1, 16)[:, :13]) == 16
