@@ -568,8 +568,28 @@ def gen_bn():
         _save("dnn_" + name, **arrays)
 
 
+def gen_widths():
+    """Embedding widths the lane layouts of the kernels do not divide (found wrong or refused by tests/test_gpu_fuzz.py in round 5): CIN over
+    embedding_dim 12 (interaction.py:277-325 — three 4-row groups of an MFMA tile per sample), embedding_dim="auto"
+    (feature_column.py:44-45: 6 * int(vocabulary_size ** 0.25) = 30 for 700 ids), rows of 80 floats through the plain lookups, the masked
+    pooling and the hashed lookups (inputs.py:101-158)."""
+    rng = np.random.RandomState(31)
+    B = 24
+    fixed12 = [d for d in mixed_spec(12, False) if d["type"] != "varlen"]
+    feed12 = _feed_for(fixed12, B, rng)
+    _run_model("model_xdeepfm_d12", "deepctr.models.xdeepfm", "xDeepFM", fixed12, fixed12, feed12,
+               {"dnn_hidden_units": [8, 4], "cin_layer_size": [8, 6], "cin_split_half": True})
+    auto = [dict(type="sparse", name="a%d" % i, vocabulary_size=700, embedding_dim="auto") for i in range(3)] + \
+           [dict(type="dense", name="dense_feature_0", dimension=1), dict(type="dense", name="dense_vec", dimension=3)]
+    feed_a = _feed_for(auto, B, rng)
+    _run_model("model_deepfm_auto", "deepctr.models.deepfm", "DeepFM", auto, auto, feed_a, {"dnn_hidden_units": [16, 8]})
+    spec80 = mixed_spec(80, True)
+    feed80 = _feed_for(spec80, B, rng)
+    _run_model("model_wdl_e80", "deepctr.models.wdl", "WDL", spec80, spec80, feed80, {"dnn_hidden_units": [16, 8]})
+
+
 def main(argv=None):
-    """``python -m oracle.make_golden [--out DIR] [siblings | bn]``: every generator (or one add-on group) into DIR
+    """``python -m oracle.make_golden [--out DIR] [siblings | bn | widths]``: every generator (or one add-on group) into DIR
     (default tests/golden).  tests/test_oracle_golden.py::test_recipe_regenerates_every_fixture runs it into a scratch
     directory and compares every file with the committed one, so the recipe cannot rot unnoticed."""
     global OUT
@@ -584,6 +604,8 @@ def main(argv=None):
         return gen_siblings()
     if argv and argv[0] == "bn":
         return gen_bn()
+    if argv and argv[0] == "widths":
+        return gen_widths()
     gen_hash()
     gen_interaction()
     gen_sequence()
@@ -592,6 +614,7 @@ def main(argv=None):
     gen_criteo_sample()
     gen_siblings()
     gen_bn()
+    gen_widths()
 
 
 if __name__ == "__main__":

@@ -283,7 +283,7 @@ MODEL_FIXTURES = ["model_deepfm_mixed", "model_deepfm_hash", "model_dcn_vector",
                   "model_fnn_fixed", "model_afm", "model_afm_two_groups", "model_afm_noatt", "model_pnn_inner",
                   "model_pnn_plain", "model_nfm", "model_nfm_fixed", "model_dcnmix", "model_dcnmix_crossonly",
                   "model_dcnmix_fixed", "model_deepfm_bn", "model_dcn_bn", "model_xdeepfm_bn", "model_deepfm_bn_fixed",
-                  "model_din_bn_dice", "model_din_bn_sigmoid"]
+                  "model_din_bn_dice", "model_din_bn_sigmoid", "model_xdeepfm_d12", "model_deepfm_auto", "model_wdl_e80"]
 
 
 def run_oracle_model(g, dtype=np.float32, task=None, abs_weights=False):
