@@ -73,22 +73,56 @@ import torch             # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F, V, E, ND, B = 26, 100000, 16, 13, 4096
 HIDDEN = (256, 128, 64)
-ALG_BYTES_PER_SAMPLE = F * 4 + F * E * 4 + F * 4 + ND * 4 + 4          # 1,928 B
-DNN_FLOP_PER_SAMPLE = 2 * ((F * E + ND) * 256 + 256 * 128 + 128 * 64 + 64)   # 301,696
+# BASELINE.json configs the bench can time.  "c2" = configs[1], the configuration the metric is quoted on (default); "c5" = configs[4]:
+# the same model over vocabularies of 1e7 and embedding_dim 32 (26 x [1e7, 32] fp32 = 33.3 GB of tables + 1.04 GB of linear tables per
+# replica), 65,536 rows per step row-sharded over 8 GPUs = 8192 rows per GPU (SURVEY.md §8 d / e).
+WORKLOADS = {
+    "c2": {"F": 26, "V": 100000, "E": 16, "ND": 13, "B": 4096, "metric": "samples/sec fwd DeepFM Criteo-26x1e5 emb16 b4096",
+           "config": "BASELINE configs[1]: DeepFM forward, 26 sparse x vocab 1e5 + 13 dense, emb_dim 16, DNN 256-128-64, batch 4096 per GPU"},
+    "c5": {"F": 26, "V": 10 ** 7, "E": 32, "ND": 13, "B": 8192, "metric": "samples/sec fwd DeepFM Criteo-26x1e7 emb32 b65536 row-sharded x8",
+           "config": "BASELINE configs[4]: DeepFM forward, 26 sparse x vocab 1e7 + 13 dense, emb_dim 32, DNN 256-128-64, batch 65536 "
+                     "row-sharded over 8 GPUs = 8192 rows per GPU (tables replicated: 34.3 GB per GPU)"},
+}
+WORKLOAD = "c2"
+F = V = E = ND = B = ALG_BYTES_PER_SAMPLE = DNN_FLOP_PER_SAMPLE = 0
+
+
+def set_workload(name):
+    """Module-level shape constants of the chosen workload (algorithmic bytes / DNN FLOP per sample — c2: 1,928 B and
+    301,696 FLOP; c5: 3,592 B and 514,688 FLOP)."""
+    global WORKLOAD, F, V, E, ND, B, ALG_BYTES_PER_SAMPLE, DNN_FLOP_PER_SAMPLE
+    w = WORKLOADS[name]
+    WORKLOAD, F, V, E, ND, B = name, w["F"], w["V"], w["E"], w["ND"], w["B"]
+    ALG_BYTES_PER_SAMPLE = F * 4 + F * E * 4 + F * 4 + ND * 4 + 4
+    DNN_FLOP_PER_SAMPLE = 2 * ((F * E + ND) * HIDDEN[0] + HIDDEN[0] * HIDDEN[1] + HIDDEN[1] * HIDDEN[2] + HIDDEN[2])
+    return w
+
+
+set_workload("c2")
 HBM_PEAK_GBS = 8000.0
 F32_MFMA_PEAK_TF = 157.3
 F32_MFMA_SUSTAINED_TF = 139.8   # scripts/mfma_lab.cpp, pure v_mfma_f32_16x16x4 loop on all CUs (profiles/r02_mfma_lab.log)
 
 
-def build_model(device):
+# Criteo's own per-column cardinalities (the Kaggle display-advertising set, C1..C26): 3 ... 1e7 rows, the shape real feature columns have.
+# Every other configuration of this file has 26 EQUAL vocabularies — the blind spot the round-5 fuzz found an out-of-bounds read in.
+CRITEO_VOCABS = (1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10, 5652, 2173, 4,
+                 7046547, 18, 15, 286181, 105, 142572)
+
+
+def build_model(device, vocabs=None):
     from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.initializers import Zeros
     from deepctr_amd.models import DeepFM
-    cols = [SparseFeat("C%d" % i, V, E) for i in range(1, F + 1)] + [DenseFeat("I%d" % i, 1) for i in range(1, ND + 1)]
+    vocabs = [V] * F if vocabs is None else list(vocabs)
+    # (no host RNG pass over tables of > 2^24 elements: those are drawn on the device below)
+    cols = [SparseFeat("C%d" % i, v, E, **({"embeddings_initializer": Zeros()} if v * E > (1 << 24) else {})) for i, v in enumerate(vocabs, 1)]
+    cols += [DenseFeat("I%d" % i, 1) for i in range(1, ND + 1)]
     model = DeepFM(cols, cols, dnn_hidden_units=HIDDEN, device=device)
     g = torch.Generator(device="cpu").manual_seed(2020)
-    with torch.no_grad():
+    gd = torch.Generator(device=device).manual_seed(2020)   # tables past 64 MB are drawn on the device (c5: 34 GB; same seed on every rank
+    with torch.no_grad():                                   # = identical replicas, SURVEY.md §8(d))
         for name, t in model.named_weights():           # random-init, "trained-like" scale (no checkpoints offline)
             if name.endswith("embeddings"):
                 std = 0.1 if t.shape[-1] == 1 else 0.05
@@ -96,6 +130,9 @@ def build_model(device):
                 std = 0.05
             else:
                 std = float((2.0 / sum(t.shape)) ** 0.5) if t.dim() == 2 else 0.05
+            if t.numel() > (1 << 24):
+                t.normal_(0.0, std, generator=gd)
+                continue
             chunk = 1 << 22
             flat = t.view(-1)
             for i in range(0, flat.numel(), chunk):
@@ -104,13 +141,14 @@ def build_model(device):
     return model, cols
 
 
-def synthetic_feed(rows, seed, dist="uniform"):
+def synthetic_feed(rows, seed, dist="uniform", vocabs=None):
     """ids i.i.d. uniform on [0, V) (primary, cache-hostile) or Zipf(1.05) folded into [0, V) (secondary)."""
     rng = np.random.RandomState(seed)
+    vocabs = [V] * F if vocabs is None else list(vocabs)
     if dist == "zipf":
-        feed = {"C%d" % i: ((rng.zipf(1.05, rows) - 1) % V).astype(np.int32) for i in range(1, F + 1)}
+        feed = {"C%d" % i: ((rng.zipf(1.05, rows) - 1) % v).astype(np.int32) for i, v in enumerate(vocabs, 1)}
     else:
-        feed = {"C%d" % i: rng.randint(0, V, rows).astype(np.int32) for i in range(1, F + 1)}
+        feed = {"C%d" % i: rng.randint(0, v, rows).astype(np.int32) for i, v in enumerate(vocabs, 1)}
     feed.update({"I%d" % i: rng.rand(rows).astype(np.float32) for i in range(1, ND + 1)})
     return feed
 
@@ -176,12 +214,46 @@ def probe_kernels(model, staged, ring, reps=48):
     return mean(t_step), mean(t_gather), mean(t_mlp), mean(t_lo), mean(t_big), mean(t_big_lo), big, mean(t_rec), mean(t_rec_lo)
 
 
+def compact_problem(model, feed):
+    """The same forward over tables the host can hold: per field the distinct ids of `feed`, their rows copied back from the device,
+    ids renumbered to positions in those compact tables (same values row for row).  Returns (cols, weights by name, feed).  Used by the
+    checker and the CPU baseline when the tables are too large to copy (c5: 34 GB); tests/test_gpu_c5.py does the same."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    named = dict(model.named_weights())
+    w, sub, ccols = {}, {}, []
+    for i in range(1, F + 1):
+        name = "C%d" % i
+        uniq, inv = np.unique(np.asarray(feed[name]).astype(np.int64), return_inverse=True)
+        idx = torch.as_tensor(uniq, device=model.device)
+        for prefix in ("sparse_emb_", "linear0sparse_emb_"):
+            key = prefix + name + "/embeddings"
+            w[key] = named[key][idx].cpu().numpy()
+        ccols.append(SparseFeat(name, len(uniq), E))
+        sub[name] = inv.astype(np.int64)
+    for i in range(1, ND + 1):
+        ccols.append(DenseFeat("I%d" % i, 1))
+        sub["I%d" % i] = np.asarray(feed["I%d" % i])
+    for k, t in named.items():
+        if not k.endswith("embeddings"):
+            w[k] = t.detach().cpu().numpy()
+    return ccols, w, sub
+
+
+def big_tables():
+    return F * V * E * 4 > (2 << 30)
+
+
 def cpu_baseline(model, cols, budget_s=14.0):
     """The oracle's CPU port of the reference op sequence on a bounded sample of the same workload; torch's intra-op thread
     count is swept (all cores over-subscribe the small ops of a 4096-row batch) and the best setting is reported."""
     from oracle.cpu_deepfm import CpuDeepFM
-    cpu = CpuDeepFM(model.get_weights_by_name(), F, ND)
     feed = synthetic_feed(B, 7)
+    compact = big_tables()
+    if compact:                                         # c5: the batch's own rows only (tables of <= B rows: kinder to the CPU's caches
+        _, wts, feed = compact_problem(model, feed)     # than the 34 GB the GPU reads from — said in `sample`)
+    else:
+        wts = model.get_weights_by_name()
+    cpu = CpuDeepFM(wts, F, ND)
     ids = [torch.from_numpy(feed["C%d" % i].astype(np.int64)) for i in range(1, F + 1)]
     dense = [torch.from_numpy(feed["I%d" % i]).reshape(-1, 1) for i in range(1, ND + 1)]
     ncpu = os.cpu_count() or 1
@@ -221,10 +293,11 @@ def cpu_baseline(model, cols, budget_s=14.0):
     return {"value": B / med, "unit": "samples/s", "cores": int(nt), "kind": "port", "host_cores": int(ncpu),
             "thread_sweep_samples_per_s": sweep,
             "sample": "%d batches of %d rows (median) at the best of %d thread counts, torch-CPU restatement of the TF op "
-                      "sequence (TensorFlow not installable here)" % (n, B, len(cands))}
+                      "sequence (TensorFlow not installable here)%s" % (
+                          n, B, len(cands), "; tables compacted to the rows this batch touches (the full 34 GB stay on the device)" if compact else "")}
 
 
-def check_parity(model, cols, staged, launches, logits, n_rows, rank):
+def check_parity(model, cols, staged, launches, logits, n_rows, rank, compact=None):
     """What the timed region wrote, checked: a sample of its output rows against the float64 oracle (oracle/ref_models.py — the
     checker, never the thing measured) on the same ids / dense values / weights.  Output row o of launch (lo, hi, o0, o1) is
     input row lo + (o - o0) of the staged ring."""
@@ -242,7 +315,11 @@ def check_parity(model, cols, staged, launches, logits, n_rows, rank):
     sp = model.stage_plan
     feed = {f.fc.name: ids[i] for i, f in enumerate(sp.fields)}
     feed.update({fc.name: dense[:, i] for i, fc in enumerate(sp.dense_cols)})
-    ref = ref_models.deepfm(cols, cols, model.get_weights_by_name(), feed, dnn_hidden_units=HIDDEN, dtype=np.float64).reshape(-1)
+    if big_tables() if compact is None else compact:
+        ccols, wts, feed = compact_problem(model, feed)
+        ref = ref_models.deepfm(ccols, ccols, wts, feed, dnn_hidden_units=HIDDEN, dtype=np.float64).reshape(-1)
+    else:
+        ref = ref_models.deepfm(cols, cols, model.get_weights_by_name(), feed, dnn_hidden_units=HIDDEN, dtype=np.float64).reshape(-1)
     got = logits[torch.as_tensor(pick, device=logits.device)].cpu().numpy().astype(np.float64)
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)
     # the bar of the parity tests (tests/util.py): probabilities within 1e-4 relative (+ 1e-6 absolute floor)
@@ -295,12 +372,10 @@ def host_preprocess(seconds, rows=200000):
     return n
 
 
-def measure_traffic(K, rows_launch, dist_name, timeout_s=120, fused_records=False):
-    """roofline.traffic measured IN THIS RUN: FETCH_SIZE and WRITE_SIZE of the timed region's kernel from two rocprofv3 counter passes
-    over a child of this script (same K, same launch shape; `--kernel-trace --pmc <one counter>` only — counters are never combined
-    with API traces; cwd and TMPDIR = /tmp as the profiling recipe asks).  Returns (bytes per launch, description) or (None, reason).
-    Units as in rounds 1-4: the counters are KB at the L2's memory side (Infinity-Cache hits included); on this kernel's 64-B row reads
-    FETCH_SIZE was calibrated at 0.992x of a known byte count (profiles/r04_pmc_gather.json), so no correction factor is applied."""
+def pmc_pass(ctr, kernel_substr, child_args, timeout_s):
+    """One rocprofv3 counter pass (`--kernel-trace --pmc <one counter>` only — counters are never combined with API traces; cwd and
+    TMPDIR = /tmp as the profiling recipe asks) over a child of this script.  Returns (median counter value over the dispatches of the
+    most frequent grid of kernels whose name contains `kernel_substr`, number of those dispatches); raises on failure."""
     import csv
     import glob
     import shutil
@@ -308,35 +383,62 @@ def measure_traffic(K, rows_launch, dist_name, timeout_s=120, fused_records=Fals
     import tempfile
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None, "rocprofv3 not on PATH"
+        raise RuntimeError("rocprofv3 not on PATH")
+    d = tempfile.mkdtemp(prefix="dctr_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.join(ROOT, "bench.py")] + list(child_args)
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=timeout_s)
+        vals = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == ctr and kernel_substr in row.get("Kernel_Name", ""):
+                    key = (row.get("Dispatch_Id"), row.get("Grid_Size"))
+                    vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])       # (one row per dispatch and dimension)
+        if r.returncode != 0 or not vals:
+            raise RuntimeError("rocprofv3 --pmc %s pass gave no %s rows (rc %d)" % (ctr, kernel_substr, r.returncode))
+        grids = [g for _, g in vals]
+        top = max(set(grids), key=grids.count)                                         # the launches of interest (every launch of the child)
+        return float(np.median([v for (_, g), v in vals.items() if g == top])), len([1 for g in grids if g == top])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_traffic(K, rows_launch, dist_name, timeout_s=120, fused_records=False):
+    """roofline.traffic measured IN THIS RUN: FETCH_SIZE and WRITE_SIZE of the timed region's kernel from two rocprofv3 counter passes
+    over a child of this script (same K, same launch shape).  Returns (bytes per launch, description) or (None, reason).
+    Units as in rounds 1-4: the counters are KB at the L2's memory side (Infinity-Cache hits included); on this kernel's 64-B row reads
+    FETCH_SIZE was calibrated at 0.992x of a known byte count (profiles/r04_pmc_gather.json), so no correction factor is applied."""
+    if big_tables():
+        timeout_s = max(timeout_s, 420)                 # the child draws 34 GB of tables first
+    child = ["--steps", str(K), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic", "--prewarm-ms", "10", "--regions", "2",
+             "--parity-rows", "0", "--dist", dist_name, "--workload", WORKLOAD] + (["--fused-records"] if fused_records else [])
     got = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="dctr_pmc_", dir="/tmp")
-        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", str(K), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic",
-               "--prewarm-ms", "10", "--regions", "2", "--parity-rows", "0", "--dist", dist_name] + (["--fused-records"] if fused_records else [])
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                               timeout=timeout_s)
-            vals = {}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == ctr and "chain_kernel" in row.get("Kernel_Name", ""):
-                        key = (row.get("Dispatch_Id"), row.get("Grid_Size"))
-                        vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])       # (one row per dispatch and dimension)
-            if r.returncode != 0 or not vals:
-                return None, "rocprofv3 --pmc %s pass gave no chain_kernel rows (rc %d)" % (ctr, r.returncode)
-            grids = [g for _, g in vals]
-            top = max(set(grids), key=grids.count)                                         # the K-step launches (every launch of the child)
-            got[ctr] = float(np.median([v for (_, g), v in vals.items() if g == top])), len([1 for g in grids if g == top])
+            got[ctr] = pmc_pass(ctr, "chain_kernel", child, timeout_s)
         except Exception as e:                                                             # noqa: BLE001 — never take the line down
             return None, "rocprofv3 --pmc %s pass failed: %r" % (ctr, e)
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
     total = (got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
     return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child of this "
                    "command, median over %d / %d launches of %d rows; FETCH %.1f MB + WRITE %.1f MB per launch" % (
                        got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], rows_launch, got["FETCH_SIZE"][0] * 1024 / 1e6, got["WRITE_SIZE"][0] * 1024 / 1e6))
+
+
+def measure_gather_traffic(rows, dist_name, timeout_s=420):
+    """The stand-alone gather_fm_kernel (the HBM-bound kernel north_star names) where it really is HBM-bound — c5's 34 GB of tables
+    do not fit the 256-MiB Infinity Cache: FETCH_SIZE (KB at the L2's memory side) and TCP_TCC_READ_REQ (vector-L1 -> L2 read requests)
+    per `rows`-row logits-only launch, one rocprofv3 pass each over a `--gather-only` child."""
+    child = ["--gather-only", str(rows), "--workload", WORKLOAD, "--dist", dist_name]
+    out = {}
+    for ctr in ("FETCH_SIZE", "TCP_TCC_READ_REQ_sum"):
+        try:
+            v, n = pmc_pass(ctr, "gather_fm_kernel", child, timeout_s)
+            out[ctr] = {"per_launch": v * (1024.0 if ctr == "FETCH_SIZE" else 1.0), "launches": n}
+        except Exception as e:                                                             # noqa: BLE001
+            out[ctr] = {"error": repr(e)}
+    return out
 
 
 def dom_ok(timed):
@@ -348,7 +450,7 @@ def load_traffic(rows):
     """FETCH_SIZE + WRITE_SIZE per launch from the committed PMC passes, scaled to `rows` rows per launch (the fallback when the
     in-run measurement is not available)."""
     tp = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-    if not os.path.exists(tp):
+    if WORKLOAD != "c2" or not os.path.exists(tp):
         return None, None
     try:
         j = json.load(open(tp))
@@ -357,8 +459,51 @@ def load_traffic(rows):
         return None, None
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(gpus, argv, env, n_devices, share_gpu=False):
+    """`python bench.py --gpus N` must really run N ranks (the reference's multi-GPU form always builds its N replicas:
+    /root/reference/examples/run_classification_criteo_multi_gpu.py:47).  Returns None when this process is the one that measures
+    (N = 1, or it IS a rank of a torch.distributed.run job whose world equals N), or the command line that starts the N ranks — one
+    process per GPU under `python -m torch.distributed.run` on 127.0.0.1 — which the caller runs in place of itself.  Raises SystemExit
+    (non-zero) when --gpus disagrees with the world that came up or with the devices that are visible: a line that says n_gpus 1 for
+    --gpus 8 must never be printed.  Pure function of its arguments (tests/test_cpu_baseline.py drives it with a fake device count)."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    under_launcher = "WORLD_SIZE" in env or "TORCHELASTIC_RUN_ID" in env
+    if under_launcher:
+        world = int(env.get("WORLD_SIZE", "1"))
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but the job that came up has WORLD_SIZE=%d" % (gpus, world))
+        if not share_gpu and n_devices < int(env.get("LOCAL_WORLD_SIZE", world)):
+            raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible (one process per GPU)" % (world, n_devices))
+        return None
+    if gpus == 1:
+        return None
+    if not share_gpu and n_devices < gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (gpus, n_devices))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = BASELINE configs[1] (the metric's configuration, default); c5 = configs[4]: vocab 1e7, emb_dim 32, 8192 rows "
+                         "per GPU of a 65,536-row step row-sharded over 8 GPUs (34 GB of replicated tables per GPU)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the N > 1 path: nccl = RCCL over xGMI (default); gloo = host tensors (the logits cross PCIe: "
+                         "only for running the rank path where RCCL cannot, e.g. two ranks on one GPU with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--gather-only", type=int, default=0, metavar="ROWS",
+                    help="child mode of the counter passes: four logits-only dctr_embed_gather_fm launches of ROWS rows, no JSON line")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
@@ -391,20 +536,29 @@ def main():
                     help="rows of the timed region's output compared with the float64 oracle after the region (0 = off)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU path exists for the product)")
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL wants one GPU per rank)")
+    cmd = launcher_command(args.gpus, sys.argv[1:], os.environ, torch.cuda.device_count(), args.share_gpu)
+    if cmd is not None:                                       # `python bench.py --gpus N`: start the N ranks, be their exit code
+        import subprocess
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
+    set_workload(args.workload)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    host_exchange = args.backend == "gloo"
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run: always take the rank path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if host_exchange:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from deepctr_amd import _C
     lib = _C.lib()
@@ -417,6 +571,16 @@ def main():
     ring = ((max(args.ring, G) + G - 1) // G) * G                          # whole launches
     staged = model.stage(synthetic_feed(ring * B, 1000 + rank, args.dist))       # device-resident before timing
     model._begin()
+    if args.gather_only:
+        sp = model.stage_plan
+        n_g = min(args.gather_only, staged.n)
+        ws = sp.run_pools(staged, 0, n_g)
+        ga = sp.gather_args(staged, 0, n_g, ws)
+        ga.dnn_in = None
+        for _ in range(4):
+            _C.check(lib.dctr_embed_gather_fm(ctypes.byref(ga), _C.stream_ptr()), "dctr_embed_gather_fm")
+        torch.cuda.synchronize()
+        return None
     logits = torch.empty(max(K, 1) * B, dtype=torch.float32, device=device)
     gathered = torch.empty(world * logits.numel(), dtype=torch.float32, device=device) if dist is not None else None
     fused = bool(model._fast_path(staged))
@@ -455,10 +619,35 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if host_exchange:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
+
+    gathered_h = logits_h = None
+    if dist is not None and host_exchange:
+        logits_h = torch.empty(logits.numel(), dtype=torch.float32).pin_memory()
+        gathered_h = torch.empty(world * logits.numel(), dtype=torch.float32).pin_memory()
+
+    def all_gather_logits():
+        """The path's one exchange.  RCCL: device to device over xGMI; gloo: through pinned host buffers."""
+        if host_exchange:
+            logits_h.copy_(logits)
+            dist.all_gather_into_tensor(gathered_h, logits_h)
+            gathered.copy_(gathered_h)
+        else:
+            dist.all_gather_into_tensor(gathered, logits)
+
+    def all_reduce_max(t):
+        if host_exchange:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            return h
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
 
     if dist is not None:                                               # untimed: RCCL sets up its all-gather channels
-        dist.all_gather_into_tensor(gathered, logits)
+        all_gather_logits()
         torch.cuda.synchronize()
 
     exchange_s = {}                     # region kind -> [(forward seconds, all-gather seconds)] of this rank
@@ -475,7 +664,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()                                       # this rank's K steps
         if dist is not None:
-            dist.all_gather_into_tensor(gathered, logits)              # the path's one exchange: the K steps' logits
+            all_gather_logits()                                        # the path's one exchange: the K steps' logits
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             exchange_s.setdefault(kind, []).append((t1 - t0, t2 - t1))
@@ -515,14 +704,11 @@ def main():
     exchange = forward_only = None
     if dist is not None:                                    # every region: MAX over ranks
         ex = exchange_s["value"]                            # (forward, all-gather) of the `value` regions
-        t = torch.tensor([float(np.median([e for _, e in ex])), float(np.median([f for f, _ in ex]))], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = all_reduce_max(torch.tensor([float(np.median([e for _, e in ex])), float(np.median([f for f, _ in ex]))], dtype=torch.float64, device=device))
         exchange, forward_only = float(t[0].item()), float(t[1].item())
-        t = torch.tensor(region_s, dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = all_reduce_max(torch.tensor(region_s, dtype=torch.float64, device=device))
         region_s = [float(v) for v in t.tolist()]
-        t = torch.tensor([cold_s], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = all_reduce_max(torch.tensor([cold_s], dtype=torch.float64, device=device))
         cold_s = float(t.item())
     elapsed = float(np.median(region_s))
     model._check_status()
@@ -598,7 +784,7 @@ def main():
             torch.cuda.synchronize()
             tp = time.perf_counter() - t0
             model.tile_rows, model.span_batches = tr, True
-            per_batch = {"mode": "one launch per 4096-row batch (32-row tile kernel), K launches in one hipGraph on %d streams" % n_streams,
+            per_batch = {"mode": "one launch per %d-row batch (32-row tile kernel), K launches in one hipGraph on %d streams" % (B, n_streams),
                          "samples_per_s": K * B / tp, "ms_per_step": tp / K * 1e3,
                          "aggregate_frac_of_f32_mfma_peak": K * B / tp * DNN_FLOP_PER_SAMPLE / 1e12 / F32_MFMA_PEAK_TF}
 
@@ -740,6 +926,45 @@ def main():
         except Exception as e:
             zipf = {"error": repr(e)}
 
+    # STANDING configuration with UNEQUAL vocabularies (Criteo's own cardinalities, 3 ... 1e7 rows per table, 2.2 GB): the same K-step
+    # region on its own model, checked against the float64 oracle like `value` — an index that strays across tables shows up here.
+    mixed = None
+    if K > 0 and dist is None and not args.no_secondary and WORKLOAD == "c2":
+        try:
+            model_m, cols_m = build_model(device, CRITEO_VOCABS)
+            staged_m = model_m.stage(synthetic_feed(ring * B, 3000 + rank, "uniform", CRITEO_VOCABS))
+            for i, v in enumerate(CRITEO_VOCABS):                 # every table's first and last row are hit
+                staged_m.ids[i, :2] = torch.tensor([0, v - 1], dtype=staged_m.ids.dtype, device=device)
+            model_m._begin()
+            logits_m = torch.empty_like(logits)
+            prep_m = [model_m.prepare_launch(staged_m, lo, hi, logits_m[o0:o1]) for lo, hi, o0, o1 in launches]
+
+            def run_m():
+                for fn in prep_m:
+                    fn()
+            t_end = time.perf_counter() + 0.03
+            while time.perf_counter() < t_end:
+                run_m()
+                torch.cuda.synchronize()
+            tm = []
+            for _ in range(n_regions):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_m()
+                torch.cuda.synchronize()
+                tm.append(time.perf_counter() - t0)
+            model_m._check_status()
+            par_m = check_parity(model_m, cols_m, staged_m, launches, logits_m, max(args.parity_rows // 4, 256), rank, compact=True)
+            tmed = float(np.median(tm))
+            mixed = {"vocabularies": "Criteo's 26 cardinalities (%d ... %d rows; %.2f GB of tables)" % (
+                         min(CRITEO_VOCABS), max(CRITEO_VOCABS), sum(CRITEO_VOCABS) * (E + 1) * 4 / 1e9),
+                     "samples_per_s": K * B / tmed, "ms_per_step": tmed / K * 1e3, "regions_ms": [t * 1e3 for t in tm],
+                     "parity_max_rel": par_m["max_rel"], "parity": par_m}
+            del model_m, staged_m, logits_m, prep_m
+            torch.cuda.empty_cache()
+        except Exception as e:
+            mixed = {"error": repr(e)}
+
     result = None
     if rank == 0:
         value = world * B * K / elapsed if K else 0.0
@@ -789,20 +1014,20 @@ def main():
                             "hbm_algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
         if t_fused32 is not None:
             tf = DNN_FLOP_PER_SAMPLE * B / t_fused32 / 1e12
-            kernels.append({"kernel": "mlp_ring_kernel, fused gather, ONE isolated 4096-row launch (256 workgroups x 16 rows, every wave's weight "
+            kernels.append({"kernel": "mlp_ring_kernel / tile kernel, fused gather, ONE isolated %d-row launch (c2: 256 workgroups x 16 rows, every wave's weight " % B +
                                       "slice by LDS-DMA; rounds 1-4: mlp_kernel<2>, 128 workgroups x 32 rows, 26.8 us)",
                             "in_step": False, "us_per_launch": t_fused32 * 1e6, "bound": "mfma", "achieved": tf,
                             "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF})
         gather_gbs = ALG_BYTES_PER_SAMPLE * B / t_gather / 1e9
         mlp_tf = DNN_FLOP_PER_SAMPLE * B / t_mlp / 1e12
-        kernels.append({"kernel": "gather_fm_kernel (stand-alone fused 26-table gather + concat + linear + FM), isolated 4096-row launch",
+        kernels.append({"kernel": "gather_fm_kernel (stand-alone fused 26-table gather + concat + linear + FM), isolated %d-row launch" % B,
                         "in_step": False, "us_per_launch": t_gather * 1e6, "bound": "hbm", "achieved": gather_gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gather_gbs / HBM_PEAK_GBS})
         # what bounds it (profiles/r04_pmc_gather.json, profiles/r04_gather_bw_lab.log): 54 L2 requests per row against the 27 of the
         # pure row reads — the 26 four-byte linear-table gathers cost as many requests (and 64 B of fabric traffic each) as the rows;
         # pure random 64-B row reads reach 0.45-0.49 of 8 TB/s on this part, a read + concat-write kernel 0.41-0.46
         wr_bytes = (F * E + ND) * 4
-        for what, t_, rows_, with_write in (("logits only (no dnn_in write), isolated 4096-row launch", t_gather_lo, B, False),
+        for what, t_, rows_, with_write in (("logits only (no dnn_in write), isolated %d-row launch" % B, t_gather_lo, B, False),
                                             ("-> dnn_in, %d-row launch" % big_rows, t_gather_big, big_rows, True),
                                             ("logits only, %d-row launch" % big_rows, t_gather_big_lo, big_rows, False),
                                             ("RECORD-form tables (row + linear weight in one 128-B record) -> dnn_in, %d-row launch" % big_rows,
@@ -815,7 +1040,7 @@ def main():
                                 "bytes_counted": "ids + rows + linear entries + dense" + (" + the dnn_in write" if with_write else ""),
                                 "pure_random_64B_row_read_line_frac": 0.45,
                                 "evidence": "profiles/r04_pmc_gather.json, profiles/r05_gather_records_lab.log (requests per row: 54 plain, 28 records)"})
-        kernels.append({"kernel": "mlp_ring_kernel (stand-alone DNN 429-256-128-64 + head, f32 MFMA, 16-row workgroups), isolated 4096-row launch", "in_step": False,
+        kernels.append({"kernel": "stand-alone DNN %d-256-128-64 + head (f32 MFMA; c2: mlp_ring_kernel, 16-row workgroups), isolated %d-row launch" % (F * E + ND, B), "in_step": False,
                         "us_per_launch": t_mlp * 1e6, "bound": "mfma", "achieved": mlp_tf, "peak": F32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": mlp_tf / F32_MFMA_PEAK_TF})
         dom = kernels[0]
@@ -833,17 +1058,19 @@ def main():
         roofline["aggregate_frac"] = roofline["aggregate_achieved"] / F32_MFMA_PEAK_TF
         roofline["sustained_mfma_f32_peak_measured"] = F32_MFMA_SUSTAINED_TF
         roofline["frac_of_sustained"] = dom["achieved"] / F32_MFMA_SUSTAINED_TF if dom["unit"] == "TFLOP/s" else None
-        roofline["note"] = ("fp32 DNN: 301,696 FLOP/sample against 1,928 algorithmic B/sample -> the step is bound by the f32 matrix "
-                            "pipe (a 4096-row batch: 7.9 us of MFMA vs 1.0 us of HBM), so whole-forward HBM-roofline fractions "
-                            "are capped at ~0.12 in exact fp32 (SURVEY.md §7)")
+        roofline["note"] = ("fp32 DNN: %d FLOP/sample against %d algorithmic B/sample -> the step is bound by the f32 matrix "
+                            "pipe (a %d-row batch: %.1f us of MFMA vs %.1f us of HBM), so whole-forward HBM-roofline fractions "
+                            "are capped at ~%.2f in exact fp32 (SURVEY.md §7)" % (
+                                DNN_FLOP_PER_SAMPLE, ALG_BYTES_PER_SAMPLE, B, DNN_FLOP_PER_SAMPLE * B / F32_MFMA_PEAK_TF / 1e6,
+                                ALG_BYTES_PER_SAMPLE * B / HBM_PEAK_GBS / 1e3,
+                                F32_MFMA_PEAK_TF * 1e12 / DNN_FLOP_PER_SAMPLE * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS))
         result = {
-            "metric": "samples/sec fwd DeepFM Criteo-26x1e5 emb16 b4096", "value": value, "unit": "samples/s",
+            "metric": WORKLOADS[WORKLOAD]["metric"], "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3 if K else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DeepFM forward, 26 sparse x vocab 1e5 + 13 dense, emb_dim 16, "
-                                   "DNN 256-128-64, batch 4096 per GPU, ids int32 [F,B] device-resident, ids %s, ring of %d "
+            "config": {"workload": "%s, ids int32 [F,B] device-resident, ids %s, ring of %d "
                                    "distinct batches, the K steps issued as %d call(s) of %d consecutive batches (%s)" % (
-                                       args.dist, ring, len(launches), G,
+                                       WORKLOADS[WORKLOAD]["config"], args.dist, ring, len(launches), G,
                                        "fused gather+DNN, %s kernel launch(es) per call" % "+".join(str(launches_of(pl)) for pl in plans[:1]) if fused
                                        else "2 launches per span"),
                        "per_gpu_batch": B, "global_batch": B * world, "launch_batches": G,
@@ -857,7 +1084,9 @@ def main():
             "roofline": roofline, "kernels": kernels,
             "whole_forward_frac_of_hbm_roofline": (value / world) * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
             "fp32_ceiling_of_that_fraction": F32_MFMA_PEAK_TF * 1e12 / DNN_FLOP_PER_SAMPLE * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
-            "long_run": long_run, "predict_e2e": e2e, "one_launch_per_batch": per_batch, "zipf_ids": zipf,
+            "long_run": long_run, "predict_e2e": e2e, "one_launch_per_batch": per_batch, "zipf_ids": zipf, "criteo_vocabularies": mixed,
+            "collective": None if dist is None else {"backend": "RCCL (torch.distributed 'nccl')" if not host_exchange else "gloo (host tensors)",
+                                                     "world_size": int(dist.get_world_size()), "ranks_share_one_gpu": bool(args.share_gpu)},
             "exchange": None if exchange is None else {
                 "what": "one RCCL all-gather of the K steps' logits (%d floats per rank) behind the K steps, %s; median over the value "
                         "regions, MAX over ranks" % (K * B, "INSIDE the timed region" if world > 1 else "outside the 1-GPU region"),
@@ -875,6 +1104,19 @@ def main():
             "clock_prewarm_ms": args.prewarm_ms,
             "parity_max_rel": None if parity is None else parity["max_rel"], "parity": parity,
         }
+        if mixed is not None and "parity" in mixed and not mixed["parity"]["within_1e-4"]:
+            raise SystemExit("bench.py: the unequal-vocabulary configuration is outside the 1e-4 parity bar: %r" % (mixed["parity"],))
+        if WORKLOAD == "c5" and world == 1 and K > 0 and not args.no_traffic and not args.no_secondary:
+            # the stand-alone gather on tables that do not fit the Infinity Cache: time (kernels[] above) and the memory-side counters
+            gh = measure_gather_traffic(big_rows, args.dist)
+            t_g = t_gather_big_lo
+            result["gather_hbm_resident"] = {
+                "kernel": "gather_fm_kernel, logits only, %d-row launch over 26 x [1e7, 32] fp32 tables (34 GB: HBM-resident)" % big_rows,
+                "us_per_launch": None if not t_g else t_g * 1e6,
+                "algorithmic_GBps": None if not t_g else ALG_BYTES_PER_SAMPLE * big_rows / t_g / 1e9,
+                "frac_of_hbm_peak": None if not t_g else ALG_BYTES_PER_SAMPLE * big_rows / t_g / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * big_rows, "counters": gh,
+                "counter_note": "FETCH_SIZE in bytes at the L2's memory side; TCP_TCC_READ_REQ_sum = vector-L1 -> L2 read requests"}
         if parity is not None and not parity["within_1e-4"]:
             raise SystemExit("bench.py: the timed region's output is outside the 1e-4 parity bar: %r" % (parity,))
         if world == 1 and not args.no_cpu_baseline:
@@ -886,7 +1128,7 @@ def main():
                                   "(profiles/r05_longrun_diagnosis.md); timed legs are taken with the BLAS workers of earlier host work asleep"}
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     return result
 

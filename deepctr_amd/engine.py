@@ -1120,14 +1120,26 @@ class Model(object):
         return name if isinstance(name, str) else getattr(name, "__name__", str(name))
 
     @on_model_device
-    def evaluate(self, x, y, batch_size=256, verbose=0, return_dict=False, **kwargs):
+    def evaluate(self, x, y, batch_size=256, verbose=0, return_dict=False, steps=None, **kwargs):
         """Loss of the compiled (or the task's default) loss function, followed by the compiled metrics — a scalar when there are
-        none, a list [loss, metric...] otherwise, or a name -> value dict with ``return_dict=True`` (tf.keras.Model.evaluate)."""
+        none, a list [loss, metric...] otherwise, or a name -> value dict with ``return_dict=True`` (tf.keras.Model.evaluate,
+        /root/reference/docs/source/Model_Methods.md:24-43).  As in tf.keras the reported loss is the data loss PLUS the l2 penalties
+        of the constructor's regularisers (the same total fit() reports as `loss`; the metrics carry the bare data terms).  ``steps``:
+        only the first ``steps`` batches of ``batch_size`` rows are evaluated."""
+        if steps is not None:
+            rows = int(steps) * int(batch_size or 0)
+            if rows <= 0:
+                raise ValueError("evaluate(steps=%r) needs a batch_size" % (steps,))
+            feed = self._as_feed(x)
+            x = {k: np.asarray(v)[:rows] for k, v in feed.items()}
+            y = np.asarray(y)[:rows]
         p = self.predict(x, batch_size).reshape(-1).astype(np.float64)
         y = np.asarray(y, dtype=np.float64).reshape(-1)
         c = self._compiled or {}
         loss_name = c.get("loss") or ("binary_crossentropy" if self.task == "binary" else "mse")
         loss = self._metric("binary_crossentropy" if loss_name in ("binary_crossentropy", "logloss") else "mse", p, y)
+        from .training import l2_penalty
+        loss += l2_penalty(self)
         metrics = list(c.get("metrics") or [])
         vals = [(self._metric_name(m), self._metric(m, p, y)) for m in metrics]
         if return_dict:

@@ -113,10 +113,12 @@ def fit_distributed(model, x, y, batch_size=256, epochs=1, verbose=0, shuffle=Tr
     """``model.fit`` with every GLOBAL batch of ``batch_size`` rows split across the ranks of the process group (the reference's
     multi-GPU example trains: examples/run_classification_criteo_multi_gpu.py:47-52).  Every rank passes the same ``x`` / ``y`` and
     holds the same weights; gradients are exchanged once per step (training._DataParallel: the touched rows of the embedding tables
-    + the dense gradients in one all-reduce) and every rank applies the same update, so the replicas stay identical.  Returns the
-    History of ``fit`` (the loss is the mean over all ranks' rows)."""
+    + the dense gradients in one all-reduce) and every rank applies the same update, so the replicas stay identical.  Models with
+    BatchNormalization / Dice (DIN's default) train with per-replica batch statistics, as keras multi_gpu_model's replicas do; their
+    stored statistics ride the same all-reduce (training._DataParallel).  Returns the History of ``fit`` (the loss is the mean over all
+    ranks' rows)."""
     from .training import _DataParallel, fit_model
-    dp = _DataParallel(group, seed)
+    dp = _DataParallel(group, seed, device=model.device if model.device.type == "cuda" else None)
     with torch.cuda.device(model.device) if model.device.type == "cuda" else _null():
         return fit_model(model, x, y, batch_size=batch_size, epochs=epochs, verbose=verbose if dp.rank == 0 else 0, shuffle=shuffle,
                          _dp=dp, **kwargs)

@@ -188,6 +188,19 @@ def frozen_weights(model):
     return out
 
 
+def l2_penalty(model, regs=None):
+    """sum over the regularised weights of l2 * sum(w^2), in float64 — the value tf.keras adds to the data loss wherever it reports a
+    loss: fit's `loss`, evaluate() / test_on_batch, `val_loss` (regularisers: reference inputs.py:22, layers/core.py:170,
+    interaction.py:100,258,387; docs/source/Model_Methods.md:24-43).  No float64 copy of a table is made (C5's tables are 1.3 GB each)."""
+    if regs is None:
+        frozen = frozen_weights(model)
+        regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
+    tot = 0.0
+    for t, l2 in regs:
+        tot += l2 * float(torch.linalg.vector_norm(t.detach().reshape(-1), dtype=torch.float64).item()) ** 2
+    return tot
+
+
 def regularized_weights(model):
     """[(tensor, l2)] for every weight the reference attaches ``l2(l2_reg_*)`` to: embedding tables (inputs.py:22-41), the
     linear part (feature_column.py:171-210, layers/utils.py:142-158), DNN kernels (core.py:160-166), CrossNet / CrossNetMix
@@ -428,29 +441,46 @@ class _DataParallel(object):
          gradient], each rank's share scaled by B_local / B_global (the loss is a mean over the GLOBAL batch),
     after which every rank applies the same optimizer step to the same gradients: the replicas stay bit-identical with each other.
     At C2 and 8 x 4096 rows that is ~50 MB per step instead of the 177 MB of the tables (C5: 218 MB instead of 34 GB).  The epoch's
-    loss is one more all-reduce per epoch.  Models that take statistics over the batch (training-mode BatchNormalization / Dice) are
-    refused: a shard's statistics are not the batch's."""
+    loss is one more all-reduce per epoch.
 
-    def __init__(self, group=None, seed=None):
+    Models that take statistics over the batch while training (BatchNormalization: DNN(use_bn=True), layers/core.py:200-201; Dice:
+    layers/activation.py:37-64, DIN's default att_activation, models/sequence/din.py:25-27) train with PER-REPLICA statistics — every
+    rank normalises its own sub-batch with that sub-batch's mean / variance, exactly what the replicas of keras multi_gpu_model (the
+    reference's only multi-GPU form) do.  The STORED statistics (moving_mean / moving_variance, which multi_gpu_model's replicas race to
+    assign) ride the step's one all-reduce: every rank moves its copy with its sub-batch's statistics, the copies are then replaced by
+    their B_local / B_global-weighted mean = momentum * old + (1 - momentum) * (weighted mean of the replicas' batch statistics), so
+    the replicas stay bit-identical with each other here too.  Not the whole-batch statistics: that would take a second exchange in
+    the middle of every forward and backward pass, and is not what the reference's replicas compute."""
+
+    def __init__(self, group=None, seed=None, device=None):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("fit_distributed needs an initialised torch.distributed process group")
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.host = dist.get_backend(group) == "gloo"          # gloo exchanges host tensors (several ranks may share one GPU)
+        # device tensors of the collectives live on the MODEL's device (RCCL: one GPU per rank — not on whatever device is current)
+        self.device = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if not self.host else None)
         s = torch.tensor([int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)], dtype=torch.int64)
         self._bcast(s)
         self.rng = np.random.RandomState(int(s.item()))         # the SAME shuffle on every rank
         self._tables = None
+        self._moving = None
 
     def _bcast(self, t):
         if self.host:
             self.dist.broadcast(t, src=0, group=self.group)
             return t
-        d = t.cuda()
+        d = t.to(self.device)
         self.dist.broadcast(d, src=0, group=self.group)
         t.copy_(d.cpu())
         return t
+
+    def moving_statistics(self, model):
+        """The stored BatchNormalization / Dice statistics of a model (class docstring): they ride the gradient all-reduce."""
+        if self._moving is None:
+            self._moving = [t for name, t in model.named_weights() if name.rsplit("/", 1)[-1] in ("moving_mean", "moving_variance")]
+        return self._moving
 
     def _all_reduce(self, t):
         if self.host and t.is_cuda:
@@ -514,6 +544,8 @@ class _DataParallel(object):
             parts.append(p.g.index_select(0, u).reshape(-1))
             parts.extend(q.g.view(q.w.shape[0], -1).index_select(0, u).reshape(-1) for q in comp[id(p)])
         parts.extend(p.g.reshape(-1) for p in dense)
+        moving = self.moving_statistics(tr.model)                  # (scaled like the gradients: their sum is the weighted mean)
+        parts.extend(t.reshape(-1) for t in moving)
         flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float32, device=dev)
         if scale != 1.0:
             flat.mul_(scale)
@@ -532,22 +564,33 @@ class _DataParallel(object):
             n = p.g.numel()
             p.g.copy_(flat[o:o + n].view_as(p.g))
             o += n
+        for t in moving:
+            n = t.numel()
+            t.copy_(flat[o:o + n].view_as(t))
+            o += n
 
-    def exchange_torch(self, params, b_local, b_global):
-        """The torch-autograd step: one flat all-reduce over every .grad (dense tables included — the fallback step is not the fast one)."""
+    def exchange_torch(self, params, b_local, b_global, moving=()):
+        """The torch-autograd step: one flat all-reduce over every .grad (dense tables included — the fallback step is not the fast one)
+        and the stored BatchNormalization / Dice statistics ``moving`` (class docstring)."""
         scale = float(b_local) / float(max(b_global, 1))
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]) * scale
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] +
+                         [t.detach().reshape(-1) for t in moving]) * scale
         self._all_reduce(flat)
         o = 0
         for p in params:
             n = p.numel()
             p.grad = flat[o:o + n].view_as(p).clone()
             o += n
+        with torch.no_grad():
+            for t in moving:
+                n = t.numel()
+                t.copy_(flat[o:o + n].view_as(t))
+                o += n
 
     def loss_mean(self, total, count):
         t = torch.tensor([float(total), float(count)], dtype=torch.float64)
         if not self.host:
-            t = t.cuda()
+            t = t.to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return float(t[0].item()) / max(float(t[1].item()), 1.0)
 
@@ -562,9 +605,6 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
     tr = getattr(model, "_hip_trainer", None)
     if tr is None or tr.kind != model._compiled["optimizer"].lower():
         tr = model._hip_trainer = HipTrainer(model, model._compiled["optimizer"])
-    if dp is not None and tr.batch_statistics():
-        raise NotImplementedError("fit_distributed: this model takes statistics over the batch while training (BatchNormalization / "
-                                  "Dice): a rank's shard would see other statistics than the global batch")
     perm_of = np.random.permutation if dp is None else dp.permutation
     cursor = _BatchCursor(n_tr, bs, steps, (lambda: permute_staged_(
         staged, yt, torch.from_numpy(perm_of(n_tr)).to(yt.device), wt)) if shuffle else None)
@@ -572,7 +612,7 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
     regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
 
     def penalty():
-        return float(sum(l2 * float((t.double() * t.double()).sum().item()) for t, l2 in regs)) if regs else 0.0
+        return l2_penalty(model, regs)
     pen0 = penalty()
     for ep in range(initial_epoch, epochs):
         # the epoch's loss: dctr_bce_grad adds every batch's summed loss into that batch's element of ONE device vector (summed in
@@ -602,9 +642,10 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
     return epoch_end.finish()
 
 
-_FIT_UNSUPPORTED = ("validation_steps",)
-_FIT_OPTIONS = ("sample_weight", "class_weight", "steps_per_epoch", "initial_epoch")
-_FIT_IGNORED = ("workers", "use_multiprocessing", "max_queue_size", "validation_batch_size", "validation_freq")
+_FIT_UNSUPPORTED = ()
+_FIT_OPTIONS = ("sample_weight", "class_weight", "steps_per_epoch", "initial_epoch", "validation_steps", "validation_batch_size",
+                "validation_freq")
+_FIT_IGNORED = ("workers", "use_multiprocessing", "max_queue_size")
 
 
 class _EpochEnd(object):
@@ -614,8 +655,20 @@ class _EpochEnd(object):
     ``model.stop_training`` ends the loop.  Callback classes themselves are tf.keras' and out of scope: any object with
     that method works."""
 
-    def __init__(self, model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks):
+    def __init__(self, model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks, validation_steps=None,
+                 validation_batch_size=None, validation_freq=1):
         self.model, self.bs, self.epochs, self.verbose = model, bs, epochs, verbose
+        # tf.keras.Model.fit: validation runs at the end of epoch e (1-based) when e % validation_freq == 0 (an int) or e is in
+        # validation_freq (a collection); over the first `validation_steps` batches of `validation_batch_size` (default: batch_size)
+        # rows when validation_steps is given, else over all validation rows
+        self.val_bs = int(validation_batch_size) if validation_batch_size else bs
+        self.val_steps = None if validation_steps is None else int(validation_steps)
+        self.val_freq = validation_freq if validation_freq is not None else 1
+        if isinstance(self.val_freq, (int, np.integer)):
+            if int(self.val_freq) < 1:
+                raise ValueError("fit(validation_freq=%r): an int >= 1 or a collection of epochs" % (validation_freq,))
+        else:
+            self.val_freq = set(int(e) for e in self.val_freq)
         self.val = None
         if validation_data is not None:
             if len(validation_data) != 2:
@@ -623,6 +676,11 @@ class _EpochEnd(object):
             self.val = (validation_data[0], np.asarray(validation_data[1], dtype=np.float32).reshape(-1))
         elif n_val:
             self.val = ({k: np.asarray(v)[n_tr:] for k, v in feed.items()}, y[n_tr:])
+        if self.val is not None and self.val_steps is not None:
+            n_rows = int(np.asarray(self.val[1]).shape[0])
+            have = (n_rows + self.val_bs - 1) // max(self.val_bs, 1)
+            if self.val_steps < 1 or self.val_steps > have:       # (tf.keras: "Your input ran out of data" and a truncated evaluation)
+                raise ValueError("fit(validation_steps=%d): the validation arrays hold %d batches of %d" % (self.val_steps, have, self.val_bs))
         self.callbacks = list(callbacks or [])
         self.hist = History()
         self.hist.history["loss"] = []
@@ -639,8 +697,9 @@ class _EpochEnd(object):
         h.history["loss"].append(loss)
         h.epoch.append(ep)
         logs = {"loss": loss}
-        if self.val is not None:
-            for k, v in self.model.evaluate(self.val[0], self.val[1], batch_size=self.bs, return_dict=True).items():
+        due = (ep + 1) % int(self.val_freq) == 0 if isinstance(self.val_freq, (int, np.integer)) else (ep + 1) in self.val_freq
+        if self.val is not None and due:
+            for k, v in self.model.evaluate(self.val[0], self.val[1], batch_size=self.val_bs, steps=self.val_steps, return_dict=True).items():
                 logs["val_" + k] = v                      # val_loss and val_<metric> of the compiled metrics
                 h.history.setdefault("val_" + k, []).append(v)
         if self.verbose:
@@ -703,7 +762,9 @@ def fit_model(model, x, y, batch_size=256, epochs=1, verbose=1, validation_split
     if initial_epoch < 0:
         raise ValueError("fit(initial_epoch=%d)" % initial_epoch)
     return fit(model, staged, yt, n_tr, bs, epochs, shuffle,
-               _EpochEnd(model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks),
+               _EpochEnd(model, feed, y, n_tr, n_val, bs, epochs, verbose, validation_data, callbacks,
+                         validation_steps=kwargs.get("validation_steps"), validation_batch_size=kwargs.get("validation_batch_size"),
+                         validation_freq=kwargs.get("validation_freq", 1)),
                wt=wt, steps=steps, initial_epoch=initial_epoch, **({} if _dp is None else {"dp": _dp}))
 
 
@@ -756,7 +817,7 @@ def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None,
                 lo, hi = (g_lo, g_hi) if dp is None else dp.shard(int(g_lo), int(g_hi))
                 if hi <= lo:                                       # (more ranks than rows in the last batch: zero gradients from here)
                     opt.zero_grad(set_to_none=True)
-                    dp.exchange_torch(params, 0, g_hi - g_lo)
+                    dp.exchange_torch(params, 0, g_hi - g_lo, dp.moving_statistics(model))
                     opt.step()
                     continue
                 model._begin()
@@ -781,7 +842,7 @@ def _fit_torch(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None,
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
                 if dp is not None:
-                    dp.exchange_torch(params, hi - lo, g_hi - g_lo)
+                    dp.exchange_torch(params, hi - lo, g_hi - g_lo, dp.moving_statistics(model))
                 opt.step()
                 tot += float(shown.item()) * (hi - lo)
                 cnt += hi - lo

@@ -703,8 +703,8 @@ class HipTrainer(object):
         self.model._raw_weight_writes = getattr(self.model, "_raw_weight_writes", 0) + 1
 
     def batch_statistics(self):
-        """True when the step takes statistics over the BATCH (training-mode BatchNormalization / Dice): a rank's shard of a global batch
-        then sees other statistics than the whole batch would — data-parallel fit refuses such models instead of training something else."""
+        """True when the step takes statistics over the BATCH (training-mode BatchNormalization / Dice): under data-parallel fit a rank
+        normalises with its own sub-batch's statistics (training._DataParallel: per-replica statistics, stored ones averaged)."""
         la = self.model.attention.local_att if self.is_din else None
         din_dice = la is not None and la.dnn.activation in ("dice", "Dice") and not getattr(self.model, "hip_dice_stored_statistics", False)
         return bool(self.bn_layers or self.dice_dnn or din_dice)

@@ -164,3 +164,100 @@ def test_data_parallel_fit_gloo_world2_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(ok for _, ok in res)
+
+
+def _fit_bn_worker(rank, world, port, q):
+    """Data-parallel fit of models with batch statistics (BatchNormalization, Dice in the DNN, DIN's Dice attention unit): per-replica
+    statistics (training._DataParallel).  Every global batch is built from two IDENTICAL halves, so a replica's sub-batch statistics ARE
+    the whole batch's and the single-process run on the same global batches is the exact reference — weights, stored statistics and
+    losses; the replicas must also stay bit-identical with each other on ordinary (non-duplicated, shuffled) data."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deepctr_amd import engine, training
+        from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+        from deepctr_amd.models import DIN, DeepFM
+        torch.set_num_threads(1)
+        rng = np.random.RandomState(3)
+        bs, nb = 32, 3
+        half = {"a": rng.randint(0, 20, (nb, bs // 2)), "b": rng.randint(0, 9, (nb, bs // 2)), "d": rng.rand(nb, bs // 2, 2).astype(np.float32)}
+        dup = {k: np.concatenate([v, v], axis=1).reshape((nb * bs,) + v.shape[2:]) for k, v in half.items()}      # batch = [h, h]
+        plain = {"a": rng.randint(0, 20, nb * bs + 7), "b": rng.randint(0, 9, nb * bs + 7), "d": rng.rand(nb * bs + 7, 2).astype(np.float32)}
+        cols = [SparseFeat("a", 20, 4), SparseFeat("b", 9, 4), DenseFeat("d", 2)]
+        # DIN (reference examples/run_din.py:7-33 scaled down), default att_activation = 'dice'
+        dcols = [SparseFeat("user", 5, 4), SparseFeat("item_id", 12, 4), DenseFeat("pay", 1),
+                 VarLenSparseFeat(SparseFeat("hist_item_id", 12, 4, embedding_name="item_id"), maxlen=4)]
+        dhalf = {"user": rng.randint(0, 5, (nb, bs // 2)), "item_id": rng.randint(1, 12, (nb, bs // 2)), "pay": rng.rand(nb, bs // 2).astype(np.float32),
+                 "hist_item_id": rng.randint(0, 12, (nb, bs // 2, 4))}
+        ddup = {k: np.concatenate([v, v], axis=1).reshape((nb * bs,) + v.shape[2:]) for k, v in dhalf.items()}
+
+        def run(make, fd, dp, shuffle, epochs=2):
+            n_rows = len(next(iter(fd.values())))
+            yv = (np.asarray(fd["b" if "b" in fd else "item_id"]) % 2).astype(np.float32)
+            model = make()
+            # (sgd: a bias in front of a BatchNormalization has a zero gradient up to rounding, which Adam's g / sqrt(v) turns into
+            # +- lr steps whose signs are rounding noise — not a property of the exchange)
+            model.compile("sgd", "binary_crossentropy")
+            staged = engine.Staged(n_rows)
+            model._stage_inputs(fd, staged)
+            h = training._fit_torch(model, staged, torch.from_numpy(yv.copy()), n_rows, bs, epochs, shuffle,
+                                    training._EpochEnd(model, fd, yv, n_rows, 0, bs, epochs, 0, None, None),
+                                    **({} if dp is None else {"dp": dp}))
+            return model.get_weights_by_name(), h.history["loss"]
+
+        cpu = torch.device("cpu")
+        makers = {
+            "bn": (lambda: DeepFM(cols, cols, dnn_hidden_units=(8, 4), dnn_use_bn=True, seed=7, device=cpu), dup, plain),
+            "dice": (lambda: DeepFM(cols, cols, dnn_hidden_units=(8,), dnn_activation="dice", seed=7, device=cpu), dup, plain),
+            "din": (lambda: DIN(dcols, ["item_id"], dnn_hidden_units=(8,), att_hidden_size=(6, 3), seed=7, device=cpu), ddup, None),
+        }
+        ok, why = True, []
+        for name, (make, fd_dup, fd_plain) in makers.items():
+            w_dp, loss_dp = run(make, fd_dup, training._DataParallel(seed=5), False)
+            w_1, loss_1 = run(make, fd_dup, None, False)
+            moved = [k for k in w_1 if k.endswith("moving_mean")]
+            assert moved, name
+            made = make().get_weights_by_name()
+            if not any(np.abs(w_1[k] - made[k]).max() > 0 for k in moved):
+                ok = False
+                why.append("%s: the stored statistics never moved" % name)
+            for k in w_1:
+                if not np.allclose(w_dp[k], w_1[k], rtol=5e-5, atol=5e-7):
+                    ok = False
+                    why.append("%s: %s differs from the single-process run by %.3g" % (name, k, np.abs(w_dp[k] - w_1[k]).max()))
+            if not np.allclose(loss_dp, loss_1, rtol=1e-5):
+                ok = False
+                why.append("%s: loss %r vs %r" % (name, loss_dp, loss_1))
+            if fd_plain is not None:                      # ordinary data, shuffled: replicas bit-identical (stored statistics included)
+                w_s, _ = run(make, fd_plain, training._DataParallel(seed=None), True)
+                flat = torch.from_numpy(np.concatenate([v.reshape(-1) for v in w_s.values()]).astype(np.float64))
+                other = flat.clone()
+                dist.broadcast(other, src=0)
+                if not torch.equal(flat, other):
+                    ok = False
+                    why.append("%s: replicas diverged" % name)
+        q.put((rank, bool(ok), why))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_fit_with_batch_statistics_gloo_world2():
+    """fit_distributed for BatchNormalization / Dice models — DIN's default att_activation='dice'
+    (/root/reference/deepctr/models/sequence/din.py:25-27, layers/activation.py:37-64): per-replica statistics as keras
+    multi_gpu_model's replicas take them, stored statistics averaged inside the step's all-reduce."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1] and all(ok for _, ok, _ in res), [w for _, _, w in res]

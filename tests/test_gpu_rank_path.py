@@ -66,6 +66,28 @@ def test_bench_under_torch_distributed_run_one_rank(device):
             json.dump({"plain": ref, "torchrun_nproc1": line, "cmd": " ".join(cmd)}, f)
 
 
+def test_bench_gpus2_starts_two_ranks(device):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py itself starts the two ranks (torch.distributed.run on 127.0.0.1)
+    and the line says n_gpus 2 — here both ranks on the box's one GPU (--share-gpu, exchange over gloo: RCCL wants a GPU per rank),
+    the same code path the 8-GPU command takes.  Without --share-gpu the same command on a 1-GPU box must exit non-zero, not print
+    an n_gpus 1 line."""
+    args = ["bench.py", "--gpus", "2", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--regions", "3",
+            "--prewarm-ms", "20"]
+    run = subprocess.run([sys.executable] + args + ["--share-gpu", "--backend", "gloo"], cwd=ROOT, env=_env(), capture_output=True,
+                         text=True, timeout=900)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-3000:])
+    line = _last_json_line(run.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 8 and line["collective"]["world_size"] == 2
+    assert line["config"]["global_batch"] == 2 * line["config"]["per_gpu_batch"] and line["exchange"]["ms"] > 0
+    assert line["parity"]["within_1e-4"] and line["value"] > 0
+    assert sum(1 for ln in run.stdout.splitlines() if ln.startswith("{")) == 1          # rank 0 prints the ONE line
+    import torch
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable] + args, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and "n_gpus" not in bad.stdout, bad.stdout[-500:]
+        assert "only 1 GPU" in (bad.stderr + bad.stdout)
+
+
 _CHILD = r'''
 import os, sys
 import numpy as np
@@ -267,6 +289,112 @@ def test_two_ranks_on_one_gpu_data_parallel_fit_matches_single_process(device):
         env = _env()
         env.update({"MASTER_PORT": port, "RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
         procs.append(subprocess.Popen([sys.executable, "-c", _CHILD_FIT % {"root": ROOT}], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    for r, (rc, out, err) in enumerate(outs):
+        assert rc == 0, (r, out[-2000:], err[-3000:])
+        assert "RANK%d_OK" % r in out, (r, out[-3000:])
+
+
+# ---- fit_distributed for models with batch statistics on the HIP step: BatchNormalization (DNN(use_bn=True)), Dice in the DNN, DIN with
+# its default att_activation='dice' (/root/reference/deepctr/models/sequence/din.py:25-27).  Per-replica statistics (as keras
+# multi_gpu_model's replicas take them); every global batch below is two IDENTICAL halves, so a replica's statistics are the whole
+# batch's and ONE process on the same global batches is the exact reference; on ordinary shuffled data the replicas stay bit-identical.
+_CHILD_FIT_BN = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from deepctr_amd import parallel
+from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+from deepctr_amd.models import DIN, DeepFM
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.RandomState(5)
+bs, nb = 1024, 3
+def dup(h):
+    return {k: np.concatenate([v, v], axis=1).reshape((nb * bs,) + v.shape[2:]) for k, v in h.items()}
+cols = [SparseFeat("C%%d" %% i, 300 + 40 * i, 8) for i in range(6)] + [DenseFeat("I%%d" %% i, 1) for i in range(3)]
+half = {"C%%d" %% i: rng.randint(0, 300 + 40 * i, (nb, bs // 2)).astype(np.int32) for i in range(6)}
+half.update({"I%%d" %% i: rng.rand(nb, bs // 2).astype(np.float32) for i in range(3)})
+feed = dup(half)
+plain = {k: rng.permutation(v) for k, v in feed.items()}
+E = 8
+dcols = [SparseFeat("user", 50, E), SparseFeat("gender", 2, E), SparseFeat("item_id", 200, E), SparseFeat("cate_id", 30, E), DenseFeat("pay_score", 1),
+         VarLenSparseFeat(SparseFeat("hist_item_id", 200, E, embedding_name="item_id"), maxlen=6),
+         VarLenSparseFeat(SparseFeat("hist_cate_id", 30, E, embedding_name="cate_id"), maxlen=6)]
+dhalf = {"user": rng.randint(0, 50, (nb, bs // 2)), "gender": rng.randint(0, 2, (nb, bs // 2)), "item_id": rng.randint(1, 200, (nb, bs // 2)),
+         "cate_id": rng.randint(1, 30, (nb, bs // 2)), "pay_score": rng.rand(nb, bs // 2).astype(np.float32)}
+hist = rng.randint(1, 200, (nb, bs // 2, 6)); hist[rng.rand(nb, bs // 2, 6) > 0.6] = 0
+dhalf["hist_item_id"] = hist
+dhalf["hist_cate_id"] = np.where(hist > 0, hist %% 29 + 1, 0)
+dfeed = dup(dhalf)
+cases = [("bn", lambda: DeepFM(cols, cols, dnn_hidden_units=(32, 16), dnn_use_bn=True, device=dev), feed, "C1"),
+         ("dice", lambda: DeepFM(cols, cols, dnn_hidden_units=(32, 16), dnn_activation="dice", device=dev), feed, "C1"),
+         ("din", lambda: DIN(dcols, ["item_id", "cate_id"], dnn_hidden_units=(32, 16), att_hidden_size=(16, 8), device=dev), dfeed, "item_id")]
+ok = True
+for name, make, fd, ycol in cases:
+    labels = (np.asarray(fd[ycol]) %% 2).astype(np.float32)
+    ws = {}
+    for mode in ("dp", "single"):
+        m = make()
+        r2 = np.random.RandomState(9)
+        w0 = {k: ((np.abs(r2.standard_normal(v.shape)) + 0.5) if k.endswith("moving_variance") else
+                  r2.standard_normal(v.shape) * (0.05 if k.endswith("embeddings") else 0.1)).astype(np.float32)
+              for k, v in m.get_weights_by_name().items()}
+        m.set_weights_by_name(w0)
+        m.compile("sgd", "binary_crossentropy")
+        if mode == "dp":
+            h = parallel.fit_distributed(m, fd, labels, batch_size=bs, epochs=2, shuffle=False)
+        else:
+            h = m.fit(fd, labels, batch_size=bs, epochs=2, shuffle=False, verbose=0)
+        assert getattr(m, "_hip_trainer", None) is not None and m._hip_trainer.batch_statistics(), "the HIP training step (batch statistics) did not run"
+        ws[mode] = (m.get_weights_by_name(), h.history["loss"])
+    moved = [k for k in w0 if k.endswith("moving_mean") and np.abs(ws["single"][0][k] - w0[k]).max() > 0]
+    if not moved:
+        print("rank %%d %%s: the stored statistics never moved" %% (rank, name), flush=True)
+        ok = False
+    for k, v in ws["single"][0].items():
+        good = bool(np.allclose(ws["dp"][0][k], v, rtol=2e-4, atol=2e-6))
+        if not good:
+            print("rank %%d %%s %%s: max diff %%.3e" %% (rank, name, k, np.abs(ws["dp"][0][k] - v).max()), flush=True)
+        ok = ok and good
+    ok = ok and bool(np.allclose(ws["dp"][1], ws["single"][1], rtol=1e-4))
+    print("rank %%d %%s losses dp %%r single %%r" %% (rank, name, ws["dp"][1], ws["single"][1]), flush=True)
+    if fd is feed:
+        m = make()
+        m.compile("adam", "binary_crossentropy")
+        h = parallel.fit_distributed(m, plain, (plain["C1"] %% 2).astype(np.float32), batch_size=bs, epochs=2, shuffle=True)
+        flat = torch.from_numpy(np.concatenate([v.reshape(-1) for v in m.get_weights_by_name().values()]).astype(np.float64))
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        same = bool(torch.equal(flat, other))
+        print("rank %%d %%s replicas identical on shuffled data: %%s" %% (rank, name, same), flush=True)
+        ok = ok and same
+dist.barrier()
+dist.destroy_process_group()
+print("RANK%%d_OK" %% rank if ok else "RANK%%d_MISMATCH" %% rank, flush=True)
+'''
+
+
+def test_two_ranks_on_one_gpu_data_parallel_fit_with_batch_statistics(device):
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = _env()
+        env.update({"MASTER_PORT": port, "RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+        procs.append(subprocess.Popen([sys.executable, "-c", _CHILD_FIT_BN % {"root": ROOT}], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
     for r, p in enumerate(procs):
