@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 E_UNSUPPORTED = -5               # DCTR_E_UNSUPPORTED: valid request this build does not implement
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
@@ -212,6 +212,7 @@ SYMBOLS = {
     "dctr_bi_interaction_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_inner_product_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dctr_mlp_workspace_bytes": (c_sz, [ctypes.POINTER(MlpArgs)]),
+    "dctr_mlp_fwd_supported": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), ctypes.c_int32, ctypes.c_int32]),
     "dctr_crossnet_fold_consts": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "dctr_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), c_vp]),
     "dctr_embed_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(GatherFmArgs), ctypes.POINTER(MlpArgs), c_i32, c_i32, c_vp]),

@@ -30,7 +30,7 @@ SOURCES = [
     "mlp_kernels_rt1.hip",
     "mlp_kernels_rt2.hip",
     "mlp_kernels_rt4.hip",
-    "mlp_kernels_ring.hip", "mlp_kernels_wide.hip",
+    "mlp_kernels_ring.hip", "mlp_kernels_wide.hip", "mlp_kernels_layered.hip",
     "stream_kernels.hip",
     "chain_kernels.hip",
     "chain_kernels_r2w8_m42.hip",

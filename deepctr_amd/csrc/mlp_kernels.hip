@@ -35,6 +35,10 @@ size_t bf3_workspace_bytes(int in_dim);                                         
 namespace dctr_stream {
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);
 }
+namespace dctr_mlp {
+size_t layered_workspace_bytes(const dctr_mlp_args_t* a);                               // mlp_kernels_layered.hip
+int launch_layered(const dctr_mlp_args_t* a, hipStream_t stream, int (*head)(const dctr_mlp_args_t*, void*));
+}
 
 namespace {
 
@@ -53,17 +57,31 @@ size_t mlp_lds_bytes(int rows, int lda, size_t cross_bytes = 0) {
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
+// the 16-row workgroups of mlp_wide_kernel (the smallest tile any one-launch form has) hold two tiles of the widest layer
+bool widest_layer_fits_lds(const dctr_mlp_args_t* a) {
+    int wmax = 0;
+    for (int l = 0; l < a->n_layers; ++l) wmax = a->units[l] > wmax ? a->units[l] : wmax;
+    return mlp_lds_bytes(16, (((wmax > 64 ? wmax : 64) + 63) & ~63) + 4) <= LDS_PER_CU;
+}
+
 }  // namespace
 
-// activations live in LDS; only the exploratory bf16x3 precision keeps a packed copy of the weights in HBM
+// activations live in LDS — except (a) the exploratory bf16x3 precision, which keeps a packed copy of the weights in HBM, and (b) DNNs
+// with a layer wider than the LDS tile holds (> 1,216 units), which run layer by layer through two activation buffers
 extern "C" size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* a) {
-    if (a == nullptr || a->precision < 1 || a->precision > 2 || a->in_dim < 1) return 0;
-    return dctr_chain::bf3_workspace_bytes(a->in_dim);
+    if (a == nullptr || a->in_dim < 1) return 0;
+    if (a->precision == 1 || a->precision == 2) return dctr_chain::bf3_workspace_bytes(a->in_dim);
+    if (a->precision != 0 || a->n_layers < 1 || a->n_layers > MAX_LAYERS || a->units == nullptr) return 0;
+    return widest_layer_fits_lds(a) ? 0 : dctr_mlp::layered_workspace_bytes(a);
 }
 
 static thread_local int g_last_fwd_kernel = -1;   // DCTR_FWD_KERNEL_* of this thread's last dctr_embed_mlp_fwd launch
 
-static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream) {
+static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream, bool dry = false);
+static int mlp_head_launch(const dctr_mlp_args_t* a, void* stream) { return mlp_launch(a, nullptr, 0, 0, stream); }
+
+// dry: every check of a launch, no launch (dctr_mlp_fwd_supported / dctr_embed_mlp_fwd_supported)
+static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream, bool dry) {
     DCTR_REQUIRE(a == nullptr || a->precision == 0 || ((a->precision == 1 || a->precision == 2) && ga != nullptr), DCTR_E_UNSUPPORTED,
                  "mlp_fwd: precision %d (0 = fp32; 1 / 2 = bf16x3 with dctr_embed_mlp_fwd only)", a != nullptr ? a->precision : 0);
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_fwd: null args");
@@ -169,6 +187,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         DCTR_REQUIRE(!forced || ok, DCTR_E_UNSUPPORTED,
                      "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 4 / 8 / 16 / 32 / 64, instantiated units, a head", a->tile_rows);
         if (ok) {
+            if (dry) return DCTR_OK;
             const int rc = dctr_chain::launch(a, ga, fm_used, lin_used, a->tile_rows, (hipStream_t)stream);
             if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_CHAIN;
             return rc;
@@ -177,7 +196,8 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     // fused launches with >= 64 rows per CU (or tile_rows == 64): the streaming kernel, when the model is eligible
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 64)) {
         int rc = DCTR_OK;
-        if (dctr_stream::try_launch(a, ga, fm_used, lin_used, a->tile_rows == 64, (hipStream_t)stream, &rc)) {
+        if (dry && dctr_stream::eligible(a, ga, a->tile_rows == 64)) return DCTR_OK;
+        if (!dry && dctr_stream::try_launch(a, ga, fm_used, lin_used, a->tile_rows == 64, (hipStream_t)stream, &rc)) {
             if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_STREAM;
             return rc;
         }
@@ -222,12 +242,19 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     if (lda == 0 && ga != nullptr && a->tile_rows == 0 && dctr_chain::eligible(a, ga, true)) {
         // a DNN input too wide for the LDS tile (e.g. 33 fields of embedding_dim 64: [16, 2128] x 2 floats) on a launch below 64 rows
         // per CU: the row-chained kernel streams layer 0 by k-block and holds no input tile — its tail phase takes the rows
+        if (dry) return DCTR_OK;
         const int rc = dctr_chain::launch(a, ga, fm_used, lin_used, 0, (hipStream_t)stream);
         if (rc == DCTR_OK) g_last_fwd_kernel = DCTR_FWD_KERNEL_CHAIN;
         return rc;
     }
     if (lda == 0 && ga == nullptr && !cross && a->precision == 0 && (a->n_layers >= 1 || a->has_head)) {
+        if (a->n_layers >= 1 && !widest_layer_fits_lds(a)) {
+            // a layer too wide for any LDS tile (> 1,216 units): layer by layer through the caller's workspace (mlp_kernels_layered.hip)
+            if (dry) return DCTR_OK;
+            return dctr_mlp::launch_layered(a, (hipStream_t)stream, mlp_head_launch);
+        }
         // an input row wider than the tile, read from HBM: 16-row workgroups that walk it in K chunks (mlp_kernels_wide.hip)
+        if (dry) return DCTR_OK;
         int wmax = 0;
         for (int l = 0; l < a->n_layers; ++l) wmax = a->units[l] > wmax ? a->units[l] : wmax;
         int kc = 512;
@@ -241,7 +268,9 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
         return launch_wide(p, kc, (unsigned)wblocks, mlp_lds_bytes(16, wl), (hipStream_t)stream);
     }
     DCTR_REQUIRE(lda > 0, DCTR_E_UNSUPPORTED,
-                 "mlp_fwd: layer widths do not fit the 160 KiB LDS tile (or are too small for the gather partial sums)");
+                 "mlp_fwd: layer widths do not fit the 160 KiB LDS tile (or are too small for the gather partial sums)%s",
+                 ga != nullptr ? "; dctr_embed_gather_fm + dctr_mlp_fwd take this shape" : "");
+    if (dry) return DCTR_OK;
     p.lda = lda;
     const int rows = 16 * rt;
     const size_t lds = mlp_lds_bytes(rows, lda, cross ? ((size_t)CROSS_NV * rows + 8 + (size_t)CROSS_NV * ((a->in_dim + 63) & ~63)) * sizeof(float) : 0);
@@ -287,6 +316,15 @@ extern "C" int dctr_crossnet_fold_consts(const float* cross_w, const float* cros
 }
 
 extern "C" int dctr_mlp_fwd(const dctr_mlp_args_t* a, void* stream) { return mlp_launch(a, nullptr, 0, 0, stream); }
+
+// Would the launch be taken?  Every argument check and kernel-shape decision of dctr_mlp_fwd (g == NULL) / dctr_embed_mlp_fwd, no launch.
+// 1 = yes (dctr_mlp_fwd: given the workspace dctr_mlp_workspace_bytes() asks for), 0 = no — dctr_last_error() says why.  The host asks
+// instead of re-deriving the library's limits (LDS tile sizes, instantiated shapes).
+extern "C" int dctr_mlp_fwd_supported(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit, int32_t add_lin_logit) {
+    if (m == nullptr) return 0;
+    if (g != nullptr && !(m->has_head || (!add_fm_logit && !add_lin_logit))) return 0;
+    return mlp_launch(m, g, add_fm_logit ? 1 : 0, add_lin_logit ? 1 : 0, nullptr, true) == DCTR_OK ? 1 : 0;
+}
 
 extern "C" int dctr_embed_mlp_fwd(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit,
                                   int32_t add_lin_logit, void* stream) {

@@ -75,13 +75,17 @@ __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__
 // ~23 G distinct-address atomics/s) and a row census per table that lets rows hit once take a plain 16-B read-modify-write
 // (62 us + two 6.6-us census launches = the same: then the ~640 k random sector accesses of the kernel are the limit, at the
 // rate the forward gather reaches at this launch size).
-template <int LPR, bool HASH>
+// Any embedding width (round 6; the reference's embedding_dim is free, feature_column.py:44-45 gives e.g. 102 for "auto"): a lane owns
+// the VEC-float chunks q, q + LPR, q + 2 LPR, ... of its sample's rows — ONE chunk when the widths fit 4 LPR <= 64 floats (the loop
+// below then runs once: the kernel of rounds 2-5), several for wider rows; VEC = 1 (element per lane, scalar loads) when some width is
+// not a multiple of 4 (rows are then not 16-B aligned).  The sum S is per chunk, so a chunk's share closes before the next starts.
+template <int LPR, bool HASH, int VEC = 4>
 __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_t p, const dctr_field_grad_t* __restrict__ gr,
                                                             const float* __restrict__ d_in, int64_t d_stride,
                                                             const float* __restrict__ d_fm, const float* __restrict__ d_lin,
                                                             float* __restrict__ g_dense_lin_w,
                                                             const int32_t* __restrict__ dense_lin_rows) {
-    constexpr int VEC = 4, SPW = 64 / LPR, NWV = 4;
+    constexpr int SPW = 64 / LPR, NWV = 4;
     __shared__ float s_part[NWV][64][VEC];
     // low-cardinality fields (DIN's `gender`: 2 rows for 2,048 samples = 1,024 atomics per address, ~90 ns each): their gradient
     // rows (and linear rows) accumulate in LDS and leave as one atomic per element and workgroup
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
     for (int i = threadIdx.x; i < s_total; i += 256) s_small[i] = 0.f;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = lane / LPR, q = lane % LPR;
+    const int s = lane / LPR, q0 = lane % LPR;
     const int64_t b = (int64_t)blockIdx.x * SPW + s;
     const bool valid = b < p.batch;
     cfield_ptr F = (cfield_ptr)p.fields;
@@ -117,9 +121,13 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
         }
         return r;
     };
+    for (int q = q0; (q - q0) * VEC < p.max_dim; q += LPR) {      // (workgroup-uniform trip count: the barrier below is safe)
     // pass 1: S = sum over the FM fields of e_f (this wave's fields, then the four partial sums)
-    float S[VEC] = {0.f, 0.f, 0.f, 0.f};
+    float S[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) S[c] = 0.f;
     if (d_fm != nullptr) {
+        if (q != q0) __syncthreads();                              // (the previous chunk's partial sums have been read)
         for (int j = wave; j < p.n_fields; j += NWV) {
             const FieldRegs f = load_field(F, j);
             if (!f.in_fm) continue;
@@ -146,18 +154,17 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
         float* gl = gr[j].g_lin_table;
         const int so = j < SMALL_FIELDS ? s_soff[j] : -1;
         if (ok && gt != nullptr) {
-            float g[VEC] = {0.f, 0.f, 0.f, 0.f};
-            if (f.out_offset >= 0 && d_in != nullptr) {
-                const float4 t = *reinterpret_cast<const float4*>(d_in + b * d_stride + f.out_offset + q * VEC);
-                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
-            }
+            float g[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) g[c] = 0.f;
+            if (f.out_offset >= 0 && d_in != nullptr) load_vec<VEC>(d_in + b * d_stride + f.out_offset + q * VEC, g);
             if (f.in_fm && d_fm != nullptr) {
                 float v[VEC];
                 load_vec<VEC>(f.table + r * f.dim + q * VEC, v);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) g[c] = fmaf(dfm, S[c] - v[c], g[c]);
             }
-            if (gr[j].touched != nullptr) gr[j].touched[(r * f.dim) / VEC + q] = 1;      // (dim % 4 == 0: all_dim4 of the launch)
+            if (gr[j].touched != nullptr) gr[j].touched[(r * f.dim + q * VEC) >> 2] = 1;  // (one byte per 16-B group: tables with dim % 4 == 0 only)
             if (so >= 0) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) atomicAdd(&s_small[so + (int)r * f.dim + q * VEC + c], g[c]);
@@ -172,6 +179,8 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
             else unsafeAtomicAdd(gl + r, dlin);
         }
     }
+    }   // chunks
+    const int q = q0;
     // dense . Linear.kernel: d w[k] += sum_b d_lin[b] * dense[b, k]  — dense column k by wave k % 4, the wave's samples summed
     // before the one atomic (4096 atomics on one address serialise)
     if (g_dense_lin_w != nullptr && p.n_dense > 0) {
@@ -211,14 +220,16 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
 // contributed  e_t * wt_t * mk_t  (sum), the same / denom (mean), or was the per-dimension maximum (max); the
 // gradient of the pooled vector is scattered back to the rows with those factors.  Per-position weights are inputs.
 // ---------------------------------------------------------------------------------------------------
-template <int LPR>
+// (any embedding width, as gather_fm_bwd_kernel: a lane walks the VEC-float chunks q0, q0 + LPR, ... of the row; VEC = 1 when dim % 4 != 0)
+template <int LPR, int VEC = 4>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const float* __restrict__ d_out, int64_t d_stride,
                                                        const float* __restrict__ d_lin_out, float* __restrict__ g_table,
                                                        float* __restrict__ g_lin_table) {
-    constexpr int VEC = 4, SPB = 256 / LPR;
-    const int s = threadIdx.x / LPR, q = threadIdx.x % LPR;
+    constexpr int SPB = 256 / LPR;
+    const int s = threadIdx.x / LPR, q0 = threadIdx.x % LPR;
     const int64_t b = (int64_t)blockIdx.x * SPB + s;
     if (b >= a.batch) return;
+    for (int q = q0; q * VEC < a.dim || q == q0; q += LPR) {
     const int T = a.maxlen;
     const bool by_len = a.length != nullptr;
     const int len = by_len ? a.length[b] : 0;
@@ -238,7 +249,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const
         const float w = a.weight[b * (int64_t)T + t];
         return wnorm ? expf((m ? w : PAD) - wmax) / wden : (m ? w : 0.f);
     };
-    float dv[VEC] = {0.f, 0.f, 0.f, 0.f};
+    float dv[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) dv[c] = 0.f;
     if (colok && d_out != nullptr) load_vec<VEC>(d_out + b * d_stride + q * VEC, dv);
     const float dl = (d_lin_out != nullptr && q == 0) ? d_lin_out[b] : 0.f;
     const bool is_max = a.combiner == DCTR_POOL_MAX;
@@ -250,20 +263,26 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const
         denom = (by_len ? (float)len : cnt) + 1e-8f;
     }
     // max: forward maxima per dimension (and of the 1-wide linear term), then the first position that attains each
-    float mx[VEC] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, lmx = -INFINITY;
+    float mx[VEC], lmx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) mx[c] = -INFINITY;
     if (is_max) {
         for (int t = 0; t < T; ++t) {
             const int64_t r = row_of(t);
             const bool ok = (uint64_t)r < (uint64_t)a.vocab, m = mask_of(t, r);
             const float wt = weight_of(t, m), pen = m ? 0.f : 1e9f;
-            float v[VEC] = {0.f, 0.f, 0.f, 0.f};
+            float v[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[c] = 0.f;
             if (ok && colok) load_vec<VEC>(a.table + r * a.dim + q * VEC, v);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) mx[c] = fmaxf(mx[c], v[c] * wt - pen);
             if (q == 0 && a.lin_table != nullptr) lmx = fmaxf(lmx, (ok ? a.lin_table[r] : 0.f) * wt - pen);
         }
     }
-    bool taken[VEC] = {false, false, false, false};
+    bool taken[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) taken[c] = false;
     bool ltaken = false;
     for (int t = 0; t < T; ++t) {
         const int64_t r = row_of(t);
@@ -272,7 +291,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const
         const float wt = weight_of(t, m);
         if (is_max) {
             const float pen = m ? 0.f : 1e9f;
-            float v[VEC] = {0.f, 0.f, 0.f, 0.f};
+            float v[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[c] = 0.f;
             if (colok) load_vec<VEC>(a.table + r * a.dim + q * VEC, v);
             if (colok && g_table != nullptr) {
 #pragma unroll
@@ -297,6 +318,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dctr_pool_args_t a, const
             }
         }
     }
+    }   // chunks
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1945,15 +1967,26 @@ extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void
     DCTR_REQUIRE(f->batch >= 0 && f->n_fields >= 0, DCTR_E_DIM, "embed_gather_fm_bwd: bad sizes");
     if (f->batch == 0 || f->n_fields == 0) return DCTR_OK;
     DCTR_REQUIRE(f->fields && f->ids && a->grads, DCTR_E_NULL, "embed_gather_fm_bwd: null fields / ids / grads");
-    DCTR_REQUIRE(f->all_dim4 && f->max_dim <= 64 && !f->any_pitch, DCTR_E_UNSUPPORTED,
-                 "embed_gather_fm_bwd: needs every embedding_dim %% 4 == 0 and <= 64, plain (not record-form) tables");
-    DCTR_REQUIRE(a->d_dnn_in == nullptr || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_dnn_in)), DCTR_E_ALIGN,
+    DCTR_REQUIRE(!f->any_pitch && f->max_dim >= 1, DCTR_E_UNSUPPORTED, "embed_gather_fm_bwd: plain (not record-form) tables, max_dim >= 1");
+    DCTR_REQUIRE(a->d_dnn_in == nullptr || !f->all_dim4 || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_dnn_in)), DCTR_E_ALIGN,
                  "embed_gather_fm_bwd: d_dnn_in must be 16-B aligned with a stride %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    if (!f->all_dim4) {
+        // some width is not a multiple of 4 (rows / DNN-input columns not 16-B aligned): element per lane, 16 lanes per sample
+        const int64_t blocks1 = dctr_ceil_div(f->batch, (int64_t)4);
+        DCTR_REQUIRE(blocks1 <= 0x7fffffffLL, DCTR_E_DIM, "embed_gather_fm_bwd: batch too large");
+        if (f->any_hash)
+            hipLaunchKernelGGL((gather_fm_bwd_kernel<16, true, 1>), dim3((unsigned)blocks1), dim3(256), 0, st, *f, a->grads, a->d_dnn_in,
+                               a->d_stride, a->d_fm, a->d_lin, a->g_dense_lin_w, a->dense_lin_rows);
+        else
+            hipLaunchKernelGGL((gather_fm_bwd_kernel<16, false, 1>), dim3((unsigned)blocks1), dim3(256), 0, st, *f, a->grads, a->d_dnn_in,
+                               a->d_stride, a->d_fm, a->d_lin, a->g_dense_lin_w, a->dense_lin_rows);
+        return dctr_launch_status("dctr_embed_gather_fm_bwd");
+    }
     int lpr = 1;
-    while (lpr * 4 < f->max_dim) lpr <<= 1;
+    while (lpr * 4 < f->max_dim && lpr < 16) lpr <<= 1;                          // (rows wider than 64 floats: several chunks per lane)
     const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(64 / lpr));        // one wave's worth of samples per workgroup
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_gather_fm_bwd: batch too large");
-    hipStream_t st = (hipStream_t)stream;
 #define CALL_BWD(L)                                                                                                       \
     do {                                                                                                                  \
         if (f->any_hash)                                                                                                  \
@@ -1977,19 +2010,26 @@ extern "C" int dctr_embed_gather_fm_bwd(const dctr_gather_fm_bwd_args_t* a, void
 extern "C" int dctr_embed_pool_bwd(const dctr_pool_bwd_args_t* a, void* stream) {
     DCTR_REQUIRE(a != nullptr && a->fwd != nullptr, DCTR_E_NULL, "embed_pool_bwd: null args");
     const dctr_pool_args_t* f = a->fwd;
-    DCTR_REQUIRE(f->batch >= 0 && f->maxlen >= 1 && f->dim >= 1 && f->dim <= 64 && f->dim % 4 == 0, DCTR_E_UNSUPPORTED,
-                 "embed_pool_bwd: needs embedding_dim %% 4 == 0 and <= 64");
+    DCTR_REQUIRE(f->batch >= 0 && f->maxlen >= 1 && f->dim >= 1, DCTR_E_DIM, "embed_pool_bwd: bad sizes");
     if (f->batch == 0) return DCTR_OK;
     DCTR_REQUIRE(f->idx && f->table, DCTR_E_NULL, "embed_pool_bwd: null idx / table");
-    DCTR_REQUIRE(a->d_out == nullptr || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_out)), DCTR_E_ALIGN,
+    const bool vec4 = f->dim % 4 == 0;
+    DCTR_REQUIRE(a->d_out == nullptr || !vec4 || (a->d_stride % 4 == 0 && dctr_aligned16(a->d_out)), DCTR_E_ALIGN,
                  "embed_pool_bwd: d_out must be 16-B aligned with a stride %% 4 == 0");
+    DCTR_REQUIRE(a->touched == nullptr || vec4, DCTR_E_DIM, "embed_pool_bwd: touched bytes need dim %% 4 == 0 (dim %d)", f->dim);
     int lpr = 1;
-    while (lpr * 4 < f->dim) lpr <<= 1;
+    while (lpr * 4 < f->dim && lpr < 16) lpr <<= 1;          // (rows wider than 64 floats: several chunks per lane)
+    if (!vec4) lpr = 16;                                     // element per lane
     const int64_t blocks = dctr_ceil_div(f->batch, (int64_t)(256 / lpr));
     DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "embed_pool_bwd: batch too large");
     hipStream_t st = (hipStream_t)stream;
     if (a->touched != nullptr && a->g_table != nullptr)
         launch_mark_rows(st, f->idx, f->batch, f->maxlen, f->idx_stride, f->idx_is_i64, f->hash_mode, f->vocab, f->dim, a->touched);
+    if (!vec4) {
+        hipLaunchKernelGGL((pool_bwd_kernel<16, 1>), dim3((unsigned)blocks), dim3(256), 0, st, *f, a->d_out, a->d_stride, a->d_lin_out,
+                           a->g_table, a->g_lin_table);
+        return dctr_launch_status("dctr_embed_pool_bwd");
+    }
 #define CALL_PB(L) \
     hipLaunchKernelGGL((pool_bwd_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, *f, a->d_out, a->d_stride, a->d_lin_out, \
                        a->g_table, a->g_lin_table)

@@ -93,6 +93,7 @@ class FusedForward(object):
     matrix_precision = "fp32"
     _pad = _pad_spec = _bf3 = None
     _declined = frozenset()     # launch sizes dctr_embed_mlp_fwd declined (_forward_fast)
+    _accepted = frozenset()
 
     # ---- hooks --------------------------------------------------------------------------------------------------------------
     def _head_weights(self):
@@ -127,6 +128,7 @@ class FusedForward(object):
         self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
         self._declined = set()      # launch sizes the library declined (DCTR_E_UNSUPPORTED): these go through dnn_in
+        self._accepted = set()      # (rows, tile_rows, precision, task) the library said it takes (dctr_mlp_fwd_supported)
         self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
         self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
@@ -271,8 +273,21 @@ class FusedForward(object):
         if B in self._declined:
             return False
         g, m = self._forward_fast_args(staged, lo, hi, out)
-        self._launch_extra(staged, lo, hi, self._extra_logit_buffers(B))      # (CIN / matrix CrossNet: in front of the fused launch)
         sp = self.stage_plan
+        akey = (B, self.tile_rows, self.matrix_precision, self.task)
+        if akey not in self._accepted:
+            # the library is asked BEFORE anything is launched or allocated for this launch size (dctr_mlp_fwd_supported runs every check
+            # and kernel-shape decision of the launch): a declined size goes through dnn_in without _launch_extra having run for it
+            if m.precision == 0 and self.tile_rows == 0 and not _C.lib().dctr_mlp_fwd_supported(
+                    ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear)):
+                if len(self._declined) >= 64:
+                    self._declined.clear()
+                self._declined.add(B)
+                return False
+            if len(self._accepted) >= 256:
+                self._accepted.clear()
+            self._accepted.add(akey)
+        self._launch_extra(staged, lo, hi, self._extra_logit_buffers(B))      # (CIN / matrix CrossNet: in front of the fused launch)
         rc = _C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear), _C.stream_ptr())
         if rc == _C.E_UNSUPPORTED and m.precision == 0 and self.tile_rows == 0:
             # the library is the authority on what its fused kernels take (e.g. a DNN input wider than every LDS tile in front of widths

@@ -55,14 +55,19 @@ class _DeepFM(FusedForward, FeatureModel):
                 if e.rc != _C.E_UNSUPPORTED or self.tile_rows != 0:
                     raise
                 self._declined.add(hi - lo)
-        ws = self.stage_plan.run(staged, lo, hi, records=self.gather_records and self._records_capable)
-        add = self._logits_to_add(ws)
-        if self.stage_plan.fm_group_names:
-            add.append(ws["fm"])
-            add.extend(ws["fm_extra"])
-        ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
-                head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
-                sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out, tile_rows=self.tile_rows)
+        # the route through dnn_in owns a [rows, in_dim] buffer: a span sized for the one-launch path (up to 2^20 rows) is walked in
+        # sub-spans of the base class's size (the models that get here are the wide ones: 2^20 x ~2,500 floats would be 10 GB)
+        step = max(int(self.span_rows or 0), 4096)
+        for a in range(lo, hi, step):
+            b = min(hi, a + step)
+            ws = self.stage_plan.run(staged, a, b, records=self.gather_records and self._records_capable)
+            add = self._logits_to_add(ws)
+            if self.stage_plan.fm_group_names:
+                add.append(ws["fm"])
+                add.extend(ws["fm_extra"])
+            ops.mlp(ws["dnn_in"], self.dnn.kernels, self.dnn.biases, self.dnn.activation, dice=self.dnn.dice_params(), bn=self.dnn.bn_params(),
+                    head_w=self.dense.w('kernel'), add=add, global_bias=self.prediction.w('global_bias'),
+                    sigmoid_out=self.task == "binary", in_dim=self.stage_plan.in_dim, out=out[a - lo:b - lo], tile_rows=self.tile_rows)
 
 
 def DeepFM(linear_feature_columns, dnn_feature_columns, fm_group=(DEFAULT_GROUP_NAME,), dnn_hidden_units=(256, 128, 64),

@@ -611,6 +611,25 @@ def crossnet_fold_consts(kernels, bias, head, out=None):
 # ---------------------------------------------------------------------------------------------
 # adjacent: DNN (+ head), DIN attention
 # ---------------------------------------------------------------------------------------------
+_MLP_SCRATCH = {}
+_MLP_SCRATCH_MAX = 1 << 29      # 512 MiB: the layer-by-layer DNN walks the rows in chunks of what its scratch holds
+
+
+def _mlp_scratch(device, nbytes):
+    """Per-device scratch of the layer-by-layer DNN route (grown on demand; launches on one stream are ordered, so one buffer serves)."""
+    t = _MLP_SCRATCH.get(device)
+    if t is None or t.numel() * 4 < nbytes:
+        t = _MLP_SCRATCH[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return t
+
+
+def mlp_fwd_supported(gather, m, add_fm_logit=False, add_lin_logit=False):
+    """dctr_mlp_fwd_supported: would the library take this (fused, when ``gather`` is given) DNN launch?  The host asks; it does not
+    re-derive the library's LDS / instantiation limits."""
+    return bool(_C.lib().dctr_mlp_fwd_supported(None if gather is None else ctypes.byref(gather), ctypes.byref(m), int(bool(add_fm_logit)),
+                                                int(bool(add_lin_logit))))
+
+
 def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=None, add=(), global_bias=None,
         sigmoid_out=False, in_dim=None, out=None, gather=None, add_fm_logit=False, add_lin_logit=False, batch=None,
         tile_rows=0, save_acts=None, probe=None, launch=True, bn=None, precision=0, workspace=None, cross=None):
@@ -694,6 +713,13 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
         a.save_acts = ctypes.cast(sa, ctypes.c_void_p)
     if not launch:                      # caller keeps the marshalled arguments and launches itself (per-batch fast path)
         return a, (keep, ua, kp, bp, da, dm, dv, add_arr, add, head_w, global_bias, out)
+    if gather is None and workspace is None and precision == 0 and n > 0:
+        # a layer wider than any LDS tile: the library runs the DNN layer by layer through two activation buffers it asks for (0 otherwise)
+        need = int(_C.lib().dctr_mlp_workspace_bytes(ctypes.byref(a)))
+        if need > 0:
+            ws_t = _mlp_scratch(out.device, min(need, _MLP_SCRATCH_MAX))
+            a.workspace, a.workspace_bytes = ws_t.data_ptr(), ws_t.numel() * 4
+            keep.append(ws_t)
     if gather is not None:
         _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(gather), ctypes.byref(a), int(bool(add_fm_logit)),
                                              int(bool(add_lin_logit)), _C.stream_ptr()), "dctr_embed_mlp_fwd")

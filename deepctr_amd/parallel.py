@@ -83,7 +83,7 @@ def evaluate_distributed(model, x, y, batch_size=256, group=None):
     collective in the forward) and ONE all-reduce of [sum of per-sample losses, sum of squared errors, sum of absolute errors,
     count of correct 0.5-threshold decisions] over RCCL / gloo gives every rank the loss of the whole feed — additive
     statistics only; rank-order metrics (auc) need the gathered predictions: ``predict_distributed``.
-    Returns {"loss", "mse", "mae", "accuracy"} (loss = the compiled loss: binary_crossentropy or mse)."""
+    Returns {"loss", "mse", "mae", "accuracy"} (loss = the compiled loss: binary_crossentropy or mse, plus the l2 penalties)."""
     import torch.distributed as dist
     feed = model._as_feed(x)
     n = model._num_rows(feed)
@@ -106,7 +106,9 @@ def evaluate_distributed(model, x, y, batch_size=256, group=None):
     acc = ((p > 0.5) == (yt > 0.5)).to(torch.float64).sum()
     first = bce if loss_name in ("binary_crossentropy", "logloss") else se
     out = sharded_loss(torch.stack([first, se, ae, acc]), n, group)
-    return {"loss": float(out[0]), "mse": float(out[1]), "mae": float(out[2]), "accuracy": float(out[3])}
+    from .training import l2_penalty
+    # (as model.evaluate / tf.keras: data loss + the l2 penalties of the replicated weights — no exchange, every rank holds them)
+    return {"loss": float(out[0]) + l2_penalty(model), "mse": float(out[1]), "mae": float(out[2]), "accuracy": float(out[3])}
 
 
 def fit_distributed(model, x, y, batch_size=256, epochs=1, verbose=0, shuffle=True, group=None, seed=None, **kwargs):

@@ -44,8 +44,12 @@ def supported(model):
         # Dice runs as tf.keras runs it under fit(): BatchNormalization in training mode — this batch's statistics, gradients
         # through them, stored statistics moved (dctr_dice_train_fwd + dctr_mlp_bwd's dice_batch_*);
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
-    if sp.lin_only or not sp.all_dim4 or sp.max_dim > 64:
+    if sp.lin_only:
         return False
+    # (round 6: any embedding width — widths that are not a multiple of 4 or exceed 64, embedding_dim="auto" — the scatter kernels walk a
+    # row in chunks, element per lane where rows are not 16-B aligned; such tables carry no touched-group marks: dense optimizer pass)
+    if kind == "_xDeepFM" and sp.max_dim > 128:
+        return False                        # (dctr_cin_fwd / dctr_cin_bwd hold a field's row in registers: embedding_dim <= 128)
     if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "matrix" and sp.in_dim > 832:
         return False                        # (the training forward's matrix CrossNet keeps [16, dim] tiles of x_0 / x_l / x_{l+1} in LDS)
     if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector":

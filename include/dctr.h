@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 11
+#define DCTR_ABI_VERSION 12
 
 enum {
     DCTR_OK = 0,
@@ -447,7 +447,16 @@ typedef struct {
                                    * compute at the start of every launch (one wave, ~7 dependent L2 round trips: a few us of a
                                    * 4096-row launch) */
 } dctr_mlp_args_t;
+/* Scratch dctr_mlp_fwd needs for these arguments (0 for most): precision 1 / 2 -> the packed weight images; a DNN with a layer wider
+ * than any LDS tile holds (> 1,216 units — the reference's DNN takes any hidden_units, layers/core.py:160-175) -> two activation
+ * buffers of [min(batch, 65536) rounded up to 64 rows, widest layer] floats: such a DNN runs layer by layer (own f32-MFMA GEMM +
+ * one bias / BatchNormalization / activation launch per layer, rows in chunks of what the workspace holds; any workspace of >= 64
+ * rows works), the head through the no-hidden-layer form of the same entry point. */
 size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* args);
+/* Would dctr_mlp_fwd (g == NULL) / dctr_embed_mlp_fwd (g != NULL) take these arguments?  Runs every argument check and kernel-shape
+ * decision of the launch without launching: 1 = yes, 0 = no (dctr_last_error() carries the reason).  Hosts ask this instead of
+ * re-deriving the library's shape limits. */
+int dctr_mlp_fwd_supported(const dctr_gather_fm_args_t* g, const dctr_mlp_args_t* m, int32_t add_fm_logit, int32_t add_lin_logit);
 /* consts[l] = (cross_b[0] + .. + cross_b[l-1]) . v_l with v_l = cross_w[l] for l < layers and cross_head for l = layers (consts has
  * room for 4 floats; layers in 1 .. 3).  One tiny launch per change of the weights, not per batch. */
 int dctr_crossnet_fold_consts(const float* cross_w, const float* cross_b, const float* cross_head, int32_t layers, int32_t dim,

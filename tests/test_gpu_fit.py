@@ -45,7 +45,11 @@ def test_fit_reduces_loss_and_predict_uses_trained_weights(device):
         model.fit(feed, y)
     model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc", "accuracy"])
     before, bce0, auc0, acc0 = model.evaluate(feed, y, batch_size=512)        # tf.keras: [loss, metric, ...] with compiled metrics
-    assert before == bce0 and 0.3 < auc0 < 0.7
+    # tf.keras: `loss` = the data loss + the l2 penalties of the constructor's regularisers (defaults 1e-5 on embeddings / linear);
+    # the binary_crossentropy METRIC is the bare data term
+    from deepctr_amd import training
+    pen = sum(l2 * float((t.double() ** 2).sum()) for t, l2 in training.regularized_weights(model))
+    assert pen > 0 and abs(before - (bce0 + pen)) <= 1e-9 * max(1.0, before) and 0.3 < auc0 < 0.7
     np.random.seed(20260921)             # fit(shuffle=True) permutes with numpy's global generator, as keras does with its own
     h = model.fit(feed, y, batch_size=256, epochs=16, verbose=0, validation_split=0.25)
     assert len(h.history["loss"]) == 16 and len(h.history["val_loss"]) == 16 and len(h.history["val_auc"]) == 16
@@ -118,3 +122,38 @@ def test_frozen_embedding_is_bit_identical_after_fit(device, on_hip):
         assert np.array_equal(before[k], after[k]), k
     assert not np.array_equal(before["sparse_emb_b/embeddings"], after["sparse_emb_b/embeddings"])
     assert not np.array_equal(before["dnn/kernel0"], after["dnn/kernel0"])
+
+
+def test_validation_steps_freq_and_penalties(device):
+    """tf.keras.Model.fit / evaluate semantics the reference's users rely on (/root/reference/docs/source/Model_Methods.md:24-43):
+    val_loss = evaluate()'s loss on the validation rows = data loss + l2 penalties; validation_steps bounds the validation to its first
+    batches (of validation_batch_size rows); validation_freq picks the epochs that validate (int: every k-th; collection: those epochs,
+    1-based); evaluate(steps=k) scores the first k batches."""
+    from deepctr_amd import training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(4)
+    n = 1500
+    cols = [SparseFeat("a", 20, 8), SparseFeat("b", 30, 8), DenseFeat("d", 2)]
+    feed = {"a": rng.randint(0, 20, n), "b": rng.randint(0, 30, n), "d": rng.rand(n, 2).astype(np.float32)}
+    y = ((feed["a"] % 2) ^ (feed["d"][:, 0] > 0.5)).astype(np.float32)
+    xv = {k: v[1000:] for k, v in feed.items()}
+    yv = y[1000:]
+    model = DeepFM(cols, cols, dnn_hidden_units=(16,), l2_reg_embedding=1e-3, l2_reg_linear=1e-3, l2_reg_dnn=1e-3, device=device)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy"])
+    h = model.fit({k: v[:1000] for k, v in feed.items()}, y[:1000], batch_size=100, epochs=4, verbose=0, shuffle=False,
+                  validation_data=(xv, yv), validation_steps=2, validation_batch_size=64, validation_freq=2)
+    assert len(h.history["loss"]) == 4 and len(h.history["val_loss"]) == 2           # epochs 2 and 4 validated
+    ev = model.evaluate(xv, yv, batch_size=64, steps=2, return_dict=True)            # the weights of the last epoch: epoch 4's validation
+    assert abs(ev["loss"] - h.history["val_loss"][-1]) <= 1e-9
+    pen = sum(l2 * float((t.double() ** 2).sum()) for t, l2 in training.regularized_weights(model))
+    first128 = model.evaluate({k: v[:128] for k, v in xv.items()}, yv[:128], batch_size=64, return_dict=True)
+    assert abs(ev["loss"] - first128["loss"]) <= 1e-9 and pen > 1e-4
+    assert abs(ev["loss"] - (ev["binary_crossentropy"] + pen)) <= 1e-7
+    full = model.evaluate(xv, yv, batch_size=64, return_dict=True)
+    assert abs(full["loss"] - ev["loss"]) > 1e-6                                      # 500 rows are not the first 128
+    h2 = model.fit({k: v[:1000] for k, v in feed.items()}, y[:1000], batch_size=100, epochs=5, verbose=0, validation_data=(xv, yv),
+                   validation_freq=[1, 5])
+    assert len(h2.history["val_loss"]) == 2 and len(h2.history["loss"]) == 5
+    with pytest.raises(ValueError, match="validation_steps"):
+        model.fit(feed, y, batch_size=100, epochs=1, verbose=0, validation_data=(xv, yv), validation_steps=9)

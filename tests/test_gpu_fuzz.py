@@ -18,6 +18,9 @@ from tests.util import assert_close
 FM_MODELS = ("DeepFM", "NFM", "AFM", "PNN", "xDeepFM")          # one embedding width for every field (the reference concatenates them)
 ALL_MODELS = ("DeepFM", "WDL", "FNN", "DCN", "DCNM", "DCNMix") + FM_MODELS[1:]
 DNN_SHAPES = [(8,), (32, 16), (256, 128, 64), (200, 80), (128, 128), (64,), (400, 400), (17, 9, 5), (256, 256, 256, 128)]
+# hidden_units with a layer wider than any LDS tile holds (> 1,216 units: the layer-by-layer route of dctr_mlp_fwd; reference
+# layers/core.py:160-175 takes any width).  Chosen by the seed alone — no generator draw — so every other configuration stays what it was
+WIDE_DNN_SHAPES = [(1024, 512, 256), (2048,), (1300, 40), (2048, 1024)]
 ROW_COUNTS = [1, 7, 300, 1000, 4099, 20011, 70001, 2, 65, 16384, 16383, 8192]
 
 
@@ -108,6 +111,8 @@ def random_config(seed, rows=None, dims4=False):
             linear.append({"type": "dense", "name": "ld", "dimension": 2})
             feed["ld"] = rng.rand(n, 2).astype(np.float32)
     units = DNN_SHAPES[int(rng.randint(len(DNN_SHAPES)))]
+    if seed % 23 == 5:
+        units = WIDE_DNN_SHAPES[(seed // 23) % len(WIDE_DNN_SHAPES)]
     act = str(rng.choice(["relu", "relu", "tanh", "sigmoid"]))
     kw = {"seed": 1024 + seed}
     name = model
@@ -235,6 +240,8 @@ def random_din_config(seed, dims4=False):
           "att_hidden_size": [(80, 40), (8,), (64, 16), (36, 20, 4)][int(rng.randint(4))],
           "att_activation": str(rng.choice(["dice", "dice", "sigmoid", "relu"])),
           "att_weight_normalization": bool(rng.rand() < 0.5)}
+    if seed % 11 == 3:
+        kw["dnn_hidden_units"] = WIDE_DNN_SHAPES[(seed // 11) % len(WIDE_DNN_SHAPES)]
     if rng.rand() < 0.2:
         kw["dnn_use_bn"] = True
     if rng.rand() < 0.1:

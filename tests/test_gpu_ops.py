@@ -570,6 +570,72 @@ def test_mlp_input_wider_than_the_lds_tile(device, in_dim, units, act):
             assert_close(y.cpu().numpy(), h, rtol=1e-4, atol=1e-5, what="wide mlp activations B=%d" % B)
 
 
+@pytest.mark.parametrize("in_dim,units,act", [(429, (2048, 1024), "relu"), (77, (1300, 40), "tanh"), (845, (1024, 512, 256), "relu"),
+                                              (2600, (2048,), "sigmoid"), (64, (1217, 1216, 3), "dice")])
+def test_mlp_layers_wider_than_the_lds_tile(device, in_dim, units, act):
+    """DNN.call takes any hidden_units (/root/reference/deepctr/layers/core.py:160-175, :189-208): a layer wider than any LDS tile holds
+    (> 1,216 units) runs layer by layer — own f32-MFMA GEMM + one bias / BatchNormalization / activation launch per layer — through the
+    workspace dctr_mlp_workspace_bytes() asks for; with and without the head, BatchNormalization, Dice, save_acts, ragged batch sizes,
+    and a workspace so small that the rows go in several chunks (same bits as one chunk).  float64 oracle."""
+    import ctypes
+    from deepctr_amd import _C, ops
+    rng = np.random.RandomState(in_dim + len(units))
+    dims = [in_dim] + list(units)
+    ks = [(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / (dims[i] + dims[i + 1]))).astype(np.float32) for i in range(len(units))]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(units))]
+    hw = rng.standard_normal(dims[-1]).astype(np.float32) * 0.1
+    gb = np.array([0.3], np.float32)
+    dice = dice64 = None
+    if act == "dice":
+        dice = [(rng.rand(n).astype(np.float32), rng.standard_normal(n).astype(np.float32) * 0.3, rng.rand(n).astype(np.float32) + 0.5) for n in units]
+        dice64 = [tuple(t.astype(np.float64) for t in d) for d in dice]
+    bn = [(rng.rand(n).astype(np.float32) + 0.5, rng.standard_normal(n).astype(np.float32) * 0.1) for n in units]      # (scale, shift)
+    dk, db = [dev(k, device) for k in ks], [dev(b, device) for b in bs]
+    ddice = None if dice is None else [tuple(dev(t, device) for t in d) for d in dice]
+    for B in (1, 130, 1000):
+        stride = (in_dim + 3) // 4 * 4 + 4
+        x = np.full((B, stride), np.nan, np.float32)           # stride padding must never be read
+        x[:, :in_dim] = rng.standard_normal((B, in_dim)).astype(np.float32)
+        a0 = rng.standard_normal(B).astype(np.float32)
+        x64 = x[:, :in_dim].astype(np.float64)
+        for use_bn in (False, True):
+            h = x64
+            acts = []
+            for i in range(len(units)):                         # (the oracle's layer, with the BatchNormalization as its scale / shift form)
+                z = h @ ks[i].astype(np.float64) + bs[i]
+                if use_bn:
+                    z = z * bn[i][0] + bn[i][1]
+                h = R.dice(z, *dice64[i]) if act == "dice" else R._act(act, z)
+                acts.append(h)
+            logit = h @ hw.astype(np.float64) + a0 + gb[0]
+            mag = np.abs(h) @ np.abs(hw.astype(np.float64)) + np.abs(a0) + 0.3
+            dbn = [tuple(dev(t, device) for t in b_) for b_ in bn] if use_bn else None
+            save = [torch.full((B, n), float("nan"), dtype=torch.float32, device=device) for n in units]
+            y = ops.mlp(dev(x, device), dk, db, act, dice=ddice, bn=dbn, head_w=dev(hw, device), add=(dev(a0, device),),
+                        global_bias=dev(gb, device), sigmoid_out=False, in_dim=in_dim, save_acts=save)
+            assert_close_terms(y.cpu().numpy(), logit, mag, what="layered mlp head logits B=%d bn=%s" % (B, use_bn))
+            for i, sv in enumerate(save):
+                assert_close(sv.cpu().numpy(), acts[i], rtol=1e-4, atol=2e-5, what="layered mlp save_acts[%d] B=%d" % (i, B))
+            y2 = ops.mlp(dev(x, device), dk, db, act, dice=ddice, bn=dbn, in_dim=in_dim)
+            assert_close(y2.cpu().numpy(), h, rtol=1e-4, atol=2e-5, what="layered mlp activations B=%d bn=%s" % (B, use_bn))
+            if B == 1000 and not use_bn:
+                # a workspace of 2 x 128 rows: eight chunks, the last one ragged — the same bits (a row's GEMM tile does not depend on the chunk)
+                wmax = (max(units) + 3) // 4 * 4
+                small = torch.empty(2 * 128 * wmax, dtype=torch.float32, device=device)
+                y3 = ops.mlp(dev(x, device), dk, db, act, dice=ddice, head_w=dev(hw, device), add=(dev(a0, device),), global_bias=dev(gb, device),
+                             sigmoid_out=False, in_dim=in_dim, workspace=small)
+                assert_close_terms(y3.cpu().numpy(), logit, mag, what="layered mlp, chunked rows")
+                if max(units) > 1216:                                                       # (1,024 units still fit a 16-row LDS tile)
+                    tiny = torch.empty(64 * wmax, dtype=torch.float32, device=device)       # fewer than 64 rows of two layers: refused
+                    with pytest.raises(_C.DctrError):
+                        ops.mlp(dev(x, device), dk, db, act, dice=ddice, in_dim=in_dim, workspace=tiny)
+    # the query: a workspace is asked for exactly when a layer does not fit any LDS tile
+    a, keep = ops.mlp(dev(x, device), dk, db, act, dice=ddice, in_dim=in_dim, launch=False)
+    assert (_C.lib().dctr_mlp_workspace_bytes(ctypes.byref(a)) > 0) == (max(units) > 1216) and ops.mlp_fwd_supported(None, a)
+    a2, keep2 = ops.mlp(dev(x, device), [dev(ks[0][:, :64].copy(), device)], [dev(bs[0][:64].copy(), device)], "relu", in_dim=in_dim, launch=False)
+    assert _C.lib().dctr_mlp_workspace_bytes(ctypes.byref(a2)) == 0 and ops.mlp_fwd_supported(None, a2)
+
+
 def _att_weights(g, prefix, n_layers, act, device):
     ks = [dev(g["%s/dnn/kernel%d" % (prefix, i)], device) for i in range(n_layers)]
     bs = [dev(g["%s/dnn/bias%d" % (prefix, i)], device) for i in range(n_layers)]

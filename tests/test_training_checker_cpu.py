@@ -283,8 +283,10 @@ def test_frozen_embedding_and_fit_keyword_contract():
     real = _C.require_device
     _C.require_device = lambda: None
     try:
-        with pytest.raises(NotImplementedError, match="validation_steps"):
-            training.fit_model(model, feed, y, validation_steps=3)
+        with pytest.raises(ValueError, match="validation_steps"):        # more validation batches than the validation rows hold
+            training.fit_model(model, feed, y, validation_split=0.25, validation_steps=10 ** 6)
+        with pytest.raises(ValueError, match="validation_freq"):
+            training.fit_model(model, feed, y, validation_split=0.25, validation_freq=0)
         with pytest.raises(TypeError, match="bogus"):
             training.fit_model(model, feed, y, bogus=1)
     finally:
