@@ -847,51 +847,6 @@ def main():
         finally:
             model.probe = None
 
-    # EXPLORATORY line (never `value`, never the library's default): the same K-step region with the DNN products as three bf16
-    # MFMAs each (dctr_mlp_args_t.precision; model.matrix_precision = "bf16x3") — what the one-launch kernel's gather side
-    # sustains once the matrix pipe is no longer the bound.  Same steps, same inputs, own output buffer, own parity check.
-    bf3 = None
-    if K > 0 and fused and dist is None and not args.no_secondary and all(k == "chain" for pl in plans for _, k, _ in pl):
-        try:
-            model.matrix_precision = "bf16x3"
-            logits_b = torch.empty_like(logits)
-            prep_b = [model.prepare_launch(staged, lo, hi, logits_b[o0:o1]) for lo, hi, o0, o1 in launches]
-
-            def run_b():
-                for fn in prep_b:
-                    fn()
-            run_b()
-            torch.cuda.synchronize()
-            t_end = time.perf_counter() + args.prewarm_ms * 1e-3
-            while time.perf_counter() < t_end:
-                run_b()
-                torch.cuda.synchronize()
-            tb = []
-            for _ in range(n_regions):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                run_b()
-                torch.cuda.synchronize()
-                tb.append(time.perf_counter() - t0)
-            lib.dctr_profile_arm(min(n_kern, 256))
-            run_b()
-            torch.cuda.synchronize()
-            msb = (ctypes.c_float * 256)()
-            nb_t = lib.dctr_profile_collect(msb, min(n_kern, 256))
-            par_b = check_parity(model, cols, staged, launches, logits_b, max(args.parity_rows, 64), rank)
-            dev_fp32 = float((logits_b[:K * B] - logits[:K * B]).abs().max().item())
-            tmed = float(np.median(tb))
-            us = [msb[i] * 1e3 for i in range(nb_t) if msb[i] > 0]
-            bf3 = {"dtype": "bf16x3", "status": "exploratory: not the library's arithmetic, not bit-comparable with the fp32 kernels",
-                   "samples_per_s": K * B / tmed, "ms_per_step": tmed / K * 1e3, "regions_ms": [t * 1e3 for t in tb],
-                   "us_per_launch": float(np.mean(us)) if us else None,
-                   "whole_forward_frac_of_hbm_roofline": K * B / tmed * ALG_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS,
-                   "parity_max_rel": par_b["max_rel"], "parity": par_b, "max_abs_diff_vs_fp32_output": dev_fp32}
-        except Exception as e:                              # an exploratory leg never takes the bench line down
-            bf3 = {"dtype": "bf16x3", "error": repr(e)}
-        finally:
-            model.matrix_precision = "fp32"
-
     # SURVEY §8(d)'s secondary input distribution: the same K-step region on Zipf(1.05) ids (hot rows: L2 / MALL hits), own staged
     # ring, own output buffer, own parity check against the float64 oracle
     zipf = None
@@ -1093,7 +1048,6 @@ def main():
                 "ms": exchange * 1e3, "forward_only_ms": forward_only * 1e3,
                 "forward_only_samples_per_s": world * B * K / forward_only if K else 0.0,
                 "samples_per_s_region_plus_exchange": world * B * K / (forward_only + exchange) if K else 0.0},
-            "exploratory_bf16x3": bf3,
             "regions_ms": [t * 1e3 for t in region_s],
             "value_is": "median of %d one-shot regions of exactly K steps (each: barrier + sync | K steps | sync%s), taken right after "
                         "%.0f ms (%.0f ms from the second region on) of the same steps untimed, i.e. at the clock the part holds "

@@ -38,7 +38,6 @@ SOURCES = [
     "chain_kernels_r2w8_m22.hip",
     "chain_kernels_r2w8_m21.hip",
     "chain_kernels_r2w4_m42.hip",
-    "chain_kernels_r2w8_m42_bf3.hip",
     "chain_kernels_r2w8_m42_x.hip",
     "chain_kernels_r2w8_m42_q.hip",
     "chain_kernels_r2w8_m42_t.hip",

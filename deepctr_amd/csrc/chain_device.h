@@ -227,30 +227,6 @@ struct XBlkT {
 
 // RT, NW: launch shape (above); EB = embedding_dim / 16 k-blocks per field; I64: int64 ids; M0 / M1 / M2 = units[l] / 64
 // (M2 == 0: two layers)
-// ---- bf16 x 3 split (EXPLORATORY variant, BF3: never the default, never the headline number; dctr_mlp_args_t.precision == 1).
-// An fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|); a product x w is evaluated as
-// hi_w hi_x + hi_w lo_x + lo_w hi_x on v_mfma_f32_16x16x16_bf16 with fp32 accumulation (the lo_w lo_x term, 2^-16 relative, is dropped).
-// One bf16 MFMA covers a whole 16-deep k-block of one M-tile: lane (g, j) supplies k = 4g .. 4g + 3 — exactly the four values it holds
-// in the fp32 form (a 16-B piece of a gathered row; the four registers of an accumulator tile), so the row-chained structure is kept.
-// The weights arrive pre-split and pre-arranged (chain_pack_bf3_kernel): per (k-slot g, M-tile) 16 lanes x 16 B = {4 hi, 4 lo}.
-typedef short bf16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void bf3_split(const f32x4& x, uint2& h, uint2& l) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    const uint32_t h01 = __builtin_bit_cast(uint32_t, (bf2){(__bf16)x[0], (__bf16)x[1]});
-    const uint32_t h23 = __builtin_bit_cast(uint32_t, (bf2){(__bf16)x[2], (__bf16)x[3]});
-    const float r0 = x[0] - __builtin_bit_cast(float, h01 << 16), r1 = x[1] - __builtin_bit_cast(float, h01 & 0xffff0000u);
-    const float r2 = x[2] - __builtin_bit_cast(float, h23 << 16), r3 = x[3] - __builtin_bit_cast(float, h23 & 0xffff0000u);
-    h = uint2{h01, h23};
-    l = uint2{__builtin_bit_cast(uint32_t, (bf2){(__bf16)r0, (__bf16)r1}), __builtin_bit_cast(uint32_t, (bf2){(__bf16)r2, (__bf16)r3})};
-}
-__device__ __forceinline__ void mfma_bf(f32x4& acc, uint2 a, uint2 b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, a), __builtin_bit_cast(bf16x4_t, b), acc, 0, 0, 0);
-}
-// two M-tiles' fragments of one k-block: {hi.x, hi.y, lo.x, lo.y} each
-struct BfFrag2 {
-    uint4 a, b;
-};
-
 // parameter-area offsets (floats) shared by the kernel's once-per-launch loads and the passes
 template <int M0, int M1, int M2>
 struct ChainOff {
@@ -271,8 +247,7 @@ struct ChainOff {
 // next block's range check, the ids of the block after next.  Same arithmetic, same k order as the tile kernels' layer 0.
 // REC (dctr_field_t.row_pitch, the RECORD form of embedding_dim-16 tables: a row's linear weight lies behind it, records 32 floats apart):
 // row r of a field lies at table + 128 r bytes and its linear entry at lin_table + 128 r — compile-time shifts, no instruction more
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false,
-          bool REC = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool CROSS = false, int FPB = 1, bool EXPACT = false, bool REC = false>
 __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
                                              const int row_end, const int first, const int stride, const int n_pass, int& oor) {
     if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
@@ -282,8 +257,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     constexpr int S1 = M0 * M1, S2 = M1 * M2;      // chunks (= steps) of layers 1 and 2
     constexpr int SL = S1 + S2;
     static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
-    static_assert(FPB == 1 || (EB == 1 && (FPB == 2 || FPB == 4) && !BF3 && !CROSS), "several fields per k-block: E = 8 / 4, plain fp32 kernels");
-    static_assert(!REC || (EB == 1 && FPB == 1 && !BF3 && !CROSS && !EXPACT), "record-form tables: embedding_dim 16, plain fp32 kernels");
+    static_assert(FPB == 1 || (EB == 1 && (FPB == 2 || FPB == 4) && !CROSS), "several fields per k-block: E = 8 / 4, plain fp32 kernels");
+    static_assert(!REC || (EB == 1 && FPB == 1 && !CROSS && !EXPACT), "record-form tables: embedding_dim 16, plain fp32 kernels");
     constexpr int E = FPB > 1 ? 16 / FPB : 16 * EB;
     constexpr int PPB = FPB / 2;                   // field pairs per k-block (FPB > 1)
     constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair (FPB == 1)
@@ -338,7 +313,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         asm volatile("" : "+v"(ln));
         const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);                  // this lane's byte inside piece `wave`
         const int row0 = (FPB > 1 && b >= NBE) ? emb_rows + 16 * (b - NBE) : 16 * b;     // first W0 row of the block
-        if (BF3 || row0 + 16 <= p.in_dim) {                                    // a whole block: 16 KiB (M0 = 4) as they lie (BF3: the packed image is zero-padded)
+        if (row0 + 16 <= p.in_dim) {                                           // a whole block: 16 KiB (M0 = 4) as they lie
             const char* base = reinterpret_cast<const char*>(p.W[0]) + (size_t)row0 * ROW_B;
 #pragma unroll
             for (int pc0 = 0; pc0 < 4 * M0; pc0 += NW)
@@ -357,12 +332,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const uint32_t o = (uint32_t)(1024 * wave + 16 * ln);
-        if constexpr (BF3) {                                                   // packed sub-blocks lie one after the other, 16 KiB each
-            const char* pbase = reinterpret_cast<const char*>(W) + (size_t)(mg * (N / 64) + mg1) * 16384;
-#pragma unroll
-            for (int pc0 = 0; pc0 < 16; pc0 += NW) dma16(pbase + pc0 * 1024, o, dst + (pc0 + wave) * 256);
-            return;
-        }
         const uint32_t voff = (o >> 8) * (uint32_t)(N * 4) + (o & 255u);       // image row o / 256 <-> weight row, 256 B of it
         const char* base = reinterpret_cast<const char*>(W) + ((size_t)(64 * mg) * N + 64 * mg1) * 4;   // scalar
 #pragma unroll
@@ -468,7 +437,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     // per request — + 0.5 % in a same-box A/B, scripts/ab_libs.sh; the same treatment of the id / linear-entry requests measured - 1.7 %)
     const uint32_t bp4_ = ((uint32_t)lane & 15u) << 2;
     const uint64_t gg16_ = (uint64_t)(((uint32_t)lane >> 4) << 4);
-    constexpr bool KEEP_LC = !CROSS && !BF3;          // (the folded-CrossNet and bf16x3 instantiations sit at 252 - 256 registers: they rebuild)
+    constexpr bool KEEP_LC = !CROSS;                  // (the folded-CrossNet instantiations sit at 252 - 256 registers: they rebuild)
     auto issue_x1 = [&](int cb, uint32_t idc, int half, XBlk& X, auto NTc) {
         constexpr int nt = decltype(NTc)::value;
         const int f = cb / EB, h = cb % EB;
@@ -841,70 +810,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             }                                                                                                    \
             slot_next();                                                                                         \
         }
-        // BF3 form of the step: the k-block's B operand is split once (xh / xl), a half-group hs = (M-group hs / 2, M-tiles 2 (hs % 2),
-        // + 1) is two ds_read_b128 of the packed chunk ([k-slot g][M-group][M-tile][lane j] x 16 B: the 16 lanes of a lane group read
-        // 256 contiguous bytes) and 3 x 2 x RT MFMAs (hi hi, hi lo, lo hi; the three updates of an accumulator 2 RT MFMAs apart);
-        // fragments are requested two half-groups ahead; the request pieces sit behind half-groups 0 .. 3 and the last one
-        BfFrag2 fA, fB, fC;
-        auto read_bf0 = [&](const float* sb, int hs) -> BfFrag2 {
-            const int mg = hs >> 1, mt = 2 * (hs & 1);
-            const float* q = sb + (((g * M0 + mg) * 4 + mt) * 16 + j) * 4;
-            BfFrag2 f;
-            f.a = *reinterpret_cast<const uint4*>(q);
-            f.b = *reinterpret_cast<const uint4*>(q + 64);
-            return f;
-        };
-        auto mfma_bf0 = [&](const BfFrag2& f, const uint2 (&xh)[RT], const uint2 (&xl)[RT], int hs) {
-            const int t0 = 4 * (hs >> 1) + 2 * (hs & 1);
-#pragma unroll
-            for (int nt = 0; nt < RT; ++nt) {
-                mfma_bf(acc0[t0][nt], uint2{f.a.x, f.a.y}, xh[nt]);
-                mfma_bf(acc0[t0 + 1][nt], uint2{f.b.x, f.b.y}, xh[nt]);
-            }
-#pragma unroll
-            for (int nt = 0; nt < RT; ++nt) {
-                mfma_bf(acc0[t0][nt], uint2{f.a.x, f.a.y}, xl[nt]);
-                mfma_bf(acc0[t0 + 1][nt], uint2{f.b.x, f.b.y}, xl[nt]);
-            }
-#pragma unroll
-            for (int nt = 0; nt < RT; ++nt) {
-                mfma_bf(acc0[t0][nt], uint2{f.a.z, f.a.w}, xh[nt]);
-                mfma_bf(acc0[t0 + 1][nt], uint2{f.b.z, f.b.w}, xh[nt]);
-            }
-        };
-#define CHAIN_STEP0_BF(S, XC, XN)                                                                                \
-        {                                                                                                        \
-            constexpr int s_ = (S);                                                                              \
-            const int b_ = pr_ * PAIR + s_;                                                                      \
-            CHAIN_TOP_X(XC);                                                                                     \
-            const float* sb_ = slot_ptr(0);                                                                      \
-            if (b_ == 0) {                                                                                       \
-                fA = read_bf0(sb_, 0);                                                                           \
-                fB = read_bf0(sb_, 1);                                                                           \
-            }                                                                                                    \
-            if (b_ >= NBE) {                                                                                     \
-                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
-                    XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
-            }                                                                                                    \
-            uint2 xh_[RT], xl_[RT];                                                                              \
-            _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_) bf3_split(XC.x[nt_], xh_[nt_], xl_[nt_]);       \
-            _Pragma("unroll") for (int hs_ = 0; hs_ < 2 * M0; ++hs_) {                                           \
-                if (hs_ + 2 < 2 * M0) fC = read_bf0(sb_, hs_ + 2);                                               \
-                else if (b_ + 1 < NB) fC = read_bf0(slot_ptr(1), hs_ + 2 - 2 * M0);                              \
-                DCTR_SB;                                                                                         \
-                mfma_bf0(fA, xh_, xl_, hs_);                                                                     \
-                DCTR_SB;                                                                                         \
-                if (hs_ == 0) CHAIN_PIECE0(0, XC, XN)                                                            \
-                if (hs_ == 1) CHAIN_PIECE0(1, XC, XN)                                                            \
-                if (hs_ == 2) CHAIN_PIECE0(2, XC, XN)                                                            \
-                if (hs_ == 3) CHAIN_PIECE0(3, XC, XN)                                                            \
-                if (hs_ == 2 * M0 - 1 && hs_ > 3) CHAIN_PIECE0(2 * M0 - 1, XC, XN)                               \
-                if (2 * hs_ == DMA_LATE0 && !dma_early) dma_chunk(b_ + 2, slot_ptr(2));                          \
-                if (hs_ + 1 < 2 * M0 || b_ + 1 < NB) fA = fB;                                                    \
-                if (hs_ + 2 < 2 * M0 || b_ + 1 < NB) fB = fC;                                                    \
-            }                                                                                                    \
-            slot_next();                                                                                         \
-        }
         // FPB > 1: a step = one k-block of FPB fields.  Slot i behind the MFMAs of micro-step 2 i: 0: DMA share (waves 0-3), range check
         // of the NEXT block's ids (requested a step ago), the previous block's linear entries; 1 / 2: rows of the next block, N tile
         // 0 / 1; 3: this block's linear entries, the ids of the block after next; last: FM bookkeeping
@@ -1003,33 +908,23 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             if constexpr (PPB > 1) linacc += (lvnB_has && NB - 1 < NBE) ? lvnB : 0.f;
         } else {
         for (int pr_ = 0; pr_ * PAIR < NB; ++pr_) {
-            if constexpr (BF3) {
-                CHAIN_STEP0_BF(0, XA, XB);
-                if (pr_ * PAIR + 1 < NB) CHAIN_STEP0_BF(1, XB, XA);
-                if constexpr (EB >= 2) {
-                    if (pr_ * PAIR + 2 < NB) CHAIN_STEP0_BF(2, XA, XB);
-                    if (pr_ * PAIR + 3 < NB) CHAIN_STEP0_BF(3, XB, XA);
-                }
-            } else {
-                CHAIN_STEP0(0, XA, XB);
-                if (pr_ * PAIR + 1 < NB) CHAIN_STEP0(1, XB, XA);
-                if constexpr (EB >= 2) {
-                    if (pr_ * PAIR + 2 < NB) CHAIN_STEP0(2, XA, XB);
-                    if (pr_ * PAIR + 3 < NB) CHAIN_STEP0(3, XB, XA);
-                }
-                if constexpr (EB == 4) {               // embedding_dim 64: eight k-blocks per field pair
-                    if (pr_ * PAIR + 4 < NB) CHAIN_STEP0(4, XA, XB);
-                    if (pr_ * PAIR + 5 < NB) CHAIN_STEP0(5, XB, XA);
-                    if (pr_ * PAIR + 6 < NB) CHAIN_STEP0(6, XA, XB);
-                    if (pr_ * PAIR + 7 < NB) CHAIN_STEP0(7, XB, XA);
-                }
+            CHAIN_STEP0(0, XA, XB);
+            if (pr_ * PAIR + 1 < NB) CHAIN_STEP0(1, XB, XA);
+            if constexpr (EB >= 2) {
+                if (pr_ * PAIR + 2 < NB) CHAIN_STEP0(2, XA, XB);
+                if (pr_ * PAIR + 3 < NB) CHAIN_STEP0(3, XB, XA);
+            }
+            if constexpr (EB == 4) {                   // embedding_dim 64: eight k-blocks per field pair
+                if (pr_ * PAIR + 4 < NB) CHAIN_STEP0(4, XA, XB);
+                if (pr_ * PAIR + 5 < NB) CHAIN_STEP0(5, XB, XA);
+                if (pr_ * PAIR + 6 < NB) CHAIN_STEP0(6, XA, XB);
+                if (pr_ * PAIR + 7 < NB) CHAIN_STEP0(7, XB, XA);
             }
             idc = idcn;
         }
         }
 #undef CHAIN_STEPQ
 #undef CHAIN_PIECEQ
-#undef CHAIN_STEP0_BF
 #undef CHAIN_STEP0
 #undef CHAIN_PIECE0
 #undef CHAIN_PHASE0
@@ -1097,20 +992,6 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         // (BatchNormalization scale / shift,) activation in place: acc0 is now the B operand of layer 1
         if (p.bn_scale[0] != nullptr) bn_block<4 * M0, RT>(cpar + Off::BN_S, cpar + Off::BN_T, g, acc0);
         act_block<4 * M0, RT, EXPACT>(p.activation, acc0);
-        // BF3: an accumulator tile's four registers (features 16g + 4r + mt of a row) become {hi pair, hi pair, lo pair, lo pair} in
-        // place — the B operand of ONE bf16 MFMA per output M-tile
-        auto pack_bf = [&](auto& acc, auto NMc) {
-            constexpr int NM = decltype(NMc)::value;
-#pragma unroll
-            for (int m = 0; m < NM; ++m)
-#pragma unroll
-                for (int nt = 0; nt < RT; ++nt) {
-                    uint2 h, l;
-                    bf3_split(acc[m][nt], h, l);
-                    acc[m][nt] = __builtin_bit_cast(f32x4, uint4{h.x, h.y, l.x, l.y});
-                }
-        };
-        if constexpr (BF3) pack_bf(acc0, std::integral_constant<int, 4 * M0>{});
         if constexpr (M0 > 1) {
             f32x4* park = park_ptr();
 #pragma unroll
@@ -1225,94 +1106,9 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 }
             }
         };
-        // BF3 form: a step = one packed 64 x 64 sub-block = 8 half-groups (input tile mt = hs / 2, output M-tiles 2 (hs % 2), + 1)
-        // of two ds_read_b128 + 3 x 2 x RT MFMAs; accin holds the packed B operands (pack_bf)
-        auto read_bfn = [&](const float* sb, int hs) -> BfFrag2 {
-            const int mt = hs >> 1, mt1 = 2 * (hs & 1);
-            const float* q = sb + (((g * 4 + mt) * 4 + mt1) * 16 + j) * 4;
-            BfFrag2 f;
-            f.a = *reinterpret_cast<const uint4*>(q);
-            f.b = *reinterpret_cast<const uint4*>(q + 64);
-            return f;
-        };
-        auto dense_layer_bf = [&](auto& accin, auto& accout, auto MIc, auto MOc, auto PARKc) {
-            constexpr int MI = decltype(MIc)::value, MO = decltype(MOc)::value;
-            constexpr bool PARKED = decltype(PARKc)::value && MI > 1;
-#pragma unroll
-            for (int mg = 0; mg < MI; ++mg) {
-#pragma unroll
-                for (int mg1 = 0; mg1 < MO; ++mg1) {
-                    const bool first = sidx == 0;
-                    const bool last = sidx == SL - 1;
-                    if (last) CHAIN_TOP_ID();
-                    else CHAIN_TOP();
-                    const float* sb = slot_ptr(0);
-                    if (last && NDB > 0) {
-                        dense_store(0, td);
-                        dense_rest(pass_n);
-                    }
-                    if (first) {
-                        fA = read_bfn(sb, 0);
-                        fB = read_bfn(sb, 1);
-                    }
-                    if (PARKED && mg == MI - 1 && mg1 == 0) {
-                        const f32x4* park = park_ptr();
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < RT; ++nt) accin[4 * mg + mt][nt] = park[(mt * RT + nt) * 64];
-                    }
-#pragma unroll
-                    for (int hs_ = 0; hs_ < 8; ++hs_) {
-                        if (hs_ + 2 < 8) fC = read_bfn(sb, hs_ + 2);
-                        else if (!last) fC = read_bfn(slot_ptr(1), hs_ + 2 - 8);
-                        DCTR_SB;
-                        {
-                            const int t1 = 4 * mg1 + 2 * (hs_ & 1);
-#pragma unroll
-                            for (int nt = 0; nt < RT; ++nt) {
-                                const uint4 bq = __builtin_bit_cast(uint4, accin[4 * mg + (hs_ >> 1)][nt]);
-                                mfma_bf(accout[t1][nt], uint2{fA.a.x, fA.a.y}, uint2{bq.x, bq.y});
-                                mfma_bf(accout[t1 + 1][nt], uint2{fA.b.x, fA.b.y}, uint2{bq.x, bq.y});
-                            }
-#pragma unroll
-                            for (int nt = 0; nt < RT; ++nt) {
-                                const uint4 bq = __builtin_bit_cast(uint4, accin[4 * mg + (hs_ >> 1)][nt]);
-                                mfma_bf(accout[t1][nt], uint2{fA.a.x, fA.a.y}, uint2{bq.z, bq.w});
-                                mfma_bf(accout[t1 + 1][nt], uint2{fA.b.x, fA.b.y}, uint2{bq.z, bq.w});
-                            }
-#pragma unroll
-                            for (int nt = 0; nt < RT; ++nt) {
-                                const uint4 bq = __builtin_bit_cast(uint4, accin[4 * mg + (hs_ >> 1)][nt]);
-                                mfma_bf(accout[t1][nt], uint2{fA.a.z, fA.a.w}, uint2{bq.x, bq.y});
-                                mfma_bf(accout[t1 + 1][nt], uint2{fA.b.z, fA.b.w}, uint2{bq.x, bq.y});
-                            }
-                        }
-                        DCTR_SB;
-                        if (hs_ == 0) {
-                            if (dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
-                            if (sidx == SL - 2) {
-                                request_pair_ids(0, pass_n, idr_lo, idr_hi);
-                                if (NDB > 0) dense_request(0, pass_n, td);
-                            }
-                            if (last) {
-                                idc = fold_pair_ids(0, pass_n, idr_lo, idr_hi);
-                                issue_x(0, idc, 0, XA);
-                            }
-                        }
-                        if (hs_ == 4 && !dma_early) dma_chunk(NB + sidx + 2, slot_ptr(2));
-                        if (hs_ + 1 < 8 || !last) fA = fB;
-                        if (hs_ + 2 < 8 || !last) fB = fC;
-                    }
-                    slot_next();
-                    ++sidx;
-                }
-            }
-        };
         f32x4 acc1[4 * M1][RT];
         init_acc(acc1, B1_OFF, std::integral_constant<int, M1>{});
-        if constexpr (BF3) dense_layer_bf(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{}, std::true_type{});
-        else dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{}, std::true_type{});
+        dense_layer(acc0, acc1, std::integral_constant<int, M0>{}, std::integral_constant<int, M1>{}, std::true_type{});
         mfma_drain();
         float hs[RT];
         // head of the last layer: act(acc) . head_w over this lane's 16 features per M-group, then over g
@@ -1344,12 +1140,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             act_block<4 * M1, RT, EXPACT>(p.activation, acc1);
             f32x4 acc2[4 * (M2 > 0 ? M2 : 1)][RT];
             init_acc(acc2, B2_OFF, std::integral_constant<int, M2>{});
-            if constexpr (BF3) {
-                pack_bf(acc1, std::integral_constant<int, 4 * M1>{});
-                dense_layer_bf(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{}, std::false_type{});
-            } else {
-                dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{}, std::false_type{});
-            }
+            dense_layer(acc1, acc2, std::integral_constant<int, M1>{}, std::integral_constant<int, M2>{}, std::false_type{});
             mfma_drain();
             head(acc2, std::integral_constant<int, M2>{}, 2, 64 * (M0 + M1));
         } else {
@@ -1381,8 +1172,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 }
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool BF3 = false, bool CROSS = false, int FPB = 1, bool EXPACT = false,
-          bool REC = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool CROSS = false, int FPB = 1, bool EXPACT = false, bool REC = false>
 __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
@@ -1438,14 +1228,14 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     __syncthreads();                                   // LDS parameters written
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
-    chain_passes<RT, NW, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
             // every wave is through with the ring and the staging areas of the main phase; waves 4.. leave (s_barrier waits for
             // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
             __syncthreads();
             if (wave < 4)
-                chain_passes<1, 4, EB, I64, M0, M1, M2, BF3, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
+                chain_passes<1, 4, EB, I64, M0, M1, M2, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
                                                                          (int)gridDim.x, p.n_tail, oor);
         }
     }
@@ -1465,8 +1255,5 @@ int launch_r2w8_m42q(const ChainParams& p, int E, int M2, unsigned blocks, hipSt
 int launch_r2w8_m42t(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // sigmoid / tanh DNNs (chain_kernels_r2w8_m42_t.hip)
 int launch_r2w8_m42w(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 64 (chain_kernels_r2w8_m42_w.hip)
 int launch_r2w8_m42r(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // record-form tables, embedding_dim 16 (chain_kernels_r2w8_m42_r.hip)
-// the exploratory bf16 x 3 variant (chain_kernels_r2w8_m42_bf3.hip): packs the weights into `ws` (if `pack`), then launches
-size_t bf3_workspace_bytes(int in_dim);
-int launch_r2w8_m42_bf3(const ChainParams& p, int E, void* ws, bool pack, unsigned blocks, hipStream_t stream);
 
 }  // namespace dctr_chain

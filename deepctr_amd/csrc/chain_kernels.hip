@@ -32,7 +32,7 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
     if (expact && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && (E == 16 || E == 32) && a->cross_layers == 0)) return 0;
     // embedding_dim 64 (four k-blocks per field): the m42 kernels, fp32, ReLU / linear, no folded CrossNet
     if (E == 64 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && a->cross_layers == 0)) return 0;
-    if (a->precision != 0 && !(M[0] == 4 && M[1] == 2 && M[2] == 1 && a->tile_rows != 128 && a->bn_scale == nullptr)) return 0;
+    if (a->precision != 0) return 0;                      // (fp32 only: the bf16x3 exploration was removed in round 6)
     // record-form tables (row_pitch 32, embedding_dim 16): the m42 kernels, fp32, ReLU / linear, no identity fields, no folded CrossNet
     if (g->any_pitch && !(E == 16 && M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && a->cross_layers == 0 && !expact &&
                           !g->any_identity))
@@ -149,14 +149,6 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     const int64_t slots = n_cus();
     const int64_t want = p.n_pass > p.n_tail ? p.n_pass : p.n_tail;
     const unsigned blocks = (unsigned)(want < slots ? want : slots);
-    if (a->precision != 0) {                               // exploratory bf16 x 3 variant (eligible() admitted 256-128-64 only)
-        const size_t need = bf3_workspace_bytes(p.in_dim);
-        if (a->workspace == nullptr || a->workspace_bytes < need || !dctr_aligned16(a->workspace)) {
-            dctr_set_error("embed_mlp_fwd(chain, bf16x3): needs a 16-B aligned workspace of %zu B for the packed weights", need);
-            return DCTR_E_NULL;
-        }
-        return launch_r2w8_m42_bf3(p, E, a->workspace, a->precision == 1, blocks, stream);
-    }
     if (g->any_pitch) return launch_r2w8_m42r(p, E, M[2], blocks, stream);
     if (a->cross_layers > 0) return launch_r2w8_m42x(p, E, M[2], blocks, stream);
     if (a->activation == DCTR_ACT_SIGMOID || a->activation == DCTR_ACT_TANH) return launch_r2w8_m42t(p, E, M[2], blocks, stream);

@@ -30,7 +30,6 @@ namespace dctr_chain {
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);   // chain_kernels.hip
 int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used, int lin_used, int shape, hipStream_t stream);
 int plan(int64_t batch, int shape, int64_t* rows, int32_t* rpw, int max);
-size_t bf3_workspace_bytes(int in_dim);                                                 // chain_kernels_r2w8_m42_bf3.hip
 }
 namespace dctr_stream {
 int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forced);
@@ -66,11 +65,10 @@ bool widest_layer_fits_lds(const dctr_mlp_args_t* a) {
 
 }  // namespace
 
-// activations live in LDS — except (a) the exploratory bf16x3 precision, which keeps a packed copy of the weights in HBM, and (b) DNNs
-// with a layer wider than the LDS tile holds (> 1,216 units), which run layer by layer through two activation buffers
+// activations live in LDS — except in DNNs with a layer wider than the LDS tile holds (> 1,216 units), which run layer by layer through
+// two activation buffers
 extern "C" size_t dctr_mlp_workspace_bytes(const dctr_mlp_args_t* a) {
     if (a == nullptr || a->in_dim < 1) return 0;
-    if (a->precision == 1 || a->precision == 2) return dctr_chain::bf3_workspace_bytes(a->in_dim);
     if (a->precision != 0 || a->n_layers < 1 || a->n_layers > MAX_LAYERS || a->units == nullptr) return 0;
     return widest_layer_fits_lds(a) ? 0 : dctr_mlp::layered_workspace_bytes(a);
 }
@@ -82,8 +80,8 @@ static int mlp_head_launch(const dctr_mlp_args_t* a, void* stream) { return mlp_
 
 // dry: every check of a launch, no launch (dctr_mlp_fwd_supported / dctr_embed_mlp_fwd_supported)
 static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga, int fm_used, int lin_used, void* stream, bool dry) {
-    DCTR_REQUIRE(a == nullptr || a->precision == 0 || ((a->precision == 1 || a->precision == 2) && ga != nullptr), DCTR_E_UNSUPPORTED,
-                 "mlp_fwd: precision %d (0 = fp32; 1 / 2 = bf16x3 with dctr_embed_mlp_fwd only)", a != nullptr ? a->precision : 0);
+    DCTR_REQUIRE(a == nullptr || a->precision == 0, DCTR_E_UNSUPPORTED,
+                 "mlp_fwd: precision %d (0 = fp32 is the only arithmetic of this library)", a != nullptr ? a->precision : 0);
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "mlp_fwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->in_dim >= 1 && a->n_layers >= 0 && a->n_layers <= MAX_LAYERS, DCTR_E_DIM,
                  "mlp_fwd: bad sizes (batch=%lld in_dim=%d layers=%d, max %d layers)", (long long)a->batch, a->in_dim,
@@ -139,7 +137,7 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
                      a->cross_layers, CROSS_MAXL);
         DCTR_REQUIRE(a->cross_w && a->cross_b && a->cross_head, DCTR_E_NULL, "mlp_fwd: cross_layers without cross_w / cross_b / cross_head");
         DCTR_REQUIRE(a->has_head, DCTR_E_DIM, "mlp_fwd: the folded CrossNet adds the cross branch's logit to the head (has_head)");
-        DCTR_REQUIRE(a->save_acts == nullptr && a->precision == 0, DCTR_E_UNSUPPORTED, "mlp_fwd: cross_layers with save_acts / bf16x3");
+        DCTR_REQUIRE(a->save_acts == nullptr && a->precision == 0, DCTR_E_UNSUPPORTED, "mlp_fwd: cross_layers with save_acts");
         p.cross_w = a->cross_w;
         p.cross_b = a->cross_b;
         p.cross_head = a->cross_head;
@@ -182,8 +180,6 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 256 || a->tile_rows == 128)) {
         const bool forced = a->tile_rows != 0;
         const int ok = dctr_chain::eligible(a, ga, forced);
-        DCTR_REQUIRE(a->precision == 0 || ok, DCTR_E_UNSUPPORTED,
-                     "embed_mlp_fwd: precision 1 / 2 (bf16x3, exploratory) exists for the row-chained kernel with DNN 256-128-64 only");
         DCTR_REQUIRE(!forced || ok, DCTR_E_UNSUPPORTED,
                      "embed_mlp_fwd: tile_rows %d (row-chained kernel) needs uniform embedding_dim 4 / 8 / 16 / 32 / 64, instantiated units, a head", a->tile_rows);
         if (ok) {

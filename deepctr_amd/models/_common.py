@@ -90,8 +90,7 @@ class FusedForward(object):
     tile_rows = 0
     span_batches = True
     probe = None
-    matrix_precision = "fp32"
-    _pad = _pad_spec = _bf3 = None
+    _pad = _pad_spec = None
     _declined = frozenset()     # launch sizes dctr_embed_mlp_fwd declined (_forward_fast)
     _accepted = frozenset()
 
@@ -128,14 +127,10 @@ class FusedForward(object):
         self.span_batches = True    # predict(): let one fused launch span many batches (False: one launch per batch_size rows)
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
         self._declined = set()      # launch sizes the library declined (DCTR_E_UNSUPPORTED): these go through dnn_in
-        self._accepted = set()      # (rows, tile_rows, precision, task) the library said it takes (dctr_mlp_fwd_supported)
+        self._accepted = set()      # (rows, tile_rows, task) the library said it takes (dctr_mlp_fwd_supported)
         self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
         self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
-        # "fp32" (exact, the only supported mode) | "bf16x3": EXPLORATORY (include/dctr.h: dctr_mlp_args_t.precision) — the row-chained
-        # kernel's products as three bf16 MFMAs each; applies to launches that kernel takes (>= 64 rows per CU, DNN 256-128-64)
-        self.matrix_precision = "fp32"
-        self._bf3 = None            # {"ws": packed weight images, "fresh": they match the current weights}
 
     # -- DNN widths the row-chained kernel has no instantiation for --------------------------------------------------------
     _CHAIN_MIN_ROWS = 64 * 256         # launches below 64 rows per CU take the 32-row kernel (csrc/chain_kernels.hip: eligible)
@@ -239,7 +234,7 @@ class FusedForward(object):
         sp = self.stage_plan
         units = list(self._pad_spec) if self._pad_spec else [int(k.shape[1]) for k in self.dnn.kernels]
         return bool(sp.uniform_dim == 16 and self.dnn.activation in ("relu", "linear") and not self.dnn.dice_layers and
-                    len(units) in (2, 3) and units[0] == 256 and units[1] == 128 and self.matrix_precision == "fp32" and
+                    len(units) in (2, 3) and units[0] == 256 and units[1] == 128 and
                     self.tile_rows in (0, 16, 32, 256))
 
     def _records_on(self, staged):
@@ -248,19 +243,10 @@ class FusedForward(object):
     def _begin(self):
         super(FusedForward, self)._begin()
         if getattr(self, "_trainer_step", False):
-            return                      # (the HIP training step reads neither the padded copies nor the bf16x3 images)
+            return                      # (the HIP training step does not read the padded copies)
         self.stage_plan.begin_records(self.gather_records and self._records_capable, getattr(self, "_raw_weight_writes", 0))
         if self._pad is not None:
             self._padded_dnn()          # refresh in place: marshalled launches keep pointing at the buffers
-        if self._bf3 is not None:
-            self._bf3["fresh"] = False  # weights may have changed since the last predict(): the next launch repacks
-
-    def _bf3_on(self, B):
-        if self.matrix_precision == "fp32":
-            return False
-        if self.matrix_precision != "bf16x3":
-            raise ValueError("matrix_precision must be 'fp32' or 'bf16x3' (exploratory), got %r" % (self.matrix_precision,))
-        return B >= self._CHAIN_MIN_ROWS or self.tile_rows == 256
 
     def _forward_fast(self, staged, lo, hi, out):
         """Fixed-length features on the fused path: the two argument structs are marshalled once per batch size and only
@@ -274,11 +260,11 @@ class FusedForward(object):
             return False
         g, m = self._forward_fast_args(staged, lo, hi, out)
         sp = self.stage_plan
-        akey = (B, self.tile_rows, self.matrix_precision, self.task)
+        akey = (B, self.tile_rows, self.task)
         if akey not in self._accepted:
             # the library is asked BEFORE anything is launched or allocated for this launch size (dctr_mlp_fwd_supported runs every check
             # and kernel-shape decision of the launch): a declined size goes through dnn_in without _launch_extra having run for it
-            if m.precision == 0 and self.tile_rows == 0 and not _C.lib().dctr_mlp_fwd_supported(
+            if self.tile_rows == 0 and not _C.lib().dctr_mlp_fwd_supported(
                     ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear)):
                 if len(self._declined) >= 64:
                     self._declined.clear()
@@ -289,7 +275,7 @@ class FusedForward(object):
             self._accepted.add(akey)
         self._launch_extra(staged, lo, hi, self._extra_logit_buffers(B))      # (CIN / matrix CrossNet: in front of the fused launch)
         rc = _C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), int(bool(sp.fm_group_names)), int(sp.has_linear), _C.stream_ptr())
-        if rc == _C.E_UNSUPPORTED and m.precision == 0 and self.tile_rows == 0:
+        if rc == _C.E_UNSUPPORTED and self.tile_rows == 0:
             # the library is the authority on what its fused kernels take (e.g. a DNN input wider than every LDS tile in front of widths
             # the row-chained kernel is not instantiated for): launches of this size go through dnn_in from now on
             if len(self._declined) >= 64:
@@ -297,8 +283,6 @@ class FusedForward(object):
             self._declined.add(B)
             return False
         _C.check(rc, "dctr_embed_mlp_fwd")
-        if m.precision:
-            self._bf3["fresh"] = True
         return True
 
     def _forward_fast_args(self, staged, lo, hi, out):
@@ -310,9 +294,8 @@ class FusedForward(object):
         sp, B = self.stage_plan, hi - lo
         padded = self._use_padded(B)
         pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)     # (ids hashed at stage(): plain rows at every size)
-        bf3 = self._bf3_on(B)
         rec = self._records_on(staged) and (pre or not sp.any_hash)
-        key = (B, padded, pre, bf3, self.task, rec)      # (the marshalled struct carries sigmoid_out: predict_logits has its own entries)
+        key = (B, padded, pre, self.task, rec)      # (the marshalled struct carries sigmoid_out: predict_logits has its own entries)
         c = self._fast.get(key)
         hashed = sp.prehash(staged, lo, hi, sp.light_workspace()) if pre else None
         if c is None:
@@ -325,12 +308,6 @@ class FusedForward(object):
                               head_w=hw, global_bias=self.prediction.w('global_bias'),
                               sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out, gather=g, batch=B, launch=False,
                               cross=self._cross_operands())
-            if bf3:
-                if self._bf3 is None:
-                    m.precision = 1
-                    need = int(_C.lib().dctr_mlp_workspace_bytes(ctypes.byref(m)))
-                    self._bf3 = {"ws": torch.empty(need, dtype=torch.uint8, device=self.device), "fresh": False}
-                m.workspace, m.workspace_bytes = self._bf3["ws"].data_ptr(), self._bf3["ws"].numel()
             c = self._fast[key] = (g, m, keep, ws)
         else:
             self._fast[key] = self._fast.pop(key)        # (dicts keep insertion order: most recently used last)
@@ -350,7 +327,6 @@ class FusedForward(object):
         m.y = out.data_ptr()
         m.tile_rows = int(self.tile_rows)
         m.probe = None if self.probe is None else self.probe.data_ptr()
-        m.precision = 0 if not bf3 else (2 if self._bf3["fresh"] else 1)
         self._fast_g = g                                                # (xDeepFM: the CIN launch reads the same gather arguments)
         for i, t in enumerate(self._extra_logit_buffers(B)):
             m.add[i] = t.data_ptr()
@@ -381,8 +357,7 @@ class FusedForward(object):
         B = hi - lo
         sp = self.stage_plan
         pre = self._prehash(B) or (staged.hashed is not None and sp.any_hash)
-        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre, self._bf3_on(B), self.task,
-                                     self._records_on(staged) and (pre or not sp.any_hash))]
+        g, m, keep, ws = self._fast[(B, self._use_padded(B), pre, self.task, self._records_on(staged) and (pre or not sp.any_hash))]
         g, m = type(g).from_buffer_copy(g), type(m).from_buffer_copy(m)     # private copies of the two argument structs
         fn, stream = _C.lib().dctr_embed_mlp_fwd, _C.stream_ptr()
         a, b = int(bool(sp.fm_group_names)), int(sp.has_linear)
@@ -403,8 +378,6 @@ class FusedForward(object):
             self._fast_g = g
             self._launch_extra(staged, lo, hi, own_add)
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
-            if m.precision == 1:                                         # bf16x3: the first launch packed the weights
-                m.precision = 2
         launch.keep = (g, m, keep, ws, staged, out, own_ids, own_add)
         return launch
 

@@ -34,9 +34,6 @@ class _DeepFM(FusedForward, FeatureModel):
         sp = self.stage_plan
         if self._fast_path(staged) and self._forward_fast(staged, lo, hi, out):
             return
-        if self.matrix_precision != "fp32":
-            raise ValueError("matrix_precision %r (bf16x3 is exploratory) exists on the row-chained one-launch path only: fixed-length "
-                             "features, fused=True" % (self.matrix_precision,))
         if sp.fusable and self.fused and (hi - lo) not in self._declined:
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
             ws = sp.run_pools(staged, lo, hi, light=True)

@@ -688,7 +688,7 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
                    global_bias=None if global_bias is None else global_bias.data_ptr(), y=out.data_ptr(),
                    y_stride=0 if has_head else out.stride(0), workspace=None, workspace_bytes=0,
                    tile_rows=int(tile_rows), precision=int(precision))
-    if workspace is not None:           # precision 1 (exploratory bf16x3): the packed weight images live here
+    if workspace is not None:           # caller-provided scratch of the layer-by-layer route (dctr_mlp_workspace_bytes)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
         keep.append(workspace)
     if probe is not None:               # measurement aid: uint64[2] {min start, max end} wall-clock stamps (dctr.h)

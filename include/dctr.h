@@ -413,14 +413,8 @@ typedef struct {
                                      row-chained kernel as ONE launch: 256-row passes for the whole multiples of 256 rows x CUs,
                                      64-row units inside the same kernel for what is left; a row's result does not depend on
                                      the shape, the phase or the row's position in the launch. */
-    int32_t precision;            /* 0 (default): exact fp32 (v_mfma_f32_16x16x4_f32 = an fmaf chain).  1: EXPLORATORY, dctr_embed_mlp_fwd's
-                                     row-chained kernel only (DNN 256-128-64; else DCTR_E_UNSUPPORTED): every product as three bf16 MFMAs
-                                     (hi hi + hi lo + lo hi of a two-term bf16 split, fp32 accumulation: ~2^-16 relative per product instead of
-                                     2^-24) — measures what the kernel's gather side sustains once the matrix pipe is ~5x faster; never the
-                                     library's default and not bit-comparable with the fp32 kernels.  Needs `workspace` (the packed weight
-                                     images, written by the call): dctr_mlp_workspace_bytes() = 16384 * ceil(in_dim / 16) + 163840 bytes,
-                                     16-B aligned.  2: as 1, and the caller vouches `workspace` still holds what a precision-1 call over
-                                     the same kernels wrote (skips the three packing launches). */
+    int32_t precision;            /* must be 0: exact fp32 (v_mfma_f32_16x16x4_f32 = an fmaf chain) is the library's only arithmetic.  (ABI <= 11
+                                     carried an exploratory bf16x3 mode here; removed — DESIGN.md §9 — anything but 0 is DCTR_E_UNSUPPORTED.) */
     unsigned long long* probe;    /* measurement aid, normally NULL: DEVICE uint64[2]; every workgroup does
                                      atomicMin(probe[0], t_start) / atomicMax(probe[1], t_end) with the constant-rate
                                      wall clock (dctr_wall_clock_khz()), so probe[1] - probe[0] is this launch's duration
@@ -447,7 +441,7 @@ typedef struct {
                                    * compute at the start of every launch (one wave, ~7 dependent L2 round trips: a few us of a
                                    * 4096-row launch) */
 } dctr_mlp_args_t;
-/* Scratch dctr_mlp_fwd needs for these arguments (0 for most): precision 1 / 2 -> the packed weight images; a DNN with a layer wider
+/* Scratch dctr_mlp_fwd needs for these arguments (0 for most): a DNN with a layer wider
  * than any LDS tile holds (> 1,216 units — the reference's DNN takes any hidden_units, layers/core.py:160-175) -> two activation
  * buffers of [min(batch, 65536) rounded up to 64 rows, widest layer] floats: such a DNN runs layer by layer (own f32-MFMA GEMM +
  * one bias / BatchNormalization / activation launch per layer, rows in chunks of what the workspace holds; any workspace of >= 64

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 CHAIN_UNITS = [("chain_kernels_r2w8_m42.hip", 256), ("chain_kernels_r2w8_m41.hip", 256), ("chain_kernels_r2w8_m22.hip", 256),
-               ("chain_kernels_r2w8_m21.hip", 256), ("chain_kernels_r2w4_m42.hip", 512), ("chain_kernels_r2w8_m42_bf3.hip", 256),
+               ("chain_kernels_r2w8_m21.hip", 256), ("chain_kernels_r2w4_m42.hip", 512),
                ("chain_kernels_r2w8_m42_x.hip", 256), ("chain_kernels_r2w8_m42_q.hip", 256), ("chain_kernels_r2w8_m42_t.hip", 256),
                ("chain_kernels_r2w8_m42_w.hip", 256)]
 
@@ -41,7 +41,7 @@ def test_chain_kernel_needs_no_scratch(tmp_path):
         agprs = [int(x) for x in re.findall(r" AGPRs: (\d+)", out)]
         assert len(names) >= 4 and len(names) == len(scratch) == len(vgprs) == len(agprs), (tu, out[-2000:])
         for n, sc, v, a in zip(names, scratch, vgprs, agprs):
-            assert "chain_kernel" in n or "chain_pack_bf3_kernel" in n
+            assert "chain_kernel" in n
             assert sc == 0, "%s: %s spills to scratch (%d B/lane)" % (tu, n, sc)
             assert v + a <= max_vgprs, "%s: %s needs %d registers" % (tu, n, v + a)
 

@@ -5,6 +5,7 @@ kernel DeepFM-family launches of >= 64 rows per CU take.  Checked against the fl
 rows in one launch; the C5 shape E = 32 with int64-range vocabularies): row-permutation equivariance bit for bit, launch
 shape invariance bit for bit (every shape walks k in the same order), launch split invariance."""
 import numpy as np
+import torch
 import pytest
 
 from oracle import ref_models as RM
@@ -526,45 +527,20 @@ def test_record_form_tables_give_the_bits_of_plain_tables(device):
     assert not ok                                                   # DCTR_E_UNSUPPORTED -> the op reports "declined"
 
 
-@pytest.mark.parametrize("E,n,F,ND", [(16, 20 * 4096, 26, 13), (32, 16384 + 4096 + 77, 26, 13), (16, 16384 + 129, 7, 0), (32, 700, 12, 20)])
-def test_chain_bf16x3_exploratory_precision(device, E, n, F, ND):
-    """The EXPLORATORY precision (dctr_mlp_args_t.precision = 1 / 2; model.matrix_precision = "bf16x3"): every MLP product as three
-    bf16 MFMAs.  Not bit-comparable with the fp32 kernels — it must stay inside the same 1e-4 bar against the float64 oracle, stay
-    close to the fp32 chain (2^-16 per product), keep the kernel's invariances (row permutation, main / tail membership), see weight
-    updates (repacking) and refuse DNNs it has no instantiation for."""
-    from deepctr_amd import _C
-    from deepctr_amd.models import DeepFM
-    rng = np.random.RandomState(900 + E + F)
-    cols, feed = _criteo_like(rng, n, F=F, V=5000, E=E, ND=ND)
-    model = DeepFM(cols, cols, device=device)
-    w = _randomise(model, rng)
-    force = {} if n >= 16384 else {"tile_rows": 256}
-    y32 = _predict(model, feed, 4096, **force)
-    yb = _predict(model, feed, 4096, matrix_precision="bf16x3", **force)
-    assert _last_kernel() == "chain" and model._bf3 is not None and model._bf3["fresh"]
-    assert np.isfinite(yb).all()
-    rows = np.unique(np.concatenate([np.arange(0, min(n, 300)), np.arange(max(0, n - 300), n)]))
-    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
-    check_probs(yb[rows], ref.astype(np.float32), "bf16x3 chain E=%d F=%d" % (E, F))
-    assert_close(yb, y32, rtol=3e-5, atol=3e-6, what="bf16x3 vs fp32 chain")
-    assert not np.array_equal(yb, y32)                              # (it is a different arithmetic: the flag must have taken effect)
-    # second call: the packed images are reused inside a predict(), repacked across predicts; same bits either way
-    assert np.array_equal(_predict(model, feed, 4096, matrix_precision="bf16x3", **force), yb)
-    perm = rng.permutation(n)
-    yp = _predict(model, {k: v[perm] for k, v in feed.items()}, 4096, matrix_precision="bf16x3", **force)
-    assert np.array_equal(yp, yb[perm])
-    # new weights are seen (the first launch of a predict() repacks)
-    w2 = _randomise(model, np.random.RandomState(5))
-    y2 = _predict(model, feed, 4096, matrix_precision="bf16x3", **force)
-    ref2 = RM.deepfm(cols, cols, w2, {k: v[rows] for k, v in feed.items()}, dtype=np.float64)
-    check_probs(y2[rows], ref2.astype(np.float32), "bf16x3 chain, new weights")
-    # other widths: refused loudly, never silently fp32
-    other = DeepFM(cols, cols, dnn_hidden_units=(128, 64), device=device)
-    _randomise(other, rng)
-    with pytest.raises((_C.DctrError, ValueError), match="bf16x3"):
-        _predict(other, feed, 4096, matrix_precision="bf16x3", tile_rows=256)
-    with pytest.raises(ValueError):
-        _predict(model, feed, 4096, matrix_precision="fp16")
+def test_only_fp32_arithmetic(device):
+    """dctr_mlp_args_t.precision: 0 = exact fp32 is the library's only arithmetic (ABI <= 11 carried an exploratory bf16x3 mode of the
+    row-chained kernel; removed in round 6 — DESIGN.md §9).  Anything else is refused, never silently computed in fp32."""
+    import ctypes
+    from deepctr_amd import _C, ops
+    x = torch.zeros(64, 32, device=device)
+    k = [torch.zeros(32, 16, device=device)]
+    b = [torch.zeros(16, device=device)]
+    a, keep = ops.mlp(x, k, b, "relu", launch=False)
+    a.precision = 1
+    assert _C.lib().dctr_mlp_fwd(ctypes.byref(a), _C.stream_ptr()) == _C.E_UNSUPPORTED
+    assert not ops.mlp_fwd_supported(None, a)
+    a.precision = 0
+    assert ops.mlp_fwd_supported(None, a)
 
 
 @pytest.mark.parametrize("E,V,n,F,ND,units", [
