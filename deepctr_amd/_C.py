@@ -52,7 +52,11 @@ class GatherFmArgs(ctypes.Structure):
                 ("dense_lin_w", c_vp), ("dense_out_offset", c_i32), ("dense_copy_cols", c_i32), ("batch", c_i64),
                 ("dnn_in", c_vp), ("out_stride", c_i64), ("fm_logit", c_vp), ("lin_logit", c_vp), ("status", c_vp),
                 ("split_col", c_i32), ("split_field", c_i32), ("uniform_dim", c_i32), ("any_identity", c_i32),
-                ("any_pitch", c_i32), ("pad_", c_i32)]
+                ("any_pitch", c_i32), ("n_pools", c_i32), ("pools", c_vp), ("pool_row0", c_i64), ("pool_pieces", c_i32), ("pool_flags", c_i32)]
+
+
+class PoolSeq(ctypes.Structure):       # dctr_pool_seq_t: a sequence feature pooled inside dctr_embed_mlp_fwd (DEVICE array)
+    _fields_ = [("idx", c_vp), ("length", c_vp), ("idx_stride", c_i64), ("maxlen", c_i32), ("combiner", c_i32)]
 
 
 class PoolArgs(ctypes.Structure):

@@ -43,6 +43,7 @@ SOURCES = [
     "chain_kernels_r2w8_m42_t.hip",
     "chain_kernels_r2w8_m42_w.hip",
     "chain_kernels_r2w8_m42_r.hip",
+    "chain_kernels_r2w8_m42_p.hip",
     "interaction_kernels.hip",
     "cin_kernels.hip",
     "cin_bwd_kernels.hip",

@@ -61,6 +61,7 @@ using namespace dctr_mlp;
 constexpr int NSLOT = 3;
 constexpr int SLOT_F = 4096;                   // floats per ring chunk (16 KiB)
 constexpr int CPAR_OFF = 0;                    // biases of every layer, head weights, BatchNormalization scale / shift (<= 2048 floats)
+constexpr int POOLD_OFF = 2016;                // [n_pool <= 4][8 dwords]: the POOL kernels' sequence descriptors (the tail of the parameter area)
 constexpr int FDESC_OFF = 2048;                // [n_fields <= 64][12 dwords]
 constexpr int DLW_OFF = 2816;                  // dense_lin_w (<= 256 floats, zeros when absent)
 constexpr int RING_OFF = 3072;
@@ -104,13 +105,30 @@ struct ChainParams {
     const float* bn_shift[3];
     // CrossNet, vector parameterization, folded into the pass (kernels instantiated with CROSS; mlp_device.h: cross_logit): the
     // L + 1 vectors w_0 .. w_{L-1}, k_c lie zero-padded in LDS at xv_off ([CROSS_NV][16 NB] floats + the CROSS_NV constants)
-    const float* cross_w;
-    const float* cross_b;
-    const float* cross_head;
-    const float* cross_const;      // [CROSS_NV] precomputed (dctr_crossnet_fold_consts) or NULL: wave 0 computes them
+    // the same 32 bytes serve the CROSS kernels' vectors or the POOL kernels' sequences (a kernel is instantiated with at most one of the
+    // two; the struct — the kernel argument — keeps its size and layout, so the other instantiations' code does not depend on either)
+    union {
+        struct {
+            const float* cross_w;
+            const float* cross_b;
+            const float* cross_head;
+            const float* cross_const;  // [CROSS_NV] precomputed (dctr_crossnet_fold_consts) or NULL: wave 0 computes them
+        };
+        // VarLenSparseFeat pooled INSIDE the pass (kernels instantiated with POOL): the LAST n_pool fields of `fields` are sequences; their
+        // descriptors carry table / lin_table / vocab / in_fm as for a SparseFeat, pool[i] (DEVICE array, dctr_pool_seq_t) the id
+        // matrix of the i-th of them from the staged data's row 0; the launch's rows are rows pool_row0 ... of those matrices
+        struct {
+            const dctr_pool_seq_t* pool;
+            int64_t pool_row0;
+            int32_t n_pool;
+            int32_t pool_flags;        // bit i: sequence i is mean-pooled; bit 4 + i: it has a length vector (dctr_gather_fm_args_t.pool_flags)
+            int32_t pool_pad_[2];
+        };
+    };
     int32_t cross_layers;
     int32_t xv_off;
 };
+static_assert(sizeof(dctr_pool_seq_t) == 32, "dctr_pool_seq_t: 32 bytes (two scalar loads)");
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // loads through pointers that come out of LDS (field descriptors) would be FLAT instructions (vmcnt AND lgkmcnt, slower
@@ -120,6 +138,7 @@ typedef const __attribute__((address_space(1))) float* gbl_f_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) u32x2* gbl_u2_t;
 typedef const __attribute__((address_space(1))) uint32_t* gbl_u_t;
+typedef const __attribute__((address_space(1))) int32_t* gbl_i_t;
 
 // field descriptor words as they lie in LDS (copied once per launch); decoded to scalars where they are used
 struct FieldRaw {
@@ -247,7 +266,7 @@ struct ChainOff {
 // next block's range check, the ids of the block after next.  Same arithmetic, same k order as the tile kernels' layer 0.
 // REC (dctr_field_t.row_pitch, the RECORD form of embedding_dim-16 tables: a row's linear weight lies behind it, records 32 floats apart):
 // row r of a field lies at table + 128 r bytes and its linear entry at lin_table + 128 r — compile-time shifts, no instruction more
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool CROSS = false, int FPB = 1, bool EXPACT = false, bool REC = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool CROSS = false, int FPB = 1, bool EXPACT = false, bool REC = false, bool POOL = false>
 __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, const int wave, const int lane, const int row_base,
                                              const int row_end, const int first, const int stride, const int n_pass, int& oor) {
     if (first >= n_pass) return;                   // (workgroup-uniform: every wave of the phase skips it)
@@ -259,12 +278,13 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     static_assert(SL >= 2, "the next pass's gather prologue needs two steps behind layer 0");
     static_assert(FPB == 1 || (EB == 1 && (FPB == 2 || FPB == 4) && !CROSS), "several fields per k-block: E = 8 / 4, plain fp32 kernels");
     static_assert(!REC || (EB == 1 && FPB == 1 && !CROSS && !EXPACT), "record-form tables: embedding_dim 16, plain fp32 kernels");
+    static_assert(!POOL || (EB == 1 && FPB == 1 && !CROSS && !EXPACT && !REC && M0 == 4), "in-pass sequence pooling: embedding_dim 16, plain fp32 kernels, units[0] = 256");
     constexpr int E = FPB > 1 ? 16 / FPB : 16 * EB;
     constexpr int PPB = FPB / 2;                   // field pairs per k-block (FPB > 1)
     constexpr int PAIR = 2 * EB;                   // layer-0 steps per field pair (FPB == 1)
     typedef ChainOff<M0, M1, M2> Off;
     constexpr int B1_OFF = Off::B1, B2_OFF = Off::B2, HW_OFF = Off::HW, GB_OFF = Off::GB;
-    static_assert(Off::END <= FDESC_OFF, "biases + head weights + global bias + BatchNormalization must fit the parameter area");
+    static_assert(Off::END <= (POOL ? POOLD_OFF : FDESC_OFF), "biases + head weights + global bias + BatchNormalization must fit the parameter area");
     float* cpar = smem + CPAR_OFF;
     float* fdesc = smem + FDESC_OFF;
     float* dlw = smem + DLW_OFF;
@@ -281,6 +301,10 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     const int NBE = FPB > 1 ? (p.n_fields + FPB - 1) / FPB : p.n_fields * EB;         // embedding k-blocks
     const int NB = FPB > 1 ? NBE + ((p.n_dense + 15) >> 4) : (p.in_dim + 15) >> 4;     // k-blocks of the DNN input (= steps of layer 0)
     const int NDB = NB - NBE;                      // dense k-blocks (0 .. MAX_DENSE_BLOCKS)
+    // POOL: the last n_pool fields are sequences pooled inside the pass — the pair machinery below (ids, range checks, linear entries, row
+    // requests) covers the first NSF fields = NBS k-blocks only; their k-blocks [NBS, NBE) take their operand from the pooled vectors
+    const int NSF = POOL ? p.n_fields - p.n_pool : p.n_fields;
+    const int NBS = POOL ? NSF * EB : NBE;
     const int emb_rows = p.n_fields * E;           // rows of W0 the embedding part takes (FPB > 1: not necessarily whole k-blocks)
     const int STEPS = NB + SL;
     const int k_last = p.in_dim - 1;
@@ -374,9 +398,9 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         // (ids_stride_b == 1: chain_kernels.hip, eligible), so no per-lane 64-bit multiply (they were 6 quarter-rate instructions
         // per pair, and fp32 MFMAs share the vector lanes)
         const int ln = opaque_lane(), q = ln >> 5;
-        const int f0 = min(2 * pr, p.n_fields - 1);
+        const int f0 = min(2 * pr, NSF - 1);
         const int64_t sbase = (int64_t)f0 * p.ids_stride_f;
-        const int64_t qstep = 2 * pr + 1 <= p.n_fields - 1 ? p.ids_stride_f : (int64_t)0;
+        const int64_t qstep = 2 * pr + 1 <= NSF - 1 ? p.ids_stride_f : (int64_t)0;
         const int r = min(row_base + pass * PROWS + WROWS * wave + min(ln & 31, WROWS - 1), row_end - 1);
         const int64_t eo = sbase + (q ? qstep : (int64_t)0) + (int64_t)r;
         if constexpr (I64) {
@@ -392,7 +416,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         // the lane's field of the pair: its vocabulary and identity flag come from the descriptors in LDS PER LANE (two reads; as
         // scalars of both fields + per-lane selects they were ~10 more vector instructions per pair)
         const int ln = opaque_lane(), q = ln >> 5;
-        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const int fi = min(2 * pr + q, NSF - 1);
         const uint2 vv = *reinterpret_cast<const uint2*>(fdesc + 12 * fi + 4);
         const uint32_t lim = vv.y != 0u ? 0xffffffffu : vv.x;
         // identity fields (pre-pooled by dctr_embed_pool: dctr_field_t.identity): the row is the sample's index in the launch
@@ -400,17 +424,17 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
         const int rr = row_base + pass * PROWS + WROWS * wave + (ln & 31);
         const uint32_t upper = I64 ? hi : (uint32_t)((int32_t)lo >> 31);      // anything but 0: negative or >= 2^32
         const bool ok = ident || (upper == 0u && lo < lim);
-        const bool counts = (ln & 31) < WROWS && rr < row_end && 2 * pr + q < p.n_fields;
+        const bool counts = (ln & 31) < WROWS && rr < row_end && 2 * pr + q < NSF;
         if (__any(!ok && counts)) oor = 1;                 // (wave-uniform flag: a scalar register, not a VGPR)
         return ident ? (uint32_t)min(rr, row_end - 1) : (ok ? lo : 0u);
     };
     // linear-table entries of the pair (row per lane); fields without a linear table, or past the last field, give 0
     auto pair_lin_ptr = [&](int pr, uint32_t idc, bool& has) -> gbl_f_t {
         const int q = opaque_lane() >> 5;
-        const int fi = min(2 * pr + q, p.n_fields - 1);
+        const int fi = min(2 * pr + q, NSF - 1);
         const uint2 l = *reinterpret_cast<const uint2*>(fdesc + 12 * fi + 2);          // (per lane: its field's linear table)
         const uint64_t base = ((uint64_t)l.y << 32) | l.x;
-        has = base != 0 && 2 * pr + q < p.n_fields;
+        has = base != 0 && 2 * pr + q < NSF;
         const float* t = has ? reinterpret_cast<const float*>(base) : reinterpret_cast<const float*>(p.fields);
         return (gbl_f_t)(t + (has ? (REC ? idc << 5 : idc) : 0u));            // (REC: linear entries lie 32 floats apart, as the rows)
     };
@@ -437,7 +461,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
     // per request — + 0.5 % in a same-box A/B, scripts/ab_libs.sh; the same treatment of the id / linear-entry requests measured - 1.7 %)
     const uint32_t bp4_ = ((uint32_t)lane & 15u) << 2;
     const uint64_t gg16_ = (uint64_t)(((uint32_t)lane >> 4) << 4);
-    constexpr bool KEEP_LC = !CROSS;                  // (the folded-CrossNet instantiations sit at 252 - 256 registers: they rebuild)
+    constexpr bool KEEP_LC = !CROSS && !POOL;         // (the folded-CrossNet and in-pass pooling instantiations sit at 252 - 256 registers: they rebuild)
     auto issue_x1 = [&](int cb, uint32_t idc, int half, XBlk& X, auto NTc) {
         constexpr int nt = decltype(NTc)::value;
         const int f = cb / EB, h = cb % EB;
@@ -650,6 +674,157 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #pragma unroll
             for (int h = 0; h < EB; ++h) sum[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // ---- POOL: VarLenSparseFeat pooled inside the pass (reference inputs.py:120-158 varlen_embedding_lookup + get_varlen_pooling_list,
+        // layers/sequence.py:76-106 SequencePoolingLayer: sum / mean over the valid positions).  The rows of a sequence are requested TWO
+        // POSITIONS PER LAYER-0 STEP beside the step's MFMAs — a three-stage pipeline across steps, every stage's loads landing behind the
+        // next step's barrier: ids of positions (t, t + 1) [one 8-B load per N tile] -> their rows (lane (g, j): 16-B piece g of sample j's
+        // row, the layout of the block's B operand) + linear entries -> acc += row * mask in the order of t (dctr_embed_pool's order and
+        // arithmetic: the pooled vector is bit-identical to the pre-pass's).  A finished sequence's vector waits, lane-private, in the
+        // wave's park area (free during layer 0) until its k-block's step reads it as the dense k-blocks read theirs.  All of this state
+        // dies with layer 0: the register peak of the kernel (layer 1: 192 accumulator registers) is untouched.
+        int pl_next_f = 0, pl_next_t = 0;              // (wave-uniform) the next (sequence, position) whose ids are requested
+        int pl_ids_f = -1, pl_ids_t = 0;               // sequence / first position of the ids in flight (-1: none)
+        int pl_rows_f = -1;                            // sequence of the rows in flight (-1: none)
+        bool pl_ids_last = false, pl_rows_last = false;    // ... and whether they are that sequence's last
+        u32x2 pl_id[RT];
+        f32x4 pl_row[2][RT], pl_acc[RT];
+        float pl_lv[2][RT], pl_lin[RT], pl_cnt[RT];    // pl_cnt: the mean's denominator so far (valid positions, or the row's length)
+        float pl_lf[2] = {0.f, 0.f};                   // finished sequences' pooled first-order terms, row per lane (sequence 2 r + lane half -> [r])
+        int pl_len[RT];                                // valid lengths of the sequence whose ids are in flight (length_name given)
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt) {
+            pl_acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pl_lin[nt] = 0.f;
+            pl_cnt[nt] = 0.f;
+            pl_len[nt] = 0;
+            pl_id[nt] = u32x2{0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pl_row[u][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pl_lv[u][nt] = 0.f;
+            }
+        }
+        // (descriptor i lies in LDS since the launch's start — a load through p.pool here would be a vector load + a wait for EVERYTHING
+        // in flight: the DMA, the rows — in every step: measured, + 1.7 us per step)
+        auto pool_seq = [&](int i) -> dctr_pool_seq_t {
+            const uint4 a = *reinterpret_cast<const uint4*>(cpar + POOLD_OFF + 8 * i), b = *reinterpret_cast<const uint4*>(cpar + POOLD_OFF + 8 * i + 4);
+            dctr_pool_seq_t d;
+            d.idx = reinterpret_cast<const void*>(sgpr64(a.x, a.y));
+            d.length = reinterpret_cast<const int32_t*>(sgpr64(a.z, a.w));
+            d.idx_stride = (int64_t)sgpr64(b.x, b.y);
+            d.maxlen = __builtin_amdgcn_readfirstlane((int)b.z);
+            d.combiner = __builtin_amdgcn_readfirstlane((int)b.w);
+            return d;
+        };
+        auto pool_piece = [&]() {
+            if constexpr (POOL) {
+                // (A) the rows requested a step ago have landed: accumulate; a finished sequence leaves for the park area
+                if (pl_rows_f >= 0) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < RT; ++nt) {
+                            // (a masked or out-of-range position arrives as zeros — stage B — where the pre-pass adds row * 0: acc + 0 = acc)
+                            pl_acc[nt] += pl_row[u][nt];
+                            pl_lin[nt] += pl_lv[u][nt];
+                        }
+                    if (pl_rows_last) {
+                        const bool mean = ((p.pool_flags >> pl_rows_f) & 1) != 0;
+                        f32x4* pv = park_ptr();
+                        float lfin[RT];
+#pragma unroll
+                        for (int nt = 0; nt < RT; ++nt) {
+                            f32x4 v = pl_acc[nt];
+                            float l = pl_lin[nt];
+                            if (mean) {
+                                const float denom = pl_cnt[nt] + 1e-8f;                                                 // sequence.py:65,103
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] / denom;
+                                l = l / denom;
+                            }
+                            pv[(pl_rows_f * RT + nt) * 64] = v;
+                            lfin[nt] = l;
+                            pl_acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            pl_lin[nt] = 0.f;
+                            pl_cnt[nt] = 0.f;
+                        }
+                        // the pooled first-order term joins the linear sum where the pre-pooled (identity) form added it: row per lane,
+                        // lanes 0-31 / 32-63 = the even / odd field of a pair, after the SparseFeat pairs in field order
+                        const int ln = opaque_lane(), r = ln & 31;
+                        float take = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (r & 15), __builtin_bit_cast(int, lfin[0])));
+                        if constexpr (RT > 1) {
+                            const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (r & 15), __builtin_bit_cast(int, lfin[RT - 1])));
+                            take = (r >> 4) ? t1 : take;
+                        }
+                        // (kept until the SparseFeat pairs' entries are in — below, behind the step loop — so that the sum's order is the
+                        // identity form's: sequence i is field NSF + i, the lane half of its parity, pairs in field order)
+                        const uint2 lt = *reinterpret_cast<const uint2*>(fdesc + 12 * (NSF + pl_rows_f) + 2);
+                        const bool has_lin = (lt.x | lt.y) != 0u;
+                        const bool mine = has_lin && (ln >> 5) == ((NSF + pl_rows_f) & 1);
+                        const int rnd = pl_rows_f >> 1;        // sequences i and i + 2 share a lane half: [0] the half's first, [1] its second
+                        if (rnd == 0) pl_lf[0] = mine ? take : pl_lf[0];
+                        else pl_lf[1] = mine ? take : pl_lf[1];
+                    }
+                    pl_rows_f = -1;
+                }
+                // (B) the ids requested a step ago have landed: range check, masks, row + linear-entry requests
+                if (pl_ids_f >= 0) {
+                    const bool by_len = ((p.pool_flags >> (4 + pl_ids_f)) & 1) != 0;
+                    const int fi = NSF + pl_ids_f;
+                    const uint4 tw = *reinterpret_cast<const uint4*>(fdesc + 12 * fi);           // table, lin_table
+                    const uint2 vw = *reinterpret_cast<const uint2*>(fdesc + 12 * fi + 4);       // vocab
+                    const char* table = reinterpret_cast<const char*>(sgpr64(tw.x, tw.y));
+                    const uint64_t linb = sgpr64(tw.z, tw.w);
+                    const uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vw.y != 0u ? 0xffffffffu : vw.x));
+                    const int gg = opaque_lane() >> 4;
+                    bool bad = false;
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) {
+                        const bool row_ok = row_of(pass, nt) < row_end;
+                        if (by_len) pl_cnt[nt] = (float)pl_len[nt];                    // (mean over length_name's lengths)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t id = pl_id[nt][u];
+                            const int t = pl_ids_t + u;                               // (< maxlen: maxlen is even, pieces are pairs)
+                            const bool ok = id < lim && (int32_t)id >= 0;
+                            const bool m = by_len ? t < pl_len[nt] : id != 0u;
+                            bad = bad || (row_ok && !ok);
+                            if (!by_len && m) pl_cnt[nt] += 1.f;                       // (mean over the valid positions, in range or not)
+                            pl_row[u][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            pl_lv[u][nt] = 0.f;
+                            if (m && ok) {                                             // masked positions request nothing
+                                // (scalar base + one 32-bit lane offset: the host admits tables below 4 GiB here — no 64-bit address pair per load)
+                                pl_row[u][nt] = *(gbl_f4_t)(table + (uint32_t)((id << 6) + (uint32_t)(16 * gg)));
+                                if (linb != 0) pl_lv[u][nt] = *(gbl_f_t)(reinterpret_cast<const char*>(linb) + (uint32_t)(id << 2));
+                            }
+                        }
+                    }
+                    if (__any(bad)) oor = 1;
+                    pl_rows_f = pl_ids_f;
+                    pl_rows_last = pl_ids_last;
+                    pl_ids_f = -1;
+                }
+                // (C) the next two positions' ids (one 8-B load per N tile; at a sequence's first positions also its rows' lengths)
+                if (pl_next_f < p.n_pool) {
+                    const dctr_pool_seq_t sq = pool_seq(pl_next_f);
+#pragma unroll
+                    for (int nt = 0; nt < RT; ++nt) {
+                        // (32-bit lane offsets from the scalar bases: the host admits id matrices below 4 GiB)
+                        const uint32_t br = (uint32_t)brow_of(pass, nt) + (uint32_t)p.pool_row0;
+                        pl_id[nt] = *(gbl_u2_t)(reinterpret_cast<const char*>(sq.idx) + (uint32_t)((br * (uint32_t)sq.idx_stride + (uint32_t)pl_next_t) << 2));
+                        if (pl_next_t == 0 && sq.length != nullptr) pl_len[nt] = *(gbl_i_t)(reinterpret_cast<const char*>(sq.length) + (uint32_t)(br << 2));
+                    }
+                    pl_ids_f = pl_next_f;
+                    pl_ids_t = pl_next_t;
+                    pl_next_t += 2;
+                    pl_ids_last = pl_next_t >= sq.maxlen;
+                    if (pl_ids_last) {
+                        ++pl_next_f;
+                        pl_next_t = 0;
+                    }
+                }
+            }
+        };
         // operand pipeline of every layer: micro-steps of ONE ds_read_b128 (4 A fragments = 4 M-tiles) + 4 x RT MFMAs; the
         // fragment of micro-step u + 1 is requested before the MFMAs of micro-step u (two 4-register buffers, c0 / c1).
         // Layer 0, k-block step: micro-step u = (k-step t = u / M0, M-group mg = u % M0) reads weight row 4g + t
@@ -712,16 +887,16 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 /* every request is issued unconditionally (past the last field / pair: a clamped, redundant one):   \
                    a conditionally written register keeps its old value alive — through layers 1.. where 192 of the   \
                    256 registers hold accumulators */                                                             \
-                const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                 \
-                if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                                    \
+                const int prn_ = min(pr_ + 1, (NBS - 1) / PAIR);                                                 \
+                if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBS) ? lvn : 0.f;                                    \
                 if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);                            \
                 /* (past the last embedding block the clamped request would pair the LAST field's table with another field's ids — \
                    beyond the table where that field's vocabulary is the larger one: such a request reads row 0) */                \
-                if (s_ + 1 < PAIR) issue_x(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idc, (s_ + 1) / EB, XN);                  \
-                else issue_x(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, 0, XN);                                           \
+                if (s_ + 1 < PAIR) issue_x(min(b_ + 1, NBS - 1), b_ + 1 > NBS - 1 ? 0u : idc, (s_ + 1) / EB, XN);                  \
+                else issue_x(min(b_ + 1, NBS - 1), b_ + 1 > NBS - 1 ? 0u : idcn, 0, XN);                                           \
                 if (s_ == 0) {                                                                                   \
                     bool has_;                                                                                   \
-                    lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
+                    lvn = *pair_lin_ptr(min(pr_, (NBS - 1) / PAIR), idc, has_);                                  \
                     lvn_has = has_;                                                                              \
                 }                                                                                                \
                 if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
@@ -739,24 +914,24 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #define CHAIN_PIECE0(I, XC, XN)                                                                                  \
         {                                                                                                        \
             constexpr int i_ = (I);                                                                              \
-            const int prn_ = min(pr_ + 1, (NBE - 1) / PAIR);                                                     \
+            const int prn_ = min(pr_ + 1, (NBS - 1) / PAIR);                                                     \
             if (i_ == 0) {                                                                                       \
                 if (dma_early) dma_chunk(b_ + 2, slot_ptr(2));                                                   \
-                if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBE) ? lvn : 0.f;                    \
+                if (s_ == 1) linacc += (lvn_has && b_ - 1 < NBS) ? lvn : 0.f;                    \
                 if (s_ == PAIR - 1) idcn = fold_pair_ids(prn_, pass, idr_lo, idr_hi);            \
             }                                                                                                    \
             if (i_ == 1) {                                                                       \
-                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idc, (s_ + 1) / EB, XN, std::integral_constant<int, 0>{});      \
-                else issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, 0, XN, std::integral_constant<int, 0>{});             \
+                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBS - 1), b_ + 1 > NBS - 1 ? 0u : idc, (s_ + 1) / EB, XN, std::integral_constant<int, 0>{});      \
+                else issue_x1(min(b_ + 1, NBS - 1), b_ + 1 > NBS - 1 ? 0u : idcn, 0, XN, std::integral_constant<int, 0>{});             \
             }                                                                                                    \
             if (i_ == 2 && RT > 1) {                                                             \
-                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idc, (s_ + 1) / EB, XN, std::integral_constant<int, RT - 1>{}); \
-                else issue_x1(min(b_ + 1, NBE - 1), b_ + 1 > NBE - 1 ? 0u : idcn, 0, XN, std::integral_constant<int, RT - 1>{});        \
+                if (s_ + 1 < PAIR) issue_x1(min(b_ + 1, NBS - 1), b_ + 1 > NBS - 1 ? 0u : idc, (s_ + 1) / EB, XN, std::integral_constant<int, RT - 1>{}); \
+                else issue_x1(min(b_ + 1, NBS - 1), b_ + 1 > NBS - 1 ? 0u : idcn, 0, XN, std::integral_constant<int, RT - 1>{});        \
             }                                                                                                    \
             if (i_ == 3) {                                                                       \
                 if (s_ == 0) {                                                                                   \
                     bool has_;                                                                                   \
-                    lvn = *pair_lin_ptr(min(pr_, (NBE - 1) / PAIR), idc, has_);                                  \
+                    lvn = *pair_lin_ptr(min(pr_, (NBS - 1) / PAIR), idc, has_);                                  \
                     lvn_has = has_;                                                                              \
                 }                                                                                                \
                 if (s_ == PAIR - 2) request_pair_ids(prn_, pass, idr_lo, idr_hi);                                \
@@ -771,12 +946,20 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
             constexpr int s_ = (S);                                                                              \
             const int b_ = pr_ * PAIR + s_;                                                                      \
             CHAIN_TOP_X(XC);                                                                                     \
+            if constexpr (POOL) {   /* (the pooling pipeline's loads have landed behind the same wait: hipcc's bookkeeping goes here) */ \
+                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
+                    asm volatile("" : "+v"(pl_id[nt_]), "+v"(pl_len[nt_]), "+v"(pl_row[0][nt_]), "+v"(pl_row[1][nt_]),  \
+                                 "+v"(pl_lv[0][nt_]), "+v"(pl_lv[1][nt_]));                                      \
+            }                                                                                                    \
             const float* sb_ = slot_ptr(0);                                                                      \
             if (b_ == 0) c0 = read_l0(sb_, 0);                                                                   \
             if (DEEP && b_ == 0) c1 = read_l0(sb_, 1);                                                           \
             if (b_ >= NBE) {                                                                                     \
                 _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_)                                             \
                     XC.x[nt_] = *reinterpret_cast<const f32x4*>(dreg + (16 * nt_ + j) * (16 * NDB) + 16 * (b_ - NBE) + 4 * g); \
+            } else if (POOL && b_ >= NBS) {                                                                      \
+                const f32x4* pv_ = park_ptr();                /* the pooled vector of sequence b_ - NBS (pool_piece) */ \
+                _Pragma("unroll") for (int nt_ = 0; nt_ < RT; ++nt_) XC.x[nt_] = pv_[((b_ - NBS) * RT + nt_) * 64]; \
             }                                                                                                    \
             _Pragma("unroll") for (int u_ = 0; u_ < 4 * M0; u_ += 2) {                                           \
                 if (!DEEP) c1 = read_l0(sb_, u_ + 1);                                                            \
@@ -785,6 +968,7 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
                 DCTR_SB;                                                                                         \
                 mfma_l0(c0, XC, u_);                                                                             \
                 DCTR_SB;                                                                                         \
+                if (POOL && u_ == 0 && b_ < NBS) pool_piece();   /* first in the step: its loads get the whole step to land */ \
                 if (CHAIN_SPREAD) {                                                                              \
                     if (u_ == 0) CHAIN_PIECE0(0, XC, XN)                                                         \
                     if (u_ == 2) CHAIN_PIECE0(1, XC, XN)                                                         \
@@ -928,7 +1112,11 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 #undef CHAIN_STEP0
 #undef CHAIN_PIECE0
 #undef CHAIN_PHASE0
-        if (FPB == 1 && (NB - 1) % PAIR == 0 && NB - 1 < NBE) {
+        if constexpr (POOL) {      // the pooled first-order terms, in the pairs' order
+            linacc += pl_lf[0];
+            linacc += pl_lf[1];
+        }
+        if (FPB == 1 && (NB - 1) % PAIR == 0 && NB - 1 < NBS) {
             // the last step was step 0 of a field pair (odd field count, no dense k-block behind it): the pair's linear
             // entries, added up in a pair's step 1, are still on their way
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lvn) : : "memory");
@@ -1172,7 +1360,8 @@ __device__ __forceinline__ void chain_passes(const ChainParams& p, float* smem, 
 }
 
 // RT, NW: launch shape of the main phase; TAIL: the kernel also carries the tail phase (64-row units: 4 waves x 16 rows)
-template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool CROSS = false, int FPB = 1, bool EXPACT = false, bool REC = false>
+template <int RT, int NW, int EB, bool I64, int M0, int M1, int M2, bool TAIL, bool CROSS = false, int FPB = 1, bool EXPACT = false, bool REC = false,
+          bool POOL = false>
 __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     constexpr int NT = 64 * NW;
     typedef ChainOff<M0, M1, M2> Off;
@@ -1206,6 +1395,10 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
         }
     }
     for (int i = threadIdx.x; i < 256; i += NT) dlw[i] = (p.dense_lin_w != nullptr && i < p.n_dense) ? p.dense_lin_w[i] : 0.f;
+    if constexpr (POOL) {       // the pooled sequences' descriptors (8 dwords each)
+        for (int i = threadIdx.x; i < 8 * p.n_pool; i += NT)
+            reinterpret_cast<uint32_t*>(cpar + POOLD_OFF)[i] = reinterpret_cast<const uint32_t*>(p.pool)[i];
+    }
     if constexpr (CROSS) {
         // the cross vectors, zero-padded to whole k-blocks, and the row-independent constants of the recurrence
         float* xv = smem + p.xv_off;
@@ -1228,14 +1421,14 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(ChainParams p) {
     __syncthreads();                                   // LDS parameters written
     int oor = 0;
     const int main_end = (int)(TAIL ? p.main_rows : p.batch);
-    chain_passes<RT, NW, EB, I64, M0, M1, M2, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
+    chain_passes<RT, NW, EB, I64, M0, M1, M2, CROSS, FPB, EXPACT, REC, POOL>(p, smem, wave, lane, 0, main_end, (int)blockIdx.x, (int)gridDim.x, p.n_pass, oor);
     if constexpr (TAIL) {
         if (p.n_tail > 0) {
             // every wave is through with the ring and the staging areas of the main phase; waves 4.. leave (s_barrier waits for
             // the surviving waves of a workgroup only), waves 0-3 take the workgroup's 64-row units
             __syncthreads();
             if (wave < 4)
-                chain_passes<1, 4, EB, I64, M0, M1, M2, CROSS, FPB, EXPACT, REC>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
+                chain_passes<1, 4, EB, I64, M0, M1, M2, CROSS, FPB, EXPACT, REC, POOL>(p, smem, wave, lane, main_end, (int)p.batch, (int)blockIdx.x,
                                                                          (int)gridDim.x, p.n_tail, oor);
         }
     }
@@ -1255,5 +1448,6 @@ int launch_r2w8_m42q(const ChainParams& p, int E, int M2, unsigned blocks, hipSt
 int launch_r2w8_m42t(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // sigmoid / tanh DNNs (chain_kernels_r2w8_m42_t.hip)
 int launch_r2w8_m42w(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // embedding_dim 64 (chain_kernels_r2w8_m42_w.hip)
 int launch_r2w8_m42r(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // record-form tables, embedding_dim 16 (chain_kernels_r2w8_m42_r.hip)
+int launch_r2w8_m42p(const ChainParams& p, int E, int M2, unsigned blocks, hipStream_t stream);     // in-pass sequence pooling, embedding_dim 16 (chain_kernels_r2w8_m42_p.hip)
 
 }  // namespace dctr_chain

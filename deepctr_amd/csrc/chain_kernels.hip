@@ -38,6 +38,13 @@ int eligible(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, bool forc
                           !g->any_identity))
         return 0;
     if (g->n_fields < 1 || g->n_fields > 64 || g->n_dense > 16 * MAX_DENSE_BLOCKS) return 0;
+    // sequences pooled inside the pass (POOL): the m42 kernels, embedding_dim 16, ReLU / linear, plain tables, no identity fields; the
+    // sequences' positions must fit the request slots of the SparseFeat k-blocks' steps (two per step, a pipeline of depth two)
+    if (g->n_pools != 0 && !(g->n_pools >= 1 && g->n_pools <= 4 && g->pools != nullptr && E == 16 && M[0] == 4 && M[1] == 2 && a->tile_rows != 128 &&
+                             a->cross_layers == 0 && !expact && !g->any_pitch && !g->any_identity && g->n_pools < g->n_fields &&
+                             g->pool_pieces >= g->n_pools && g->pool_pieces + 2 <= g->n_fields - g->n_pools && g->pool_row0 >= 0 &&
+                             g->pool_row0 + a->batch < (1LL << 31)))
+        return 0;
     if (a->cross_layers > 0 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && E >= 16)) return 0;   // CROSS: the m42 kernels
     // embedding_dim 8 / 4 (several fields per k-block): the m42 kernels, fp32, no identity (pre-pooled) fields, <= 4 dense k-blocks
     if (E < 16 && !(M[0] == 4 && M[1] == 2 && a->precision == 0 && a->tile_rows != 128 && !g->any_identity)) return 0;
@@ -149,6 +156,13 @@ int launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* g, int fm_used
     const int64_t slots = n_cus();
     const int64_t want = p.n_pass > p.n_tail ? p.n_pass : p.n_tail;
     const unsigned blocks = (unsigned)(want < slots ? want : slots);
+    if (g->n_pools > 0) {
+        p.pool = g->pools;
+        p.pool_row0 = g->pool_row0;
+        p.n_pool = g->n_pools;
+        p.pool_flags = g->pool_flags;
+        return launch_r2w8_m42p(p, E, M[2], blocks, stream);
+    }
     if (g->any_pitch) return launch_r2w8_m42r(p, E, M[2], blocks, stream);
     if (a->cross_layers > 0) return launch_r2w8_m42x(p, E, M[2], blocks, stream);
     if (a->activation == DCTR_ACT_SIGMOID || a->activation == DCTR_ACT_TANH) return launch_r2w8_m42t(p, E, M[2], blocks, stream);

@@ -189,6 +189,11 @@ static int mlp_launch(const dctr_mlp_args_t* a, const dctr_gather_fm_args_t* ga,
             return rc;
         }
     }
+    // sequences pooled inside the launch exist in the row-chained kernel only
+    DCTR_REQUIRE(ga == nullptr || ga->n_pools == 0, DCTR_E_UNSUPPORTED,
+                 "embed_mlp_fwd: n_pools %d: in-launch sequence pooling exists for row-chained launches (>= 64 rows per CU, uniform_dim 16, DNN of the "
+                 "256-128-x family, sum / mean, pool_pieces + 2 <= SparseFeat fields); pre-pool with dctr_embed_pool (identity fields) otherwise",
+                 ga != nullptr ? ga->n_pools : 0);
     // fused launches with >= 64 rows per CU (or tile_rows == 64): the streaming kernel, when the model is eligible
     if (ga != nullptr && (a->tile_rows == 0 || a->tile_rows == 64)) {
         int rc = DCTR_OK;

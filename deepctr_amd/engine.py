@@ -677,10 +677,11 @@ class EmbeddingStage(object):
         ops.hash_fields(ws["desc"], nf, staged.ids[:nf, lo:hi], out)
         return out
 
-    def gather_args(self, staged, lo, hi, ws, to_hbm=True, prehashed=None, records=False):
+    def gather_args(self, staged, lo, hi, ws, to_hbm=True, prehashed=None, records=False, pools=None):
         """dctr_gather_fm_args_t for rows [lo, hi) (pooled fields must already be in the workspace).  ``prehashed``: the id
         matrix ``prehash`` returned — the fields are then described as plain rows.  ``records``: the record-form copies of the tables
-        (refresh_records; the caller has checked records_ready(): plain or pre-hashed ids only)."""
+        (refresh_records; the caller has checked records_ready(): plain or pre-hashed ids only).  ``pools`` = pool_inside_args(staged):
+        the sequence features are pooled inside the launch (nothing of them needs to be in the workspace)."""
         B = hi - lo
         nf = len(self.fields)
         ids = staged.ids[:, lo:hi] if staged.ids is not None else None
@@ -693,6 +694,12 @@ class EmbeddingStage(object):
                 raise ValueError("gather_args(records=True): hashed ids must be resolved first (prehashed=...)")
             desc = self._rec_desc
         dense = staged.dense[lo:hi] if staged.dense is not None else None
+        pool_kw = {}
+        if pools is not None:
+            if records or prehashed is not None:
+                raise ValueError("gather_args(pools=...): plain tables, plain ids")
+            desc = self.pool_descriptors()
+            pool_kw = dict(pools=pools[0], pool_row0=lo, pool_pieces=pools[1], n_pools=len(self.pooled_fields), pool_flags=pools[3])
         return ops.make_gather_args(desc, nf, ids, stride_f, 1, B, self.max_dim,
                                     self.all_dim4, any_hash, dense=dense, dense_lin_w=self.dense_lin_w,
                                     dense_out_offset=self.dense_offset if self.n_dense_dnn else -1,
@@ -700,8 +707,57 @@ class EmbeddingStage(object):
                                     out_stride=self.out_stride,
                                     fm_logit=ws["fm"] if (self.fm_group_names and to_hbm) else None,
                                     lin_logit=ws["lin"] if (self.has_linear and to_hbm) else None, status=ws["status"],
-                                    split=self.k_split, uniform_dim=self.uniform_dim, any_identity=bool(self.pooled_fields),
-                                    any_pitch=bool(records))
+                                    split=self.k_split, uniform_dim=self.uniform_dim, any_identity=bool(self.pooled_fields) and pools is None,
+                                    any_pitch=bool(records), **pool_kw)
+
+    # -- sequences pooled INSIDE the fused launch (dctr_gather_fm_args_t.pools; csrc/chain_device.h: pool_piece) ------------------------
+    # Built and measured in round 6, and NOT the default: C2 + two mean-pooled T = 20 sequences, 131,072 rows per call, same box —
+    # pooled inside 298 - 299 M samples/s, dctr_embed_pool pre-pass + the same kernel 322 - 323 M (profiles/r06e_varlen_pool_inside_ab.log).
+    # fp32 MFMAs execute on the vector lanes: the ~70 vector instructions a pooling piece adds to a layer-0 step (masks, addresses,
+    # accumulation; both waves of a SIMD) are matrix time lost one for one, the same vector work the pre-pass spends with the matrix pipe
+    # idle — and its rows, competing with 166 MB of SparseFeat tables for the L2, come from the Infinity Cache where the pre-pass finds
+    # them in L2.  What in-launch pooling saves (two launches, the pooled rows' round trip through HBM) is less than that.
+    pool_inside = False         # True: VarLenSparseFeat (sum / mean) pooled inside the row-chained launch; the two forms give the same bits
+
+    def pool_inside_args(self, staged):
+        """(DEVICE dctr_pool_seq_t array, pool_pieces) when this plan's sequence features meet the contract of in-launch pooling for
+        ``staged`` (include/dctr.h: dctr_pool_seq_t — the library cannot check device-resident descriptors, the host does), else None.
+        Whether a given launch takes that form is the library's answer (dctr_mlp_fwd_supported), not decided here."""
+        if not (self.pool_inside and self.pooled_fields) or self.any_hash or self.lin_only or self.uniform_dim != 16:
+            return None
+        got = getattr(staged, "_pool_inside", None)
+        if got is not None:
+            return got or None
+        npf = len(self.pooled_fields)
+        ok = npf <= 4 and all(f.kind == "pooled" for f in self.fields[-npf:]) and len(self.fields) > npf
+        seqs = []
+        for f in self.pooled_fields if ok else ():
+            fc = f.fc
+            ids = staged.seq.get(fc.name)
+            ln = staged.length.get(fc.length_name) if fc.length_name is not None else None
+            ok = ok and (fc.combiner in ("sum", "mean") and fc.weight_name is None and not (fc.use_hash and not prehashed_on_host(fc))
+                         and ids is not None and ids.dtype == torch.int32 and ids.dim() == 2 and ids.is_contiguous()
+                         and ids.shape[1] % 2 == 0 and ids.shape[1] >= 2 and ids.data_ptr() % 8 == 0 and ids.numel() * 4 < 2 ** 32
+                         and f.table.numel() * 4 < 2 ** 32 and f.table.is_contiguous()
+                         and (fc.length_name is None or (ln is not None and ln.dtype == torch.int32 and ln.is_contiguous())))
+            if not ok:
+                break
+            seqs.append((ids, ln, fc.combiner))
+        if not ok:
+            staged._pool_inside = False
+            return None
+        flags = sum(((s[2] == "mean") << i) | ((s[1] is not None) << (4 + i)) for i, s in enumerate(seqs))
+        staged._pool_inside = (ops.make_pool_seqs(seqs, self.device), sum(s[0].shape[1] // 2 for s in seqs), seqs, flags)
+        return staged._pool_inside
+
+    def pool_descriptors(self):
+        """The gather's field descriptors with the sequence features as what they are — tables, not identity rows (in-launch pooling)."""
+        d = getattr(self, "_desc_pool", None)
+        if d is None:
+            fields = [dict(table=f.table, lin_table=f.lin_table, vocab=f.table.shape[0], dim=f.dim, out_offset=f.out_offset, in_fm=f.in_fm,
+                           hash_mode=f.hash_mode if f.kind == "sparse" else 0) for f in self.fields]
+            d = self._desc_pool = ops.make_field_descriptors(fields, self.device)
+        return d
 
     def run_pools(self, staged, lo, hi, light=False):
         ws = self.workspace(hi - lo, light)

@@ -93,6 +93,7 @@ class FusedForward(object):
     _pad = _pad_spec = None
     _declined = frozenset()     # launch sizes dctr_embed_mlp_fwd declined (_forward_fast)
     _accepted = frozenset()
+    _pool_declined = frozenset()
 
     # ---- hooks --------------------------------------------------------------------------------------------------------------
     def _head_weights(self):
@@ -128,6 +129,7 @@ class FusedForward(object):
         self._fast = {}             # batch size -> marshalled argument structs of the fused launch
         self._declined = set()      # launch sizes the library declined (DCTR_E_UNSUPPORTED): these go through dnn_in
         self._accepted = set()      # (rows, tile_rows, task) the library said it takes (dctr_mlp_fwd_supported)
+        self._pool_declined = set() # launch sizes whose sequences the library does not pool inside the launch (pre-pass route)
         self._pad = None            # zero-padded copies of the DNN weights at widths the row-chained kernel is instantiated for
         self._pad_spec = self._chain_pad_spec(dnn_hidden_units, dnn_activation)
         self.probe = None           # bench: uint64[2] device tensor receiving the fused launch's wall-clock stamps
@@ -380,6 +382,33 @@ class FusedForward(object):
             _C.check(fn(ctypes.byref(g), ctypes.byref(m), a, b, stream), "dctr_embed_mlp_fwd")
         launch.keep = (g, m, keep, ws, staged, out, own_ids, own_add)
         return launch
+
+    def _forward_pool_inside(self, staged, lo, hi, out):
+        """Rows [lo, hi) with the VarLenSparseFeat pooled INSIDE the fused launch (reference inputs.py:133-158 get_varlen_pooling_list +
+        layers/sequence.py:76-106, combiner sum / mean): True when the launch went out that way.  The plan says whether the staged
+        sequences meet the contract (EmbeddingStage.pool_inside_args), the library whether this launch takes the form
+        (dctr_mlp_fwd_supported: row-chained launches, the positions must fit the request slots) — asked once per launch size."""
+        import ctypes
+        from .. import _C
+        sp, B = self.stage_plan, hi - lo
+        pools = sp.pool_inside_args(staged) if (sp.pooled_fields and self.tile_rows in (0, 256)) else None
+        if pools is None or B in self._pool_declined:
+            return False
+        ws = {"desc": None, "status": sp.status(), "dnn_in": None, "fm": None, "lin": None}      # (no per-row buffer: any span)
+        g = sp.gather_args(staged, lo, hi, ws, to_hbm=False, pools=pools)
+        ks, bs, hw, bn = self._dnn_operands(B)
+        m, keep = ops.mlp(None, ks, bs, self.dnn.activation, dice=self.dnn.dice_params(), bn=bn, head_w=hw,
+                          global_bias=self.prediction.w('global_bias'), sigmoid_out=self.task == "binary", in_dim=sp.in_dim, out=out,
+                          gather=g, batch=B, launch=False, tile_rows=self.tile_rows, probe=self.probe)
+        fm, lin = int(bool(sp.fm_group_names)), int(sp.has_linear)
+        if not _C.lib().dctr_mlp_fwd_supported(ctypes.byref(g), ctypes.byref(m), fm, lin):
+            if len(self._pool_declined) >= 64:
+                self._pool_declined.clear()
+            self._pool_declined.add(B)
+            return False
+        _C.check(_C.lib().dctr_embed_mlp_fwd(ctypes.byref(g), ctypes.byref(m), fm, lin, _C.stream_ptr()), "dctr_embed_mlp_fwd")
+        del keep
+        return True
 
     def _fast_path(self, staged):
         sp = self.stage_plan

@@ -34,6 +34,8 @@ class _DeepFM(FusedForward, FeatureModel):
         sp = self.stage_plan
         if self._fast_path(staged) and self._forward_fast(staged, lo, hi, out):
             return
+        if sp.fusable and self.fused and (hi - lo) not in self._declined and self._forward_pool_inside(staged, lo, hi, out):
+            return          # (the sequences were pooled inside the one launch: no dctr_embed_pool pre-pass, no pooled rows in HBM)
         if sp.fusable and self.fused and (hi - lo) not in self._declined:
             # ONE launch: gather -> LDS tile -> DNN -> head (+ linear + FM logits from the gather epilogue)
             ws = sp.run_pools(staged, lo, hi, light=True)

@@ -286,9 +286,11 @@ def row_stride(t):
 
 def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max_dim, all_dim4, any_hash,
                      dense=None, dense_lin_w=None, dense_out_offset=-1, dense_copy_cols=None, dnn_in=None, out_stride=0,
-                     fm_logit=None, lin_logit=None, status=None, split=(0, 0), uniform_dim=0, any_identity=False, any_pitch=False):
+                     fm_logit=None, lin_logit=None, status=None, split=(0, 0), uniform_dim=0, any_identity=False, any_pitch=False,
+                     pools=None, pool_row0=0, pool_pieces=0, n_pools=0, pool_flags=0):
     """Fill a dctr_gather_fm_args_t (see include/dctr.h).  The caller keeps every tensor alive.
-    ``split`` = (split_col, split_field), see the header; (0, 0) = none."""
+    ``split`` = (split_col, split_field), see the header; (0, 0) = none.  ``pools``: DEVICE array of dctr_pool_seq_t (make_pool_seqs) for
+    the last ``n_pools`` fields — sequences pooled inside dctr_embed_mlp_fwd; the launch's rows start at row ``pool_row0`` of their ids."""
     _dev_check(desc, ids, dense, dnn_in)
     is64 = 0
     if ids is not None:
@@ -310,7 +312,18 @@ def make_gather_args(desc, n_fields, ids, ids_stride_f, ids_stride_b, batch, max
                            lin_logit=None if lin_logit is None else lin_logit.data_ptr(),
                            status=None if status is None else status.data_ptr(),
                            split_col=int(split[0]), split_field=int(split[1]), uniform_dim=int(uniform_dim),
-                           any_identity=int(bool(any_identity)), any_pitch=int(bool(any_pitch)))
+                           any_identity=int(bool(any_identity)), any_pitch=int(bool(any_pitch)),
+                           n_pools=int(n_pools), pools=None if pools is None else pools.data_ptr(), pool_row0=int(pool_row0),
+                           pool_pieces=int(pool_pieces), pool_flags=int(pool_flags))
+
+
+def make_pool_seqs(seqs, device):
+    """DEVICE array of dctr_pool_seq_t from [(ids [N, T] int32 tensor, length [N] int32 tensor or None, combiner 'sum' | 'mean'), ...]."""
+    arr = (_C.PoolSeq * max(1, len(seqs)))()
+    for i, (ids, length, combiner) in enumerate(seqs):
+        arr[i].idx, arr[i].length = ids.data_ptr(), (None if length is None else length.data_ptr())
+        arr[i].idx_stride, arr[i].maxlen, arr[i].combiner = ids.stride(0), ids.shape[1], _C.POOL_CODES[combiner]
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
 def embed_gather_fm(*args, **kwargs):

@@ -123,6 +123,19 @@ typedef struct {
                                 takes descriptors rejects args->any_pitch (DCTR_E_UNSUPPORTED)                           */
 } dctr_field_t;
 
+enum { DCTR_POOL_SUM = 0, DCTR_POOL_MEAN = 1, DCTR_POOL_MAX = 2 };   /* combiner of a5 (dctr_embed_pool below, dctr_pool_seq_t) */
+
+/* a sequence feature pooled inside dctr_embed_mlp_fwd (dctr_gather_fm_args_t.pools; 32 bytes).  Contract (the descriptors live in
+ * device memory, the library cannot check them): int32 ids, idx 8-B aligned, idx_stride even, maxlen even and >= 2, the id matrix and
+ * the embedding table below 4 GiB each (32-bit lane offsets from scalar bases). */
+typedef struct {
+    const void* idx;         /* [rows, idx_stride] int32 ids of the staged data (row 0)                 */
+    const int32_t* length;   /* [rows] valid lengths (length_name given) or NULL = mask_zero on id != 0 */
+    int64_t idx_stride;      /* elements                                                                */
+    int32_t maxlen;          /* T                                                                       */
+    int32_t combiner;        /* DCTR_POOL_SUM or DCTR_POOL_MEAN                                         */
+} dctr_pool_seq_t;
+
 typedef struct {
     const dctr_field_t* fields;   /* DEVICE array [n_fields]                                            */
     const void* ids;              /* DEVICE id matrix: field j, sample b at ids[j*ids_stride_f + b*ids_stride_b]
@@ -163,7 +176,20 @@ typedef struct {
                                      kernel (LDS-DMA gather ring, 64-row tiles).  0 = unknown / not uniform              */
     int32_t any_identity;         /* 1: some field has identity != 0 (host copy of the descriptors' flags)               */
     int32_t any_pitch;            /* 1: some field has row_pitch != 0 (host copy; ABI 10)                                 */
-    int32_t pad_;
+    int32_t n_pools;              /* dctr_embed_mlp_fwd only (ABI 12); 0 = none.  The LAST n_pools fields are VarLenSparseFeat whose sequences
+                                     are pooled INSIDE the launch (inputs.py:120-158, layers/sequence.py:76-106; combiner sum / mean): their
+                                     descriptors carry table / lin_table / vocab / dim / out_offset / in_fm as a SparseFeat's would
+                                     (identity = 0, hash_mode = 0; their rows of the id matrix are unused), pools[i] the ids of the i-th.
+                                     Taken by the row-chained kernel only (launches of >= 64 rows per CU, uniform_dim 16, ReLU / linear DNN
+                                     of the 256-128-x family, no identity / hashed / record-form fields, n_pools <= 4 and
+                                     pool_pieces + 2 <= n_fields - n_pools: the sequences' rows are requested two positions per
+                                     layer-0 step of the SparseFeat k-blocks); everything else answers DCTR_E_UNSUPPORTED — pre-pool with
+                                     dctr_embed_pool and hand the fields over as identity fields (ask dctr_mlp_fwd_supported first).
+                                     The pooled vectors are bit-identical to dctr_embed_pool's (same order over t, same arithmetic).  */
+    const dctr_pool_seq_t* pools; /* DEVICE array [n_pools] (the caller's, like `fields`)                                   */
+    int64_t pool_row0;            /* the launch's row 0 is row pool_row0 of the pools' id matrices / length vectors        */
+    int32_t pool_pieces;          /* host copy: sum over the pools of maxlen / 2                                          */
+    int32_t pool_flags;           /* host copy: bit i = pools[i].combiner == DCTR_POOL_MEAN, bit 4 + i = pools[i].length != NULL */
 } dctr_gather_fm_args_t;
 
 int dctr_embed_gather_fm(const dctr_gather_fm_args_t* args, void* stream);
@@ -180,8 +206,6 @@ int dctr_hash_fields(const dctr_field_t* fields, int32_t n_fields, const void* i
  * a5  varlen_embedding_lookup + WeightedSequenceLayer + SequencePoolingLayer
  *     deepctr/inputs.py:120-158, layers/sequence.py:76-106 and :155-183.
  * ------------------------------------------------------------------------------------------------ */
-enum { DCTR_POOL_SUM = 0, DCTR_POOL_MEAN = 1, DCTR_POOL_MAX = 2 };
-
 typedef struct {
     const void* idx;         /* [B, T] ids, row stride idx_stride (elements)                            */
     const float* table;      /* [vocab, dim]                                                            */

@@ -162,7 +162,10 @@ def main():
                 a = rng.randint(1, 100000, (rows, T)).astype(np.int32)
                 a[np.arange(T)[None, :] >= rng.randint(1, T + 1, rows)[:, None]] = 0
                 feed["S%d" % i] = a
-            run_span("C2 + 2 mean-pooled seq (pool + chain)", m, feed, 4096, dnn_flop=dnn_flop(461))
+            run_span("C2 + 2 mean-pooled seq (pool pre-pass + chain)", m, feed, 4096, dnn_flop=dnn_flop(461))
+            m.stage_plan.pool_inside = True                # A/B: the sequences pooled inside the row-chained launch (round 6; not the default)
+            run_span("C2 + 2 mean-pooled seq (pooled inside the launch)", m, feed, 4096, dnn_flop=dnn_flop(461))
+            m.stage_plan.pool_inside = False
         del m
     if "c2_wide" in want:    # other DNN widths on the row-chained kernel
         for units in ((128, 128), (256, 128), (200, 80), (256, 128, 128)):

@@ -33,7 +33,7 @@ def test_struct_sizes_match_the_header_layout():
     import ctypes
     from deepctr_amd import _C
     assert ctypes.sizeof(_C.FieldDesc) == 48
-    assert ctypes.sizeof(_C.GatherFmArgs) == 8 * 4 + 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 6
+    assert ctypes.sizeof(_C.GatherFmArgs) == 8 * 4 + 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 6 + 8 * 2 + 4 * 2
     assert ctypes.sizeof(_C.LookupArgs) == 8 * 4 + 4 * 4 + 8 * 4
     assert ctypes.sizeof(_C.PoolArgs) == 8 * 8 + 4 * 6 + 8 * 4
 
@@ -213,7 +213,8 @@ def test_every_ctypes_mirror_has_the_layout_the_c_compiler_gives_the_header(tmp_
              "FieldGrad": "dctr_field_grad_t", "GatherFmBwdArgs": "dctr_gather_fm_bwd_args_t", "PoolBwdArgs": "dctr_pool_bwd_args_t",
              "MlpBwdArgs": "dctr_mlp_bwd_args_t", "DnnTrainLayer": "dctr_dnn_train_layer_t", "CinBwdArgs": "dctr_cin_bwd_args_t", "CrossBwdArgs": "dctr_crossnet_bwd_args_t", "CrossMixBwdArgs": "dctr_crossnet_mix_bwd_args_t",
              "AfmBwdArgs": "dctr_afm_bwd_args_t", "HostCol": "dctr_host_col_t", "AdamSeg": "dctr_adam_seg_t",
-             "DinAttnArgs": "dctr_din_attn_args_t", "CrossnetArgs": "dctr_crossnet_args_t", "DinGatherArgs": "dctr_din_gather_t"}
+             "DinAttnArgs": "dctr_din_attn_args_t", "CrossnetArgs": "dctr_crossnet_args_t", "DinGatherArgs": "dctr_din_gather_t",
+             "PoolSeq": "dctr_pool_seq_t"}
     mirrors = [n for n in dir(_C) if isinstance(getattr(_C, n), type) and issubclass(getattr(_C, n), ctypes.Structure)
                and getattr(_C, n) is not ctypes.Structure]
     assert sorted(mirrors) == sorted(pairs), "a ctypes mirror without a header struct in this test: %s" % (set(mirrors) ^ set(pairs))

