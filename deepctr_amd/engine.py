@@ -587,13 +587,18 @@ class EmbeddingStage(object):
         recs = getattr(self, "_rec", None)
         if recs is None:
             recs = self._rec = {}
+        # INVARIANT of this weight cache: a copy is current iff (torch's in-place version counters of the table and its linear table, the
+        # model's count of raw-pointer weight writes — HipTrainer.apply_update bumps model._raw_weight_writes) are what they were when it was
+        # made.  A weight write that moves neither (none exists in this repository) must call invalidate_records().  Copies are keyed by
+        # (address, shape): a reallocated table gets a new copy AND new descriptors.
         with torch.no_grad():
             for f in self.fields:
-                key = f.table.data_ptr()
+                key = (f.table.data_ptr(), tuple(f.table.shape))
                 ver = (f.table._version, -1 if f.lin_table is None else f.lin_table._version, int(raw_writes))
                 ent = recs.get(key)
                 if ent is None:
                     ent = recs[key] = [torch.zeros(f.table.shape[0], 32, dtype=torch.float32, device=self.device), None]
+                    self._rec_desc = None                     # (descriptors point at record tensors: rebuilt below)
                 if ent[1] != ver:
                     ent[0][:, :16].copy_(f.table)
                     if f.lin_table is not None:
@@ -602,11 +607,16 @@ class EmbeddingStage(object):
         if getattr(self, "_rec_desc", None) is None:
             fields = []
             for f in self.fields:
-                rec = recs[f.table.data_ptr()][0]
+                rec = recs[(f.table.data_ptr(), tuple(f.table.shape))][0]
                 fields.append(dict(table=rec, lin_table=None if f.lin_table is None else rec.view(-1)[16:], vocab=f.table.shape[0],
                                    dim=f.dim, out_offset=f.out_offset, in_fm=f.in_fm, hash_mode=0, row_pitch=32))
             self._rec_desc = ops.make_field_descriptors(fields, self.device)
         self.records_current = True
+
+    def invalidate_records(self):
+        """Drop the record-form copies: the next launch that wants them rebuilds copies and descriptors (set_weights and the trainer go
+        through the version counters; this is the explicit hook for any other writer)."""
+        self._rec, self._rec_desc, self.records_current = {}, None, False
 
     def records_ready(self, staged):
         """Record descriptors may serve a launch on these staged rows: the copies are current (refreshed here, once per predict() call,

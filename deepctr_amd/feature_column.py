@@ -5,7 +5,7 @@ Mirrors ``/root/reference/deepctr/feature_column.py`` (names, field order, defau
 ``get_feature_names`` (:140-142), ``build_input_features`` (:145-168).  What differs is what sits
 behind them: the reference turns columns into Keras ``Input``/``Embedding`` graph nodes; here they
 are compiled once per model into a *plan* (table registry, id-matrix layout, descriptor arrays —
-``deepctr_amd/plan.py``) executed by HIP kernels.
+``deepctr_amd/engine.py``: ``EmbeddingStage``) executed by HIP kernels.
 """
 from collections import OrderedDict, namedtuple
 

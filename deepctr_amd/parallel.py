@@ -22,32 +22,42 @@ def slice_feed(feed, lo, hi):
     return {k: np.asarray(v)[lo:hi] for k, v in feed.items()}
 
 
-def sharded_predict(local_predict, feed, n, group=None):
+def sharded_predict(local_predict, feed, n, group=None, presharded=False):
     """Run ``local_predict(feed_shard) -> 1-D float32 tensor`` on this rank's row shard and all-gather the pieces.
-    Works with any backend (nccl/RCCL with device tensors, gloo with CPU tensors).  Returns np.ndarray [n, 1] on
-    every rank."""
+    Works with any backend (nccl/RCCL with device tensors, gloo with CPU tensors).  Returns np.ndarray [n_total, 1] on
+    every rank.  ``presharded``: ``feed`` holds THIS RANK'S rows only (``n`` of them; shards in rank order make up the whole) — a predict
+    over 1e8 rows need not exist in full on every rank; one more tiny all-gather tells every rank the shard sizes."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         out = local_predict(feed)
         return out.detach().cpu().numpy().reshape(-1, 1)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    lo, hi = shard_bounds(n, rank, world)
-    local = local_predict(slice_feed(feed, lo, hi)).reshape(-1).to(torch.float32)
-    if dist.get_backend(group) == "gloo":                    # gloo exchanges host tensors (several ranks may share one GPU)
+    host = dist.get_backend(group) == "gloo"                 # gloo exchanges host tensors (several ranks may share one GPU)
+    if presharded:
+        counts = torch.zeros(world, dtype=torch.int64)
+        mine = torch.tensor([int(n)], dtype=torch.int64)
+        if not host:
+            counts, mine = counts.cuda(), mine.cuda()
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        sizes = [int(c) for c in counts.cpu().tolist()]
+        lo, hi = 0, int(n)
+        shard = feed
+    else:
+        sizes = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
+        lo, hi = shard_bounds(n, rank, world)
+        shard = slice_feed(feed, lo, hi)
+    local = local_predict(shard).reshape(-1).to(torch.float32) if hi > lo else torch.zeros(0, dtype=torch.float32)
+    if host:
         local = local.cpu()
-    width = shard_bounds(n, 0, world)[1]                     # largest shard (rank 0)
+    width = max(max(sizes), 1)                               # largest shard
     padded = torch.zeros(width, dtype=torch.float32, device=local.device)
     padded[:hi - lo] = local
     gathered = torch.empty(world * width, dtype=torch.float32, device=local.device)
     dist.all_gather_into_tensor(gathered, padded, group=group) if hasattr(dist, "all_gather_into_tensor") and \
         local.is_cuda else _gather_list(dist, gathered, padded, world, group)
     g = gathered.cpu().numpy().reshape(world, width)
-    parts = []
-    for r in range(world):
-        l, h = shard_bounds(n, r, world)
-        parts.append(g[r, :h - l])
-    return np.concatenate(parts).reshape(-1, 1)
+    return np.concatenate([g[r, :sizes[r]] for r in range(world)]).reshape(-1, 1)
 
 
 def _gather_list(dist, gathered, padded, world, group):
@@ -55,14 +65,15 @@ def _gather_list(dist, gathered, padded, world, group):
     dist.all_gather(chunks, padded, group=group)
 
 
-def predict_distributed(model, x, batch_size=256, group=None):
-    """``model.predict`` with the rows of ``x`` sharded across the ranks of the process group."""
+def predict_distributed(model, x, batch_size=256, group=None, presharded=False):
+    """``model.predict`` with the rows of ``x`` sharded across the ranks of the process group.  ``presharded=True``: ``x`` is this
+    rank's shard only (rank order = row order of the result)."""
     feed = model._as_feed(x)
     n = model._num_rows(feed)
 
     def local(shard):
         return model.predict_tensor(shard, batch_size)
-    return sharded_predict(local, feed, n, group)
+    return sharded_predict(local, feed, n, group, presharded=presharded)
 
 
 def sharded_loss(local_loss_sums, n, group=None):
