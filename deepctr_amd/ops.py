@@ -624,6 +624,7 @@ def crossnet_fold_consts(kernels, bias, head, out=None):
 # ---------------------------------------------------------------------------------------------
 # adjacent: DNN (+ head), DIN attention
 # ---------------------------------------------------------------------------------------------
+_ONES = {}
 _MLP_SCRATCH = {}
 _MLP_SCRATCH_MAX = 1 << 29      # 512 MiB: the layer-by-layer DNN walks the rows in chunks of what its scratch holds
 
@@ -676,8 +677,16 @@ def mlp(x, kernels, biases, activation="relu", dice=None, dice_eps=1e-9, head_w=
         dev_t = x if x is not None else (kernels[0] if kernels else head_w)
         out = torch.empty((B,) if has_head else (B, last), dtype=torch.float32, device=dev_t.device)
     add = [a_ for a_ in add if a_ is not None]
-    if len(add) > 4:
-        raise ValueError("at most four extra logit vectors can be fused into the head")
+    while len(add) > 4:
+        # the fused head adds up to four extra logit vectors (DeepFM(fm_group=...) over many groups has more: linear + one FM logit per
+        # group, models/deepfm.py:53-57): the surplus is summed by the head itself — its no-hidden-layer form, x . 1 + sum(add) — five
+        # vectors into one per launch
+        v = add[-5:]
+        one = _ONES.get(v[0].device)
+        if one is None:
+            one = _ONES[v[0].device] = torch.ones(1, 1, dtype=torch.float32, device=v[0].device)
+        folded = mlp(_f32c(v[0], "add").reshape(-1, 1), [], [], "linear", head_w=one, add=v[1:], in_dim=1)
+        add = add[:-5] + [folded]
     add_arr = (ctypes.c_void_p * 4)()
     for i_, t_ in enumerate(add):
         add_arr[i_] = t_.data_ptr()

@@ -46,6 +46,8 @@ def supported(model):
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
     if sp.lin_only:
         return False
+    if kind == "_DIN" and (not sp.all_dim4 or sp.max_dim > 64):
+        return False                        # (the attention unit's training kernels hold a key row per lane group: widths % 4 == 0, <= 64)
     # (round 6: any embedding width — widths that are not a multiple of 4 or exceed 64, embedding_dim="auto" — the scatter kernels walk a
     # row in chunks, element per lane where rows are not 16-B aligned; such tables carry no touched-group marks: dense optimizer pass)
     if kind == "_xDeepFM" and sp.max_dim > 128:

@@ -4,7 +4,7 @@
 # kernel-trace/stats and every PMC group are SEPARATE passes (counters are never combined with API traces).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -27,6 +27,8 @@ done
 python $ROOT/scripts/pmc_summary.py $OUT/pmc_configs_summary.json $OUT/cfgpmc_* > $OUT/pmc_configs_summary.txt 2>&1
 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
 python $ROOT/bench.py > $OUT/bench_steps256.json 2> $OUT/bench_steps256.err
+python $ROOT/bench.py --workload c5 --steps 20 --warmup 5 > $OUT/bench_c5_steps20.json 2> $OUT/bench_c5_steps20.err
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $ROOT/scripts/mfma_valu_lab.cpp -o /tmp/mfma_valu_lab > /dev/null 2>&1 && /tmp/mfma_valu_lab > $OUT/mfma_valu_lab.log 2>&1
 python $ROOT/scripts/bench_configs.py > $OUT/bench_configs.log 2>&1
 for m in DeepFM DCN DCNM xDeepFM DIN; do python $ROOT/scripts/bench_train.py --model $m --batches $([ $m = DIN ] && echo 2048 || echo 4096) >> $OUT/train_steps.log 2>&1; done
 find $OUT -name "*kernel_trace.csv" -size +1M -delete

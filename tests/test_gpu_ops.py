@@ -636,6 +636,24 @@ def test_mlp_layers_wider_than_the_lds_tile(device, in_dim, units, act):
     assert _C.lib().dctr_mlp_workspace_bytes(ctypes.byref(a2)) == 0 and ops.mlp_fwd_supported(None, a2)
 
 
+def test_mlp_head_adds_any_number_of_logit_vectors(device):
+    """add_func over the logits of a model (reference layers/utils.py:328-333; DeepFM(fm_group=...) hands the head one FM logit per
+    group, models/deepfm.py:53-57): the fused head adds four vectors, more are summed through its own no-hidden-layer form first."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(3)
+    B, K = 1000, 24
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    w = (rng.standard_normal((K, 8)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32) * 0.1
+    hw = rng.standard_normal(8).astype(np.float32)
+    for n_add in (0, 4, 5, 9, 13):
+        adds = [rng.standard_normal(B).astype(np.float32) for _ in range(n_add)]
+        ref = np.maximum(x.astype(np.float64) @ w + b, 0) @ hw.astype(np.float64) + sum(a.astype(np.float64) for a in adds) + 0.25
+        y = ops.mlp(dev(x, device), [dev(w, device)], [dev(b, device)], "relu", head_w=dev(hw, device), add=[dev(a, device) for a in adds],
+                    global_bias=dev(np.array([0.25], np.float32), device))
+        assert_close(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5, what="head with %d extra logit vectors" % n_add)
+
+
 def _att_weights(g, prefix, n_layers, act, device):
     ks = [dev(g["%s/dnn/kernel%d" % (prefix, i)], device) for i in range(n_layers)]
     bs = [dev(g["%s/dnn/bias%d" % (prefix, i)], device) for i in range(n_layers)]
