@@ -793,7 +793,31 @@ def din_attention(query, keys, key_mask, kernels, biases, out_kernel, out_bias, 
         need = int(_C.lib().dctr_din_attn_workspace_bytes(ctypes.byref(a))) if compact else B * T * 4
         ws = torch.empty(max(1, (need + 3) // 4), dtype=torch.float32, device=keys.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    _C.check(_C.lib().dctr_din_attn_pool_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_din_attn_pool_fwd")
+    rc = _C.lib().dctr_din_attn_pool_fwd(ctypes.byref(a), _C.stream_ptr())
+    if rc == _C.E_UNSUPPORTED:
+        # a key width / attention MLP the on-chip kernels do not hold (e.g. three 32-wide history features: [q, k, q - k, q * k] is 384
+        # wide, two 64-position tiles of it exceed the LDS): the materialised route of the training forward — [B*T, 4E] in HBM,
+        # dctr_mlp_fwd (any width), masked (softmax-ed) weighted sum — samples in chunks of <= 256 MB of attention input
+        step = max(1, (1 << 26) // max(1, T * 4 * E))
+        for lo in range(0, B, step):
+            hi = min(B, lo + step)
+            att_in = torch.empty((hi - lo) * T, 4 * E, dtype=torch.float32, device=keys.device)
+            din_att_in(query[lo:hi], keys[lo:hi], att_in)
+            score = mlp(att_in, kernels, biases, activation, dice=dice, dice_eps=dice_eps, head_w=_f32c(out_kernel, "out_kernel").reshape(-1, 1),
+                        global_bias=out_bias, in_dim=4 * E)
+            m_ = mask[lo:hi]
+            o_ = out[lo:hi] if out.dim() == 2 else out[lo:hi].reshape(hi - lo, -1)
+            if weight_normalization:
+                prob = din_softmax(score, m_, torch.empty_like(score))
+                din_wsum(prob, torch.ones_like(m_), keys[lo:hi], o_)
+                if scores is not None:
+                    scores[lo:hi].copy_(prob.view(hi - lo, T))
+            else:
+                din_wsum(score, m_, keys[lo:hi], o_)
+                if scores is not None:           # (the eager layer API only: the masked raw scores)
+                    scores[lo:hi].copy_(torch.where(m_ != 0, score.view(hi - lo, T), torch.zeros((), device=score.device)))
+    else:
+        _C.check(rc, "dctr_din_attn_pool_fwd")
     if return_score:
         return scores.reshape(B, 1, T)
     return out.reshape(B, 1, E) if own_out else out
