@@ -2,9 +2,12 @@
 """bench.py — BASELINE.json metric: samples/sec of the DeepFM FORWARD pass on synthetic Criteo-shaped input
 (26 sparse features x vocabulary 1e5, 13 dense, embedding_dim 16, batch 4096 per GPU), fp32.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher around it: the script starts its own N ranks —
+                                                              torch.distributed.run on 127.0.0.1 — and exits non-zero when --gpus
+                                                              disagrees with the world or with the visible devices: launcher_command)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --workload c5 ...                         (BASELINE configs[4]: vocab 1e7, emb 32, 8192 rows per GPU; default c2)
 
 A "step" = one pass of the whole hot path over ONE batch of 4096 rows per GPU: ids -> multi-table gather + linear
 term + FM -> DNN 429-256-128-64 + Dense(1) + logit sum + sigmoid.  Nothing is skipped, inputs are device-resident

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
     cfield_ptr F = (cfield_ptr)p.fields;
     const float dfm = (valid && d_fm != nullptr) ? d_fm[b] : 0.f;
     const float dlin = (valid && d_lin != nullptr) ? d_lin[b] : 0.f;
+    // the forward's dnn_in still holds every field's row of this sample (dctr_gather_fm_bwd_args_t.fwd->dnn_in; VEC = 4: 16-B aligned rows)
+    const bool from_x = p.dnn_in != nullptr && (VEC == 1 || (p.out_stride % 4 == 0 && ((uintptr_t)p.dnn_in & 15) == 0));
     auto row_of = [&](const FieldRegs& f, int j) -> int64_t {
         int64_t r = f.identity ? b : read_id(p.ids, (int64_t)j * p.ids_stride_f + (valid ? b : 0) * p.ids_stride_b, p.ids_is_i64);
         if constexpr (HASH) {
@@ -134,7 +136,9 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
             const int64_t r = row_of(f, j);
             const bool ok = valid && (uint64_t)r < (uint64_t)f.vocab && q * VEC < f.dim;
             float v[VEC];
-            load_vec<VEC>(f.table + (ok ? r : 0) * f.dim + (ok ? q * VEC : 0), v);
+            // (the forward left this row in the sample's dnn_in row: a coalesced read instead of a second random one — same bits)
+            if (from_x && f.out_offset >= 0) load_vec<VEC>(p.dnn_in + (valid ? b : 0) * p.out_stride + f.out_offset + (ok ? q * VEC : 0), v);
+            else load_vec<VEC>(f.table + (ok ? r : 0) * f.dim + (ok ? q * VEC : 0), v);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) S[c] += ok ? v[c] : 0.f;
         }
@@ -160,7 +164,8 @@ __global__ __launch_bounds__(256) void gather_fm_bwd_kernel(dctr_gather_fm_args_
             if (f.out_offset >= 0 && d_in != nullptr) load_vec<VEC>(d_in + b * d_stride + f.out_offset + q * VEC, g);
             if (f.in_fm && d_fm != nullptr) {
                 float v[VEC];
-                load_vec<VEC>(f.table + r * f.dim + q * VEC, v);
+                if (from_x && f.out_offset >= 0) load_vec<VEC>(p.dnn_in + b * p.out_stride + f.out_offset + q * VEC, v);
+                else load_vec<VEC>(f.table + r * f.dim + q * VEC, v);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) g[c] = fmaf(dfm, S[c] - v[c], g[c]);
             }

@@ -602,7 +602,9 @@ typedef struct {
  * layers/interaction.py:588-604):  d e_f = d_dnn_in[b, off_f..] + d_fm[b] * (sum_f' e_f' - e_f);  d lin_f[row] += d_lin[b];
  * d dense_lin_w[k] += d_lin[b] * dense[b,k]. */
 typedef struct {
-    const dctr_gather_fm_args_t* fwd;   /* the forward call's arguments (descriptors, ids, dense)            */
+    const dctr_gather_fm_args_t* fwd;   /* the forward call's arguments (descriptors, ids, dense).  fwd->dnn_in, when not NULL, must
+                                           still hold what that forward wrote in the fields' columns: the FM term reads e_f from
+                                           there (coalesced) instead of the tables (a second random row read); NULL: from the tables */
     const dctr_field_grad_t* grads;     /* DEVICE array [n_fields], parallel to fwd->fields                  */
     const float* d_dnn_in;              /* [B, d_stride] gradient w.r.t. dnn_in, or NULL                      */
     int64_t d_stride;

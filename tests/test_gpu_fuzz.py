@@ -165,7 +165,10 @@ def run_case(seed, device, config=None):
 
 # 400 seeds + what the one-off sweeps over further seeds found (round 6, seeds 400 .. 1199: DeepFM(fm_group=...) over so many groups that
 # the head had more than four extra logit vectors to add — 690, 910, 930, 1050, 1170; scripts/gpu_call_r06g.sh)
-SEEDS = [int(t) for t in os.environ.get("DCTR_FUZZ_SEEDS", "").split(",") if t] or (list(range(400)) + [690, 910, 930, 1050, 1170])
+# 789, 2399, 3199, 3619: xDeepFM configurations whose logits reach 9 - 16 — the CHECKER's finding: logit(p) recovered from fp32
+# probabilities is ill-conditioned there, the float32 NumPy oracle misses the old bar too (tests/test_gpu_models.check_probs)
+SEEDS = [int(t) for t in os.environ.get("DCTR_FUZZ_SEEDS", "").split(",") if t] or (
+    list(range(400)) + [690, 910, 930, 1050, 1170, 789, 2399, 3199, 3619])
 
 
 @pytest.mark.gpu
