@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdctr_hip.so")
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 E_UNSUPPORTED = -5               # DCTR_E_UNSUPPORTED: valid request this build does not implement
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
@@ -204,9 +204,11 @@ SYMBOLS = {
     "dctr_crossnet_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "dctr_crossnet_head_fwd": (ctypes.c_int, [ctypes.POINTER(CrossnetArgs), c_vp]),
     "dctr_crossnet_gather_head_fwd": (ctypes.c_int, [ctypes.POINTER(CrossnetArgs), ctypes.POINTER(GatherFmArgs), c_vp]),
+    "dctr_crossnet_fwd_supported": (ctypes.c_int, [ctypes.POINTER(CrossnetArgs), ctypes.POINTER(GatherFmArgs)]),
     "dctr_crossnet_matrix_step": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "dctr_cin_workspace_bytes": (c_sz, [ctypes.POINTER(CinArgs)]),
     "dctr_cin_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), c_vp]),
+    "dctr_cin_fwd_supported": (ctypes.c_int, [ctypes.POINTER(CinArgs), ctypes.POINTER(GatherFmArgs), ctypes.c_int32]),
     "dctr_cin_gather_fwd": (ctypes.c_int, [ctypes.POINTER(CinArgs), ctypes.POINTER(GatherFmArgs), c_vp, c_vp, c_vp]),
     "dctr_afm_fwd": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "dctr_host_pack_columns": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_i32, c_i32]),

@@ -512,19 +512,114 @@ int cin_out_dim(const dctr_cin_args_t* a) {
     return o;
 }
 
-}  // namespace
+// ---- embedding_dim > 128 (interaction.py:277-325 has no limit on D) ----------------------------------------------------------
+// CIN never mixes the embedding dimensions: every (sample, d) is an independent GEMM row until the final reduce_sum over d
+// (:322-323).  A sample of width D is therefore walked as D / dd pseudo-samples of width dd (the largest divisor of D that the
+// kernel's tile holds, <= 128) whose summed maps add up to the sample's: a pre-pass lays x [B, F0, D] out as [B * D/dd, F0, dd] in
+// the caller's workspace, the kernel above runs on that, a post-pass adds the D / dd partial map vectors of a sample in the order
+// of d.  The two passes move 2 x 4 F0 D bytes per sample beside 2 F0 sum(F_k H_k) D flops: under 2 % of the kernel's time.
+constexpr int CIN_WIDE_ROWS = 1024;            // samples per chunk the workspace query provides for (any workspace of >= 64 works)
 
-// intermediates live in LDS; the workspace holds layer 0's folded filter rows + pair table (optional: without it layer 0 walks all
-// F0 x F0 products — same result up to the rounding of W[ij] + W[ji], ~1.2x the time at C3)
-extern "C" size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* a) {
-    if (a == nullptr || a->fields < 1 || a->dim < 1 || a->n_layers < 1 || a->layer_size == nullptr || a->layer_size[0] < 1) return 0;
+__global__ __launch_bounds__(256) void cin_reslice_kernel(const float* __restrict__ x, int64_t x_stride, int64_t rows, int F0, int D, int dd,
+                                                          float* __restrict__ xs) {
+    const int nsl = D / dd;
+    const int64_t fd = (int64_t)F0 * D, total = rows * fd;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / fd;
+        const int r = (int)(o - b * fd);
+        const int f = r / D, d = r - f * D;
+        const int sl = d / dd, dl = d - sl * dd;
+        xs[((b * nsl + sl) * F0 + f) * dd + dl] = x[b * x_stride + r];
+    }
+}
+
+__global__ __launch_bounds__(256) void cin_slice_sum_kernel(const float* __restrict__ part, int64_t rows, int nsl, int out_dim,
+                                                            float* __restrict__ out) {
+    const int64_t total = rows * out_dim;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / out_dim;
+        const int c = (int)(o - b * out_dim);
+        const float* pp = part + (b * nsl) * out_dim + c;
+        float acc = 0.f;
+        for (int sl = 0; sl < nsl; ++sl) acc += pp[(int64_t)sl * out_dim];      // (fixed order: deterministic)
+        out[o] = acc;
+    }
+}
+
+size_t cin_fold_bytes(const dctr_cin_args_t* a) {
     const size_t ks = (size_t)cin_sym_ksteps(a->fields, a->dim);
     return ks * 4 * ((size_t)a->layer_size[0] + 1) * sizeof(float);
 }
 
-static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream);
+size_t cin_wide_row_bytes(const dctr_cin_args_t* a, int dd) {
+    return ((size_t)a->fields * a->dim + (size_t)(a->dim / dd) * cin_out_dim(a)) * sizeof(float);
+}
 
-extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) { return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream); }
+}  // namespace
+
+// intermediates live in LDS; the workspace holds layer 0's folded filter rows + pair table (optional: without it layer 0 walks all
+// F0 x F0 products — same result up to the rounding of W[ij] + W[ji], ~1.2x the time at C3)
+static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream,
+                        bool dry = false);
+static int cin_gather_checks(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g);
+static int cin_fwd_wide(const dctr_cin_args_t* a, int dd, void* stream, bool dry);
+
+// the slice width dctr_cin_fwd walks a sample in: a->dim itself when the kernel takes the sample whole, else the largest divisor of
+// a->dim it takes (cin_fwd_impl's own shape decisions, dry), 0 = none
+static int cin_pick_slice(const dctr_cin_args_t* a) {
+    if (a->dim < 1) return 0;
+    dctr_cin_args_t b = *a;
+    b.batch = 1;
+    b.save_y = nullptr;
+    for (int dd = a->dim < 128 ? a->dim : 128; dd >= 1; --dd) {
+        if (a->dim % dd != 0) continue;
+        b.dim = dd;
+        if (cin_fwd_impl(&b, nullptr, nullptr, nullptr, nullptr, true) == DCTR_OK) return dd;
+    }
+    return 0;
+}
+
+// dctr_cin_fwd: the sample whole, or in slices of d
+static int cin_fwd_route(const dctr_cin_args_t* a, void* stream, bool dry) {
+    DCTR_REQUIRE(a != nullptr && a->layer_size != nullptr, DCTR_E_NULL, "cin_fwd: null args");
+    DCTR_REQUIRE(a->fields >= 1 && a->dim >= 1 && a->n_layers >= 1 && a->n_layers <= CIN_MAX_LAYERS, DCTR_E_DIM,
+                 "cin_fwd: bad sizes (F=%d D=%d layers=%d)", a->fields, a->dim, a->n_layers);
+    if (a->dim <= 64) return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream, dry);
+    for (int k = 0; k < a->n_layers; ++k) DCTR_REQUIRE(a->layer_size[k] >= 1, DCTR_E_DIM, "cin_fwd: layer_size[%d]=%d", k, a->layer_size[k]);
+    const int dd = cin_pick_slice(a);
+    if (dd == a->dim || dd == 0) return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream, dry);     // (0: its refusal is the answer)
+    return cin_fwd_wide(a, dd, stream, dry);
+}
+
+// ABI 13: samples the kernel does not take whole (embedding_dim > 128, or > 64 with more maps than fit the LDS beside a 128-row
+// tile): + room for CIN_WIDE_ROWS samples of the sliced route — REQUIRED there, whatever the batch
+extern "C" size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* a) {
+    if (a == nullptr || a->fields < 1 || a->dim < 1 || a->n_layers < 1 || a->n_layers > CIN_MAX_LAYERS || a->layer_size == nullptr ||
+        a->layer_size[0] < 1)
+        return 0;
+    const size_t fold = cin_fold_bytes(a);
+    if (a->dim <= 64) return fold;
+    for (int k = 0; k < a->n_layers; ++k)
+        if (a->layer_size[k] < 1) return fold;
+    dctr_cin_args_t b = *a;
+    if (b.activation < DCTR_ACT_LINEAR || b.activation > DCTR_ACT_TANH) b.activation = DCTR_ACT_RELU;   // (size queries come without one)
+    const int dd = cin_pick_slice(&b);
+    if (dd == a->dim || dd == 0) return fold;
+    return ((fold + 15) & ~(size_t)15) + (size_t)CIN_WIDE_ROWS * cin_wide_row_bytes(a, dd);
+}
+
+extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) { return cin_fwd_route(a, stream, false); }
+
+// ABI 13 — would dctr_cin_fwd (gather == NULL) / dctr_cin_gather_fwd (gather != NULL; fused_head: with head_w / logit) take these
+// arguments?  Every shape check and kernel-shape decision of the call, no launch; device pointers are not looked at (args->layer_size
+// is: a HOST array).  1 = yes, 0 = no (dctr_last_error() says why).
+extern "C" int dctr_cin_fwd_supported(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, int32_t fused_head) {
+    if (a == nullptr || a->layer_size == nullptr) return 0;
+    if (g == nullptr) return cin_fwd_route(a, nullptr, true) == DCTR_OK ? 1 : 0;
+    if (cin_gather_checks(a, g) != DCTR_OK) return 0;
+    static const float one_float = 0.f;
+    return cin_fwd_impl(a, g, fused_head ? &one_float : nullptr, nullptr, nullptr, true) == DCTR_OK ? 1 : 0;
+}
 
 // ABI 8 — CIN.call over the embeddings of a gather (models/xdeepfm.py:52-66): exFM_in = concat of the fields' rows is read from the
 // tables inside the kernel (g: plain ids, every field `dim` wide, dim % 4 == 0, no pre-pooled field; g->dnn_in etc. unused), and with
@@ -533,25 +628,93 @@ extern "C" int dctr_cin_gather_fwd(const dctr_cin_args_t* a, const dctr_gather_f
     DCTR_REQUIRE(a != nullptr && g != nullptr, DCTR_E_NULL, "cin_gather_fwd: null args");
     DCTR_REQUIRE((head_w == nullptr) == (logit == nullptr), DCTR_E_NULL, "cin_gather_fwd: head_w and logit come together");
     DCTR_REQUIRE(g->fields != nullptr && g->ids != nullptr, DCTR_E_NULL, "cin_gather_fwd: null descriptors / ids");
+    const int rc = cin_gather_checks(a, g);
+    if (rc != DCTR_OK) return rc;
+    return cin_fwd_impl(a, g, head_w, logit, stream);
+}
+
+static int cin_gather_checks(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g) {
     DCTR_REQUIRE(g->n_fields == a->fields && g->batch == a->batch, DCTR_E_DIM, "cin_gather_fwd: gather of %d fields x %lld rows against CIN over %d x %lld",
                  g->n_fields, (long long)g->batch, a->fields, (long long)a->batch);
     DCTR_REQUIRE(a->dim % 4 == 0 && g->uniform_dim == a->dim && g->all_dim4 && !g->any_hash && !g->any_identity && !g->any_pitch, DCTR_E_UNSUPPORTED,
                  "cin_gather_fwd: every field must be a plain (unhashed, not pre-pooled) lookup of width dim = %d, a multiple of 4", a->dim);
     DCTR_REQUIRE(a->save_y == nullptr, DCTR_E_UNSUPPORTED, "cin_gather_fwd: inference only (save_y: use dctr_embed_gather_fm + dctr_cin_fwd)");
-    return cin_fwd_impl(a, g, head_w, logit, stream);
+    DCTR_REQUIRE(a->dim <= 128, DCTR_E_UNSUPPORTED, "cin_gather_fwd: embedding_dim %d > 128 (use dctr_embed_gather_fm + dctr_cin_fwd: the sliced route)", a->dim);
+    return DCTR_OK;
 }
 
-static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream) {
+// dctr_cin_fwd over samples the kernel does not take whole, in slices of dd embedding dimensions (see cin_reslice_kernel)
+static int cin_fwd_wide(const dctr_cin_args_t* a, int dd, void* stream, bool dry) {
+    const int D = a->dim, nsl = D / dd, F0 = a->fields;
+    const int out_dim = cin_out_dim(a);
+    dctr_cin_args_t b = *a;
+    b.dim = dd;
+    b.x_stride = (int64_t)F0 * dd;
+    b.save_y = nullptr;
+    if (dry) {                                  // the kernel's own shape decisions for the slice width
+        b.batch = (a->batch > 0 ? a->batch : 1) * nsl;
+        b.workspace = nullptr;
+        b.workspace_bytes = 0;
+        return cin_fwd_impl(&b, nullptr, nullptr, nullptr, nullptr, true);
+    }
+    if (a->batch == 0) return DCTR_OK;
+    const size_t fold = cin_fold_bytes(a), fold_al = (fold + 15) & ~(size_t)15, per_row = cin_wide_row_bytes(a, dd);
+    DCTR_REQUIRE(a->workspace != nullptr && dctr_aligned16(a->workspace) && a->workspace_bytes >= fold_al + 64 * per_row, DCTR_E_NULL,
+                 "cin_fwd: embedding_dim %d goes out in slices of %d and needs a 16-B aligned workspace (dctr_cin_workspace_bytes: %zu B; at "
+                 "least %zu B)", D, dd, dctr_cin_workspace_bytes(a), fold_al + 64 * per_row);
+    DCTR_REQUIRE(a->x != nullptr && a->out != nullptr, DCTR_E_NULL, "cin_fwd: null pointer");
+    int64_t cap = (int64_t)((a->workspace_bytes - fold_al) / per_row);
+    cap = cap > 65536 ? 65536 : cap & ~(int64_t)15;
+    if (a->save_y != nullptr) {                 // (a chunk's part of a y_k stays inside the 2 GiB a buffer descriptor addresses)
+        int hmax = 1;
+        for (int k = 0; k < a->n_layers; ++k) hmax = a->layer_size[k] > hmax ? a->layer_size[k] : hmax;
+        const int64_t lim = (0x7fffffffLL / ((int64_t)D * hmax * 4) - 1) & ~(int64_t)15;
+        DCTR_REQUIRE(lim >= 16, DCTR_E_DIM, "cin_fwd: save_y rows of %d x %d floats are too long", D, hmax);
+        cap = cap > lim ? lim : cap;
+    }
+    float* xs = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + fold_al);
+    float* part = xs + (size_t)cap * F0 * D;    // (cap is a multiple of 16: 16-B aligned)
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t r0 = 0; r0 < a->batch; r0 += cap) {
+        const int64_t rows = a->batch - r0 < cap ? a->batch - r0 : cap;
+        int64_t nb = dctr_ceil_div(rows * F0 * D, (int64_t)256);
+        DCTR_LAUNCH(cin_reslice_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, st, a->x + r0 * a->x_stride, a->x_stride,
+                    rows, F0, D, dd, xs);
+        b.x = xs;
+        b.batch = rows * nsl;
+        b.out = part;
+        b.workspace = fold > 0 ? a->workspace : nullptr;
+        b.workspace_bytes = fold;
+        b.workspace_ready = r0 == 0 ? a->workspace_ready : 1;
+        // save_y: row (b, d) of y_k is row b * D + d = (b * nsl + sl) * dd + dl — the pseudo-samples' rows ARE the sample's rows
+        float* sv[CIN_MAX_LAYERS];
+        if (a->save_y != nullptr) {
+            for (int k = 0; k < a->n_layers; ++k)
+                sv[k] = a->save_y[k] != nullptr ? a->save_y[k] + (size_t)r0 * D * a->layer_size[k] : nullptr;
+            b.save_y = sv;
+        }
+        const int rc = cin_fwd_impl(&b, nullptr, nullptr, nullptr, stream);
+        if (rc != DCTR_OK) return rc;
+        nb = dctr_ceil_div(rows * out_dim, (int64_t)256);
+        DCTR_LAUNCH(cin_slice_sum_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, st, part, rows, nsl, out_dim,
+                    a->out + r0 * out_dim);
+    }
+    return dctr_launch_status("dctr_cin_fwd");
+}
+
+static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g, const float* head_w, float* logit, void* stream, bool dry) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "cin_fwd: null args");
     DCTR_REQUIRE(a->batch >= 0 && a->fields >= 1 && a->dim >= 1 && a->n_layers >= 1 && a->n_layers <= CIN_MAX_LAYERS,
                  DCTR_E_DIM, "cin_fwd: bad sizes (B=%lld F=%d D=%d layers=%d)", (long long)a->batch, a->fields, a->dim,
                  a->n_layers);
-    if (a->batch == 0) return DCTR_OK;
-    DCTR_REQUIRE((a->x || g) && (a->out || logit) && a->layer_size && a->filters && a->bias, DCTR_E_NULL, "cin_fwd: null pointer");
+    if (a->batch == 0 && !dry) return DCTR_OK;
+    DCTR_REQUIRE(dry ? a->layer_size != nullptr : ((a->x || g) && (a->out || logit) && a->layer_size && a->filters && a->bias), DCTR_E_NULL,
+                 "cin_fwd: null pointer");
     DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "cin_fwd: activation %d",
                  a->activation);
-    DCTR_REQUIRE(g != nullptr || a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
-    DCTR_REQUIRE(a->dim <= 128, DCTR_E_UNSUPPORTED, "cin_fwd: embedding_dim %d > 128 not supported (a sample's rows are one workgroup's MFMA tiles)", a->dim);
+    DCTR_REQUIRE(g != nullptr || dry || a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
+    DCTR_REQUIRE(a->dim <= 128, DCTR_E_UNSUPPORTED, "cin kernel: embedding_dim %d > 128 (a sample's rows are one workgroup's MFMA tiles: dctr_cin_fwd "
+                 "walks such samples in slices)", a->dim);
     CinParams p{};
     p.x = g != nullptr ? nullptr : a->x;
     if (g != nullptr) {
@@ -582,12 +745,14 @@ static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g
         if (a->split_half && !last)
             DCTR_REQUIRE(H % 2 == 0, DCTR_E_DIM,
                          "cin_fwd: layer_size must be even except for the last layer when split_half=True");
-        DCTR_REQUIRE(a->filters[k] && a->bias[k], DCTR_E_NULL, "cin_fwd: filters/bias[%d] null", k);
-        DCTR_REQUIRE((((uintptr_t)a->filters[k]) & 7u) == 0, DCTR_E_ALIGN, "cin_fwd: filters[%d] not 8-B aligned", k);
         p.H[k] = H;
-        p.W[k] = a->filters[k];
-        p.bias[k] = a->bias[k];
-        p.save[k] = a->save_y != nullptr ? a->save_y[k] : nullptr;
+        if (!dry) {
+            DCTR_REQUIRE(a->filters[k] && a->bias[k], DCTR_E_NULL, "cin_fwd: filters/bias[%d] null", k);
+            DCTR_REQUIRE((((uintptr_t)a->filters[k]) & 7u) == 0, DCTR_E_ALIGN, "cin_fwd: filters[%d] not 8-B aligned", k);
+            p.W[k] = a->filters[k];
+            p.bias[k] = a->bias[k];
+        }
+        p.save[k] = (!dry && a->save_y != nullptr) ? a->save_y[k] : nullptr;
         DCTR_REQUIRE(p.save[k] == nullptr || a->batch * (int64_t)a->dim * H * 4 < 0x7fffffffLL, DCTR_E_DIM,
                      "cin_fwd: save_y[%d] of %lld x %d floats exceeds the 2 GiB a buffer descriptor addresses", k,
                      (long long)(a->batch * a->dim), H);
@@ -603,8 +768,9 @@ static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g
     // filter stream from L2, 851 KB per workgroup at C3 layer 2, is what bounds this kernel) when two workgroups
     // still fit a CU's LDS, else 64
     // layer 0 folded over its symmetry when the caller brought the workspace for it
-    const size_t sym_need = dctr_cin_workspace_bytes(a);
-    if (a->workspace != nullptr && sym_need > 0) {
+    const size_t sym_need = cin_fold_bytes(a);
+    if (dry) p.sym_ks = sym_need > 0 ? cin_sym_ksteps(p.F0, p.D) : 0;     // (the LDS of the folded form: the larger one)
+    else if (a->workspace != nullptr && sym_need > 0) {
         DCTR_REQUIRE(a->workspace_bytes >= sym_need && dctr_aligned16(a->workspace), DCTR_E_DIM,
                      "cin_fwd: workspace of %zu B (16-B aligned) needed, got %zu B", sym_need, a->workspace_bytes);
         p.sym_ks = cin_sym_ksteps(p.F0, p.D);
@@ -639,6 +805,7 @@ static int cin_fwd_impl(const dctr_cin_args_t* a, const dctr_gather_fm_args_t* g
 #endif
     const size_t lds = lds_of(rt) + CIN_LDS_PAD;
     DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "cin_fwd: needs %zu B of LDS (> 160 KiB)", lds);
+    if (dry) return DCTR_OK;
     const bool save = a->save_y != nullptr;
     const void* fn = rt == 8 ? (save ? (const void*)cin_kernel<8, true> : (const void*)cin_kernel<8, false>)
                              : (save ? (const void*)cin_kernel<4, true> : (const void*)cin_kernel<4, false>);

@@ -817,8 +817,10 @@ extern "C" int dctr_din_attn_pool_fwd(const dctr_din_attn_args_t* a, void* strea
         DinFastParams f{};
         size_t lds = 0;
         const int64_t rows = a->batch * (int64_t)a->maxlen;
+        // (histories past 4,096 positions — din_pool_kernel keeps 4 samples' scores in 64 KiB of LDS — take the one-kernel form below,
+        //  whose score row of one sample fits up to ~30,000 positions: nothing is launched here for a shape that would then be refused)
         if (a->workspace != nullptr && a->workspace_bytes >= (size_t)rows * sizeof(float) && rows < 0x7fffffffLL &&
-            dctr_aligned16(a->query) && dctr_aligned16(a->keys) && din_fast_plan(a, f, lds)) {
+            (size_t)4 * a->maxlen * sizeof(float) <= 64 * 1024 && dctr_aligned16(a->query) && dctr_aligned16(a->keys) && din_fast_plan(a, f, lds)) {
             f.query = a->query;
             f.keys = a->keys;
             f.rows = rows;

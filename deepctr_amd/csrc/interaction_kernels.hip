@@ -560,6 +560,57 @@ __global__ __launch_bounds__(256) void afm_kernel(const float* __restrict__ x, i
     if (lane == 0) y[b] = out;
 }
 
+// The layer for shapes whose sample tile + pair logits do not fit the LDS (fields x embedding_dim x 16 B + 16 B per pair > 160 KiB:
+// the reference has no such limit, interaction.py:116-146): nothing is staged.  One wave per sample; a lane walks pairs p = lane,
+// lane + 64, ... ONCE — a pair's attention logit and its projected product p . (e_i * e_j) come out of the same walk over e — and keeps
+// a running (max, sum of exp, weighted sum): softmax over the pairs without storing a logit (the streaming form of :138-145: the weights
+// exp(l_p - max) / sum are the same numbers, summed in another order).  x, attention_W and the projections are read through the L1.
+__global__ __launch_bounds__(256) void afm_stream_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F, int E,
+                                                         const float* __restrict__ att_w, const float* __restrict__ att_b,
+                                                         const float* __restrict__ proj_h, const float* __restrict__ proj_p,
+                                                         int A, float* __restrict__ y) {
+    const int P = F * (F - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    const float* xs = x + b * x_stride;
+    float mx = -INFINITY, den = 0.f, num = 0.f;
+    for (int p = lane; p < P; p += 64) {
+        int i, j;
+        pair_ij(p, F, i, j);
+        const float* xi = xs + (int64_t)i * E;
+        const float* xj = xs + (int64_t)j * E;
+        float lg = 0.f;
+        for (int a = 0; a < A; ++a) {
+            float t = att_b[a];
+            for (int e = 0; e < E; ++e) t = fmaf(xi[e] * xj[e], att_w[(int64_t)e * A + a], t);
+            lg = fmaf(fmaxf(t, 0.f), proj_h[a], lg);
+        }
+        float t = 0.f;
+        for (int e = 0; e < E; ++e) t = fmaf(xi[e] * xj[e], proj_p[e], t);
+        if (lg > mx) {                          // rescale what was summed under the old maximum
+            const float r = expf(mx - lg);      // (exp(-inf) = 0 the first time)
+            den *= r;
+            num *= r;
+            mx = lg;
+        }
+        const float w = expf(lg - mx);
+        den += w;
+        num = fmaf(w, t, num);
+    }
+    // lanes -> one (max, den, num)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float omx = __shfl_xor(mx, m, 64), oden = __shfl_xor(den, m, 64), onum = __shfl_xor(num, m, 64);
+        const float nmx = fmaxf(mx, omx);
+        const float ra = mx == -INFINITY ? 0.f : expf(mx - nmx), rb = omx == -INFINITY ? 0.f : expf(omx - nmx);
+        den = den * ra + oden * rb;
+        num = num * ra + onum * rb;
+        mx = nmx;
+    }
+    if (lane == 0) y[b] = num / den;
+}
+
 // The same layer on the matrix pipe (embedding_dim % 16 == 0, attention_factor <= 15).  Per sample the attention net is a
 // [P pairs, E] x [E, A] product: tiles of 16 pairs are the MFMA M dimension, the pair products e_i * e_j are formed in registers
 // as the A operand (two ds_read_b128 + four multiplies per four k-steps: k-slot g of k-step t is dimension 4g + t, a K permutation
@@ -687,6 +738,33 @@ __global__ __launch_bounds__(256) void inner_product_kernel(const float* __restr
             int i, j;
             pair_ij(p, F, i, j);
             y[b * y_stride + o] = xs[i * E + e] * xs[j * E + e];
+        }
+    }
+}
+
+// ... and for sample tiles past the LDS (4 x fields x embedding_dim floats > 160 KiB): the rows straight from global memory (L1 / L2)
+__global__ __launch_bounds__(256) void inner_product_stream_kernel(const float* __restrict__ x, int64_t x_stride, int64_t batch, int F,
+                                                                   int E, int reduce_sum, float* __restrict__ y, int64_t y_stride) {
+    const int P = F * (F - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    const float* xs = x + b * x_stride;
+    if (reduce_sum) {
+        for (int p = lane; p < P; p += 64) {
+            int i, j;
+            pair_ij(p, F, i, j);
+            float t = 0.f;
+            for (int e = 0; e < E; ++e) t = fmaf(xs[(int64_t)i * E + e], xs[(int64_t)j * E + e], t);
+            y[b * y_stride + p] = t;
+        }
+    } else {
+        const int64_t total = (int64_t)P * E;
+        for (int64_t o = lane; o < total; o += 64) {
+            const int p = (int)(o / E), e = (int)(o % E);
+            int i, j;
+            pair_ij(p, F, i, j);
+            y[b * y_stride + o] = xs[(int64_t)i * E + e] * xs[(int64_t)j * E + e];
         }
     }
 }
@@ -968,7 +1046,8 @@ extern "C" size_t dctr_crossnet_workspace_bytes(int32_t dim, int32_t layers, int
     return (size_t)layers * dim * ((dim + 3) & ~3) * sizeof(float);
 }
 
-static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dctr_gather_fm_args_t* gg = nullptr) {
+// dry: every shape check and kernel-shape decision of the call, no launch, device pointers not looked at (dctr_crossnet_fwd_supported)
+static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dctr_gather_fm_args_t* gg = nullptr, bool dry = false) {
     DCTR_REQUIRE(a != nullptr, DCTR_E_NULL, "crossnet_fwd: null args");
     const float* x = a->x;
     const int64_t batch = a->batch, x_stride = a->x_stride, y_stride = a->y_stride;
@@ -980,10 +1059,12 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
     const size_t workspace_bytes = a->workspace_bytes;
     DCTR_REQUIRE(batch >= 0 && dim >= 1 && layers >= 0, DCTR_E_DIM, "crossnet_fwd: bad sizes");
     DCTR_REQUIRE(mode == DCTR_CROSS_VECTOR || mode == DCTR_CROSS_MATRIX, DCTR_E_ENUM, "crossnet_fwd: mode %d", mode);
-    if (batch == 0) return DCTR_OK;
-    DCTR_REQUIRE((x || gg) && (y || a->head_w) && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
-    DCTR_REQUIRE((a->head_w == nullptr) == (a->logit == nullptr), DCTR_E_NULL, "crossnet_fwd: head_w and logit go together");
-    DCTR_REQUIRE((gg != nullptr || x_stride >= dim) && (y == nullptr || y_stride >= dim), DCTR_E_DIM, "crossnet_fwd: stride < dim");
+    if (batch == 0 && !dry) return DCTR_OK;
+    if (!dry) {
+        DCTR_REQUIRE((x || gg) && (y || a->head_w) && (layers == 0 || (kernels && bias)), DCTR_E_NULL, "crossnet_fwd: null pointer");
+        DCTR_REQUIRE((a->head_w == nullptr) == (a->logit == nullptr), DCTR_E_NULL, "crossnet_fwd: head_w and logit go together");
+        DCTR_REQUIRE((gg != nullptr || x_stride >= dim) && (y == nullptr || y_stride >= dim), DCTR_E_DIM, "crossnet_fwd: stride < dim");
+    }
     DCTR_REQUIRE(a->save_u == nullptr || (mode == DCTR_CROSS_MATRIX && layers >= 1 && (layers == 1 || a->save_x != nullptr)), DCTR_E_UNSUPPORTED,
                  "crossnet_fwd: save_u / save_x exist for the matrix form (save_x with more than one layer)");
     hipStream_t st = (hipStream_t)stream;
@@ -991,6 +1072,7 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
         DCTR_REQUIRE(dim <= 64 * 128, DCTR_E_UNSUPPORTED, "crossnet_fwd(vector): dim %d > 8192", dim);
         const int64_t blocks = dctr_ceil_div(batch, 4);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
+        if (dry) return DCTR_OK;
         const int nr = pow2_at_least((dim + 63) / 64, 128);      // values of x_0 / x_l per lane (one wave per sample; 128: 256 VGPRs)
 #define CALL_CV(N)                                                                                                  \
     DCTR_LAUNCH((cross_vector_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, \
@@ -1036,6 +1118,8 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
         }
         const size_t lds = rt4 ? lds4 : rt2 ? lds2 : (size_t)3 * 16 * lda * sizeof(float);
         DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d needs %zu B of LDS", dim, lds);
+        DCTR_REQUIRE((int64_t)dim * (dim + 3) * 4 < 0x7fffffffLL, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d too large", dim);
+        if (dry) return DCTR_OK;
         const int maxt = dim <= 128 ? 1 : dim <= 256 ? 2 : 4;          // column tiles a wave of the in-place kernel holds in registers
         if (lds > 64 * 1024) {
             const void* fn = rt4 ? (maxt == 1 ? (const void*)cross_matrix_inplace_kernel<1> : maxt == 2 ? (const void*)cross_matrix_inplace_kernel<2>
@@ -1046,7 +1130,6 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
         }
         const int64_t blocks = dctr_ceil_div(batch, rt4 ? 64 : rt2 ? 32 : 16);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
-        DCTR_REQUIRE((int64_t)dim * (dim + 3) * 4 < 0x7fffffffLL, DCTR_E_UNSUPPORTED, "crossnet_fwd(matrix): dim %d too large", dim);
         const size_t need = dctr_crossnet_workspace_bytes(dim, layers, mode, kernels);
         const float* wk = kernels;
         int wstride = dim;
@@ -1094,19 +1177,34 @@ extern "C" int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* a, void* strea
 // ABI 8 — CrossNet (matrix parameterization) + the branch's share of DCN's Dense(1) over the embeddings of a gather (reference
 // models/dcn.py:48-66, layers/interaction.py:405-424): the workgroup's [64, dim] tile of the DNN input is read from the tables and the
 // dense matrix inside the kernel (a->x is ignored), logit[b] = x_L[b] . head_w leaves (y optional).  Spans only: >= 64 rows per CU.
-extern "C" int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* a, const dctr_gather_fm_args_t* g, void* stream) {
+static int crossnet_gather_checks(const dctr_crossnet_args_t* a, const dctr_gather_fm_args_t* g, bool dry) {
     DCTR_REQUIRE(a != nullptr && g != nullptr, DCTR_E_NULL, "crossnet_gather_head_fwd: null args");
     DCTR_REQUIRE(a->mode == DCTR_CROSS_MATRIX && a->layers >= 1, DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: matrix parameterization, >= 1 layer");
-    DCTR_REQUIRE(g->fields != nullptr && g->ids != nullptr && g->batch == a->batch, DCTR_E_NULL, "crossnet_gather_head_fwd: gather of another batch / null");
+    DCTR_REQUIRE((dry || (g->fields != nullptr && g->ids != nullptr)) && g->batch == a->batch, DCTR_E_NULL, "crossnet_gather_head_fwd: gather of another batch / null");
     DCTR_REQUIRE(g->uniform_dim >= 4 && (g->uniform_dim & (g->uniform_dim - 1)) == 0 && g->all_dim4 && !g->any_hash && !g->any_identity &&
                      !g->any_pitch && g->ids_stride_b == 1,
                  DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: plain (unhashed, not pre-pooled) lookups of one width (a power of two >= 4), contiguous id rows");
     const int n_dense = g->dense_copy_cols > 0 ? g->dense_copy_cols : 0;
-    DCTR_REQUIRE(a->dim == g->n_fields * g->uniform_dim + n_dense && (n_dense == 0 || (g->dense != nullptr && g->dense_out_offset == g->n_fields * g->uniform_dim)),
+    DCTR_REQUIRE(a->dim == g->n_fields * g->uniform_dim + n_dense && (n_dense == 0 || ((dry || g->dense != nullptr) && g->dense_out_offset == g->n_fields * g->uniform_dim)),
                  DCTR_E_DIM, "crossnet_gather_head_fwd: dim %d is not the gather's DNN-input width (%d fields x %d + %d dense)", a->dim, g->n_fields,
                  g->uniform_dim, n_dense);
     DCTR_REQUIRE(a->save_u == nullptr, DCTR_E_UNSUPPORTED, "crossnet_gather_head_fwd: inference only");
+    return DCTR_OK;
+}
+
+extern "C" int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* a, const dctr_gather_fm_args_t* g, void* stream) {
+    const int rc = crossnet_gather_checks(a, g, false);
+    if (rc != DCTR_OK) return rc;
     return crossnet_launch(a, stream, g);
+}
+
+// ABI 13 — would dctr_crossnet_head_fwd / dctr_crossnet_fwd (gather == NULL) or dctr_crossnet_gather_head_fwd (gather != NULL) take these
+// arguments?  1 = yes, 0 = no (dctr_last_error() says why); nothing is launched, device pointers are not looked at — save_u counts as
+// "training forward" when non-NULL, args->kernels only for its 16-B alignment (the re-pack workspace)
+extern "C" int dctr_crossnet_fwd_supported(const dctr_crossnet_args_t* a, const dctr_gather_fm_args_t* g) {
+    if (a == nullptr) return 0;
+    if (g != nullptr && crossnet_gather_checks(a, g, true) != DCTR_OK) return 0;
+    return crossnet_launch(a, nullptr, g, true) == DCTR_OK ? 1 : 0;
 }
 
 namespace {
@@ -1167,7 +1265,13 @@ extern "C" int dctr_afm_fwd(const float* x, int64_t batch, int64_t x_stride, int
         }
     }
     const size_t lds = ((size_t)dim * att_factor + 2 * att_factor + dim + 4 * ((size_t)fields * dim + P)) * sizeof(float);
-    DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "afm_fwd: needs %zu B of LDS", lds);
+    if (lds > 160 * 1024) {                     // no shape is refused: the streaming form stages nothing
+        const int64_t blocks_s = dctr_ceil_div(batch, 4);
+        DCTR_REQUIRE(blocks_s <= 0x7fffffffLL, DCTR_E_DIM, "afm_fwd: batch too large");
+        DCTR_LAUNCH(afm_stream_kernel, dim3((unsigned)blocks_s), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch, fields, dim, att_w, att_b,
+                    proj_h, proj_p, att_factor, y);
+        return dctr_launch_status("dctr_afm_fwd");
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)afm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DCTR_REQUIRE(e == hipSuccess, (int)e, "afm_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));
@@ -1188,7 +1292,13 @@ extern "C" int dctr_inner_product_fwd(const float* x, int64_t batch, int64_t x_s
     if (batch == 0) return DCTR_OK;
     DCTR_REQUIRE(x && y, DCTR_E_NULL, "inner_product_fwd: null pointer");
     const size_t lds = (size_t)4 * fields * dim * sizeof(float);
-    DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "inner_product_fwd: needs %zu B of LDS", lds);
+    if (lds > 160 * 1024) {                     // no shape is refused: rows from global memory
+        const int64_t blocks_s = dctr_ceil_div(batch, 4);
+        DCTR_REQUIRE(blocks_s <= 0x7fffffffLL, DCTR_E_DIM, "inner_product_fwd: batch too large");
+        DCTR_LAUNCH(inner_product_stream_kernel, dim3((unsigned)blocks_s), dim3(256), 0, (hipStream_t)stream, x, x_stride, batch, fields, dim,
+                    reduce_sum, y, y_stride);
+        return dctr_launch_status("dctr_inner_product_fwd");
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)inner_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);

@@ -2,6 +2,8 @@
 Launches per batch: fused gather (+ linear logit) -> CrossNet kernel and DNN kernel writing the two halves
 of one [B, d + hidden] buffer (the reference's Concatenate) -> head kernel (Dense(1) + linear logit +
 global bias + sigmoid)."""
+import ctypes
+
 import torch
 
 from .. import ops
@@ -49,6 +51,7 @@ class _DCN(FusedForward, FeatureModel):
         else:
             self.fused = False
         self.fold_cross = True      # False: the layer-by-layer cross kernels (gather -> HBM -> cross / DNN launches)
+        self._matrix_lib_ok = {}     # launch rows -> dctr_crossnet_fwd_supported's answer for the gather form
         self._matrix_failed = False  # set when the library refuses the gather form of the matrix CrossNet (DCTR_E_UNSUPPORTED)
         self._cus = None
 
@@ -130,11 +133,24 @@ class _DCN(FusedForward, FeatureModel):
                 getattr(self.cross, "parameterization", None) == "matrix" and not getattr(self, "_matrix_failed", False)):
             return False
         sp = self.stage_plan
-        if self._cus is None:
-            self._cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
-        cus = self._cus
-        return bool(FusedForward._fast_path(self, staged) and sp.uniform_dim in (4, 8, 16, 32, 64) and sp.in_dim <= 512 and
-                    B >= 64 * cus and (not sp.any_hash or self._prehash(B)) and not self.dnn.dice_layers)
+        if not (FusedForward._fast_path(self, staged) and (not sp.any_hash or self._prehash(B)) and not self.dnn.dice_layers):
+            return False
+        # which launches dctr_crossnet_gather_head_fwd takes (rows per CU, widths) is the library's answer, asked once per launch size
+        ok = self._matrix_lib_ok.get(B)
+        if ok is None:
+            from .. import _C
+            a = _C.CrossnetArgs(batch=B, x_stride=sp.in_dim, dim=sp.in_dim, layers=int(self.cross.layer_num), mode=_C.CROSS_MATRIX, y_stride=sp.in_dim)
+            g = _C.GatherFmArgs(batch=B, n_fields=len(sp.fields), ids_stride_b=1, max_dim=sp.max_dim, all_dim4=int(sp.all_dim4), any_hash=0,
+                                uniform_dim=int(sp.uniform_dim), any_identity=int(bool(sp.pooled_fields)), any_pitch=0,
+                                dense_copy_cols=int(sp.n_dense_dnn), dense_out_offset=int(sp.dense_offset) if sp.n_dense_dnn else -1)
+            if self.device.type != "cuda":
+                return False
+            with torch.cuda.device(self.device):            # (rows per CU: the launch's device)
+                ok = bool(_C.lib().dctr_crossnet_fwd_supported(ctypes.byref(a), ctypes.byref(g)))
+            if len(self._matrix_lib_ok) > 64:
+                self._matrix_lib_ok.clear()
+            self._matrix_lib_ok[B] = ok
+        return ok
 
     def _extra_logit_buffers(self, B):
         """The matrix CrossNet's share of Dense(1), a [B] logit the fused head adds."""

@@ -42,14 +42,26 @@ class _xDeepFM(FusedForward, FeatureModel):
         self._buf = {}
         self._cin_ws = None         # layer 0's folded filter rows (dctr_cin_args_t.workspace): written by the first CIN launch after _begin()
         self._cin_ws_ready = False
+        self._cin_gather_ok = None  # dctr_cin_fwd_supported's answer for the two-launch form (asked once)
         self._fast_g = None         # the marshalled gather arguments of the fused launch being issued (FusedForward)
         self.fuse_cin = True        # False: the route through dnn_in (gather -> HBM -> CIN / DNN launches)
         if len(dnn_hidden_units) > 0:
             self._init_fused(dnn_hidden_units, dnn_activation)
 
     def _cin_fuse_ok(self):
-        sp = self.stage_plan
-        return bool(self.fuse_cin and self.fused and (self.cin is None or (self.cin_dim % 4 == 0 and sp.uniform_dim == self.cin_dim)))
+        """The two-launch form needs dctr_cin_gather_fwd to take the CIN with its head: the library answers (dctr_cin_fwd_supported) —
+        asked once, for the summary a fused launch's gather arguments carry (ids pre-hashed, plain tables)."""
+        if not (self.fuse_cin and self.fused):
+            return False
+        if self.cin is None:
+            return True
+        if self._cin_gather_ok is None:
+            sp = self.stage_plan
+            self._cin_gather_ok = ops.cin_supported(
+                len(sp.fields), self.cin_dim, list(self.cin.layer_size), self.cin.split_half, self.cin.activation, fused_head=True,
+                gather=dict(n_fields=len(sp.fields), uniform_dim=sp.uniform_dim, all_dim4=sp.all_dim4, any_hash=0,
+                            any_identity=bool(sp.pooled_fields), any_pitch=0))
+        return self._cin_gather_ok
 
     def _prehash(self, B):
         # hashed SparseFeat: ALWAYS hashed by the dctr_hash_fields launch in front (the CIN launch takes plain rows only)

@@ -452,18 +452,39 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
         _check_saved_y(save_y, B * D, layer_size, x)
         sp = _ptr_array(list(save_y))
         a.save_y = ctypes.cast(sp, ctypes.c_void_p)
-    if fold:
-        need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
+    need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
+    if fold or (D > 64 and need > _cin_fold_bytes(F0, layer_size)):     # (samples walked in slices of d need their workspace, fold or not)
         if need:
             if workspace is not None:
-                if workspace.dtype != torch.float32 or not workspace.is_contiguous() or workspace.numel() * 4 < need or workspace.device != x.device:
-                    raise ValueError("cin: workspace must be a contiguous float32 tensor of >= %d bytes on %s" % (need, x.device))
-                ws, a.workspace_ready = workspace, int(bool(workspace_ready))
+                if workspace.dtype != torch.float32 or not workspace.is_contiguous() or workspace.device != x.device:
+                    raise ValueError("cin: workspace must be a contiguous float32 tensor (dctr_cin_workspace_bytes: %d bytes) on %s" % (need, x.device))
+                # (its size is the library's to judge: the fold needs all of its share, the sliced route works in any room for >= 64 samples)
+                ws, a.workspace_ready, need = workspace, int(bool(workspace_ready)), workspace.numel() * 4
             else:
                 ws = _scratch(x.device, need)   # rewritten by every call (the filters may have moved): stream order keeps calls apart
             a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _C.check(_C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_fwd")
     return out
+
+
+def _cin_fold_bytes(fields, layer_size):
+    """The fold's share of dctr_cin_workspace_bytes (a narrow CIN's whole need: the fold does not depend on the embedding width)."""
+    return cin_workspace_bytes(fields, 4, layer_size)
+
+
+def cin_supported(fields, dim, layer_size, split_half=True, activation="relu", gather=None, fused_head=False, batch=4096):
+    """dctr_cin_fwd_supported: would the library take this CIN (``gather`` None: dctr_cin_fwd over a materialised x; else a
+    GatherFmArgs — or a dict of its summary fields n_fields / uniform_dim / all_dim4 / any_hash / any_identity / any_pitch — :
+    dctr_cin_gather_fwd, ``fused_head`` with the Dense(1) on chip)?  The host asks; it does not keep a copy of the kernels' limits."""
+    ls = _i32_array(layer_size)
+    a = _C.CinArgs(batch=int(batch), fields=int(fields), dim=int(dim), n_layers=len(layer_size), split_half=int(bool(split_half)),
+                   activation=_C.ACT_CODES.get(activation, -1), layer_size=ctypes.cast(ls, ctypes.c_void_p))
+    g = None
+    if gather is not None:
+        if isinstance(gather, dict):
+            gather = _C.GatherFmArgs(batch=int(batch), **{k: int(v) for k, v in gather.items()})
+        g = ctypes.byref(gather)
+    return bool(_C.lib().dctr_cin_fwd_supported(ctypes.byref(a), g, int(bool(fused_head))))
 
 
 def cin_gather(gather, filters, biases, layer_size, split_half, activation, dim, head_w, logit, workspace, workspace_ready=False, out=None):
@@ -498,7 +519,9 @@ def cin_gather(gather, filters, biases, layer_size, split_half, activation, dim,
 
 
 def cin_workspace_bytes(fields, dim, layer_size):
-    """Bytes of the fold workspace dctr_cin_fwd takes for a CIN over ``fields`` embeddings of width ``dim`` (0: no fold)."""
+    """Bytes of the workspace dctr_cin_fwd takes for a CIN over ``fields`` embeddings of width ``dim``: layer 0's fold (0: no fold) +,
+    for samples the kernel walks in slices of d (embedding_dim > 128 ...), the room that route REQUIRES.  (split_half unknown here:
+    sized for the larger output of split_half=False.)"""
     ls = _i32_array(layer_size)
     a = _C.CinArgs(fields=int(fields), dim=int(dim), n_layers=len(layer_size), layer_size=ctypes.cast(ls, ctypes.c_void_p))
     return int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))

@@ -50,8 +50,9 @@ def supported(model):
         return False                        # (the attention unit's training kernels hold a key row per lane group: widths % 4 == 0, <= 64)
     # (round 6: any embedding width — widths that are not a multiple of 4 or exceed 64, embedding_dim="auto" — the scatter kernels walk a
     # row in chunks, element per lane where rows are not 16-B aligned; such tables carry no touched-group marks: dense optimizer pass)
-    if kind == "_xDeepFM" and sp.max_dim > 128:
-        return False                        # (dctr_cin_fwd / dctr_cin_bwd hold a field's row in registers: embedding_dim <= 128)
+    if kind == "_xDeepFM" and getattr(model, "cin", None) is not None and not ops.cin_supported(
+            len(sp.fields), model.cin_dim, list(model.cin.layer_size), model.cin.split_half, model.cin.activation):
+        return False                        # (the library's answer — dctr_cin_fwd_supported; round 6: any embedding width, in slices of d past 128)
     if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "matrix" and sp.in_dim > 832:
         return False                        # (the training forward's matrix CrossNet keeps [16, dim] tiles of x_0 / x_l / x_{l+1} in LDS)
     if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector":

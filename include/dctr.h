@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTR_ABI_VERSION 12
+#define DCTR_ABI_VERSION 13
 
 enum {
     DCTR_OK = 0,
@@ -310,6 +310,12 @@ int dctr_crossnet_head_fwd(const dctr_crossnet_args_t* args, void* stream);
  * dim <= 512 (the 64-row kernel whose layer outputs wait in registers); anything else returns DCTR_E_UNSUPPORTED — use
  * dctr_embed_gather_fm + dctr_crossnet_head_fwd.  Inference only (save_u / save_x must be NULL). */
 int dctr_crossnet_gather_head_fwd(const dctr_crossnet_args_t* args, const dctr_gather_fm_args_t* gather, void* stream);
+/* ABI 13 — would dctr_crossnet_head_fwd / dctr_crossnet_fwd (gather == NULL) or dctr_crossnet_gather_head_fwd (gather != NULL) take these
+ * arguments?  Runs every shape check and kernel-shape decision of the call (rows per workgroup by batch and dim, LDS) without launching;
+ * device pointers are not looked at (save_u non-NULL = "the training forward"; of `gather` the summary fields n_fields / batch /
+ * uniform_dim / all_dim4 / any_hash / any_identity / any_pitch / ids_stride_b / dense_copy_cols / dense_out_offset).  1 = yes, 0 = no
+ * (dctr_last_error() carries the reason).  A matrix form wider than the kernels hold runs as dctr_sgemm + dctr_crossnet_matrix_step. */
+int dctr_crossnet_fwd_supported(const dctr_crossnet_args_t* args, const dctr_gather_fm_args_t* gather);
 /* ABI 11 — the elementwise half of ONE matrix-form layer (interaction.py:416-420) for inputs wider than the kernels above hold on chip
  * (their [16, dim] tiles of x_0 / x_l / x_{l+1} live in LDS: dim <= ~800; wider calls return DCTR_E_UNSUPPORTED):
  *     x_next[b, c] = x0[b, c] * (u[b, c] + bias[c]) + xl[b, c],     u = x_l W_l^T from dctr_sgemm ([B, dim], contiguous).
@@ -348,8 +354,21 @@ typedef struct {
                                    * activations y_k [B*D, H_k] row-major (row b*D + d, ALL H_k maps) are also written there
                                    * — what dctr_cin_bwd otherwise recomputes with one GEMM per layer (ABI 4) */
 } dctr_cin_args_t;
+/* Bytes of `workspace` for these arguments (fields, dim, n_layers, layer_size, split_half are read; batch is not): the fold of layer 0,
+ * plus — ABI 13 — for samples the kernel does not take whole, room for 1,024 samples of the sliced route.  CIN never mixes embedding
+ * dimensions before its final reduce_sum over d (interaction.py:288-295, :322-323), and the reference puts no limit on embedding_dim:
+ * a sample wider than one workgroup's MFMA tiles (embedding_dim > 128; > 64 when the maps of a 128-row tile would not fit the LDS) is
+ * walked as dim / dd pseudo-samples of dd dimensions (dd = the largest divisor of dim the kernel takes) laid out in the workspace by a
+ * pre-pass, their partial map sums added in the order of d by a post-pass; rows in chunks of what the workspace holds.  For such
+ * arguments the workspace is REQUIRED (DCTR_E_NULL without; any workspace with room for >= 64 samples works); save_y is written as
+ * for whole samples (row b * dim + d). */
 size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* args);
 int dctr_cin_fwd(const dctr_cin_args_t* args, void* stream);
+/* ABI 13 — would dctr_cin_fwd (gather == NULL) / dctr_cin_gather_fwd (gather != NULL; fused_head != 0: with head_w / logit) take these
+ * arguments?  Runs every shape check and kernel-shape decision of the call without launching; device pointers are not looked at
+ * (args->layer_size, a HOST array, is; of `gather` the summary fields n_fields / batch / uniform_dim / all_dim4 / any_hash / any_identity /
+ * any_pitch).  1 = yes, 0 = no (dctr_last_error() carries the reason).  Hosts ask this instead of re-deriving the kernels' limits. */
+int dctr_cin_fwd_supported(const dctr_cin_args_t* args, const dctr_gather_fm_args_t* gather, int32_t fused_head);
 
 /* ABI 8 — CIN.call over the embeddings of a gather, as deepctr/models/xdeepfm.py:52-66 wires it: exFM_in = concat_func(sparse_embedding_list,
  * axis=1) -> CIN -> Dense(1, use_bias=False).  The workgroup's [samples, F0, D] tile is read from the embedding tables inside the kernel

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, s), "libdctr_hip.so does not export %s" % s
         assert s in _C.SYMBOLS, "deepctr_amd/_C.py has no binding for %s" % s
     assert set(_C.SYMBOLS) == set(syms)
-    assert lib.dctr_abi_version() == _C.ABI_VERSION == 12
+    assert lib.dctr_abi_version() == _C.ABI_VERSION == 13
     assert lib.dctr_target_arch() == b"gfx950"
 
 
@@ -181,7 +181,7 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     src.write_text('#include <stdio.h>\n#include <string.h>\n#include "dctr.h"\n'
                    "int main(void) {\n"
                    "    dctr_gather_fm_args_t g; memset(&g, 0, sizeof g); g.batch = 4;\n"
-                   "    if (dctr_abi_version() != DCTR_ABI_VERSION || DCTR_ABI_VERSION != 12 || strcmp(dctr_target_arch(), \"gfx950\") != 0) return 1;\n"
+                   "    if (dctr_abi_version() != DCTR_ABI_VERSION || DCTR_ABI_VERSION != 13 || strcmp(dctr_target_arch(), \"gfx950\") != 0) return 1;\n"
                    "    if (dctr_fm_fwd(NULL, 4, 8, 2, 4, NULL, NULL) != DCTR_E_NULL) return 2;      /* rejected before any launch */\n"
                    "    if (dctr_embed_gather_fm(&g, NULL) != DCTR_E_DIM) return 3;\n"
                    "    if (strlen(dctr_last_error()) == 0) return 4;\n"

@@ -295,9 +295,15 @@ def test_random_configuration_trains_alike_on_the_hip_and_the_autograd_step(devi
         meta, feed, n = random_din_config(seed, dims4=dims4)
         n = min(n, 2 * bs + max(1, bs // 3), 700)
         feed = {k: v[:n] for k, v in feed.items()}
+    _check_fit(meta, feed, n, seed, bs, device)
+
+
+def _check_fit(meta, feed, n, seed, bs, device, must_be_supported=False):
+    from deepctr_amd import training_hip
     rng = np.random.RandomState(seed)
     probe = build_model(meta, device)
     if not training_hip.supported(probe):
+        assert not must_be_supported, "%s: fit() would take the autograd step" % meta["model"]
         pytest.skip("%s: outside the HIP training step's family (fit() takes the autograd step)" % meta["model"])
     w = _randomise(probe, rng)
     for k, v in w.items():
@@ -334,6 +340,53 @@ def test_random_configuration_trains_alike_on_the_hip_and_the_autograd_step(devi
                 continue
             bad = float((err > 0.1).mean())
             assert bad < 1e-2, "%s: update of %s (largest %.3g): %.2f %% of the elements differ by > 10 %% of it" % (what, k, moved, 100 * bad)
+
+
+WIDE_CIN_WIDTHS = [132, 160, 192, 256, 131, 136]
+
+
+def wide_xdeepfm_config(seed, rows=None):
+    """An xDeepFM configuration of random_config with every embedding as wide as WIDE_CIN_WIDTHS says: past the 128 dimensions one
+    workgroup of the CIN kernel holds (the reference's CIN takes any width, interaction.py:277-325; "auto" = 6 * vocab ** 0.25 passes 128
+    from 2e5 ids on, feature_column.py:44-45) — dctr_cin_fwd walks such samples in slices of d."""
+    meta, feed, n = random_config(9 + 10 * seed, rows=[300, 1000, 4099, 65][seed % 4] if rows is None else rows)
+    assert meta["model"] == "xDeepFM"
+    W = WIDE_CIN_WIDTHS[seed % len(WIDE_CIN_WIDTHS)]
+    for lst in (meta["dnn"], meta["linear"]):
+        for d in lst:
+            if d["type"] == "sparse":
+                d["embedding_dim"] = W
+            elif d["type"] == "varlen":
+                d["sparsefeat"]["embedding_dim"] = W
+    return meta, feed, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_xdeepfm_over_embeddings_wider_than_128_matches_the_oracle(device, seed):
+    meta, model, feed, n, ref = run_case(seed, device, wide_xdeepfm_config)
+    from tests.test_gpu_models import well_conditioned_rows
+    ok = well_conditioned_rows(meta, feed, n)
+    what = "wide xDeepFM %d (embedding_dim %d) n=%d" % (seed, WIDE_CIN_WIDTHS[seed % len(WIDE_CIN_WIDTHS)], n)
+    for bs in (4096, 333):
+        y = model.predict(feed, batch_size=bs)
+        if meta["kwargs"].get("task") == "regression":
+            assert_close(y[ok], ref[ok], rtol=1e-4, atol=2e-5, what="%s bs=%d" % (what, bs))
+        else:
+            check_probs(y, ref, "%s bs=%d" % (what, bs), ok)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_xdeepfm_over_embeddings_wider_than_128_trains_on_the_hip_step(device, seed):
+    """... and fit() keeps the HIP training step for them (the forward's saved activations are the sample's rows whatever the slicing;
+    dctr_cin_bwd works on rows (b, d))."""
+    bs = [64, 256][seed % 2]
+    n = 2 * bs + max(1, bs // 3)
+    meta, feed, n = wide_xdeepfm_config(seed, rows=n)
+    if any(d["type"] == "sparse" and d not in meta["dnn"] for d in meta["linear"]):
+        pytest.skip("linear-only features: the autograd step")
+    _check_fit(meta, feed, n, 7000 + seed, bs, device, must_be_supported=True)
 
 
 def test_random_configurations_are_valid_for_the_oracle():

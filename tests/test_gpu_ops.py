@@ -1021,3 +1021,121 @@ def test_afm_matrix_pipe_kernel(device, B, F, E, A):
     wide[:, 4:4 + F * E] = dev(x.reshape(B, -1), device)
     ys = ops.afm(wide[:, 4:4 + F * E], dev(W, device), dev(b, device), dev(h, device), dev(pvec, device), fields=F, dim=E)
     assert_close(ys.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6, what="afm strided input")
+
+
+def _cin_case(rng, B, F0, D, ls, split):
+    x = (rng.standard_normal((B, F0, D)) * 0.5).astype(np.float32)
+    fk = [F0] + [(h // 2 if split else h) for h in ls[:-1]]
+    fs = [(rng.standard_normal((1, F0 * fk[k], ls[k])) / np.sqrt(F0 * fk[k])).astype(np.float32) for k in range(len(ls))]
+    bs = [rng.standard_normal(ls[k]).astype(np.float32) * 0.1 for k in range(len(ls))]
+    return x, fs, bs
+
+
+@pytest.mark.parametrize("D", [132, 136, 160, 192, 256, 131, 384])
+def test_cin_embedding_dims_past_128(device, D):
+    """CIN.call has no limit on the embedding width (interaction.py:277-325; embedding_dim="auto" is 6 * vocab ** 0.25, feature_column.py:44-45):
+    samples wider than one workgroup's MFMA tiles go out in slices of d (dctr_cin_fwd, ABI 13) — D with a divisor of 128 / 96 / 68 / 66,
+    a prime (slices of ONE dimension), split_half on / off, fold on / off, a ragged batch, rows in more than one chunk of the workspace —
+    against the float64 oracle; a small caller workspace gives the same bits as the default one."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(300 + D)
+    B, F0 = 203, 7
+    assert ops.cin_supported(F0, D, (16, 8)) and ops.cin_workspace_bytes(F0, D, (16, 8)) > ops.cin_workspace_bytes(F0, 16, (16, 8))
+    for split, ls in ((True, (16, 8)), (False, (10, 6, 4))):
+        x, fs, bs = _cin_case(rng, B, F0, D, ls, split)
+        ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], split, "relu")
+        mag = R.cin(np.abs(x).astype(np.float64), [np.abs(f).astype(np.float64) for f in fs], [np.abs(b).astype(np.float64) for b in bs], split, "relu")
+        args = (dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, "relu")
+        y = ops.cin(*args)
+        assert_close_terms(y.cpu().numpy(), ref, mag, what="cin D=%d split=%s" % (D, split))
+        assert_close_terms(ops.cin(*args, fold=False).cpu().numpy(), ref, mag, what="cin D=%d split=%s (fold=False)" % (D, split))
+        # room for 80 samples: three chunks of rows
+        fold_b = ops._cin_fold_bytes(F0, ls)
+        per_row = (ops.cin_workspace_bytes(F0, D, ls) - ((fold_b + 15) & ~15)) // 1024
+        ws = torch.empty((((fold_b + 15) & ~15) + 80 * per_row) // 4 + 4, dtype=torch.float32, device=device)
+        assert torch.equal(ops.cin(*args, workspace=ws), y)
+    # an embedding read in place from a wider concat buffer (x_stride > F0 * D), as the models hand it over
+    x, fs, bs = _cin_case(rng, 37, 5, D, (12, 9), True)
+    buf = torch.zeros(37, 5 * D + 13, dtype=torch.float32, device=device)
+    buf[:, :5 * D] = dev(x.reshape(37, -1), device)
+    ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], True, "sigmoid")
+    y = ops.cin(buf, [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], (12, 9), True, "sigmoid", fields=5, dim=D)
+    assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="cin D=%d in place" % D)
+
+
+def test_cin_more_maps_than_a_128_row_tile_holds(device):
+    """embedding_dim 65 .. 128 with so many maps that the LDS cannot hold them beside a 128-row tile (refused before ABI 13): the same
+    slices, now of <= 64 dimensions; save_y rows are the sample's rows whatever the slicing (row b * D + d)."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(77)
+    B, F0, D, ls = 150, 26, 128, (200, 200, 200)
+    assert ops.cin_supported(F0, D, ls, False)
+    x, fs, bs = _cin_case(rng, B, F0, D, ls, False)
+    rows = np.arange(0, B, 7)
+    ref = R.cin(x[rows].astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], False, "relu")
+    mag = R.cin(np.abs(x[rows]).astype(np.float64), [np.abs(f).astype(np.float64) for f in fs], [np.abs(b).astype(np.float64) for b in bs], False, "relu")
+    args = (dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, False, "relu")
+    save = [torch.empty(B * D, h, dtype=torch.float32, device=device) for h in ls]
+    y = ops.cin(*args, save_y=save)
+    assert_close_terms(y.cpu().numpy()[rows], ref, mag, what="cin 26 x 128, maps (200, 200, 200)")
+    # the activations: D = 128 as two hand-made half-width samples through the whole-sample route
+    xh = dev(np.ascontiguousarray(x.reshape(B, F0, 2, 64).transpose(0, 2, 1, 3)).reshape(2 * B, F0, 64), device)
+    save_h = [torch.empty(2 * B * 64, h, dtype=torch.float32, device=device) for h in ls]
+    yh = ops.cin(xh, *args[1:], save_y=save_h)
+    for k in range(3):
+        assert torch.equal(save[k], save_h[k]), "save_y[%d]" % k
+    assert_close(y.cpu().numpy(), yh.cpu().numpy().reshape(B, 2, -1).sum(1), rtol=1e-6, atol=1e-6, what="sum of the halves")
+    # still refused: more maps than ANY tile height leaves room for
+    assert not ops.cin_supported(26, 64, (600, 600), False)
+
+
+def test_afm_inner_product_past_the_lds(device):
+    """AFMLayer / InnerProductLayer (interaction.py:116-146, :655-678) over sample tiles the LDS does not hold (4 samples x fields x
+    embedding_dim floats > 160 KiB; refused before round 6): the streaming kernels — nothing staged, softmax over the pairs as a running
+    (max, sum) — against the float64 oracle."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(5)
+    B, F, E, A = 9, 90, 128, 8
+    x = (rng.standard_normal((B, F, E)) * 0.3).astype(np.float32)
+    W = (rng.standard_normal((E, A)) / np.sqrt(E)).astype(np.float32)
+    b = (rng.standard_normal(A) * 0.1).astype(np.float32)
+    h = rng.standard_normal((A, 1)).astype(np.float32)
+    p = rng.standard_normal((E, 1)).astype(np.float32)
+    emb = [x[:, i:i + 1, :].astype(np.float64) for i in range(F)]
+    ref = R.afm(emb, W.astype(np.float64), b.astype(np.float64), h.astype(np.float64), p.astype(np.float64))
+    y = ops.afm(dev(x, device), dev(W, device), dev(b, device), dev(h, device), dev(p, device))
+    assert_close(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5, what="afm 90 x 128")
+    assert_close(ops.inner_product(dev(x, device), True).cpu().numpy(), R.inner_product(emb, True), rtol=1e-4, atol=1e-5, what="ip sum 90 x 128")
+    xs = x[:3]
+    embs = [xs[:, i:i + 1, :].astype(np.float64) for i in range(F)]
+    assert_close(ops.inner_product(dev(xs, device), False).cpu().numpy(), R.inner_product(embs, False), rtol=1e-5, atol=1e-6, what="ip full 90 x 128")
+
+
+def test_din_attention_history_past_4096_positions(device):
+    """AttentionSequencePoolingLayer over a history longer than the two-launch form's pooling kernel holds (4 samples x T scores in
+    64 KiB of LDS: T <= 4,096; the reference's layer takes any T, layers/sequence.py:261-298): the one-kernel form (no launch in front
+    of a refusal: round 6), with and without the workspace, against the float64 oracle."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(12)
+    B, T, E, hid = 3, 5000, 16, (36, 8)
+    q = rng.standard_normal((B, 1, E)).astype(np.float32) * 0.5
+    k = rng.standard_normal((B, T, E)).astype(np.float32) * 0.5
+    lens = np.array([T, 4097, 0])
+    km = np.arange(T)[None, :] < lens[:, None]
+    dims = [4 * E] + list(hid)
+    ks = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(hid))]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(hid))]
+    ok = rng.standard_normal((dims[-1], 1)).astype(np.float32) * 0.3
+    ob = np.array([0.05], np.float32)
+    for act, wn in (("sigmoid", True), ("relu", False)):
+        ref = R.attention_sequence_pooling(q.astype(np.float64), k.astype(np.float64), km, [w.astype(np.float64) for w in ks],
+                                           [b.astype(np.float64) for b in bs], ok.astype(np.float64), ob.astype(np.float64), act, None, wn)
+        score = R.attention_sequence_pooling(q.astype(np.float64), k.astype(np.float64), km, [w.astype(np.float64) for w in ks],
+                                             [b.astype(np.float64) for b in bs], ok.astype(np.float64), ob.astype(np.float64), act, None, wn,
+                                             return_score=True)
+        mag = np.abs(score) @ np.abs(k.astype(np.float64))
+        args = (dev(q, device), dev(k, device), dev(km, device), [dev(w, device) for w in ks], [dev(b, device) for b in bs], dev(ok, device),
+                dev(ob, device), act, None)
+        for ws in (True, False):
+            y = ops.din_attention(*args, weight_normalization=wn, **({} if ws else {"workspace": False}))
+            assert_close_terms(y.cpu().numpy(), ref, mag, rtol_terms=4e-6, what="din attention T=5000 %s workspace=%s" % (act, ws))
