@@ -738,6 +738,74 @@ __global__ __launch_bounds__(256) void cross_vector_bwd_kernel(const float* __re
     }
 }
 
+// vector form, any width (the kernel above keeps a wave's x_l, d w, d b in LDS and a row's gradient in registers: <= 2048 columns and
+// 48 L d bytes of LDS): the same recurrence layer by layer over the whole batch, x_l / s_l / g / d x0 in the caller's workspace —
+// memory-bound passes, no limit on d.  Forward step: s_l[b] = x_l[b] . w_l;  x_{l+1}[b] = x0[b] * s_l[b] + b_l + x_l[b]  (one wave per sample)
+__global__ __launch_bounds__(256) void cross_vec_fwd_step_kernel(const float* __restrict__ x0, int64_t x0_stride, const float* __restrict__ xl,
+                                                                 int64_t xl_stride, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 int64_t batch, int d, float* __restrict__ s, float* __restrict__ xn) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    const float* r0 = x0 + b * x0_stride;
+    const float* rl = xl + b * xl_stride;
+    float dot = 0.f;
+    for (int i = lane; i < d; i += 64) dot = fmaf(rl[i], w[i], dot);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    if (lane == 0) s[b] = dot;
+    if (xn != nullptr)
+        for (int i = lane; i < d; i += 64) xn[b * d + i] = r0[i] * dot + bias[i] + rl[i];
+}
+
+// ds[b] = g[b] . x0[b]
+__global__ __launch_bounds__(256) void cross_vec_dot_kernel(const float* __restrict__ g, const float* __restrict__ x0, int64_t x0_stride,
+                                                            int64_t batch, int d, float* __restrict__ ds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    const float* gr = g + b * d;
+    const float* r0 = x0 + b * x0_stride;
+    float dot = 0.f;
+    for (int i = lane; i < d; i += 64) dot = fmaf(gr[i], r0[i], dot);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    if (lane == 0) ds[b] = dot;
+}
+
+// d b_l[i] += sum_b g[b, i];  d w_l[i] += sum_b ds[b] * x_l[b, i]: a thread owns a column over a slice of the rows (coalesced across the
+// workgroup), one atomic per column and slice
+__global__ __launch_bounds__(256) void cross_vec_colsum_kernel(const float* __restrict__ g, const float* __restrict__ ds,
+                                                               const float* __restrict__ xl, int64_t xl_stride, int64_t batch, int d,
+                                                               float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d) return;
+    const int64_t per = (batch + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = (int64_t)blockIdx.y * per, b1 = b0 + per < batch ? b0 + per : batch;
+    float aw = 0.f, ab = 0.f;
+    for (int64_t b = b0; b < b1; ++b) {
+        ab += g[b * d + i];
+        aw = fmaf(ds[b], xl[b * xl_stride + i], aw);
+    }
+    if (b1 > b0) {
+        unsafeAtomicAdd(dw + i, aw);
+        unsafeAtomicAdd(db + i, ab);
+    }
+}
+
+// d x0[b, i] += g[b, i] * s_l[b];  g[b, i] += ds[b] * w_l[i]
+__global__ __launch_bounds__(256) void cross_vec_update_kernel(float* __restrict__ g, float* __restrict__ dx0, const float* __restrict__ ds,
+                                                               const float* __restrict__ s, const float* __restrict__ w, int64_t batch, int d) {
+    const int64_t total = batch * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / d;
+        const int i = (int)(e - b * d);
+        const float gv = g[e];
+        dx0[e] = fmaf(gv, s[b], dx0[e]);
+        g[e] = fmaf(ds[b], w[i], gv);
+    }
+}
+
 // matrix form, elementwise parts (the GEMMs are dctr_gemm): forward  x_next = x0 .* (u + b) + x_l
 __global__ __launch_bounds__(256) void cross_matrix_fwd_elem_kernel(const float* __restrict__ x0, int64_t x_stride,
                                                                     const float* __restrict__ xl, int64_t xl_stride,
@@ -2484,8 +2552,17 @@ extern "C" int dctr_dense1_bwd(const float* x, int64_t x_stride, int64_t batch, 
     return dctr_launch_status("dctr_dense1_bwd");
 }
 
+// vector form: does the one-kernel backward (x_l of a wave's sample + its d w / d b accumulators in LDS, the row's gradient in registers) hold it?
+static bool cross_vector_bwd_on_chip(int d, int L) { return d <= 2048 && (size_t)4 * (3 * (size_t)L * d + L) * sizeof(float) <= 160 * 1024; }
+
 extern "C" size_t dctr_crossnet_bwd_workspace_bytes(const dctr_crossnet_bwd_args_t* a) {
-    if (a == nullptr || a->batch <= 0 || a->layers <= 0 || a->mode != DCTR_CROSS_MATRIX) return 0;
+    if (a == nullptr || a->batch <= 0 || a->layers <= 0) return 0;
+    if (a->mode == DCTR_CROSS_VECTOR) {
+        // the layer-by-layer form of wide inputs: x_1 .. x_{L-1}, g, d x0 [B, d] each; s_0 .. s_{L-1}, ds [B] each
+        if (a->dim < 1 || cross_vector_bwd_on_chip(a->dim, a->layers)) return 0;
+        return ((size_t)(a->layers + 1) * a->batch * a->dim + (size_t)(a->layers + 1) * a->batch) * sizeof(float);
+    }
+    if (a->mode != DCTR_CROSS_MATRIX) return 0;
     // x_1 .. x_{L-1}, u_0 .. u_{L-1}, g, du, dx0; from 8192 rows on the partial dW of the row slices (as in dctr_mlp_bwd)
     const int parts = mlp_dw_parts(a->batch, (int64_t)a->dim * a->dim);
     return ((size_t)(2 * a->layers + 2) * a->batch * a->dim + (parts > 1 ? (size_t)parts * a->dim * a->dim : 0)) * sizeof(float);
@@ -2507,10 +2584,50 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
         return dctr_launch_status("dctr_crossnet_bwd");
     }
     DCTR_REQUIRE(a->kernels && a->bias && a->d_kernels && a->d_bias, DCTR_E_NULL, "crossnet_bwd: null weights / gradients");
+    if (a->mode == DCTR_CROSS_VECTOR && !cross_vector_bwd_on_chip(d, L)) {
+        // any width (round 6; the reference's CrossNet has none, interaction.py:405-424): layer by layer over the batch
+        DCTR_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= dctr_crossnet_bwd_workspace_bytes(a), DCTR_E_NULL,
+                     "crossnet_bwd(vector): %d layers x dim %d need a workspace of dctr_crossnet_bwd_workspace_bytes() bytes", L, d);
+        const size_t bd = (size_t)a->batch * d;
+        float* ws = static_cast<float*>(a->workspace);
+        float* xsave = ws;                                   // x_1 .. x_{L-1}
+        float* g = ws + (size_t)(L - 1) * bd;
+        float* dx0 = g + bd;
+        float* sl = dx0 + bd;                                // [L][B]
+        float* ds = sl + (size_t)L * a->batch;               // [B]
+        const unsigned wb = (unsigned)dctr_ceil_div(a->batch, (int64_t)4);
+        DCTR_REQUIRE(dctr_ceil_div(a->batch, (int64_t)4) <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_bwd: batch too large");
+        auto xl_of = [&](int l, const float*& p, int64_t& ld) {
+            if (l == 0) { p = a->x; ld = a->x_stride; }
+            else { p = xsave + (size_t)(l - 1) * bd; ld = d; }
+        };
+        for (int l = 0; l < L; ++l) {
+            const float* xl; int64_t ldx;
+            xl_of(l, xl, ldx);
+            hipLaunchKernelGGL(cross_vec_fwd_step_kernel, dim3(wb), dim3(256), 0, st, a->x, a->x_stride, xl, ldx, a->kernels + (size_t)l * d,
+                               a->bias + (size_t)l * d, a->batch, d, sl + (size_t)l * a->batch, l + 1 < L ? xsave + (size_t)l * bd : (float*)nullptr);
+        }
+        hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, a->dy, a->dy_stride, a->batch, d, g, (int64_t)d, 0);
+        hipError_t me = hipMemsetAsync(dx0, 0, bd * sizeof(float), st);
+        DCTR_REQUIRE(me == hipSuccess, (int)me, "crossnet_bwd: memset failed: %s", hipGetErrorString(me));
+        int64_t slices = dctr_ceil_div(a->batch, (int64_t)64);
+        if (slices > 64) slices = 64;
+        for (int l = L - 1; l >= 0; --l) {
+            const float* xl; int64_t ldx;
+            xl_of(l, xl, ldx);
+            hipLaunchKernelGGL(cross_vec_dot_kernel, dim3(wb), dim3(256), 0, st, (const float*)g, a->x, a->x_stride, a->batch, d, ds);
+            hipLaunchKernelGGL(cross_vec_colsum_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)slices), dim3(256), 0, st, (const float*)g,
+                               (const float*)ds, xl, ldx, a->batch, d, a->d_kernels + (size_t)l * d, a->d_bias + (size_t)l * d);
+            hipLaunchKernelGGL(cross_vec_update_kernel, dim3(eb), dim3(256), 0, st, g, dx0, (const float*)ds, (const float*)(sl + (size_t)l * a->batch),
+                               a->kernels + (size_t)l * d, a->batch, d);
+        }
+        hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, (const float*)g, (int64_t)d, a->batch, d, dx0, (int64_t)d, 1);
+        hipLaunchKernelGGL(add_rows_kernel, dim3(eb), dim3(256), 0, st, (const float*)dx0, (int64_t)d, a->batch, d, a->dx, a->dx_stride,
+                           (int)a->dx_accumulate);
+        return dctr_launch_status("dctr_crossnet_bwd");
+    }
     if (a->mode == DCTR_CROSS_VECTOR) {
-        DCTR_REQUIRE(d <= 2048, DCTR_E_UNSUPPORTED, "crossnet_bwd(vector): dim %d > 2048", d);
         const size_t lds = (size_t)4 * (3 * (size_t)L * d + L) * sizeof(float);
-        DCTR_REQUIRE(lds <= 160 * 1024, DCTR_E_UNSUPPORTED, "crossnet_bwd(vector): %d layers x dim %d need %zu B of LDS", L, d, lds);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)cross_vector_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DCTR_REQUIRE(e == hipSuccess, (int)e, "crossnet_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e));

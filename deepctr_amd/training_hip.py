@@ -46,20 +46,20 @@ def supported(model):
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
     if sp.lin_only:
         return False
-    if kind == "_DIN" and (not sp.all_dim4 or sp.max_dim > 64):
-        return False                        # (the attention unit's training kernels hold a key row per lane group: widths % 4 == 0, <= 64)
+    # (round 6: DIN over any key width — the attention unit trains on the materialised [B * T, 4 E'] input, dctr_embed_lookup_bwd scatters
+    #  any width (its sorted-tile form up to 64 columns, plain atomics past that); tables whose width is not a multiple of 4 carry no
+    #  touched-group marks)
     # (round 6: any embedding width — widths that are not a multiple of 4 or exceed 64, embedding_dim="auto" — the scatter kernels walk a
     # row in chunks, element per lane where rows are not 16-B aligned; such tables carry no touched-group marks: dense optimizer pass)
     if kind == "_xDeepFM" and getattr(model, "cin", None) is not None and not ops.cin_supported(
             len(sp.fields), model.cin_dim, list(model.cin.layer_size), model.cin.split_half, model.cin.activation):
         return False                        # (the library's answer — dctr_cin_fwd_supported; round 6: any embedding width, in slices of d past 128)
-    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "matrix" and sp.in_dim > 832:
-        return False                        # (the training forward's matrix CrossNet keeps [16, dim] tiles of x_0 / x_l / x_{l+1} in LDS)
-    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector":
-        # dctr_crossnet_bwd's vector form holds a row's gradient in registers (<= 2048 columns) and every layer's x_l in LDS
-        n_l = int(getattr(model.cross, "layer_num", 0))
-        if sp.in_dim > 2048 or 16 * (3 * n_l * sp.in_dim + n_l) > 160 * 1024:
-            return False
+    # (round 6: a matrix CrossNet of any width — past the [16, dim] LDS tiles of the one-kernel training forward, ~832 columns, i.e. Criteo
+    #  at embedding_dim 32, the forward runs layer by layer on dctr_sgemm + dctr_crossnet_matrix_step straight into saved_u / saved_x:
+    #  _cross_fwd; dctr_crossnet_bwd's matrix form has no width of its own)
+    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector" and sp.in_dim > 8192:
+        return False                        # (dctr_crossnet_fwd's vector form holds a row of x_0 / x_l in registers: <= 8192 columns; the
+                                            #  backward takes any width since round 6 — layer by layer past 2048 columns / 48 L d bytes of LDS)
     if len(sp.fm_group_names) > 1:          # further FM groups (DeepFM / AFM fm_group): their logits ride on the head's four `add` slots
         n_add = int(bool(sp.has_linear)) + len(sp.fm_group_names)
         if kind not in ("_DeepFM", "_AFM") or n_add > 4:
@@ -225,6 +225,7 @@ class HipTrainer(object):
             self.p_cin_b = [param(b) for b in model.cin.biases]
             self.p_head1 = param(model.dense_1.w("kernel"))
         self.p_cross_k = self.p_cross_b = None
+        self._cross_one_kernel = {}         # (rows, dim, layers) -> dctr_crossnet_fwd_supported's answer for the training forward
         self.p_mix = None
         if self.is_mix and model.cross is not None:
             # CrossNetMix: U / V / C stacked over layers, the experts' gating kernels, the biases — five packed parameter
@@ -634,7 +635,34 @@ class HipTrainer(object):
                             workspace_ready=0, kernels=ks.data_ptr(), bias=bs.data_ptr(), y=stack.data_ptr(), y_stride=stack.stride(0),
                             workspace=self._cross_ws.data_ptr() if need else None, workspace_bytes=need,
                             save_u=None if su is None else su.data_ptr(), save_x=None if sx is None else sx.data_ptr())
+        if su is not None:
+            # the one-kernel form keeps [16, dim] tiles of x_0 / x_l / x_{l+1} in LDS: whether it takes this width is the library's answer
+            key = (dnn_in.shape[0], d, ks.shape[0])
+            ok = self._cross_one_kernel.get(key)
+            if ok is None:
+                ok = self._cross_one_kernel[key] = bool(_C.lib().dctr_crossnet_fwd_supported(ctypes.byref(a), None))
+            if not ok:
+                return self._cross_fwd_layered(dnn_in, d, stack, su, sx)
         _C.check(_C.lib().dctr_crossnet_head_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_crossnet_head_fwd")
+
+    def _cross_fwd_layered(self, dnn_in, d, stack, su, sx):
+        """Matrix CrossNet (interaction.py:416-420) of any width, layer by layer, writing what dctr_crossnet_bwd reads: u_l = x_l W_l^T
+        (the library's f32-MFMA GEMM, dctr_sgemm) -> saved_u[l]; x_{l+1} = x_0 * (u_l + b_l) + x_l (dctr_crossnet_matrix_step) ->
+        saved_x[l] (x_1 .. x_{L-1}) and, for the last layer, the cross half of the stack."""
+        import ctypes  # noqa: F401
+        from . import _C
+        ks, bs = self.p_cross_k.w, self.p_cross_b.w       # [L, d, d] (W_l: [out n, in k]), [L, d]
+        L, B, st = ks.shape[0], dnn_in.shape[0], _C.stream_ptr()
+        xl, xl_stride = dnn_in, ops.row_stride(dnn_in)
+        for l in range(L):
+            u = su[l]
+            # column-major BLAS view: u^T (d x B) = W^T-view (k x n)^T . x_l^T (k x B)
+            _C.check(_C.lib().dctr_sgemm(1, 0, d, B, d, ks[l].data_ptr(), d, 0, xl.data_ptr(), int(xl_stride), 0, 0.0, u.data_ptr(), d, 0, 1, st),
+                     "dctr_sgemm")
+            nxt, nxt_stride = (stack, ops.row_stride(stack)) if l == L - 1 else (sx[l], d)
+            _C.check(_C.lib().dctr_crossnet_matrix_step(dnn_in.data_ptr(), ops.row_stride(dnn_in), xl.data_ptr(), int(xl_stride), u.data_ptr(),
+                                                        bs[l].data_ptr(), B, d, nxt.data_ptr(), int(nxt_stride), st), "dctr_crossnet_matrix_step")
+            xl, xl_stride = nxt, nxt_stride
 
     def step(self, staged, lo, hi, y, apply=True, loss_acc=None, weight=None):
         """One optimizer step on rows [lo, hi) of the staged inputs; y: device float tensor [hi-lo].  Returns the mean

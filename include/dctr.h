@@ -816,8 +816,11 @@ typedef struct {
 } dctr_afm_bwd_args_t;
 int dctr_afm_bwd(const dctr_afm_bwd_args_t* args, void* stream);
 
-/* backward of dctr_crossnet_fwd (interaction.py:405-424).  vector: one fused kernel (x_l recomputed).  matrix: GEMMs on dctr_sgemm's
- * kernel + elementwise kernels through the workspace; u_l / x_l recomputed unless the forward saved them (saved_u / saved_x). */
+/* backward of dctr_crossnet_fwd (interaction.py:405-424).  vector: one fused kernel (x_l recomputed) while a wave's x_l and its d w / d b
+ * accumulators fit the LDS and a row's gradient the registers (dim <= 2048, 48 * layers * dim bytes <= 160 KiB); wider inputs (ABI 13: any
+ * dim — Criteo at embedding_dim 64 is 1,677 columns) run the same recurrence layer by layer over the batch through the workspace.
+ * matrix: GEMMs on dctr_sgemm's kernel + elementwise kernels through the workspace; u_l / x_l recomputed unless the forward saved
+ * them (saved_u / saved_x).  dctr_crossnet_bwd_workspace_bytes() says what a call needs (0 for the on-chip vector form). */
 typedef struct {
     const float* x;               /* [B, x_stride] the forward's input x_0                               */
     int64_t x_stride;
@@ -831,7 +834,7 @@ typedef struct {
     float* d_bias;                /* accumulated [layers, dim]                                           */
     float* dx;                    /* [B, dx_stride] gradient w.r.t. x_0                                  */
     int64_t dx_stride;
-    void* workspace;              /* dctr_crossnet_bwd_workspace_bytes() bytes (matrix form), 16-B aligned */
+    void* workspace;              /* dctr_crossnet_bwd_workspace_bytes() bytes (matrix form; wide vector form), 16-B aligned */
     size_t workspace_bytes;
     const float* saved_u;         /* ABI 6, matrix form: NULL (u_l and x_l are recomputed: one GEMM + one elementwise launch per layer),   */
     const float* saved_x;         /* or what the forward wrote through dctr_crossnet_args_t.save_u / save_x (saved_x may be NULL: 1 layer) */

@@ -309,6 +309,9 @@ def _check_fit(meta, feed, n, seed, bs, device, must_be_supported=False):
     for k, v in w.items():
         if "batch_normalization" in k and k.endswith("moving_variance"):
             w[k] = (0.5 + rng.rand(*v.shape)).astype(np.float32)
+    # (the probe scores with the STORED statistics: it must see the positive variances too — before this line every configuration with
+    #  BatchNormalization / Dice probed NaN logits and was skipped as "saturated")
+    probe.set_weights_by_name(w)
     y = (rng.rand(n) > 0.5).astype(np.float32)
     optimizer = "adam" if seed % 3 == 2 else "sgd"
     lg = probe.predict_logits(feed, batch_size=4096) if hasattr(probe, "predict_logits") else np.zeros(1)
@@ -387,6 +390,67 @@ def test_xdeepfm_over_embeddings_wider_than_128_trains_on_the_hip_step(device, s
     if any(d["type"] == "sparse" and d not in meta["dnn"] for d in meta["linear"]):
         pytest.skip("linear-only features: the autograd step")
     _check_fit(meta, feed, n, 7000 + seed, bs, device, must_be_supported=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("par,emb,cross_num", [("matrix", 32, 2), ("vector", 64, 2), ("matrix", 64, 1), ("vector", 96, 3)])
+def test_dcn_over_criteo_width_inputs_trains_on_the_hip_step(device, par, emb, cross_num):
+    """DCN over Criteo's 26 + 13 columns at embedding_dim 32 / 64 / 96 — 845 / 1,677 / 2,509 DNN-input columns: past the one-kernel
+    training forward of the matrix CrossNet (~832) and the one-kernel backward of the vector form (2048 columns, 48 L d bytes of LDS).
+    Round 6: fit() keeps the HIP step (layer-by-layer forward into saved_u / saved_x; layer-by-layer vector backward) — same loss and
+    updates as the autograd step; predict() against the float64 oracle."""
+    seed = {"matrix": 11, "vector": 12}[par] + emb
+    rng = np.random.RandomState(seed)
+    bs = 64
+    n = 2 * bs + 21
+    cols, feed = [], {}
+    for i in range(26):
+        v = int(rng.choice([7, 100, 1000]))
+        cols.append({"type": "sparse", "name": "C%d" % i, "vocabulary_size": v, "embedding_dim": emb})
+        feed["C%d" % i] = rng.randint(0, v, n).astype(np.int32)
+    for i in range(13):
+        cols.append({"type": "dense", "name": "I%d" % i, "dimension": 1})
+        feed["I%d" % i] = rng.rand(n, 1).astype(np.float32)
+    meta = json.loads(json.dumps({"model": "DCN", "linear": cols, "dnn": cols, "kwargs": {
+        "seed": 1024 + seed, "cross_num": cross_num, "cross_parameterization": par, "dnn_hidden_units": [64, 32], "dnn_activation": "relu"}}))
+    _, model, _, _, ref = run_case(seed, device, lambda s: (meta, feed, n))
+    check_probs(model.predict(feed, batch_size=4096), ref, "DCN %s emb %d" % (par, emb), None)
+    _check_fit(meta, feed, n, seed, bs, device, must_be_supported=True)
+
+
+DIN_KEY_WIDTHS = [128, 6, 10, 72, 3, 100]
+
+
+def odd_width_din_config(seed, rows=None):
+    """A DIN configuration of random_din_config whose behaviour features (and their histories) are DIN_KEY_WIDTHS wide: not a multiple of
+    4, or past 64 — the widths the HIP training step left to the autograd step before round 6."""
+    meta, feed, n = random_din_config(seed)
+    if rows is not None and rows < n:
+        n = rows
+        feed = {k: v[:n] for k, v in feed.items()}
+    W = DIN_KEY_WIDTHS[seed % len(DIN_KEY_WIDTHS)]
+    hist = set(meta["extra_args"][0])
+    for d in meta["dnn"]:
+        if d["type"] == "sparse" and d["name"] in hist:
+            d["embedding_dim"] = W
+        elif d["type"] == "varlen" and d["sparsefeat"].get("embedding_name") in hist:
+            d["sparsefeat"]["embedding_dim"] = W
+    return meta, feed, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_din_over_any_key_width_trains_on_the_hip_step(device, seed):
+    bs = [64, 256][seed % 2]
+    meta, feed, n = odd_width_din_config(seed, rows=2 * bs + max(1, bs // 3))
+    _, model, _, _, ref = run_case(seed, device, lambda s: (meta, feed, n))
+    what = "DIN key width %d (%d)" % (DIN_KEY_WIDTHS[seed % len(DIN_KEY_WIDTHS)], seed)
+    y = model.predict(feed, batch_size=4096)
+    if meta["kwargs"].get("task") == "regression":
+        assert_close(y, ref, rtol=1e-4, atol=2e-5, what=what)
+    else:
+        check_probs(y, ref, what, None)
+    _check_fit(meta, feed, n, 9000 + seed, bs, device, must_be_supported=True)
 
 
 def test_random_configurations_are_valid_for_the_oracle():
