@@ -256,6 +256,8 @@ SYMBOLS = {
     "dctr_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_adam_multi": (ctypes.c_int, [c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "dctr_opt_multi": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "dctr_opt_multi_l2": (ctypes.c_int, [ctypes.c_int32, c_vp, c_i32, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                          c_i32, c_vp, ctypes.c_float, c_vp]),
     "dctr_din_attn_workspace_bytes": (c_sz, [ctypes.POINTER(DinAttnArgs)]),
     "dctr_din_attn_pool_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), c_vp]),
     "dctr_din_attn_gather_fwd": (ctypes.c_int, [ctypes.POINTER(DinAttnArgs), ctypes.POINTER(DinGatherArgs), c_vp]),

@@ -568,9 +568,11 @@ __device__ __forceinline__ void st4(float4* p, const float4& v) {
     else *p = v;
 }
 
-template <int KIND, int U = 2, bool NT = false>
+// PEN: also adds  pen_scale * sum_segments l2 * sum(w^2)  of the weights BEFORE the update to *pen — the l2 penalties tf.keras adds to
+// that batch's loss (regularizers: inputs.py:22, layers/core.py:170, interaction.py:100,258,387); the weights pass through registers anyway
+template <int KIND, int U = 2, bool NT = false, bool PEN = false>
 __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* __restrict__ segs, float lr, float b1, float b2,
-                                                        float eps, int zero_grad) {
+                                                        float eps, int zero_grad, double* __restrict__ pen, float pen_scale) {
     const dctr_adam_seg_t sg = segs[blockIdx.y];
     float4* __restrict__ w = reinterpret_cast<float4*>(sg.w);
     float4* __restrict__ m = reinterpret_cast<float4*>(sg.m);
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* _
     const int64_t stride = (int64_t)gridDim.x * 256;
     constexpr bool USE_M = KIND == DCTR_OPT_ADAM, USE_V = KIND != DCTR_OPT_SGD;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float psum = 0.f;                  // (PEN: this thread's share of sum(w^2): a few hundred terms at most)
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
         bool in[U], has[U];
         float4 wv[U], mv[U], vv[U], gv[U];
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* _
             if (!in[u]) continue;
             const int64_t i = i0 + u * stride;
             float* wp = &wv[u].x; float* mp = &mv[u].x; float* vp = &vv[u].x; const float* gp = &gv[u].x;
+            if constexpr (PEN) psum += (wp[0] * wp[0] + wp[1] * wp[1]) + (wp[2] * wp[2] + wp[3] * wp[3]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) opt_update<KIND>(wp[c], mp[c], vp[c], fmaf(2.f * l2, wp[c], gp[c]), lr, b1, b2, eps);
             st4<NT>(w + i, wv[u]);
@@ -619,10 +623,25 @@ __global__ __launch_bounds__(256) void opt_multi_kernel(const dctr_adam_seg_t* _
     if (blockIdx.x == 0) {
         for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
             float mm = USE_M ? sg.m[i] : 0.f, vv = USE_V ? sg.v[i] : 0.f;
+            if constexpr (PEN) psum = fmaf(sg.w[i], sg.w[i], psum);
             opt_update<KIND>(sg.w[i], mm, vv, fmaf(2.f * l2, sg.w[i], sg.g[i]), lr, b1, b2, eps);
             if (USE_M) sg.m[i] = mm;
             if (USE_V) sg.v[i] = vv;
             if (zero_grad) sg.g[i] = 0.f;
+        }
+    }
+    if constexpr (PEN) {
+        if (l2 != 0.f) {               // (uniform per workgroup: a segment's l2)
+            __shared__ double pw[4];
+            double d = (double)psum;
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) d += __shfl_xor(d, mk, 64);
+            if ((threadIdx.x & 63) == 0) pw[threadIdx.x >> 6] = d;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double t = (pw[0] + pw[1]) + (pw[2] + pw[3]);
+                if (t != 0.0) unsafeAtomicAdd(pen, t * (double)l2 * (double)pen_scale);
+            }
         }
     }
 }
@@ -2506,6 +2525,13 @@ extern "C" int dctr_adam_step(float* w, float* m, float* v, float* g, int64_t n,
 
 extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
                               float beta2, float eps, int32_t zero_grad, void* stream) {
+    return dctr_opt_multi_l2(kind, segs, n_segs, max_n, lr, beta1, beta2, eps, zero_grad, nullptr, 0.f, stream);
+}
+
+// ABI 13 — the same step; with l2_penalty != NULL the launch also adds penalty_scale * sum over the segments of l2 * sum(w^2), taken on the
+// weights BEFORE the update, to *l2_penalty (a DEVICE double): what tf.keras adds to that batch's reported loss
+extern "C" int dctr_opt_multi_l2(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
+                                 float beta2, float eps, int32_t zero_grad, double* l2_penalty, float penalty_scale, void* stream) {
     DCTR_REQUIRE(kind >= DCTR_OPT_ADAM && kind <= DCTR_OPT_SGD, DCTR_E_ENUM, "opt_multi: optimizer kind %d", kind);
     DCTR_REQUIRE(n_segs >= 0 && n_segs <= 65535 && max_n >= 0, DCTR_E_DIM, "opt_multi: bad n_segs / max_n");
     if (n_segs == 0 || max_n == 0) return DCTR_OK;
@@ -2521,18 +2547,26 @@ extern "C" int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t
     hipStream_t st = (hipStream_t)stream;
 #define DCTR_OPT_LAUNCH(K)                                                                                                                     \
     do {                                                                                                                                       \
-        if (variant == 0) hipLaunchKernelGGL((opt_multi_kernel<K, 2, false>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad);      \
-        else if (variant == 1) hipLaunchKernelGGL((opt_multi_kernel<K, 4, false>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); \
-        else if (variant == 3) hipLaunchKernelGGL((opt_multi_kernel<K, 4, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad);  \
-        else hipLaunchKernelGGL((opt_multi_kernel<K, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad);                    \
+        if (pen != nullptr) hipLaunchKernelGGL((opt_multi_kernel<K, 2, true, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, penalty_scale); \
+        else if (variant == 0) hipLaunchKernelGGL((opt_multi_kernel<K, 2, false>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, 0.f);      \
+        else if (variant == 1) hipLaunchKernelGGL((opt_multi_kernel<K, 4, false>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, 0.f); \
+        else if (variant == 3) hipLaunchKernelGGL((opt_multi_kernel<K, 4, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, 0.f);  \
+        else hipLaunchKernelGGL((opt_multi_kernel<K, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, 0.f);                    \
     } while (0)
+#define DCTR_OPT_LAUNCH2(K)                                                                                                                    \
+    do {                                                                                                                                       \
+        if (pen != nullptr) hipLaunchKernelGGL((opt_multi_kernel<K, 2, true, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, penalty_scale); \
+        else hipLaunchKernelGGL((opt_multi_kernel<K, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad, pen, 0.f);  \
+    } while (0)
+    double* pen = l2_penalty;
     switch (kind) {
         case DCTR_OPT_ADAM: DCTR_OPT_LAUNCH(DCTR_OPT_ADAM); break;
-        case DCTR_OPT_ADAGRAD: hipLaunchKernelGGL((opt_multi_kernel<DCTR_OPT_ADAGRAD, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
-        case DCTR_OPT_RMSPROP: hipLaunchKernelGGL((opt_multi_kernel<DCTR_OPT_RMSPROP, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
-        default: hipLaunchKernelGGL((opt_multi_kernel<DCTR_OPT_SGD, 2, true>), grid, dim3(256), 0, st, segs, lr, beta1, beta2, eps, (int)zero_grad); break;
+        case DCTR_OPT_ADAGRAD: DCTR_OPT_LAUNCH2(DCTR_OPT_ADAGRAD); break;
+        case DCTR_OPT_RMSPROP: DCTR_OPT_LAUNCH2(DCTR_OPT_RMSPROP); break;
+        default: DCTR_OPT_LAUNCH2(DCTR_OPT_SGD); break;
     }
 #undef DCTR_OPT_LAUNCH
+#undef DCTR_OPT_LAUNCH2
     return dctr_launch_status("dctr_opt_multi");
 }
 

@@ -1165,8 +1165,17 @@ def adam_multi(segs, n_segs, max_n, alpha, beta1=0.9, beta2=0.999, eps=1e-7, zer
                                       float(eps), int(bool(zero_grad)), _C.stream_ptr()), "dctr_adam_multi")
 
 
-def opt_multi(kind, segs, n_segs, max_n, lr, beta1=0.9, beta2=0.999, eps=1e-7, zero_grad=True):
-    """One optimizer step (kind: adam | adagrad | rmsprop | sgd) over every parameter segment in one launch."""
+def opt_multi(kind, segs, n_segs, max_n, lr, beta1=0.9, beta2=0.999, eps=1e-7, zero_grad=True, penalty=None, penalty_scale=0.0):
+    """One optimizer step (kind: adam | adagrad | rmsprop | sgd) over every parameter segment in one launch.  ``penalty`` (a device
+    float64 tensor of one element): the launch also adds penalty_scale * sum_segments l2 * sum(w^2) of the weights BEFORE the update to
+    it — the regularisation losses tf.keras adds to the batch's loss (dctr_opt_multi_l2)."""
+    if penalty is not None:
+        if penalty.dtype != torch.float64 or penalty.numel() != 1 or not penalty.is_cuda:
+            raise ValueError("opt_multi: penalty must be a device float64 tensor of one element")
+        _C.check(_C.lib().dctr_opt_multi_l2(_C.OPT_CODES[kind], _ptr(segs), int(n_segs), int(max_n), float(lr), float(beta1), float(beta2),
+                                            float(eps), int(bool(zero_grad)), penalty.data_ptr(), float(penalty_scale), _C.stream_ptr()),
+                 "dctr_opt_multi_l2")
+        return
     _C.check(_C.lib().dctr_opt_multi(_C.OPT_CODES[kind], _ptr(segs), int(n_segs), int(max_n), float(lr), float(beta1),
                                      float(beta2), float(eps), int(bool(zero_grad)), _C.stream_ptr()), "dctr_opt_multi")
 

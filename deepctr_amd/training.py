@@ -598,9 +598,10 @@ class _DataParallel(object):
 def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, steps=None, initial_epoch=0, dp=None):
     """fit() on the HIP training step (training_hip.HipTrainer): no autograd, no torch optimizer.  The trainer (Adam
     moments, step count) lives on the model, so successive fit / train_on_batch calls continue the same optimisation.
-    The reported loss is what tf.keras reports: the data loss plus the l2 penalties l * sum(w^2) of the constructor's regularisers.  The
-    penalties (they also enter the gradients, as 2 l w inside the optimizer launch) are taken at the epoch's two ends and averaged —
-    keras averages them over the epoch's steps; the two differ in the second order of an epoch's weight change."""
+    The reported loss is what tf.keras reports: the batch-size-weighted mean over the epoch's steps of [data loss + the l2 penalties
+    l * sum(w^2) of the constructor's regularisers at THAT step's weights].  The penalties (they also enter the gradients, as 2 l w inside
+    the optimizer launch) are summed by the optimizer launch itself, on the weights it is about to update (dctr_opt_multi_l2: no further
+    pass over the tables) — round 6; before, they were taken at the epoch's two ends and averaged."""
     from .training_hip import HipTrainer
     tr = getattr(model, "_hip_trainer", None)
     if tr is None or tr.kind != model._compiled["optimizer"].lower():
@@ -611,16 +612,34 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
     frozen = frozen_weights(model)
     regs = [(t, l2) for t, l2 in regularized_weights(model) if t.data_ptr() not in frozen]
 
-    def penalty():
-        return l2_penalty(model, regs)
-    pen0 = penalty()
+    # every regularised, trainable weight should be a segment of the optimizer launch with its l2 (the trainer packs some of them —
+    # CrossNet kernels — into tensors of its own): checked by value, once; a model whose segments do not carry exactly the regularisers
+    # keeps the penalties of the epoch's two ends, averaged
+    pen_model = l2_penalty(model, regs)
+    pen_segs = sum(float(p.l2) * float(torch.linalg.vector_norm(p.w.detach().reshape(-1), dtype=torch.float64).item()) ** 2
+                   for p in tr.params if getattr(p, "l2", 0.0))
+    exact = abs(pen_model - pen_segs) <= 1e-9 * max(abs(pen_model), abs(pen_segs)) + 1e-30
+    pen_acc = torch.zeros(1, dtype=torch.float64, device=model.device) if exact else None
+    tr.penalty_acc = pen_acc
+    try:
+        return _fit_hip_epochs(model, tr, staged, yt, wt, cursor, dp, epochs, initial_epoch, epoch_end, pen_acc,
+                               None if exact else (lambda: l2_penalty(model, regs)), pen_model)
+    finally:
+        tr.penalty_acc, tr.penalty_rows = None, 0
+
+
+def _fit_hip_epochs(model, tr, staged, yt, wt, cursor, dp, epochs, initial_epoch, epoch_end, pen_acc, penalty, pen0):
     for ep in range(initial_epoch, epochs):
         # the epoch's loss: dctr_bce_grad adds every batch's summed loss into that batch's element of ONE device vector (summed in
         # float64 at the end of the epoch; step() refreshes the weight-derived buffers itself) — no per-step zero / divide / add launches
         # and no host round trip for it
         tot = torch.zeros(max(cursor.steps, 1), dtype=torch.float32, device=model.device)
-        seen = 0
+        if pen_acc is not None:
+            pen_acc.zero_()
+        seen = rows = 0
         for i, (lo, hi) in enumerate(cursor.epoch()):
+            tr.penalty_rows = int(hi - lo)                   # (the GLOBAL batch: replicas hold the same weights, every rank sums the same penalties)
+            rows += int(hi - lo)
             if dp is None:
                 tr.step(staged, int(lo), int(hi), yt[lo:hi], loss_acc=tot[i:i + 1], weight=None if wt is None else wt[lo:hi])
                 seen += hi - lo
@@ -634,9 +653,12 @@ def _fit_hip(model, staged, yt, n_tr, bs, epochs, shuffle, epoch_end, wt=None, s
         model._check_status()
         total = float(tot.double().sum().item())
         mean = total / max(seen, 1) if dp is None else dp.loss_mean(total, seen)
-        pen1 = penalty()
-        mean += 0.5 * (pen0 + pen1)
-        pen0 = pen1
+        if pen_acc is not None:
+            mean += float(pen_acc.item()) / max(rows, 1)
+        else:
+            pen1 = penalty()
+            mean += 0.5 * (pen0 + pen1)
+            pen0 = pen1
         if epoch_end(ep, mean):
             break
     return epoch_end.finish()

@@ -225,6 +225,7 @@ class HipTrainer(object):
             self.p_cin_b = [param(b) for b in model.cin.biases]
             self.p_head1 = param(model.dense_1.w("kernel"))
         self.p_cross_k = self.p_cross_b = None
+        self.penalty_acc, self.penalty_rows = None, 0   # (fit(): device float64 accumulator of rows * l2 penalties; rows of the next update)
         self._cross_one_kernel = {}         # (rows, dim, layers) -> dctr_crossnet_fwd_supported's answer for the training forward
         self.p_mix = None
         if self.is_mix and model.cross is not None:
@@ -733,7 +734,11 @@ class HipTrainer(object):
         lr = self.lr
         if self.kind == "adam":
             lr = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        ops.opt_multi(self.kind, self.segs, self.n_segs, self.max_n, lr, self.b1, self.b2, self.eps)
+        # fit(): the l2 penalties of THIS step's weights, weighted by the batch's rows, ride the launch (tf.keras' reported loss is the
+        # batch-size-weighted mean of data loss + regularisation losses: training._fit_hip sets penalty_acc / penalty_rows)
+        pen = self.penalty_acc if self.penalty_rows else None
+        ops.opt_multi(self.kind, self.segs, self.n_segs, self.max_n, lr, self.b1, self.b2, self.eps, penalty=pen,
+                      penalty_scale=float(self.penalty_rows) if pen is not None else 0.0)
         # the weights moved through raw pointers (torch's version counters did not): derived inference copies are stale
         self.model._raw_weight_writes = getattr(self.model, "_raw_weight_writes", 0) + 1
 

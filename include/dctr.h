@@ -923,6 +923,13 @@ int dctr_adam_multi(const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, 
 enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_RMSPROP = 2, DCTR_OPT_SGD = 3 };
 int dctr_opt_multi(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
                    float beta2, float eps, int32_t zero_grad, void* stream);
+/* ABI 13 — the same step; with l2_penalty != NULL (a DEVICE double, accumulated into) the launch also adds
+ *     penalty_scale * sum over the segments of l2 * sum(w^2),   taken on the weights BEFORE the update:
+ * the regularisation losses tf.keras adds to that batch's reported loss (kernel_regularizer=l2(...) of inputs.py:22, layers/core.py:170,
+ * interaction.py:100,258,387; tf.keras.Model.fit's `loss` is the batch-size-weighted mean of data loss + penalties: penalty_scale = the
+ * batch's rows).  The weights pass through the step's registers anyway: no further pass over the tables. */
+int dctr_opt_multi_l2(int32_t kind, const dctr_adam_seg_t* segs, int32_t n_segs, int64_t max_n, float lr, float beta1,
+                      float beta2, float eps, int32_t zero_grad, double* l2_penalty, float penalty_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * the plain fp32 contractions of the backward step — dW = X^T dZ, dH = dZ W^T of DNN.call

@@ -157,3 +157,40 @@ def test_validation_steps_freq_and_penalties(device):
     assert len(h2.history["val_loss"]) == 2 and len(h2.history["loss"]) == 5
     with pytest.raises(ValueError, match="validation_steps"):
         model.fit(feed, y, batch_size=100, epochs=1, verbose=0, validation_data=(xv, yv), validation_steps=9)
+
+
+@pytest.mark.parametrize("kind", ["DeepFM", "DCN", "xDeepFM"])
+def test_fit_loss_carries_every_steps_l2_penalties(device, kind):
+    """tf.keras.Model.fit's `loss` = batch-size-weighted mean over the epoch's steps of [data loss + the regularisation losses at that
+    step's weights] (regularisers: reference inputs.py:22, layers/core.py:170, interaction.py:100,258,387).  With regularisers large enough
+    to matter (1e-3: the penalties are ~ the data loss) and a ragged last batch, the HIP step's epoch loss — the optimizer launch sums the
+    penalties of the weights it is about to update (dctr_opt_multi_l2) — equals the formula evaluated step by step with train_on_batch-free
+    means: per step, evaluate()-style data loss is not needed — the penalties are recomputed on the host from copies of the weights."""
+    from deepctr_amd import models, training
+    from deepctr_amd.feature_column import DenseFeat, SparseFeat
+    rng = np.random.RandomState(3)
+    n, bs = 2 * 256 + 77, 256
+    cols = [SparseFeat("a", 50, 8), SparseFeat("b", 70, 8), SparseFeat("c", 9, 8), DenseFeat("d", 3)]
+    feed = {"a": rng.randint(0, 50, n), "b": rng.randint(0, 70, n), "c": rng.randint(0, 9, n), "d": rng.rand(n, 3).astype(np.float32)}
+    y = (rng.rand(n) > 0.5).astype(np.float32)
+    kw = dict(l2_reg_embedding=1e-3, l2_reg_linear=1e-3, l2_reg_dnn=1e-3, dnn_hidden_units=(16, 8), device=device)
+    if kind == "DCN":
+        kw.update(l2_reg_cross=1e-3, cross_num=2)
+    if kind == "xDeepFM":
+        kw.update(l2_reg_cin=1e-3, cin_layer_size=(8, 8))
+    losses = {}
+    for hip in (True, False):
+        model = getattr(models, kind)(cols, cols, **kw)
+        model.compile("adam", "binary_crossentropy")
+        model.hip_training = hip
+        w0 = model.get_weights_by_name() if hip else w0
+        model.set_weights_by_name(w0)
+        # two epochs: the second starts from moved weights and Adam moments
+        h = model.fit(feed, y, batch_size=bs, epochs=2, verbose=0, shuffle=False)
+        assert (getattr(model, "_hip_trainer", None) is not None) == hip
+        losses[hip] = h.history["loss"]
+        if hip:
+            pen_end = training.l2_penalty(model)
+    # the autograd step adds l2_penalty(model) to every batch's loss (training.KerasAdam path): the same formula, step by step
+    assert_close(np.array(losses[True]), np.array(losses[False]), rtol=2e-5, atol=1e-7, what="%s: fit loss, HIP step vs autograd step" % kind)
+    assert pen_end > 0.02 * losses[True][-1], "the regularisers are meant to matter here (1,000 x the bar above)"
