@@ -579,16 +579,43 @@ static int cin_pick_slice(const dctr_cin_args_t* a) {
     return 0;
 }
 
-// dctr_cin_fwd: the sample whole, or in slices of d
-static int cin_fwd_route(const dctr_cin_args_t* a, void* stream, bool dry) {
+// train_kernels.hip: CIN layer by layer on the library's GEMM (z materialised per chunk of samples) — any layer sizes
+size_t dctr_cin_layered_sample_floats(const dctr_cin_args_t* a);
+int dctr_cin_fwd_layered(const dctr_cin_args_t* a, void* workspace, size_t workspace_bytes, void* stream);
+constexpr int CIN_LAYERED_SAMPLES = 256;       // samples per chunk the workspace query provides for (any room for >= 16 works)
+
+// the argument checks every route shares (sizes, enums): what is left to fail in cin_fwd_impl afterwards is the LDS the shape needs
+static int cin_shape_checks(const dctr_cin_args_t* a) {
     DCTR_REQUIRE(a != nullptr && a->layer_size != nullptr, DCTR_E_NULL, "cin_fwd: null args");
-    DCTR_REQUIRE(a->fields >= 1 && a->dim >= 1 && a->n_layers >= 1 && a->n_layers <= CIN_MAX_LAYERS, DCTR_E_DIM,
-                 "cin_fwd: bad sizes (F=%d D=%d layers=%d)", a->fields, a->dim, a->n_layers);
-    if (a->dim <= 64) return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream, dry);
-    for (int k = 0; k < a->n_layers; ++k) DCTR_REQUIRE(a->layer_size[k] >= 1, DCTR_E_DIM, "cin_fwd: layer_size[%d]=%d", k, a->layer_size[k]);
-    const int dd = cin_pick_slice(a);
-    if (dd == a->dim || dd == 0) return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream, dry);     // (0: its refusal is the answer)
-    return cin_fwd_wide(a, dd, stream, dry);
+    DCTR_REQUIRE(a->batch >= 0 && a->fields >= 1 && a->dim >= 1 && a->n_layers >= 1 && a->n_layers <= CIN_MAX_LAYERS, DCTR_E_DIM,
+                 "cin_fwd: bad sizes (B=%lld F=%d D=%d layers=%d)", (long long)a->batch, a->fields, a->dim, a->n_layers);
+    DCTR_REQUIRE(a->activation >= DCTR_ACT_LINEAR && a->activation <= DCTR_ACT_TANH, DCTR_E_ENUM, "cin_fwd: activation %d", a->activation);
+    for (int k = 0; k < a->n_layers; ++k) {
+        DCTR_REQUIRE(a->layer_size[k] >= 1, DCTR_E_DIM, "cin_fwd: layer_size[%d]=%d", k, a->layer_size[k]);
+        if (a->split_half && k != a->n_layers - 1)
+            DCTR_REQUIRE(a->layer_size[k] % 2 == 0, DCTR_E_DIM, "cin_fwd: layer_size must be even except for the last layer when split_half=True");
+    }
+    return DCTR_OK;
+}
+
+// 1: the one-kernel form takes the sample whole; 2: in slices of *dd dimensions; 3: neither — layer by layer (train_kernels.hip)
+static int cin_route_of(const dctr_cin_args_t* a, int* dd) {
+    *dd = cin_pick_slice(a);
+    if (*dd == a->dim) return 1;
+    return *dd > 0 ? 2 : 3;
+}
+
+// dctr_cin_fwd: the sample whole, in slices of d, or — layer sizes no tile of the kernel holds — layer by layer
+static int cin_fwd_route(const dctr_cin_args_t* a, void* stream, bool dry) {
+    const int rc = cin_shape_checks(a);
+    if (rc != DCTR_OK) return rc;
+    int dd = 0;
+    const int route = cin_route_of(a, &dd);
+    if (route == 1) return cin_fwd_impl(a, nullptr, nullptr, nullptr, stream, dry);
+    if (route == 2) return cin_fwd_wide(a, dd, stream, dry);
+    if (dry || a->batch == 0) return DCTR_OK;
+    DCTR_REQUIRE(a->x_stride >= (int64_t)a->fields * a->dim, DCTR_E_DIM, "cin_fwd: x_stride < fields*dim");
+    return dctr_cin_fwd_layered(a, a->workspace, a->workspace_bytes, stream);
 }
 
 // ABI 13: samples the kernel does not take whole (embedding_dim > 128, or > 64 with more maps than fit the LDS beside a 128-row
@@ -598,14 +625,20 @@ extern "C" size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* a) {
         a->layer_size[0] < 1)
         return 0;
     const size_t fold = cin_fold_bytes(a);
-    if (a->dim <= 64) return fold;
     for (int k = 0; k < a->n_layers; ++k)
         if (a->layer_size[k] < 1) return fold;
     dctr_cin_args_t b = *a;
     if (b.activation < DCTR_ACT_LINEAR || b.activation > DCTR_ACT_TANH) b.activation = DCTR_ACT_RELU;   // (size queries come without one)
-    const int dd = cin_pick_slice(&b);
-    if (dd == a->dim || dd == 0) return fold;
-    return ((fold + 15) & ~(size_t)15) + (size_t)CIN_WIDE_ROWS * cin_wide_row_bytes(a, dd);
+    b.batch = 1;
+    int dd = 0;
+    const int route = cin_route_of(&b, &dd);
+    if (route == 1) return fold;
+    if (route == 2) return ((fold + 15) & ~(size_t)15) + (size_t)CIN_WIDE_ROWS * cin_wide_row_bytes(a, dd);
+    // (at most 256 MiB unless 16 samples need more: z is F0 * F_k products per (sample, d))
+    const size_t per = dctr_cin_layered_sample_floats(a) * sizeof(float), cap = (size_t)256 << 20;
+    size_t n = (size_t)CIN_LAYERED_SAMPLES;
+    if (n * per > cap) n = cap / per < 16 ? 16 : cap / per;
+    return n * per;
 }
 
 extern "C" int dctr_cin_fwd(const dctr_cin_args_t* a, void* stream) { return cin_fwd_route(a, stream, false); }

@@ -2748,6 +2748,109 @@ extern "C" int dctr_crossnet_bwd(const dctr_crossnet_bwd_args_t* a, void* stream
     return dctr_launch_status("dctr_crossnet_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// CIN.call, layer by layer (interaction.py:277-325 as the reference writes it: z materialised per layer, 1x1 conv = GEMM) — the route of
+// dctr_cin_fwd for layer sizes no LDS tile of the one-kernel form holds (a layer of more than ~480 maps: cin_kernels.hip refuses it for
+// every tile height).  Rows r = (b, d); samples in chunks of what the workspace holds; per chunk and layer: z = x_0 (outer) x_k
+// (cin_outer_kernel), y = z W_k on dctr_gemm, bias + activation in place, the direct maps summed over d into `out`; y goes straight to
+// save_y[k] when the caller asked for the activations (the same [B * D, H_k] rows).  Not part of the ABI: called by cin_kernels.hip.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void cin_bias_act_kernel(float* __restrict__ y, int64_t rows, int H, const float* __restrict__ bias, int act) {
+    const int64_t total = rows * H;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256)
+        y[o] = act_value(y[o] + bias[(int)(o % H)], act);
+}
+// out[b, off + j] = sum_d y[(b D + d), d0 + j]   (j < nd): deterministic serial sum over d, as the one-kernel form's LDS sum
+__global__ __launch_bounds__(256) void cin_sum_d_kernel(const float* __restrict__ y, int H, int64_t batch, int D, int d0, int nd,
+                                                        float* __restrict__ out, int64_t out_dim, int off) {
+    const int64_t total = batch * nd;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / nd;
+        const int j = (int)(o - b * nd);
+        const float* yp = y + (b * D) * H + d0 + j;
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += yp[(int64_t)d * H];
+        out[b * out_dim + off + j] = acc;
+    }
+}
+}  // namespace
+
+// floats of workspace per SAMPLE of the layered route: x0t [D, F0] + z [D, max F0 F_k] + two y buffers [D, max H]
+size_t dctr_cin_layered_sample_floats(const dctr_cin_args_t* a) {
+    size_t kmax = 0, hmax = 0;
+    int fk = a->fields;
+    for (int k = 0; k < a->n_layers; ++k) {
+        const int H = a->layer_size[k];
+        const bool last = k == a->n_layers - 1;
+        kmax = (size_t)a->fields * fk > kmax ? (size_t)a->fields * fk : kmax;
+        hmax = (size_t)H > hmax ? (size_t)H : hmax;
+        fk = last ? 0 : (a->split_half ? H / 2 : H);
+    }
+    return (size_t)a->dim * ((((size_t)a->fields + 3) & ~(size_t)3) + ((kmax + 3) & ~(size_t)3) + 2 * ((hmax + 3) & ~(size_t)3));
+}
+
+int dctr_cin_fwd_layered(const dctr_cin_args_t* a, void* workspace, size_t workspace_bytes, void* stream) {
+    const int F0 = a->fields, D = a->dim, L = a->n_layers;
+    const size_t per = dctr_cin_layered_sample_floats(a) * sizeof(float);
+    DCTR_REQUIRE(workspace != nullptr && dctr_aligned16(workspace) && workspace_bytes >= 16 * per, DCTR_E_NULL,
+                 "cin_fwd: these layer sizes run layer by layer and need a 16-B aligned workspace (dctr_cin_workspace_bytes; at least %zu B)", 16 * per);
+    DCTR_REQUIRE(a->x != nullptr && a->out != nullptr && a->filters != nullptr && a->bias != nullptr, DCTR_E_NULL, "cin_fwd: null pointer");
+    int64_t cap = (int64_t)(workspace_bytes / per);
+    cap = cap > 65536 ? 65536 : cap & ~(int64_t)3;
+    size_t kmax = 0, hmax = 0;
+    int out_dim = 0;
+    {
+        int fk = F0;
+        for (int k = 0; k < L; ++k) {
+            const int H = a->layer_size[k];
+            const bool last = k == L - 1;
+            DCTR_REQUIRE(a->filters[k] && a->bias[k], DCTR_E_NULL, "cin_fwd: filters/bias[%d] null", k);
+            kmax = (size_t)F0 * fk > kmax ? (size_t)F0 * fk : kmax;
+            hmax = (size_t)H > hmax ? (size_t)H : hmax;
+            out_dim += a->split_half ? (last ? H : H - H / 2) : H;
+            fk = last ? 0 : (a->split_half ? H / 2 : H);
+        }
+    }
+    // (the GEMM's sizes and element offsets are ints: a chunk's z stays below 2^31 elements)
+    while (cap > 16 && (int64_t)cap * D * (int64_t)(kmax > hmax ? kmax : hmax) >= 0x7fffffffLL) cap = (cap >> 1) & ~(int64_t)3;
+    DCTR_REQUIRE((int64_t)cap * D * (int64_t)(kmax > hmax ? kmax : hmax) < 0x7fffffffLL, DCTR_E_DIM, "cin_fwd: layer too large (%zu products per row)", kmax);
+    float* ws = static_cast<float*>(workspace);
+    const size_t f0p = ((size_t)F0 + 3) & ~(size_t)3, kp = (kmax + 3) & ~(size_t)3, hp = (hmax + 3) & ~(size_t)3;
+    float* x0t = ws;
+    float* z = x0t + (size_t)cap * D * f0p;
+    float* ybuf[2] = {z + (size_t)cap * D * kp, z + (size_t)cap * D * kp + (size_t)cap * D * hp};
+    hipStream_t st = (hipStream_t)stream;
+    auto grid = [](int64_t n) { int64_t b = dctr_ceil_div(n, (int64_t)256); return dim3((unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b))); };
+    for (int64_t r0 = 0; r0 < a->batch; r0 += cap) {
+        const int64_t nb = a->batch - r0 < cap ? a->batch - r0 : cap;
+        const int64_t R = nb * D;
+        hipLaunchKernelGGL(cin_to_rows_kernel, grid(R * F0), dim3(256), 0, st, a->x + r0 * a->x_stride, a->x_stride, nb, F0, D, x0t);
+        const float* xk = x0t;
+        int64_t ldk = F0;
+        int fk = F0, off = 0;
+        for (int k = 0; k < L; ++k) {
+            const int H = a->layer_size[k];
+            const bool last = k == L - 1;
+            const int Hn = last ? 0 : (a->split_half ? H / 2 : H), d0 = a->split_half ? (last ? 0 : H / 2) : 0;
+            const int K = F0 * fk;
+            hipLaunchKernelGGL(cin_outer_kernel, grid(R * K), dim3(256), 0, st, (const float*)x0t, F0, xk, ldk, fk, R, z);
+            float* y = (a->save_y != nullptr && a->save_y[k] != nullptr) ? a->save_y[k] + (size_t)r0 * D * H : ybuf[k & 1];
+            // row-major y [R, H] = z [R, K] W [K, H]  <=>  column-major y' (H x R) = W' (H x K) z' (K x R)
+            const int rs = dctr_gemm::sgemm(st, dctr_gemm::OP_N, dctr_gemm::OP_N, H, (int)R, K, a->filters[k], H, z, K, 0.f, y, H);
+            DCTR_REQUIRE(rs == 0, DCTR_E_UNSUPPORTED, "cin_fwd: sgemm(layer %d) failed (%d)", k, rs);
+            hipLaunchKernelGGL(cin_bias_act_kernel, grid(R * H), dim3(256), 0, st, y, R, H, a->bias[k], (int)a->activation);
+            hipLaunchKernelGGL(cin_sum_d_kernel, grid(nb * (H - d0)), dim3(256), 0, st, (const float*)y, H, nb, D, d0, H - d0, a->out + r0 * out_dim,
+                               (int64_t)out_dim, off);
+            off += H - d0;
+            xk = y;
+            ldk = H;
+            fk = Hn;
+        }
+    }
+    return dctr_launch_status("dctr_cin_fwd");
+}
+
 namespace dctr_cinbwd {      // cin_bwd_kernels.hip: the z-free backward of one CIN layer (filter gradient; input gradients)
 bool fused_shape_ok(int F0, int Fk, int H);
 int64_t dw_parts_floats(int F0, int Fk, int H, int64_t rows);

@@ -77,7 +77,7 @@ class _xDeepFM(FusedForward, FeatureModel):
 
     def _cin_workspace(self):
         if self._cin_ws is None:
-            need = ops.cin_workspace_bytes(len(self.stage_plan.fields), self.cin_dim, list(self.cin.layer_size))
+            need = ops.cin_workspace_bytes(len(self.stage_plan.fields), self.cin_dim, list(self.cin.layer_size), self.cin.split_half)
             self._cin_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=self.device)
         return self._cin_ws
 

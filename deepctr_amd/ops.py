@@ -453,7 +453,7 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
         sp = _ptr_array(list(save_y))
         a.save_y = ctypes.cast(sp, ctypes.c_void_p)
     need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
-    if fold or (D > 64 and need > _cin_fold_bytes(F0, layer_size)):     # (samples walked in slices of d need their workspace, fold or not)
+    if fold or need > _cin_fold_bytes(F0, layer_size):     # (samples walked in slices of d / layer by layer need their workspace, fold or not)
         if need:
             if workspace is not None:
                 if workspace.dtype != torch.float32 or not workspace.is_contiguous() or workspace.device != x.device:
@@ -518,12 +518,13 @@ def cin_gather(gather, filters, biases, layer_size, split_half, activation, dim,
     return True
 
 
-def cin_workspace_bytes(fields, dim, layer_size):
-    """Bytes of the workspace dctr_cin_fwd takes for a CIN over ``fields`` embeddings of width ``dim``: layer 0's fold (0: no fold) +,
-    for samples the kernel walks in slices of d (embedding_dim > 128 ...), the room that route REQUIRES.  (split_half unknown here:
-    sized for the larger output of split_half=False.)"""
+def cin_workspace_bytes(fields, dim, layer_size, split_half=False):
+    """Bytes of the workspace dctr_cin_fwd takes for a CIN over ``fields`` embeddings of width ``dim``: layer 0's fold (0: no fold), or
+    the room the sliced (embedding_dim > 128 ...) / layer-by-layer (a layer of more than ~480 maps) routes REQUIRE.  split_half=False
+    (the default) is the larger need of the two."""
     ls = _i32_array(layer_size)
-    a = _C.CinArgs(fields=int(fields), dim=int(dim), n_layers=len(layer_size), layer_size=ctypes.cast(ls, ctypes.c_void_p))
+    a = _C.CinArgs(fields=int(fields), dim=int(dim), n_layers=len(layer_size), split_half=int(bool(split_half)),
+                   layer_size=ctypes.cast(ls, ctypes.c_void_p))
     return int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
 
 

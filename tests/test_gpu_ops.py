@@ -1085,8 +1085,8 @@ def test_cin_more_maps_than_a_128_row_tile_holds(device):
     for k in range(3):
         assert torch.equal(save[k], save_h[k]), "save_y[%d]" % k
     assert_close(y.cpu().numpy(), yh.cpu().numpy().reshape(B, 2, -1).sum(1), rtol=1e-6, atol=1e-6, what="sum of the halves")
-    # still refused: more maps than ANY tile height leaves room for
-    assert not ops.cin_supported(26, 64, (600, 600), False)
+    # (more maps than ANY tile height leaves room for: layer by layer, test_cin_layer_sizes_past_every_tile)
+    assert ops.cin_supported(26, 64, (600, 600), False)
 
 
 def test_afm_inner_product_past_the_lds(device):
@@ -1139,3 +1139,34 @@ def test_din_attention_history_past_4096_positions(device):
         for ws in (True, False):
             y = ops.din_attention(*args, weight_normalization=wn, **({} if ws else {"workspace": False}))
             assert_close_terms(y.cpu().numpy(), ref, mag, rtol_terms=4e-6, what="din attention T=5000 %s workspace=%s" % (act, ws))
+
+
+@pytest.mark.parametrize("F0,D,ls,split", [(26, 16, (600, 40), False), (9, 64, (512, 512), False), (5, 20, (1100, 8, 30), True), (4, 192, (700, 700), False)])
+def test_cin_layer_sizes_past_every_tile(device, F0, D, ls, split):
+    """CIN.call with more maps in a layer than any LDS tile of the one-kernel form holds (~480; the reference takes any layer_size,
+    interaction.py:241-275): dctr_cin_fwd runs such a network layer by layer as the reference writes it — z materialised per chunk of
+    samples, the 1x1 convolution on the library's GEMM — against the float64 oracle; save_y = every layer's activations; with room for
+    an eighth of the samples (several chunks) as well."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(500 + F0)
+    B = 83
+    assert ops.cin_supported(F0, D, ls, split)
+    x, fs, bs = _cin_case(rng, B, F0, D, ls, split)
+    ref = R.cin(x.astype(np.float64), [f.astype(np.float64) for f in fs], [b.astype(np.float64) for b in bs], split, "relu")
+    mag = R.cin(np.abs(x).astype(np.float64), [np.abs(f).astype(np.float64) for f in fs], [np.abs(b).astype(np.float64) for b in bs], split, "relu")
+    args = (dev(x, device), [dev(f[0], device) for f in fs], [dev(b, device) for b in bs], ls, split, "relu")
+    save = [torch.full((B * D, h), float("nan"), dtype=torch.float32, device=device) for h in ls]
+    y = ops.cin(*args, save_y=save)
+    assert_close_terms(y.cpu().numpy(), ref, mag, what="cin layer by layer F0=%d D=%d %s" % (F0, D, ls))
+    assert all(bool(torch.isfinite(t).all()) for t in save)
+    # the last layer's activations summed over d are its share of the output
+    last = save[-1].reshape(B, D, ls[-1]).sum(1)
+    assert_close(last.cpu().numpy(), y.cpu().numpy()[:, -ls[-1]:], rtol=1e-5, atol=1e-5, what="save_y of the last layer")
+    per = ops.cin_workspace_bytes(F0, D, ls, split) // 4
+    ws = torch.empty(max(per // 8, 1), dtype=torch.float32, device=device)        # room for an eighth of the samples the query provides for
+    try:
+        y2 = ops.cin(*args, workspace=ws)
+    except Exception as e:                                                          # (below 16 samples: the library says so)
+        assert "workspace" in str(e)
+    else:                                                                           # (the GEMM cuts k by the problem's size: same sum, another order)
+        assert_close_terms(y2.cpu().numpy(), ref, mag, what="cin layer by layer, small workspace")
