@@ -96,6 +96,71 @@ __global__ __launch_bounds__(256) void cross_vector_kernel(const float* __restri
     }
 }
 
+// The same layer for rows past the register file (d > 8192; the reference has no limit, interaction.py:405-424).  The vector recurrence has a
+// closed form: with s_l = x_l . w_l,  x_{l+1} = x_0 s_l + b_l + x_l  gives  x_l = (1 + S_l) x_0 + B_l,  S_l = s_0 + .. + s_{l-1},
+// B_l = b_0 + .. + b_{l-1}, hence  s_l = (1 + S_l) (x_0 . w_l) + B_l . w_l: a row needs its L (+ 1: the head) dot products with x_0 — ONE walk
+// over the row — and the weight-only constants c_l = B_l . v_l (v_l = w_l, v_L = head_w), which every workgroup forms for itself (no scratch:
+// O(L^2 d) multiply-adds per four samples).  x_L is then written in a second walk.  Same arithmetic as the folded CrossNet of the one-launch
+// forward (mlp_device.h: cross_logit); up to CROSS_STREAM_MAXL layers.
+constexpr int CROSS_STREAM_MAXL = 8;
+__global__ __launch_bounds__(256) void cross_vector_stream_kernel(const float* __restrict__ x, int64_t batch, int d, int64_t x_stride,
+                                                                  const float* __restrict__ w, const float* __restrict__ bias, int layers,
+                                                                  float* __restrict__ y, int64_t y_stride, const float* __restrict__ head_w,
+                                                                  float* __restrict__ logit) {
+    __shared__ float cs[CROSS_STREAM_MAXL + 1];
+    __shared__ float part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = layers + (head_w != nullptr ? 1 : 0);
+    for (int l = 0; l < nv; ++l) {                        // c_l = (b_0 + .. + b_{l-1}) . v_l
+        const float* v = l < layers ? w + (int64_t)l * d : head_w;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < d; i += 256) {
+            float bs = 0.f;
+            for (int j = 0; j < l; ++j) bs += bias[(int64_t)j * d + i];
+            acc = fmaf(bs, v[i], acc);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) cs[l] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+    }
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    const float* x0 = x + b * x_stride;
+    float p[CROSS_STREAM_MAXL + 1];
+#pragma unroll
+    for (int l = 0; l <= CROSS_STREAM_MAXL; ++l) p[l] = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float xv = x0[i];
+#pragma unroll
+        for (int l = 0; l <= CROSS_STREAM_MAXL; ++l)
+            if (l < nv) p[l] = fmaf(xv, (l < layers ? w + (int64_t)l * d : head_w)[i], p[l]);
+    }
+#pragma unroll
+    for (int l = 0; l <= CROSS_STREAM_MAXL; ++l)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) p[l] += __shfl_xor(p[l], m, 64);
+    float S = 0.f;
+#pragma unroll
+    for (int l = 0; l < CROSS_STREAM_MAXL; ++l)
+        if (l < layers) S += fmaf(1.f + S, p[l], cs[l]);
+    if (y != nullptr)
+        for (int i = lane; i < d; i += 64) {
+            float bs = 0.f;
+            for (int j = 0; j < layers; ++j) bs += bias[(int64_t)j * d + i];
+            y[b * y_stride + i] = fmaf(1.f + S, x0[i], bs);
+        }
+    if (head_w != nullptr && lane == 0) {
+        float ph = 0.f;
+#pragma unroll
+        for (int l = 0; l <= CROSS_STREAM_MAXL; ++l)
+            if (l == layers) ph = p[l];
+        logit[b] = fmaf(1.f + S, ph, cs[layers]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // CrossNet 'matrix' (interaction.py:416-420): x_{l+1} = x_0 * (W_l x_l + b_l) + x_l.
 // 16-sample tile per workgroup of 8 waves; x_0, x_l, x_{l+1} in LDS; W_l x_l on v_mfma_f32_16x16x4_f32.
@@ -1069,10 +1134,16 @@ static int crossnet_launch(const dctr_crossnet_args_t* a, void* stream, const dc
                  "crossnet_fwd: save_u / save_x exist for the matrix form (save_x with more than one layer)");
     hipStream_t st = (hipStream_t)stream;
     if (mode == DCTR_CROSS_VECTOR || layers == 0) {
-        DCTR_REQUIRE(dim <= 64 * 128, DCTR_E_UNSUPPORTED, "crossnet_fwd(vector): dim %d > 8192", dim);
+        DCTR_REQUIRE(dim <= 64 * 128 || layers <= CROSS_STREAM_MAXL, DCTR_E_UNSUPPORTED,
+                     "crossnet_fwd(vector): dim %d > 8192 (rows past the register file: the closed form) with more than %d layers", dim, CROSS_STREAM_MAXL);
         const int64_t blocks = dctr_ceil_div(batch, 4);
         DCTR_REQUIRE(blocks <= 0x7fffffffLL, DCTR_E_DIM, "crossnet_fwd: batch too large");
         if (dry) return DCTR_OK;
+        if (dim > 64 * 128) {
+            DCTR_LAUNCH(cross_vector_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, kernels, bias, layers, y, y_stride,
+                        a->head_w, a->logit);
+            return dctr_launch_status("dctr_crossnet_fwd");
+        }
         const int nr = pow2_at_least((dim + 63) / 64, 128);      // values of x_0 / x_l per lane (one wave per sample; 128: 256 VGPRs)
 #define CALL_CV(N)                                                                                                  \
     DCTR_LAUNCH((cross_vector_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, x, batch, dim, x_stride, \

@@ -57,9 +57,10 @@ def supported(model):
     # (round 6: a matrix CrossNet of any width — past the [16, dim] LDS tiles of the one-kernel training forward, ~832 columns, i.e. Criteo
     #  at embedding_dim 32, the forward runs layer by layer on dctr_sgemm + dctr_crossnet_matrix_step straight into saved_u / saved_x:
     #  _cross_fwd; dctr_crossnet_bwd's matrix form has no width of its own)
-    if kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector" and sp.in_dim > 8192:
-        return False                        # (dctr_crossnet_fwd's vector form holds a row of x_0 / x_l in registers: <= 8192 columns; the
-                                            #  backward takes any width since round 6 — layer by layer past 2048 columns / 48 L d bytes of LDS)
+    if (kind == "_DCN" and getattr(getattr(model, "cross", None), "parameterization", None) == "vector" and sp.in_dim > 8192
+            and int(getattr(model.cross, "layer_num", 0)) > 8):
+        return False                        # (rows past the register file — 8192 columns — run the closed form of the vector recurrence, up to 8
+                                            #  layers; the backward takes any width: layer by layer past 2048 columns / 48 L d bytes of LDS)
     if len(sp.fm_group_names) > 1:          # further FM groups (DeepFM / AFM fm_group): their logits ride on the head's four `add` slots
         n_add = int(bool(sp.has_linear)) + len(sp.fm_group_names)
         if kind not in ("_DeepFM", "_AFM") or n_add > 4:

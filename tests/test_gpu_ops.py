@@ -1170,3 +1170,29 @@ def test_cin_layer_sizes_past_every_tile(device, F0, D, ls, split):
         assert "workspace" in str(e)
     else:                                                                           # (the GEMM cuts k by the problem's size: same sum, another order)
         assert_close_terms(y2.cpu().numpy(), ref, mag, what="cin layer by layer, small workspace")
+
+
+@pytest.mark.parametrize("B,d,L", [(37, 9000, 3), (5, 8200, 1), (9, 12345, 8), (3, 8193, 0)])
+def test_crossnet_vector_rows_past_the_register_file(device, B, d, L):
+    """CrossNet, vector parameterization (interaction.py:405-424: no limit on the input width), over more than 8,192 columns — past the
+    registers a wave holds x_0 / x_l in: the closed form x_l = (1 + S_l) x_0 + B_l of the recurrence, one walk over the row for its L + 1
+    dot products.  Output and head logit against the float64 oracle."""
+    from deepctr_amd import ops
+    rng = np.random.RandomState(90 + L)
+    x = (rng.standard_normal((B, d)) * 0.5).astype(np.float32)
+    ks = (rng.standard_normal((L, d)) / np.sqrt(d)).astype(np.float32) if L else None
+    bs = (rng.standard_normal((L, d)).astype(np.float32) * 0.1) if L else None
+    hw = (rng.standard_normal(d) / np.sqrt(d)).astype(np.float32)
+    k64 = [ks[l].astype(np.float64).reshape(d, 1) for l in range(L)]
+    b64 = [bs[l].astype(np.float64).reshape(d, 1) for l in range(L)]
+    ref = R.crossnet(x.astype(np.float64), k64, b64, "vector")
+    mag = R.crossnet(np.abs(x).astype(np.float64), [np.abs(k) for k in k64], [np.abs(b) for b in b64], "vector")
+    xd, kd, bd, hd = dev(x, device), (dev(ks, device) if L else None), (dev(bs, device) if L else None), dev(hw, device)
+    y = ops.crossnet(xd, kd, bd, "vector")
+    assert_close_terms(y.cpu().numpy(), ref, mag, what="crossnet vector d=%d L=%d" % (d, L))
+    logit, y2 = ops.crossnet_head(xd, kd, bd, "vector", hd, want_y=True)
+    assert torch.equal(y2, y)
+    lref, lmag = ref @ hw.astype(np.float64), mag @ np.abs(hw).astype(np.float64)
+    assert float(np.max(np.abs(logit.cpu().numpy() - lref) / (lmag + 1e-30))) < 4e-6, "head logit"
+    logit3, none = ops.crossnet_head(xd, kd, bd, "vector", hd, want_y=False)
+    assert none is None and torch.equal(logit3, logit)
