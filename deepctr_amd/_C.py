@@ -15,6 +15,7 @@ c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 
 ABI_VERSION = 13
 
+E_NULL = -1                      # DCTR_E_NULL: a required pointer (or required workspace) is missing
 E_UNSUPPORTED = -5               # DCTR_E_UNSUPPORTED: valid request this build does not implement
 POOL_SUM, POOL_MEAN, POOL_MAX = 0, 1, 2
 CROSS_VECTOR, CROSS_MATRIX = 0, 1

@@ -453,23 +453,26 @@ def cin(x, filters, biases, layer_size, split_half=True, activation="relu", fiel
         sp = _ptr_array(list(save_y))
         a.save_y = ctypes.cast(sp, ctypes.c_void_p)
     need = int(_C.lib().dctr_cin_workspace_bytes(ctypes.byref(a)))
-    if fold or need > _cin_fold_bytes(F0, layer_size):     # (samples walked in slices of d / layer by layer need their workspace, fold or not)
-        if need:
-            if workspace is not None:
-                if workspace.dtype != torch.float32 or not workspace.is_contiguous() or workspace.device != x.device:
-                    raise ValueError("cin: workspace must be a contiguous float32 tensor (dctr_cin_workspace_bytes: %d bytes) on %s" % (need, x.device))
-                # (its size is the library's to judge: the fold needs all of its share, the sliced route works in any room for >= 64 samples)
-                ws, a.workspace_ready, need = workspace, int(bool(workspace_ready)), workspace.numel() * 4
-            else:
-                ws = _scratch(x.device, need)   # rewritten by every call (the filters may have moved): stream order keeps calls apart
-            a.workspace, a.workspace_bytes = ws.data_ptr(), need
-    _C.check(_C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr()), "dctr_cin_fwd")
+
+    def with_workspace(need):
+        if workspace is not None:
+            if workspace.dtype != torch.float32 or not workspace.is_contiguous() or workspace.device != x.device:
+                raise ValueError("cin: workspace must be a contiguous float32 tensor (dctr_cin_workspace_bytes: %d bytes) on %s" % (need, x.device))
+            # (its size is the library's to judge: the fold needs all of its share, the sliced route works in any room for >= 64 samples)
+            ws, a.workspace_ready, need = workspace, int(bool(workspace_ready)), workspace.numel() * 4
+        else:
+            ws = _scratch(x.device, need)   # rewritten by every call (the filters may have moved): stream order keeps calls apart
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+        return ws
+    ws = with_workspace(need) if (fold and need) else None
+    rc = _C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr())
+    if rc == _C.E_NULL and ws is None and need:
+        # fold=False, but the arguments take a route that REQUIRES its workspace (samples in slices of d, layer by layer): the library
+        # says so before it launches anything
+        ws = with_workspace(need)
+        rc = _C.lib().dctr_cin_fwd(ctypes.byref(a), _C.stream_ptr())
+    _C.check(rc, "dctr_cin_fwd")
     return out
-
-
-def _cin_fold_bytes(fields, layer_size):
-    """The fold's share of dctr_cin_workspace_bytes (a narrow CIN's whole need: the fold does not depend on the embedding width)."""
-    return cin_workspace_bytes(fields, 4, layer_size)
 
 
 def cin_supported(fields, dim, layer_size, split_half=True, activation="relu", gather=None, fused_head=False, batch=4096):

@@ -44,8 +44,8 @@ def supported(model):
         # Dice runs as tf.keras runs it under fit(): BatchNormalization in training mode — this batch's statistics, gradients
         # through them, stored statistics moved (dctr_dice_train_fwd + dctr_mlp_bwd's dice_batch_*);
         # model.hip_dice_stored_statistics = True keeps the stored statistics instead (tests of the inference-form backward)
-    if sp.lin_only:
-        return False
+    # (round 6: features only the linear part sees — linear_feature_columns is its own list in every constructor — train on the HIP step:
+    #  their first-order weights receive d logit through the second gather's backward, HipTrainer.step)
     # (round 6: DIN over any key width — the attention unit trains on the materialised [B * T, 4 E'] input, dctr_embed_lookup_bwd scatters
     #  any width (its sorted-tile form up to 64 columns, plain atomics past that); tables whose width is not a multiple of 4 carry no
     #  touched-group marks)
@@ -172,6 +172,11 @@ class HipTrainer(object):
             pt = param(f.table, l2e).track_rows()
             pl = param(f.lin_table, l2l) if f.lin_table is not None else None
             self.field_params.append((f, pt, pl))
+        # features of the linear part alone (feature_column.py:171-210 builds the linear logit from linear_feature_columns only): their
+        # 1-wide tables are parameters too; the second gather of the forward (EmbeddingStage.run_lin_only) has its own backward in step()
+        from .feature_column import VarLenSparseFeat as _VarLen
+        self.lin_only_params = [(fc, param(model.linear_tables[fc.embedding_name].embeddings, l2l)) for fc in sp.lin_only]
+        self.lin_only_varlen = [(fc, p) for fc, p in self.lin_only_params if isinstance(fc, _VarLen)]
         # Linear.kernel (dense features of the linear part): the forward reads a copy permuted into dense-matrix column
         # order (EmbeddingStage.refresh); the backward kernel scatters straight into the real kernel's gradient
         self.p_dense_lin, self.dense_rows = None, None
@@ -290,6 +295,12 @@ class HipTrainer(object):
                 else:
                     entries.append((pt.g, None if pl is None else pl.g, pt.touched))
             b["field_grads"] = ops.make_field_grads(entries, dev)
+            if self.lin_only_params:
+                # the second gather's fields (EmbeddingStage: desc2): a SparseFeat scatters d logit into its linear table's gradient, a
+                # pooled sequence into a per-batch vector that dctr_embed_pool_bwd carries on to the table
+                b["lin2_pool_g"] = {fc.name: torch.zeros(B, 1, dtype=torch.float32, device=dev) for fc, _ in self.lin_only_varlen}
+                entries2 = [(None, b["lin2_pool_g"][fc.name].reshape(-1) if fc.name in b["lin2_pool_g"] else p.g) for fc, p in self.lin_only_params]
+                b["field_grads2"] = ops.make_field_grads(entries2, dev)
         return b
 
     def bind_cross_views(self):
@@ -642,6 +653,8 @@ class HipTrainer(object):
             key = (dnn_in.shape[0], d, ks.shape[0])
             ok = self._cross_one_kernel.get(key)
             if ok is None:
+                if len(self._cross_one_kernel) > 64:            # (ragged batch sizes must not pile up)
+                    self._cross_one_kernel.clear()
                 ok = self._cross_one_kernel[key] = bool(_C.lib().dctr_crossnet_fwd_supported(ctypes.byref(a), None))
             if not ok:
                 return self._cross_fwd_layered(dnn_in, d, stack, su, sx)
@@ -694,6 +707,8 @@ class HipTrainer(object):
             pool_calls = sp.pool_trace
         finally:
             sp.pool_trace = None
+        if self.lin_only_params:            # the linear-only features' logit joins the linear logit every model adds to its head
+            ws["lin"].add_(ws["lin2"])
         if self.is_dcn:
             self._dcn_forward_backward(ws, buf, y, B, binary)
         elif self.is_din:
@@ -719,10 +734,22 @@ class HipTrainer(object):
                                 dense_lin_rows=self.dense_rows)
         # sequence features: pooled-vector gradients -> rows of their tables
         pooled = [(f, pt, pl) for f, pt, pl in self.field_params if f.kind == "pooled"]
-        assert len(pool_calls) == len(pooled)
+        assert len(pool_calls) == len(pooled) + len(self.lin_only_varlen)
         for (args, _keep), (f, pt, pl) in zip(pool_calls, pooled):
             ops.embed_pool_bwd(args, d_out=buf["pooled_g"][f.fc.name], d_lin_out=buf["pooled_lin_g"].get(f.fc.name),
                                g_table=pt.g, g_lin_table=None if pl is None else pl.g, touched=pt.touched)
+        if self.lin_only_params:
+            # features of the linear part alone: d logit -> rows of their linear tables (the backward of run_lin_only's gather; pooled
+            # sequences through their per-batch vectors)
+            for t in buf["lin2_pool_g"].values():
+                t.zero_()
+            nf = len(sp.fields)
+            g2 = ops.make_gather_args(ws["desc2"], ws["n_fields2"], staged.ids[nf:, lo:hi], staged.ids.stride(0), 1, B, 1, False,
+                                      ws["any_hash2"], lin_logit=ws["lin2"], status=ws["status"])
+            ops.embed_gather_fm_bwd(g2, buf["field_grads2"], d_lin=buf["dlogit"])
+            for (args, _keep), (fc, p) in zip(pool_calls[len(pooled):], self.lin_only_varlen):
+                if p.g is not None:
+                    ops.embed_pool_bwd(args, d_out=buf["lin2_pool_g"][fc.name], g_table=p.g)
         self._join_side()
         if apply:
             self.apply_update()
