@@ -359,9 +359,12 @@ typedef struct {
  * dimensions before its final reduce_sum over d (interaction.py:288-295, :322-323), and the reference puts no limit on embedding_dim:
  * a sample wider than one workgroup's MFMA tiles (embedding_dim > 128; > 64 when the maps of a 128-row tile would not fit the LDS) is
  * walked as dim / dd pseudo-samples of dd dimensions (dd = the largest divisor of dim the kernel takes) laid out in the workspace by a
- * pre-pass, their partial map sums added in the order of d by a post-pass; rows in chunks of what the workspace holds.  For such
- * arguments the workspace is REQUIRED (DCTR_E_NULL without; any workspace with room for >= 64 samples works); save_y is written as
- * for whole samples (row b * dim + d). */
+ * pre-pass, their partial map sums added in the order of d by a post-pass; rows in chunks of what the workspace holds.  A network with
+ * a layer of more maps than ANY tile height leaves LDS for (~480; the reference takes any layer_size) runs layer by layer as the
+ * reference writes it (interaction.py:288-300): z = x_0 (outer) x_k materialised per chunk of samples, the 1 x 1 convolution on the
+ * library's GEMM, bias + activation, the direct maps summed over d (room for up to 256 samples, at most 256 MiB unless 16 samples need
+ * more).  For such arguments the workspace is REQUIRED (DCTR_E_NULL without, before anything is launched; any workspace with room for
+ * >= 64 / >= 16 samples works); save_y is written as for whole samples (row b * dim + d). */
 size_t dctr_cin_workspace_bytes(const dctr_cin_args_t* args);
 int dctr_cin_fwd(const dctr_cin_args_t* args, void* stream);
 /* ABI 13 — would dctr_cin_fwd (gather == NULL) / dctr_cin_gather_fwd (gather != NULL; fused_head != 0: with head_w / logit) take these
