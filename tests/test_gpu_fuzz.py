@@ -280,7 +280,9 @@ def _fit_once(meta, feed, y, weights, device, hip, optimizer, bs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [int(t) for t in os.environ.get("DCTR_FUZZ_FIT_SEEDS", "").split(",") if t] or list(range(160)))
+# (+ 569, 581: round 6's sweep — Adam losses 1.2 - 1.5 x off their bar while the HIP step reported the l2 penalties of an epoch's two ends;
+#  + 14, 28, 42 ... hold features of the linear part alone, on the HIP step since round 6)
+@pytest.mark.parametrize("seed", [int(t) for t in os.environ.get("DCTR_FUZZ_FIT_SEEDS", "").split(",") if t] or (list(range(160)) + [569, 581, 306, 312, 329]))
 def test_random_configuration_trains_alike_on_the_hip_and_the_autograd_step(device, seed):
     """fit() — three consecutive batches, the last one ragged — on the HIP training step against the torch-autograd step (the checker:
     autograd over the restatement of the forward that tests/test_training_checker_cpu.py pins to the fixtures) from the same weights:
