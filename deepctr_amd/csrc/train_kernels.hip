@@ -2866,7 +2866,7 @@ struct CinPlan {
     int H[8], Fk[8], Hn[8], d0[8], off[8];
     bool fused[8];         // layer runs on the z-free kernels of cin_bwd_kernels.hip: no z / dz for it
     int64_t R;
-    size_t x0t, y[8], z[8], dpre, dz, dx0t, dxk[2], fwd_out, parts, total;
+    size_t x0t, y[8], z[8], dpre, dz, dx0t, dxk[2], fwd_out, fwd_ws, fwd_ws_bytes, parts, total;
     int out_dim;
 };
 bool cin_plan(const dctr_cin_args_t* f, CinPlan& p) {
@@ -2909,6 +2909,9 @@ bool cin_plan(const dctr_cin_args_t* f, CinPlan& p) {
     p.dx0t = take((size_t)p.R * p.F0);
     p.dxk[0] = take((size_t)p.R * fkmax);
     p.dxk[1] = take((size_t)p.R * fkmax);
+    // the re-run forward's own workspace (layer 0's fold; REQUIRED by the sliced / layer-by-layer routes of wide samples / layers)
+    p.fwd_ws_bytes = dctr_cin_workspace_bytes(f);
+    p.fwd_ws = take((p.fwd_ws_bytes + 3) / 4);
     p.total = cur;
     return true;
 }
@@ -2954,6 +2957,11 @@ extern "C" int dctr_cin_bwd(const dctr_cin_bwd_args_t* a, void* stream) {
         for (int k = 0; k < p.L; ++k) sv[k] = yk[k] == ws + p.y[k] ? ws + p.y[k] : nullptr;
         fa.save_y = sv;
         fa.out = ws + p.fwd_out;
+        if (p.fwd_ws_bytes > 0 && (fa.workspace == nullptr || fa.workspace_bytes < p.fwd_ws_bytes)) {   // (fwd->workspace is documented unused here)
+            fa.workspace = ws + p.fwd_ws;
+            fa.workspace_bytes = p.fwd_ws_bytes;
+            fa.workspace_ready = 0;
+        }
         const int rc = dctr_cin_fwd(&fa, stream);
         if (rc != 0) return rc;
     }

@@ -274,6 +274,7 @@ class HipTrainer(object):
                 "cin_y": [torch.empty(B * self.model.cin_dim, h, dtype=torch.float32, device=dev)
                           for h in self.model.cin.layer_size]
                 if (self.p_cin_f and B * self.model.cin_dim * max(self.model.cin.layer_size) * 4 < 2 ** 31) else None,
+                # (None: dctr_cin_bwd re-runs the forward into its own workspace — whichever route the shape takes, round 6)
                 "acts": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units],
                 "pre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if (self.slow_dnn or self.dice_dnn) else None,
                 "dpre": [torch.empty(B, n, dtype=torch.float32, device=dev) for n in units] if self.slow_dnn else None,

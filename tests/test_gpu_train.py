@@ -756,7 +756,10 @@ def test_dcnmix_hip_training_gradients_match_torch_autograd(device, cross_num, h
 
 @pytest.mark.parametrize("B,F0,D,ls,split,act", [(37, 7, 8, (12, 10), True, "relu"), (9, 5, 4, (8, 6, 5), False, "linear"),
                                                  (64, 26, 16, (32, 16), True, "relu"), (20, 6, 6, (8,), True, "sigmoid"),
-                                                 (33, 26, 16, (128, 128), True, "relu"), (10, 5, 4, (48, 16), False, "linear")])
+                                                 (33, 26, 16, (128, 128), True, "relu"), (10, 5, 4, (48, 16), False, "linear"),
+                                                 # round 6: samples walked in slices of d (D > 128) and a layer of more maps than any LDS tile
+                                                 # holds (layer by layer) — the forward's routes behind save_y and behind the backward's re-run
+                                                 (11, 5, 160, (12, 8), True, "relu"), (13, 4, 8, (520, 6), False, "relu")])
 @pytest.mark.parametrize("saved", [False, True])
 def test_cin_bwd_matches_autograd(device, B, F0, D, ls, split, act, saved):
     """saved=True: the forward kernel writes the layer activations (cin(save_y=)) and the backward takes them instead of
